@@ -1,0 +1,290 @@
+"""ctypes binding of include/cpprob_hip.h (harness for tests and bench; not a compute path)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcpprob_hip.so")
+
+ALG_SIS, ALG_SMC = 2, 4
+MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README, MODEL_LINEAR_GAUSSIAN_1D, MODEL_HMM3 = 0, 1, 2, 3
+RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
+N_KERNEL_CLASSES = 6
+KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", "resample"]
+
+# every symbol include/cpprob_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "cpprob_hip_abi_version", "cpprob_hip_device_count", "cpprob_hip_create", "cpprob_hip_destroy", "cpprob_hip_last_error",
+    "cpprob_hip_stream", "cpprob_hip_sync", "cpprob_hip_infer_begin", "cpprob_hip_infer_run", "cpprob_hip_infer_summary",
+    "cpprob_hip_infer_stats", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
+    "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
+    "cpprob_hip_smc_finish", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
+    "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
+    "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
+    "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_resample", "cpprob_hip_gather_f64",
+    "cpprob_hip_gather_i32", "cpprob_hip_profile_enable", "cpprob_hip_profile_read",
+]
+
+
+class CpprobHipError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("algorithm", C.c_int32), ("model", C.c_int32), ("resampler", C.c_int32), ("keep_history", C.c_int32),
+                ("ess_threshold", C.c_double), ("seed", C.c_uint64), ("n_particles", C.c_uint64),
+                ("particle_offset", C.c_uint64), ("n_global", C.c_uint64)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("log_evidence", C.c_double), ("ess_final", C.c_double), ("log_norm", C.c_double), ("max_logw", C.c_double),
+                ("n_predict", C.c_int32), ("stats_per_predict", C.c_int32), ("is_int", C.c_int32), ("n_resampled", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libcpprob_hip.so.  Import torch first when both live in one process so that the
+    already-loaded libamdhip64.so.7 (same SONAME) is shared."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise CpprobHipError("%s is missing: run `python -m cpprob_amd.build` (there is no CPU fallback)" % p)
+    L = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    vp, u64, i64, i32, dbl, sz = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_double, C.c_size_t
+    sig = {
+        "cpprob_hip_abi_version": (C.c_int, []),
+        "cpprob_hip_device_count": (C.c_int, []),
+        "cpprob_hip_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "cpprob_hip_destroy": (None, [vp]),
+        "cpprob_hip_last_error": (C.c_char_p, [vp]),
+        "cpprob_hip_stream": (vp, [vp]),
+        "cpprob_hip_sync": (C.c_int, [vp]),
+        "cpprob_hip_infer_begin": (C.c_int, [vp, C.POINTER(Config), C.POINTER(dbl), sz]),
+        "cpprob_hip_infer_run": (C.c_int, [vp, u64]),
+        "cpprob_hip_infer_summary": (C.c_int, [vp, C.POINTER(Summary)]),
+        "cpprob_hip_infer_stats": (C.c_int, [vp, C.POINTER(dbl), sz]),
+        "cpprob_hip_infer_step_trace": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(i32)]),
+        "cpprob_hip_copy_values": (C.c_int, [vp, vp, sz]),
+        "cpprob_hip_copy_ancestors": (C.c_int, [vp, vp, sz]),
+        "cpprob_hip_copy_logw": (C.c_int, [vp, vp, sz]),
+        "cpprob_hip_copy_paths": (C.c_int, [vp, vp, sz]),
+        "cpprob_hip_smc_step_begin": (C.c_int, [vp, i32, C.POINTER(vp)]),
+        "cpprob_hip_smc_step_end": (C.c_int, [vp, i32, vp, i32, i32]),
+        "cpprob_hip_smc_finish": (C.c_int, [vp]),
+        "cpprob_hip_philox_blocks": (C.c_int, [vp, u64, u64, u64, sz, vp]),
+        "cpprob_hip_draw_normal": (C.c_int, [vp, u64, u64, u64, dbl, dbl, sz, vp]),
+        "cpprob_hip_draw_uniform_smallint": (C.c_int, [vp, u64, u64, u64, i64, i64, sz, vp]),
+        "cpprob_hip_draw_discrete": (C.c_int, [vp, u64, u64, u64, C.POINTER(dbl), i32, sz, vp]),
+        "cpprob_hip_draw_uniform_real": (C.c_int, [vp, u64, u64, u64, dbl, dbl, sz, vp]),
+        "cpprob_hip_logpdf_normal": (C.c_int, [vp, vp, vp, vp, sz, vp]),
+        "cpprob_hip_logpdf_uniform_real": (C.c_int, [vp, vp, vp, vp, sz, vp]),
+        "cpprob_hip_logpdf_poisson": (C.c_int, [vp, vp, vp, sz, vp]),
+        "cpprob_hip_logpdf_uniform_smallint": (C.c_int, [vp, vp, i64, i64, sz, vp]),
+        "cpprob_hip_logpdf_discrete": (C.c_int, [vp, vp, C.POINTER(dbl), i32, sz, vp]),
+        "cpprob_hip_logsumexp_ess": (C.c_int, [vp, vp, sz, C.POINTER(dbl)]),
+        "cpprob_hip_weighted_moments": (C.c_int, [vp, vp, vp, sz, C.POINTER(dbl)]),
+        "cpprob_hip_weighted_hist": (C.c_int, [vp, vp, vp, sz, i32, C.POINTER(dbl)]),
+        "cpprob_hip_resample": (C.c_int, [vp, i32, vp, sz, u64, u64, u64, sz, u64, vp]),
+        "cpprob_hip_gather_f64": (C.c_int, [vp, vp, vp, sz, vp]),
+        "cpprob_hip_gather_i32": (C.c_int, [vp, vp, vp, sz, vp]),
+        "cpprob_hip_profile_enable": (C.c_int, [vp, i32]),
+        "cpprob_hip_profile_read": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(i64), i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    if L.cpprob_hip_abi_version() != 1:
+        raise CpprobHipError("ABI version mismatch")
+    if path is None:
+        _lib = L
+    return L
+
+
+def _dptr(t):
+    """Device pointer of a torch tensor (contiguous), or None."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One context = one device, one stream, one particle shard (include/cpprob_hip.h)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.cpprob_hip_create(int(device), C.byref(h))
+        if rc:
+            msg = self.L.cpprob_hip_last_error(None)
+            raise CpprobHipError("cpprob_hip_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self.h = h
+        self.device = device
+        self.cfg = None
+        self.T = 0
+        self.is_int = False
+        self.K = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cpprob_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            msg = self.L.cpprob_hip_last_error(self.h)
+            raise CpprobHipError("cpprob_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+    @property
+    def stream_ptr(self):
+        return self.L.cpprob_hip_stream(self.h)
+
+    def sync(self):
+        self._chk(self.L.cpprob_hip_sync(self.h))
+
+    # ---- cpprob::inference --------------------------------------------------------------
+    def begin(self, algorithm, model, observes, n_particles, seed=12345, resampler=RESAMPLE_SYSTEMATIC, ess_threshold=2.0,
+              particle_offset=0, n_global=None):
+        obs = np.ascontiguousarray(observes, np.float64)
+        cfg = Config(algorithm, model, resampler, 1, float(ess_threshold), int(seed), int(n_particles), int(particle_offset),
+                     int(n_particles if n_global is None else n_global))
+        self._chk(self.L.cpprob_hip_infer_begin(self.h, C.byref(cfg), obs.ctypes.data_as(C.POINTER(C.c_double)), len(obs)))
+        self.cfg = cfg
+        gauss = model in (MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README)
+        self.T = 1 if gauss else len(obs)
+        self.is_int = model == MODEL_HMM3
+        self.K = 3 if self.is_int else 2
+        self.n = int(n_particles)
+        return self
+
+    def run(self, run_index=0):
+        self._chk(self.L.cpprob_hip_infer_run(self.h, int(run_index)))
+
+    def summary(self):
+        s = Summary()
+        self._chk(self.L.cpprob_hip_infer_summary(self.h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in Summary._fields_}
+
+    def stats(self):
+        out = np.zeros((self.T, self.K))
+        self._chk(self.L.cpprob_hip_infer_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size))
+        return out
+
+    def step_trace(self):
+        ess = np.zeros(self.T)
+        res = np.zeros(self.T, np.int32)
+        self._chk(self.L.cpprob_hip_infer_step_trace(self.h, ess.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     res.ctypes.data_as(C.POINTER(C.c_int32))))
+        return ess, res
+
+    def values(self):
+        out = np.zeros((self.T, self.n), np.int32 if self.is_int else np.float64)
+        self._chk(self.L.cpprob_hip_copy_values(self.h, out.ctypes.data, out.nbytes))
+        return out
+
+    def ancestors(self):
+        out = np.zeros((self.T, self.n), np.int32)
+        self._chk(self.L.cpprob_hip_copy_ancestors(self.h, out.ctypes.data, out.nbytes))
+        return out
+
+    def logw(self):
+        out = np.zeros(self.n)
+        self._chk(self.L.cpprob_hip_copy_logw(self.h, out.ctypes.data, out.nbytes))
+        return out
+
+    def paths(self):
+        out = np.zeros((self.T, self.n), np.int32 if self.is_int else np.float64)
+        self._chk(self.L.cpprob_hip_copy_paths(self.h, out.ctypes.data, out.nbytes))
+        return out
+
+    # ---- sharded SMC ---------------------------------------------------------------------
+    def step_begin(self, t):
+        p = C.c_void_p()
+        self._chk(self.L.cpprob_hip_smc_step_begin(self.h, int(t), C.byref(p)))
+        return p.value
+
+    def step_end(self, t, all_totals_ptr, world, rank):
+        self._chk(self.L.cpprob_hip_smc_step_end(self.h, int(t), C.c_void_p(all_totals_ptr), int(world), int(rank)))
+
+    def finish(self):
+        self._chk(self.L.cpprob_hip_smc_finish(self.h))
+
+    # ---- building blocks (torch tensors on this device carry the memory) -------------------
+    def philox_blocks(self, seed, pid0, draw, out):
+        self._chk(self.L.cpprob_hip_philox_blocks(self.h, seed, pid0, draw, out.numel() // 4, _dptr(out)))
+
+    def draw_normal(self, seed, pid0, draw, mean, sigma, out):
+        self._chk(self.L.cpprob_hip_draw_normal(self.h, seed, pid0, draw, mean, sigma, out.numel(), _dptr(out)))
+
+    def draw_uniform_smallint(self, seed, pid0, draw, a, b, out):
+        self._chk(self.L.cpprob_hip_draw_uniform_smallint(self.h, seed, pid0, draw, a, b, out.numel(), _dptr(out)))
+
+    def draw_discrete(self, seed, pid0, draw, weights, out):
+        w = (C.c_double * len(weights))(*weights)
+        self._chk(self.L.cpprob_hip_draw_discrete(self.h, seed, pid0, draw, w, len(weights), out.numel(), _dptr(out)))
+
+    def draw_uniform_real(self, seed, pid0, draw, a, b, out):
+        self._chk(self.L.cpprob_hip_draw_uniform_real(self.h, seed, pid0, draw, a, b, out.numel(), _dptr(out)))
+
+    def logpdf_normal(self, x, mean, sigma, out):
+        self._chk(self.L.cpprob_hip_logpdf_normal(self.h, _dptr(x), _dptr(mean), _dptr(sigma), x.numel(), _dptr(out)))
+
+    def logpdf_uniform_real(self, x, a, b, out):
+        self._chk(self.L.cpprob_hip_logpdf_uniform_real(self.h, _dptr(x), _dptr(a), _dptr(b), x.numel(), _dptr(out)))
+
+    def logpdf_poisson(self, x, mean, out):
+        self._chk(self.L.cpprob_hip_logpdf_poisson(self.h, _dptr(x), _dptr(mean), x.numel(), _dptr(out)))
+
+    def logpdf_uniform_smallint(self, x, a, b, out):
+        self._chk(self.L.cpprob_hip_logpdf_uniform_smallint(self.h, _dptr(x), a, b, x.numel(), _dptr(out)))
+
+    def logpdf_discrete(self, x, weights, out):
+        w = (C.c_double * len(weights))(*weights)
+        self._chk(self.L.cpprob_hip_logpdf_discrete(self.h, _dptr(x), w, len(weights), x.numel(), _dptr(out)))
+
+    def logsumexp_ess(self, logw):
+        out = (C.c_double * 3)()
+        self._chk(self.L.cpprob_hip_logsumexp_ess(self.h, _dptr(logw), logw.numel(), out))
+        return tuple(out)
+
+    def weighted_moments(self, x, logw):
+        out = (C.c_double * 4)()
+        self._chk(self.L.cpprob_hip_weighted_moments(self.h, _dptr(x), _dptr(logw), logw.numel(), out))
+        return tuple(out)
+
+    def weighted_hist(self, x, logw, k):
+        out = (C.c_double * 8)()
+        self._chk(self.L.cpprob_hip_weighted_hist(self.h, _dptr(x), _dptr(logw), logw.numel(), k, out))
+        return np.array(out[:k])
+
+    def resample(self, kind, logw, seed, step, anc_out, j0=0, n_total_out=None):
+        n_out = anc_out.numel()
+        nt = logw.numel() if n_total_out is None else n_total_out
+        self._chk(self.L.cpprob_hip_resample(self.h, kind, _dptr(logw), logw.numel(), seed, step, j0, n_out, nt, _dptr(anc_out)))
+
+    def gather(self, src, idx, dst):
+        import torch
+        fn = self.L.cpprob_hip_gather_f64 if src.dtype == torch.float64 else self.L.cpprob_hip_gather_i32
+        self._chk(fn(self.h, _dptr(src), _dptr(idx), idx.numel(), _dptr(dst)))
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.cpprob_hip_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * N_KERNEL_CLASSES)()
+        calls = (C.c_int64 * N_KERNEL_CLASSES)()
+        self._chk(self.L.cpprob_hip_profile_read(self.h, ms, calls, 1 if reset else 0))
+        return {KERNEL_CLASS_NAMES[k]: (ms[k], calls[k]) for k in range(N_KERNEL_CLASSES)}

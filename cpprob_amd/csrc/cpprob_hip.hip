@@ -1,0 +1,777 @@
+// C ABI of the gfx950 SIS / SMC engine: context, particle store, launch sequencing.
+// Declarations and the reference interfaces they replace: include/cpprob_hip.h.
+#include "../../include/cpprob_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace cph;
+
+namespace {
+
+std::string g_last_error;
+
+struct EventPair { hipEvent_t a, b; int cls; };
+
+}  // namespace
+
+struct cpprob_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    cpprob_hip_config cfg{};
+    bool begun = false, ran = false;
+    int T = 0;              // predict hits per trace
+    int n_obs = 0;
+    bool is_int = false;
+    int K = 0;              // stats per predict
+    int64_t n = 0, ld = 0;
+    int nb = 0;             // tiles
+    int smooth_grid = 0;
+    ModelParams mp{};
+    uint64_t run_seed = 0;
+
+    // device buffers
+    double* d_obs = nullptr;
+    double* d_logw[2] = {nullptr, nullptr};
+    void* d_values = nullptr;
+    int32_t* d_anc = nullptr;
+    void* d_paths = nullptr;
+    Partial* d_part = nullptr;
+    double* d_bc = nullptr;
+    StepCtrl* d_ctrl = nullptr;
+    double* d_ess = nullptr;
+    int32_t* d_resampled = nullptr;
+    double* d_stats_part = nullptr;
+    double* d_stats = nullptr;
+    double* d_cdf = nullptr;        // multinomial only
+    int32_t* d_anc_pre = nullptr;   // multinomial only
+    double* d_local_totals = nullptr;
+    int cur = 0;                    // logw buffer holding the latest generation
+    size_t cap_particles = 0; int cap_T = 0; bool cap_int = false; bool cap_multinomial = false;
+
+    // scratch for building blocks
+    Partial* d_bb_part = nullptr; double* d_bb_bc = nullptr; StepCtrl* d_bb_ctrl = nullptr; size_t bb_cap_nb = 0;
+    double* d_bb_stats_part = nullptr; double* d_bb_stats = nullptr; double* d_bb_cdf = nullptr; size_t bb_cdf_cap = 0;
+
+    // optional per-kernel-class timing
+    bool profile = false;
+    std::vector<EventPair> ev_used, ev_free;
+    double prof_ms[CPPROB_HIP_N_KERNEL_CLASSES] = {0};
+    int64_t prof_calls[CPPROB_HIP_N_KERNEL_CLASSES] = {0};
+};
+
+namespace {
+
+int fail(cpprob_hip_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e__ = (expr);                                                                            \
+        if (e__ != hipSuccess)                                                                              \
+            return fail(ctx, CPPROB_HIP_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));       \
+    } while (0)
+
+template <class T>
+void dfree(T*& p)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+struct ProfScope {
+    cpprob_hip_ctx* c; int cls; EventPair ep{}; bool on;
+    ProfScope(cpprob_hip_ctx* ctx, int k) : c(ctx), cls(k), on(ctx->profile)
+    {
+        if (!on) return;
+        if (!c->ev_free.empty()) { ep = c->ev_free.back(); c->ev_free.pop_back(); }
+        else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
+        ep.cls = cls;
+        (void)hipEventRecord(ep.a, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(ep.b, c->stream);
+        c->ev_used.push_back(ep);
+    }
+};
+
+void host_model_params(ModelParams& mp, int model)
+{
+    std::memset(&mp, 0, sizeof mp);
+    const double pi = 3.14159265358979323846;
+    if (model == CPPROB_HIP_MODEL_GAUSSIAN_UNKNOWN_MEAN) {          // models.hpp:26-30
+        mp.mu0 = 1; mp.sigma0 = std::sqrt(5.0); mp.sigma = std::sqrt(2.0);
+    } else if (model == CPPROB_HIP_MODEL_GAUSSIAN_README) {         // gaussian.cpp:8
+        mp.mu0 = 1; mp.sigma0 = 1.5; mp.sigma = 2;
+    } else { mp.mu0 = 0; mp.sigma0 = 1; mp.sigma = 1; }
+    mp.log_norm_lik = std::log(2 * pi * mp.sigma * mp.sigma);       // utils_normal_distribution.hpp:40
+    mp.log_norm_unit = std::log(2 * pi * 1.0 * 1.0);
+    const double mean[3] = {-1, 0, 1};                               // models.hpp:122
+    const double T[3][3] = {{0.1, 0.5, 0.4}, {0.2, 0.2, 0.6}, {0.15, 0.15, 0.7}};  // models.hpp:123-125
+    for (int s = 0; s < 3; ++s) {
+        mp.hmm_mean[s] = mean[s];
+        double tot = 0.0;
+        for (int j = 0; j < 3; ++j) tot += T[s][j];
+        double acc = 0.0;
+        for (int j = 0; j < 2; ++j) { acc += T[s][j]; mp.hmm_thr[s][j] = acc / tot; }
+    }
+}
+
+int model_T(int model, size_t n_obs)
+{
+    return (model == CPPROB_HIP_MODEL_GAUSSIAN_UNKNOWN_MEAN || model == CPPROB_HIP_MODEL_GAUSSIAN_README) ? 1 : (int)n_obs;
+}
+
+int ensure_bb(cpprob_hip_ctx* ctx, size_t n)
+{
+    const size_t nb = (n + kTile - 1) / kTile;
+    if (nb > ctx->bb_cap_nb || !ctx->d_bb_ctrl) {
+        dfree(ctx->d_bb_part); dfree(ctx->d_bb_bc); dfree(ctx->d_bb_stats_part);
+        const size_t cap = std::max<size_t>(nb, 1024);
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_part, cap * sizeof(Partial)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_bc, (cap + 1) * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_stats_part, 2048 * 8 * sizeof(double)));
+        if (!ctx->d_bb_ctrl) HIP_TRY(ctx, hipMalloc(&ctx->d_bb_ctrl, sizeof(StepCtrl)));
+        if (!ctx->d_bb_stats) HIP_TRY(ctx, hipMalloc(&ctx->d_bb_stats, 16 * sizeof(double)));
+        ctx->bb_cap_nb = cap;
+    }
+    return 0;
+}
+
+// partials + scan of an arbitrary logw array into the building-block scratch
+int bb_normalise(cpprob_hip_ctx* ctx, const double* d_logw, size_t n, double n_total)
+{
+    if (int rc = ensure_bb(ctx, n)) return rc;
+    const int nb = (int)((n + kTile - 1) / kTile);
+    hipLaunchKernelGGL(weights_partials_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, d_logw, (int64_t)n, ctx->d_bb_part);
+    ScanArgs sa{};
+    sa.part = ctx->d_bb_part; sa.nb = nb; sa.bc = ctx->d_bb_bc; sa.ctrl = ctx->d_bb_ctrl; sa.t = 0; sa.T = 1;
+    sa.n_global = n_total; sa.ess_frac = 0.0; sa.force_no_resample = 1; sa.phase = 0;
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, sa);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class Model>
+void launch_sis(cpprob_hip_ctx* c)
+{
+    SisArgs<Model> a{};
+    a.mp = c->mp; a.obs = c->d_obs; a.T = c->T; a.n = c->n; a.ld = c->ld; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
+    a.values = static_cast<typename Model::value_t*>(c->d_values); a.logw = c->d_logw[0]; a.part = c->d_part;
+    ProfScope ps(c, 4);
+    hipLaunchKernelGGL(sis_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+}
+
+template <class Model>
+void launch_step(cpprob_hip_ctx* c, int t)
+{
+    StepArgs<Model> a{};
+    a.mp = c->mp; a.obs = c->d_obs; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.seed = c->run_seed;
+    a.pid0 = c->cfg.particle_offset; a.n_global = c->cfg.n_global;
+    a.values = static_cast<typename Model::value_t*>(c->d_values); a.anc = c->d_anc;
+    a.logw_prev = c->d_logw[c->cur]; a.logw_next = c->d_logw[c->cur ^ 1];
+    a.part = c->d_part; a.bc = c->d_bc; a.nb = c->nb; a.ctrl = c->d_ctrl; a.anc_pre = c->d_anc_pre;
+    if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && t > 0) {
+        // literal thesis Alg. 1: materialise the CDF, draw N independent positions.  Runs
+        // unconditionally; the step kernel ignores the result when ctrl says "no resampling".
+        ProfScope ps(c, 5);
+        hipLaunchKernelGGL(cdf_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, c->d_logw[c->cur], c->n, c->d_bc, c->d_ctrl, c->d_cdf);
+        hipLaunchKernelGGL(multinomial_kernel, dim3((unsigned)((c->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, c->d_cdf, c->n,
+                           c->d_ctrl, c->run_seed, (uint64_t)t, c->cfg.particle_offset, c->n, c->d_anc_pre);
+    }
+    ProfScope ps(c, 0);
+    switch (c->cfg.resampler) {
+    case CPPROB_HIP_RESAMPLE_SYSTEMATIC:
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_SYSTEMATIC>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
+    case CPPROB_HIP_RESAMPLE_STRATIFIED:
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_STRATIFIED>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
+    default:
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_PRECOMPUTED>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
+    }
+    c->cur ^= 1;
+}
+
+void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, int world, int rank)
+{
+    ScanArgs sa{};
+    sa.part = c->d_part; sa.nb = c->nb; sa.bc = c->d_bc; sa.ctrl = c->d_ctrl; sa.t = t; sa.T = c->T;
+    sa.n_global = (double)c->cfg.n_global; sa.ess_frac = c->cfg.ess_threshold;
+    sa.ess_trace = c->d_ess; sa.resampled = c->d_resampled;
+    sa.force_no_resample = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
+    sa.all_totals = all_totals; sa.world = world; sa.rank = rank; sa.local_totals = c->d_local_totals; sa.phase = phase;
+    ProfScope ps(c, 1);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, sa);
+}
+
+template <class Model>
+void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
+{
+    SmoothArgs<Model> a{};
+    a.values = static_cast<const typename Model::value_t*>(c->d_values); a.anc = c->d_anc; a.logw = c->d_logw[c->cur]; a.ctrl = c->d_ctrl;
+    a.resampled = c->d_resampled; a.T = c->T; a.n = c->n; a.ld = c->ld;
+    a.identity = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
+    a.stats_part = c->d_stats_part;
+    a.paths = with_paths ? static_cast<typename Model::value_t*>(c->d_paths) : nullptr;
+    const size_t shm = (size_t)kWaves * c->T * Model::kStats * sizeof(double);
+    {
+        ProfScope ps(c, 2);
+        hipLaunchKernelGGL(smooth_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a);
+    }
+    ProfScope ps(c, 3);
+    hipLaunchKernelGGL(finalize_kernel, dim3(std::max(1, std::min(64, (c->T * Model::kStats + kThreads - 1) / kThreads))), dim3(kThreads), 0, c->stream,
+                       c->d_stats_part, c->smooth_grid, c->T, Model::kStats, Model::kIsInt ? 1 : 0, c->d_ctrl, c->d_stats);
+}
+
+template <class F>
+int dispatch_model(cpprob_hip_ctx* c, F&& f)
+{
+    switch (c->cfg.model) {
+    case CPPROB_HIP_MODEL_GAUSSIAN_UNKNOWN_MEAN:
+    case CPPROB_HIP_MODEL_GAUSSIAN_README: f(ModelGaussian{}); return 0;
+    case CPPROB_HIP_MODEL_LINEAR_GAUSSIAN_1D: f(ModelLinearGaussian1D{}); return 0;
+    case CPPROB_HIP_MODEL_HMM3: f(ModelHmm3{}); return 0;
+    }
+    return fail(c, CPPROB_HIP_EINVAL, "unknown model id");
+}
+
+void free_run_buffers(cpprob_hip_ctx* c)
+{
+    dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
+    dfree(c->d_part); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
+    dfree(c->d_cdf); dfree(c->d_anc_pre);
+    c->cap_particles = 0; c->cap_T = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpprob_hip_abi_version(void) { return CPPROB_HIP_ABI_VERSION; }
+
+int cpprob_hip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return CPPROB_HIP_EDEVICE; }
+    return n;
+}
+
+const char* cpprob_hip_last_error(const cpprob_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int cpprob_hip_create(int device, cpprob_hip_ctx** out)
+{
+    if (!out) return fail(nullptr, CPPROB_HIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, CPPROB_HIP_EDEVICE, std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                                                     "); this engine has no CPU fallback");
+    if (device < 0 || device >= n) return fail(nullptr, CPPROB_HIP_EINVAL, "device index out of range");
+    cpprob_hip_ctx* c = new cpprob_hip_ctx();
+    c->device = device;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    HIP_TRY(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(nullptr, hipMalloc(&c->d_ctrl, sizeof(StepCtrl)));
+    HIP_TRY(nullptr, hipMalloc(&c->d_local_totals, 4 * sizeof(double)));
+    HIP_TRY(nullptr, hipMemsetAsync(c->d_ctrl, 0, sizeof(StepCtrl), c->stream));
+    *out = c;
+    return 0;
+}
+
+void cpprob_hip_destroy(cpprob_hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_run_buffers(c);
+    dfree(c->d_ctrl); dfree(c->d_local_totals);
+    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf);
+    for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* cpprob_hip_stream(cpprob_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int cpprob_hip_sync(cpprob_hip_ctx* c)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, const double* h_obs, size_t n_obs)
+{
+    if (!c || !cfg || !h_obs) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (cfg->algorithm != CPPROB_HIP_ALG_SIS && cfg->algorithm != CPPROB_HIP_ALG_SMC)
+        return fail(c, CPPROB_HIP_EUNSUPPORTED, "algorithm must be sis or smc (compile/csis/dryrun are outside this engine)");
+    if (cfg->model < 0 || cfg->model > CPPROB_HIP_MODEL_HMM3) return fail(c, CPPROB_HIP_EINVAL, "unknown model id");
+    if (n_obs == 0) return fail(c, CPPROB_HIP_EINVAL, "the model has to receive the observed values (cpprob.hpp:182)");
+    const bool gauss = cfg->model == CPPROB_HIP_MODEL_GAUSSIAN_UNKNOWN_MEAN || cfg->model == CPPROB_HIP_MODEL_GAUSSIAN_README;
+    if (gauss && n_obs != 2) return fail(c, CPPROB_HIP_EINVAL, "gaussian_unknown_mean takes exactly two observes");
+    if (cfg->n_particles == 0) return fail(c, CPPROB_HIP_EINVAL, "n_particles must be > 0");
+    if (cfg->n_particles > (uint64_t)INT32_MAX - kTile) return fail(c, CPPROB_HIP_EINVAL, "n_particles per context must fit int32 ancestor indices");
+    if (cfg->n_global < cfg->n_particles || cfg->particle_offset + cfg->n_particles > cfg->n_global)
+        return fail(c, CPPROB_HIP_EINVAL, "shard [particle_offset, particle_offset + n_particles) must lie inside [0, n_global)");
+    if (cfg->algorithm == CPPROB_HIP_ALG_SMC) {
+        if (cfg->resampler < 0 || cfg->resampler > CPPROB_HIP_RESAMPLE_MULTINOMIAL) return fail(c, CPPROB_HIP_EINVAL, "unknown resampler");
+        if (!(cfg->ess_threshold >= 0.0)) return fail(c, CPPROB_HIP_EINVAL, "ess_threshold must be >= 0");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    c->cfg = *cfg;
+    c->T = model_T(cfg->model, n_obs);
+    c->n_obs = (int)n_obs;
+    c->is_int = cfg->model == CPPROB_HIP_MODEL_HMM3;
+    c->K = c->is_int ? 3 : 2;
+    c->n = (int64_t)cfg->n_particles;
+    c->ld = (c->n + 3) & ~(int64_t)3;
+    c->nb = (int)((c->n + kTile - 1) / kTile);
+    c->smooth_grid = std::min(c->nb, 2048);
+    host_model_params(c->mp, cfg->model);
+    const bool smc = cfg->algorithm == CPPROB_HIP_ALG_SMC;
+    const bool multinomial = smc && cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL;
+
+    const bool realloc = (size_t)c->ld > c->cap_particles || c->T > c->cap_T || c->is_int != c->cap_int || (multinomial && !c->cap_multinomial) || !c->d_values;
+    if (realloc) {
+        free_run_buffers(c);
+        const size_t ld = (size_t)c->ld, T = (size_t)c->T;
+        const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
+        HIP_TRY(c, hipMalloc(&c->d_logw[0], ld * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_logw[1], ld * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_values, T * ld * vsz));
+        HIP_TRY(c, hipMalloc(&c->d_anc, T * ld * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_part, (size_t)c->nb * sizeof(Partial)));
+        HIP_TRY(c, hipMalloc(&c->d_bc, ((size_t)c->nb + 1) * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_ess, T * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_resampled, T * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_stats_part, (size_t)c->smooth_grid * T * 8 * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_stats, T * 8 * sizeof(double)));
+        if (multinomial) {
+            HIP_TRY(c, hipMalloc(&c->d_cdf, ld * sizeof(double)));
+            HIP_TRY(c, hipMalloc(&c->d_anc_pre, ld * sizeof(int32_t)));
+        }
+        c->cap_particles = ld; c->cap_T = c->T; c->cap_int = c->is_int; c->cap_multinomial = multinomial;
+    }
+    dfree(c->d_obs);
+    HIP_TRY(c, hipMalloc(&c->d_obs, n_obs * sizeof(double)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_obs, h_obs, n_obs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_resampled, 0, (size_t)c->T * sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->begun = true; c->ran = false;
+    return 0;
+}
+
+int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->begun) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_infer_begin has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->run_seed = c->cfg.seed + run_index;
+    c->cur = 0;
+    if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
+        dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
+        launch_scan(c, c->T - 1, 0, nullptr, 1, 0);
+    } else {
+        for (int t = 0; t < c->T; ++t) {
+            dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
+            launch_scan(c, t, 0, nullptr, 1, 0);
+        }
+    }
+    dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
+    HIP_TRY(c, hipGetLastError());
+    c->ran = true;
+    return 0;
+}
+
+int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, double** d_local_totals)
+{
+    if (!c || !d_local_totals) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->begun) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_infer_begin has not been called");
+    if (t < 0 || t >= c->T) return fail(c, CPPROB_HIP_EINVAL, "step out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (t == 0) { c->run_seed = c->cfg.seed; c->cur = 0; }
+    if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
+        if (t != c->T - 1) return fail(c, CPPROB_HIP_EINVAL, "SIS shards run in one launch: call step_begin(T-1) only");
+        c->cur = 0;
+        dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
+    } else {
+        dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
+    }
+    launch_scan(c, t, 1, nullptr, 1, 0);
+    HIP_TRY(c, hipGetLastError());
+    *d_local_totals = c->d_local_totals;
+    return 0;
+}
+
+int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_totals, int32_t world, int32_t rank)
+{
+    if (!c || !d_all_totals) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank");
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_scan(c, t, 2, d_all_totals, world, rank);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_smc_finish(cpprob_hip_ctx* c)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
+    HIP_TRY(c, hipGetLastError());
+    c->ran = true;
+    return 0;
+}
+
+int cpprob_hip_infer_summary(cpprob_hip_ctx* c, cpprob_hip_summary* out)
+{
+    if (!c || !out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    StepCtrl h{};
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->log_evidence = h.log_z;
+    out->ess_final = h.ess;
+    out->log_norm = h.M + std::log(h.W);
+    out->max_logw = h.M;
+    out->n_predict = c->T;
+    out->stats_per_predict = c->K;
+    out->is_int = c->is_int ? 1 : 0;
+    out->n_resampled = h.n_resampled;
+    return 0;
+}
+
+int cpprob_hip_infer_stats(cpprob_hip_ctx* c, double* h_stats, size_t n_doubles)
+{
+    if (!c || !h_stats) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    const size_t need = (size_t)c->T * c->K;
+    if (n_doubles < need) return fail(c, CPPROB_HIP_EINVAL, "h_stats too small");
+    HIP_TRY(c, hipMemcpyAsync(h_stats, c->d_stats, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int cpprob_hip_infer_step_trace(cpprob_hip_ctx* c, double* h_ess, int32_t* h_resampled)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
+        // one weighting pass: only the final entry is defined
+        if (h_ess) { for (int t = 0; t < c->T; ++t) h_ess[t] = 0.0; }
+        if (h_resampled) { for (int t = 0; t < c->T; ++t) h_resampled[t] = 0; }
+        if (h_ess) HIP_TRY(c, hipMemcpyAsync(h_ess + (c->T - 1), c->d_ess + (c->T - 1), sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        if (h_ess) HIP_TRY(c, hipMemcpyAsync(h_ess, c->d_ess, (size_t)c->T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (h_resampled) HIP_TRY(c, hipMemcpyAsync(h_resampled, c->d_resampled, (size_t)c->T * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int copy_rows(cpprob_hip_ctx* c, void* h, const void* d, size_t elem, size_t rows, size_t n_bytes)
+{
+    const size_t need = rows * (size_t)c->n * elem;
+    if (n_bytes < need) return fail(c, CPPROB_HIP_EINVAL, "host buffer too small");
+    HIP_TRY(c, hipMemcpy2DAsync(h, (size_t)c->n * elem, d, (size_t)c->ld * elem, (size_t)c->n * elem, rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int cpprob_hip_copy_values(cpprob_hip_ctx* c, void* h, size_t n_bytes)
+{
+    if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    return copy_rows(c, h, c->d_values, c->is_int ? sizeof(int32_t) : sizeof(double), (size_t)c->T, n_bytes);
+}
+
+int cpprob_hip_copy_ancestors(cpprob_hip_ctx* c, int32_t* h, size_t n_bytes)
+{
+    if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (c->cfg.algorithm != CPPROB_HIP_ALG_SMC) return fail(c, CPPROB_HIP_ESTATE, "SIS keeps no ancestors (every trace is its own line)");
+    return copy_rows(c, h, c->d_anc, sizeof(int32_t), (size_t)c->T, n_bytes);
+}
+
+int cpprob_hip_copy_logw(cpprob_hip_ctx* c, double* h, size_t n_bytes)
+{
+    if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    return copy_rows(c, h, c->d_logw[c->cur], sizeof(double), 1, n_bytes);
+}
+
+int cpprob_hip_copy_paths(cpprob_hip_ctx* c, void* h, size_t n_bytes)
+{
+    if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
+    if (!c->d_paths) HIP_TRY(c, hipMalloc(&c->d_paths, (size_t)c->cap_T * c->cap_particles * vsz));
+    dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, true); });
+    HIP_TRY(c, hipGetLastError());
+    return copy_rows(c, h, c->d_paths, vsz, (size_t)c->T, n_bytes);
+}
+
+// ---- building blocks ----------------------------------------------------------------------
+
+#define BB_PRELUDE(c)                                                         \
+    if (!(c)) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");         \
+    HIP_TRY(c, hipSetDevice((c)->device));
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, c->stream
+
+int cpprob_hip_philox_blocks(cpprob_hip_ctx* c, uint64_t seed, uint64_t pid0, uint64_t draw, size_t n, uint32_t* d_out)
+{
+    BB_PRELUDE(c);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(philox_blocks_kernel, GRID1(n), seed, pid0, draw, (int64_t)n, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_draw_normal(cpprob_hip_ctx* c, uint64_t seed, uint64_t pid0, uint64_t draw, double mean, double sigma, size_t n, double* d_out)
+{
+    BB_PRELUDE(c);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(draw_normal_kernel, GRID1(n), seed, pid0, draw, mean, sigma, (int64_t)n, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_draw_uniform_smallint(cpprob_hip_ctx* c, uint64_t seed, uint64_t pid0, uint64_t draw, int64_t a, int64_t b, size_t n, int32_t* d_out)
+{
+    BB_PRELUDE(c);
+    if (b < a) return fail(c, CPPROB_HIP_EINVAL, "uniform_smallint needs a <= b");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(draw_smallint_kernel, GRID1(n), seed, pid0, draw, a, b, (int64_t)n, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+static int make_dw(cpprob_hip_ctx* c, const double* w, int32_t k, DiscreteW& dw)
+{
+    if (!w || k < 1 || k > 8) return fail(c, CPPROB_HIP_EINVAL, "discrete: need 1 <= k <= 8 weights");
+    std::memset(&dw, 0, sizeof dw);
+    for (int i = 0; i < k; ++i) dw.w[i] = w[i];
+    dw.k = k;
+    return 0;
+}
+
+int cpprob_hip_draw_discrete(cpprob_hip_ctx* c, uint64_t seed, uint64_t pid0, uint64_t draw, const double* h_w, int32_t k, size_t n, int32_t* d_out)
+{
+    BB_PRELUDE(c);
+    DiscreteW dw;
+    if (int rc = make_dw(c, h_w, k, dw)) return rc;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(draw_discrete_kernel, GRID1(n), seed, pid0, draw, dw, (int64_t)n, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_draw_uniform_real(cpprob_hip_ctx* c, uint64_t seed, uint64_t pid0, uint64_t draw, double a, double b, size_t n, double* d_out)
+{
+    BB_PRELUDE(c);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(draw_uniform_real_kernel, GRID1(n), seed, pid0, draw, a, b, (int64_t)n, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_logpdf_normal(cpprob_hip_ctx* c, const double* x, const double* mean, const double* sigma, size_t n, double* out)
+{
+    BB_PRELUDE(c);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(logpdf_normal_kernel, GRID1(n), x, mean, sigma, (int64_t)n, out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_logpdf_uniform_real(cpprob_hip_ctx* c, const double* x, const double* a, const double* b, size_t n, double* out)
+{
+    BB_PRELUDE(c);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(logpdf_uniform_real_kernel, GRID1(n), x, a, b, (int64_t)n, out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_logpdf_poisson(cpprob_hip_ctx* c, const int32_t* x, const double* mean, size_t n, double* out)
+{
+    BB_PRELUDE(c);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(logpdf_poisson_kernel, GRID1(n), x, mean, (int64_t)n, out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_logpdf_uniform_smallint(cpprob_hip_ctx* c, const int32_t* x, int64_t a, int64_t b, size_t n, double* out)
+{
+    BB_PRELUDE(c);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(logpdf_smallint_kernel, GRID1(n), x, a, b, (int64_t)n, out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_logpdf_discrete(cpprob_hip_ctx* c, const int32_t* x, const double* h_w, int32_t k, size_t n, double* out)
+{
+    BB_PRELUDE(c);
+    DiscreteW dw;
+    if (int rc = make_dw(c, h_w, k, dw)) return rc;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(logpdf_discrete_kernel, GRID1(n), x, dw, (int64_t)n, out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_logsumexp_ess(cpprob_hip_ctx* c, const double* d_logw, size_t n, double* h_out3)
+{
+    BB_PRELUDE(c);
+    if (!d_logw || !h_out3) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (n == 0) { h_out3[0] = 0; h_out3[1] = 0; h_out3[2] = 0; return 0; }   // empty: value-initialised (empirical_distribution.hpp:131-133)
+    if (int rc = bb_normalise(c, d_logw, n, (double)n)) return rc;
+    StepCtrl h{};
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_bb_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    h_out3[0] = h.M; h_out3[1] = h.M + std::log(h.W); h_out3[2] = h.ess;
+    return 0;
+}
+
+}  // extern "C"
+template <class Col>
+static int column_stats(cpprob_hip_ctx* c, const typename Col::value_t* d_x, const double* d_logw, size_t n, double* h_raw, double* h_lse_ess)
+{
+    if (int rc = bb_normalise(c, d_logw, n, (double)n)) return rc;
+    SmoothArgs<Col> a{};
+    a.values = d_x; a.anc = nullptr; a.logw = d_logw; a.ctrl = c->d_bb_ctrl; a.resampled = nullptr; a.T = 1; a.n = (int64_t)n; a.ld = (int64_t)n;
+    a.identity = 1; a.stats_part = c->d_bb_stats_part; a.paths = nullptr;
+    const int grid = (int)std::min<size_t>((n + kTile - 1) / kTile, 2048);
+    hipLaunchKernelGGL(smooth_kernel<Col>, dim3(grid), dim3(kThreads), (size_t)kWaves * Col::kStats * sizeof(double), c->stream, a);
+    // is_int = 1 -> plain normalised sums
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, c->stream, c->d_bb_stats_part, grid, 1, Col::kStats, 1, c->d_bb_ctrl, c->d_bb_stats);
+    HIP_TRY(c, hipGetLastError());
+    StepCtrl h{};
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_bb_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_raw, c->d_bb_stats, Col::kStats * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    h_lse_ess[0] = h.M + std::log(h.W); h_lse_ess[1] = h.ess;
+    return 0;
+}
+extern "C" {
+
+int cpprob_hip_weighted_moments(cpprob_hip_ctx* c, const double* d_x, const double* d_logw, size_t n, double* h_out4)
+{
+    BB_PRELUDE(c);
+    if (!d_x || !d_logw || !h_out4) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (n == 0) return fail(c, CPPROB_HIP_EINVAL, "empty distribution");
+    double raw[2], le[2];
+    if (int rc = column_stats<ColumnReal>(c, d_x, d_logw, n, raw, le)) return rc;
+    h_out4[0] = raw[0];
+    h_out4[1] = raw[1] - raw[0] * raw[0];     // variance(mean) = raw_moment(2) - mean*mean  (:78-81)
+    h_out4[2] = le[0]; h_out4[3] = le[1];
+    return 0;
+}
+
+int cpprob_hip_weighted_hist(cpprob_hip_ctx* c, const int32_t* d_x, const double* d_logw, size_t n, int32_t k, double* h_out)
+{
+    BB_PRELUDE(c);
+    if (!d_x || !d_logw || !h_out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (k < 1 || k > 8) return fail(c, CPPROB_HIP_EINVAL, "need 1 <= k <= 8");
+    if (n == 0) return fail(c, CPPROB_HIP_EINVAL, "empty distribution");
+    double raw[8], le[2];
+    if (int rc = column_stats<ColumnInt8>(c, d_x, d_logw, n, raw, le)) return rc;
+    for (int s = 0; s < k; ++s) h_out[s] = raw[s];
+    return 0;
+}
+
+int cpprob_hip_resample(cpprob_hip_ctx* c, int32_t kind, const double* d_logw, size_t n_in, uint64_t seed, uint64_t step, uint64_t j0, size_t n_out,
+                        uint64_t n_total_out, int32_t* d_anc)
+{
+    BB_PRELUDE(c);
+    if (!d_logw || !d_anc) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (n_in == 0) return fail(c, CPPROB_HIP_EINVAL, "cannot resample an empty population");
+    if (n_in > (size_t)INT32_MAX - kTile) return fail(c, CPPROB_HIP_EINVAL, "population too large for int32 ancestors");
+    if (n_total_out == 0 || j0 + n_out > n_total_out) return fail(c, CPPROB_HIP_EINVAL, "output range outside [0, n_total_out)");
+    if (n_out == 0) return 0;
+    if (int rc = bb_normalise(c, d_logw, n_in, (double)n_in)) return rc;
+    const int nb_in = (int)((n_in + kTile - 1) / kTile);
+    if (kind == CPPROB_HIP_RESAMPLE_MULTINOMIAL) {
+        if (n_in > c->bb_cdf_cap) { dfree(c->d_bb_cdf); HIP_TRY(c, hipMalloc(&c->d_bb_cdf, n_in * sizeof(double))); c->bb_cdf_cap = n_in; }
+        hipLaunchKernelGGL(cdf_kernel, dim3(nb_in), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n_in, c->d_bb_bc, c->d_bb_ctrl, c->d_bb_cdf);
+        hipLaunchKernelGGL(multinomial_kernel, GRID1(n_out), c->d_bb_cdf, (int64_t)n_in, c->d_bb_ctrl, seed, step, j0, (int64_t)n_out, d_anc);
+    } else if (kind == CPPROB_HIP_RESAMPLE_SYSTEMATIC || kind == CPPROB_HIP_RESAMPLE_STRATIFIED) {
+        ResampleArgs a{};
+        a.logw = d_logw; a.n_in = (int64_t)n_in; a.bc = c->d_bb_bc; a.nb = nb_in; a.ctrl = c->d_bb_ctrl; a.seed = seed; a.step = step; a.j0 = j0;
+        a.n_total_out = n_total_out; a.n_out = (int64_t)n_out; a.anc = d_anc;
+        const int nb_out = (int)((n_out + kTile - 1) / kTile);
+        ProfScope ps(c, 5);
+        if (kind == CPPROB_HIP_RESAMPLE_SYSTEMATIC) hipLaunchKernelGGL(resample_kernel<RS_SYSTEMATIC>, dim3(nb_out), dim3(kThreads), 0, c->stream, a);
+        else hipLaunchKernelGGL(resample_kernel<RS_STRATIFIED>, dim3(nb_out), dim3(kThreads), 0, c->stream, a);
+    } else {
+        return fail(c, CPPROB_HIP_EINVAL, "unknown resampler");
+    }
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_gather_f64(cpprob_hip_ctx* c, const double* src, const int32_t* idx, size_t n, double* dst)
+{
+    BB_PRELUDE(c);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gather_kernel<double>, GRID1(n), src, idx, (int64_t)n, dst);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_gather_i32(cpprob_hip_ctx* c, const int32_t* src, const int32_t* idx, size_t n, int32_t* dst)
+{
+    BB_PRELUDE(c);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gather_kernel<int32_t>, GRID1(n), src, idx, (int64_t)n, dst);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_profile_enable(cpprob_hip_ctx* c, int32_t on)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    c->profile = on != 0;
+    return 0;
+}
+
+int cpprob_hip_profile_read(cpprob_hip_ctx* c, double* h_ms, int64_t* h_calls, int32_t reset)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& ep : c->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->prof_ms[ep.cls] += ms; c->prof_calls[ep.cls] += 1; }
+        c->ev_free.push_back(ep);
+    }
+    c->ev_used.clear();
+    for (int k = 0; k < CPPROB_HIP_N_KERNEL_CLASSES; ++k) {
+        if (h_ms) h_ms[k] = c->prof_ms[k];
+        if (h_calls) h_calls[k] = c->prof_calls[k];
+        if (reset) { c->prof_ms[k] = 0; c->prof_calls[k] = 0; }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Device logpdf functors -- the weight side of cpprob::observe
+// (reference include/cpprob/cpprob.hpp:79-90 -> StateInfer::increment_log_prob,
+// src/cpprob/state.cpp:212-223).  One function per reference functor, same branch order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace cph {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// logpdf<boost::random::normal_distribution<R>>
+// reference include/cpprob/distributions/utils_normal_distribution.hpp:20-45
+__host__ __device__ __forceinline__ double normal_logpdf(double x, double mean, double sigma)
+{
+    if (sigma == 0) return x == mean ? 0.0 : -INFINITY;     // :28-32 Dirac delta
+    if (fabs(x) == INFINITY) return -INFINITY;              // :34-36
+    double r = (x - mean) / sigma;                           // :38
+    r *= r;                                                  // :39
+    r += log(2 * kPi * sigma * sigma);                       // :40
+    r *= -0.5;                                               // :41
+    return r;
+}
+
+// Same value with the sigma-only term hoisted: log_norm = log(2*pi*sigma^2) computed once
+// per model ("log term hoistable").  Bitwise equal to normal_logpdf
+// when the same log_norm is passed, for finite x and sigma > 0.
+__host__ __device__ __forceinline__ double normal_logpdf_hoisted(double x, double mean, double sigma, double log_norm)
+{
+    if (fabs(x) == INFINITY) return -INFINITY;
+    double r = (x - mean) / sigma;
+    r *= r;
+    r += log_norm;
+    r *= -0.5;
+    return r;
+}
+
+// logpdf<boost::random::uniform_smallint<I>>  utils_uniform_smallint.hpp:17-27
+__host__ __device__ __forceinline__ double uniform_smallint_logpdf(int64_t x, int64_t a, int64_t b)
+{
+    if (x < a || x > b) return -INFINITY;
+    return -log((double)(b - a) + 1.0);
+}
+
+// logpdf<boost::random::discrete_distribution<I, W>>  utils_discrete.hpp:17-27
+__host__ __device__ __forceinline__ double discrete_logpdf(int64_t x, const double* w, int k)
+{
+    if (x < 0 || x > k - 1) return -INFINITY;
+    double tot = 0.0;
+    for (int i = 0; i < k; ++i) tot += w[i];
+    return log(w[x] / tot);
+}
+
+// logpdf<boost::random::uniform_real_distribution<R>>  utils_uniform_real.hpp:21-31
+__host__ __device__ __forceinline__ double uniform_real_logpdf(double x, double a, double b)
+{
+    if (x < a || x > b) return -INFINITY;
+    return -log(b - a);
+}
+
+// logpdf<boost::random::poisson_distribution<I, R>>  utils_poisson.hpp:17-36
+__host__ __device__ __forceinline__ double poisson_logpdf(int64_t x, double l)
+{
+    if (l == 0.0) return -INFINITY;
+    double ret = (double)x * log(l) - l;
+    for (int64_t i = 1; i <= x; ++i) ret -= log((double)i);
+    return ret;
+}
+
+}  // namespace cph

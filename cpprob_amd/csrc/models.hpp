@@ -1,0 +1,98 @@
+// Built-in model step functors: the bodies of the reference's target models in
+// "one observe per step" form, so that the SIS kernel can run them to completion in
+// registers and the SMC kernel can stop every particle at each observe.
+//
+// Statement order inside a step follows the reference model line by line; the draw index of a
+// sample statement is its ordinal in the trace (t-th sample -> draw t), which is what the
+// oracle (oracle/cpprob_oracle.c) uses too.
+#pragma once
+#include "dist.hpp"
+#include "rng.hpp"
+
+namespace cph {
+
+// Host-precomputed constants (identical IEEE fp64 operations to the device's own, so hoisting
+// them does not change a single bit of the discrete draws).
+struct ModelParams {
+    // gaussian_unknown_mean: prior N(mu0, sigma0), likelihood N(mu, sigma)
+    double mu0, sigma0, sigma, log_norm_lik;      // log_norm_lik = log(2*pi*sigma^2)
+    // hmm: k = 3
+    double hmm_mean[3];
+    double hmm_thr[3][2];                         // cumulative thresholds of row s: {w0/tot, (w0+w1)/tot}
+    double log_norm_unit;                         // log(2*pi*1*1)
+};
+
+// reference include/models/models.hpp:22-35 and src/models/gaussian.cpp:6-17 (same body,
+// different hyper-parameters).  One step, two observes, one real predict.
+struct ModelGaussian {
+    using value_t = double;
+    static constexpr bool kIsInt = false;
+    static constexpr int kStats = 2;  // sum w x, sum w x^2
+    __device__ static __forceinline__ value_t propagate(const ModelParams& mp, uint64_t seed, uint64_t pid, int /*t*/, value_t /*prev*/)
+    {
+        return draw_normal(seed, pid, 0, mp.mu0, mp.sigma0);          // mu = sample(prior, true)   models.hpp:26-27
+    }
+    __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t mu, int /*t*/, const double* __restrict__ obs)
+    {
+        double lw = 0.0;                                               // TraceInfer::log_w_ = 0     trace.hpp:59
+        lw += normal_logpdf_hoisted(obs[0], mu, mp.sigma, mp.log_norm_lik);   // observe(likelihood, y1)  models.hpp:32
+        lw += normal_logpdf_hoisted(obs[1], mu, mp.sigma, mp.log_norm_lik);   // observe(likelihood, y2)  models.hpp:33
+        return lw;
+    }
+    __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
+    {
+        acc[0] += w * x;
+        acc[1] += w * (x * x);
+    }
+};
+
+// reference include/models/models.hpp:67-80: x_0 = 0, x_t ~ N(x_{t-1}, 1), y_t ~ N(x_t, 1),
+// predict(x_t, "State") after the observe.
+struct ModelLinearGaussian1D {
+    using value_t = double;
+    static constexpr bool kIsInt = false;
+    static constexpr int kStats = 2;
+    __device__ static __forceinline__ value_t propagate(const ModelParams&, uint64_t seed, uint64_t pid, int t, value_t prev)
+    {
+        const double state = t == 0 ? 0.0 : prev;                      // models.hpp:72
+        return draw_normal(seed, pid, (uint64_t)t, state, 1.0);        // :74-75
+    }
+    __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t x, int t, const double* __restrict__ obs)
+    {
+        return normal_logpdf_hoisted(obs[t], x, 1.0, mp.log_norm_unit);  // :76-77
+    }
+    __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
+    {
+        acc[0] += w * x;
+        acc[1] += w * (x * x);
+    }
+};
+
+// reference include/models/models.hpp:114-141: 3 states, uniform initial state, rows T :123-125,
+// emission N(state_mean[s], 1); predict(state, "State") before the observe.
+struct ModelHmm3 {
+    using value_t = int32_t;
+    static constexpr bool kIsInt = true;
+    static constexpr int kStats = 3;  // sum w [x == s]
+    __device__ static __forceinline__ value_t propagate(const ModelParams& mp, uint64_t seed, uint64_t pid, int t, value_t prev)
+    {
+        if (t == 0) return (value_t)draw_smallint(seed, pid, 0, 0, 2);  // uniform_smallint{0,2}   :126-127
+        const double u = draw_u01(seed, pid, (uint64_t)t);              // discrete_distribution{T[state]} :135-136
+        const double c0 = prev == 0 ? mp.hmm_thr[0][0] : (prev == 1 ? mp.hmm_thr[1][0] : mp.hmm_thr[2][0]);
+        const double c1 = prev == 0 ? mp.hmm_thr[0][1] : (prev == 1 ? mp.hmm_thr[1][1] : mp.hmm_thr[2][1]);
+        return (value_t)((u >= c0) + (u >= c1));
+    }
+    __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t s, int t, const double* __restrict__ obs)
+    {
+        const double mean = s == 0 ? mp.hmm_mean[0] : (s == 1 ? mp.hmm_mean[1] : mp.hmm_mean[2]);
+        return normal_logpdf_hoisted(obs[t], mean, 1.0, mp.log_norm_unit);  // :130-131,138-139
+    }
+    __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
+    {
+        acc[0] += x == 0 ? w : 0.0;
+        acc[1] += x == 1 ? w : 0.0;
+        acc[2] += x == 2 ? w : 0.0;
+    }
+};
+
+}  // namespace cph

@@ -1,0 +1,200 @@
+/*
+ * cpprob_hip.h -- C ABI of the MI355X (gfx950) SIS / SMC inference engine.
+ *
+ * Drop-in boundary for ONE path of lezcano/CPProb: cpprob::inference(StateType::sis, ...)
+ * (reference include/cpprob/cpprob.hpp:173-203) and the StateType::smc mode the reference never
+ * shipped.  The reference has no FFI for this path -- it is a header-level C++14 template API
+ *  -- so the entry points below are what the C++14 compatibility layer
+ * in cpprob_amd/include/cpprob/ binds, and what a maintainer of the reference would call from
+ * cpprob::inference instead of the per-particle loop.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  No C++/torch types.
+ *   - Every function returns 0 on success, a negative CPPROB_HIP_E* code otherwise;
+ *     cpprob_hip_last_error(ctx) then describes the failure.  Library code never exits
+ *     (the reference's exit()/terminate() paths, SURVEY section 5, are not reproduced).
+ *   - A context owns one device, one HIP stream and all device buffers of a run.  No process
+ *     globals (the reference's State::state_, StateInfer::trace_, TraceInfer::ids_predict_,
+ *     src/cpprob/state.cpp:20-21,148-155, are per-context here).  One run at a time per context;
+ *     contexts are independent and may live on different threads.
+ *   - Pointers named d_* are DEVICE pointers valid on the context's device, h_* are host
+ *     pointers.  Work is enqueued on the context's stream; functions that fill host memory
+ *     synchronise that stream, all others are asynchronous.
+ *   - All arithmetic is fp64 (reference: double log_w_, include/cpprob/trace.hpp:59); discrete
+ *     values and ancestor indices are int32.
+ */
+#ifndef CPPROB_HIP_H_
+#define CPPROB_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define CPPROB_HIP_ABI_VERSION 1
+
+/* error codes */
+#define CPPROB_HIP_OK 0
+#define CPPROB_HIP_EINVAL (-1)     /* bad argument                                   */
+#define CPPROB_HIP_EDEVICE (-2)    /* HIP runtime error (no GPU, launch failure, OOM) */
+#define CPPROB_HIP_ESTATE (-3)     /* call out of order (e.g. stats before run)       */
+#define CPPROB_HIP_EUNSUPPORTED (-4)
+
+/* StateType -- reference include/cpprob/state.hpp:28-33 {compile, csis, sis, dryrun}; smc is new. */
+#define CPPROB_HIP_ALG_SIS 2
+#define CPPROB_HIP_ALG_SMC 4
+
+/* Built-in models: hand-fused kernels for the models of namespace models on this path. */
+#define CPPROB_HIP_MODEL_GAUSSIAN_UNKNOWN_MEAN 0 /* include/models/models.hpp:22-35  obs (y1,y2), predict "Mu"    */
+#define CPPROB_HIP_MODEL_GAUSSIAN_README 1       /* src/models/gaussian.cpp:6-17     obs (x1,x2), predict "Mean"  */
+#define CPPROB_HIP_MODEL_LINEAR_GAUSSIAN_1D 2    /* include/models/models.hpp:67-80  obs[T],      predict "State" */
+#define CPPROB_HIP_MODEL_HMM3 3                  /* include/models/models.hpp:114-141 obs[T],     predict "State" */
+
+/* Resamplers (thesis Alg. 1 p.36: multinomial; remark p.36: systematic / stratified). */
+#define CPPROB_HIP_RESAMPLE_SYSTEMATIC 0
+#define CPPROB_HIP_RESAMPLE_STRATIFIED 1
+#define CPPROB_HIP_RESAMPLE_MULTINOMIAL 2
+
+typedef struct cpprob_hip_ctx cpprob_hip_ctx;
+
+/* Run configuration.  Replaces the arguments of cpprob::inference (cpprob.hpp:173-180):
+ * algorithm <- StateType, model <- const Func& f, n_particles <- std::size_t n; the observes
+ * tuple is passed flattened to cpprob_hip_infer_begin.  The reference has no seed (its RNG is
+ * a random_device-seeded global, src/cpprob/utils.cpp:16-20); here runs are reproducible. */
+typedef struct cpprob_hip_config {
+    int32_t algorithm;        /* CPPROB_HIP_ALG_*                                              */
+    int32_t model;            /* CPPROB_HIP_MODEL_*                                            */
+    int32_t resampler;        /* CPPROB_HIP_RESAMPLE_* (SMC only)                              */
+    int32_t keep_history;     /* 1: keep per-step values + ancestors (needed for smoothing /
+                                 dumps; always 1 in this version)                             */
+    double ess_threshold;     /* SMC: resample after a step iff ESS < ess_threshold * N_global;
+                                 > 1 resamples after every step (thesis p.37 uses 0.5)        */
+    uint64_t seed;            /* Philox key                                                    */
+    uint64_t n_particles;     /* particles held by THIS context (the shard)                    */
+    uint64_t particle_offset; /* global id of local particle 0 (RNG counters use global ids)   */
+    uint64_t n_global;        /* total particles over all shards (= n_particles for 1 GPU)     */
+} cpprob_hip_config;
+
+/* Posterior summary of a finished run -- what StatsPrinter prints
+ * (include/cpprob/postprocess/stats_printer.hpp:42-79) plus SMC diagnostics. */
+typedef struct cpprob_hip_summary {
+    double log_evidence;  /* log Z-hat: logsumexp(logw) - log N for SIS; SMC product estimate     */
+    double ess_final;     /* (sum W_i^2)^-1 of the final weights, thesis p.37                      */
+    double log_norm;      /* logsumexp of the final log-weights (EmpiricalDistribution :117-123)  */
+    double max_logw;      /* max of the final log-weights                                         */
+    int32_t n_predict;    /* predict hits per trace (T)                                           */
+    int32_t stats_per_predict; /* 2 for real predicts (mean, variance); k for int predicts (P(x=s)) */
+    int32_t is_int;       /* 1: predicts are integral (.int file), 0: real (.real)                */
+    int32_t n_resampled;  /* number of steps after which resampling happened                      */
+} cpprob_hip_summary;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int cpprob_hip_abi_version(void);
+/* Number of visible HIP devices, or a negative error code (no GPU -> CPPROB_HIP_EDEVICE). */
+int cpprob_hip_device_count(void);
+/* Creates a context on `device` with its own stream.  Fails loudly without a GPU. */
+int cpprob_hip_create(int device, cpprob_hip_ctx** out);
+void cpprob_hip_destroy(cpprob_hip_ctx* ctx);
+const char* cpprob_hip_last_error(const cpprob_hip_ctx* ctx); /* ctx may be NULL: global message */
+/* The context's hipStream_t, for event timing / interop by the caller. */
+void* cpprob_hip_stream(cpprob_hip_ctx* ctx);
+int cpprob_hip_sync(cpprob_hip_ctx* ctx);
+
+/* ---- cpprob::inference ------------------------------------------------------------------
+ * begin : State::set + StateInfer::start_infer + config_file (cpprob.hpp:184-192): validates,
+ *         (re)allocates the particle store in HBM and uploads the observes.
+ * run   : the whole `for (i < n)` loop of cpprob.hpp:194-201 for all particles at once, plus
+ *         (SMC) weight normalisation, ESS test and resampling between observes, plus the
+ *         posterior read-out (stats_printer.hpp:88-120 / empirical_distribution.hpp:30-81).
+ *         Asynchronous; may be called repeatedly (each call is one full run; pass run_index to
+ *         decorrelate runs: the Philox key used is seed + run_index).
+ * summary / stats : finish_infer + StatsPrinter: synchronise and copy results to the host.
+ *         h_stats receives n_predict * stats_per_predict doubles, row t = predict hit t:
+ *         real -> {mean, variance} (raw_moment(2) - mean^2, empirical_distribution.hpp:78-81);
+ *         int  -> {P(x_t = 0), ..., P(x_t = k-1)} (distribution(), :30-40).
+ */
+int cpprob_hip_infer_begin(cpprob_hip_ctx* ctx, const cpprob_hip_config* cfg, const double* h_observes, size_t n_observes);
+int cpprob_hip_infer_run(cpprob_hip_ctx* ctx, uint64_t run_index);
+int cpprob_hip_infer_summary(cpprob_hip_ctx* ctx, cpprob_hip_summary* out);
+int cpprob_hip_infer_stats(cpprob_hip_ctx* ctx, double* h_stats, size_t n_doubles);
+/* Per-step diagnostics of the last run: ESS after weighting step t and whether resampling
+ * followed it.  Arrays of n_predict entries (either may be NULL). */
+int cpprob_hip_infer_step_trace(cpprob_hip_ctx* ctx, double* h_ess, int32_t* h_resampled);
+
+/* The particle store of the last run (the in-HBM form of the reference's posterior files,
+ * src/cpprob/state.cpp:193-202,262-267).  Copies to host, synchronising.
+ *   values    : [n_predict][n_particles], fp64 for real models, int32 for int models:
+ *               value of predict hit t in slot i of generation t
+ *   ancestors : [n_predict][n_particles] int32: slot of generation t-1 that slot i of
+ *               generation t extends (row 0 and non-resampled steps: identity); SMC only
+ *   logw      : [n_particles] final log-weights
+ *   paths     : [n_predict][n_particles]: values along the ancestral line of final particle i,
+ *               i.e. the full trace the reference would have dumped for particle i */
+int cpprob_hip_copy_values(cpprob_hip_ctx* ctx, void* h_values, size_t n_bytes);
+int cpprob_hip_copy_ancestors(cpprob_hip_ctx* ctx, int32_t* h_anc, size_t n_bytes);
+int cpprob_hip_copy_logw(cpprob_hip_ctx* ctx, double* h_logw, size_t n_bytes);
+int cpprob_hip_copy_paths(cpprob_hip_ctx* ctx, void* h_paths, size_t n_bytes);
+
+/* ---- sharded SMC (one context per GPU; the caller runs the collective) -------------------
+ * Per step: step_begin(t) propagates and weighs the local shard and leaves this shard's
+ * (max logw, sum exp(logw-max), sum exp(2(logw-max))) in d_local_totals (3 doubles, device);
+ * the caller all-gathers those over ranks (RCCL) into d_all_totals[3*world]; step_end(t)
+ * combines them into the global normaliser / ESS / resampling decision on device.
+ * See cpprob_amd/distributed.py and DESIGN.md section "Multi-GPU". */
+int cpprob_hip_smc_step_begin(cpprob_hip_ctx* ctx, int32_t t, double** d_local_totals);
+int cpprob_hip_smc_step_end(cpprob_hip_ctx* ctx, int32_t t, const double* d_all_totals, int32_t world, int32_t rank);
+int cpprob_hip_smc_finish(cpprob_hip_ctx* ctx);
+
+/* ---- building blocks (also the unit-parity surface) --------------------------------------
+ * All pointers are device pointers; n is the element count. */
+
+/* Raw Philox4x32-10 blocks: d_out[4*i..4*i+3] = block(seed, pid0 + i, draw). */
+int cpprob_hip_philox_blocks(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, size_t n, uint32_t* d_out);
+/* Variate generators standing in for boost::random::*::operator()(get_rng()) (cpprob.hpp:34):
+ * element i is the draw of global particle pid0+i at statement ordinal `draw`. */
+int cpprob_hip_draw_normal(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, double mean, double sigma, size_t n, double* d_out);
+int cpprob_hip_draw_uniform_smallint(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, int64_t a, int64_t b, size_t n, int32_t* d_out);
+int cpprob_hip_draw_discrete(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, const double* h_weights, int32_t k, size_t n, int32_t* d_out);
+int cpprob_hip_draw_uniform_real(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, double a, double b, size_t n, double* d_out);
+
+/* logpdf functors (include/cpprob/distributions/utils_*.hpp), elementwise. */
+int cpprob_hip_logpdf_normal(cpprob_hip_ctx* ctx, const double* d_x, const double* d_mean, const double* d_sigma, size_t n, double* d_out);
+int cpprob_hip_logpdf_uniform_real(cpprob_hip_ctx* ctx, const double* d_x, const double* d_a, const double* d_b, size_t n, double* d_out);
+int cpprob_hip_logpdf_poisson(cpprob_hip_ctx* ctx, const int32_t* d_x, const double* d_mean, size_t n, double* d_out);
+int cpprob_hip_logpdf_uniform_smallint(cpprob_hip_ctx* ctx, const int32_t* d_x, int64_t a, int64_t b, size_t n, double* d_out);
+int cpprob_hip_logpdf_discrete(cpprob_hip_ctx* ctx, const int32_t* d_x, const double* h_weights, int32_t k, size_t n, double* d_out);
+
+/* EmpiricalDistribution (include/cpprob/postprocess/empirical_distribution.hpp):
+ * h_out[0] = max, [1] = logsumexp (:125-143), [2] = ESS = (sum W^2)^-1. */
+int cpprob_hip_logsumexp_ess(cpprob_hip_ctx* ctx, const double* d_logw, size_t n, double* h_out3);
+/* h_out[0] = mean (:68-71), [1] = variance (:78-81), [2] = logsumexp, [3] = ESS. */
+int cpprob_hip_weighted_moments(cpprob_hip_ctx* ctx, const double* d_x, const double* d_logw, size_t n, double* h_out4);
+/* h_out[s] = sum_i W_i [x_i == s], s < k <= 8  (distribution(), :30-40). */
+int cpprob_hip_weighted_hist(cpprob_hip_ctx* ctx, const int32_t* d_x, const double* d_logw, size_t n, int32_t k, double* h_out);
+
+/* Resampling: d_anc[jj] = ancestor (index into d_logw[0..n_in)) of output j0 + jj, for n_out
+ * consecutive outputs of a population of n_total_out positions.  Uniforms come from
+ * draw index (1<<40) + step (systematic: particle id 0; otherwise particle id j). */
+int cpprob_hip_resample(cpprob_hip_ctx* ctx, int32_t kind, const double* d_logw, size_t n_in, uint64_t seed, uint64_t step,
+                        uint64_t j0, size_t n_out, uint64_t n_total_out, int32_t* d_anc);
+/* d_dst[i] = d_src[d_idx[i]] */
+int cpprob_hip_gather_f64(cpprob_hip_ctx* ctx, const double* d_src, const int32_t* d_idx, size_t n, double* d_dst);
+int cpprob_hip_gather_i32(cpprob_hip_ctx* ctx, const int32_t* d_src, const int32_t* d_idx, size_t n, int32_t* d_dst);
+
+/* Kernel timing of the last cpprob_hip_infer_run, measured with HIP events on the context's
+ * stream when enabled (adds two event records per kernel class; off by default).
+ * h_ms[k] = accumulated milliseconds, h_calls[k] = launches of kernel class k since the last
+ * reset; classes: 0 propagate/step, 1 scan-partials, 2 smoothing read-out, 3 finalize,
+ * 4 sis, 5 resample-only.  Synchronises. */
+#define CPPROB_HIP_N_KERNEL_CLASSES 6
+int cpprob_hip_profile_enable(cpprob_hip_ctx* ctx, int32_t on);
+int cpprob_hip_profile_read(cpprob_hip_ctx* ctx, double* h_ms, int64_t* h_calls, int32_t reset);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPPROB_HIP_H_ */

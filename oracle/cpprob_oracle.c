@@ -1,0 +1,573 @@
+/*
+ * cpprob_oracle.c -- CPU restatement of the cpprob::inference(sis) hot path of
+ * lezcano/CPProb, plus the SMC extension the reference never shipped.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may build, load or call it.  The product
+ * (cpprob_amd/, include/) never links, imports or falls back to it.
+ *
+ * Parity status
+ *   - logpdf(normal/uniform_smallint/discrete/uniform_real/poisson): PINNED against
+ *     the grid of the reference's own test tests/cpprob/logpdf.cpp:23-35,61-78
+ *     (tests/golden/logpdf_grid.npz, closed form from scipy) -- tests/test_oracle.py.
+ *   - estimators (logsumexp / mean / variance / distribution): PINNED against the
+ *     analytic posteriors the reference publishes (README.md:118, thesis p.85).
+ *   - text dump grammar: PINNED against the reference's own printer/parser
+ *     (include/cpprob/serialization.hpp compiled into oracle/_ref/).
+ *   - sampler streams: UNPINNABLE.  The reference draws from Boost.Random 1.66
+ *     (un-vendored, .travis.yml:74) on a std::mt19937 seeded from random_device
+ *     (src/cpprob/utils.cpp:16-20); no seed exists in its API.  The generators
+ *     below are a counter-based replacement (Philox4x32-10, rocRAND-compatible
+ *     layout) pinned against rocRAND's own host-callable engine
+ *     (tests/golden/philox_rocrand.json) and distributionally against the
+ *     exact laws.
+ *   - SMC: the reference has none (include/cpprob/state.hpp:28-33).  The driver
+ *     follows thesis Alg. 1 p.36 / ESS p.37 and is pinned against exact
+ *     posteriors (forward-backward, Kalman/RTS) in oracle/exact.py.
+ *
+ * Everything is strict IEEE fp64, compiled with -ffp-contract=off.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* Model ids, algorithms and resamplers (mirror include/cpprob_hip.h)         */
+/* ------------------------------------------------------------------------- */
+enum { ORC_MODEL_GAUSSIAN_UNKNOWN_MEAN = 0, /* include/models/models.hpp:22-35 */
+       ORC_MODEL_GAUSSIAN_README = 1,       /* src/models/gaussian.cpp:6-17    */
+       ORC_MODEL_LINEAR_GAUSSIAN_1D = 2,    /* include/models/models.hpp:67-80 */
+       ORC_MODEL_HMM3 = 3 };                /* include/models/models.hpp:114-141 */
+enum { ORC_RESAMPLE_SYSTEMATIC = 0, ORC_RESAMPLE_STRATIFIED = 1, ORC_RESAMPLE_MULTINOMIAL = 2 };
+
+#define ORC_RESAMPLE_DRAW_BASE (1ull << 40) /* draw index of the resampling uniforms */
+
+/* ------------------------------------------------------------------------- */
+/* Philox4x32-10 (Salmon et al., SC'11; same constants as Random123/rocRAND)  */
+/* Replaces get_rng(), src/cpprob/utils.cpp:16-20 (unseedable mt19937).       */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+    uint32_t k0 = key_in[0], k1 = key_in[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* One 128-bit block per sample statement: key = seed, counter = (draw index,
+ * global particle id).  Identical to rocrand_init(seed, subsequence = pid,
+ * offset = 4*draw) followed by rocrand4(). */
+ORC_API void orc_draw_block(uint64_t seed, uint64_t pid, uint64_t draw, uint32_t out[4])
+{
+    uint32_t ctr[4] = { (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)pid, (uint32_t)(pid >> 32) };
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    orc_philox4x32_10(ctr, key, out);
+}
+
+static const double TWO_POW_M53 = 1.1102230246251565e-16; /* 2^-53 */
+
+/* 53-bit integer from two words, rocRAND's uniform_distribution_double(v1, v2). */
+static inline uint64_t bits53(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)(hi >> 11) << 32); }
+
+/* (0, 1] */
+ORC_API double orc_u01_open0(uint32_t lo, uint32_t hi) { return TWO_POW_M53 + (double)bits53(lo, hi) * TWO_POW_M53; }
+/* [0, 1) */
+ORC_API double orc_u01_open1(uint32_t lo, uint32_t hi) { return (double)bits53(lo, hi) * TWO_POW_M53; }
+
+/* sin(pi*w) for w in (0, 2], exact range reduction then libm. */
+static double sinpi_02(double w)
+{
+    /* reduce to r in [-0.5, 0.5]: sin(pi w) = sin(pi r) * sign */
+    double sign = 1.0;
+    if (w > 1.0) { w -= 1.0; sign = -1.0; }   /* exact: w in (1,2] */
+    if (w > 0.5) w = 1.0 - w;                  /* exact */
+    if (w <= 0.25) return sign * sin(M_PI * w);
+    return sign * cos(M_PI * (0.5 - w));
+}
+
+/* Standard normal, Box-Muller, first output of rocRAND's box_muller_double(uint4):
+ * u = 2^-53 + v1*2^-53, v1 = x ^ (y << 21); w = 2^-52 + v2*2^-52, v2 = z ^ (w << 21);
+ * z = sqrt(-2 log u) * sin(pi w).
+ * Stands in for boost::random::normal_distribution::operator() (row a14). */
+ORC_API double orc_std_normal_from_block(const uint32_t r[4])
+{
+    uint64_t v1 = (uint64_t)r[0] ^ ((uint64_t)r[1] << 21);
+    uint64_t v2 = (uint64_t)r[2] ^ ((uint64_t)r[3] << 21);
+    double u = TWO_POW_M53 + (double)v1 * TWO_POW_M53;
+    double w = (TWO_POW_M53 * 2.0) + (double)v2 * (TWO_POW_M53 * 2.0);
+    double s = sqrt(-2.0 * log(u));
+    return s * sinpi_02(w);
+}
+
+ORC_API double orc_draw_normal(uint64_t seed, uint64_t pid, uint64_t draw, double mean, double sigma)
+{
+    uint32_t r[4];
+    orc_draw_block(seed, pid, draw, r);
+    return mean + sigma * orc_std_normal_from_block(r);
+}
+
+/* uniform_smallint<size_t>{a, b}: a + floor(word * range / 2^32) */
+ORC_API uint64_t orc_draw_smallint(uint64_t seed, uint64_t pid, uint64_t draw, uint64_t a, uint64_t b)
+{
+    uint32_t r[4];
+    orc_draw_block(seed, pid, draw, r);
+    uint64_t range = b - a + 1;
+    return a + (((uint64_t)r[0] * range) >> 32);
+}
+
+/* discrete_distribution over k weights: inverse CDF on the normalised cumulative
+ * sums, u in [0,1).  (Boost uses an alias table; law is identical.) */
+static uint64_t discrete_from_u(double u, const double *w, int k)
+{
+    double tot = 0.0;
+    for (int i = 0; i < k; ++i) tot += w[i];
+    double acc = 0.0;
+    uint64_t idx = 0;
+    for (int i = 0; i < k - 1; ++i) {
+        acc += w[i];
+        if (u >= acc / tot) idx = (uint64_t)(i + 1);
+    }
+    return idx;
+}
+
+ORC_API uint64_t orc_draw_discrete(uint64_t seed, uint64_t pid, uint64_t draw, const double *w, int k)
+{
+    uint32_t r[4];
+    orc_draw_block(seed, pid, draw, r);
+    return discrete_from_u(orc_u01_open1(r[0], r[1]), w, k);
+}
+
+/* uniform_real_distribution{a,b}: a + (b-a)*u, u in [0,1) */
+ORC_API double orc_draw_uniform_real(uint64_t seed, uint64_t pid, uint64_t draw, double a, double b)
+{
+    uint32_t r[4];
+    orc_draw_block(seed, pid, draw, r);
+    return a + (b - a) * orc_u01_open1(r[0], r[1]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* logpdf functors                                                            */
+/* ------------------------------------------------------------------------- */
+/* include/cpprob/distributions/utils_normal_distribution.hpp:20-45 */
+ORC_API double orc_normal_logpdf(double x, double mean, double std)
+{
+    if (std == 0) {                                   /* :28-32 Dirac delta */
+        return x == mean ? 0 : -INFINITY;
+    }
+    if (fabs(x) == INFINITY) {                        /* :34-36 */
+        return -INFINITY;
+    }
+    double result = (x - mean) / std;                 /* :38 */
+    result *= result;                                 /* :39 */
+    result += log(2 * M_PI * std * std);              /* :40 */
+    result *= -0.5;                                   /* :41 */
+    return result;
+}
+
+/* include/cpprob/distributions/utils_uniform_smallint.hpp:17-27 */
+ORC_API double orc_uniform_smallint_logpdf(int64_t x, int64_t a, int64_t b)
+{
+    if (x < a || x > b) return -INFINITY;
+    return -log((double)(b - a) + 1.0);
+}
+
+/* include/cpprob/distributions/utils_discrete.hpp:17-27 (probabilities() are normalised) */
+ORC_API double orc_discrete_logpdf(int64_t x, const double *w, int k)
+{
+    if (x < 0 || x > k - 1) return -INFINITY;
+    double tot = 0.0;
+    for (int i = 0; i < k; ++i) tot += w[i];
+    return log(w[x] / tot);
+}
+
+/* include/cpprob/distributions/utils_uniform_real.hpp:21-31 */
+ORC_API double orc_uniform_real_logpdf(double x, double a, double b)
+{
+    if (x < a || x > b) return -INFINITY;
+    return -log(b - a);
+}
+
+/* include/cpprob/distributions/utils_poisson.hpp:17-36 */
+ORC_API double orc_poisson_logpdf(int64_t x, double l)
+{
+    if (l == 0.0) return -INFINITY;
+    double ret = (double)x * log(l) - l;
+    for (int64_t i = 1; i <= x; ++i) ret -= log((double)i);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Trace record: what TraceInfer holds for one particle                       */
+/* (include/cpprob/trace.hpp:34-63): predict lists + double log_w_ = 0.        */
+/* In memory the predict lists become columns: real[t][i] / ints[t][i].       */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t seed, pid;      /* replaces the global mt19937 */
+    uint64_t n_sample;       /* ordinal of the next sample statement (draw index) */
+    double log_w;            /* trace.hpp:59 */
+    double *real; int32_t *ints; /* predict columns of THIS particle (strided) */
+    size_t stride; int n_pred;
+} orc_trace;
+
+/* cpprob::sample, SIS branch: `return distr(get_rng())`  cpprob.hpp:33-35,72-74 */
+static double tr_sample_normal(orc_trace *tr, double mean, double sigma)
+{ return orc_draw_normal(tr->seed, tr->pid, tr->n_sample++, mean, sigma); }
+static uint64_t tr_sample_smallint(orc_trace *tr, uint64_t a, uint64_t b)
+{ return orc_draw_smallint(tr->seed, tr->pid, tr->n_sample++, a, b); }
+static uint64_t tr_sample_discrete(orc_trace *tr, const double *w, int k)
+{ return orc_draw_discrete(tr->seed, tr->pid, tr->n_sample++, w, k); }
+
+/* cpprob::observe -> StateInfer::increment_log_prob: trace_.log_w_ += logpdf
+ * cpprob.hpp:79-90, state.cpp:212-223 */
+static void tr_observe_normal(orc_trace *tr, double mean, double sigma, double x)
+{ tr->log_w += orc_normal_logpdf(x, mean, sigma); }
+
+/* cpprob::predict -> StateInfer::add_predict (real / int lists) cpprob.hpp:92-98,
+ * state.hpp:312-327.  All target models use ONE address, so the k-th hit is column k. */
+static void tr_predict_real(orc_trace *tr, double x) { tr->real[(size_t)tr->n_pred++ * tr->stride] = x; }
+static void tr_predict_int(orc_trace *tr, uint64_t x) { tr->ints[(size_t)tr->n_pred++ * tr->stride] = (int32_t)x; }
+
+/* ------------------------------------------------------------------------- */
+/* Models (row a12)                                                           */
+/* ------------------------------------------------------------------------- */
+/* include/models/models.hpp:22-35 */
+static void model_gaussian_unknown_mean(orc_trace *tr, const double *y)
+{
+    const double mu = tr_sample_normal(tr, 1, sqrt(5));   /* :26-27 prior {1, sqrt(5)} */
+    const double var = sqrt(2);                            /* :28 (used as sigma)      */
+    tr_observe_normal(tr, mu, var, y[0]);                  /* :32 */
+    tr_observe_normal(tr, mu, var, y[1]);                  /* :33 */
+    tr_predict_real(tr, mu);                               /* :34 "Mu" */
+}
+/* src/models/gaussian.cpp:6-17 */
+static void model_gaussian_readme(orc_trace *tr, const double *y)
+{
+    const double mu0 = 1, sigma0 = 1.5, sigma = 2;         /* :8 */
+    const double mu = tr_sample_normal(tr, mu0, sigma0);   /* :10-11 */
+    tr_observe_normal(tr, mu, sigma, y[0]);                /* :14 */
+    tr_observe_normal(tr, mu, sigma, y[1]);                /* :15 */
+    tr_predict_real(tr, mu);                               /* :16 "Mean" */
+}
+/* include/models/models.hpp:67-80 */
+static void model_linear_gaussian_1d(orc_trace *tr, const double *obs, size_t T)
+{
+    double state = 0;                                      /* :72 */
+    for (size_t t = 0; t < T; ++t) {                       /* :73 */
+        state = tr_sample_normal(tr, state, 1);            /* :74-75 */
+        tr_observe_normal(tr, state, 1, obs[t]);           /* :76-77 */
+        tr_predict_real(tr, state);                        /* :78 "State" */
+    }
+}
+/* include/models/models.hpp:114-141 */
+static const double HMM_MEAN[3] = { -1, 0, 1 };                               /* :122 */
+static const double HMM_T[3][3] = { { 0.1, 0.5, 0.4 }, { 0.2, 0.2, 0.6 }, { 0.15, 0.15, 0.7 } }; /* :123-125 */
+static void model_hmm3(orc_trace *tr, const double *obs, size_t T)
+{
+    uint64_t state = tr_sample_smallint(tr, 0, 2);         /* :126-127 */
+    tr_predict_int(tr, state);                             /* :128 */
+    tr_observe_normal(tr, HMM_MEAN[state], 1, obs[0]);     /* :130-131 */
+    for (size_t t = 1; t < T; ++t) {                       /* :134 */
+        state = tr_sample_discrete(tr, HMM_T[state], 3);   /* :135-136 */
+        tr_predict_int(tr, state);                         /* :137 */
+        tr_observe_normal(tr, HMM_MEAN[state], 1, obs[t]); /* :138-139 */
+    }
+}
+
+static int model_is_int(int model) { return model == ORC_MODEL_HMM3; }
+ORC_API int orc_model_num_predicts(int model, size_t n_obs)
+{ return (model == ORC_MODEL_GAUSSIAN_UNKNOWN_MEAN || model == ORC_MODEL_GAUSSIAN_README) ? 1 : (int)n_obs; }
+
+static int run_model(int model, orc_trace *tr, const double *obs, size_t n_obs)
+{
+    switch (model) {
+    case ORC_MODEL_GAUSSIAN_UNKNOWN_MEAN: if (n_obs != 2) return -1; model_gaussian_unknown_mean(tr, obs); return 0;
+    case ORC_MODEL_GAUSSIAN_README:       if (n_obs != 2) return -1; model_gaussian_readme(tr, obs); return 0;
+    case ORC_MODEL_LINEAR_GAUSSIAN_1D:    if (n_obs < 1) return -1;  model_linear_gaussian_1d(tr, obs, n_obs); return 0;
+    case ORC_MODEL_HMM3:                  if (n_obs < 1) return -1;  model_hmm3(tr, obs, n_obs); return 0;
+    }
+    return -2;
+}
+
+/* ------------------------------------------------------------------------- */
+/* cpprob::inference(StateType::sis, ...)  include/cpprob/cpprob.hpp:173-203  */
+/* In-memory form: finish_trace() appends to column arrays, not to files.     */
+/*   val_real / val_int : [n_pred][n] column-major predict values             */
+/*   logw               : [n]                                                 */
+/* pid0 = global id of local particle 0 (sharding).                           */
+/* ------------------------------------------------------------------------- */
+ORC_API int orc_sis(int model, const double *obs, size_t n_obs, uint64_t n, uint64_t seed, uint64_t pid0,
+                    double *val_real, int32_t *val_int, double *logw)
+{
+    for (uint64_t i = 0; i < n; ++i) {                    /* cpprob.hpp:194 */
+        orc_trace tr;                                      /* start_trace(): trace_ = TraceInfer() state.cpp:188-191 */
+        memset(&tr, 0, sizeof tr);
+        tr.seed = seed; tr.pid = pid0 + i; tr.log_w = 0;
+        tr.real = val_real ? val_real + i : NULL;
+        tr.ints = val_int ? val_int + i : NULL;
+        tr.stride = n;
+        int rc = run_model(model, &tr, obs, n_obs);        /* call_f_tuple(f, observes) cpprob.hpp:199 */
+        if (rc) return rc;
+        logw[i] = tr.log_w;                                /* finish_trace() state.cpp:193-202 */
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Faithful on-disk form (row a10): StateInfer::dump_predicts state.cpp:262-267*/
+/* `([(id v) (id v) ...] logw)`, std::scientific, precision digits10 = 15;     */
+/* grammar serialization.hpp:41-46,71-98.  One open/append/close per particle  */
+/* per file, exactly like finish_trace() state.cpp:193-202 (all three files).  */
+/* ------------------------------------------------------------------------- */
+static void dump_line(const char *path, int n_pred, const double *real, const int32_t *ints, size_t stride, double logw)
+{
+    FILE *f = fopen(path, "a");                           /* std::ios::app state.cpp:264 */
+    if (!f) return;
+    fputs("([", f);
+    for (int k = 0; k < n_pred; ++k) {
+        if (k) fputc(' ', f);
+        if (real) fprintf(f, "(0 %.15e)", real[(size_t)k * stride]);
+        else      fprintf(f, "(0 %d)", ints[(size_t)k * stride]);
+    }
+    fprintf(f, "] %.15e)\n", logw);
+    fclose(f);
+}
+
+ORC_API int orc_sis_faithful(int model, const double *obs, size_t n_obs, uint64_t n, uint64_t seed,
+                             const char *file_prefix, const char *address, int progress)
+{
+    char p_real[4096], p_int[4096], p_any[4096], p_ids[4096];
+    snprintf(p_real, sizeof p_real, "%s.real", file_prefix);
+    snprintf(p_int, sizeof p_int, "%s.int", file_prefix);
+    snprintf(p_any, sizeof p_any, "%s.any", file_prefix);
+    snprintf(p_ids, sizeof p_ids, "%s.ids", file_prefix);
+    int n_pred = orc_model_num_predicts(model, n_obs);
+    double *real = (double *)calloc((size_t)n_pred, sizeof(double));
+    int32_t *ints = (int32_t *)calloc((size_t)n_pred, sizeof(int32_t));
+    int is_int = model_is_int(model);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (progress && i % 100 == 0) { printf("Generating trace %llu\n", (unsigned long long)i); fflush(stdout); } /* cpprob.hpp:195-197 (endl flushes) */
+        orc_trace tr; memset(&tr, 0, sizeof tr);
+        tr.seed = seed; tr.pid = i; tr.real = real; tr.ints = ints; tr.stride = 1;
+        int rc = run_model(model, &tr, obs, n_obs);
+        if (rc) { free(real); free(ints); return rc; }
+        /* finish_trace(): three dumps, empty lists print as `([] logw)` */
+        dump_line(p_int, is_int ? n_pred : 0, NULL, ints, 1, tr.log_w);
+        dump_line(p_real, is_int ? 0 : n_pred, real, NULL, 1, tr.log_w);
+        dump_line(p_any, 0, real, NULL, 1, tr.log_w);
+    }
+    /* finish_infer(): ids file, then delete the all-empty files state.cpp:164-180 */
+    FILE *f = fopen(p_ids, "w");
+    if (f) { fprintf(f, "%s\n", address); fclose(f); }
+    if (is_int) remove(p_real); else remove(p_int);
+    remove(p_any);
+    free(real); free(ints);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Estimators (row a13) include/cpprob/postprocess/empirical_distribution.hpp  */
+/* ------------------------------------------------------------------------- */
+/* logsumexp :125-143 -- max-shifted, sequential accumulate */
+ORC_API double orc_logsumexp(const double *logw, uint64_t n)
+{
+    if (n == 0) return 0.0;                               /* :131-133 value-initialised */
+    double max = logw[0];
+    for (uint64_t i = 1; i < n; ++i) if (logw[i] > max) max = logw[i];  /* supremum :135 */
+    double acc = 0.0;
+    for (uint64_t i = 0; i < n; ++i) acc += exp(logw[i] - max);         /* :136-139 */
+    return log(acc) + max;                                               /* :140 */
+}
+
+/* raw_moment(1), raw_moment(2) - mean^2  :52-81 ; ESS = (sum W^2)^-1 thesis p.37 */
+ORC_API void orc_weighted_moments(const double *x, const double *logw, uint64_t n, double out[4])
+{
+    double log_norm = orc_logsumexp(logw, n);
+    double m1 = 0.0, m2 = 0.0, q = 0.0;
+    for (uint64_t i = 0; i < n; ++i) {
+        double w = exp(logw[i] - log_norm);               /* :63 */
+        m1 += w * x[i];
+        m2 += w * (x[i] * x[i]);
+        q += w * w;
+    }
+    out[0] = m1;                 /* mean()              :68-71 */
+    out[1] = m2 - m1 * m1;       /* variance(mean)      :78-81 */
+    out[2] = log_norm;
+    out[3] = 1.0 / q;            /* ESS */
+}
+
+/* distribution() :30-40 for integer predicts with support {0..k-1} */
+ORC_API void orc_weighted_hist(const int32_t *x, const double *logw, uint64_t n, int k, double *out)
+{
+    double log_norm = orc_logsumexp(logw, n);
+    for (int j = 0; j < k; ++j) out[j] = 0.0;
+    for (uint64_t i = 0; i < n; ++i)
+        if (x[i] >= 0 && x[i] < k) out[x[i]] += exp(logw[i] - log_norm);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Resampling (row a15; spec: thesis Alg. 1 p.36, remark on systematic p.36)   */
+/* weights w_k = exp(logw_k - max), inclusive CDF C_k, total W.                */
+/* position of output j:  systematic (j + u0) * W/N, stratified (j + u_j) * W/N,*/
+/* multinomial u_j * W.   ancestor a_j = min{k : C_k > p_j} (clamped to N-1).   */
+/* u0 = draw(seed, pid 0, RESAMPLE_BASE + step), u_j = draw(seed, pid j, same). */
+/* ------------------------------------------------------------------------- */
+static uint64_t upper_bound_d(const double *c, uint64_t n, double p)
+{
+    uint64_t lo = 0, hi = n;          /* first k with c[k] > p */
+    while (lo < hi) { uint64_t mid = lo + (hi - lo) / 2; if (c[mid] > p) hi = mid; else lo = mid + 1; }
+    return lo < n ? lo : n - 1;
+}
+
+static double resample_u(uint64_t seed, uint64_t pid, uint64_t step)
+{
+    uint32_t r[4];
+    orc_draw_block(seed, pid, ORC_RESAMPLE_DRAW_BASE + step, r);
+    return orc_u01_open1(r[0], r[1]);
+}
+
+/* n_out outputs [j0, j0+n_out) of a population of n_total_out positions drawn
+ * over the n_in weights.  (Sharded runs call this with j0 != 0.) */
+ORC_API int orc_resample(int kind, const double *logw, uint64_t n_in, uint64_t seed, uint64_t step,
+                         uint64_t j0, uint64_t n_out, uint64_t n_total_out, int32_t *anc, double *cdf_scratch)
+{
+    double *cdf = cdf_scratch ? cdf_scratch : (double *)malloc(n_in * sizeof(double));
+    if (!cdf) return -1;
+    double max = logw[0];
+    for (uint64_t i = 1; i < n_in; ++i) if (logw[i] > max) max = logw[i];
+    double acc = 0.0;
+    for (uint64_t i = 0; i < n_in; ++i) { acc += exp(logw[i] - max); cdf[i] = acc; }
+    const double W = acc;
+    const double step_w = W / (double)n_total_out;
+    const double u0 = resample_u(seed, 0, step);
+    for (uint64_t jj = 0; jj < n_out; ++jj) {
+        uint64_t j = j0 + jj;
+        double p;
+        if (kind == ORC_RESAMPLE_SYSTEMATIC) p = ((double)j + u0) * step_w;
+        else if (kind == ORC_RESAMPLE_STRATIFIED) p = ((double)j + resample_u(seed, j, step)) * step_w;
+        else p = resample_u(seed, j, step) * W;
+        anc[jj] = (int32_t)upper_bound_d(cdf, n_in, p);
+    }
+    if (!cdf_scratch) free(cdf);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SMC driver (row a15).  Markov step form of the three state-space models:   */
+/* step t: x_t ~ p(.|x_{t-1}) [sample #t], predict, logw += log p(y_t|x_t).    */
+/* After weighting step t (t < T-1): ESS_t = W^2/Q; resample iff ESS_t <       */
+/* ess_frac*N (ess_frac > 1: every step); then logw <- 0 and                   */
+/* logZ += max + log(W/N).  No resampling after the last step.                 */
+/* hist_real/hist_int [T][n]: value of predict t in slot i of generation t.    */
+/* hist_anc [T][n]: slot of generation t-1 that slot i of generation t extends */
+/* (row 0 = identity).                                                         */
+/* ------------------------------------------------------------------------- */
+ORC_API int orc_smc(int model, const double *obs, size_t T, uint64_t n, uint64_t seed,
+                    int resampler, double ess_frac,
+                    double *hist_real, int32_t *hist_int, int32_t *hist_anc,
+                    double *logw_final, double *log_z, double *ess_trace, int32_t *resampled)
+{
+    if (model != ORC_MODEL_LINEAR_GAUSSIAN_1D && model != ORC_MODEL_HMM3) return -2;
+    if ((model == ORC_MODEL_HMM3) != (hist_int != NULL)) return -3;
+    double *logw = (double *)calloc(n, sizeof(double));
+    double *cdf = (double *)malloc(n * sizeof(double));
+    int32_t *anc = (int32_t *)malloc(n * sizeof(int32_t));
+    if (!logw || !cdf || !anc) return -1;
+    double lz = 0.0;
+    int do_resample = 0;
+    for (size_t t = 0; t < T; ++t) {
+        if (do_resample) {
+            orc_resample(resampler, logw, n, seed, (uint64_t)t, 0, n, n, anc, cdf);
+        } else {
+            for (uint64_t i = 0; i < n; ++i) anc[i] = (int32_t)i;
+        }
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t a = (uint64_t)anc[i];
+            hist_anc[t * n + i] = anc[i];
+            double lw = do_resample ? 0.0 : logw[a];      /* a == i when not resampling */
+            if (model == ORC_MODEL_LINEAR_GAUSSIAN_1D) {
+                double prev = t == 0 ? 0.0 : hist_real[(t - 1) * n + a];
+                double x = orc_draw_normal(seed, i, (uint64_t)t, prev, 1);
+                hist_real[t * n + i] = x;
+                lw += orc_normal_logpdf(obs[t], x, 1);
+            } else {
+                uint64_t s;
+                if (t == 0) s = orc_draw_smallint(seed, i, 0, 0, 2);
+                else s = orc_draw_discrete(seed, i, (uint64_t)t, HMM_T[hist_int[(t - 1) * n + a]], 3);
+                hist_int[t * n + i] = (int32_t)s;
+                lw += orc_normal_logpdf(obs[t], HMM_MEAN[s], 1);
+            }
+            cdf[i] = lw;                                  /* staging: new logw */
+        }
+        memcpy(logw, cdf, n * sizeof(double));
+        /* weights of generation t */
+        double max = logw[0];
+        for (uint64_t i = 1; i < n; ++i) if (logw[i] > max) max = logw[i];
+        double W = 0.0, Q = 0.0;
+        for (uint64_t i = 0; i < n; ++i) { double w = exp(logw[i] - max); W += w; Q += w * w; }
+        double ess = W * W / Q;
+        if (ess_trace) ess_trace[t] = ess;
+        do_resample = (t + 1 < T) && (ess < ess_frac * (double)n);
+        if (resampled) resampled[t] = do_resample;
+        if (do_resample) lz += max + log(W / (double)n);
+        else if (t + 1 == T) lz += max + log(W / (double)n);
+    }
+    memcpy(logw_final, logw, n * sizeof(double));
+    if (log_z) *log_z = lz;
+    free(logw); free(cdf); free(anc);
+    return 0;
+}
+
+/* Lineage read-out: path[t][i] = slot of generation t on the ancestral line of
+ * final particle i.  This is what makes each surviving particle a full trace
+ * (list of T predicts + one weight) as in TraceInfer / stats_printer.hpp:106-118. */
+ORC_API void orc_trace_lineage(const int32_t *hist_anc, size_t T, uint64_t n, int32_t *path)
+{
+    for (uint64_t i = 0; i < n; ++i) path[(T - 1) * n + i] = (int32_t)i;
+    for (size_t t = T - 1; t > 0; --t)
+        for (uint64_t i = 0; i < n; ++i)
+            path[(t - 1) * n + i] = hist_anc[t * n + (uint64_t)path[t * n + i]];
+}
+
+/* Smoothing estimators over lineages: per predict hit t, StatsPrinter's numbers.
+ * real: out[t*2+0] = mean, out[t*2+1] = variance; int: out[t*k + s] = P(x_t = s). */
+ORC_API void orc_smoothing_real(const double *hist_real, const int32_t *hist_anc, const double *logw,
+                                size_t T, uint64_t n, double *out)
+{
+    int32_t *path = (int32_t *)malloc(T * n * sizeof(int32_t));
+    double *col = (double *)malloc(n * sizeof(double));
+    orc_trace_lineage(hist_anc, T, n, path);
+    for (size_t t = 0; t < T; ++t) {
+        for (uint64_t i = 0; i < n; ++i) col[i] = hist_real[t * n + (uint64_t)path[t * n + i]];
+        double m[4];
+        orc_weighted_moments(col, logw, n, m);
+        out[t * 2] = m[0]; out[t * 2 + 1] = m[1];
+    }
+    free(path); free(col);
+}
+
+ORC_API void orc_smoothing_int(const int32_t *hist_int, const int32_t *hist_anc, const double *logw,
+                               size_t T, uint64_t n, int k, double *out)
+{
+    int32_t *path = (int32_t *)malloc(T * n * sizeof(int32_t));
+    int32_t *col = (int32_t *)malloc(n * sizeof(int32_t));
+    orc_trace_lineage(hist_anc, T, n, path);
+    for (size_t t = 0; t < T; ++t) {
+        for (uint64_t i = 0; i < n; ++i) col[i] = hist_int[t * n + (uint64_t)path[t * n + i]];
+        orc_weighted_hist(col, logw, n, k, out + t * k);
+    }
+    free(path); free(col);
+}

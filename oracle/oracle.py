@@ -1,0 +1,173 @@
+"""ctypes front-end of oracle/cpprob_oracle.c (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README, MODEL_LINEAR_GAUSSIAN_1D, MODEL_HMM3 = 0, 1, 2, 3
+RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
+RESAMPLE_DRAW_BASE = 1 << 40
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_up = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "_build", "liboracle.so")
+    src = os.path.join(_HERE, "cpprob_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "_build/liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        u64, i64, dbl, sz = C.c_uint64, C.c_int64, C.c_double, C.c_size_t
+        L.orc_philox4x32_10.argtypes = [_up, _up, _up]
+        L.orc_draw_block.argtypes = [u64, u64, u64, _up]
+        L.orc_u01_open0.restype = dbl; L.orc_u01_open0.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_u01_open1.restype = dbl; L.orc_u01_open1.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_std_normal_from_block.restype = dbl; L.orc_std_normal_from_block.argtypes = [_up]
+        L.orc_draw_normal.restype = dbl; L.orc_draw_normal.argtypes = [u64, u64, u64, dbl, dbl]
+        L.orc_draw_smallint.restype = u64; L.orc_draw_smallint.argtypes = [u64, u64, u64, u64, u64]
+        L.orc_draw_discrete.restype = u64; L.orc_draw_discrete.argtypes = [u64, u64, u64, _dp, C.c_int]
+        L.orc_draw_uniform_real.restype = dbl; L.orc_draw_uniform_real.argtypes = [u64, u64, u64, dbl, dbl]
+        L.orc_normal_logpdf.restype = dbl; L.orc_normal_logpdf.argtypes = [dbl, dbl, dbl]
+        L.orc_uniform_smallint_logpdf.restype = dbl; L.orc_uniform_smallint_logpdf.argtypes = [i64, i64, i64]
+        L.orc_discrete_logpdf.restype = dbl; L.orc_discrete_logpdf.argtypes = [i64, _dp, C.c_int]
+        L.orc_uniform_real_logpdf.restype = dbl; L.orc_uniform_real_logpdf.argtypes = [dbl, dbl, dbl]
+        L.orc_poisson_logpdf.restype = dbl; L.orc_poisson_logpdf.argtypes = [i64, dbl]
+        L.orc_model_num_predicts.restype = C.c_int; L.orc_model_num_predicts.argtypes = [C.c_int, sz]
+        L.orc_sis.restype = C.c_int
+        L.orc_sis.argtypes = [C.c_int, _dp, sz, u64, u64, u64, C.c_void_p, C.c_void_p, _dp]
+        L.orc_sis_faithful.restype = C.c_int
+        L.orc_sis_faithful.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_char_p, C.c_char_p, C.c_int]
+        L.orc_logsumexp.restype = dbl; L.orc_logsumexp.argtypes = [_dp, u64]
+        L.orc_weighted_moments.argtypes = [_dp, _dp, u64, _dp]
+        L.orc_weighted_hist.argtypes = [_ip, _dp, u64, C.c_int, _dp]
+        L.orc_resample.restype = C.c_int
+        L.orc_resample.argtypes = [C.c_int, _dp, u64, u64, u64, u64, u64, u64, _ip, C.c_void_p]
+        L.orc_smc.restype = C.c_int
+        L.orc_smc.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
+                              C.POINTER(dbl), _dp, _ip]
+        L.orc_trace_lineage.argtypes = [_ip, sz, u64, _ip]
+        L.orc_smoothing_real.argtypes = [_dp, _ip, _dp, sz, u64, _dp]
+        L.orc_smoothing_int.argtypes = [_ip, _ip, _dp, sz, u64, C.c_int, _dp]
+        _LIB = L
+    return _LIB
+
+
+def philox(ctr, key):
+    out = np.zeros(4, np.uint32)
+    lib().orc_philox4x32_10(np.asarray(ctr, np.uint32), np.asarray(key, np.uint32), out)
+    return out
+
+
+def draw_block(seed, pid, draw):
+    out = np.zeros(4, np.uint32)
+    lib().orc_draw_block(seed, pid, draw, out)
+    return out
+
+
+def is_int_model(model):
+    return model == MODEL_HMM3
+
+
+def sis(model, obs, n, seed, pid0=0):
+    """cpprob::inference(StateType::sis,...) in memory. Returns (values[n_pred][n], logw[n])."""
+    obs = np.ascontiguousarray(obs, np.float64)
+    T = lib().orc_model_num_predicts(model, len(obs))
+    logw = np.zeros(n, np.float64)
+    if is_int_model(model):
+        vals = np.zeros((T, n), np.int32)
+        rc = lib().orc_sis(model, obs, len(obs), n, seed, pid0, None, vals.ctypes.data, logw)
+    else:
+        vals = np.zeros((T, n), np.float64)
+        rc = lib().orc_sis(model, obs, len(obs), n, seed, pid0, vals.ctypes.data, None, logw)
+    if rc:
+        raise RuntimeError("orc_sis failed rc=%d" % rc)
+    return vals, logw
+
+
+def sis_faithful(model, obs, n, seed, prefix, address, progress=False):
+    obs = np.ascontiguousarray(obs, np.float64)
+    rc = lib().orc_sis_faithful(model, obs, len(obs), n, seed, prefix.encode(), address.encode(), int(progress))
+    if rc:
+        raise RuntimeError("orc_sis_faithful failed rc=%d" % rc)
+
+
+def logsumexp(logw):
+    logw = np.ascontiguousarray(logw, np.float64)
+    return lib().orc_logsumexp(logw, len(logw))
+
+
+def weighted_moments(x, logw):
+    """(mean, variance, log_norm, ess) as EmpiricalDistribution computes them."""
+    out = np.zeros(4)
+    lib().orc_weighted_moments(np.ascontiguousarray(x, np.float64), np.ascontiguousarray(logw, np.float64), len(logw), out)
+    return out
+
+
+def weighted_hist(x, logw, k):
+    out = np.zeros(k)
+    lib().orc_weighted_hist(np.ascontiguousarray(x, np.int32), np.ascontiguousarray(logw, np.float64), len(logw), k, out)
+    return out
+
+
+def resample(kind, logw, seed, step, j0=0, n_out=None, n_total_out=None):
+    logw = np.ascontiguousarray(logw, np.float64)
+    n_in = len(logw)
+    n_out = n_in if n_out is None else n_out
+    n_total_out = n_in if n_total_out is None else n_total_out
+    anc = np.zeros(n_out, np.int32)
+    rc = lib().orc_resample(kind, logw, n_in, seed, step, j0, n_out, n_total_out, anc, None)
+    if rc:
+        raise RuntimeError("orc_resample failed")
+    return anc
+
+
+def smc(model, obs, n, seed, resampler=RESAMPLE_SYSTEMATIC, ess_frac=2.0):
+    """Returns dict(hist, anc, logw, log_z, ess, resampled)."""
+    obs = np.ascontiguousarray(obs, np.float64)
+    T = len(obs)
+    anc = np.zeros((T, n), np.int32)
+    logw = np.zeros(n)
+    ess = np.zeros(T)
+    res = np.zeros(T, np.int32)
+    lz = C.c_double(0.0)
+    if is_int_model(model):
+        hist = np.zeros((T, n), np.int32)
+        rc = lib().orc_smc(model, obs, T, n, seed, resampler, ess_frac, None, hist.ctypes.data, anc, logw,
+                           C.byref(lz), ess, res)
+    else:
+        hist = np.zeros((T, n), np.float64)
+        rc = lib().orc_smc(model, obs, T, n, seed, resampler, ess_frac, hist.ctypes.data, None, anc, logw,
+                           C.byref(lz), ess, res)
+    if rc:
+        raise RuntimeError("orc_smc failed rc=%d" % rc)
+    return dict(hist=hist, anc=anc, logw=logw, log_z=lz.value, ess=ess, resampled=res)
+
+
+def smoothing(hist, anc, logw, k=3):
+    T, n = hist.shape
+    if hist.dtype == np.int32:
+        out = np.zeros((T, k))
+        lib().orc_smoothing_int(hist, anc, np.ascontiguousarray(logw), T, n, k, out.reshape(-1))
+    else:
+        out = np.zeros((T, 2))
+        lib().orc_smoothing_real(hist, anc, np.ascontiguousarray(logw), T, n, out.reshape(-1))
+    return out
+
+
+def lineage(anc):
+    T, n = anc.shape
+    path = np.zeros((T, n), np.int32)
+    lib().orc_trace_lineage(np.ascontiguousarray(anc), T, n, path)
+    return path

@@ -1,0 +1,243 @@
+"""GPU parity of the building blocks, through the C ABI, against the CPU oracle.
+
+Bars: raw Philox words, discrete draws, ancestor indices on exactly-summable weights: bit-exact.
+Floating point (normal draws, logpdf, logsumexp, moments): relative/absolute 1e-12 (device libm
+vs glibc differ by <= 2 ulp in log/exp/sinpi; FMA contraction by 1 ulp).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FP_TOL = 1e-12
+
+
+def _t(a, dtype=None):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def test_philox_words_bit_exact_vs_oracle_and_rocrand(engine, golden_dir):
+    import torch
+    with open(os.path.join(golden_dir, "philox_rocrand.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        out = torch.zeros(4, dtype=torch.int32, device="cuda")
+        engine.philox_blocks(c["seed"], c["pid"], c["draw"], out)
+        engine.sync()
+        words = out.cpu().numpy().view(np.uint32)
+        assert words.tolist() == c["words"]
+        assert O.draw_block(c["seed"], c["pid"], c["draw"]).tolist() == c["words"]
+    n = 100003
+    out = torch.zeros(4 * n, dtype=torch.int32, device="cuda")
+    engine.philox_blocks(777, 5, 9, out)
+    engine.sync()
+    got = out.cpu().numpy().view(np.uint32).reshape(n, 4)
+    for i in (0, 1, 63, 64, 4095, n - 1):
+        assert got[i].tolist() == O.draw_block(777, 5 + i, 9).tolist()
+
+
+def test_draws_match_oracle(engine):
+    import torch
+    n = 20000
+    L = O.lib()
+    out = torch.zeros(n, dtype=torch.float64, device="cuda")
+    engine.draw_normal(42, 1000, 3, 1.0, np.sqrt(5), out)
+    engine.sync()
+    ref = np.array([L.orc_draw_normal(42, 1000 + i, 3, 1.0, np.sqrt(5)) for i in range(n)])
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=FP_TOL, atol=FP_TOL)
+
+    outi = torch.zeros(n, dtype=torch.int32, device="cuda")
+    engine.draw_uniform_smallint(42, 0, 0, 0, 2, outi)
+    engine.sync()
+    ref = np.array([L.orc_draw_smallint(42, i, 0, 0, 2) for i in range(n)])
+    assert np.array_equal(outi.cpu().numpy(), ref)
+
+    for row in ([0.1, 0.5, 0.4], [0.2, 0.2, 0.6], [0.15, 0.15, 0.7], [3.0, 1.0, 2.0, 2.0]):
+        engine.draw_discrete(9, 10, 7, row, outi)
+        engine.sync()
+        w = np.array(row)
+        ref = np.array([L.orc_draw_discrete(9, 10 + i, 7, w, len(row)) for i in range(n)])
+        assert np.array_equal(outi.cpu().numpy(), ref)
+
+    engine.draw_uniform_real(1, 0, 2, -3.0, 5.0, out)
+    engine.sync()
+    ref = np.array([L.orc_draw_uniform_real(1, i, 2, -3.0, 5.0) for i in range(n)])
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=FP_TOL, atol=FP_TOL)
+
+
+def test_logpdf_normal_reference_grid(engine, golden_dir):
+    """The grid of the reference's own test (tests/cpprob/logpdf.cpp:23-35), eps 1e-8 there."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "logpdf_grid.npz"))
+    grid = g["normal_grid"]
+    x, mean, sigma = (_t(grid[:, k].copy()) for k in range(3))
+    out = torch.zeros_like(x)
+    engine.logpdf_normal(x, mean, sigma, out)
+    engine.sync()
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got, g["normal_expected"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(np.exp(got), np.exp(g["normal_expected"]), rtol=0, atol=1e-8)
+    L = O.lib()
+    ref = np.array([L.orc_normal_logpdf(*r) for r in grid[::7]])
+    np.testing.assert_allclose(got[::7], ref, rtol=FP_TOL, atol=FP_TOL)
+
+
+def test_logpdf_edge_cases(engine):
+    import torch
+    inf = float("inf")
+    x = _t([1.0, 2.0, inf, -inf, 0.0])
+    mean = _t([1.0, 1.0, 0.0, 0.0, 0.0])
+    sigma = _t([0.0, 0.0, 1.0, 1.0, 2.0])
+    out = torch.zeros_like(x)
+    engine.logpdf_normal(x, mean, sigma, out)
+    engine.sync()
+    got = out.cpu().numpy()
+    L = O.lib()
+    ref = [L.orc_normal_logpdf(a, b, c) for a, b, c in zip(x.cpu().numpy(), mean.cpu().numpy(), sigma.cpu().numpy())]
+    assert got[0] == 0.0 and got[1] == -inf and got[2] == -inf and got[3] == -inf
+    np.testing.assert_allclose(got, ref, rtol=FP_TOL)
+
+
+def test_logpdf_other_functors(engine, golden_dir):
+    import torch
+    g = np.load(os.path.join(golden_dir, "logpdf_grid.npz"))
+    u = g["uniform_grid"]
+    x, a, b = (_t(u[:, k].copy()) for k in range(3))
+    out = torch.zeros_like(x)
+    engine.logpdf_uniform_real(x, a, b, out)
+    engine.sync()
+    got = out.cpu().numpy()
+    exp = g["uniform_expected"]
+    fin = np.isfinite(exp)
+    assert np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], exp[fin], atol=1e-8)
+    p = g["poisson_grid"]
+    xi = _t(p[:, 0].astype(np.int32))
+    lam = _t(p[:, 1].copy())
+    out = torch.zeros(len(p), dtype=torch.float64, device="cuda")
+    engine.logpdf_poisson(xi, lam, out)
+    engine.sync()
+    np.testing.assert_allclose(out.cpu().numpy(), g["poisson_expected"], atol=1e-9)
+    xs = _t(np.array([-1, 0, 1, 2, 3], np.int32))
+    out = torch.zeros(5, dtype=torch.float64, device="cuda")
+    engine.logpdf_uniform_smallint(xs, 0, 2, out)
+    engine.sync()
+    L = O.lib()
+    np.testing.assert_allclose(out.cpu().numpy(), [L.orc_uniform_smallint_logpdf(int(v), 0, 2) for v in xs.cpu().numpy()], rtol=FP_TOL)
+    engine.logpdf_discrete(xs, [0.1, 0.5, 0.4], out)
+    engine.sync()
+    w = np.array([0.1, 0.5, 0.4])
+    np.testing.assert_allclose(out.cpu().numpy(), [L.orc_discrete_logpdf(int(v), w, 3) for v in xs.cpu().numpy()], rtol=FP_TOL)
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 1023, 1024, 1025, 4097, 300001])
+def test_logsumexp_ess_and_moments(engine, n):
+    rng = np.random.default_rng(n)
+    logw = rng.normal(size=n) * 3 - 700.0      # far from 0: needs the max shift
+    x = rng.normal(size=n) * 2 + 1
+    m, lse, ess = engine.logsumexp_ess(_t(logw))
+    assert m == logw.max()
+    assert abs(lse - O.logsumexp(logw)) < 1e-11
+    ref = O.weighted_moments(x, logw)
+    got = engine.weighted_moments(_t(x), _t(logw))
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-11)
+    xi = rng.integers(0, 3, n).astype(np.int32)
+    np.testing.assert_allclose(engine.weighted_hist(_t(xi), _t(logw), 3), O.weighted_hist(xi, logw, 3), rtol=1e-10, atol=1e-12)
+
+
+def test_logsumexp_with_minus_inf_entries(engine):
+    logw = np.array([-np.inf, 0.0, -np.inf, np.log(3.0)] * 600)
+    m, lse, ess = engine.logsumexp_ess(_t(logw))
+    assert abs(lse - O.logsumexp(logw)) < 1e-12
+    assert abs(ess - 1.0 / (600 * (0.25 ** 2 + 0.75 ** 2) / 600 ** 2)) < 1e-6
+
+
+@pytest.mark.parametrize("kind", [O.RESAMPLE_SYSTEMATIC, O.RESAMPLE_STRATIFIED, O.RESAMPLE_MULTINOMIAL])
+@pytest.mark.parametrize("n,alive", [(1, 1.0), (5, 0.6), (1024, 0.3), (1025, 0.3), (5000, 0.01), (262144 + 17, 0.5), (262144 + 17, 1.0)])
+def test_resample_exact_weights_bit_exact(engine, kind, n, alive):
+    """log-weights in {0, -inf}: exp(lw - max) is exactly 1 or 0 on both sides and every partial
+    sum is an exact integer in any summation order, so ancestors must match the sequential
+    oracle bit for bit (index work)."""
+    import torch
+    rng = np.random.default_rng(1000 + n)
+    logw = np.where(rng.random(n) < alive, 0.0, -np.inf)
+    logw[rng.integers(0, n)] = 0.0
+    anc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    engine.resample(kind, _t(logw), 31337, 4, anc)
+    engine.sync()
+    ref = O.resample(kind, logw, 31337, 4)
+    got = anc.cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert np.all(logw[got] == 0.0)
+
+
+@pytest.mark.parametrize("kind", [O.RESAMPLE_SYSTEMATIC, O.RESAMPLE_STRATIFIED, O.RESAMPLE_MULTINOMIAL])
+def test_resample_generic_weights(engine, kind):
+    import torch
+    n = 200000
+    rng = np.random.default_rng(5)
+    logw = rng.normal(size=n) * 2.0
+    anc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    engine.resample(kind, _t(logw), 99, 1, anc)
+    engine.sync()
+    got = anc.cpu().numpy()
+    ref = O.resample(kind, logw, 99, 1)
+    mism = got != ref
+    assert mism.mean() < 1e-4
+    assert np.all(np.abs(got[mism].astype(np.int64) - ref[mism]) <= 1)
+    if kind != O.RESAMPLE_MULTINOMIAL:
+        assert np.all(np.diff(got) >= 0)           # sortedness
+    # offspring counts follow the weights: |count_k - N W_k| < 1 for systematic
+    if kind == O.RESAMPLE_SYSTEMATIC:
+        w = np.exp(logw - logw.max()); w /= w.sum()
+        cnt = np.bincount(got, minlength=n)
+        assert np.all(np.abs(cnt - n * w) < 1.0 + 1e-6)
+
+
+def test_resample_degenerate_weight(engine):
+    import torch
+    n = 10000
+    logw = np.full(n, -np.inf)
+    logw[1234] = 0.0
+    anc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for kind in (O.RESAMPLE_SYSTEMATIC, O.RESAMPLE_STRATIFIED, O.RESAMPLE_MULTINOMIAL):
+        engine.resample(kind, _t(logw), 1, 0, anc)
+        engine.sync()
+        assert np.all(anc.cpu().numpy() == 1234)
+
+
+def test_resample_subrange_matches_full(engine):
+    """Sharded use: outputs [j0, j0+n_out) of n_total positions."""
+    import torch
+    n = 50000
+    rng = np.random.default_rng(8)
+    logw = rng.normal(size=n)
+    full = torch.zeros(n, dtype=torch.int32, device="cuda")
+    engine.resample(O.RESAMPLE_SYSTEMATIC, _t(logw), 3, 2, full)
+    part = torch.zeros(7777, dtype=torch.int32, device="cuda")
+    engine.resample(O.RESAMPLE_SYSTEMATIC, _t(logw), 3, 2, part, j0=12345, n_total_out=n)
+    engine.sync()
+    assert np.array_equal(part.cpu().numpy(), full.cpu().numpy()[12345:12345 + 7777])
+
+
+def test_gather(engine):
+    import torch
+    n = 100000
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, n, n).astype(np.int32)
+    src = rng.normal(size=n)
+    dst = torch.zeros(n, dtype=torch.float64, device="cuda")
+    engine.gather(_t(src), _t(idx), dst)
+    engine.sync()
+    assert np.array_equal(dst.cpu().numpy(), src[idx])
+    srci = rng.integers(0, 3, n).astype(np.int32)
+    dsti = torch.zeros(n, dtype=torch.int32, device="cuda")
+    engine.gather(_t(srci), _t(idx), dsti)
+    engine.sync()
+    assert np.array_equal(dsti.cpu().numpy(), srci[idx])

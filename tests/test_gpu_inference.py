@@ -1,0 +1,230 @@
+"""GPU parity of cpprob::inference (SIS and SMC) through the C ABI.
+
+Against the oracle on the same seed (particle by particle), against the committed golden
+observation vectors + exact posteriors, and through size-independent properties at full size.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cpprob_amd as cp
+from oracle import exact as E
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FP_TOL = 1e-11
+
+
+def _obs(golden_dir, key):
+    return np.load(os.path.join(golden_dir, "observations.npz"))[key]
+
+
+@pytest.mark.parametrize("model,obs", [(cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, [3.0, 4.0]), (cp.MODEL_GAUSSIAN_README, [3.0, 4.0]),
+                                       (cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, [8.0, 9.0])])
+@pytest.mark.parametrize("n", [1, 1000, 10000, 4099])
+def test_sis_gaussian_matches_oracle_per_particle(engine, model, obs, n):
+    engine.begin(cp.ALG_SIS, model, obs, n, seed=2024)
+    engine.run()
+    vals, logw = O.sis(model, obs, n, 2024)
+    np.testing.assert_allclose(engine.values(), vals, rtol=FP_TOL, atol=FP_TOL)
+    np.testing.assert_allclose(engine.logw(), logw, rtol=FP_TOL, atol=FP_TOL)
+    ref = O.weighted_moments(vals[0], logw)
+    st = engine.stats()
+    np.testing.assert_allclose(st[0], ref[:2], rtol=1e-9, atol=1e-10)
+    s = engine.summary()
+    assert abs(s["log_norm"] - ref[2]) < 1e-10
+    assert abs(s["log_evidence"] - (ref[2] - np.log(n))) < 1e-10
+    assert abs(s["ess_final"] - ref[3]) < 1e-6 * max(1.0, ref[3])
+    assert s["n_predict"] == 1 and s["is_int"] == 0 and s["n_resampled"] == 0
+
+
+def test_sis_config1_plumbing_10000_particles(engine, golden_dir):
+    """BASELINE.json configs[0]: gaussian_unknown_mean, observes (3,4), 10^4 particles."""
+    with open(os.path.join(golden_dir, "posteriors.json")) as f:
+        post = json.load(f)["models_gaussian_obs_3_4"]
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, [3.0, 4.0], 10000, seed=1)
+    engine.run()
+    mean, var = engine.stats()[0]
+    # MCSE at N=10^4, ESS/N = 0.344: sd(mean) ~ sqrt(0.833/3440) = 0.016
+    assert abs(mean - post["mean"]) < 5 * 0.016
+    assert abs(var - post["variance"]) < 5 * 0.025
+
+
+def test_sis_gaussian_1e7_within_1e3_of_analytic(engine, golden_dir):
+    """BASELINE.json configs[1] / north_star: posterior mean/variance within 1e-3 at 10^7 particles.
+    MCSE(mean) = 3.4e-4, MCSE(var) = 4.3e-4; seed fixed."""
+    with open(os.path.join(golden_dir, "posteriors.json")) as f:
+        post = json.load(f)
+    n = 10_000_000
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, [3.0, 4.0], n, seed=12345)
+    engine.run()
+    mean, var = engine.stats()[0]
+    s = engine.summary()
+    p = post["models_gaussian_obs_3_4"]
+    assert abs(mean - p["mean"]) < 1e-3, mean
+    assert abs(var - p["variance"]) < 1e-3, var
+    assert abs(s["ess_final"] / n - 0.344) < 0.01
+    assert abs(s["log_evidence"] - p["log_evidence"]) < 1e-3
+    # README model, README.md:118
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_README, [3.0, 4.0], n, seed=12345)
+    engine.run()
+    mean, var = engine.stats()[0]
+    assert abs(mean - 2.32353) < 1e-3 and abs(var - 1.05882) < 1.5e-3
+    # thesis p.85: obs (8,9) -> N(7.25, 5/6); prior is far from the data, so ESS is lower
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, [8.0, 9.0], n, seed=12345)
+    engine.run()
+    mean, var = engine.stats()[0]
+    assert abs(mean - 7.25) < 5e-3 and abs(var - 5.0 / 6.0) < 5e-3
+
+
+@pytest.mark.parametrize("model,key,T", [(cp.MODEL_HMM3, "hmm16", 16), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 12)])
+def test_sis_state_space_matches_oracle(engine, golden_dir, model, key, T):
+    obs = _obs(golden_dir, key)[:T]
+    n = 20011
+    engine.begin(cp.ALG_SIS, model, obs, n, seed=7)
+    engine.run()
+    vals, logw = O.sis(model, obs, n, 7)
+    got = engine.values()
+    if model == cp.MODEL_HMM3:
+        assert np.array_equal(got, vals)                       # integer states: bit-exact
+    else:
+        np.testing.assert_allclose(got, vals, rtol=FP_TOL, atol=FP_TOL)
+    np.testing.assert_allclose(engine.logw(), logw, rtol=1e-10, atol=1e-10)
+    st = engine.stats()
+    if model == cp.MODEL_HMM3:
+        ref = np.array([O.weighted_hist(vals[t], logw, 3) for t in range(T)])
+    else:
+        ref = np.array([O.weighted_moments(vals[t], logw)[:2] for t in range(T)])
+    np.testing.assert_allclose(st, ref, rtol=1e-8, atol=1e-10)
+    # SIS: every trace is its own line
+    assert np.array_equal(engine.paths(), got) if model == cp.MODEL_HMM3 else np.allclose(engine.paths(), got)
+
+
+def _compare_smc(engine, model, obs, n, seed, resampler, ess):
+    engine.begin(cp.ALG_SMC, model, obs, n, seed=seed, resampler=resampler, ess_threshold=ess)
+    engine.run()
+    ref = O.smc(model, obs, n, seed, resampler, ess)
+    vals, anc, logw = engine.values(), engine.ancestors(), engine.logw()
+    gess, gres = engine.step_trace()
+    assert np.array_equal(gres, ref["resampled"])
+    np.testing.assert_allclose(gess, ref["ess"], rtol=1e-6)
+    T = len(obs)
+    # ancestors / states: identical except for (rare) CDF-boundary flips caused by the different
+    # summation order of the parallel scan; a flipped particle stays different afterwards.
+    frac_anc = np.mean(anc != ref["anc"])
+    assert frac_anc < 2e-4, frac_anc
+    if vals.dtype == np.int32:
+        assert np.mean(vals != ref["hist"]) < 1e-3
+    else:
+        assert np.mean(np.abs(vals - ref["hist"]) > 1e-9) < 1e-3
+    s = engine.summary()
+    assert abs(s["log_evidence"] - ref["log_z"]) < 1e-6
+    assert s["n_resampled"] == int(ref["resampled"].sum())
+    sm_ref = O.smoothing(ref["hist"], ref["anc"], ref["logw"])
+    np.testing.assert_allclose(engine.stats(), sm_ref, atol=2e-3)
+    # internal consistency, exact: device smoothing == oracle estimator applied to the DEVICE's own store
+    sm_self = O.smoothing(vals, anc, logw)
+    np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-9, atol=1e-11)
+    # paths == lineage read-out of the device store (index work: bit-exact)
+    path_idx = O.lineage(anc)
+    expect = np.take_along_axis(vals, path_idx, axis=1)
+    assert np.array_equal(engine.paths(), expect)
+    return ref
+
+
+@pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_STRATIFIED, cp.RESAMPLE_MULTINOMIAL])
+@pytest.mark.parametrize("ess", [2.0, 0.5])
+def test_smc_hmm_matches_oracle(engine, golden_dir, resampler, ess):
+    obs = _obs(golden_dir, "hmm16")
+    _compare_smc(engine, cp.MODEL_HMM3, obs, 30000, 11, resampler, ess)
+
+
+@pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_MULTINOMIAL])
+@pytest.mark.parametrize("ess", [2.0, 0.5])
+def test_smc_lgssm_matches_oracle(engine, golden_dir, resampler, ess):
+    obs = _obs(golden_dir, "lgssm100")[:25]
+    _compare_smc(engine, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, 20000, 5, resampler, ess)
+
+
+@pytest.mark.parametrize("n", [1, 2, 1023, 1025])
+def test_smc_tiny_and_ragged_populations(engine, golden_dir, n):
+    obs = _obs(golden_dir, "hmm16")[:5]
+    _compare_smc(engine, cp.MODEL_HMM3, obs, n, 3, cp.RESAMPLE_SYSTEMATIC, 2.0) if n > 2 else None
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=3)
+    engine.run()
+    st = engine.stats()
+    np.testing.assert_allclose(st.sum(axis=1), 1.0, rtol=1e-12)
+
+
+def test_smc_hmm16_config3_vs_forward_backward(engine, golden_dir):
+    """BASELINE.json configs[2]: hmm<16>, systematic resampling every step, 10^6 particles."""
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    n = 1_000_000
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, z["hmm16"], n, seed=12345, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=2.0)
+    engine.run()
+    st = engine.stats()
+    s = engine.summary()
+    assert s["n_resampled"] == 15
+    # filtering-quality at t = T-1, smoothing degrades towards t = 0 through path degeneracy
+    assert np.abs(st[-1] - z["hmm16_smooth"][-1]).max() < 3e-3
+    assert np.abs(st - z["hmm16_smooth"]).max() < 2e-2
+    assert abs(s["log_evidence"] - float(z["hmm16_logz"])) < 5e-3
+    np.testing.assert_allclose(st.sum(axis=1), 1.0, rtol=1e-12)
+    anc = engine.ancestors()
+    assert np.all(np.diff(anc[1:], axis=1) >= 0)      # systematic ancestors are sorted
+    assert np.array_equal(anc[0], np.arange(n))
+
+
+def test_smc_lgssm_vs_kalman(engine, golden_dir):
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    n = 1_000_000
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, z["lgssm100"], n, seed=12345, ess_threshold=0.5)
+    engine.run()
+    st = engine.stats()
+    s = engine.summary()
+    assert abs(st[-1, 0] - z["lgssm100_smooth_mean"][-1]) < 5e-3
+    assert abs(st[-1, 1] - z["lgssm100_smooth_var"][-1]) < 5e-3
+    assert abs(s["log_evidence"] - float(z["lgssm100_logz"])) < 2e-2
+    # last 10 steps are barely degenerate
+    assert np.abs(st[-10:, 0] - z["lgssm100_smooth_mean"][-10:]).max() < 3e-2
+
+
+def test_run_index_decorrelates_and_is_reproducible(engine, golden_dir):
+    obs = _obs(golden_dir, "hmm16")
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 50000, seed=1)
+    engine.run(0); a = engine.stats().copy()
+    engine.run(1); b = engine.stats().copy()
+    engine.run(0); c = engine.stats().copy()
+    assert np.array_equal(a, c)          # bitwise reproducible
+    assert not np.array_equal(a, b)
+
+
+def test_sharded_ids_reproduce_single_shard(engine):
+    """Particle ids are global: shard [off, off+n) of an SIS population equals that slice."""
+    obs = [3.0, 4.0]
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, obs, 10000, seed=5)
+    engine.run()
+    full = engine.values()[0].copy()
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, obs, 2500, seed=5, particle_offset=5000, n_global=10000)
+    engine.run()
+    assert np.array_equal(engine.values()[0], full[5000:7500])
+
+
+def test_error_paths(engine):
+    with pytest.raises(cp.CpprobHipError):
+        engine.begin(0, cp.MODEL_HMM3, [0.0], 10)                       # StateType::compile: unsupported
+    with pytest.raises(cp.CpprobHipError):
+        engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, [1.0, 2.0, 3.0], 10)
+    with pytest.raises(cp.CpprobHipError):
+        engine.begin(cp.ALG_SIS, 17, [1.0], 10)
+    with pytest.raises(cp.CpprobHipError):
+        engine.begin(cp.ALG_SIS, cp.MODEL_HMM3, [1.0], 0)
+    engine.begin(cp.ALG_SIS, cp.MODEL_HMM3, [1.0], 10)
+    with pytest.raises(cp.CpprobHipError):
+        engine.stats()                                                  # no finished run
+    engine.run()
+    with pytest.raises(cp.CpprobHipError):
+        engine.ancestors()                                              # SIS keeps none
