@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particles/sec of the SIS/SMC hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+For N > 1 it is launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, RCCL); run directly with --gpus N > 1 it starts that launcher itself as a child.
+
+A "step" is one complete inference run of the workload: BASELINE.json's metric is quoted on
+"HMM T=16 SMC" = configs[2]: 3-state HMM (reference include/models/models.hpp:114-141), T = 16
+observes, 10^6 particles per GPU, systematic resampling after every step, including the final
+posterior read-out (smoothing marginals).  Observes are the committed synthetic vector
+tests/golden/observations.npz (simulated from the model); particles are drawn on
+device, so inputs are resident in HBM when the timed region starts.
+
+value        = particles (complete T-step traces) per second over all GPUs
+roofline     = dominant kernel (smc_step): algorithmic bytes per launch (56 B per
+               particle-step for the HMM) / mean launch duration measured with HIP events on the
+               engine's own stream in a separate profiled pass of the same K steps
+cpu_baseline = the CPU oracle (oracle/cpprob_oracle.c, a port: the reference itself cannot be
+               built here) on one host core, compute-only, on a bounded sample
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES = {"hmm": 56, "lgssm": 72, "gaussian_sis": 32}  # SURVEY 8(d) per particle(-step)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
+    p.add_argument("--workload", default="hmm16_smc", choices=["hmm16_smc", "hmm128_smc_ess", "lgssm100_smc", "gaussian_sis"])
+    p.add_argument("--scope", default="auto", choices=["auto", "global", "island"])
+    p.add_argument("--seed", type=int, default=12345)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample", type=int, default=3_000_000, help="particles of the CPU-baseline sample")
+    p.add_argument("--no-extras", action="store_true", help="skip the secondary gaussian SIS measurement")
+    return p.parse_args()
+
+
+def relaunch_under_torchrun(args):
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def workload_spec(name, golden):
+    import numpy as np
+    import cpprob_amd as cp
+    z = np.load(golden)
+    if name == "hmm16_smc":
+        return dict(alg=cp.ALG_SMC, model=cp.MODEL_HMM3, obs=z["hmm16"], ess=2.0, bytes_key="hmm", exact=z["hmm16_smooth"],
+                    desc="3-state HMM (models.hpp:114-141) SMC, T=16, systematic resampling every step")
+    if name == "hmm128_smc_ess":
+        return dict(alg=cp.ALG_SMC, model=cp.MODEL_HMM3, obs=z["hmm128"], ess=0.5, bytes_key="hmm", exact=z["hmm128_smooth"],
+                    desc="3-state HMM SMC, T=128, resample when ESS < N/2")
+    if name == "lgssm100_smc":
+        return dict(alg=cp.ALG_SMC, model=cp.MODEL_LINEAR_GAUSSIAN_1D, obs=z["lgssm100"], ess=0.5, bytes_key="lgssm",
+                    exact=np.stack([z["lgssm100_smooth_mean"], z["lgssm100_smooth_var"]], 1),
+                    desc="linear_gaussian_1d<100> (models.hpp:67-80) SMC, resample when ESS < N/2")
+    return dict(alg=cp.ALG_SIS, model=cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, obs=np.array([3.0, 4.0]), ess=2.0, bytes_key="gaussian_sis",
+                exact=np.array([[3.0833333333333335, 0.8333333333333334]]), desc="gaussian_unknown_mean (models.hpp:22-35) SIS, observes (3,4)")
+
+
+def timed_runs(eng, steps, warmup, world, device, island, first_index=0):
+    """W untimed + exactly K timed runs bracketed by barrier + synchronize; returns max-over-ranks seconds."""
+    import torch
+    import torch.distributed as dist
+    from cpprob_amd import distributed as D
+
+    def one(i):
+        if island and world > 1:
+            return D.run_islands(eng, i, device)
+        eng.run(i)
+        return None
+
+    for i in range(warmup):
+        one(first_index + i)
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = one(first_index + warmup + i)
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, last
+
+
+def cpu_baseline(spec, n_sample, seed):
+    """The oracle timed on one host core, compute-only (mode B of BASELINE.md), bounded sample."""
+    import numpy as np
+    from oracle import oracle as O
+    O.lib()
+    t0 = time.perf_counter()
+    import cpprob_amd as cp
+    if spec["alg"] == cp.ALG_SIS:
+        vals, lw = O.sis(spec["model"], spec["obs"], n_sample, seed)
+        O.weighted_moments(vals[0], lw)
+    else:
+        r = O.smc(spec["model"], spec["obs"], n_sample, seed, O.RESAMPLE_SYSTEMATIC, spec["ess"])
+        O.smoothing(r["hist"], r["anc"], r["logw"])
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "particles/s", "cores": 1, "kind": "port",
+            "sample": "%d particles of the same workload (all T steps + read-out), oracle/cpprob_oracle.c -O2, in-memory (no file dumps), %.1f s"
+                      % (n_sample, dt), "host_cores_available": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env == 1:
+        sys.exit(relaunch_under_torchrun(args))   # child process; nothing has touched the GPU yet
+
+    import numpy as np
+    import torch
+    import cpprob_amd as cp
+    from cpprob_amd import distributed as D
+
+    world, rank, local = D.init_process_group(device_is_gpu=True)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    eng = cp.Engine(local)
+
+    spec = workload_spec(args.workload, os.path.join(ROOT, "tests", "golden", "observations.npz"))
+    n = args.particles
+    T = 1 if args.workload == "gaussian_sis" else len(spec["obs"])
+    scope = args.scope
+    if scope == "auto":
+        scope = "global" if world == 1 or spec["alg"] == cp.ALG_SIS else "island"
+    island = scope == "island"
+    if world > 1 and not island and spec["alg"] == cp.ALG_SMC:
+        raise SystemExit("joint (global-scope) resampling across ranks is driven by cpprob_amd.distributed; use --scope island")
+    eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
+              particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND if island else cp.SCOPE_GLOBAL)
+
+    dt, last = timed_runs(eng, args.steps, args.warmup, world, device, island)
+    n_global = world * n
+    value = n_global * args.steps / dt
+
+    # posterior of the last timed run against the exact answer (validity of what was timed)
+    if last is not None:
+        stats = last[0]
+    else:
+        stats = eng.stats()
+    err = float(np.abs(stats - spec["exact"]).max())
+    summ = eng.summary()
+
+    # profiled pass: same K steps with HIP events around every launch on the engine's stream
+    eng.profile_enable(True)
+    eng.profile_read(reset=True)
+    for i in range(args.steps):
+        eng.run(10_000 + i)
+    prof = eng.profile_read(reset=True)
+    eng.profile_enable(False)
+    dom = "sis" if spec["alg"] == cp.ALG_SIS else "smc_step"
+    dom_ms, dom_calls = prof[dom]
+    avg_s = dom_ms * 1e-3 / max(dom_calls, 1)
+    bytes_per_unit = ALGO_BYTES[spec["bytes_key"]]
+    if spec["alg"] == cp.ALG_SIS:
+        bytes_per_unit = 16  # the sis kernel's own share of the 32 B: it writes value + logw; the read-out pass reads them back
+    achieved = bytes_per_unit * n / avg_s / 1e9 if avg_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_unit": bytes_per_unit, "units_per_launch": n, "avg_launch_us": avg_s * 1e6,
+                "launches": int(dom_calls),
+                "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]}}
+
+    out = {
+        "metric": "particles/sec (whole node) + achieved HBM GB/s, HMM T=16 SMC" if args.workload == "hmm16_smc" else "particles/sec (whole node), " + args.workload,
+        "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s, %d particles per GPU" % (spec["desc"], n), "particles_per_gpu": n, "T": T,
+                   "resampler": "systematic", "ess_threshold": spec["ess"], "scope": scope, "n_global": n_global},
+        "particle_steps_per_sec": value * T,
+        "roofline": roofline,
+        "posterior_max_abs_err_vs_exact": err, "log_evidence": summ["log_evidence"], "n_resampled": summ["n_resampled"],
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "hmm16_smc":
+        # secondary: BASELINE.json configs[1], gaussian_unknown_mean SIS at 10^7 particles
+        g = workload_spec("gaussian_sis", os.path.join(ROOT, "tests", "golden", "observations.npz"))
+        ng = 10_000_000
+        eng.begin(g["alg"], g["model"], g["obs"], ng, seed=args.seed)
+        gdt, _ = timed_runs(eng, args.steps, args.warmup, 1, device, False)
+        gst = eng.stats()
+        eng.profile_enable(True); eng.profile_read(reset=True)
+        for i in range(args.steps):
+            eng.run(20_000 + i)
+        gp = eng.profile_read(reset=True)
+        eng.profile_enable(False)
+        sis_s = gp["sis"][0] * 1e-3 / max(gp["sis"][1], 1)
+        sm_s = gp["smooth"][0] * 1e-3 / max(gp["smooth"][1], 1)
+        out["gaussian_sis_1e7"] = {"particles_per_sec": ng * args.steps / gdt, "ms_per_run": gdt / args.steps * 1e3,
+                                   "posterior_mean_var": gst[0].tolist(), "analytic_mean_var": g["exact"][0].tolist(),
+                                   "sis_kernel_us": sis_s * 1e6, "sis_kernel_GBs": 16 * ng / sis_s / 1e9 if sis_s else None,
+                                   "readout_kernel_us": sm_s * 1e6, "readout_kernel_GBs": 16 * ng / sm_s / 1e9 if sm_s else None,
+                                   "end_to_end_GBs_at_32B": 32 * ng * args.steps / gdt / 1e9}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(spec, args.cpu_sample, args.seed)
+        out["gpu_over_cpu_1core"] = value / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

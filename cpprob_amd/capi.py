@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcpprob_hip.so")
 ALG_SIS, ALG_SMC = 2, 4
 MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README, MODEL_LINEAR_GAUSSIAN_1D, MODEL_HMM3 = 0, 1, 2, 3
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
+SCOPE_GLOBAL, SCOPE_ISLAND = 0, 1
 N_KERNEL_CLASSES = 6
 KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", "resample"]
 
@@ -32,7 +33,8 @@ class CpprobHipError(RuntimeError):
 
 
 class Config(C.Structure):
-    _fields_ = [("algorithm", C.c_int32), ("model", C.c_int32), ("resampler", C.c_int32), ("keep_history", C.c_int32),
+    _fields_ = [("algorithm", C.c_int32), ("model", C.c_int32), ("resampler", C.c_int32), ("resample_scope", C.c_int32),
+                ("keep_history", C.c_int32), ("reserved", C.c_int32),
                 ("ess_threshold", C.c_double), ("seed", C.c_uint64), ("n_particles", C.c_uint64),
                 ("particle_offset", C.c_uint64), ("n_global", C.c_uint64)]
 
@@ -157,9 +159,9 @@ class Engine:
 
     # ---- cpprob::inference --------------------------------------------------------------
     def begin(self, algorithm, model, observes, n_particles, seed=12345, resampler=RESAMPLE_SYSTEMATIC, ess_threshold=2.0,
-              particle_offset=0, n_global=None):
+              particle_offset=0, n_global=None, scope=SCOPE_GLOBAL):
         obs = np.ascontiguousarray(observes, np.float64)
-        cfg = Config(algorithm, model, resampler, 1, float(ess_threshold), int(seed), int(n_particles), int(particle_offset),
+        cfg = Config(algorithm, model, resampler, scope, 1, 0, float(ess_threshold), int(seed), int(n_particles), int(particle_offset),
                      int(n_particles if n_global is None else n_global))
         self._chk(self.L.cpprob_hip_infer_begin(self.h, C.byref(cfg), obs.ctypes.data_as(C.POINTER(C.c_double)), len(obs)))
         self.cfg = cfg

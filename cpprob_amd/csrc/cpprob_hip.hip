@@ -39,10 +39,15 @@ struct cpprob_hip_ctx {
     int smooth_grid = 0;
     ModelParams mp{};
     uint64_t run_seed = 0;
+    uint64_t pop_n = 0;     // size of the population this shard is resampled with (n_global, or n for islands)
+    uint64_t pos0 = 0;      // index of local slot 0 inside that population
 
     // device buffers
     double* d_obs = nullptr;
     double* d_logw[2] = {nullptr, nullptr};
+    double* d_wrel[2] = {nullptr, nullptr};
+    double* d_bf = nullptr;
+    double* d_ll_tab = nullptr;     // hmm: [T][3] emission log-densities
     void* d_values = nullptr;
     int32_t* d_anc = nullptr;
     void* d_paths = nullptr;
@@ -60,7 +65,8 @@ struct cpprob_hip_ctx {
     size_t cap_particles = 0; int cap_T = 0; bool cap_int = false; bool cap_multinomial = false;
 
     // scratch for building blocks
-    Partial* d_bb_part = nullptr; double* d_bb_bc = nullptr; StepCtrl* d_bb_ctrl = nullptr; size_t bb_cap_nb = 0;
+    Partial* d_bb_part = nullptr; double* d_bb_bc = nullptr; double* d_bb_bf = nullptr; double* d_bb_wrel = nullptr; void* d_bb_col = nullptr;
+    StepCtrl* d_bb_ctrl = nullptr; size_t bb_cap_nb = 0;
     double* d_bb_stats_part = nullptr; double* d_bb_stats = nullptr; double* d_bb_cdf = nullptr; size_t bb_cdf_cap = 0;
 
     // optional per-kernel-class timing
@@ -128,7 +134,7 @@ void host_model_params(ModelParams& mp, int model)
         double tot = 0.0;
         for (int j = 0; j < 3; ++j) tot += T[s][j];
         double acc = 0.0;
-        for (int j = 0; j < 2; ++j) { acc += T[s][j]; mp.hmm_thr[s][j] = acc / tot; }
+        for (int j = 0; j < 2; ++j) { acc += T[s][j]; mp.hmm_thr[s][j] = (uint64_t)std::ceil((acc / tot) * 4294967296.0); }   // u >= c  <=>  word >= ceil(c * 2^32)
     }
 }
 
@@ -141,10 +147,13 @@ int ensure_bb(cpprob_hip_ctx* ctx, size_t n)
 {
     const size_t nb = (n + kTile - 1) / kTile;
     if (nb > ctx->bb_cap_nb || !ctx->d_bb_ctrl) {
-        dfree(ctx->d_bb_part); dfree(ctx->d_bb_bc); dfree(ctx->d_bb_stats_part);
+        dfree(ctx->d_bb_part); dfree(ctx->d_bb_bc); dfree(ctx->d_bb_bf); dfree(ctx->d_bb_wrel); dfree(ctx->d_bb_col); dfree(ctx->d_bb_stats_part);
         const size_t cap = std::max<size_t>(nb, 1024);
         HIP_TRY(ctx, hipMalloc(&ctx->d_bb_part, cap * sizeof(Partial)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_bb_bc, (cap + 1) * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_bf, cap * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_wrel, cap * kTile * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_col, cap * kTile * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_bb_stats_part, 2048 * 8 * sizeof(double)));
         if (!ctx->d_bb_ctrl) HIP_TRY(ctx, hipMalloc(&ctx->d_bb_ctrl, sizeof(StepCtrl)));
         if (!ctx->d_bb_stats) HIP_TRY(ctx, hipMalloc(&ctx->d_bb_stats, 16 * sizeof(double)));
@@ -153,15 +162,15 @@ int ensure_bb(cpprob_hip_ctx* ctx, size_t n)
     return 0;
 }
 
-// partials + scan of an arbitrary logw array into the building-block scratch
+// partials + linear weights + scan of an arbitrary logw array into the building-block scratch
 int bb_normalise(cpprob_hip_ctx* ctx, const double* d_logw, size_t n, double n_total)
 {
     if (int rc = ensure_bb(ctx, n)) return rc;
     const int nb = (int)((n + kTile - 1) / kTile);
-    hipLaunchKernelGGL(weights_partials_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, d_logw, (int64_t)n, ctx->d_bb_part);
+    hipLaunchKernelGGL(weights_partials_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, d_logw, (int64_t)n, ctx->d_bb_part, ctx->d_bb_wrel);
     ScanArgs sa{};
-    sa.part = ctx->d_bb_part; sa.nb = nb; sa.bc = ctx->d_bb_bc; sa.ctrl = ctx->d_bb_ctrl; sa.t = 0; sa.T = 1;
-    sa.n_global = n_total; sa.ess_frac = 0.0; sa.force_no_resample = 1; sa.phase = 0;
+    sa.part = ctx->d_bb_part; sa.nb = nb; sa.bc = ctx->d_bb_bc; sa.bf = ctx->d_bb_bf; sa.ctrl = ctx->d_bb_ctrl; sa.t = 0; sa.T = 1;
+    sa.n_pop = n_total; sa.ess_frac = 0.0; sa.force_no_resample = 1; sa.phase = 0; sa.seed = 0;
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, sa);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -172,7 +181,7 @@ void launch_sis(cpprob_hip_ctx* c)
 {
     SisArgs<Model> a{};
     a.mp = c->mp; a.obs = c->d_obs; a.T = c->T; a.n = c->n; a.ld = c->ld; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
-    a.values = static_cast<typename Model::value_t*>(c->d_values); a.logw = c->d_logw[0]; a.part = c->d_part;
+    a.values = static_cast<typename Model::value_t*>(c->d_values); a.logw = c->d_logw[0]; a.wrel = c->d_wrel[0]; a.part = c->d_part;
     ProfScope ps(c, 4);
     hipLaunchKernelGGL(sis_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
 }
@@ -182,17 +191,18 @@ void launch_step(cpprob_hip_ctx* c, int t)
 {
     StepArgs<Model> a{};
     a.mp = c->mp; a.obs = c->d_obs; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.seed = c->run_seed;
-    a.pid0 = c->cfg.particle_offset; a.n_global = c->cfg.n_global;
+    a.pid0 = c->cfg.particle_offset; a.n_pop = c->pop_n; a.pos0 = c->pos0;
     a.values = static_cast<typename Model::value_t*>(c->d_values); a.anc = c->d_anc;
     a.logw_prev = c->d_logw[c->cur]; a.logw_next = c->d_logw[c->cur ^ 1];
-    a.part = c->d_part; a.bc = c->d_bc; a.nb = c->nb; a.ctrl = c->d_ctrl; a.anc_pre = c->d_anc_pre;
+    a.wrel_prev = c->d_wrel[c->cur]; a.wrel_next = c->d_wrel[c->cur ^ 1];
+    a.part = c->d_part; a.bc = c->d_bc; a.bf = c->d_bf; a.nb = c->nb; a.ctrl = c->d_ctrl; a.anc_pre = c->d_anc_pre;
     if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && t > 0) {
         // literal thesis Alg. 1: materialise the CDF, draw N independent positions.  Runs
         // unconditionally; the step kernel ignores the result when ctrl says "no resampling".
         ProfScope ps(c, 5);
-        hipLaunchKernelGGL(cdf_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, c->d_logw[c->cur], c->n, c->d_bc, c->d_ctrl, c->d_cdf);
+        hipLaunchKernelGGL(cdf_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, c->d_wrel[c->cur], c->d_bc, c->d_bf, c->d_ctrl, c->d_cdf);
         hipLaunchKernelGGL(multinomial_kernel, dim3((unsigned)((c->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, c->d_cdf, c->n,
-                           c->d_ctrl, c->run_seed, (uint64_t)t, c->cfg.particle_offset, c->n, c->d_anc_pre);
+                           c->d_ctrl, c->run_seed, (uint64_t)t, c->pos0, c->n, c->d_anc_pre);
     }
     ProfScope ps(c, 0);
     switch (c->cfg.resampler) {
@@ -209,8 +219,8 @@ void launch_step(cpprob_hip_ctx* c, int t)
 void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, int world, int rank)
 {
     ScanArgs sa{};
-    sa.part = c->d_part; sa.nb = c->nb; sa.bc = c->d_bc; sa.ctrl = c->d_ctrl; sa.t = t; sa.T = c->T;
-    sa.n_global = (double)c->cfg.n_global; sa.ess_frac = c->cfg.ess_threshold;
+    sa.part = c->d_part; sa.nb = c->nb; sa.bc = c->d_bc; sa.bf = c->d_bf; sa.ctrl = c->d_ctrl; sa.t = t; sa.T = c->T;
+    sa.n_pop = (double)c->pop_n; sa.ess_frac = c->cfg.ess_threshold; sa.seed = c->run_seed;
     sa.ess_trace = c->d_ess; sa.resampled = c->d_resampled;
     sa.force_no_resample = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
     sa.all_totals = all_totals; sa.world = world; sa.rank = rank; sa.local_totals = c->d_local_totals; sa.phase = phase;
@@ -222,7 +232,7 @@ template <class Model>
 void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
 {
     SmoothArgs<Model> a{};
-    a.values = static_cast<const typename Model::value_t*>(c->d_values); a.anc = c->d_anc; a.logw = c->d_logw[c->cur]; a.ctrl = c->d_ctrl;
+    a.values = static_cast<const typename Model::value_t*>(c->d_values); a.anc = c->d_anc; a.wrel = c->d_wrel[c->cur]; a.bf = c->d_bf; a.ctrl = c->d_ctrl;
     a.resampled = c->d_resampled; a.T = c->T; a.n = c->n; a.ld = c->ld;
     a.identity = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
     a.stats_part = c->d_stats_part;
@@ -233,8 +243,8 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
         hipLaunchKernelGGL(smooth_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a);
     }
     ProfScope ps(c, 3);
-    hipLaunchKernelGGL(finalize_kernel, dim3(std::max(1, std::min(64, (c->T * Model::kStats + kThreads - 1) / kThreads))), dim3(kThreads), 0, c->stream,
-                       c->d_stats_part, c->smooth_grid, c->T, Model::kStats, Model::kIsInt ? 1 : 0, c->d_ctrl, c->d_stats);
+    hipLaunchKernelGGL(finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream,
+                       c->d_stats_part, c->smooth_grid, c->T, Model::kStats, Model::kIsInt ? 1 : 0, c->d_ctrl, c->d_stats, 1);
 }
 
 template <class F>
@@ -251,7 +261,7 @@ int dispatch_model(cpprob_hip_ctx* c, F&& f)
 
 void free_run_buffers(cpprob_hip_ctx* c)
 {
-    dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
+    dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
     dfree(c->d_cdf); dfree(c->d_anc_pre);
     c->cap_particles = 0; c->cap_T = 0;
@@ -301,7 +311,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
     dfree(c->d_ctrl); dfree(c->d_local_totals);
-    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf);
+    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -337,14 +347,19 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
 
+    if (cfg->resample_scope != CPPROB_HIP_SCOPE_GLOBAL && cfg->resample_scope != CPPROB_HIP_SCOPE_ISLAND)
+        return fail(c, CPPROB_HIP_EINVAL, "unknown resample_scope");
     c->cfg = *cfg;
+    const bool island = cfg->resample_scope == CPPROB_HIP_SCOPE_ISLAND;
+    c->pop_n = island ? cfg->n_particles : cfg->n_global;
+    c->pos0 = island ? 0 : cfg->particle_offset;
     c->T = model_T(cfg->model, n_obs);
     c->n_obs = (int)n_obs;
     c->is_int = cfg->model == CPPROB_HIP_MODEL_HMM3;
     c->K = c->is_int ? 3 : 2;
     c->n = (int64_t)cfg->n_particles;
-    c->ld = (c->n + 3) & ~(int64_t)3;
     c->nb = (int)((c->n + kTile - 1) / kTile);
+    c->ld = (int64_t)c->nb * kTile;                 // padded to the tile: no ragged tails in any kernel
     c->smooth_grid = std::min(c->nb, 2048);
     host_model_params(c->mp, cfg->model);
     const bool smc = cfg->algorithm == CPPROB_HIP_ALG_SMC;
@@ -357,7 +372,11 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
         HIP_TRY(c, hipMalloc(&c->d_logw[0], ld * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_logw[1], ld * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_wrel[0], ld * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_wrel[1], ld * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_bf, (size_t)c->nb * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_values, T * ld * vsz));
+        HIP_TRY(c, hipMemsetAsync(c->d_values, 0, T * ld * vsz, c->stream));
         HIP_TRY(c, hipMalloc(&c->d_anc, T * ld * sizeof(int32_t)));
         HIP_TRY(c, hipMalloc(&c->d_part, (size_t)c->nb * sizeof(Partial)));
         HIP_TRY(c, hipMalloc(&c->d_bc, ((size_t)c->nb + 1) * sizeof(double)));
@@ -375,6 +394,18 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     HIP_TRY(c, hipMalloc(&c->d_obs, n_obs * sizeof(double)));
     HIP_TRY(c, hipMemcpyAsync(c->d_obs, h_obs, n_obs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_resampled, 0, (size_t)c->T * sizeof(int32_t), c->stream));
+    dfree(c->d_ll_tab);
+    c->mp.ll_tab = nullptr;
+    if (cfg->model == CPPROB_HIP_MODEL_HMM3) {
+        // log N(y_t; state_mean[s], 1): three values per step, computed once with the same functor
+        // the reference applies per particle (utils_normal_distribution.hpp:20-45)
+        std::vector<double> tab((size_t)c->T * 3);
+        for (int t = 0; t < c->T; ++t)
+            for (int s2 = 0; s2 < 3; ++s2) tab[(size_t)t * 3 + s2] = normal_logpdf(h_obs[t], c->mp.hmm_mean[s2], 1.0);
+        HIP_TRY(c, hipMalloc(&c->d_ll_tab, tab.size() * sizeof(double)));
+        HIP_TRY(c, hipMemcpy(c->d_ll_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->mp.ll_tab = c->d_ll_tab;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->begun = true; c->ran = false;
     return 0;
@@ -658,14 +689,19 @@ int cpprob_hip_logsumexp_ess(cpprob_hip_ctx* c, const double* d_logw, size_t n, 
 template <class Col>
 static int column_stats(cpprob_hip_ctx* c, const typename Col::value_t* d_x, const double* d_logw, size_t n, double* h_raw, double* h_lse_ess)
 {
+    using V = typename Col::value_t;
     if (int rc = bb_normalise(c, d_logw, n, (double)n)) return rc;
+    const int nb = (int)((n + kTile - 1) / kTile);
+    const int64_t ld = (int64_t)nb * kTile;
+    V* col = static_cast<V*>(c->d_bb_col);
+    hipLaunchKernelGGL(pad_copy_kernel<V>, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, c->stream, d_x, (int64_t)n, ld, col);
     SmoothArgs<Col> a{};
-    a.values = d_x; a.anc = nullptr; a.logw = d_logw; a.ctrl = c->d_bb_ctrl; a.resampled = nullptr; a.T = 1; a.n = (int64_t)n; a.ld = (int64_t)n;
+    a.values = col; a.anc = nullptr; a.wrel = c->d_bb_wrel; a.bf = c->d_bb_bf; a.ctrl = c->d_bb_ctrl; a.resampled = nullptr; a.T = 1; a.n = (int64_t)n; a.ld = ld;
     a.identity = 1; a.stats_part = c->d_bb_stats_part; a.paths = nullptr;
-    const int grid = (int)std::min<size_t>((n + kTile - 1) / kTile, 2048);
+    const int grid = std::min(nb, 2048);
     hipLaunchKernelGGL(smooth_kernel<Col>, dim3(grid), dim3(kThreads), (size_t)kWaves * Col::kStats * sizeof(double), c->stream, a);
     // is_int = 1 -> plain normalised sums
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, c->stream, c->d_bb_stats_part, grid, 1, Col::kStats, 1, c->d_bb_ctrl, c->d_bb_stats);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, c->stream, c->d_bb_stats_part, grid, 1, Col::kStats, 1, c->d_bb_ctrl, c->d_bb_stats, 1);
     HIP_TRY(c, hipGetLastError());
     StepCtrl h{};
     HIP_TRY(c, hipMemcpyAsync(&h, c->d_bb_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -713,12 +749,12 @@ int cpprob_hip_resample(cpprob_hip_ctx* c, int32_t kind, const double* d_logw, s
     if (int rc = bb_normalise(c, d_logw, n_in, (double)n_in)) return rc;
     const int nb_in = (int)((n_in + kTile - 1) / kTile);
     if (kind == CPPROB_HIP_RESAMPLE_MULTINOMIAL) {
-        if (n_in > c->bb_cdf_cap) { dfree(c->d_bb_cdf); HIP_TRY(c, hipMalloc(&c->d_bb_cdf, n_in * sizeof(double))); c->bb_cdf_cap = n_in; }
-        hipLaunchKernelGGL(cdf_kernel, dim3(nb_in), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n_in, c->d_bb_bc, c->d_bb_ctrl, c->d_bb_cdf);
+        if ((size_t)nb_in * kTile > c->bb_cdf_cap) { dfree(c->d_bb_cdf); HIP_TRY(c, hipMalloc(&c->d_bb_cdf, (size_t)nb_in * kTile * sizeof(double))); c->bb_cdf_cap = (size_t)nb_in * kTile; }
+        hipLaunchKernelGGL(cdf_kernel, dim3(nb_in), dim3(kThreads), 0, c->stream, c->d_bb_wrel, c->d_bb_bc, c->d_bb_bf, c->d_bb_ctrl, c->d_bb_cdf);
         hipLaunchKernelGGL(multinomial_kernel, GRID1(n_out), c->d_bb_cdf, (int64_t)n_in, c->d_bb_ctrl, seed, step, j0, (int64_t)n_out, d_anc);
     } else if (kind == CPPROB_HIP_RESAMPLE_SYSTEMATIC || kind == CPPROB_HIP_RESAMPLE_STRATIFIED) {
         ResampleArgs a{};
-        a.logw = d_logw; a.n_in = (int64_t)n_in; a.bc = c->d_bb_bc; a.nb = nb_in; a.ctrl = c->d_bb_ctrl; a.seed = seed; a.step = step; a.j0 = j0;
+        a.wrel = c->d_bb_wrel; a.n_in = (int64_t)n_in; a.bc = c->d_bb_bc; a.bf = c->d_bb_bf; a.nb = nb_in; a.ctrl = c->d_bb_ctrl; a.seed = seed; a.step = step; a.j0 = j0;
         a.n_total_out = n_total_out; a.n_out = (int64_t)n_out; a.anc = d_anc;
         const int nb_out = (int)((n_out + kTile - 1) / kTile);
         ProfScope ps(c, 5);

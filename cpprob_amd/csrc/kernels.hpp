@@ -5,14 +5,19 @@
 //                      row t-1 doubles as the state the step-t kernel reads (no separate state)
 //   anc      [T][ld]   int32 slot of generation t-1 extended by slot i of generation t
 //   logw     [2][ld]   fp64 log-weights, ping-pong between steps
-//   part     [nb]      per-tile {max, sum exp(lw-max), sum exp(2(lw-max))} written by the kernel
-//                      that produced the weights (no separate normalisation pass over logw)
+//   wrel     [2][ld]   fp64 exp(logw - tile max): the linear weights the resampler scans, written
+//                      by the kernel that produced the weights (it has them in registers for the
+//                      tile partial anyway), so no exp() is ever recomputed downstream
+//   part     [nb]      per-tile {max, sum exp(lw-max), sum exp(2(lw-max))} from the same kernel
 //   bc       [nb+1]    exclusive prefix of the tile sums rescaled to the global max: the
-//                      resampling CDF at tile granularity
-//   ctrl               device-resident control block: max, W, Q, ESS, log Z, resample decision
-// ld = N rounded up to 4 so that every lane's 4 consecutive particles are one aligned 32-B
-// (fp64) or 16-B (int32) access.  One particle per lane-slot, structure of arrays, every access
-// of a step coalesced; the only gather (ancestor state) reads sorted indices.
+//   bf       [nb]      resampling CDF at tile granularity, and the per-tile rescale factors
+//   ctrl               device-resident control block: max, W, Q, ESS, log Z, resample decision,
+//                      the systematic offset u0 of the next resampling step
+// ld = N rounded up to the tile (1024): every lane's 4 consecutive particles are one aligned
+// 32-B (fp64) or 16-B (int32) access and no kernel has a ragged tail; padding slots carry
+// logw = -inf / wrel = 0, so they never become ancestors and add nothing to any sum.
+// One particle per lane-slot, structure of arrays, every access of a step coalesced; the only
+// gather (ancestor state) reads sorted indices.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -36,7 +41,9 @@ struct StepCtrl {
     double log_z;     // accumulated log evidence
     double cdf_lo;    // sharded runs: global CDF offset of this shard (0 on one GPU)
     double w_local;   // this shard's sum rescaled to M
-    double scale;     // exp(M_local - M): factor that rescales bc[] to the global max
+    double scale;     // exp(M_local - M): rescales bc[] / bf[] (built against the local max) to M
+    double u0;        // systematic offset in [0,1) of the resampling that precedes the NEXT step
+    double inv_stepw; // N_population / W: positions -> output indices
     int32_t do_resample;  // decision taken after the last weighted step
     int32_t n_resampled;
     int32_t pad[2];
@@ -45,98 +52,86 @@ struct StepCtrl {
 enum { RS_SYSTEMATIC = 0, RS_STRATIFIED = 1, RS_PRECOMPUTED = 2 };
 
 // ---------------------------------------------------------------------------------------------
-// 4-wide accesses
+// 4-wide accesses (arrays are padded to the tile: no tails)
 // ---------------------------------------------------------------------------------------------
 template <class T> struct Vec4;
 template <> struct Vec4<double> { using type = double __attribute__((ext_vector_type(4))); };
 template <> struct Vec4<int32_t> { using type = int __attribute__((ext_vector_type(4))); };
 
 template <class T>
-__device__ __forceinline__ void load4(const T* __restrict__ p, int64_t i, int64_t n, T (&v)[kPPT], T fill)
+__device__ __forceinline__ void load4(const T* __restrict__ p, int64_t i, T (&v)[kPPT])
 {
-    if (i + kPPT <= n) {
-        const typename Vec4<T>::type x = *reinterpret_cast<const typename Vec4<T>::type*>(p + i);
-        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
-    } else {
-#pragma unroll
-        for (int k = 0; k < kPPT; ++k) v[k] = (i + k < n) ? p[i + k] : fill;
-    }
+    const typename Vec4<T>::type x = *reinterpret_cast<const typename Vec4<T>::type*>(p + i);
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
 }
 
 template <class T>
-__device__ __forceinline__ void store4(T* __restrict__ p, int64_t i, int64_t n, const T (&v)[kPPT])
+__device__ __forceinline__ void store4(T* __restrict__ p, int64_t i, const T (&v)[kPPT])
 {
-    if (i + kPPT <= n) {
-        typename Vec4<T>::type x;
-        x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
-        *reinterpret_cast<typename Vec4<T>::type*>(p + i) = x;
-    } else {
-#pragma unroll
-        for (int k = 0; k < kPPT; ++k)
-            if (i + k < n) p[i + k] = v[k];
-    }
+    typename Vec4<T>::type x;
+    x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+    *reinterpret_cast<typename Vec4<T>::type*>(p + i) = x;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tile partial of the weights this workgroup just produced: {max, sum e, sum e^2}
+// Tile partial of the weights this workgroup just produced: {max, sum e, sum e^2}; the linear
+// weights e = exp(lw - max) are returned for the wrel store.  lw of padding slots must be -inf.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void write_partial(const double (&lw)[kPPT], const bool (&valid)[kPPT], Partial* __restrict__ part,
-                                              double* s_scr)
+__device__ __forceinline__ void tile_partial(const double (&lw)[kPPT], double (&e)[kPPT], Partial* __restrict__ part,
+                                             double* s_scr /* >= 3*kWaves doubles, unused by any in-flight combine */)
 {
-    double m = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k)
-        if (valid[k]) m = fmax(m, lw[k]);
+    double m = fmax(fmax(lw[0], lw[1]), fmax(lw[2], lw[3]));
     m = block_max(m, s_scr);
     double s = 0.0, q = 0.0;
-    if (m != -INFINITY) {
 #pragma unroll
-        for (int k = 0; k < kPPT; ++k)
-            if (valid[k]) { const double e = exp(lw[k] - m); s += e; q += e * e; }
+    for (int k = 0; k < kPPT; ++k) {
+        e[k] = (lw[k] == -INFINITY) ? 0.0 : exp(lw[k] - m);   // also covers m == -inf (empty tile)
+        s += e[k]; q += e[k] * e[k];
     }
-    s = block_sum(s, s_scr);
-    q = block_sum(q, s_scr);
+    block_sum2(s, q, s_scr + kWaves);
     if (threadIdx.x == 0) { Partial p; p.m = m; p.s = s; p.q = q; p.pad = 0.0; part[blockIdx.x] = p; }
 }
 
-// Standalone: partials of an arbitrary log-weight array (building block / tests).
-__global__ __launch_bounds__(kThreads) void weights_partials_kernel(const double* __restrict__ logw, int64_t n, Partial* __restrict__ part)
+// Standalone: partials + linear weights of an arbitrary log-weight array of n entries
+// (building block / tests).  wrel has room for gridDim.x * kTile entries.
+__global__ __launch_bounds__(kThreads) void weights_partials_kernel(const double* __restrict__ logw, int64_t n, Partial* __restrict__ part,
+                                                                     double* __restrict__ wrel)
 {
-    __shared__ double s_scr[16];
+    __shared__ double s_scr[3 * kWaves];
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
-    double lw[kPPT]; bool valid[kPPT];
-    load4(logw, j0, n, lw, (double)-INFINITY);
+    double lw[kPPT], e[kPPT];
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < n;
-    write_partial(lw, valid, part, s_scr);
+    for (int k = 0; k < kPPT; ++k) lw[k] = (j0 + k < n) ? logw[j0 + k] : -INFINITY;
+    tile_partial(lw, e, part, s_scr);
+    store4(wrel, j0, e);
 }
 
 // ---------------------------------------------------------------------------------------------
 // scan_partials: one workgroup of 1024 threads turns the tile partials of the generation
-// just weighted into: global max M, normaliser W, ESS, the tile-level CDF bc[], the evidence
-// increment and the resampling decision (ESS < ess_frac * N; thesis p.37).  Launched once per
-// step; everything stays on the device, so the host never waits inside a run.
+// just weighted into: global max M, normaliser W, ESS, the tile-level CDF bc[] and rescale
+// factors bf[], the evidence increment, the resampling decision (ESS < ess_frac * N; thesis
+// p.37) and the systematic offset of the resampling that may follow.  Launched once per step;
+// everything stays on the device, so the host never waits inside a run.
 // ---------------------------------------------------------------------------------------------
 constexpr int kScanThreads = 1024;
 
 struct ScanArgs {
     const Partial* part; int nb;
-    double* bc; StepCtrl* ctrl;
+    double* bc; double* bf; StepCtrl* ctrl;
     int t, T;
-    double n_global, ess_frac;
+    double n_pop, ess_frac;    // population the shard is resampled with
+    uint64_t seed;
     double* ess_trace; int32_t* resampled;
     int force_no_resample;     // SIS: never resample
-    // sharded: when all_totals != nullptr the global (M, W, Q) come from the all-gathered
-    // per-rank totals instead of the local partials
-    const double* all_totals; int world, rank;
-    double* local_totals;      // out: {M_local, W_local, Q_local} for the all-gather (phase 1)
-    int phase;                 // 0: single GPU (everything); 1: local totals + local bc only; 2: combine
+    const double* all_totals; int world, rank;   // phase 2: all-gathered per-rank {M, W, Q}
+    double* local_totals;      // phase 1 out: {M_local, W_local, Q_local}
+    int phase;                 // 0: single shard (everything); 1: local part; 2: combine ranks
 };
 
 __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
 {
-    __shared__ double s_scr[2 * (kScanThreads / kWave)];
     constexpr int NW = kScanThreads / kWave;
+    __shared__ double s_scr[3 * NW];
     const int tid = threadIdx.x;
     StepCtrl* ctrl = a.ctrl;
 
@@ -154,13 +149,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
             Q += p.q * (e * e);
         }
         double W;
-        const double excl = block_excl_scan<NW>(S, s_scr, &W);
-        const double Qt = block_sum<NW>(Q, s_scr);
+        const double excl = block_excl_scan<NW>(S, s_scr + NW, &W);
+        const double Qt = block_sum<NW>(Q, s_scr + 2 * NW);
         double run = excl;
         for (int c = lo; c < hi; ++c) {
             const Partial p = a.part[c];
             const double e = (p.m == -INFINITY) ? 0.0 : exp(p.m - M);
             a.bc[c] = run;
+            a.bf[c] = e;
             run += p.s * e;
         }
         if (tid == 0) {
@@ -194,113 +190,233 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
         const double ess = W * W / Q;
         ctrl->ess = ess;
         const bool last = a.t + 1 == a.T;
-        const bool rs = !a.force_no_resample && !last && (ess < a.ess_frac * a.n_global);
+        const bool rs = !a.force_no_resample && !last && (ess < a.ess_frac * a.n_pop);
         ctrl->do_resample = rs ? 1 : 0;
         if (a.t == 0) { ctrl->log_z = 0.0; ctrl->n_resampled = 0; }
-        if (rs || last) ctrl->log_z += M + log(W / a.n_global);
+        if (rs || last) ctrl->log_z += M + log(W / a.n_pop);
         if (rs) ctrl->n_resampled += 1;
+        ctrl->inv_stepw = a.n_pop / W;
+        const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(a.t + 1));
+        ctrl->u0 = u01_53(r.x, r.y);
         if (a.ess_trace) a.ess_trace[a.t] = ess;
         if (a.resampled) a.resampled[a.t] = rs ? 1 : 0;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ancestor search for one tile of (sorted) output positions.
-//   position of output j: systematic (j + u0) * W/N_out, stratified (j + u_j) * W/N_out
-//   ancestor = min{k : C_k > p}, C = inclusive CDF of w_k = exp(logw_k - M)
-// The tile walks the source tiles its positions fall into (usually 1-2: tile sums are nearly
-// equal), rebuilds each source tile's CDF in LDS from logw (scan of 1024 doubles) and binary-
-// searches it.  The full-resolution CDF is never written to HBM.
+// Ancestor search for one tile of 1024 consecutive outputs.
+//
+// Tile-level CDF window: bc[] entries around the source tile the outputs are expected in
+// (tile sums are nearly equal) are staged once in LDS; HBM is only searched when weights are so
+// uneven that the target lies outside the window.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tile_search(const double* __restrict__ bc, int lo, int hi, double p)
-{
-    // largest c in [lo, hi) with bc[c] <= p (bc[lo] <= p is guaranteed by the caller)
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (bc[mid] <= p) lo = mid; else hi = mid;
-    }
-    return lo;
-}
+constexpr int kWin = 256;
 
-template <int RS>
-__device__ __forceinline__ void find_ancestors(const double* __restrict__ logw, int64_t n_in, const double* __restrict__ bc, int nb,
-                                               double M, double W, double bc_scale, double cdf_lo, uint64_t seed, uint64_t step,
-                                               uint64_t gj0, uint64_t n_total_out, int n_valid_tile, const bool (&valid)[kPPT],
-                                               int32_t (&anc)[kPPT], double* s_cdf, double* s_scr, double* s_pos, int* s_idx)
+struct AncestorLds {
+    union { double cdf[kTile]; int32_t slot[kTile]; } u;   // stratified: tile CDF; systematic: scatter slots
+    double bcw[kWin + 1];    // bc[w0 .. w0 + kWin], rescaled to the global max
+    double scr[2][kWaves];   // scan scratch, double-buffered across source tiles
+    int iscr[kWaves];
+    double pos[2];
+    int cnt;
+};
+
+struct AncestorIn {
+    const double* wrel; const double* bc; const double* bf; int nb; int64_t n_in;
+    double W, scale, cdf_lo, u0, inv_stepw;
+    uint64_t seed, step, gj_tile0, n_total_out; int n_valid_tile;
+};
+
+__device__ __forceinline__ int stage_window(const AncestorIn& in, AncestorLds& L, double q_guess)
 {
     const int tid = threadIdx.x;
-    const double stepw = W / (double)n_total_out;
-    double p[kPPT];
-    double u0 = 0.0;
-    if (RS == RS_SYSTEMATIC) u0 = draw_u01(seed, 0, kResampleDrawBase + step);
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        const double u = RS == RS_SYSTEMATIC ? u0 : draw_u01(seed, gj0 + k, kResampleDrawBase + step);
-        // positions are relative to this shard's CDF segment [cdf_lo, cdf_lo + w_local)
-        p[k] = ((double)(gj0 + k) + u) * stepw - cdf_lo;
-        anc[k] = 0;
-    }
-    if (tid == 0) s_pos[0] = p[0];
+    const double w_local = in.bc[in.nb] * in.scale;
+    const int guess = w_local > 0.0 ? (int)(fmin(fmax(q_guess / w_local, 0.0), 1.0) * in.nb) : 0;
+    int w0 = guess - kWin / 2;
+    if (w0 > in.nb - kWin) w0 = in.nb - kWin;
+    if (w0 < 0) w0 = 0;
+    const int wn = in.nb - w0 < kWin ? in.nb - w0 : kWin;    // window covers tiles [w0, w0 + wn), entries [0, wn]
+    if (tid <= wn) L.bcw[tid] = in.bc[w0 + tid] * in.scale;
+    if (tid == 0 && wn == kWin) L.bcw[kWin] = in.bc[w0 + kWin] * in.scale;
+    return w0;
+}
+
+// ---- systematic: inverse (offspring-range) form ---------------------------------------------
+// With positions (j + u0) * W/N, source k owns the outputs j in [G(C_{k-1}), G(C_k)),
+// G(C) = ceil(C * N/W - u0), C the inclusive CDF: a partition of the outputs (G is monotone).
+// Each visited source tile rebuilds its CDF from wrel (one scan), every source with a non-empty
+// range writes its index into the LDS slot of its FIRST output, and one prefix-max over the
+// 1024 slots hands every output its ancestor.  Cost per tile is independent of how the weights
+// are spread (one heavy particle = one slot write), and there is no per-output search.
+__device__ __forceinline__ double g_of(double c, double inv, double u0) { return ceil(c * inv - u0); }
+
+__device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32_t (&anc)[kPPT], AncestorLds& L)
+{
+    const int tid = threadIdx.x;
+    const double inv = in.inv_stepw, u0 = in.u0;
+    const double gj_first = (double)in.gj_tile0, gj_last = (double)(in.gj_tile0 + (uint64_t)in.n_valid_tile - 1);
+    const int w0 = stage_window(in, L, gj_first / inv - in.cdf_lo);
+    const int wn = in.nb - w0 < kWin ? in.nb - w0 : kWin;
     {
-        const int last = n_valid_tile - 1;
-        if ((last >> 2) == tid) s_pos[1] = (last & 3) == 0 ? p[0] : ((last & 3) == 1 ? p[1] : ((last & 3) == 2 ? p[2] : p[3]));
+        const int32_t neg[kPPT] = {-1, -1, -1, -1};
+        store4(L.u.slot, (int64_t)tid * kPPT, neg);
     }
     __syncthreads();
-    const double p_first = fmax(s_pos[0], 0.0), p_last = s_pos[1];
-    bool res[kPPT];
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) res[k] = !valid[k];
-
-    int c = tile_search(bc, 0, nb, p_first / bc_scale);
-    for (;;) {
-        const int64_t base = (int64_t)c * kTile + (int64_t)tid * kPPT;
+    // tile-level value: start index of tile c's outputs
+    auto bcv = [&](int c) -> double { return (c >= w0 && c <= w0 + wn) ? L.bcw[c - w0] : in.bc[c] * in.scale; };
+    auto gt = [&](int c) -> double { return c >= in.nb ? INFINITY : g_of(in.cdf_lo + bcv(c), inv, u0); };
+    // largest c in [lo, nb) with gt(c) <= g  (gt(lo) <= g guaranteed)
+    auto locate = [&](double g, int lo) -> int {
+        int a = lo, b = in.nb;
+        // narrow to the window first when the answer is inside it
+        if (w0 >= lo && gt(w0) <= g) a = w0;
+        if (w0 + wn < in.nb && w0 + wn > a && gt(w0 + wn) > g) b = w0 + wn;
+        while (b - a > 1) { const int mid = (a + b) >> 1; if (gt(mid) <= g) a = mid; else b = mid; }
+        return a;
+    };
+    const int c_lo = locate(gj_first, 0);
+    const int c_hi = locate(gj_last, c_lo);
+    int it = 0;
+    for (int c = c_lo; c <= c_hi; ++c) {
+        const double b0 = bcv(c), b1 = bcv(c + 1);
+        if (!(b1 > b0)) continue;                              // tile without mass: owns no output
         double w[kPPT];
-        load4(logw, base, n_in, w, (double)-INFINITY);
-#pragma unroll
-        for (int k = 0; k < kPPT; ++k) w[k] = exp(w[k] - M);   // exp(-inf) = 0 for padding
+        load4(in.wrel, (int64_t)c * kTile + (int64_t)tid * kPPT, w);
         w[1] += w[0]; w[2] += w[1]; w[3] += w[2];
         double tot;
-        const double excl = block_excl_scan(w[3], s_scr, &tot);
-        const double off = bc[c] * bc_scale + excl;
+        const double excl = block_excl_scan(w[3], L.scr[it & 1], &tot);
+        ++it;
+        const double bfc = in.bf[c] * in.scale;
+        const double off = in.cdf_lo + b0;
+        const double g_lo = g_of(off, inv, u0), g_hi = (c + 1 >= in.nb) ? INFINITY : g_of(in.cdf_lo + b1, inv, u0);
+        double g_prev = fmin(fmax(g_of(off + bfc * excl, inv, u0), g_lo), g_hi);
+        if (tid == 0) g_prev = g_lo;
 #pragma unroll
-        for (int k = 0; k < kPPT; ++k) s_cdf[tid * kPPT + k] = off + w[k];
+        for (int k = 0; k < kPPT; ++k) {
+            double g = fmin(fmax(g_of(off + bfc * (excl + w[k]), inv, u0), g_lo), g_hi);
+            if (tid == kThreads - 1 && k == kPPT - 1) g = g_hi;           // the tile ends where the next one starts
+            if (g > g_prev) {
+                const double s = g_prev - gj_first, e = g - gj_first;    // exact: integers
+                if (e > 0.0 && s < (double)kTile) L.u.slot[s > 0.0 ? (int)s : 0] = (int32_t)((int64_t)c * kTile + tid * kPPT + k);
+            }
+            g_prev = g;
+        }
+    }
+    __syncthreads();
+    // inclusive prefix-max over the 1024 slots
+    int32_t v[kPPT];
+    load4(L.u.slot, (int64_t)tid * kPPT, v);
+    v[1] = max(v[1], v[0]); v[2] = max(v[2], v[1]); v[3] = max(v[3], v[2]);
+    int32_t incl = wave_incl_max_i32(v[3]);
+    if (lane_id() == kWave - 1) L.iscr[wave_id()] = incl;
+    int32_t excl = dpp_or_i32<0x138 /* wave_shr:1 */>(incl, -1);
+    if (lane_id() == 0) excl = -1;
+    __syncthreads();
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv)
+        if (wv < wave_id()) excl = max(excl, L.iscr[wv]);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) anc[k] = max(max(v[k], excl), 0);
+}
+
+// ---- stratified: forward search --------------------------------------------------------------
+// position of output j: (j + u_j) * W/N, u_j = 32-bit uniform of particle id j; ancestor =
+// min{k : C_k > p}.  Positions are sorted, so the tile walks the source tiles they fall into,
+// rebuilds each CDF in LDS and searches it (first output: binary search; the other three: the
+// neighbour's result plus a short probe).
+__device__ __forceinline__ void ancestors_stratified(const AncestorIn& in, int32_t (&anc)[kPPT], AncestorLds& L)
+{
+    const int tid = threadIdx.x;
+    const double stepw = in.W / (double)in.n_total_out;
+    const uint64_t gj0 = in.gj_tile0 + (uint64_t)tid * kPPT;
+    double p[kPPT];
+    {
+        uint32_t wd[4];
+        draw_words4(in.seed, gj0, kResampleDrawBase + in.step, wd);
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) { p[k] = ((double)(gj0 + k) + u01_32(wd[k])) * stepw - in.cdf_lo; anc[k] = 0; }
+    }
+    const int w0 = stage_window(in, L, (double)in.gj_tile0 * stepw - in.cdf_lo);
+    const int wn = in.nb - w0 < kWin ? in.nb - w0 : kWin;
+    if (tid == 0) { L.pos[0] = p[0]; L.cnt = 0; }
+    {
+        const int last = in.n_valid_tile - 1;
+        if ((last >> 2) == tid) L.pos[1] = (last & 3) == 0 ? p[0] : ((last & 3) == 1 ? p[1] : ((last & 3) == 2 ? p[2] : p[3]));
+    }
+    __syncthreads();
+    const double p_first = fmax(L.pos[0], 0.0), p_last = L.pos[1];
+    auto bcv = [&](int c) -> double { return (c >= w0 && c <= w0 + wn) ? L.bcw[c - w0] : in.bc[c] * in.scale; };
+    auto locate = [&](double q, int lo) -> int {               // largest c in [lo, nb) with bc[c] <= q
+        int a = lo, b = in.nb;
+        if (w0 >= lo && bcv(w0) <= q) a = w0;
+        if (w0 + wn < in.nb && w0 + wn > a && bcv(w0 + wn) > q) b = w0 + wn;
+        while (b - a > 1) { const int mid = (a + b) >> 1; if (bcv(mid) <= q) a = mid; else b = mid; }
+        return a;
+    };
+    bool res[kPPT];
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) res[k] = (tid * kPPT + k) >= in.n_valid_tile;
+    int c = locate(p_first, 0);
+    int it = 0;
+    for (;;) {
+        double w[kPPT];
+        load4(in.wrel, (int64_t)c * kTile + (int64_t)tid * kPPT, w);
+        w[1] += w[0]; w[2] += w[1]; w[3] += w[2];
+        double tot;
+        const double excl = block_excl_scan(w[3], L.scr[it & 1], &tot);
+        ++it;
+        const double bfc = in.bf[c] * in.scale;
+        const double off = bcv(c);
+        double cd[kPPT];
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) cd[k] = off + bfc * (excl + w[k]);
+        store4(L.u.cdf, (int64_t)tid * kPPT, cd);
         __syncthreads();
-        const double hi_c = (c == nb - 1) ? INFINITY : bc[c + 1] * bc_scale;
-        const int64_t rem = n_in - (int64_t)c * kTile;
+        const double hi_c = (c == in.nb - 1) ? INFINITY : bcv(c + 1);
+        const int64_t rem = in.n_in - (int64_t)c * kTile;
         const int n_src = rem < kTile ? (int)rem : kTile;
+        auto lower = [&](double q, int from) -> int {          // first index >= from with cdf > q (n_src if none)
+            int a = from, b = n_src;
+            while (a < b) { const int mid = (a + b) >> 1; if (L.u.cdf[mid] > q) b = mid; else a = mid + 1; }
+            return a;
+        };
+        int newly = 0, prev_pos = 0;
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
             if (!res[k] && p[k] < hi_c) {
-                int lo = 0, hi = n_src;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_cdf[mid] > p[k]) hi = mid; else lo = mid + 1;
-                }
-                if (lo >= n_src) lo = n_src - 1;
-                anc[k] = (int32_t)((int64_t)c * kTile + lo);
+                int pos = prev_pos;
+                // short probe from the neighbour's ancestor, then binary search
+                int probe = 0;
+                while (probe < 3 && pos < n_src && L.u.cdf[pos] <= p[k]) { ++pos; ++probe; }
+                if (pos < n_src && L.u.cdf[pos] <= p[k]) pos = lower(p[k], pos);
+                if (pos >= n_src) pos = n_src - 1;
+                prev_pos = pos;
+                anc[k] = (int32_t)((int64_t)c * kTile + pos);
                 res[k] = true;
+                ++newly;
             }
         }
-        if (p_last < hi_c) break;   // workgroup-uniform
-        if (tid == 0) *s_idx = INT_MAX;
+        if (p_last < hi_c) break;   // workgroup-uniform: every output of this tile is resolved
+        if (newly) atomicAdd(&L.cnt, newly);
         __syncthreads();
-        int mine = INT_MAX;
-#pragma unroll
-        for (int k = kPPT - 1; k >= 0; --k)
-            if (!res[k]) mine = tid * kPPT + k;
-        if (mine != INT_MAX) atomicMin(s_idx, mine);
-        __syncthreads();
-        const int f = *s_idx;
-        if ((f >> 2) == tid) s_pos[0] = (f & 3) == 0 ? p[0] : ((f & 3) == 1 ? p[1] : ((f & 3) == 2 ? p[2] : p[3]));
-        __syncthreads();
-        c = tile_search(bc, c + 1, nb, s_pos[0] / bc_scale);
+        // outputs are sorted, so the resolved ones are a prefix: the next position is that of output #cnt
+        const uint64_t gjn = in.gj_tile0 + (uint64_t)L.cnt;
+        const double p_next = ((double)gjn + u01_32(draw_word(in.seed, gjn, kResampleDrawBase + in.step))) * stepw - in.cdf_lo;
+        c = locate(p_next, c + 1);
     }
 }
 
-// Standalone resampler (building block; also the multinomial path's first half is elsewhere).
+template <int RS>
+__device__ __forceinline__ void find_ancestors(const AncestorIn& in, int32_t (&anc)[kPPT], AncestorLds& L)
+{
+    if (RS == RS_SYSTEMATIC) ancestors_systematic(in, anc, L);
+    else ancestors_stratified(in, anc, L);
+}
+
+// Standalone resampler over an arbitrary weight array (building block).
 struct ResampleArgs {
-    const double* logw; int64_t n_in;
-    const double* bc; int nb; const StepCtrl* ctrl;
+    const double* wrel; int64_t n_in;
+    const double* bc; const double* bf; int nb; const StepCtrl* ctrl;
     uint64_t seed, step, j0, n_total_out; int64_t n_out;
     int32_t* anc;
 };
@@ -308,40 +424,42 @@ struct ResampleArgs {
 template <int RS>
 __global__ __launch_bounds__(kThreads) void resample_kernel(ResampleArgs a)
 {
-    __shared__ double s_cdf[kTile];
-    __shared__ double s_scr[16];
-    __shared__ double s_pos[2];
-    __shared__ int s_idx;
+    __shared__ AncestorLds L;
     const int64_t l0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
-    bool valid[kPPT];
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) valid[k] = l0 + k < a.n_out;
     const int64_t rem = a.n_out - (int64_t)blockIdx.x * kTile;
-    const int n_valid_tile = rem < kTile ? (int)rem : kTile;
+    AncestorIn in;
+    in.wrel = a.wrel; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n_in;
+    in.W = a.ctrl->W; in.scale = a.ctrl->scale; in.cdf_lo = a.ctrl->cdf_lo;
+    in.inv_stepw = (double)a.n_total_out / a.ctrl->W;
+    {
+        const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + a.step);
+        in.u0 = u01_53(r.x, r.y);
+    }
+    in.seed = a.seed; in.step = a.step; in.gj_tile0 = a.j0 + (uint64_t)blockIdx.x * kTile; in.n_total_out = a.n_total_out;
+    in.n_valid_tile = rem < kTile ? (int)rem : kTile;
     int32_t anc[kPPT];
-    find_ancestors<RS>(a.logw, a.n_in, a.bc, a.nb, a.ctrl->M, a.ctrl->W, a.ctrl->scale, a.ctrl->cdf_lo, a.seed, a.step,
-                       a.j0 + (uint64_t)l0, a.n_total_out, n_valid_tile, valid, anc, s_cdf, s_scr, s_pos, &s_idx);
-    store4(a.anc, l0, a.n_out, anc);
+    find_ancestors<RS>(in, anc, L);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k)
+        if (l0 + k < a.n_out) a.anc[l0 + k] = anc[k];
 }
 
 // Multinomial (thesis Alg. 1 p.36, literal): independent positions u_j * W, unsorted, so the
 // full-resolution CDF is materialised once (cdf_kernel) and searched per output.
-__global__ __launch_bounds__(kThreads) void cdf_kernel(const double* __restrict__ logw, int64_t n, const double* __restrict__ bc,
+__global__ __launch_bounds__(kThreads) void cdf_kernel(const double* __restrict__ wrel, const double* __restrict__ bc, const double* __restrict__ bf,
                                                         const StepCtrl* __restrict__ ctrl, double* __restrict__ cdf)
 {
-    __shared__ double s_scr[16];
+    __shared__ double s_scr[kWaves];
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
     double w[kPPT];
-    load4(logw, j0, n, w, (double)-INFINITY);
-    const double M = ctrl->M;
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) w[k] = exp(w[k] - M);
+    load4(wrel, j0, w);
     w[1] += w[0]; w[2] += w[1]; w[3] += w[2];
     double tot;
-    const double off = bc[blockIdx.x] * ctrl->scale + block_excl_scan(w[3], s_scr, &tot);
+    const double excl = block_excl_scan(w[3], s_scr, &tot);
+    const double off = bc[blockIdx.x] * ctrl->scale, bfc = bf[blockIdx.x] * ctrl->scale;
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) w[k] += off;
-    store4(cdf, j0, n, w);
+    for (int k = 0; k < kPPT; ++k) w[k] = off + bfc * (excl + w[k]);
+    store4(cdf, j0, w);
 }
 
 __global__ __launch_bounds__(kThreads) void multinomial_kernel(const double* __restrict__ cdf, int64_t n_in, const StepCtrl* __restrict__ ctrl,
@@ -349,7 +467,7 @@ __global__ __launch_bounds__(kThreads) void multinomial_kernel(const double* __r
 {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= n_out) return;
-    const double p = draw_u01(seed, j0 + (uint64_t)i, kResampleDrawBase + step) * ctrl->W - ctrl->cdf_lo;
+    const double p = draw_u01_53(seed, j0 + (uint64_t)i, kResampleDrawBase + step) * ctrl->W - ctrl->cdf_lo;
     int64_t lo = 0, hi = n_in;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -362,49 +480,54 @@ __global__ __launch_bounds__(kThreads) void multinomial_kernel(const double* __r
 // ---------------------------------------------------------------------------------------------
 // SIS: cpprob::inference(StateType::sis) for all particles at once
 // (reference include/cpprob/cpprob.hpp:194-201).  One lane runs 4 particles to completion:
-// draw priors -> sum logpdf(observe) -> record predicts.  Writes values[t][i] and logw[i]
-// coalesced, plus the tile partial of the final weights.
+// draw priors -> sum logpdf(observe) -> record predicts.  Writes values[t][i], logw[i] and
+// wrel[i] coalesced, plus the tile partial of the final weights.
 // ---------------------------------------------------------------------------------------------
 template <class Model>
 struct SisArgs {
     ModelParams mp; const double* obs; int T; int64_t n, ld;
     uint64_t seed, pid0;
-    typename Model::value_t* values; double* logw; Partial* part;
+    typename Model::value_t* values; double* logw; double* wrel; Partial* part;
 };
 
 template <class Model>
 __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
 {
     using V = typename Model::value_t;
-    __shared__ double s_scr[16];
+    __shared__ double s_scr[3 * kWaves];
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
-    bool valid[kPPT]; double lw[kPPT]; V x[kPPT];
+    double lw[kPPT]; V x[kPPT];
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) { valid[k] = j0 + k < a.n; lw[k] = 0.0; x[k] = V(0); }   // start_trace(): log_w_ = 0
+    for (int k = 0; k < kPPT; ++k) { lw[k] = 0.0; x[k] = V(0); }                              // start_trace(): log_w_ = 0
     for (int t = 0; t < a.T; ++t) {
+        V nx[kPPT];
+        Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0, t, x, nx);                     // sample: distr(get_rng())  cpprob.hpp:72-74
 #pragma unroll
-        for (int k = 0; k < kPPT; ++k) {
-            x[k] = Model::propagate(a.mp, a.seed, a.pid0 + (uint64_t)(j0 + k), t, x[k]);   // sample: distr(get_rng())  cpprob.hpp:72-74
-            lw[k] += Model::loglik(a.mp, x[k], t, a.obs);                                   // observe: log_w_ += logpdf  state.cpp:212-223
-        }
-        store4(a.values + (int64_t)t * a.ld, j0, a.n, x);                                   // predict: add_predict       state.hpp:312-327
+        for (int k = 0; k < kPPT; ++k) { x[k] = nx[k]; lw[k] += Model::loglik(a.mp, x[k], t, a.obs); }   // observe: log_w_ += logpdf  state.cpp:212-223
+        store4(a.values + (int64_t)t * a.ld, j0, x);                                          // predict: add_predict       state.hpp:312-327
     }
-    store4(a.logw, j0, a.n, lw);                                                            // finish_trace()
-    write_partial(lw, valid, a.part, s_scr);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k)
+        if (j0 + k >= a.n) lw[k] = -INFINITY;                                                 // padding slots
+    store4(a.logw, j0, lw);                                                                   // finish_trace()
+    double e[kPPT];
+    tile_partial(lw, e, a.part, s_scr);
+    store4(a.wrel, j0, e);
 }
 
 // ---------------------------------------------------------------------------------------------
 // SMC step t (fused): [resample generation t-1 -> ancestors] -> gather ancestor state ->
-// sample x_t -> weight by observe t -> record predict + ancestor -> tile partial.
+// sample x_t -> weight by observe t -> record predict + ancestor -> tile partial + linear weights.
 // ---------------------------------------------------------------------------------------------
 template <class Model>
 struct StepArgs {
     ModelParams mp; const double* obs; int t, T; int64_t n, ld;
-    uint64_t seed, pid0, n_global;
+    uint64_t seed, pid0, pos0, n_pop;   // pid0: RNG id of local slot 0; pos0: index of local slot 0 in the resampled population
     typename Model::value_t* values; int32_t* anc;
     const double* logw_prev; double* logw_next;
-    const Partial* part_prev_unused; Partial* part;
-    const double* bc; int nb; const StepCtrl* ctrl;
+    const double* wrel_prev; double* wrel_next;
+    Partial* part;
+    const double* bc; const double* bf; int nb; const StepCtrl* ctrl;
     const int32_t* anc_pre;   // RS_PRECOMPUTED: ancestors computed by multinomial_kernel
 };
 
@@ -412,49 +535,50 @@ template <class Model, int RS>
 __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
 {
     using V = typename Model::value_t;
-    __shared__ double s_cdf[RS == RS_PRECOMPUTED ? 1 : kTile];
-    __shared__ double s_scr[16];
-    __shared__ double s_pos[2];
-    __shared__ int s_idx;
+    __shared__ AncestorLds L;
+    __shared__ double s_scr[3 * kWaves];
     const int tid = threadIdx.x;
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)tid * kPPT;
     const int t = a.t;
-    bool valid[kPPT];
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
     const bool resample = t > 0 && a.ctrl->do_resample != 0;   // workgroup-uniform (scalar load)
 
     int32_t anc[kPPT]; double lw[kPPT];
     if (!resample) {
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) { anc[k] = (int32_t)(j0 + k); lw[k] = 0.0; }
-        if (t > 0) load4(a.logw_prev, j0, a.n, lw, 0.0);     // weights carry over when no resampling happened
+        if (t > 0) load4(a.logw_prev, j0, lw);               // weights carry over when no resampling happened
     } else {
         if (RS == RS_PRECOMPUTED) {
-            load4(a.anc_pre, j0, a.n, anc, 0);
+            load4(a.anc_pre, j0, anc);
         } else {
             const int64_t rem = a.n - (int64_t)blockIdx.x * kTile;
-            const int n_valid_tile = rem < kTile ? (int)rem : kTile;
-            find_ancestors<RS>(a.logw_prev, a.n, a.bc, a.nb, a.ctrl->M, a.ctrl->W, a.ctrl->scale, a.ctrl->cdf_lo, a.seed, (uint64_t)t,
-                               a.pid0 + (uint64_t)j0, a.n_global, n_valid_tile, valid, anc, s_cdf, s_scr, s_pos, &s_idx);
+            AncestorIn in;
+            in.wrel = a.wrel_prev; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n;
+            in.W = a.ctrl->W; in.scale = a.ctrl->scale; in.cdf_lo = a.ctrl->cdf_lo; in.u0 = a.ctrl->u0; in.inv_stepw = a.ctrl->inv_stepw;
+            in.seed = a.seed; in.step = (uint64_t)t; in.gj_tile0 = a.pos0 + (uint64_t)blockIdx.x * kTile; in.n_total_out = a.n_pop;
+            in.n_valid_tile = rem < kTile ? (int)rem : kTile;
+            find_ancestors<RS>(in, anc, L);
         }
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) lw[k] = 0.0;          // equal weights after resampling
     }
 
-    V x[kPPT];
+    V prev[kPPT], x[kPPT];
     const V* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.ld;
 #pragma unroll
+    for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? prev_row[anc[k]] : V(0);                 // ancestor's state (sorted gather)
+    Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0, t, prev, x);                       // sample #t
+#pragma unroll
     for (int k = 0; k < kPPT; ++k) {
-        V prev = V(0);
-        if (t > 0 && valid[k]) prev = prev_row[anc[k]];                                   // ancestor's state (sorted gather)
-        x[k] = Model::propagate(a.mp, a.seed, a.pid0 + (uint64_t)(j0 + k), t, prev);     // sample #t
-        lw[k] += Model::loglik(a.mp, x[k], t, a.obs);                                     // observe #t
+        lw[k] += Model::loglik(a.mp, x[k], t, a.obs);                                         // observe #t
+        if (j0 + k >= a.n) lw[k] = -INFINITY;                                                 // padding slots
     }
-    store4(a.values + (int64_t)t * a.ld, j0, a.n, x);                                     // predict #t
-    store4(a.anc + (int64_t)t * a.ld, j0, a.n, anc);
-    store4(a.logw_next, j0, a.n, lw);
-    write_partial(lw, valid, a.part, s_scr);
+    store4(a.values + (int64_t)t * a.ld, j0, x);                                              // predict #t
+    store4(a.anc + (int64_t)t * a.ld, j0, anc);
+    store4(a.logw_next, j0, lw);
+    double e[kPPT];
+    tile_partial(lw, e, a.part, s_scr);
+    store4(a.wrel_next, j0, e);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -463,13 +587,13 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
 // goes to the k-th distribution; empirical_distribution.hpp:30-40,52-81).  A final particle's
 // trace is its ancestral line, so each lane walks anc[] backwards from its final slot and
 // accumulates W_i * f(x_t) per step; ancestors are sorted, so the walk stays coalesced and
-// collapses onto the surviving lineages (L2 hits).
+// collapses onto the surviving lineages (L2 hits).  Final weights are wrel * bf[tile]: no exp.
 // ---------------------------------------------------------------------------------------------
 template <class Model>
 struct SmoothArgs {
-    const typename Model::value_t* values; const int32_t* anc; const double* logw; const StepCtrl* ctrl;
+    const typename Model::value_t* values; const int32_t* anc; const double* wrel; const double* bf; const StepCtrl* ctrl;
     const int32_t* resampled; int T; int64_t n, ld; int identity;
-    double* stats_part;   // [gridDim.x][T * kStats]
+    double* stats_part;   // [T * kStats][gridDim.x]
     typename Model::value_t* paths;   // optional [T][ld]: materialised traces (dump / tests)
 };
 
@@ -483,16 +607,16 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
     const int TK = a.T * K;
     for (int i = tid; i < kWaves * TK; i += kThreads) s_stat[i] = 0.0;
     __syncthreads();
-    const double M = a.ctrl->M;
+    const double scale = a.ctrl->scale;
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int64_t idx[kPPT]; double w[kPPT]; int64_t self[kPPT];
+        const double f = a.bf[tile] * scale;
+        int32_t idx[kPPT]; double w[kPPT];
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
             const int64_t i = tile * kTile + (int64_t)k * kThreads + tid;   // lane-strided: coalesced first touch
-            self[k] = i;
-            idx[k] = i < a.n ? i : 0;
-            w[k] = i < a.n ? exp(a.logw[i] - M) : 0.0;
+            idx[k] = (int32_t)i;
+            w[k] = a.wrel[i] * f;                                            // padding slots: wrel = 0
         }
         for (int t = a.T - 1; t >= 0; --t) {
             double acc[K];
@@ -503,7 +627,7 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
             for (int k = 0; k < kPPT; ++k) {
                 const V x = row[idx[k]];
                 Model::accumulate(x, w[k], acc);
-                if (a.paths && self[k] < a.n) a.paths[(int64_t)t * a.ld + self[k]] = x;
+                if (a.paths) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)k * kThreads + tid] = x;
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) acc[j] = wave_sum(acc[j]);
@@ -523,30 +647,36 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
         double s = 0.0;
 #pragma unroll
         for (int w2 = 0; w2 < kWaves; ++w2) s += s_stat[w2 * TK + i];
-        a.stats_part[(int64_t)blockIdx.x * TK + i] = s;
+        a.stats_part[(int64_t)i * gridDim.x + blockIdx.x] = s;
     }
 }
 
-// Sums the per-workgroup partial statistics in a fixed order (bitwise reproducible) and
-// normalises: real -> {mean, raw2 - mean^2}; int -> probabilities.
+// Sums the per-workgroup partial statistics (layout [T*K][grid]) in a fixed order (bitwise
+// reproducible) and normalises: real -> {mean, raw2 - mean^2}; int -> probabilities.
+// One workgroup per predict hit t.  normalise = 0 leaves raw weighted sums (sharded runs
+// all-reduce them before normalising).
 __global__ __launch_bounds__(kThreads) void finalize_kernel(const double* __restrict__ stats_part, int grid, int T, int K, int is_int,
-                                                             const StepCtrl* __restrict__ ctrl, double* __restrict__ stats)
+                                                             const StepCtrl* __restrict__ ctrl, double* __restrict__ stats, int normalise)
 {
-    const int TK = T * K;
-    const double W = ctrl->W;
-    if (is_int) {
-        for (int i = blockIdx.x * kThreads + threadIdx.x; i < TK; i += gridDim.x * kThreads) {
-            double s = 0.0;
-            for (int g = 0; g < grid; ++g) s += stats_part[(int64_t)g * TK + i];
-            stats[i] = s / W;
-        }
-    } else {
-        for (int t = blockIdx.x * kThreads + threadIdx.x; t < T; t += gridDim.x * kThreads) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int g = 0; g < grid; ++g) { s1 += stats_part[(int64_t)g * TK + t * K]; s2 += stats_part[(int64_t)g * TK + t * K + 1]; }
-            const double mean = s1 / W;
+    __shared__ double s_scr[8][kWaves];
+    __shared__ double s_out[8];
+    const int t = blockIdx.x;
+    const double W = normalise ? ctrl->W : 1.0;
+    for (int j = 0; j < K; ++j) {
+        const double* col = stats_part + (int64_t)(t * K + j) * grid;
+        double s = 0.0;
+        for (int g = threadIdx.x; g < grid; g += kThreads) s += col[g];
+        s = block_sum(s, s_scr[j]);
+        if (threadIdx.x == 0) s_out[j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (is_int || !normalise) {
+            for (int j = 0; j < K; ++j) stats[t * K + j] = s_out[j] / W;
+        } else {
+            const double mean = s_out[0] / W;
             stats[t * K] = mean;
-            stats[t * K + 1] = s2 / W - mean * mean;
+            stats[t * K + 1] = s_out[1] / W - mean * mean;
         }
     }
 }
@@ -554,11 +684,11 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(const double* __rest
 // ---------------------------------------------------------------------------------------------
 // Elementwise building blocks (unit-parity surface)
 // ---------------------------------------------------------------------------------------------
-__global__ void philox_blocks_kernel(uint64_t seed, uint64_t pid0, uint64_t draw, int64_t n, uint32_t* __restrict__ out)
+__global__ void philox_blocks_kernel(uint64_t seed, uint64_t group0, uint64_t draw, int64_t n, uint32_t* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const u32x4 r = draw_block(seed, pid0 + (uint64_t)i, draw);
+    const u32x4 r = draw_block(seed, group0 + (uint64_t)i, draw);
     out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
 }
 
@@ -578,7 +708,7 @@ struct DiscreteW { double w[8]; int k; };
 __global__ void draw_discrete_kernel(uint64_t seed, uint64_t pid0, uint64_t draw, DiscreteW dw, int64_t n, int32_t* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (int32_t)discrete_from_u_dyn(draw_u01(seed, pid0 + (uint64_t)i, draw), dw.w, dw.k);
+    if (i < n) out[i] = (int32_t)discrete_from_u_dyn(u01_32(draw_word(seed, pid0 + (uint64_t)i, draw)), dw.w, dw.k);
 }
 
 __global__ void draw_uniform_real_kernel(uint64_t seed, uint64_t pid0, uint64_t draw, double a, double b, int64_t n, double* __restrict__ out)
@@ -620,6 +750,14 @@ __global__ void gather_kernel(const T* __restrict__ src, const int32_t* __restri
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
+}
+
+// Copy a user column into a tile-padded scratch column (building blocks operate on padded arrays).
+template <class T>
+__global__ void pad_copy_kernel(const T* __restrict__ src, int64_t n, int64_t ld, T* __restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ld) dst[i] = i < n ? src[i] : T(0);
 }
 
 // Weighted moments / histogram of one column against one log-weight array (EmpiricalDistribution

@@ -4,7 +4,8 @@
 //
 // Statement order inside a step follows the reference model line by line; the draw index of a
 // sample statement is its ordinal in the trace (t-th sample -> draw t), which is what the
-// oracle (oracle/cpprob_oracle.c) uses too.
+// oracle (oracle/cpprob_oracle.c) uses too.  Every functor advances the 4 consecutive
+// particles a lane owns at once so that they share Philox blocks (rng.hpp).
 #pragma once
 #include "dist.hpp"
 #include "rng.hpp"
@@ -18,8 +19,9 @@ struct ModelParams {
     double mu0, sigma0, sigma, log_norm_lik;      // log_norm_lik = log(2*pi*sigma^2)
     // hmm: k = 3
     double hmm_mean[3];
-    double hmm_thr[3][2];                         // cumulative thresholds of row s: {w0/tot, (w0+w1)/tot}
+    uint64_t hmm_thr[3][2];                       // ceil(2^32 * cumulative probability) of row s
     double log_norm_unit;                         // log(2*pi*1*1)
+    const double* ll_tab;                         // hmm: [T][3] log N(y_t; mean[s], 1), device pointer
 };
 
 // reference include/models/models.hpp:22-35 and src/models/gaussian.cpp:6-17 (same body,
@@ -28,13 +30,17 @@ struct ModelGaussian {
     using value_t = double;
     static constexpr bool kIsInt = false;
     static constexpr int kStats = 2;  // sum w x, sum w x^2
-    __device__ static __forceinline__ value_t propagate(const ModelParams& mp, uint64_t seed, uint64_t pid, int /*t*/, value_t /*prev*/)
+    __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int /*t*/,
+                                                      const value_t (&)[4], value_t (&x)[4])
     {
-        return draw_normal(seed, pid, 0, mp.mu0, mp.sigma0);          // mu = sample(prior, true)   models.hpp:26-27
+        double z[4];
+        draw_std_normals4(seed, pid0, 0, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = mp.mu0 + mp.sigma0 * z[k];    // mu = sample(prior, true)   models.hpp:26-27
     }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t mu, int /*t*/, const double* __restrict__ obs)
     {
-        double lw = 0.0;                                               // TraceInfer::log_w_ = 0     trace.hpp:59
+        double lw = 0.0;                                                  // TraceInfer::log_w_ = 0     trace.hpp:59
         lw += normal_logpdf_hoisted(obs[0], mu, mp.sigma, mp.log_norm_lik);   // observe(likelihood, y1)  models.hpp:32
         lw += normal_logpdf_hoisted(obs[1], mu, mp.sigma, mp.log_norm_lik);   // observe(likelihood, y2)  models.hpp:33
         return lw;
@@ -52,14 +58,20 @@ struct ModelLinearGaussian1D {
     using value_t = double;
     static constexpr bool kIsInt = false;
     static constexpr int kStats = 2;
-    __device__ static __forceinline__ value_t propagate(const ModelParams&, uint64_t seed, uint64_t pid, int t, value_t prev)
+    __device__ static __forceinline__ void propagate4(const ModelParams&, uint64_t seed, uint64_t pid0, int t, const value_t (&prev)[4],
+                                                      value_t (&x)[4])
     {
-        const double state = t == 0 ? 0.0 : prev;                      // models.hpp:72
-        return draw_normal(seed, pid, (uint64_t)t, state, 1.0);        // :74-75
+        double z[4];
+        draw_std_normals4(seed, pid0, (uint64_t)t, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double state = t == 0 ? 0.0 : prev[k];                  // models.hpp:72
+            x[k] = state + 1.0 * z[k];                                    // :74-75  normal{state, 1}
+        }
     }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t x, int t, const double* __restrict__ obs)
     {
-        return normal_logpdf_hoisted(obs[t], x, 1.0, mp.log_norm_unit);  // :76-77
+        return normal_logpdf_hoisted(obs[t], x, 1.0, mp.log_norm_unit);   // :76-77
     }
     __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
     {
@@ -74,18 +86,29 @@ struct ModelHmm3 {
     using value_t = int32_t;
     static constexpr bool kIsInt = true;
     static constexpr int kStats = 3;  // sum w [x == s]
-    __device__ static __forceinline__ value_t propagate(const ModelParams& mp, uint64_t seed, uint64_t pid, int t, value_t prev)
+    __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int t, const value_t (&prev)[4],
+                                                      value_t (&x)[4])
     {
-        if (t == 0) return (value_t)draw_smallint(seed, pid, 0, 0, 2);  // uniform_smallint{0,2}   :126-127
-        const double u = draw_u01(seed, pid, (uint64_t)t);              // discrete_distribution{T[state]} :135-136
-        const double c0 = prev == 0 ? mp.hmm_thr[0][0] : (prev == 1 ? mp.hmm_thr[1][0] : mp.hmm_thr[2][0]);
-        const double c1 = prev == 0 ? mp.hmm_thr[0][1] : (prev == 1 ? mp.hmm_thr[1][1] : mp.hmm_thr[2][1]);
-        return (value_t)((u >= c0) + (u >= c1));
+        uint32_t w[4];
+        draw_words4(seed, pid0, (uint64_t)t, w);
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = (value_t)smallint_from_word(w[k], 0, 2);   // uniform_smallint{0,2}   :126-127
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                                  // discrete_distribution{T[state]} :135-136
+                const uint64_t c0 = prev[k] == 0 ? mp.hmm_thr[0][0] : (prev[k] == 1 ? mp.hmm_thr[1][0] : mp.hmm_thr[2][0]);
+                const uint64_t c1 = prev[k] == 0 ? mp.hmm_thr[0][1] : (prev[k] == 1 ? mp.hmm_thr[1][1] : mp.hmm_thr[2][1]);
+                x[k] = (value_t)(((uint64_t)w[k] >= c0) + ((uint64_t)w[k] >= c1));
+            }
+        }
     }
-    __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t s, int t, const double* __restrict__ obs)
+    __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t s, int t, const double* __restrict__ /*obs*/)
     {
-        const double mean = s == 0 ? mp.hmm_mean[0] : (s == 1 ? mp.hmm_mean[1] : mp.hmm_mean[2]);
-        return normal_logpdf_hoisted(obs[t], mean, 1.0, mp.log_norm_unit);  // :130-131,138-139
+        // log N(y_t; state_mean[s], 1) from the per-run table: three values per step    :130-131,138-139
+        const double* row = mp.ll_tab + 3 * t;
+        const double l0 = row[0], l1 = row[1], l2 = row[2];
+        return s == 0 ? l0 : (s == 1 ? l1 : l2);
     }
     __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
     {

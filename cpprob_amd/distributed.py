@@ -1,0 +1,107 @@
+"""Multi-GPU driver: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference is single-process, single-threaded (src/cpprob/state.cpp:20-21); sharding is new.
+Particles are independent between resampling points, so the population splits into
+contiguous shards, rank r holding global ids [r*n, (r+1)*n); RNG counters use global ids.
+
+Two scopes (include/cpprob_hip.h, cpprob_hip_config.resample_scope):
+
+  ISLAND  every rank runs SMC on its own population of n particles (local ESS test, local
+          resampling): no data-path collective at all.  The shards are combined ONCE at the
+          end by importance-weighting each island with its evidence estimate Z_r:
+              E[f] = sum_r Z_r E_r[f] / sum_r Z_r,     Z = mean_r Z_r
+          (unbiased Z; consistent posterior; for iid shards of >= 1e5 particles the Z_r agree
+          to ~1e-3 relative, so the efficiency loss against one joint population is negligible).
+          Communication: one all-gather of (1 + T*K) doubles per rank per run.
+
+  GLOBAL  one joint population: per step every rank all-gathers its (max, sum, sum-of-squares)
+          of weights so all ranks agree on the global normaliser, ESS and the resampling
+          decision (cpprob_hip_smc_step_begin/_end).  SIS needs only this (no resampling);
+          joint resampling with ancestor redistribution is driven from here too.
+
+Host logic in this file is pure numpy/torch and is covered by gloo world_size-2 tests on CPU.
+"""
+import os
+
+import numpy as np
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_process_group(device_is_gpu=True):
+    """Initialises torch.distributed from the torchrun environment (no-op for world size 1)."""
+    import torch.distributed as dist
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl" if device_is_gpu else "gloo", rank=rank, world_size=world)
+    return world, rank, local
+
+
+def shard_bounds(n_global, world, rank):
+    """Contiguous shard of rank: particle i lives on rank floor(i * world / n_global)."""
+    base, rem = divmod(int(n_global), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, base + (1 if rank < rem else 0)
+
+
+def logsumexp(a):
+    a = np.asarray(a, np.float64)
+    m = np.max(a)
+    if not np.isfinite(m):
+        return m
+    return m + np.log(np.sum(np.exp(a - m)))
+
+
+def combine_islands(log_z, stats, is_int):
+    """Evidence-weighted combination of per-island posterior summaries.
+
+    log_z : [R]        per-island log evidence estimates
+    stats : [R, T, K]  per-island summaries: int -> probabilities; real -> (mean, variance)
+    Returns (stats[T, K], log_evidence, island_weights[R], island_ess).
+    """
+    log_z = np.asarray(log_z, np.float64)
+    stats = np.asarray(stats, np.float64)
+    lse = logsumexp(log_z)
+    w = np.exp(log_z - lse)                       # normalised island weights
+    if is_int:
+        out = np.tensordot(w, stats, axes=(0, 0))
+    else:
+        mean_r = stats[:, :, 0]
+        raw2_r = stats[:, :, 1] + mean_r * mean_r   # variance(mean) = raw2 - mean^2 (empirical_distribution.hpp:78-81)
+        mean = w @ mean_r
+        raw2 = w @ raw2_r
+        out = np.stack([mean, raw2 - mean * mean], axis=1)
+    return out, float(lse - np.log(len(log_z))), w, float(1.0 / np.sum(w * w))
+
+
+def allgather_vector(vec, device=None):
+    """all-gather of a small float64 vector: returns [world, len(vec)] as numpy."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    v = np.ascontiguousarray(vec, np.float64)
+    if world == 1:
+        return v[None, :]
+    t = torch.from_numpy(v)
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty((world, v.size), dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out.view(-1), t) if t.device.type == "cuda" else dist.all_gather(list(out.unbind(0)), t)
+    return out.cpu().numpy()
+
+
+def run_islands(engine, run_index=0, device=None):
+    """One island-scope run on every rank + the final evidence-weighted combination.
+    `engine` must have been begun with scope=SCOPE_ISLAND.  Returns (stats, log_evidence, island_ess)."""
+    engine.run(run_index)
+    s = engine.summary()
+    st = engine.stats()
+    vec = np.concatenate([[s["log_evidence"]], st.reshape(-1)])
+    allv = allgather_vector(vec, device)
+    out, lz, _, iess = combine_islands(allv[:, 0], allv[:, 1:].reshape(allv.shape[0], *st.shape), engine.is_int)
+    return out, lz, iess

@@ -58,6 +58,9 @@ extern "C" {
 #define CPPROB_HIP_RESAMPLE_STRATIFIED 1
 #define CPPROB_HIP_RESAMPLE_MULTINOMIAL 2
 
+#define CPPROB_HIP_SCOPE_GLOBAL 0
+#define CPPROB_HIP_SCOPE_ISLAND 1
+
 typedef struct cpprob_hip_ctx cpprob_hip_ctx;
 
 /* Run configuration.  Replaces the arguments of cpprob::inference (cpprob.hpp:173-180):
@@ -68,8 +71,14 @@ typedef struct cpprob_hip_config {
     int32_t algorithm;        /* CPPROB_HIP_ALG_*                                              */
     int32_t model;            /* CPPROB_HIP_MODEL_*                                            */
     int32_t resampler;        /* CPPROB_HIP_RESAMPLE_* (SMC only)                              */
+    int32_t resample_scope;   /* CPPROB_HIP_SCOPE_GLOBAL: one population of n_global particles,
+                                 resampled jointly (sharded runs use the step_begin/step_end
+                                 protocol); CPPROB_HIP_SCOPE_ISLAND: this shard is an independent
+                                 population of n_particles (particle_offset only selects the
+                                 RNG streams); shards are combined by their evidence estimates */
     int32_t keep_history;     /* 1: keep per-step values + ancestors (needed for smoothing /
                                  dumps; always 1 in this version)                             */
+    int32_t reserved;
     double ess_threshold;     /* SMC: resample after a step iff ESS < ess_threshold * N_global;
                                  > 1 resamples after every step (thesis p.37 uses 0.5)        */
     uint64_t seed;            /* Philox key                                                    */
@@ -151,10 +160,14 @@ int cpprob_hip_smc_finish(cpprob_hip_ctx* ctx);
 /* ---- building blocks (also the unit-parity surface) --------------------------------------
  * All pointers are device pointers; n is the element count. */
 
-/* Raw Philox4x32-10 blocks: d_out[4*i..4*i+3] = block(seed, pid0 + i, draw). */
-int cpprob_hip_philox_blocks(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, size_t n, uint32_t* d_out);
+/* Raw Philox4x32-10 blocks: d_out[4*i..4*i+3] = block(seed, group0 + i, draw)
+ * (= rocrand_init(seed, subsequence = group, offset = 4*draw); rocrand4()). */
+int cpprob_hip_philox_blocks(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t group0, uint64_t draw, size_t n, uint32_t* d_out);
 /* Variate generators standing in for boost::random::*::operator()(get_rng()) (cpprob.hpp:34):
- * element i is the draw of global particle pid0+i at statement ordinal `draw`. */
+ * element i is the draw of global particle pid0+i at statement ordinal `draw`.  Neighbouring
+ * particles share Philox blocks: 32-bit variates (uniform_smallint, discrete) take word pid&3 of
+ * block(group pid>>2); normal variates take component pid&1 of rocRAND's box_muller_double of
+ * block(group pid>>1); 53-bit uniforms (uniform_real) take word pair pid&1 of block(pid>>1). */
 int cpprob_hip_draw_normal(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, double mean, double sigma, size_t n, double* d_out);
 int cpprob_hip_draw_uniform_smallint(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, int64_t a, int64_t b, size_t n, int32_t* d_out);
 int cpprob_hip_draw_discrete(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, const double* h_weights, int32_t k, size_t n, int32_t* d_out);
@@ -177,7 +190,8 @@ int cpprob_hip_weighted_hist(cpprob_hip_ctx* ctx, const int32_t* d_x, const doub
 
 /* Resampling: d_anc[jj] = ancestor (index into d_logw[0..n_in)) of output j0 + jj, for n_out
  * consecutive outputs of a population of n_total_out positions.  Uniforms come from
- * draw index (1<<40) + step (systematic: particle id 0; otherwise particle id j). */
+ * draw index (1<<40) + step: systematic one 53-bit uniform of group 0; stratified the 32-bit
+ * uniform of id j; multinomial the 53-bit uniform of id j. */
 int cpprob_hip_resample(cpprob_hip_ctx* ctx, int32_t kind, const double* d_logw, size_t n_in, uint64_t seed, uint64_t step,
                         uint64_t j0, size_t n_out, uint64_t n_total_out, int32_t* d_anc);
 /* d_dst[i] = d_src[d_idx[i]] */

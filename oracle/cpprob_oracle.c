@@ -68,69 +68,99 @@ ORC_API void orc_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* One 128-bit block per sample statement: key = seed, counter = (draw index,
- * global particle id).  Identical to rocrand_init(seed, subsequence = pid,
- * offset = 4*draw) followed by rocrand4(). */
-ORC_API void orc_draw_block(uint64_t seed, uint64_t pid, uint64_t draw, uint32_t out[4])
+/* One 128-bit block per (group, draw): key = seed, counter = (draw index, group id).
+ * Identical to rocrand_init(seed, subsequence = group, offset = 4*draw); rocrand4().
+ * Neighbouring particles share a block (mirrors cpprob_amd/csrc/rng.hpp):
+ *   32-bit variates : word (pid & 3) of block(group = pid >> 2)
+ *   normal variates : rocRAND box_muller_double(block(group = pid >> 1)), component pid & 1
+ *   53-bit uniforms : words (2(pid&1), 2(pid&1)+1) of block(group = pid >> 1)            */
+ORC_API void orc_draw_block(uint64_t seed, uint64_t group, uint64_t draw, uint32_t out[4])
 {
-    uint32_t ctr[4] = { (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)pid, (uint32_t)(pid >> 32) };
+    uint32_t ctr[4] = { (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)group, (uint32_t)(group >> 32) };
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     orc_philox4x32_10(ctr, key, out);
 }
 
 static const double TWO_POW_M53 = 1.1102230246251565e-16; /* 2^-53 */
+static const double TWO_POW_M32 = 2.3283064365386963e-10; /* 2^-32 */
 
 /* 53-bit integer from two words, rocRAND's uniform_distribution_double(v1, v2). */
 static inline uint64_t bits53(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)(hi >> 11) << 32); }
 
-/* (0, 1] */
-ORC_API double orc_u01_open0(uint32_t lo, uint32_t hi) { return TWO_POW_M53 + (double)bits53(lo, hi) * TWO_POW_M53; }
-/* [0, 1) */
-ORC_API double orc_u01_open1(uint32_t lo, uint32_t hi) { return (double)bits53(lo, hi) * TWO_POW_M53; }
+/* [0, 1) from 53 bits / from 32 bits */
+ORC_API double orc_u01_53(uint32_t lo, uint32_t hi) { return (double)bits53(lo, hi) * TWO_POW_M53; }
+ORC_API double orc_u01_32(uint32_t w) { return (double)w * TWO_POW_M32; }
 
-/* sin(pi*w) for w in (0, 2], exact range reduction then libm. */
+/* sin(pi*w), cos(pi*w) for w in (0, 2]: exact range reduction, then libm. */
 static double sinpi_02(double w)
 {
-    /* reduce to r in [-0.5, 0.5]: sin(pi w) = sin(pi r) * sign */
     double sign = 1.0;
     if (w > 1.0) { w -= 1.0; sign = -1.0; }   /* exact: w in (1,2] */
     if (w > 0.5) w = 1.0 - w;                  /* exact */
     if (w <= 0.25) return sign * sin(M_PI * w);
     return sign * cos(M_PI * (0.5 - w));
 }
+static double cospi_02(double w)
+{
+    double sign = 1.0;
+    if (w > 1.0) { w -= 1.0; sign = -1.0; }   /* cos(pi(w+1)) = -cos(pi w) */
+    if (w > 0.5) { w = 1.0 - w; sign = -sign; } /* cos(pi(1-r)) = -cos(pi r) */
+    if (w <= 0.25) return sign * cos(M_PI * w);
+    return sign * sin(M_PI * (0.5 - w));
+}
 
-/* Standard normal, Box-Muller, first output of rocRAND's box_muller_double(uint4):
+/* Both outputs of rocRAND's box_muller_double(uint4):
  * u = 2^-53 + v1*2^-53, v1 = x ^ (y << 21); w = 2^-52 + v2*2^-52, v2 = z ^ (w << 21);
- * z = sqrt(-2 log u) * sin(pi w).
+ * s = sqrt(-2 log u); out = (s sin(pi w), s cos(pi w)).
  * Stands in for boost::random::normal_distribution::operator() (row a14). */
-ORC_API double orc_std_normal_from_block(const uint32_t r[4])
+ORC_API void orc_box_muller(const uint32_t r[4], double out[2])
 {
     uint64_t v1 = (uint64_t)r[0] ^ ((uint64_t)r[1] << 21);
     uint64_t v2 = (uint64_t)r[2] ^ ((uint64_t)r[3] << 21);
     double u = TWO_POW_M53 + (double)v1 * TWO_POW_M53;
     double w = (TWO_POW_M53 * 2.0) + (double)v2 * (TWO_POW_M53 * 2.0);
     double s = sqrt(-2.0 * log(u));
-    return s * sinpi_02(w);
+    out[0] = s * sinpi_02(w);
+    out[1] = s * cospi_02(w);
+}
+
+ORC_API uint32_t orc_draw_word(uint64_t seed, uint64_t pid, uint64_t draw)
+{
+    uint32_t r[4];
+    orc_draw_block(seed, pid >> 2, draw, r);
+    return r[pid & 3];
+}
+
+ORC_API double orc_draw_std_normal(uint64_t seed, uint64_t pid, uint64_t draw)
+{
+    uint32_t r[4];
+    double z[2];
+    orc_draw_block(seed, pid >> 1, draw, r);
+    orc_box_muller(r, z);
+    return z[pid & 1];
+}
+
+ORC_API double orc_draw_u01_53(uint64_t seed, uint64_t pid, uint64_t draw)
+{
+    uint32_t r[4];
+    orc_draw_block(seed, pid >> 1, draw, r);
+    return (pid & 1) ? orc_u01_53(r[2], r[3]) : orc_u01_53(r[0], r[1]);
 }
 
 ORC_API double orc_draw_normal(uint64_t seed, uint64_t pid, uint64_t draw, double mean, double sigma)
 {
-    uint32_t r[4];
-    orc_draw_block(seed, pid, draw, r);
-    return mean + sigma * orc_std_normal_from_block(r);
+    return mean + sigma * orc_draw_std_normal(seed, pid, draw);
 }
 
 /* uniform_smallint<size_t>{a, b}: a + floor(word * range / 2^32) */
 ORC_API uint64_t orc_draw_smallint(uint64_t seed, uint64_t pid, uint64_t draw, uint64_t a, uint64_t b)
 {
-    uint32_t r[4];
-    orc_draw_block(seed, pid, draw, r);
     uint64_t range = b - a + 1;
-    return a + (((uint64_t)r[0] * range) >> 32);
+    return a + (((uint64_t)orc_draw_word(seed, pid, draw) * range) >> 32);
 }
 
 /* discrete_distribution over k weights: inverse CDF on the normalised cumulative
- * sums, u in [0,1).  (Boost uses an alias table; law is identical.) */
+ * sums, u = word * 2^-32 in [0,1).  (Boost uses an alias table; law is identical.) */
 static uint64_t discrete_from_u(double u, const double *w, int k)
 {
     double tot = 0.0;
@@ -146,17 +176,13 @@ static uint64_t discrete_from_u(double u, const double *w, int k)
 
 ORC_API uint64_t orc_draw_discrete(uint64_t seed, uint64_t pid, uint64_t draw, const double *w, int k)
 {
-    uint32_t r[4];
-    orc_draw_block(seed, pid, draw, r);
-    return discrete_from_u(orc_u01_open1(r[0], r[1]), w, k);
+    return discrete_from_u(orc_u01_32(orc_draw_word(seed, pid, draw)), w, k);
 }
 
-/* uniform_real_distribution{a,b}: a + (b-a)*u, u in [0,1) */
+/* uniform_real_distribution{a,b}: a + (b-a)*u, u in [0,1) from 53 bits */
 ORC_API double orc_draw_uniform_real(uint64_t seed, uint64_t pid, uint64_t draw, double a, double b)
 {
-    uint32_t r[4];
-    orc_draw_block(seed, pid, draw, r);
-    return a + (b - a) * orc_u01_open1(r[0], r[1]);
+    return a + (b - a) * orc_draw_u01_53(seed, pid, draw);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -432,11 +458,13 @@ static uint64_t upper_bound_d(const double *c, uint64_t n, double p)
     return lo < n ? lo : n - 1;
 }
 
-static double resample_u(uint64_t seed, uint64_t pid, uint64_t step)
+/* systematic: one 53-bit uniform of group 0; stratified: 32-bit uniform of output j;
+ * multinomial: 53-bit uniform of output j */
+static double resample_u0(uint64_t seed, uint64_t step)
 {
     uint32_t r[4];
-    orc_draw_block(seed, pid, ORC_RESAMPLE_DRAW_BASE + step, r);
-    return orc_u01_open1(r[0], r[1]);
+    orc_draw_block(seed, 0, ORC_RESAMPLE_DRAW_BASE + step, r);
+    return orc_u01_53(r[0], r[1]);
 }
 
 /* n_out outputs [j0, j0+n_out) of a population of n_total_out positions drawn
@@ -452,13 +480,13 @@ ORC_API int orc_resample(int kind, const double *logw, uint64_t n_in, uint64_t s
     for (uint64_t i = 0; i < n_in; ++i) { acc += exp(logw[i] - max); cdf[i] = acc; }
     const double W = acc;
     const double step_w = W / (double)n_total_out;
-    const double u0 = resample_u(seed, 0, step);
+    const double u0 = resample_u0(seed, step);
     for (uint64_t jj = 0; jj < n_out; ++jj) {
         uint64_t j = j0 + jj;
         double p;
         if (kind == ORC_RESAMPLE_SYSTEMATIC) p = ((double)j + u0) * step_w;
-        else if (kind == ORC_RESAMPLE_STRATIFIED) p = ((double)j + resample_u(seed, j, step)) * step_w;
-        else p = resample_u(seed, j, step) * W;
+        else if (kind == ORC_RESAMPLE_STRATIFIED) p = ((double)j + orc_u01_32(orc_draw_word(seed, j, ORC_RESAMPLE_DRAW_BASE + step))) * step_w;
+        else p = orc_draw_u01_53(seed, j, ORC_RESAMPLE_DRAW_BASE + step) * W;
         anc[jj] = (int32_t)upper_bound_d(cdf, n_in, p);
     }
     if (!cdf_scratch) free(cdf);

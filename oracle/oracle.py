@@ -32,9 +32,12 @@ def lib():
         u64, i64, dbl, sz = C.c_uint64, C.c_int64, C.c_double, C.c_size_t
         L.orc_philox4x32_10.argtypes = [_up, _up, _up]
         L.orc_draw_block.argtypes = [u64, u64, u64, _up]
-        L.orc_u01_open0.restype = dbl; L.orc_u01_open0.argtypes = [C.c_uint32, C.c_uint32]
-        L.orc_u01_open1.restype = dbl; L.orc_u01_open1.argtypes = [C.c_uint32, C.c_uint32]
-        L.orc_std_normal_from_block.restype = dbl; L.orc_std_normal_from_block.argtypes = [_up]
+        L.orc_u01_53.restype = dbl; L.orc_u01_53.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_u01_32.restype = dbl; L.orc_u01_32.argtypes = [C.c_uint32]
+        L.orc_box_muller.argtypes = [_up, _dp]
+        L.orc_draw_word.restype = C.c_uint32; L.orc_draw_word.argtypes = [u64, u64, u64]
+        L.orc_draw_std_normal.restype = dbl; L.orc_draw_std_normal.argtypes = [u64, u64, u64]
+        L.orc_draw_u01_53.restype = dbl; L.orc_draw_u01_53.argtypes = [u64, u64, u64]
         L.orc_draw_normal.restype = dbl; L.orc_draw_normal.argtypes = [u64, u64, u64, dbl, dbl]
         L.orc_draw_smallint.restype = u64; L.orc_draw_smallint.argtypes = [u64, u64, u64, u64, u64]
         L.orc_draw_discrete.restype = u64; L.orc_draw_discrete.argtypes = [u64, u64, u64, _dp, C.c_int]
@@ -70,9 +73,15 @@ def philox(ctr, key):
     return out
 
 
-def draw_block(seed, pid, draw):
+def draw_block(seed, group, draw):
     out = np.zeros(4, np.uint32)
-    lib().orc_draw_block(seed, pid, draw, out)
+    lib().orc_draw_block(seed, group, draw, out)
+    return out
+
+
+def box_muller(words):
+    out = np.zeros(2)
+    lib().orc_box_muller(np.asarray(words, np.uint32), out)
     return out
 
 

@@ -10,6 +10,7 @@
 int main()
 {
     const unsigned long long seeds[] = {0ull, 12345ull, 0xdeadbeefdeadbeefull};
+    // "pid" is the rocRAND subsequence = the engine's block group id
     const unsigned long long pids[] = {0ull, 1ull, 9999999ull, (1ull << 33) + 7ull};
     const unsigned long long draws[] = {0ull, 1ull, 15ull, (1ull << 40) + 3ull};
     std::printf("{\"cases\": [\n");
@@ -21,8 +22,8 @@ int main()
         double2 n = rocrand_device::detail::box_muller_double(r);
         double u = rocrand_device::detail::uniform_distribution_double(r.x, r.y);
         std::printf("%s{\"seed\": %llu, \"pid\": %llu, \"draw\": %llu, \"words\": [%u, %u, %u, %u], "
-                    "\"normal_x\": \"%a\", \"u01\": \"%a\"}",
-                    first ? "" : ",\n", seed, pid, draw, r.x, r.y, r.z, r.w, n.x, u);
+                    "\"normal_x\": \"%a\", \"normal_y\": \"%a\", \"u01\": \"%a\"}",
+                    first ? "" : ",\n", seed, pid, draw, r.x, r.y, r.z, r.w, n.x, n.y, u);
         first = false;
     }
     std::printf("\n]}\n");

@@ -33,6 +33,9 @@ def test_philox_words_bit_exact_vs_oracle_and_rocrand(engine, golden_dir):
         words = out.cpu().numpy().view(np.uint32)
         assert words.tolist() == c["words"]
         assert O.draw_block(c["seed"], c["pid"], c["draw"]).tolist() == c["words"]
+        # Box-Muller of that block: both rocRAND outputs (host libm there: not bit-exact)
+        z = O.box_muller(c["words"])
+        assert abs(z[0] - float.fromhex(c["normal_x"])) < 1e-13 and abs(z[1] - float.fromhex(c["normal_y"])) < 1e-13
     n = 100003
     out = torch.zeros(4 * n, dtype=torch.int32, device="cuda")
     engine.philox_blocks(777, 5, 9, out)
