@@ -3,8 +3,7 @@
 // registers and the SMC kernel can stop every particle at each observe.
 //
 // Statement order inside a step follows the reference model line by line; the draw index of a
-// sample statement is its ordinal in the trace (t-th sample -> draw t), which is what the
-// oracle (oracle/cpprob_oracle.c) uses too.  Every functor advances the 4 consecutive
+// sample statement is its ordinal in the trace (t-th sample -> draw t).  Every functor advances the 4 consecutive
 // particles a lane owns at once so that they share Philox blocks (rng.hpp).
 #pragma once
 #include "dist.hpp"

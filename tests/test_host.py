@@ -1,0 +1,147 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/cpprob_hip.h
+declares, fails loudly without a GPU, and the multi-GPU host logic (gloo, world size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _no_gpu():
+    import cpprob_amd
+    return cpprob_amd.load_library().cpprob_hip_device_count() <= 0
+
+
+def test_library_exports_every_declared_symbol():
+    import cpprob_amd
+    from cpprob_amd import build as B
+    B.build_lib()
+    hdr = open(os.path.join(ROOT, "include", "cpprob_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(cpprob_hip_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 35
+    assert sorted(cpprob_amd.capi.SYMBOLS) == declared
+    out = subprocess.check_output(["nm", "-D", "--defined-only", cpprob_amd.capi.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (cpprob_hip_\w+)", out))
+    assert set(declared) <= exported
+    L = cpprob_amd.load_library()
+    assert L.cpprob_hip_abi_version() == 1
+    # nothing but the C ABI is exported (no C++ symbols leak)
+    assert not [l for l in out.splitlines() if " T " in l and "cpprob_hip_" not in l and "_init" not in l and "_fini" not in l]
+
+
+def test_config_struct_layout_matches_header():
+    import ctypes as C
+    from cpprob_amd import capi
+    assert C.sizeof(capi.Config) == 6 * 4 + 8 + 4 * 8
+    assert capi.Config.ess_threshold.offset == 24 and capi.Config.seed.offset == 32
+    assert C.sizeof(capi.Summary) == 4 * 8 + 4 * 4
+
+
+def test_fails_loudly_without_gpu():
+    import cpprob_amd
+    if not _no_gpu():
+        pytest.skip("a GPU is present")
+    with pytest.raises(cpprob_amd.CpprobHipError) as e:
+        cpprob_amd.Engine(0)
+    assert "no HIP device" in str(e.value) and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under cpprob_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("cpprob_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hpp", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"^\s*(from|import)\s+oracle|liboracle|cpprob_oracle|#include\s+[\"<].*oracle", txt, re.M):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_shard_bounds_partition():
+    from cpprob_amd import distributed as D
+    for n, w in [(10, 3), (1000000, 8), (7, 8), (100000001, 8)]:
+        seen = 0
+        for r in range(w):
+            lo, cnt = D.shard_bounds(n, w, r)
+            assert lo == seen
+            seen += cnt
+        assert seen == n
+
+
+def test_combine_islands_is_evidence_weighting():
+    from cpprob_amd import distributed as D
+    rng = np.random.default_rng(0)
+    R, T = 4, 5
+    log_z = rng.normal(size=R) - 30
+    p = rng.dirichlet(np.ones(3), size=(R, T))
+    out, lz, w, iess = D.combine_islands(log_z, p, True)
+    wz = np.exp(log_z - log_z.max()); wz /= wz.sum()
+    assert np.allclose(out, np.einsum("r,rtk->tk", wz, p)) and np.allclose(out.sum(1), 1)
+    assert abs(lz - np.log(np.mean(np.exp(log_z)))) < 1e-12
+    mv = np.stack([rng.normal(size=(R, T)), rng.random((R, T)) + 0.1], axis=2)
+    out, _, _, _ = D.combine_islands(log_z, mv, False)
+    mean = wz @ mv[:, :, 0]
+    raw2 = wz @ (mv[:, :, 1] + mv[:, :, 0] ** 2)
+    assert np.allclose(out[:, 0], mean) and np.allclose(out[:, 1], raw2 - mean ** 2)
+    # equal islands: identity
+    out, lz, w, iess = D.combine_islands(np.full(3, -5.0), np.tile(p[:1], (3, 1, 1)), True)
+    assert np.allclose(out, p[0]) and abs(lz + 5.0) < 1e-12 and abs(iess - 3.0) < 1e-12
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from cpprob_amd import distributed as D
+from oracle import oracle as O, exact as E
+world, rank, local = D.init_process_group(device_is_gpu=False)
+assert world == 2 and dist.get_backend() == "gloo"
+# every rank runs its island with the CPU oracle standing in for the device (test only) and the
+# product's host logic combines them
+obs = np.load(os.path.join(%(root)r, "tests", "golden", "observations.npz"))["hmm16"]
+n = 40000
+lo, cnt = D.shard_bounds(2 * n, world, rank)
+assert cnt == n and lo == rank * n
+r = O.smc(O.MODEL_HMM3, obs, n, 100 + rank, O.RESAMPLE_SYSTEMATIC, 2.0)
+st = O.smoothing(r["hist"], r["anc"], r["logw"])
+vec = np.concatenate([[r["log_z"]], st.reshape(-1)])
+allv = D.allgather_vector(vec)
+assert allv.shape == (2, 1 + 48)
+assert np.array_equal(allv[rank], vec)
+out, lz, w, iess = D.combine_islands(allv[:, 0], allv[:, 1:].reshape(2, 16, 3), True)
+t = torch.tensor([lz], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert abs(float(t) - lz) < 1e-15          # identical on both ranks
+g = np.load(os.path.join(%(root)r, "tests", "golden", "observations.npz"))["hmm16_smooth"]
+assert np.abs(out - g).max() < 0.03 and np.allclose(out.sum(1), 1)
+assert iess > 1.9
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_gloo_world2_island_combine(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER % {"root": ROOT})
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("ok") == 2
+
+
+def test_bench_cli_parses_and_graft_entry_builds():
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    assert callable(ge.build) and callable(ge.smoke)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in src

@@ -1,0 +1,258 @@
+"""CPU tests: the oracle against every golden vector / known answer the reference holds for the path.
+
+  * normal logpdf on the grid of the reference's own test (tests/cpprob/logpdf.cpp:23-35, eps 1e-8 :16)
+  * uniform_real logpdf on the grid of tests/cpprob/logpdf.cpp:61-78; the other functors vs closed forms
+  * Philox4x32-10 / Box-Muller against rocRAND's host engine (tests/golden/philox_rocrand.json)
+  * estimators against the analytic posteriors (README.md:118, thesis p.85)
+  * dump grammar against lines printed by the reference's own serialization.hpp
+  * SMC against exact forward-backward / Kalman-RTS posteriors
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import exact as E
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_normal_logpdf_reference_grid():
+    g = np.load(os.path.join(GOLD, "logpdf_grid.npz"))
+    L = O.lib()
+    grid, exp = g["normal_grid"], g["normal_expected"]
+    got = np.array([L.orc_normal_logpdf(*row) for row in grid])
+    eps = 1e-8                                   # tests/cpprob/logpdf.cpp:16
+    assert np.max(np.abs(got - exp)) < eps
+    assert np.max(np.abs(np.exp(got) - np.exp(exp))) < eps
+    assert np.max(np.abs(got - exp)) < 1e-12     # and far tighter in fact
+
+
+def test_normal_logpdf_branches():
+    L = O.lib()
+    inf = float("inf")
+    assert L.orc_normal_logpdf(1.0, 1.0, 0.0) == 0.0            # Dirac delta, utils_normal_distribution.hpp:28-32
+    assert L.orc_normal_logpdf(2.0, 1.0, 0.0) == -inf
+    assert L.orc_normal_logpdf(inf, 0.0, 1.0) == -inf           # :34-36
+    assert L.orc_normal_logpdf(-inf, 0.0, 1.0) == -inf
+
+
+def test_other_logpdfs_closed_forms():
+    g = np.load(os.path.join(GOLD, "logpdf_grid.npz"))
+    L = O.lib()
+    got = np.array([L.orc_uniform_real_logpdf(*row) for row in g["uniform_grid"]])
+    exp = g["uniform_expected"]
+    fin = np.isfinite(exp)
+    assert np.array_equal(np.isfinite(got), fin)
+    assert np.max(np.abs(got[fin] - exp[fin])) < 1e-8
+    got = np.array([L.orc_poisson_logpdf(int(k), l) for k, l in g["poisson_grid"]])
+    assert np.max(np.abs(got - g["poisson_expected"])) < 1e-10
+    assert L.orc_uniform_smallint_logpdf(1, 0, 2) == pytest.approx(-np.log(3.0))
+    assert L.orc_uniform_smallint_logpdf(3, 0, 2) == -float("inf")
+    w = np.array([0.1, 0.5, 0.4])
+    assert L.orc_discrete_logpdf(1, w, 3) == pytest.approx(np.log(0.5))
+    assert L.orc_discrete_logpdf(-1, w, 3) == -float("inf")
+
+
+def test_philox_matches_rocrand_host_engine():
+    with open(os.path.join(GOLD, "philox_rocrand.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 48
+    for c in cases:
+        assert O.draw_block(c["seed"], c["pid"], c["draw"]).tolist() == c["words"]
+        z = O.box_muller(c["words"])
+        assert abs(z[0] - float.fromhex(c["normal_x"])) < 1e-13
+        assert abs(z[1] - float.fromhex(c["normal_y"])) < 1e-13
+        u = O.lib().orc_u01_53(c["words"][0], c["words"][1])     # rocRAND's is (0,1]: one ulp of 2^-53 higher
+        assert abs((u + 2.0 ** -53) - float.fromhex(c["u01"])) < 1e-18
+    # Random123 known-answer test
+    assert O.philox([0, 0, 0, 0], [0, 0]).tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2).tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]).tolist() == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_generators_have_the_right_laws():
+    L = O.lib()
+    n = 200000
+    z = np.array([L.orc_draw_std_normal(3, i, 0) for i in range(n)])
+    assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.var() - 1) < 4 * np.sqrt(2 / n)
+    assert abs(np.mean(z ** 3)) < 0.03 and abs(np.mean(z ** 4) - 3) < 0.08
+    assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 0.01       # the two Box-Muller outputs of a block
+    s = np.array([L.orc_draw_smallint(3, i, 1, 0, 2) for i in range(n)])
+    assert np.all(np.abs(np.bincount(s, minlength=3) / n - 1 / 3) < 0.005)
+    w = np.array([0.15, 0.15, 0.7])
+    d = np.array([L.orc_draw_discrete(3, i, 2, w, 3) for i in range(n)])
+    assert np.all(np.abs(np.bincount(d, minlength=3) / n - w) < 0.005)
+    u = np.array([L.orc_draw_uniform_real(3, i, 3, -1.0, 3.0) for i in range(n)])
+    assert u.min() >= -1.0 and u.max() < 3.0 and abs(u.mean() - 1.0) < 0.02
+
+
+def test_estimators_against_published_posteriors():
+    with open(os.path.join(GOLD, "posteriors.json")) as f:
+        post = json.load(f)
+    n = 400000
+    # README.md:118 -- src/models/gaussian.cpp, observes (3,4): mean 2.32353, variance 1.05882
+    v, lw = O.sis(O.MODEL_GAUSSIAN_README, [3.0, 4.0], n, 99)
+    m = O.weighted_moments(v[0], lw)
+    assert abs(m[0] - 2.32353) < 0.01 and abs(m[1] - 1.05882) < 0.015
+    assert abs(post["readme_gaussian_obs_3_4"]["derived"][0] - 2.32353) < 5e-6
+    # thesis p.85 -- models.hpp gaussian, observes (8,9): N(7.25, 5/6).  ESS/N ~ 0.02: wide tolerance
+    v, lw = O.sis(O.MODEL_GAUSSIAN_UNKNOWN_MEAN, [8.0, 9.0], n, 99)
+    m = O.weighted_moments(v[0], lw)
+    assert abs(m[0] - 7.25) < 0.06 and abs(m[1] - 5.0 / 6.0) < 0.08
+    # BASELINE.json configs[0]: observes (3,4), 10^4 particles
+    v, lw = O.sis(O.MODEL_GAUSSIAN_UNKNOWN_MEAN, [3.0, 4.0], 10000, 1)
+    m = O.weighted_moments(v[0], lw)
+    assert abs(m[0] - post["models_gaussian_obs_3_4"]["mean"]) < 0.08
+    assert abs(m[1] - post["models_gaussian_obs_3_4"]["variance"]) < 0.12
+    assert abs((m[2] - np.log(10000)) - post["models_gaussian_obs_3_4"]["log_evidence"]) < 0.05
+    assert abs(m[3] / 10000 - 0.344) < 0.03                     # importance-sampling efficiency, SURVEY 8(d)
+
+
+def test_logsumexp_and_moments_definitions():
+    rng = np.random.default_rng(0)
+    lw = rng.normal(size=1000) * 5 - 1000
+    x = rng.normal(size=1000)
+    lse = O.logsumexp(lw)
+    assert abs(lse - (np.log(np.sum(np.exp(lw - lw.max()))) + lw.max())) < 1e-12
+    w = np.exp(lw - lse)
+    m = O.weighted_moments(x, lw)
+    assert abs(m[0] - np.sum(w * x)) < 1e-12 and abs(m[1] - (np.sum(w * x * x) - np.sum(w * x) ** 2)) < 1e-12
+    assert O.logsumexp(np.zeros(0)) == 0.0                      # empirical_distribution.hpp:131-133
+    xi = rng.integers(0, 3, 1000).astype(np.int32)
+    h = O.weighted_hist(xi, lw, 3)
+    assert abs(h.sum() - 1) < 1e-12 and abs(h[1] - w[xi == 1].sum()) < 1e-12
+
+
+def test_faithful_dump_matches_reference_grammar(tmp_path):
+    """orc_sis_faithful writes what StateInfer::dump_predicts would (state.cpp:262-267); the
+    expected text comes from the reference's own serialization.hpp (tests/golden/serialization.json)."""
+    with open(os.path.join(GOLD, "serialization.json")) as f:
+        gold = json.load(f)
+    # 1. the C formatter of the oracle reproduces the reference's lines for the golden inputs
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.snprintf.restype = ctypes.c_int
+    for case in gold["real"]:
+        vals = [float.fromhex(v) for v in case["values"]]
+        lw = float.fromhex(case["logw"])
+        line = "([" + " ".join("(0 %.15e)" % v for v in vals) + "] %.15e)" % lw
+        assert line == case["line"]
+    for case in gold["int"]:
+        lw = float.fromhex(case["logw"])
+        line = "([" + " ".join("(0 %d)" % v for v in case["values"]) + "] %.15e)" % lw
+        assert line == case["line"]
+    # 2. a faithful run: three append-mode files per particle, all-empty ones removed, ids written
+    prefix = str(tmp_path / "posterior")
+    O.sis_faithful(O.MODEL_GAUSSIAN_UNKNOWN_MEAN, [3.0, 4.0], 50, 7, prefix, "Mu")
+    assert os.path.exists(prefix + ".real") and os.path.exists(prefix + ".ids")
+    assert not os.path.exists(prefix + ".int") and not os.path.exists(prefix + ".any")
+    assert open(prefix + ".ids").read() == "Mu\n"
+    lines = open(prefix + ".real").read().splitlines()
+    vals, lw = O.sis(O.MODEL_GAUSSIAN_UNKNOWN_MEAN, [3.0, 4.0], 50, 7)
+    assert len(lines) == 50
+    assert lines[0] == "([(0 %.15e)] %.15e)" % (vals[0, 0], lw[0])
+    # 3. when the reference-built parser is available, it reads the file back
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_serialization")
+    if os.path.exists(ref):
+        out = subprocess.check_output([ref, "parse-real"], input="\n".join(lines).encode()).decode().splitlines()
+        assert len(out) == 50 and not any(o == "BAD" for o in out)
+        f = out[3].split()
+        assert int(f[0]) == 1 and abs(float(f[2]) - vals[0, 3]) < 1e-14 * max(1, abs(vals[0, 3])) and abs(float(f[3]) - lw[3]) < 1e-13
+    O.sis_faithful(O.MODEL_HMM3, E.simulate_hmm(4, 1), 10, 7, prefix + "_h", "State")
+    assert os.path.exists(prefix + "_h.int") and not os.path.exists(prefix + "_h.real")
+    assert open(prefix + "_h.int").readline().count("(0 ") == 4
+
+
+@pytest.mark.parametrize("kind", [O.RESAMPLE_SYSTEMATIC, O.RESAMPLE_STRATIFIED, O.RESAMPLE_MULTINOMIAL])
+def test_resamplers_are_unbiased(kind):
+    rng = np.random.default_rng(1)
+    n = 2000
+    lw = rng.normal(size=n)
+    w = np.exp(lw - lw.max()); w /= w.sum()
+    counts = np.zeros(n)
+    reps = 200
+    for r in range(reps):
+        counts += np.bincount(O.resample(kind, lw, 5, r), minlength=n)
+    z = (counts / reps - n * w) / np.sqrt(np.maximum(n * w, 1e-9) / reps)
+    assert np.abs(z).max() < 6.0
+    if kind != O.RESAMPLE_MULTINOMIAL:
+        assert np.all(np.diff(O.resample(kind, lw, 5, 0)) >= 0)
+
+
+def test_smc_against_exact_posteriors():
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    r = O.smc(O.MODEL_HMM3, z["hmm16"], 200000, 3, O.RESAMPLE_SYSTEMATIC, 2.0)
+    sm = O.smoothing(r["hist"], r["anc"], r["logw"])
+    assert np.abs(sm - z["hmm16_smooth"]).max() < 0.02
+    assert np.abs(sm[-1] - z["hmm16_smooth"][-1]).max() < 5e-3          # last step = filtering quality
+    assert abs(r["log_z"] - float(z["hmm16_logz"])) < 0.02
+    assert r["resampled"].sum() == 15 and r["resampled"][-1] == 0
+    r = O.smc(O.MODEL_LINEAR_GAUSSIAN_1D, z["lgssm100"][:30], 100000, 3, O.RESAMPLE_SYSTEMATIC, 0.5)
+    sm = O.smoothing(r["hist"], r["anc"], r["logw"])
+    ms, ps, _, _, ll = E.kalman_rts(z["lgssm100"][:30])
+    assert abs(sm[-1, 0] - ms[-1]) < 0.02 and abs(sm[-1, 1] - ps[-1]) < 0.02
+    assert abs(r["log_z"] - ll) < 0.05
+    assert 0 < r["resampled"].sum() < 29                                  # ESS-triggered: not every step
+
+
+def test_sis_equals_smc_without_resampling():
+    obs = E.simulate_hmm(6, 5)
+    v, lw = O.sis(O.MODEL_HMM3, obs, 5000, 11)
+    r = O.smc(O.MODEL_HMM3, obs, 5000, 11, O.RESAMPLE_SYSTEMATIC, 0.0)   # ESS < 0 never holds
+    assert np.array_equal(v, r["hist"]) and np.allclose(lw, r["logw"], rtol=0, atol=1e-12)
+    assert np.array_equal(r["anc"], np.tile(np.arange(5000, dtype=np.int32), (6, 1)))
+
+
+def test_exact_solvers_self_consistency():
+    obs = E.simulate_hmm(5, 2)
+    g, a, ll = E.hmm_forward_backward(obs)
+    # brute force over 3^5 paths
+    import itertools
+    tot = 0.0
+    marg = np.zeros((5, 3))
+    for path in itertools.product(range(3), repeat=5):
+        p = 1.0 / 3.0
+        for t, s in enumerate(path):
+            if t > 0:
+                p *= E.HMM_T[path[t - 1], s]
+            p *= np.exp(E.normal_logpdf(obs[t], E.HMM_MEAN[s], 1.0))
+        tot += p
+        for t, s in enumerate(path):
+            marg[t, s] += p
+    assert abs(np.log(tot) - ll) < 1e-12 and np.abs(marg / tot - g).max() < 1e-12
+    m, v = E.gaussian_posterior(1, 1.5, 2, [3, 4])
+    assert abs(m - 2.323529411764706) < 1e-12 and abs(v - 1.0588235294117647) < 1e-12
+
+
+def test_oracle_under_sanitizers():
+    """run the CPU oracle under ASan/UBSan (the GPU pool offers no sanitizer)."""
+    src = os.path.join(ROOT, "oracle", "cpprob_oracle.c")
+    exe = "/tmp/orc_asan_test"
+    drv = "/tmp/orc_asan_drv.c"
+    with open(drv, "w") as f:
+        f.write('''
+#include <stdint.h>
+#include <stdlib.h>
+#include <stdio.h>
+int orc_smc(int, const double*, size_t, uint64_t, uint64_t, int, double, double*, int32_t*, int32_t*, double*, double*, double*, int32_t*);
+int orc_sis(int, const double*, size_t, uint64_t, uint64_t, uint64_t, double*, int32_t*, double*);
+void orc_smoothing_int(const int32_t*, const int32_t*, const double*, size_t, uint64_t, int, double*);
+int main(void) {
+  double obs[7] = {0.3,-1.2,0.8,1.5,-0.1,0.4,2.0}; size_t T = 7; uint64_t n = 1531;
+  int32_t* hist = malloc(T*n*4); int32_t* anc = malloc(T*n*4); double* lw = malloc(n*8); double lz, ess[7]; int32_t rs[7];
+  double out[21];
+  for (int k = 0; k < 3; ++k) { if (orc_smc(3, obs, T, n, 5, k, k == 0 ? 2.0 : 0.5, NULL, hist, anc, lw, &lz, ess, rs)) return 1;
+    orc_smoothing_int(hist, anc, lw, T, n, 3, out); }
+  double* vr = malloc(n*8); if (orc_sis(0, obs, 2, n, 1, 0, vr, NULL, lw)) return 2;
+  free(hist); free(anc); free(lw); free(vr); printf("ok\\n"); return 0; }
+''')
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu99", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
+                           "-o", exe, drv, src, "-lm"])
+    out = subprocess.check_output([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1")).decode()
+    assert out.strip() == "ok"
