@@ -24,9 +24,9 @@
 #include <math.h>
 #include <stdint.h>
 
-#include "dist.hpp"
+#include "cpprob/detail/dist.hpp"
 #include "models.hpp"
-#include "rng.hpp"
+#include "cpprob/detail/rng.hpp"
 #include "wave.hpp"
 
 namespace cph {

@@ -6,8 +6,8 @@
 // sample statement is its ordinal in the trace (t-th sample -> draw t).  Every functor advances the 4 consecutive
 // particles a lane owns at once so that they share Philox blocks (rng.hpp).
 #pragma once
-#include "dist.hpp"
-#include "rng.hpp"
+#include "cpprob/detail/dist.hpp"
+#include "cpprob/detail/rng.hpp"
 
 namespace cph {
 

@@ -1,0 +1,121 @@
+// Host driver in plain C++14 with the command-line surface of the reference's src/main.cpp for the
+// sis path (flags :145-170, flow :69-107), plus --smc:
+//     cpprob_main --model hmm16 --smc --n_samples 100000 --observes "[0.3 -1 ...]" --estimate
+// Flags: --model {gaussian_unknown_mean, gaussian_readme, linear_gaussian_1d25, linear_gaussian_1d100, hmm16, hmm128}
+//        --sis | --smc        --n_samples N (default 10000)    --observes "…" | --observes_file F
+//        --generated_file NAME (default "post")   --model_folder DIR (default ".")   --estimate
+//        additions: --seed S  --resampler {systematic,stratified,multinomial}  --ess_threshold X
+//                   --generic (run the unchanged model body on the GPU instead of the fused kernels)
+//                   --no_dump  --json (print the in-memory result as one JSON line)
+// This file never touches HIP: it calls cpprob::inference exactly as the reference's main does.
+#include <array>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <tuple>
+
+#include "cpprob/cpprob.hpp"
+#include "cpprob/postprocess/stats_printer.hpp"
+#include "cpprob/serialization.hpp"
+#include "registered_models.hpp"
+
+namespace {
+
+struct Args {
+    std::string model, model_folder = ".", observes, observes_file, generated_file = "post";
+    bool sis = false, smc = false, estimate = false, json = false;
+    std::size_t n_samples = 10000;            // src/main.cpp:166
+};
+
+void print_json(const cpprob::gpu::Result& r)
+{
+    std::cout.precision(17);
+    std::cout << "{\"n\": " << r.n_particles << ", \"log_evidence\": " << r.log_evidence << ", \"ess\": " << r.ess
+              << ", \"n_resampled\": " << r.n_resampled << ", \"builtin\": " << (r.used_builtin ? "true" : "false") << ", \"predicts\": [";
+    for (std::size_t i = 0; i < r.predicts.size(); ++i) {
+        const auto& p = r.predicts[i];
+        if (i) std::cout << ", ";
+        std::cout << "{\"address\": \"" << p.address << "\", ";
+        if (p.is_int) {
+            std::cout << "\"p\": [";
+            for (std::size_t s = 0; s < p.probabilities.size(); ++s) std::cout << (s ? ", " : "") << p.probabilities[s];
+            std::cout << "]}";
+        } else {
+            std::cout << "\"mean\": " << p.mean << ", \"variance\": " << p.variance << "}";
+        }
+    }
+    std::cout << "]}" << std::endl;
+}
+
+template <class F>
+int execute(const F& model, const Args& a)
+{
+    if (a.observes_file.empty() == a.observes.empty()) {
+        std::cerr << R"(In SIS or SMC mode exactly one of the options "--observes" or "--observes_file" has to be set)" << std::endl;   // main.cpp:72-75
+        return EXIT_FAILURE;
+    }
+    cpprob::tuple_observes_t<F> observes;
+    const bool ok = a.observes_file.empty() ? cpprob::parse_string(a.observes, observes)
+                                            : cpprob::parse_file(a.model_folder + "/" + a.observes_file, observes);
+    if (!ok) {
+        std::cerr << "Could not parse the observations.\n"
+                  << "Please use spaces to separate the observations and elements of an aggregate type instead of commas.\n";   // main.cpp:87-92
+        return EXIT_FAILURE;
+    }
+    const std::string post = a.model_folder + "/" + a.generated_file + (a.smc ? "_smc" : "_sis");                            // main.cpp:49-53
+    if (a.smc) {
+        std::cout << "Sequential Monte Carlo (SMC)" << std::endl;
+        cpprob::inference(cpprob::StateType::smc, model, observes, a.n_samples, post);
+    } else {
+        std::cout << "Sequential Importance Sampling (SIS)" << std::endl;                                                   // main.cpp:99
+        cpprob::inference(cpprob::StateType::sis, model, observes, a.n_samples, post);
+    }
+    if (a.json) print_json(cpprob::gpu::last_result());
+    if (a.estimate) {
+        std::cout << "Posterior Distribution Estimators" << std::endl;                                                      // main.cpp:104
+        std::cout << cpprob::StatsPrinter{post};
+    }
+    return EXIT_SUCCESS;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Args a;
+    auto& opt = cpprob::gpu::options();
+    for (int i = 1; i < argc; ++i) {
+        const std::string f = argv[i];
+        auto next = [&]() -> std::string { if (i + 1 >= argc) { std::cerr << "missing value for " << f << std::endl; std::exit(EXIT_FAILURE); } return argv[++i]; };
+        if (f == "--model" || f == "-m") a.model = next();
+        else if (f == "--model_folder") a.model_folder = next();
+        else if (f == "--sis") a.sis = true;
+        else if (f == "--smc") a.smc = true;
+        else if (f == "--estimate" || f == "-e") a.estimate = true;
+        else if (f == "--n_samples" || f == "-n") a.n_samples = std::stoull(next());
+        else if (f == "--observes" || f == "-o") a.observes = next();
+        else if (f == "--observes_file") a.observes_file = next();
+        else if (f == "--generated_file") a.generated_file = next();
+        else if (f == "--seed") opt.seed = std::stoull(next());
+        else if (f == "--ess_threshold") opt.ess_threshold = std::stod(next());
+        else if (f == "--resampler") { const std::string r = next(); opt.resampler = r == "multinomial" ? 2 : (r == "stratified" ? 1 : 0); }
+        else if (f == "--generic") opt.prefer_builtin = false;
+        else if (f == "--no_dump") opt.dump = false;
+        else if (f == "--json") a.json = true;
+        else { std::cerr << "unknown option " << f << std::endl; return EXIT_FAILURE; }
+    }
+    if (a.sis == a.smc) { std::cerr << "exactly one of --sis / --smc has to be set" << std::endl; return EXIT_FAILURE; }
+    try {
+        if (a.model == "gaussian_unknown_mean") return execute(models::gaussian_unknown_mean<double>, a);     // main.cpp:123-130
+        if (a.model == "gaussian_readme") return execute(models::gaussian_readme<double>, a);
+        if (a.model == "linear_gaussian_1d25") return execute(models::linear_gaussian_1d<25>, a);
+        if (a.model == "linear_gaussian_1d100") return execute(models::linear_gaussian_1d<100>, a);
+        if (a.model == "hmm16") return execute(models::hmm<16>, a);
+        if (a.model == "hmm128") return execute(models::hmm<128>, a);
+        std::cerr << "unknown model " << a.model << std::endl;
+        return EXIT_FAILURE;
+    } catch (const std::exception& e) {
+        std::cerr << "error: " << e.what() << std::endl;
+        return 2;
+    }
+}

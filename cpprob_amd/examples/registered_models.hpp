@@ -1,0 +1,18 @@
+// Host view of the model library (libcpprob_models.so, built from registered_models.hip).
+// The `extern template` lines stop a host translation unit from instantiating its own copy of a model:
+// cpprob::inference finds a model's device code by the ADDRESS of the function it is given, so host
+// code must refer to the very instantiation the model library registered (the reference links its
+// models from src/models/*.cpp the same way).  Alternative: link the host program with -rdynamic.
+#ifndef CPPROB_EXAMPLES_REGISTERED_MODELS_HPP
+#define CPPROB_EXAMPLES_REGISTERED_MODELS_HPP
+#include "target_models.hpp"
+
+namespace models {
+extern template void gaussian_unknown_mean<double>(double, double);
+extern template void gaussian_readme<double>(double, double);
+extern template void linear_gaussian_1d<25>(const std::array<double, 25>&);
+extern template void linear_gaussian_1d<100>(const std::array<double, 100>&);
+extern template void hmm<16>(const std::array<double, 16>&);
+extern template void hmm<128>(const std::array<double, 128>&);
+}
+#endif

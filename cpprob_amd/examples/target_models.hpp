@@ -1,0 +1,80 @@
+// The models of the sis/smc scope table written against the CPProb statement API, as a user would
+// write them.  They restate, statement for statement, reference include/models/models.hpp:22-35
+// (gaussian_unknown_mean), src/models/gaussian.cpp:6-17 (README variant), models.hpp:67-80
+// (linear_gaussian_1d), models.hpp:114-141 (hmm); tests compile the reference's own header instead
+// when /root/reference is available.  Nothing here is device-specific.
+#ifndef CPPROB_EXAMPLES_TARGET_MODELS_HPP
+#define CPPROB_EXAMPLES_TARGET_MODELS_HPP
+#include <array>
+#include <cmath>
+#include <cstddef>
+
+#include <boost/random/discrete_distribution.hpp>
+#include <boost/random/normal_distribution.hpp>
+#include <boost/random/uniform_smallint.hpp>
+
+#include "cpprob/cpprob.hpp"
+
+namespace models {
+
+// prior N(1, sd sqrt 5), two observes with sd sqrt 2, predict "Mu"
+template <class Real = double>
+void gaussian_unknown_mean(const Real y1, const Real y2)
+{
+    boost::random::normal_distribution<Real> prior{1, std::sqrt(5)};
+    const Real mu = cpprob::sample(prior, true);
+    boost::random::normal_distribution<Real> lik{mu, static_cast<Real>(std::sqrt(2))};
+    cpprob::observe(lik, y1);
+    cpprob::observe(lik, y2);
+    cpprob::predict(mu, "Mu");
+}
+
+// README variant: prior N(1, 1.5), likelihood sd 2, predict "Mean"
+template <class Real = double>
+void gaussian_readme(const Real x1, const Real x2)
+{
+    boost::normal_distribution<Real> prior{1, 1.5};
+    const Real mu = cpprob::sample(prior, true);
+    boost::normal_distribution<Real> lik{mu, 2};
+    cpprob::observe(lik, x1);
+    cpprob::observe(lik, x2);
+    cpprob::predict(mu, "Mean");
+}
+
+// random walk observed with unit noise; predict "State" after every observe
+template <std::size_t N>
+void linear_gaussian_1d(const std::array<double, N>& ys)
+{
+    double x = 0;
+    for (const auto y : ys) {
+        boost::random::normal_distribution<> step{x, 1};
+        x = cpprob::sample(step, true);
+        boost::random::normal_distribution<> lik{x, 1};
+        cpprob::observe(lik, y);
+        cpprob::predict(x, "State");
+    }
+}
+
+// 3-state HMM, emission N(mean[s], 1); predict "State" before every observe
+template <std::size_t N>
+void hmm(const std::array<double, N>& ys)
+{
+    constexpr int k = 3;
+    static const std::array<double, k> mean{{-1, 0, 1}};
+    static const std::array<std::array<double, k>, k> A{{{{0.1, 0.5, 0.4}}, {{0.2, 0.2, 0.6}}, {{0.15, 0.15, 0.7}}}};
+    boost::random::uniform_smallint<std::size_t> init{0, 2};
+    auto s = cpprob::sample(init, true);
+    cpprob::predict(s, "State");
+    boost::random::normal_distribution<> lik{mean[s], 1};
+    cpprob::observe(lik, ys[0]);
+    for (std::size_t t = 1; t < N; ++t) {
+        boost::random::discrete_distribution<std::size_t> next{A[s].begin(), A[s].end()};
+        s = cpprob::sample(next, true);
+        cpprob::predict(s, "State");
+        lik = boost::random::normal_distribution<>{mean[s], 1};
+        cpprob::observe(lik, ys[t]);
+    }
+}
+
+}  // namespace models
+#endif

@@ -1,0 +1,130 @@
+// Device side of the statement API (hipcc only): what cpprob::sample / observe / predict do when
+// the model body runs on a GPU lane.  Replaces the reference's process-global trace record
+// (StateInfer::trace_, src/cpprob/state.cpp:148; TraceInfer, include/cpprob/trace.hpp:34-63) by a
+// per-lane record in LDS, one particle per lane.
+//
+//   sample  #j : SIS -> a fresh draw (Philox block of (particle id, ordinal j), cpprob/detail/rng.hpp);
+//                SMC step t -> the stored value of the lane's ancestor for j < n_stored (trace replay),
+//                a fresh draw otherwise; every value is written to the lane's new trace column.
+//   observe #m : log_w += logpdf for first_observe <= m; after observe #stop_after the lane is `done`
+//                and every later statement is a no-op (SMC stops all particles at the same observe).
+//   predict    : k-th real / int hit -> column k of the particle store (only when the pointers are set).
+#ifndef CPPROB_COMPAT_DETAIL_DEVICE_TRACE_HPP
+#define CPPROB_COMPAT_DETAIL_DEVICE_TRACE_HPP
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include <boost/random/discrete_distribution.hpp>
+#include <boost/random/normal_distribution.hpp>
+#include <boost/random/uniform_real_distribution.hpp>
+#include <boost/random/uniform_smallint.hpp>
+
+#include "cpprob/detail/rng.hpp"
+#include "cpprob/distributions/utils_distributions.hpp"
+
+namespace cpprob {
+namespace device {
+
+constexpr int kLaneBlock = 256;
+
+struct LaneCtx {
+    uint64_t seed, pid;
+    double log_w;
+    const uint64_t* trace_in;     // ancestor's stored sample values, stride ld (nullptr: none)
+    uint64_t* trace_out;          // this lane's new trace column, stride ld (nullptr: do not record)
+    double* pred_real;            // this lane's predict columns, stride ld (nullptr: do not record)
+    int32_t* pred_int;
+    int64_t ld;
+    uint32_t n_sample, n_observe, n_pred_real, n_pred_int;
+    uint32_t n_stored;            // samples available in trace_in
+    uint32_t n_recorded;          // samples executed before the lane was done
+    int32_t first_observe;        // observes with a smaller index were weighted in earlier steps
+    int32_t stop_after;           // index of the observe that ends this step (-1: run to completion)
+    uint32_t done;
+};
+
+__device__ inline LaneCtx& lane_ctx()
+{
+    __shared__ LaneCtx s_ctx[kLaneBlock];
+    return s_ctx[threadIdx.x];
+}
+
+// 8-byte raw slots of the sample trace
+template <class T> __device__ inline uint64_t to_raw(T v)
+{
+    if (std::is_floating_point<T>::value) { const double d = static_cast<double>(v); return __double_as_longlong(d); }
+    return static_cast<uint64_t>(static_cast<int64_t>(v));
+}
+template <class T> __device__ inline T from_raw(uint64_t r)
+{
+    if (std::is_floating_point<T>::value) return static_cast<T>(__longlong_as_double(static_cast<long long>(r)));
+    return static_cast<T>(static_cast<int64_t>(r));
+}
+
+// ---- variate generators: stand-ins for boost::random::X::operator()(get_rng()) -------------------------
+template <class R>
+__device__ inline R draw(const boost::random::normal_distribution<R>& d, uint64_t seed, uint64_t pid, uint64_t j)
+{
+    return static_cast<R>(d.mean() + d.sigma() * cph::draw_std_normal(seed, pid, j));
+}
+template <class I>
+__device__ inline I draw(const boost::random::uniform_smallint<I>& d, uint64_t seed, uint64_t pid, uint64_t j)
+{
+    return static_cast<I>(d.a() + static_cast<I>(cph::smallint_from_word(cph::draw_word(seed, pid, j), 0, static_cast<uint64_t>(d.b() - d.a()))));
+}
+template <class I, class W>
+__device__ inline I draw(const boost::random::discrete_distribution<I, W>& d, uint64_t seed, uint64_t pid, uint64_t j)
+{
+    const auto& w = d.weights();
+    return static_cast<I>(cph::discrete_from_u_dyn(cph::u01_32(cph::draw_word(seed, pid, j)), w.p, static_cast<int>(w.n)));
+}
+template <class R>
+__device__ inline R draw(const boost::random::uniform_real_distribution<R>& d, uint64_t seed, uint64_t pid, uint64_t j)
+{
+    return static_cast<R>(cph::draw_uniform_real(seed, pid, j, d.a(), d.b()));
+}
+
+template <class Distribution>
+__device__ inline typename std::decay_t<Distribution>::result_type sample_impl(Distribution& distr)
+{
+    using R = typename std::decay_t<Distribution>::result_type;
+    LaneCtx& c = lane_ctx();
+    const uint32_t j = c.n_sample++;
+    if (c.done) return R();
+    R value;
+    if (j < c.n_stored) value = from_raw<R>(c.trace_in[(int64_t)j * c.ld]);
+    else value = draw(distr, c.seed, c.pid, (uint64_t)j);
+    if (c.trace_out) c.trace_out[(int64_t)j * c.ld] = to_raw<R>(value);
+    c.n_recorded = j + 1;
+    return value;
+}
+
+template <class Distribution, class X>
+__device__ inline void observe_impl(Distribution& distr, const X& x)
+{
+    LaneCtx& c = lane_ctx();
+    const int32_t m = (int32_t)c.n_observe++;
+    if (c.done || m < c.first_observe) return;
+    c.log_w += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
+    if (m == c.stop_after) c.done = 1;
+}
+
+template <class T>
+__device__ inline void predict_impl(const T& x)
+{
+    using V = std::decay_t<T>;
+    LaneCtx& c = lane_ctx();
+    if (c.done) return;
+    if (std::is_integral<V>::value) {                                   // state.hpp:312-318 -> predict_int_
+        const uint32_t k = c.n_pred_int++;
+        if (c.pred_int) c.pred_int[(int64_t)k * c.ld] = static_cast<int32_t>(x);
+    } else if (std::is_floating_point<V>::value) {                      // state.hpp:320-326 -> predict_real_
+        const uint32_t k = c.n_pred_real++;
+        if (c.pred_real) c.pred_real[(int64_t)k * c.ld] = static_cast<double>(x);
+    }
+}
+
+}  // namespace device
+}  // namespace cpprob
+#endif

@@ -1,0 +1,169 @@
+// Host driver of a device inference run: RAII over the C ABI (include/cpprob_hip.h), the built-in-model
+// path, the posterior file dump in the reference grammar, and the glue cpprob::inference uses.
+// Plain C++14.  Errors from the C ABI become std::runtime_error (the reference has no error returns
+// on this path: SURVEY section 8(b)).
+#ifndef CPPROB_COMPAT_DETAIL_HOST_ENGINE_HPP
+#define CPPROB_COMPAT_DETAIL_HOST_ENGINE_HPP
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iomanip>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "cpprob/detail/registry.hpp"
+#include "cpprob/detail/traits.hpp"
+#include "cpprob_hip.h"
+
+namespace cpprob {
+namespace gpu {
+
+class Context {
+public:
+    explicit Context(int device)
+    {
+        const int rc = cpprob_hip_create(device, &h_);
+        if (rc) throw std::runtime_error(std::string("cpprob_hip_create: ") + cpprob_hip_last_error(nullptr));
+    }
+    ~Context() { if (h_) cpprob_hip_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    cpprob_hip_ctx* get() const { return h_; }
+    void check(int rc, const char* what) const
+    {
+        if (rc) throw std::runtime_error(std::string(what) + ": " + cpprob_hip_last_error(h_));
+    }
+private:
+    cpprob_hip_ctx* h_ = nullptr;
+};
+
+// ---- flatten the observes tuple into doubles (scalars and std::array<double, N>) -----------------
+inline void flatten_one(std::vector<double>& out, double x) { out.push_back(x); }
+inline void flatten_one(std::vector<double>& out, float x) { out.push_back(x); }
+template <class T, std::size_t N> void flatten_one(std::vector<double>& out, const std::array<T, N>& a) { for (const auto& x : a) out.push_back(static_cast<double>(x)); }
+template <class T> void flatten_one(std::vector<double>& out, const std::vector<T>& a) { for (const auto& x : a) out.push_back(static_cast<double>(x)); }
+template <class Tuple, std::size_t... I>
+void flatten_impl(std::vector<double>& out, const Tuple& t, std::index_sequence<I...>) { (void)std::initializer_list<int>{(flatten_one(out, std::get<I>(t)), 0)...}; }
+template <class... A>
+std::vector<double> flatten(const std::tuple<A...>& t) { std::vector<double> out; flatten_impl(out, t, std::index_sequence_for<A...>{}); return out; }
+
+// ---- posterior files: StateInfer::dump_predicts / dump_ids (src/cpprob/state.cpp:250-267) -----------
+// line i of <file>.real / .int:  ([(id v) (id v) ...] logw)   scientific, precision digits10 = 15
+inline void dump_posterior(const std::string& file, const detail::TraceStructure& st, const HostStore& hs, std::size_t max_particles)
+{
+    const std::size_t n = (max_particles && max_particles < hs.n) ? max_particles : hs.n;
+    auto write = [&](const std::string& path, const std::vector<std::size_t>& ids, bool is_int) {
+        if (ids.empty()) { std::remove(path.c_str()); return; }          // all-empty files are removed (state.cpp:166-174)
+        std::ofstream f(path.c_str(), std::ios::app);                     // append mode, as the reference (state.cpp:264)
+        f.precision(std::numeric_limits<double>::digits10);
+        f << std::scientific;
+        for (std::size_t i = 0; i < n; ++i) {
+            f << "([";
+            for (std::size_t k = 0; k < ids.size(); ++k) {
+                if (k) f << ' ';
+                f << '(' << ids[k] << ' ';
+                if (is_int) f << hs.ints[k * hs.n + i]; else f << hs.real[k * hs.n + i];
+                f << ')';
+            }
+            f << "] " << hs.logw[i] << ")\n";
+        }
+    };
+    write(file + ".int", st.int_ids, true);
+    write(file + ".real", st.real_ids, false);
+    std::remove((file + ".any").c_str());
+    std::ofstream ids((file + ".ids").c_str());
+    for (const auto& a : st.addresses) ids << a << std::endl;
+}
+
+inline void fill_predict_names(Result& res, const detail::TraceStructure& st)
+{
+    res.predicts.clear();
+    for (std::size_t id : st.real_ids) { PredictStats p; p.address = st.addresses[id]; p.is_int = false; res.predicts.push_back(p); }
+    for (std::size_t id : st.int_ids) { PredictStats p; p.address = st.addresses[id]; p.is_int = true; res.predicts.push_back(p); }
+}
+
+// ---- built-in models: the hand-fused kernels behind cpprob_hip_infer_* ---------------------------
+inline void run_builtin(StateType algorithm, int model_id, const std::vector<double>& obs, std::size_t n, const detail::TraceStructure& st,
+                        const Options& opt, Result& res, HostStore* store)
+{
+    Context ctx(opt.device);
+    cpprob_hip_config cfg{};
+    cfg.algorithm = algorithm == StateType::smc ? CPPROB_HIP_ALG_SMC : CPPROB_HIP_ALG_SIS;
+    cfg.model = model_id;
+    cfg.resampler = opt.resampler;
+    cfg.resample_scope = CPPROB_HIP_SCOPE_GLOBAL;
+    cfg.keep_history = 1;
+    cfg.ess_threshold = opt.ess_threshold;
+    cfg.seed = opt.seed;
+    cfg.n_particles = n; cfg.particle_offset = 0; cfg.n_global = n;
+    ctx.check(cpprob_hip_infer_begin(ctx.get(), &cfg, obs.data(), obs.size()), "cpprob_hip_infer_begin");
+    ctx.check(cpprob_hip_infer_run(ctx.get(), 0), "cpprob_hip_infer_run");
+    cpprob_hip_summary s{};
+    ctx.check(cpprob_hip_infer_summary(ctx.get(), &s), "cpprob_hip_infer_summary");
+    const std::size_t T = static_cast<std::size_t>(s.n_predict), K = static_cast<std::size_t>(s.stats_per_predict);
+    if ((s.is_int ? st.int_ids.size() : st.real_ids.size()) != T)
+        throw std::runtime_error("built-in model kernel and the model function disagree on the number of predict statements");
+    std::vector<double> stats(T * K);
+    ctx.check(cpprob_hip_infer_stats(ctx.get(), stats.data(), stats.size()), "cpprob_hip_infer_stats");
+    res.n_particles = n; res.log_evidence = s.log_evidence; res.ess = s.ess_final; res.log_norm = s.log_norm; res.n_resampled = s.n_resampled;
+    res.used_builtin = true;
+    fill_predict_names(res, st);
+    for (std::size_t t = 0; t < T; ++t) {
+        PredictStats& p = res.predicts[t];
+        if (s.is_int) p.probabilities.assign(stats.begin() + t * K, stats.begin() + (t + 1) * K);
+        else { p.mean = stats[t * K]; p.variance = stats[t * K + 1]; }
+    }
+    res.step_ess.assign(T, 0.0);
+    ctx.check(cpprob_hip_infer_step_trace(ctx.get(), res.step_ess.data(), nullptr), "cpprob_hip_infer_step_trace");
+    if (store) {
+        store->n = n;
+        store->logw.resize(n);
+        ctx.check(cpprob_hip_copy_logw(ctx.get(), store->logw.data(), n * sizeof(double)), "cpprob_hip_copy_logw");
+        if (s.is_int) { store->ints.resize(T * n); ctx.check(cpprob_hip_copy_paths(ctx.get(), store->ints.data(), T * n * sizeof(std::int32_t)), "cpprob_hip_copy_paths"); }
+        else { store->real.resize(T * n); ctx.check(cpprob_hip_copy_paths(ctx.get(), store->real.data(), T * n * sizeof(double)), "cpprob_hip_copy_paths"); }
+    }
+}
+
+// ---- the body of cpprob::inference -------------------------------------------------------------------
+template <class Func, class... Args>
+void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>& observes, std::size_t n, const std::string& file)
+{
+    using ObsTuple = tuple_observes_t<Func>;
+    static_assert(std::tuple_size<ObsTuple>::value == sizeof...(Args), "the observes tuple must have one element per model argument");
+    const ObsTuple obs(observes);                                   // implicit conversions, as call_f_tuple's forwarding does
+
+    // structural dry run on the host (one trace): statement counts, predict types and addresses
+    detail::TraceStructure st;
+    {
+        const StateType saved = algorithm;
+        State::set(StateType::dryrun);
+        detail::recorder() = &st;
+        try { call_f_tuple(f, obs); } catch (...) { detail::recorder() = nullptr; State::set(saved); throw; }
+        detail::recorder() = nullptr;
+        State::set(saved);
+    }
+    if (st.n_observe == 0) throw std::runtime_error("cpprob::inference: the model executes no observe statement");
+    if (st.n_other_predicts) throw std::runtime_error("cpprob::inference: non-scalar predicts (.any file) are not supported by the device engine");
+
+    const Key key = key_of(f, std::integral_constant<bool, detail::fn_traits<std::remove_cv_t<std::remove_reference_t<Func>>>::is_function>{});
+    const Entry* e = find_entry(key);
+    if (!e) throw std::runtime_error("cpprob::inference: this model has no device code: compile its source with hipcc and add "
+                                     "CPPROB_REGISTER_MODEL(<model>) (or CPPROB_REGISTER_BUILTIN) -- there is no CPU fallback");
+    const Options& opt = options();
+    Result& res = last_result();
+    res = Result();
+    HostStore hs;
+    HostStore* store = opt.dump ? &hs : nullptr;
+    if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic)) run_builtin(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
+    else if (e->generic) e->generic(algorithm, &obs, n, st, opt, res, store);
+    else throw std::runtime_error("cpprob::inference: registry entry without a launcher");
+    if (opt.dump) dump_posterior(file, st, hs, opt.dump_max_particles);      // finish_trace() x n + finish_infer()
+}
+
+}  // namespace gpu
+}  // namespace cpprob
+#endif

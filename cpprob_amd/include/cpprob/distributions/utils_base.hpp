@@ -1,0 +1,11 @@
+// Trait declarations -- reference include/cpprob/distributions/utils_base.hpp:6-28.  Only logpdf is on
+// the sis/smc path; buffer/proposal/flatbuffers traits belong to the NN protocol (out of scope).
+#ifndef CPPROB_COMPAT_UTILS_BASE_HPP
+#define CPPROB_COMPAT_UTILS_BASE_HPP
+namespace cpprob {
+template <class Distribution> struct logpdf;
+template <class Distribution> struct proposal;
+template <class Distribution> struct buffer;
+template <class Distribution> struct normalise;
+}
+#endif

@@ -1,0 +1,197 @@
+// gpu.hpp -- turns an UNCHANGED CPProb model function into MI355X kernels (hipcc, C++17 only).
+//
+// A model translation unit looks like this:
+//
+//     #include "cpprob/gpu.hpp"
+//     #pragma clang force_cuda_host_device begin
+//     #include "models/models.hpp"                  // the reference's model source, untouched
+//     #pragma clang force_cuda_host_device end
+//     CPPROB_REGISTER_MODEL(models::hmm<16>);
+//
+// and from then on `cpprob::inference(StateType::sis | smc, models::hmm<16>, observes, n, file)` -- the
+// reference's call, from any C++14 host code -- runs the model body on the GPU, one particle per lane.
+//
+//   SIS : one launch; every lane runs the model to completion (cpprob.hpp:194-201 for all i at once).
+//   SMC : one launch per observe (trace replay): the lane re-runs the model from
+//         the top, `sample` statements already executed by its ancestor return the stored values, the
+//         next ones draw fresh, the step's observe adds the incremental weight and ends the lane.
+//         Between launches the C-ABI building blocks normalise the weights, test the ESS and resample
+//         (cpprob_hip_logsumexp_ess / cpprob_hip_resample); the stored sample values of the chosen
+//         ancestors are carried along by the replay itself (each step rewrites the full trace), so the
+//         final launch regenerates every predict of every surviving particle.
+// Cost: O(T^2) statement executions for T observes -- the price of not editing the model; the built-in
+// kernels (CPPROB_REGISTER_BUILTIN) are the O(T) fast path for the models they cover.
+// Restriction: the number and order of sample / observe / predict statements must not depend on sampled
+// values (true of the scope-table models; rejection-sampling loops are not supported yet).
+#ifndef CPPROB_COMPAT_GPU_HPP
+#define CPPROB_COMPAT_GPU_HPP
+#if !defined(__HIPCC__) && !defined(__HIP__)
+#error "cpprob/gpu.hpp needs hipcc (-std=c++17 --offload-arch=gfx950); host-only code includes cpprob/cpprob.hpp"
+#endif
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "cpprob/cpprob.hpp"
+
+namespace cpprob {
+namespace gpu {
+
+struct ModelKernelArgs {
+    int64_t n, ld;
+    uint64_t seed;
+    const int32_t* anc;            // nullptr: identity (no resampling before this step)
+    const double* logw_in;         // nullptr or carried log-weights (used when anc == nullptr)
+    double* logw_out;
+    const uint64_t* trace_in; uint64_t* trace_out;
+    const int32_t* nstored_in; int32_t* nstored_out;
+    double* pred_real; int32_t* pred_int;
+    int32_t first_observe, stop_after;
+};
+
+template <class FP, FP F, class Tuple>
+__global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelArgs a, const Tuple* __restrict__ observes)
+{
+    const int64_t i = (int64_t)blockIdx.x * device::kLaneBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const int64_t src = a.anc ? (int64_t)a.anc[i] : i;
+    device::LaneCtx& c = device::lane_ctx();
+    c.seed = a.seed; c.pid = (uint64_t)i; c.log_w = 0.0;
+    c.trace_in = a.trace_in ? a.trace_in + src : nullptr;
+    c.trace_out = a.trace_out ? a.trace_out + i : nullptr;
+    c.pred_real = a.pred_real ? a.pred_real + i : nullptr;
+    c.pred_int = a.pred_int ? a.pred_int + i : nullptr;
+    c.ld = a.ld;
+    c.n_sample = c.n_observe = c.n_pred_real = c.n_pred_int = 0;
+    c.n_stored = a.nstored_in ? (uint32_t)a.nstored_in[src] : 0u;
+    c.n_recorded = 0;
+    c.first_observe = a.first_observe; c.stop_after = a.stop_after; c.done = 0;
+    call_f_tuple(F, *observes);                                   // the model body, cpprob.hpp:199
+    const double carried = (a.anc == nullptr && a.logw_in) ? a.logw_in[i] : 0.0;   // equal weights after resampling
+    a.logw_out[i] = carried + c.log_w;                            // finish_trace(): the particle's log_w_
+    if (a.nstored_out) a.nstored_out[i] = (int32_t)c.n_recorded;
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { if (count && hipMalloc(&p, count * sizeof(T)) != hipSuccess) throw std::runtime_error("hipMalloc failed"); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+inline void hip_check(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <class FP, FP F>
+void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
+                      Result& res, HostStore* store)
+{
+    using Tuple = tuple_observes_t<FP>;
+    static_assert(std::is_trivially_copyable<Tuple>::value || true, "observes are copied to the device bytewise");
+    Context ctx(opt.device);
+    hip_check(hipSetDevice(opt.device), "hipSetDevice");
+    hipStream_t stream = static_cast<hipStream_t>(cpprob_hip_stream(ctx.get()));
+    const int64_t ld = (int64_t)n;
+    const size_t n_real = st.real_ids.size(), n_int = st.int_ids.size(), S = st.n_sample;
+    const int T = (int)st.n_observe;
+    const bool smc = algorithm == StateType::smc;
+
+    DevBuf<Tuple> d_obs(1);
+    hip_check(hipMemcpy(d_obs.p, observes_v, sizeof(Tuple), hipMemcpyHostToDevice), "copy observes");
+    DevBuf<double> d_real(n_real * n), d_logw0(n), d_logw1(smc ? n : 0);
+    DevBuf<int32_t> d_int(n_int * n), d_anc(smc ? n : 0), d_ns0(smc ? n : 0), d_ns1(smc ? n : 0);
+    DevBuf<uint64_t> d_tr0(smc ? S * n : 0), d_tr1(smc ? S * n : 0);
+    double* logw[2] = {d_logw0.p, d_logw1.p};
+    int32_t* ns[2] = {d_ns0.p, d_ns1.p};
+    uint64_t* tr[2] = {d_tr0.p, d_tr1.p};
+    const dim3 grid((unsigned)((n + device::kLaneBlock - 1) / device::kLaneBlock)), block(device::kLaneBlock);
+
+    ModelKernelArgs a{};
+    a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed;
+    double log_z = 0.0;
+    int cur = 0, n_resampled = 0;
+    res.step_ess.clear();
+    if (!smc) {
+        a.logw_out = logw[0]; a.pred_real = d_real.p; a.pred_int = d_int.p; a.first_observe = 0; a.stop_after = -1;
+        hipLaunchKernelGGL((model_kernel<FP, F, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
+        hip_check(hipGetLastError(), "model_kernel");
+    } else {
+        bool resampled = false;
+        for (int t = 0; t < T; ++t) {
+            const bool last = t + 1 == T;
+            a.anc = resampled ? d_anc.p : nullptr;
+            a.logw_in = t > 0 ? logw[cur] : nullptr;
+            a.logw_out = logw[cur ^ 1];
+            a.trace_in = t > 0 ? tr[cur] : nullptr; a.trace_out = tr[cur ^ 1];
+            a.nstored_in = t > 0 ? ns[cur] : nullptr; a.nstored_out = ns[cur ^ 1];
+            a.pred_real = last ? d_real.p : nullptr; a.pred_int = last ? d_int.p : nullptr;
+            a.first_observe = t; a.stop_after = last ? -1 : t;
+            hipLaunchKernelGGL((model_kernel<FP, F, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
+            hip_check(hipGetLastError(), "model_kernel");
+            cur ^= 1;
+            double o3[3];
+            ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), logw[cur], n, o3), "cpprob_hip_logsumexp_ess");
+            res.step_ess.push_back(o3[2]);
+            resampled = !last && (o3[2] < opt.ess_threshold * (double)n);          // ESS test, thesis p.37
+            if (resampled) {
+                ctx.check(cpprob_hip_resample(ctx.get(), opt.resampler, logw[cur], n, opt.seed, (uint64_t)(t + 1), 0, n, n, d_anc.p), "cpprob_hip_resample");
+                log_z += o3[1] - std::log((double)n);
+                ++n_resampled;
+            }
+        }
+    }
+    double o3[3];
+    ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), logw[cur], n, o3), "cpprob_hip_logsumexp_ess");
+    log_z += o3[1] - std::log((double)n);
+    res.n_particles = n; res.log_evidence = log_z; res.log_norm = o3[1]; res.ess = o3[2]; res.n_resampled = n_resampled; res.used_builtin = false;
+    fill_predict_names(res, st);
+    for (size_t k = 0; k < n_real; ++k) {
+        double o4[4];
+        ctx.check(cpprob_hip_weighted_moments(ctx.get(), d_real.p + k * n, logw[cur], n, o4), "cpprob_hip_weighted_moments");
+        res.predicts[k].mean = o4[0]; res.predicts[k].variance = o4[1];
+    }
+    for (size_t k = 0; k < n_int; ++k) {
+        double h[8];
+        ctx.check(cpprob_hip_weighted_hist(ctx.get(), d_int.p + k * n, logw[cur], n, 8, h), "cpprob_hip_weighted_hist");
+        int top = 8;
+        while (top > 1 && h[top - 1] == 0.0) --top;
+        res.predicts[n_real + k].probabilities.assign(h, h + top);
+    }
+    if (store) {
+        store->n = n;
+        store->logw.resize(n); store->real.resize(n_real * n); store->ints.resize(n_int * n);
+        hip_check(hipMemcpyAsync(store->logw.data(), logw[cur], n * sizeof(double), hipMemcpyDeviceToHost, stream), "copy logw");
+        if (n_real) hip_check(hipMemcpyAsync(store->real.data(), d_real.p, n_real * n * sizeof(double), hipMemcpyDeviceToHost, stream), "copy real predicts");
+        if (n_int) hip_check(hipMemcpyAsync(store->ints.data(), d_int.p, n_int * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy int predicts");
+    }
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+}
+
+template <class FP, FP F>
+bool register_model(const char* name)
+{
+    Entry e; e.name = name; e.generic = &generic_launcher<FP, F>;
+    return add_entry(Key{reinterpret_cast<const void*>(F), 0}, e);
+}
+
+// functor models (e.g. models::Gauss<>): keyed by type, called through a default-constructed instance
+template <class Functor> struct functor_thunk;
+template <class Functor>
+bool register_functor(const char* name);
+
+}  // namespace gpu
+}  // namespace cpprob
+
+#define CPPROB_REGISTER_MODEL(fn) \
+    static const bool CPPROB_PP_CAT(cpprob_reg_model_, __LINE__) = ::cpprob::gpu::register_model<decltype(&fn), &fn>(#fn)
+
+#endif

@@ -1,0 +1,47 @@
+// Host-visible results and options of a device inference run (additions to the reference API; the
+// reference returns nothing and leaves everything in files).
+#ifndef CPPROB_COMPAT_GPU_RESULT_HPP
+#define CPPROB_COMPAT_GPU_RESULT_HPP
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "cpprob_hip.h"
+
+namespace cpprob {
+namespace gpu {
+
+struct Options {
+    int device = 0;
+    std::uint64_t seed = 12345;
+    int resampler = CPPROB_HIP_RESAMPLE_SYSTEMATIC;   // smc
+    double ess_threshold = 0.5;                       // smc: resample when ESS < threshold * N (thesis p.37); > 1: every step
+    bool dump = true;                                 // write <file>.real/.int/.ids like the reference (state.cpp:193-202)
+    std::size_t dump_max_particles = 0;               // 0 = all particles
+    bool prefer_builtin = true;                       // use the hand-fused kernels when the model is one of the built-ins
+    bool progress = false;
+};
+
+struct PredictStats {            // one per predict hit, StatsPrinter's numbers
+    std::string address;
+    bool is_int = false;
+    double mean = 0, variance = 0;            // real predicts
+    std::vector<double> probabilities;        // int predicts: P(x = s), s = 0..k-1
+};
+
+struct Result {
+    std::size_t n_particles = 0;
+    double log_evidence = 0, ess = 0, log_norm = 0;
+    int n_resampled = 0;
+    bool used_builtin = false;
+    std::vector<PredictStats> predicts;       // real hits first (in trace order), then int hits
+    std::vector<double> step_ess;             // smc: ESS after each observe
+};
+
+inline Options& options() { static thread_local Options o; return o; }
+inline Result& last_result() { static thread_local Result r; return r; }
+
+}  // namespace gpu
+}  // namespace cpprob
+#endif
