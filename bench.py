@@ -79,9 +79,17 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0):
     import torch.distributed as dist
     from cpprob_amd import distributed as D
 
+    coll = D.TorchCollective(eng) if (world > 1 and not island) else None
+    bufs = None
+    if coll is not None:
+        bufs = (torch.zeros(4, dtype=torch.float64, device=device), torch.zeros(3 * world, dtype=torch.float64, device=device), None)
+
     def one(i):
-        if island and world > 1:
-            return D.run_islands(eng, i, device)
+        if world > 1 and island:
+            return D.run_islands(eng, i, device)          # no data-path collective; one all-gather of summaries per run
+        if world > 1:
+            st, _ = D.run_joint(eng, coll, i, bufs)       # one RCCL all-gather of 3 doubles per rank per step
+            return (st,)
         eng.run(i)
         return None
 
@@ -147,10 +155,8 @@ def main():
     T = 1 if args.workload == "gaussian_sis" else len(spec["obs"])
     scope = args.scope
     if scope == "auto":
-        scope = "global" if world == 1 or spec["alg"] == cp.ALG_SIS else "island"
+        scope = "global"          # one joint population: per-step all-gather of the weight totals (north_star)
     island = scope == "island"
-    if world > 1 and not island and spec["alg"] == cp.ALG_SMC:
-        raise SystemExit("joint (global-scope) resampling across ranks is driven by cpprob_amd.distributed; use --scope island")
     eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
               particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND if island else cp.SCOPE_GLOBAL)
 
@@ -165,8 +171,13 @@ def main():
         stats = eng.stats()
     err = float(np.abs(stats - spec["exact"]).max())
     summ = eng.summary()
+    collective = "none" if world == 1 else ("all_gather(1+T*K doubles) once per run" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
 
     # profiled pass: same K steps with HIP events around every launch on the engine's stream
+    # (per-shard kernels only: on several GPUs each rank profiles its own shard as an island)
+    if world > 1 and not island:
+        eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
+                  particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND)
     eng.profile_enable(True)
     eng.profile_read(reset=True)
     for i in range(args.steps):
@@ -191,7 +202,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s, %d particles per GPU" % (spec["desc"], n), "particles_per_gpu": n, "T": T,
-                   "resampler": "systematic", "ess_threshold": spec["ess"], "scope": scope, "n_global": n_global},
+                   "resampler": "systematic", "ess_threshold": spec["ess"], "scope": scope, "n_global": n_global, "collective": collective},
         "particle_steps_per_sec": value * T,
         "roofline": roofline,
         "posterior_max_abs_err_vs_exact": err, "log_evidence": summ["log_evidence"], "n_resampled": summ["n_resampled"],

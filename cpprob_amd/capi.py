@@ -75,7 +75,7 @@ def load_library(path=None):
         "cpprob_hip_copy_ancestors": (C.c_int, [vp, vp, sz]),
         "cpprob_hip_copy_logw": (C.c_int, [vp, vp, sz]),
         "cpprob_hip_copy_paths": (C.c_int, [vp, vp, sz]),
-        "cpprob_hip_smc_step_begin": (C.c_int, [vp, i32, C.POINTER(vp)]),
+        "cpprob_hip_smc_step_begin": (C.c_int, [vp, i32, u64, vp]),
         "cpprob_hip_smc_step_end": (C.c_int, [vp, i32, vp, i32, i32]),
         "cpprob_hip_smc_finish": (C.c_int, [vp]),
         "cpprob_hip_philox_blocks": (C.c_int, [vp, u64, u64, u64, sz, vp]),
@@ -213,13 +213,12 @@ class Engine:
         return out
 
     # ---- sharded SMC ---------------------------------------------------------------------
-    def step_begin(self, t):
-        p = C.c_void_p()
-        self._chk(self.L.cpprob_hip_smc_step_begin(self.h, int(t), C.byref(p)))
-        return p.value
+    def step_begin(self, t, local_totals, run_index=0):
+        """local_totals: torch float64 tensor (>= 3) on this device, filled on the engine's stream."""
+        self._chk(self.L.cpprob_hip_smc_step_begin(self.h, int(t), int(run_index), _dptr(local_totals)))
 
-    def step_end(self, t, all_totals_ptr, world, rank):
-        self._chk(self.L.cpprob_hip_smc_step_end(self.h, int(t), C.c_void_p(all_totals_ptr), int(world), int(rank)))
+    def step_end(self, t, all_totals, world, rank):
+        self._chk(self.L.cpprob_hip_smc_step_end(self.h, int(t), _dptr(all_totals), int(world), int(rank)))
 
     def finish(self):
         self._chk(self.L.cpprob_hip_smc_finish(self.h))

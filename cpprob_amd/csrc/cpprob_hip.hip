@@ -61,6 +61,8 @@ struct cpprob_hip_ctx {
     double* d_cdf = nullptr;        // multinomial only
     int32_t* d_anc_pre = nullptr;   // multinomial only
     double* d_local_totals = nullptr;
+    double* totals_out = nullptr;   // caller-provided {max, sum, sum of squares} of the shard (step protocol)
+    bool sharded = false;           // the last run went through the step protocol: stats stay un-normalised
     int cur = 0;                    // logw buffer holding the latest generation
     size_t cap_particles = 0; int cap_T = 0; bool cap_int = false; bool cap_multinomial = false;
 
@@ -170,7 +172,7 @@ int bb_normalise(cpprob_hip_ctx* ctx, const double* d_logw, size_t n, double n_t
     hipLaunchKernelGGL(weights_partials_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, d_logw, (int64_t)n, ctx->d_bb_part, ctx->d_bb_wrel);
     ScanArgs sa{};
     sa.part = ctx->d_bb_part; sa.nb = nb; sa.bc = ctx->d_bb_bc; sa.bf = ctx->d_bb_bf; sa.ctrl = ctx->d_bb_ctrl; sa.t = 0; sa.T = 1;
-    sa.n_pop = n_total; sa.ess_frac = 0.0; sa.force_no_resample = 1; sa.phase = 0; sa.seed = 0;
+    sa.n_pop = n_total; sa.n_local = (double)n; sa.ess_frac = 0.0; sa.force_no_resample = 1; sa.phase = 0; sa.seed = 0;
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, sa);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
@@ -191,7 +193,7 @@ void launch_step(cpprob_hip_ctx* c, int t)
 {
     StepArgs<Model> a{};
     a.mp = c->mp; a.obs = c->d_obs; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.seed = c->run_seed;
-    a.pid0 = c->cfg.particle_offset; a.n_pop = c->pop_n; a.pos0 = c->pos0;
+    a.pid0 = c->cfg.particle_offset;
     a.values = static_cast<typename Model::value_t*>(c->d_values); a.anc = c->d_anc;
     a.logw_prev = c->d_logw[c->cur]; a.logw_next = c->d_logw[c->cur ^ 1];
     a.wrel_prev = c->d_wrel[c->cur]; a.wrel_next = c->d_wrel[c->cur ^ 1];
@@ -202,7 +204,7 @@ void launch_step(cpprob_hip_ctx* c, int t)
         ProfScope ps(c, 5);
         hipLaunchKernelGGL(cdf_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, c->d_wrel[c->cur], c->d_bc, c->d_bf, c->d_ctrl, c->d_cdf);
         hipLaunchKernelGGL(multinomial_kernel, dim3((unsigned)((c->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, c->d_cdf, c->n,
-                           c->d_ctrl, c->run_seed, (uint64_t)t, c->pos0, c->n, c->d_anc_pre);
+                           c->d_ctrl, c->run_seed, (uint64_t)t, c->cfg.particle_offset, c->n, c->d_anc_pre);
     }
     ProfScope ps(c, 0);
     switch (c->cfg.resampler) {
@@ -220,10 +222,10 @@ void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, 
 {
     ScanArgs sa{};
     sa.part = c->d_part; sa.nb = c->nb; sa.bc = c->d_bc; sa.bf = c->d_bf; sa.ctrl = c->d_ctrl; sa.t = t; sa.T = c->T;
-    sa.n_pop = (double)c->pop_n; sa.ess_frac = c->cfg.ess_threshold; sa.seed = c->run_seed;
+    sa.n_pop = (double)c->pop_n; sa.n_local = (double)c->n; sa.ess_frac = c->cfg.ess_threshold; sa.seed = c->run_seed;
     sa.ess_trace = c->d_ess; sa.resampled = c->d_resampled;
     sa.force_no_resample = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
-    sa.all_totals = all_totals; sa.world = world; sa.rank = rank; sa.local_totals = c->d_local_totals; sa.phase = phase;
+    sa.all_totals = all_totals; sa.world = world; sa.rank = rank; sa.local_totals = c->totals_out ? c->totals_out : c->d_local_totals; sa.phase = phase;
     ProfScope ps(c, 1);
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, sa);
 }
@@ -244,7 +246,7 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
     }
     ProfScope ps(c, 3);
     hipLaunchKernelGGL(finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream,
-                       c->d_stats_part, c->smooth_grid, c->T, Model::kStats, Model::kIsInt ? 1 : 0, c->d_ctrl, c->d_stats, 1);
+                       c->d_stats_part, c->smooth_grid, c->T, Model::kStats, Model::kIsInt ? 1 : 0, c->d_ctrl, c->d_stats, c->sharded ? 0 : 1);
 }
 
 template <class F>
@@ -416,8 +418,11 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
     if (!c->begun) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_infer_begin has not been called");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->cfg.resample_scope == CPPROB_HIP_SCOPE_GLOBAL && c->cfg.n_global != c->cfg.n_particles)
+        return fail(c, CPPROB_HIP_ESTATE, "this context holds one shard of a joint population: drive it with cpprob_hip_smc_step_begin/_end/_finish");
     c->run_seed = c->cfg.seed + run_index;
     c->cur = 0;
+    c->sharded = false;
     if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
         dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
         launch_scan(c, c->T - 1, 0, nullptr, 1, 0);
@@ -433,23 +438,21 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     return 0;
 }
 
-int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, double** d_local_totals)
+int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, double* d_local_totals)
 {
     if (!c || !d_local_totals) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->begun) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_infer_begin has not been called");
     if (t < 0 || t >= c->T) return fail(c, CPPROB_HIP_EINVAL, "step out of range");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (t == 0) { c->run_seed = c->cfg.seed; c->cur = 0; }
-    if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
-        if (t != c->T - 1) return fail(c, CPPROB_HIP_EINVAL, "SIS shards run in one launch: call step_begin(T-1) only");
-        c->cur = 0;
-        dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
-    } else {
-        dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
-    }
+    const bool sis = c->cfg.algorithm == CPPROB_HIP_ALG_SIS;
+    if (sis && t != c->T - 1) return fail(c, CPPROB_HIP_EINVAL, "SIS shards run in one launch: call step_begin(T-1) only");
+    if (t == 0 || sis) { c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->ran = false; }
+    if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
+    else dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
+    c->totals_out = d_local_totals;
     launch_scan(c, t, 1, nullptr, 1, 0);
     HIP_TRY(c, hipGetLastError());
-    *d_local_totals = c->d_local_totals;
+    c->sharded = true;
     return 0;
 }
 

@@ -43,7 +43,9 @@ struct StepCtrl {
     double w_local;   // this shard's sum rescaled to M
     double scale;     // exp(M_local - M): rescales bc[] / bf[] (built against the local max) to M
     double u0;        // systematic offset in [0,1) of the resampling that precedes the NEXT step
-    double inv_stepw; // N_population / W: positions -> output indices
+    double inv_stepw; // n_local / (local weight sum, local units): CDF positions -> local output indices
+    double lw_after;  // log-weight every particle of this shard carries right after resampling: log of the
+                      // shard's mean weight over the population's mean weight (0 on a single shard)
     int32_t do_resample;  // decision taken after the last weighted step
     int32_t n_resampled;
     int32_t pad[2];
@@ -119,7 +121,8 @@ struct ScanArgs {
     const Partial* part; int nb;
     double* bc; double* bf; StepCtrl* ctrl;
     int t, T;
-    double n_pop, ess_frac;    // population the shard is resampled with
+    double n_pop, ess_frac;    // joint population size (ESS test, evidence)
+    double n_local;            // particles of this shard
     uint64_t seed;
     double* ess_trace; int32_t* resampled;
     int force_no_resample;     // SIS: never resample
@@ -195,7 +198,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
         if (a.t == 0) { ctrl->log_z = 0.0; ctrl->n_resampled = 0; }
         if (rs || last) ctrl->log_z += M + log(W / a.n_pop);
         if (rs) ctrl->n_resampled += 1;
-        ctrl->inv_stepw = a.n_pop / W;
+        // Resampling is local to the shard (particles never migrate): outputs 0..n_local-1 are drawn over the
+        // shard's own CDF, and the shard's share of the total mass is carried by lw_after
+        // (distributed resampling with non-proportional allocation; exact for one shard, where lw_after = 0).
+        const double w_loc_units = a.bc[a.nb];                       // local sum in local-max units
+        ctrl->inv_stepw = a.n_local / w_loc_units;
+        ctrl->lw_after = (a.phase == 2) ? log((ctrl->w_local / a.n_local) / (W / a.n_pop)) : 0.0;
         const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(a.t + 1));
         ctrl->u0 = u01_53(r.x, r.y);
         if (a.ess_trace) a.ess_trace[a.t] = ess;
@@ -225,6 +233,7 @@ struct AncestorIn {
     const double* wrel; const double* bc; const double* bf; int nb; int64_t n_in;
     double W, scale, cdf_lo, u0, inv_stepw;
     uint64_t seed, step, gj_tile0, n_total_out; int n_valid_tile;
+    uint64_t id0;      // RNG id of output 0 (stratified offsets are drawn per global particle id)
 };
 
 __device__ __forceinline__ int stage_window(const AncestorIn& in, AncestorLds& L, double q_guess)
@@ -332,7 +341,7 @@ __device__ __forceinline__ void ancestors_stratified(const AncestorIn& in, int32
     double p[kPPT];
     {
         uint32_t wd[4];
-        draw_words4(in.seed, gj0, kResampleDrawBase + in.step, wd);
+        draw_words4(in.seed, in.id0 + gj0, kResampleDrawBase + in.step, wd);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) { p[k] = ((double)(gj0 + k) + u01_32(wd[k])) * stepw - in.cdf_lo; anc[k] = 0; }
     }
@@ -401,7 +410,7 @@ __device__ __forceinline__ void ancestors_stratified(const AncestorIn& in, int32
         __syncthreads();
         // outputs are sorted, so the resolved ones are a prefix: the next position is that of output #cnt
         const uint64_t gjn = in.gj_tile0 + (uint64_t)L.cnt;
-        const double p_next = ((double)gjn + u01_32(draw_word(in.seed, gjn, kResampleDrawBase + in.step))) * stepw - in.cdf_lo;
+        const double p_next = ((double)gjn + u01_32(draw_word(in.seed, in.id0 + gjn, kResampleDrawBase + in.step))) * stepw - in.cdf_lo;
         c = locate(p_next, c + 1);
     }
 }
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(ResampleArgs a)
     }
     in.seed = a.seed; in.step = a.step; in.gj_tile0 = a.j0 + (uint64_t)blockIdx.x * kTile; in.n_total_out = a.n_total_out;
     in.n_valid_tile = rem < kTile ? (int)rem : kTile;
+    in.id0 = 0;
     int32_t anc[kPPT];
     find_ancestors<RS>(in, anc, L);
 #pragma unroll
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(kThreads) void multinomial_kernel(const double* __r
 {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= n_out) return;
-    const double p = draw_u01_53(seed, j0 + (uint64_t)i, kResampleDrawBase + step) * ctrl->W - ctrl->cdf_lo;
+    const double p = draw_u01_53(seed, j0 + (uint64_t)i, kResampleDrawBase + step) * cdf[n_in - 1];
     int64_t lo = 0, hi = n_in;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
 template <class Model>
 struct StepArgs {
     ModelParams mp; const double* obs; int t, T; int64_t n, ld;
-    uint64_t seed, pid0, pos0, n_pop;   // pid0: RNG id of local slot 0; pos0: index of local slot 0 in the resampled population
+    uint64_t seed, pid0;   // pid0: RNG id of local slot 0
     typename Model::value_t* values; int32_t* anc;
     const double* logw_prev; double* logw_next;
     const double* wrel_prev; double* wrel_next;
@@ -554,13 +564,15 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
             const int64_t rem = a.n - (int64_t)blockIdx.x * kTile;
             AncestorIn in;
             in.wrel = a.wrel_prev; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n;
-            in.W = a.ctrl->W; in.scale = a.ctrl->scale; in.cdf_lo = a.ctrl->cdf_lo; in.u0 = a.ctrl->u0; in.inv_stepw = a.ctrl->inv_stepw;
-            in.seed = a.seed; in.step = (uint64_t)t; in.gj_tile0 = a.pos0 + (uint64_t)blockIdx.x * kTile; in.n_total_out = a.n_pop;
+            in.W = a.bc[a.nb]; in.scale = 1.0; in.cdf_lo = 0.0; in.u0 = a.ctrl->u0; in.inv_stepw = a.ctrl->inv_stepw;
+            in.seed = a.seed; in.step = (uint64_t)t; in.gj_tile0 = (uint64_t)blockIdx.x * kTile; in.n_total_out = (uint64_t)a.n;
+            in.id0 = a.pid0;
             in.n_valid_tile = rem < kTile ? (int)rem : kTile;
             find_ancestors<RS>(in, anc, L);
         }
+        const double lwa = a.ctrl->lw_after;
 #pragma unroll
-        for (int k = 0; k < kPPT; ++k) lw[k] = 0.0;          // equal weights after resampling
+        for (int k = 0; k < kPPT; ++k) lw[k] = lwa;          // equal weights after resampling (the shard's mass share)
     }
 
     V prev[kPPT], x[kPPT];

@@ -14,10 +14,14 @@ Two scopes (include/cpprob_hip.h, cpprob_hip_config.resample_scope):
           to ~1e-3 relative, so the efficiency loss against one joint population is negligible).
           Communication: one all-gather of (1 + T*K) doubles per rank per run.
 
-  GLOBAL  one joint population: per step every rank all-gathers its (max, sum, sum-of-squares)
-          of weights so all ranks agree on the global normaliser, ESS and the resampling
-          decision (cpprob_hip_smc_step_begin/_end).  SIS needs only this (no resampling);
-          joint resampling with ancestor redistribution is driven from here too.
+  GLOBAL  one joint population of n_global particles: per step every rank all-gathers its
+          (max, sum, sum-of-squares) of weights (3 doubles per rank -- latency-bound, RCCL over xGMI)
+          so all ranks agree ON DEVICE on the joint normaliser, evidence, ESS and the resampling
+          decision (cpprob_hip_smc_step_begin / _end).  Resampling is then local to each shard
+          and the shard's particles carry its share of the mass (distributed resampling with
+          non-proportional allocation): particles never migrate, nothing but the 3 doubles crosses
+          xGMI, and there is no host synchronisation inside a run.  With one rank this is exactly
+          the single-GPU algorithm.  At the end the un-normalised weighted sums are all-reduced.
 
 Host logic in this file is pure numpy/torch and is covered by gloo world_size-2 tests on CPU.
 """
@@ -105,3 +109,67 @@ def run_islands(engine, run_index=0, device=None):
     allv = allgather_vector(vec, device)
     out, lz, _, iess = combine_islands(allv[:, 0], allv[:, 1:].reshape(allv.shape[0], *st.shape), engine.is_int)
     return out, lz, iess
+
+
+# ---- joint population (GLOBAL scope) ------------------------------------------------------------
+
+class TorchCollective:
+    """all-gather / all-reduce of small float64 device tensors on the ENGINE's stream (no host sync):
+    torch.distributed orders the RCCL kernel after the work already queued on the current stream."""
+
+    def __init__(self, engine):
+        import torch
+        import torch.distributed as dist
+        self.dist = dist
+        self.torch = torch
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.stream = torch.cuda.ExternalStream(engine.stream_ptr, device=torch.device("cuda", engine.device))
+
+    def all_gather(self, local, out):
+        if self.world == 1:
+            with self.torch.cuda.stream(self.stream):
+                out.copy_(local[: out.numel()])
+            return
+        with self.torch.cuda.stream(self.stream):
+            self.dist.all_gather_into_tensor(out, local[: out.numel() // self.world].contiguous())
+
+    def all_reduce_sum(self, t):
+        if self.world == 1:
+            return
+        with self.torch.cuda.stream(self.stream):
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+
+def normalise_joint_stats(raw, log_norm, max_logw, is_int):
+    """raw [T, K]: all-reduced un-normalised sums relative to exp(max_logw).  Returns StatsPrinter's numbers."""
+    raw = np.asarray(raw, np.float64)
+    W = np.exp(log_norm - max_logw)
+    if is_int:
+        return raw / W
+    mean = raw[:, 0] / W
+    return np.stack([mean, raw[:, 1] / W - mean * mean], axis=1)      # raw_moment(2) - mean^2, empirical_distribution.hpp:78-81
+
+
+def run_joint(engine, collective, run_index=0, buffers=None):
+    """One run of a joint population sharded over `collective.world` ranks (engine begun with
+    scope=SCOPE_GLOBAL, n_global = sum of shards).  Returns (stats[T, K], summary dict)."""
+    import torch
+    from . import capi
+    dev = torch.device("cuda", engine.device)
+    world, rank = collective.world, collective.rank
+    if buffers is None:
+        buffers = (torch.zeros(4, dtype=torch.float64, device=dev), torch.zeros(3 * world, dtype=torch.float64, device=dev),
+                   torch.zeros(engine.T * engine.K, dtype=torch.float64, device=dev))
+    local, allt, _ = buffers
+    steps = [engine.T - 1] if engine.cfg.algorithm == capi.ALG_SIS else range(engine.T)
+    for t in steps:
+        engine.step_begin(t, local, run_index)
+        collective.all_gather(local, allt)
+        engine.step_end(t, allt, world, rank)
+    engine.finish()
+    s = engine.summary()
+    raw = torch.from_numpy(engine.stats()).to(dev)
+    collective.all_reduce_sum(raw)
+    stats = normalise_joint_stats(raw.cpu().numpy(), s["log_norm"], s["max_logw"], engine.is_int)
+    return stats, s

@@ -147,13 +147,20 @@ int cpprob_hip_copy_ancestors(cpprob_hip_ctx* ctx, int32_t* h_anc, size_t n_byte
 int cpprob_hip_copy_logw(cpprob_hip_ctx* ctx, double* h_logw, size_t n_bytes);
 int cpprob_hip_copy_paths(cpprob_hip_ctx* ctx, void* h_paths, size_t n_bytes);
 
-/* ---- sharded SMC (one context per GPU; the caller runs the collective) -------------------
- * Per step: step_begin(t) propagates and weighs the local shard and leaves this shard's
- * (max logw, sum exp(logw-max), sum exp(2(logw-max))) in d_local_totals (3 doubles, device);
- * the caller all-gathers those over ranks (RCCL) into d_all_totals[3*world]; step_end(t)
- * combines them into the global normaliser / ESS / resampling decision on device.
- * See cpprob_amd/distributed.py and DESIGN.md section "Multi-GPU". */
-int cpprob_hip_smc_step_begin(cpprob_hip_ctx* ctx, int32_t t, double** d_local_totals);
+/* ---- one joint population sharded over several contexts (one per GPU; the caller runs the collective) --
+ * cfg.resample_scope = GLOBAL with n_global > n_particles.  Per step t = 0..T-1 (SIS: t = T-1 only):
+ *   step_begin(t) propagates and weighs the local shard and writes this shard's
+ *                 {max logw, sum exp(logw-max), sum exp(2(logw-max))} to d_local_totals (3 doubles, device);
+ *   the caller all-gathers those over ranks (RCCL) into d_all_totals[3*world];
+ *   step_end(t)   combines them ON DEVICE into the joint normaliser, ESS, evidence and resampling decision.
+ * Resampling itself is local to the shard -- particles never migrate; right after a resampling step the
+ * shard's particles carry log(shard mean weight / population mean weight), i.e. the shard's share of the
+ * mass (distributed resampling with non-proportional allocation).  With world = 1 the protocol is
+ * bit-identical to cpprob_hip_infer_run.  finish() runs the posterior read-out; cpprob_hip_infer_stats then
+ * returns UN-NORMALISED weighted sums relative to exp(max_logw) -- real: {sum w x, sum w x^2}, int:
+ * {sum w [x = s]} -- which the caller all-reduces and divides by W = exp(log_norm - max_logw)
+ * (cpprob_amd/distributed.py; DESIGN.md section "Multi-GPU").  Everything is stream-ordered: no host sync. */
+int cpprob_hip_smc_step_begin(cpprob_hip_ctx* ctx, int32_t t, uint64_t run_index, double* d_local_totals);
 int cpprob_hip_smc_step_end(cpprob_hip_ctx* ctx, int32_t t, const double* d_all_totals, int32_t world, int32_t rank);
 int cpprob_hip_smc_finish(cpprob_hip_ctx* ctx);
 

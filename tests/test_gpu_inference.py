@@ -208,9 +208,13 @@ def test_sharded_ids_reproduce_single_shard(engine):
     engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, obs, 10000, seed=5)
     engine.run()
     full = engine.values()[0].copy()
-    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, obs, 2500, seed=5, particle_offset=5000, n_global=10000)
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, obs, 2500, seed=5, particle_offset=5000, n_global=10000, scope=cp.SCOPE_ISLAND)
     engine.run()
     assert np.array_equal(engine.values()[0], full[5000:7500])
+    # a shard of a JOINT population must go through the step protocol
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, obs, 2500, seed=5, particle_offset=5000, n_global=10000)
+    with pytest.raises(cp.CpprobHipError):
+        engine.run()
 
 
 def test_error_paths(engine):
@@ -228,3 +232,94 @@ def test_error_paths(engine):
     engine.run()
     with pytest.raises(cp.CpprobHipError):
         engine.ancestors()                                              # SIS keeps none
+
+
+# ---- joint population sharded over several contexts (virtual ranks on one GPU) -----------------------
+
+class _InProcessCollective:
+    """Test double for RCCL: the shards live in contexts of ONE process on one GPU; the all-gather is a
+    concatenation.  (The product's TorchCollective is exercised with world = 1 below.)"""
+
+    def __init__(self, engines, rank):
+        self.engines, self.rank, self.world = engines, rank, len(engines)
+
+
+def _run_joint_virtual(model, alg, obs, n_per, world, seed, ess):
+    import torch
+    from cpprob_amd import distributed as D
+    engines = [cp.Engine(0) for _ in range(world)]
+    for r, e in enumerate(engines):
+        e.begin(alg, model, obs, n_per, seed=seed, ess_threshold=ess, particle_offset=r * n_per, n_global=world * n_per, scope=cp.SCOPE_GLOBAL)
+    T, K = engines[0].T, engines[0].K
+    locals_ = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in range(world)]
+    allt = torch.zeros(3 * world, dtype=torch.float64, device="cuda")
+    steps = [T - 1] if alg == cp.ALG_SIS else range(T)
+    for t in steps:
+        for r, e in enumerate(engines):
+            e.step_begin(t, locals_[r])
+        for e in engines:
+            e.sync()
+        allt.copy_(torch.cat([l[:3] for l in locals_]))
+        torch.cuda.synchronize()
+        for r, e in enumerate(engines):
+            e.step_end(t, allt, world, r)
+    raw = np.zeros((T, K))
+    summ = None
+    for e in engines:
+        e.finish()
+        raw += e.stats()
+        s = e.summary()
+        if summ is not None:
+            assert s["log_evidence"] == summ["log_evidence"] and s["log_norm"] == summ["log_norm"]     # identical on every rank
+        summ = s
+    stats = D.normalise_joint_stats(raw, summ["log_norm"], summ["max_logw"], engines[0].is_int)
+    traces = [e.step_trace() for e in engines]
+    for e in engines:
+        e.close()
+    return stats, summ, traces
+
+
+def test_step_protocol_world1_is_bit_identical_to_run(engine, golden_dir):
+    import torch
+    from cpprob_amd import distributed as D
+    obs = _obs(golden_dir, "hmm16")
+    n = 30000
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, ess_threshold=0.5)
+    engine.run()
+    ref_stats, ref_sum, ref_vals = engine.stats().copy(), engine.summary(), engine.values().copy()
+    coll = D.TorchCollective(engine)
+    stats, s = D.run_joint(engine, coll)
+    assert np.array_equal(engine.values(), ref_vals)
+    np.testing.assert_allclose(stats, ref_stats, rtol=1e-13, atol=1e-15)
+    assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_joint_population_over_virtual_ranks_smc(golden_dir, world):
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    n_per = 100000
+    stats, s, traces = _run_joint_virtual(cp.MODEL_HMM3, cp.ALG_SMC, z["hmm16"], n_per, world, 21, 2.0)
+    assert s["n_resampled"] == 15
+    np.testing.assert_allclose(stats.sum(axis=1), 1.0, rtol=1e-10)
+    assert np.abs(stats - z["hmm16_smooth"]).max() < 0.03
+    assert np.abs(stats[-1] - z["hmm16_smooth"][-1]).max() < 5e-3
+    assert abs(s["log_evidence"] - float(z["hmm16_logz"])) < 0.02
+    for ess, res in traces:                       # joint ESS / decisions agree on all ranks
+        assert np.array_equal(res, traces[0][1]) and np.allclose(ess, traces[0][0], rtol=1e-12)
+    # ESS-triggered LGSSM
+    stats, s, _ = _run_joint_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, cp.ALG_SMC, z["lgssm100"][:30], n_per, world, 22, 0.5)
+    from oracle import exact as E
+    ms, ps, _, _, ll = E.kalman_rts(z["lgssm100"][:30])
+    assert abs(stats[-1, 0] - ms[-1]) < 0.02 and abs(stats[-1, 1] - ps[-1]) < 0.02 and abs(s["log_evidence"] - ll) < 0.05
+    assert 0 < s["n_resampled"] < 29
+
+
+def test_joint_population_sis_equals_single_shard(engine):
+    """SIS shards: ids are global, so 4 shards of 25000 hold exactly the particles of one run of 100000."""
+    obs = [3.0, 4.0]
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, obs, 100000, seed=8)
+    engine.run()
+    ref, rs = engine.stats().copy(), engine.summary()
+    stats, s, _ = _run_joint_virtual(cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, cp.ALG_SIS, obs, 25000, 4, 8, 2.0)
+    np.testing.assert_allclose(stats, ref, rtol=1e-10)
+    assert abs(s["log_evidence"] - rs["log_evidence"]) < 1e-12 and abs(s["ess_final"] - rs["ess_final"]) < 1e-6 * rs["ess_final"]
