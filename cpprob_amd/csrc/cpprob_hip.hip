@@ -51,7 +51,9 @@ struct cpprob_hip_ctx {
     void* d_values = nullptr;
     int32_t* d_anc = nullptr;
     void* d_paths = nullptr;
-    Partial* d_part = nullptr;
+    Partial* d_part[2] = {nullptr, nullptr};   // tile partials, ping-pong between generations
+    int cur_part = 0;                          // which one holds the latest generation
+    double* d_e_tab = nullptr;                 // hmm: [T][4]
     double* d_bc = nullptr;
     StepCtrl* d_ctrl = nullptr;
     double* d_ess = nullptr;
@@ -63,6 +65,7 @@ struct cpprob_hip_ctx {
     double* d_local_totals = nullptr;
     double* totals_out = nullptr;   // caller-provided {max, sum, sum of squares} of the shard (step protocol)
     bool sharded = false;           // the last run went through the step protocol: stats stay un-normalised
+    bool step_protocol = false;     // a step-protocol run is in progress (the step kernel must not normalise on its own)
     int cur = 0;                    // logw buffer holding the latest generation
     size_t cap_particles = 0; int cap_T = 0; bool cap_int = false; bool cap_multinomial = false;
 
@@ -183,9 +186,30 @@ void launch_sis(cpprob_hip_ctx* c)
 {
     SisArgs<Model> a{};
     a.mp = c->mp; a.obs = c->d_obs; a.T = c->T; a.n = c->n; a.ld = c->ld; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
-    a.values = static_cast<typename Model::value_t*>(c->d_values); a.logw = c->d_logw[0]; a.wrel = c->d_wrel[0]; a.part = c->d_part;
+    a.values = static_cast<typename Model::value_t*>(c->d_values); a.logw = c->d_logw[0]; a.wrel = c->d_wrel[0]; a.part = c->d_part[0];
+    c->cur_part = 0;
     ProfScope ps(c, 4);
     hipLaunchKernelGGL(sis_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+}
+
+template <class Model, bool FUSED>
+void launch_step_impl(cpprob_hip_ctx* c, StepArgs<Model>& a)
+{
+    const size_t shm = FUSED ? (size_t)(2 * c->nb + 1) * sizeof(double) : 0;
+    switch (c->cfg.resampler) {
+    case CPPROB_HIP_RESAMPLE_SYSTEMATIC:
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_SYSTEMATIC, FUSED>), dim3(c->nb), dim3(kThreads), shm, c->stream, a); break;
+    case CPPROB_HIP_RESAMPLE_STRATIFIED:
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_STRATIFIED, FUSED>), dim3(c->nb), dim3(kThreads), shm, c->stream, a); break;
+    default:
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_PRECOMPUTED, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
+    }
+}
+
+// fused = the step kernel normalises the previous generation itself (no scan_partials launch between steps)
+bool step_is_fused(const cpprob_hip_ctx* c)
+{
+    return c->nb <= kFuseMaxTiles && c->cfg.resampler != CPPROB_HIP_RESAMPLE_MULTINOMIAL && !c->step_protocol;
 }
 
 template <class Model>
@@ -197,7 +221,10 @@ void launch_step(cpprob_hip_ctx* c, int t)
     a.values = static_cast<typename Model::value_t*>(c->d_values); a.anc = c->d_anc;
     a.logw_prev = c->d_logw[c->cur]; a.logw_next = c->d_logw[c->cur ^ 1];
     a.wrel_prev = c->d_wrel[c->cur]; a.wrel_next = c->d_wrel[c->cur ^ 1];
-    a.part = c->d_part; a.bc = c->d_bc; a.bf = c->d_bf; a.nb = c->nb; a.ctrl = c->d_ctrl; a.anc_pre = c->d_anc_pre;
+    a.part_prev = c->d_part[c->cur_part]; a.part = c->d_part[t == 0 ? c->cur_part : c->cur_part ^ 1];
+    a.bc = c->d_bc; a.bf = c->d_bf; a.nb = c->nb; a.ctrl = c->d_ctrl; a.anc_pre = c->d_anc_pre;
+    a.n_pop = (double)c->pop_n; a.ess_frac = c->cfg.ess_threshold; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
+    a.store_logw = c->cfg.ess_threshold > 1.0 ? 0 : 1;      // ESS <= N always: threshold > 1 resamples after every step
     if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && t > 0) {
         // literal thesis Alg. 1: materialise the CDF, draw N independent positions.  Runs
         // unconditionally; the step kernel ignores the result when ctrl says "no resampling".
@@ -206,22 +233,18 @@ void launch_step(cpprob_hip_ctx* c, int t)
         hipLaunchKernelGGL(multinomial_kernel, dim3((unsigned)((c->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, c->d_cdf, c->n,
                            c->d_ctrl, c->run_seed, (uint64_t)t, c->cfg.particle_offset, c->n, c->d_anc_pre);
     }
-    ProfScope ps(c, 0);
-    switch (c->cfg.resampler) {
-    case CPPROB_HIP_RESAMPLE_SYSTEMATIC:
-        hipLaunchKernelGGL((smc_step_kernel<Model, RS_SYSTEMATIC>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
-    case CPPROB_HIP_RESAMPLE_STRATIFIED:
-        hipLaunchKernelGGL((smc_step_kernel<Model, RS_STRATIFIED>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
-    default:
-        hipLaunchKernelGGL((smc_step_kernel<Model, RS_PRECOMPUTED>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
+    {
+        ProfScope ps(c, 0);
+        if (step_is_fused(c)) launch_step_impl<Model, true>(c, a); else launch_step_impl<Model, false>(c, a);
     }
     c->cur ^= 1;
+    if (t > 0) c->cur_part ^= 1;
 }
 
 void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, int world, int rank)
 {
     ScanArgs sa{};
-    sa.part = c->d_part; sa.nb = c->nb; sa.bc = c->d_bc; sa.bf = c->d_bf; sa.ctrl = c->d_ctrl; sa.t = t; sa.T = c->T;
+    sa.part = c->d_part[c->cur_part]; sa.nb = c->nb; sa.bc = c->d_bc; sa.bf = c->d_bf; sa.ctrl = c->d_ctrl; sa.t = t; sa.T = c->T;
     sa.n_pop = (double)c->pop_n; sa.n_local = (double)c->n; sa.ess_frac = c->cfg.ess_threshold; sa.seed = c->run_seed;
     sa.ess_trace = c->d_ess; sa.resampled = c->d_resampled;
     sa.force_no_resample = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
@@ -264,7 +287,7 @@ int dispatch_model(cpprob_hip_ctx* c, F&& f)
 void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
-    dfree(c->d_part); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
+    dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
     dfree(c->d_cdf); dfree(c->d_anc_pre);
     c->cap_particles = 0; c->cap_T = 0;
 }
@@ -380,7 +403,8 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_values, T * ld * vsz));
         HIP_TRY(c, hipMemsetAsync(c->d_values, 0, T * ld * vsz, c->stream));
         HIP_TRY(c, hipMalloc(&c->d_anc, T * ld * sizeof(int32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_part, (size_t)c->nb * sizeof(Partial)));
+        HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)c->nb * sizeof(Partial)));
+        HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)c->nb * sizeof(Partial)));
         HIP_TRY(c, hipMalloc(&c->d_bc, ((size_t)c->nb + 1) * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_ess, T * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_resampled, T * sizeof(int32_t)));
@@ -397,7 +421,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     HIP_TRY(c, hipMemcpyAsync(c->d_obs, h_obs, n_obs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_resampled, 0, (size_t)c->T * sizeof(int32_t), c->stream));
     dfree(c->d_ll_tab);
-    c->mp.ll_tab = nullptr;
+    c->mp.ll_tab = nullptr; c->mp.e_tab = nullptr;
     if (cfg->model == CPPROB_HIP_MODEL_HMM3) {
         // log N(y_t; state_mean[s], 1): three values per step, computed once with the same functor
         // the reference applies per particle (utils_normal_distribution.hpp:20-45)
@@ -407,6 +431,18 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_ll_tab, tab.size() * sizeof(double)));
         HIP_TRY(c, hipMemcpy(c->d_ll_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
         c->mp.ll_tab = c->d_ll_tab;
+        // linear weights of the three values against their maximum: exp(ll - max), and the max itself
+        std::vector<double> et((size_t)c->T * 4);
+        for (int t = 0; t < c->T; ++t) {
+            const double* l = &tab[(size_t)t * 3];
+            const double mx = std::max(l[0], std::max(l[1], l[2]));
+            for (int s2 = 0; s2 < 3; ++s2) et[(size_t)t * 4 + s2] = std::exp(l[s2] - mx);
+            et[(size_t)t * 4 + 3] = mx;
+        }
+        dfree(c->d_e_tab);
+        HIP_TRY(c, hipMalloc(&c->d_e_tab, et.size() * sizeof(double)));
+        HIP_TRY(c, hipMemcpy(c->d_e_tab, et.data(), et.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->mp.e_tab = c->d_e_tab;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->begun = true; c->ran = false;
@@ -421,15 +457,17 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     if (c->cfg.resample_scope == CPPROB_HIP_SCOPE_GLOBAL && c->cfg.n_global != c->cfg.n_particles)
         return fail(c, CPPROB_HIP_ESTATE, "this context holds one shard of a joint population: drive it with cpprob_hip_smc_step_begin/_end/_finish");
     c->run_seed = c->cfg.seed + run_index;
-    c->cur = 0;
+    c->cur = 0; c->cur_part = 0;
     c->sharded = false;
     if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
         dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
         launch_scan(c, c->T - 1, 0, nullptr, 1, 0);
     } else {
+        c->step_protocol = false;
+        const bool fused = step_is_fused(c);
         for (int t = 0; t < c->T; ++t) {
             dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
-            launch_scan(c, t, 0, nullptr, 1, 0);
+            if (!fused || t + 1 == c->T) launch_scan(c, t, 0, nullptr, 1, 0);   // fused: only the final generation needs the standalone pass
         }
     }
     dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
@@ -446,7 +484,8 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     HIP_TRY(c, hipSetDevice(c->device));
     const bool sis = c->cfg.algorithm == CPPROB_HIP_ALG_SIS;
     if (sis && t != c->T - 1) return fail(c, CPPROB_HIP_EINVAL, "SIS shards run in one launch: call step_begin(T-1) only");
-    if (t == 0 || sis) { c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->ran = false; }
+    if (t == 0 || sis) { c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; }
+    c->step_protocol = true;
     if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
     else dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
     c->totals_out = d_local_totals;

@@ -234,11 +234,13 @@ struct AncestorIn {
     double W, scale, cdf_lo, u0, inv_stepw;
     uint64_t seed, step, gj_tile0, n_total_out; int n_valid_tile;
     uint64_t id0;      // RNG id of output 0 (stratified offsets are drawn per global particle id)
+    int bc_in_lds;     // bc / bf already point at LDS copies of the whole tile-level CDF (fused step kernel)
 };
 
 __device__ __forceinline__ int stage_window(const AncestorIn& in, AncestorLds& L, double q_guess)
 {
     const int tid = threadIdx.x;
+    if (in.bc_in_lds) return in.nb + 1;                      // empty window beyond the table: every lookup reads in.bc (LDS) directly
     const double w_local = in.bc[in.nb] * in.scale;
     const int guess = w_local > 0.0 ? (int)(fmin(fmax(q_guess / w_local, 0.0), 1.0) * in.nb) : 0;
     int w0 = guess - kWin / 2;
@@ -278,8 +280,10 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     auto locate = [&](double g, int lo) -> int {
         int a = lo, b = in.nb;
         // narrow to the window first when the answer is inside it
-        if (w0 >= lo && gt(w0) <= g) a = w0;
-        if (w0 + wn < in.nb && w0 + wn > a && gt(w0 + wn) > g) b = w0 + wn;
+        if (!in.bc_in_lds) {
+            if (w0 >= lo && gt(w0) <= g) a = w0;
+            if (w0 + wn < in.nb && w0 + wn > a && gt(w0 + wn) > g) b = w0 + wn;
+        }
         while (b - a > 1) { const int mid = (a + b) >> 1; if (gt(mid) <= g) a = mid; else b = mid; }
         return a;
     };
@@ -357,8 +361,10 @@ __device__ __forceinline__ void ancestors_stratified(const AncestorIn& in, int32
     auto bcv = [&](int c) -> double { return (c >= w0 && c <= w0 + wn) ? L.bcw[c - w0] : in.bc[c] * in.scale; };
     auto locate = [&](double q, int lo) -> int {               // largest c in [lo, nb) with bc[c] <= q
         int a = lo, b = in.nb;
-        if (w0 >= lo && bcv(w0) <= q) a = w0;
-        if (w0 + wn < in.nb && w0 + wn > a && bcv(w0 + wn) > q) b = w0 + wn;
+        if (!in.bc_in_lds) {
+            if (w0 >= lo && bcv(w0) <= q) a = w0;
+            if (w0 + wn < in.nb && w0 + wn > a && bcv(w0 + wn) > q) b = w0 + wn;
+        }
         while (b - a > 1) { const int mid = (a + b) >> 1; if (bcv(mid) <= q) a = mid; else b = mid; }
         return a;
     };
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(ResampleArgs a)
     }
     in.seed = a.seed; in.step = a.step; in.gj_tile0 = a.j0 + (uint64_t)blockIdx.x * kTile; in.n_total_out = a.n_total_out;
     in.n_valid_tile = rem < kTile ? (int)rem : kTile;
-    in.id0 = 0;
+    in.id0 = 0; in.bc_in_lds = 0;
     int32_t anc[kPPT];
     find_ancestors<RS>(in, anc, L);
 #pragma unroll
@@ -526,9 +532,20 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// SMC step t (fused): [resample generation t-1 -> ancestors] -> gather ancestor state ->
-// sample x_t -> weight by observe t -> record predict + ancestor -> tile partial + linear weights.
+// SMC step t (fused): [normalise generation t-1] -> [resample it -> ancestors] -> gather ancestor
+// state -> sample x_t -> weight by observe t -> record predict + ancestor -> tile partial + linear
+// weights.
+//
+// FUSED = true (populations of <= kFuseMaxTiles tiles): the normalisation of generation t-1 --
+// what scan_partials_kernel does -- runs in the prologue of EVERY workgroup, redundantly, from
+// the nb tile partials (32 B each, L2-resident): global max, W, ESS, the resampling decision and
+// the whole tile-level CDF, kept in LDS.  All workgroups execute identical arithmetic in identical
+// order, so they take identical decisions; workgroup 0 records them in ctrl for the host.  This
+// removes one launch + one kernel boundary (~5 us) per step.  FUSED = false reads what
+// scan_partials_kernel left in ctrl / bc / bf (large populations, sharded runs).
 // ---------------------------------------------------------------------------------------------
+constexpr int kFuseMaxTiles = 2048;
+
 template <class Model>
 struct StepArgs {
     ModelParams mp; const double* obs; int t, T; int64_t n, ld;
@@ -536,21 +553,117 @@ struct StepArgs {
     typename Model::value_t* values; int32_t* anc;
     const double* logw_prev; double* logw_next;
     const double* wrel_prev; double* wrel_next;
-    Partial* part;
-    const double* bc; const double* bf; int nb; const StepCtrl* ctrl;
+    const Partial* part_prev; Partial* part;
+    const double* bc; const double* bf; int nb; StepCtrl* ctrl;
     const int32_t* anc_pre;   // RS_PRECOMPUTED: ancestors computed by multinomial_kernel
+    double n_pop, ess_frac;   // FUSED: ESS test
+    double* ess_trace; int32_t* resampled;
+    int store_logw;           // 0: every step resamples (known on the host), so only the last step's log-weights are ever read
 };
 
-template <class Model, int RS>
+// Tile partial when every particle's log-weight is lwa + (one of K table values): no exp, no fp64
+// reduction -- per-value counts by ballot + popcount (scalar unit), one barrier.
+template <int K>
+__device__ __forceinline__ void tile_partial_table(const int (&idx)[kPPT], const bool (&valid)[kPPT], const double (&e_tab)[K], double m_ref,
+                                                   double (&e)[kPPT], Partial* __restrict__ part, int* s_cnt /* kWaves*K ints */)
+{
+    int cnt[K];
+#pragma unroll
+    for (int s2 = 0; s2 < K; ++s2) cnt[s2] = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        e[k] = 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < K; ++s2) {
+            const bool hit = valid[k] && idx[k] == s2;
+            cnt[s2] += __popcll(__ballot(hit));
+            if (hit) e[k] = e_tab[s2];
+        }
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < K; ++s2) s_cnt[wave_id() * K + s2] = cnt[s2];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sm = 0.0, q = 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < K; ++s2) {
+            int c = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) c += s_cnt[w * K + s2];
+            sm += (double)c * e_tab[s2];
+            q += (double)c * (e_tab[s2] * e_tab[s2]);
+        }
+        Partial p; p.m = m_ref; p.s = sm; p.q = q; p.pad = 0.0;
+        part[blockIdx.x] = p;
+    }
+}
+
+template <class Model, int RS, bool FUSED>
 __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
 {
     using V = typename Model::value_t;
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // FUSED: bc[nb+1] then bf[nb]
     __shared__ AncestorLds L;
     __shared__ double s_scr[3 * kWaves];
+    __shared__ int s_cnt[kWaves * 4];
     const int tid = threadIdx.x;
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)tid * kPPT;
     const int t = a.t;
-    const bool resample = t > 0 && a.ctrl->do_resample != 0;   // workgroup-uniform (scalar load)
+    double* s_bc = s_dyn;
+    double* s_bf = s_dyn + (a.nb + 1);
+
+    bool resample = false;
+    double u0 = 0.0, inv_stepw = 0.0, lwa = 0.0;
+    if (t > 0) {
+        if (FUSED) {
+            // ---- normalise generation t-1 from its tile partials (every workgroup, identically) ----
+            const int per = (a.nb + kThreads - 1) / kThreads;
+            const int lo = tid * per, hi = min(a.nb, lo + per);
+            double m = -INFINITY;
+            for (int c = lo; c < hi; ++c) m = fmax(m, a.part_prev[c].m);
+            const double M = block_max(m, s_scr);
+            double S = 0.0, Q = 0.0;
+            for (int c = lo; c < hi; ++c) {
+                const Partial p = a.part_prev[c];
+                double e = 1.0;
+                if (p.m != M) e = (p.m == -INFINITY) ? 0.0 : exp(p.m - M);   // table-weight models: every tile has the same reference
+                s_bf[c] = e;
+                S += p.s * e;
+                Q += p.q * (e * e);
+            }
+            double W;
+            const double excl = block_excl_scan(S, L.scr[0], &W);
+            block_sum2(Q, S, s_scr + kWaves);                                 // Q total (S total again, unused)
+            double run = excl;
+            for (int c = lo; c < hi; ++c) { s_bc[c] = run; run += a.part_prev[c].s * s_bf[c]; }
+            if (tid == 0) s_bc[a.nb] = W;
+            const double ess = W * W / Q;
+            resample = ess < a.ess_frac * a.n_pop;                            // ESS test, thesis p.37 (t-1 is never the last step here)
+            inv_stepw = (double)a.n / W;
+            lwa = 0.0;
+            {
+                const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)t);
+                u0 = u01_53(r.x, r.y);
+            }
+            if (blockIdx.x == 0 && tid == 0) {                                // bookkeeping for the host
+                StepCtrl* c = a.ctrl;
+                c->M = M; c->W = W; c->Q = Q; c->ess = ess; c->do_resample = resample ? 1 : 0;
+                c->cdf_lo = 0.0; c->w_local = W; c->scale = 1.0; c->u0 = u0; c->inv_stepw = inv_stepw; c->lw_after = 0.0;
+                double lz = (t == 1) ? 0.0 : c->log_z;
+                int nr = (t == 1) ? 0 : c->n_resampled;
+                if (resample) { lz += M + log(W / a.n_pop); nr += 1; }
+                c->log_z = lz; c->n_resampled = nr;
+                if (a.ess_trace) a.ess_trace[t - 1] = ess;
+                if (a.resampled) a.resampled[t - 1] = resample ? 1 : 0;
+            }
+            __syncthreads();
+        } else {
+            resample = a.ctrl->do_resample != 0;                             // workgroup-uniform (scalar load)
+            u0 = a.ctrl->u0; inv_stepw = a.ctrl->inv_stepw; lwa = a.ctrl->lw_after;
+        }
+    }
 
     int32_t anc[kPPT]; double lw[kPPT];
     if (!resample) {
@@ -563,14 +676,14 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         } else {
             const int64_t rem = a.n - (int64_t)blockIdx.x * kTile;
             AncestorIn in;
-            in.wrel = a.wrel_prev; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n;
-            in.W = a.bc[a.nb]; in.scale = 1.0; in.cdf_lo = 0.0; in.u0 = a.ctrl->u0; in.inv_stepw = a.ctrl->inv_stepw;
+            in.wrel = a.wrel_prev; in.nb = a.nb; in.n_in = a.n;
+            if (FUSED) { in.bc = s_bc; in.bf = s_bf; in.bc_in_lds = 1; } else { in.bc = a.bc; in.bf = a.bf; in.bc_in_lds = 0; }
+            in.W = in.bc[a.nb]; in.scale = 1.0; in.cdf_lo = 0.0; in.u0 = u0; in.inv_stepw = inv_stepw;
             in.seed = a.seed; in.step = (uint64_t)t; in.gj_tile0 = (uint64_t)blockIdx.x * kTile; in.n_total_out = (uint64_t)a.n;
             in.id0 = a.pid0;
             in.n_valid_tile = rem < kTile ? (int)rem : kTile;
             find_ancestors<RS>(in, anc, L);
         }
-        const double lwa = a.ctrl->lw_after;
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) lw[k] = lwa;          // equal weights after resampling (the shard's mass share)
     }
@@ -580,16 +693,37 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? prev_row[anc[k]] : V(0);                 // ancestor's state (sorted gather)
     Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0, t, prev, x);                       // sample #t
+    bool valid[kPPT];
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) {
-        lw[k] += Model::loglik(a.mp, x[k], t, a.obs);                                         // observe #t
-        if (j0 + k >= a.n) lw[k] = -INFINITY;                                                 // padding slots
-    }
+    for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
     store4(a.values + (int64_t)t * a.ld, j0, x);                                              // predict #t
     store4(a.anc + (int64_t)t * a.ld, j0, anc);
-    store4(a.logw_next, j0, lw);
     double e[kPPT];
-    tile_partial(lw, e, a.part, s_scr);
+    const bool fresh = (t == 0) || resample;                                                  // every particle starts the step at log-weight lwa
+    if (Model::kWeightTable > 0 && fresh) {
+        // observe #t for models whose incremental weight takes one of K values: table look-ups only
+        constexpr int K = Model::kWeightTable > 0 ? Model::kWeightTable : 1;
+        double ll[K], et[K], mref;
+        Model::weight_table(a.mp, t, ll, et, mref);
+        int idx[kPPT];
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            idx[k] = Model::weight_index(x[k]);
+            double l = ll[0];
+#pragma unroll
+            for (int s2 = 1; s2 < K; ++s2) l = idx[k] == s2 ? ll[s2] : l;
+            lw[k] = valid[k] ? lw[k] + l : -INFINITY;
+        }
+        tile_partial_table<K>(idx, valid, et, (t == 0 ? 0.0 : lwa) + mref, e, a.part, s_cnt);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            lw[k] += Model::loglik(a.mp, x[k], t, a.obs);                                     // observe #t
+            if (!valid[k]) lw[k] = -INFINITY;                                                 // padding slots
+        }
+        tile_partial(lw, e, a.part, s_scr);
+    }
+    if (a.store_logw || t + 1 == a.T) store4(a.logw_next, j0, lw);
     store4(a.wrel_next, j0, e);
 }
 

@@ -21,6 +21,7 @@ struct ModelParams {
     uint64_t hmm_thr[3][2];                       // ceil(2^32 * cumulative probability) of row s
     double log_norm_unit;                         // log(2*pi*1*1)
     const double* ll_tab;                         // hmm: [T][3] log N(y_t; mean[s], 1), device pointer
+    const double* e_tab;                          // hmm: [T][4] exp(ll - max ll) for s = 0..2, then max ll
 };
 
 // reference include/models/models.hpp:22-35 and src/models/gaussian.cpp:6-17 (same body,
@@ -29,6 +30,9 @@ struct ModelGaussian {
     using value_t = double;
     static constexpr bool kIsInt = false;
     static constexpr int kStats = 2;  // sum w x, sum w x^2
+    static constexpr int kWeightTable = 0;   // incremental weights are continuous
+    __device__ static __forceinline__ void weight_table(const ModelParams&, int, double (&)[1], double (&)[1], double&) {}
+    __device__ static __forceinline__ int weight_index(value_t) { return 0; }
     __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int /*t*/,
                                                       const value_t (&)[4], value_t (&x)[4])
     {
@@ -57,6 +61,9 @@ struct ModelLinearGaussian1D {
     using value_t = double;
     static constexpr bool kIsInt = false;
     static constexpr int kStats = 2;
+    static constexpr int kWeightTable = 0;
+    __device__ static __forceinline__ void weight_table(const ModelParams&, int, double (&)[1], double (&)[1], double&) {}
+    __device__ static __forceinline__ int weight_index(value_t) { return 0; }
     __device__ static __forceinline__ void propagate4(const ModelParams&, uint64_t seed, uint64_t pid0, int t, const value_t (&prev)[4],
                                                       value_t (&x)[4])
     {
@@ -85,6 +92,17 @@ struct ModelHmm3 {
     using value_t = int32_t;
     static constexpr bool kIsInt = true;
     static constexpr int kStats = 3;  // sum w [x == s]
+    // the incremental weight of a step takes one of 3 values: log N(y_t; mean[s], 1).  ll_tab row t holds them,
+    // e_tab row t holds {exp(ll - max ll)} and max ll (host-computed once per run)
+    static constexpr int kWeightTable = 3;
+    __device__ static __forceinline__ void weight_table(const ModelParams& mp, int t, double (&ll)[3], double (&e)[3], double& mref)
+    {
+        const double* r = mp.ll_tab + 3 * t;
+        const double* q = mp.e_tab + 4 * t;
+        ll[0] = r[0]; ll[1] = r[1]; ll[2] = r[2];
+        e[0] = q[0]; e[1] = q[1]; e[2] = q[2]; mref = q[3];
+    }
+    __device__ static __forceinline__ int weight_index(value_t s) { return (int)s; }
     __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int t, const value_t (&prev)[4],
                                                       value_t (&x)[4])
     {
