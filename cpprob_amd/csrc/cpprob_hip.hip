@@ -154,7 +154,7 @@ int ensure_bb(cpprob_hip_ctx* ctx, size_t n)
     if (nb > ctx->bb_cap_nb || !ctx->d_bb_ctrl) {
         dfree(ctx->d_bb_part); dfree(ctx->d_bb_bc); dfree(ctx->d_bb_bf); dfree(ctx->d_bb_wrel); dfree(ctx->d_bb_col); dfree(ctx->d_bb_stats_part);
         const size_t cap = std::max<size_t>(nb, 1024);
-        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_part, cap * sizeof(Partial)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_part, cap * 3 * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_bb_bc, (cap + 1) * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_bb_bf, cap * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_bb_wrel, cap * kTile * sizeof(double)));
@@ -225,6 +225,10 @@ void launch_step(cpprob_hip_ctx* c, int t)
     a.bc = c->d_bc; a.bf = c->d_bf; a.nb = c->nb; a.ctrl = c->d_ctrl; a.anc_pre = c->d_anc_pre;
     a.n_pop = (double)c->pop_n; a.ess_frac = c->cfg.ess_threshold; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
     a.store_logw = c->cfg.ess_threshold > 1.0 ? 0 : 1;      // ESS <= N always: threshold > 1 resamples after every step
+#ifdef CPPROB_STAMPS
+    { static unsigned long long* d_st = nullptr; if (!d_st) (void)hipMalloc(&d_st, (size_t)65536 * 8 * 8); a.stamps = d_st;
+      if (t == 8 && getenv("CPPROB_STAMP_DUMP")) { /* dump after launch below */ } }
+#endif
     if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && t > 0) {
         // literal thesis Alg. 1: materialise the CDF, draw N independent positions.  Runs
         // unconditionally; the step kernel ignores the result when ctrl says "no resampling".
@@ -237,6 +241,19 @@ void launch_step(cpprob_hip_ctx* c, int t)
         ProfScope ps(c, 0);
         if (step_is_fused(c)) launch_step_impl<Model, true>(c, a); else launch_step_impl<Model, false>(c, a);
     }
+#ifdef CPPROB_STAMPS
+    if (t == 8 && getenv("CPPROB_STAMP_DUMP")) {
+        (void)hipStreamSynchronize(c->stream);
+        std::vector<unsigned long long> h((size_t)c->nb * 8);
+        (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull; for (int b = 0; b < c->nb; ++b) t0 = std::min(t0, h[(size_t)b * 8]);
+        double acc[6] = {0}; double mx[6] = {0};
+        for (int b = 0; b < c->nb; ++b) for (int k = 0; k < 6; ++k) { double v = (double)(h[(size_t)b * 8 + k] - t0) * 0.01; acc[k] += v; mx[k] = std::max(mx[k], v); }
+        fprintf(stderr, "STAMPS t=8 (us since first block start) mean/max: ");
+        for (int k = 0; k < 6; ++k) fprintf(stderr, "[%d] %.2f/%.2f  ", k, acc[k] / c->nb, mx[k]);
+        fprintf(stderr, "\n");
+    }
+#endif
     c->cur ^= 1;
     if (t > 0) c->cur_part ^= 1;
 }
@@ -403,8 +420,8 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_values, T * ld * vsz));
         HIP_TRY(c, hipMemsetAsync(c->d_values, 0, T * ld * vsz, c->stream));
         HIP_TRY(c, hipMalloc(&c->d_anc, T * ld * sizeof(int32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)c->nb * sizeof(Partial)));
-        HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)c->nb * sizeof(Partial)));
+        HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)c->nb * 3 * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)c->nb * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_bc, ((size_t)c->nb + 1) * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_ess, T * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_resampled, T * sizeof(int32_t)));

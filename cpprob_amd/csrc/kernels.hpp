@@ -31,7 +31,13 @@
 
 namespace cph {
 
-struct __attribute__((aligned(32))) Partial { double m, s, q, pad; };
+// Tile partials {max, sum e, sum e^2} are kept as three arrays of nb doubles (structure of arrays:
+// the consumers read them coalesced): part[0..nb) = max, part[nb..2nb) = sum, part[2nb..3nb) = sum of squares.
+using Partial = double;
+__device__ __forceinline__ void put_partial(Partial* __restrict__ part, int nb, int b, double m, double s, double q)
+{
+    part[b] = m; part[nb + b] = s; part[2 * nb + b] = q;
+}
 
 struct StepCtrl {
     double M;         // max log-weight of the current generation (global over shards)
@@ -91,7 +97,7 @@ __device__ __forceinline__ void tile_partial(const double (&lw)[kPPT], double (&
         s += e[k]; q += e[k] * e[k];
     }
     block_sum2(s, q, s_scr + kWaves);
-    if (threadIdx.x == 0) { Partial p; p.m = m; p.s = s; p.q = q; p.pad = 0.0; part[blockIdx.x] = p; }
+    if (threadIdx.x == 0) put_partial(part, (int)gridDim.x, (int)blockIdx.x, m, s, q);
 }
 
 // Standalone: partials + linear weights of an arbitrary log-weight array of n entries
@@ -137,31 +143,32 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
     __shared__ double s_scr[3 * NW];
     const int tid = threadIdx.x;
     StepCtrl* ctrl = a.ctrl;
+    // NOTE: every thread of the workgroup takes every barrier below (uniform trip counts)
 
     if (a.phase != 2) {
-        const int chunk = (a.nb + kScanThreads - 1) / kScanThreads;
-        const int lo = tid * chunk, hi = min(a.nb, lo + chunk);
+        const double* pm = a.part; const double* psum = a.part + a.nb; const double* pq = a.part + 2 * a.nb;
         double m = -INFINITY;
-        for (int c = lo; c < hi; ++c) m = fmax(m, a.part[c].m);
+        for (int c = tid; c < a.nb; c += kScanThreads) m = fmax(m, pm[c]);          // coalesced
         const double M = block_max<NW>(m, s_scr);
-        double S = 0.0, Q = 0.0;
-        for (int c = lo; c < hi; ++c) {
-            const Partial p = a.part[c];
-            const double e = (p.m == -INFINITY) ? 0.0 : exp(p.m - M);
-            S += p.s * e;
-            Q += p.q * (e * e);
+        // tiles in index order, 1024 at a time: one workgroup scan per slab plus a running carry
+        double W = 0.0, Qacc = 0.0;
+        int it = 0;
+        for (int base = 0; base < a.nb; base += kScanThreads, ++it) {
+            const int c = base + tid;
+            double e = 0.0, v = 0.0;
+            if (c < a.nb) {
+                const double mc = pm[c];
+                e = (mc == -INFINITY) ? 0.0 : exp(mc - M);
+                v = psum[c] * e;
+                Qacc += pq[c] * (e * e);
+            }
+            double tot;
+            const double excl = block_excl_scan<NW>(v, s_scr + NW + (it & 1) * NW, &tot);
+            if (c < a.nb) { a.bc[c] = W + excl; a.bf[c] = e; }
+            W += tot;
         }
-        double W;
-        const double excl = block_excl_scan<NW>(S, s_scr + NW, &W);
-        const double Qt = block_sum<NW>(Q, s_scr + 2 * NW);
-        double run = excl;
-        for (int c = lo; c < hi; ++c) {
-            const Partial p = a.part[c];
-            const double e = (p.m == -INFINITY) ? 0.0 : exp(p.m - M);
-            a.bc[c] = run;
-            a.bf[c] = e;
-            run += p.s * e;
-        }
+        __syncthreads();
+        const double Qt = block_sum<NW>(Qacc, s_scr);
         if (tid == 0) {
             a.bc[a.nb] = W;
             if (a.phase == 1) {
@@ -276,10 +283,15 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     // tile-level value: start index of tile c's outputs
     auto bcv = [&](int c) -> double { return (c >= w0 && c <= w0 + wn) ? L.bcw[c - w0] : in.bc[c] * in.scale; };
     auto gt = [&](int c) -> double { return c >= in.nb ? INFINITY : g_of(in.cdf_lo + bcv(c), inv, u0); };
-    // largest c in [lo, nb) with gt(c) <= g  (gt(lo) <= g guaranteed)
-    auto locate = [&](double g, int lo) -> int {
+    // largest c in [lo, nb) with gt(c) <= g  (gt(lo) <= g guaranteed).  Tile masses are nearly equal, so the
+    // answer is within a tile or two of `guess`: probe there first, binary search only when that fails.
+    auto locate = [&](double g, int lo, int guess) -> int {
+        int c = guess < lo ? lo : (guess >= in.nb ? in.nb - 1 : guess);
+        int probes = 0;
+        while (probes < 6 && c > lo && gt(c) > g) { --c; ++probes; }
+        while (probes < 6 && c + 1 < in.nb && gt(c + 1) <= g) { ++c; ++probes; }
+        if (gt(c) <= g && (c + 1 >= in.nb || gt(c + 1) > g)) return c;
         int a = lo, b = in.nb;
-        // narrow to the window first when the answer is inside it
         if (!in.bc_in_lds) {
             if (w0 >= lo && gt(w0) <= g) a = w0;
             if (w0 + wn < in.nb && w0 + wn > a && gt(w0 + wn) > g) b = w0 + wn;
@@ -287,8 +299,9 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
         while (b - a > 1) { const int mid = (a + b) >> 1; if (gt(mid) <= g) a = mid; else b = mid; }
         return a;
     };
-    const int c_lo = locate(gj_first, 0);
-    const int c_hi = locate(gj_last, c_lo);
+    const int guess0 = (int)((gj_first / inv - in.cdf_lo) / fmax(bcv(in.nb), 1e-300) * in.nb);
+    const int c_lo = locate(gj_first, 0, guess0);
+    const int c_hi = locate(gj_last, c_lo, c_lo + 1);
     int it = 0;
     for (int c = c_lo; c <= c_hi; ++c) {
         const double b0 = bcv(c), b1 = bcv(c + 1);
@@ -559,6 +572,9 @@ struct StepArgs {
     double n_pop, ess_frac;   // FUSED: ESS test
     double* ess_trace; int32_t* resampled;
     int store_logw;           // 0: every step resamples (known on the host), so only the last step's log-weights are ever read
+#ifdef CPPROB_STAMPS
+    unsigned long long* stamps;   // diagnostic build only: [nb][8] s_memrealtime stamps
+#endif
 };
 
 // Tile partial when every particle's log-weight is lwa + (one of K table values): no exp, no fp64
@@ -595,8 +611,7 @@ __device__ __forceinline__ void tile_partial_table(const int (&idx)[kPPT], const
             sm += (double)c * e_tab[s2];
             q += (double)c * (e_tab[s2] * e_tab[s2]);
         }
-        Partial p; p.m = m_ref; p.s = sm; p.q = q; p.pad = 0.0;
-        part[blockIdx.x] = p;
+        put_partial(part, (int)gridDim.x, (int)blockIdx.x, m_ref, sm, q);
     }
 }
 
@@ -613,31 +628,53 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     const int t = a.t;
     double* s_bc = s_dyn;
     double* s_bf = s_dyn + (a.nb + 1);
+#ifdef CPPROB_STAMPS
+#define STAMP(k) do { if (tid == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+    STAMP(0);
 
     bool resample = false;
     double u0 = 0.0, inv_stepw = 0.0, lwa = 0.0;
     if (t > 0) {
         if (FUSED) {
             // ---- normalise generation t-1 from its tile partials (every workgroup, identically) ----
+            // one coalesced pass over the three partial arrays into registers (<= kFuseMaxTiles / 256 per lane)
+            constexpr int kPer = kFuseMaxTiles / kThreads;
+            const double* pm = a.part_prev; const double* psum = a.part_prev + a.nb; const double* pq = a.part_prev + 2 * a.nb;
+            double rm[kPer], rs[kPer], rq[kPer];
+            double m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int c = tid + i * kThreads;
+                const bool in = c < a.nb;
+                rm[i] = in ? pm[c] : -INFINITY; rs[i] = in ? psum[c] : 0.0; rq[i] = in ? pq[c] : 0.0;
+                m = fmax(m, rm[i]);
+            }
+            const double M = block_max(m, s_scr);
+            double Q = 0.0;
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int c = tid + i * kThreads;
+                if (c < a.nb) {
+                    double e = 1.0;
+                    if (rm[i] != M) e = (rm[i] == -INFINITY) ? 0.0 : exp(rm[i] - M);   // table-weight models: every tile has the same reference
+                    s_bf[c] = e;
+                    s_bc[c] = rs[i] * e;                                                 // tile mass; prefix-summed below
+                    Q += rq[i] * (e * e);
+                }
+            }
+            Q = block_sum(Q, s_scr + kWaves);                                            // (barrier: the LDS tile masses are visible)
+            // exclusive prefix over the tiles in index order: each lane owns `per` consecutive tiles
             const int per = (a.nb + kThreads - 1) / kThreads;
             const int lo = tid * per, hi = min(a.nb, lo + per);
-            double m = -INFINITY;
-            for (int c = lo; c < hi; ++c) m = fmax(m, a.part_prev[c].m);
-            const double M = block_max(m, s_scr);
-            double S = 0.0, Q = 0.0;
-            for (int c = lo; c < hi; ++c) {
-                const Partial p = a.part_prev[c];
-                double e = 1.0;
-                if (p.m != M) e = (p.m == -INFINITY) ? 0.0 : exp(p.m - M);   // table-weight models: every tile has the same reference
-                s_bf[c] = e;
-                S += p.s * e;
-                Q += p.q * (e * e);
-            }
+            double S = 0.0;
+            for (int c = lo; c < hi; ++c) S += s_bc[c];
             double W;
             const double excl = block_excl_scan(S, L.scr[0], &W);
-            block_sum2(Q, S, s_scr + kWaves);                                 // Q total (S total again, unused)
             double run = excl;
-            for (int c = lo; c < hi; ++c) { s_bc[c] = run; run += a.part_prev[c].s * s_bf[c]; }
+            for (int c = lo; c < hi; ++c) { const double v = s_bc[c]; s_bc[c] = run; run += v; }
             if (tid == 0) s_bc[a.nb] = W;
             const double ess = W * W / Q;
             resample = ess < a.ess_frac * a.n_pop;                            // ESS test, thesis p.37 (t-1 is never the last step here)
@@ -665,6 +702,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         }
     }
 
+    STAMP(1);
     int32_t anc[kPPT]; double lw[kPPT];
     if (!resample) {
 #pragma unroll
@@ -688,11 +726,14 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         for (int k = 0; k < kPPT; ++k) lw[k] = lwa;          // equal weights after resampling (the shard's mass share)
     }
 
+    STAMP(2);
     V prev[kPPT], x[kPPT];
     const V* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.ld;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? prev_row[anc[k]] : V(0);                 // ancestor's state (sorted gather)
     Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0, t, prev, x);                       // sample #t
+    if (x[0] == V(-12345)) STAMP(7);
+    STAMP(3);
     bool valid[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
@@ -723,8 +764,10 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         }
         tile_partial(lw, e, a.part, s_scr);
     }
+    STAMP(4);
     if (a.store_logw || t + 1 == a.T) store4(a.logw_next, j0, lw);
     store4(a.wrel_next, j0, e);
+    STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
