@@ -150,21 +150,33 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
         double m = -INFINITY;
         for (int c = tid; c < a.nb; c += kScanThreads) m = fmax(m, pm[c]);          // coalesced
         const double M = block_max<NW>(m, s_scr);
-        // tiles in index order, 1024 at a time: one workgroup scan per slab plus a running carry
+        // tiles in index order, 4096 at a time (4 consecutive tiles per lane: 32-B coalesced loads): one
+        // workgroup scan per slab plus a running carry
         double W = 0.0, Qacc = 0.0;
         int it = 0;
-        for (int base = 0; base < a.nb; base += kScanThreads, ++it) {
-            const int c = base + tid;
-            double e = 0.0, v = 0.0;
-            if (c < a.nb) {
-                const double mc = pm[c];
-                e = (mc == -INFINITY) ? 0.0 : exp(mc - M);
-                v = psum[c] * e;
-                Qacc += pq[c] * (e * e);
+        for (int base = 0; base < a.nb; base += 4 * kScanThreads, ++it) {
+            const int c0 = base + 4 * tid;
+            double e[4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;
+                e[k] = 0.0; v[k] = 0.0;
+                if (c < a.nb) {
+                    const double mc = pm[c];
+                    e[k] = (mc == M) ? 1.0 : ((mc == -INFINITY) ? 0.0 : exp(mc - M));
+                    v[k] = psum[c] * e[k];
+                    Qacc += pq[c] * (e[k] * e[k]);
+                }
             }
             double tot;
-            const double excl = block_excl_scan<NW>(v, s_scr + NW + (it & 1) * NW, &tot);
-            if (c < a.nb) { a.bc[c] = W + excl; a.bf[c] = e; }
+            const double excl = block_excl_scan<NW>((v[0] + v[1]) + (v[2] + v[3]), s_scr + NW + (it & 1) * NW, &tot);
+            double run = W + excl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;
+                if (c < a.nb) { a.bc[c] = run; a.bf[c] = e[k]; }
+                run += v[k];
+            }
             W += tot;
         }
         __syncthreads();
@@ -302,12 +314,23 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     const int guess0 = (int)((gj_first / inv - in.cdf_lo) / fmax(bcv(in.nb), 1e-300) * in.nb);
     const int c_lo = locate(gj_first, 0, guess0);
     const int c_hi = locate(gj_last, c_lo, c_lo + 1);
+    // linear weights of the 4 sources this lane owns in source tile c
+    auto load_w = [&](int c, double (&w)[kPPT]) {
+        const int64_t i0 = (int64_t)c * kTile + (int64_t)tid * kPPT;
+        load4(in.wrel, i0, w);
+    };
+    // the two tiles an output tile normally overlaps are fetched together (one memory round trip)
+    double w_first[kPPT], w_second[kPPT];
+    load_w(c_lo, w_first);
+    if (c_lo + 1 <= c_hi) load_w(c_lo + 1, w_second);
     int it = 0;
     for (int c = c_lo; c <= c_hi; ++c) {
         const double b0 = bcv(c), b1 = bcv(c + 1);
         if (!(b1 > b0)) continue;                              // tile without mass: owns no output
         double w[kPPT];
-        load4(in.wrel, (int64_t)c * kTile + (int64_t)tid * kPPT, w);
+        if (c == c_lo) { w[0] = w_first[0]; w[1] = w_first[1]; w[2] = w_first[2]; w[3] = w_first[3]; }
+        else if (c == c_lo + 1) { w[0] = w_second[0]; w[1] = w_second[1]; w[2] = w_second[2]; w[3] = w_second[3]; }
+        else load_w(c, w);
         w[1] += w[0]; w[2] += w[1]; w[3] += w[2];
         double tot;
         const double excl = block_excl_scan(w[3], L.scr[it & 1], &tot);
