@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--scope", default="auto", choices=["auto", "global", "island"])
     p.add_argument("--seed", type=int, default=12345)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample", type=int, default=3_000_000, help="particles of the CPU-baseline sample")
+    p.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample")
     p.add_argument("--no-extras", action="store_true", help="skip the secondary gaussian SIS measurement")
     return p.parse_args()
 

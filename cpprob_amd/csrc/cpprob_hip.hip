@@ -19,7 +19,7 @@ namespace {
 
 std::string g_last_error;
 
-struct EventPair { hipEvent_t a, b; int cls; };
+struct EventPair { hipEvent_t a, b; int cls; int count; };
 
 }  // namespace
 
@@ -76,6 +76,7 @@ struct cpprob_hip_ctx {
 
     // optional per-kernel-class timing
     bool profile = false;
+    bool profile_suspended = false;   // an enclosing group scope is timing these launches
     std::vector<EventPair> ev_used, ev_free;
     double prof_ms[CPPROB_HIP_N_KERNEL_CLASSES] = {0};
     int64_t prof_calls[CPPROB_HIP_N_KERNEL_CLASSES] = {0};
@@ -105,12 +106,14 @@ void dfree(T*& p)
 
 struct ProfScope {
     cpprob_hip_ctx* c; int cls; EventPair ep{}; bool on;
-    ProfScope(cpprob_hip_ctx* ctx, int k) : c(ctx), cls(k), on(ctx->profile)
+    // count = launches bracketed by this pair (back-to-back launches of one class are timed as a group, so the
+    // event records do not sit between them)
+    ProfScope(cpprob_hip_ctx* ctx, int k, int count = 1) : c(ctx), cls(k), on(ctx->profile && !ctx->profile_suspended)
     {
         if (!on) return;
         if (!c->ev_free.empty()) { ep = c->ev_free.back(); c->ev_free.pop_back(); }
         else { (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b); }
-        ep.cls = cls;
+        ep.cls = cls; ep.count = count;
         (void)hipEventRecord(ep.a, c->stream);
     }
     ~ProfScope()
@@ -482,9 +485,20 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     } else {
         c->step_protocol = false;
         const bool fused = step_is_fused(c);
-        for (int t = 0; t < c->T; ++t) {
-            dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
-            if (!fused || t + 1 == c->T) launch_scan(c, t, 0, nullptr, 1, 0);   // fused: only the final generation needs the standalone pass
+        if (fused) {
+            // the T step kernels run back to back: one event pair around the group
+            {
+                ProfScope group(c, 0, c->T);
+                c->profile_suspended = true;
+                for (int t = 0; t < c->T; ++t) dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
+                c->profile_suspended = false;
+            }
+            launch_scan(c, c->T - 1, 0, nullptr, 1, 0);                          // only the final generation needs the standalone pass
+        } else {
+            for (int t = 0; t < c->T; ++t) {
+                dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
+                launch_scan(c, t, 0, nullptr, 1, 0);
+            }
         }
     }
     dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
@@ -857,7 +871,7 @@ int cpprob_hip_profile_read(cpprob_hip_ctx* c, double* h_ms, int64_t* h_calls, i
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (auto& ep : c->ev_used) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->prof_ms[ep.cls] += ms; c->prof_calls[ep.cls] += 1; }
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->prof_ms[ep.cls] += ms; c->prof_calls[ep.cls] += ep.count; }
         c->ev_free.push_back(ep);
     }
     c->ev_used.clear();

@@ -81,6 +81,20 @@ __device__ __forceinline__ void store4(T* __restrict__ p, int64_t i, const T (&v
     *reinterpret_cast<typename Vec4<T>::type*>(p + i) = x;
 }
 
+// Streaming store: the particle store is written once per step and next read by a different kernel
+// (possibly on another XCD), so the lines need not stay in this XCD's L2.
+template <class T>
+__device__ __forceinline__ void store4_stream(T* __restrict__ p, int64_t i, const T (&v)[kPPT])
+{
+#ifdef CPPROB_NT_STORES
+    typename Vec4<T>::type x;
+    x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+    __builtin_nontemporal_store(x, reinterpret_cast<typename Vec4<T>::type*>(p + i));
+#else
+    store4(p, i, v);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile partial of the weights this workgroup just produced: {max, sum e, sum e^2}; the linear
 // weights e = exp(lw - max) are returned for the wrel store.  lw of padding slots must be -inf.
@@ -760,8 +774,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     bool valid[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
-    store4(a.values + (int64_t)t * a.ld, j0, x);                                              // predict #t
-    store4(a.anc + (int64_t)t * a.ld, j0, anc);
+    store4_stream(a.values + (int64_t)t * a.ld, j0, x);                                       // predict #t
+    store4_stream(a.anc + (int64_t)t * a.ld, j0, anc);
     double e[kPPT];
     const bool fresh = (t == 0) || resample;                                                  // every particle starts the step at log-weight lwa
     if (Model::kWeightTable > 0 && fresh) {
@@ -788,8 +802,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         tile_partial(lw, e, a.part, s_scr);
     }
     STAMP(4);
-    if (a.store_logw || t + 1 == a.T) store4(a.logw_next, j0, lw);
-    store4(a.wrel_next, j0, e);
+    if (a.store_logw || t + 1 == a.T) store4_stream(a.logw_next, j0, lw);
+    store4_stream(a.wrel_next, j0, e);
     STAMP(5);
 }
 
