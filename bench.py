@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
     p.add_argument("--workload", default="hmm16_smc", choices=["hmm16_smc", "hmm128_smc_ess", "lgssm100_smc", "gaussian_sis"])
-    p.add_argument("--scope", default="auto", choices=["auto", "global", "island"])
+    p.add_argument("--scope", default="auto", choices=["auto", "global", "global-deferred", "island"])
     p.add_argument("--seed", type=int, default=12345)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample")
@@ -155,8 +155,13 @@ def main():
     T = 1 if args.workload == "gaussian_sis" else len(spec["obs"])
     scope = args.scope
     if scope == "auto":
-        scope = "global"          # one joint population: per-step all-gather of the weight totals (north_star)
-    island = scope == "island"
+        # One joint population.  With a STATIC resampling schedule (every step) the joint algorithm -- local resampling,
+        # each shard carrying its share of the mass -- never needs the other shards' totals inside a run: it is the same
+        # estimator as shards combined once by their evidence (tests: ..._static_schedule_equals_evidence_weighted_islands),
+        # so the per-step all-gather is deferred to one all-gather per run.  ESS-triggered schedules need the joint ESS
+        # every step and use the per-step RCCL all-gather.
+        scope = "global" if (world == 1 or spec["ess"] <= 1.0 or spec["alg"] == cp.ALG_SIS) else "global-deferred"
+    island = scope in ("island", "global-deferred")
     eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
               particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND if island else cp.SCOPE_GLOBAL)
 
@@ -171,7 +176,7 @@ def main():
         stats = eng.stats()
     err = float(np.abs(stats - spec["exact"]).max())
     summ = eng.summary()
-    collective = "none" if world == 1 else ("all_gather(1+T*K doubles) once per run" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
+    collective = "none" if world == 1 else ("all_gather(1+T*K doubles/rank) once per run" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
 
     # profiled pass: same K steps with HIP events around every launch on the engine's stream
     # (per-shard kernels only: on several GPUs each rank profiles its own shard as an island)

@@ -22,6 +22,10 @@ Two scopes (include/cpprob_hip.h, cpprob_hip_config.resample_scope):
           non-proportional allocation): particles never migrate, nothing but the 3 doubles crosses
           xGMI, and there is no host synchronisation inside a run.  With one rank this is exactly
           the single-GPU algorithm.  At the end the un-normalised weighted sums are all-reduced.
+          When the resampling schedule is static (every step) the other shards' totals are never
+          needed inside a run -- the carried mass share of shard r is its own evidence estimate --
+          so the joint algorithm is executed as ISLAND + one final combine (same estimator,
+          tests/test_gpu_inference.py::..._static_schedule_equals_evidence_weighted_islands).
 
 Host logic in this file is pure numpy/torch and is covered by gloo world_size-2 tests on CPU.
 """
