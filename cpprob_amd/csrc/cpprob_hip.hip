@@ -195,7 +195,7 @@ void launch_sis(cpprob_hip_ctx* c)
     hipLaunchKernelGGL(sis_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
 }
 
-template <class Model, bool FUSED>
+template <class Model, int FUSED>
 void launch_step_impl(cpprob_hip_ctx* c, StepArgs<Model>& a)
 {
     const size_t shm = FUSED ? (size_t)(2 * c->nb + 1) * sizeof(double) : 0;
@@ -205,7 +205,7 @@ void launch_step_impl(cpprob_hip_ctx* c, StepArgs<Model>& a)
     case CPPROB_HIP_RESAMPLE_STRATIFIED:
         hipLaunchKernelGGL((smc_step_kernel<Model, RS_STRATIFIED, FUSED>), dim3(c->nb), dim3(kThreads), shm, c->stream, a); break;
     default:
-        hipLaunchKernelGGL((smc_step_kernel<Model, RS_PRECOMPUTED, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_PRECOMPUTED, 0>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
     }
 }
 
@@ -242,7 +242,10 @@ void launch_step(cpprob_hip_ctx* c, int t)
     }
     {
         ProfScope ps(c, 0);
-        if (step_is_fused(c)) launch_step_impl<Model, true>(c, a); else launch_step_impl<Model, false>(c, a);
+        if (!step_is_fused(c)) launch_step_impl<Model, 0>(c, a);
+        else if (c->nb <= 2 * kThreads) launch_step_impl<Model, 2>(c, a);
+        else if (c->nb <= 4 * kThreads) launch_step_impl<Model, 4>(c, a);
+        else launch_step_impl<Model, 8>(c, a);
     }
 #ifdef CPPROB_STAMPS
     if (t == 8 && getenv("CPPROB_STAMP_DUMP")) {

@@ -49,6 +49,8 @@ struct StepCtrl {
     double w_local;   // this shard's sum rescaled to M
     double scale;     // exp(M_local - M): rescales bc[] / bf[] (built against the local max) to M
     double u0;        // systematic offset in [0,1) of the resampling that precedes the NEXT step
+    double u0_pp[2];  // fused step kernels: offset of the resampling before step t lives in u0_pp[t & 1] (written by
+                      // workgroup 0 of step t-1 while step t-1's other workgroups may still read u0_pp[(t-1) & 1])
     double inv_stepw; // n_local / (local weight sum, local units): CDF positions -> local output indices
     double lw_after;  // log-weight every particle of this shard carries right after resampling: log of the
                       // shard's mean weight over the population's mean weight (0 on a single shard)
@@ -268,6 +270,7 @@ struct AncestorIn {
     uint64_t seed, step, gj_tile0, n_total_out; int n_valid_tile;
     uint64_t id0;      // RNG id of output 0 (stratified offsets are drawn per global particle id)
     int bc_in_lds;     // bc / bf already point at LDS copies of the whole tile-level CDF (fused step kernel)
+    int guess;         // >= 0: source tile the first output is expected in (equal shard sizes: the output tile's own index)
 };
 
 __device__ __forceinline__ int stage_window(const AncestorIn& in, AncestorLds& L, double q_guess)
@@ -325,7 +328,7 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
         while (b - a > 1) { const int mid = (a + b) >> 1; if (gt(mid) <= g) a = mid; else b = mid; }
         return a;
     };
-    const int guess0 = (int)((gj_first / inv - in.cdf_lo) / fmax(bcv(in.nb), 1e-300) * in.nb);
+    const int guess0 = in.guess >= 0 ? in.guess : (int)((gj_first / inv - in.cdf_lo) / fmax(bcv(in.nb), 1e-300) * in.nb);
     const int c_lo = locate(gj_first, 0, guess0);
     const int c_hi = locate(gj_last, c_lo, c_lo + 1);
     // linear weights of the 4 sources this lane owns in source tile c
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(ResampleArgs a)
     }
     in.seed = a.seed; in.step = a.step; in.gj_tile0 = a.j0 + (uint64_t)blockIdx.x * kTile; in.n_total_out = a.n_total_out;
     in.n_valid_tile = rem < kTile ? (int)rem : kTile;
-    in.id0 = 0; in.bc_in_lds = 0;
+    in.id0 = 0; in.bc_in_lds = 0; in.guess = -1;
     int32_t anc[kPPT];
     find_ancestors<RS>(in, anc, L);
 #pragma unroll
@@ -652,7 +655,9 @@ __device__ __forceinline__ void tile_partial_table(const int (&idx)[kPPT], const
     }
 }
 
-template <class Model, int RS, bool FUSED>
+// FUSED: 0 = read ctrl / bc / bf (scan_partials_kernel ran); otherwise the number of tile partials each lane
+// holds in registers in the normalisation prologue (2, 4 or 8: populations of <= 512, 1024, 2048 tiles)
+template <class Model, int RS, int FUSED>
 __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
 {
     using V = typename Model::value_t;
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         if (FUSED) {
             // ---- normalise generation t-1 from its tile partials (every workgroup, identically) ----
             // one coalesced pass over the three partial arrays into registers (<= kFuseMaxTiles / 256 per lane)
-            constexpr int kPer = kFuseMaxTiles / kThreads;
+            constexpr int kPer = FUSED > 0 ? FUSED : 1;
             const double* pm = a.part_prev; const double* psum = a.part_prev + a.nb; const double* pq = a.part_prev + 2 * a.nb;
             double rm[kPer], rs[kPer], rq[kPer];
             double m = -INFINITY;
@@ -717,10 +722,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
             resample = ess < a.ess_frac * a.n_pop;                            // ESS test, thesis p.37 (t-1 is never the last step here)
             inv_stepw = (double)a.n / W;
             lwa = 0.0;
-            {
-                const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)t);
-                u0 = u01_53(r.x, r.y);
-            }
+            u0 = a.ctrl->u0_pp[t & 1];                                        // left there by workgroup 0 of step t-1
             if (blockIdx.x == 0 && tid == 0) {                                // bookkeeping for the host
                 StepCtrl* c = a.ctrl;
                 c->M = M; c->W = W; c->Q = Q; c->ess = ess; c->do_resample = resample ? 1 : 0;
@@ -757,6 +759,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
             in.seed = a.seed; in.step = (uint64_t)t; in.gj_tile0 = (uint64_t)blockIdx.x * kTile; in.n_total_out = (uint64_t)a.n;
             in.id0 = a.pid0;
             in.n_valid_tile = rem < kTile ? (int)rem : kTile;
+            in.guess = (int)blockIdx.x;
             find_ancestors<RS>(in, anc, L);
         }
 #pragma unroll
@@ -804,6 +807,10 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     STAMP(4);
     if (a.store_logw || t + 1 == a.T) store4_stream(a.logw_next, j0, lw);
     store4_stream(a.wrel_next, j0, e);
+    if (FUSED && blockIdx.x == 0 && tid == 0 && t + 1 < a.T) {              // systematic offset of the resampling before step t+1
+        const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(t + 1));
+        a.ctrl->u0_pp[(t + 1) & 1] = u01_53(r.x, r.y);
+    }
     STAMP(5);
 }
 
