@@ -21,7 +21,7 @@ SYMBOLS = [
     "cpprob_hip_infer_stats", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
     "cpprob_hip_smc_finish", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
-    "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
+    "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
     "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
     "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_resample", "cpprob_hip_gather_f64",
     "cpprob_hip_gather_i32", "cpprob_hip_profile_enable", "cpprob_hip_profile_read",
@@ -83,6 +83,7 @@ def load_library(path=None):
         "cpprob_hip_draw_uniform_smallint": (C.c_int, [vp, u64, u64, u64, i64, i64, sz, vp]),
         "cpprob_hip_draw_discrete": (C.c_int, [vp, u64, u64, u64, C.POINTER(dbl), i32, sz, vp]),
         "cpprob_hip_draw_uniform_real": (C.c_int, [vp, u64, u64, u64, dbl, dbl, sz, vp]),
+        "cpprob_hip_draw_poisson": (C.c_int, [vp, u64, u64, u64, dbl, sz, vp]),
         "cpprob_hip_logpdf_normal": (C.c_int, [vp, vp, vp, vp, sz, vp]),
         "cpprob_hip_logpdf_uniform_real": (C.c_int, [vp, vp, vp, vp, sz, vp]),
         "cpprob_hip_logpdf_poisson": (C.c_int, [vp, vp, vp, sz, vp]),
@@ -239,6 +240,9 @@ class Engine:
 
     def draw_uniform_real(self, seed, pid0, draw, a, b, out):
         self._chk(self.L.cpprob_hip_draw_uniform_real(self.h, seed, pid0, draw, a, b, out.numel(), _dptr(out)))
+
+    def draw_poisson(self, seed, pid0, draw, mean, out):
+        self._chk(self.L.cpprob_hip_draw_poisson(self.h, seed, pid0, draw, mean, out.numel(), _dptr(out)))
 
     def logpdf_normal(self, x, mean, sigma, out):
         self._chk(self.L.cpprob_hip_logpdf_normal(self.h, _dptr(x), _dptr(mean), _dptr(sigma), x.numel(), _dptr(out)))

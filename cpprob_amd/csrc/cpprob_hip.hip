@@ -701,6 +701,16 @@ int cpprob_hip_draw_uniform_real(cpprob_hip_ctx* c, uint64_t seed, uint64_t pid0
     return 0;
 }
 
+int cpprob_hip_draw_poisson(cpprob_hip_ctx* c, uint64_t seed, uint64_t pid0, uint64_t draw, double mean, size_t n, int32_t* d_out)
+{
+    BB_PRELUDE(c);
+    if (!(mean >= 0.0)) return fail(c, CPPROB_HIP_EINVAL, "poisson needs mean >= 0");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(draw_poisson_kernel, GRID1(n), seed, pid0, draw, mean, (int64_t)n, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 int cpprob_hip_logpdf_normal(cpprob_hip_ctx* c, const double* x, const double* mean, const double* sigma, size_t n, double* out)
 {
     BB_PRELUDE(c);

@@ -950,6 +950,12 @@ __global__ void draw_uniform_real_kernel(uint64_t seed, uint64_t pid0, uint64_t 
     if (i < n) out[i] = draw_uniform_real(seed, pid0 + (uint64_t)i, draw, a, b);
 }
 
+__global__ void draw_poisson_kernel(uint64_t seed, uint64_t pid0, uint64_t draw, double mean, int64_t n, int32_t* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)draw_poisson(seed, pid0 + (uint64_t)i, draw, mean);
+}
+
 __global__ void logpdf_normal_kernel(const double* __restrict__ x, const double* __restrict__ mean, const double* __restrict__ sigma, int64_t n,
                                      double* __restrict__ out)
 {

@@ -1,7 +1,7 @@
 // Host driver in plain C++14 with the command-line surface of the reference's src/main.cpp for the
 // sis path (flags :145-170, flow :69-107), plus --smc:
 //     cpprob_main --model hmm16 --smc --n_samples 100000 --observes "[0.3 -1 ...]" --estimate
-// Flags: --model {gaussian_unknown_mean, gaussian_readme, linear_gaussian_1d25, linear_gaussian_1d100, hmm16, hmm128}
+// Flags: --model {gaussian_unknown_mean, gaussian_readme, linear_gaussian_1d25, linear_gaussian_1d100, hmm16, hmm128, poisson_rate}
 //        --sis | --smc        --n_samples N (default 10000)    --observes "…" | --observes_file F
 //        --generated_file NAME (default "post")   --model_folder DIR (default ".")   --estimate
 //        additions: --seed S  --resampler {systematic,stratified,multinomial}  --ess_threshold X
@@ -112,6 +112,7 @@ int main(int argc, char** argv)
         if (a.model == "linear_gaussian_1d100") return execute(models::linear_gaussian_1d<100>, a);
         if (a.model == "hmm16") return execute(models::hmm<16>, a);
         if (a.model == "hmm128") return execute(models::hmm<128>, a);
+        if (a.model == "poisson_rate") return execute(models::poisson_rate<double>, a);
         std::cerr << "unknown model " << a.model << std::endl;
         return EXIT_FAILURE;
     } catch (const std::exception& e) {

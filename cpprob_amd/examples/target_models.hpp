@@ -11,6 +11,8 @@
 
 #include <boost/random/discrete_distribution.hpp>
 #include <boost/random/normal_distribution.hpp>
+#include <boost/random/poisson_distribution.hpp>
+#include <boost/random/uniform_real_distribution.hpp>
 #include <boost/random/uniform_smallint.hpp>
 
 #include "cpprob/cpprob.hpp"
@@ -74,6 +76,20 @@ void hmm(const std::array<double, N>& ys)
         lik = boost::random::normal_distribution<>{mean[s], 1};
         cpprob::observe(lik, ys[t]);
     }
+}
+
+// Not in the reference: a model over the remaining scalar distributions of the scope table:
+// uniform prior on a Poisson rate, two counts observed, predict "Rate".  Only runs through the generic
+// device path (no hand-fused kernel exists for it).
+template <class Real = double>
+void poisson_rate(const int k1, const int k2)
+{
+    boost::random::uniform_real_distribution<Real> prior{0.5, 10};
+    const Real rate = cpprob::sample(prior, true);
+    boost::random::poisson_distribution<int, Real> lik{rate};
+    cpprob::observe(lik, k1);
+    cpprob::observe(lik, k2);
+    cpprob::predict(rate, "Rate");
 }
 
 }  // namespace models

@@ -17,6 +17,7 @@
 
 #include <boost/random/discrete_distribution.hpp>
 #include <boost/random/normal_distribution.hpp>
+#include <boost/random/poisson_distribution.hpp>
 #include <boost/random/uniform_real_distribution.hpp>
 #include <boost/random/uniform_smallint.hpp>
 
@@ -83,6 +84,12 @@ template <class R>
 __device__ inline R draw(const boost::random::uniform_real_distribution<R>& d, uint64_t seed, uint64_t pid, uint64_t j)
 {
     return static_cast<R>(cph::draw_uniform_real(seed, pid, j, d.a(), d.b()));
+}
+
+template <class I, class R>
+__device__ inline I draw(const boost::random::poisson_distribution<I, R>& d, uint64_t seed, uint64_t pid, uint64_t j)
+{
+    return static_cast<I>(cph::draw_poisson(seed, pid, j, static_cast<double>(d.mean())));
 }
 
 template <class Distribution>

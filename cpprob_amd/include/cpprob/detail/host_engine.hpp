@@ -42,8 +42,8 @@ private:
 };
 
 // ---- flatten the observes tuple into doubles (scalars and std::array<double, N>) -----------------
-inline void flatten_one(std::vector<double>& out, double x) { out.push_back(x); }
-inline void flatten_one(std::vector<double>& out, float x) { out.push_back(x); }
+template <class T, std::enable_if_t<std::is_arithmetic<T>::value, int> = 0>
+void flatten_one(std::vector<double>& out, T x) { out.push_back(static_cast<double>(x)); }
 template <class T, std::size_t N> void flatten_one(std::vector<double>& out, const std::array<T, N>& a) { for (const auto& x : a) out.push_back(static_cast<double>(x)); }
 template <class T> void flatten_one(std::vector<double>& out, const std::vector<T>& a) { for (const auto& x : a) out.push_back(static_cast<double>(x)); }
 template <class Tuple, std::size_t... I>

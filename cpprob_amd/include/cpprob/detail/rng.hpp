@@ -125,6 +125,20 @@ __device__ __forceinline__ double draw_uniform_real(uint64_t seed, uint64_t pid,
     return a + (b - a) * draw_u01_53(seed, pid, draw);
 }
 
+// boost::random::poisson_distribution<>{mean}(rng): inversion by sequential search on one 53-bit uniform
+// (k = 0; p = F = exp(-mean); while u > F: ++k, p *= mean / k, F += p).  Exact law; cost O(mean).
+__device__ __forceinline__ int64_t poisson_from_u(double u, double mean)
+{
+    int64_t k = 0;
+    double p = exp(-mean), F = p;
+    while (u > F && k < 100000) { ++k; p *= mean / (double)k; F += p; }
+    return k;
+}
+__device__ __forceinline__ int64_t draw_poisson(uint64_t seed, uint64_t pid, uint64_t draw, double mean)
+{
+    return poisson_from_u(draw_u01_53(seed, pid, draw), mean);
+}
+
 // ---- 4 consecutive particles per lane ---------------------------------------------------------
 // 32-bit words of particles pid0 .. pid0+3 (one Philox evaluation when pid0 % 4 == 0)
 __device__ __forceinline__ void draw_words4(uint64_t seed, uint64_t pid0, uint64_t draw, uint32_t (&w)[4])

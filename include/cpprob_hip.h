@@ -179,6 +179,8 @@ int cpprob_hip_draw_normal(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, ui
 int cpprob_hip_draw_uniform_smallint(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, int64_t a, int64_t b, size_t n, int32_t* d_out);
 int cpprob_hip_draw_discrete(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, const double* h_weights, int32_t k, size_t n, int32_t* d_out);
 int cpprob_hip_draw_uniform_real(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, double a, double b, size_t n, double* d_out);
+/* poisson: inversion by sequential search on the particle's 53-bit uniform (exact law, cost O(mean)) */
+int cpprob_hip_draw_poisson(cpprob_hip_ctx* ctx, uint64_t seed, uint64_t pid0, uint64_t draw, double mean, size_t n, int32_t* d_out);
 
 /* logpdf functors (include/cpprob/distributions/utils_*.hpp), elementwise. */
 int cpprob_hip_logpdf_normal(cpprob_hip_ctx* ctx, const double* d_x, const double* d_mean, const double* d_sigma, size_t n, double* d_out);

@@ -185,6 +185,16 @@ ORC_API double orc_draw_uniform_real(uint64_t seed, uint64_t pid, uint64_t draw,
     return a + (b - a) * orc_draw_u01_53(seed, pid, draw);
 }
 
+/* poisson_distribution{mean}: inversion by sequential search on the 53-bit uniform */
+ORC_API int64_t orc_draw_poisson(uint64_t seed, uint64_t pid, uint64_t draw, double mean)
+{
+    double u = orc_draw_u01_53(seed, pid, draw);
+    int64_t k = 0;
+    double p = exp(-mean), F = p;
+    while (u > F && k < 100000) { ++k; p *= mean / (double)k; F += p; }
+    return k;
+}
+
 /* ------------------------------------------------------------------------- */
 /* logpdf functors                                                            */
 /* ------------------------------------------------------------------------- */

@@ -42,6 +42,7 @@ def lib():
         L.orc_draw_smallint.restype = u64; L.orc_draw_smallint.argtypes = [u64, u64, u64, u64, u64]
         L.orc_draw_discrete.restype = u64; L.orc_draw_discrete.argtypes = [u64, u64, u64, _dp, C.c_int]
         L.orc_draw_uniform_real.restype = dbl; L.orc_draw_uniform_real.argtypes = [u64, u64, u64, dbl, dbl]
+        L.orc_draw_poisson.restype = i64; L.orc_draw_poisson.argtypes = [u64, u64, u64, dbl]
         L.orc_normal_logpdf.restype = dbl; L.orc_normal_logpdf.argtypes = [dbl, dbl, dbl]
         L.orc_uniform_smallint_logpdf.restype = dbl; L.orc_uniform_smallint_logpdf.argtypes = [i64, i64, i64]
         L.orc_discrete_logpdf.restype = dbl; L.orc_discrete_logpdf.argtypes = [i64, _dp, C.c_int]

@@ -73,6 +73,14 @@ def test_draws_match_oracle(engine):
     ref = np.array([L.orc_draw_uniform_real(1, i, 2, -3.0, 5.0) for i in range(n)])
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=FP_TOL, atol=FP_TOL)
 
+    for lam in (0.3, 4.0, 25.0):
+        engine.draw_poisson(5, 3, 1, lam, outi)
+        engine.sync()
+        ref = np.array([L.orc_draw_poisson(5, 3 + i, 1, lam) for i in range(n)])
+        got = outi.cpu().numpy()
+        assert np.mean(got != ref) < 1e-4          # exp / running products differ by ulps: a draw on a CDF boundary may flip
+        assert abs(got.mean() - lam) < 5 * np.sqrt(lam / n) and abs(got.var() - lam) < 0.1 * lam + 0.05
+
 
 def test_logpdf_normal_reference_grid(engine, golden_dir):
     """The grid of the reference's own test (tests/cpprob/logpdf.cpp:23-35), eps 1e-8 there."""

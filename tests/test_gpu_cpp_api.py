@@ -134,3 +134,27 @@ def test_cli_errors_like_the_reference(tmp_path):
     assert "Could not parse the observations" in err
     _, _, err = run_main(tmp_path, "--model", "hmm16", "--sis", expect_rc=1)
     assert "exactly one of the options" in err
+
+
+def test_generic_path_other_distributions(tmp_path):
+    """uniform_real prior + poisson observes: only the generic device path can run it."""
+    n = 400000
+    res, _, _ = run_main(tmp_path, "--model", "poisson_rate", "--sis", "--observes", "3 5", "--n_samples", n, "--seed", 2, "--json", "--no_dump")
+    assert not res["builtin"]
+    lam = np.linspace(0.5, 10.0, 200001)
+    post = lam ** 8 * np.exp(-2 * lam)              # flat prior on [0.5, 10], counts 3 and 5
+    post /= np.trapezoid(post, lam)
+    mean = np.trapezoid(lam * post, lam)
+    var = np.trapezoid(lam ** 2 * post, lam) - mean ** 2
+    p = res["predicts"][0]
+    assert p["address"] == "Rate"
+    assert abs(p["mean"] - mean) < 0.02 and abs(p["variance"] - var) < 0.05
+    # evidence: integral of the likelihood against the flat prior
+    from scipy.special import gammaln
+    lik = np.exp(8 * np.log(lam) - 2 * lam - gammaln(4) - gammaln(6)) / 9.5
+    assert abs(res["log_evidence"] - np.log(np.trapezoid(lik, lam))) < 0.02
+    # smc on the same model: two observes -> one resampling opportunity, same posterior
+    res2, _, _ = run_main(tmp_path, "--model", "poisson_rate", "--smc", "--observes", "3 5", "--n_samples", n, "--seed", 2, "--json", "--no_dump",
+                          "--ess_threshold", 2.0)
+    assert res2["n_resampled"] == 1
+    assert abs(res2["predicts"][0]["mean"] - mean) < 0.03 and abs(res2["log_evidence"] - res["log_evidence"]) < 0.02

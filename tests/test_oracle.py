@@ -88,6 +88,8 @@ def test_generators_have_the_right_laws():
     w = np.array([0.15, 0.15, 0.7])
     d = np.array([L.orc_draw_discrete(3, i, 2, w, 3) for i in range(n)])
     assert np.all(np.abs(np.bincount(d, minlength=3) / n - w) < 0.005)
+    k = np.array([L.orc_draw_poisson(3, i, 4, 3.7) for i in range(n)])
+    assert abs(k.mean() - 3.7) < 0.03 and abs(k.var() - 3.7) < 0.08
     u = np.array([L.orc_draw_uniform_real(3, i, 3, -1.0, 3.0) for i in range(n)])
     assert u.min() >= -1.0 and u.max() < 3.0 and abs(u.mean() - 1.0) < 0.02
 
