@@ -40,7 +40,6 @@ struct cpprob_hip_ctx {
     ModelParams mp{};
     uint64_t run_seed = 0;
     uint64_t pop_n = 0;     // size of the population this shard is resampled with (n_global, or n for islands)
-    uint64_t pos0 = 0;      // index of local slot 0 inside that population
 
     // device buffers
     double* d_obs = nullptr;
@@ -400,7 +399,6 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     c->cfg = *cfg;
     const bool island = cfg->resample_scope == CPPROB_HIP_SCOPE_ISLAND;
     c->pop_n = island ? cfg->n_particles : cfg->n_global;
-    c->pos0 = island ? 0 : cfg->particle_offset;
     c->T = model_T(cfg->model, n_obs);
     c->n_obs = (int)n_obs;
     c->is_int = cfg->model == CPPROB_HIP_MODEL_HMM3;

@@ -31,7 +31,7 @@ void print_json(const cpprob::gpu::Result& r)
 {
     std::cout.precision(17);
     std::cout << "{\"n\": " << r.n_particles << ", \"log_evidence\": " << r.log_evidence << ", \"ess\": " << r.ess
-              << ", \"n_resampled\": " << r.n_resampled << ", \"builtin\": " << (r.used_builtin ? "true" : "false") << ", \"predicts\": [";
+              << ", \"n_resampled\": " << r.n_resampled << ", \"run_seconds\": " << r.run_seconds << ", \"builtin\": " << (r.used_builtin ? "true" : "false") << ", \"predicts\": [";
     for (std::size_t i = 0; i < r.predicts.size(); ++i) {
         const auto& p = r.predicts[i];
         if (i) std::cout << ", ";

@@ -5,6 +5,7 @@
 #ifndef CPPROB_COMPAT_DETAIL_HOST_ENGINE_HPP
 #define CPPROB_COMPAT_DETAIL_HOST_ENGINE_HPP
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -101,9 +102,11 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
     cfg.seed = opt.seed;
     cfg.n_particles = n; cfg.particle_offset = 0; cfg.n_global = n;
     ctx.check(cpprob_hip_infer_begin(ctx.get(), &cfg, obs.data(), obs.size()), "cpprob_hip_infer_begin");
+    const auto t0 = std::chrono::steady_clock::now();
     ctx.check(cpprob_hip_infer_run(ctx.get(), 0), "cpprob_hip_infer_run");
     cpprob_hip_summary s{};
     ctx.check(cpprob_hip_infer_summary(ctx.get(), &s), "cpprob_hip_infer_summary");
+    res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const std::size_t T = static_cast<std::size_t>(s.n_predict), K = static_cast<std::size_t>(s.stats_per_predict);
     if ((s.is_int ? st.int_ids.size() : st.real_ids.size()) != T)
         throw std::runtime_error("built-in model kernel and the model function disagree on the number of predict statements");

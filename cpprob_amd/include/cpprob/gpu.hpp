@@ -31,6 +31,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -117,6 +118,7 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
 
     ModelKernelArgs a{};
     a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed;
+    const auto t_start = std::chrono::steady_clock::now();
     double log_z = 0.0;
     int cur = 0, n_resampled = 0;
     res.step_ess.clear();
@@ -154,6 +156,7 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     log_z += o3[1] - std::log((double)n);
     res.n_particles = n; res.log_evidence = log_z; res.log_norm = o3[1]; res.ess = o3[2]; res.n_resampled = n_resampled; res.used_builtin = false;
     fill_predict_names(res, st);
+    res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();   // (the logsumexp above synchronised)
     for (size_t k = 0; k < n_real; ++k) {
         double o4[4];
         ctx.check(cpprob_hip_weighted_moments(ctx.get(), d_real.p + k * n, logw[cur], n, o4), "cpprob_hip_weighted_moments");

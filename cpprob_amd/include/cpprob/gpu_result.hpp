@@ -35,6 +35,7 @@ struct Result {
     double log_evidence = 0, ess = 0, log_norm = 0;
     int n_resampled = 0;
     bool used_builtin = false;
+    double run_seconds = 0;                   // device work of the run (launch to synchronise), excluding allocation and dumps
     std::vector<PredictStats> predicts;       // real hits first (in trace order), then int hits
     std::vector<double> step_ess;             // smc: ESS after each observe
 };
