@@ -53,6 +53,7 @@ struct cpprob_hip_ctx {
     Partial* d_part[2] = {nullptr, nullptr};   // tile partials, ping-pong between generations
     int cur_part = 0;                          // which one holds the latest generation
     double* d_e_tab = nullptr;                 // hmm: [T][4]
+    double* d_gpart = nullptr;                 // slab partials of the two-level normalisation (large populations)
     double* d_bc = nullptr;
     StepCtrl* d_ctrl = nullptr;
     double* d_ess = nullptr;
@@ -228,8 +229,8 @@ void launch_step(cpprob_hip_ctx* c, int t)
     a.n_pop = (double)c->pop_n; a.ess_frac = c->cfg.ess_threshold; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
     a.store_logw = c->cfg.ess_threshold > 1.0 ? 0 : 1;      // ESS <= N always: threshold > 1 resamples after every step
 #ifdef CPPROB_STAMPS
-    { static unsigned long long* d_st = nullptr; if (!d_st) (void)hipMalloc(&d_st, (size_t)65536 * 8 * 8); a.stamps = d_st;
-      if (t == 8 && getenv("CPPROB_STAMP_DUMP")) { /* dump after launch below */ } }
+    static unsigned long long* d_st = nullptr;
+    if (!d_st) { (void)hipMalloc(&d_st, (size_t)131072 * 16 * 8); (void)hipMemset(d_st, 0, (size_t)131072 * 16 * 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)); }
 #endif
     if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && t > 0) {
         // literal thesis Alg. 1: materialise the CDF, draw N independent positions.  Runs
@@ -249,13 +250,15 @@ void launch_step(cpprob_hip_ctx* c, int t)
 #ifdef CPPROB_STAMPS
     if (t == 8 && getenv("CPPROB_STAMP_DUMP")) {
         (void)hipStreamSynchronize(c->stream);
-        std::vector<unsigned long long> h((size_t)c->nb * 8);
-        (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
-        unsigned long long t0 = ~0ull; for (int b = 0; b < c->nb; ++b) t0 = std::min(t0, h[(size_t)b * 8]);
-        double acc[6] = {0}; double mx[6] = {0};
-        for (int b = 0; b < c->nb; ++b) for (int k = 0; k < 6; ++k) { double v = (double)(h[(size_t)b * 8 + k] - t0) * 0.01; acc[k] += v; mx[k] = std::max(mx[k], v); }
-        fprintf(stderr, "STAMPS t=8 (us since first block start) mean/max: ");
-        for (int k = 0; k < 6; ++k) fprintf(stderr, "[%d] %.2f/%.2f  ", k, acc[k] / c->nb, mx[k]);
+        std::vector<unsigned long long> h((size_t)c->nb * 16);
+        (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull; for (int b2 = 0; b2 < c->nb; ++b2) t0 = std::min(t0, h[(size_t)b2 * 16]);
+        fprintf(stderr, "STAMPS t=8 n=%lld (us since first workgroup start) mean/max:", (long long)c->n);
+        for (int k = 0; k < 12; ++k) {
+            double acc = 0, mx = 0;
+            for (int b2 = 0; b2 < c->nb; ++b2) { const double v = (double)(h[(size_t)b2 * 16 + k] - t0) * 0.01; acc += v; mx = std::max(mx, v); }
+            fprintf(stderr, " [%d] %.2f/%.2f", k, acc / c->nb, mx);
+        }
         fprintf(stderr, "\n");
     }
 #endif
@@ -272,7 +275,14 @@ void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, 
     sa.force_no_resample = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
     sa.all_totals = all_totals; sa.world = world; sa.rank = rank; sa.local_totals = c->totals_out ? c->totals_out : c->d_local_totals; sa.phase = phase;
     ProfScope ps(c, 1);
-    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, sa);
+    if (phase != 2 && c->nb > kSlabThreshold) {
+        // large population: two multi-workgroup launches instead of one single-CU pass
+        const int G = (c->nb + kSlabTiles - 1) / kSlabTiles;
+        hipLaunchKernelGGL(scan_slab_partials_kernel, dim3(G), dim3(kThreads), 0, c->stream, sa.part, c->nb, c->d_gpart);
+        hipLaunchKernelGGL(scan_slab_finish_kernel, dim3(G), dim3(kThreads), 0, c->stream, sa, (const double*)c->d_gpart, G);
+    } else {
+        hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, sa);
+    }
 }
 
 template <class Model>
@@ -309,7 +319,7 @@ int dispatch_model(cpprob_hip_ctx* c, F&& f)
 void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
-    dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
+    dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
     dfree(c->d_cdf); dfree(c->d_anc_pre);
     c->cap_particles = 0; c->cap_T = 0;
 }
@@ -385,6 +395,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     if (gauss && n_obs != 2) return fail(c, CPPROB_HIP_EINVAL, "gaussian_unknown_mean takes exactly two observes");
     if (cfg->n_particles == 0) return fail(c, CPPROB_HIP_EINVAL, "n_particles must be > 0");
     if (cfg->n_particles > (uint64_t)INT32_MAX - kTile) return fail(c, CPPROB_HIP_EINVAL, "n_particles per context must fit int32 ancestor indices");
+    if (cfg->n_particles > (uint64_t)kMaxSlabs * kSlabTiles * kTile) return fail(c, CPPROB_HIP_EINVAL, "n_particles per context exceeds 2^30");
     if (cfg->n_global < cfg->n_particles || cfg->particle_offset + cfg->n_particles > cfg->n_global)
         return fail(c, CPPROB_HIP_EINVAL, "shard [particle_offset, particle_offset + n_particles) must lie inside [0, n_global)");
     if (cfg->algorithm == CPPROB_HIP_ALG_SMC) {
@@ -427,6 +438,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)c->nb * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)c->nb * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_bc, ((size_t)c->nb + 1) * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_gpart, (size_t)3 * kMaxSlabs * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_ess, T * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_resampled, T * sizeof(int32_t)));
         HIP_TRY(c, hipMalloc(&c->d_stats_part, (size_t)c->smooth_grid * T * 8 * sizeof(double)));

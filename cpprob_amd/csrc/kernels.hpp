@@ -153,6 +153,32 @@ struct ScanArgs {
     int phase;                 // 0: single shard (everything); 1: local part; 2: combine ranks
 };
 
+// Bookkeeping of a weighted generation once (M, W, Q) sit in ctrl: ESS, resampling decision, evidence,
+// the local resampling scale, the next systematic offset.  One thread.
+__device__ __forceinline__ void scan_tail(const ScanArgs& a)
+{
+    StepCtrl* ctrl = a.ctrl;
+    const double W = ctrl->W, Q = ctrl->Q, M = ctrl->M;
+    const double ess = W * W / Q;
+    ctrl->ess = ess;
+    const bool last = a.t + 1 == a.T;
+    const bool rs = !a.force_no_resample && !last && (ess < a.ess_frac * a.n_pop);
+    ctrl->do_resample = rs ? 1 : 0;
+    if (a.t == 0) { ctrl->log_z = 0.0; ctrl->n_resampled = 0; }
+    if (rs || last) ctrl->log_z += M + log(W / a.n_pop);
+    if (rs) ctrl->n_resampled += 1;
+    // Resampling is local to the shard (particles never migrate): outputs 0..n_local-1 are drawn over the
+    // shard's own CDF, and the shard's share of the total mass is carried by lw_after
+    // (distributed resampling with non-proportional allocation; exact for one shard, where lw_after = 0).
+    const double w_loc_units = a.bc[a.nb];                       // local sum in local-max units
+    ctrl->inv_stepw = a.n_local / w_loc_units;
+    ctrl->lw_after = (a.phase == 2) ? log((ctrl->w_local / a.n_local) / (W / a.n_pop)) : 0.0;
+    const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(a.t + 1));
+    ctrl->u0 = u01_53(r.x, r.y);
+    if (a.ess_trace) a.ess_trace[a.t] = ess;
+    if (a.resampled) a.resampled[a.t] = rs ? 1 : 0;
+}
+
 __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
 {
     constexpr int NW = kScanThreads / kWave;
@@ -223,26 +249,106 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
             ctrl->M = M; ctrl->W = W; ctrl->Q = Q; ctrl->cdf_lo = lo; ctrl->w_local = wl; ctrl->scale = sc;
         }
     }
-    if (tid == 0) {
-        const double W = ctrl->W, Q = ctrl->Q, M = ctrl->M;
-        const double ess = W * W / Q;
-        ctrl->ess = ess;
-        const bool last = a.t + 1 == a.T;
-        const bool rs = !a.force_no_resample && !last && (ess < a.ess_frac * a.n_pop);
-        ctrl->do_resample = rs ? 1 : 0;
-        if (a.t == 0) { ctrl->log_z = 0.0; ctrl->n_resampled = 0; }
-        if (rs || last) ctrl->log_z += M + log(W / a.n_pop);
-        if (rs) ctrl->n_resampled += 1;
-        // Resampling is local to the shard (particles never migrate): outputs 0..n_local-1 are drawn over the
-        // shard's own CDF, and the shard's share of the total mass is carried by lw_after
-        // (distributed resampling with non-proportional allocation; exact for one shard, where lw_after = 0).
-        const double w_loc_units = a.bc[a.nb];                       // local sum in local-max units
-        ctrl->inv_stepw = a.n_local / w_loc_units;
-        ctrl->lw_after = (a.phase == 2) ? log((ctrl->w_local / a.n_local) / (W / a.n_pop)) : 0.0;
-        const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(a.t + 1));
-        ctrl->u0 = u01_53(r.x, r.y);
-        if (a.ess_trace) a.ess_trace[a.t] = ess;
-        if (a.resampled) a.resampled[a.t] = rs ? 1 : 0;
+    if (tid == 0) scan_tail(a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large populations (more than kSlabThreshold tiles): one workgroup cannot stream the partials fast
+// enough (a single CU moves ~25 GB/s), so the same normalisation runs as two multi-workgroup launches
+// over slabs of 1024 tiles:
+//   scan_slab_partials_kernel : slab g -> {max, sum, sum of squares} relative to the slab max
+//   scan_slab_finish_kernel   : every workgroup combines the <= 1024 slab partials (redundantly,
+//                               identically), then writes bc[] / bf[] of its own slab against the global
+//                               max; workgroup 0 does the bookkeeping.
+// Consumers see exactly the arrays scan_partials_kernel would have produced.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSlabTiles = kTile;          // 1024 tiles per workgroup: 4 consecutive tiles per lane
+constexpr int kSlabThreshold = 4096;
+constexpr int kMaxSlabs = 1024;
+
+__global__ __launch_bounds__(kThreads) void scan_slab_partials_kernel(const double* __restrict__ part, int nb, double* __restrict__ gpart)
+{
+    __shared__ double s_scr[3 * kWaves];
+    const int G = (int)gridDim.x, g = (int)blockIdx.x;
+    const double* pm = part; const double* psum = part + nb; const double* pq = part + 2 * nb;
+    const int c0 = g * kSlabTiles + (int)threadIdx.x * 4;
+    double m[4], sv[4], qv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        const bool in = c < nb;
+        m[k] = in ? pm[c] : -INFINITY; sv[k] = in ? psum[c] : 0.0; qv[k] = in ? pq[c] : 0.0;
+    }
+    const double mg = block_max(fmax(fmax(m[0], m[1]), fmax(m[2], m[3])), s_scr);
+    double S = 0.0, Q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double e = (m[k] == mg) ? 1.0 : ((m[k] == -INFINITY) ? 0.0 : exp(m[k] - mg));
+        S += sv[k] * e; Q += qv[k] * (e * e);
+    }
+    block_sum2(S, Q, s_scr + kWaves);
+    if (threadIdx.x == 0) { gpart[g] = mg; gpart[G + g] = S; gpart[2 * G + g] = Q; }
+}
+
+__global__ __launch_bounds__(kThreads) void scan_slab_finish_kernel(ScanArgs a, const double* __restrict__ gpart, int G)
+{
+    __shared__ double s_scr[4 * kWaves];
+    const int tid = threadIdx.x, g = (int)blockIdx.x;
+    // combine the slab partials: global max, total mass, total squares, mass of the slabs before mine
+    constexpr int kPerG = kMaxSlabs / kThreads;
+    double gm[kPerG], gs[kPerG], gq[kPerG];
+    double m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kPerG; ++i) {
+        const int j = tid + i * kThreads;
+        const bool in = j < G;
+        gm[i] = in ? gpart[j] : -INFINITY; gs[i] = in ? gpart[G + j] : 0.0; gq[i] = in ? gpart[2 * G + j] : 0.0;
+        m = fmax(m, gm[i]);
+    }
+    const double M = block_max(m, s_scr);
+    double Wt = 0.0, Qt = 0.0, before = 0.0;
+#pragma unroll
+    for (int i = 0; i < kPerG; ++i) {
+        const int j = tid + i * kThreads;
+        const double e = (gm[i] == M) ? 1.0 : ((gm[i] == -INFINITY) ? 0.0 : exp(gm[i] - M));
+        const double v = gs[i] * e;
+        Wt += v; Qt += gq[i] * (e * e);
+        if (j < g) before += v;
+    }
+    block_sum2(Wt, Qt, s_scr + kWaves);
+    before = block_sum(before, s_scr + 3 * kWaves);
+    // my slab against the global max
+    const double* pm = a.part; const double* psum = a.part + a.nb;
+    const int c0 = g * kSlabTiles + tid * 4;
+    double e[4], v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        e[k] = 0.0; v[k] = 0.0;
+        if (c < a.nb) {
+            const double mc = pm[c];
+            e[k] = (mc == M) ? 1.0 : ((mc == -INFINITY) ? 0.0 : exp(mc - M));
+            v[k] = psum[c] * e[k];
+        }
+    }
+    __syncthreads();                                            // s_scr is about to be reused
+    double tot;
+    const double excl = block_excl_scan((v[0] + v[1]) + (v[2] + v[3]), s_scr, &tot);
+    double run = before + excl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        if (c < a.nb) { a.bc[c] = run; a.bf[c] = e[k]; }
+        run += v[k];
+    }
+    if (g == 0 && tid == 0) {
+        a.bc[a.nb] = Wt;
+        if (a.phase == 1) {
+            a.local_totals[0] = M; a.local_totals[1] = Wt; a.local_totals[2] = Qt;
+        } else {
+            a.ctrl->M = M; a.ctrl->W = Wt; a.ctrl->Q = Qt; a.ctrl->cdf_lo = 0.0; a.ctrl->w_local = Wt; a.ctrl->scale = 1.0;
+            scan_tail(a);
+        }
     }
 }
 
@@ -254,6 +360,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
 // uneven that the target lies outside the window.
 // ---------------------------------------------------------------------------------------------
 constexpr int kWin = 256;
+
+#ifdef CPPROB_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;   // diagnostic build only: [nb][16] s_memrealtime stamps
+#define CPH_STAMP(k) do { if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CPH_STAMP(k) do {} while (0)
+#endif
 
 struct AncestorLds {
     union { double cdf[kTile]; int32_t slot[kTile]; } u;   // stratified: tile CDF; systematic: scatter slots
@@ -309,6 +422,7 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
         store4(L.u.slot, (int64_t)tid * kPPT, neg);
     }
     __syncthreads();
+    CPH_STAMP(2);
     // tile-level value: start index of tile c's outputs
     auto bcv = [&](int c) -> double { return (c >= w0 && c <= w0 + wn) ? L.bcw[c - w0] : in.bc[c] * in.scale; };
     auto gt = [&](int c) -> double { return c >= in.nb ? INFINITY : g_of(in.cdf_lo + bcv(c), inv, u0); };
@@ -331,6 +445,7 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     const int guess0 = in.guess >= 0 ? in.guess : (int)((gj_first / inv - in.cdf_lo) / fmax(bcv(in.nb), 1e-300) * in.nb);
     const int c_lo = locate(gj_first, 0, guess0);
     const int c_hi = locate(gj_last, c_lo, c_lo + 1);
+    CPH_STAMP(3);
     // linear weights of the 4 sources this lane owns in source tile c
     auto load_w = [&](int c, double (&w)[kPPT]) {
         const int64_t i0 = (int64_t)c * kTile + (int64_t)tid * kPPT;
@@ -340,6 +455,8 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     double w_first[kPPT], w_second[kPPT];
     load_w(c_lo, w_first);
     if (c_lo + 1 <= c_hi) load_w(c_lo + 1, w_second);
+    if (w_first[0] == -1.0) CPH_STAMP(15);
+    CPH_STAMP(4);
     int it = 0;
     for (int c = c_lo; c <= c_hi; ++c) {
         const double b0 = bcv(c), b1 = bcv(c + 1);
@@ -368,7 +485,9 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
             g_prev = g;
         }
     }
+    CPH_STAMP(5);
     __syncthreads();
+    CPH_STAMP(6);
     // inclusive prefix-max over the 1024 slots
     int32_t v[kPPT];
     load4(L.u.slot, (int64_t)tid * kPPT, v);
@@ -383,6 +502,7 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
         if (wv < wave_id()) excl = max(excl, L.iscr[wv]);
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) anc[k] = max(max(v[k], excl), 0);
+    CPH_STAMP(7);
 }
 
 // ---- stratified: forward search --------------------------------------------------------------
@@ -612,9 +732,6 @@ struct StepArgs {
     double n_pop, ess_frac;   // FUSED: ESS test
     double* ess_trace; int32_t* resampled;
     int store_logw;           // 0: every step resamples (known on the host), so only the last step's log-weights are ever read
-#ifdef CPPROB_STAMPS
-    unsigned long long* stamps;   // diagnostic build only: [nb][8] s_memrealtime stamps
-#endif
 };
 
 // Tile partial when every particle's log-weight is lwa + (one of K table values): no exp, no fp64
@@ -670,12 +787,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     const int t = a.t;
     double* s_bc = s_dyn;
     double* s_bf = s_dyn + (a.nb + 1);
-#ifdef CPPROB_STAMPS
-#define STAMP(k) do { if (tid == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
-    STAMP(0);
+    CPH_STAMP(0);
 
     bool resample = false;
     double u0 = 0.0, inv_stepw = 0.0, lwa = 0.0;
@@ -741,7 +853,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         }
     }
 
-    STAMP(1);
+    CPH_STAMP(1);
     int32_t anc[kPPT]; double lw[kPPT];
     if (!resample) {
 #pragma unroll
@@ -766,14 +878,13 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         for (int k = 0; k < kPPT; ++k) lw[k] = lwa;          // equal weights after resampling (the shard's mass share)
     }
 
-    STAMP(2);
+    CPH_STAMP(8);
     V prev[kPPT], x[kPPT];
     const V* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.ld;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? prev_row[anc[k]] : V(0);                 // ancestor's state (sorted gather)
     Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0, t, prev, x);                       // sample #t
-    if (x[0] == V(-12345)) STAMP(7);
-    STAMP(3);
+    CPH_STAMP(9);
     bool valid[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
@@ -804,14 +915,14 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         }
         tile_partial(lw, e, a.part, s_scr);
     }
-    STAMP(4);
+    CPH_STAMP(10);
     if (a.store_logw || t + 1 == a.T) store4_stream(a.logw_next, j0, lw);
     store4_stream(a.wrel_next, j0, e);
     if (FUSED && blockIdx.x == 0 && tid == 0 && t + 1 < a.T) {              // systematic offset of the resampling before step t+1
         const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(t + 1));
         a.ctrl->u0_pp[(t + 1) & 1] = u01_53(r.x, r.y);
     }
-    STAMP(5);
+    CPH_STAMP(11);
 }
 
 // ---------------------------------------------------------------------------------------------
