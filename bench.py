@@ -109,7 +109,7 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, last
@@ -228,6 +228,8 @@ def main():
         stats = eng.stats()
     err = float(np.abs(stats - spec["exact"]).max())
     summ = eng.summary()
+    if last is not None and len(last) == 3:
+        summ["log_evidence"] = last[1]          # evidence of the joint population (shards combined), not of this rank's shard
     collective = "none" if world == 1 else ("all_gather(1+T*K doubles/rank) once per run" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
 
     # profiled pass: same K steps with HIP events around every launch on the engine's stream

@@ -46,8 +46,18 @@ def init_process_group(device_is_gpu=True):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl" if device_is_gpu else "gloo", rank=rank, world_size=world)
+        # CPPROB_DIST_BACKEND=gloo + CPPROB_FORCE_DEVICE=k: test hook that lets several ranks share one GPU (RCCL refuses
+        # duplicate devices); small collectives then travel through host memory
+        backend = os.environ.get("CPPROB_DIST_BACKEND", "nccl" if device_is_gpu else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if "CPPROB_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["CPPROB_FORCE_DEVICE"])
     return world, rank, local
+
+
+def _host_collectives():
+    import torch.distributed as dist
+    return dist.is_initialized() and dist.get_backend() == "gloo"
 
 
 def shard_bounds(n_global, world, rank):
@@ -96,7 +106,7 @@ def allgather_vector(vec, device=None):
     if world == 1:
         return v[None, :]
     t = torch.from_numpy(v)
-    if device is not None:
+    if device is not None and not _host_collectives():
         t = t.to(device)
     out = torch.empty((world, v.size), dtype=torch.float64, device=t.device)
     dist.all_gather_into_tensor(out.view(-1), t) if t.device.type == "cuda" else dist.all_gather(list(out.unbind(0)), t)
@@ -136,13 +146,24 @@ class TorchCollective:
                 out.copy_(local[: out.numel()])
             return
         with self.torch.cuda.stream(self.stream):
-            self.dist.all_gather_into_tensor(out, local[: out.numel() // self.world].contiguous())
+            if _host_collectives():      # test hook (gloo): through host memory
+                mine = local[: out.numel() // self.world].cpu()
+                parts = [self.torch.empty_like(mine) for _ in range(self.world)]
+                self.dist.all_gather(parts, mine)
+                out.copy_(self.torch.cat(parts).to(out.device))
+            else:
+                self.dist.all_gather_into_tensor(out, local[: out.numel() // self.world].contiguous())
 
     def all_reduce_sum(self, t):
         if self.world == 1:
             return
         with self.torch.cuda.stream(self.stream):
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            if _host_collectives():
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+                t.copy_(h.to(t.device))
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
 
 
 def normalise_joint_stats(raw, log_norm, max_logw, is_int):
