@@ -20,6 +20,7 @@ CPPROB_REGISTER_MODEL(models::hmm<128>);
 #if !defined(CPPROB_USE_REFERENCE_MODELS)
 CPPROB_REGISTER_MODEL(models::gaussian_readme<double>);
 CPPROB_REGISTER_MODEL(models::poisson_rate<double>);
+CPPROB_REGISTER_MODEL(models::gaussian_by_rejection<double>);
 CPPROB_REGISTER_BUILTIN(models::gaussian_readme<double>, CPPROB_HIP_MODEL_GAUSSIAN_README);
 #endif
 // fast path: the hand-fused kernels of libcpprob_hip for the same functions

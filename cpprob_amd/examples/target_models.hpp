@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstddef>
 
+#include <boost/math/distributions/normal.hpp>
 #include <boost/random/discrete_distribution.hpp>
 #include <boost/random/normal_distribution.hpp>
 #include <boost/random/poisson_distribution.hpp>
@@ -76,6 +77,29 @@ void hmm(const std::array<double, N>& ys)
         lik = boost::random::normal_distribution<>{mean[s], 1};
         cpprob::observe(lik, ys[t]);
     }
+}
+
+// The Gaussian model with its prior simulated by rejection sampling from the density alone (restates reference
+// include/models/models.hpp:82-112): the number of sample statements differs from particle to particle.
+template <class Real = double>
+void gaussian_by_rejection(const Real y1, const Real y2)
+{
+    const Real mu0 = 1, s0 = std::sqrt(5), s = std::sqrt(2);
+    const boost::math::normal_distribution<Real> prior_density(mu0, s0);
+    const Real top = boost::math::pdf(prior_density, mu0);
+    boost::random::uniform_real_distribution<Real> proposal{mu0 - 20 * s0, mu0 + 20 * s0};
+    boost::random::uniform_real_distribution<Real> accept{0, top};
+    Real mu;
+    {
+        cpprob::rejection_sampling guard{};
+        do {
+            mu = cpprob::sample(proposal, true);
+        } while (cpprob::sample(accept, true) > boost::math::pdf(prior_density, mu));
+    }
+    boost::random::normal_distribution<Real> lik{mu, s};
+    cpprob::observe(lik, y1);
+    cpprob::observe(lik, y2);
+    cpprob::predict(mu, "Mu");
 }
 
 // Not in the reference: a model over the remaining scalar distributions of the scope table:

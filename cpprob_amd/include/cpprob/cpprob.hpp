@@ -92,7 +92,7 @@ CPPROB_HD void predict(T&& x)
 template <class T> CPPROB_HD void metaobserve(T&&) {}
 
 struct rejection_sampling {
-    rejection_sampling() = default;
+    CPPROB_HD rejection_sampling() {}
     rejection_sampling& operator=(const rejection_sampling&) = delete;
     rejection_sampling& operator=(rejection_sampling&&) = delete;
 };

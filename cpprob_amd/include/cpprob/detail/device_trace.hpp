@@ -39,6 +39,8 @@ struct LaneCtx {
     int64_t ld;
     uint32_t n_sample, n_observe, n_pred_real, n_pred_int;
     uint32_t n_stored;            // samples available in trace_in
+    uint32_t trace_cap;           // rows of the trace buffers; a longer trace raises *overflow (rejection loops)
+    int32_t* overflow;
     uint32_t n_recorded;          // samples executed before the lane was done
     int32_t first_observe;        // observes with a smaller index were weighted in earlier steps
     int32_t stop_after;           // index of the observe that ends this step (-1: run to completion)
@@ -102,7 +104,10 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
     R value;
     if (j < c.n_stored) value = from_raw<R>(c.trace_in[(int64_t)j * c.ld]);
     else value = draw(distr, c.seed, c.pid, (uint64_t)j);
-    if (c.trace_out) c.trace_out[(int64_t)j * c.ld] = to_raw<R>(value);
+    if (c.trace_out) {
+        if (j < c.trace_cap) c.trace_out[(int64_t)j * c.ld] = to_raw<R>(value);
+        else if (c.overflow) *c.overflow = 1;
+    }
     c.n_recorded = j + 1;
     return value;
 }

@@ -21,8 +21,9 @@
 //         final launch regenerates every predict of every surviving particle.
 // Cost: O(T^2) statement executions for T observes -- the price of not editing the model; the built-in
 // kernels (CPPROB_REGISTER_BUILTIN) are the O(T) fast path for the models they cover.
-// Restriction: the number and order of sample / observe / predict statements must not depend on sampled
-// values (true of the scope-table models; rejection-sampling loops are not supported yet).
+// Restriction: the number and order of observe / predict statements must not depend on sampled values.  The
+// number of sample statements may (rejection-sampling loops): SIS runs them as they come; SMC keeps 4x the
+// dry run's count of trace rows per particle and reports an error if a particle needs more.
 #ifndef CPPROB_COMPAT_GPU_HPP
 #define CPPROB_COMPAT_GPU_HPP
 #if !defined(__HIPCC__) && !defined(__HIP__)
@@ -52,6 +53,7 @@ struct ModelKernelArgs {
     const int32_t* nstored_in; int32_t* nstored_out;
     double* pred_real; int32_t* pred_int;
     int32_t first_observe, stop_after;
+    uint32_t trace_cap; int32_t* overflow;
 };
 
 template <class FP, FP F, class Tuple>
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
     c.n_sample = c.n_observe = c.n_pred_real = c.n_pred_int = 0;
     c.n_stored = a.nstored_in ? (uint32_t)a.nstored_in[src] : 0u;
     c.n_recorded = 0;
+    c.trace_cap = a.trace_cap; c.overflow = a.overflow;
     c.first_observe = a.first_observe; c.stop_after = a.stop_after; c.done = 0;
     call_f_tuple(F, *observes);                                   // the model body, cpprob.hpp:199
     const double carried = (a.anc == nullptr && a.logw_in) ? a.logw_in[i] : 0.0;   // equal weights after resampling
@@ -102,7 +105,9 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     hip_check(hipSetDevice(opt.device), "hipSetDevice");
     hipStream_t stream = static_cast<hipStream_t>(cpprob_hip_stream(ctx.get()));
     const int64_t ld = (int64_t)n;
-    const size_t n_real = st.real_ids.size(), n_int = st.int_ids.size(), S = st.n_sample;
+    // trace rows: the structural dry run saw st.n_sample sample statements; models with data-dependent loops
+    // (rejection sampling) may execute more on some particles, so leave head-room and detect overflow
+    const size_t n_real = st.real_ids.size(), n_int = st.int_ids.size(), S = 4 * st.n_sample + 16;
     const int T = (int)st.n_observe;
     const bool smc = algorithm == StateType::smc;
 
@@ -111,13 +116,15 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     DevBuf<double> d_real(n_real * n), d_logw0(n), d_logw1(smc ? n : 0);
     DevBuf<int32_t> d_int(n_int * n), d_anc(smc ? n : 0), d_ns0(smc ? n : 0), d_ns1(smc ? n : 0);
     DevBuf<uint64_t> d_tr0(smc ? S * n : 0), d_tr1(smc ? S * n : 0);
+    DevBuf<int32_t> d_overflow(1);
+    hip_check(hipMemset(d_overflow.p, 0, sizeof(int32_t)), "hipMemset");
     double* logw[2] = {d_logw0.p, d_logw1.p};
     int32_t* ns[2] = {d_ns0.p, d_ns1.p};
     uint64_t* tr[2] = {d_tr0.p, d_tr1.p};
     const dim3 grid((unsigned)((n + device::kLaneBlock - 1) / device::kLaneBlock)), block(device::kLaneBlock);
 
     ModelKernelArgs a{};
-    a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed;
+    a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed; a.trace_cap = (uint32_t)S; a.overflow = d_overflow.p;
     const auto t_start = std::chrono::steady_clock::now();
     double log_z = 0.0;
     int cur = 0, n_resampled = 0;
@@ -177,6 +184,10 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
         if (n_int) hip_check(hipMemcpyAsync(store->ints.data(), d_int.p, n_int * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy int predicts");
     }
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    int32_t overflow = 0;
+    hip_check(hipMemcpy(&overflow, d_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost), "read overflow flag");
+    if (overflow) throw std::runtime_error("cpprob::inference(smc): a particle executed more sample statements than the trace buffer holds "
+                                           "(data-dependent loop, e.g. rejection sampling); use StateType::sis for this model");
 }
 
 template <class FP, FP F>
