@@ -113,6 +113,7 @@ int main(int argc, char** argv)
         if (a.model == "hmm16") return execute(models::hmm<16>, a);
         if (a.model == "hmm128") return execute(models::hmm<128>, a);
         if (a.model == "poisson_rate") return execute(models::poisson_rate<double>, a);
+        if (a.model == "gauss_functor") return execute(models::GaussFunctor<double>{}, a);
         if (a.model == "gaussian_by_rejection") return execute(models::gaussian_by_rejection<double>, a);
         std::cerr << "unknown model " << a.model << std::endl;
         return EXIT_FAILURE;

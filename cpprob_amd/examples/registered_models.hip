@@ -17,9 +17,14 @@ CPPROB_REGISTER_MODEL(models::linear_gaussian_1d<25>);
 CPPROB_REGISTER_MODEL(models::linear_gaussian_1d<100>);
 CPPROB_REGISTER_MODEL(models::hmm<16>);
 CPPROB_REGISTER_MODEL(models::hmm<128>);
+#if defined(CPPROB_USE_REFERENCE_MODELS)
+CPPROB_REGISTER_MODEL(models::normal_rejection_sampling<double>);   // reference models.hpp:82-112, untouched
+CPPROB_REGISTER_FUNCTOR(models::Gauss<double>);                      // functor model, reference models.hpp:51-65
+#endif
 #if !defined(CPPROB_USE_REFERENCE_MODELS)
 CPPROB_REGISTER_MODEL(models::gaussian_readme<double>);
 CPPROB_REGISTER_MODEL(models::poisson_rate<double>);
+CPPROB_REGISTER_FUNCTOR(models::GaussFunctor<double>);
 CPPROB_REGISTER_MODEL(models::gaussian_by_rejection<double>);
 CPPROB_REGISTER_BUILTIN(models::gaussian_readme<double>, CPPROB_HIP_MODEL_GAUSSIAN_README);
 #endif

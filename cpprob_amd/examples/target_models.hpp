@@ -32,6 +32,20 @@ void gaussian_unknown_mean(const Real y1, const Real y2)
     cpprob::predict(mu, "Mu");
 }
 
+// the same model as a functor (restates reference include/models/models.hpp:51-65): found by TYPE, not by address
+template <class Real = double>
+struct GaussFunctor {
+    void operator()(const Real y1, const Real y2) const
+    {
+        boost::random::normal_distribution<Real> prior{1, std::sqrt(5)};
+        const Real mu = cpprob::sample(prior, true);
+        boost::random::normal_distribution<Real> lik{mu, static_cast<Real>(std::sqrt(2))};
+        cpprob::observe(lik, y1);
+        cpprob::observe(lik, y2);
+        cpprob::predict(mu, "Mu");
+    }
+};
+
 // README variant: prior N(1, 1.5), likelihood sd 2, predict "Mean"
 template <class Real = double>
 void gaussian_readme(const Real x1, const Real x2)

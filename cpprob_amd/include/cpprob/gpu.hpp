@@ -56,7 +56,20 @@ struct ModelKernelArgs {
     uint32_t trace_cap; int32_t* overflow;
 };
 
-template <class FP, FP F, class Tuple>
+// How the kernel reaches the model body: a function (by address, as a template argument) or a functor
+// (by type, default-constructed on the lane -- e.g. the reference's models::Gauss<>, models.hpp:51-65).
+template <class FP, FP F>
+struct FunctionCaller {
+    using observes_t = tuple_observes_t<FP>;
+    CPPROB_HD static void call(const observes_t& obs) { call_f_tuple(F, obs); }
+};
+template <class Functor>
+struct FunctorCaller {
+    using observes_t = tuple_observes_t<Functor>;
+    CPPROB_HD static void call(const observes_t& obs) { call_f_tuple(Functor{}, obs); }
+};
+
+template <class Caller, class Tuple>
 __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelArgs a, const Tuple* __restrict__ observes)
 {
     const int64_t i = (int64_t)blockIdx.x * device::kLaneBlock + threadIdx.x;
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
     c.n_recorded = 0;
     c.trace_cap = a.trace_cap; c.overflow = a.overflow;
     c.first_observe = a.first_observe; c.stop_after = a.stop_after; c.done = 0;
-    call_f_tuple(F, *observes);                                   // the model body, cpprob.hpp:199
+    Caller::call(*observes);                                      // the model body, cpprob.hpp:199
     const double carried = (a.anc == nullptr && a.logw_in) ? a.logw_in[i] : 0.0;   // equal weights after resampling
     a.logw_out[i] = carried + c.log_w;                            // finish_trace(): the particle's log_w_
     if (a.nstored_out) a.nstored_out[i] = (int32_t)c.n_recorded;
@@ -95,11 +108,11 @@ inline void hip_check(hipError_t e, const char* what)
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
-template <class FP, FP F>
+template <class Caller>
 void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
                       Result& res, HostStore* store)
 {
-    using Tuple = tuple_observes_t<FP>;
+    using Tuple = typename Caller::observes_t;
     static_assert(std::is_trivially_copyable<Tuple>::value || true, "observes are copied to the device bytewise");
     Context ctx(opt.device);
     hip_check(hipSetDevice(opt.device), "hipSetDevice");
@@ -131,7 +144,7 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     res.step_ess.clear();
     if (!smc) {
         a.logw_out = logw[0]; a.pred_real = d_real.p; a.pred_int = d_int.p; a.first_observe = 0; a.stop_after = -1;
-        hipLaunchKernelGGL((model_kernel<FP, F, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
+        hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
         hip_check(hipGetLastError(), "model_kernel");
     } else {
         bool resampled = false;
@@ -144,7 +157,7 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
             a.nstored_in = t > 0 ? ns[cur] : nullptr; a.nstored_out = ns[cur ^ 1];
             a.pred_real = last ? d_real.p : nullptr; a.pred_int = last ? d_int.p : nullptr;
             a.first_observe = t; a.stop_after = last ? -1 : t;
-            hipLaunchKernelGGL((model_kernel<FP, F, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
+            hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
             hip_check(hipGetLastError(), "model_kernel");
             cur ^= 1;
             double o3[3];
@@ -193,19 +206,24 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
 template <class FP, FP F>
 bool register_model(const char* name)
 {
-    Entry e; e.name = name; e.generic = &generic_launcher<FP, F>;
+    Entry e; e.name = name; e.generic = &generic_launcher<FunctionCaller<FP, F>>;
     return add_entry(Key{reinterpret_cast<const void*>(F), 0}, e);
 }
 
 // functor models (e.g. models::Gauss<>): keyed by type, called through a default-constructed instance
-template <class Functor> struct functor_thunk;
 template <class Functor>
-bool register_functor(const char* name);
+bool register_functor(const char* name)
+{
+    Entry e; e.name = name; e.generic = &generic_launcher<FunctorCaller<Functor>>;
+    return add_entry(Key{nullptr, typeid(Functor).hash_code()}, e);
+}
 
 }  // namespace gpu
 }  // namespace cpprob
 
 #define CPPROB_REGISTER_MODEL(fn) \
     static const bool CPPROB_PP_CAT(cpprob_reg_model_, __LINE__) = ::cpprob::gpu::register_model<decltype(&fn), &fn>(#fn)
+#define CPPROB_REGISTER_FUNCTOR(type) \
+    static const bool CPPROB_PP_CAT(cpprob_reg_functor_, __LINE__) = ::cpprob::gpu::register_functor<type>(#type)
 
 #endif

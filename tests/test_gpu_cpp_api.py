@@ -175,3 +175,14 @@ def test_rejection_sampling_model_through_generic_sis(tmp_path):
     r2, out, err = run_main(tmp_path, "--model", "gaussian_by_rejection", "--smc", "--observes", "3 4", "--n_samples", 50000, "--seed", 4, "--json",
                             "--no_dump", expect_rc=None)
     assert (r2 is not None and abs(r2["predicts"][0]["mean"] - 3.0833333) < 0.05) or "trace buffer" in err
+
+
+def test_functor_model_is_found_by_type(tmp_path):
+    """models::Gauss<>-style functor (reference models.hpp:51-65): registered with CPPROB_REGISTER_FUNCTOR."""
+    n = 100000
+    res, _, _ = run_main(tmp_path, "--model", "gauss_functor", "--sis", "--observes", "3 4", "--n_samples", n, "--seed", 7, "--json")
+    vals, lw = read_dump(str(tmp_path / "post_sis.real"), False)
+    ov, olw = O.sis(O.MODEL_GAUSSIAN_UNKNOWN_MEAN, [3.0, 4.0], n, 7)
+    np.testing.assert_allclose(vals, ov, rtol=1e-12, atol=1e-12)       # same statements -> same stream as the function form
+    np.testing.assert_allclose(lw, olw, rtol=1e-12, atol=1e-12)
+    assert not res["builtin"]
