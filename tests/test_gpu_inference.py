@@ -387,3 +387,23 @@ def test_large_population_two_level_normalisation(engine, golden_dir):
     st2, s2 = engine.stats(), engine.summary()
     assert 0 < s2["n_resampled"] < 15
     assert np.abs(st2 - z["hmm16_smooth"]).max() < 1.5e-2 and abs(s2["log_evidence"] - float(z["hmm16_logz"])) < 1e-2   # fewer resampling steps: larger evidence variance
+
+
+@pytest.mark.parametrize("n", [300_000, 1_000_000, 1_500_000, 2_500_000, 4_400_000])
+def test_back_to_back_runs_are_bitwise_reproducible(engine, golden_dir, n):
+    """Every code path of the step kernel (prologue variants for <= 512 / 1024 / 2048 tiles, ctrl-reading form above,
+    two-level normalisation above 4096 tiles): the same run index must give bit-identical results however the
+    launches interleave -- any race in the inter-step hand-offs (partials ping-pong, u0 hand-off, ctrl) would show here."""
+    obs = _obs(golden_dir, "hmm16")
+    for ess in (2.0, 0.5):
+        engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=99, ess_threshold=ess)
+        ref = {}
+        for rep in range(3):
+            for idx in (0, 1, 2, 3):
+                engine.run(idx)
+                if rep == 0:
+                    ref[idx] = (engine.stats().copy(), engine.summary()["log_evidence"])
+                elif rep == 2:
+                    st, lz = engine.stats(), engine.summary()["log_evidence"]
+                    assert np.array_equal(st, ref[idx][0]) and lz == ref[idx][1]
+        assert not np.array_equal(ref[0][0], ref[1][0])
