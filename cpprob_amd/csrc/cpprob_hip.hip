@@ -157,7 +157,7 @@ int ensure_bb(cpprob_hip_ctx* ctx, size_t n)
     if (nb > ctx->bb_cap_nb || !ctx->d_bb_ctrl) {
         dfree(ctx->d_bb_part); dfree(ctx->d_bb_bc); dfree(ctx->d_bb_bf); dfree(ctx->d_bb_wrel); dfree(ctx->d_bb_col); dfree(ctx->d_bb_stats_part);
         const size_t cap = std::max<size_t>(nb, 1024);
-        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_part, cap * 3 * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_bb_part, (size_t)part_stride((int)cap) * 3 * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_bb_bc, (cap + 1) * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_bb_bf, cap * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_bb_wrel, cap * kTile * sizeof(double)));
@@ -435,8 +435,8 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_values, T * ld * vsz));
         HIP_TRY(c, hipMemsetAsync(c->d_values, 0, T * ld * vsz, c->stream));
         HIP_TRY(c, hipMalloc(&c->d_anc, T * ld * sizeof(int32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)c->nb * 3 * sizeof(double)));
-        HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)c->nb * 3 * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_bc, ((size_t)c->nb + 1) * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_gpart, (size_t)3 * kMaxSlabs * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_ess, T * sizeof(double)));

@@ -34,9 +34,13 @@ namespace cph {
 // Tile partials {max, sum e, sum e^2} are kept as three arrays of nb doubles (structure of arrays:
 // the consumers read them coalesced): part[0..nb) = max, part[nb..2nb) = sum, part[2nb..3nb) = sum of squares.
 using Partial = double;
+// (stride = number of tiles rounded up to kPartPad so that consumers may read whole vectors past the last tile)
+constexpr int kPartPad = 2048;
+__host__ __device__ inline int part_stride(int nb) { return (nb + kPartPad - 1) / kPartPad * kPartPad; }
 __device__ __forceinline__ void put_partial(Partial* __restrict__ part, int nb, int b, double m, double s, double q)
 {
-    part[b] = m; part[nb + b] = s; part[2 * nb + b] = q;
+    const int st = part_stride(nb);
+    part[b] = m; part[st + b] = s; part[2 * st + b] = q;
 }
 
 struct StepCtrl {
@@ -188,7 +192,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
     // NOTE: every thread of the workgroup takes every barrier below (uniform trip counts)
 
     if (a.phase != 2) {
-        const double* pm = a.part; const double* psum = a.part + a.nb; const double* pq = a.part + 2 * a.nb;
+        const int pst = part_stride(a.nb);
+        const double* pm = a.part; const double* psum = a.part + pst; const double* pq = a.part + 2 * pst;
         double m = -INFINITY;
         for (int c = tid; c < a.nb; c += kScanThreads) m = fmax(m, pm[c]);          // coalesced
         const double M = block_max<NW>(m, s_scr);
@@ -270,7 +275,8 @@ __global__ __launch_bounds__(kThreads) void scan_slab_partials_kernel(const doub
 {
     __shared__ double s_scr[3 * kWaves];
     const int G = (int)gridDim.x, g = (int)blockIdx.x;
-    const double* pm = part; const double* psum = part + nb; const double* pq = part + 2 * nb;
+    const int pst = part_stride(nb);
+    const double* pm = part; const double* psum = part + pst; const double* pq = part + 2 * pst;
     const int c0 = g * kSlabTiles + (int)threadIdx.x * 4;
     double m[4], sv[4], qv[4];
 #pragma unroll
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(kThreads) void scan_slab_finish_kernel(ScanArgs a, 
     block_sum2(Wt, Qt, s_scr + kWaves);
     before = block_sum(before, s_scr + 3 * kWaves);
     // my slab against the global max
-    const double* pm = a.part; const double* psum = a.part + a.nb;
+    const double* pm = a.part; const double* psum = a.part + part_stride(a.nb);
     const int c0 = g * kSlabTiles + tid * 4;
     double e[4], v[4];
 #pragma unroll
@@ -503,6 +509,95 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) anc[k] = max(max(v[k], excl), 0);
     CPH_STAMP(7);
+}
+
+// Fast form for the fused step kernel: the tile-level CDF is in LDS (bc, bf), the slots were reset before the
+// caller's last barrier, and the linear weights of the lane's own-index source tile (w_own: tile blockIdx.x, the one an
+// output tile overlaps almost surely) were fetched at kernel entry.  The start indices of tiles b-1 .. b+2 are
+// evaluated together; anything farther away (very uneven masses) falls back to a search of the LDS table.
+__device__ __forceinline__ void ancestors_systematic_fused(const double* __restrict__ wrel, const double* s_bc, const double* s_bf, int nb,
+                                                            double u0, double inv, int n_valid_tile, const double (&w_own)[kPPT],
+                                                            int32_t (&anc)[kPPT], AncestorLds& L)
+{
+    const int tid = threadIdx.x;
+    const int b = (int)blockIdx.x;
+    const double gj_first = (double)((int64_t)b * kTile), gj_last = gj_first + (double)(n_valid_tile - 1);
+    auto gt = [&](int c) -> double { return c >= nb ? INFINITY : (c < 0 ? -INFINITY : g_of(s_bc[c], inv, u0)); };
+    const double g_m1 = gt(b - 1), g_0 = gt(b), g_p1 = gt(b + 1), g_p2 = gt(b + 2), g_p3 = gt(b + 3);
+    int c_lo, c_hi;
+    if (g_0 <= gj_first && gj_first < g_p1) c_lo = b;
+    else if (g_m1 <= gj_first && gj_first < g_0) c_lo = b - 1;
+    else if (g_p1 <= gj_first && gj_first < g_p2) c_lo = b + 1;
+    else {                                                       // rare: search the table
+        int lo = 0, hi = nb;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (gt(mid) <= gj_first) lo = mid; else hi = mid; }
+        c_lo = lo;
+    }
+    {
+        const double e1 = c_lo == b ? g_p1 : (c_lo == b - 1 ? g_0 : (c_lo == b + 1 ? g_p2 : gt(c_lo + 1)));
+        const double e2 = c_lo == b ? g_p2 : (c_lo == b - 1 ? g_p1 : (c_lo == b + 1 ? g_p3 : gt(c_lo + 2)));
+        if (gj_last < e1) c_hi = c_lo;
+        else if (gj_last < e2) c_hi = c_lo + 1;
+        else {
+            int lo = c_lo, hi = nb;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (gt(mid) <= gj_last) lo = mid; else hi = mid; }
+            c_hi = lo;
+        }
+    }
+    auto load_w = [&](int c, double (&w)[kPPT]) { load4(wrel, (int64_t)c * kTile + (int64_t)tid * kPPT, w); };
+    int it = 0;
+    auto process = [&](int c, double (&w)[kPPT]) {
+        const double b0 = s_bc[c], b1 = s_bc[c + 1];
+        if (!(b1 > b0)) return;                                  // tile without mass: owns no output (workgroup-uniform)
+        w[1] += w[0]; w[2] += w[1]; w[3] += w[2];
+        double tot;
+        const double excl = block_excl_scan(w[3], L.scr[it & 1], &tot);
+        ++it;
+        const double bfc = s_bf[c];
+        const double g_lo = g_of(b0, inv, u0), g_hi = (c + 1 >= nb) ? INFINITY : g_of(b1, inv, u0);
+        double g_prev = fmin(fmax(g_of(b0 + bfc * excl, inv, u0), g_lo), g_hi);
+        if (tid == 0) g_prev = g_lo;
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            double g = fmin(fmax(g_of(b0 + bfc * (excl + w[k]), inv, u0), g_lo), g_hi);
+            if (tid == kThreads - 1 && k == kPPT - 1) g = g_hi;   // the tile ends where the next one starts
+            if (g > g_prev) {
+                const double s = g_prev - gj_first, e = g - gj_first;    // exact: integers
+                if (e > 0.0 && s < (double)kTile) L.u.slot[s > 0.0 ? (int)s : 0] = (int32_t)((int64_t)c * kTile + tid * kPPT + k);
+            }
+            g_prev = g;
+        }
+    };
+    // the other tile's weights travel while the own-index tile is processed (slot writes of different source tiles
+    // never collide and the prefix-max below does not care about their order)
+    const bool own_in = b >= c_lo && b <= c_hi;
+    const int c_other = (c_lo != b) ? c_lo : c_lo + 1;
+    double w_other[kPPT] = {0.0, 0.0, 0.0, 0.0};
+    const bool other_in = c_other <= c_hi && c_other != b;
+    if (other_in) load_w(c_other, w_other);
+    if (own_in) { double w[kPPT] = {w_own[0], w_own[1], w_own[2], w_own[3]}; process(b, w); }
+    if (other_in) process(c_other, w_other);
+    for (int c = c_lo; c <= c_hi; ++c) {
+        if (c == b || c == c_other) continue;
+        double w[kPPT];
+        load_w(c, w);
+        process(c, w);
+    }
+    __syncthreads();
+    // inclusive prefix-max over the 1024 slots
+    int32_t v[kPPT];
+    load4(L.u.slot, (int64_t)tid * kPPT, v);
+    v[1] = max(v[1], v[0]); v[2] = max(v[2], v[1]); v[3] = max(v[3], v[2]);
+    int32_t incl = wave_incl_max_i32(v[3]);
+    if (lane_id() == kWave - 1) L.iscr[wave_id()] = incl;
+    int32_t excl = dpp_or_i32<0x138 /* wave_shr:1 */>(incl, -1);
+    if (lane_id() == 0) excl = -1;
+    __syncthreads();
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv)
+        if (wv < wave_id()) excl = max(excl, L.iscr[wv]);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) anc[k] = max(max(v[k], excl), 0);
 }
 
 // ---- stratified: forward search --------------------------------------------------------------
@@ -789,46 +884,60 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     double* s_bf = s_dyn + (a.nb + 1);
     CPH_STAMP(0);
 
+    // independent of everything this step waits for: the random part of sample #t, and (fused form) the linear weights of
+    // the source tile with this workgroup's own index -- both issued before the first memory round trip completes
+    typename Model::Rand rnd;
+    Model::draw4(a.seed, a.pid0 + (uint64_t)j0, t, rnd);
+    double w_own[kPPT] = {0.0, 0.0, 0.0, 0.0};
+    if (FUSED && RS == RS_SYSTEMATIC && t > 0) {
+        load4(a.wrel_prev, j0, w_own);
+        const int32_t neg[kPPT] = {-1, -1, -1, -1};
+        store4(L.u.slot, (int64_t)tid * kPPT, neg);
+    }
+
     bool resample = false;
     double u0 = 0.0, inv_stepw = 0.0, lwa = 0.0;
     if (t > 0) {
         if (FUSED) {
             // ---- normalise generation t-1 from its tile partials (every workgroup, identically) ----
-            // one coalesced pass over the three partial arrays into registers (<= kFuseMaxTiles / 256 per lane)
+            // each lane owns FUSED consecutive tiles: one coalesced vector load per partial array, no LDS round trip
             constexpr int kPer = FUSED > 0 ? FUSED : 1;
-            const double* pm = a.part_prev; const double* psum = a.part_prev + a.nb; const double* pq = a.part_prev + 2 * a.nb;
+            const int pst = part_stride(a.nb);
+            const double* pm = a.part_prev; const double* psum = a.part_prev + pst; const double* pq = a.part_prev + 2 * pst;
+            const int c0 = tid * kPer;
             double rm[kPer], rs[kPer], rq[kPer];
+#pragma unroll
+            for (int i = 0; i < kPer; i += 2) {                      // 16-B loads (the arrays are padded past nb)
+                const double2 vm = *reinterpret_cast<const double2*>(pm + c0 + i);
+                const double2 vs = *reinterpret_cast<const double2*>(psum + c0 + i);
+                const double2 vq = *reinterpret_cast<const double2*>(pq + c0 + i);
+                rm[i] = vm.x; rm[i + 1] = vm.y; rs[i] = vs.x; rs[i + 1] = vs.y; rq[i] = vq.x; rq[i + 1] = vq.y;
+            }
             double m = -INFINITY;
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
-                const int c = tid + i * kThreads;
-                const bool in = c < a.nb;
-                rm[i] = in ? pm[c] : -INFINITY; rs[i] = in ? psum[c] : 0.0; rq[i] = in ? pq[c] : 0.0;
+                if (c0 + i >= a.nb) { rm[i] = -INFINITY; rs[i] = 0.0; rq[i] = 0.0; }
                 m = fmax(m, rm[i]);
             }
             const double M = block_max(m, s_scr);
-            double Q = 0.0;
+            double Q = 0.0, S = 0.0, ev[kPer];
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
-                const int c = tid + i * kThreads;
-                if (c < a.nb) {
-                    double e = 1.0;
-                    if (rm[i] != M) e = (rm[i] == -INFINITY) ? 0.0 : exp(rm[i] - M);   // table-weight models: every tile has the same reference
-                    s_bf[c] = e;
-                    s_bc[c] = rs[i] * e;                                                 // tile mass; prefix-summed below
-                    Q += rq[i] * (e * e);
-                }
+                double e = 1.0;
+                if (rm[i] != M) e = (rm[i] == -INFINITY) ? 0.0 : exp(rm[i] - M);   // table-weight models: every tile has the same reference
+                ev[i] = e;
+                rs[i] *= e;                                          // tile mass
+                S += rs[i];
+                Q += rq[i] * (e * e);
             }
-            Q = block_sum(Q, s_scr + kWaves);                                            // (barrier: the LDS tile masses are visible)
-            // exclusive prefix over the tiles in index order: each lane owns `per` consecutive tiles
-            const int per = (a.nb + kThreads - 1) / kThreads;
-            const int lo = tid * per, hi = min(a.nb, lo + per);
-            double S = 0.0;
-            for (int c = lo; c < hi; ++c) S += s_bc[c];
+            Q = block_sum(Q, s_scr + kWaves);
             double W;
-            const double excl = block_excl_scan(S, L.scr[0], &W);
-            double run = excl;
-            for (int c = lo; c < hi; ++c) { const double v = s_bc[c]; s_bc[c] = run; run += v; }
+            double run = block_excl_scan(S, L.scr[0], &W);
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                if (c0 + i < a.nb) { s_bc[c0 + i] = run; s_bf[c0 + i] = ev[i]; }
+                run += rs[i];
+            }
             if (tid == 0) s_bc[a.nb] = W;
             const double ess = W * W / Q;
             resample = ess < a.ess_frac * a.n_pop;                            // ESS test, thesis p.37 (t-1 is never the last step here)
@@ -872,7 +981,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
             in.id0 = a.pid0;
             in.n_valid_tile = rem < kTile ? (int)rem : kTile;
             in.guess = (int)blockIdx.x;
-            find_ancestors<RS>(in, anc, L);
+            if (FUSED && RS == RS_SYSTEMATIC) ancestors_systematic_fused(a.wrel_prev, s_bc, s_bf, a.nb, u0, inv_stepw, in.n_valid_tile, w_own, anc, L);
+            else find_ancestors<RS>(in, anc, L);
         }
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) lw[k] = lwa;          // equal weights after resampling (the shard's mass share)
@@ -883,7 +993,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     const V* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.ld;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? prev_row[anc[k]] : V(0);                 // ancestor's state (sorted gather)
-    Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0, t, prev, x);                       // sample #t
+    Model::apply4(a.mp, t, rnd, prev, x);                                                     // sample #t
     CPH_STAMP(9);
     bool valid[kPPT];
 #pragma unroll

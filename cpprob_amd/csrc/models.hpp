@@ -33,13 +33,19 @@ struct ModelGaussian {
     static constexpr int kWeightTable = 0;   // incremental weights are continuous
     __device__ static __forceinline__ void weight_table(const ModelParams&, int, double (&)[1], double (&)[1], double&) {}
     __device__ static __forceinline__ int weight_index(value_t) { return 0; }
-    __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int /*t*/,
-                                                      const value_t (&)[4], value_t (&x)[4])
+    // the random part of the step's sample statement depends on nothing but (seed, id, t): kernels draw it early,
+    // in the shadow of their first memory round trip, and apply it once the ancestor's state is known
+    struct Rand { double z[4]; };
+    __device__ static __forceinline__ void draw4(uint64_t seed, uint64_t pid0, int /*t*/, Rand& r) { draw_std_normals4(seed, pid0, 0, r.z); }
+    __device__ static __forceinline__ void apply4(const ModelParams& mp, int /*t*/, const Rand& r, const value_t (&)[4], value_t (&x)[4])
     {
-        double z[4];
-        draw_std_normals4(seed, pid0, 0, z);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = mp.mu0 + mp.sigma0 * z[k];    // mu = sample(prior, true)   models.hpp:26-27
+        for (int k = 0; k < 4; ++k) x[k] = mp.mu0 + mp.sigma0 * r.z[k];  // mu = sample(prior, true)   models.hpp:26-27
+    }
+    __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int t, const value_t (&prev)[4],
+                                                      value_t (&x)[4])
+    {
+        Rand r; draw4(seed, pid0, t, r); apply4(mp, t, r, prev, x);
     }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t mu, int /*t*/, const double* __restrict__ obs)
     {
@@ -64,16 +70,20 @@ struct ModelLinearGaussian1D {
     static constexpr int kWeightTable = 0;
     __device__ static __forceinline__ void weight_table(const ModelParams&, int, double (&)[1], double (&)[1], double&) {}
     __device__ static __forceinline__ int weight_index(value_t) { return 0; }
-    __device__ static __forceinline__ void propagate4(const ModelParams&, uint64_t seed, uint64_t pid0, int t, const value_t (&prev)[4],
-                                                      value_t (&x)[4])
+    struct Rand { double z[4]; };
+    __device__ static __forceinline__ void draw4(uint64_t seed, uint64_t pid0, int t, Rand& r) { draw_std_normals4(seed, pid0, (uint64_t)t, r.z); }
+    __device__ static __forceinline__ void apply4(const ModelParams&, int t, const Rand& r, const value_t (&prev)[4], value_t (&x)[4])
     {
-        double z[4];
-        draw_std_normals4(seed, pid0, (uint64_t)t, z);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const double state = t == 0 ? 0.0 : prev[k];                  // models.hpp:72
-            x[k] = state + 1.0 * z[k];                                    // :74-75  normal{state, 1}
+            x[k] = state + 1.0 * r.z[k];                                  // :74-75  normal{state, 1}
         }
+    }
+    __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int t, const value_t (&prev)[4],
+                                                      value_t (&x)[4])
+    {
+        Rand r; draw4(seed, pid0, t, r); apply4(mp, t, r, prev, x);
     }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t x, int t, const double* __restrict__ obs)
     {
@@ -103,11 +113,16 @@ struct ModelHmm3 {
         e[0] = q[0]; e[1] = q[1]; e[2] = q[2]; mref = q[3];
     }
     __device__ static __forceinline__ int weight_index(value_t s) { return (int)s; }
+    struct Rand { uint32_t w[4]; };
+    __device__ static __forceinline__ void draw4(uint64_t seed, uint64_t pid0, int t, Rand& r) { draw_words4(seed, pid0, (uint64_t)t, r.w); }
     __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int t, const value_t (&prev)[4],
                                                       value_t (&x)[4])
     {
-        uint32_t w[4];
-        draw_words4(seed, pid0, (uint64_t)t, w);
+        Rand r; draw4(seed, pid0, t, r); apply4(mp, t, r, prev, x);
+    }
+    __device__ static __forceinline__ void apply4(const ModelParams& mp, int t, const Rand& r, const value_t (&prev)[4], value_t (&x)[4])
+    {
+        const uint32_t (&w)[4] = r.w;
         if (t == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = (value_t)smallint_from_word(w[k], 0, 2);   // uniform_smallint{0,2}   :126-127
