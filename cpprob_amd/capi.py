@@ -53,7 +53,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("CPPROB_HIP_LIB") or LIB_PATH      # CPPROB_HIP_LIB: alternative build of the library (A/B runs)
     if not os.path.exists(p):
         raise CpprobHipError("%s is missing: run `python -m cpprob_amd.build` (there is no CPU fallback)" % p)
     L = C.CDLL(p, mode=C.RTLD_GLOBAL)

@@ -395,7 +395,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     if (gauss && n_obs != 2) return fail(c, CPPROB_HIP_EINVAL, "gaussian_unknown_mean takes exactly two observes");
     if (cfg->n_particles == 0) return fail(c, CPPROB_HIP_EINVAL, "n_particles must be > 0");
     if (cfg->n_particles > (uint64_t)INT32_MAX - kTile) return fail(c, CPPROB_HIP_EINVAL, "n_particles per context must fit int32 ancestor indices");
-    if (cfg->n_particles > (uint64_t)kMaxSlabs * kSlabTiles * kTile) return fail(c, CPPROB_HIP_EINVAL, "n_particles per context exceeds 2^30");
+    if (cfg->n_particles > (uint64_t)kMaxSlabs * kSlabTiles * kTile) return fail(c, CPPROB_HIP_EINVAL, "n_particles per context exceeds the two-level normalisation's capacity");
     if (cfg->n_global < cfg->n_particles || cfg->particle_offset + cfg->n_particles > cfg->n_global)
         return fail(c, CPPROB_HIP_EINVAL, "shard [particle_offset, particle_offset + n_particles) must lie inside [0, n_global)");
     if (cfg->algorithm == CPPROB_HIP_ALG_SMC) {

@@ -75,16 +75,22 @@ template <> struct Vec4<int32_t> { using type = int __attribute__((ext_vector_ty
 template <class T>
 __device__ __forceinline__ void load4(const T* __restrict__ p, int64_t i, T (&v)[kPPT])
 {
-    const typename Vec4<T>::type x = *reinterpret_cast<const typename Vec4<T>::type*>(p + i);
-    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+#pragma unroll
+    for (int q = 0; q < kPPT; q += 4) {
+        const typename Vec4<T>::type x = *reinterpret_cast<const typename Vec4<T>::type*>(p + i + q);
+        v[q] = x[0]; v[q + 1] = x[1]; v[q + 2] = x[2]; v[q + 3] = x[3];
+    }
 }
 
 template <class T>
 __device__ __forceinline__ void store4(T* __restrict__ p, int64_t i, const T (&v)[kPPT])
 {
-    typename Vec4<T>::type x;
-    x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
-    *reinterpret_cast<typename Vec4<T>::type*>(p + i) = x;
+#pragma unroll
+    for (int q = 0; q < kPPT; q += 4) {
+        typename Vec4<T>::type x;
+        x[0] = v[q]; x[1] = v[q + 1]; x[2] = v[q + 2]; x[3] = v[q + 3];
+        *reinterpret_cast<typename Vec4<T>::type*>(p + i + q) = x;
+    }
 }
 
 // Streaming store: the particle store is written once per step and next read by a different kernel
@@ -92,13 +98,7 @@ __device__ __forceinline__ void store4(T* __restrict__ p, int64_t i, const T (&v
 template <class T>
 __device__ __forceinline__ void store4_stream(T* __restrict__ p, int64_t i, const T (&v)[kPPT])
 {
-#ifdef CPPROB_NT_STORES
-    typename Vec4<T>::type x;
-    x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
-    __builtin_nontemporal_store(x, reinterpret_cast<typename Vec4<T>::type*>(p + i));
-#else
     store4(p, i, v);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -108,7 +108,9 @@ __device__ __forceinline__ void store4_stream(T* __restrict__ p, int64_t i, cons
 __device__ __forceinline__ void tile_partial(const double (&lw)[kPPT], double (&e)[kPPT], Partial* __restrict__ part,
                                              double* s_scr /* >= 3*kWaves doubles, unused by any in-flight combine */)
 {
-    double m = fmax(fmax(lw[0], lw[1]), fmax(lw[2], lw[3]));
+    double m = lw[0];
+#pragma unroll
+    for (int k = 1; k < kPPT; ++k) m = fmax(m, lw[k]);
     m = block_max(m, s_scr);
     double s = 0.0, q = 0.0;
 #pragma unroll
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
 //                               max; workgroup 0 does the bookkeeping.
 // Consumers see exactly the arrays scan_partials_kernel would have produced.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSlabTiles = kTile;          // 1024 tiles per workgroup: 4 consecutive tiles per lane
+constexpr int kSlabTiles = kThreads * 4;    // 1024 tiles per workgroup: 4 consecutive tiles per lane
 constexpr int kSlabThreshold = 4096;
 constexpr int kMaxSlabs = 1024;
 
@@ -367,6 +369,28 @@ __global__ __launch_bounds__(kThreads) void scan_slab_finish_kernel(ScanArgs a, 
 // ---------------------------------------------------------------------------------------------
 constexpr int kWin = 256;
 
+// in-lane inclusive prefix over the lane's kPPT values
+template <class T> __device__ __forceinline__ void lane_prefix_sum(T (&w)[kPPT])
+{
+#pragma unroll
+    for (int k = 1; k < kPPT; ++k) w[k] += w[k - 1];
+}
+__device__ __forceinline__ void lane_prefix_max(int32_t (&v)[kPPT])
+{
+#pragma unroll
+    for (int k = 1; k < kPPT; ++k) v[k] = max(v[k], v[k - 1]);
+}
+template <class T> __device__ __forceinline__ void lane_fill(T (&v)[kPPT], T x)
+{
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) v[k] = x;
+}
+template <class T> __device__ __forceinline__ void lane_copy(T (&d)[kPPT], const T (&s)[kPPT])
+{
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) d[k] = s[k];
+}
+
 #ifdef CPPROB_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;   // diagnostic build only: [nb][16] s_memrealtime stamps
 #define CPH_STAMP(k) do { if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -424,7 +448,8 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     const int w0 = stage_window(in, L, gj_first / inv - in.cdf_lo);
     const int wn = in.nb - w0 < kWin ? in.nb - w0 : kWin;
     {
-        const int32_t neg[kPPT] = {-1, -1, -1, -1};
+        int32_t neg[kPPT];
+        lane_fill(neg, (int32_t)-1);
         store4(L.u.slot, (int64_t)tid * kPPT, neg);
     }
     __syncthreads();
@@ -459,6 +484,7 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     };
     // the two tiles an output tile normally overlaps are fetched together (one memory round trip)
     double w_first[kPPT], w_second[kPPT];
+    lane_fill(w_second, 0.0);
     load_w(c_lo, w_first);
     if (c_lo + 1 <= c_hi) load_w(c_lo + 1, w_second);
     if (w_first[0] == -1.0) CPH_STAMP(15);
@@ -468,12 +494,12 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
         const double b0 = bcv(c), b1 = bcv(c + 1);
         if (!(b1 > b0)) continue;                              // tile without mass: owns no output
         double w[kPPT];
-        if (c == c_lo) { w[0] = w_first[0]; w[1] = w_first[1]; w[2] = w_first[2]; w[3] = w_first[3]; }
-        else if (c == c_lo + 1) { w[0] = w_second[0]; w[1] = w_second[1]; w[2] = w_second[2]; w[3] = w_second[3]; }
+        if (c == c_lo) lane_copy(w, w_first);
+        else if (c == c_lo + 1) lane_copy(w, w_second);
         else load_w(c, w);
-        w[1] += w[0]; w[2] += w[1]; w[3] += w[2];
+        lane_prefix_sum(w);
         double tot;
-        const double excl = block_excl_scan(w[3], L.scr[it & 1], &tot);
+        const double excl = block_excl_scan(w[kPPT - 1], L.scr[it & 1], &tot);
         ++it;
         const double bfc = in.bf[c] * in.scale;
         const double off = in.cdf_lo + b0;
@@ -497,8 +523,8 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     // inclusive prefix-max over the 1024 slots
     int32_t v[kPPT];
     load4(L.u.slot, (int64_t)tid * kPPT, v);
-    v[1] = max(v[1], v[0]); v[2] = max(v[2], v[1]); v[3] = max(v[3], v[2]);
-    int32_t incl = wave_incl_max_i32(v[3]);
+    lane_prefix_max(v);
+    int32_t incl = wave_incl_max_i32(v[kPPT - 1]);
     if (lane_id() == kWave - 1) L.iscr[wave_id()] = incl;
     int32_t excl = dpp_or_i32<0x138 /* wave_shr:1 */>(incl, -1);
     if (lane_id() == 0) excl = -1;
@@ -549,9 +575,9 @@ __device__ __forceinline__ void ancestors_systematic_fused(const double* __restr
     auto process = [&](int c, double (&w)[kPPT]) {
         const double b0 = s_bc[c], b1 = s_bc[c + 1];
         if (!(b1 > b0)) return;                                  // tile without mass: owns no output (workgroup-uniform)
-        w[1] += w[0]; w[2] += w[1]; w[3] += w[2];
+        lane_prefix_sum(w);
         double tot;
-        const double excl = block_excl_scan(w[3], L.scr[it & 1], &tot);
+        const double excl = block_excl_scan(w[kPPT - 1], L.scr[it & 1], &tot);
         ++it;
         const double bfc = s_bf[c];
         const double g_lo = g_of(b0, inv, u0), g_hi = (c + 1 >= nb) ? INFINITY : g_of(b1, inv, u0);
@@ -572,10 +598,11 @@ __device__ __forceinline__ void ancestors_systematic_fused(const double* __restr
     // never collide and the prefix-max below does not care about their order)
     const bool own_in = b >= c_lo && b <= c_hi;
     const int c_other = (c_lo != b) ? c_lo : c_lo + 1;
-    double w_other[kPPT] = {0.0, 0.0, 0.0, 0.0};
+    double w_other[kPPT];
+    lane_fill(w_other, 0.0);
     const bool other_in = c_other <= c_hi && c_other != b;
     if (other_in) load_w(c_other, w_other);
-    if (own_in) { double w[kPPT] = {w_own[0], w_own[1], w_own[2], w_own[3]}; process(b, w); }
+    if (own_in) { double w[kPPT]; lane_copy(w, w_own); process(b, w); }
     if (other_in) process(c_other, w_other);
     for (int c = c_lo; c <= c_hi; ++c) {
         if (c == b || c == c_other) continue;
@@ -587,8 +614,8 @@ __device__ __forceinline__ void ancestors_systematic_fused(const double* __restr
     // inclusive prefix-max over the 1024 slots
     int32_t v[kPPT];
     load4(L.u.slot, (int64_t)tid * kPPT, v);
-    v[1] = max(v[1], v[0]); v[2] = max(v[2], v[1]); v[3] = max(v[3], v[2]);
-    int32_t incl = wave_incl_max_i32(v[3]);
+    lane_prefix_max(v);
+    int32_t incl = wave_incl_max_i32(v[kPPT - 1]);
     if (lane_id() == kWave - 1) L.iscr[wave_id()] = incl;
     int32_t excl = dpp_or_i32<0x138 /* wave_shr:1 */>(incl, -1);
     if (lane_id() == 0) excl = -1;
@@ -612,8 +639,9 @@ __device__ __forceinline__ void ancestors_stratified(const AncestorIn& in, int32
     const uint64_t gj0 = in.gj_tile0 + (uint64_t)tid * kPPT;
     double p[kPPT];
     {
-        uint32_t wd[4];
-        draw_words4(in.seed, in.id0 + gj0, kResampleDrawBase + in.step, wd);
+        uint32_t wd[kPPT];
+#pragma unroll
+        for (int q = 0; q < kPPT; q += 4) draw_words4(in.seed, in.id0 + gj0 + q, kResampleDrawBase + in.step, reinterpret_cast<uint32_t(&)[4]>(wd[q]));
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) { p[k] = ((double)(gj0 + k) + u01_32(wd[k])) * stepw - in.cdf_lo; anc[k] = 0; }
     }
@@ -622,7 +650,12 @@ __device__ __forceinline__ void ancestors_stratified(const AncestorIn& in, int32
     if (tid == 0) { L.pos[0] = p[0]; L.cnt = 0; }
     {
         const int last = in.n_valid_tile - 1;
-        if ((last >> 2) == tid) L.pos[1] = (last & 3) == 0 ? p[0] : ((last & 3) == 1 ? p[1] : ((last & 3) == 2 ? p[2] : p[3]));
+        if (last / kPPT == tid) {
+            double pl = p[0];
+#pragma unroll
+            for (int k = 1; k < kPPT; ++k) pl = (last % kPPT) == k ? p[k] : pl;
+            L.pos[1] = pl;
+        }
     }
     __syncthreads();
     const double p_first = fmax(L.pos[0], 0.0), p_last = L.pos[1];
@@ -644,9 +677,9 @@ __device__ __forceinline__ void ancestors_stratified(const AncestorIn& in, int32
     for (;;) {
         double w[kPPT];
         load4(in.wrel, (int64_t)c * kTile + (int64_t)tid * kPPT, w);
-        w[1] += w[0]; w[2] += w[1]; w[3] += w[2];
+        lane_prefix_sum(w);
         double tot;
-        const double excl = block_excl_scan(w[3], L.scr[it & 1], &tot);
+        const double excl = block_excl_scan(w[kPPT - 1], L.scr[it & 1], &tot);
         ++it;
         const double bfc = in.bf[c] * in.scale;
         const double off = bcv(c);
@@ -737,9 +770,9 @@ __global__ __launch_bounds__(kThreads) void cdf_kernel(const double* __restrict_
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
     double w[kPPT];
     load4(wrel, j0, w);
-    w[1] += w[0]; w[2] += w[1]; w[3] += w[2];
+    lane_prefix_sum(w);
     double tot;
-    const double excl = block_excl_scan(w[3], s_scr, &tot);
+    const double excl = block_excl_scan(w[kPPT - 1], s_scr, &tot);
     const double off = bc[blockIdx.x] * ctrl->scale, bfc = bf[blockIdx.x] * ctrl->scale;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) w[k] = off + bfc * (excl + w[k]);
@@ -785,7 +818,9 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
     for (int k = 0; k < kPPT; ++k) { lw[k] = 0.0; x[k] = V(0); }                              // start_trace(): log_w_ = 0
     for (int t = 0; t < a.T; ++t) {
         V nx[kPPT];
-        Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0, t, x, nx);                     // sample: distr(get_rng())  cpprob.hpp:72-74
+#pragma unroll
+        for (int q = 0; q < kPPT / 4; ++q)                                                    // sample: distr(get_rng())  cpprob.hpp:72-74
+            Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, reinterpret_cast<const V(&)[4]>(x[4 * q]), reinterpret_cast<V(&)[4]>(nx[4 * q]));
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) { x[k] = nx[k]; lw[k] += Model::loglik(a.mp, x[k], t, a.obs); }   // observe: log_w_ += logpdf  state.cpp:212-223
         store4(a.values + (int64_t)t * a.ld, j0, x);                                          // predict: add_predict       state.hpp:312-327
@@ -886,12 +921,15 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
 
     // independent of everything this step waits for: the random part of sample #t, and (fused form) the linear weights of
     // the source tile with this workgroup's own index -- both issued before the first memory round trip completes
-    typename Model::Rand rnd;
-    Model::draw4(a.seed, a.pid0 + (uint64_t)j0, t, rnd);
-    double w_own[kPPT] = {0.0, 0.0, 0.0, 0.0};
+    typename Model::Rand rnd[kPPT / 4];
+#pragma unroll
+    for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+    double w_own[kPPT];
+    lane_fill(w_own, 0.0);
     if (FUSED && RS == RS_SYSTEMATIC && t > 0) {
         load4(a.wrel_prev, j0, w_own);
-        const int32_t neg[kPPT] = {-1, -1, -1, -1};
+        int32_t neg[kPPT];
+        lane_fill(neg, (int32_t)-1);
         store4(L.u.slot, (int64_t)tid * kPPT, neg);
     }
 
@@ -993,7 +1031,9 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     const V* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.ld;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? prev_row[anc[k]] : V(0);                 // ancestor's state (sorted gather)
-    Model::apply4(a.mp, t, rnd, prev, x);                                                     // sample #t
+#pragma unroll
+    for (int q = 0; q < kPPT / 4; ++q)                                                        // sample #t
+        Model::apply4(a.mp, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
     CPH_STAMP(9);
     bool valid[kPPT];
 #pragma unroll
