@@ -237,8 +237,8 @@ void launch_step(cpprob_hip_ctx* c, int t)
         // unconditionally; the step kernel ignores the result when ctrl says "no resampling".
         ProfScope ps(c, 5);
         hipLaunchKernelGGL(cdf_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, c->d_wrel[c->cur], c->d_bc, c->d_bf, c->d_ctrl, c->d_cdf);
-        hipLaunchKernelGGL(multinomial_kernel, dim3((unsigned)((c->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, c->d_cdf, c->n,
-                           c->d_ctrl, c->run_seed, (uint64_t)t, c->cfg.particle_offset, c->n, c->d_anc_pre);
+        hipLaunchKernelGGL(multinomial_kernel, dim3((unsigned)((c->ld + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, c->d_cdf, c->n,
+                           c->d_ctrl, c->run_seed, (uint64_t)t, c->cfg.particle_offset, c->n, c->ld, c->d_anc_pre);
     }
     {
         ProfScope ps(c, 0);
@@ -847,7 +847,7 @@ int cpprob_hip_resample(cpprob_hip_ctx* c, int32_t kind, const double* d_logw, s
     if (kind == CPPROB_HIP_RESAMPLE_MULTINOMIAL) {
         if ((size_t)nb_in * kTile > c->bb_cdf_cap) { dfree(c->d_bb_cdf); HIP_TRY(c, hipMalloc(&c->d_bb_cdf, (size_t)nb_in * kTile * sizeof(double))); c->bb_cdf_cap = (size_t)nb_in * kTile; }
         hipLaunchKernelGGL(cdf_kernel, dim3(nb_in), dim3(kThreads), 0, c->stream, c->d_bb_wrel, c->d_bb_bc, c->d_bb_bf, c->d_bb_ctrl, c->d_bb_cdf);
-        hipLaunchKernelGGL(multinomial_kernel, GRID1(n_out), c->d_bb_cdf, (int64_t)n_in, c->d_bb_ctrl, seed, step, j0, (int64_t)n_out, d_anc);
+        hipLaunchKernelGGL(multinomial_kernel, GRID1(n_out), c->d_bb_cdf, (int64_t)n_in, c->d_bb_ctrl, seed, step, j0, (int64_t)n_out, (int64_t)n_out, d_anc);
     } else if (kind == CPPROB_HIP_RESAMPLE_SYSTEMATIC || kind == CPPROB_HIP_RESAMPLE_STRATIFIED) {
         ResampleArgs a{};
         a.wrel = c->d_bb_wrel; a.n_in = (int64_t)n_in; a.bc = c->d_bb_bc; a.bf = c->d_bb_bf; a.nb = nb_in; a.ctrl = c->d_bb_ctrl; a.seed = seed; a.step = step; a.j0 = j0;

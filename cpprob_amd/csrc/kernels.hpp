@@ -780,10 +780,14 @@ __global__ __launch_bounds__(kThreads) void cdf_kernel(const double* __restrict_
 }
 
 __global__ __launch_bounds__(kThreads) void multinomial_kernel(const double* __restrict__ cdf, int64_t n_in, const StepCtrl* __restrict__ ctrl,
-                                                                uint64_t seed, uint64_t step, uint64_t j0, int64_t n_out, int32_t* __restrict__ anc)
+                                                                uint64_t seed, uint64_t step, uint64_t j0, int64_t n_out, int64_t n_pad,
+                                                                int32_t* __restrict__ anc)
 {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n_out) return;
+    if (i >= n_out) {
+        if (i < n_pad) anc[i] = 0;          // padding slots of the particle store must hold a valid index
+        return;
+    }
     const double p = draw_u01_53(seed, j0 + (uint64_t)i, kResampleDrawBase + step) * cdf[n_in - 1];
     int64_t lo = 0, hi = n_in;
     while (lo < hi) {

@@ -147,7 +147,7 @@ def test_logpdf_other_functors(engine, golden_dir):
     np.testing.assert_allclose(out.cpu().numpy(), [L.orc_discrete_logpdf(int(v), w, 3) for v in xs.cpu().numpy()], rtol=FP_TOL)
 
 
-@pytest.mark.parametrize("n", [1, 3, 64, 1023, 1024, 1025, 4097, 300001])
+@pytest.mark.parametrize("n", [1, 3, 64, 1023, 1024, 1025, 4095, 4096, 4097, 8193, 300001])
 def test_logsumexp_ess_and_moments(engine, n):
     rng = np.random.default_rng(n)
     logw = rng.normal(size=n) * 3 - 700.0      # far from 0: needs the max shift
@@ -170,7 +170,8 @@ def test_logsumexp_with_minus_inf_entries(engine):
 
 
 @pytest.mark.parametrize("kind", [O.RESAMPLE_SYSTEMATIC, O.RESAMPLE_STRATIFIED, O.RESAMPLE_MULTINOMIAL])
-@pytest.mark.parametrize("n,alive", [(1, 1.0), (5, 0.6), (1024, 0.3), (1025, 0.3), (5000, 0.01), (262144 + 17, 0.5), (262144 + 17, 1.0)])
+@pytest.mark.parametrize("n,alive", [(1, 1.0), (5, 0.6), (1024, 0.3), (1025, 0.3), (4096, 0.3), (4097, 0.7), (5000, 0.01), (8192 + 3, 0.2),
+                                     (262144 + 17, 0.5), (262144 + 17, 1.0)])
 def test_resample_exact_weights_bit_exact(engine, kind, n, alive):
     """log-weights in {0, -inf}: exp(lw - max) is exactly 1 or 0 on both sides and every partial
     sum is an exact integer in any summation order, so ancestors must match the sequential
