@@ -13,17 +13,15 @@ namespace cph {
 constexpr int kWave = 64;
 constexpr int kThreads = 256;              // workgroup size of every particle kernel
 constexpr int kWaves = kThreads / kWave;   // 4: one wave per SIMD
-// Particles per lane.  The kernels are VALU-issue-bound with a large per-lane fixed part (Philox, scans, the
-// normalisation prologue, address arithmetic), so more particles per lane means fewer instructions per particle:
-// measured on one MI355X, hmm<16> SMC, us per run at 10^6 / 10^7 particles: 4 -> 277 / 1596, 8 -> 213 / 917,
-// 16 -> 207 / 668 (profiles/r01_ppt_sweep.md).  Below ~3*10^5 particles 4 is ~10 % faster (more workgroups);
-// -DCPPROB_PPT=4|8 builds those variants.
+// Particles per lane.  4 is the measured optimum on MI355X at every population size (profiles/r01_ppt_sweep.md:
+// 8 and 16 amortise the per-lane fixed cost but lose more to register pressure and to having fewer workgroups).
+// -DCPPROB_PPT=8|16 builds those variants; all GPU parity tests pass for each.
 #ifndef CPPROB_PPT
-#define CPPROB_PPT 16
+#define CPPROB_PPT 4
 #endif
 constexpr int kPPT = CPPROB_PPT;           // consecutive particles per lane, moved as 32-B fp64 / 16-B int32 vectors
 static_assert(kPPT == 4 || kPPT == 8 || kPPT == 16, "particles per lane");
-constexpr int kTile = kThreads * kPPT;     // particles per workgroup (4096)
+constexpr int kTile = kThreads * kPPT;     // particles per workgroup (1024)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
