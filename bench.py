@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
     p.add_argument("--workload", default="hmm16_smc", choices=["hmm16_smc", "hmm128_smc_ess", "lgssm100_smc", "gaussian_sis"])
-    p.add_argument("--scope", default="auto", choices=["auto", "global", "global-deferred", "island"])
+    p.add_argument("--scope", default="auto", choices=["auto", "global", "global-deferred", "island", "exchange"])
     p.add_argument("--seed", type=int, default=12345)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample")
@@ -73,18 +73,21 @@ def workload_spec(name, golden):
                 exact=np.array([[3.0833333333333335, 0.8333333333333334]]), desc="gaussian_unknown_mean (models.hpp:22-35) SIS, observes (3,4)")
 
 
-def timed_runs(eng, steps, warmup, world, device, island, first_index=0):
+def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchange=False, counters=None):
     """W untimed + exactly K timed runs bracketed by barrier + synchronize; returns max-over-ranks seconds."""
     import torch
     import torch.distributed as dist
     from cpprob_amd import distributed as D
 
-    coll = D.TorchCollective(eng) if (world > 1 and not island) else None
+    coll = D.TorchCollective(eng) if ((world > 1 and not island) or exchange) else None
     bufs = None
     if coll is not None:
         bufs = (torch.zeros(4, dtype=torch.float64, device=device), torch.zeros(3 * world, dtype=torch.float64, device=device), None)
 
     def one(i):
+        if exchange:
+            st, _ = D.run_exchange(eng, coll, i, counters)   # per step: all-gather of 3 doubles + one all-to-all-v of migrating lineages
+            return (st,)
         if world > 1 and island:
             return D.run_islands(eng, i, device)          # no data-path collective; one all-gather of summaries per run
         if world > 1:
@@ -214,10 +217,12 @@ def main():
         # every step and use the per-step RCCL all-gather.
         scope = "global" if (world == 1 or spec["ess"] <= 1.0 or spec["alg"] == cp.ALG_SIS) else "global-deferred"
     island = scope in ("island", "global-deferred")
+    exchange = scope == "exchange" and spec["alg"] == cp.ALG_SMC
     eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
-              particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND if island else cp.SCOPE_GLOBAL)
+              particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND if island else (cp.SCOPE_EXCHANGE if exchange else cp.SCOPE_GLOBAL))
 
-    dt, last = timed_runs(eng, args.steps, args.warmup, world, device, island)
+    moved = {}
+    dt, last = timed_runs(eng, args.steps, args.warmup, world, device, island, exchange=exchange, counters=moved)
     n_global = world * n
     value = n_global * args.steps / dt
 
@@ -230,11 +235,14 @@ def main():
     summ = eng.summary()
     if last is not None and len(last) == 3:
         summ["log_evidence"] = last[1]          # evidence of the joint population (shards combined), not of this rank's shard
-    collective = "none" if world == 1 else ("all_gather(1+T*K doubles/rank) once per run" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
+    if exchange:
+        collective = "all_gather(3 doubles/rank) + all_to_all_v(migrating lineages) per step; %d records sent by rank 0 in the last run" % moved.get("records_sent", 0)
+    else:
+        collective = "none" if world == 1 else ("all_gather(1+T*K doubles/rank) once per run" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
 
     # profiled pass: same K steps with HIP events around every launch on the engine's stream
     # (per-shard kernels only: on several GPUs each rank profiles its own shard as an island)
-    if world > 1 and not island:
+    if (world > 1 and not island) or exchange:
         eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
                   particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND)
     eng.profile_enable(True)

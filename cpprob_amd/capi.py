@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcpprob_hip.so")
 ALG_SIS, ALG_SMC = 2, 4
 MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README, MODEL_LINEAR_GAUSSIAN_1D, MODEL_HMM3 = 0, 1, 2, 3
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
-SCOPE_GLOBAL, SCOPE_ISLAND = 0, 1
+SCOPE_GLOBAL, SCOPE_ISLAND, SCOPE_EXCHANGE = 0, 1, 2
 N_KERNEL_CLASSES = 6
 KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", "resample"]
 
@@ -20,7 +20,7 @@ SYMBOLS = [
     "cpprob_hip_stream", "cpprob_hip_sync", "cpprob_hip_infer_begin", "cpprob_hip_infer_run", "cpprob_hip_infer_summary",
     "cpprob_hip_infer_stats", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
-    "cpprob_hip_smc_finish", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
+    "cpprob_hip_smc_finish", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
     "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
     "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_resample", "cpprob_hip_gather_f64",
@@ -78,6 +78,9 @@ def load_library(path=None):
         "cpprob_hip_smc_step_begin": (C.c_int, [vp, i32, u64, vp]),
         "cpprob_hip_smc_step_end": (C.c_int, [vp, i32, vp, i32, i32]),
         "cpprob_hip_smc_finish": (C.c_int, [vp]),
+        "cpprob_hip_exchange_plan": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]),
+        "cpprob_hip_exchange_pack": (C.c_int, [vp, i32, vp]),
+        "cpprob_hip_exchange_commit": (C.c_int, [vp, i32, vp]),
         "cpprob_hip_philox_blocks": (C.c_int, [vp, u64, u64, u64, sz, vp]),
         "cpprob_hip_draw_normal": (C.c_int, [vp, u64, u64, u64, dbl, dbl, sz, vp]),
         "cpprob_hip_draw_uniform_smallint": (C.c_int, [vp, u64, u64, u64, i64, i64, sz, vp]),
@@ -223,6 +226,22 @@ class Engine:
 
     def finish(self):
         self._chk(self.L.cpprob_hip_smc_finish(self.h))
+
+    # ---- exchange scope: exact global resampling with migration ----------------------------
+    def exchange_plan(self, t, world, rank, shard_begin):
+        """-> (do_resample, send_counts[world], recv_counts[world]) in lineage records of t + 1 values.  Host-synchronising."""
+        sb = np.ascontiguousarray(shard_begin, dtype=np.uint64)
+        send = np.zeros(world, np.uint64)
+        recv = np.zeros(world, np.uint64)
+        flag = C.c_int32(0)
+        self._chk(self.L.cpprob_hip_exchange_plan(self.h, int(t), int(world), int(rank), sb.ctypes.data, send.ctypes.data, recv.ctypes.data, C.byref(flag)))
+        return bool(flag.value), send, recv
+
+    def exchange_pack(self, t, send):
+        self._chk(self.L.cpprob_hip_exchange_pack(self.h, int(t), _dptr(send) if send is not None else None))
+
+    def exchange_commit(self, t, recv):
+        self._chk(self.L.cpprob_hip_exchange_commit(self.h, int(t), _dptr(recv) if recv is not None else None))
 
     # ---- building blocks (torch tensors on this device carry the memory) -------------------
     def philox_blocks(self, seed, pid0, draw, out):

@@ -35,6 +35,7 @@ struct cpprob_hip_ctx {
     bool is_int = false;
     int K = 0;              // stats per predict
     int64_t n = 0, ld = 0;
+    int64_t rs = 0;         // row stride of values[] / anc[]: ld + annex_cap
     int nb = 0;             // tiles
     int smooth_grid = 0;
     ModelParams mp{};
@@ -67,6 +68,13 @@ struct cpprob_hip_ctx {
     bool sharded = false;           // the last run went through the step protocol: stats stay un-normalised
     bool step_protocol = false;     // a step-protocol run is in progress (the step kernel must not normalise on its own)
     int cur = 0;                    // logw buffer holding the latest generation
+    // exchange scope: exact global resampling, offspring of remote sources migrate in as annex columns
+    bool exchange = false;
+    int64_t annex_cap = 0, annex_used = 0;
+    double* d_obound = nullptr;     // [world + 2]: offspring-interval bounds per rank, then the resampling decision
+    int32_t* d_send_src = nullptr; size_t send_src_cap = 0;
+    int64_t imm_l0 = 0, imm_l1 = 0, imm_col0 = 0;     // immigrant layout of the NEXT step
+    struct { int t = -1; bool resample = false; std::vector<uint64_t> send_lo, send_cnt; uint64_t n_send = 0, n_recv = 0; int64_t l0 = 0, l1 = 0; } plan;
     size_t cap_particles = 0; int cap_T = 0; bool cap_int = false; bool cap_multinomial = false;
 
     // scratch for building blocks
@@ -188,7 +196,7 @@ template <class Model>
 void launch_sis(cpprob_hip_ctx* c)
 {
     SisArgs<Model> a{};
-    a.mp = c->mp; a.obs = c->d_obs; a.T = c->T; a.n = c->n; a.ld = c->ld; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
+    a.mp = c->mp; a.obs = c->d_obs; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
     a.values = static_cast<typename Model::value_t*>(c->d_values); a.logw = c->d_logw[0]; a.wrel = c->d_wrel[0]; a.part = c->d_part[0];
     c->cur_part = 0;
     ProfScope ps(c, 4);
@@ -228,6 +236,8 @@ void launch_step(cpprob_hip_ctx* c, int t)
     a.bc = c->d_bc; a.bf = c->d_bf; a.nb = c->nb; a.ctrl = c->d_ctrl; a.anc_pre = c->d_anc_pre;
     a.n_pop = (double)c->pop_n; a.ess_frac = c->cfg.ess_threshold; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
     a.store_logw = c->cfg.ess_threshold > 1.0 ? 0 : 1;      // ESS <= N always: threshold > 1 resamples after every step
+    a.rs = c->rs;
+    a.exchange = (c->exchange && c->step_protocol) ? 1 : 0; a.imm_l0 = c->imm_l0; a.imm_l1 = c->imm_l1; a.imm_col0 = c->imm_col0;
 #ifdef CPPROB_STAMPS
     static unsigned long long* d_st = nullptr;
     if (!d_st) { (void)hipMalloc(&d_st, (size_t)131072 * 16 * 8); (void)hipMemset(d_st, 0, (size_t)131072 * 16 * 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)); }
@@ -273,6 +283,7 @@ void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, 
     sa.n_pop = (double)c->pop_n; sa.n_local = (double)c->n; sa.ess_frac = c->cfg.ess_threshold; sa.seed = c->run_seed;
     sa.ess_trace = c->d_ess; sa.resampled = c->d_resampled;
     sa.force_no_resample = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
+    sa.exchange = (c->exchange && phase == 2) ? 1 : 0; sa.obound = c->d_obound;
     sa.all_totals = all_totals; sa.world = world; sa.rank = rank; sa.local_totals = c->totals_out ? c->totals_out : c->d_local_totals; sa.phase = phase;
     ProfScope ps(c, 1);
     if (phase != 2 && c->nb > kSlabThreshold) {
@@ -290,7 +301,7 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
 {
     SmoothArgs<Model> a{};
     a.values = static_cast<const typename Model::value_t*>(c->d_values); a.anc = c->d_anc; a.wrel = c->d_wrel[c->cur]; a.bf = c->d_bf; a.ctrl = c->d_ctrl;
-    a.resampled = c->d_resampled; a.T = c->T; a.n = c->n; a.ld = c->ld;
+    a.resampled = c->d_resampled; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs;
     a.identity = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
     a.stats_part = c->d_stats_part;
     a.paths = with_paths ? static_cast<typename Model::value_t*>(c->d_paths) : nullptr;
@@ -320,8 +331,8 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre);
-    c->cap_particles = 0; c->cap_T = 0;
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound);
+    c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
 }
 
 }  // namespace
@@ -405,8 +416,11 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
 
-    if (cfg->resample_scope != CPPROB_HIP_SCOPE_GLOBAL && cfg->resample_scope != CPPROB_HIP_SCOPE_ISLAND)
+    if (cfg->resample_scope != CPPROB_HIP_SCOPE_GLOBAL && cfg->resample_scope != CPPROB_HIP_SCOPE_ISLAND && cfg->resample_scope != CPPROB_HIP_SCOPE_EXCHANGE)
         return fail(c, CPPROB_HIP_EINVAL, "unknown resample_scope");
+    const bool exchange = cfg->resample_scope == CPPROB_HIP_SCOPE_EXCHANGE && cfg->algorithm == CPPROB_HIP_ALG_SMC;
+    if (exchange && cfg->resampler != CPPROB_HIP_RESAMPLE_SYSTEMATIC)
+        return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope resamples systematically (one shared offset makes every rank's offspring range computable from the rank totals)");
     c->cfg = *cfg;
     const bool island = cfg->resample_scope == CPPROB_HIP_SCOPE_ISLAND;
     c->pop_n = island ? cfg->n_particles : cfg->n_global;
@@ -422,19 +436,25 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     const bool smc = cfg->algorithm == CPPROB_HIP_ALG_SMC;
     const bool multinomial = smc && cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL;
 
-    const bool realloc = (size_t)c->ld > c->cap_particles || c->T > c->cap_T || c->is_int != c->cap_int || (multinomial && !c->cap_multinomial) || !c->d_values;
+    c->exchange = exchange;
+    // exchange scope: room for immigrant lineages next to every row (grown on demand by cpprob_hip_exchange_commit)
+    const int64_t annex0 = exchange ? std::max<int64_t>(c->annex_cap, std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile)) : 0;
+    const bool realloc = (size_t)c->ld > c->cap_particles || c->T > c->cap_T || c->is_int != c->cap_int || (multinomial && !c->cap_multinomial) || !c->d_values ||
+                         annex0 != c->annex_cap;
     if (realloc) {
         free_run_buffers(c);
-        const size_t ld = (size_t)c->ld, T = (size_t)c->T;
+        c->annex_cap = annex0;
+        const size_t ld = (size_t)c->ld, T = (size_t)c->T, rs = ld + (size_t)annex0;
         const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
         HIP_TRY(c, hipMalloc(&c->d_logw[0], ld * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_logw[1], ld * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_wrel[0], ld * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_wrel[1], ld * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_bf, (size_t)c->nb * sizeof(double)));
-        HIP_TRY(c, hipMalloc(&c->d_values, T * ld * vsz));
-        HIP_TRY(c, hipMemsetAsync(c->d_values, 0, T * ld * vsz, c->stream));
-        HIP_TRY(c, hipMalloc(&c->d_anc, T * ld * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_values, T * rs * vsz));
+        HIP_TRY(c, hipMemsetAsync(c->d_values, 0, T * rs * vsz, c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_anc, T * rs * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_obound, (1024 + 2) * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_bc, ((size_t)c->nb + 1) * sizeof(double)));
@@ -449,6 +469,8 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         }
         c->cap_particles = ld; c->cap_T = c->T; c->cap_int = c->is_int; c->cap_multinomial = multinomial;
     }
+    c->rs = c->ld + c->annex_cap;
+    c->annex_used = 0; c->imm_l0 = 0; c->imm_l1 = c->n; c->imm_col0 = 0; c->plan.t = -1;
     dfree(c->d_obs);
     HIP_TRY(c, hipMalloc(&c->d_obs, n_obs * sizeof(double)));
     HIP_TRY(c, hipMemcpyAsync(c->d_obs, h_obs, n_obs * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -487,7 +509,7 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
     if (!c->begun) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_infer_begin has not been called");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->cfg.resample_scope == CPPROB_HIP_SCOPE_GLOBAL && c->cfg.n_global != c->cfg.n_particles)
+    if (c->cfg.resample_scope != CPPROB_HIP_SCOPE_ISLAND && c->cfg.n_global != c->cfg.n_particles)
         return fail(c, CPPROB_HIP_ESTATE, "this context holds one shard of a joint population: drive it with cpprob_hip_smc_step_begin/_end/_finish");
     c->run_seed = c->cfg.seed + run_index;
     c->cur = 0; c->cur_part = 0;
@@ -528,7 +550,9 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     HIP_TRY(c, hipSetDevice(c->device));
     const bool sis = c->cfg.algorithm == CPPROB_HIP_ALG_SIS;
     if (sis && t != c->T - 1) return fail(c, CPPROB_HIP_EINVAL, "SIS shards run in one launch: call step_begin(T-1) only");
-    if (t == 0 || sis) { c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; }
+    if (t == 0 || sis) { c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; c->annex_used = 0; c->imm_l0 = 0; c->imm_l1 = c->n; c->imm_col0 = 0; c->plan.t = -1; }
+    if (c->exchange && t > 0 && c->plan.t != t - 1)
+        return fail(c, CPPROB_HIP_ESTATE, "exchange scope: cpprob_hip_exchange_plan/_pack/_commit of the previous step must run before the next step_begin");
     c->step_protocol = true;
     if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
     else dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
@@ -556,6 +580,119 @@ int cpprob_hip_smc_finish(cpprob_hip_ctx* c)
     dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
+    return 0;
+}
+
+// ---- exchange scope -----------------------------------------------------------------------------
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, c->stream
+
+int cpprob_hip_exchange_plan(cpprob_hip_ctx* c, int32_t t, int32_t world, int32_t rank, const uint64_t* h_shard_begin, uint64_t* h_send_counts,
+                             uint64_t* h_recv_counts, int32_t* h_do_resample)
+{
+    if (!c || !h_shard_begin || !h_send_counts || !h_recv_counts) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->exchange) return fail(c, CPPROB_HIP_ESTATE, "the context was not begun with resample_scope = CPPROB_HIP_SCOPE_EXCHANGE");
+    if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank");
+    if (t < 0 || t >= c->T) return fail(c, CPPROB_HIP_EINVAL, "step out of range");
+    if (h_shard_begin[rank] != c->cfg.particle_offset || h_shard_begin[rank + 1] - h_shard_begin[rank] != (uint64_t)c->n || h_shard_begin[world] != c->cfg.n_global)
+        return fail(c, CPPROB_HIP_EINVAL, "h_shard_begin does not describe this context's shard");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<double> ob((size_t)world + 2);
+    HIP_TRY(c, hipMemcpyAsync(ob.data(), c->d_obound, ob.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    auto& p = c->plan;
+    p.t = t; p.resample = ob[(size_t)world + 1] != 0.0;
+    p.send_lo.assign((size_t)world, 0); p.send_cnt.assign((size_t)world, 0); p.n_send = 0; p.n_recv = 0;
+    for (int r = 0; r < world; ++r) { h_send_counts[r] = 0; h_recv_counts[r] = 0; }
+    p.l0 = 0; p.l1 = c->n;
+    if (h_do_resample) *h_do_resample = p.resample ? 1 : 0;
+    if (!p.resample) return 0;
+    auto clampu = [](uint64_t v, uint64_t lo, uint64_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    std::vector<uint64_t> o((size_t)world + 1);
+    for (int r = 0; r <= world; ++r) o[r] = (uint64_t)ob[r];
+    for (int r = 1; r <= world; ++r) if (o[r] < o[r - 1]) return fail(c, CPPROB_HIP_EDEVICE, "offspring bounds are not monotone");
+    const uint64_t my_lo = o[rank], my_hi = o[rank + 1];
+    for (int r = 0; r < world; ++r) {
+        const uint64_t sb = h_shard_begin[r], se = h_shard_begin[r + 1];
+        if (r != rank) {
+            const uint64_t lo = clampu(my_lo, sb, se), hi = clampu(my_hi, sb, se);        // my sources' outputs that live on rank r
+            p.send_lo[r] = lo; p.send_cnt[r] = hi - lo; p.n_send += hi - lo; h_send_counts[r] = hi - lo;
+            const uint64_t mb = h_shard_begin[rank], me = h_shard_begin[rank + 1];
+            const uint64_t rl = clampu(o[r], mb, me), rh = clampu(o[r + 1], mb, me);    // rank r's sources' outputs that live here
+            h_recv_counts[r] = rh - rl; p.n_recv += rh - rl;
+        } else {
+            p.l0 = (int64_t)(clampu(my_lo, sb, se) - sb); p.l1 = (int64_t)(clampu(my_hi, sb, se) - sb);
+        }
+    }
+    if ((int64_t)p.n_recv != c->n - (p.l1 - p.l0)) return fail(c, CPPROB_HIP_EDEVICE, "exchange plan does not cover the shard");
+    return 0;
+}
+
+int cpprob_hip_exchange_pack(cpprob_hip_ctx* c, int32_t t, void* d_send)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    auto& p = c->plan;
+    if (!c->exchange || p.t != t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_plan(t) has not run");
+    if (!p.resample || p.n_send == 0) return 0;
+    if (!d_send) return fail(c, CPPROB_HIP_EINVAL, "d_send is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (p.n_send > c->send_src_cap) { dfree(c->d_send_src); HIP_TRY(c, hipMalloc(&c->d_send_src, p.n_send * sizeof(int32_t))); c->send_src_cap = p.n_send; }
+    uint64_t off = 0;
+    for (size_t r = 0; r < p.send_cnt.size(); ++r) {
+        if (!p.send_cnt[r]) continue;
+        ResampleArgs a{};
+        a.wrel = c->d_wrel[c->cur]; a.n_in = c->n; a.bc = c->d_bc; a.bf = c->d_bf; a.nb = c->nb; a.ctrl = c->d_ctrl; a.seed = c->run_seed; a.step = (uint64_t)t + 1;
+        a.j0 = p.send_lo[r]; a.n_total_out = c->cfg.n_global; a.n_out = (int64_t)p.send_cnt[r]; a.anc = c->d_send_src + off; a.run_ctrl = 1;
+        hipLaunchKernelGGL(resample_kernel<RS_SYSTEMATIC>, dim3((unsigned)((p.send_cnt[r] + kTile - 1) / kTile)), dim3(kThreads), 0, c->stream, a);
+        off += p.send_cnt[r];
+    }
+    const int len = t + 1;
+    if (c->is_int) hipLaunchKernelGGL(extract_lineages_kernel<int32_t>, GRID1(p.n_send), static_cast<const int32_t*>(c->d_values), c->d_anc, c->rs, c->d_resampled, len,
+                                      c->d_send_src, (int64_t)p.n_send, static_cast<int32_t*>(d_send));
+    else hipLaunchKernelGGL(extract_lineages_kernel<double>, GRID1(p.n_send), static_cast<const double*>(c->d_values), c->d_anc, c->rs, c->d_resampled, len,
+                            c->d_send_src, (int64_t)p.n_send, static_cast<double*>(d_send));
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+// more annex columns: re-stride values[] / anc[] (rare: the initial annex holds ld/16 immigrants per run)
+static int grow_annex(cpprob_hip_ctx* c, int64_t need)
+{
+    int64_t cap = std::max<int64_t>(2 * c->annex_cap, (need + kTile - 1) / kTile * kTile);
+    const size_t T = (size_t)c->cap_T, vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
+    const size_t ldc = c->cap_particles, rs_new = (size_t)c->ld + (size_t)cap, rs_old = (size_t)c->rs;
+    void* nv = nullptr; int32_t* na = nullptr;
+    HIP_TRY(c, hipMalloc(&nv, T * (ldc + (size_t)cap) * vsz));
+    HIP_TRY(c, hipMalloc(&na, T * (ldc + (size_t)cap) * sizeof(int32_t)));
+    const size_t used = (size_t)(c->ld + c->annex_used);
+    HIP_TRY(c, hipMemcpy2DAsync(nv, rs_new * vsz, c->d_values, rs_old * vsz, used * vsz, (size_t)c->T, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(na, rs_new * 4, c->d_anc, rs_old * 4, used * 4, (size_t)c->T, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(c->d_values); dfree(c->d_anc);
+    c->d_values = nv; c->d_anc = na; c->annex_cap = cap; c->rs = c->ld + cap;
+    return 0;
+}
+
+int cpprob_hip_exchange_commit(cpprob_hip_ctx* c, int32_t t, const void* d_recv)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    auto& p = c->plan;
+    if (!c->exchange || p.t != t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_plan(t) has not run");
+    c->imm_l0 = 0; c->imm_l1 = c->n; c->imm_col0 = c->annex_used;
+    if (!p.resample) return 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->imm_l0 = p.l0; c->imm_l1 = p.l1;
+    if (p.n_recv == 0) return 0;
+    if (!d_recv) return fail(c, CPPROB_HIP_EINVAL, "d_recv is NULL");
+    if (c->ld + c->annex_used + (int64_t)p.n_recv + kTile > (int64_t)INT32_MAX) return fail(c, CPPROB_HIP_EINVAL, "immigrant columns exceed int32 ancestor indices");
+    if (c->annex_used + (int64_t)p.n_recv > c->annex_cap) { if (int rc = grow_annex(c, c->annex_used + (int64_t)p.n_recv)) return rc; }
+    const int len = t + 1;
+    const int64_t col0 = c->ld + c->annex_used;
+    if (c->is_int) hipLaunchKernelGGL(annex_lineages_kernel<int32_t>, GRID1(p.n_recv * len), static_cast<const int32_t*>(d_recv), (int64_t)p.n_recv, len,
+                                      static_cast<int32_t*>(c->d_values), c->d_anc, c->rs, col0);
+    else hipLaunchKernelGGL(annex_lineages_kernel<double>, GRID1(p.n_recv * len), static_cast<const double*>(d_recv), (int64_t)p.n_recv, len,
+                            static_cast<double*>(c->d_values), c->d_anc, c->rs, col0);
+    HIP_TRY(c, hipGetLastError());
+    c->annex_used += (int64_t)p.n_recv;
     return 0;
 }
 
@@ -605,11 +742,11 @@ int cpprob_hip_infer_step_trace(cpprob_hip_ctx* c, double* h_ess, int32_t* h_res
     return 0;
 }
 
-static int copy_rows(cpprob_hip_ctx* c, void* h, const void* d, size_t elem, size_t rows, size_t n_bytes)
+static int copy_rows(cpprob_hip_ctx* c, void* h, const void* d, size_t elem, size_t rows, size_t n_bytes, size_t stride)
 {
     const size_t need = rows * (size_t)c->n * elem;
     if (n_bytes < need) return fail(c, CPPROB_HIP_EINVAL, "host buffer too small");
-    HIP_TRY(c, hipMemcpy2DAsync(h, (size_t)c->n * elem, d, (size_t)c->ld * elem, (size_t)c->n * elem, rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(h, (size_t)c->n * elem, d, stride * elem, (size_t)c->n * elem, rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -618,7 +755,7 @@ int cpprob_hip_copy_values(cpprob_hip_ctx* c, void* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
-    return copy_rows(c, h, c->d_values, c->is_int ? sizeof(int32_t) : sizeof(double), (size_t)c->T, n_bytes);
+    return copy_rows(c, h, c->d_values, c->is_int ? sizeof(int32_t) : sizeof(double), (size_t)c->T, n_bytes, (size_t)c->rs);
 }
 
 int cpprob_hip_copy_ancestors(cpprob_hip_ctx* c, int32_t* h, size_t n_bytes)
@@ -626,14 +763,14 @@ int cpprob_hip_copy_ancestors(cpprob_hip_ctx* c, int32_t* h, size_t n_bytes)
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
     if (c->cfg.algorithm != CPPROB_HIP_ALG_SMC) return fail(c, CPPROB_HIP_ESTATE, "SIS keeps no ancestors (every trace is its own line)");
-    return copy_rows(c, h, c->d_anc, sizeof(int32_t), (size_t)c->T, n_bytes);
+    return copy_rows(c, h, c->d_anc, sizeof(int32_t), (size_t)c->T, n_bytes, (size_t)c->rs);
 }
 
 int cpprob_hip_copy_logw(cpprob_hip_ctx* c, double* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
-    return copy_rows(c, h, c->d_logw[c->cur], sizeof(double), 1, n_bytes);
+    return copy_rows(c, h, c->d_logw[c->cur], sizeof(double), 1, n_bytes, (size_t)c->ld);
 }
 
 int cpprob_hip_copy_paths(cpprob_hip_ctx* c, void* h, size_t n_bytes)
@@ -644,7 +781,7 @@ int cpprob_hip_copy_paths(cpprob_hip_ctx* c, void* h, size_t n_bytes)
     if (!c->d_paths) HIP_TRY(c, hipMalloc(&c->d_paths, (size_t)c->cap_T * c->cap_particles * vsz));
     dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, true); });
     HIP_TRY(c, hipGetLastError());
-    return copy_rows(c, h, c->d_paths, vsz, (size_t)c->T, n_bytes);
+    return copy_rows(c, h, c->d_paths, vsz, (size_t)c->T, n_bytes, (size_t)c->ld);
 }
 
 // ---- building blocks ----------------------------------------------------------------------
@@ -652,7 +789,6 @@ int cpprob_hip_copy_paths(cpprob_hip_ctx* c, void* h, size_t n_bytes)
 #define BB_PRELUDE(c)                                                         \
     if (!(c)) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");         \
     HIP_TRY(c, hipSetDevice((c)->device));
-#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, c->stream
 
 int cpprob_hip_philox_blocks(cpprob_hip_ctx* c, uint64_t seed, uint64_t pid0, uint64_t draw, size_t n, uint32_t* d_out)
 {
@@ -792,7 +928,7 @@ static int column_stats(cpprob_hip_ctx* c, const typename Col::value_t* d_x, con
     V* col = static_cast<V*>(c->d_bb_col);
     hipLaunchKernelGGL(pad_copy_kernel<V>, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, c->stream, d_x, (int64_t)n, ld, col);
     SmoothArgs<Col> a{};
-    a.values = col; a.anc = nullptr; a.wrel = c->d_bb_wrel; a.bf = c->d_bb_bf; a.ctrl = c->d_bb_ctrl; a.resampled = nullptr; a.T = 1; a.n = (int64_t)n; a.ld = ld;
+    a.values = col; a.anc = nullptr; a.wrel = c->d_bb_wrel; a.bf = c->d_bb_bf; a.ctrl = c->d_bb_ctrl; a.resampled = nullptr; a.T = 1; a.n = (int64_t)n; a.ld = ld; a.rs = ld;
     a.identity = 1; a.stats_part = c->d_bb_stats_part; a.paths = nullptr;
     const int grid = std::min(nb, 2048);
     hipLaunchKernelGGL(smooth_kernel<Col>, dim3(grid), dim3(kThreads), (size_t)kWaves * Col::kStats * sizeof(double), c->stream, a);

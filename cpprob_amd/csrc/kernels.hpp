@@ -58,6 +58,8 @@ struct StepCtrl {
     double inv_stepw; // n_local / (local weight sum, local units): CDF positions -> local output indices
     double lw_after;  // log-weight every particle of this shard carries right after resampling: log of the
                       // shard's mean weight over the population's mean weight (0 on a single shard)
+    double inv_global;// n_pop / W: global CDF positions -> global output indices (exchange scope)
+    double g_end;     // first output index owned by the NEXT shard's sources (+inf on the last shard and on a single shard)
     int32_t do_resample;  // decision taken after the last weighted step
     int32_t n_resampled;
     int32_t pad[2];
@@ -157,6 +159,8 @@ struct ScanArgs {
     const double* all_totals; int world, rank;   // phase 2: all-gathered per-rank {M, W, Q}
     double* local_totals;      // phase 1 out: {M_local, W_local, Q_local}
     int phase;                 // 0: single shard (everything); 1: local part; 2: combine ranks
+    int exchange;              // phase 2: resampling is global and exact (offspring of remote sources migrate in)
+    double* obound;            // phase 2, exchange: [world + 1] first output index owned by each rank's sources
 };
 
 // Bookkeeping of a weighted generation once (M, W, Q) sit in ctrl: ESS, resampling decision, evidence,
@@ -178,11 +182,37 @@ __device__ __forceinline__ void scan_tail(const ScanArgs& a)
     // (distributed resampling with non-proportional allocation; exact for one shard, where lw_after = 0).
     const double w_loc_units = a.bc[a.nb];                       // local sum in local-max units
     ctrl->inv_stepw = a.n_local / w_loc_units;
-    ctrl->lw_after = (a.phase == 2) ? log((ctrl->w_local / a.n_local) / (W / a.n_pop)) : 0.0;
+    ctrl->lw_after = (a.phase == 2 && !a.exchange) ? log((ctrl->w_local / a.n_local) / (W / a.n_pop)) : 0.0;
+    ctrl->inv_global = a.n_pop / W;
+    if (a.phase != 2) ctrl->g_end = INFINITY;
     const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(a.t + 1));
     ctrl->u0 = u01_53(r.x, r.y);
     if (a.ess_trace) a.ess_trace[a.t] = ess;
     if (a.resampled) a.resampled[a.t] = rs ? 1 : 0;
+}
+
+// Exchange scope: the sources of rank s own the outputs [o_s, o_{s+1}), o_s = G(B_s) with B_s the global CDF at the
+// start of the shard -- evaluated with exactly the expression the ancestor search uses for its first tile, so the
+// tile-level clamps of every shard meet without gap or overlap.  One thread; after scan_tail.
+__device__ __forceinline__ double g_of(double c, double inv, double u0);
+__device__ __forceinline__ void scan_exchange_bounds(const ScanArgs& a)
+{
+    StepCtrl* ctrl = a.ctrl;
+    ctrl->g_end = INFINITY;
+    if (!a.exchange) return;
+    const double M = ctrl->M, inv = ctrl->inv_global, u0 = ctrl->u0;
+    double B = 0.0;
+    for (int r = 0; r <= a.world; ++r) {
+        double o = (r == a.world) ? a.n_pop : g_of(B, inv, u0);
+        o = fmin(fmax(o, 0.0), a.n_pop);
+        if (a.obound) a.obound[r] = o;
+        if (r == a.rank + 1 && r < a.world) ctrl->g_end = o;
+        if (r < a.world) {
+            const double mr = a.all_totals[3 * r];
+            B += a.all_totals[3 * r + 1] * ((mr == -INFINITY) ? 0.0 : exp(mr - M));
+        }
+    }
+    if (a.obound) a.obound[a.world + 1] = (double)ctrl->do_resample;
 }
 
 __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
@@ -257,6 +287,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
         }
     }
     if (tid == 0) scan_tail(a);
+    if (tid == 0 && a.phase == 2) scan_exchange_bounds(a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -414,6 +445,7 @@ struct AncestorIn {
     uint64_t id0;      // RNG id of output 0 (stratified offsets are drawn per global particle id)
     int bc_in_lds;     // bc / bf already point at LDS copies of the whole tile-level CDF (fused step kernel)
     int guess;         // >= 0: source tile the first output is expected in (equal shard sizes: the output tile's own index)
+    double g_end;      // systematic: first output owned by whatever follows this CDF (+inf unless another shard's sources do)
 };
 
 __device__ __forceinline__ int stage_window(const AncestorIn& in, AncestorLds& L, double q_guess)
@@ -456,7 +488,7 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     CPH_STAMP(2);
     // tile-level value: start index of tile c's outputs
     auto bcv = [&](int c) -> double { return (c >= w0 && c <= w0 + wn) ? L.bcw[c - w0] : in.bc[c] * in.scale; };
-    auto gt = [&](int c) -> double { return c >= in.nb ? INFINITY : g_of(in.cdf_lo + bcv(c), inv, u0); };
+    auto gt = [&](int c) -> double { return c >= in.nb ? in.g_end : g_of(in.cdf_lo + bcv(c), inv, u0); };
     // largest c in [lo, nb) with gt(c) <= g  (gt(lo) <= g guaranteed).  Tile masses are nearly equal, so the
     // answer is within a tile or two of `guess`: probe there first, binary search only when that fails.
     auto locate = [&](double g, int lo, int guess) -> int {
@@ -503,7 +535,7 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
         ++it;
         const double bfc = in.bf[c] * in.scale;
         const double off = in.cdf_lo + b0;
-        const double g_lo = g_of(off, inv, u0), g_hi = (c + 1 >= in.nb) ? INFINITY : g_of(in.cdf_lo + b1, inv, u0);
+        const double g_lo = g_of(off, inv, u0), g_hi = (c + 1 >= in.nb) ? in.g_end : g_of(in.cdf_lo + b1, inv, u0);
         double g_prev = fmin(fmax(g_of(off + bfc * excl, inv, u0), g_lo), g_hi);
         if (tid == 0) g_prev = g_lo;
 #pragma unroll
@@ -735,6 +767,7 @@ struct ResampleArgs {
     const double* bc; const double* bf; int nb; const StepCtrl* ctrl;
     uint64_t seed, step, j0, n_total_out; int64_t n_out;
     int32_t* anc;
+    int run_ctrl;      // u0 / inv / g_end of a running SMC step (exchange scope) instead of (seed, step, n_total_out)
 };
 
 template <int RS>
@@ -747,7 +780,9 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(ResampleArgs a)
     in.wrel = a.wrel; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n_in;
     in.W = a.ctrl->W; in.scale = a.ctrl->scale; in.cdf_lo = a.ctrl->cdf_lo;
     in.inv_stepw = (double)a.n_total_out / a.ctrl->W;
-    {
+    in.g_end = INFINITY;
+    if (a.run_ctrl) { in.u0 = a.ctrl->u0; in.inv_stepw = a.ctrl->inv_global; in.g_end = a.ctrl->g_end; }
+    else {
         const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + a.step);
         in.u0 = u01_53(r.x, r.y);
     }
@@ -806,7 +841,7 @@ __global__ __launch_bounds__(kThreads) void multinomial_kernel(const double* __r
 // ---------------------------------------------------------------------------------------------
 template <class Model>
 struct SisArgs {
-    ModelParams mp; const double* obs; int T; int64_t n, ld;
+    ModelParams mp; const double* obs; int T; int64_t n, ld, rs;
     uint64_t seed, pid0;
     typename Model::value_t* values; double* logw; double* wrel; Partial* part;
 };
@@ -827,7 +862,7 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
             Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, reinterpret_cast<const V(&)[4]>(x[4 * q]), reinterpret_cast<V(&)[4]>(nx[4 * q]));
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) { x[k] = nx[k]; lw[k] += Model::loglik(a.mp, x[k], t, a.obs); }   // observe: log_w_ += logpdf  state.cpp:212-223
-        store4(a.values + (int64_t)t * a.ld, j0, x);                                          // predict: add_predict       state.hpp:312-327
+        store4(a.values + (int64_t)t * a.rs, j0, x);                                          // predict: add_predict       state.hpp:312-327
     }
 #pragma unroll
     for (int k = 0; k < kPPT; ++k)
@@ -866,6 +901,10 @@ struct StepArgs {
     double n_pop, ess_frac;   // FUSED: ESS test
     double* ess_trace; int32_t* resampled;
     int store_logw;           // 0: every step resamples (known on the host), so only the last step's log-weights are ever read
+    int64_t rs;               // row stride of values[] / anc[] (ld plus the immigrant annex)
+    // exchange scope (exact global resampling over shards): outputs [imm_l0, imm_l1) of this shard descend from local
+    // sources, the others from immigrants whose lineages sit in annex columns imm_col0, imm_col0 + 1, ... in output order
+    int exchange; int64_t imm_l0, imm_l1, imm_col0;
 };
 
 // Tile partial when every particle's log-weight is lwa + (one of K table values): no exp, no fp64
@@ -1023,16 +1062,29 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
             in.id0 = a.pid0;
             in.n_valid_tile = rem < kTile ? (int)rem : kTile;
             in.guess = (int)blockIdx.x;
+            in.g_end = INFINITY;
+            if (!FUSED && a.exchange) {                       // positions and outputs in global terms
+                in.scale = a.ctrl->scale; in.cdf_lo = a.ctrl->cdf_lo; in.inv_stepw = a.ctrl->inv_global; in.g_end = a.ctrl->g_end;
+                in.gj_tile0 = a.pid0 + (uint64_t)blockIdx.x * kTile; in.n_total_out = (uint64_t)a.n_pop; in.guess = -1;
+            }
             if (FUSED && RS == RS_SYSTEMATIC) ancestors_systematic_fused(a.wrel_prev, s_bc, s_bf, a.nb, u0, inv_stepw, in.n_valid_tile, w_own, anc, L);
             else find_ancestors<RS>(in, anc, L);
         }
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) lw[k] = lwa;          // equal weights after resampling (the shard's mass share)
+        if (!FUSED && a.exchange) {
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) {
+                const int64_t j = j0 + k;
+                if (j < a.imm_l0) anc[k] = (int32_t)(a.ld + a.imm_col0 + j);
+                else if (j >= a.imm_l1 && j < a.n) anc[k] = (int32_t)(a.ld + a.imm_col0 + j - (a.imm_l1 - a.imm_l0));
+            }
+        }
     }
 
     CPH_STAMP(8);
     V prev[kPPT], x[kPPT];
-    const V* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.ld;
+    const V* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? prev_row[anc[k]] : V(0);                 // ancestor's state (sorted gather)
 #pragma unroll
@@ -1042,8 +1094,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     bool valid[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
-    store4_stream(a.values + (int64_t)t * a.ld, j0, x);                                       // predict #t
-    store4_stream(a.anc + (int64_t)t * a.ld, j0, anc);
+    store4_stream(a.values + (int64_t)t * a.rs, j0, x);                                       // predict #t
+    store4_stream(a.anc + (int64_t)t * a.rs, j0, anc);
     double e[kPPT];
     const bool fresh = (t == 0) || resample;                                                  // every particle starts the step at log-weight lwa
     if (Model::kWeightTable > 0 && fresh) {
@@ -1090,7 +1142,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
 template <class Model>
 struct SmoothArgs {
     const typename Model::value_t* values; const int32_t* anc; const double* wrel; const double* bf; const StepCtrl* ctrl;
-    const int32_t* resampled; int T; int64_t n, ld; int identity;
+    const int32_t* resampled; int T; int64_t n, ld, rs; int identity;   // rs: row stride of values[] / anc[]
     double* stats_part;   // [T * kStats][gridDim.x]
     typename Model::value_t* paths;   // optional [T][ld]: materialised traces (dump / tests)
 };
@@ -1120,7 +1172,7 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
             double acc[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) acc[j] = 0.0;
-            const V* row = a.values + (int64_t)t * a.ld;
+            const V* row = a.values + (int64_t)t * a.rs;
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
                 const V x = row[idx[k]];
@@ -1134,7 +1186,7 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
                 for (int j = 0; j < K; ++j) s_stat[wv * TK + t * K + j] += acc[j];
             }
             if (t > 0 && !a.identity && a.resampled[t - 1]) {
-                const int32_t* arow = a.anc + (int64_t)t * a.ld;
+                const int32_t* arow = a.anc + (int64_t)t * a.rs;
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) idx[k] = arow[idx[k]];
             }
@@ -1177,6 +1229,40 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(const double* __rest
             stats[t * K + 1] = s_out[1] / W - mean * mean;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exchange scope: lineages that leave / enter a shard.
+//   extract_lineages_kernel : record k = the trace x_0 .. x_{len-1} of the current-generation particle src[k]
+//                             (walks anc[] like smooth_kernel; annex columns are ordinary columns to it)
+//   annex_lineages_kernel   : record k becomes annex column col0 + k of rows 0 .. len-1, with identity ancestors,
+//                             so that neither the step kernel's gather nor any lineage walk needs to know that the
+//                             particle came from another GPU
+// Records are [count][len], record-major (one contiguous block per destination rank for the all-to-all).
+// ---------------------------------------------------------------------------------------------
+template <class V>
+__global__ void extract_lineages_kernel(const V* __restrict__ values, const int32_t* __restrict__ anc, int64_t rs, const int32_t* __restrict__ resampled,
+                                        int len, const int32_t* __restrict__ src, int64_t count, V* __restrict__ rec)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    int32_t idx = src[k];
+    for (int t = len - 1; t >= 0; --t) {
+        rec[k * len + t] = values[(int64_t)t * rs + idx];
+        if (t > 0 && resampled[t - 1]) idx = anc[(int64_t)t * rs + idx];
+    }
+}
+
+template <class V>
+__global__ void annex_lineages_kernel(const V* __restrict__ rec, int64_t count, int len, V* __restrict__ values, int32_t* __restrict__ anc, int64_t rs,
+                                      int64_t col0)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count * len) return;
+    const int64_t k = i / len; const int t = (int)(i - k * len);
+    const int64_t col = col0 + k;
+    values[(int64_t)t * rs + col] = rec[i];
+    anc[(int64_t)t * rs + col] = (int32_t)col;
 }
 
 // ---------------------------------------------------------------------------------------------

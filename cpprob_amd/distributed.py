@@ -27,6 +27,15 @@ Two scopes (include/cpprob_hip.h, cpprob_hip_config.resample_scope):
           so the joint algorithm is executed as ISLAND + one final combine (same estimator,
           tests/test_gpu_inference.py::..._static_schedule_equals_evidence_weighted_islands).
 
+  EXCHANGE  GLOBAL plus particle migration: the sharded run draws exactly the ancestors one GPU holding all
+          n_global particles would (systematic resampling).  The all-gathered rank totals give
+          every rank the offspring interval [o_r, o_{r+1}) of every rank's sources, hence a deterministic
+          plan of who sends how many lineages to whom; the lineages (trace x_0..x_t of each remote ancestor)
+          travel in ONE all-to-all-v per resampling step over xGMI (point-to-point links: every pair of
+          GPUs talks directly) and become annex columns of the receiving shard.  Expected volume is
+          O(sqrt(n)) records per rank per step for well-mixed shards; worst case n.  One host
+          synchronisation per step (the split sizes of the all-to-all must be known on the host).
+
 Host logic in this file is pure numpy/torch and is covered by gloo world_size-2 tests on CPU.
 """
 import os
@@ -166,6 +175,42 @@ class TorchCollective:
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
 
 
+    def all_to_all_records(self, send, recv, send_counts, recv_counts, width):
+        """all-to-all-v of lineage records: rank r gets send_counts[r] records of `width` elements from `send` (grouped by
+        destination, rank order); `recv` is filled grouped by source."""
+        ins = [int(c) * width for c in send_counts]
+        outs = [int(c) * width for c in recv_counts]
+        with self.torch.cuda.stream(self.stream):
+            if _host_collectives():
+                h_send = send[: sum(ins)].cpu()
+                h_recv = host_all_to_all(h_send, ins, outs)
+                recv[: sum(outs)].copy_(h_recv.to(recv.device))
+            else:
+                self.dist.all_to_all_single(recv[: sum(outs)], send[: sum(ins)], output_split_sizes=outs, input_split_sizes=ins)
+
+
+def host_all_to_all(h_send, in_splits, out_splits):
+    """all-to-all-v of a 1-D CPU tensor over the default (gloo) group, as point-to-point pairs."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    h_recv = torch.empty(sum(out_splits), dtype=h_send.dtype)
+    send_parts = list(torch.split(h_send, in_splits))
+    recv_parts = list(torch.split(h_recv, out_splits))
+    recv_parts[rank].copy_(send_parts[rank])
+    reqs = []
+    for r in range(world):
+        if r == rank:
+            continue
+        if in_splits[r]:
+            reqs.append(dist.isend(send_parts[r].contiguous(), dst=r))
+        if out_splits[r]:
+            reqs.append(dist.irecv(recv_parts[r], src=r))
+    for q in reqs:
+        q.wait()
+    return h_recv
+
+
 def normalise_joint_stats(raw, log_norm, max_logw, is_int):
     """raw [T, K]: all-reduced un-normalised sums relative to exp(max_logw).  Returns StatsPrinter's numbers."""
     raw = np.asarray(raw, np.float64)
@@ -197,4 +242,52 @@ def run_joint(engine, collective, run_index=0, buffers=None):
     raw = torch.from_numpy(engine.stats()).to(dev)
     collective.all_reduce_sum(raw)
     stats = normalise_joint_stats(raw.cpu().numpy(), s["log_norm"], s["max_logw"], engine.is_int)
+    return stats, s
+
+
+def shard_begins(n_global, world):
+    return np.array([shard_bounds(n_global, world, r)[0] for r in range(world)] + [int(n_global)], np.uint64)
+
+
+def run_exchange(engine, collective, run_index=0, counters=None):
+    """One run of a joint population with EXACT global resampling (engine begun with scope=SCOPE_EXCHANGE on the shard
+    shard_bounds(n_global, world, rank)).  Returns (stats[T, K], summary).  counters (dict) receives the number of
+    lineage records this rank sent / received."""
+    import torch
+    dev = torch.device("cuda", engine.device)
+    world, rank = collective.world, collective.rank
+    n_global = int(engine.cfg.n_global)
+    begins = shard_begins(n_global, world)
+    local = torch.zeros(4, dtype=torch.float64, device=dev)
+    allt = torch.zeros(3 * world, dtype=torch.float64, device=dev)
+    vdtype = torch.int32 if engine.is_int else torch.float64
+    send = recv = None
+    n_sent = n_recv = 0
+    for t in range(engine.T):
+        engine.step_begin(t, local, run_index)
+        collective.all_gather(local, allt)
+        engine.step_end(t, allt, world, rank)
+        if t + 1 == engine.T:
+            break
+        _, sc, rc = engine.exchange_plan(t, world, rank, begins)
+        width = t + 1
+        ns, nr = int(sc.sum()), int(rc.sum())
+        if send is None or send.numel() < max(ns, 1) * engine.T:
+            send = torch.empty(max(ns, 1) * engine.T, dtype=vdtype, device=dev)
+        if recv is None or recv.numel() < max(nr, 1) * engine.T:
+            recv = torch.empty(max(nr, 1) * engine.T, dtype=vdtype, device=dev)
+        engine.exchange_pack(t, send)
+        if world > 1:        # every rank takes part even with nothing to move: the peers' counts are not known here
+            collective.all_to_all_records(send, recv, sc, rc, width)
+        engine.exchange_commit(t, recv)
+        n_sent += ns
+        n_recv += nr
+    engine.finish()
+    s = engine.summary()
+    raw = torch.from_numpy(engine.stats()).to(dev)
+    collective.all_reduce_sum(raw)
+    stats = normalise_joint_stats(raw.cpu().numpy(), s["log_norm"], s["max_logw"], engine.is_int)
+    if counters is not None:
+        counters["records_sent"] = n_sent
+        counters["records_received"] = n_recv
     return stats, s

@@ -60,6 +60,7 @@ extern "C" {
 
 #define CPPROB_HIP_SCOPE_GLOBAL 0
 #define CPPROB_HIP_SCOPE_ISLAND 1
+#define CPPROB_HIP_SCOPE_EXCHANGE 2   /* one population, resampled jointly AND exactly: offspring of remote sources migrate (below) */
 
 typedef struct cpprob_hip_ctx cpprob_hip_ctx;
 
@@ -75,7 +76,9 @@ typedef struct cpprob_hip_config {
                                  resampled jointly (sharded runs use the step_begin/step_end
                                  protocol); CPPROB_HIP_SCOPE_ISLAND: this shard is an independent
                                  population of n_particles (particle_offset only selects the
-                                 RNG streams); shards are combined by their evidence estimates */
+                                 RNG streams); shards are combined by their evidence estimates;
+                                 CPPROB_HIP_SCOPE_EXCHANGE: like GLOBAL, with particle migration
+                                 (cpprob_hip_exchange_*) so that resampling is exact over shards */
     int32_t keep_history;     /* 1: keep per-step values + ancestors (needed for smoothing /
                                  dumps; always 1 in this version)                             */
     int32_t reserved;
@@ -163,6 +166,26 @@ int cpprob_hip_copy_paths(cpprob_hip_ctx* ctx, void* h_paths, size_t n_bytes);
 int cpprob_hip_smc_step_begin(cpprob_hip_ctx* ctx, int32_t t, uint64_t run_index, double* d_local_totals);
 int cpprob_hip_smc_step_end(cpprob_hip_ctx* ctx, int32_t t, const double* d_all_totals, int32_t world, int32_t rank);
 int cpprob_hip_smc_finish(cpprob_hip_ctx* ctx);
+
+/* Exchange scope (cfg.resample_scope = CPPROB_HIP_SCOPE_EXCHANGE, systematic resampling): the sharded run draws the
+ * SAME ancestors a single GPU holding all n_global particles would (one shared offset u makes every
+ * rank's offspring range [o_r, o_{r+1}) a function of the all-gathered rank totals).  Output j lives on the rank whose
+ * shard contains j; outputs whose ancestor sits on another rank arrive as lineage records -- the ancestor's trace
+ * x_0 .. x_t, (t + 1) values of the model's value type -- and become extra columns of the receiving shard's
+ * particle store, so every later kernel treats them as ordinary particles.  Between step_end(t) and
+ * step_begin(t + 1), for every t < T - 1:
+ *   plan(t)    host-synchronising; h_shard_begin[world + 1] = first global particle id of each rank's shard.
+ *              Returns the resampling decision and, per peer, how many records this rank sends / receives
+ *              (both zero when the step does not resample or when the shards' masses happen to match);
+ *   pack(t)    writes sum(h_send_counts) records into d_send (device, caller-owned), grouped by destination rank
+ *              in rank order;
+ *   the caller moves them (RCCL all-to-all-v with the counts as split sizes, times (t + 1) elements);
+ *   commit(t)  takes sum(h_recv_counts) records from d_recv, grouped by source rank in rank order.
+ * pack/commit may be skipped data-wise (NULL pointers) when the respective count is zero, but must be called. */
+int cpprob_hip_exchange_plan(cpprob_hip_ctx* ctx, int32_t t, int32_t world, int32_t rank, const uint64_t* h_shard_begin,
+                             uint64_t* h_send_counts, uint64_t* h_recv_counts, int32_t* h_do_resample);
+int cpprob_hip_exchange_pack(cpprob_hip_ctx* ctx, int32_t t, void* d_send);
+int cpprob_hip_exchange_commit(cpprob_hip_ctx* ctx, int32_t t, const void* d_recv);
 
 /* ---- building blocks (also the unit-parity surface) --------------------------------------
  * All pointers are device pointers; n is the element count. */

@@ -279,6 +279,129 @@ def _run_joint_virtual(model, alg, obs, n_per, world, seed, ess):
     return stats, summ, traces
 
 
+def _run_exchange_virtual(model, obs, n_pers, seed, ess):
+    """EXCHANGE scope over virtual ranks: plan / pack / (in-process all-to-all) / commit.  Returns the joint stats, the
+    summary, every shard's materialised traces [T, n_r] and the number of migrated lineage records per step."""
+    import torch
+    from cpprob_amd import distributed as D
+    world = len(n_pers)
+    begins = np.concatenate([[0], np.cumsum(n_pers)]).astype(np.uint64)
+    engines = [cp.Engine(0) for _ in range(world)]
+    for r, e in enumerate(engines):
+        e.begin(cp.ALG_SMC, model, obs, n_pers[r], seed=seed, ess_threshold=ess, particle_offset=int(begins[r]), n_global=int(begins[-1]), scope=cp.SCOPE_EXCHANGE)
+    T, K = engines[0].T, engines[0].K
+    vdt = torch.int32 if engines[0].is_int else torch.float64
+    locals_ = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in range(world)]
+    allt = torch.zeros(3 * world, dtype=torch.float64, device="cuda")
+    moved = []
+    for t in range(T):
+        for r, e in enumerate(engines):
+            e.step_begin(t, locals_[r])
+        for e in engines:
+            e.sync()
+        allt.copy_(torch.cat([l[:3] for l in locals_]))
+        torch.cuda.synchronize()
+        for r, e in enumerate(engines):
+            e.step_end(t, allt, world, r)
+        if t + 1 == T:
+            break
+        plans = [e.exchange_plan(t, world, r, begins) for r, e in enumerate(engines)]
+        flags = {p[0] for p in plans}
+        assert len(flags) == 1                                                  # same decision everywhere
+        for a in range(world):
+            for b in range(world):
+                assert plans[a][1][b] == plans[b][2][a]                         # what a sends to b is what b expects from a
+        width = t + 1
+        sends = []
+        for r, e in enumerate(engines):
+            buf = torch.empty(max(int(plans[r][1].sum()), 1) * width, dtype=vdt, device="cuda")
+            e.exchange_pack(t, buf)
+            e.sync()
+            sends.append(buf)
+        for dst, e in enumerate(engines):
+            parts = []
+            for src in range(world):
+                off = int(plans[src][1][:dst].sum()) * width
+                parts.append(sends[src][off: off + int(plans[src][1][dst]) * width])
+            recv = torch.cat(parts) if parts else torch.empty(0, dtype=vdt, device="cuda")
+            assert recv.numel() == int(plans[dst][2].sum()) * width
+            torch.cuda.synchronize()
+            e.exchange_commit(t, recv if recv.numel() else None)
+            e.sync()
+        moved.append(int(sum(p[1].sum() for p in plans)))
+    raw = np.zeros((T, K))
+    summ = None
+    for e in engines:
+        e.finish()
+        raw += e.stats()
+        s = e.summary()
+        if summ is not None:
+            assert s["log_evidence"] == summ["log_evidence"] and s["log_norm"] == summ["log_norm"]
+        summ = s
+    stats = D.normalise_joint_stats(raw, summ["log_norm"], summ["max_logw"], engines[0].is_int)
+    paths = [e.paths() for e in engines]
+    logw = [e.logw() for e in engines]
+    for e in engines:
+        e.close()
+    return stats, summ, paths, logw, moved
+
+
+@pytest.mark.parametrize("n_pers", [[50000, 50000], [30000, 50001, 19999], [1000, 2000, 70000, 3000]])
+@pytest.mark.parametrize("ess", [2.0, 0.5])
+def test_exchange_scope_draws_the_single_gpu_ancestors(engine, golden_dir, n_pers, ess):
+    """SURVEY 8(e) default: exact global resampling over shards.  Every shard's traces must be the corresponding slice
+    of the traces ONE context with all particles produces (same seed): same variates (global ids), same ancestors (one
+    shared systematic offset, offspring ranges that meet without gap or overlap), lineages migrated intact."""
+    obs = _obs(golden_dir, "hmm16")
+    n = int(sum(n_pers))
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=31, ess_threshold=ess)
+    engine.run()
+    ref_paths, ref_stats, ref_sum, ref_logw = engine.paths(), engine.stats().copy(), engine.summary(), engine.logw()
+    stats, s, paths, logw, moved = _run_exchange_virtual(cp.MODEL_HMM3, obs, n_pers, 31, ess)
+    got = np.concatenate(paths, axis=1)
+    # a 1-ulp difference between the two CDF evaluations can move one offspring across a boundary (~1e-3 per run)
+    assert (got != ref_paths).any(axis=0).sum() <= 2
+    np.testing.assert_allclose(np.concatenate(logw), ref_logw, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if (got != ref_paths).any() else 1e-12)
+    assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-12 and s["n_resampled"] == ref_sum["n_resampled"]
+    assert sum(moved) > 0                                                       # particles did migrate
+
+
+def test_exchange_scope_survives_extreme_imbalance_and_grows_the_annex(engine, golden_dir):
+    """An outlying first observation puts nearly all the weight on a few particles: whole shards are repopulated from
+    another rank (more immigrants than the initial annex holds), real-valued lineages."""
+    obs = np.array(_obs(golden_dir, "lgssm100")[:12])
+    obs[0] = 7.5
+    n_pers = [40000, 40000, 40000]
+    n = sum(n_pers)
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=5, ess_threshold=0.5)
+    engine.run()
+    ref_paths, ref_stats, ref_sum = engine.paths(), engine.stats().copy(), engine.summary()
+    stats, s, paths, _, moved = _run_exchange_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n_pers, 5, 0.5)
+    got = np.concatenate(paths, axis=1)
+    assert (got != ref_paths).any(axis=0).sum() <= 2
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if (got != ref_paths).any() else 1e-11)
+    assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-11
+    assert max(moved) > 40000 // 16 + 4096                                      # beyond the initial annex: it grew
+
+
+def test_exchange_scope_world1_is_bit_identical_to_run(engine, golden_dir):
+    from cpprob_amd import distributed as D
+    obs = _obs(golden_dir, "hmm16")
+    n = 30000
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, ess_threshold=0.5)
+    engine.run()
+    ref_stats, ref_sum, ref_vals = engine.stats().copy(), engine.summary(), engine.values().copy()
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, ess_threshold=0.5, scope=cp.SCOPE_EXCHANGE)
+    cnt = {}
+    stats, s = D.run_exchange(engine, D.TorchCollective(engine), counters=cnt)
+    assert np.array_equal(engine.values(), ref_vals) and cnt["records_sent"] == 0
+    np.testing.assert_allclose(stats, ref_stats, rtol=1e-13, atol=1e-15)
+    assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
+    with pytest.raises(cp.CpprobHipError):
+        engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, resampler=cp.RESAMPLE_MULTINOMIAL, scope=cp.SCOPE_EXCHANGE)
+
+
 def test_step_protocol_world1_is_bit_identical_to_run(engine, golden_dir):
     import torch
     from cpprob_amd import distributed as D

@@ -122,6 +122,15 @@ assert abs(float(t) - lz) < 1e-15          # identical on both ranks
 g = np.load(os.path.join(%(root)r, "tests", "golden", "observations.npz"))["hmm16_smooth"]
 assert np.abs(out - g).max() < 0.03 and np.allclose(out.sum(1), 1)
 assert iess > 1.9
+# exchange scope: the all-to-all-v of lineage records through host memory (what TorchCollective uses under gloo)
+begins = D.shard_begins(11, 2)
+assert list(begins) == [0, 6, 11]
+send = torch.arange(10, dtype=torch.int32) + 100 * rank
+ins = [4, 6] if rank == 0 else [3, 7]
+outs = [4, 3] if rank == 0 else [6, 7]
+got = D.host_all_to_all(send, ins, outs)
+want = torch.cat([torch.arange(0, 4), torch.arange(100, 103)]) if rank == 0 else torch.cat([torch.arange(4, 10), torch.arange(103, 110)])
+assert torch.equal(got, want.to(torch.int32))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
