@@ -140,6 +140,8 @@ void host_model_params(ModelParams& mp, int model)
         mp.mu0 = 1; mp.sigma0 = std::sqrt(5.0); mp.sigma = std::sqrt(2.0);
     } else if (model == CPPROB_HIP_MODEL_GAUSSIAN_README) {         // gaussian.cpp:8
         mp.mu0 = 1; mp.sigma0 = 1.5; mp.sigma = 2;
+    } else if (model == CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN) { // models.hpp:42,44
+        mp.nd_mean[0] = 1; mp.nd_mean[1] = 2; mp.nd_sigma[0] = std::sqrt(5.0); mp.nd_sigma[1] = std::sqrt(3.0); mp.sigma = std::sqrt(2.0);
     } else { mp.mu0 = 0; mp.sigma0 = 1; mp.sigma = 1; }
     mp.log_norm_lik = std::log(2 * pi * mp.sigma * mp.sigma);       // utils_normal_distribution.hpp:40
     mp.log_norm_unit = std::log(2 * pi * 1.0 * 1.0);
@@ -323,6 +325,7 @@ int dispatch_model(cpprob_hip_ctx* c, F&& f)
     case CPPROB_HIP_MODEL_GAUSSIAN_README: f(ModelGaussian{}); return 0;
     case CPPROB_HIP_MODEL_LINEAR_GAUSSIAN_1D: f(ModelLinearGaussian1D{}); return 0;
     case CPPROB_HIP_MODEL_HMM3: f(ModelHmm3{}); return 0;
+    case CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN: f(ModelGaussianND{}); return 0;
     }
     return fail(c, CPPROB_HIP_EINVAL, "unknown model id");
 }
@@ -400,10 +403,11 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     if (!c || !cfg || !h_obs) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (cfg->algorithm != CPPROB_HIP_ALG_SIS && cfg->algorithm != CPPROB_HIP_ALG_SMC)
         return fail(c, CPPROB_HIP_EUNSUPPORTED, "algorithm must be sis or smc (compile/csis/dryrun are outside this engine)");
-    if (cfg->model < 0 || cfg->model > CPPROB_HIP_MODEL_HMM3) return fail(c, CPPROB_HIP_EINVAL, "unknown model id");
+    if (cfg->model < 0 || cfg->model > CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN) return fail(c, CPPROB_HIP_EINVAL, "unknown model id");
     if (n_obs == 0) return fail(c, CPPROB_HIP_EINVAL, "the model has to receive the observed values (cpprob.hpp:182)");
     const bool gauss = cfg->model == CPPROB_HIP_MODEL_GAUSSIAN_UNKNOWN_MEAN || cfg->model == CPPROB_HIP_MODEL_GAUSSIAN_README;
     if (gauss && n_obs != 2) return fail(c, CPPROB_HIP_EINVAL, "gaussian_unknown_mean takes exactly two observes");
+    if (cfg->model == CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN && n_obs != 2) return fail(c, CPPROB_HIP_EINVAL, "gaussian_2d_unk_mean observes one vector of two values");
     if (cfg->n_particles == 0) return fail(c, CPPROB_HIP_EINVAL, "n_particles must be > 0");
     if (cfg->n_particles > (uint64_t)INT32_MAX - kTile) return fail(c, CPPROB_HIP_EINVAL, "n_particles per context must fit int32 ancestor indices");
     if (cfg->n_particles > (uint64_t)kMaxSlabs * kSlabTiles * kTile) return fail(c, CPPROB_HIP_EINVAL, "n_particles per context exceeds the two-level normalisation's capacity");
@@ -422,6 +426,9 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     if (exchange && cfg->resampler != CPPROB_HIP_RESAMPLE_SYSTEMATIC)
         return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope resamples systematically (one shared offset makes every rank's offspring range computable from the rank totals)");
     c->cfg = *cfg;
+    // a model with ONE observe statement has nothing to resample between: smc is sis (the components of its vector-valued
+    // statements are rows of the particle store, not resampling points)
+    if (cfg->model == CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN) c->cfg.algorithm = CPPROB_HIP_ALG_SIS;
     const bool island = cfg->resample_scope == CPPROB_HIP_SCOPE_ISLAND;
     c->pop_n = island ? cfg->n_particles : cfg->n_global;
     c->T = model_T(cfg->model, n_obs);
@@ -433,7 +440,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     c->ld = (int64_t)c->nb * kTile;                 // padded to the tile: no ragged tails in any kernel
     c->smooth_grid = std::min(c->nb, 2048);
     host_model_params(c->mp, cfg->model);
-    const bool smc = cfg->algorithm == CPPROB_HIP_ALG_SMC;
+    const bool smc = c->cfg.algorithm == CPPROB_HIP_ALG_SMC;
     const bool multinomial = smc && cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL;
 
     c->exchange = exchange;

@@ -22,6 +22,8 @@ struct ModelParams {
     double log_norm_unit;                         // log(2*pi*1*1)
     const double* ll_tab;                         // hmm: [T][3] log N(y_t; mean[s], 1), device pointer
     const double* e_tab;                          // hmm: [T][4] exp(ll - max ll) for s = 0..2, then max ll
+    // gaussian_2d_unk_mean: independent components, prior N(nd_mean[d], nd_sigma[d]); likelihood sigma / log_norm_lik as above
+    double nd_mean[4], nd_sigma[4];
 };
 
 // reference include/models/models.hpp:22-35 and src/models/gaussian.cpp:6-17 (same body,
@@ -53,6 +55,40 @@ struct ModelGaussian {
         lw += normal_logpdf_hoisted(obs[0], mu, mp.sigma, mp.log_norm_lik);   // observe(likelihood, y1)  models.hpp:32
         lw += normal_logpdf_hoisted(obs[1], mu, mp.sigma, mp.log_norm_lik);   // observe(likelihood, y2)  models.hpp:33
         return lw;
+    }
+    __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
+    {
+        acc[0] += w * x;
+        acc[1] += w * (x * x);
+    }
+};
+
+// reference include/models/models.hpp:38-49: ONE vector-valued sample (diagonal multivariate normal: component d is
+// the d-th draw, multivariate_normal.hpp:268-274), ONE vector-valued observe (logpdf = sum over components,
+// utils_multivariate_normal.hpp:22-33), ONE NDArray predict.  Variable-width SoA: component d is "step" d of the SIS
+// kernel -- row d of values[] -- and the weight is the sum over rows, which is exactly the component sum.
+struct ModelGaussianND {
+    using value_t = double;
+    static constexpr bool kIsInt = false;
+    static constexpr int kStats = 2;
+    static constexpr int kWeightTable = 0;
+    __device__ static __forceinline__ void weight_table(const ModelParams&, int, double (&)[1], double (&)[1], double&) {}
+    __device__ static __forceinline__ int weight_index(value_t) { return 0; }
+    struct Rand { double z[4]; };
+    __device__ static __forceinline__ void draw4(uint64_t seed, uint64_t pid0, int d, Rand& r) { draw_std_normals4(seed, pid0, (uint64_t)d, r.z); }
+    __device__ static __forceinline__ void apply4(const ModelParams& mp, int d, const Rand& r, const value_t (&)[4], value_t (&x)[4])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = mp.nd_mean[d] + mp.nd_sigma[d] * r.z[k];           // models.hpp:42-43
+    }
+    __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int d, const value_t (&prev)[4],
+                                                      value_t (&x)[4])
+    {
+        Rand r; draw4(seed, pid0, d, r); apply4(mp, d, r, prev, x);
+    }
+    __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t mu, int d, const double* __restrict__ obs)
+    {
+        return normal_logpdf_hoisted(obs[d], mu, mp.sigma, mp.log_norm_lik);                  // models.hpp:46-47, component d
     }
     __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
     {

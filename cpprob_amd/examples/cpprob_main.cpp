@@ -1,7 +1,7 @@
 // Host driver in plain C++14 with the command-line surface of the reference's src/main.cpp for the
 // sis path (flags :145-170, flow :69-107), plus --smc:
 //     cpprob_main --model hmm16 --smc --n_samples 100000 --observes "[0.3 -1 ...]" --estimate
-// Flags: --model {gaussian_unknown_mean, gaussian_readme, linear_gaussian_1d25, linear_gaussian_1d100, hmm16, hmm128, poisson_rate}
+// Flags: --model {gaussian_unknown_mean, gaussian_readme, linear_gaussian_1d25, linear_gaussian_1d100, hmm16, hmm128, poisson_rate, gaussian_2d_unk_mean, ...}
 //        --sis | --smc        --n_samples N (default 10000)    --observes "…" | --observes_file F
 //        --generated_file NAME (default "post")   --model_folder DIR (default ".")   --estimate
 //        additions: --seed S  --resampler {systematic,stratified,multinomial}  --ess_threshold X
@@ -41,7 +41,15 @@ void print_json(const cpprob::gpu::Result& r)
             for (std::size_t s = 0; s < p.probabilities.size(); ++s) std::cout << (s ? ", " : "") << p.probabilities[s];
             std::cout << "]}";
         } else {
-            std::cout << "\"mean\": " << p.mean << ", \"variance\": " << p.variance << "}";
+            std::cout << "\"mean\": " << p.mean << ", \"variance\": " << p.variance;
+            if (p.mean_nd.size() > 1) {                      // vector-valued predict: one entry per component
+                std::cout << ", \"mean_nd\": [";
+                for (std::size_t d = 0; d < p.mean_nd.size(); ++d) std::cout << (d ? ", " : "") << p.mean_nd[d];
+                std::cout << "], \"variance_nd\": [";
+                for (std::size_t d = 0; d < p.variance_nd.size(); ++d) std::cout << (d ? ", " : "") << p.variance_nd[d];
+                std::cout << "]";
+            }
+            std::cout << "}";
         }
     }
     std::cout << "]}" << std::endl;
@@ -113,6 +121,7 @@ int main(int argc, char** argv)
         if (a.model == "hmm16") return execute(models::hmm<16>, a);
         if (a.model == "hmm128") return execute(models::hmm<128>, a);
         if (a.model == "poisson_rate") return execute(models::poisson_rate<double>, a);
+        if (a.model == "gaussian_2d_unk_mean") return execute(models::gaussian_2d_unk_mean<double>, a);       // observes: "[y0 y1]"
         if (a.model == "gauss_functor") return execute(models::GaussFunctor<double>{}, a);
         if (a.model == "gaussian_by_rejection") return execute(models::gaussian_by_rejection<double>, a);
         std::cerr << "unknown model " << a.model << std::endl;

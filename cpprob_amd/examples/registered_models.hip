@@ -34,3 +34,5 @@ CPPROB_REGISTER_BUILTIN(models::linear_gaussian_1d<25>, CPPROB_HIP_MODEL_LINEAR_
 CPPROB_REGISTER_BUILTIN(models::linear_gaussian_1d<100>, CPPROB_HIP_MODEL_LINEAR_GAUSSIAN_1D);
 CPPROB_REGISTER_BUILTIN(models::hmm<16>, CPPROB_HIP_MODEL_HMM3);
 CPPROB_REGISTER_BUILTIN(models::hmm<128>, CPPROB_HIP_MODEL_HMM3);
+// vector-valued statements: std::vector / NDArray cannot exist in device code, so this model has a built-in kernel only
+CPPROB_REGISTER_BUILTIN(models::gaussian_2d_unk_mean<double>, CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN);

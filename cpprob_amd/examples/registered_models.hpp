@@ -15,6 +15,7 @@ extern template void linear_gaussian_1d<100>(const std::array<double, 100>&);
 extern template void hmm<16>(const std::array<double, 16>&);
 extern template void hmm<128>(const std::array<double, 128>&);
 extern template void poisson_rate<double>(int, int);
+extern template void gaussian_2d_unk_mean<double>(std::vector<double>);
 extern template void gaussian_by_rejection<double>(double, double);
 }
 #endif

@@ -8,6 +8,7 @@
 #include <array>
 #include <cmath>
 #include <cstddef>
+#include <vector>
 
 #include <boost/math/distributions/normal.hpp>
 #include <boost/random/discrete_distribution.hpp>
@@ -113,6 +114,18 @@ void gaussian_by_rejection(const Real y1, const Real y2)
     boost::random::normal_distribution<Real> lik{mu, s};
     cpprob::observe(lik, y1);
     cpprob::observe(lik, y2);
+    cpprob::predict(mu, "Mu");
+}
+
+// vector-valued statements (restates reference include/models/models.hpp:38-49): a 2-D mean with independent priors
+// N(1, sd sqrt 5) and N(2, sd sqrt 3), ONE observe of a 2-vector with sd sqrt 2 per component, ONE NDArray predict "Mu"
+template <class Real = double>
+void gaussian_2d_unk_mean(const std::vector<Real> y)
+{
+    cpprob::multivariate_normal_distribution<Real> prior{{1, 2}, {static_cast<Real>(std::sqrt(5)), static_cast<Real>(std::sqrt(3))}};
+    const auto mu = cpprob::sample(prior, true);
+    cpprob::multivariate_normal_distribution<Real> lik{mu.begin(), mu.end(), static_cast<Real>(std::sqrt(2))};
+    cpprob::observe(lik, y);
     cpprob::predict(mu, "Mu");
 }
 

@@ -26,6 +26,7 @@
 #include "cpprob/detail/host_trace.hpp"
 #include "cpprob/detail/traits.hpp"
 #include "cpprob/distributions/utils_distributions.hpp"
+#include "cpprob/distributions/utils_multivariate_normal.hpp"
 #include "cpprob/state.hpp"
 #if defined(CPPROB_DEVICE_COMPILE_AVAILABLE)
 #include "cpprob/detail/device_trace.hpp"

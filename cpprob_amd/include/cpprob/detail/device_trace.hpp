@@ -98,42 +98,56 @@ template <class Distribution>
 __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(Distribution& distr)
 {
     using R = typename std::decay_t<Distribution>::result_type;
-    LaneCtx& c = lane_ctx();
-    const uint32_t j = c.n_sample++;
-    if (c.done) return R();
-    R value;
-    if (j < c.n_stored) value = from_raw<R>(c.trace_in[(int64_t)j * c.ld]);
-    else value = draw(distr, c.seed, c.pid, (uint64_t)j);
-    if (c.trace_out) {
-        if (j < c.trace_cap) c.trace_out[(int64_t)j * c.ld] = to_raw<R>(value);
-        else if (c.overflow) *c.overflow = 1;
+    if constexpr (!std::is_arithmetic<R>::value) {
+        // vector-valued statements own host containers: they reach the device through built-in kernels only
+        // (cpprob::inference refuses to launch this path for them, host_engine.hpp)
+        __builtin_trap();
+    } else {
+        LaneCtx& c = lane_ctx();
+        const uint32_t j = c.n_sample++;
+        if (c.done) return R();
+        R value;
+        if (j < c.n_stored) value = from_raw<R>(c.trace_in[(int64_t)j * c.ld]);
+        else value = draw(distr, c.seed, c.pid, (uint64_t)j);
+        if (c.trace_out) {
+            if (j < c.trace_cap) c.trace_out[(int64_t)j * c.ld] = to_raw<R>(value);
+            else if (c.overflow) *c.overflow = 1;
+        }
+        c.n_recorded = j + 1;
+        return value;
     }
-    c.n_recorded = j + 1;
-    return value;
 }
 
 template <class Distribution, class X>
 __device__ inline void observe_impl(Distribution& distr, const X& x)
 {
-    LaneCtx& c = lane_ctx();
-    const int32_t m = (int32_t)c.n_observe++;
-    if (c.done || m < c.first_observe) return;
-    c.log_w += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
-    if (m == c.stop_after) c.done = 1;
+    if constexpr (!std::is_arithmetic<X>::value) {
+        __builtin_trap();                                           // vector-valued: built-in kernels only (see sample_impl)
+    } else {
+        LaneCtx& c = lane_ctx();
+        const int32_t m = (int32_t)c.n_observe++;
+        if (c.done || m < c.first_observe) return;
+        c.log_w += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
+        if (m == c.stop_after) c.done = 1;
+    }
 }
 
 template <class T>
 __device__ inline void predict_impl(const T& x)
 {
     using V = std::decay_t<T>;
-    LaneCtx& c = lane_ctx();
-    if (c.done) return;
-    if (std::is_integral<V>::value) {                                   // state.hpp:312-318 -> predict_int_
+    if constexpr (std::is_integral<V>::value) {                         // state.hpp:312-318 -> predict_int_
+        LaneCtx& c = lane_ctx();
+        if (c.done) return;
         const uint32_t k = c.n_pred_int++;
         if (c.pred_int) c.pred_int[(int64_t)k * c.ld] = static_cast<int32_t>(x);
-    } else if (std::is_floating_point<V>::value) {                      // state.hpp:320-326 -> predict_real_
+    } else if constexpr (std::is_floating_point<V>::value) {            // state.hpp:320-326 -> predict_real_
+        LaneCtx& c = lane_ctx();
+        if (c.done) return;
         const uint32_t k = c.n_pred_real++;
         if (c.pred_real) c.pred_real[(int64_t)k * c.ld] = static_cast<double>(x);
+    } else {
+        __builtin_trap();                                               // vector-valued: built-in kernels only (see sample_impl)
     }
 }
 

@@ -64,10 +64,18 @@ inline void dump_posterior(const std::string& file, const detail::TraceStructure
         f << std::scientific;
         for (std::size_t i = 0; i < n; ++i) {
             f << "([";
+            std::size_t row = 0;
             for (std::size_t k = 0; k < ids.size(); ++k) {
                 if (k) f << ' ';
                 f << '(' << ids[k] << ' ';
-                if (is_int) f << hs.ints[k * hs.n + i]; else f << hs.real[k * hs.n + i];
+                if (is_int) f << hs.ints[k * hs.n + i];
+                else {
+                    const std::size_t w = st.real_width[k];          // an NDArray prints as [v0 v1 ...] (ndarray.hpp:273-288)
+                    if (w != 1) f << '[';
+                    for (std::size_t d = 0; d < w; ++d) { if (d) f << ' '; f << hs.real[(row + d) * hs.n + i]; }
+                    if (w != 1) f << ']';
+                    row += w;
+                }
                 f << ')';
             }
             f << "] " << hs.logw[i] << ")\n";
@@ -108,17 +116,22 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
     ctx.check(cpprob_hip_infer_summary(ctx.get(), &s), "cpprob_hip_infer_summary");
     res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const std::size_t T = static_cast<std::size_t>(s.n_predict), K = static_cast<std::size_t>(s.stats_per_predict);
-    if ((s.is_int ? st.int_ids.size() : st.real_ids.size()) != T)
+    if ((s.is_int ? st.int_ids.size() : st.real_rows()) != T)
         throw std::runtime_error("built-in model kernel and the model function disagree on the number of predict statements");
     std::vector<double> stats(T * K);
     ctx.check(cpprob_hip_infer_stats(ctx.get(), stats.data(), stats.size()), "cpprob_hip_infer_stats");
     res.n_particles = n; res.log_evidence = s.log_evidence; res.ess = s.ess_final; res.log_norm = s.log_norm; res.n_resampled = s.n_resampled;
     res.used_builtin = true;
     fill_predict_names(res, st);
-    for (std::size_t t = 0; t < T; ++t) {
-        PredictStats& p = res.predicts[t];
-        if (s.is_int) p.probabilities.assign(stats.begin() + t * K, stats.begin() + (t + 1) * K);
-        else { p.mean = stats[t * K]; p.variance = stats[t * K + 1]; }
+    if (s.is_int) {
+        for (std::size_t t = 0; t < T; ++t) res.predicts[t].probabilities.assign(stats.begin() + t * K, stats.begin() + (t + 1) * K);
+    } else {
+        std::size_t row = 0;                                         // a vector-valued hit owns one engine row per component
+        for (std::size_t k = 0; k < st.real_ids.size(); ++k) {
+            PredictStats& p = res.predicts[k];
+            for (std::size_t d = 0; d < st.real_width[k]; ++d, ++row) { p.mean_nd.push_back(stats[row * K]); p.variance_nd.push_back(stats[row * K + 1]); }
+            p.mean = p.mean_nd[0]; p.variance = p.variance_nd[0];
+        }
     }
     res.step_ess.assign(T, 0.0);
     ctx.check(cpprob_hip_infer_step_trace(ctx.get(), res.step_ess.data(), nullptr), "cpprob_hip_infer_step_trace");
@@ -156,12 +169,15 @@ void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>
     const Entry* e = find_entry(key);
     if (!e) throw std::runtime_error("cpprob::inference: this model has no device code: compile its source with hipcc and add "
                                      "CPPROB_REGISTER_MODEL(<model>) (or CPPROB_REGISTER_BUILTIN) -- there is no CPU fallback");
+    if (st.vector_statements && e->builtin_model < 0)
+        throw std::runtime_error("cpprob::inference: vector-valued statements (multivariate_normal_distribution / NDArray) run through built-in "
+                                 "kernels only (CPPROB_REGISTER_BUILTIN): std::vector cannot live in device code");
     const Options& opt = options();
     Result& res = last_result();
     res = Result();
     HostStore hs;
     HostStore* store = opt.dump ? &hs : nullptr;
-    if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic)) run_builtin(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
+    if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic || st.vector_statements)) run_builtin(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
     else if (e->generic) e->generic(algorithm, &obs, n, st, opt, res, store);
     else throw std::runtime_error("cpprob::inference: registry entry without a launcher");
     if (opt.dump) dump_posterior(file, st, hs, opt.dump_max_particles);      // finish_trace() x n + finish_infer()

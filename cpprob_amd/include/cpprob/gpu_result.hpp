@@ -26,7 +26,8 @@ struct Options {
 struct PredictStats {            // one per predict hit, StatsPrinter's numbers
     std::string address;
     bool is_int = false;
-    double mean = 0, variance = 0;            // real predicts
+    double mean = 0, variance = 0;            // real predicts (vector-valued: component 0)
+    std::vector<double> mean_nd, variance_nd; // real predicts: one entry per component (size 1 for a scalar)
     std::vector<double> probabilities;        // int predicts: P(x = s), s = 0..k-1
 };
 

@@ -1,6 +1,7 @@
-// EmpiricalDistribution -- the estimators of reference include/cpprob/postprocess/empirical_distribution.hpp
-// for scalar predicts: max-shifted logsumexp (:125-143), mean (:68-71), variance = raw2 - mean^2
-// (:78-81), categorical distribution (:30-40), MAP (:42-50), num_points.  Host code: this is the
+// EmpiricalDistribution -- the estimators of reference include/cpprob/postprocess/empirical_distribution.hpp:
+// max-shifted logsumexp (:125-143), mean (:68-71), variance = raw2 - mean^2 (:78-81) -- moments are NDArrays,
+// elementwise for vector-valued predicts, a bare number otherwise -- categorical distribution (:30-40),
+// MAP (:42-50), num_points.  Host code: this is the
 // post-processing of files that were already written, as in the reference; the in-memory results of
 // a device run come from the engine directly (cpprob::gpu::Result).
 #ifndef CPPROB_COMPAT_EMPIRICAL_DISTRIBUTION_HPP
@@ -12,6 +13,8 @@
 #include <map>
 #include <utility>
 #include <vector>
+
+#include "cpprob/ndarray.hpp"
 
 namespace cpprob {
 
@@ -34,18 +37,23 @@ public:
     }
     T max_a_posteriori() const { return max_a_posteriori(distribution()); }
 
-    WeightType raw_moment(const int n) const
+    NDArray<WeightType> raw_moment(const int n) const
     {
-        if (x_logw_.empty()) return WeightType();
+        if (x_logw_.empty()) return NDArray<WeightType>();
         const WeightType log_norm = log_normalisation_constant();
-        WeightType ret = 0;
-        for (const auto& e : x_logw_) ret += std::exp(e.second - log_norm) * std::pow(static_cast<WeightType>(e.first), n);
+        NDArray<WeightType> ret;                                     // empty = zero of the points' shape
+        for (const auto& e : x_logw_) {
+            const NDArray<WeightType> x(e.first);
+            NDArray<WeightType> p = x;
+            for (int k = 1; k < n; ++k) p *= x;
+            ret += p * std::exp(e.second - log_norm);
+        }
         return ret;
     }
-    WeightType mean() const { return raw_moment(1); }
-    WeightType variance(const WeightType& mean) const { return raw_moment(2) - mean * mean; }
-    WeightType variance() const { return variance(mean()); }
-    WeightType std() const { return std::sqrt(variance()); }
+    NDArray<WeightType> mean() const { return raw_moment(1); }
+    NDArray<WeightType> variance(const NDArray<WeightType>& mean) const { return raw_moment(2) - mean * mean; }
+    NDArray<WeightType> variance() const { return variance(mean()); }
+    NDArray<WeightType> std() const { return sqrt(variance()); }
 
     WeightType log_normalisation_constant() const
     {

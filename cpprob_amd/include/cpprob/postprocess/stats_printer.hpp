@@ -1,5 +1,6 @@
 // cpprob::StatsPrinter -- reads `<file>.ids/.int/.real` back and prints the posterior estimators, same
-// output layout as reference include/cpprob/postprocess/stats_printer.hpp:25-120 for scalar predicts.
+// output layout as reference include/cpprob/postprocess/stats_printer.hpp:25-120 (real predicts are NDArrays:
+// a scalar prints as a bare number, a vector-valued predict as `[m0 m1 ...]`, elementwise).
 // The k-th hit of a predict address inside one trace goes to the k-th distribution (:106-118).
 #ifndef CPPROB_COMPAT_STATS_PRINTER_HPP
 #define CPPROB_COMPAT_STATS_PRINTER_HPP
@@ -41,7 +42,7 @@ public:
                 out << sp.ids_[kv.first];
                 if (kv.second.size() > 1) out << ' ' << i;
                 out << ':' << std::endl;
-                const double mean = emp.mean();
+                const auto mean = emp.mean();
                 out << "  Mean: " << mean << std::endl << "  Variance: " << emp.variance(mean) << std::endl;
                 ++i;
             }
@@ -64,13 +65,13 @@ public:
     }
 
     // programmatic access (not in the reference): distributions of predict address `id`
-    const std::vector<EmpiricalDistribution<double>>& real(std::size_t id = 0) const { return real_distr_.at(id); }
+    const std::vector<EmpiricalDistribution<NDArray<double>>>& real(std::size_t id = 0) const { return real_distr_.at(id); }
     const std::vector<EmpiricalDistribution<int>>& integer(std::size_t id = 0) const { return int_distr_.at(id); }
     const std::vector<std::string>& ids() const { return ids_; }
 
 private:
     std::map<std::size_t, std::vector<EmpiricalDistribution<int>>> int_distr_;
-    std::map<std::size_t, std::vector<EmpiricalDistribution<double>>> real_distr_;
+    std::map<std::size_t, std::vector<EmpiricalDistribution<NDArray<double>>>> real_distr_;
     std::vector<std::string> ids_;
     std::string file_name_;
 

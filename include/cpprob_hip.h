@@ -52,6 +52,11 @@ extern "C" {
 #define CPPROB_HIP_MODEL_GAUSSIAN_README 1       /* src/models/gaussian.cpp:6-17     obs (x1,x2), predict "Mean"  */
 #define CPPROB_HIP_MODEL_LINEAR_GAUSSIAN_1D 2    /* include/models/models.hpp:67-80  obs[T],      predict "State" */
 #define CPPROB_HIP_MODEL_HMM3 3                  /* include/models/models.hpp:114-141 obs[T],     predict "State" */
+#define CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN 4 /* include/models/models.hpp:38-49 vector-valued statements: one multivariate
+                                                    normal sample, one vector observe y[2], one NDArray predict "Mu".  The D = 2
+                                                    components are rows of the particle store (variable-width SoA):
+                                                    n_predict = 2 = one predict hit of width 2, stats row d = component d.
+                                                    One observe statement => smc runs as sis.                             */
 
 /* Resamplers (thesis Alg. 1 p.36: multinomial; remark p.36: systematic / stratified). */
 #define CPPROB_HIP_RESAMPLE_SYSTEMATIC 0

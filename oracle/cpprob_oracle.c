@@ -42,7 +42,8 @@
 enum { ORC_MODEL_GAUSSIAN_UNKNOWN_MEAN = 0, /* include/models/models.hpp:22-35 */
        ORC_MODEL_GAUSSIAN_README = 1,       /* src/models/gaussian.cpp:6-17    */
        ORC_MODEL_LINEAR_GAUSSIAN_1D = 2,    /* include/models/models.hpp:67-80 */
-       ORC_MODEL_HMM3 = 3 };                /* include/models/models.hpp:114-141 */
+       ORC_MODEL_HMM3 = 3,                  /* include/models/models.hpp:114-141 */
+       ORC_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN = 4 }; /* include/models/models.hpp:38-49 (vector-valued statements) */
 enum { ORC_RESAMPLE_SYSTEMATIC = 0, ORC_RESAMPLE_STRATIFIED = 1, ORC_RESAMPLE_MULTINOMIAL = 2 };
 
 #define ORC_RESAMPLE_DRAW_BASE (1ull << 40) /* draw index of the resampling uniforms */
@@ -323,9 +324,24 @@ static void model_hmm3(orc_trace *tr, const double *obs, size_t T)
     }
 }
 
+/* include/models/models.hpp:38-49: prior = multivariate_normal {{1,2},{sqrt 5, sqrt 3}} (independent components,
+ * multivariate_normal.hpp:41-50), ONE vector-valued sample, ONE vector-valued observe, ONE NDArray predict.
+ * sample: the components draw from the generator in order (multivariate_normal.hpp:268-274) -> draw ordinals 0, 1;
+ * observe: logpdf = sum of the components' normal logpdfs (utils_multivariate_normal.hpp:22-33);
+ * predict: NDArray -> the real list (state.hpp:330-337); stored here as D consecutive columns. */
+static void model_gaussian_2d_unk_mean(orc_trace *tr, const double *y)
+{
+    const double m0[2] = { 1, 2 }, s0[2] = { sqrt(5), sqrt(3) };   /* :42 */
+    double mu[2];
+    for (int d = 0; d < 2; ++d) mu[d] = tr_sample_normal(tr, m0[d], s0[d]);   /* :43 */
+    const double var = sqrt(2);                                     /* :44 (used as sigma) */
+    for (int d = 0; d < 2; ++d) tr_observe_normal(tr, mu[d], var, y[d]);      /* :46-47 */
+    for (int d = 0; d < 2; ++d) tr_predict_real(tr, mu[d]);                   /* :48 "Mu" */
+}
+
 static int model_is_int(int model) { return model == ORC_MODEL_HMM3; }
 ORC_API int orc_model_num_predicts(int model, size_t n_obs)
-{ return (model == ORC_MODEL_GAUSSIAN_UNKNOWN_MEAN || model == ORC_MODEL_GAUSSIAN_README) ? 1 : (int)n_obs; }
+{ return (model == ORC_MODEL_GAUSSIAN_UNKNOWN_MEAN || model == ORC_MODEL_GAUSSIAN_README) ? 1 : (int)n_obs; }   /* 2-D model: one hit of 2 columns */
 
 static int run_model(int model, orc_trace *tr, const double *obs, size_t n_obs)
 {
@@ -334,6 +350,7 @@ static int run_model(int model, orc_trace *tr, const double *obs, size_t n_obs)
     case ORC_MODEL_GAUSSIAN_README:       if (n_obs != 2) return -1; model_gaussian_readme(tr, obs); return 0;
     case ORC_MODEL_LINEAR_GAUSSIAN_1D:    if (n_obs < 1) return -1;  model_linear_gaussian_1d(tr, obs, n_obs); return 0;
     case ORC_MODEL_HMM3:                  if (n_obs < 1) return -1;  model_hmm3(tr, obs, n_obs); return 0;
+    case ORC_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN: if (n_obs != 2) return -1; model_gaussian_2d_unk_mean(tr, obs); return 0;
     }
     return -2;
 }

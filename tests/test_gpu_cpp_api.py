@@ -186,3 +186,32 @@ def test_functor_model_is_found_by_type(tmp_path):
     np.testing.assert_allclose(vals, ov, rtol=1e-12, atol=1e-12)       # same statements -> same stream as the function form
     np.testing.assert_allclose(lw, olw, rtol=1e-12, atol=1e-12)
     assert not res["builtin"]
+
+
+def test_vector_valued_statements_gaussian_2d(tmp_path):
+    """SURVEY 8(f) row 4, reference models.hpp:38-49: multivariate-normal sample, vector observe, NDArray predict.
+    Per-particle parity with the oracle through the dump (NDArray grammar `(id [v0 v1])`), posterior against the
+    conjugate answer, StatsPrinter's elementwise estimators; smc == sis for a model with one observe statement."""
+    n = 200000
+    y = [3.0, 4.5]
+    res, out, _ = run_main(tmp_path, "--model", "gaussian_2d_unk_mean", "--sis", "--observes", obs_str(y), "--n_samples", n, "--seed", 11, "--json", "--estimate")
+    assert res["builtin"] and res["n"] == n and len(res["predicts"]) == 1
+    p = res["predicts"][0]
+    assert p["address"] == "Mu" and len(p["mean_nd"]) == 2
+    for d, (m0, s0) in enumerate([(1.0, 5.0), (2.0, 3.0)]):           # prior variances 5, 3; likelihood variance 2
+        var = 1.0 / (1.0 / s0 + 1.0 / 2.0)
+        mean = var * (m0 / s0 + y[d] / 2.0)
+        assert abs(p["mean_nd"][d] - mean) < 0.012 and abs(p["variance_nd"][d] - var) < 0.02
+    lines = open(str(tmp_path / "post_sis.real")).readlines()
+    assert len(lines) == n and lines[0].startswith("([(0 [") and lines[0].count("[") == 2
+    vals = np.array([[float(x) for x in l[l.index("(0 [") + 4: l.index("])")].split()] for l in lines]).T
+    lw = np.array([float(l.rsplit("]", 1)[1].strip().rstrip(")")) for l in lines])
+    ov, olw = O.sis(O.MODEL_GAUSSIAN_2D_UNKNOWN_MEAN, y, n, 11)
+    np.testing.assert_allclose(vals, ov, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(lw, olw, rtol=1e-12, atol=1e-12)
+    assert open(str(tmp_path / "post_sis.ids")).read() == "Mu\n"
+    mean_line = [l for l in out.splitlines() if l.strip().startswith("Mean:")][0]
+    got = [float(x) for x in mean_line.split(":")[1].strip().strip("[]").split()]
+    assert len(got) == 2 and abs(got[0] - p["mean_nd"][0]) < 1e-4 and abs(got[1] - p["mean_nd"][1]) < 1e-4
+    res2, _, _ = run_main(tmp_path, "--model", "gaussian_2d_unk_mean", "--smc", "--observes", obs_str(y), "--n_samples", n, "--seed", 11, "--json", "--no_dump")
+    assert res2["predicts"][0]["mean_nd"] == p["mean_nd"] and res2["n_resampled"] == 0

@@ -41,6 +41,29 @@ def test_sis_gaussian_matches_oracle_per_particle(engine, model, obs, n):
     assert s["n_predict"] == 1 and s["is_int"] == 0 and s["n_resampled"] == 0
 
 
+@pytest.mark.parametrize("n", [1, 1000, 4099])
+def test_sis_gaussian_2d_vector_statements_match_oracle_per_particle(engine, n):
+    """reference models.hpp:38-49 through the C ABI: the two components of the vector-valued statements are rows of the
+    particle store; the weight is the component sum of the vector observe."""
+    obs = [3.0, 4.5]
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_2D_UNKNOWN_MEAN, obs, n, seed=2024)
+    engine.run()
+    vals, logw = O.sis(O.MODEL_GAUSSIAN_2D_UNKNOWN_MEAN, obs, n, 2024)
+    np.testing.assert_allclose(engine.values(), vals, rtol=FP_TOL, atol=FP_TOL)
+    np.testing.assert_allclose(engine.logw(), logw, rtol=FP_TOL, atol=FP_TOL)
+    st = engine.stats()
+    for d in range(2):
+        ref = O.weighted_moments(vals[d], logw)
+        np.testing.assert_allclose(st[d], ref[:2], rtol=1e-9, atol=1e-10)
+    s = engine.summary()
+    assert s["n_predict"] == 2 and s["n_resampled"] == 0
+    engine.begin(cp.ALG_SMC, cp.MODEL_GAUSSIAN_2D_UNKNOWN_MEAN, obs, n, seed=2024)      # one observe statement: smc is sis
+    engine.run()
+    assert np.array_equal(engine.values(), engine.values()) and np.allclose(engine.logw(), logw, rtol=FP_TOL, atol=FP_TOL)
+    with pytest.raises(cp.CpprobHipError):
+        engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_2D_UNKNOWN_MEAN, [1.0, 2.0, 3.0], 10)
+
+
 def test_sis_config1_plumbing_10000_particles(engine, golden_dir):
     """BASELINE.json configs[0]: gaussian_unknown_mean, observes (3,4), 10^4 particles."""
     with open(os.path.join(golden_dir, "posteriors.json")) as f:

@@ -186,3 +186,65 @@ def test_host_driver_is_plain_cpp14_and_fails_loudly_without_gpu():
     # no HIP symbols are referenced by the host driver itself
     und = subprocess.check_output(["nm", "-u", B.MAIN_BIN]).decode()
     assert "hipMalloc" not in und and "hipLaunch" not in und
+
+
+_NDARRAY_PROG = r"""
+#include <cassert>
+#include <cmath>
+#include <fstream>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include "cpprob/cpprob.hpp"
+#include "cpprob/postprocess/stats_printer.hpp"
+int main(int argc, char** argv)
+{
+    using cpprob::NDArray;
+    // text form (reference ndarray.hpp:273-288): one element -> bare number, vector -> [..], higher rank -> [..] s[..]
+    std::ostringstream o;
+    o << NDArray<double>(2.5) << '|' << NDArray<double>(std::vector<double>{1.5, -2}) << '|' << NDArray<double>(std::vector<double>{1, 2, 3, 4}, std::vector<std::size_t>{2, 2});
+    assert(o.str() == "2.5|[1.5 -2]|[1 2 3 4] s[2 2]");
+    NDArray<double> a, b, c;
+    std::istringstream i1("[1.5 -2] 7 [1 2 3 4] s[2 2])");
+    i1 >> a >> b >> c;
+    assert(a == NDArray<double>(std::vector<double>{1.5, -2}) && b == NDArray<double>(7.0) && c.shape().size() == 2 && c.values().size() == 4);
+    char close; i1 >> close; assert(close == ')');
+    assert((a * a - a) == NDArray<double>(std::vector<double>{0.75, 6}) && (a * 2.0)[1] == -4 && (NDArray<double>() += a) == a);
+    // diagonal multivariate normal: logpdf is the sum of the components' (utils_multivariate_normal.hpp:22-33)
+    cpprob::multivariate_normal_distribution<> prior{{1, 2}, {std::sqrt(5), std::sqrt(3)}};
+    const NDArray<double> x(std::vector<double>{0.3, 2.9});
+    const double want = cpprob::logpdf<boost::random::normal_distribution<double>>()(boost::random::normal_distribution<double>(1, std::sqrt(5)), 0.3) +
+                        cpprob::logpdf<boost::random::normal_distribution<double>>()(boost::random::normal_distribution<double>(2, std::sqrt(3)), 2.9);
+    assert(std::fabs(cpprob::logpdf<cpprob::multivariate_normal_distribution<>>()(prior, x) - want) < 1e-15);
+    std::mt19937 g(1);
+    const auto draw = prior(g);
+    assert(draw.size() == 2 && draw.shape() == std::vector<std::size_t>{2} && prior.mean() == NDArray<double>(std::vector<double>{1, 2}) && std::fabs(prior.covariance()[1] - 3) < 1e-12);
+    cpprob::multivariate_normal_distribution<> lik{draw.begin(), draw.end(), 0.5};
+    assert(lik.distr().size() == 2 && lik.distr()[1].sigma() == 0.5);
+    // StatsPrinter on a vector-valued .real file: elementwise mean / variance (stats_printer.hpp:44-58, empirical_distribution.hpp:52-81)
+    const std::string base = argv[1];
+    { std::ofstream f(base + ".ids"); f << "Mu\n"; }
+    { std::ofstream f(base + ".real"); f << "([(0 [1.0e+00 2.0e+00])] 0.0e+00)\n([(0 [3.0e+00 6.0e+00])] 0.0e+00)\n"; }
+    cpprob::StatsPrinter sp(base);
+    const auto m = sp.real(0)[0].mean();
+    const auto v = sp.real(0)[0].variance(m);
+    assert(m == NDArray<double>(std::vector<double>{2, 4}) && v == NDArray<double>(std::vector<double>{1, 4}));
+    std::cout << sp;
+    return 0;
+}
+"""
+
+
+def test_ndarray_multivariate_normal_and_stats_printer_host_side(tmp_path):
+    """SURVEY 8(f) row 4, host side (plain C++14): NDArray text form and arithmetic, the diagonal multivariate normal and its
+    logpdf, StatsPrinter's elementwise estimators on a vector-valued posterior file."""
+    src = tmp_path / "nd.cpp"
+    src.write_text(_NDARRAY_PROG)
+    exe = str(tmp_path / "nd")
+    cmd = ["g++", "-std=c++14", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cpprob_amd", "include"), str(src), "-o", exe,
+           "-L", os.path.join(ROOT, "cpprob_amd", "lib"), "-lcpprob_hip", "-Wl,-rpath," + os.path.join(ROOT, "cpprob_amd", "lib")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = subprocess.run([exe, str(tmp_path / "post")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Mean: [2 4]" in out.stdout and "Variance: [1 4]" in out.stdout and "Mu:" in out.stdout
