@@ -239,6 +239,14 @@ void launch_step(cpprob_hip_ctx* c, int t)
     a.n_pop = (double)c->pop_n; a.ess_frac = c->cfg.ess_threshold; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
     a.store_logw = c->cfg.ess_threshold > 1.0 ? 0 : 1;      // ESS <= N always: threshold > 1 resamples after every step
     a.rs = c->rs;
+    {
+        // table-weight model + every step resamples + systematic + fused: the step kernel reads states instead of wrel
+        static const bool enabled = !(getenv("CPPROB_WREL_FROM_STATE") && getenv("CPPROB_WREL_FROM_STATE")[0] == '0');
+        // (pays from ~2.6e5 particles: below, the extra selects cost more than the halved traffic saves -- profiles/r01_ab_notes.md)
+        static const int min_tiles = getenv("CPPROB_WREL_FROM_STATE_MIN_TILES") ? atoi(getenv("CPPROB_WREL_FROM_STATE_MIN_TILES")) : 256;
+        a.wrel_from_state = (enabled && Model::kWeightTable > 0 && c->cfg.ess_threshold > 1.0 && c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC &&
+                             !c->step_protocol && c->nb >= min_tiles) ? 1 : 0;
+    }
     a.exchange = (c->exchange && c->step_protocol) ? 1 : 0; a.imm_l0 = c->imm_l0; a.imm_l1 = c->imm_l1; a.imm_col0 = c->imm_col0;
 #ifdef CPPROB_STAMPS
     static unsigned long long* d_st = nullptr;

@@ -100,7 +100,16 @@ __device__ __forceinline__ void store4(T* __restrict__ p, int64_t i, const T (&v
 template <class T>
 __device__ __forceinline__ void store4_stream(T* __restrict__ p, int64_t i, const T (&v)[kPPT])
 {
+#ifdef CPPROB_NT_STORES
+#pragma unroll
+    for (int q = 0; q < kPPT; q += 4) {
+        typename Vec4<T>::type x;
+        x[0] = v[q]; x[1] = v[q + 1]; x[2] = v[q + 2]; x[3] = v[q + 3];
+        __builtin_nontemporal_store(x, reinterpret_cast<typename Vec4<T>::type*>(p + i + q));
+    }
+#else
     store4(p, i, v);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,7 +481,14 @@ __device__ __forceinline__ int stage_window(const AncestorIn& in, AncestorLds& L
 // are spread (one heavy particle = one slot write), and there is no per-output search.
 __device__ __forceinline__ double g_of(double c, double inv, double u0) { return ceil(c * inv - u0); }
 
-__device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32_t (&anc)[kPPT], AncestorLds& L)
+// plain source of linear weights: the stored array
+struct WrelSource {
+    const double* wrel;
+    __device__ __forceinline__ void load(int64_t i0, double (&w)[kPPT]) const { load4(wrel, i0, w); }
+};
+
+template <class WS>
+__device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32_t (&anc)[kPPT], AncestorLds& L, const WS& ws)
 {
     const int tid = threadIdx.x;
     const double inv = in.inv_stepw, u0 = in.u0;
@@ -512,7 +528,7 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     // linear weights of the 4 sources this lane owns in source tile c
     auto load_w = [&](int c, double (&w)[kPPT]) {
         const int64_t i0 = (int64_t)c * kTile + (int64_t)tid * kPPT;
-        load4(in.wrel, i0, w);
+        ws.load(i0, w);
     };
     // the two tiles an output tile normally overlaps are fetched together (one memory round trip)
     double w_first[kPPT], w_second[kPPT];
@@ -569,11 +585,39 @@ __device__ __forceinline__ void ancestors_systematic(const AncestorIn& in, int32
     CPH_STAMP(7);
 }
 
+// Where the fused step kernel finds the linear weights of generation t-1: the stored array, or -- table-weight models
+// on an every-step resampling schedule, where every weight is e_tab[t-1][state] -- the stored STATES (4 bytes instead
+// of 8 read per source, and no wrel store at all between steps).
+template <class Model>
+struct WeightSource {
+    using V = typename Model::value_t;
+    static constexpr int K = Model::kWeightTable > 0 ? Model::kWeightTable : 1;
+    const double* wrel; const V* states; int64_t n; double e[K]; bool from_states;
+    __device__ __forceinline__ void load(int64_t i0, double (&w)[kPPT]) const
+    {
+        if (Model::kWeightTable > 0 && from_states) {
+            V st[kPPT];
+            load4(states, i0, st);
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) {
+                const int idx = Model::weight_index(st[k]);
+                double v = e[0];
+#pragma unroll
+                for (int s2 = 1; s2 < K; ++s2) v = idx == s2 ? e[s2] : v;
+                w[k] = (i0 + k < n) ? v : 0.0;                       // padding slots weigh nothing
+            }
+        } else {
+            load4(wrel, i0, w);
+        }
+    }
+};
+
 // Fast form for the fused step kernel: the tile-level CDF is in LDS (bc, bf), the slots were reset before the
 // caller's last barrier, and the linear weights of the lane's own-index source tile (w_own: tile blockIdx.x, the one an
 // output tile overlaps almost surely) were fetched at kernel entry.  The start indices of tiles b-1 .. b+2 are
 // evaluated together; anything farther away (very uneven masses) falls back to a search of the LDS table.
-__device__ __forceinline__ void ancestors_systematic_fused(const double* __restrict__ wrel, const double* s_bc, const double* s_bf, int nb,
+template <class WS>
+__device__ __forceinline__ void ancestors_systematic_fused(const WS& ws, const double* s_bc, const double* s_bf, int nb,
                                                             double u0, double inv, int n_valid_tile, const double (&w_own)[kPPT],
                                                             int32_t (&anc)[kPPT], AncestorLds& L)
 {
@@ -602,7 +646,7 @@ __device__ __forceinline__ void ancestors_systematic_fused(const double* __restr
             c_hi = lo;
         }
     }
-    auto load_w = [&](int c, double (&w)[kPPT]) { load4(wrel, (int64_t)c * kTile + (int64_t)tid * kPPT, w); };
+    auto load_w = [&](int c, double (&w)[kPPT]) { ws.load((int64_t)c * kTile + (int64_t)tid * kPPT, w); };
     int it = 0;
     auto process = [&](int c, double (&w)[kPPT]) {
         const double b0 = s_bc[c], b1 = s_bc[c + 1];
@@ -754,10 +798,10 @@ __device__ __forceinline__ void ancestors_stratified(const AncestorIn& in, int32
     }
 }
 
-template <int RS>
-__device__ __forceinline__ void find_ancestors(const AncestorIn& in, int32_t (&anc)[kPPT], AncestorLds& L)
+template <int RS, class WS>
+__device__ __forceinline__ void find_ancestors(const AncestorIn& in, int32_t (&anc)[kPPT], AncestorLds& L, const WS& ws)
 {
-    if (RS == RS_SYSTEMATIC) ancestors_systematic(in, anc, L);
+    if (RS == RS_SYSTEMATIC) ancestors_systematic(in, anc, L, ws);
     else ancestors_stratified(in, anc, L);
 }
 
@@ -790,7 +834,7 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(ResampleArgs a)
     in.n_valid_tile = rem < kTile ? (int)rem : kTile;
     in.id0 = 0; in.bc_in_lds = 0; in.guess = -1;
     int32_t anc[kPPT];
-    find_ancestors<RS>(in, anc, L);
+    find_ancestors<RS>(in, anc, L, WrelSource{a.wrel});
 #pragma unroll
     for (int k = 0; k < kPPT; ++k)
         if (l0 + k < a.n_out) a.anc[l0 + k] = anc[k];
@@ -901,6 +945,7 @@ struct StepArgs {
     double n_pop, ess_frac;   // FUSED: ESS test
     double* ess_trace; int32_t* resampled;
     int store_logw;           // 0: every step resamples (known on the host), so only the last step's log-weights are ever read
+    int wrel_from_state;      // table-weight model, every step resamples systematically: weights of generation t-1 = e_tab[t-1][state] (WeightSource)
     int64_t rs;               // row stride of values[] / anc[] (ld plus the immigrant annex)
     // exchange scope (exact global resampling over shards): outputs [imm_l0, imm_l1) of this shard descend from local
     // sources, the others from immigrants whose lineages sit in annex columns imm_col0, imm_col0 + 1, ... in output order
@@ -969,8 +1014,15 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
     double w_own[kPPT];
     lane_fill(w_own, 0.0);
+    WeightSource<Model> ws;
+    ws.wrel = a.wrel_prev; ws.states = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs; ws.n = a.n; ws.from_states = a.wrel_from_state != 0;
+    if (Model::kWeightTable > 0 && ws.from_states && t > 0) {
+        constexpr int K = WeightSource<Model>::K;
+        double ll[K], mref;
+        Model::weight_table(a.mp, t - 1, ll, ws.e, mref);
+    }
     if (FUSED && RS == RS_SYSTEMATIC && t > 0) {
-        load4(a.wrel_prev, j0, w_own);
+        ws.load(j0, w_own);
         int32_t neg[kPPT];
         lane_fill(neg, (int32_t)-1);
         store4(L.u.slot, (int64_t)tid * kPPT, neg);
@@ -1067,8 +1119,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
                 in.scale = a.ctrl->scale; in.cdf_lo = a.ctrl->cdf_lo; in.inv_stepw = a.ctrl->inv_global; in.g_end = a.ctrl->g_end;
                 in.gj_tile0 = a.pid0 + (uint64_t)blockIdx.x * kTile; in.n_total_out = (uint64_t)a.n_pop; in.guess = -1;
             }
-            if (FUSED && RS == RS_SYSTEMATIC) ancestors_systematic_fused(a.wrel_prev, s_bc, s_bf, a.nb, u0, inv_stepw, in.n_valid_tile, w_own, anc, L);
-            else find_ancestors<RS>(in, anc, L);
+            if (FUSED && RS == RS_SYSTEMATIC) ancestors_systematic_fused(ws, s_bc, s_bf, a.nb, u0, inv_stepw, in.n_valid_tile, w_own, anc, L);
+            else find_ancestors<RS>(in, anc, L, ws);
         }
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) lw[k] = lwa;          // equal weights after resampling (the shard's mass share)
@@ -1123,7 +1175,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     }
     CPH_STAMP(10);
     if (a.store_logw || t + 1 == a.T) store4_stream(a.logw_next, j0, lw);
-    store4_stream(a.wrel_next, j0, e);
+    if (!a.wrel_from_state || t + 1 == a.T) store4_stream(a.wrel_next, j0, e);   // otherwise the next step reads the states
     if (FUSED && blockIdx.x == 0 && tid == 0 && t + 1 < a.T) {              // systematic offset of the resampling before step t+1
         const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(t + 1));
         a.ctrl->u0_pp[(t + 1) & 1] = u01_53(r.x, r.y);
