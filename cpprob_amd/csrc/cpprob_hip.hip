@@ -222,7 +222,8 @@ void launch_step_impl(cpprob_hip_ctx* c, StepArgs<Model>& a)
 // fused = the step kernel normalises the previous generation itself (no scan_partials launch between steps)
 bool step_is_fused(const cpprob_hip_ctx* c)
 {
-    return c->nb <= kFuseMaxTiles && c->cfg.resampler != CPPROB_HIP_RESAMPLE_MULTINOMIAL && !c->step_protocol;
+    static const int max_tiles = getenv("CPPROB_FUSE_MAX_TILES") ? std::min(atoi(getenv("CPPROB_FUSE_MAX_TILES")), (int)kFuseMaxTiles) : kFuseMaxTiles;
+    return c->nb <= max_tiles && c->cfg.resampler != CPPROB_HIP_RESAMPLE_MULTINOMIAL && !c->step_protocol;
 }
 
 template <class Model>

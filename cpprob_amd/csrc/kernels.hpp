@@ -929,8 +929,10 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
 // order, so they take identical decisions; workgroup 0 records them in ctrl for the host.  This
 // removes one launch + one kernel boundary (~5 us) per step.  FUSED = false reads what
 // scan_partials_kernel left in ctrl / bc / bf (large populations, sharded runs).
+// The LDS copy of the tile-level CDF (16 B per tile) caps the resident workgroups per CU: measured crossover against the
+// un-fused form at ~1.7e6 particles (profiles/r01_ab_notes.md), hence 1664 tiles rather than the 2048 the prologue could hold.
 // ---------------------------------------------------------------------------------------------
-constexpr int kFuseMaxTiles = 2048;
+constexpr int kFuseMaxTiles = 1664;
 
 template <class Model>
 struct StepArgs {
@@ -1063,9 +1065,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
                 S += rs[i];
                 Q += rq[i] * (e * e);
             }
-            Q = block_sum(Q, s_scr + kWaves);
             double W;
-            double run = block_excl_scan(S, L.scr[0], &W);
+            double run = block_sum_and_excl_scan(Q, S, s_scr + kWaves, &W);      // one barrier for both
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
                 if (c0 + i < a.nb) { s_bc[c0 + i] = run; s_bf[c0 + i] = ev[i]; }

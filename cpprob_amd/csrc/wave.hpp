@@ -161,4 +161,32 @@ __device__ __forceinline__ double block_excl_scan(double v, double* scratch, dou
     return off + excl;
 }
 
+// One workgroup sum and one exclusive scan behind a single barrier (same operation order as block_sum /
+// block_excl_scan: bit-identical results).  scratch holds 2*NWAVES doubles.
+template <int NWAVES = kWaves>
+__device__ __forceinline__ double block_sum_and_excl_scan(double& sum_v, double scan_v, double* scratch, double* total)
+{
+    const double ws = wave_sum(sum_v);
+    const double incl = wave_incl_scan(scan_v);
+    if (lane_id() == 0) scratch[wave_id()] = ws;
+    if (lane_id() == kWave - 1) scratch[NWAVES + wave_id()] = incl;
+    __syncthreads();
+    double r = scratch[0];
+#pragma unroll
+    for (int w = 1; w < NWAVES; ++w) r += scratch[w];
+    sum_v = r;
+    double off = 0.0, tot = 0.0;
+    const int wv = wave_id();
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) {
+        const double s = scratch[NWAVES + w];
+        if (w < wv) off += s;
+        tot += s;
+    }
+    *total = tot;
+    double excl = dpp_or<0x138 /* wave_shr:1 */>(incl, 0.0);
+    if (lane_id() == 0) excl = 0.0;
+    return off + excl;
+}
+
 }  // namespace cph
