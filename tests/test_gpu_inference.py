@@ -165,6 +165,36 @@ def test_smc_hmm_matches_oracle(engine, golden_dir, resampler, ess):
     _compare_smc(engine, cp.MODEL_HMM3, obs, 30000, 11, resampler, ess)
 
 
+@pytest.mark.parametrize("n", [300_000, 1_200_000, 2_000_000])
+def test_smc_hmm_matches_oracle_on_the_weights_from_states_paths(engine, golden_dir, n):
+    """From 256 tiles up, table-weight models on an every-step schedule derive the previous generation's weights from the
+    stored states (no wrel traffic between steps): fused prologue with 2 / 8 partials per lane, and the un-fused form
+    above 1664 tiles.  Per-particle parity with the oracle: bit-identical states and ancestors up to the first CDF-boundary
+    flip (the parallel scan rounds differently from the oracle's sequential sum: ~1e-10 per boundary, ~2e7 boundaries);
+    the flip itself moves a handful of offspring to the neighbouring source, after which systematic resampling -- one
+    shared offset -- legitimately diverges and only the estimators are compared."""
+    obs = _obs(golden_dir, "hmm16")
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=11, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=2.0)
+    engine.run()
+    ref = O.smc(cp.MODEL_HMM3, obs, n, 11, cp.RESAMPLE_SYSTEMATIC, 2.0)
+    vals, anc = engine.values(), engine.ancestors()
+    T = len(obs)
+    differs = [t for t in range(1, T) if not np.array_equal(anc[t], ref["anc"][t])]
+    first = differs[0] if differs else T
+    assert np.array_equal(vals[:first], ref["hist"][:first]) and np.array_equal(anc[1:first], ref["anc"][1:first])
+    if first < T:
+        d = anc[first].astype(np.int64) - ref["anc"][first].astype(np.int64)
+        assert np.abs(d).max() == 1 and np.count_nonzero(d) <= 8  # a boundary flip: a few offspring moved to the adjacent source
+    gess, gres = engine.step_trace()
+    assert np.array_equal(gres, ref["resampled"])
+    np.testing.assert_allclose(gess[:first], ref["ess"][:first], rtol=1e-9)
+    np.testing.assert_allclose(gess, ref["ess"], rtol=2e-3)
+    s = engine.summary()
+    assert abs(s["log_evidence"] - ref["log_z"]) < (1e-9 if first == T else 1e-2)       # diverged runs: two draws of the estimator
+    np.testing.assert_allclose(engine.stats(), O.smoothing(ref["hist"], ref["anc"], ref["logw"]), atol=1e-12 if first == T else 5e-3)
+    np.testing.assert_allclose(engine.stats(), O.smoothing(vals, anc, engine.logw()), rtol=1e-9, atol=1e-11)
+
+
 @pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_MULTINOMIAL])
 @pytest.mark.parametrize("ess", [2.0, 0.5])
 def test_smc_lgssm_matches_oracle(engine, golden_dir, resampler, ess):
