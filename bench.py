@@ -81,6 +81,7 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchang
     from cpprob_amd import distributed as D
 
     coll = D.TorchCollective(eng) if ((world > 1 and not island) or exchange) else None
+    batch = D.IslandBatch(eng, min(max(steps, warmup, 1), 64)) if (world > 1 and island) else None
     bufs = None
     if coll is not None:
         bufs = (torch.zeros(4, dtype=torch.float64, device=device), torch.zeros(3 * world, dtype=torch.float64, device=device), None)
@@ -90,7 +91,8 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchang
             st, _ = D.run_exchange(eng, coll, i, counters)   # per step: all-gather of 3 doubles + one all-to-all-v of migrating lineages
             return (st,)
         if world > 1 and island:
-            return D.run_islands(eng, i, device)          # no data-path collective; one all-gather of summaries per run
+            batch.run(i % batch.depth, i)                 # no data-path collective; one async all-gather of summaries per run
+            return None
         if world > 1:
             st, _ = D.run_joint(eng, coll, i, bufs)       # one RCCL all-gather of 3 doubles per rank per step
             return (st,)
@@ -112,6 +114,8 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchang
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if batch is not None:
+        last = batch.results((first_index + warmup + steps - 1) % batch.depth)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -239,7 +243,7 @@ def main():
     if exchange:
         collective = "all_gather(3 doubles/rank) + all_to_all_v(migrating lineages) per step; %d records sent by rank 0 in the last run" % moved.get("records_sent", 0)
     else:
-        collective = "none" if world == 1 else ("all_gather(1+T*K doubles/rank) once per run" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
+        collective = "none" if world == 1 else ("all_gather(4+T*K doubles/rank) once per run, asynchronous (no host synchronisation between runs)" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
 
     # profiled pass: same K steps with HIP events around every launch on the engine's stream
     # (per-shard kernels only: on several GPUs each rank profiles its own shard as an island)

@@ -18,7 +18,7 @@ KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", 
 SYMBOLS = [
     "cpprob_hip_abi_version", "cpprob_hip_device_count", "cpprob_hip_create", "cpprob_hip_destroy", "cpprob_hip_last_error",
     "cpprob_hip_stream", "cpprob_hip_sync", "cpprob_hip_infer_begin", "cpprob_hip_infer_run", "cpprob_hip_infer_summary",
-    "cpprob_hip_infer_stats", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
+    "cpprob_hip_infer_stats", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
     "cpprob_hip_smc_finish", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
@@ -70,6 +70,7 @@ def load_library(path=None):
         "cpprob_hip_infer_run": (C.c_int, [vp, u64]),
         "cpprob_hip_infer_summary": (C.c_int, [vp, C.POINTER(Summary)]),
         "cpprob_hip_infer_stats": (C.c_int, [vp, C.POINTER(dbl), sz]),
+        "cpprob_hip_infer_results_device": (C.c_int, [vp, vp, sz]),
         "cpprob_hip_infer_step_trace": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(i32)]),
         "cpprob_hip_copy_values": (C.c_int, [vp, vp, sz]),
         "cpprob_hip_copy_ancestors": (C.c_int, [vp, vp, sz]),
@@ -188,6 +189,10 @@ class Engine:
         out = np.zeros((self.T, self.K))
         self._chk(self.L.cpprob_hip_infer_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size))
         return out
+
+    def results_device(self, out):
+        """{log_evidence, ess, log_norm, max_logw, stats...} of the enqueued run into a device tensor; no host sync."""
+        self._chk(self.L.cpprob_hip_infer_results_device(self.h, _dptr(out), out.numel()))
 
     def step_trace(self):
         ess = np.zeros(self.T)

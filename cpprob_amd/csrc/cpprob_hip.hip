@@ -741,6 +741,19 @@ int cpprob_hip_infer_stats(cpprob_hip_ctx* c, double* h_stats, size_t n_doubles)
     return 0;
 }
 
+int cpprob_hip_infer_results_device(cpprob_hip_ctx* c, double* d_out, size_t n_doubles)
+{
+    if (!c || !d_out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    const size_t need = 4 + (size_t)c->T * c->K;
+    if (n_doubles < need) return fail(c, CPPROB_HIP_EINVAL, "d_out too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int ns = c->T * c->K;
+    hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, c->d_ctrl, c->d_stats, ns, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 int cpprob_hip_infer_step_trace(cpprob_hip_ctx* c, double* h_ess, int32_t* h_resampled)
 {
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");

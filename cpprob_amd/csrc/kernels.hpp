@@ -1318,6 +1318,14 @@ __global__ void annex_lineages_kernel(const V* __restrict__ rec, int64_t count, 
     anc[(int64_t)t * rs + col] = (int32_t)col;
 }
 
+// {log_evidence, ess, log_norm, max_logw, stats[n_stats]} of the finished run into one device buffer
+__global__ void pack_results_kernel(const StepCtrl* __restrict__ ctrl, const double* __restrict__ stats, int n_stats, double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { out[0] = ctrl->log_z; out[1] = ctrl->ess; out[2] = ctrl->M + log(ctrl->W); out[3] = ctrl->M; }
+    if (i < n_stats) out[4 + i] = stats[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Elementwise building blocks (unit-parity surface)
 // ---------------------------------------------------------------------------------------------

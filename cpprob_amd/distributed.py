@@ -134,6 +134,51 @@ def run_islands(engine, run_index=0, device=None):
     return out, lz, iess
 
 
+class IslandBatch:
+    """Island-scope runs back to back with NO host synchronisation between them: every run leaves
+    {log_evidence, ess, log_norm, max_logw, stats} in a device slot (cpprob_hip_infer_results_device) and the slot is
+    all-gathered over the ranks by RCCL on the engine's stream; the host looks at a slot only when asked (results()).
+    This is what keeps N GPUs at N times one GPU's rate: the only inter-GPU traffic is 8 * (4 + T*K) bytes per rank per
+    run, and nobody waits for it."""
+
+    def __init__(self, engine, depth):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.engine = torch, dist, engine
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        dev = torch.device("cuda", engine.device)
+        self.width = 4 + engine.T * engine.K
+        self.depth = int(depth)
+        self.packed = torch.zeros((self.depth, self.width), dtype=torch.float64, device=dev)
+        self.gathered = torch.zeros((self.depth, self.world, self.width), dtype=torch.float64, device=dev)
+        self.stream = torch.cuda.ExternalStream(engine.stream_ptr, device=dev)
+
+    def run(self, slot, run_index):
+        e, torch = self.engine, self.torch
+        e.run(run_index)
+        e.results_device(self.packed[slot])
+        with torch.cuda.stream(self.stream):
+            if self.world == 1:
+                self.gathered[slot, 0].copy_(self.packed[slot])
+            elif _host_collectives():          # test hook (gloo): through host memory, synchronising
+                mine = self.packed[slot].cpu()
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                self.dist.all_gather(parts, mine)
+                self.gathered[slot].copy_(torch.stack(parts).to(self.gathered.device))
+            else:
+                self.dist.all_gather_into_tensor(self.gathered[slot].view(-1), self.packed[slot])
+
+    def results(self, slot):
+        """Synchronises and combines the islands of one slot: (stats[T, K], log_evidence, island_ess)."""
+        self.engine.sync()
+        self.torch.cuda.synchronize()
+        g = self.gathered[slot].cpu().numpy()
+        e = self.engine
+        out, lz, _, iess = combine_islands(g[:, 0], g[:, 4:].reshape(self.world, e.T, e.K), e.is_int)
+        return out, lz, iess
+
+
 # ---- joint population (GLOBAL scope) ------------------------------------------------------------
 
 class TorchCollective:

@@ -137,6 +137,11 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* ctx, const cpprob_hip_config* cfg, co
 int cpprob_hip_infer_run(cpprob_hip_ctx* ctx, uint64_t run_index);
 int cpprob_hip_infer_summary(cpprob_hip_ctx* ctx, cpprob_hip_summary* out);
 int cpprob_hip_infer_stats(cpprob_hip_ctx* ctx, double* h_stats, size_t n_doubles);
+/* The same results left ON THE DEVICE, stream-ordered, no host synchronisation: d_out (device, caller-owned, at least
+ * 4 + n_predict * stats_per_predict doubles) receives {log_evidence, ess_final, log_norm, max_logw, stats...} of the
+ * run that was just enqueued.  For callers that feed them to a collective (multi-GPU island combine) or batch many
+ * runs before looking at any. */
+int cpprob_hip_infer_results_device(cpprob_hip_ctx* ctx, double* d_out, size_t n_doubles);
 /* Per-step diagnostics of the last run: ESS after weighting step t and whether resampling
  * followed it.  Arrays of n_predict entries (either may be NULL). */
 int cpprob_hip_infer_step_trace(cpprob_hip_ctx* ctx, double* h_ess, int32_t* h_resampled);

@@ -455,6 +455,30 @@ def test_exchange_scope_world1_is_bit_identical_to_run(engine, golden_dir):
         engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, resampler=cp.RESAMPLE_MULTINOMIAL, scope=cp.SCOPE_EXCHANGE)
 
 
+def test_results_device_and_island_batch_match_the_host_read_out(engine, golden_dir):
+    """cpprob_hip_infer_results_device leaves summary + stats on the device without a host sync; IslandBatch chains
+    runs on it (world = 1 here: the all-gather degenerates to a copy)."""
+    import torch
+    from cpprob_amd import distributed as D
+    obs = _obs(golden_dir, "hmm16")
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 50000, seed=3, ess_threshold=0.5, scope=cp.SCOPE_ISLAND)
+    out = torch.zeros(4 + 16 * 3, dtype=torch.float64, device="cuda")
+    engine.run(5)
+    engine.results_device(out)
+    engine.sync()
+    s, st = engine.summary(), engine.stats()
+    h = out.cpu().numpy()
+    assert h[0] == s["log_evidence"] and h[1] == s["ess_final"] and abs(h[2] - s["log_norm"]) < 1e-14 and h[3] == s["max_logw"]
+    assert np.array_equal(h[4:].reshape(16, 3), st)
+    batch = D.IslandBatch(engine, 4)
+    for i in range(6):
+        batch.run(i % 4, i)
+    stats, lz, iess = batch.results(5 % 4)
+    assert np.array_equal(stats, st) and abs(lz - s["log_evidence"]) < 1e-14 and iess == 1.0
+    with pytest.raises(cp.CpprobHipError):
+        engine.results_device(torch.zeros(3, dtype=torch.float64, device="cuda"))
+
+
 def test_step_protocol_world1_is_bit_identical_to_run(engine, golden_dir):
     import torch
     from cpprob_amd import distributed as D
