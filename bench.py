@@ -85,6 +85,10 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchang
     bufs = None
     if coll is not None:
         bufs = (torch.zeros(4, dtype=torch.float64, device=device), torch.zeros(3 * world, dtype=torch.float64, device=device), None)
+    jslots = None
+    if coll is not None and not exchange:
+        jdepth = min(max(steps, warmup, 1), 64)
+        jslots = torch.zeros((jdepth, 4 + eng.T * eng.K), dtype=torch.float64, device=device)
 
     def one(i):
         if exchange:
@@ -94,8 +98,8 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchang
             batch.run(i % batch.depth, i)                 # no data-path collective; one async all-gather of summaries per run
             return None
         if world > 1:
-            st, _ = D.run_joint(eng, coll, i, bufs)       # one RCCL all-gather of 3 doubles per rank per step
-            return (st,)
+            D.run_joint(eng, coll, i, bufs, slot=jslots[i % jslots.shape[0]])   # one RCCL all-gather of 3 doubles per rank per step; no host sync
+            return None
         eng.run(i)
         return None
 
@@ -116,6 +120,9 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchang
     dt = time.perf_counter() - t0
     if batch is not None:
         last = batch.results((first_index + warmup + steps - 1) % batch.depth)
+    elif jslots is not None:
+        st, js = D.joint_results(eng, jslots[(first_index + warmup + steps - 1) % jslots.shape[0]])
+        last = (st, js["log_evidence"], 0.0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -266,7 +266,7 @@ def normalise_joint_stats(raw, log_norm, max_logw, is_int):
     return np.stack([mean, raw[:, 1] / W - mean * mean], axis=1)      # raw_moment(2) - mean^2, empirical_distribution.hpp:78-81
 
 
-def run_joint(engine, collective, run_index=0, buffers=None):
+def run_joint(engine, collective, run_index=0, buffers=None, slot=None):
     """One run of a joint population sharded over `collective.world` ranks (engine begun with
     scope=SCOPE_GLOBAL, n_global = sum of shards).  Returns (stats[T, K], summary dict)."""
     import torch
@@ -283,10 +283,27 @@ def run_joint(engine, collective, run_index=0, buffers=None):
         collective.all_gather(local, allt)
         engine.step_end(t, allt, world, rank)
     engine.finish()
+    if slot is not None:
+        # no host synchronisation: {log_evidence, ess, log_norm, max_logw, raw sums...} stay on the device; the sums are
+        # all-reduced in place on the engine's stream; joint_results() reads the slot later
+        engine.results_device(slot)
+        collective.all_reduce_sum(slot[4:])
+        return None
     s = engine.summary()
     raw = torch.from_numpy(engine.stats()).to(dev)
     collective.all_reduce_sum(raw)
     stats = normalise_joint_stats(raw.cpu().numpy(), s["log_norm"], s["max_logw"], engine.is_int)
+    return stats, s
+
+
+def joint_results(engine, slot):
+    """Host read-out of a slot left by run_joint(..., slot=...): (stats[T, K], summary dict)."""
+    import torch
+    engine.sync()
+    torch.cuda.synchronize()
+    h = slot.cpu().numpy()
+    s = {"log_evidence": float(h[0]), "ess_final": float(h[1]), "log_norm": float(h[2]), "max_logw": float(h[3])}
+    stats = normalise_joint_stats(h[4:].reshape(engine.T, engine.K), s["log_norm"], s["max_logw"], engine.is_int)
     return stats, s
 
 

@@ -492,6 +492,13 @@ def test_step_protocol_world1_is_bit_identical_to_run(engine, golden_dir):
     assert np.array_equal(engine.values(), ref_vals)
     np.testing.assert_allclose(stats, ref_stats, rtol=1e-13, atol=1e-15)
     assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
+    # the same with the results left on the device (no host synchronisation inside run_joint)
+    import torch
+    slot = torch.zeros(4 + engine.T * engine.K, dtype=torch.float64, device="cuda")
+    assert D.run_joint(engine, coll, slot=slot) is None
+    stats2, s2 = D.joint_results(engine, slot)
+    np.testing.assert_allclose(stats2, stats, rtol=1e-15, atol=0)
+    assert s2["log_evidence"] == s["log_evidence"]
 
 
 @pytest.mark.parametrize("world", [2, 4])
