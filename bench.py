@@ -61,13 +61,13 @@ def workload_spec(name, golden):
     import cpprob_amd as cp
     z = np.load(golden)
     if name == "hmm16_smc":
-        return dict(alg=cp.ALG_SMC, model=cp.MODEL_HMM3, obs=z["hmm16"], ess=2.0, bytes_key="hmm", exact=z["hmm16_smooth"],
+        return dict(alg=cp.ALG_SMC, model=cp.MODEL_HMM3, obs=z["hmm16"], ess=2.0, bytes_key="hmm", exact=z["hmm16_smooth"], exact_logz=float(z["hmm16_logz"]),
                     desc="3-state HMM (models.hpp:114-141) SMC, T=16, systematic resampling every step")
     if name == "hmm128_smc_ess":
-        return dict(alg=cp.ALG_SMC, model=cp.MODEL_HMM3, obs=z["hmm128"], ess=0.5, bytes_key="hmm", exact=z["hmm128_smooth"],
+        return dict(alg=cp.ALG_SMC, model=cp.MODEL_HMM3, obs=z["hmm128"], ess=0.5, bytes_key="hmm", exact=z["hmm128_smooth"], exact_logz=float(z["hmm128_logz"]),
                     desc="3-state HMM SMC, T=128, resample when ESS < N/2")
     if name == "lgssm100_smc":
-        return dict(alg=cp.ALG_SMC, model=cp.MODEL_LINEAR_GAUSSIAN_1D, obs=z["lgssm100"], ess=0.5, bytes_key="lgssm",
+        return dict(alg=cp.ALG_SMC, model=cp.MODEL_LINEAR_GAUSSIAN_1D, obs=z["lgssm100"], ess=0.5, bytes_key="lgssm", exact_logz=float(z["lgssm100_logz"]),
                     exact=np.stack([z["lgssm100_smooth_mean"], z["lgssm100_smooth_var"]], 1),
                     desc="linear_gaussian_1d<100> (models.hpp:67-80) SMC, resample when ESS < N/2")
     return dict(alg=cp.ALG_SIS, model=cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, obs=np.array([3.0, 4.0]), ess=2.0, bytes_key="gaussian_sis",
@@ -295,6 +295,18 @@ def main():
         "roofline": roofline,
         "posterior_max_abs_err_vs_exact": err, "log_evidence": summ["log_evidence"], "n_resampled": summ["n_resampled"],
     }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # error bars: five run seeds of the headline configuration against the exact posterior
+        eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
+        errs, lzs = [], []
+        for k in range(5):
+            eng.run(50_000 + k)
+            errs.append(float(np.abs(eng.stats() - spec["exact"]).max()))
+            lzs.append(eng.summary()["log_evidence"])
+        out["five_seeds"] = {"posterior_max_abs_err_vs_exact": {"mean": float(np.mean(errs)), "sd": float(np.std(errs, ddof=1)), "max": float(np.max(errs))},
+                             "log_evidence": {"mean": float(np.mean(lzs)), "sd": float(np.std(lzs, ddof=1))},
+                             "exact_log_evidence": spec.get("exact_logz")}
 
     if rank == 0 and world == 1 and not args.no_extras and spec["alg"] == cp.ALG_SMC and not exchange:
         # secondary: the same runs with several contexts in flight.  One run is a dependent chain of ~19 launches whose
