@@ -36,6 +36,7 @@ struct cpprob_hip_ctx {
     int K = 0;              // stats per predict
     int64_t n = 0, ld = 0;
     int64_t rs = 0;         // row stride of values[] / anc[]: ld + annex_cap
+    size_t ssz = 8;         // bytes per element of values[] (Model::store_t; may be narrower than the model's value type)
     int nb = 0;             // tiles
     int smooth_grid = 0;
     ModelParams mp{};
@@ -199,7 +200,7 @@ void launch_sis(cpprob_hip_ctx* c)
 {
     SisArgs<Model> a{};
     a.mp = c->mp; a.obs = c->d_obs; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
-    a.values = static_cast<typename Model::value_t*>(c->d_values); a.logw = c->d_logw[0]; a.wrel = c->d_wrel[0]; a.part = c->d_part[0];
+    a.values = static_cast<typename Model::store_t*>(c->d_values); a.logw = c->d_logw[0]; a.wrel = c->d_wrel[0]; a.part = c->d_part[0];
     c->cur_part = 0;
     ProfScope ps(c, 4);
     hipLaunchKernelGGL(sis_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
@@ -232,7 +233,7 @@ void launch_step(cpprob_hip_ctx* c, int t)
     StepArgs<Model> a{};
     a.mp = c->mp; a.obs = c->d_obs; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.seed = c->run_seed;
     a.pid0 = c->cfg.particle_offset;
-    a.values = static_cast<typename Model::value_t*>(c->d_values); a.anc = c->d_anc;
+    a.values = static_cast<typename Model::store_t*>(c->d_values); a.anc = c->d_anc;
     a.logw_prev = c->d_logw[c->cur]; a.logw_next = c->d_logw[c->cur ^ 1];
     a.wrel_prev = c->d_wrel[c->cur]; a.wrel_next = c->d_wrel[c->cur ^ 1];
     a.part_prev = c->d_part[c->cur_part]; a.part = c->d_part[t == 0 ? c->cur_part : c->cur_part ^ 1];
@@ -311,7 +312,7 @@ template <class Model>
 void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
 {
     SmoothArgs<Model> a{};
-    a.values = static_cast<const typename Model::value_t*>(c->d_values); a.anc = c->d_anc; a.wrel = c->d_wrel[c->cur]; a.bf = c->d_bf; a.ctrl = c->d_ctrl;
+    a.values = static_cast<const typename Model::store_t*>(c->d_values); a.anc = c->d_anc; a.wrel = c->d_wrel[c->cur]; a.bf = c->d_bf; a.ctrl = c->d_ctrl;
     a.resampled = c->d_resampled; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs;
     a.identity = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
     a.stats_part = c->d_stats_part;
@@ -455,13 +456,15 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     c->exchange = exchange;
     // exchange scope: room for immigrant lineages next to every row (grown on demand by cpprob_hip_exchange_commit)
     const int64_t annex0 = exchange ? std::max<int64_t>(c->annex_cap, std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile)) : 0;
+    c->ssz = 8;
+    dispatch_model(c, [&](auto m) { c->ssz = sizeof(typename decltype(m)::store_t); });
     const bool realloc = (size_t)c->ld > c->cap_particles || c->T > c->cap_T || c->is_int != c->cap_int || (multinomial && !c->cap_multinomial) || !c->d_values ||
                          annex0 != c->annex_cap;
     if (realloc) {
         free_run_buffers(c);
         c->annex_cap = annex0;
         const size_t ld = (size_t)c->ld, T = (size_t)c->T, rs = ld + (size_t)annex0;
-        const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
+        const size_t vsz = c->ssz;
         HIP_TRY(c, hipMalloc(&c->d_logw[0], ld * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_logw[1], ld * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_wrel[0], ld * sizeof(double)));
@@ -662,10 +665,11 @@ int cpprob_hip_exchange_pack(cpprob_hip_ctx* c, int32_t t, void* d_send)
         off += p.send_cnt[r];
     }
     const int len = t + 1;
-    if (c->is_int) hipLaunchKernelGGL(extract_lineages_kernel<int32_t>, GRID1(p.n_send), static_cast<const int32_t*>(c->d_values), c->d_anc, c->rs, c->d_resampled, len,
-                                      c->d_send_src, (int64_t)p.n_send, static_cast<int32_t*>(d_send));
-    else hipLaunchKernelGGL(extract_lineages_kernel<double>, GRID1(p.n_send), static_cast<const double*>(c->d_values), c->d_anc, c->rs, c->d_resampled, len,
-                            c->d_send_src, (int64_t)p.n_send, static_cast<double*>(d_send));
+    dispatch_model(c, [&](auto m) {
+        using S = typename decltype(m)::store_t; using V = typename decltype(m)::value_t;
+        hipLaunchKernelGGL((extract_lineages_kernel<S, V>), GRID1(p.n_send), static_cast<const S*>(c->d_values), c->d_anc, c->rs, c->d_resampled, len,
+                           c->d_send_src, (int64_t)p.n_send, static_cast<V*>(d_send));
+    });
     HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -674,7 +678,7 @@ int cpprob_hip_exchange_pack(cpprob_hip_ctx* c, int32_t t, void* d_send)
 static int grow_annex(cpprob_hip_ctx* c, int64_t need)
 {
     int64_t cap = std::max<int64_t>(2 * c->annex_cap, (need + kTile - 1) / kTile * kTile);
-    const size_t T = (size_t)c->cap_T, vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
+    const size_t T = (size_t)c->cap_T, vsz = c->ssz;
     const size_t ldc = c->cap_particles, rs_new = (size_t)c->ld + (size_t)cap, rs_old = (size_t)c->rs;
     void* nv = nullptr; int32_t* na = nullptr;
     HIP_TRY(c, hipMalloc(&nv, T * (ldc + (size_t)cap) * vsz));
@@ -703,10 +707,11 @@ int cpprob_hip_exchange_commit(cpprob_hip_ctx* c, int32_t t, const void* d_recv)
     if (c->annex_used + (int64_t)p.n_recv > c->annex_cap) { if (int rc = grow_annex(c, c->annex_used + (int64_t)p.n_recv)) return rc; }
     const int len = t + 1;
     const int64_t col0 = c->ld + c->annex_used;
-    if (c->is_int) hipLaunchKernelGGL(annex_lineages_kernel<int32_t>, GRID1(p.n_recv * len), static_cast<const int32_t*>(d_recv), (int64_t)p.n_recv, len,
-                                      static_cast<int32_t*>(c->d_values), c->d_anc, c->rs, col0);
-    else hipLaunchKernelGGL(annex_lineages_kernel<double>, GRID1(p.n_recv * len), static_cast<const double*>(d_recv), (int64_t)p.n_recv, len,
-                            static_cast<double*>(c->d_values), c->d_anc, c->rs, col0);
+    dispatch_model(c, [&](auto m) {
+        using S = typename decltype(m)::store_t; using V = typename decltype(m)::value_t;
+        hipLaunchKernelGGL((annex_lineages_kernel<S, V>), GRID1(p.n_recv * len), static_cast<const V*>(d_recv), (int64_t)p.n_recv, len,
+                           static_cast<S*>(c->d_values), c->d_anc, c->rs, col0);
+    });
     HIP_TRY(c, hipGetLastError());
     c->annex_used += (int64_t)p.n_recv;
     return 0;
@@ -784,7 +789,16 @@ int cpprob_hip_copy_values(cpprob_hip_ctx* c, void* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
-    return copy_rows(c, h, c->d_values, c->is_int ? sizeof(int32_t) : sizeof(double), (size_t)c->T, n_bytes, (size_t)c->rs);
+    const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
+    if (c->ssz == vsz) return copy_rows(c, h, c->d_values, vsz, (size_t)c->T, n_bytes, (size_t)c->rs);
+    // narrow store: widen to the value type on the device first (d_paths doubles as the staging buffer)
+    if (!c->d_paths) HIP_TRY(c, hipMalloc(&c->d_paths, (size_t)c->cap_T * c->cap_particles * vsz));
+    dispatch_model(c, [&](auto m) {
+        using S = typename decltype(m)::store_t; using V = typename decltype(m)::value_t;
+        hipLaunchKernelGGL((widen_rows_kernel<S, V>), GRID1(c->n), static_cast<const S*>(c->d_values), c->rs, c->T, c->n, c->ld, static_cast<V*>(c->d_paths));
+    });
+    HIP_TRY(c, hipGetLastError());
+    return copy_rows(c, h, c->d_paths, vsz, (size_t)c->T, n_bytes, (size_t)c->ld);
 }
 
 int cpprob_hip_copy_ancestors(cpprob_hip_ctx* c, int32_t* h, size_t n_bytes)

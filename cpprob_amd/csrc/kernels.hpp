@@ -73,6 +73,7 @@ enum { RS_SYSTEMATIC = 0, RS_STRATIFIED = 1, RS_PRECOMPUTED = 2 };
 template <class T> struct Vec4;
 template <> struct Vec4<double> { using type = double __attribute__((ext_vector_type(4))); };
 template <> struct Vec4<int32_t> { using type = int __attribute__((ext_vector_type(4))); };
+template <> struct Vec4<int8_t> { using type = signed char __attribute__((ext_vector_type(4))); };
 
 template <class T>
 __device__ __forceinline__ void load4(const T* __restrict__ p, int64_t i, T (&v)[kPPT])
@@ -93,6 +94,25 @@ __device__ __forceinline__ void store4(T* __restrict__ p, int64_t i, const T (&v
         x[0] = v[q]; x[1] = v[q + 1]; x[2] = v[q + 2]; x[3] = v[q + 3];
         *reinterpret_cast<typename Vec4<T>::type*>(p + i + q) = x;
     }
+}
+
+// Rows of the particle store may be narrower than the type the model computes in (Model::store_t vs value_t: the HMM's
+// states 0..2 travel as one byte): converting forms of the 4-wide accesses.
+template <class S, class V>
+__device__ __forceinline__ void load4_as(const S* __restrict__ p, int64_t i, V (&v)[kPPT])
+{
+    S raw[kPPT];
+    load4(p, i, raw);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) v[k] = static_cast<V>(raw[k]);
+}
+template <class S, class V>
+__device__ __forceinline__ void store4_as(S* __restrict__ p, int64_t i, const V (&v)[kPPT])
+{
+    S raw[kPPT];
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) raw[k] = static_cast<S>(v[k]);
+    store4(p, i, raw);
 }
 
 // Streaming store: the particle store is written once per step and next read by a different kernel
@@ -592,12 +612,13 @@ template <class Model>
 struct WeightSource {
     using V = typename Model::value_t;
     static constexpr int K = Model::kWeightTable > 0 ? Model::kWeightTable : 1;
-    const double* wrel; const V* states; int64_t n; double e[K]; bool from_states;
+    using S = typename Model::store_t;
+    const double* wrel; const S* states; int64_t n; double e[K]; bool from_states;
     __device__ __forceinline__ void load(int64_t i0, double (&w)[kPPT]) const
     {
         if (Model::kWeightTable > 0 && from_states) {
             V st[kPPT];
-            load4(states, i0, st);
+            load4_as(states, i0, st);
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
                 const int idx = Model::weight_index(st[k]);
@@ -887,7 +908,7 @@ template <class Model>
 struct SisArgs {
     ModelParams mp; const double* obs; int T; int64_t n, ld, rs;
     uint64_t seed, pid0;
-    typename Model::value_t* values; double* logw; double* wrel; Partial* part;
+    typename Model::store_t* values; double* logw; double* wrel; Partial* part;
 };
 
 template <class Model>
@@ -906,7 +927,7 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
             Model::propagate4(a.mp, a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, reinterpret_cast<const V(&)[4]>(x[4 * q]), reinterpret_cast<V(&)[4]>(nx[4 * q]));
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) { x[k] = nx[k]; lw[k] += Model::loglik(a.mp, x[k], t, a.obs); }   // observe: log_w_ += logpdf  state.cpp:212-223
-        store4(a.values + (int64_t)t * a.rs, j0, x);                                          // predict: add_predict       state.hpp:312-327
+        store4_as(a.values + (int64_t)t * a.rs, j0, x);                                       // predict: add_predict       state.hpp:312-327
     }
 #pragma unroll
     for (int k = 0; k < kPPT; ++k)
@@ -938,7 +959,7 @@ template <class Model>
 struct StepArgs {
     ModelParams mp; const double* obs; int t, T; int64_t n, ld;
     uint64_t seed, pid0;   // pid0: RNG id of local slot 0
-    typename Model::value_t* values; int32_t* anc;
+    typename Model::store_t* values; int32_t* anc;
     const double* logw_prev; double* logw_next;
     const double* wrel_prev; double* wrel_next;
     const Partial* part_prev; Partial* part;
@@ -1137,9 +1158,9 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
 
     CPH_STAMP(8);
     V prev[kPPT], x[kPPT];
-    const V* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs;
+    const typename Model::store_t* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs;
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? prev_row[anc[k]] : V(0);                 // ancestor's state (sorted gather)
+    for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>(prev_row[anc[k]]) : V(0);                 // ancestor's state (sorted gather)
 #pragma unroll
     for (int q = 0; q < kPPT / 4; ++q)                                                        // sample #t
         Model::apply4(a.mp, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
@@ -1147,7 +1168,12 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     bool valid[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
-    store4_stream(a.values + (int64_t)t * a.rs, j0, x);                                       // predict #t
+    {
+        typename Model::store_t xs[kPPT];
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) xs[k] = static_cast<typename Model::store_t>(x[k]);
+        store4_stream(a.values + (int64_t)t * a.rs, j0, xs);                                  // predict #t
+    }
     store4_stream(a.anc + (int64_t)t * a.rs, j0, anc);
     double e[kPPT];
     const bool fresh = (t == 0) || resample;                                                  // every particle starts the step at log-weight lwa
@@ -1194,7 +1220,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
 // ---------------------------------------------------------------------------------------------
 template <class Model>
 struct SmoothArgs {
-    const typename Model::value_t* values; const int32_t* anc; const double* wrel; const double* bf; const StepCtrl* ctrl;
+    const typename Model::store_t* values; const int32_t* anc; const double* wrel; const double* bf; const StepCtrl* ctrl;
     const int32_t* resampled; int T; int64_t n, ld, rs; int identity;   // rs: row stride of values[] / anc[]
     double* stats_part;   // [T * kStats][gridDim.x]
     typename Model::value_t* paths;   // optional [T][ld]: materialised traces (dump / tests)
@@ -1225,10 +1251,10 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
             double acc[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) acc[j] = 0.0;
-            const V* row = a.values + (int64_t)t * a.rs;
+            const typename Model::store_t* row = a.values + (int64_t)t * a.rs;
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
-                const V x = row[idx[k]];
+                const V x = static_cast<V>(row[idx[k]]);
                 Model::accumulate(x, w[k], acc);
                 if (a.paths) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)k * kThreads + tid] = x;
             }
@@ -1293,29 +1319,38 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(const double* __rest
 //                             particle came from another GPU
 // Records are [count][len], record-major (one contiguous block per destination rank for the all-to-all).
 // ---------------------------------------------------------------------------------------------
-template <class V>
-__global__ void extract_lineages_kernel(const V* __restrict__ values, const int32_t* __restrict__ anc, int64_t rs, const int32_t* __restrict__ resampled,
+template <class S, class V>
+__global__ void extract_lineages_kernel(const S* __restrict__ values, const int32_t* __restrict__ anc, int64_t rs, const int32_t* __restrict__ resampled,
                                         int len, const int32_t* __restrict__ src, int64_t count, V* __restrict__ rec)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
     int32_t idx = src[k];
     for (int t = len - 1; t >= 0; --t) {
-        rec[k * len + t] = values[(int64_t)t * rs + idx];
+        rec[k * len + t] = static_cast<V>(values[(int64_t)t * rs + idx]);
         if (t > 0 && resampled[t - 1]) idx = anc[(int64_t)t * rs + idx];
     }
 }
 
-template <class V>
-__global__ void annex_lineages_kernel(const V* __restrict__ rec, int64_t count, int len, V* __restrict__ values, int32_t* __restrict__ anc, int64_t rs,
+template <class S, class V>
+__global__ void annex_lineages_kernel(const V* __restrict__ rec, int64_t count, int len, S* __restrict__ values, int32_t* __restrict__ anc, int64_t rs,
                                       int64_t col0)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count * len) return;
     const int64_t k = i / len; const int t = (int)(i - k * len);
     const int64_t col = col0 + k;
-    values[(int64_t)t * rs + col] = rec[i];
+    values[(int64_t)t * rs + col] = static_cast<S>(rec[i]);
     anc[(int64_t)t * rs + col] = (int32_t)col;
+}
+
+// rows of a narrow particle store widened to the model's value type ([T][rs] -> [T][ld]): copy-out through the C ABI
+template <class S, class V>
+__global__ void widen_rows_kernel(const S* __restrict__ src, int64_t rs, int T, int64_t n, int64_t ld, V* __restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int t = 0; t < T; ++t) dst[(int64_t)t * ld + i] = static_cast<V>(src[(int64_t)t * rs + i]);
 }
 
 // {log_evidence, ess, log_norm, max_logw, stats[n_stats]} of the finished run into one device buffer
@@ -1413,9 +1448,9 @@ __global__ void pad_copy_kernel(const T* __restrict__ src, int64_t n, int64_t ld
 
 // Weighted moments / histogram of one column against one log-weight array (EmpiricalDistribution
 // on device): the column is a 1-step "trace", so this is smooth_kernel with T = 1.
-struct ColumnReal { using value_t = double; static constexpr int kStats = 2;
+struct ColumnReal { using value_t = double; using store_t = double; static constexpr int kStats = 2;
     __device__ static __forceinline__ void accumulate(double x, double w, double (&acc)[2]) { acc[0] += w * x; acc[1] += w * (x * x); } };
-struct ColumnInt8 { using value_t = int32_t; static constexpr int kStats = 8;
+struct ColumnInt8 { using value_t = int32_t; using store_t = int32_t; static constexpr int kStats = 8;
     __device__ static __forceinline__ void accumulate(int32_t x, double w, double (&acc)[8]) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] += x == s ? w : 0.0; } };

@@ -30,6 +30,7 @@ struct ModelParams {
 // different hyper-parameters).  One step, two observes, one real predict.
 struct ModelGaussian {
     using value_t = double;
+    using store_t = double;
     static constexpr bool kIsInt = false;
     static constexpr int kStats = 2;  // sum w x, sum w x^2
     static constexpr int kWeightTable = 0;   // incremental weights are continuous
@@ -69,6 +70,7 @@ struct ModelGaussian {
 // kernel -- row d of values[] -- and the weight is the sum over rows, which is exactly the component sum.
 struct ModelGaussianND {
     using value_t = double;
+    using store_t = double;
     static constexpr bool kIsInt = false;
     static constexpr int kStats = 2;
     static constexpr int kWeightTable = 0;
@@ -101,6 +103,7 @@ struct ModelGaussianND {
 // predict(x_t, "State") after the observe.
 struct ModelLinearGaussian1D {
     using value_t = double;
+    using store_t = double;
     static constexpr bool kIsInt = false;
     static constexpr int kStats = 2;
     static constexpr int kWeightTable = 0;
@@ -136,6 +139,7 @@ struct ModelLinearGaussian1D {
 // emission N(state_mean[s], 1); predict(state, "State") before the observe.
 struct ModelHmm3 {
     using value_t = int32_t;
+    using store_t = int8_t;           // states 0..2: one byte per particle-step in the particle store (the C ABI widens on copy-out)
     static constexpr bool kIsInt = true;
     static constexpr int kStats = 3;  // sum w [x == s]
     // the incremental weight of a step takes one of 3 values: log N(y_t; mean[s], 1).  ll_tab row t holds them,
