@@ -153,9 +153,13 @@ class IslandBatch:
         self.packed = torch.zeros((self.depth, self.width), dtype=torch.float64, device=dev)
         self.gathered = torch.zeros((self.depth, self.world, self.width), dtype=torch.float64, device=dev)
         self.stream = torch.cuda.ExternalStream(engine.stream_ptr, device=dev)
+        self.works = [None] * self.depth          # pending all-gathers (the engine's stream never waits for them)
 
     def run(self, slot, run_index):
         e, torch = self.engine, self.torch
+        if self.works[slot] is not None:          # the slot's previous all-gather must have read packed[slot] (long done by now)
+            self.works[slot].wait()
+            self.works[slot] = None
         e.run(run_index)
         e.results_device(self.packed[slot])
         with torch.cuda.stream(self.stream):
@@ -167,10 +171,16 @@ class IslandBatch:
                 self.dist.all_gather(parts, mine)
                 self.gathered[slot].copy_(torch.stack(parts).to(self.gathered.device))
             else:
-                self.dist.all_gather_into_tensor(self.gathered[slot].view(-1), self.packed[slot])
+                # async_op: RCCL's stream waits for the engine's (it sees the packed slot), but the engine's stream does NOT
+                # wait for the collective -- the next run starts while the 8 * width bytes per rank are still travelling
+                self.works[slot] = self.dist.all_gather_into_tensor(self.gathered[slot].view(-1), self.packed[slot], async_op=True)
 
     def results(self, slot):
         """Synchronises and combines the islands of one slot: (stats[T, K], log_evidence, island_ess)."""
+        for i, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[i] = None
         self.engine.sync()
         self.torch.cuda.synchronize()
         g = self.gathered[slot].cpu().numpy()
