@@ -455,6 +455,29 @@ def test_exchange_scope_world1_is_bit_identical_to_run(engine, golden_dir):
         engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, resampler=cp.RESAMPLE_MULTINOMIAL, scope=cp.SCOPE_EXCHANGE)
 
 
+def test_contexts_in_flight_do_not_interfere(engine, golden_dir):
+    """Independent runs enqueued round-robin on three contexts (their kernels overlap on the GPU: bench.py's `pipelined`
+    figure) give bit-identical results to the same runs one at a time."""
+    obs = _obs(golden_dir, "hmm16")
+    n = 400_000
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=6, ess_threshold=2.0)
+    ref = []
+    for i in range(6):
+        engine.run(i)
+        ref.append((engine.stats().copy(), engine.summary()["log_evidence"]))
+    engs = [cp.Engine(0) for _ in range(3)]
+    for e in engs:
+        e.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=6, ess_threshold=2.0)
+    for rnd in range(2):
+        for k, e in enumerate(engs):
+            e.run(rnd * 3 + k)                      # no synchronisation in between: up to three runs in flight
+        for k, e in enumerate(engs):
+            st, lz = e.stats(), e.summary()["log_evidence"]
+            assert np.array_equal(st, ref[rnd * 3 + k][0]) and lz == ref[rnd * 3 + k][1]
+    for e in engs:
+        e.close()
+
+
 def test_results_device_and_island_batch_match_the_host_read_out(engine, golden_dir):
     """cpprob_hip_infer_results_device leaves summary + stats on the device without a host sync; IslandBatch chains
     runs on it (world = 1 here: the all-gather degenerates to a copy)."""
