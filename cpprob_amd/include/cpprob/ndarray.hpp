@@ -13,6 +13,7 @@
 #include <cstddef>
 #include <functional>
 #include <istream>
+#include <iterator>
 #include <numeric>
 #include <ostream>
 #include <stdexcept>
@@ -31,7 +32,13 @@ public:
     NDArray(T x) : values_{x}, shape_{1} {}
     NDArray(std::vector<T> values) : values_(std::move(values)), shape_{values_.size()} {}
     NDArray(std::vector<T> values, std::vector<std::size_t> shape) : values_(std::move(values)), shape_(std::move(shape)) {}
-    template <class Iter> NDArray(Iter first, Iter last) : values_(first, last), shape_{values_.size()} {}
+    // From a range of numbers (any arithmetic type) or of nested containers: ragged nesting is padded with zeros to the
+    // smallest enclosing box, row-major (the behaviour pinned by the reference's tests/cpprob/ndarray.cpp).
+    template <class Iter> NDArray(Iter first, Iter last)
+    {
+        using Elem = typename std::iterator_traits<Iter>::value_type;
+        build(first, last, std::is_arithmetic<Elem>{});
+    }
     template <class U> NDArray(const NDArray<U>& o) : values_(o.begin(), o.end()), shape_(o.shape()) {}
 
     const std::vector<T>& values() const { return values_; }
@@ -113,6 +120,42 @@ public:
 private:
     std::vector<T> values_;
     std::vector<std::size_t> shape_;
+
+    template <class Iter> void build(Iter first, Iter last, std::true_type /*numbers*/)
+    {
+        for (Iter it = first; it != last; ++it) values_.push_back(static_cast<T>(*it));
+        shape_.assign(1, values_.size());
+    }
+    template <class Iter> void build(Iter first, Iter last, std::false_type /*containers*/)
+    {
+        shape_.assign(1, static_cast<std::size_t>(std::distance(first, last)));
+        for (Iter it = first; it != last; ++it) extent(*it, 1);
+        std::size_t total = 1;
+        for (auto d : shape_) total *= d;
+        values_.assign(total, T());
+        std::size_t i = 0;
+        for (Iter it = first; it != last; ++it, ++i) place(*it, 1, i * stride(0));
+    }
+    std::size_t stride(std::size_t axis) const
+    {
+        std::size_t st = 1;
+        for (std::size_t d = axis + 1; d < shape_.size(); ++d) st *= shape_[d];
+        return st;
+    }
+    // largest extent found at every nesting depth
+    template <class C> std::enable_if_t<!std::is_arithmetic<C>::value> extent(const C& c, std::size_t depth)
+    {
+        if (shape_.size() <= depth) shape_.resize(depth + 1, 0);
+        if (c.size() > shape_[depth]) shape_[depth] = c.size();
+        for (const auto& e : c) extent(e, depth + 1);
+    }
+    template <class C> std::enable_if_t<std::is_arithmetic<C>::value> extent(const C&, std::size_t) {}
+    template <class C> std::enable_if_t<!std::is_arithmetic<C>::value> place(const C& c, std::size_t depth, std::size_t offset)
+    {
+        std::size_t i = 0;
+        for (const auto& e : c) { place(e, depth + 1, offset + i * stride(depth)); ++i; }
+    }
+    template <class C> std::enable_if_t<std::is_arithmetic<C>::value> place(const C& x, std::size_t, std::size_t offset) { values_[offset] = static_cast<T>(x); }
 
     template <class Op>
     NDArray& combine(const NDArray& o, Op op)

@@ -248,3 +248,49 @@ def test_ndarray_multivariate_normal_and_stats_printer_host_side(tmp_path):
     out = subprocess.run([exe, str(tmp_path / "post")], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Mean: [2 4]" in out.stdout and "Variance: [1 4]" in out.stdout and "Mu:" in out.stdout
+
+
+def _cpp_nested(x, elem):
+    if isinstance(x, list):
+        depth = lambda v: 1 + depth(v[0]) if isinstance(v, list) else 0
+        t = elem
+        for _ in range(depth(x)):
+            t = "std::vector<%s>" % t
+        return "%s{%s}" % (t, ", ".join(_cpp_nested(e, elem) for e in x))
+    return repr(float(x)) + ("f" if elem == "float" else "") if elem != "int" else str(int(x))
+
+
+def test_ndarray_constructors_against_the_reference_test_vectors(tmp_path):
+    """The reference's own NDArray tests (tests/cpprob/ndarray.cpp), as data: nested ragged containers become zero-padded
+    row-major boxes; element types convert.  tests/golden/ndarray_cases.json holds inputs and expected values / shapes."""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "ndarray_cases.json")))
+    body = []
+    k = 0
+    for c in g["cases"]:
+        for elem in (["int", "float", "double"] if c["type"] == "double" else ["int"]):
+            k += 1
+            body.append("  { auto in = %s; cpprob::NDArray<%s> a(in.begin(), in.end());\n    check(%d, a.values() == std::vector<%s>{%s} && a.shape() == std::vector<std::size_t>{%s}); }" % (
+                _cpp_nested(c["input"], elem), c["type"], k, c["type"], ", ".join(str(v) for v in c["values"]), ", ".join(str(v) for v in c["shape"])))
+    prog = """#include <cstdio>
+#include <vector>
+#include "cpprob/ndarray.hpp"
+static int bad = 0;
+static void check(int k, bool ok) { if (!ok) { std::printf("case %%d FAILED\\n", k); ++bad; } }
+int main() {
+  { cpprob::NDArray<double> e{}; cpprob::NDArray<int> ei{}; check(-1, e.values().empty() && e.shape().empty() && ei.values().empty() && ei.shape().empty()); }
+  { cpprob::NDArray<double> a{2.0}; cpprob::NDArray<int> b{3}; cpprob::NDArray<double> c{2}; cpprob::NDArray<double> d{3.0f};
+    check(-2, a.values() == std::vector<double>{2.0} && a.shape() == std::vector<std::size_t>{1} && b.values() == std::vector<int>{3} &&
+              c.values() == std::vector<double>{2.0} && d.values() == std::vector<double>{3.0} && d.shape() == std::vector<std::size_t>{1}); }
+%s
+  std::printf("%%d cases, %%d failed\\n", %d, bad);
+  return bad;
+}
+""" % ("\n".join(body), k)
+    src = tmp_path / "ndc.cpp"
+    src.write_text(prog)
+    exe = str(tmp_path / "ndc")
+    p = subprocess.run(["g++", "-std=c++14", "-Wall", "-I", os.path.join(ROOT, "cpprob_amd", "include"), str(src), "-o", exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "0 failed" in out.stdout, out.stdout
