@@ -23,7 +23,7 @@ SYMBOLS = [
     "cpprob_hip_smc_finish", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
     "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
-    "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_resample", "cpprob_hip_gather_f64",
+    "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_gather_f64",
     "cpprob_hip_gather_i32", "cpprob_hip_profile_enable", "cpprob_hip_profile_read",
 ]
 
@@ -97,6 +97,7 @@ def load_library(path=None):
         "cpprob_hip_weighted_moments": (C.c_int, [vp, vp, vp, sz, C.POINTER(dbl)]),
         "cpprob_hip_weighted_hist": (C.c_int, [vp, vp, vp, sz, i32, C.POINTER(dbl)]),
         "cpprob_hip_resample": (C.c_int, [vp, i32, vp, sz, u64, u64, u64, sz, u64, vp]),
+        "cpprob_hip_smc_bookkeep": (C.c_int, [vp, i32, vp, sz, u64, i32, i32, dbl, vp, vp, vp, vp]),
         "cpprob_hip_gather_f64": (C.c_int, [vp, vp, vp, sz, vp]),
         "cpprob_hip_gather_i32": (C.c_int, [vp, vp, vp, sz, vp]),
         "cpprob_hip_profile_enable": (C.c_int, [vp, i32]),
@@ -303,6 +304,11 @@ class Engine:
         n_out = anc_out.numel()
         nt = logw.numel() if n_total_out is None else n_total_out
         self._chk(self.L.cpprob_hip_resample(self.h, kind, _dptr(logw), logw.numel(), seed, step, j0, n_out, nt, _dptr(anc_out)))
+
+    def smc_bookkeep(self, kind, logw, seed, step, last, ess_frac, ess, resampled, log_z, anc):
+        """Device-side SMC bookkeeping of one step (all tensors on this device; no host sync)."""
+        self._chk(self.L.cpprob_hip_smc_bookkeep(self.h, kind, _dptr(logw), logw.numel(), seed, int(step), 1 if last else 0, float(ess_frac),
+                                                 _dptr(ess), _dptr(resampled), _dptr(log_z), _dptr(anc)))
 
     def gather(self, src, idx, dst):
         import torch

@@ -260,7 +260,7 @@ void launch_step(cpprob_hip_ctx* c, int t)
         ProfScope ps(c, 5);
         hipLaunchKernelGGL(cdf_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, c->d_wrel[c->cur], c->d_bc, c->d_bf, c->d_ctrl, c->d_cdf);
         hipLaunchKernelGGL(multinomial_kernel, dim3((unsigned)((c->ld + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, c->d_cdf, c->n,
-                           c->d_ctrl, c->run_seed, (uint64_t)t, c->cfg.particle_offset, c->n, c->ld, c->d_anc_pre);
+                           c->d_ctrl, c->run_seed, (uint64_t)t, c->cfg.particle_offset, c->n, c->ld, c->d_anc_pre, 0);
     }
     {
         ProfScope ps(c, 0);
@@ -1026,7 +1026,7 @@ int cpprob_hip_resample(cpprob_hip_ctx* c, int32_t kind, const double* d_logw, s
     if (kind == CPPROB_HIP_RESAMPLE_MULTINOMIAL) {
         if ((size_t)nb_in * kTile > c->bb_cdf_cap) { dfree(c->d_bb_cdf); HIP_TRY(c, hipMalloc(&c->d_bb_cdf, (size_t)nb_in * kTile * sizeof(double))); c->bb_cdf_cap = (size_t)nb_in * kTile; }
         hipLaunchKernelGGL(cdf_kernel, dim3(nb_in), dim3(kThreads), 0, c->stream, c->d_bb_wrel, c->d_bb_bc, c->d_bb_bf, c->d_bb_ctrl, c->d_bb_cdf);
-        hipLaunchKernelGGL(multinomial_kernel, GRID1(n_out), c->d_bb_cdf, (int64_t)n_in, c->d_bb_ctrl, seed, step, j0, (int64_t)n_out, (int64_t)n_out, d_anc);
+        hipLaunchKernelGGL(multinomial_kernel, GRID1(n_out), c->d_bb_cdf, (int64_t)n_in, c->d_bb_ctrl, seed, step, j0, (int64_t)n_out, (int64_t)n_out, d_anc, 0);
     } else if (kind == CPPROB_HIP_RESAMPLE_SYSTEMATIC || kind == CPPROB_HIP_RESAMPLE_STRATIFIED) {
         ResampleArgs a{};
         a.wrel = c->d_bb_wrel; a.n_in = (int64_t)n_in; a.bc = c->d_bb_bc; a.bf = c->d_bb_bf; a.nb = nb_in; a.ctrl = c->d_bb_ctrl; a.seed = seed; a.step = step; a.j0 = j0;
@@ -1037,6 +1037,39 @@ int cpprob_hip_resample(cpprob_hip_ctx* c, int32_t kind, const double* d_logw, s
         else hipLaunchKernelGGL(resample_kernel<RS_STRATIFIED>, dim3(nb_out), dim3(kThreads), 0, c->stream, a);
     } else {
         return fail(c, CPPROB_HIP_EINVAL, "unknown resampler");
+    }
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_smc_bookkeep(cpprob_hip_ctx* c, int32_t kind, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last, double ess_frac,
+                            double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc)
+{
+    BB_PRELUDE(c);
+    if (!d_logw || !d_ess || !d_resampled || !d_log_z || !d_anc) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (n == 0 || n > (size_t)INT32_MAX - kTile) return fail(c, CPPROB_HIP_EINVAL, "population size out of range");
+    if (kind < CPPROB_HIP_RESAMPLE_SYSTEMATIC || kind > CPPROB_HIP_RESAMPLE_MULTINOMIAL) return fail(c, CPPROB_HIP_EINVAL, "unknown resampler");
+    if (step < 0) return fail(c, CPPROB_HIP_EINVAL, "step out of range");
+    if (int rc = ensure_bb(c, n)) return rc;
+    const int nb = (int)((n + kTile - 1) / kTile);
+    hipLaunchKernelGGL(weights_partials_kernel, dim3(nb), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, c->d_bb_part, c->d_bb_wrel);
+    ScanArgs sa{};
+    sa.part = c->d_bb_part; sa.nb = nb; sa.bc = c->d_bb_bc; sa.bf = c->d_bb_bf; sa.ctrl = c->d_bb_ctrl; sa.t = step; sa.T = last ? step + 1 : step + 2;
+    sa.n_pop = (double)n; sa.n_local = (double)n; sa.ess_frac = ess_frac; sa.force_no_resample = 0; sa.phase = 0; sa.seed = seed;
+    sa.ess_trace = d_ess; sa.resampled = d_resampled; sa.log_z_out = d_log_z;
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, sa);
+    if (!last) {
+        if (kind == CPPROB_HIP_RESAMPLE_MULTINOMIAL) {
+            if ((size_t)nb * kTile > c->bb_cdf_cap) { dfree(c->d_bb_cdf); HIP_TRY(c, hipMalloc(&c->d_bb_cdf, (size_t)nb * kTile * sizeof(double))); c->bb_cdf_cap = (size_t)nb * kTile; }
+            hipLaunchKernelGGL(cdf_kernel, dim3(nb), dim3(kThreads), 0, c->stream, c->d_bb_wrel, c->d_bb_bc, c->d_bb_bf, c->d_bb_ctrl, c->d_bb_cdf);
+            hipLaunchKernelGGL(multinomial_kernel, GRID1(n), c->d_bb_cdf, (int64_t)n, c->d_bb_ctrl, seed, (uint64_t)step + 1, (uint64_t)0, (int64_t)n, (int64_t)n, d_anc, 1);
+        } else {
+            ResampleArgs a{};
+            a.wrel = c->d_bb_wrel; a.n_in = (int64_t)n; a.bc = c->d_bb_bc; a.bf = c->d_bb_bf; a.nb = nb; a.ctrl = c->d_bb_ctrl; a.seed = seed; a.step = (uint64_t)step + 1;
+            a.j0 = 0; a.n_total_out = n; a.n_out = (int64_t)n; a.anc = d_anc; a.run_ctrl = 1; a.identity_unless_resampling = 1;
+            if (kind == CPPROB_HIP_RESAMPLE_SYSTEMATIC) hipLaunchKernelGGL(resample_kernel<RS_SYSTEMATIC>, dim3(nb), dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL(resample_kernel<RS_STRATIFIED>, dim3(nb), dim3(kThreads), 0, c->stream, a);
+        }
     }
     HIP_TRY(c, hipGetLastError());
     return 0;

@@ -188,6 +188,7 @@ struct ScanArgs {
     const double* all_totals; int world, rank;   // phase 2: all-gathered per-rank {M, W, Q}
     double* local_totals;      // phase 1 out: {M_local, W_local, Q_local}
     int phase;                 // 0: single shard (everything); 1: local part; 2: combine ranks
+    double* log_z_out;         // optional: the running log evidence after this step's bookkeeping (building block)
     int exchange;              // phase 2: resampling is global and exact (offspring of remote sources migrate in)
     double* obound;            // phase 2, exchange: [world + 1] first output index owned by each rank's sources
 };
@@ -218,6 +219,7 @@ __device__ __forceinline__ void scan_tail(const ScanArgs& a)
     ctrl->u0 = u01_53(r.x, r.y);
     if (a.ess_trace) a.ess_trace[a.t] = ess;
     if (a.resampled) a.resampled[a.t] = rs ? 1 : 0;
+    if (a.log_z_out) *a.log_z_out = ctrl->log_z;
 }
 
 // Exchange scope: the sources of rank s own the outputs [o_s, o_{s+1}), o_s = G(B_s) with B_s the global CDF at the
@@ -833,6 +835,7 @@ struct ResampleArgs {
     uint64_t seed, step, j0, n_total_out; int64_t n_out;
     int32_t* anc;
     int run_ctrl;      // u0 / inv / g_end of a running SMC step (exchange scope) instead of (seed, step, n_total_out)
+    int identity_unless_resampling;   // ctrl->do_resample == 0: every output is its own ancestor (device-side decision)
 };
 
 template <int RS>
@@ -840,6 +843,12 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(ResampleArgs a)
 {
     __shared__ AncestorLds L;
     const int64_t l0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
+    if (a.identity_unless_resampling && !a.ctrl->do_resample) {     // workgroup-uniform, before any barrier
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k)
+            if (l0 + k < a.n_out) a.anc[l0 + k] = (int32_t)(a.j0 + (uint64_t)(l0 + k));
+        return;
+    }
     const int64_t rem = a.n_out - (int64_t)blockIdx.x * kTile;
     AncestorIn in;
     in.wrel = a.wrel; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n_in;
@@ -881,13 +890,14 @@ __global__ __launch_bounds__(kThreads) void cdf_kernel(const double* __restrict_
 
 __global__ __launch_bounds__(kThreads) void multinomial_kernel(const double* __restrict__ cdf, int64_t n_in, const StepCtrl* __restrict__ ctrl,
                                                                 uint64_t seed, uint64_t step, uint64_t j0, int64_t n_out, int64_t n_pad,
-                                                                int32_t* __restrict__ anc)
+                                                                int32_t* __restrict__ anc, int identity_unless_resampling)
 {
     const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= n_out) {
         if (i < n_pad) anc[i] = 0;          // padding slots of the particle store must hold a valid index
         return;
     }
+    if (identity_unless_resampling && !ctrl->do_resample) { anc[i] = (int32_t)(j0 + (uint64_t)i); return; }
     const double p = draw_u01_53(seed, j0 + (uint64_t)i, kResampleDrawBase + step) * cdf[n_in - 1];
     int64_t lo = 0, hi = n_in;
     while (lo < hi) {

@@ -24,6 +24,7 @@ namespace {
 struct Args {
     std::string model, model_folder = ".", observes, observes_file, generated_file = "post";
     bool sis = false, smc = false, estimate = false, json = false;
+    int repeat = 1;
     std::size_t n_samples = 10000;            // src/main.cpp:166
 };
 
@@ -71,12 +72,12 @@ int execute(const F& model, const Args& a)
         return EXIT_FAILURE;
     }
     const std::string post = a.model_folder + "/" + a.generated_file + (a.smc ? "_smc" : "_sis");                            // main.cpp:49-53
-    if (a.smc) {
-        std::cout << "Sequential Monte Carlo (SMC)" << std::endl;
-        cpprob::inference(cpprob::StateType::smc, model, observes, a.n_samples, post);
-    } else {
-        std::cout << "Sequential Importance Sampling (SIS)" << std::endl;                                                   // main.cpp:99
-        cpprob::inference(cpprob::StateType::sis, model, observes, a.n_samples, post);
+    if (a.smc) std::cout << "Sequential Monte Carlo (SMC)" << std::endl;
+    else std::cout << "Sequential Importance Sampling (SIS)" << std::endl;                                                   // main.cpp:99
+    for (int rep = 0; rep < a.repeat; ++rep) {                       // --repeat: the first call pays code loading; later ones show the warm rate
+        if (rep) cpprob::gpu::options().seed += 1;
+        cpprob::inference(a.smc ? cpprob::StateType::smc : cpprob::StateType::sis, model, observes, a.n_samples, post);
+        if (a.repeat > 1) std::cout << "run " << rep << ": " << cpprob::gpu::last_result().run_seconds * 1e3 << " ms" << std::endl;
     }
     if (a.json) print_json(cpprob::gpu::last_result());
     if (a.estimate) {
@@ -108,6 +109,7 @@ int main(int argc, char** argv)
         else if (f == "--ess_threshold") opt.ess_threshold = std::stod(next());
         else if (f == "--resampler") { const std::string r = next(); opt.resampler = r == "multinomial" ? 2 : (r == "stratified" ? 1 : 0); }
         else if (f == "--generic") opt.prefer_builtin = false;
+        else if (f == "--repeat") a.repeat = std::stoi(next());
         else if (f == "--no_dump") opt.dump = false;
         else if (f == "--json") a.json = true;
         else { std::cerr << "unknown option " << f << std::endl; return EXIT_FAILURE; }

@@ -15,8 +15,8 @@
 //   SMC : one launch per observe (trace replay): the lane re-runs the model from
 //         the top, `sample` statements already executed by its ancestor return the stored values, the
 //         next ones draw fresh, the step's observe adds the incremental weight and ends the lane.
-//         Between launches the C-ABI building blocks normalise the weights, test the ESS and resample
-//         (cpprob_hip_logsumexp_ess / cpprob_hip_resample); the stored sample values of the chosen
+//         Between launches one C-ABI building block (cpprob_hip_smc_bookkeep) normalises the weights, tests the ESS and
+//         resamples ON THE DEVICE -- no host synchronisation inside a run; the stored sample values of the chosen
 //         ancestors are carried along by the replay itself (each step rewrites the full trace), so the
 //         final launch regenerates every predict of every surviving particle.
 // Cost: O(T^2) statement executions for T observes -- the price of not editing the model; the built-in
@@ -46,8 +46,9 @@ namespace gpu {
 struct ModelKernelArgs {
     int64_t n, ld;
     uint64_t seed;
-    const int32_t* anc;            // nullptr: identity (no resampling before this step)
-    const double* logw_in;         // nullptr or carried log-weights (used when anc == nullptr)
+    const int32_t* anc;            // ancestors of this generation (identity where the previous step did not resample); nullptr at step 0
+    const int32_t* resampled_prev; // device flag: did the previous step resample?  (the decision is taken on the device)
+    const double* logw_in;         // log-weights of the previous generation, carried over when it was not resampled
     double* logw_out;
     const uint64_t* trace_in; uint64_t* trace_out;
     const int32_t* nstored_in; int32_t* nstored_out;
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
 {
     const int64_t i = (int64_t)blockIdx.x * device::kLaneBlock + threadIdx.x;
     if (i >= a.n) return;
-    const int64_t src = a.anc ? (int64_t)a.anc[i] : i;
+    const bool resampled = a.resampled_prev && *a.resampled_prev != 0;
+    const int64_t src = (a.anc && resampled) ? (int64_t)a.anc[i] : i;
     device::LaneCtx& c = device::lane_ctx();
     c.seed = a.seed; c.pid = (uint64_t)i; c.log_w = 0.0;
     c.trace_in = a.trace_in ? a.trace_in + src : nullptr;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
     c.trace_cap = a.trace_cap; c.overflow = a.overflow;
     c.first_observe = a.first_observe; c.stop_after = a.stop_after; c.done = 0;
     Caller::call(*observes);                                      // the model body, cpprob.hpp:199
-    const double carried = (a.anc == nullptr && a.logw_in) ? a.logw_in[i] : 0.0;   // equal weights after resampling
+    const double carried = (!resampled && a.logw_in) ? a.logw_in[i] : 0.0;         // equal weights after resampling
     a.logw_out[i] = carried + c.log_w;                            // finish_trace(): the particle's log_w_
     if (a.nstored_out) a.nstored_out[i] = (int32_t)c.n_recorded;
 }
@@ -141,16 +143,19 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     const auto t_start = std::chrono::steady_clock::now();
     double log_z = 0.0;
     int cur = 0, n_resampled = 0;
+    bool smc_log_z_done = false;
+    DevBuf<double> d_ess(smc ? (size_t)T : 0), d_logz(smc ? 1 : 0);
+    DevBuf<int32_t> d_res(smc ? (size_t)T : 0);
     res.step_ess.clear();
     if (!smc) {
         a.logw_out = logw[0]; a.pred_real = d_real.p; a.pred_int = d_int.p; a.first_observe = 0; a.stop_after = -1;
         hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
         hip_check(hipGetLastError(), "model_kernel");
     } else {
-        bool resampled = false;
         for (int t = 0; t < T; ++t) {
             const bool last = t + 1 == T;
-            a.anc = resampled ? d_anc.p : nullptr;
+            a.anc = t > 0 ? d_anc.p : nullptr;
+            a.resampled_prev = t > 0 ? d_res.p + (t - 1) : nullptr;
             a.logw_in = t > 0 ? logw[cur] : nullptr;
             a.logw_out = logw[cur ^ 1];
             a.trace_in = t > 0 ? tr[cur] : nullptr; a.trace_out = tr[cur ^ 1];
@@ -160,20 +165,23 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
             hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
             hip_check(hipGetLastError(), "model_kernel");
             cur ^= 1;
-            double o3[3];
-            ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), logw[cur], n, o3), "cpprob_hip_logsumexp_ess");
-            res.step_ess.push_back(o3[2]);
-            resampled = !last && (o3[2] < opt.ess_threshold * (double)n);          // ESS test, thesis p.37
-            if (resampled) {
-                ctx.check(cpprob_hip_resample(ctx.get(), opt.resampler, logw[cur], n, opt.seed, (uint64_t)(t + 1), 0, n, n, d_anc.p), "cpprob_hip_resample");
-                log_z += o3[1] - std::log((double)n);
-                ++n_resampled;
-            }
+            // normalise, ESS test (thesis p.37), evidence, ancestors of the next generation: all on the device
+            ctx.check(cpprob_hip_smc_bookkeep(ctx.get(), opt.resampler, logw[cur], n, opt.seed, t, last ? 1 : 0, opt.ess_threshold,
+                                              d_ess.p, d_res.p, d_logz.p, d_anc.p), "cpprob_hip_smc_bookkeep");
         }
+        std::vector<double> h_ess((size_t)T);
+        std::vector<int32_t> h_res((size_t)T);
+        hip_check(hipMemcpyAsync(h_ess.data(), d_ess.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, stream), "copy ess");
+        hip_check(hipMemcpyAsync(h_res.data(), d_res.p, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy decisions");
+        hip_check(hipMemcpyAsync(&log_z, d_logz.p, sizeof(double), hipMemcpyDeviceToHost, stream), "copy log evidence");
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        res.step_ess = h_ess;
+        for (int t = 0; t < T; ++t) n_resampled += h_res[(size_t)t];
+        smc_log_z_done = true;
     }
     double o3[3];
     ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), logw[cur], n, o3), "cpprob_hip_logsumexp_ess");
-    log_z += o3[1] - std::log((double)n);
+    if (!smc_log_z_done) log_z += o3[1] - std::log((double)n);       // SIS: evidence = mean weight
     res.n_particles = n; res.log_evidence = log_z; res.log_norm = o3[1]; res.ess = o3[2]; res.n_resampled = n_resampled; res.used_builtin = false;
     fill_predict_names(res, st);
     res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();   // (the logsumexp above synchronised)

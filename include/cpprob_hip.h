@@ -236,6 +236,14 @@ int cpprob_hip_weighted_hist(cpprob_hip_ctx* ctx, const int32_t* d_x, const doub
  * uniform of id j; multinomial the 53-bit uniform of id j. */
 int cpprob_hip_resample(cpprob_hip_ctx* ctx, int32_t kind, const double* d_logw, size_t n_in, uint64_t seed, uint64_t step,
                         uint64_t j0, size_t n_out, uint64_t n_total_out, int32_t* d_anc);
+/* One step of SMC bookkeeping ON THE DEVICE, stream-ordered, no host synchronisation (what the generic model path runs
+ * between two launches of the model body): normalises d_logw[0..n), stores the ESS in d_ess[step], decides
+ * (ESS < ess_frac * n, never at the last step) into d_resampled[step], keeps the running log evidence in *d_log_z
+ * (reset at step 0; + log mean weight whenever the step resamples or is the last), and fills d_anc[0..n) with the next
+ * generation's ancestors -- the identity when the step does not resample.  Uniforms: draw index (1<<40) + step + 1,
+ * as cpprob_hip_resample(seed, step + 1). */
+int cpprob_hip_smc_bookkeep(cpprob_hip_ctx* ctx, int32_t kind, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last,
+                            double ess_frac, double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc);
 /* d_dst[i] = d_src[d_idx[i]] */
 int cpprob_hip_gather_f64(cpprob_hip_ctx* ctx, const double* d_src, const int32_t* d_idx, size_t n, double* d_dst);
 int cpprob_hip_gather_i32(cpprob_hip_ctx* ctx, const int32_t* d_src, const int32_t* d_idx, size_t n, int32_t* d_dst);

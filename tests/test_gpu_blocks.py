@@ -212,6 +212,39 @@ def test_resample_generic_weights(engine, kind):
         assert np.all(np.abs(cnt - n * w) < 1.0 + 1e-6)
 
 
+@pytest.mark.parametrize("kind", [O.RESAMPLE_SYSTEMATIC, O.RESAMPLE_STRATIFIED, O.RESAMPLE_MULTINOMIAL])
+def test_smc_bookkeep_decides_and_resamples_on_the_device(engine, kind):
+    """cpprob_hip_smc_bookkeep = logsumexp/ESS + ESS test + evidence + ancestors without a host round trip: against the
+    oracle's estimators and resampler for a resampling step, identity ancestors for a non-resampling one."""
+    import torch
+    n = 50000
+    rng = np.random.default_rng(9)
+    ess = torch.zeros(3, dtype=torch.float64, device="cuda")
+    res = torch.zeros(3, dtype=torch.int32, device="cuda")
+    lz = torch.zeros(1, dtype=torch.float64, device="cuda")
+    anc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    want_lz = 0.0
+    for step, (spread, last) in enumerate([(2.0, False), (0.01, False), (1.0, True)]):
+        logw = rng.normal(size=n) * spread                      # spread 2: ESS << N/2 -> resample; 0.01: ESS ~ N -> keep
+        engine.smc_bookkeep(kind, _t(logw), 77, step, last, 0.5, ess, res, lz, anc)
+        engine.sync()
+        ref_lse, ref_ess = O.logsumexp(logw), O.weighted_moments(np.zeros(n), logw)[3]
+        got_anc = anc.cpu().numpy()
+        assert abs(float(ess[step]) - ref_ess) < 1e-6 * ref_ess
+        if step == 0:
+            assert int(res[0]) == 1
+            ref = O.resample(kind, logw, 77, 1)
+            mism = got_anc != ref
+            assert mism.mean() < 1e-4 and np.all(np.abs(got_anc[mism].astype(np.int64) - ref[mism]) <= 1)
+            want_lz += ref_lse - np.log(n)
+        elif step == 1:
+            assert int(res[1]) == 0 and np.array_equal(got_anc, np.arange(n))
+        else:
+            assert int(res[2]) == 0                              # the last step never resamples, but closes the evidence
+            want_lz += ref_lse - np.log(n)
+        assert abs(float(lz[0]) - want_lz) < 1e-10
+
+
 def test_resample_degenerate_weight(engine):
     import torch
     n = 10000
