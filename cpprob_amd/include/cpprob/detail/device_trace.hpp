@@ -107,7 +107,7 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
         const uint32_t j = c.n_sample++;
         if (c.done) return R();
         R value;
-        if (j < c.n_stored) value = from_raw<R>(c.trace_in[(int64_t)j * c.ld]);
+        if (j < c.n_stored && j < c.trace_cap) value = from_raw<R>(c.trace_in[(int64_t)j * c.ld]);   // (beyond the rows: the run is being repeated anyway)
         else value = draw(distr, c.seed, c.pid, (uint64_t)j);
         if (c.trace_out) {
             if (j < c.trace_cap) c.trace_out[(int64_t)j * c.ld] = to_raw<R>(value);

@@ -110,9 +110,10 @@ inline void hip_check(hipError_t e, const char* what)
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// One attempt with S trace rows per particle; returns true when some particle needed more (nothing in res is valid then).
 template <class Caller>
-void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
-                      Result& res, HostStore* store)
+bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
+                     Result& res, HostStore* store, const std::size_t S)
 {
     using Tuple = typename Caller::observes_t;
     static_assert(std::is_trivially_copyable<Tuple>::value || true, "observes are copied to the device bytewise");
@@ -120,9 +121,7 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     hip_check(hipSetDevice(opt.device), "hipSetDevice");
     hipStream_t stream = static_cast<hipStream_t>(cpprob_hip_stream(ctx.get()));
     const int64_t ld = (int64_t)n;
-    // trace rows: the structural dry run saw st.n_sample sample statements; models with data-dependent loops
-    // (rejection sampling) may execute more on some particles, so leave head-room and detect overflow
-    const size_t n_real = st.real_ids.size(), n_int = st.int_ids.size(), S = 4 * st.n_sample + 16;
+    const size_t n_real = st.real_ids.size(), n_int = st.int_ids.size();
     const int T = (int)st.n_observe;
     const bool smc = algorithm == StateType::smc;
 
@@ -207,8 +206,20 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
     int32_t overflow = 0;
     hip_check(hipMemcpy(&overflow, d_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost), "read overflow flag");
-    if (overflow) throw std::runtime_error("cpprob::inference(smc): a particle executed more sample statements than the trace buffer holds "
-                                           "(data-dependent loop, e.g. rejection sampling); use StateType::sis for this model");
+    return overflow != 0;
+}
+
+template <class Caller>
+void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
+                      Result& res, HostStore* store)
+{
+    // trace rows: the structural dry run saw st.n_sample sample statements; particles of models with data-dependent loops
+    // (rejection sampling) may execute more -- start with head-room, and on overflow repeat the run with 4x the rows
+    std::size_t S = 4 * st.n_sample + 16;
+    for (int attempt = 0; attempt < 4; ++attempt, S *= 4)
+        if (!generic_attempt<Caller>(algorithm, observes_v, n, st, opt, res, store, S)) return;
+    throw std::runtime_error("cpprob::inference(smc): a particle executed more than " + std::to_string(S / 4) + " sample statements "
+                             "(data-dependent loop, e.g. rejection sampling, that rarely terminates); use StateType::sis for this model");
 }
 
 template <class FP, FP F>

@@ -170,11 +170,11 @@ def test_rejection_sampling_model_through_generic_sis(tmp_path):
     assert not res["builtin"] and p["address"] == "Mu"
     assert abs(p["mean"] - 3.0833333) < 0.012 and abs(p["variance"] - 0.8333333) < 0.02
     assert abs(res["ess"] / n - 0.344) < 0.02              # same importance-sampling efficiency as the direct prior draw
-    # SMC keeps 4x the dry run's trace rows; rejection loops are geometric (acceptance ~ 1/16 here): a particle may overflow,
-    # which must be reported, never silently truncated
-    r2, out, err = run_main(tmp_path, "--model", "gaussian_by_rejection", "--smc", "--observes", "3 4", "--n_samples", 50000, "--seed", 4, "--json",
-                            "--no_dump", expect_rc=None)
-    assert (r2 is not None and abs(r2["predicts"][0]["mean"] - 3.0833333) < 0.05) or "trace buffer" in err
+    # SMC keeps 4x the dry run's trace rows per particle; rejection loops are geometric (acceptance ~ 1/16 here), so some
+    # particle overflows them: the run is repeated with 4x more rows until every trace fits -- never silently truncated
+    r2, out, err = run_main(tmp_path, "--model", "gaussian_by_rejection", "--smc", "--observes", "3 4", "--n_samples", 200000, "--seed", 4, "--json",
+                            "--no_dump")
+    assert abs(r2["predicts"][0]["mean"] - 3.0833333) < 0.02 and abs(r2["predicts"][0]["variance"] - 0.8333333) < 0.03
 
 
 def test_functor_model_is_found_by_type(tmp_path):
