@@ -40,6 +40,7 @@ struct LaneCtx {
     uint32_t n_sample, n_observe, n_pred_real, n_pred_int;
     uint32_t n_stored;            // samples available in trace_in
     uint32_t trace_cap;           // rows of the trace buffers; a longer trace raises *overflow (rejection loops)
+    uint32_t pred_real_cap, pred_int_cap;   // predict columns the host allocated (hits seen by the structural dry run)
     int32_t* overflow;
     uint32_t n_recorded;          // samples executed before the lane was done
     int32_t first_observe;        // observes with a smaller index were weighted in earlier steps
@@ -140,12 +141,18 @@ __device__ inline void predict_impl(const T& x)
         LaneCtx& c = lane_ctx();
         if (c.done) return;
         const uint32_t k = c.n_pred_int++;
-        if (c.pred_int) c.pred_int[(int64_t)k * c.ld] = static_cast<int32_t>(x);
+        if (c.pred_int) {
+            if (k < c.pred_int_cap) c.pred_int[(int64_t)k * c.ld] = static_cast<int32_t>(x);
+            else if (c.overflow) *c.overflow = 2;                       // more predict hits than the dry run: data-dependent predicts
+        }
     } else if constexpr (std::is_floating_point<V>::value) {            // state.hpp:320-326 -> predict_real_
         LaneCtx& c = lane_ctx();
         if (c.done) return;
         const uint32_t k = c.n_pred_real++;
-        if (c.pred_real) c.pred_real[(int64_t)k * c.ld] = static_cast<double>(x);
+        if (c.pred_real) {
+            if (k < c.pred_real_cap) c.pred_real[(int64_t)k * c.ld] = static_cast<double>(x);
+            else if (c.overflow) *c.overflow = 2;
+        }
     } else {
         __builtin_trap();                                               // vector-valued: built-in kernels only (see sample_impl)
     }

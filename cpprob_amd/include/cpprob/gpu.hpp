@@ -55,6 +55,7 @@ struct ModelKernelArgs {
     double* pred_real; int32_t* pred_int;
     int32_t first_observe, stop_after;
     uint32_t trace_cap; int32_t* overflow;
+    uint32_t pred_real_cap, pred_int_cap;
 };
 
 // How the kernel reaches the model body: a function (by address, as a template argument) or a functor
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
     c.n_stored = a.nstored_in ? (uint32_t)a.nstored_in[src] : 0u;
     c.n_recorded = 0;
     c.trace_cap = a.trace_cap; c.overflow = a.overflow;
+    c.pred_real_cap = a.pred_real_cap; c.pred_int_cap = a.pred_int_cap;
     c.first_observe = a.first_observe; c.stop_after = a.stop_after; c.done = 0;
     Caller::call(*observes);                                      // the model body, cpprob.hpp:199
     const double carried = (!resampled && a.logw_in) ? a.logw_in[i] : 0.0;         // equal weights after resampling
@@ -139,6 +141,7 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
 
     ModelKernelArgs a{};
     a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed; a.trace_cap = (uint32_t)S; a.overflow = d_overflow.p;
+    a.pred_real_cap = (uint32_t)n_real; a.pred_int_cap = (uint32_t)n_int;
     const auto t_start = std::chrono::steady_clock::now();
     double log_z = 0.0;
     int cur = 0, n_resampled = 0;
@@ -206,6 +209,9 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
     int32_t overflow = 0;
     hip_check(hipMemcpy(&overflow, d_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost), "read overflow flag");
+    if (overflow == 2)
+        throw std::runtime_error("cpprob::inference: a particle executed more predict statements than the model's dry run did; the number "
+                                 "and order of observe / predict statements must not depend on sampled values on the device path");
     return overflow != 0;
 }
 
