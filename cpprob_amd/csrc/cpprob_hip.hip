@@ -585,7 +585,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
 int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_totals, int32_t world, int32_t rank)
 {
     if (!c || !d_all_totals) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
-    if (world < 1 || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank");
+    if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank (1 <= world <= 1024)");
     HIP_TRY(c, hipSetDevice(c->device));
     launch_scan(c, t, 2, d_all_totals, world, rank);
     HIP_TRY(c, hipGetLastError());
