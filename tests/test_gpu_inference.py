@@ -637,3 +637,25 @@ def test_back_to_back_runs_are_bitwise_reproducible(engine, golden_dir, n):
                     st, lz = engine.stats(), engine.summary()["log_evidence"]
                     assert np.array_equal(st, ref[idx][0]) and lz == ref[idx][1]
         assert not np.array_equal(ref[0][0], ref[1][0])
+
+
+@pytest.mark.parametrize("scope", ["auto", "global", "exchange"])
+def test_bench_two_ranks_on_one_gpu(scope):
+    """The N > 1 path of bench.py end to end -- torchrun, one process per rank, IslandBatch / run_joint / run_exchange --
+    with both ranks sharing cuda:0 and the collectives going through gloo (test hook CPPROB_DIST_BACKEND / CPPROB_FORCE_DEVICE:
+    RCCL refuses two ranks on one device).  Everything but the transport is the production code."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CPPROB_DIST_BACKEND="gloo", CPPROB_FORCE_DEVICE="0")
+    port = 29700 + (os.getpid() + hash(scope)) % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--particles", "200000", "--scope", scope, "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                          # rank 0 prints the one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["n_global"] == 400000 and d["value"] > 0
+    assert d["posterior_max_abs_err_vs_exact"] < 0.01 and abs(d["log_evidence"] + 26.326) < 0.02
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
