@@ -115,21 +115,26 @@ __device__ __forceinline__ void store4_as(S* __restrict__ p, int64_t i, const V 
     store4(p, i, raw);
 }
 
-// Streaming store: the particle store is written once per step and next read by a different kernel
-// (possibly on another XCD), so the lines need not stay in this XCD's L2.
+// Rows that the step kernels re-read (states, weights) use plain stores: they are wanted in L2.
 template <class T>
 __device__ __forceinline__ void store4_stream(T* __restrict__ p, int64_t i, const T (&v)[kPPT])
 {
-#ifdef CPPROB_NT_STORES
+    store4(p, i, v);
+}
+
+// Write-through store (sc1) for rows no step kernel reads again -- the ancestor rows, which only the read-out walks: they
+// reach memory while the kernel still runs instead of at its boundary, where dirty bytes cost time (-2 % per run at 10^6;
+// the same policy on re-read rows costs up to +33 %: profiles/r01_ab_notes.md).
+__device__ __forceinline__ void store4_write_through(int32_t* __restrict__ p, int64_t i, const int32_t (&v)[kPPT])
+{
+    using I4 = int __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int q = 0; q < kPPT; q += 4) {
-        typename Vec4<T>::type x;
-        x[0] = v[q]; x[1] = v[q + 1]; x[2] = v[q + 2]; x[3] = v[q + 3];
-        __builtin_nontemporal_store(x, reinterpret_cast<typename Vec4<T>::type*>(p + i + q));
+        I4 w;
+        w[0] = v[q]; w[1] = v[q + 1]; w[2] = v[q + 2]; w[3] = v[q + 3];
+        int32_t* addr = p + i + q;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(addr), "v"(w) : "memory");
     }
-#else
-    store4(p, i, v);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1184,7 +1189,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         for (int k = 0; k < kPPT; ++k) xs[k] = static_cast<typename Model::store_t>(x[k]);
         store4_stream(a.values + (int64_t)t * a.rs, j0, xs);                                  // predict #t
     }
-    store4_stream(a.anc + (int64_t)t * a.rs, j0, anc);
+    store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
     double e[kPPT];
     const bool fresh = (t == 0) || resample;                                                  // every particle starts the step at log-weight lwa
     if (Model::kWeightTable > 0 && fresh) {
