@@ -248,6 +248,8 @@ void launch_step(cpprob_hip_ctx* c, int t)
         static const int min_tiles = getenv("CPPROB_WREL_FROM_STATE_MIN_TILES") ? atoi(getenv("CPPROB_WREL_FROM_STATE_MIN_TILES")) : 256;
         a.wrel_from_state = (enabled && Model::kWeightTable > 0 && c->cfg.ess_threshold > 1.0 && c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC &&
                              !c->step_protocol && c->nb >= min_tiles) ? 1 : 0;
+        static const bool counts = !(getenv("CPPROB_PART_COUNTS") && getenv("CPPROB_PART_COUNTS")[0] == '0');
+        a.part_counts = (counts && a.wrel_from_state && step_is_fused(c)) ? 1 : 0;
     }
     a.exchange = (c->exchange && c->step_protocol) ? 1 : 0; a.imm_l0 = c->imm_l0; a.imm_l1 = c->imm_l1; a.imm_col0 = c->imm_col0;
 #ifdef CPPROB_STAMPS

@@ -983,6 +983,7 @@ struct StepArgs {
     double n_pop, ess_frac;   // FUSED: ESS test
     double* ess_trace; int32_t* resampled;
     int store_logw;           // 0: every step resamples (known on the host), so only the last step's log-weights are ever read
+    int part_counts;          // with wrel_from_state in the fused form: tile partials between steps are packed per-value counts
     int wrel_from_state;      // table-weight model, every step resamples systematically: weights of generation t-1 = e_tab[t-1][state] (WeightSource)
     int64_t rs;               // row stride of values[] / anc[] (ld plus the immigrant annex)
     // exchange scope (exact global resampling over shards): outputs [imm_l0, imm_l1) of this shard descend from local
@@ -992,9 +993,40 @@ struct StepArgs {
 
 // Tile partial when every particle's log-weight is lwa + (one of K table values): no exp, no fp64
 // reduction -- per-value counts by ballot + popcount (scalar unit), one barrier.
+//
+// {sum e, sum e^2} of a tile from its per-value counts: the one place this arithmetic lives (producer and consumers must agree
+// to the bit).
+template <int K>
+__device__ __forceinline__ void table_sums(const int (&c)[K], const double (&e_tab)[K], double& sm, double& q)
+{
+    sm = 0.0; q = 0.0;
+#pragma unroll
+    for (int s2 = 0; s2 < K; ++s2) {
+        sm += (double)c[s2] * e_tab[s2];
+        q += (double)c[s2] * (e_tab[s2] * e_tab[s2]);
+    }
+}
+// A tile partial as packed counts (16 bits per table value): 8 bytes per tile instead of 24 for the step kernels' all-to-all
+static_assert(kTile <= 65535, "packed counts hold 16 bits per value");
+template <int K>
+__device__ __forceinline__ uint64_t pack_counts(const int (&c)[K])
+{
+    static_assert(K <= 4, "four 16-bit counts per word");
+    uint64_t w = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < K; ++s2) w |= (uint64_t)(uint32_t)c[s2] << (16 * s2);
+    return w;
+}
+template <int K>
+__device__ __forceinline__ void unpack_counts(uint64_t w, int (&c)[K])
+{
+#pragma unroll
+    for (int s2 = 0; s2 < K; ++s2) c[s2] = (int)((w >> (16 * s2)) & 0xFFFFu);
+}
+
 template <int K>
 __device__ __forceinline__ void tile_partial_table(const int (&idx)[kPPT], const bool (&valid)[kPPT], const double (&e_tab)[K], double m_ref,
-                                                   double (&e)[kPPT], Partial* __restrict__ part, int* s_cnt /* kWaves*K ints */)
+                                                   double (&e)[kPPT], Partial* __restrict__ part, int* s_cnt /* kWaves*K ints */, bool counts_out)
 {
     int cnt[K];
 #pragma unroll
@@ -1015,16 +1047,20 @@ __device__ __forceinline__ void tile_partial_table(const int (&idx)[kPPT], const
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double sm = 0.0, q = 0.0;
+        int c[K];
 #pragma unroll
         for (int s2 = 0; s2 < K; ++s2) {
-            int c = 0;
+            c[s2] = 0;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) c += s_cnt[w * K + s2];
-            sm += (double)c * e_tab[s2];
-            q += (double)c * (e_tab[s2] * e_tab[s2]);
+            for (int w = 0; w < kWaves; ++w) c[s2] += s_cnt[w * K + s2];
         }
-        put_partial(part, (int)gridDim.x, (int)blockIdx.x, m_ref, sm, q);
+        if (counts_out) {
+            reinterpret_cast<uint64_t*>(part)[blockIdx.x] = pack_counts<K>(c);   // the next step kernel rebuilds {sum, sum of squares}
+        } else {
+            double sm, q;
+            table_sums<K>(c, e_tab, sm, q);
+            put_partial(part, (int)gridDim.x, (int)blockIdx.x, m_ref, sm, q);
+        }
     }
 }
 
@@ -1077,20 +1113,45 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
             const double* pm = a.part_prev; const double* psum = a.part_prev + pst; const double* pq = a.part_prev + 2 * pst;
             const int c0 = tid * kPer;
             double rm[kPer], rs[kPer], rq[kPer];
+            double M;
+            if (Model::kWeightTable > 0 && a.part_counts) {
+                // packed counts (8 B per tile): every tile shares the reference lwa + the step's largest table value, so
+                // there is no max to reduce, and {sum, sum of squares} follow from the counts
+                constexpr int K = Model::kWeightTable > 0 ? Model::kWeightTable : 1;
+                const uint64_t* pc = reinterpret_cast<const uint64_t*>(a.part_prev);
+                uint64_t wv[kPer];
 #pragma unroll
-            for (int i = 0; i < kPer; i += 2) {                      // 16-B loads (the arrays are padded past nb)
-                const double2 vm = *reinterpret_cast<const double2*>(pm + c0 + i);
-                const double2 vs = *reinterpret_cast<const double2*>(psum + c0 + i);
-                const double2 vq = *reinterpret_cast<const double2*>(pq + c0 + i);
-                rm[i] = vm.x; rm[i + 1] = vm.y; rs[i] = vs.x; rs[i + 1] = vs.y; rq[i] = vq.x; rq[i + 1] = vq.y;
-            }
-            double m = -INFINITY;
+                for (int i = 0; i < kPer; i += 2) {
+                    const ulonglong2 v2 = *reinterpret_cast<const ulonglong2*>(pc + c0 + i);
+                    wv[i] = v2.x; wv[i + 1] = v2.y;
+                }
+                double ll[K], et[K], mref;
+                Model::weight_table(a.mp, t - 1, ll, et, mref);
+                M = mref;
 #pragma unroll
-            for (int i = 0; i < kPer; ++i) {
-                if (c0 + i >= a.nb) { rm[i] = -INFINITY; rs[i] = 0.0; rq[i] = 0.0; }
-                m = fmax(m, rm[i]);
+                for (int i = 0; i < kPer; ++i) {
+                    int c[K];
+                    unpack_counts<K>(wv[i], c);
+                    table_sums<K>(c, et, rs[i], rq[i]);
+                    rm[i] = M;
+                    if (c0 + i >= a.nb) { rm[i] = -INFINITY; rs[i] = 0.0; rq[i] = 0.0; }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kPer; i += 2) {                      // 16-B loads (the arrays are padded past nb)
+                    const double2 vm = *reinterpret_cast<const double2*>(pm + c0 + i);
+                    const double2 vs = *reinterpret_cast<const double2*>(psum + c0 + i);
+                    const double2 vq = *reinterpret_cast<const double2*>(pq + c0 + i);
+                    rm[i] = vm.x; rm[i + 1] = vm.y; rs[i] = vs.x; rs[i + 1] = vs.y; rq[i] = vq.x; rq[i + 1] = vq.y;
+                }
+                double m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < kPer; ++i) {
+                    if (c0 + i >= a.nb) { rm[i] = -INFINITY; rs[i] = 0.0; rq[i] = 0.0; }
+                    m = fmax(m, rm[i]);
+                }
+                M = block_max(m, s_scr);
             }
-            const double M = block_max(m, s_scr);
             double Q = 0.0, S = 0.0, ev[kPer];
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
@@ -1206,7 +1267,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
             for (int s2 = 1; s2 < K; ++s2) l = idx[k] == s2 ? ll[s2] : l;
             lw[k] = valid[k] ? lw[k] + l : -INFINITY;
         }
-        tile_partial_table<K>(idx, valid, et, (t == 0 ? 0.0 : lwa) + mref, e, a.part, s_cnt);
+        tile_partial_table<K>(idx, valid, et, (t == 0 ? 0.0 : lwa) + mref, e, a.part, s_cnt, FUSED && a.part_counts && t + 1 < a.T);
     } else {
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
