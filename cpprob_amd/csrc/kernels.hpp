@@ -142,7 +142,7 @@ __device__ __forceinline__ void store4_write_through(int32_t* __restrict__ p, in
 // weights e = exp(lw - max) are returned for the wrel store.  lw of padding slots must be -inf.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile_partial(const double (&lw)[kPPT], double (&e)[kPPT], Partial* __restrict__ part,
-                                             double* s_scr /* >= 3*kWaves doubles, unused by any in-flight combine */)
+                                             double* s_scr /* >= 3*kWaves doubles, unused by any in-flight combine */, int tile)
 {
     double m = lw[0];
 #pragma unroll
@@ -155,7 +155,7 @@ __device__ __forceinline__ void tile_partial(const double (&lw)[kPPT], double (&
         s += e[k]; q += e[k] * e[k];
     }
     block_sum2(s, q, s_scr + kWaves);
-    if (threadIdx.x == 0) put_partial(part, (int)gridDim.x, (int)blockIdx.x, m, s, q);
+    if (threadIdx.x == 0) put_partial(part, (int)gridDim.x, tile, m, s, q);
 }
 
 // Standalone: partials + linear weights of an arbitrary log-weight array of n entries
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void weights_partials_kernel(const double
     double lw[kPPT], e[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) lw[k] = (j0 + k < n) ? logw[j0 + k] : -INFINITY;
-    tile_partial(lw, e, part, s_scr);
+    tile_partial(lw, e, part, s_scr, (int)blockIdx.x);
     store4(wrel, j0, e);
 }
 
@@ -647,10 +647,9 @@ struct WeightSource {
 template <class WS>
 __device__ __forceinline__ void ancestors_systematic_fused(const WS& ws, const double* s_bc, const double* s_bf, int nb,
                                                             double u0, double inv, int n_valid_tile, const double (&w_own)[kPPT],
-                                                            int32_t (&anc)[kPPT], AncestorLds& L)
+                                                            int32_t (&anc)[kPPT], AncestorLds& L, const int b /* this workgroup's output tile */)
 {
     const int tid = threadIdx.x;
-    const int b = (int)blockIdx.x;
     const double gj_first = (double)((int64_t)b * kTile), gj_last = gj_first + (double)(n_valid_tile - 1);
     auto gt = [&](int c) -> double { return c >= nb ? INFINITY : (c < 0 ? -INFINITY : g_of(s_bc[c], inv, u0)); };
     const double g_m1 = gt(b - 1), g_0 = gt(b), g_p1 = gt(b + 1), g_p2 = gt(b + 2), g_p3 = gt(b + 3);
@@ -949,7 +948,7 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
         if (j0 + k >= a.n) lw[k] = -INFINITY;                                                 // padding slots
     store4(a.logw, j0, lw);                                                                   // finish_trace()
     double e[kPPT];
-    tile_partial(lw, e, a.part, s_scr);
+    tile_partial(lw, e, a.part, s_scr, (int)blockIdx.x);
     store4(a.wrel, j0, e);
 }
 
@@ -969,6 +968,18 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
 // un-fused form at ~1.7e6 particles (profiles/r01_ab_notes.md), hence 1664 tiles rather than the 2048 the prologue could hold.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFuseMaxTiles = 1664;
+
+// blockIdx -> tile such that the workgroups with equal blockIdx % 8 (one XCD under round-robin dispatch; only speed depends on
+// that) own a contiguous range of tiles.  A bijection of [0, nb) for every nb.
+__device__ __forceinline__ int xcd_contiguous_tile(int b, int nb)
+{
+#ifdef CPPROB_NO_XCD_SWIZZLE
+    return b;
+#else
+    const int x = b & 7, j = b >> 3, q = nb >> 3, r = nb & 7;
+    return x * q + (x < r ? x : r) + j;
+#endif
+}
 
 template <class Model>
 struct StepArgs {
@@ -1026,7 +1037,7 @@ __device__ __forceinline__ void unpack_counts(uint64_t w, int (&c)[K])
 
 template <int K>
 __device__ __forceinline__ void tile_partial_table(const int (&idx)[kPPT], const bool (&valid)[kPPT], const double (&e_tab)[K], double m_ref,
-                                                   double (&e)[kPPT], Partial* __restrict__ part, int* s_cnt /* kWaves*K ints */, bool counts_out)
+                                                   double (&e)[kPPT], Partial* __restrict__ part, int* s_cnt /* kWaves*K ints */, bool counts_out, int tile)
 {
     int cnt[K];
 #pragma unroll
@@ -1055,11 +1066,11 @@ __device__ __forceinline__ void tile_partial_table(const int (&idx)[kPPT], const
             for (int w = 0; w < kWaves; ++w) c[s2] += s_cnt[w * K + s2];
         }
         if (counts_out) {
-            reinterpret_cast<uint64_t*>(part)[blockIdx.x] = pack_counts<K>(c);   // the next step kernel rebuilds {sum, sum of squares}
+            reinterpret_cast<uint64_t*>(part)[tile] = pack_counts<K>(c);   // the next step kernel rebuilds {sum, sum of squares}
         } else {
             double sm, q;
             table_sums<K>(c, e_tab, sm, q);
-            put_partial(part, (int)gridDim.x, (int)blockIdx.x, m_ref, sm, q);
+            put_partial(part, (int)gridDim.x, tile, m_ref, sm, q);
         }
     }
 }
@@ -1075,7 +1086,10 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
     __shared__ double s_scr[3 * kWaves];
     __shared__ int s_cnt[kWaves * 4];
     const int tid = threadIdx.x;
-    const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)tid * kPPT;
+    // output tile of this workgroup: workgroups that share an XCD (blockIdx % 8, round-robin dispatch) take a CONTIGUOUS range
+    // of tiles, so the neighbouring source tiles a workgroup reads were requested by its XCD's other workgroups too (one L2)
+    const int bid = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
+    const int64_t j0 = (int64_t)bid * kTile + (int64_t)tid * kPPT;
     const int t = a.t;
     double* s_bc = s_dyn;
     double* s_bf = s_dyn + (a.nb + 1);
@@ -1175,7 +1189,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
             inv_stepw = (double)a.n / W;
             lwa = 0.0;
             u0 = a.ctrl->u0_pp[t & 1];                                        // left there by workgroup 0 of step t-1
-            if (blockIdx.x == 0 && tid == 0) {                                // bookkeeping for the host
+            if (bid == 0 && tid == 0) {                                       // bookkeeping for the host
                 StepCtrl* c = a.ctrl;
                 c->M = M; c->W = W; c->Q = Q; c->ess = ess; c->do_resample = resample ? 1 : 0;
                 c->cdf_lo = 0.0; c->w_local = W; c->scale = 1.0; c->u0 = u0; c->inv_stepw = inv_stepw; c->lw_after = 0.0;
@@ -1203,21 +1217,21 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
         if (RS == RS_PRECOMPUTED) {
             load4(a.anc_pre, j0, anc);
         } else {
-            const int64_t rem = a.n - (int64_t)blockIdx.x * kTile;
+            const int64_t rem = a.n - (int64_t)bid * kTile;
             AncestorIn in;
             in.wrel = a.wrel_prev; in.nb = a.nb; in.n_in = a.n;
             if (FUSED) { in.bc = s_bc; in.bf = s_bf; in.bc_in_lds = 1; } else { in.bc = a.bc; in.bf = a.bf; in.bc_in_lds = 0; }
             in.W = in.bc[a.nb]; in.scale = 1.0; in.cdf_lo = 0.0; in.u0 = u0; in.inv_stepw = inv_stepw;
-            in.seed = a.seed; in.step = (uint64_t)t; in.gj_tile0 = (uint64_t)blockIdx.x * kTile; in.n_total_out = (uint64_t)a.n;
+            in.seed = a.seed; in.step = (uint64_t)t; in.gj_tile0 = (uint64_t)bid * kTile; in.n_total_out = (uint64_t)a.n;
             in.id0 = a.pid0;
             in.n_valid_tile = rem < kTile ? (int)rem : kTile;
-            in.guess = (int)blockIdx.x;
+            in.guess = bid;
             in.g_end = INFINITY;
             if (!FUSED && a.exchange) {                       // positions and outputs in global terms
                 in.scale = a.ctrl->scale; in.cdf_lo = a.ctrl->cdf_lo; in.inv_stepw = a.ctrl->inv_global; in.g_end = a.ctrl->g_end;
-                in.gj_tile0 = a.pid0 + (uint64_t)blockIdx.x * kTile; in.n_total_out = (uint64_t)a.n_pop; in.guess = -1;
+                in.gj_tile0 = a.pid0 + (uint64_t)bid * kTile; in.n_total_out = (uint64_t)a.n_pop; in.guess = -1;
             }
-            if (FUSED && RS == RS_SYSTEMATIC) ancestors_systematic_fused(ws, s_bc, s_bf, a.nb, u0, inv_stepw, in.n_valid_tile, w_own, anc, L);
+            if (FUSED && RS == RS_SYSTEMATIC) ancestors_systematic_fused(ws, s_bc, s_bf, a.nb, u0, inv_stepw, in.n_valid_tile, w_own, anc, L, bid);
             else find_ancestors<RS>(in, anc, L, ws);
         }
 #pragma unroll
@@ -1267,19 +1281,19 @@ __global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
             for (int s2 = 1; s2 < K; ++s2) l = idx[k] == s2 ? ll[s2] : l;
             lw[k] = valid[k] ? lw[k] + l : -INFINITY;
         }
-        tile_partial_table<K>(idx, valid, et, (t == 0 ? 0.0 : lwa) + mref, e, a.part, s_cnt, FUSED && a.part_counts && t + 1 < a.T);
+        tile_partial_table<K>(idx, valid, et, (t == 0 ? 0.0 : lwa) + mref, e, a.part, s_cnt, FUSED && a.part_counts && t + 1 < a.T, bid);
     } else {
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
             lw[k] += Model::loglik(a.mp, x[k], t, a.obs);                                     // observe #t
             if (!valid[k]) lw[k] = -INFINITY;                                                 // padding slots
         }
-        tile_partial(lw, e, a.part, s_scr);
+        tile_partial(lw, e, a.part, s_scr, bid);
     }
     CPH_STAMP(10);
     if (a.store_logw || t + 1 == a.T) store4_stream(a.logw_next, j0, lw);
     if (!a.wrel_from_state || t + 1 == a.T) store4_stream(a.wrel_next, j0, e);   // otherwise the next step reads the states
-    if (FUSED && blockIdx.x == 0 && tid == 0 && t + 1 < a.T) {              // systematic offset of the resampling before step t+1
+    if (FUSED && bid == 0 && tid == 0 && t + 1 < a.T) {              // systematic offset of the resampling before step t+1
         const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(t + 1));
         a.ctrl->u0_pp[(t + 1) & 1] = u01_53(r.x, r.y);
     }
