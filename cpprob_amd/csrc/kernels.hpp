@@ -1328,7 +1328,8 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
     __syncthreads();
     const double scale = a.ctrl->scale;
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // (one XCD's workgroups walk neighbouring tiles: their lineages converge on the same ancestor rows)
+    for (int64_t tile = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x); tile < ntiles; tile += gridDim.x) {
         const double f = a.bf[tile] * scale;
         int32_t idx[kPPT]; double w[kPPT];
 #pragma unroll
