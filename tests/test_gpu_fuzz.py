@@ -1,0 +1,87 @@
+"""Randomised (fixed-seed) sweeps over population sizes, step counts, resamplers, ESS thresholds and shard layouts: structural
+invariants of every SMC run through the C ABI, and the exchange scope against the single-context run."""
+import os
+
+import numpy as np
+import pytest
+
+import cpprob_amd as cp
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+EDGE_SIZES = [1, 2, 1023, 1024, 1025, 262143, 262144, 262145, 1048576, 1048577, 1703936, 1703937, 2097153]
+
+
+@pytest.mark.parametrize("sweep", [11, 12, 13])
+def test_random_smc_runs_keep_their_invariants(engine, golden_dir, sweep):
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    rng = np.random.default_rng(sweep)
+    for _ in range(40):
+        model = [cp.MODEL_HMM3, cp.MODEL_LINEAR_GAUSSIAN_1D][rng.integers(0, 2)]
+        T = int(rng.integers(1, 24))
+        obs = (z["hmm128"] if model == cp.MODEL_HMM3 else z["lgssm100"])[:T] * (1.0 + 3.0 * (rng.random() < 0.2))   # sometimes outlying
+        n = int(max(1, rng.integers(1, 10) * rng.choice([1e1, 1e2, 1e3, 1e4, 1e5, 1e6]) / 3))
+        if rng.random() < 0.25:
+            n = int(rng.choice(EDGE_SIZES))                          # tile / fuse / weights-from-states thresholds
+        ess = float(rng.choice([2.0, 0.5, 0.9, 0.1, 0.0]))
+        rs = int(rng.choice([0, 0, 0, 1, 2]))
+        if rs == cp.RESAMPLE_MULTINOMIAL:
+            n = min(n, 400000)
+        seed = int(rng.integers(0, 2**31))
+        tag = "model %d T %d n %d ess %.1f resampler %d seed %d" % (model, T, n, ess, rs, seed)
+        engine.begin(cp.ALG_SMC, model, obs, n, seed=seed, resampler=rs, ess_threshold=ess)
+        engine.run(0)
+        st, s = engine.stats().copy(), engine.summary()
+        anc, vals = engine.ancestors(), engine.values()
+        assert np.isfinite(st).all() and np.isfinite(s["log_evidence"]), tag
+        if model == cp.MODEL_HMM3:
+            assert np.allclose(st.sum(1), 1.0, rtol=1e-10) and vals.min() >= 0 and vals.max() <= 2, tag
+        if T > 1:
+            assert anc[1:].min() >= 0 and anc[1:].max() < n, tag
+            if rs != cp.RESAMPLE_MULTINOMIAL:
+                assert np.all(np.diff(anc[1:].astype(np.int64), axis=1) >= 0), tag        # sorted ancestors
+        ess_tr, res = engine.step_trace()
+        assert res[-1] == 0 and (ess_tr > 0).all() and (ess_tr <= n * (1 + 1e-9)).all(), tag
+        if ess == 0.0:
+            assert res.sum() == 0, tag
+        if ess > 1.0:
+            assert res[:-1].all(), tag
+        if n <= 300000:
+            # read-out == the oracle's estimator applied to the device's own store; paths == lineages of that store
+            assert np.allclose(st, O.smoothing(vals, anc, engine.logw()), rtol=1e-8, atol=1e-10), tag
+            assert np.array_equal(engine.paths(), np.take_along_axis(vals, O.lineage(anc), axis=1)), tag
+        engine.run(0)
+        assert np.array_equal(engine.stats(), st) and engine.summary()["log_evidence"] == s["log_evidence"], tag   # reproducible
+
+
+@pytest.mark.parametrize("sweep", [21, 22])
+def test_random_shard_layouts_exchange_scope(engine, golden_dir, sweep):
+    """Exchange scope over random shard layouts (2..5 virtual ranks, sizes from 1 particle up, outlying observations that
+    shift the mass between shards): the shards' traces are the single-context traces, up to isolated boundary flips."""
+    from test_gpu_inference import _run_exchange_virtual
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    rng = np.random.default_rng(sweep)
+    for _ in range(8):
+        model = [cp.MODEL_HMM3, cp.MODEL_LINEAR_GAUSSIAN_1D][rng.integers(0, 2)]
+        T = int(rng.integers(2, 14))
+        obs = np.array((z["hmm128"] if model == cp.MODEL_HMM3 else z["lgssm100"])[:T])
+        if rng.random() < 0.4:
+            obs[rng.integers(0, T)] *= 4.0
+        world = int(rng.integers(2, 6))
+        n_pers = [int(max(1, rng.integers(1, 60000) if rng.random() < 0.8 else rng.integers(1, 5))) for _ in range(world)]
+        ess = float(rng.choice([2.0, 0.5]))
+        seed = int(rng.integers(0, 2**31))
+        tag = "model %d T %d shards %s ess %.1f seed %d" % (model, T, n_pers, ess, seed)
+        n = int(sum(n_pers))
+        engine.begin(cp.ALG_SMC, model, obs, n, seed=seed, ess_threshold=ess)
+        engine.run()
+        ref_paths, ref_stats, ref_sum = engine.paths(), engine.stats().copy(), engine.summary()
+        stats, s, paths, _, moved = _run_exchange_virtual(model, obs, n_pers, seed, ess)
+        got = np.concatenate(paths, axis=1)
+        differing = (got != ref_paths).any(axis=0).sum()
+        assert differing <= max(2, n // 20000), tag                                  # isolated CDF-boundary flips only
+        assert s["n_resampled"] == ref_sum["n_resampled"], tag
+        if differing == 0:
+            np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-11, err_msg=tag)
+            assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-11, tag
