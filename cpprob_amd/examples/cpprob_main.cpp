@@ -53,7 +53,16 @@ void print_json(const cpprob::gpu::Result& r)
             std::cout << "}";
         }
     }
-    std::cout << "]}" << std::endl;
+    std::cout << "]";
+    if (r.n_replicates > 1) {
+        std::cout << ", \"replicates\": " << r.n_replicates << ", \"log_evidence_mean\": " << r.log_evidence_mean << ", \"log_evidence_sd\": " << r.log_evidence_sd
+                  << ", \"replicates_seconds\": " << r.replicates_seconds << ", \"predict_mean\": [";
+        for (std::size_t h = 0; h < r.predict_mean.size(); ++h) std::cout << (h ? ", " : "") << r.predict_mean[h];
+        std::cout << "], \"predict_sd\": [";
+        for (std::size_t h = 0; h < r.predict_sd.size(); ++h) std::cout << (h ? ", " : "") << r.predict_sd[h];
+        std::cout << "]";
+    }
+    std::cout << "}" << std::endl;
 }
 
 template <class F>
@@ -110,6 +119,7 @@ int main(int argc, char** argv)
         else if (f == "--resampler") { const std::string r = next(); opt.resampler = r == "multinomial" ? 2 : (r == "stratified" ? 1 : 0); }
         else if (f == "--generic") opt.prefer_builtin = false;
         else if (f == "--repeat") a.repeat = std::stoi(next());
+        else if (f == "--replicates") opt.replicates = std::stoi(next());
         else if (f == "--no_dump") opt.dump = false;
         else if (f == "--json") a.json = true;
         else { std::cerr << "unknown option " << f << std::endl; return EXIT_FAILURE; }

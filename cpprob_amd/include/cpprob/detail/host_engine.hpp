@@ -11,6 +11,8 @@
 #include <fstream>
 #include <iomanip>
 #include <limits>
+#include <memory>
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -141,6 +143,64 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
         ctx.check(cpprob_hip_copy_logw(ctx.get(), store->logw.data(), n * sizeof(double)), "cpprob_hip_copy_logw");
         if (s.is_int) { store->ints.resize(T * n); ctx.check(cpprob_hip_copy_paths(ctx.get(), store->ints.data(), T * n * sizeof(std::int32_t)), "cpprob_hip_copy_paths"); }
         else { store->real.resize(T * n); ctx.check(cpprob_hip_copy_paths(ctx.get(), store->real.data(), T * n * sizeof(double)), "cpprob_hip_copy_paths"); }
+    }
+    // ---- replicates (error bars): further seeds, up to three runs in flight on contexts of their own ----
+    const int R = opt.replicates;
+    if (R > 1) {
+        const std::size_t H = res.predicts.size();
+        res.n_replicates = R;
+        res.replicate_values.assign(H, std::vector<double>(static_cast<std::size_t>(R), 0.0));
+        std::vector<double> lz(static_cast<std::size_t>(R), 0.0);
+        auto value_of = [&](const std::vector<double>& stv, std::size_t hit) {          // mean of component 0 / P(x = 0)
+            if (s.is_int) return stv[hit * K];
+            std::size_t row = 0;
+            for (std::size_t k = 0; k < hit; ++k) row += st.real_width[k];
+            return stv[row * K];
+        };
+        for (std::size_t h = 0; h < H; ++h) res.replicate_values[h][0] = value_of(stats, h);
+        lz[0] = s.log_evidence;
+        const int lanes = R - 1 < 3 ? R - 1 : 3;
+        std::vector<std::unique_ptr<Context>> extra;
+        for (int l = 0; l < lanes; ++l) {
+            extra.emplace_back(new Context(opt.device));
+            extra.back()->check(cpprob_hip_infer_begin(extra.back()->get(), &cfg, obs.data(), obs.size()), "cpprob_hip_infer_begin");
+        }
+        std::vector<int> pending(static_cast<std::size_t>(lanes), -1);
+        auto harvest = [&](int l) {
+            const int r = pending[static_cast<std::size_t>(l)];
+            if (r < 0) return;
+            cpprob_hip_summary sr{};
+            std::vector<double> str(T * K);
+            extra[l]->check(cpprob_hip_infer_summary(extra[l]->get(), &sr), "cpprob_hip_infer_summary");
+            extra[l]->check(cpprob_hip_infer_stats(extra[l]->get(), str.data(), str.size()), "cpprob_hip_infer_stats");
+            lz[static_cast<std::size_t>(r)] = sr.log_evidence;
+            for (std::size_t h = 0; h < H; ++h) res.replicate_values[h][static_cast<std::size_t>(r)] = value_of(str, h);
+            pending[static_cast<std::size_t>(l)] = -1;
+        };
+        const auto tr0 = std::chrono::steady_clock::now();
+        for (int r = 1; r < R; ++r) {
+            const int l = (r - 1) % lanes;
+            harvest(l);                                               // synchronises that context only; the others keep running
+            extra[l]->check(cpprob_hip_infer_run(extra[l]->get(), static_cast<std::uint64_t>(r)), "cpprob_hip_infer_run");
+            pending[static_cast<std::size_t>(l)] = r;
+        }
+        for (int l = 0; l < lanes; ++l) harvest(l);
+        res.replicates_seconds = res.run_seconds + std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+        res.predict_mean.assign(H, 0.0); res.predict_sd.assign(H, 0.0);
+        for (std::size_t h = 0; h < H; ++h) {
+            double m = 0, v = 0;
+            for (double x : res.replicate_values[h]) m += x;
+            m /= R;
+            for (double x : res.replicate_values[h]) v += (x - m) * (x - m);
+            res.predict_mean[h] = m; res.predict_sd[h] = std::sqrt(v / (R - 1));
+        }
+        double mx = lz[0], acc = 0, ml = 0, vl = 0;
+        for (double x : lz) { mx = std::max(mx, x); ml += x; }
+        for (double x : lz) acc += std::exp(x - mx);
+        ml /= R;
+        for (double x : lz) vl += (x - ml) * (x - ml);
+        res.log_evidence_mean = mx + std::log(acc / R);
+        res.log_evidence_sd = std::sqrt(vl / (R - 1));
     }
 }
 

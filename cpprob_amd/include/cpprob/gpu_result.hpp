@@ -21,6 +21,8 @@ struct Options {
     std::size_t dump_max_particles = 0;               // 0 = all particles
     bool prefer_builtin = true;                       // use the hand-fused kernels when the model is one of the built-ins
     bool progress = false;
+    int replicates = 1;                               // built-in models: R independent runs (seeds seed .. seed + R - 1), up to three in
+                                                      // flight on separate contexts; Result then carries their spread (error bars)
 };
 
 struct PredictStats {            // one per predict hit, StatsPrinter's numbers
@@ -39,6 +41,12 @@ struct Result {
     double run_seconds = 0;                   // device work of the run (launch to synchronise), excluding allocation and dumps
     std::vector<PredictStats> predicts;       // real hits first (in trace order), then int hits
     std::vector<double> step_ess;             // smc: ESS after each observe
+    // Options::replicates > 1: replicate 0 is what the fields above (and the dump) describe; across replicates:
+    int n_replicates = 1;
+    double log_evidence_mean = 0, log_evidence_sd = 0;        // log of the mean evidence (unbiased in Z); sd of the log estimates
+    std::vector<std::vector<double>> replicate_values;        // [predict hit][replicate]: mean (real, component 0) or P(x = 0) (int)
+    std::vector<double> predict_mean, predict_sd;             // per predict hit over the replicates
+    double replicates_seconds = 0;                            // device time of all replicates together
 };
 
 inline Options& options() { static thread_local Options o; return o; }

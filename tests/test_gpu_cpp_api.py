@@ -215,3 +215,22 @@ def test_vector_valued_statements_gaussian_2d(tmp_path):
     assert len(got) == 2 and abs(got[0] - p["mean_nd"][0]) < 1e-4 and abs(got[1] - p["mean_nd"][1]) < 1e-4
     res2, _, _ = run_main(tmp_path, "--model", "gaussian_2d_unk_mean", "--smc", "--observes", obs_str(y), "--n_samples", n, "--seed", 11, "--json", "--no_dump")
     assert res2["predicts"][0]["mean_nd"] == p["mean_nd"] and res2["n_resampled"] == 0
+
+
+def test_replicates_give_error_bars(tmp_path):
+    """Options::replicates (CLI --replicates): R seeds of the same inference, up to three runs in flight on their own contexts;
+    the spread over the replicates is the Monte-Carlo error bar (seeds for error bars)."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    n, R = 200000, 6
+    res, _, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(z["hmm16"]), "--n_samples", n, "--seed", 40, "--ess_threshold", "2.0",
+                         "--json", "--no_dump", "--replicates", R)
+    assert res["replicates"] == R and len(res["predict_mean"]) == 16 and len(res["predict_sd"]) == 16
+    exact = z["hmm16_smooth"][:, 0]
+    pm, sd = np.array(res["predict_mean"]), np.array(res["predict_sd"])
+    assert (sd > 0).all() and sd.max() < 5e-3                       # ~1e-3 at 2e5 particles
+    assert np.all(np.abs(pm - exact) < 5 * sd / np.sqrt(R) + 1e-3)  # the replicate mean sits within its own error bar of the truth
+    assert abs(res["log_evidence_mean"] - float(z["hmm16_logz"])) < 0.01 and 0 < res["log_evidence_sd"] < 0.02
+    # replicate 0 is the plain run with the same seed
+    one, _, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(z["hmm16"]), "--n_samples", n, "--seed", 40, "--ess_threshold", "2.0",
+                         "--json", "--no_dump")
+    assert one["log_evidence"] == res["log_evidence"] and one["predicts"][0]["p"] == res["predicts"][0]["p"]
