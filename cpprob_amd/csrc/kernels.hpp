@@ -1,14 +1,17 @@
 // Particle kernels of the SIS / SMC engine (gfx950, wave64, fp64).
 //
 // Data layout in HBM (one context = one shard of the population):
-//   values   [T][ld]   value of predict hit t in slot i of generation t (fp64 or int32);
-//                      row t-1 doubles as the state the step-t kernel reads (no separate state)
-//   anc      [T][ld]   int32 slot of generation t-1 extended by slot i of generation t
+//   values   [T][rs]   value of predict hit t in slot i of generation t, stored as Model::store_t (fp64; one byte for the
+//                      HMM's states); row t-1 doubles as the state the step-t kernel reads (no separate state).
+//                      rs = ld + the immigrant annex of the exchange scope (0 otherwise)
+//   anc      [T][rs]   int32 slot of generation t-1 extended by slot i of generation t (stored write-through)
 //   logw     [2][ld]   fp64 log-weights, ping-pong between steps
 //   wrel     [2][ld]   fp64 exp(logw - tile max): the linear weights the resampler scans, written
 //                      by the kernel that produced the weights (it has them in registers for the
-//                      tile partial anyway), so no exp() is ever recomputed downstream
-//   part     [nb]      per-tile {max, sum exp(lw-max), sum exp(2(lw-max))} from the same kernel
+//                      tile partial anyway), so no exp() is ever recomputed downstream.  Table-weight models on an
+//                      every-step schedule skip it between steps: state + emission table give the weight (WeightSource)
+//   part     [nb]      per-tile {max, sum exp(lw-max), sum exp(2(lw-max))} from the same kernel -- or, in that same
+//                      table-weight mode, one word of packed per-value counts per tile
 //   bc       [nb+1]    exclusive prefix of the tile sums rescaled to the global max: the
 //   bf       [nb]      resampling CDF at tile granularity, and the per-tile rescale factors
 //   ctrl               device-resident control block: max, W, Q, ESS, log Z, resample decision,
