@@ -154,6 +154,11 @@ class IslandBatch:
         self.gathered = torch.zeros((self.depth, self.world, self.width), dtype=torch.float64, device=dev)
         self.stream = torch.cuda.ExternalStream(engine.stream_ptr, device=dev)
         self.works = [None] * self.depth          # pending all-gathers (the engine's stream never waits for them)
+        if self.world > 1 and not _host_collectives():
+            # first use of a collective builds RCCL's communicator and channels (milliseconds): do it here, outside anybody's timing
+            with torch.cuda.stream(self.stream):
+                dist.all_gather_into_tensor(self.gathered[0].view(-1), self.packed[0])
+            torch.cuda.synchronize()
 
     def run(self, slot, run_index):
         e, torch = self.engine, self.torch
