@@ -208,6 +208,15 @@ class TorchCollective:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.stream = torch.cuda.ExternalStream(engine.stream_ptr, device=torch.device("cuda", engine.device))
+        if self.world > 1 and not _host_collectives():
+            # build RCCL's communicator and channels now (first use costs milliseconds), outside anybody's timing
+            dev = torch.device("cuda", engine.device)
+            probe = torch.zeros(3, dtype=torch.float64, device=dev)
+            out = torch.zeros(3 * self.world, dtype=torch.float64, device=dev)
+            with torch.cuda.stream(self.stream):
+                dist.all_gather_into_tensor(out, probe)
+                dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
 
     def all_gather(self, local, out):
         if self.world == 1:
