@@ -973,12 +973,15 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
 constexpr int kFuseMaxTiles = 1664;
 
 // blockIdx -> tile such that the workgroups with equal blockIdx % 8 (one XCD under round-robin dispatch; only speed depends on
-// that) own a contiguous range of tiles.  A bijection of [0, nb) for every nb.
+// that) own a contiguous range of tiles.  A bijection of [0, nb) for every nb.  Only while the whole grid is resident at once
+// (<= 2048 workgroups): beyond that the waves of workgroups in flight should sweep ONE region of HBM together, and the plain
+// order is 2-4 % faster (profiles/r01_ab_notes.md).
 __device__ __forceinline__ int xcd_contiguous_tile(int b, int nb)
 {
 #ifdef CPPROB_NO_XCD_SWIZZLE
     return b;
 #else
+    if (nb > 2048) return b;
     const int x = b & 7, j = b >> 3, q = nb >> 3, r = nb & 7;
     return x * q + (x < r ? x : r) + j;
 #endif
@@ -1332,7 +1335,7 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
     const double scale = a.ctrl->scale;
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     // (one XCD's workgroups walk neighbouring tiles: their lineages converge on the same ancestor rows)
-    for (int64_t tile = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x); tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const double f = a.bf[tile] * scale;
         int32_t idx[kPPT]; double w[kPPT];
 #pragma unroll
