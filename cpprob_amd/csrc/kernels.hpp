@@ -1083,8 +1083,11 @@ __device__ __forceinline__ void tile_partial_table(const int (&idx)[kPPT], const
 
 // FUSED: 0 = read ctrl / bc / bf (scan_partials_kernel ran); otherwise the number of tile partials each lane
 // holds in registers in the normalisation prologue (2, 4 or 8: populations of <= 512, 1024, 2048 tiles)
+// (launch bounds: the 8-partials-per-lane form of continuous-weight models is held to 6 waves per SIMD = 80 VGPRs, so that the
+//  1025..1664 workgroups it serves are all resident: linear_gaussian_1d 1.25e6 particles 2399 -> 2211 us per run; the table-weight
+//  form spills at that limit and stays unconstrained -- profiles/r01_ab_notes.md)
 template <class Model, int RS, int FUSED>
-__global__ __launch_bounds__(kThreads) void smc_step_kernel(StepArgs<Model> a)
+__global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) ? 6 : 1) void smc_step_kernel(StepArgs<Model> a)
 {
     using V = typename Model::value_t;
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // FUSED: bc[nb+1] then bf[nb]
