@@ -13,14 +13,14 @@ namespace cph {
 constexpr int kWave = 64;
 constexpr int kThreads = 256;              // workgroup size of every particle kernel
 constexpr int kWaves = kThreads / kWave;   // 4: one wave per SIMD
-// Particles per lane.  4 is the measured optimum on MI355X at every population size (profiles/r01_ppt_sweep.md:
-// 8 and 16 amortise the per-lane fixed cost but lose more to register pressure and to having fewer workgroups).
-// -DCPPROB_PPT=8|16 builds those variants; all GPU parity tests pass for each.
+// Particles per lane: 4.  An earlier build of these kernels was generic over 4 / 8 / 16 and 4 measured fastest at every population
+// size (profiles/r01_ppt_sweep.md: 8 and 16 amortise the per-lane fixed cost but lose more to register pressure and to having
+// fewer workgroups); the code since then is maintained and tested for 4 only.
 #ifndef CPPROB_PPT
 #define CPPROB_PPT 4
 #endif
 constexpr int kPPT = CPPROB_PPT;           // consecutive particles per lane, moved as 32-B fp64 / 16-B int32 vectors
-static_assert(kPPT == 4 || kPPT == 8 || kPPT == 16, "particles per lane");
+static_assert(kPPT == 4, "the kernels are maintained for 4 particles per lane");
 constexpr int kTile = kThreads * kPPT;     // particles per workgroup (1024)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
