@@ -206,18 +206,26 @@ void launch_sis(cpprob_hip_ctx* c)
     hipLaunchKernelGGL(sis_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
 }
 
-template <class Model, int FUSED>
-void launch_step_impl(cpprob_hip_ctx* c, StepArgs<Model>& a)
+template <class Model, int FUSED, bool COUNTS>
+void launch_step_kernels(cpprob_hip_ctx* c, StepArgs<Model>& a)
 {
     const size_t shm = FUSED ? (size_t)(2 * c->nb + 1) * sizeof(double) : 0;
     switch (c->cfg.resampler) {
     case CPPROB_HIP_RESAMPLE_SYSTEMATIC:
-        hipLaunchKernelGGL((smc_step_kernel<Model, RS_SYSTEMATIC, FUSED>), dim3(c->nb), dim3(kThreads), shm, c->stream, a); break;
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_SYSTEMATIC, FUSED, COUNTS>), dim3(c->nb), dim3(kThreads), shm, c->stream, a); break;
     case CPPROB_HIP_RESAMPLE_STRATIFIED:
-        hipLaunchKernelGGL((smc_step_kernel<Model, RS_STRATIFIED, FUSED>), dim3(c->nb), dim3(kThreads), shm, c->stream, a); break;
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_STRATIFIED, FUSED, COUNTS>), dim3(c->nb), dim3(kThreads), shm, c->stream, a); break;
     default:
-        hipLaunchKernelGGL((smc_step_kernel<Model, RS_PRECOMPUTED, 0>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
+        hipLaunchKernelGGL((smc_step_kernel<Model, RS_PRECOMPUTED, 0, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a); break;
     }
+}
+
+template <class Model, int FUSED>
+void launch_step_impl(cpprob_hip_ctx* c, StepArgs<Model>& a)
+{
+    // packed-count partials exist for table-weight models in the fused form only (a.part_counts is set accordingly)
+    if (Model::kWeightTable > 0 && FUSED != 0 && a.part_counts) launch_step_kernels<Model, FUSED, (Model::kWeightTable > 0 && FUSED != 0)>(c, a);
+    else launch_step_kernels<Model, FUSED, false>(c, a);
 }
 
 // fused = the step kernel normalises the previous generation itself (no scan_partials launch between steps)

@@ -1086,7 +1086,9 @@ __device__ __forceinline__ void tile_partial_table(const int (&idx)[kPPT], const
 // (launch bounds: the 8-partials-per-lane form of continuous-weight models is held to 6 waves per SIMD = 80 VGPRs, so that the
 //  1025..1664 workgroups it serves are all resident: linear_gaussian_1d 1.25e6 particles 2399 -> 2211 us per run; the table-weight
 //  form spills at that limit and stays unconstrained -- profiles/r01_ab_notes.md)
-template <class Model, int RS, int FUSED>
+// COUNTS: the tile partials between steps are packed per-value counts (table-weight models on an every-step schedule; a compile-
+// time form because the {max, sum, sum of squares} prologue it replaces costs 14-24 VGPRs: 73 -> 59 at 4 partials per lane, 101 -> 77 at 8)
+template <class Model, int RS, int FUSED, bool COUNTS = false>
 __global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) ? 6 : 1) void smc_step_kernel(StepArgs<Model> a)
 {
     using V = typename Model::value_t;
@@ -1137,7 +1139,7 @@ __global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) 
             const int c0 = tid * kPer;
             double rm[kPer], rs[kPer], rq[kPer];
             double M;
-            if (Model::kWeightTable > 0 && a.part_counts) {
+            if (Model::kWeightTable > 0 && COUNTS) {
                 // packed counts (8 B per tile): every tile shares the reference lwa + the step's largest table value, so
                 // there is no max to reduce, and {sum, sum of squares} follow from the counts
                 constexpr int K = Model::kWeightTable > 0 ? Model::kWeightTable : 1;
@@ -1290,7 +1292,7 @@ __global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) 
             for (int s2 = 1; s2 < K; ++s2) l = idx[k] == s2 ? ll[s2] : l;
             lw[k] = valid[k] ? lw[k] + l : -INFINITY;
         }
-        tile_partial_table<K>(idx, valid, et, (t == 0 ? 0.0 : lwa) + mref, e, a.part, s_cnt, FUSED && a.part_counts && t + 1 < a.T, bid);
+        tile_partial_table<K>(idx, valid, et, (t == 0 ? 0.0 : lwa) + mref, e, a.part, s_cnt, FUSED && COUNTS && t + 1 < a.T, bid);
     } else {
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
