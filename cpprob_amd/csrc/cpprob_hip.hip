@@ -73,6 +73,7 @@ struct cpprob_hip_ctx {
     bool exchange = false;
     int64_t annex_cap = 0, annex_used = 0;
     double* d_obound = nullptr;     // [world + 2]: offspring-interval bounds per rank, then the resampling decision
+    double* h_obound = nullptr;     // pinned host copy (the one host read-back per step of the exchange scope)
     int32_t* d_send_src = nullptr; size_t send_src_cap = 0;
     int64_t imm_l0 = 0, imm_l1 = 0, imm_col0 = 0;     // immigrant layout of the NEXT step
     struct { int t = -1; bool resample = false; std::vector<uint64_t> send_lo, send_cnt; uint64_t n_send = 0, n_recv = 0; int64_t l0 = 0, l1 = 0; } plan;
@@ -402,6 +403,8 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
     dfree(c->d_ctrl); dfree(c->d_local_totals);
+    dfree(c->d_send_src);
+    if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -625,8 +628,9 @@ int cpprob_hip_exchange_plan(cpprob_hip_ctx* c, int32_t t, int32_t world, int32_
     if (h_shard_begin[rank] != c->cfg.particle_offset || h_shard_begin[rank + 1] - h_shard_begin[rank] != (uint64_t)c->n || h_shard_begin[world] != c->cfg.n_global)
         return fail(c, CPPROB_HIP_EINVAL, "h_shard_begin does not describe this context's shard");
     HIP_TRY(c, hipSetDevice(c->device));
-    std::vector<double> ob((size_t)world + 2);
-    HIP_TRY(c, hipMemcpyAsync(ob.data(), c->d_obound, ob.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (!c->h_obound) HIP_TRY(c, hipHostMalloc(&c->h_obound, (1024 + 2) * sizeof(double), hipHostMallocDefault));
+    double* ob = c->h_obound;
+    HIP_TRY(c, hipMemcpyAsync(ob, c->d_obound, ((size_t)world + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     auto& p = c->plan;
     p.t = t; p.resample = ob[(size_t)world + 1] != 0.0;

@@ -139,10 +139,16 @@ print("rank", rank, "ok")
 def test_gloo_world2_island_combine(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER % {"root": ROOT})
-    port = 29600 + os.getpid() % 300
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script)]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    import socket
+    for attempt in range(2):                                        # one retry if the probed port was taken in between
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(script)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        if out.returncode == 0:
+            break
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
 
