@@ -36,6 +36,7 @@ struct cpprob_hip_ctx {
     int K = 0;              // stats per predict
     int64_t n = 0, ld = 0;
     int64_t rs = 0;         // row stride of values[] / anc[]: ld + annex_cap
+    bool grid_refs = false; // continuous-weight model: tile references on the grid {k ln 2} (kernels.hpp, grid_reference)
     size_t ssz = 8;         // bytes per element of values[] (Model::store_t; may be narrower than the model's value type)
     int nb = 0;             // tiles
     int smooth_grid = 0;
@@ -306,13 +307,14 @@ void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, 
     sa.n_pop = (double)c->pop_n; sa.n_local = (double)c->n; sa.ess_frac = c->cfg.ess_threshold; sa.seed = c->run_seed;
     sa.ess_trace = c->d_ess; sa.resampled = c->d_resampled;
     sa.force_no_resample = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
+    sa.grid_refs = c->grid_refs ? 1 : 0;
     sa.exchange = (c->exchange && phase == 2) ? 1 : 0; sa.obound = c->d_obound;
     sa.all_totals = all_totals; sa.world = world; sa.rank = rank; sa.local_totals = c->totals_out ? c->totals_out : c->d_local_totals; sa.phase = phase;
     ProfScope ps(c, 1);
     if (phase != 2 && c->nb > kSlabThreshold) {
         // large population: two multi-workgroup launches instead of one single-CU pass
         const int G = (c->nb + kSlabTiles - 1) / kSlabTiles;
-        hipLaunchKernelGGL(scan_slab_partials_kernel, dim3(G), dim3(kThreads), 0, c->stream, sa.part, c->nb, c->d_gpart);
+        hipLaunchKernelGGL(scan_slab_partials_kernel, dim3(G), dim3(kThreads), 0, c->stream, sa.part, c->nb, c->d_gpart, sa.grid_refs);
         hipLaunchKernelGGL(scan_slab_finish_kernel, dim3(G), dim3(kThreads), 0, c->stream, sa, (const double*)c->d_gpart, G);
     } else {
         hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, sa);
@@ -470,7 +472,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     // exchange scope: room for immigrant lineages next to every row (grown on demand by cpprob_hip_exchange_commit)
     const int64_t annex0 = exchange ? std::max<int64_t>(c->annex_cap, std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile)) : 0;
     c->ssz = 8;
-    dispatch_model(c, [&](auto m) { c->ssz = sizeof(typename decltype(m)::store_t); });
+    dispatch_model(c, [&](auto m) { c->ssz = sizeof(typename decltype(m)::store_t); c->grid_refs = decltype(m)::kWeightTable == 0; });
     const bool realloc = (size_t)c->ld > c->cap_particles || c->T > c->cap_T || c->is_int != c->cap_int || (multinomial && !c->cap_multinomial) || !c->d_values ||
                          annex0 != c->annex_cap;
     if (realloc) {
