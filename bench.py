@@ -90,6 +90,8 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchang
         jdepth = min(max(steps, warmup, 1), 64)
         jslots = torch.zeros((jdepth, 4 + eng.T * eng.K), dtype=torch.float64, device=device)
 
+    torch.cuda.synchronize()          # buffers above were filled on torch's stream; the engine works on its own
+
     def one(i):
         if exchange:
             st, _ = D.run_exchange(eng, coll, i, counters)   # per step: all-gather of 3 doubles + one all-to-all-v of migrating lineages

@@ -114,12 +114,21 @@ def load_library(path=None):
     return L
 
 
+# The engine's stream is non-blocking: work torch queued on ITS stream for a tensor (the fill of torch.zeros, an H2D copy) is not
+# ordered before what the engine then does with that memory.  Callers that create tensors right before a call either synchronise
+# themselves (cpprob_amd/distributed.py does, once, after allocating its buffers) or set this switch (the test suite does).
+SYNC_TORCH_BEFORE_CALLS = False
+
+
 def _dptr(t):
     """Device pointer of a torch tensor (contiguous), or None."""
     if t is None:
         return None
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
+    if SYNC_TORCH_BEFORE_CALLS:
+        import torch
+        torch.cuda.current_stream(t.device).synchronize()
     return C.c_void_p(t.data_ptr())
 
 

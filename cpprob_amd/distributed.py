@@ -153,6 +153,7 @@ class IslandBatch:
         self.packed = torch.zeros((self.depth, self.width), dtype=torch.float64, device=dev)
         self.gathered = torch.zeros((self.depth, self.world, self.width), dtype=torch.float64, device=dev)
         self.stream = torch.cuda.ExternalStream(engine.stream_ptr, device=dev)
+        torch.cuda.synchronize()                  # the fills above ran on torch's stream; the engine's stream is not ordered after it
         self.works = [None] * self.depth          # pending all-gathers (the engine's stream never waits for them)
         if self.world > 1 and not _host_collectives():
             # first use of a collective builds RCCL's communicator and channels (milliseconds): do it here, outside anybody's timing
@@ -300,6 +301,7 @@ def run_joint(engine, collective, run_index=0, buffers=None, slot=None):
     if buffers is None:
         buffers = (torch.zeros(4, dtype=torch.float64, device=dev), torch.zeros(3 * world, dtype=torch.float64, device=dev),
                    torch.zeros(engine.T * engine.K, dtype=torch.float64, device=dev))
+        torch.cuda.synchronize()                  # fills on torch's stream before the engine's stream touches them
     local, allt, _ = buffers
     steps = [engine.T - 1] if engine.cfg.algorithm == capi.ALG_SIS else range(engine.T)
     for t in steps:
@@ -315,6 +317,7 @@ def run_joint(engine, collective, run_index=0, buffers=None, slot=None):
         return None
     s = engine.summary()
     raw = torch.from_numpy(engine.stats()).to(dev)
+    torch.cuda.current_stream().synchronize()     # the copy ran on torch's stream, the collective runs on the engine's
     collective.all_reduce_sum(raw)
     stats = normalise_joint_stats(raw.cpu().numpy(), s["log_norm"], s["max_logw"], engine.is_int)
     return stats, s
@@ -347,6 +350,7 @@ def run_exchange(engine, collective, run_index=0, counters=None):
     local = torch.zeros(4, dtype=torch.float64, device=dev)
     allt = torch.zeros(3 * world, dtype=torch.float64, device=dev)
     vdtype = torch.int32 if engine.is_int else torch.float64
+    torch.cuda.synchronize()                      # fills on torch's stream before the engine's stream touches them
     send = recv = None
     n_sent = n_recv = 0
     for t in range(engine.T):
@@ -371,6 +375,7 @@ def run_exchange(engine, collective, run_index=0, counters=None):
     engine.finish()
     s = engine.summary()
     raw = torch.from_numpy(engine.stats()).to(dev)
+    torch.cuda.current_stream().synchronize()     # the copy ran on torch's stream, the collective runs on the engine's
     collective.all_reduce_sum(raw)
     stats = normalise_joint_stats(raw.cpu().numpy(), s["log_norm"], s["max_logw"], engine.is_int)
     if counters is not None:

@@ -24,6 +24,9 @@ def engine():
     """One context on cuda:0 shared by the GPU tests (fails loudly if the library or GPU is missing)."""
     import torch  # noqa: F401  (first: shares libamdhip64 with the extension)
     import cpprob_amd
+    # tensors created by a test (torch.zeros, .cuda()) are produced on torch's stream, the engine works on its own
+    # non-blocking stream: order the two at every call of the harness
+    cpprob_amd.capi.SYNC_TORCH_BEFORE_CALLS = True
     eng = cpprob_amd.Engine(0)
     yield eng
     eng.close()
