@@ -133,7 +133,7 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
     DevBuf<int32_t> d_int(n_int * n), d_anc(smc ? n : 0), d_ns0(smc ? n : 0), d_ns1(smc ? n : 0);
     DevBuf<uint64_t> d_tr0(smc ? S * n : 0), d_tr1(smc ? S * n : 0);
     DevBuf<int32_t> d_overflow(1);
-    hip_check(hipMemset(d_overflow.p, 0, sizeof(int32_t)), "hipMemset");
+    hip_check(hipMemsetAsync(d_overflow.p, 0, sizeof(int32_t), stream), "hipMemsetAsync");   // on the launches' own (non-blocking) stream
     double* logw[2] = {d_logw0.p, d_logw1.p};
     int32_t* ns[2] = {d_ns0.p, d_ns1.p};
     uint64_t* tr[2] = {d_tr0.p, d_tr1.p};
