@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Tensors a test creates (torch.zeros, .cuda()) are produced on torch's stream while every engine works on its own
+    # non-blocking stream: have the harness order the two at each call, for every engine of the session.
+    import cpprob_amd.capi
+    cpprob_amd.capi.SYNC_TORCH_BEFORE_CALLS = True
 
 
 @pytest.fixture(scope="session")
@@ -24,9 +28,6 @@ def engine():
     """One context on cuda:0 shared by the GPU tests (fails loudly if the library or GPU is missing)."""
     import torch  # noqa: F401  (first: shares libamdhip64 with the extension)
     import cpprob_amd
-    # tensors created by a test (torch.zeros, .cuda()) are produced on torch's stream, the engine works on its own
-    # non-blocking stream: order the two at every call of the harness
-    cpprob_amd.capi.SYNC_TORCH_BEFORE_CALLS = True
     eng = cpprob_amd.Engine(0)
     yield eng
     eng.close()
