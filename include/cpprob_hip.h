@@ -17,6 +17,8 @@
  *     globals (the reference's State::state_, StateInfer::trace_, TraceInfer::ids_predict_,
  *     src/cpprob/state.cpp:20-21,148-155, are per-context here).  One run at a time per context;
  *     contexts are independent and may live on different threads.
+ *   - The context's stream is NON-blocking (no implicit ordering with the null stream or any other stream): d_* buffers the
+ *     caller produced elsewhere must be complete before the call that reads them.
  *   - Pointers named d_* are DEVICE pointers valid on the context's device, h_* are host
  *     pointers.  Work is enqueued on the context's stream; functions that fill host memory
  *     synchronise that stream, all others are asynchronous.
