@@ -352,11 +352,13 @@ def main():
         gp = eng.profile_read(reset=True)
         eng.profile_enable(False)
         sis_s = gp["sis"][0] * 1e-3 / max(gp["sis"][1], 1)
-        sm_s = gp["smooth"][0] * 1e-3 / max(gp["smooth"][1], 1)
+        sm_s = gp["smooth"][0] * 1e-3 / max(gp["smooth"][1], 1)      # 0 calls when the read-out rides the normalisation (fused SIS read-out)
+        norm_s = gp["scan_partials"][0] * 1e-3 / max(gp["scan_partials"][1], 1)
         out["gaussian_sis_1e7"] = {"particles_per_sec": ng * args.steps / gdt, "ms_per_run": gdt / args.steps * 1e3,
                                    "posterior_mean_var": gst[0].tolist(), "analytic_mean_var": g["exact"][0].tolist(),
                                    "sis_kernel_us": sis_s * 1e6, "sis_kernel_GBs": 16 * ng / sis_s / 1e9 if sis_s else None,
                                    "readout_kernel_us": sm_s * 1e6, "readout_kernel_GBs": 16 * ng / sm_s / 1e9 if sm_s else None,
+                                   "normalise_and_readout_us": norm_s * 1e6,
                                    "end_to_end_GBs_at_32B": 32 * ng * args.steps / gdt / 1e9}
         if not args.no_cpu_baseline:
             out["gaussian_sis_1e7"]["cpu_compute_only_1core"] = cpu_baseline("gaussian_sis", 4_000_000, args.seed)

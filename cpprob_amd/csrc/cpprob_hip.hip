@@ -57,6 +57,8 @@ struct cpprob_hip_ctx {
     int cur_part = 0;                          // which one holds the latest generation
     double* d_e_tab = nullptr;                 // hmm: [T][4]
     double* d_gpart = nullptr;                 // slab partials of the two-level normalisation (large populations)
+    double* d_stile = nullptr;                 // SIS fused read-out: per-tile weighted sums [kMaxReadoutCols][nb]
+    double* d_gstat = nullptr;                 //                     per-slab weighted sums [kMaxReadoutCols][kMaxSlabs]
     double* d_bc = nullptr;
     StepCtrl* d_ctrl = nullptr;
     double* d_ess = nullptr;
@@ -197,15 +199,42 @@ int bb_normalise(cpprob_hip_ctx* ctx, const double* d_logw, size_t n, double n_t
     return 0;
 }
 
+// the SIS read-out can ride the normalisation (no read-back of the particle store) when its columns are few
 template <class Model>
-void launch_sis(cpprob_hip_ctx* c)
+bool sis_readout_fused(const cpprob_hip_ctx* c)
+{
+    static const bool enabled = !(getenv("CPPROB_SIS_FUSED_READOUT") && getenv("CPPROB_SIS_FUSED_READOUT")[0] == '0');
+    return enabled && c->T <= kMaxReadoutT && c->T * Model::kStats <= kMaxReadoutCols;
+}
+
+template <class Model>
+void launch_sis(cpprob_hip_ctx* c, bool readout)
 {
     SisArgs<Model> a{};
     a.mp = c->mp; a.obs = c->d_obs; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
     a.values = static_cast<typename Model::store_t*>(c->d_values); a.logw = c->d_logw[0]; a.wrel = c->d_wrel[0]; a.part = c->d_part[0];
+    a.stile = c->d_stile;
     c->cur_part = 0;
     ProfScope ps(c, 4);
-    hipLaunchKernelGGL(sis_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+    if (readout) hipLaunchKernelGGL((sis_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL((sis_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+}
+
+// normalisation of the final SIS weights + the weighted moments in the same two launches (slab form at every size)
+template <class Model>
+void launch_sis_readout(cpprob_hip_ctx* c)
+{
+    ScanArgs sa{};
+    sa.part = c->d_part[c->cur_part]; sa.nb = c->nb; sa.bc = c->d_bc; sa.bf = c->d_bf; sa.ctrl = c->d_ctrl; sa.t = c->T - 1; sa.T = c->T;
+    sa.n_pop = (double)c->pop_n; sa.n_local = (double)c->n; sa.ess_frac = c->cfg.ess_threshold; sa.seed = c->run_seed;
+    sa.ess_trace = c->d_ess; sa.resampled = c->d_resampled; sa.force_no_resample = 1; sa.grid_refs = c->grid_refs ? 1 : 0; sa.phase = 0;
+    const int G = (c->nb + kSlabTiles - 1) / kSlabTiles;
+    const int n_col = c->T * Model::kStats;
+    ProfScope ps(c, 1);
+    hipLaunchKernelGGL(scan_slab_partials_kernel, dim3(G), dim3(kThreads), 0, c->stream, sa.part, c->nb, c->d_gpart, sa.grid_refs,
+                       (const double*)c->d_stile, n_col, c->d_gstat);
+    hipLaunchKernelGGL(scan_slab_finish_kernel, dim3(G), dim3(kThreads), 0, c->stream, sa, (const double*)c->d_gpart, G,
+                       (const double*)c->d_gstat, n_col, (int)Model::kStats, Model::kIsInt ? 1 : 0, c->d_stats);
 }
 
 template <class Model, int FUSED, bool COUNTS>
@@ -356,7 +385,7 @@ int dispatch_model(cpprob_hip_ctx* c, F&& f)
 void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
-    dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
+    dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
     dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
 }
@@ -493,6 +522,8 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_bc, ((size_t)c->nb + 1) * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_gpart, (size_t)3 * kMaxSlabs * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_stile, (size_t)kMaxReadoutCols * c->nb * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_gstat, (size_t)kMaxReadoutCols * kMaxSlabs * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_ess, T * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_resampled, T * sizeof(int32_t)));
         HIP_TRY(c, hipMalloc(&c->d_stats_part, (size_t)c->smooth_grid * T * 8 * sizeof(double)));
@@ -548,9 +579,15 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     c->run_seed = c->cfg.seed + run_index;
     c->cur = 0; c->cur_part = 0;
     c->sharded = false;
+    bool readout_done = false;
     if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
-        dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
-        launch_scan(c, c->T - 1, 0, nullptr, 1, 0);
+        dispatch_model(c, [&](auto m) {
+            using M = decltype(m);
+            readout_done = sis_readout_fused<M>(c);
+            launch_sis<M>(c, readout_done);
+            if (readout_done) launch_sis_readout<M>(c);
+        });
+        if (!readout_done) launch_scan(c, c->T - 1, 0, nullptr, 1, 0);
     } else {
         c->step_protocol = false;
         const bool fused = step_is_fused(c);
@@ -570,7 +607,7 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
             }
         }
     }
-    dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
+    if (!readout_done) dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
     return 0;
@@ -588,7 +625,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     if (c->exchange && t > 0 && c->plan.t != t - 1)
         return fail(c, CPPROB_HIP_ESTATE, "exchange scope: cpprob_hip_exchange_plan/_pack/_commit of the previous step must run before the next step_begin");
     c->step_protocol = true;
-    if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c); });
+    if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c, false); });
     else dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
     c->totals_out = d_local_totals;
     launch_scan(c, t, 1, nullptr, 1, 0);

@@ -358,9 +358,16 @@ constexpr int kSlabTiles = kThreads * 4;    // 1024 tiles per workgroup: 4 conse
 constexpr int kSlabThreshold = 4096;
 constexpr int kMaxSlabs = 1024;
 
-__global__ __launch_bounds__(kThreads) void scan_slab_partials_kernel(const double* __restrict__ part, int nb, double* __restrict__ gpart, int grid_refs)
+// Optional SIS read-out columns (kMaxReadoutCols at most): stile[j][nb] holds, per tile, sum e * f_j(x) relative to the tile's own
+// reference (sis_kernel<Model, true>); they are carried through both launches like the tile sums, so that the weighted moments come
+// out of the normalisation itself and the particle store is never read back.
+constexpr int kMaxReadoutCols = 4;
+
+__global__ __launch_bounds__(kThreads) void scan_slab_partials_kernel(const double* __restrict__ part, int nb, double* __restrict__ gpart, int grid_refs,
+                                                                       const double* __restrict__ stile = nullptr, int n_col = 0, double* __restrict__ gstat = nullptr)
 {
     __shared__ double s_scr[3 * kWaves];
+    __shared__ double s_col[2 * kWaves];
     const int G = (int)gridDim.x, g = (int)blockIdx.x;
     const int pst = part_stride(nb);
     const double* pm = part; const double* psum = part + pst; const double* pq = part + 2 * pst;
@@ -373,19 +380,38 @@ __global__ __launch_bounds__(kThreads) void scan_slab_partials_kernel(const doub
         m[k] = in ? pm[c] : -INFINITY; sv[k] = in ? psum[c] : 0.0; qv[k] = in ? pq[c] : 0.0;
     }
     const double mg = block_max(fmax(fmax(m[0], m[1]), fmax(m[2], m[3])), s_scr);
-    double S = 0.0, Q = 0.0;
+    double S = 0.0, Q = 0.0, ef[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const double e = rescale_factor(m[k], mg, grid_refs != 0);
+        ef[k] = e;
         S += sv[k] * e; Q += qv[k] * (e * e);
     }
     block_sum2(S, Q, s_scr + kWaves);
     if (threadIdx.x == 0) { gpart[g] = mg; gpart[G + g] = S; gpart[2 * G + g] = Q; }
+    for (int j = 0; j < n_col; j += 2) {                          // workgroup-uniform trip count
+        double ca = 0.0, cb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            if (c < nb) {
+                ca += stile[(size_t)j * nb + c] * ef[k];
+                if (j + 1 < n_col) cb += stile[(size_t)(j + 1) * nb + c] * ef[k];
+            }
+        }
+        __syncthreads();                                          // s_col is reused by the next pair
+        block_sum2(ca, cb, s_col);
+        if (threadIdx.x == 0) { gstat[(size_t)j * G + g] = ca; if (j + 1 < n_col) gstat[(size_t)(j + 1) * G + g] = cb; }
+    }
 }
 
-__global__ __launch_bounds__(kThreads) void scan_slab_finish_kernel(ScanArgs a, const double* __restrict__ gpart, int G)
+__global__ __launch_bounds__(kThreads) void scan_slab_finish_kernel(ScanArgs a, const double* __restrict__ gpart, int G,
+                                                                     const double* __restrict__ gstat = nullptr, int n_col = 0, int K = 0, int is_int = 0,
+                                                                     double* __restrict__ stats = nullptr)
 {
     __shared__ double s_scr[4 * kWaves];
+    __shared__ double s_col[kMaxReadoutCols][kWaves];
+    __shared__ double s_ctot[kMaxReadoutCols];
     const int tid = threadIdx.x, g = (int)blockIdx.x;
     // combine the slab partials: global max, total mass, total squares, mass of the slabs before mine
     constexpr int kPerG = kMaxSlabs / kThreads;
@@ -399,7 +425,7 @@ __global__ __launch_bounds__(kThreads) void scan_slab_finish_kernel(ScanArgs a, 
         m = fmax(m, gm[i]);
     }
     const double M = block_max(m, s_scr);
-    double Wt = 0.0, Qt = 0.0, before = 0.0;
+    double Wt = 0.0, Qt = 0.0, before = 0.0, ct[kMaxReadoutCols] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < kPerG; ++i) {
         const int j = tid + i * kThreads;
@@ -407,9 +433,30 @@ __global__ __launch_bounds__(kThreads) void scan_slab_finish_kernel(ScanArgs a, 
         const double v = gs[i] * e;
         Wt += v; Qt += gq[i] * (e * e);
         if (j < g) before += v;
+        if (g == 0 && j < G) {
+            for (int col = 0; col < n_col; ++col) ct[col] += gstat[(size_t)col * G + j] * e;
+        }
     }
     block_sum2(Wt, Qt, s_scr + kWaves);
     before = block_sum(before, s_scr + 3 * kWaves);
+    if (g == 0 && n_col > 0) {                                   // workgroup-uniform
+        for (int col = 0; col < n_col; ++col) {
+            const double tot = block_sum(ct[col], s_col[col]);
+            if (tid == 0) s_ctot[col] = tot;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // finalize_kernel's normalisation: real -> {mean, raw2 - mean^2} per row, int -> probabilities
+            for (int r = 0; r * K < n_col; ++r) {
+                if (is_int) { for (int j = 0; j < K; ++j) stats[r * K + j] = s_ctot[r * K + j] / Wt; }
+                else {
+                    const double mean = s_ctot[r * K] / Wt;
+                    stats[r * K] = mean;
+                    stats[r * K + 1] = s_ctot[r * K + 1] / Wt - mean * mean;
+                }
+            }
+        }
+    }
     // my slab against the global max
     const double* pm = a.part; const double* psum = a.part + part_stride(a.nb);
     const int c0 = g * kSlabTiles + tid * 4;
@@ -941,15 +988,21 @@ struct SisArgs {
     ModelParams mp; const double* obs; int T; int64_t n, ld, rs;
     uint64_t seed, pid0;
     typename Model::store_t* values; double* logw; double* wrel; Partial* part;
+    double* stile;     // READOUT: [T * kStats][gridDim.x] per-tile weighted sums (the read-out rides the normalisation)
 };
 
-template <class Model>
+constexpr int kMaxReadoutT = 2;
+
+template <class Model, bool READOUT = false>
 __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
 {
     using V = typename Model::value_t;
+    constexpr int K = Model::kStats;
     __shared__ double s_scr[3 * kWaves];
+    __shared__ double s_ro[2 * kWaves];
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
     double lw[kPPT]; V x[kPPT];
+    V xt[READOUT ? kMaxReadoutT : 1][kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) { lw[k] = 0.0; x[k] = V(0); }                              // start_trace(): log_w_ = 0
     for (int t = 0; t < a.T; ++t) {
@@ -960,6 +1013,14 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) { x[k] = nx[k]; lw[k] += Model::loglik(a.mp, x[k], t, a.obs); }   // observe: log_w_ += logpdf  state.cpp:212-223
         store4_as(a.values + (int64_t)t * a.rs, j0, x);                                       // predict: add_predict       state.hpp:312-327
+        if (READOUT) {                                                                        // (static indices: registers)
+#pragma unroll
+            for (int tt = 0; tt < kMaxReadoutT; ++tt)
+                if (t == tt) {
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) xt[READOUT ? tt : 0][k] = x[k];
+                }
+        }
     }
 #pragma unroll
     for (int k = 0; k < kPPT; ++k)
@@ -968,6 +1029,27 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
     double e[kPPT];
     tile_partial(lw, e, a.part, s_scr, (int)blockIdx.x, Model::kWeightTable == 0);
     store4(a.wrel, j0, e);
+    if (READOUT) {
+        // StatsPrinter's sums for this tile, relative to the tile's reference: sum e f(x_t) per predict hit t (a.T <= kMaxReadoutT)
+#pragma unroll
+        for (int t = 0; t < kMaxReadoutT; ++t) {
+            if (t >= a.T) break;                                    // workgroup-uniform
+            double acc[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) Model::accumulate(xt[READOUT ? t : 0][k], e[k], acc);
+            for (int j = 0; j < K; j += 2) {
+                double ca = acc[j], cb = j + 1 < K ? acc[j + 1] : 0.0;
+                __syncthreads();                                    // s_ro is reused pair after pair
+                block_sum2(ca, cb, s_ro);
+                if (threadIdx.x == 0) {
+                    a.stile[(size_t)(t * K + j) * gridDim.x + blockIdx.x] = ca;
+                    if (j + 1 < K) a.stile[(size_t)(t * K + j + 1) * gridDim.x + blockIdx.x] = cb;
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
