@@ -149,6 +149,7 @@ void host_model_params(ModelParams& mp, int model)
         mp.nd_mean[0] = 1; mp.nd_mean[1] = 2; mp.nd_sigma[0] = std::sqrt(5.0); mp.nd_sigma[1] = std::sqrt(3.0); mp.sigma = std::sqrt(2.0);
     } else { mp.mu0 = 0; mp.sigma0 = 1; mp.sigma = 1; }
     mp.log_norm_lik = std::log(2 * pi * mp.sigma * mp.sigma);       // utils_normal_distribution.hpp:40
+    mp.inv_sigma = 1.0 / mp.sigma;
     mp.log_norm_unit = std::log(2 * pi * 1.0 * 1.0);
     const double mean[3] = {-1, 0, 1};                               // models.hpp:122
     const double T[3][3] = {{0.1, 0.5, 0.4}, {0.2, 0.2, 0.6}, {0.15, 0.15, 0.7}};  // models.hpp:123-125
@@ -874,6 +875,8 @@ int cpprob_hip_copy_paths(cpprob_hip_ctx* c, void* h, size_t n_bytes)
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
     const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
+    // SIS: every trace is its own line -- the paths are the values (and a fused-read-out run keeps no linear weights to re-run the read-out on)
+    if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) return cpprob_hip_copy_values(c, h, n_bytes);
     if (!c->d_paths) HIP_TRY(c, hipMalloc(&c->d_paths, (size_t)c->cap_T * c->cap_particles * vsz));
     dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, true); });
     HIP_TRY(c, hipGetLastError());

@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
     store4(a.logw, j0, lw);                                                                   // finish_trace()
     double e[kPPT];
     tile_partial(lw, e, a.part, s_scr, (int)blockIdx.x, Model::kWeightTable == 0);
-    store4(a.wrel, j0, e);
+    if (!READOUT) store4(a.wrel, j0, e);          // the linear weights only serve the read-out pass, which READOUT replaces
     if (READOUT) {
         // StatsPrinter's sums for this tile, relative to the tile's reference: sum e f(x_t) per predict hit t (a.T <= kMaxReadoutT)
 #pragma unroll

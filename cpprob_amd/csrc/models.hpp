@@ -16,6 +16,7 @@ namespace cph {
 struct ModelParams {
     // gaussian_unknown_mean: prior N(mu0, sigma0), likelihood N(mu, sigma)
     double mu0, sigma0, sigma, log_norm_lik;      // log_norm_lik = log(2*pi*sigma^2)
+    double inv_sigma;                             // 1 / sigma (host-computed)
     // hmm: k = 3
     double hmm_mean[3];
     uint64_t hmm_thr[3][2];                       // ceil(2^32 * cumulative probability) of row s
@@ -53,8 +54,8 @@ struct ModelGaussian {
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t mu, int /*t*/, const double* __restrict__ obs)
     {
         double lw = 0.0;                                                  // TraceInfer::log_w_ = 0     trace.hpp:59
-        lw += normal_logpdf_hoisted(obs[0], mu, mp.sigma, mp.log_norm_lik);   // observe(likelihood, y1)  models.hpp:32
-        lw += normal_logpdf_hoisted(obs[1], mu, mp.sigma, mp.log_norm_lik);   // observe(likelihood, y2)  models.hpp:33
+        lw += normal_logpdf_scaled(obs[0], mu, mp.inv_sigma, mp.log_norm_lik);   // observe(likelihood, y1)  models.hpp:32
+        lw += normal_logpdf_scaled(obs[1], mu, mp.inv_sigma, mp.log_norm_lik);   // observe(likelihood, y2)  models.hpp:33
         return lw;
     }
     __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
@@ -90,7 +91,7 @@ struct ModelGaussianND {
     }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t mu, int d, const double* __restrict__ obs)
     {
-        return normal_logpdf_hoisted(obs[d], mu, mp.sigma, mp.log_norm_lik);                  // models.hpp:46-47, component d
+        return normal_logpdf_scaled(obs[d], mu, mp.inv_sigma, mp.log_norm_lik);               // models.hpp:46-47, component d
     }
     __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
     {
