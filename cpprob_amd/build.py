@@ -30,15 +30,27 @@ def _newer(target, sources):
 def lib_sources():
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
     srcs.append(os.path.join(ROOT, "include", "cpprob_hip.h"))
-    srcs += [os.path.join(HERE, "include", "cpprob", "detail", f) for f in ("rng.hpp", "dist.hpp")]
+    srcs += [os.path.join(HERE, "include", "cpprob", "detail", f) for f in ("rng.hpp", "dist.hpp", "hd.hpp")]
     return srcs
+
+
+def source_hash():
+    """sha256 over the library's sources (names and contents): embedded in the binary as cpprob_hip_build_id()."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in lib_sources():
+        h.update(os.path.relpath(s, ROOT).encode())
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and not _newer(LIB, lib_sources()):
         return LIB
-    cmd = [HIPCC] + HIP_FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "include"), "-o", LIB, os.path.join(CSRC, "cpprob_hip.hip")]
+    cmd = [HIPCC] + HIP_FLAGS + ['-DCPPROB_BUILD_ID="%s"' % source_hash(), "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "include"), "-o", LIB,
+                                 os.path.join(CSRC, "cpprob_hip.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

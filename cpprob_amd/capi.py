@@ -16,7 +16,7 @@ KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", 
 
 # every symbol include/cpprob_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "cpprob_hip_abi_version", "cpprob_hip_device_count", "cpprob_hip_create", "cpprob_hip_destroy", "cpprob_hip_last_error",
+    "cpprob_hip_abi_version", "cpprob_hip_build_id", "cpprob_hip_device_count", "cpprob_hip_create", "cpprob_hip_destroy", "cpprob_hip_last_error",
     "cpprob_hip_stream", "cpprob_hip_sync", "cpprob_hip_infer_begin", "cpprob_hip_infer_run", "cpprob_hip_infer_summary",
     "cpprob_hip_infer_stats", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
@@ -60,6 +60,7 @@ def load_library(path=None):
     vp, u64, i64, i32, dbl, sz = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_double, C.c_size_t
     sig = {
         "cpprob_hip_abi_version": (C.c_int, []),
+        "cpprob_hip_build_id": (C.c_char_p, []),
         "cpprob_hip_device_count": (C.c_int, []),
         "cpprob_hip_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "cpprob_hip_destroy": (None, [vp]),
@@ -109,26 +110,27 @@ def load_library(path=None):
         fn.argtypes = args
     if L.cpprob_hip_abi_version() != 1:
         raise CpprobHipError("ABI version mismatch")
+    if p == LIB_PATH:
+        # the in-tree binary must be the build of the sources next to it (a stale .so that merely looks newer is refused)
+        from . import build as B
+        have, want = L.cpprob_hip_build_id().decode(), B.source_hash()
+        if have != want:
+            raise CpprobHipError("%s was built from other sources (build id %s, sources %s): run `python -m cpprob_amd.build`" % (p, have, want))
     if path is None:
         _lib = L
     return L
 
 
-# The engine's stream is non-blocking: work torch queued on ITS stream for a tensor (the fill of torch.zeros, an H2D copy) is not
-# ordered before what the engine then does with that memory.  Callers that create tensors right before a call either synchronise
-# themselves (cpprob_amd/distributed.py does, once, after allocating its buffers) or set this switch (the test suite does).
-SYNC_TORCH_BEFORE_CALLS = False
-
-
 def _dptr(t):
-    """Device pointer of a torch tensor (contiguous), or None."""
+    """Device pointer of a torch tensor (contiguous), or None.
+
+    Stream contract (include/cpprob_hip.h): the engine's stream is non-blocking, so work torch queued on ITS stream for a
+    tensor (the fill of torch.zeros, an H2D copy) is not ordered before what the engine then does with that memory.  The
+    caller completes its tensors first -- torch.cuda.current_stream().synchronize() after creating them, once."""
     if t is None:
         return None
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
-    if SYNC_TORCH_BEFORE_CALLS:
-        import torch
-        torch.cuda.current_stream(t.device).synchronize()
     return C.c_void_p(t.data_ptr())
 
 

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "step_counts.hpp"
 
 using namespace cph;
 
@@ -71,6 +72,7 @@ struct cpprob_hip_ctx {
     double* totals_out = nullptr;   // caller-provided {max, sum, sum of squares} of the shard (step protocol)
     bool sharded = false;           // the last run went through the step protocol: stats stay un-normalised
     bool step_protocol = false;     // a step-protocol run is in progress (the step kernel must not normalise on its own)
+    int step_t = -1;                // step of the last cpprob_hip_smc_step_begin
     int cur = 0;                    // logw buffer holding the latest generation
     // exchange scope: exact global resampling, offspring of remote sources migrate in as annex columns
     bool exchange = false;
@@ -81,6 +83,12 @@ struct cpprob_hip_ctx {
     int64_t imm_l0 = 0, imm_l1 = 0, imm_col0 = 0;     // immigrant layout of the NEXT step
     struct { int t = -1; bool resample = false; std::vector<uint64_t> send_lo, send_cnt; uint64_t n_send = 0, n_recv = 0; int64_t l0 = 0, l1 = 0; } plan;
     size_t cap_particles = 0; int cap_T = 0; bool cap_int = false; bool cap_multinomial = false;
+    // prefix-count form of the step (table-weight models on an every-step schedule; step_counts.hpp)
+    uint64_t* d_hier = nullptr; size_t hier_entries = 0;   // three copies of the 64-ary count hierarchy
+    Hier hier{};
+    size_t hier_upper_off = 0, hier_upper_n = 0;           // copy 1's levels >= 1 (cleared at the start of every run)
+    int64_t* d_annex_base = nullptr;                       // [T + 1] exchange scope: annex columns in use before each step's immigrants
+    bool counts_mode = false;                              // this run's steps use smc_step_counts_kernel
 
     // scratch for building blocks
     Partial* d_bb_part = nullptr; double* d_bb_bc = nullptr; double* d_bb_bf = nullptr; double* d_bb_wrel = nullptr; void* d_bb_col = nullptr;
@@ -330,6 +338,34 @@ void launch_step(cpprob_hip_ctx* c, int t)
     if (t > 0) c->cur_part ^= 1;
 }
 
+// The prefix-count form serves table-weight models (three values) whose every step resamples systematically: ancestors are
+// then a function of integer counts (bit-exact against the oracle at any size), no step needs a normalisation launch, and the
+// per-step prologue is one wavefront reduction.  CPPROB_STEP_COUNTS=0 keeps the floating-point form (A/B runs).
+template <class Model>
+bool counts_eligible(const cpprob_hip_ctx* c)
+{
+    static const bool enabled = !(getenv("CPPROB_STEP_COUNTS") && getenv("CPPROB_STEP_COUNTS")[0] == '0');
+    return enabled && Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1 && c->cfg.algorithm == CPPROB_HIP_ALG_SMC &&
+           c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && c->cfg.ess_threshold > 1.0 &&
+           (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND);
+}
+
+template <class Model>
+void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int world, int rank)
+{
+    if constexpr (Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1) {
+        StepCountsArgs<Model> a{};
+        a.mp = c->mp; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
+        a.values = static_cast<typename Model::store_t*>(c->d_values); a.anc = c->d_anc;
+        a.logw_next = c->d_logw[0]; a.wrel_next = c->d_wrel[0]; a.part = c->d_part[0];
+        a.h = c->hier; a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
+        a.all_totals = all_totals; a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
+        ProfScope ps(c, 0);
+        hipLaunchKernelGGL(smc_step_counts_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        if (t + 1 == c->T) { c->cur = 0; c->cur_part = 0; }        // the last step left logw / wrel / partials in buffer 0
+    }
+}
+
 void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, int world, int rank)
 {
     ScanArgs sa{};
@@ -387,7 +423,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound);
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
 }
 
@@ -396,6 +432,11 @@ void free_run_buffers(cpprob_hip_ctx* c)
 extern "C" {
 
 int cpprob_hip_abi_version(void) { return CPPROB_HIP_ABI_VERSION; }
+
+#ifndef CPPROB_BUILD_ID
+#define CPPROB_BUILD_ID "unknown"
+#endif
+const char* cpprob_hip_build_id(void) { return CPPROB_BUILD_ID; }
 
 int cpprob_hip_device_count(void)
 {
@@ -419,11 +460,15 @@ int cpprob_hip_create(int device, cpprob_hip_ctx** out)
     if (device < 0 || device >= n) return fail(nullptr, CPPROB_HIP_EINVAL, "device index out of range");
     cpprob_hip_ctx* c = new cpprob_hip_ctx();
     c->device = device;
-    HIP_TRY(nullptr, hipSetDevice(device));
-    HIP_TRY(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(nullptr, hipMalloc(&c->d_ctrl, sizeof(StepCtrl)));
-    HIP_TRY(nullptr, hipMalloc(&c->d_local_totals, 4 * sizeof(double)));
-    HIP_TRY(nullptr, hipMemsetAsync(c->d_ctrl, 0, sizeof(StepCtrl), c->stream));
+    const int rc = [&]() -> int {
+        HIP_TRY(nullptr, hipSetDevice(device));
+        HIP_TRY(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(nullptr, hipMalloc(&c->d_ctrl, sizeof(StepCtrl)));
+        HIP_TRY(nullptr, hipMalloc(&c->d_local_totals, 4 * sizeof(double)));
+        HIP_TRY(nullptr, hipMemsetAsync(c->d_ctrl, 0, sizeof(StepCtrl), c->stream));
+        return 0;
+    }();
+    if (rc) { cpprob_hip_destroy(c); return rc; }     // nothing leaks on a failed create
     *out = c;
     return 0;
 }
@@ -488,6 +533,9 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     c->pop_n = island ? cfg->n_particles : cfg->n_global;
     c->T = model_T(cfg->model, n_obs);
     c->n_obs = (int)n_obs;
+    c->begun = false; c->step_protocol = false; c->step_t = -1;
+    // the read-out keeps kWaves * T * kStats accumulators in LDS (smooth_kernel)
+    if ((size_t)kWaves * (size_t)c->T * 3 * sizeof(double) > 64 * 1024) return fail(c, CPPROB_HIP_EUNSUPPORTED, "too many predict hits per trace for the read-out kernel's LDS accumulators (T <= 682)");
     c->is_int = cfg->model == CPPROB_HIP_MODEL_HMM3;
     c->K = c->is_int ? 3 : 2;
     c->n = (int64_t)cfg->n_particles;
@@ -529,11 +577,32 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_resampled, T * sizeof(int32_t)));
         HIP_TRY(c, hipMalloc(&c->d_stats_part, (size_t)c->smooth_grid * T * 8 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_stats, T * 8 * sizeof(double)));
+        {
+            // 64-ary hierarchy of per-tile state counts, three rotating copies (step_counts.hpp)
+            size_t per_copy = 0;
+            for (size_t e = (size_t)c->nb;; e = (e + 63) / 64) { per_copy += e; if (e <= 64) break; }
+            c->hier_entries = 3 * per_copy;
+            HIP_TRY(c, hipMalloc(&c->d_hier, c->hier_entries * sizeof(uint64_t)));
+            HIP_TRY(c, hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream));
+            HIP_TRY(c, hipMalloc(&c->d_annex_base, (T + 1) * sizeof(int64_t)));
+            HIP_TRY(c, hipMemsetAsync(c->d_annex_base, 0, (T + 1) * sizeof(int64_t), c->stream));
+        }
         if (multinomial) {
             HIP_TRY(c, hipMalloc(&c->d_cdf, ld * sizeof(double)));
             HIP_TRY(c, hipMalloc(&c->d_anc_pre, ld * sizeof(int32_t)));
         }
         c->cap_particles = ld; c->cap_T = c->T; c->cap_int = c->is_int; c->cap_multinomial = multinomial;
+    }
+    {
+        std::memset(&c->hier, 0, sizeof c->hier);
+        size_t per_copy = 0; int nl = 0;
+        size_t off[kHierMaxLevels] = {0, 0, 0, 0};
+        for (size_t e = (size_t)c->nb;; e = (e + 63) / 64) { off[nl] = per_copy; c->hier.n_ent[nl] = (int)e; per_copy += e; ++nl; if (e <= 64) break; }
+        c->hier.n_lev = nl;
+        for (int k = 0; k < 3; ++k)
+            for (int l = 0; l < nl; ++l) c->hier.lvl[k][l] = c->d_hier + (size_t)k * per_copy + off[l];
+        c->hier_upper_off = per_copy + (nl > 1 ? off[1] : per_copy); c->hier_upper_n = nl > 1 ? per_copy - off[1] : 0;
+        if (3 * per_copy > c->hier_entries) return fail(c, CPPROB_HIP_EDEVICE, "count hierarchy exceeds its allocation");
     }
     c->rs = c->ld + c->annex_cap;
     c->annex_used = 0; c->imm_l0 = 0; c->imm_l1 = c->n; c->imm_col0 = 0; c->plan.t = -1;
@@ -591,8 +660,19 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
         if (!readout_done) launch_scan(c, c->T - 1, 0, nullptr, 1, 0);
     } else {
         c->step_protocol = false;
+        c->counts_mode = false;
+        dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); });
         const bool fused = step_is_fused(c);
-        if (fused) {
+        if (c->counts_mode) {
+            if (c->hier_upper_n) HIP_TRY(c, hipMemsetAsync(c->d_hier + c->hier_upper_off, 0, c->hier_upper_n * sizeof(uint64_t), c->stream));
+            {
+                ProfScope group(c, 0, c->T);
+                c->profile_suspended = true;
+                for (int t = 0; t < c->T; ++t) dispatch_model(c, [&](auto m) { launch_step_counts<decltype(m)>(c, t, nullptr, 1, 0); });
+                c->profile_suspended = false;
+            }
+            launch_scan(c, c->T - 1, 0, nullptr, 1, 0);
+        } else if (fused) {
             // the T step kernels run back to back: one event pair around the group
             {
                 ProfScope group(c, 0, c->T);
@@ -625,7 +705,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     if (t == 0 || sis) { c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; c->annex_used = 0; c->imm_l0 = 0; c->imm_l1 = c->n; c->imm_col0 = 0; c->plan.t = -1; }
     if (c->exchange && t > 0 && c->plan.t != t - 1)
         return fail(c, CPPROB_HIP_ESTATE, "exchange scope: cpprob_hip_exchange_plan/_pack/_commit of the previous step must run before the next step_begin");
-    c->step_protocol = true;
+    c->step_protocol = true; c->step_t = t;
     if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c, false); });
     else dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
     c->totals_out = d_local_totals;
@@ -638,6 +718,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
 int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_totals, int32_t world, int32_t rank)
 {
     if (!c || !d_all_totals) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->begun || !c->step_protocol || t != c->step_t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_step_end(t) follows cpprob_hip_smc_step_begin(t)");
     if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank (1 <= world <= 1024)");
     HIP_TRY(c, hipSetDevice(c->device));
     launch_scan(c, t, 2, d_all_totals, world, rank);
@@ -648,6 +729,7 @@ int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_to
 int cpprob_hip_smc_finish(cpprob_hip_ctx* c)
 {
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->begun || !c->step_protocol || c->step_t != c->T - 1) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_finish follows the last step's cpprob_hip_smc_step_end");
     HIP_TRY(c, hipSetDevice(c->device));
     dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
     HIP_TRY(c, hipGetLastError());

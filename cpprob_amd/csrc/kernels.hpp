@@ -118,13 +118,6 @@ __device__ __forceinline__ void store4_as(S* __restrict__ p, int64_t i, const V 
     store4(p, i, raw);
 }
 
-// Rows that the step kernels re-read (states, weights) use plain stores: they are wanted in L2.
-template <class T>
-__device__ __forceinline__ void store4_stream(T* __restrict__ p, int64_t i, const T (&v)[kPPT])
-{
-    store4(p, i, v);
-}
-
 // Write-through store (sc1) for rows no step kernel reads again -- the ancestor rows, which only the read-out walks: they
 // reach memory while the kernel still runs instead of at its boundary, where dirty bytes cost time (-2 % per run at 10^6;
 // the same policy on re-read rows costs up to +33 %: profiles/r01_ab_notes.md).
@@ -1370,7 +1363,7 @@ __global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) 
         typename Model::store_t xs[kPPT];
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) xs[k] = static_cast<typename Model::store_t>(x[k]);
-        store4_stream(a.values + (int64_t)t * a.rs, j0, xs);                                  // predict #t
+        store4(a.values + (int64_t)t * a.rs, j0, xs);                                  // predict #t
     }
     store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
     double e[kPPT];
@@ -1399,8 +1392,8 @@ __global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) 
         tile_partial(lw, e, a.part, s_scr, bid, Model::kWeightTable == 0);
     }
     CPH_STAMP(10);
-    if (a.store_logw || t + 1 == a.T) store4_stream(a.logw_next, j0, lw);
-    if (!a.wrel_from_state || t + 1 == a.T) store4_stream(a.wrel_next, j0, e);   // otherwise the next step reads the states
+    if (a.store_logw || t + 1 == a.T) store4(a.logw_next, j0, lw);
+    if (!a.wrel_from_state || t + 1 == a.T) store4(a.wrel_next, j0, e);   // otherwise the next step reads the states
     if (FUSED && bid == 0 && tid == 0 && t + 1 < a.T) {              // systematic offset of the resampling before step t+1
         const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(t + 1));
         a.ctrl->u0_pp[(t + 1) & 1] = u01_53(r.x, r.y);

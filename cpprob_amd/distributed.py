@@ -163,8 +163,9 @@ class IslandBatch:
 
     def run(self, slot, run_index):
         e, torch = self.engine, self.torch
-        if self.works[slot] is not None:          # the slot's previous all-gather must have read packed[slot] (long done by now)
-            self.works[slot].wait()
+        if self.works[slot] is not None:          # the slot's previous all-gather must have read packed[slot] before this run rewrites it:
+            with torch.cuda.stream(self.stream):  # Work.wait() orders the CURRENT stream after the collective -- make that the engine's
+                self.works[slot].wait()
             self.works[slot] = None
         e.run(run_index)
         e.results_device(self.packed[slot])
@@ -319,6 +320,7 @@ def run_joint(engine, collective, run_index=0, buffers=None, slot=None):
     raw = torch.from_numpy(engine.stats()).to(dev)
     torch.cuda.current_stream().synchronize()     # the copy ran on torch's stream, the collective runs on the engine's
     collective.all_reduce_sum(raw)
+    engine.sync()                                 # the reduction ran on the engine's stream; .cpu() below runs on torch's
     stats = normalise_joint_stats(raw.cpu().numpy(), s["log_norm"], s["max_logw"], engine.is_int)
     return stats, s
 
@@ -377,6 +379,7 @@ def run_exchange(engine, collective, run_index=0, counters=None):
     raw = torch.from_numpy(engine.stats()).to(dev)
     torch.cuda.current_stream().synchronize()     # the copy ran on torch's stream, the collective runs on the engine's
     collective.all_reduce_sum(raw)
+    engine.sync()                                 # the reduction ran on the engine's stream; .cpu() below runs on torch's
     stats = normalise_joint_stats(raw.cpu().numpy(), s["log_norm"], s["max_logw"], engine.is_int)
     if counters is not None:
         counters["records_sent"] = n_sent

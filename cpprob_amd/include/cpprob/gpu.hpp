@@ -97,6 +97,12 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
     if (a.nstored_out) a.nstored_out[i] = (int32_t)c.n_recorded;
 }
 
+template <class Tuple> struct observes_bytewise_copyable;
+template <class... A> struct observes_bytewise_copyable<std::tuple<A...>>
+{
+    static constexpr bool value = (std::is_trivially_copyable<A>::value && ...);
+};
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -118,7 +124,10 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
                      Result& res, HostStore* store, const std::size_t S)
 {
     using Tuple = typename Caller::observes_t;
-    static_assert(std::is_trivially_copyable<Tuple>::value || true, "observes are copied to the device bytewise");
+    // (std::tuple itself is not trivially copyable in libstdc++ even when every element is: check the elements)
+    static_assert(observes_bytewise_copyable<Tuple>::value,
+                  "CPPROB_REGISTER_MODEL: the observes tuple is copied to the device bytewise, so every model argument must be trivially "
+                  "copyable (arithmetic types, std::array of them); models with std::vector / NDArray arguments own host heap memory");
     Context ctx(opt.device);
     hip_check(hipSetDevice(opt.device), "hipSetDevice");
     hipStream_t stream = static_cast<hipStream_t>(cpprob_hip_stream(ctx.get()));

@@ -113,6 +113,9 @@ typedef struct cpprob_hip_summary {
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 int cpprob_hip_abi_version(void);
+/* Hash of the sources this binary was built from (cpprob_amd/build.py embeds it; "unknown" for a hand-rolled build):
+ * lets a loader refuse a stale libcpprob_hip.so that is newer than, but different from, the sources next to it. */
+const char* cpprob_hip_build_id(void);
 /* Number of visible HIP devices, or a negative error code (no GPU -> CPPROB_HIP_EDEVICE). */
 int cpprob_hip_device_count(void);
 /* Creates a context on `device` with its own stream.  Fails loudly without a GPU. */

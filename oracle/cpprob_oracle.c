@@ -521,6 +521,68 @@ ORC_API int orc_resample(int kind, const double *logw, uint64_t n_in, uint64_t s
 }
 
 /* ------------------------------------------------------------------------- */
+/* Systematic resampling of a TABLE-WEIGHT generation, order-independent form. */
+/* When every particle entered the step at the same log-weight (t = 0, or the   */
+/* previous step resampled) and the model's incremental weight takes one of K   */
+/* values (HMM: log N(y_t; mean[s], 1), K = 3; models.hpp:130-131,138-139), the  */
+/* weight of particle k is e[x_k] with e[s] = exp(ll_s - max ll), and the        */
+/* inclusive CDF is a function of INTEGER prefix counts c_s(k) = #{i <= k:        */
+/* x_i = s}:   C_k = fma(c_2, e_2, fma(c_1, e_1, c_0 * e_0))   (this order).       */
+/* Output j (position (j + u0) W/N, thesis p.36 remark) descends from            */
+/* a_j = min{k : C_k > (j + u0) W/N} = min{k : G_k > j},                          */
+/* G_k = ceil(fma(C_k, N/W, -u0)) clamped to [0, N], G of the last source = N.    */
+/* No running floating-point sum exists, so any evaluation order -- a serial     */
+/* loop here, tiles and wavefronts on the GPU, shards on several GPUs -- yields   */
+/* the same integers: this is the form whose ancestors are compared bit for bit. */
+/* before[s] = count of state s in the shards that precede this one (0 on one     */
+/* GPU), total[s] = count over the whole population; outputs [j0, j0 + n_out).     */
+/* Outputs whose ancestor is not among these n_in sources get -1.                  */
+/* ------------------------------------------------------------------------- */
+static double table_cdf(const uint64_t c[3], const double e[3])
+{
+    return fma((double)c[2], e[2], fma((double)c[1], e[1], (double)c[0] * e[0]));
+}
+
+ORC_API int orc_resample_table_systematic(const int32_t *x, uint64_t n_in, const double e[3], const uint64_t before[3],
+                                          const uint64_t total[3], int last_shard, uint64_t seed, uint64_t step,
+                                          uint64_t j0, uint64_t n_out, uint64_t n_total_out, int32_t *anc)
+{
+    const double N = (double)n_total_out;
+    const double W = table_cdf(total, e);
+    const double inv = N / W;
+    const double u0 = resample_u0(seed, step);
+    uint64_t c[3] = { before[0], before[1], before[2] };
+    for (uint64_t jj = 0; jj < n_out; ++jj) anc[jj] = -1;
+    double g_prev = ceil(fma(table_cdf(c, e), inv, -u0));     /* first output owned by this shard's sources */
+    if (g_prev < 0.0 || (before[0] + before[1] + before[2]) == 0) g_prev = 0.0;
+    if (g_prev > N) g_prev = N;
+    for (uint64_t k = 0; k < n_in; ++k) {
+        if (x[k] < 0 || x[k] > 2) return -2;
+        c[x[k]] += 1;
+        double g = ceil(fma(table_cdf(c, e), inv, -u0));
+        if (g < 0.0) g = 0.0;
+        if (g > N) g = N;
+        if (last_shard && k + 1 == n_in) g = N;
+        for (double j = g_prev; j < g; j += 1.0) {
+            if (j >= (double)j0 && j < (double)(j0 + n_out)) anc[(uint64_t)j - j0] = (int32_t)k;
+        }
+        if (g > g_prev) g_prev = g;
+    }
+    return 0;
+}
+
+/* e[s] = exp(ll_s - max ll) of step t of the HMM: the table the weights of generation t are drawn from */
+static void hmm_weight_table(double y, double e[3], double *mref)
+{
+    double l[3], mx;
+    for (int s = 0; s < 3; ++s) l[s] = orc_normal_logpdf(y, HMM_MEAN[s], 1);
+    mx = l[0] > l[1] ? l[0] : l[1];
+    if (l[2] > mx) mx = l[2];
+    for (int s = 0; s < 3; ++s) e[s] = exp(l[s] - mx);
+    if (mref) *mref = mx;
+}
+
+/* ------------------------------------------------------------------------- */
 /* SMC driver (row a15).  Markov step form of the three state-space models:   */
 /* step t: x_t ~ p(.|x_{t-1}) [sample #t], predict, logw += log p(y_t|x_t).    */
 /* After weighting step t (t < T-1): ESS_t = W^2/Q; resample iff ESS_t <       */
@@ -544,7 +606,14 @@ ORC_API int orc_smc(int model, const double *obs, size_t T, uint64_t n, uint64_t
     double lz = 0.0;
     int do_resample = 0;
     for (size_t t = 0; t < T; ++t) {
-        if (do_resample) {
+        if (do_resample && model == ORC_MODEL_HMM3 && resampler == ORC_RESAMPLE_SYSTEMATIC && ess_frac > 1.0) {
+            /* every step resamples: generation t-1 carries table weights -> the order-independent form */
+            double e[3];
+            uint64_t before[3] = { 0, 0, 0 }, total[3] = { 0, 0, 0 };
+            hmm_weight_table(obs[t - 1], e, NULL);
+            for (uint64_t i = 0; i < n; ++i) total[hist_int[(t - 1) * n + i]] += 1;
+            if (orc_resample_table_systematic(hist_int + (t - 1) * n, n, e, before, total, 1, seed, (uint64_t)t, 0, n, n, anc)) return -4;
+        } else if (do_resample) {
             orc_resample(resampler, logw, n, seed, (uint64_t)t, 0, n, n, anc, cdf);
         } else {
             for (uint64_t i = 0; i < n; ++i) anc[i] = (int32_t)i;

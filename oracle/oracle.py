@@ -15,6 +15,7 @@ RESAMPLE_DRAW_BASE = 1 << 40
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _up = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
@@ -58,6 +59,8 @@ def lib():
         L.orc_weighted_hist.argtypes = [_ip, _dp, u64, C.c_int, _dp]
         L.orc_resample.restype = C.c_int
         L.orc_resample.argtypes = [C.c_int, _dp, u64, u64, u64, u64, u64, u64, _ip, C.c_void_p]
+        L.orc_resample_table_systematic.restype = C.c_int
+        L.orc_resample_table_systematic.argtypes = [_ip, u64, _dp, _u64p, _u64p, C.c_int, u64, u64, u64, u64, u64, _ip]
         L.orc_smc.restype = C.c_int
         L.orc_smc.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
                               C.POINTER(dbl), _dp, _ip]
@@ -140,6 +143,23 @@ def resample(kind, logw, seed, step, j0=0, n_out=None, n_total_out=None):
     rc = lib().orc_resample(kind, logw, n_in, seed, step, j0, n_out, n_total_out, anc, None)
     if rc:
         raise RuntimeError("orc_resample failed")
+    return anc
+
+
+def resample_table_systematic(x, e, seed, step, before=None, total=None, last_shard=True, j0=0, n_out=None, n_total_out=None):
+    """Order-independent systematic resampling of a table-weight generation (integer prefix counts): ancestors of the
+    outputs [j0, j0 + n_out) among the sources x (states 0..2, weights e[state]); -1 where the ancestor is on another shard."""
+    x = np.ascontiguousarray(x, np.int32)
+    e = np.ascontiguousarray(e, np.float64)
+    cnt = np.bincount(x, minlength=3).astype(np.uint64)
+    before = np.zeros(3, np.uint64) if before is None else np.ascontiguousarray(before, np.uint64)
+    total = cnt if total is None else np.ascontiguousarray(total, np.uint64)
+    n_out = len(x) if n_out is None else n_out
+    n_total_out = len(x) if n_total_out is None else n_total_out
+    anc = np.zeros(n_out, np.int32)
+    rc = lib().orc_resample_table_systematic(x, len(x), e, before, total, int(bool(last_shard)), seed, step, j0, n_out, n_total_out, anc)
+    if rc:
+        raise RuntimeError("orc_resample_table_systematic failed rc=%d" % rc)
     return anc
 
 

@@ -12,10 +12,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # Tensors a test creates (torch.zeros, .cuda()) are produced on torch's stream while every engine works on its own
-    # non-blocking stream: have the harness order the two at each call, for every engine of the session.
-    import cpprob_amd.capi
-    cpprob_amd.capi.SYNC_TORCH_BEFORE_CALLS = True
 
 
 @pytest.fixture(scope="session")

@@ -10,6 +10,8 @@ import os
 import numpy as np
 import pytest
 
+from devmem import dcat, dtensor, dzeros, dzeros_like  # noqa: F401
+
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -18,8 +20,7 @@ FP_TOL = 1e-12
 
 
 def _t(a, dtype=None):
-    import torch
-    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+    return dtensor(a, dtype)
 
 
 def test_philox_words_bit_exact_vs_oracle_and_rocrand(engine, golden_dir):
@@ -27,7 +28,7 @@ def test_philox_words_bit_exact_vs_oracle_and_rocrand(engine, golden_dir):
     with open(os.path.join(golden_dir, "philox_rocrand.json")) as f:
         cases = json.load(f)["cases"]
     for c in cases:
-        out = torch.zeros(4, dtype=torch.int32, device="cuda")
+        out = dzeros(4, dtype=torch.int32)
         engine.philox_blocks(c["seed"], c["pid"], c["draw"], out)
         engine.sync()
         words = out.cpu().numpy().view(np.uint32)
@@ -37,7 +38,7 @@ def test_philox_words_bit_exact_vs_oracle_and_rocrand(engine, golden_dir):
         z = O.box_muller(c["words"])
         assert abs(z[0] - float.fromhex(c["normal_x"])) < 1e-13 and abs(z[1] - float.fromhex(c["normal_y"])) < 1e-13
     n = 100003
-    out = torch.zeros(4 * n, dtype=torch.int32, device="cuda")
+    out = dzeros(4 * n, dtype=torch.int32)
     engine.philox_blocks(777, 5, 9, out)
     engine.sync()
     got = out.cpu().numpy().view(np.uint32).reshape(n, 4)
@@ -49,13 +50,13 @@ def test_draws_match_oracle(engine):
     import torch
     n = 20000
     L = O.lib()
-    out = torch.zeros(n, dtype=torch.float64, device="cuda")
+    out = dzeros(n, dtype=torch.float64)
     engine.draw_normal(42, 1000, 3, 1.0, np.sqrt(5), out)
     engine.sync()
     ref = np.array([L.orc_draw_normal(42, 1000 + i, 3, 1.0, np.sqrt(5)) for i in range(n)])
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=FP_TOL, atol=FP_TOL)
 
-    outi = torch.zeros(n, dtype=torch.int32, device="cuda")
+    outi = dzeros(n, dtype=torch.int32)
     engine.draw_uniform_smallint(42, 0, 0, 0, 2, outi)
     engine.sync()
     ref = np.array([L.orc_draw_smallint(42, i, 0, 0, 2) for i in range(n)])
@@ -88,7 +89,7 @@ def test_logpdf_normal_reference_grid(engine, golden_dir):
     g = np.load(os.path.join(golden_dir, "logpdf_grid.npz"))
     grid = g["normal_grid"]
     x, mean, sigma = (_t(grid[:, k].copy()) for k in range(3))
-    out = torch.zeros_like(x)
+    out = dzeros_like(x)
     engine.logpdf_normal(x, mean, sigma, out)
     engine.sync()
     got = out.cpu().numpy()
@@ -105,7 +106,7 @@ def test_logpdf_edge_cases(engine):
     x = _t([1.0, 2.0, inf, -inf, 0.0])
     mean = _t([1.0, 1.0, 0.0, 0.0, 0.0])
     sigma = _t([0.0, 0.0, 1.0, 1.0, 2.0])
-    out = torch.zeros_like(x)
+    out = dzeros_like(x)
     engine.logpdf_normal(x, mean, sigma, out)
     engine.sync()
     got = out.cpu().numpy()
@@ -120,7 +121,7 @@ def test_logpdf_other_functors(engine, golden_dir):
     g = np.load(os.path.join(golden_dir, "logpdf_grid.npz"))
     u = g["uniform_grid"]
     x, a, b = (_t(u[:, k].copy()) for k in range(3))
-    out = torch.zeros_like(x)
+    out = dzeros_like(x)
     engine.logpdf_uniform_real(x, a, b, out)
     engine.sync()
     got = out.cpu().numpy()
@@ -131,12 +132,12 @@ def test_logpdf_other_functors(engine, golden_dir):
     p = g["poisson_grid"]
     xi = _t(p[:, 0].astype(np.int32))
     lam = _t(p[:, 1].copy())
-    out = torch.zeros(len(p), dtype=torch.float64, device="cuda")
+    out = dzeros(len(p), dtype=torch.float64)
     engine.logpdf_poisson(xi, lam, out)
     engine.sync()
     np.testing.assert_allclose(out.cpu().numpy(), g["poisson_expected"], atol=1e-9)
     xs = _t(np.array([-1, 0, 1, 2, 3], np.int32))
-    out = torch.zeros(5, dtype=torch.float64, device="cuda")
+    out = dzeros(5, dtype=torch.float64)
     engine.logpdf_uniform_smallint(xs, 0, 2, out)
     engine.sync()
     L = O.lib()
@@ -180,7 +181,7 @@ def test_resample_exact_weights_bit_exact(engine, kind, n, alive):
     rng = np.random.default_rng(1000 + n)
     logw = np.where(rng.random(n) < alive, 0.0, -np.inf)
     logw[rng.integers(0, n)] = 0.0
-    anc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    anc = dzeros(n, dtype=torch.int32)
     engine.resample(kind, _t(logw), 31337, 4, anc)
     engine.sync()
     ref = O.resample(kind, logw, 31337, 4)
@@ -195,7 +196,7 @@ def test_resample_generic_weights(engine, kind):
     n = 200000
     rng = np.random.default_rng(5)
     logw = rng.normal(size=n) * 2.0
-    anc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    anc = dzeros(n, dtype=torch.int32)
     engine.resample(kind, _t(logw), 99, 1, anc)
     engine.sync()
     got = anc.cpu().numpy()
@@ -219,10 +220,10 @@ def test_smc_bookkeep_decides_and_resamples_on_the_device(engine, kind):
     import torch
     n = 50000
     rng = np.random.default_rng(9)
-    ess = torch.zeros(3, dtype=torch.float64, device="cuda")
-    res = torch.zeros(3, dtype=torch.int32, device="cuda")
-    lz = torch.zeros(1, dtype=torch.float64, device="cuda")
-    anc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ess = dzeros(3, dtype=torch.float64)
+    res = dzeros(3, dtype=torch.int32)
+    lz = dzeros(1, dtype=torch.float64)
+    anc = dzeros(n, dtype=torch.int32)
     want_lz = 0.0
     for step, (spread, last) in enumerate([(2.0, False), (0.01, False), (1.0, True)]):
         logw = rng.normal(size=n) * spread                      # spread 2: ESS << N/2 -> resample; 0.01: ESS ~ N -> keep
@@ -250,7 +251,7 @@ def test_resample_degenerate_weight(engine):
     n = 10000
     logw = np.full(n, -np.inf)
     logw[1234] = 0.0
-    anc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    anc = dzeros(n, dtype=torch.int32)
     for kind in (O.RESAMPLE_SYSTEMATIC, O.RESAMPLE_STRATIFIED, O.RESAMPLE_MULTINOMIAL):
         engine.resample(kind, _t(logw), 1, 0, anc)
         engine.sync()
@@ -263,9 +264,9 @@ def test_resample_subrange_matches_full(engine):
     n = 50000
     rng = np.random.default_rng(8)
     logw = rng.normal(size=n)
-    full = torch.zeros(n, dtype=torch.int32, device="cuda")
+    full = dzeros(n, dtype=torch.int32)
     engine.resample(O.RESAMPLE_SYSTEMATIC, _t(logw), 3, 2, full)
-    part = torch.zeros(7777, dtype=torch.int32, device="cuda")
+    part = dzeros(7777, dtype=torch.int32)
     engine.resample(O.RESAMPLE_SYSTEMATIC, _t(logw), 3, 2, part, j0=12345, n_total_out=n)
     engine.sync()
     assert np.array_equal(part.cpu().numpy(), full.cpu().numpy()[12345:12345 + 7777])
@@ -277,12 +278,12 @@ def test_gather(engine):
     rng = np.random.default_rng(0)
     idx = rng.integers(0, n, n).astype(np.int32)
     src = rng.normal(size=n)
-    dst = torch.zeros(n, dtype=torch.float64, device="cuda")
+    dst = dzeros(n, dtype=torch.float64)
     engine.gather(_t(src), _t(idx), dst)
     engine.sync()
     assert np.array_equal(dst.cpu().numpy(), src[idx])
     srci = rng.integers(0, 3, n).astype(np.int32)
-    dsti = torch.zeros(n, dtype=torch.int32, device="cuda")
+    dsti = dzeros(n, dtype=torch.int32)
     engine.gather(_t(srci), _t(idx), dsti)
     engine.sync()
     assert np.array_equal(dsti.cpu().numpy(), srci[idx])

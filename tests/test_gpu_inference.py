@@ -5,9 +5,13 @@ observation vectors + exact posteriors, and through size-independent properties 
 """
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
+
+from devmem import dcat, dtensor, dzeros, dzeros_like  # noqa: F401
 
 import cpprob_amd as cp
 from oracle import exact as E
@@ -139,6 +143,9 @@ def _compare_smc(engine, model, obs, n, seed, resampler, ess):
     # summation order of the parallel scan; a flipped particle stays different afterwards.
     frac_anc = np.mean(anc != ref["anc"])
     assert frac_anc < 2e-4, frac_anc
+    if model == cp.MODEL_HMM3 and resampler == cp.RESAMPLE_SYSTEMATIC and ess > 1.0:
+        # table weights on an every-step schedule: integer prefix counts, bit-exact index work
+        assert np.array_equal(anc, ref["anc"]) and np.array_equal(vals, ref["hist"])
     if vals.dtype == np.int32:
         assert np.mean(vals != ref["hist"]) < 1e-3
     else:
@@ -165,34 +172,54 @@ def test_smc_hmm_matches_oracle(engine, golden_dir, resampler, ess):
     _compare_smc(engine, cp.MODEL_HMM3, obs, 30000, 11, resampler, ess)
 
 
-@pytest.mark.parametrize("n", [300_000, 1_200_000, 2_000_000])
-def test_smc_hmm_matches_oracle_on_the_weights_from_states_paths(engine, golden_dir, n):
-    """From 256 tiles up, table-weight models on an every-step schedule derive the previous generation's weights from the
-    stored states (no wrel traffic between steps): fused prologue with 2 / 8 partials per lane, and the un-fused form
-    above 1664 tiles.  Per-particle parity with the oracle: bit-identical states and ancestors up to the first CDF-boundary
-    flip (the parallel scan rounds differently from the oracle's sequential sum: ~1e-10 per boundary, ~2e7 boundaries);
-    the flip itself moves a handful of offspring to the neighbouring source, after which systematic resampling -- one
-    shared offset -- legitimately diverges and only the estimators are compared."""
+@pytest.mark.parametrize("n", [30_000, 300_000, 1_200_000, 2_000_000, 4_300_000])
+def test_smc_hmm_every_step_is_bit_exact_against_the_oracle(engine, golden_dir, n):
+    """Index work is bit-exact: table-weight models on an every-step schedule resample from INTEGER prefix counts
+    (cpprob_amd/csrc/step_counts.hpp; oracle: orc_resample_table_systematic states the same arithmetic), so states and
+    ancestors equal the oracle's at every size -- one level of the count hierarchy (<= 64 tiles), two (<= 4096) and three."""
     obs = _obs(golden_dir, "hmm16")
     engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=11, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=2.0)
     engine.run()
     ref = O.smc(cp.MODEL_HMM3, obs, n, 11, cp.RESAMPLE_SYSTEMATIC, 2.0)
     vals, anc = engine.values(), engine.ancestors()
-    T = len(obs)
-    differs = [t for t in range(1, T) if not np.array_equal(anc[t], ref["anc"][t])]
-    first = differs[0] if differs else T
-    assert np.array_equal(vals[:first], ref["hist"][:first]) and np.array_equal(anc[1:first], ref["anc"][1:first])
-    if first < T:
-        d = anc[first].astype(np.int64) - ref["anc"][first].astype(np.int64)
-        assert np.abs(d).max() == 1 and np.count_nonzero(d) <= 8  # a boundary flip: a few offspring moved to the adjacent source
+    assert np.array_equal(anc, ref["anc"])
+    assert np.array_equal(vals, ref["hist"])
     gess, gres = engine.step_trace()
     assert np.array_equal(gres, ref["resampled"])
-    np.testing.assert_allclose(gess[:first], ref["ess"][:first], rtol=1e-9)
-    np.testing.assert_allclose(gess, ref["ess"], rtol=2e-3)
+    np.testing.assert_allclose(gess, ref["ess"], rtol=1e-9)
     s = engine.summary()
-    assert abs(s["log_evidence"] - ref["log_z"]) < (1e-9 if first == T else 1e-2)       # diverged runs: two draws of the estimator
-    np.testing.assert_allclose(engine.stats(), O.smoothing(ref["hist"], ref["anc"], ref["logw"]), atol=1e-12 if first == T else 5e-3)
-    np.testing.assert_allclose(engine.stats(), O.smoothing(vals, anc, engine.logw()), rtol=1e-9, atol=1e-11)
+    assert abs(s["log_evidence"] - ref["log_z"]) < 1e-9
+    np.testing.assert_allclose(engine.stats(), O.smoothing(ref["hist"], ref["anc"], ref["logw"]), atol=1e-12)
+    np.testing.assert_allclose(engine.logw(), ref["logw"], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(engine.paths(), np.take_along_axis(vals, O.lineage(anc), axis=1))
+
+
+def test_smc_hmm_every_step_floating_point_form_stays_within_its_flip_bound(engine, golden_dir):
+    """The floating-point form of the same step (CPPROB_STEP_COUNTS=0 in a fresh process; what continuous-weight models and
+    ESS-triggered schedules run) differs from the oracle only by CDF-boundary flips of the parallel summation order."""
+    code = (
+        "import numpy as np, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch\nimport cpprob_amd as cp\nfrom oracle import oracle as O\n"
+        "obs = np.load(%r)['hmm16']\n"
+        "e = cp.Engine(0)\n"
+        "e.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 1200000, seed=11, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=2.0)\n"
+        "e.run()\n"
+        "ref = O.smc(cp.MODEL_HMM3, obs, 1200000, 11, cp.RESAMPLE_SYSTEMATIC, 2.0)\n"
+        "anc = e.ancestors()\n"
+        "T = len(obs)\n"
+        "differs = [t for t in range(1, T) if not np.array_equal(anc[t], ref['anc'][t])]\n"
+        "first = differs[0] if differs else T\n"
+        "assert np.array_equal(e.values()[:first], ref['hist'][:first])\n"
+        "if first < T:\n"
+        "    d = anc[first].astype(np.int64) - ref['anc'][first].astype(np.int64)\n"
+        "    assert np.abs(d).max() == 1 and np.count_nonzero(d) <= 8, (np.abs(d).max(), np.count_nonzero(d))\n"
+        "assert np.abs(e.stats() - O.smoothing(ref['hist'], ref['anc'], ref['logw'])).max() < 5e-3\n"
+        "print('first differing step', first)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(golden_dir, "observations.npz"))
+    env = dict(os.environ, CPPROB_STEP_COUNTS="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
 
 
 @pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_MULTINOMIAL])
@@ -304,8 +331,8 @@ def _run_joint_virtual(model, alg, obs, n_per, world, seed, ess):
     for r, e in enumerate(engines):
         e.begin(alg, model, obs, n_per, seed=seed, ess_threshold=ess, particle_offset=r * n_per, n_global=world * n_per, scope=cp.SCOPE_GLOBAL)
     T, K = engines[0].T, engines[0].K
-    locals_ = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in range(world)]
-    allt = torch.zeros(3 * world, dtype=torch.float64, device="cuda")
+    locals_ = [dzeros(4, dtype=torch.float64) for _ in range(world)]
+    allt = dzeros(3 * world, dtype=torch.float64)
     steps = [T - 1] if alg == cp.ALG_SIS else range(T)
     for t in steps:
         for r, e in enumerate(engines):
@@ -344,8 +371,8 @@ def _run_exchange_virtual(model, obs, n_pers, seed, ess):
         e.begin(cp.ALG_SMC, model, obs, n_pers[r], seed=seed, ess_threshold=ess, particle_offset=int(begins[r]), n_global=int(begins[-1]), scope=cp.SCOPE_EXCHANGE)
     T, K = engines[0].T, engines[0].K
     vdt = torch.int32 if engines[0].is_int else torch.float64
-    locals_ = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in range(world)]
-    allt = torch.zeros(3 * world, dtype=torch.float64, device="cuda")
+    locals_ = [dzeros(4, dtype=torch.float64) for _ in range(world)]
+    allt = dzeros(3 * world, dtype=torch.float64)
     moved = []
     for t in range(T):
         for r, e in enumerate(engines):
@@ -485,7 +512,7 @@ def test_results_device_and_island_batch_match_the_host_read_out(engine, golden_
     from cpprob_amd import distributed as D
     obs = _obs(golden_dir, "hmm16")
     engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 50000, seed=3, ess_threshold=0.5, scope=cp.SCOPE_ISLAND)
-    out = torch.zeros(4 + 16 * 3, dtype=torch.float64, device="cuda")
+    out = dzeros(4 + 16 * 3, dtype=torch.float64)
     engine.run(5)
     engine.results_device(out)
     engine.sync()
@@ -499,7 +526,7 @@ def test_results_device_and_island_batch_match_the_host_read_out(engine, golden_
     stats, lz, iess = batch.results(5 % 4)
     assert np.array_equal(stats, st) and abs(lz - s["log_evidence"]) < 1e-14 and iess == 1.0
     with pytest.raises(cp.CpprobHipError):
-        engine.results_device(torch.zeros(3, dtype=torch.float64, device="cuda"))
+        engine.results_device(dzeros(3, dtype=torch.float64))
 
 
 def test_step_protocol_world1_is_bit_identical_to_run(engine, golden_dir):
@@ -517,7 +544,7 @@ def test_step_protocol_world1_is_bit_identical_to_run(engine, golden_dir):
     assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
     # the same with the results left on the device (no host synchronisation inside run_joint)
     import torch
-    slot = torch.zeros(4 + engine.T * engine.K, dtype=torch.float64, device="cuda")
+    slot = dzeros(4 + engine.T * engine.K, dtype=torch.float64)
     assert D.run_joint(engine, coll, slot=slot) is None
     stats2, s2 = D.joint_results(engine, slot)
     np.testing.assert_allclose(stats2, stats, rtol=1e-15, atol=0)
