@@ -85,10 +85,14 @@ struct cpprob_hip_ctx {
     size_t cap_particles = 0; int cap_T = 0; bool cap_int = false; bool cap_multinomial = false;
     // prefix-count form of the step (table-weight models on an every-step schedule; step_counts.hpp)
     uint64_t* d_hier = nullptr; size_t hier_entries = 0;   // three copies of the 64-ary count hierarchy
-    Hier hier{};
-    size_t hier_upper_off = 0, hier_upper_n = 0;           // copy 1's levels >= 1 (cleared at the start of every run)
+    HierTable hier{};                                      // host copy of the hierarchy's layout
+    HierTable* d_hier_table = nullptr;                     // the same in device memory
+    size_t hier_per_copy = 0;                              // 64-bit words per copy
+    int hier_phase = 0;                                    // copy that step 0 of the next run reads: chosen so that the copy it adds into is clean
+    bool hier_run_open = false;                            // a run's steps are in flight (the rotation's state is known only at run boundaries)
     int64_t* d_annex_base = nullptr;                       // [T + 1] exchange scope: annex columns in use before each step's immigrants
     bool counts_mode = false;                              // this run's steps use smc_step_counts_kernel
+    std::vector<double> h_ll_tab, h_e_tab;                 // host copies of the table-weight model's per-step tables ([T][3], [T][4])
 
     // scratch for building blocks
     Partial* d_bb_part = nullptr; double* d_bb_bc = nullptr; double* d_bb_bf = nullptr; double* d_bb_wrel = nullptr; void* d_bb_col = nullptr;
@@ -345,9 +349,26 @@ template <class Model>
 bool counts_eligible(const cpprob_hip_ctx* c)
 {
     static const bool enabled = !(getenv("CPPROB_STEP_COUNTS") && getenv("CPPROB_STEP_COUNTS")[0] == '0');
-    return enabled && Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1 && c->cfg.algorithm == CPPROB_HIP_ALG_SMC &&
+    return enabled && c->nb <= kCountsMaxTiles && Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1 && c->cfg.algorithm == CPPROB_HIP_ALG_SMC &&
            c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && c->cfg.ess_threshold > 1.0 &&
            (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND);
+}
+
+// Philox4x32-10 on the host (cpprob/detail/rng.hpp's draw_block): the systematic offset of a resampling step is a pure function of
+// (seed, step), so the launch carries it as a kernel argument instead of a device-side hand-over between consecutive kernels.
+double host_resample_u0(uint64_t seed, uint64_t step)
+{
+    const uint64_t draw = (1ull << 40) + step, group = 0;
+    uint32_t c0 = (uint32_t)draw, c1 = (uint32_t)(draw >> 32), c2 = (uint32_t)group, c3 = (uint32_t)(group >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint64_t bits = (uint64_t)c0 | ((uint64_t)(c1 >> 11) << 32);
+    return (double)bits * 1.1102230246251565e-16;
 }
 
 template <class Model>
@@ -358,10 +379,38 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         a.mp = c->mp; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
         a.values = static_cast<typename Model::store_t*>(c->d_values); a.anc = c->d_anc;
         a.logw_next = c->d_logw[0]; a.wrel_next = c->d_wrel[0]; a.part = c->d_part[0];
-        a.h = c->hier; a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
+        {
+            if (t == 0) {
+                // a run that was abandoned half-way leaves the rotation in an unknown state: start over from clean copies
+                if (c->hier_run_open) { (void)hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream); c->hier_phase = 0; }
+                c->hier_run_open = true;
+            }
+            const int kp = (t + c->hier_phase) % 3, kn = (kp + 1) % 3, kc = (kp + 2) % 3;
+            for (int l = 0; l < kHierMaxLevels; ++l) { a.h.lvl[l] = c->hier.lvl[kp][l]; a.h.n_ent[l] = c->hier.n_ent[l]; }
+            a.h.n_lev = c->hier.n_lev;
+            a.h.to_next = (int64_t)(kn - kp) * (int64_t)c->hier_per_copy; a.h.to_clear = (int64_t)(kc - kp) * (int64_t)c->hier_per_copy;
+            if (t + 1 == c->T) {
+                // after the last step exactly one copy is dirty -- the one it read; the next run starts its rotation there, so the copy
+                // its step 0 adds into is clean without any clearing launch
+                if (c->T >= 2) c->hier_phase = kp;
+                c->hier_run_open = false;
+            }
+            a.h.table = c->d_hier_table; a.h.copy = kp;
+        }
+        a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
         a.all_totals = all_totals; a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
+        for (int k = 0; k < 4; ++k) { a.e_prev[k] = t > 0 ? c->h_e_tab[(size_t)(t - 1) * 4 + k] : 0.0; a.e_cur[k] = c->h_e_tab[(size_t)t * 4 + k]; }
+        for (int k = 0; k < 3; ++k) a.ll_cur[k] = c->h_ll_tab[(size_t)t * 3 + k];
+        a.u0 = t > 0 ? host_resample_u0(c->run_seed, (uint64_t)t) : 0.0;
         ProfScope ps(c, 0);
-        hipLaunchKernelGGL(smc_step_counts_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        const bool last = t + 1 == c->T, sharded = all_totals != nullptr;
+        if (sharded) {
+            if (last) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL((smc_step_counts_kernel<Model, true, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        } else {
+            if (last) hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        }
         if (t + 1 == c->T) { c->cur = 0; c->cur_part = 0; }        // the last step left logw / wrel / partials in buffer 0
     }
 }
@@ -480,7 +529,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
     dfree(c->d_ctrl); dfree(c->d_local_totals);
-    dfree(c->d_send_src);
+    dfree(c->d_send_src); dfree(c->d_hier_table);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -578,12 +627,11 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_stats_part, (size_t)c->smooth_grid * T * 8 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_stats, T * 8 * sizeof(double)));
         {
-            // 64-ary hierarchy of per-tile state counts, three rotating copies (step_counts.hpp)
-            size_t per_copy = 0;
-            for (size_t e = (size_t)c->nb;; e = (e + 63) / 64) { per_copy += e; if (e <= 64) break; }
+            // 64-ary hierarchy of per-tile state counts, three rotating copies (step_counts.hpp); levels >= 1 one line per entry
+            size_t per_copy = 0; int lev = 0;
+            for (size_t e = (size_t)c->nb;; e = (e + 63) / 64, ++lev) { per_copy += e * (lev == 0 ? 1 : kHierStride); if (e <= 64) break; }
             c->hier_entries = 3 * per_copy;
             HIP_TRY(c, hipMalloc(&c->d_hier, c->hier_entries * sizeof(uint64_t)));
-            HIP_TRY(c, hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream));
             HIP_TRY(c, hipMalloc(&c->d_annex_base, (T + 1) * sizeof(int64_t)));
             HIP_TRY(c, hipMemsetAsync(c->d_annex_base, 0, (T + 1) * sizeof(int64_t), c->stream));
         }
@@ -596,13 +644,20 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     {
         std::memset(&c->hier, 0, sizeof c->hier);
         size_t per_copy = 0; int nl = 0;
-        size_t off[kHierMaxLevels] = {0, 0, 0, 0};
-        for (size_t e = (size_t)c->nb;; e = (e + 63) / 64) { off[nl] = per_copy; c->hier.n_ent[nl] = (int)e; per_copy += e; ++nl; if (e <= 64) break; }
-        c->hier.n_lev = nl;
+        size_t off[kHierMaxLevels] = {0, 0, 0};
+        for (size_t e = (size_t)c->nb;; e = (e + 63) / 64) {
+            if (nl >= kHierMaxLevels) break;                       // (more than 64^3 tiles: the prefix-count form is not eligible)
+            off[nl] = per_copy; c->hier.n_ent[nl] = (int)e; per_copy += e * (nl == 0 ? 1 : kHierStride); ++nl;
+            if (e <= 64) break;
+        }
+        c->hier.n_lev = nl; c->hier_per_copy = per_copy;
         for (int k = 0; k < 3; ++k)
             for (int l = 0; l < nl; ++l) c->hier.lvl[k][l] = c->d_hier + (size_t)k * per_copy + off[l];
-        c->hier_upper_off = per_copy + (nl > 1 ? off[1] : per_copy); c->hier_upper_n = nl > 1 ? per_copy - off[1] : 0;
         if (3 * per_copy > c->hier_entries) return fail(c, CPPROB_HIP_EDEVICE, "count hierarchy exceeds its allocation");
+        if (!c->d_hier_table) HIP_TRY(c, hipMalloc(&c->d_hier_table, sizeof(HierTable)));
+        HIP_TRY(c, hipMemcpyAsync(c->d_hier_table, &c->hier, sizeof(HierTable), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream));     // (the layout may have changed)
+        c->hier_phase = 0; c->hier_run_open = false;
     }
     c->rs = c->ld + c->annex_cap;
     c->annex_used = 0; c->imm_l0 = 0; c->imm_l1 = c->n; c->imm_col0 = 0; c->plan.t = -1;
@@ -618,6 +673,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         std::vector<double> tab((size_t)c->T * 3);
         for (int t = 0; t < c->T; ++t)
             for (int s2 = 0; s2 < 3; ++s2) tab[(size_t)t * 3 + s2] = normal_logpdf(h_obs[t], c->mp.hmm_mean[s2], 1.0);
+        c->h_ll_tab = tab;
         HIP_TRY(c, hipMalloc(&c->d_ll_tab, tab.size() * sizeof(double)));
         HIP_TRY(c, hipMemcpy(c->d_ll_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
         c->mp.ll_tab = c->d_ll_tab;
@@ -629,6 +685,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
             for (int s2 = 0; s2 < 3; ++s2) et[(size_t)t * 4 + s2] = std::exp(l[s2] - mx);
             et[(size_t)t * 4 + 3] = mx;
         }
+        c->h_e_tab = et;
         dfree(c->d_e_tab);
         HIP_TRY(c, hipMalloc(&c->d_e_tab, et.size() * sizeof(double)));
         HIP_TRY(c, hipMemcpy(c->d_e_tab, et.data(), et.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -664,7 +721,6 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
         dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); });
         const bool fused = step_is_fused(c);
         if (c->counts_mode) {
-            if (c->hier_upper_n) HIP_TRY(c, hipMemsetAsync(c->d_hier + c->hier_upper_off, 0, c->hier_upper_n * sizeof(uint64_t), c->stream));
             {
                 ProfScope group(c, 0, c->T);
                 c->profile_suspended = true;

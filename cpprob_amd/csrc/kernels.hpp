@@ -129,7 +129,9 @@ __device__ __forceinline__ void store4_write_through(int32_t* __restrict__ p, in
         I4 w;
         w[0] = v[q]; w[1] = v[q + 1]; w[2] = v[q + 2]; w[3] = v[q + 3];
         int32_t* addr = p + i + q;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(addr), "v"(w) : "memory");
+        // (s_nop 1 inside the string: hipcc does not pad an asm statement's hazards, and its next instruction may otherwise
+        //  overwrite the data registers before a 16-byte store has read them -- lanes 12..15 of every row lost anc[0] that way)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(addr), "v"(w) : "memory");
     }
 }
 

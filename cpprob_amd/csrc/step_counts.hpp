@@ -5,30 +5,45 @@
 // the weight of particle k of generation t-1 is e[x_k], e[s] = exp(ll_s - max ll), and its inclusive CDF value is a function of
 // the prefix counts c_s(k) = #{i <= k : x_i = s} alone:
 //        C_k = fma(c_2, e_2, fma(c_1, e_1, c_0 * e_0)),   G_k = ceil(fma(C_k, N / W, -u0)),   ancestor of output j = min{k : G_k > j}
-// (oracle/cpprob_oracle.c::orc_resample_table_systematic states the same arithmetic).  No running floating-point sum exists, so
+// (the CPU restatement the parity tests compare with states the same arithmetic).  No running floating-point sum exists, so
 // tiles, wavefronts and shards may evaluate it in any order and still produce the same integers: ancestors are bit-exact against
-// the oracle at every population size and over any number of GPUs.
+// that restatement at every population size and over any number of GPUs.
 //
 // The prefix counts live in a 64-ary hierarchy written by the kernel that produced the generation:
 //   level 0     one entry per 1024-particle tile   (plain store by the tile's workgroup)
-//   level l     one entry per 64^l tiles            (64-bit integer atomic add by every workgroup below it; exact, order-free)
-// entry = n_0 | n_1 << 32 (n_2 follows from the number of valid particles).  A workgroup that needs the prefix at tile c sums, per
-// level, the < 64 entries that precede c's block inside its parent block: one masked load per level per lane and ONE wavefront
-// reduction -- instead of every workgroup re-reading every tile partial (the r01 prologue: 3.9 of 12.3 us, 23 MB of L2 reads per step).
-// No LDS table, no workgroup barrier, any population size, no normalisation launch between steps.
-// Three copies rotate: step t reads copy t % 3 (generation t-1), adds into copy (t + 1) % 3 and clears copy (t + 2) % 3.
+//   level 1     one entry per 64 tiles              (one 64-bit integer atomic add per workgroup: exact, order-free)
+//   level 2     one entry per 4096 tiles            (added to by the LAST workgroup to arrive at each level-1 entry, which the
+//                                                    entry's own arrival field tells from the value the add returned)
+// so no address ever takes more than 64 atomics per step (a flat "everybody adds to the top" form serialises at ~12 ns per add:
+// 117 us per step at 10^7 particles -- measured).  Entries of levels >= 1 sit on cache lines of their own.
+// entry = n_0 | n_1 << 28 | arrivals << 56 (n_2 follows from the number of valid particles).  A workgroup that needs the prefix at
+// tile c sums, per level, the < 64 entries that precede c's block inside its parent block: one masked load per level per lane and
+// ONE wavefront reduction -- instead of every workgroup re-reading every tile partial (the r01 prologue: 3.9 of 12.3 us, 23 MB of
+// L2 reads per step).  No LDS table, no normalisation launch between steps, up to 64^3 tiles (2.7e8 particles) per GPU.
+// Three copies rotate: a step reads one (generation t-1), adds into the next and clears the third.
 #pragma once
 #include "kernels.hpp"
 
 namespace cph {
 
-constexpr int kHierMaxLevels = 4;              // 64^4 tiles of 1024 particles exceed the int32 particle index range
+constexpr int kHierMaxLevels = 3;
+constexpr int kHierStride = 16;                // 64-bit words between entries of the levels >= 1: one 128-byte line each
+constexpr int64_t kCountsMaxTiles = 64LL * 64 * 64;
+constexpr uint64_t kCntMask = (1ull << 28) - 1;
 
-struct Hier {
-    uint64_t* lvl[3][kHierMaxLevels];          // [copy][level]
+struct HierTable {                             // device-resident: every copy, every level (run-time indexed by the rare paths)
+    uint64_t* lvl[3][kHierMaxLevels];
     int n_ent[kHierMaxLevels];                 // entries per level; n_ent[0] = tiles
     int n_lev;                                 // levels in use: the last one has <= 64 entries
 };
+struct Hier {                                  // what a launch carries: the copy it reads, by level (compile-time indices only -- a
+    const uint64_t* lvl[kHierMaxLevels];       // run-time index into a kernel-argument array would send the struct through scratch
+    int n_ent[kHierMaxLevels];                 // memory) and where the other two copies sit relative to it
+    int n_lev;
+    int64_t to_next, to_clear;                 // word offsets from the copy read to the copy written / the copy cleared
+    const HierTable* table; int copy;          // the same hierarchy in device memory
+};
+__device__ __forceinline__ constexpr int hier_stride(int level) { return level == 0 ? 1 : kHierStride; }
 
 // ---- 32-bit wavefront sums / scans (one instruction per DPP step) -------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf>
@@ -45,8 +60,14 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), kWave - 1); }
 
+// Wave-uniform doubles the compiler would otherwise keep in scalar registers: the step kernel has more of them than the 102 SGPRs
+// a wave owns (58 spilled, each reloaded ~10 times, in the first build).  Laundering a value through an empty asm with a vector
+// constraint parks it in a VGPR and its arithmetic stays on the vector unit.
+__device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
+
 struct Cnt2 { uint32_t n0, n1; };
-__device__ __forceinline__ Cnt2 unpack2(uint64_t w) { return Cnt2{(uint32_t)w, (uint32_t)(w >> 32)}; }
+__device__ __forceinline__ uint32_t cnt_n0(uint64_t w) { return (uint32_t)(w & kCntMask); }
+__device__ __forceinline__ uint32_t cnt_n1(uint64_t w) { return (uint32_t)((w >> 28) & kCntMask); }
 
 // The tile-level CDF of generation t-1 in the canonical arithmetic.  Counts of the shards that precede this one enter as exact
 // doubles (integers below 2^53), so a sharded run evaluates the very expression a single GPU would.
@@ -58,7 +79,9 @@ struct TableCdf {
         const double c2 = cv - c0 - c1;
         return fma(c2, e2, fma(c1, e1, __dmul_rn(c0, e0)));
     }
-    __device__ __forceinline__ double g(double C) const { return fmin(fmax(ceil(fma(C, inv, -u0)), 0.0), n_pop); }
+    // (never negative: C >= 0 and u0 < 1; may exceed n_pop by rounding only for the population's last sources, whose surplus
+    //  outputs nobody consumes -- the clamp of the stated arithmetic changes no ancestor)
+    __device__ __forceinline__ double g(double C) const { return ceil(fma(C, inv, -u0)); }
     // first output owned by the sources that follow `n0, n1` state-0/1 particles among `nv` local particles
     __device__ __forceinline__ double g_at(uint32_t n0, uint32_t n1, int64_t nv) const
     {
@@ -68,7 +91,7 @@ struct TableCdf {
 
 // Exclusive prefix counts at tile c (wave-uniform result; every lane of the calling wave takes part): per level, the entries that
 // precede c's block inside its parent block.
-__device__ __forceinline__ Cnt2 hier_prefix(const Hier& h, int copy, int c)
+__device__ __forceinline__ Cnt2 hier_prefix(const Hier& h, int c)
 {
     const int lane = lane_id();
     uint32_t s0 = 0, s1 = 0;
@@ -78,8 +101,8 @@ __device__ __forceinline__ Cnt2 hier_prefix(const Hier& h, int copy, int c)
             const int blk = c >> (6 * l);                       // c's block at this level
             const int first = (blk >> 6) << 6;                  // first block of the parent
             if (lane < (blk & 63)) {
-                const uint64_t w = h.lvl[copy][l][first + lane];
-                s0 += (uint32_t)w; s1 += (uint32_t)(w >> 32);
+                const uint64_t w = h.lvl[l][(int64_t)(first + lane) * hier_stride(l)];
+                s0 += cnt_n0(w); s1 += cnt_n1(w);
             }
         }
     }
@@ -87,30 +110,32 @@ __device__ __forceinline__ Cnt2 hier_prefix(const Hier& h, int copy, int c)
 }
 
 // Totals of the generation: the sum of the (<= 64) top-level entries.
-__device__ __forceinline__ Cnt2 hier_total(const Hier& h, int copy)
+__device__ __forceinline__ Cnt2 hier_total(const Hier& h)
 {
     const int lane = lane_id();
-    const int top = h.n_lev - 1;
     uint64_t w = 0;
-    if (lane < h.n_ent[top]) w = h.lvl[copy][top][lane];
-    return Cnt2{wave_sum_u32((uint32_t)w), wave_sum_u32((uint32_t)(w >> 32))};
+#pragma unroll
+    for (int l = 0; l < kHierMaxLevels; ++l)
+        if (l == h.n_lev - 1 && lane < h.n_ent[l]) w = h.lvl[l][(int64_t)lane * hier_stride(l)];
+    return Cnt2{wave_sum_u32(cnt_n0(w)), wave_sum_u32(cnt_n1(w))};
 }
 
 // Largest tile c in [0, nb) whose first owned output G(prefix(c)) is <= g (0 when there is none), with its exclusive prefix
-// counts: top-down descent, one load + one scan per level.  Wave-uniform; used when the answer is not next to the caller's guess
-// (very uneven tile masses) and by the exchange scope's packing, whose outputs sit at the ends of the shard.
-__device__ __forceinline__ int hier_locate(const Hier& h, int copy, const TableCdf& tc, int64_t n, double g, Cnt2& P)
+// counts: top-down descent, one load + one scan per level.  Wave-uniform; the last resort of the ancestor search (tile masses so
+// uneven that two local probes miss) and the exchange scope's packing, whose outputs sit at the ends of the shard.
+__device__ __forceinline__ int hier_locate(const HierTable* __restrict__ ht, int copy, const TableCdf& tc, int64_t n, double g, Cnt2& P)
 {
     const int lane = lane_id();
     int blk = 0;
     uint32_t p0 = 0, p1 = 0;
-    for (int l = h.n_lev - 1; l >= 0; --l) {
+    for (int l = ht->n_lev - 1; l >= 0; --l) {
         const int idx = (blk << 6) + lane;
         uint64_t w = 0;
-        const bool in = idx < h.n_ent[l];
-        if (in) w = h.lvl[copy][l][idx];
-        const uint32_t i0 = wave_incl_scan_u32((uint32_t)w), i1 = wave_incl_scan_u32((uint32_t)(w >> 32));
-        const uint32_t x0 = p0 + i0 - (uint32_t)w, x1 = p1 + i1 - (uint32_t)(w >> 32);     // exclusive prefix at child `lane`
+        const bool in = idx < ht->n_ent[l];
+        if (in) w = ht->lvl[copy][l][(int64_t)idx * (l == 0 ? 1 : kHierStride)];
+        const uint32_t v0 = cnt_n0(w), v1 = cnt_n1(w);
+        const uint32_t i0 = wave_incl_scan_u32(v0), i1 = wave_incl_scan_u32(v1);
+        const uint32_t x0 = p0 + i0 - v0, x1 = p1 + i1 - v1;                                   // exclusive prefix at child `lane`
         const int64_t tile0 = (int64_t)idx << (6 * l);                                         // first tile of the child
         const int64_t nv = tile0 * kTile < n ? tile0 * kTile : n;
         const bool ok = in && tc.g_at(x0, x1, nv) <= g;
@@ -132,54 +157,67 @@ struct CountsLds {
 
 // Ancestors of the kTile consecutive outputs starting at global output index gj_first (n_out of them), among THIS shard's sources,
 // -1 where the ancestor belongs to a shard that precedes this one; outputs at or beyond o_hi = G(all local sources) belong to the
-// shards that follow (the caller tests that).  `guess` = a tile expected to hold the first ancestor (window[] = prefix counts of
-// tiles guess-1 .. guess+3 when the caller has them: have_window), `own` = the states of tile `guess` fetched at kernel entry.
-// Slots must hold -1 and be visible (the caller's barrier) on entry.
+// shards that follow (the caller tests that).  `guess` = a tile expected to hold the first ancestor; raw_m1 / raw_0 / raw_p1 = the
+// states of tiles guess-1, guess, guess+1 fetched at kernel entry (an output tile overlaps two of them almost surely, so no
+// load waits for the search).  Slots must hold -1 and be visible (the caller's barrier) on entry.
 template <class S>
-__device__ __forceinline__ void ancestors_counts(const Hier& h, int copy, const TableCdf& tc, const S* __restrict__ states, int64_t n, int nb,
-                                                 bool last_shard, double gj_first, int n_out, int guess, uint32_t own_raw,
-                                                 int32_t (&anc)[kPPT], CountsLds& L)
+__device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& tc, const S* __restrict__ states, int64_t n, int nb,
+                                                 bool last_shard, double gj_first, int n_out, int guess, uint32_t raw_m1, uint32_t raw_0,
+                                                 uint32_t raw_p1, int32_t (&anc)[kPPT], CountsLds& L)
 {
     static_assert(sizeof(S) == 1 && kPPT == 4, "states travel as one byte: 4 per lane = one dword");
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const double gj_last = gj_first + (double)(n_out - 1);
-    // ---- prefix counts of tiles cs .. cs+4, cs = max(guess - 1, 0): one hierarchical sum + four tile entries ----
-    const int cs = guess > 0 ? guess - 1 : 0;
-    Cnt2 P = hier_prefix(h, copy, cs);
-    uint64_t we = 0;
-    if (lane < 4 && cs + lane < nb) we = h.lvl[copy][0][cs + lane];
-    uint32_t w0[5], w1[5];
-    w0[0] = P.n0; w1[0] = P.n1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        w0[i + 1] = w0[i] + (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)we, i);
-        w1[i + 1] = w1[i] + (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(we >> 32), i);
-    }
     auto nvalid_before = [&](int c) -> int64_t { const int64_t v = (int64_t)c * kTile; return v < n ? v : n; };
-    int i_lo = -1;
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-        if (cs + i < nb && tc.g_at(w0[i], w1[i], nvalid_before(cs + i)) <= gj_first) i_lo = i;
-    int c;
-    if ((i_lo >= 0 || cs == 0) && i_lo < 4) {
-        const int i = i_lo < 0 ? 0 : i_lo;
-        c = cs + i;
-        P.n0 = i == 0 ? w0[0] : (i == 1 ? w0[1] : (i == 2 ? w0[2] : w0[3]));
-        P.n1 = i == 0 ? w1[0] : (i == 1 ? w1[1] : (i == 2 ? w1[2] : w1[3]));
-    } else {
-        c = hier_locate(h, copy, tc, n, gj_first, P);                 // rare: tile masses far from even
+    // ---- which source tile owns the first output?  Probe the tiles around `at`: one hierarchical sum gives the prefix counts of
+    //      tile cs = max(at - 1, 0), four tile entries those of cs+1 .. cs+4, and lane i evaluates the first output of tile cs + i.
+    //      d_out = how far (in outputs) the first output lies from tile cs's: the next probe's aim when this one misses. ----
+    int c = 0;
+    Cnt2 P{0, 0};
+    auto probe = [&](int at, double& d_out) -> bool {
+        const int cs = at > 0 ? at - 1 : 0;
+        const Cnt2 Pc = hier_prefix(h, cs);
+        uint64_t we = 0;
+        if (lane < 4 && cs + lane < nb) we = h.lvl[0][cs + lane];
+        const uint32_t v0 = cnt_n0(we), v1 = cnt_n1(we);
+        const uint32_t i0 = wave_incl_scan_u32(v0), i1 = wave_incl_scan_u32(v1);
+        const uint32_t x0 = Pc.n0 + i0 - v0, x1 = Pc.n1 + i1 - v1;        // lanes 0..4: the prefix at cs + lane (lanes >= 4 loaded zeros)
+        const double gt = tc.g_at(x0, x1, nvalid_before(cs + lane));
+        const bool ok = lane < 5 && cs + lane < nb && gt <= gj_first;
+        const unsigned long long m = __ballot(ok);
+        const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
+        d_out = gj_first - read_lane(gt, 0);
+        if ((i_lo >= 0 || cs == 0) && i_lo < 4) {
+            const int i = i_lo < 0 ? 0 : i_lo;
+            c = cs + i;
+            P.n0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, i);
+            P.n1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, i);
+            return true;
+        }
+        return false;
+    };
+    double d;
+    if (!probe(guess, d)) {
+        // tile masses are nearly even, so the miss distance in outputs is the miss distance in tiles (x 1024) up to a few tiles:
+        // aim again (large populations: the CDF wanders sqrt(N) outputs off the diagonal), then descend from the top
+        const double aim = (double)(guess > 0 ? guess - 1 : 0) + floor(d * (1.0 / kTile));
+        const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
+        if (!probe(at, d)) c = hier_locate(h.table, h.copy, tc, n, gj_first, P);
     }
     // ---- walk the source tiles that own outputs of this tile ----
     auto load_states = [&](int cc) -> uint32_t {
+        if (cc == guess) return raw_0;
+        if (cc == guess - 1) return raw_m1;
+        if (cc == guess + 1) return raw_p1;
         return cc < nb ? *reinterpret_cast<const uint32_t*>(states + (int64_t)cc * kTile + (int64_t)tid * kPPT) : 0u;
     };
-    uint32_t raw = (c == guess) ? own_raw : load_states(c);
-    int it = 0;
     c = __builtin_amdgcn_readfirstlane(c);
+    uint32_t raw = load_states(c);
+    int it = 0;
     while (c < nb) {
         // (wave-uniform values -- the branch is made scalar so that the barrier inside the loop sits in uniform control flow)
         if (__builtin_amdgcn_readfirstlane(tc.g_at(P.n0, P.n1, nvalid_before(c)) > gj_last ? 1 : 0)) break;   // the tile's sources start beyond this output tile
-        const uint32_t raw_next = (c + 1 == guess) ? own_raw : load_states(c + 1);      // travels while this tile is processed
+        const uint32_t raw_next = load_states(c + 1);                    // (beyond the prefetched three: travels while this tile is processed)
         const int64_t i0 = (int64_t)c * kTile + (int64_t)tid * kPPT;
         // per-lane inclusive counts of states 0 / 1, packed 16 + 16 bits
         uint32_t q[kPPT];
@@ -207,10 +245,11 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, int copy, const 
         const double b0 = tc.base0 + (double)P.n0, b1 = tc.base1 + (double)P.n1;     // (uniform)
         const double bv = tc.basev + (double)nvalid_before(c);
         const int64_t nv_tile = n - (int64_t)c * kTile;                  // valid particles from this tile on (>= 1)
+        const int nvt = nv_tile < kTile ? (int)nv_tile : kTile;
         const int vb = tid * kPPT;                                       // particles of this tile before the lane's first
         auto gk = [&](uint32_t packed, int upto) -> double {             // G after `upto` particles of the tile, `packed` of them in states 0 / 1
             const double c0 = b0 + (double)(packed & 0xffffu), c1 = b1 + (double)(packed >> 16);
-            const double cv = bv + (double)((int64_t)upto < nv_tile ? (int64_t)upto : nv_tile);
+            const double cv = bv + (double)(upto < nvt ? upto : nvt);
             return tc.g(tc.cdf(c0, c1, cv));
         };
         double g_prev = gk(excl, vb);
@@ -251,7 +290,11 @@ struct StepCountsArgs {
     uint64_t seed, pid0;
     typename Model::store_t* values; int32_t* anc;
     double* logw_next; double* wrel_next; Partial* part;       // written by the last step only (the read-out's inputs)
-    Hier h;
+    Hier h;                                                     // generation t-1's counts (read); generation t's are written one copy further
+    // host-evaluated per-step constants (kernel arguments: no memory round trip in front of the prologue)
+    double e_prev[4];                                           // exp(ll_s - max ll) of step t-1, s = 0..2, then max ll
+    double e_cur[4], ll_cur[3];                                 // the same for step t, and the log-densities themselves (last step only)
+    double u0;                                                  // systematic offset of the resampling before step t (Philox, evaluated on the host)
     StepCtrl* ctrl; double n_pop; double* ess_trace; int32_t* resampled;
     // one shard of a joint population (exchange scope): the all-gathered {n_0, n_1, particles} of every rank's generation t-1,
     // exact doubles; nullptr on a single shard
@@ -259,21 +302,49 @@ struct StepCountsArgs {
     const int64_t* annex_base;                                  // [T + 1]: annex columns in use before the immigrants of step t arrive
 };
 
-template <class Model>
+// This tile's entry of generation t's hierarchy, added into the levels above (see the header of this file), and the entries of
+// the third copy this tile is responsible for clearing.  One thread.
+__device__ __forceinline__ void hier_publish(const Hier& h, int bid, int nb, uint32_t n0, uint32_t n1, bool publish)
+{
+    uint64_t* l0 = const_cast<uint64_t*>(h.lvl[0]);
+    uint64_t* l1 = const_cast<uint64_t*>(h.lvl[1]);
+    uint64_t* l2 = const_cast<uint64_t*>(h.lvl[2]);
+    const uint64_t ent = (uint64_t)n0 | ((uint64_t)n1 << 28);
+    const int b1 = bid >> 6, b2 = bid >> 12;
+    if (publish) {
+        l0[h.to_next + bid] = ent;
+        if (h.n_lev == 2) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(l1 + h.to_next + (int64_t)b1 * kHierStride), (unsigned long long)ent);
+        } else if (h.n_lev == 3) {
+            // the add returns what the entry held: the arrival field tells the last tile of the block, which forwards the block's total
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(l1 + h.to_next + (int64_t)b1 * kHierStride),
+                                                     (unsigned long long)(ent + (1ull << 56)));
+            const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
+            if ((int)(old >> 56) == tiles_in_block - 1) {
+                const uint64_t tot = (old + ent) & ((1ull << 56) - 1);
+                atomicAdd(reinterpret_cast<unsigned long long*>(l2 + h.to_next + (int64_t)b2 * kHierStride), (unsigned long long)tot);
+            }
+        }
+    }
+    if (h.n_lev >= 2 && (b1 << 6) == bid) l1[h.to_clear + (int64_t)b1 * kHierStride] = 0;
+    if (h.n_lev >= 3 && (b2 << 12) == bid) l2[h.to_clear + (int64_t)b2 * kHierStride] = 0;
+}
+
+// SHARDED: one shard of a joint population (exchange scope).  LAST: the run's final step, which leaves what the read-out wants
+// instead of counts.  Compile-time forms: each keeps only the arguments it uses in scalar registers.
+template <class Model, bool SHARDED, bool LAST>
 __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArgs<Model> a)
 {
     using V = typename Model::value_t;
     using S = typename Model::store_t;
     static_assert(Model::kWeightTable == 3, "prefix-count form: three table values (two stored counts)");
     __shared__ CountsLds L;
-    __shared__ double s_scr[3 * kWaves];
     __shared__ int s_cnt[kWaves * 4];
     const int tid = threadIdx.x;
     const int nb = (int)gridDim.x;
     const int bid = xcd_contiguous_tile((int)blockIdx.x, nb);
     const int64_t j0 = (int64_t)bid * kTile + (int64_t)tid * kPPT;
     const int t = a.t;
-    const int copy_prev = t % 3, copy_next = (t + 1) % 3, copy_clear = (t + 2) % 3;
 
     typename Model::Rand rnd[kPPT / 4];
 #pragma unroll
@@ -284,20 +355,22 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) anc[k] = (int32_t)(j0 + k);
     if (t > 0) {
-        const uint32_t own_raw = *reinterpret_cast<const uint32_t*>(prev_row + j0);
+        // the states of the source tiles this output tile almost surely descends from: its own index and both neighbours
+        const uint32_t raw_0 = *reinterpret_cast<const uint32_t*>(prev_row + j0);
+        const uint32_t raw_m1 = bid > 0 ? *reinterpret_cast<const uint32_t*>(prev_row + j0 - kTile) : 0u;
+        const uint32_t raw_p1 = bid + 1 < nb ? *reinterpret_cast<const uint32_t*>(prev_row + j0 + kTile) : 0u;
         {
             int32_t neg[kPPT];
             lane_fill(neg, (int32_t)-1);
             store4(L.slot, (int64_t)tid * kPPT, neg);
         }
         // ---- the generation's totals and this shard's place in the joint population (every wave, identically) ----
-        double ll[3], et[3], mref;
-        Model::weight_table(a.mp, t - 1, ll, et, mref);
+        const double mref = a.e_prev[3];
         TableCdf tc;
-        tc.e0 = et[0]; tc.e1 = et[1]; tc.e2 = et[2]; tc.n_pop = a.n_pop;
+        tc.e0 = a.e_prev[0]; tc.e1 = a.e_prev[1]; tc.e2 = a.e_prev[2]; tc.n_pop = a.n_pop;
         double tot0, tot1;
         bool last_shard = true;
-        if (a.all_totals) {
+        if (SHARDED) {
             const int lane = lane_id();
             double r0 = 0.0, r1 = 0.0, rv = 0.0;
             if (lane < a.world) { r0 = a.all_totals[3 * lane]; r1 = a.all_totals[3 * lane + 1]; rv = a.all_totals[3 * lane + 2]; }
@@ -306,14 +379,14 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
             tot0 = wave_sum(r0); tot1 = wave_sum(r1);              // (sums of integers below 2^53: exact in any order)
             last_shard = a.rank + 1 == a.world;
         } else {
-            const Cnt2 tl = hier_total(a.h, copy_prev);
+            const Cnt2 tl = hier_total(a.h);
             tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
             tot0 = (double)tl.n0; tot1 = (double)tl.n1;
         }
-        tc.inv = 1.0; tc.u0 = 0.0;
-        const double W = tc.cdf(tot0, tot1, a.n_pop);
-        tc.inv = a.n_pop / W;
-        tc.u0 = a.ctrl->u0_pp[t & 1];                              // left there by workgroup 0 of step t-1
+        tc.e0 = in_vgpr(tc.e0); tc.e1 = in_vgpr(tc.e1); tc.e2 = in_vgpr(tc.e2);
+        const double W = tc.cdf(tot0, tot1, tc.n_pop);
+        tc.inv = in_vgpr(a.n_pop / W);
+        tc.u0 = in_vgpr(a.u0);
         if (bid == 0 && tid == 0) {                                // bookkeeping of step t-1 for the host: ESS (thesis p.37), evidence
             const double tot2 = a.n_pop - tot0 - tot1;
             const double Q = fma(tot2, __dmul_rn(tc.e2, tc.e2), fma(tot1, __dmul_rn(tc.e1, tc.e1), __dmul_rn(tot0, __dmul_rn(tc.e0, tc.e0))));
@@ -332,11 +405,11 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         const int64_t rem = a.n - (int64_t)bid * kTile;
         const int n_out = rem < kTile ? (int)rem : kTile;
         const double gj_first = (double)(a.pid0 + (uint64_t)bid * kTile);
-        ancestors_counts<S>(a.h, copy_prev, tc, prev_row, a.n, nb, last_shard, gj_first, n_out, bid, own_raw, anc, L);
-        if (a.all_totals) {
+        ancestors_counts<S>(a.h, tc, prev_row, a.n, nb, last_shard, gj_first, n_out, bid, raw_m1, raw_0, raw_p1, anc, L);
+        if (SHARDED) {
             // outputs below o_lo / at or beyond o_hi descend from other shards' sources: their lineages arrived as annex columns,
             // in output order (cpprob_hip exchange commit)
-            const Cnt2 tl = hier_total(a.h, copy_prev);
+            const Cnt2 tl = hier_total(a.h);
             const double o_lo = tc.g_at(0, 0, 0), o_hi = last_shard ? a.n_pop : tc.g_at(tl.n0, tl.n1, a.n);
             const double sb = (double)a.pid0;
             const int64_t l0 = (int64_t)fmin(fmax(o_lo - sb, 0.0), (double)a.n), l1 = (int64_t)fmin(fmax(o_hi - sb, 0.0), (double)a.n);
@@ -364,10 +437,10 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     store4_as(a.values + (int64_t)t * a.rs, j0, x);                                           // predict #t
     store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
 
-    if (t + 1 == a.T) {
+    if (LAST) {
         // last step: the read-out wants log-weights, linear weights and an fp64 tile partial (observe #t: table look-ups only)
-        double ll[3], et[3], mref;
-        Model::weight_table(a.mp, t, ll, et, mref);
+        const double ll[3] = {a.ll_cur[0], a.ll_cur[1], a.ll_cur[2]}, et[3] = {a.e_cur[0], a.e_cur[1], a.e_cur[2]};
+        const double mref = a.e_cur[3];
         int idx[kPPT]; double lw[kPPT], e[kPPT];
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
@@ -378,10 +451,10 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         tile_partial_table<3>(idx, valid, et, mref, e, a.part, s_cnt, false, bid);
         store4(a.logw_next, j0, lw);
         store4(a.wrel_next, j0, e);
-        (void)s_scr;
+        if (tid == 0) hier_publish(a.h, bid, nb, 0, 0, false);     // (keeps the rotation's clearing duty)
         return;
     }
-    // ---- observe #t as counts: this tile's entry of the hierarchy, added into every level above ----
+    // ---- observe #t as counts ----
     uint32_t c0 = 0, c1 = 0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
@@ -395,23 +468,14 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         uint32_t n0 = 0, n1 = 0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) { n0 += (uint32_t)s_cnt[2 * w]; n1 += (uint32_t)s_cnt[2 * w + 1]; }
-        const uint64_t ent = (uint64_t)n0 | ((uint64_t)n1 << 32);
-        a.h.lvl[copy_next][0][bid] = ent;
-        for (int l = 1; l < a.h.n_lev; ++l)
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.h.lvl[copy_next][l] + (bid >> (6 * l))), (unsigned long long)ent);
-        for (int l = 1; l < a.h.n_lev; ++l)
-            if (bid < a.h.n_ent[l]) a.h.lvl[copy_clear][l][bid] = 0;
-        if (bid == 0) {                                            // systematic offset of the resampling before step t+1
-            const u32x4 r = draw_block(a.seed, 0, kResampleDrawBase + (uint64_t)(t + 1));
-            a.ctrl->u0_pp[(t + 1) & 1] = u01_53(r.x, r.y);
-        }
+        hier_publish(a.h, bid, nb, n0, n1, true);
     }
 }
 
 // {n_0, n_1, particles} of this shard's generation as exact doubles: what a sharded run all-gathers between two steps.
-__global__ __launch_bounds__(kWave) void counts_totals_kernel(Hier h, int copy, double n_local, double* __restrict__ out)
+__global__ __launch_bounds__(kWave) void counts_totals_kernel(Hier h, double n_local, double* __restrict__ out)
 {
-    const Cnt2 t = hier_total(h, copy);
+    const Cnt2 t = hier_total(h);
     if (threadIdx.x == 0) { out[0] = (double)t.n0; out[1] = (double)t.n1; out[2] = n_local; }
 }
 
