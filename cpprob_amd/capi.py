@@ -20,7 +20,8 @@ SYMBOLS = [
     "cpprob_hip_stream", "cpprob_hip_sync", "cpprob_hip_infer_begin", "cpprob_hip_infer_run", "cpprob_hip_infer_summary",
     "cpprob_hip_infer_stats", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
-    "cpprob_hip_smc_finish", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
+    "cpprob_hip_smc_finish", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
+    "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
     "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
     "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_gather_f64",
@@ -83,6 +84,11 @@ def load_library(path=None):
         "cpprob_hip_exchange_plan": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]),
         "cpprob_hip_exchange_pack": (C.c_int, [vp, i32, vp]),
         "cpprob_hip_exchange_commit": (C.c_int, [vp, i32, vp]),
+        "cpprob_hip_exchange_setup": (C.c_int, [vp, i32, i32, vp, i32, u64]),
+        "cpprob_hip_exchange_transport": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(u64), C.POINTER(u64)]),
+        "cpprob_hip_exchange_pack_async": (C.c_int, [vp, i32]),
+        "cpprob_hip_exchange_commit_async": (C.c_int, [vp, i32]),
+        "cpprob_hip_exchange_status": (C.c_int, [vp, C.POINTER(i32), C.POINTER(u64)]),
         "cpprob_hip_philox_blocks": (C.c_int, [vp, u64, u64, u64, sz, vp]),
         "cpprob_hip_draw_normal": (C.c_int, [vp, u64, u64, u64, dbl, dbl, sz, vp]),
         "cpprob_hip_draw_uniform_smallint": (C.c_int, [vp, u64, u64, u64, i64, i64, sz, vp]),

@@ -13,6 +13,7 @@
 
 #include "kernels.hpp"
 #include "step_counts.hpp"
+#include "exchange.hpp"
 
 using namespace cph;
 
@@ -80,7 +81,15 @@ struct cpprob_hip_ctx {
     double* d_obound = nullptr;     // [world + 2]: offspring-interval bounds per rank, then the resampling decision
     double* h_obound = nullptr;     // pinned host copy (the one host read-back per step of the exchange scope)
     int32_t* d_send_src = nullptr; size_t send_src_cap = 0;
-    int64_t imm_l0 = 0, imm_l1 = 0, imm_col0 = 0;     // immigrant layout of the NEXT step
+    // device-resident exchange plan (exchange.hpp) and the transport geometry
+    ExchangePlan* d_xplan = nullptr;
+    int64_t* d_shard_begin = nullptr; int32_t* d_slot_of_rank = nullptr;
+    int x_world = 0, x_rank = 0;                  // as of the last step_end
+    const double* x_all_totals = nullptr;
+    bool x_fixed = false; int64_t x_cap = 0; int x_mode = 0; std::vector<int> x_peers;   // fixed-capacity transport (cpprob_hip_exchange_setup)
+    void* d_xsend = nullptr; void* d_xrecv = nullptr; size_t x_buf_bytes = 0;
+    std::vector<uint64_t> x_shard_begin;
+    int x_plan_t = -1;                            // step whose plan sits in d_xplan
     struct { int t = -1; bool resample = false; std::vector<uint64_t> send_lo, send_cnt; uint64_t n_send = 0, n_recv = 0; int64_t l0 = 0, l1 = 0; } plan;
     size_t cap_particles = 0; int cap_T = 0; bool cap_int = false; bool cap_multinomial = false;
     // prefix-count form of the step (table-weight models on an every-step schedule; step_counts.hpp)
@@ -89,6 +98,7 @@ struct cpprob_hip_ctx {
     HierTable* d_hier_table = nullptr;                     // the same in device memory
     size_t hier_per_copy = 0;                              // 64-bit words per copy
     int hier_phase = 0;                                    // copy that step 0 of the next run reads: chosen so that the copy it adds into is clean
+    int hier_phase_run = 0;                                // ... of the run in flight
     bool hier_run_open = false;                            // a run's steps are in flight (the rotation's state is known only at run boundaries)
     int64_t* d_annex_base = nullptr;                       // [T + 1] exchange scope: annex columns in use before each step's immigrants
     bool counts_mode = false;                              // this run's steps use smc_step_counts_kernel
@@ -303,7 +313,7 @@ void launch_step(cpprob_hip_ctx* c, int t)
         static const bool counts = !(getenv("CPPROB_PART_COUNTS") && getenv("CPPROB_PART_COUNTS")[0] == '0');
         a.part_counts = (counts && a.wrel_from_state && step_is_fused(c)) ? 1 : 0;
     }
-    a.exchange = (c->exchange && c->step_protocol) ? 1 : 0; a.imm_l0 = c->imm_l0; a.imm_l1 = c->imm_l1; a.imm_col0 = c->imm_col0;
+    a.exchange = (c->exchange && c->step_protocol) ? 1 : 0; a.imm_l01 = c->d_xplan ? &c->d_xplan->l0 : nullptr; a.annex_base = c->d_annex_base;
 #ifdef CPPROB_STAMPS
     static unsigned long long* d_st = nullptr;
     if (!d_st) { (void)hipMalloc(&d_st, (size_t)131072 * 16 * 8); (void)hipMemset(d_st, 0, (size_t)131072 * 16 * 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)); }
@@ -383,9 +393,9 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
             if (t == 0) {
                 // a run that was abandoned half-way leaves the rotation in an unknown state: start over from clean copies
                 if (c->hier_run_open) { (void)hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream); c->hier_phase = 0; }
-                c->hier_run_open = true;
+                c->hier_run_open = true; c->hier_phase_run = c->hier_phase;
             }
-            const int kp = (t + c->hier_phase) % 3, kn = (kp + 1) % 3, kc = (kp + 2) % 3;
+            const int kp = (t + c->hier_phase_run) % 3, kn = (kp + 1) % 3, kc = (kp + 2) % 3;
             for (int l = 0; l < kHierMaxLevels; ++l) { a.h.lvl[l] = c->hier.lvl[kp][l]; a.h.n_ent[l] = c->hier.n_ent[l]; }
             a.h.n_lev = c->hier.n_lev;
             a.h.to_next = (int64_t)(kn - kp) * (int64_t)c->hier_per_copy; a.h.to_clear = (int64_t)(kc - kp) * (int64_t)c->hier_per_copy;
@@ -529,7 +539,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
     dfree(c->d_ctrl); dfree(c->d_local_totals);
-    dfree(c->d_send_src); dfree(c->d_hier_table);
+    dfree(c->d_send_src); dfree(c->d_hier_table); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -660,7 +670,8 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         c->hier_phase = 0; c->hier_run_open = false;
     }
     c->rs = c->ld + c->annex_cap;
-    c->annex_used = 0; c->imm_l0 = 0; c->imm_l1 = c->n; c->imm_col0 = 0; c->plan.t = -1;
+    c->annex_used = 0; c->plan.t = -1; c->x_plan_t = -1; c->x_all_totals = nullptr;
+    if (!c->d_xplan) { HIP_TRY(c, hipMalloc(&c->d_xplan, sizeof(ExchangePlan))); HIP_TRY(c, hipMemsetAsync(c->d_xplan, 0, sizeof(ExchangePlan), c->stream)); }
     dfree(c->d_obs);
     HIP_TRY(c, hipMalloc(&c->d_obs, n_obs * sizeof(double)));
     HIP_TRY(c, hipMemcpyAsync(c->d_obs, h_obs, n_obs * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -758,14 +769,34 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     HIP_TRY(c, hipSetDevice(c->device));
     const bool sis = c->cfg.algorithm == CPPROB_HIP_ALG_SIS;
     if (sis && t != c->T - 1) return fail(c, CPPROB_HIP_EINVAL, "SIS shards run in one launch: call step_begin(T-1) only");
-    if (t == 0 || sis) { c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; c->annex_used = 0; c->imm_l0 = 0; c->imm_l1 = c->n; c->imm_col0 = 0; c->plan.t = -1; }
-    if (c->exchange && t > 0 && c->plan.t != t - 1)
-        return fail(c, CPPROB_HIP_ESTATE, "exchange scope: cpprob_hip_exchange_plan/_pack/_commit of the previous step must run before the next step_begin");
+    if (t == 0 || sis) {
+        c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; c->annex_used = 0; c->plan.t = -1; c->x_plan_t = -1;
+        c->counts_mode = false;
+        if (!sis && c->exchange) dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); });
+    }
+    if (c->exchange && t > 0 && c->x_plan_t != t - 1)
+        return fail(c, CPPROB_HIP_ESTATE, "exchange scope: the exchange of the previous step (plan / pack / commit) must run before the next step_begin");
     c->step_protocol = true; c->step_t = t;
-    if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c, false); });
-    else dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
     c->totals_out = d_local_totals;
-    launch_scan(c, t, 1, nullptr, 1, 0);
+    if (c->counts_mode) {
+        // prefix-count form: the step consumes the all-gathered counts of generation t-1 itself; what leaves is this shard's
+        // {n_0, n_1, particles} (exact doubles) -- or, after the last step, {max, sum, sum of squares} for the read-out
+        if (t > 0 && !c->x_all_totals) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_step_end(t-1) has not run");
+        dispatch_model(c, [&](auto m) { launch_step_counts<decltype(m)>(c, t, t > 0 ? c->x_all_totals : nullptr, c->x_world, c->x_rank); });
+        if (t + 1 < c->T) {
+            Hier h{};
+            const int kn = (t + 1 + c->hier_phase_run) % 3;
+            for (int l = 0; l < kHierMaxLevels; ++l) { h.lvl[l] = c->hier.lvl[kn][l]; h.n_ent[l] = c->hier.n_ent[l]; }
+            h.n_lev = c->hier.n_lev;
+            hipLaunchKernelGGL(counts_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals);
+        } else {
+            launch_scan(c, t, 1, nullptr, 1, 0);
+        }
+    } else {
+        if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c, false); });
+        else dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
+        launch_scan(c, t, 1, nullptr, 1, 0);
+    }
     HIP_TRY(c, hipGetLastError());
     c->sharded = true;
     return 0;
@@ -776,8 +807,10 @@ int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_to
     if (!c || !d_all_totals) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->begun || !c->step_protocol || t != c->step_t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_step_end(t) follows cpprob_hip_smc_step_begin(t)");
     if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank (1 <= world <= 1024)");
+    if (c->exchange && world > kMaxWorld) return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope plans on one wavefront: world <= 64");
     HIP_TRY(c, hipSetDevice(c->device));
-    launch_scan(c, t, 2, d_all_totals, world, rank);
+    c->x_all_totals = d_all_totals; c->x_world = world; c->x_rank = rank;
+    if (!(c->counts_mode && t + 1 < c->T)) launch_scan(c, t, 2, d_all_totals, world, rank);
     HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -796,78 +829,77 @@ int cpprob_hip_smc_finish(cpprob_hip_ctx* c)
 // ---- exchange scope -----------------------------------------------------------------------------
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, c->stream
 
-int cpprob_hip_exchange_plan(cpprob_hip_ctx* c, int32_t t, int32_t world, int32_t rank, const uint64_t* h_shard_begin, uint64_t* h_send_counts,
-                             uint64_t* h_recv_counts, int32_t* h_do_resample)
+}  // extern "C"
+
+namespace {
+
+int upload_geometry(cpprob_hip_ctx* c, int world, int rank, const uint64_t* h_shard_begin)
 {
-    if (!c || !h_shard_begin || !h_send_counts || !h_recv_counts) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
-    if (!c->exchange) return fail(c, CPPROB_HIP_ESTATE, "the context was not begun with resample_scope = CPPROB_HIP_SCOPE_EXCHANGE");
-    if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank");
-    if (t < 0 || t >= c->T) return fail(c, CPPROB_HIP_EINVAL, "step out of range");
+    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank (1 <= world <= 64)");
     if (h_shard_begin[rank] != c->cfg.particle_offset || h_shard_begin[rank + 1] - h_shard_begin[rank] != (uint64_t)c->n || h_shard_begin[world] != c->cfg.n_global)
         return fail(c, CPPROB_HIP_EINVAL, "h_shard_begin does not describe this context's shard");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->h_obound) HIP_TRY(c, hipHostMalloc(&c->h_obound, (1024 + 2) * sizeof(double), hipHostMallocDefault));
-    double* ob = c->h_obound;
-    HIP_TRY(c, hipMemcpyAsync(ob, c->d_obound, ((size_t)world + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    auto& p = c->plan;
-    p.t = t; p.resample = ob[(size_t)world + 1] != 0.0;
-    p.send_lo.assign((size_t)world, 0); p.send_cnt.assign((size_t)world, 0); p.n_send = 0; p.n_recv = 0;
-    for (int r = 0; r < world; ++r) { h_send_counts[r] = 0; h_recv_counts[r] = 0; }
-    p.l0 = 0; p.l1 = c->n;
-    if (h_do_resample) *h_do_resample = p.resample ? 1 : 0;
-    if (!p.resample) return 0;
-    auto clampu = [](uint64_t v, uint64_t lo, uint64_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    std::vector<uint64_t> o((size_t)world + 1);
-    for (int r = 0; r <= world; ++r) o[r] = (uint64_t)ob[r];
-    for (int r = 1; r <= world; ++r) if (o[r] < o[r - 1]) return fail(c, CPPROB_HIP_EDEVICE, "offspring bounds are not monotone");
-    const uint64_t my_lo = o[rank], my_hi = o[rank + 1];
-    for (int r = 0; r < world; ++r) {
-        const uint64_t sb = h_shard_begin[r], se = h_shard_begin[r + 1];
-        if (r != rank) {
-            const uint64_t lo = clampu(my_lo, sb, se), hi = clampu(my_hi, sb, se);        // my sources' outputs that live on rank r
-            p.send_lo[r] = lo; p.send_cnt[r] = hi - lo; p.n_send += hi - lo; h_send_counts[r] = hi - lo;
-            const uint64_t mb = h_shard_begin[rank], me = h_shard_begin[rank + 1];
-            const uint64_t rl = clampu(o[r], mb, me), rh = clampu(o[r + 1], mb, me);    // rank r's sources' outputs that live here
-            h_recv_counts[r] = rh - rl; p.n_recv += rh - rl;
-        } else {
-            p.l0 = (int64_t)(clampu(my_lo, sb, se) - sb); p.l1 = (int64_t)(clampu(my_hi, sb, se) - sb);
+    std::vector<uint64_t> sb(h_shard_begin, h_shard_begin + world + 1);
+    if (sb == c->x_shard_begin && c->d_shard_begin) return 0;
+    if (!c->d_shard_begin) HIP_TRY(c, hipMalloc(&c->d_shard_begin, (kMaxWorld + 1) * sizeof(int64_t)));
+    std::vector<int64_t> h(sb.begin(), sb.end());
+    HIP_TRY(c, hipMemcpyAsync(c->d_shard_begin, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));           // (h is a local)
+    c->x_shard_begin = sb;
+    return 0;
+}
+
+// the plan of the exchange that follows step t, on the device (no host synchronisation)
+int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
+{
+    ExchangeGeom g{};
+    g.world = c->x_world; g.rank = c->x_rank; g.n = c->n; g.shard_begin = c->d_shard_begin;
+    g.slot_of_rank = fixed_layout ? c->d_slot_of_rank : nullptr; g.cap = fixed_layout ? c->x_cap : (int64_t)1 << 40;
+    g.annex_cap = fixed_layout ? c->annex_cap : (int64_t)1 << 40;      // (callers that synchronise grow the annex themselves)
+    PlanCountsIn pc{};
+    pc.all_totals = c->x_all_totals; pc.n_pop = (double)c->pop_n;
+    if (c->counts_mode) {
+        pc.e0 = c->h_e_tab[(size_t)t * 4]; pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
+        pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
+        hipLaunchKernelGGL(exchange_plan_kernel<true>, dim3(1), dim3(kWave), 0, c->stream, g, pc, (const double*)c->d_obound, t, c->d_annex_base, c->d_xplan);
+    } else {
+        hipLaunchKernelGGL(exchange_plan_kernel<false>, dim3(1), dim3(kWave), 0, c->stream, g, pc, (const double*)c->d_obound, t, c->d_annex_base, c->d_xplan);
+    }
+    c->x_plan_t = t;
+    return 0;
+}
+
+template <class Model, class R>
+void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid)
+{
+    PackArgs<Model, R> a{};
+    a.values = static_cast<const typename Model::store_t*>(c->d_values); a.anc = c->d_anc; a.rs = c->rs; a.n = c->n; a.nb = c->nb;
+    a.resampled = c->d_resampled; a.t = t; a.plan = c->d_xplan; a.world = c->x_world; a.rank = c->x_rank; a.send = d_send;
+    a.pc.all_totals = c->x_all_totals; a.pc.n_pop = (double)c->pop_n;
+    a.wrel = c->d_wrel[c->cur]; a.bc = c->d_bc; a.bf = c->d_bf; a.ctrl = c->d_ctrl; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
+    if constexpr (Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1) {
+        if (c->counts_mode) {
+            const int kn = (t + 1 + c->hier_phase_run) % 3;            // the copy step t wrote = the one step t+1 reads
+            for (int l = 0; l < kHierMaxLevels; ++l) { a.h.lvl[l] = c->hier.lvl[kn][l]; a.h.n_ent[l] = c->hier.n_ent[l]; }
+            a.h.n_lev = c->hier.n_lev; a.h.table = c->d_hier_table; a.h.copy = kn;
+            a.pc.e0 = c->h_e_tab[(size_t)t * 4]; a.pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; a.pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
+            a.pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
+            hipLaunchKernelGGL((exchange_pack_kernel<Model, R, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+            return;
         }
     }
-    if ((int64_t)p.n_recv != c->n - (p.l1 - p.l0)) return fail(c, CPPROB_HIP_EDEVICE, "exchange plan does not cover the shard");
-    return 0;
+    hipLaunchKernelGGL((exchange_pack_kernel<Model, R, false>), dim3(grid), dim3(kThreads), 0, c->stream, a);
 }
 
-int cpprob_hip_exchange_pack(cpprob_hip_ctx* c, int32_t t, void* d_send)
+template <class Model, class R>
+void launch_commit(cpprob_hip_ctx* c, int t, const R* d_recv, int grid)
 {
-    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
-    auto& p = c->plan;
-    if (!c->exchange || p.t != t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_plan(t) has not run");
-    if (!p.resample || p.n_send == 0) return 0;
-    if (!d_send) return fail(c, CPPROB_HIP_EINVAL, "d_send is NULL");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (p.n_send > c->send_src_cap) { dfree(c->d_send_src); HIP_TRY(c, hipMalloc(&c->d_send_src, p.n_send * sizeof(int32_t))); c->send_src_cap = p.n_send; }
-    uint64_t off = 0;
-    for (size_t r = 0; r < p.send_cnt.size(); ++r) {
-        if (!p.send_cnt[r]) continue;
-        ResampleArgs a{};
-        a.wrel = c->d_wrel[c->cur]; a.n_in = c->n; a.bc = c->d_bc; a.bf = c->d_bf; a.nb = c->nb; a.ctrl = c->d_ctrl; a.seed = c->run_seed; a.step = (uint64_t)t + 1;
-        a.j0 = p.send_lo[r]; a.n_total_out = c->cfg.n_global; a.n_out = (int64_t)p.send_cnt[r]; a.anc = c->d_send_src + off; a.run_ctrl = 1;
-        hipLaunchKernelGGL(resample_kernel<RS_SYSTEMATIC>, dim3((unsigned)((p.send_cnt[r] + kTile - 1) / kTile)), dim3(kThreads), 0, c->stream, a);
-        off += p.send_cnt[r];
-    }
-    const int len = t + 1;
-    dispatch_model(c, [&](auto m) {
-        using S = typename decltype(m)::store_t; using V = typename decltype(m)::value_t;
-        hipLaunchKernelGGL((extract_lineages_kernel<S, V>), GRID1(p.n_send), static_cast<const S*>(c->d_values), c->d_anc, c->rs, c->d_resampled, len,
-                           c->d_send_src, (int64_t)p.n_send, static_cast<V*>(d_send));
-    });
-    HIP_TRY(c, hipGetLastError());
-    return 0;
+    using S = typename Model::store_t;
+    hipLaunchKernelGGL((exchange_commit_kernel<S, R>), dim3(grid), dim3(kThreads), 0, c->stream, (const ExchangePlan*)c->d_xplan, c->x_world, d_recv, t,
+                       (const int64_t*)c->d_annex_base, static_cast<S*>(c->d_values), c->d_anc, c->rs, c->ld);
 }
 
-// more annex columns: re-stride values[] / anc[] (rare: the initial annex holds ld/16 immigrants per run)
-static int grow_annex(cpprob_hip_ctx* c, int64_t need)
+// more annex columns: re-stride values[] / anc[] (callers that synchronise per step only)
+int grow_annex(cpprob_hip_ctx* c, int64_t need)
 {
     int64_t cap = std::max<int64_t>(2 * c->annex_cap, (need + kTile - 1) / kTile * kTile);
     const size_t T = (size_t)c->cap_T, vsz = c->ssz;
@@ -884,28 +916,145 @@ static int grow_annex(cpprob_hip_ctx* c, int64_t need)
     return 0;
 }
 
+}  // namespace
+
+extern "C" {
+
+// ---- exchange, synchronising form: the caller sizes its buffers from host-visible counts ----
+int cpprob_hip_exchange_plan(cpprob_hip_ctx* c, int32_t t, int32_t world, int32_t rank, const uint64_t* h_shard_begin, uint64_t* h_send_counts,
+                             uint64_t* h_recv_counts, int32_t* h_do_resample)
+{
+    if (!c || !h_shard_begin || !h_send_counts || !h_recv_counts) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->exchange) return fail(c, CPPROB_HIP_ESTATE, "the context was not begun with resample_scope = CPPROB_HIP_SCOPE_EXCHANGE");
+    if (t < 0 || t >= c->T) return fail(c, CPPROB_HIP_EINVAL, "step out of range");
+    if (!c->step_protocol || c->step_t != t || !c->x_all_totals || world != c->x_world || rank != c->x_rank)
+        return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_plan(t) follows cpprob_hip_smc_step_end(t) with the same world / rank");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = upload_geometry(c, world, rank, h_shard_begin)) return rc;
+    if (int rc = launch_plan(c, t, false)) return rc;
+    HIP_TRY(c, hipGetLastError());
+    ExchangePlan h;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_xplan, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    auto& p = c->plan;
+    p.t = t; p.resample = h.resample != 0; p.n_send = (uint64_t)h.n_send; p.n_recv = (uint64_t)h.n_recv; p.l0 = h.l0; p.l1 = h.l1;
+    for (int r = 0; r < world; ++r) { h_send_counts[r] = (uint64_t)h.send_cnt[r]; h_recv_counts[r] = (uint64_t)h.recv_cnt[r]; }
+    if (h_do_resample) *h_do_resample = p.resample ? 1 : 0;
+    if (p.resample && (int64_t)p.n_recv != c->n - (p.l1 - p.l0)) return fail(c, CPPROB_HIP_EDEVICE, "exchange plan does not cover the shard");
+    return 0;
+}
+
+int cpprob_hip_exchange_pack(cpprob_hip_ctx* c, int32_t t, void* d_send)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    auto& p = c->plan;
+    if (!c->exchange || p.t != t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_plan(t) has not run");
+    if (!p.resample || p.n_send == 0) return 0;
+    if (!d_send) return fail(c, CPPROB_HIP_EINVAL, "d_send is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int grid = (int)std::min<uint64_t>((p.n_send + kTile - 1) / kTile + 1, 1024);
+    dispatch_model(c, [&](auto m) { using M = decltype(m); launch_pack<M, typename M::value_t>(c, t, static_cast<typename M::value_t*>(d_send), grid); });
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 int cpprob_hip_exchange_commit(cpprob_hip_ctx* c, int32_t t, const void* d_recv)
 {
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
     auto& p = c->plan;
     if (!c->exchange || p.t != t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_plan(t) has not run");
-    c->imm_l0 = 0; c->imm_l1 = c->n; c->imm_col0 = c->annex_used;
-    if (!p.resample) return 0;
-    HIP_TRY(c, hipSetDevice(c->device));
-    c->imm_l0 = p.l0; c->imm_l1 = p.l1;
-    if (p.n_recv == 0) return 0;
+    if (!p.resample || p.n_recv == 0) return 0;
     if (!d_recv) return fail(c, CPPROB_HIP_EINVAL, "d_recv is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
     if (c->ld + c->annex_used + (int64_t)p.n_recv + kTile > (int64_t)INT32_MAX) return fail(c, CPPROB_HIP_EINVAL, "immigrant columns exceed int32 ancestor indices");
     if (c->annex_used + (int64_t)p.n_recv > c->annex_cap) { if (int rc = grow_annex(c, c->annex_used + (int64_t)p.n_recv)) return rc; }
-    const int len = t + 1;
-    const int64_t col0 = c->ld + c->annex_used;
-    dispatch_model(c, [&](auto m) {
-        using S = typename decltype(m)::store_t; using V = typename decltype(m)::value_t;
-        hipLaunchKernelGGL((annex_lineages_kernel<S, V>), GRID1(p.n_recv * len), static_cast<const V*>(d_recv), (int64_t)p.n_recv, len,
-                           static_cast<S*>(c->d_values), c->d_anc, c->rs, col0);
-    });
+    const int grid = (int)std::min<uint64_t>((p.n_recv * (uint64_t)(t + 1) + kThreads - 1) / kThreads, 2048);
+    dispatch_model(c, [&](auto m) { using M = decltype(m); launch_commit<M, typename M::value_t>(c, t, static_cast<const typename M::value_t*>(d_recv), grid); });
     HIP_TRY(c, hipGetLastError());
     c->annex_used += (int64_t)p.n_recv;
+    return 0;
+}
+
+// ---- exchange, stream-ordered form: fixed-capacity transport segments, no host synchronisation inside a run ----
+int cpprob_hip_exchange_setup(cpprob_hip_ctx* c, int32_t world, int32_t rank, const uint64_t* h_shard_begin, int32_t all_peers, uint64_t records_per_peer)
+{
+    if (!c || !h_shard_begin) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->begun || !c->exchange) return fail(c, CPPROB_HIP_ESTATE, "begin the context with resample_scope = CPPROB_HIP_SCOPE_EXCHANGE first");
+    if (records_per_peer == 0) return fail(c, CPPROB_HIP_EINVAL, "records_per_peer must be > 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = upload_geometry(c, world, rank, h_shard_begin)) return rc;
+    std::vector<int32_t> slot((size_t)kMaxWorld, -1);
+    c->x_peers.clear();
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) continue;
+        if (all_peers || r == rank - 1 || r == rank + 1) { slot[(size_t)r] = (int32_t)c->x_peers.size(); c->x_peers.push_back(r); }
+    }
+    if (!c->d_slot_of_rank) HIP_TRY(c, hipMalloc(&c->d_slot_of_rank, kMaxWorld * sizeof(int32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_slot_of_rank, slot.data(), kMaxWorld * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->x_cap = (int64_t)records_per_peer; c->x_mode = all_peers ? 1 : 0; c->x_fixed = true;
+    const size_t need = std::max<size_t>(1, c->x_peers.size()) * (size_t)records_per_peer * (size_t)c->T * c->ssz;
+    if (need > c->x_buf_bytes) {
+        dfree(c->d_xsend); dfree(c->d_xrecv);
+        HIP_TRY(c, hipMalloc(&c->d_xsend, need));
+        HIP_TRY(c, hipMalloc(&c->d_xrecv, need));
+        c->x_buf_bytes = need;
+    }
+    c->x_world = world; c->x_rank = rank;
+    return 0;
+}
+
+int cpprob_hip_exchange_transport(cpprob_hip_ctx* c, void** d_send, void** d_recv, int32_t* n_peers, int32_t* h_peers, uint64_t* records_per_peer,
+                                  uint64_t* bytes_per_value)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->x_fixed) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_setup has not run");
+    if (d_send) *d_send = c->d_xsend;
+    if (d_recv) *d_recv = c->d_xrecv;
+    if (n_peers) *n_peers = (int32_t)c->x_peers.size();
+    if (h_peers) for (size_t i = 0; i < c->x_peers.size(); ++i) h_peers[i] = c->x_peers[i];
+    if (records_per_peer) *records_per_peer = (uint64_t)c->x_cap;
+    if (bytes_per_value) *bytes_per_value = (uint64_t)c->ssz;
+    return 0;
+}
+
+int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* c, int32_t t)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->exchange || !c->x_fixed) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_setup has not run");
+    if (!c->step_protocol || c->step_t != t || !c->x_all_totals) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_pack_async(t) follows cpprob_hip_smc_step_end(t)");
+    if (t < 0 || t + 1 >= c->T) return fail(c, CPPROB_HIP_EINVAL, "no exchange follows the last step");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc = launch_plan(c, t, true)) return rc;
+    // enough workgroups for a full segment per peer; those beyond the planned tiles leave at once
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>(1, (c->x_cap + kTile - 1) / kTile), 256);
+    dispatch_model(c, [&](auto m) { using M = decltype(m); launch_pack<M, typename M::store_t>(c, t, static_cast<typename M::store_t*>(c->d_xsend), grid); });
+    HIP_TRY(c, hipGetLastError());
+    c->plan.t = t;
+    return 0;
+}
+
+int cpprob_hip_exchange_commit_async(cpprob_hip_ctx* c, int32_t t)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->exchange || !c->x_fixed || c->x_plan_t != t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_pack_async(t) has not run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    dispatch_model(c, [&](auto m) { using M = decltype(m); launch_commit<M, typename M::store_t>(c, t, static_cast<const typename M::store_t*>(c->d_xrecv), 256); });
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_exchange_status(cpprob_hip_ctx* c, int32_t* h_overflow, uint64_t* h_annex_used)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->exchange || !c->d_xplan) return fail(c, CPPROB_HIP_ESTATE, "no exchange-scope run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int32_t head[2] = {0, 0};
+    std::vector<int64_t> ab((size_t)c->T + 1, 0);
+    HIP_TRY(c, hipMemcpyAsync(head, c->d_xplan, sizeof head, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ab.data(), c->d_annex_base, ab.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h_overflow) *h_overflow = head[1];
+    if (h_annex_used) *h_annex_used = (uint64_t)(c->T >= 2 ? ab[(size_t)c->T - 1] : 0);
     return 0;
 }
 

@@ -1,0 +1,234 @@
+// Exchange scope (exact global resampling over shards): the device-resident plan and the kernels that move lineages.
+//
+// One joint population is sharded contiguously over `world` ranks.  With systematic resampling -- one shared offset -- the sources of
+// rank r own the outputs [o_r, o_{r+1}), o_r = G(CDF at the start of shard r): a function of the all-gathered rank totals alone, so
+// every rank derives the SAME plan on its own device, with no host in the loop:
+//     output j lives on the rank whose shard contains j; the part of [o_rank, o_rank+1) outside the own shard is sent (the
+//     lineage x_0..x_t of each such output's ancestor), the part of the own shard outside it arrives, in output order.
+// exchange_plan_kernel   o_r -> per-peer send / receive intervals, offsets into the transport buffers, annex bookkeeping, overflow flag
+// exchange_pack_kernel   ancestors of the outputs this shard's sources own elsewhere (the step kernels' own search) + their lineages
+// exchange_commit_kernel received lineages -> annex columns of the particle store (identity ancestors): later kernels see ordinary particles
+// Transport buffers hold one fixed-capacity segment per peer slot (sizes are host constants: RCCL send/recv counts cannot depend on
+// device data), or -- for callers that synchronise and size their buffers exactly -- one compact block per rank (cpprob_hip_exchange_*).
+// A step that does not resample, or whose shards' masses happen to match, plans zero records; its transfers carry stale bytes nobody reads.
+#pragma once
+#include "kernels.hpp"
+#include "step_counts.hpp"
+
+namespace cph {
+
+constexpr int kMaxWorld = 64;
+
+struct ExchangePlan {
+    int32_t resample;                 // the step's decision (device-side)
+    int32_t overflow;                 // sticky per run: 1 = a peer segment or the annex was too small, 2 = a rank outside the peer list was needed
+    int64_t l0, l1;                   // local outputs [l0, l1) descend from local sources
+    int64_t n_send, n_recv;
+    int64_t send_lo[kMaxWorld];       // per RANK: first global output of mine that lives there, how many, where its records start (in records)
+    int64_t send_cnt[kMaxWorld];
+    int64_t send_base[kMaxWorld];
+    int64_t recv_cnt[kMaxWorld];      // per RANK: records that arrive from it, where they sit in the receive buffer, their first annex column offset
+    int64_t recv_base[kMaxWorld];
+    int64_t recv_off[kMaxWorld];
+};
+
+struct ExchangeGeom {
+    int world, rank;
+    int64_t n;                        // local particles
+    const int64_t* shard_begin;       // [world + 1] device
+    const int32_t* slot_of_rank;      // [world] device: transport slot of each rank (-1: not a peer in this mode); nullptr: compact layout
+    int64_t cap;                      // records per slot (fixed layout)
+    int64_t annex_cap;
+};
+
+struct PlanCountsIn {                 // prefix-count form: o_r from the all-gathered {n_0, n_1, particles}
+    const double* all_totals; double e0, e1, e2, u0, n_pop;
+};
+
+// One wave.  COUNTS: bounds from integer counts (canonical arithmetic, the step kernel's own expressions); otherwise from obound[]
+// (scan_exchange_bounds) and its decision word.
+template <bool COUNTS>
+__global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, PlanCountsIn pc, const double* __restrict__ obound, int t,
+                                                              int64_t* __restrict__ annex_base, ExchangePlan* __restrict__ plan)
+{
+    const int lane = lane_id();
+    const int world = g.world, rank = g.rank;
+    double o = 0.0;                                            // lane r: o_r, r = 0..world
+    bool resample;
+    if (COUNTS) {
+        double r0 = 0.0, r1 = 0.0, rv = 0.0;
+        if (lane < world) { r0 = pc.all_totals[3 * lane]; r1 = pc.all_totals[3 * lane + 1]; rv = pc.all_totals[3 * lane + 2]; }
+        // exclusive prefix over ranks: sums of integers below 2^53 -- exact, so every rank (and the step kernel's masked sums) agree
+        const double i0 = wave_incl_scan(r0), i1 = wave_incl_scan(r1), iv = wave_incl_scan(rv);
+        TableCdf tc;
+        tc.e0 = pc.e0; tc.e1 = pc.e1; tc.e2 = pc.e2; tc.u0 = pc.u0; tc.n_pop = pc.n_pop;
+        tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
+        const double W = tc.cdf(read_lane(i0, kWave - 1), read_lane(i1, kWave - 1), pc.n_pop);
+        tc.inv = pc.n_pop / W;
+        o = tc.g(tc.cdf(i0 - r0, i1 - r1, iv - rv));
+        if (lane >= world) o = pc.n_pop;
+        resample = true;
+    } else {
+        if (lane <= world) o = obound[lane];
+        resample = obound[world + 1] != 0.0;
+    }
+    // my sources' interval and what each rank's shard takes of it / gives to me
+    const double my_lo = read_lane(o, rank), my_hi = read_lane(o, rank + 1);
+    const double o_next = dpp_or<0x130 /* wave_shl:1 */>(o, 0.0);        // lane r: o_{r+1}
+    auto clampd = [](double v, double lo, double hi) { return fmin(fmax(v, lo), hi); };
+    int64_t send_lo = 0, send_cnt = 0, recv_cnt = 0, l0 = 0, l1 = g.n;
+    int32_t flag = 0;
+    const double mb = (double)g.shard_begin[rank], me = (double)g.shard_begin[rank + 1];
+    if (lane < world && resample) {
+        const double sb = (double)g.shard_begin[lane], se = (double)g.shard_begin[lane + 1];
+        if (lane != rank) {
+            const double lo = clampd(my_lo, sb, se), hi = clampd(my_hi, sb, se);          // my sources' outputs that live on rank `lane`
+            send_lo = (int64_t)lo; send_cnt = (int64_t)(hi - lo);
+            const double rl = clampd(o, mb, me), rh = clampd(o_next, mb, me);             // rank `lane`'s sources' outputs that live here
+            recv_cnt = (int64_t)(rh - rl);
+        }
+    }
+    if (resample) { l0 = (int64_t)(clampd(my_lo, mb, me) - mb); l1 = (int64_t)(clampd(my_hi, mb, me) - mb); }
+    // layout: fixed slots (capacity-checked) or compact blocks in rank order
+    int64_t send_base = 0, recv_base = 0;
+    const uint32_t rs_incl = wave_incl_scan_u32((uint32_t)recv_cnt), ss_incl = wave_incl_scan_u32((uint32_t)send_cnt);
+    if (g.slot_of_rank) {
+        const int slot = lane < world ? g.slot_of_rank[lane] : -1;
+        if (lane < world && lane != rank) {
+            if (slot < 0) { if (send_cnt | recv_cnt) flag = 2; send_cnt = 0; recv_cnt = 0; }
+            else {
+                if (send_cnt > g.cap || recv_cnt > g.cap) { flag = 1; send_cnt = send_cnt < g.cap ? send_cnt : g.cap; recv_cnt = recv_cnt < g.cap ? recv_cnt : g.cap; }
+                send_base = (int64_t)slot * g.cap; recv_base = (int64_t)slot * g.cap;
+            }
+        }
+    } else {
+        send_base = (int64_t)(ss_incl - (uint32_t)send_cnt); recv_base = (int64_t)(rs_incl - (uint32_t)recv_cnt);
+    }
+    // (annex columns follow the receive order = rank order = output order; recomputed after any clamping)
+    const uint32_t ro_incl = wave_incl_scan_u32((uint32_t)recv_cnt), so_incl = wave_incl_scan_u32((uint32_t)send_cnt);
+    const int64_t recv_off = (int64_t)(ro_incl - (uint32_t)recv_cnt);
+    int64_t n_recv = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ro_incl, kWave - 1);
+    const int64_t n_send = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)so_incl, kWave - 1);
+    const int64_t base = t == 0 ? 0 : annex_base[t];
+    if (base + n_recv > g.annex_cap) flag = flag ? flag : 1;
+    const unsigned long long any1 = __ballot(flag == 1), any2 = __ballot(flag == 2);
+    if (lane < world) {
+        plan->send_lo[lane] = send_lo; plan->send_cnt[lane] = send_cnt; plan->send_base[lane] = send_base;
+        plan->recv_cnt[lane] = recv_cnt; plan->recv_base[lane] = recv_base; plan->recv_off[lane] = recv_off;
+    }
+    if (lane == 0) {
+        const bool over_annex = base + n_recv > g.annex_cap;
+        plan->resample = resample ? 1 : 0;
+        if (t == 0) plan->overflow = 0;
+        if (any2) plan->overflow = 2; else if (any1 && plan->overflow == 0) plan->overflow = 1;
+        plan->l0 = l0; plan->l1 = l1; plan->n_send = n_send; plan->n_recv = over_annex ? 0 : n_recv;
+        if (t == 0) annex_base[0] = 0;
+        annex_base[t + 1] = base + (over_annex ? 0 : n_recv);
+    }
+}
+
+// Lineage of the generation-t particle in slot `idx`: x_0 .. x_t into rec[0 .. t].
+template <class S, class R>
+__device__ __forceinline__ void extract_lineage(const S* __restrict__ values, const int32_t* __restrict__ anc, int64_t rs, const int32_t* __restrict__ resampled,
+                                                int t, int32_t idx, R* __restrict__ rec)
+{
+    for (int tt = t; tt >= 0; --tt) {
+        rec[tt] = static_cast<R>(values[(int64_t)tt * rs + idx]);
+        if (tt > 0 && resampled[tt - 1]) idx = anc[(int64_t)tt * rs + idx];
+    }
+}
+
+template <class Model, class R>
+struct PackArgs {
+    const typename Model::store_t* values; const int32_t* anc; int64_t rs, n; int nb; const int32_t* resampled; int t;   // generation t is the one resampled
+    const ExchangePlan* plan; int world, rank;
+    R* send;                                                     // records of t + 1 values
+    // prefix-count form
+    Hier h; PlanCountsIn pc;
+    // floating-point form
+    const double* wrel; const double* bc; const double* bf; const StepCtrl* ctrl; uint64_t seed;
+    uint64_t pid0;
+};
+
+template <class Model, class R, bool COUNTS>
+__global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model, R> a)
+{
+    using S = typename Model::store_t;
+    __shared__ CountsLds Lc;
+    __shared__ AncestorLds Lf;
+    const int tid = threadIdx.x;
+    if (!a.plan->resample || a.plan->n_send == 0) return;       // workgroup-uniform
+    TableCdf tc;
+    bool last_shard = a.rank + 1 == a.world;
+    if constexpr (COUNTS) {
+        const int lane = lane_id();
+        double r0 = 0.0, r1 = 0.0, rv = 0.0;
+        if (lane < a.world) { r0 = a.pc.all_totals[3 * lane]; r1 = a.pc.all_totals[3 * lane + 1]; rv = a.pc.all_totals[3 * lane + 2]; }
+        const bool before = lane < a.rank;
+        tc.e0 = a.pc.e0; tc.e1 = a.pc.e1; tc.e2 = a.pc.e2; tc.u0 = a.pc.u0; tc.n_pop = a.pc.n_pop;
+        tc.base0 = wave_sum(before ? r0 : 0.0); tc.base1 = wave_sum(before ? r1 : 0.0); tc.basev = wave_sum(before ? rv : 0.0);
+        const double t0 = wave_sum(r0), t1 = wave_sum(r1);
+        tc.inv = 1.0;
+        const double W = tc.cdf(t0, t1, a.pc.n_pop);
+        tc.inv = a.pc.n_pop / W;
+    }
+    const int len = a.t + 1;
+    for (int r = 0; r < a.world; ++r) {
+        const int64_t cnt = a.plan->send_cnt[r];
+        if (r == a.rank || cnt == 0) continue;                  // uniform
+        const int64_t lo = a.plan->send_lo[r], base = a.plan->send_base[r];
+        for (int64_t tl = blockIdx.x; tl * kTile < cnt; tl += gridDim.x) {
+            const int64_t rem = cnt - tl * kTile;
+            const int n_out = rem < kTile ? (int)rem : kTile;
+            const uint64_t gj0 = (uint64_t)(lo + tl * kTile);
+            int32_t anc[kPPT];
+            if constexpr (COUNTS) {
+                {
+                    int32_t neg[kPPT];
+                    lane_fill(neg, (int32_t)-1);
+                    store4(Lc.slot, (int64_t)tid * kPPT, neg);
+                }
+                __syncthreads();
+                ancestors_counts<S>(a.h, tc, a.values + (int64_t)a.t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, -16, 0u, 0u, 0u, anc, Lc);
+            } else {
+                AncestorIn in;
+                in.wrel = a.wrel; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n;
+                in.W = a.ctrl->W; in.scale = a.ctrl->scale; in.cdf_lo = a.ctrl->cdf_lo;
+                in.u0 = a.ctrl->u0; in.inv_stepw = a.ctrl->inv_global; in.g_end = a.ctrl->g_end;
+                in.seed = a.seed; in.step = (uint64_t)a.t + 1; in.gj_tile0 = gj0; in.n_total_out = (uint64_t)a.pc.n_pop;
+                in.n_valid_tile = n_out; in.id0 = 0; in.bc_in_lds = 0; in.guess = -1;
+                ancestors_systematic(in, anc, Lf, WrelSource{a.wrel});
+            }
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) {
+                const int q = tid * kPPT + k;
+                if (q < n_out) extract_lineage<S, R>(a.values, a.anc, a.rs, a.resampled, a.t, max(anc[k], 0), a.send + (base + tl * kTile + q) * len);
+            }
+            __syncthreads();                                    // LDS is reused by the next tile
+        }
+    }
+}
+
+// Received records -> annex columns annex_base[t] + recv_off[r] + k of rows 0 .. t, identity ancestors.
+template <class S, class R>
+__global__ __launch_bounds__(kThreads) void exchange_commit_kernel(const ExchangePlan* __restrict__ plan, int world, const R* __restrict__ recv, int t,
+                                                                    const int64_t* __restrict__ annex_base, S* __restrict__ values, int32_t* __restrict__ anc,
+                                                                    int64_t rs, int64_t ld)
+{
+    if (!plan->resample || plan->n_recv == 0) return;
+    const int len = t + 1;
+    const int64_t col0 = ld + annex_base[t];
+    for (int r = 0; r < world; ++r) {
+        const int64_t cnt = plan->recv_cnt[r];
+        if (cnt == 0) continue;
+        const int64_t base = plan->recv_base[r], off = plan->recv_off[r];
+        for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < cnt * len; i += (int64_t)gridDim.x * kThreads) {
+            const int64_t k = i / len; const int tt = (int)(i - k * len);
+            const int64_t col = col0 + off + k;
+            values[(int64_t)tt * rs + col] = static_cast<S>(recv[(base + k) * len + tt]);
+            anc[(int64_t)tt * rs + col] = (int32_t)col;
+        }
+    }
+}
+
+}  // namespace cph

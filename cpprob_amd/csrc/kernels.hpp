@@ -1097,7 +1097,9 @@ struct StepArgs {
     int64_t rs;               // row stride of values[] / anc[] (ld plus the immigrant annex)
     // exchange scope (exact global resampling over shards): outputs [imm_l0, imm_l1) of this shard descend from local
     // sources, the others from immigrants whose lineages sit in annex columns imm_col0, imm_col0 + 1, ... in output order
-    int exchange; int64_t imm_l0, imm_l1, imm_col0;
+    int exchange;
+    const int64_t* imm_l01;       // device: {l0, l1} of the plan the previous step's exchange left (exchange.hpp: ExchangePlan::l0, l1)
+    const int64_t* annex_base;    // device [T + 1]: annex columns in use before each step's immigrants
 };
 
 // Tile partial when every particle's log-weight is lwa + (one of K table values): no exp, no fp64
@@ -1340,11 +1342,12 @@ __global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) 
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) lw[k] = lwa;          // equal weights after resampling (the shard's mass share)
         if (!FUSED && a.exchange) {
+            const int64_t l0 = a.imm_l01[0], l1 = a.imm_l01[1], col0 = a.ld + a.annex_base[t - 1];
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
                 const int64_t j = j0 + k;
-                if (j < a.imm_l0) anc[k] = (int32_t)(a.ld + a.imm_col0 + j);
-                else if (j >= a.imm_l1 && j < a.n) anc[k] = (int32_t)(a.ld + a.imm_col0 + j - (a.imm_l1 - a.imm_l0));
+                if (j < l0) anc[k] = (int32_t)(col0 + j);
+                else if (j >= l1 && j < a.n) anc[k] = (int32_t)(col0 + j - (l1 - l0));
             }
         }
     }

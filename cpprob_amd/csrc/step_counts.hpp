@@ -404,7 +404,9 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         __syncthreads();                                           // slots reset
         const int64_t rem = a.n - (int64_t)bid * kTile;
         const int n_out = rem < kTile ? (int)rem : kTile;
-        const double gj_first = (double)(a.pid0 + (uint64_t)bid * kTile);
+        // (a shard of a joint population draws the population's outputs; a population of its own -- islands included, whose pid0
+        //  only selects RNG streams -- draws its own)
+        const double gj_first = SHARDED ? (double)(a.pid0 + (uint64_t)bid * kTile) : (double)((uint64_t)bid * kTile);
         ancestors_counts<S>(a.h, tc, prev_row, a.n, nb, last_shard, gj_first, n_out, bid, raw_m1, raw_0, raw_p1, anc, L);
         if (SHARDED) {
             // outputs below o_lo / at or beyond o_hi descend from other shards' sources: their lineages arrived as annex columns,

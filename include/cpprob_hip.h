@@ -203,6 +203,29 @@ int cpprob_hip_exchange_plan(cpprob_hip_ctx* ctx, int32_t t, int32_t world, int3
 int cpprob_hip_exchange_pack(cpprob_hip_ctx* ctx, int32_t t, void* d_send);
 int cpprob_hip_exchange_commit(cpprob_hip_ctx* ctx, int32_t t, const void* d_recv);
 
+/* The same exchange WITHOUT any host synchronisation inside a run (what the multi-GPU drivers use: RCCL send / receive counts are
+ * host constants, so the transport moves fixed-capacity segments and the plan lives on the device).
+ *   setup      once after cpprob_hip_infer_begin: the shards' layout, the peer set -- all_peers = 0: the two neighbouring ranks (the
+ *              offspring interval of a rank's sources leaves its shard by O(sqrt(n)) outputs: neighbours are all a well-mixed run
+ *              needs), all_peers = 1: every rank -- and records_per_peer, the capacity of one peer segment;
+ *   transport  the context-owned buffers: peer slot s (peer rank h_peers[s]) owns records_per_peer * (t + 1) values of
+ *              bytes_per_value bytes at byte offset s * records_per_peer * (t + 1) * bytes_per_value of d_send / d_recv
+ *              during the exchange that follows step t;
+ *   between step_end(t) and step_begin(t + 1), t < T - 1:
+ *     pack_async(t)    plans on the device and fills d_send;
+ *     the caller moves slot s of d_send to rank h_peers[s], into the slot that rank keeps for this one, stream-ordered;
+ *     commit_async(t)  turns what arrived in d_recv into annex columns;
+ *   status     after the run (synchronises): overflow = 0 fine; 1 a peer segment or the immigrant annex was too small; 2 a rank
+ *              outside the peer set was needed.  A non-zero value invalidates the run on EVERY rank of the group (ranks must
+ *              agree on it -- all-reduce the flag): repeat it with a larger capacity / all_peers = 1.  Results do not depend on the
+ *              transport parameters. */
+int cpprob_hip_exchange_setup(cpprob_hip_ctx* ctx, int32_t world, int32_t rank, const uint64_t* h_shard_begin, int32_t all_peers, uint64_t records_per_peer);
+int cpprob_hip_exchange_transport(cpprob_hip_ctx* ctx, void** d_send, void** d_recv, int32_t* n_peers, int32_t* h_peers, uint64_t* records_per_peer,
+                                  uint64_t* bytes_per_value);
+int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* ctx, int32_t t);
+int cpprob_hip_exchange_commit_async(cpprob_hip_ctx* ctx, int32_t t);
+int cpprob_hip_exchange_status(cpprob_hip_ctx* ctx, int32_t* h_overflow, uint64_t* h_annex_used);
+
 /* ---- building blocks (also the unit-parity surface) --------------------------------------
  * All pointers are device pointers; n is the element count. */
 
