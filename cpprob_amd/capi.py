@@ -21,7 +21,9 @@ SYMBOLS = [
     "cpprob_hip_infer_stats", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
     "cpprob_hip_smc_finish", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
-    "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
+    "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_group_unique_id", "cpprob_hip_group_create", "cpprob_hip_group_destroy",
+    "cpprob_hip_group_last_error", "cpprob_hip_group_begin", "cpprob_hip_group_run", "cpprob_hip_group_sync", "cpprob_hip_group_size",
+    "cpprob_hip_group_context", "cpprob_hip_group_results", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
     "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
     "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_gather_f64",
@@ -89,6 +91,16 @@ def load_library(path=None):
         "cpprob_hip_exchange_pack_async": (C.c_int, [vp, i32]),
         "cpprob_hip_exchange_commit_async": (C.c_int, [vp, i32]),
         "cpprob_hip_exchange_status": (C.c_int, [vp, C.POINTER(i32), C.POINTER(u64)]),
+        "cpprob_hip_group_unique_id": (C.c_int, [vp, sz]),
+        "cpprob_hip_group_create": (C.c_int, [C.POINTER(i32), i32, i32, i32, vp, C.POINTER(vp)]),
+        "cpprob_hip_group_destroy": (None, [vp]),
+        "cpprob_hip_group_last_error": (C.c_char_p, [vp]),
+        "cpprob_hip_group_begin": (C.c_int, [vp, C.POINTER(Config), C.POINTER(dbl), sz, vp]),
+        "cpprob_hip_group_run": (C.c_int, [vp, u64]),
+        "cpprob_hip_group_sync": (C.c_int, [vp]),
+        "cpprob_hip_group_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "cpprob_hip_group_context": (vp, [vp, i32]),
+        "cpprob_hip_group_results": (C.c_int, [vp, C.POINTER(Summary), C.POINTER(dbl), sz, C.POINTER(i32)]),
         "cpprob_hip_philox_blocks": (C.c_int, [vp, u64, u64, u64, sz, vp]),
         "cpprob_hip_draw_normal": (C.c_int, [vp, u64, u64, u64, dbl, dbl, sz, vp]),
         "cpprob_hip_draw_uniform_smallint": (C.c_int, [vp, u64, u64, u64, i64, i64, sz, vp]),
@@ -340,3 +352,92 @@ class Engine:
         calls = (C.c_int64 * N_KERNEL_CLASSES)()
         self._chk(self.L.cpprob_hip_profile_read(self.h, ms, calls, 1 if reset else 0))
         return {KERNEL_CLASS_NAMES[k]: (ms[k], calls[k]) for k in range(N_KERNEL_CLASSES)}
+
+
+class Group:
+    """One joint population over several GPUs, driven by the library's own host code (cpprob_amd/csrc/group.hpp): the
+    exchange scope's per-step protocol with RCCL collectives on each context's stream and no host synchronisation inside a
+    run.  devices: this process's GPUs.  world > len(devices): one rank of a multi-process group (unique_id from
+    Group.unique_id() on rank 0, distributed by the launcher).  All devices equal: loopback (every rank on that one GPU)."""
+
+    def __init__(self, devices, world=None, first_rank=0, unique_id=None):
+        self.L = load_library()
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        world = len(devices) if world is None else int(world)
+        h = C.c_void_p()
+        uid = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+        rc = self.L.cpprob_hip_group_create(devs, len(devices), world, int(first_rank), uid, C.byref(h))
+        if rc:
+            msg = self.L.cpprob_hip_group_last_error(None)
+            raise CpprobHipError("cpprob_hip_group_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self.h = h
+        self.world, self.n_local, self.first_rank = world, len(devices), int(first_rank)
+        self.T = self.K = 0
+        self.is_int = False
+
+    @staticmethod
+    def unique_id():
+        L = load_library()
+        buf = C.create_string_buffer(128)
+        rc = L.cpprob_hip_group_unique_id(buf, 128)
+        if rc:
+            msg = L.cpprob_hip_group_last_error(None)
+            raise CpprobHipError("cpprob_hip_group_unique_id failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cpprob_hip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            msg = self.L.cpprob_hip_group_last_error(self.h)
+            raise CpprobHipError("cpprob_hip group error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+    def begin(self, algorithm, model, observes, n_particles, seed=12345, resampler=RESAMPLE_SYSTEMATIC, ess_threshold=2.0, shard_sizes=None):
+        """n_particles = the whole population."""
+        obs = np.ascontiguousarray(observes, np.float64)
+        cfg = Config(algorithm, model, resampler, SCOPE_EXCHANGE, 1, 0, float(ess_threshold), int(seed), int(n_particles), 0, int(n_particles))
+        ss = None
+        if shard_sizes is not None:
+            ss = np.ascontiguousarray(shard_sizes, np.uint64)
+            assert len(ss) == self.world
+        self._chk(self.L.cpprob_hip_group_begin(self.h, C.byref(cfg), obs.ctypes.data_as(C.POINTER(C.c_double)), len(obs),
+                                                ss.ctypes.data if ss is not None else None))
+        gauss = model in (MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README)
+        self.T = 1 if gauss else len(obs)
+        self.is_int = model == MODEL_HMM3
+        self.K = 3 if self.is_int else 2
+        self.n = int(n_particles)
+        return self
+
+    def run(self, run_index=0):
+        self._chk(self.L.cpprob_hip_group_run(self.h, int(run_index)))
+
+    def sync(self):
+        self._chk(self.L.cpprob_hip_group_sync(self.h))
+
+    def results(self):
+        """(stats[T, K], summary dict, reruns): the joint population's numbers, as one GPU holding all particles would report them."""
+        s = Summary()
+        out = np.zeros((self.T, self.K))
+        rr = C.c_int32(0)
+        self._chk(self.L.cpprob_hip_group_results(self.h, C.byref(s), out.ctypes.data_as(C.POINTER(C.c_double)), out.size, C.byref(rr)))
+        return out, {f: getattr(s, f) for f, _ in Summary._fields_}, int(rr.value)
+
+    def context(self, local_index):
+        """The rank's context as an Engine view (not owned): shard-level read-outs (paths, values, logw)."""
+        e = Engine.__new__(Engine)
+        e.L = self.L
+        e.h = C.c_void_p(self.L.cpprob_hip_group_context(self.h, int(local_index)))
+        e.device = None
+        e.T, e.K, e.is_int = self.T, self.K, self.is_int
+        e.close = lambda: None
+        return e

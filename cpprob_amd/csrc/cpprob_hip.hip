@@ -19,7 +19,7 @@ using namespace cph;
 
 namespace {
 
-std::string g_last_error;
+thread_local std::string g_last_error;      // per thread: contexts (and the group driver's workers) live on threads of their own
 
 struct EventPair { hipEvent_t a, b; int cls; int count; };
 
@@ -607,7 +607,8 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
 
     c->exchange = exchange;
     // exchange scope: room for immigrant lineages next to every row (grown on demand by cpprob_hip_exchange_commit)
-    const int64_t annex0 = exchange ? std::max<int64_t>(c->annex_cap, std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile)) : 0;
+    const int64_t annex_want = cfg->reserved > 0 ? (int64_t)cfg->reserved * 1024 : std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile);
+    const int64_t annex0 = exchange ? std::max<int64_t>(c->annex_cap, annex_want) : 0;
     c->ssz = 8;
     dispatch_model(c, [&](auto m) { c->ssz = sizeof(typename decltype(m)::store_t); c->grid_refs = decltype(m)::kWeightTable == 0; });
     const bool realloc = (size_t)c->ld > c->cap_particles || c->T > c->cap_T || c->is_int != c->cap_int || (multinomial && !c->cap_multinomial) || !c->d_values ||
@@ -1462,3 +1463,5 @@ int cpprob_hip_profile_read(cpprob_hip_ctx* c, double* h_ms, int64_t* h_calls, i
 }
 
 }  // extern "C"
+
+#include "group.hpp"

@@ -1,0 +1,519 @@
+// Multi-GPU driver of one joint population: one context per GPU, the exchange scope's per-step protocol (include/cpprob_hip.h)
+// issued from C++ with no host synchronisation inside a run -- what cpprob::inference calls when cpprob::gpu::options().devices names
+// several GPUs, and what bench.py runs under torchrun.
+//
+// Transports
+//   RCCL (xGMI)  dlopen()ed (the copy the process already holds, else /opt/rocm's): per step one ncclAllGather of 3 doubles per
+//                rank and one group of ncclSend / ncclRecv of the fixed-capacity lineage segments, all on each context's own stream.
+//                In-process form: one communicator per local GPU (ncclCommInitAll) driven by one host thread each;
+//                one-process-per-GPU form: ncclCommInitRank from a unique id the launcher distributes.
+//   loopback     every rank's context on ONE device and ONE stream; the "collectives" are device copies.  This is how a one-GPU box
+//                exercises the whole protocol, shard layouts and capacities included (RCCL refuses duplicate devices).
+// Included by cpprob_hip.hip (it uses the context's internals).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string where;
+};
+
+// One RCCL per process: prefer the copy that is already mapped (a PyTorch process has its own), so that the two never coexist.
+RcclApi* rccl_api(std::string& err)
+{
+    static RcclApi api;
+    static bool tried = false;
+    static std::string first_err;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (api.lib) return &api;
+    if (tried) { err = first_err; return nullptr; }
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int pass = 0; pass < 2 && !api.lib; ++pass)
+        for (const char* n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (api.lib) { api.where = std::string(n) + (pass == 0 ? " (already loaded)" : ""); break; }
+        }
+    if (!api.lib) { first_err = err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "?"); return nullptr; }
+    bool ok = true;
+    auto sym = [&](const char* s) -> void* { void* p = dlsym(api.lib, s); if (!p) { ok = false; first_err = std::string("RCCL lacks ") + s; } return p; };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { err = first_err; dlclose(api.lib); api.lib = nullptr; return nullptr; }
+    return &api;
+}
+
+// {raw weighted sums ..., overflow flag} of a finished sharded run into one buffer: what the final all-reduce carries
+__global__ void pack_joint_kernel(const double* __restrict__ stats, int n_stats, const cph::ExchangePlan* __restrict__ plan, double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_stats) out[i] = stats[i];
+    if (i == 0) out[n_stats] = plan ? (double)plan->overflow : 0.0;
+}
+
+// loopback collectives: every rank lives on this device and this stream
+__global__ void loop_allgather_kernel(double* const* __restrict__ locals, double* const* __restrict__ alls, int world)
+{
+    const int i = threadIdx.x;                        // world * 3 <= 192 threads
+    if (i >= 3 * world) return;
+    const double v = locals[i / 3][i % 3];
+    for (int q = 0; q < world; ++q) alls[q][i] = v;
+}
+__global__ void loop_allreduce_kernel(double* const* __restrict__ bufs, int world, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int q = 0; q < world; ++q) s += bufs[q][i];   // rank order: bitwise reproducible
+    __syncthreads();
+    for (int q = 0; q < world; ++q) bufs[q][i] = s;
+}
+
+}  // namespace
+
+struct cpprob_hip_group {
+    int world = 0, first_rank = 0;
+    std::vector<cpprob_hip_ctx*> ctx;                  // local ranks first_rank .. first_rank + n_local - 1
+    bool loopback = false;
+    RcclApi* rccl = nullptr;
+    std::vector<ncclComm_t> comm;
+    std::string err;
+    // run configuration
+    cpprob_hip_config cfg{};
+    std::vector<double> obs;
+    std::vector<uint64_t> shard_begin;
+    bool begun = false, exchange = false;
+    int T = 0, K = 0, n_stats = 0;
+    int all_peers = 0; uint64_t cap = 0; int annex_kcols = 0;
+    // per local rank device buffers
+    std::vector<double*> d_local, d_all, d_joint;
+    double* const* d_ptr_locals = nullptr; double* const* d_ptr_alls = nullptr; double* const* d_ptr_joints = nullptr;   // loopback: device arrays of pointers
+    std::vector<hipStream_t> own_stream;               // loopback: the streams the contexts were created with
+    uint64_t last_run = 0; bool ran = false;
+    int reruns = 0;
+    // worker threads (RCCL, several local ranks)
+    std::vector<std::thread> workers;
+    std::mutex m; std::condition_variable cv_job, cv_done;
+    uint64_t job_gen = 0; uint64_t job_run = 0; int job_pending = 0; bool stopping = false;
+    std::vector<int> job_rc; std::vector<std::string> job_err;
+};
+
+namespace {
+
+// (worker threads report through a thread-local message; the group's own string is written by the calling thread only)
+thread_local std::string tl_group_err;
+int gfail(cpprob_hip_group* g, int code, const std::string& msg)
+{
+    (void)g;
+    tl_group_err = msg;
+    g_last_error = msg;
+    return code;
+}
+int gkeep(cpprob_hip_group* g, int rc)                  // calling thread: make the message the group's
+{
+    if (rc && g) g->err = tl_group_err.empty() ? g_last_error : tl_group_err;
+    return rc;
+}
+
+#define NCCL_TRY(g, expr)                                                                                                        \
+    do {                                                                                                                         \
+        ncclResult_t r__ = (expr);                                                                                               \
+        if (r__ != ncclSuccess) return gfail(g, CPPROB_HIP_EDEVICE, std::string(#expr) + ": " + (g)->rccl->GetErrorString(r__)); \
+    } while (0)
+
+// the exchange that follows step t, as seen by local rank i (RCCL form): its peers' segments
+int rccl_exchange(cpprob_hip_group* g, int i, int t)
+{
+    cpprob_hip_ctx* c = g->ctx[(size_t)i];
+    void* d_send = nullptr; void* d_recv = nullptr; int32_t np = 0; int32_t peers[cph::kMaxWorld]; uint64_t cap = 0, bpv = 0;
+    if (int rc = cpprob_hip_exchange_transport(c, &d_send, &d_recv, &np, peers, &cap, &bpv)) return gfail(g, rc, cpprob_hip_last_error(c));
+    const size_t seg = (size_t)cap * (size_t)(t + 1) * (size_t)bpv;
+    if (np == 0) return 0;
+    NCCL_TRY(g, g->rccl->GroupStart());
+    for (int s = 0; s < np; ++s) {
+        NCCL_TRY(g, g->rccl->Send(static_cast<const char*>(d_send) + (size_t)s * seg, seg, ncclInt8, peers[s], g->comm[(size_t)i], c->stream));
+        NCCL_TRY(g, g->rccl->Recv(static_cast<char*>(d_recv) + (size_t)s * seg, seg, ncclInt8, peers[s], g->comm[(size_t)i], c->stream));
+    }
+    NCCL_TRY(g, g->rccl->GroupEnd());
+    return 0;
+}
+
+// One whole run of local rank i (RCCL form): every collective is stream-ordered, nothing waits on the host.
+int rccl_run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
+{
+    cpprob_hip_ctx* c = g->ctx[(size_t)i];
+    const int rank = g->first_rank + i, world = g->world;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool sis = g->cfg.algorithm == CPPROB_HIP_ALG_SIS;
+    for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
+        if (int rc = cpprob_hip_smc_step_begin(c, t, run_index, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
+        NCCL_TRY(g, g->rccl->AllGather(g->d_local[(size_t)i], g->d_all[(size_t)i], 3, ncclDouble, g->comm[(size_t)i], c->stream));
+        if (int rc = cpprob_hip_smc_step_end(c, t, g->d_all[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
+        if (g->exchange && t + 1 < g->T) {
+            if (int rc = cpprob_hip_exchange_pack_async(c, t)) return gfail(g, rc, cpprob_hip_last_error(c));
+            if (int rc = rccl_exchange(g, i, t)) return rc;
+            if (int rc = cpprob_hip_exchange_commit_async(c, t)) return gfail(g, rc, cpprob_hip_last_error(c));
+        }
+    }
+    if (int rc = cpprob_hip_smc_finish(c)) return gfail(g, rc, cpprob_hip_last_error(c));
+    hipLaunchKernelGGL(pack_joint_kernel, dim3((unsigned)((g->n_stats + 256) / 256)), dim3(256), 0, c->stream, (const double*)c->d_stats, g->n_stats,
+                       g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, g->d_joint[(size_t)i]);
+    NCCL_TRY(g, g->rccl->AllReduce(g->d_joint[(size_t)i], g->d_joint[(size_t)i], (size_t)g->n_stats + 1, ncclDouble, ncclSum, g->comm[(size_t)i], c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+// One whole run of all ranks on one device and one stream: the phases of all ranks interleave in program order.
+int loopback_run(cpprob_hip_group* g, uint64_t run_index)
+{
+    const int world = g->world;
+    cpprob_hip_ctx* c0 = g->ctx[0];
+    HIP_TRY(c0, hipSetDevice(c0->device));
+    hipStream_t st = c0->stream;
+    const bool sis = g->cfg.algorithm == CPPROB_HIP_ALG_SIS;
+    for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
+        for (int r = 0; r < world; ++r)
+            if (int rc = cpprob_hip_smc_step_begin(g->ctx[(size_t)r], t, run_index, g->d_local[(size_t)r])) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+        hipLaunchKernelGGL(loop_allgather_kernel, dim3(1), dim3(192), 0, st, g->d_ptr_locals, g->d_ptr_alls, world);
+        for (int r = 0; r < world; ++r)
+            if (int rc = cpprob_hip_smc_step_end(g->ctx[(size_t)r], t, g->d_all[(size_t)r], world, r)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+        if (g->exchange && t + 1 < g->T) {
+            for (int r = 0; r < world; ++r)
+                if (int rc = cpprob_hip_exchange_pack_async(g->ctx[(size_t)r], t)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+            for (int r = 0; r < world; ++r) {
+                cpprob_hip_ctx* c = g->ctx[(size_t)r];
+                const size_t seg = (size_t)c->x_cap * (size_t)(t + 1) * c->ssz;
+                for (size_t s = 0; s < c->x_peers.size(); ++s) {
+                    cpprob_hip_ctx* p = g->ctx[(size_t)c->x_peers[s]];
+                    size_t ps = 0;                                   // the slot the peer keeps for rank r
+                    while (ps < p->x_peers.size() && p->x_peers[ps] != r) ++ps;
+                    if (ps == p->x_peers.size()) return gfail(g, CPPROB_HIP_EDEVICE, "loopback transport: asymmetric peer sets");
+                    HIP_TRY(c, hipMemcpyAsync(static_cast<char*>(p->d_xrecv) + ps * seg, static_cast<const char*>(c->d_xsend) + s * seg, seg, hipMemcpyDeviceToDevice, st));
+                }
+            }
+            for (int r = 0; r < world; ++r)
+                if (int rc = cpprob_hip_exchange_commit_async(g->ctx[(size_t)r], t)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+        }
+    }
+    for (int r = 0; r < world; ++r) {
+        cpprob_hip_ctx* c = g->ctx[(size_t)r];
+        if (int rc = cpprob_hip_smc_finish(c)) return gfail(g, rc, cpprob_hip_last_error(c));
+        hipLaunchKernelGGL(pack_joint_kernel, dim3((unsigned)((g->n_stats + 256) / 256)), dim3(256), 0, st, (const double*)c->d_stats, g->n_stats,
+                           g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, g->d_joint[(size_t)r]);
+    }
+    hipLaunchKernelGGL(loop_allreduce_kernel, dim3((unsigned)((g->n_stats + 256) / 256)), dim3(256), 0, st, g->d_ptr_joints, world, g->n_stats + 1);
+    HIP_TRY(c0, hipGetLastError());
+    return 0;
+}
+
+void group_worker(cpprob_hip_group* g, int i)
+{
+    uint64_t seen = 0;
+    for (;;) {
+        uint64_t run;
+        {
+            std::unique_lock<std::mutex> lock(g->m);
+            g->cv_job.wait(lock, [&] { return g->stopping || g->job_gen != seen; });
+            if (g->stopping) return;
+            seen = g->job_gen; run = g->job_run;
+        }
+        tl_group_err.clear();
+        const int rc = rccl_run_rank(g, i, run);
+        {
+            std::lock_guard<std::mutex> lock(g->m);
+            g->job_rc[(size_t)i] = rc;
+            if (rc) g->job_err[(size_t)i] = tl_group_err.empty() ? g_last_error : tl_group_err;
+            if (--g->job_pending == 0) g->cv_done.notify_all();
+        }
+    }
+}
+
+int group_begin_contexts(cpprob_hip_group* g)
+{
+    const int n_local = (int)g->ctx.size();
+    for (int i = 0; i < n_local; ++i) {
+        const int rank = g->first_rank + i;
+        cpprob_hip_config c = g->cfg;
+        c.n_particles = g->shard_begin[(size_t)rank + 1] - g->shard_begin[(size_t)rank];
+        c.particle_offset = g->shard_begin[(size_t)rank];
+        c.n_global = g->shard_begin[(size_t)g->world];
+        c.resample_scope = g->exchange ? CPPROB_HIP_SCOPE_EXCHANGE : CPPROB_HIP_SCOPE_GLOBAL;
+        c.reserved = g->annex_kcols;
+        cpprob_hip_ctx* x = g->ctx[(size_t)i];
+        if (int rc = cpprob_hip_infer_begin(x, &c, g->obs.data(), g->obs.size())) return gfail(g, rc, cpprob_hip_last_error(x));
+        if (g->exchange)
+            if (int rc = cpprob_hip_exchange_setup(x, g->world, rank, g->shard_begin.data(), g->all_peers, g->cap)) return gfail(g, rc, cpprob_hip_last_error(x));
+    }
+    return 0;
+}
+
+int group_enqueue(cpprob_hip_group* g, uint64_t run_index)
+{
+    if (g->loopback) return loopback_run(g, run_index);
+    if (g->ctx.size() == 1) return rccl_run_rank(g, 0, run_index);
+    {
+        std::lock_guard<std::mutex> lock(g->m);
+        g->job_run = run_index; g->job_pending = (int)g->ctx.size(); ++g->job_gen;
+        std::fill(g->job_rc.begin(), g->job_rc.end(), 0);
+    }
+    g->cv_job.notify_all();
+    std::unique_lock<std::mutex> lock(g->m);
+    g->cv_done.wait(lock, [&] { return g->job_pending == 0; });
+    for (size_t i = 0; i < g->ctx.size(); ++i)
+        if (g->job_rc[i]) return gfail(g, g->job_rc[i], g->job_err[i]);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cpprob_hip_group_unique_id(void* out, size_t n_bytes)
+{
+    if (!out || n_bytes < NCCL_UNIQUE_ID_BYTES) return fail(nullptr, CPPROB_HIP_EINVAL, "need a buffer of 128 bytes");
+    std::string err;
+    RcclApi* api = rccl_api(err);
+    if (!api) return fail(nullptr, CPPROB_HIP_EDEVICE, err);
+    ncclUniqueId id;
+    const ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, CPPROB_HIP_EDEVICE, std::string("ncclGetUniqueId: ") + api->GetErrorString(r));
+    std::memcpy(out, &id, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t world, int32_t first_rank, const void* unique_id, cpprob_hip_group** out)
+{
+    if (!out || !devices) return fail(nullptr, CPPROB_HIP_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (n_local < 1 || world < n_local || world > cph::kMaxWorld || first_rank < 0 || first_rank + n_local > world)
+        return fail(nullptr, CPPROB_HIP_EINVAL, "need 1 <= n_local <= world <= 64 and first_rank + n_local <= world");
+    if (world > n_local && (n_local != 1 || !unique_id)) return fail(nullptr, CPPROB_HIP_EINVAL, "ranks in other processes: one GPU per process and the group's unique id");
+    cpprob_hip_group* g = new cpprob_hip_group();
+    g->world = world; g->first_rank = first_rank;
+    bool same = n_local > 1;
+    for (int i = 1; i < n_local; ++i) same = same && devices[i] == devices[0];
+    g->loopback = same && world == n_local;
+    if (!g->loopback && world == n_local)
+        for (int i = 0; i < n_local; ++i)
+            for (int j = 0; j < i; ++j)
+                if (devices[i] == devices[j]) { delete g; return fail(nullptr, CPPROB_HIP_EINVAL, "a device may appear once (RCCL) or every rank sits on the same device (loopback)"); }
+    auto bail = [&](int rc) { const std::string e = g->err; cpprob_hip_group_destroy(g); g_last_error = e; return rc; };
+    for (int i = 0; i < n_local; ++i) {
+        cpprob_hip_ctx* c = nullptr;
+        if (int rc = cpprob_hip_create(devices[i], &c)) { g->err = g_last_error; return bail(rc); }
+        g->ctx.push_back(c);
+    }
+    if (g->loopback) {
+        // one stream for every rank: program order is the only synchronisation the loopback collectives need
+        for (auto* c : g->ctx) g->own_stream.push_back(c->stream);
+        for (auto* c : g->ctx) c->stream = g->ctx[0]->stream;
+    } else {
+        std::string err;
+        g->rccl = rccl_api(err);
+        if (!g->rccl) { g->err = err; return bail(CPPROB_HIP_EDEVICE); }
+        g->comm.assign((size_t)n_local, nullptr);
+        ncclResult_t r;
+        if (world == n_local) {
+            std::vector<int> devs(devices, devices + n_local);
+            r = g->rccl->CommInitAll(g->comm.data(), n_local, devs.data());
+        } else {
+            ncclUniqueId id;
+            std::memcpy(&id, unique_id, NCCL_UNIQUE_ID_BYTES);
+            (void)hipSetDevice(devices[0]);
+            r = g->rccl->CommInitRank(&g->comm[0], world, id, first_rank);
+        }
+        if (r != ncclSuccess) { g->err = std::string("RCCL communicator: ") + g->rccl->GetErrorString(r); g->comm.clear(); return bail(CPPROB_HIP_EDEVICE); }
+    }
+    *out = g;
+    return 0;
+}
+
+void cpprob_hip_group_destroy(cpprob_hip_group* g)
+{
+    if (!g) return;
+    if (!g->workers.empty()) {
+        { std::lock_guard<std::mutex> lock(g->m); g->stopping = true; }
+        g->cv_job.notify_all();
+        for (auto& w : g->workers) w.join();
+    }
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        (void)hipSetDevice(g->ctx[i]->device);
+        (void)hipStreamSynchronize(g->ctx[i]->stream);
+    }
+    for (size_t i = 0; i < g->comm.size(); ++i)
+        if (g->comm[i]) (void)g->rccl->CommDestroy(g->comm[i]);
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        (void)hipSetDevice(g->ctx[i]->device);
+        if (i < g->d_local.size()) { (void)hipFree(g->d_local[i]); (void)hipFree(g->d_all[i]); (void)hipFree(g->d_joint[i]); }
+        if (g->loopback && i < g->own_stream.size()) g->ctx[i]->stream = g->own_stream[i];
+    }
+    if (g->d_ptr_locals) { (void)hipFree((void*)g->d_ptr_locals); (void)hipFree((void*)g->d_ptr_alls); (void)hipFree((void*)g->d_ptr_joints); }
+    for (auto* c : g->ctx) cpprob_hip_destroy(c);
+    delete g;
+}
+
+const char* cpprob_hip_group_last_error(const cpprob_hip_group* g) { return g ? g->err.c_str() : g_last_error.c_str(); }
+
+int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, const double* h_observes, size_t n_observes, const uint64_t* h_shard_sizes)
+{
+    if (!g || !cfg || !h_observes) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "NULL argument"));
+    if (cfg->n_particles < (uint64_t)g->world) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "fewer particles than ranks"));
+    g->cfg = *cfg;
+    g->obs.assign(h_observes, h_observes + n_observes);
+    g->shard_begin.assign((size_t)g->world + 1, 0);
+    uint64_t largest = 0;
+    for (int r = 0; r < g->world; ++r) {
+        // contiguous shards: particle i lives on rank floor(i * world / N) unless the caller names the sizes
+        const uint64_t base = cfg->n_particles / (uint64_t)g->world, rem = cfg->n_particles % (uint64_t)g->world;
+        const uint64_t sz = h_shard_sizes ? h_shard_sizes[r] : base + ((uint64_t)r < rem ? 1 : 0);
+        if (sz == 0) return gfail(g, CPPROB_HIP_EINVAL, "empty shard");
+        g->shard_begin[(size_t)r + 1] = g->shard_begin[(size_t)r] + sz;
+        largest = std::max(largest, sz);
+    }
+    if (g->shard_begin[(size_t)g->world] != cfg->n_particles) return gfail(g, CPPROB_HIP_EINVAL, "shard sizes do not add up to n_particles");
+    g->exchange = cfg->algorithm == CPPROB_HIP_ALG_SMC && cfg->resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC;
+    // transport defaults: the two neighbours, room for the O(sqrt(N)) outputs a rank's offspring interval leaves its shard by
+    g->all_peers = 0;
+    const uint64_t guess = (uint64_t)(8.0 * std::sqrt((double)cfg->n_particles)) / kTile * kTile + 4 * kTile;
+    g->cap = std::min<uint64_t>(largest, guess);
+    g->annex_kcols = 0;
+    if (const char* e = getenv("CPPROB_GROUP_CAP")) g->cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    if (const char* e = getenv("CPPROB_GROUP_ALL_PEERS")) g->all_peers = e[0] == '1';
+    if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
+    g->T = g->ctx[0]->T; g->K = g->ctx[0]->K; g->n_stats = g->T * g->K;
+    const int n_local = (int)g->ctx.size();
+    if (g->d_local.empty()) { g->d_local.assign((size_t)n_local, nullptr); g->d_all.assign((size_t)n_local, nullptr); g->d_joint.assign((size_t)n_local, nullptr); }
+    for (int i = 0; i < n_local; ++i) {
+        cpprob_hip_ctx* c = g->ctx[(size_t)i];
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (g->d_local[(size_t)i]) { (void)hipFree(g->d_local[(size_t)i]); (void)hipFree(g->d_all[(size_t)i]); (void)hipFree(g->d_joint[(size_t)i]); }
+        HIP_TRY(c, hipMalloc(&g->d_local[(size_t)i], 4 * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&g->d_all[(size_t)i], 3 * (size_t)g->world * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&g->d_joint[(size_t)i], ((size_t)g->n_stats + 1) * sizeof(double)));
+        HIP_TRY(c, hipMemset(g->d_local[(size_t)i], 0, 4 * sizeof(double)));
+        HIP_TRY(c, hipMemset(g->d_all[(size_t)i], 0, 3 * (size_t)g->world * sizeof(double)));
+        HIP_TRY(c, hipMemset(g->d_joint[(size_t)i], 0, ((size_t)g->n_stats + 1) * sizeof(double)));
+    }
+    if (g->loopback) {
+        cpprob_hip_ctx* c = g->ctx[0];
+        if (g->d_ptr_locals) { (void)hipFree((void*)g->d_ptr_locals); (void)hipFree((void*)g->d_ptr_alls); (void)hipFree((void*)g->d_ptr_joints); }
+        void *pl = nullptr, *pa = nullptr, *pj = nullptr;
+        HIP_TRY(c, hipMalloc(&pl, (size_t)n_local * sizeof(double*)));
+        HIP_TRY(c, hipMalloc(&pa, (size_t)n_local * sizeof(double*)));
+        HIP_TRY(c, hipMalloc(&pj, (size_t)n_local * sizeof(double*)));
+        HIP_TRY(c, hipMemcpy(pl, g->d_local.data(), (size_t)n_local * sizeof(double*), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(pa, g->d_all.data(), (size_t)n_local * sizeof(double*), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(pj, g->d_joint.data(), (size_t)n_local * sizeof(double*), hipMemcpyHostToDevice));
+        g->d_ptr_locals = static_cast<double* const*>(pl); g->d_ptr_alls = static_cast<double* const*>(pa); g->d_ptr_joints = static_cast<double* const*>(pj);
+    } else if (n_local > 1 && g->workers.empty()) {
+        g->job_rc.assign((size_t)n_local, 0); g->job_err.assign((size_t)n_local, "");
+        for (int i = 0; i < n_local; ++i) g->workers.emplace_back(group_worker, g, i);
+    }
+    g->begun = true; g->ran = false; g->reruns = 0;
+    return 0;
+}
+
+int cpprob_hip_group_run(cpprob_hip_group* g, uint64_t run_index)
+{
+    if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
+    if (!g->begun) return gfail(g, CPPROB_HIP_ESTATE, "cpprob_hip_group_begin has not been called");
+    if (int rc = group_enqueue(g, run_index)) return gkeep(g, rc);
+    g->last_run = run_index; g->ran = true;
+    return 0;
+}
+
+int cpprob_hip_group_sync(cpprob_hip_group* g)
+{
+    if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
+    for (auto* c : g->ctx)
+        if (int rc = cpprob_hip_sync(c)) return gfail(g, rc, cpprob_hip_last_error(c));
+    return 0;
+}
+
+int cpprob_hip_group_size(const cpprob_hip_group* g, int32_t* world, int32_t* n_local, int32_t* first_rank)
+{
+    if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
+    if (world) *world = g->world;
+    if (n_local) *n_local = (int32_t)g->ctx.size();
+    if (first_rank) *first_rank = g->first_rank;
+    return 0;
+}
+
+cpprob_hip_ctx* cpprob_hip_group_context(cpprob_hip_group* g, int32_t local_index)
+{
+    return (g && local_index >= 0 && (size_t)local_index < g->ctx.size()) ? g->ctx[(size_t)local_index] : nullptr;
+}
+
+int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, double* h_stats, size_t n_doubles, int32_t* h_reruns)
+{
+    if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
+    if (!g->ran) return gfail(g, CPPROB_HIP_ESTATE, "no finished run");
+    if (h_stats && n_doubles < (size_t)g->n_stats) return gfail(g, CPPROB_HIP_EINVAL, "h_stats too small");
+    std::vector<double> joint((size_t)g->n_stats + 1);
+    for (int attempt = 0;; ++attempt) {
+        if (int rc = cpprob_hip_group_sync(g)) return rc;
+        cpprob_hip_ctx* c = g->ctx[0];
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipMemcpy(joint.data(), g->d_joint[0], joint.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (joint[(size_t)g->n_stats] == 0.0) break;
+        // some rank's transport segment or annex was too small (every rank sees the same all-reduced flag and takes the same
+        // decision): repeat the run with every rank as a peer, full-shard segments and a larger annex.  Results do not depend
+        // on the transport parameters, only their validity does.
+        if (attempt >= 4) return gfail(g, CPPROB_HIP_EDEVICE, "exchange transport still too small after four enlargements");
+        uint64_t largest = 0;
+        for (int r = 0; r < g->world; ++r) largest = std::max(largest, g->shard_begin[(size_t)r + 1] - g->shard_begin[(size_t)r]);
+        g->all_peers = 1; g->cap = largest;
+        g->annex_kcols = std::max(4, g->annex_kcols * 4);
+        while ((uint64_t)g->annex_kcols * 1024 < largest / 4) g->annex_kcols *= 2;
+        if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
+        ++g->reruns;
+        if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
+    }
+    if (h_reruns) *h_reruns = g->reruns;
+    cpprob_hip_summary s{};
+    if (int rc = cpprob_hip_infer_summary(g->ctx[0], &s)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[0]));
+    if (out) *out = s;
+    if (h_stats) {
+        // StatsPrinter's numbers from the all-reduced un-normalised sums (relative to exp(max_logw))
+        const double W = std::exp(s.log_norm - s.max_logw);
+        for (int t = 0; t < g->T; ++t) {
+            if (s.is_int) { for (int k = 0; k < g->K; ++k) h_stats[t * g->K + k] = joint[(size_t)(t * g->K + k)] / W; }
+            else {
+                const double mean = joint[(size_t)(t * g->K)] / W;
+                h_stats[t * g->K] = mean;
+                h_stats[t * g->K + 1] = joint[(size_t)(t * g->K + 1)] / W - mean * mean;      // raw_moment(2) - mean^2, empirical_distribution.hpp:78-81
+            }
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -88,7 +88,8 @@ typedef struct cpprob_hip_config {
                                  (cpprob_hip_exchange_*) so that resampling is exact over shards */
     int32_t keep_history;     /* 1: keep per-step values + ancestors (needed for smoothing /
                                  dumps; always 1 in this version)                             */
-    int32_t reserved;
+    int32_t reserved;         /* exchange scope: immigrant-annex capacity in units of 1024 columns per row (0 = default: 1/16 of
+                                 the shard, at least 4096); stream-ordered runs cannot grow it mid-run and report overflow instead */
     double ess_threshold;     /* SMC: resample after a step iff ESS < ess_threshold * N_global;
                                  > 1 resamples after every step (thesis p.37 uses 0.5)        */
     uint64_t seed;            /* Philox key                                                    */
@@ -225,6 +226,35 @@ int cpprob_hip_exchange_transport(cpprob_hip_ctx* ctx, void** d_send, void** d_r
 int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* ctx, int32_t t);
 int cpprob_hip_exchange_commit_async(cpprob_hip_ctx* ctx, int32_t t);
 int cpprob_hip_exchange_status(cpprob_hip_ctx* ctx, int32_t* h_overflow, uint64_t* h_annex_used);
+
+/* ---- one joint population over several GPUs, driven from the host side of this library ------------------------------------
+ * A group = one context per GPU + a transport; cpprob_hip_group_run enqueues a WHOLE exchange-scope run on every local rank --
+ * per step: propagate / weigh, all-gather of 3 doubles per rank, device-side plan, send / receive of the migrating lineages,
+ * commit -- with no host synchronisation inside (cpprob_amd/csrc/group.hpp).  Replaces what a caller of the reference would have
+ * to build around cpprob::inference to use more than one device (the reference is single-process, src/cpprob/state.cpp:20-21).
+ *   create   world == n_local: every rank in this process.  Distinct devices: RCCL over xGMI, one communicator and one host
+ *            thread per GPU.  All devices equal: "loopback" -- every rank's context on that one device and one stream, copies
+ *            instead of collectives (how a one-GPU machine exercises the protocol; RCCL refuses duplicate devices).
+ *            world > n_local: one rank (n_local = 1) of a group spread over processes; unique_id = the 128 bytes rank 0 got from
+ *            cpprob_hip_group_unique_id and handed to every rank (the launcher's job: torchrun, MPI, a file).
+ *   begin    cfg as for cpprob_hip_infer_begin with n_particles = the WHOLE population (particle_offset / n_global / scope are
+ *            set per rank by the group); shards are contiguous and equal unless h_shard_sizes[world] names them.  Systematic SMC
+ *            runs in the exchange scope (exact global resampling); other resamplers and SIS in the global scope.
+ *   run      asynchronous; results synchronises, all-reduces and normalises: h_stats as cpprob_hip_infer_stats of ONE GPU holding
+ *            the whole population would return.  If a transport segment or the annex overflowed, results repeats the last run
+ *            with a larger transport first (h_reruns counts those since begin): the numbers never depend on the transport.
+ *   context  the rank's context, e.g. for cpprob_hip_copy_paths of its shard. */
+typedef struct cpprob_hip_group cpprob_hip_group;
+int cpprob_hip_group_unique_id(void* out128, size_t n_bytes);
+int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t world, int32_t first_rank, const void* unique_id, cpprob_hip_group** out);
+void cpprob_hip_group_destroy(cpprob_hip_group* group);
+const char* cpprob_hip_group_last_error(const cpprob_hip_group* group);
+int cpprob_hip_group_begin(cpprob_hip_group* group, const cpprob_hip_config* cfg, const double* h_observes, size_t n_observes, const uint64_t* h_shard_sizes);
+int cpprob_hip_group_run(cpprob_hip_group* group, uint64_t run_index);
+int cpprob_hip_group_sync(cpprob_hip_group* group);
+int cpprob_hip_group_size(const cpprob_hip_group* group, int32_t* world, int32_t* n_local, int32_t* first_rank);
+cpprob_hip_ctx* cpprob_hip_group_context(cpprob_hip_group* group, int32_t local_index);
+int cpprob_hip_group_results(cpprob_hip_group* group, cpprob_hip_summary* out, double* h_stats, size_t n_doubles, int32_t* h_reruns);
 
 /* ---- building blocks (also the unit-parity surface) --------------------------------------
  * All pointers are device pointers; n is the element count. */

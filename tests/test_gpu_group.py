@@ -1,0 +1,151 @@
+"""The library's own multi-GPU driver (cpprob_amd/csrc/group.hpp) on one GPU: every rank of the group sits on cuda:0
+("loopback": one stream, copies instead of collectives), so the WHOLE stream-ordered exchange protocol -- device-side
+plan, fixed-capacity transport segments, annex commit, sharded prefix-count steps -- runs exactly as it would over RCCL,
+and its results are compared with ONE context holding all particles."""
+import os
+
+import numpy as np
+import pytest
+
+import cpprob_amd as cp
+
+pytestmark = pytest.mark.gpu
+
+
+def _obs(golden_dir, key):
+    return np.load(os.path.join(golden_dir, "observations.npz"))[key]
+
+
+def _single(engine, alg, model, obs, n, seed, ess):
+    engine.begin(alg, model, obs, n, seed=seed, ess_threshold=ess)
+    engine.run()
+    return engine.stats().copy(), engine.summary(), engine.paths(), engine.logw()
+
+
+@pytest.mark.parametrize("shards", [[50000, 50000], [30000, 50001, 19999], [25000] * 8, [1000, 2000, 70000, 3000]])
+def test_group_hmm_every_step_is_bit_identical_to_one_gpu(engine, golden_dir, shards):
+    """Table-weight model, every-step schedule: integer prefix counts make the sharded run draw EXACTLY the ancestors one
+    GPU would -- every trace, every weight, the evidence and the posterior, bit for bit, for any shard layout."""
+    import torch  # noqa: F401
+    obs = _obs(golden_dir, "hmm16")
+    n = int(sum(shards))
+    ref_stats, ref_sum, ref_paths, ref_logw = _single(engine, cp.ALG_SMC, cp.MODEL_HMM3, obs, n, 31, 2.0)
+    g = cp.Group([0] * len(shards))
+    g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=31, ess_threshold=2.0, shard_sizes=shards)
+    g.run()
+    stats, s, reruns = g.results()
+    paths = np.concatenate([_ctx_paths(g, r, shards[r], len(obs), True) for r in range(len(shards))], axis=1)
+    assert np.array_equal(paths, ref_paths)
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
+    assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
+    g.close()
+
+
+def _ctx_paths(g, r, n_r, T, is_int):
+    e = g.context(r)
+    e.n = n_r
+    e.T = T
+    return e.paths()
+
+
+@pytest.mark.parametrize("ess", [2.0, 0.5])
+def test_group_lgssm_matches_one_gpu(engine, golden_dir, ess):
+    """Continuous weights (floating-point form of the step, device-side decision when ESS-triggered): the sharded run's
+    CDF is evaluated in a different order, so at most a couple of boundary offspring may differ."""
+    import torch  # noqa: F401
+    obs = _obs(golden_dir, "lgssm100")[:20]
+    shards = [40000, 40001, 39999]
+    n = sum(shards)
+    ref_stats, ref_sum, ref_paths, _ = _single(engine, cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, 5, ess)
+    g = cp.Group([0] * 3)
+    g.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=5, ess_threshold=ess, shard_sizes=shards)
+    g.run()
+    stats, s, _ = g.results()
+    paths = np.concatenate([_ctx_paths(g, r, shards[r], len(obs), False) for r in range(3)], axis=1)
+    differ = (paths != ref_paths).any(axis=0).sum()
+    assert differ <= 2
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if differ else 1e-11)
+    assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-11 and s["n_resampled"] == ref_sum["n_resampled"]
+    g.close()
+
+
+def test_group_hmm128_ess_triggered_matches_one_gpu(engine, golden_dir):
+    import torch  # noqa: F401
+    obs = _obs(golden_dir, "hmm128")
+    shards = [60000, 60000]
+    n = sum(shards)
+    ref_stats, ref_sum, ref_paths, _ = _single(engine, cp.ALG_SMC, cp.MODEL_HMM3, obs, n, 9, 0.5)
+    g = cp.Group([0, 0])
+    g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=9, ess_threshold=0.5, shard_sizes=shards)
+    g.run()
+    stats, s, _ = g.results()
+    paths = np.concatenate([_ctx_paths(g, r, shards[r], len(obs), True) for r in range(2)], axis=1)
+    differ = (paths != ref_paths).any(axis=0).sum()
+    assert differ <= 2
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if differ else 1e-11)
+    assert s["n_resampled"] == ref_sum["n_resampled"] and 0 < s["n_resampled"] < 127
+    g.close()
+
+
+def test_group_repopulation_from_one_rank_enlarges_the_transport(engine, golden_dir):
+    """An outlying first observation leaves the mass on a few particles of one shard: whole shards are repopulated from it --
+    far more immigrants than the default segments and annex hold.  The overflow flag travels with the final all-reduce and the
+    driver repeats the run with full-size segments; the answer is the one-GPU answer."""
+    import torch  # noqa: F401
+    obs = np.array(_obs(golden_dir, "lgssm100")[:12])
+    obs[0] = 7.5
+    shards = [40000, 40000, 40000]
+    n = sum(shards)
+    ref_stats, ref_sum, ref_paths, _ = _single(engine, cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, 5, 0.5)
+    g = cp.Group([0] * 3)
+    g.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=5, ess_threshold=0.5, shard_sizes=shards)
+    g.run()
+    stats, s, reruns = g.results()
+    assert reruns >= 1
+    paths = np.concatenate([_ctx_paths(g, r, shards[r], len(obs), False) for r in range(3)], axis=1)
+    differ = (paths != ref_paths).any(axis=0).sum()
+    assert differ <= 2
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if differ else 1e-11)
+    g.close()
+
+
+def test_group_sis_and_back_to_back_runs(engine, golden_dir):
+    import torch  # noqa: F401
+    n = 100003
+    engine.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, [3.0, 4.0], n, seed=3)
+    engine.run()
+    ref = engine.stats().copy()
+    g = cp.Group([0, 0, 0])
+    g.begin(cp.ALG_SIS, cp.MODEL_GAUSSIAN_UNKNOWN_MEAN, [3.0, 4.0], n, seed=3)
+    g.run()
+    stats, s, _ = g.results()
+    np.testing.assert_allclose(stats, ref, rtol=1e-12)
+    # several runs in flight, one synchronisation: the last one's results; run indices decorrelate
+    obs = _obs(golden_dir, "hmm16")
+    g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 90000, seed=1, ess_threshold=2.0)
+    for i in range(5):
+        g.run(i)
+    a, sa, _ = g.results()
+    g.run(4)
+    b, sb, _ = g.results()
+    assert np.array_equal(a, b) and sa["log_evidence"] == sb["log_evidence"]
+    g.run(0)
+    c, _, _ = g.results()
+    assert not np.array_equal(a, c)
+    g.close()
+
+
+def test_group_over_rccl_with_one_rank(engine, golden_dir):
+    """world = 1 over the real transport: the library's RCCL calls (communicator, all-gather, all-reduce on the context's
+    stream) run on this GPU; bit-identical to the plain run."""
+    import torch  # noqa: F401
+    obs = _obs(golden_dir, "hmm16")
+    n = 200000
+    ref_stats, ref_sum, _, _ = _single(engine, cp.ALG_SMC, cp.MODEL_HMM3, obs, n, 4, 2.0)
+    g = cp.Group([0])
+    g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, ess_threshold=2.0)
+    g.run()
+    stats, s, reruns = g.results()
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
+    assert s["log_evidence"] == ref_sum["log_evidence"] and reruns == 0
+    g.close()
