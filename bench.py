@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample")
     p.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (pipelined runs, gaussian SIS)")
     p.add_argument("--in-flight", type=int, default=3, help="contexts in flight for the secondary pipelined measurement")
+    p.add_argument("--python-host", action="store_true", help="N > 1: drive the exchange scope from Python / torch.distributed instead of the library's C++ driver")
     return p.parse_args()
 
 
@@ -132,6 +133,42 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchang
     return dt, last
 
 
+def timed_group_runs(group, steps, warmup, world, device, first_index=0):
+    """The same bracket for the library's own multi-GPU driver (cpprob_hip_group_run: a whole exchange-scope run per call,
+    RCCL collectives on the context's stream, no host synchronisation inside)."""
+    import torch
+    import torch.distributed as dist
+    for i in range(warmup):
+        group.run(first_index + i)
+    group.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        group.run(first_index + warmup + i)
+    group.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stats, summ, reruns = group.results()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, stats, summ, reruns
+
+
+def make_rank_group(cp, world, rank, local):
+    """This process's rank of a group spread over the launcher's processes: rank 0 draws the RCCL unique id, torch.distributed
+    (already initialised by the launcher's environment) hands it to everybody."""
+    import torch.distributed as dist
+    box = [cp.Group.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return cp.Group([local], world=world, first_rank=rank, unique_id=box[0])
+
+
 def _oracle_run(args):
     """One oracle run (worker of the all-cores baseline; top-level so that multiprocessing can pickle it)."""
     alg_is_sis, model, obs, n_sample, seed, ess = args
@@ -149,7 +186,7 @@ def cpu_baseline_worker(workload, n_sample, seed):
     """Runs in a FRESH interpreter (no GPU state, so forking a process pool is safe): the oracle timed on the host
     (BASELINE.md section 2), bounded samples:
     value      = mode B: one core, compute-only, in memory (the reference is single-threaded with global state);
-    all_cores  = mode C: independent replicas with distinct seeds on up to 32 cores (what processes could do)."""
+    all_cores  = mode C: independent replicas with distinct seeds on every host core (what processes could do)."""
     import multiprocessing as mp
     import cpprob_amd as cp
     from oracle import oracle as O
@@ -163,8 +200,8 @@ def cpu_baseline_worker(workload, n_sample, seed):
            "sample": "%d particles of the same workload (all T steps + read-out), oracle/cpprob_oracle.c -O2, in-memory (no file dumps), %.1f s"
                      % (n_sample, dt), "host_cores_available": os.cpu_count()}
     try:
-        procs = max(1, min(32, os.cpu_count() or 1))
-        per = max(10000, n_sample // 4)
+        procs = max(1, os.cpu_count() or 1)            # mode C of BASELINE.md: every host core, independent replicas
+        per = max(10000, n_sample // 16)
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(procs) as pool:
             done = sum(pool.map(_oracle_run, [(is_sis, spec["model"], spec["obs"], per, seed + 1 + i, spec["ess"]) for i in range(procs)]))
@@ -184,7 +221,7 @@ def cpu_baseline(workload, n_sample, seed):
     return json.loads(p.stdout.strip().splitlines()[-1])
 
 
-def cpu_as_shipped(n_sample, seed):
+def cpu_as_shipped(n_sample, seed, model=None, obs=None, address="Mu", label="gaussian_unknown_mean"):
     """Mode A of BASELINE.md for the SIS path: what the reference actually does per particle -- three append-mode
     file open/write/close (src/cpprob/state.cpp:193-202,262-267) and a progress line every 100 traces."""
     import tempfile
@@ -192,12 +229,13 @@ def cpu_as_shipped(n_sample, seed):
     from oracle import oracle as O
     d = tempfile.mkdtemp(prefix="cpprob_as_shipped_")
     t0 = time.perf_counter()
-    O.sis_faithful(O.MODEL_GAUSSIAN_UNKNOWN_MEAN, np.array([3.0, 4.0]), n_sample, seed, os.path.join(d, "posterior"), "Mu", progress=False)
+    O.sis_faithful(O.MODEL_GAUSSIAN_UNKNOWN_MEAN if model is None else model, np.array([3.0, 4.0]) if obs is None else obs, n_sample, seed,
+                   os.path.join(d, "posterior"), address, progress=False)
     dt = time.perf_counter() - t0
     for f in os.listdir(d):
         os.remove(os.path.join(d, f))
     os.rmdir(d)
-    return {"value": n_sample / dt, "unit": "particles/s", "cores": 1, "sample": "%d particles, gaussian_unknown_mean SIS with per-particle file dumps, %.1f s" % (n_sample, dt)}
+    return {"value": n_sample / dt, "unit": "particles/s", "cores": 1, "sample": "%d particles, %s SIS with per-particle file dumps, %.1f s" % (n_sample, label, dt)}
 
 
 def main():
@@ -208,6 +246,11 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env == 1:
         sys.exit(relaunch_under_torchrun(args))   # child process; nothing has touched the GPU yet
+    # stdout carries ONE line, the JSON: libraries that print there (RCCL announces its version on the first communicator) are
+    # sent to stderr for the whole run; the line itself goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -223,21 +266,37 @@ def main():
     n = args.particles
     T = 1 if args.workload == "gaussian_sis" else len(spec["obs"])
     scope = args.scope
+    smc = spec["alg"] == cp.ALG_SMC
     if scope == "auto":
-        # One joint population.  With a STATIC resampling schedule (every step) the joint algorithm -- local resampling,
-        # each shard carrying its share of the mass -- never needs the other shards' totals inside a run: it is the same
-        # estimator as shards combined once by their evidence (tests: ..._static_schedule_equals_evidence_weighted_islands),
-        # so the per-step all-gather is deferred to one all-gather per run.  ESS-triggered schedules need the joint ESS
-        # every step and use the per-step RCCL all-gather.
-        scope = "global" if (world == 1 or spec["ess"] <= 1.0 or spec["alg"] == cp.ALG_SIS) else "global-deferred"
+        # SURVEY 8(e) / north_star: one joint population, resampled exactly as ONE GPU holding all particles would -- per step an
+        # all-gather of the rank totals and the redistribution of the offspring whose ancestor sits on another GPU (exchange scope).
+        # The migration-free scopes (island / global) are measured beside it as labelled secondary numbers.
+        scope = "exchange" if (world > 1 and smc) else "global"
     island = scope in ("island", "global-deferred")
-    exchange = scope == "exchange" and spec["alg"] == cp.ALG_SMC
-    eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
-              particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND if island else (cp.SCOPE_EXCHANGE if exchange else cp.SCOPE_GLOBAL))
-
-    moved = {}
-    dt, last = timed_runs(eng, args.steps, args.warmup, world, device, island, exchange=exchange, counters=moved)
+    exchange = scope == "exchange" and smc
     n_global = world * n
+    # the library's own C++ driver issues the collectives (RCCL) unless several ranks share one GPU (test hook: RCCL refuses that)
+    native = exchange and world > 1 and not D._host_collectives() and not args.python_host
+    host = "python (torch.distributed)"
+    group = None
+    native_error = None
+    if native:
+        try:
+            group = make_rank_group(cp, world, rank, local)
+            host = "C++ (cpprob_hip_group_run: RCCL on the context's stream, no host synchronisation inside a run)"
+        except Exception as e:      # reported, never silent: the run then goes through torch.distributed's collectives
+            native_error = str(e)
+    moved = {}
+    reruns = 0
+    if group is not None:
+        group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
+        dt, stats, summ, reruns = timed_group_runs(group, args.steps, args.warmup, world, device)
+        last = (stats,)
+    else:
+        eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
+                  particle_offset=rank * n, n_global=n_global, scope=cp.SCOPE_ISLAND if island else (cp.SCOPE_EXCHANGE if exchange else cp.SCOPE_GLOBAL))
+        dt, last = timed_runs(eng, args.steps, args.warmup, world, device, island, exchange=exchange, counters=moved)
+        summ = None
     value = n_global * args.steps / dt
 
     # posterior of the last timed run against the exact answer (validity of what was timed)
@@ -246,17 +305,18 @@ def main():
     else:
         stats = eng.stats()
     err = float(np.abs(stats - spec["exact"]).max())
-    summ = eng.summary()
+    if summ is None:
+        summ = eng.summary()
     if last is not None and len(last) == 3:
         summ["log_evidence"] = last[1]          # evidence of the joint population (shards combined), not of this rank's shard
     if exchange:
-        collective = "all_gather(3 doubles/rank) + all_to_all_v(migrating lineages) per step; %d records sent by rank 0 in the last run" % moved.get("records_sent", 0)
+        collective = "all_gather(3 doubles/rank) + all_to_all_v of the migrating lineages (ncclSend/ncclRecv of per-peer segments) per step; all_reduce(T*K+1 doubles) per run"
     else:
         collective = "none" if world == 1 else ("all_gather(4+T*K doubles/rank) once per run, asynchronous (no host synchronisation between runs)" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
 
     # profiled pass: same K steps with HIP events around every launch on the engine's stream
     # (per-shard kernels only: on several GPUs each rank profiles its own shard as an island)
-    if (world > 1 and not island) or exchange:
+    if (world > 1 and not island) or exchange or group is not None:
         eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
                   particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND)
     eng.profile_enable(True)
@@ -292,11 +352,45 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s, %d particles per GPU" % (spec["desc"], n), "particles_per_gpu": n, "T": T,
-                   "resampler": "systematic", "ess_threshold": spec["ess"], "scope": scope, "n_global": n_global, "collective": collective},
+                   "resampler": "systematic", "ess_threshold": spec["ess"], "scope": scope, "n_global": n_global, "collective": collective,
+                   "host": host if world > 1 else "one context, one stream", "exchange_reruns": reruns},
         "particle_steps_per_sec": value * T,
         "roofline": roofline,
         "posterior_max_abs_err_vs_exact": err, "log_evidence": summ["log_evidence"], "n_resampled": summ["n_resampled"],
     }
+
+    if native_error:
+        out["config"]["native_driver_error"] = native_error
+
+    if world > 1 and exchange and not args.no_extras:
+        # secondary, labelled: the migration-free scopes on the same shards (every rank takes part).  "island": independent
+        # populations combined once per run by their evidence -- no data-path collective; "global": one joint population, per-step
+        # all-gather of 3 doubles per rank, resampling local to the shard (mass share carried) -- a different estimator from the
+        # headline's exact global resampling ("offer it as an option, not the default").
+        sec = {}
+        k2, w2 = max(2, min(args.steps, 20)), max(1, min(args.warmup, 3))
+        for name, isl in (("island", True), ("global", False)):
+            eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
+                      particle_offset=rank * n, n_global=n_global, scope=cp.SCOPE_ISLAND if isl else cp.SCOPE_GLOBAL)
+            sdt, slast = timed_runs(eng, k2, w2, world, device, isl, first_index=70_000)
+            sec[name] = {"particles_per_sec": n_global * k2 / sdt, "ms_per_run": sdt / k2 * 1e3, "runs": k2,
+                         "posterior_max_abs_err_vs_exact": float(np.abs(slast[0] - spec["exact"]).max()) if slast is not None else None,
+                         "collective": "all_gather(4+T*K doubles/rank) once per run" if isl else "all_gather(3 doubles/rank) per step, no migration"}
+        out["secondary_scopes"] = sec
+
+    if rank == 0 and world == 1 and not args.no_extras and smc:
+        # secondary: the multi-GPU protocol at world = 1 -- the library's C++ driver over RCCL with a single rank: per step the sharded
+        # step kernel, the 3-double all-gather and the device-side bookkeeping, no peers to exchange with
+        try:
+            g1 = cp.Group([local])
+            g1.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
+            gdt, gstats, _, grr = timed_group_runs(g1, args.steps, args.warmup, 1, device, first_index=60_000)
+            out["exchange_world1"] = {"ms_per_run": gdt / args.steps * 1e3, "particles_per_sec": n * args.steps / gdt, "reruns": grr,
+                                      "posterior_max_abs_err_vs_exact": float(np.abs(gstats - spec["exact"]).max()),
+                                      "note": "cpprob_hip_group_run, world = 1, RCCL all-gather per step on the context's stream"}
+            g1.close()
+        except Exception as e:
+            out["exchange_world1"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not args.no_extras:
         # error bars: five run seeds of the headline configuration against the exact posterior
@@ -368,9 +462,20 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.seed)
         if "value" in out["cpu_baseline"]:
             out["gpu_over_cpu_1core"] = value / out["cpu_baseline"]["value"]
+        if spec["model"] == cp.MODEL_HMM3:
+            # mode A of BASELINE.md (as shipped: one core, three file appends per particle) for this workload's model run as SIS --
+            # the only mode the reference has
+            try:
+                out["cpu_baseline"]["as_shipped_sis_1core"] = cpu_as_shipped(100_000, args.seed, model=cp.MODEL_HMM3, obs=spec["obs"], address="State",
+                                                                             label="hmm<%d>" % T)
+            except Exception as e:
+                out["cpu_baseline"]["as_shipped_sis_1core"] = {"error": str(e)}
 
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if group is not None:
+        group.close()
     eng.close()
     if world > 1:
         import torch.distributed as dist

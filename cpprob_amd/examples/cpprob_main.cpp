@@ -6,6 +6,8 @@
 //        --generated_file NAME (default "post")   --model_folder DIR (default ".")   --estimate
 //        additions: --seed S  --resampler {systematic,stratified,multinomial}  --ess_threshold X
 //                   --generic (run the unchanged model body on the GPU instead of the fused kernels)
+//                   --gpus N | --devices a,b,...  (one joint population sharded over several GPUs: exact global resampling, RCCL over xGMI;
+//                                                  equal entries, e.g. 0,0,0: every rank on that GPU)
 //                   --no_dump  --json (print the in-memory result as one JSON line)
 // This file never touches HIP: it calls cpprob::inference exactly as the reference's main does.
 #include <array>
@@ -32,7 +34,8 @@ void print_json(const cpprob::gpu::Result& r)
 {
     std::cout.precision(17);
     std::cout << "{\"n\": " << r.n_particles << ", \"log_evidence\": " << r.log_evidence << ", \"ess\": " << r.ess
-              << ", \"n_resampled\": " << r.n_resampled << ", \"run_seconds\": " << r.run_seconds << ", \"builtin\": " << (r.used_builtin ? "true" : "false") << ", \"predicts\": [";
+              << ", \"n_resampled\": " << r.n_resampled << ", \"run_seconds\": " << r.run_seconds << ", \"builtin\": " << (r.used_builtin ? "true" : "false")
+              << ", \"n_gpus\": " << r.n_gpus << ", \"exchange_reruns\": " << r.exchange_reruns << ", \"predicts\": [";
     for (std::size_t i = 0; i < r.predicts.size(); ++i) {
         const auto& p = r.predicts[i];
         if (i) std::cout << ", ";
@@ -118,6 +121,12 @@ int main(int argc, char** argv)
         else if (f == "--ess_threshold") opt.ess_threshold = std::stod(next());
         else if (f == "--resampler") { const std::string r = next(); opt.resampler = r == "multinomial" ? 2 : (r == "stratified" ? 1 : 0); }
         else if (f == "--generic") opt.prefer_builtin = false;
+        else if (f == "--gpus") { const int k = std::stoi(next()); opt.devices.clear(); for (int d = 0; d < k; ++d) opt.devices.push_back(d); }
+        else if (f == "--devices") {                        // e.g. 0,1,2,3 -- or 0,0 for two ranks on one GPU (loopback transport)
+            const std::string v = next(); opt.devices.clear();
+            std::size_t p0 = 0;
+            while (p0 <= v.size()) { const std::size_t q = v.find(',', p0); opt.devices.push_back(std::stoi(v.substr(p0, q == std::string::npos ? q : q - p0))); if (q == std::string::npos) break; p0 = q + 1; }
+        }
         else if (f == "--repeat") a.repeat = std::stoi(next());
         else if (f == "--replicates") opt.replicates = std::stoi(next());
         else if (f == "--no_dump") opt.dump = false;

@@ -97,6 +97,96 @@ inline void fill_predict_names(Result& res, const detail::TraceStructure& st)
     for (std::size_t id : st.int_ids) { PredictStats p; p.address = st.addresses[id]; p.is_int = true; res.predicts.push_back(p); }
 }
 
+// ---- built-in models over several GPUs: cpprob_hip_group_* (one joint population, exact global resampling) -------------------
+class Group {
+public:
+    explicit Group(const std::vector<int>& devices)
+    {
+        std::vector<std::int32_t> d(devices.begin(), devices.end());
+        const int rc = cpprob_hip_group_create(d.data(), static_cast<std::int32_t>(d.size()), static_cast<std::int32_t>(d.size()), 0, nullptr, &h_);
+        if (rc) throw std::runtime_error(std::string("cpprob_hip_group_create: ") + cpprob_hip_group_last_error(nullptr));
+    }
+    ~Group() { if (h_) cpprob_hip_group_destroy(h_); }
+    Group(const Group&) = delete;
+    Group& operator=(const Group&) = delete;
+    cpprob_hip_group* get() const { return h_; }
+    void check(int rc, const char* what) const
+    {
+        if (rc) throw std::runtime_error(std::string(what) + ": " + cpprob_hip_group_last_error(h_));
+    }
+private:
+    cpprob_hip_group* h_ = nullptr;
+};
+
+inline void run_builtin_group(StateType algorithm, int model_id, const std::vector<double>& obs, std::size_t n, const detail::TraceStructure& st,
+                              const Options& opt, Result& res, HostStore* store)
+{
+    const std::size_t world = opt.devices.size();
+    Group grp(opt.devices);
+    cpprob_hip_config cfg{};
+    cfg.algorithm = algorithm == StateType::smc ? CPPROB_HIP_ALG_SMC : CPPROB_HIP_ALG_SIS;
+    cfg.model = model_id;
+    cfg.resampler = opt.resampler;
+    cfg.resample_scope = CPPROB_HIP_SCOPE_EXCHANGE;
+    cfg.keep_history = 1;
+    cfg.ess_threshold = opt.ess_threshold;
+    cfg.seed = opt.seed;
+    cfg.n_particles = n; cfg.particle_offset = 0; cfg.n_global = n;
+    grp.check(cpprob_hip_group_begin(grp.get(), &cfg, obs.data(), obs.size(), nullptr), "cpprob_hip_group_begin");
+    const auto t0 = std::chrono::steady_clock::now();
+    grp.check(cpprob_hip_group_run(grp.get(), 0), "cpprob_hip_group_run");
+    cpprob_hip_summary s{};
+    std::int32_t reruns = 0;
+    // (sizes from the model structure: results() fills exactly n_predict * stats_per_predict doubles)
+    const std::size_t K_guess = st.int_ids.empty() ? 2 : 3;
+    const std::size_t T_guess = st.int_ids.empty() ? st.real_rows() : st.int_ids.size();
+    std::vector<double> stats(T_guess * K_guess);
+    grp.check(cpprob_hip_group_results(grp.get(), &s, stats.data(), stats.size(), &reruns), "cpprob_hip_group_results");
+    res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const std::size_t T = static_cast<std::size_t>(s.n_predict), K = static_cast<std::size_t>(s.stats_per_predict);
+    if ((s.is_int ? st.int_ids.size() : st.real_rows()) != T || T * K != stats.size())
+        throw std::runtime_error("built-in model kernel and the model function disagree on the number of predict statements");
+    res.n_particles = n; res.log_evidence = s.log_evidence; res.ess = s.ess_final; res.log_norm = s.log_norm; res.n_resampled = s.n_resampled;
+    res.used_builtin = true; res.n_gpus = static_cast<int>(world); res.exchange_reruns = reruns;
+    fill_predict_names(res, st);
+    if (s.is_int) {
+        for (std::size_t t = 0; t < T; ++t) res.predicts[t].probabilities.assign(stats.begin() + t * K, stats.begin() + (t + 1) * K);
+    } else {
+        std::size_t row = 0;
+        for (std::size_t k = 0; k < st.real_ids.size(); ++k) {
+            PredictStats& p = res.predicts[k];
+            for (std::size_t d = 0; d < st.real_width[k]; ++d, ++row) { p.mean_nd.push_back(stats[row * K]); p.variance_nd.push_back(stats[row * K + 1]); }
+            p.mean = p.mean_nd[0]; p.variance = p.variance_nd[0];
+        }
+    }
+    res.step_ess.assign(T, 0.0);
+    cpprob_hip_ctx* c0 = cpprob_hip_group_context(grp.get(), 0);
+    if (cpprob_hip_infer_step_trace(c0, res.step_ess.data(), nullptr)) throw std::runtime_error(std::string("cpprob_hip_infer_step_trace: ") + cpprob_hip_last_error(c0));
+    if (store) {
+        // the shards' traces side by side: particle i of the population lives on rank floor(i * world / n) (contiguous, equal shards)
+        store->n = n;
+        store->logw.resize(n);
+        if (s.is_int) store->ints.resize(T * n); else store->real.resize(T * n);
+        std::size_t begin = 0;
+        for (std::size_t r = 0; r < world; ++r) {
+            const std::size_t nr = n / world + (r < n % world ? 1 : 0);
+            cpprob_hip_ctx* c = cpprob_hip_group_context(grp.get(), static_cast<std::int32_t>(r));
+            auto chk = [&](int rc, const char* what) { if (rc) throw std::runtime_error(std::string(what) + ": " + cpprob_hip_last_error(c)); };
+            chk(cpprob_hip_copy_logw(c, store->logw.data() + begin, nr * sizeof(double)), "cpprob_hip_copy_logw");
+            if (s.is_int) {
+                std::vector<std::int32_t> part(T * nr);
+                chk(cpprob_hip_copy_paths(c, part.data(), part.size() * sizeof(std::int32_t)), "cpprob_hip_copy_paths");
+                for (std::size_t t = 0; t < T; ++t) std::copy(part.begin() + t * nr, part.begin() + (t + 1) * nr, store->ints.begin() + t * n + begin);
+            } else {
+                std::vector<double> part(T * nr);
+                chk(cpprob_hip_copy_paths(c, part.data(), part.size() * sizeof(double)), "cpprob_hip_copy_paths");
+                for (std::size_t t = 0; t < T; ++t) std::copy(part.begin() + t * nr, part.begin() + (t + 1) * nr, store->real.begin() + t * n + begin);
+            }
+            begin += nr;
+        }
+    }
+}
+
 // ---- built-in models: the hand-fused kernels behind cpprob_hip_infer_* ---------------------------
 inline void run_builtin(StateType algorithm, int model_id, const std::vector<double>& obs, std::size_t n, const detail::TraceStructure& st,
                         const Options& opt, Result& res, HostStore* store)
@@ -237,7 +327,11 @@ void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>
     res = Result();
     HostStore hs;
     HostStore* store = opt.dump ? &hs : nullptr;
-    if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic || st.vector_statements)) run_builtin(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
+    if (opt.devices.size() > 1) {
+        if (e->builtin_model < 0) throw std::runtime_error("cpprob::inference: several GPUs (cpprob::gpu::options().devices) serve built-in models only");
+        run_builtin_group(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
+    }
+    else if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic || st.vector_statements)) run_builtin(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
     else if (e->generic) e->generic(algorithm, &obs, n, st, opt, res, store);
     else throw std::runtime_error("cpprob::inference: registry entry without a launcher");
     if (opt.dump) dump_posterior(file, st, hs, opt.dump_max_particles);      // finish_trace() x n + finish_infer()

@@ -14,6 +14,11 @@ namespace gpu {
 
 struct Options {
     int device = 0;
+    std::vector<int> devices;                         // more than one entry: ONE joint population sharded over these GPUs, resampled exactly as
+                                                      // one GPU holding every particle would (exchange scope: per step an RCCL all-gather of the
+                                                      // rank totals and the redistribution of offspring over xGMI; cpprob_hip_group_*).  All
+                                                      // entries equal: every rank on that one GPU (loopback transport; a one-GPU machine's way
+                                                      // to run the protocol).  Built-in models only.
     std::uint64_t seed = 12345;
     int resampler = CPPROB_HIP_RESAMPLE_SYSTEMATIC;   // smc
     double ess_threshold = 0.5;                       // smc: resample when ESS < threshold * N (thesis p.37); > 1: every step
@@ -38,6 +43,8 @@ struct Result {
     double log_evidence = 0, ess = 0, log_norm = 0;
     int n_resampled = 0;
     bool used_builtin = false;
+    int n_gpus = 1;                           // ranks the population was sharded over
+    int exchange_reruns = 0;                  // multi-GPU: runs repeated with a larger lineage transport (results never depend on it)
     double run_seconds = 0;                   // device work of the run (launch to synchronise), excluding allocation and dumps
     std::vector<PredictStats> predicts;       // real hits first (in trace order), then int hits
     std::vector<double> step_ess;             // smc: ESS after each observe

@@ -234,3 +234,29 @@ def test_replicates_give_error_bars(tmp_path):
     one, _, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(z["hmm16"]), "--n_samples", n, "--seed", 40, "--ess_threshold", "2.0",
                          "--json", "--no_dump")
     assert one["log_evidence"] == res["log_evidence"] and one["predicts"][0]["p"] == res["predicts"][0]["p"]
+
+
+def test_cpp_host_shards_one_population_over_several_ranks(tmp_path):
+    """SURVEY 8(e) from the C++14 host: cpprob::gpu::options().devices (cpprob_main --devices) makes cpprob::inference run ONE
+    joint population over several ranks -- here three on this GPU (loopback transport; distinct devices take RCCL over xGMI) --
+    through cpprob_hip_group_*: the answers, the dump and the estimators are those of the single-GPU call, bit for bit (hmm<16>,
+    every-step schedule: integer prefix counts), and within a couple of boundary offspring for continuous weights."""
+    obs = np.load(os.path.join(GOLD, "observations.npz"))["hmm16"]
+    n = 150001
+    common = ["--model", "hmm16", "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 3, "--ess_threshold", 2.0, "--json"]
+    one, _, _ = run_main(tmp_path, *common, "--generated_file", "one")
+    many, _, _ = run_main(tmp_path, *common, "--generated_file", "many", "--devices", "0,0,0")
+    assert one["n_gpus"] == 1 and many["n_gpus"] == 3 and many["builtin"]
+    assert many["log_evidence"] == one["log_evidence"] and many["n_resampled"] == one["n_resampled"] == 15
+    for a, b in zip(one["predicts"], many["predicts"]):
+        np.testing.assert_allclose(a["p"], b["p"], rtol=0, atol=1e-13)
+    assert open(str(tmp_path / "one_smc.int")).read() == open(str(tmp_path / "many_smc.int")).read()       # every trace, every weight
+    # continuous weights, ESS-triggered, two ranks
+    lg = np.load(os.path.join(GOLD, "observations.npz"))["lgssm100"][:25]
+    common = ["--model", "linear_gaussian_1d25", "--smc", "--observes", obs_str(lg), "--n_samples", 100000, "--seed", 5, "--ess_threshold", 0.5, "--json", "--no_dump"]
+    one, _, _ = run_main(tmp_path, *common)
+    two, _, _ = run_main(tmp_path, *common, "--devices", "0,0")
+    assert two["n_gpus"] == 2 and two["n_resampled"] == one["n_resampled"]
+    assert abs(two["log_evidence"] - one["log_evidence"]) < 1e-9
+    for a, b in zip(one["predicts"], two["predicts"]):
+        assert abs(a["mean"] - b["mean"]) < 1e-3 and abs(a["variance"] - b["variance"]) < 1e-3
