@@ -103,6 +103,8 @@ struct cpprob_hip_ctx {
     int64_t* d_annex_base = nullptr;                       // [T + 1] exchange scope: annex columns in use before each step's immigrants
     bool counts_mode = false;                              // this run's steps use smc_step_counts_kernel
     std::vector<double> h_ll_tab, h_e_tab;                 // host copies of the table-weight model's per-step tables ([T][3], [T][4])
+    double* d_wpart = nullptr;                             // bounded SIS: per-workgroup partial rows
+    bool sis_bounded_ok = false;                           // this run's model / observes admit the bounded-weight SIS kernel
 
     // scratch for building blocks
     Partial* d_bb_part = nullptr; double* d_bb_bc = nullptr; double* d_bb_bf = nullptr; double* d_bb_wrel = nullptr; void* d_bb_col = nullptr;
@@ -258,6 +260,31 @@ void launch_sis_readout(cpprob_hip_ctx* c)
                        (const double*)c->d_stile, n_col, c->d_gstat);
     hipLaunchKernelGGL(scan_slab_finish_kernel, dim3(G), dim3(kThreads), 0, c->stream, sa, (const double*)c->d_gpart, G,
                        (const double*)c->d_gstat, n_col, (int)Model::kStats, Model::kIsInt ? 1 : 0, c->d_stats);
+}
+
+// Bounded-weight SIS (kernels.hpp: sis_bounded_kernel): the whole run in two launches.  CPPROB_SIS_BOUNDED=0 keeps the per-tile form.
+template <class Model>
+bool launch_sis_bounded(cpprob_hip_ctx* c)
+{
+    static const bool enabled = !(getenv("CPPROB_SIS_BOUNDED") && getenv("CPPROB_SIS_BOUNDED")[0] == '0');
+    if constexpr (Model::kBounded) {
+        if (!enabled || !c->sis_bounded_ok) return false;
+        SisBoundedArgs<Model> a{};
+        a.mp = c->mp; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.nb = c->nb; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
+        a.values = static_cast<typename Model::store_t*>(c->d_values); a.logw = c->d_logw[0]; a.wpart = c->d_wpart;
+        const int G = std::min(c->nb, (int)kSisBoundedMaxGrid);
+        c->cur = 0; c->cur_part = 0;
+        {
+            ProfScope ps(c, 4);
+            if (c->T == 1) hipLaunchKernelGGL((sis_bounded_kernel<Model, 1>), dim3(G), dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL((sis_bounded_kernel<Model, 2>), dim3(G), dim3(kThreads), 0, c->stream, a);
+        }
+        ProfScope ps(c, 1);
+        hipLaunchKernelGGL(sis_bounded_finish_kernel, dim3(1), dim3(kThreads), 0, c->stream, (const double*)c->d_wpart, G, c->T, (int)Model::kStats, c->mp.lw_ref,
+                           (double)c->pop_n, c->d_ctrl, c->d_stats, c->d_ess, c->d_resampled, 1);
+        return true;
+    }
+    return false;
 }
 
 template <class Model, int FUSED, bool COUNTS>
@@ -539,7 +566,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
     dfree(c->d_ctrl); dfree(c->d_local_totals);
-    dfree(c->d_send_src); dfree(c->d_hier_table); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv);
+    dfree(c->d_send_src); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -677,6 +704,34 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     HIP_TRY(c, hipMalloc(&c->d_obs, n_obs * sizeof(double)));
     HIP_TRY(c, hipMemcpyAsync(c->d_obs, h_obs, n_obs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_resampled, 0, (size_t)c->T * sizeof(int32_t), c->stream));
+    {
+        // Gaussian models: the log-weight as a quadratic in the prior's standard-normal variate (extended precision on the host),
+        // and the grid point above its maximum
+        c->sis_bounded_ok = false;
+        const bool g1 = gauss, g2 = cfg->model == CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN;
+        bool finite = true;
+        for (size_t i = 0; i < n_obs; ++i) finite = finite && std::isfinite(h_obs[i]);
+        if ((g1 || g2) && finite) {
+            long double lmax = 0.0L;
+            const long double sg = c->mp.sigma, ln = c->mp.log_norm_lik;
+            if (g1) {
+                const long double b = (long double)c->mp.sigma0 / sg, a1 = ((long double)h_obs[0] - c->mp.mu0) / sg, a2 = ((long double)h_obs[1] - c->mp.mu0) / sg;
+                const long double A = -b * b, B = b * (a1 + a2), C = -0.5L * (a1 * a1 + a2 * a2) - ln;
+                c->mp.quad[0][0] = (double)A; c->mp.quad[0][1] = (double)B; c->mp.quad[0][2] = (double)C;
+                lmax = C - B * B / (4.0L * A);
+            } else {
+                for (int d = 0; d < 2; ++d) {
+                    const long double b = (long double)c->mp.nd_sigma[d] / sg, a = ((long double)h_obs[d] - c->mp.nd_mean[d]) / sg;
+                    const long double A = -0.5L * b * b, B = a * b, C = -0.5L * a * a - 0.5L * ln;
+                    c->mp.quad[d][0] = (double)A; c->mp.quad[d][1] = (double)B; c->mp.quad[d][2] = (double)C;
+                    lmax += C - B * B / (4.0L * A);
+                }
+            }
+            c->mp.lw_ref = std::ceil((double)lmax * kInvLn2) * kLn2;
+            c->sis_bounded_ok = c->T <= kMaxReadoutT;
+            if (!c->d_wpart) HIP_TRY(c, hipMalloc(&c->d_wpart, (size_t)(2 + kMaxReadoutT * 2) * kSisBoundedMaxGrid * sizeof(double)));
+        }
+    }
     dfree(c->d_ll_tab);
     c->mp.ll_tab = nullptr; c->mp.e_tab = nullptr;
     if (cfg->model == CPPROB_HIP_MODEL_HMM3) {
@@ -718,10 +773,12 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     c->run_seed = c->cfg.seed + run_index;
     c->cur = 0; c->cur_part = 0;
     c->sharded = false;
-    bool readout_done = false;
+    bool readout_done = false, sis_bounded = false;
+    (void)sis_bounded;
     if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
         dispatch_model(c, [&](auto m) {
             using M = decltype(m);
+            if (launch_sis_bounded<M>(c)) { readout_done = true; sis_bounded = true; return; }
             readout_done = sis_readout_fused<M>(c);
             launch_sis<M>(c, readout_done);
             if (readout_done) launch_sis_readout<M>(c);

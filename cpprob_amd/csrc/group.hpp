@@ -175,8 +175,9 @@ int rccl_run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
     const bool sis = g->cfg.algorithm == CPPROB_HIP_ALG_SIS;
     for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
         if (int rc = cpprob_hip_smc_step_begin(c, t, run_index, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
-        NCCL_TRY(g, g->rccl->AllGather(g->d_local[(size_t)i], g->d_all[(size_t)i], 3, ncclDouble, g->comm[(size_t)i], c->stream));
-        if (int rc = cpprob_hip_smc_step_end(c, t, g->d_all[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
+        // (a group of one has nobody to gather from: its own totals ARE the gathered totals)
+        if (world > 1) NCCL_TRY(g, g->rccl->AllGather(g->d_local[(size_t)i], g->d_all[(size_t)i], 3, ncclDouble, g->comm[(size_t)i], c->stream));
+        if (int rc = cpprob_hip_smc_step_end(c, t, world > 1 ? g->d_all[(size_t)i] : g->d_local[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
         if (g->exchange && t + 1 < g->T) {
             if (int rc = cpprob_hip_exchange_pack_async(c, t)) return gfail(g, rc, cpprob_hip_last_error(c));
             if (int rc = rccl_exchange(g, i, t)) return rc;

@@ -163,7 +163,7 @@ __device__ __forceinline__ void tile_partial(const double (&lw)[kPPT], double (&
     double s = 0.0, q = 0.0;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
-        e[k] = (lw[k] == -INFINITY) ? 0.0 : exp(lw[k] - m);   // also covers m == -inf (empty tile)
+        e[k] = exp_nonpos(fmax(lw[k] - m, -1000.0));            // lw <= m; -inf (padding) and the empty tile's NaN clamp to an exact 0
         s += e[k]; q += e[k] * e[k];
     }
     block_sum2(s, q, s_scr + kWaves);
@@ -1043,6 +1043,124 @@ __global__ __launch_bounds__(kThreads) void sis_kernel(SisArgs<Model> a)
                     if (j + 1 < K) a.stile[(size_t)(t * K + j + 1) * gridDim.x + blockIdx.x] = cb;
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SIS for models whose log-weight has a host-known upper bound (Model::kBounded: the Gaussian models, whose weight is a quadratic
+// in the prior's standard-normal variate): every weight is taken against ONE reference fixed before the launch (ModelParams::
+// lw_ref), so nothing has to be reduced before the linear weights exist -- no tile maximum, no rescaling between tiles -- and a
+// workgroup can carry its sums of e, e^2, e f(x) in registers over SEVERAL tiles (grid-stride, fixed tile set per workgroup: bitwise
+// reproducible) and reduce across lanes once.  What the per-tile form paid per 1024 particles -- five DPP reductions, three
+// barriers, the two logpdf evaluations -- is paid once per workgroup or not at all; the read-out needs one single-workgroup launch
+// over <= 2048 partial rows instead of two launches over nb tile rows.  (cpprob.hpp:194-201 for all particles at once, as sis_kernel.)
+// ---------------------------------------------------------------------------------------------
+constexpr int kSisBoundedMaxGrid = 2048;
+
+template <class Model>
+struct SisBoundedArgs {
+    ModelParams mp; int T; int64_t n, ld, rs; int nb;
+    uint64_t seed, pid0;
+    typename Model::store_t* values; double* logw;
+    double* wpart;                                   // [2 + T * kStats][gridDim.x]: sums of e, e^2, then e f_j(x_t)
+};
+
+template <class Model, int TT>
+__global__ __launch_bounds__(kThreads) void sis_bounded_kernel(SisBoundedArgs<Model> a)
+{
+    using V = typename Model::value_t;
+    constexpr int K = Model::kStats;
+    static_assert(K == 2 && TT >= 1 && TT <= kMaxReadoutT, "real-valued read-out: {sum e x, sum e x^2} per predict hit");
+    __shared__ double s_ro[2 * kWaves];
+    double acc[2 + TT * K];
+#pragma unroll
+    for (int j = 0; j < 2 + TT * K; ++j) acc[j] = 0.0;
+    const double ref = a.mp.lw_ref;
+    for (int tile = (int)blockIdx.x; tile < a.nb; tile += (int)gridDim.x) {
+        const int64_t j0 = (int64_t)tile * kTile + (int64_t)threadIdx.x * kPPT;
+        double lw[kPPT]; V xt[TT][kPPT];
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) lw[k] = 0.0;                                            // start_trace(): log_w_ = 0
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            typename Model::Rand r;
+            const V zero[4] = {V(0), V(0), V(0), V(0)};
+            Model::draw4(a.seed, a.pid0 + (uint64_t)j0, t, r);                                 // sample: distr(get_rng())  cpprob.hpp:72-74
+            Model::apply4(a.mp, t, r, zero, xt[t]);
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) lw[k] += Model::logw_of_z(a.mp, t, r.z[k]);         // observe(s): log_w_ += logpdf  state.cpp:212-223
+            store4_as(a.values + (int64_t)t * a.rs, j0, xt[t]);                               // predict: add_predict       state.hpp:312-327
+        }
+        if (tile == a.nb - 1) {                                                                // (workgroup-uniform: only the last tile has padding slots)
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k)
+                if (j0 + k >= a.n) lw[k] = -INFINITY;
+        }
+        store4(a.logw, j0, lw);                                                                // finish_trace()
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            // (branch-free: a padding slot's -inf is clamped to where the exponential underflows to exactly 0)
+            const double e = exp_nonpos(fmax(lw[k] - ref, -1000.0));
+            acc[0] += e; acc[1] = fma(e, e, acc[1]);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const double ex = e * xt[t][k];
+                acc[2 + t * K] += ex; acc[2 + t * K + 1] = fma(ex, xt[t][k], acc[2 + t * K + 1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2 + TT * K; j += 2) {
+        double ca = acc[j], cb = acc[j + 1];
+        if (j) __syncthreads();                                                                // s_ro is reused pair after pair
+        block_sum2(ca, cb, s_ro);
+        if (threadIdx.x == 0) { a.wpart[(size_t)j * gridDim.x + blockIdx.x] = ca; a.wpart[(size_t)(j + 1) * gridDim.x + blockIdx.x] = cb; }
+    }
+}
+
+// One workgroup: the partial rows of sis_bounded_kernel -> ctrl (reference, W, Q, ESS, evidence) and StatsPrinter's numbers.
+__global__ __launch_bounds__(kThreads) void sis_bounded_finish_kernel(const double* __restrict__ wpart, int G, int T, int K, double lw_ref, double n_pop,
+                                                                       StepCtrl* __restrict__ ctrl, double* __restrict__ stats, double* __restrict__ ess_trace,
+                                                                       int32_t* __restrict__ resampled, int normalise)
+{
+    constexpr int kCols = 2 + kMaxReadoutT * 2, kPer = kSisBoundedMaxGrid / kThreads;
+    __shared__ double s_col[kCols][kWaves];
+    const int n_col = 2 + T * K;
+    // every load of every column first (one memory round trip), then the sums in a fixed order: bitwise reproducible
+    double v[kCols][kPer];
+#pragma unroll
+    for (int j = 0; j < kCols; ++j)
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int g = i * kThreads + (int)threadIdx.x;
+            v[j][i] = (j < n_col && g < G) ? wpart[(size_t)j * G + g] : 0.0;
+        }
+#pragma unroll
+    for (int j = 0; j < kCols; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) s += v[j][i];
+        s = wave_sum(s);
+        if (lane_id() == 0) s_col[j][wave_id()] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot[kCols];
+#pragma unroll
+        for (int j = 0; j < kCols; ++j) { tot[j] = s_col[j][0]; for (int w = 1; w < kWaves; ++w) tot[j] += s_col[j][w]; }
+        const double W = tot[0], Q = tot[1];
+        ctrl->M = lw_ref; ctrl->W = W; ctrl->Q = Q; ctrl->ess = W * W / Q;
+        ctrl->log_z = lw_ref + log(W / n_pop);                                                 // SIS evidence: the mean weight
+        ctrl->n_resampled = 0; ctrl->do_resample = 0; ctrl->cdf_lo = 0.0; ctrl->w_local = W; ctrl->scale = 1.0; ctrl->lw_after = 0.0;
+        if (ess_trace) ess_trace[T - 1] = W * W / Q;
+        if (resampled) resampled[T - 1] = 0;
+        for (int t = 0; t < T; ++t) {
+            if (normalise) {
+                const double mean = tot[2 + t * K] / W;
+                stats[t * K] = mean;
+                stats[t * K + 1] = tot[2 + t * K + 1] / W - mean * mean;                      // raw_moment(2) - mean^2, empirical_distribution.hpp:78-81
+            } else { stats[t * K] = tot[2 + t * K]; stats[t * K + 1] = tot[2 + t * K + 1]; }
         }
     }
 }

@@ -25,6 +25,11 @@ struct ModelParams {
     const double* e_tab;                          // hmm: [T][4] exp(ll - max ll) for s = 0..2, then max ll
     // gaussian_2d_unk_mean: independent components, prior N(nd_mean[d], nd_sigma[d]); likelihood sigma / log_norm_lik as above
     double nd_mean[4], nd_sigma[4];
+    // Gaussian models: the log-weight as a polynomial in the standard-normal variate z_d of row d (x_d = mean_d + sigma_d z_d),
+    // logw = sum_d quad[d][0] z_d^2 + quad[d][1] z_d + quad[d][2], host-evaluated from the observes; lw_ref = the smallest grid
+    // point {k ln 2} above its maximum over z: a reference every particle's weight can be taken against BEFORE any is known
+    double quad[2][3];
+    double lw_ref;
 };
 
 // reference include/models/models.hpp:22-35 and src/models/gaussian.cpp:6-17 (same body,
@@ -51,6 +56,9 @@ struct ModelGaussian {
     {
         Rand r; draw4(seed, pid0, t, r); apply4(mp, t, r, prev, x);
     }
+    // the same weight from the variate: both observes' log-densities are one quadratic in z (models.hpp:32-33 expanded on the host)
+    static constexpr bool kBounded = true;
+    __device__ static __forceinline__ double logw_of_z(const ModelParams& mp, int /*d*/, double z) { return fma(fma(mp.quad[0][0], z, mp.quad[0][1]), z, mp.quad[0][2]); }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t mu, int /*t*/, const double* __restrict__ obs)
     {
         double lw = 0.0;                                                  // TraceInfer::log_w_ = 0     trace.hpp:59
@@ -89,6 +97,8 @@ struct ModelGaussianND {
     {
         Rand r; draw4(seed, pid0, d, r); apply4(mp, d, r, prev, x);
     }
+    static constexpr bool kBounded = true;
+    __device__ static __forceinline__ double logw_of_z(const ModelParams& mp, int d, double z) { return fma(fma(mp.quad[d][0], z, mp.quad[d][1]), z, mp.quad[d][2]); }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t mu, int d, const double* __restrict__ obs)
     {
         return normal_logpdf_scaled(obs[d], mu, mp.inv_sigma, mp.log_norm_lik);               // models.hpp:46-47, component d
@@ -125,6 +135,8 @@ struct ModelLinearGaussian1D {
     {
         Rand r; draw4(seed, pid0, t, r); apply4(mp, t, r, prev, x);
     }
+    static constexpr bool kBounded = false;
+    __device__ static __forceinline__ double logw_of_z(const ModelParams&, int, double) { return 0.0; }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t x, int t, const double* __restrict__ obs)
     {
         return normal_logpdf_hoisted(obs[t], x, 1.0, mp.log_norm_unit);   // :76-77
@@ -176,6 +188,8 @@ struct ModelHmm3 {
             }
         }
     }
+    static constexpr bool kBounded = false;
+    __device__ static __forceinline__ double logw_of_z(const ModelParams&, int, double) { return 0.0; }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t s, int t, const double* __restrict__ /*obs*/)
     {
         // log N(y_t; state_mean[s], 1) from the per-run table: three values per step    :130-131,138-139

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "cpprob/detail/fastmath.hpp"
+
 namespace cph {
 
 struct u32x4 { uint32_t x, y, z, w; };
@@ -65,9 +67,10 @@ __device__ __forceinline__ void box_muller(const u32x4 r, double& x, double& y)
     const uint64_t v2 = (uint64_t)r.z ^ ((uint64_t)r.w << 21);
     const double u = kTwoPowM53 + (double)v1 * kTwoPowM53;
     const double w = (kTwoPowM53 * 2.0) + (double)v2 * (kTwoPowM53 * 2.0);
-    const double s = sqrt(-2.0 * log(u));
+    // (range-specific forms of log / sincospi, faithfully rounded like the library's: cpprob/detail/fastmath.hpp)
+    const double s = sqrt(-2.0 * log01(u));
     double sn, cs;
-    sincospi(w, &sn, &cs);
+    sincospi02(w, sn, cs);
     x = s * sn;
     y = s * cs;
 }

@@ -104,7 +104,7 @@ typedef struct cpprob_hip_summary {
     double log_evidence;  /* log Z-hat: logsumexp(logw) - log N for SIS; SMC product estimate     */
     double ess_final;     /* (sum W_i^2)^-1 of the final weights, thesis p.37                      */
     double log_norm;      /* logsumexp of the final log-weights (EmpiricalDistribution :117-123)  */
-    double max_logw;      /* reference of the final weights: their max, or (continuous-weight models)
+    double max_logw;      /* reference of the final weights: their max, or (continuous-weight models; bounded-weight SIS: an upper bound of it)
                              the smallest multiple of ln 2 above it; sums are relative to exp(max_logw) */
     int32_t n_predict;    /* predict hits per trace (T)                                           */
     int32_t stats_per_predict; /* 2 for real predicts (mean, variance); k for int predicts (P(x=s)) */
