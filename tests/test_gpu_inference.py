@@ -272,6 +272,38 @@ def test_smc_lgssm_vs_kalman(engine, golden_dir):
     assert np.abs(st[-10:, 0] - z["lgssm100_smooth_mean"][-10:]).max() < 3e-2
 
 
+def test_smc_hmm128_config5_per_gpu_size_vs_forward_backward(engine, golden_dir):
+    """BASELINE.json configs[4] at its per-GPU size: hmm<128>, FULL length T = 128, resampling when ESS < N/2, 1.25e7 particles
+    (10^8 over 8 GPUs), against the exact forward-backward posterior and evidence."""
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    n = 12_500_000
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, z["hmm128"], n, seed=12345, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=0.5)
+    engine.run()
+    st, s = engine.stats(), engine.summary()
+    ess, res = engine.step_trace()
+    assert len(z["hmm128"]) == 128 and 0 < s["n_resampled"] < 127 and int(res.sum()) == s["n_resampled"]
+    assert np.all(ess[res == 1] < 0.5 * n) and np.all(ess[:-1][res[:-1] == 0] >= 0.5 * n)      # the trigger, thesis p.37
+    assert abs(s["log_evidence"] - float(z["hmm128_logz"])) < 5e-3
+    np.testing.assert_allclose(st.sum(axis=1), 1.0, rtol=1e-12)
+    assert np.abs(st[-16:] - z["hmm128_smooth"][-16:]).max() < 3e-3       # the recent past is barely degenerate
+    assert np.abs(st - z["hmm128_smooth"]).max() < 5e-2                    # early marginals rest on few surviving lineages
+
+
+@pytest.mark.parametrize("n", [1_250_000, 10_000_000])
+def test_smc_lgssm_config4_sizes_vs_kalman(engine, golden_dir, n):
+    """BASELINE.json configs[3]: linear_gaussian_1d<100>, T = 100, at its per-GPU size (1.25e6 = 10^7 / 8) and at the whole
+    10^7 on one GPU, against the Kalman filter / RTS smoother."""
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, z["lgssm100"], n, seed=12345, ess_threshold=0.5)
+    engine.run()
+    st, s = engine.stats(), engine.summary()
+    tol = 5e-3 if n < 5_000_000 else 2.5e-3
+    assert abs(st[-1, 0] - z["lgssm100_smooth_mean"][-1]) < tol and abs(st[-1, 1] - z["lgssm100_smooth_var"][-1]) < tol
+    assert abs(s["log_evidence"] - float(z["lgssm100_logz"])) < (5e-2 if n < 5_000_000 else 2e-2)        # sd of the estimator ~ 1.5e-2 at 1.25e6
+    assert np.abs(st[-10:, 0] - z["lgssm100_smooth_mean"][-10:]).max() < 3e-2
+    assert 0 < s["n_resampled"] < 99
+
+
 def test_run_index_decorrelates_and_is_reproducible(engine, golden_dir):
     obs = _obs(golden_dir, "hmm16")
     engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 50000, seed=1)
@@ -666,8 +698,9 @@ def test_back_to_back_runs_are_bitwise_reproducible(engine, golden_dir, n):
         assert not np.array_equal(ref[0][0], ref[1][0])
 
 
-@pytest.mark.parametrize("scope", ["auto", "global", "exchange"])
-def test_bench_two_ranks_on_one_gpu(scope):
+@pytest.mark.parametrize("scope,workload", [("auto", "hmm16_smc"), ("global", "hmm16_smc"), ("exchange", "hmm16_smc"), ("exchange", "hmm128_smc_ess"),
+                                            ("exchange", "lgssm100_smc")])
+def test_bench_two_ranks_on_one_gpu(scope, workload):
     """The N > 1 path of bench.py end to end -- torchrun, one process per rank, IslandBatch / run_joint / run_exchange --
     with both ranks sharing cuda:0 and the collectives going through gloo (test hook CPPROB_DIST_BACKEND / CPPROB_FORCE_DEVICE:
     RCCL refuses two ranks on one device).  Everything but the transport is the production code."""
@@ -681,7 +714,8 @@ def test_bench_two_ranks_on_one_gpu(scope):
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--particles", "200000", "--scope", scope, "--no-cpu-baseline"]
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--particles", "200000", "--scope", scope, "--no-cpu-baseline",
+               "--workload", workload, "--no-extras"]
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
         if p.returncode == 0:
             break
@@ -690,5 +724,11 @@ def test_bench_two_ranks_on_one_gpu(scope):
     assert len(lines) == 1                                          # rank 0 prints the one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["n_global"] == 400000 and d["value"] > 0
-    assert d["posterior_max_abs_err_vs_exact"] < 0.01 and abs(d["log_evidence"] + 26.326) < 0.02
+    if workload == "hmm16_smc":
+        assert d["posterior_max_abs_err_vs_exact"] < 0.01 and abs(d["log_evidence"] + 26.326) < 0.02
+        assert d["config"]["scope"] == ("exchange" if scope in ("auto", "exchange") else scope)      # exact global resampling is the default
+    else:
+        z = np.load(os.path.join(root, "tests", "golden", "observations.npz"))
+        key = "hmm128_logz" if workload == "hmm128_smc_ess" else "lgssm100_logz"
+        assert abs(d["log_evidence"] - float(z[key])) < 0.05 and 0 < d["n_resampled"] < len(z[key.replace("_logz", "")]) - 1
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
