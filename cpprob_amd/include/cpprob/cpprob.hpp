@@ -84,9 +84,8 @@ CPPROB_HD void predict(T&& x)
 #if defined(__HIP_DEVICE_COMPILE__)
     device::predict_impl(x);
 #else
-    // the reference derives the address from the call stack (utils.cpp:71-128); every hit of an
-    // address-less predict shares one synthetic address here
-    detail::host_predict(x, std::string("<predict>"));
+    // the reference derives the address from the call stack (utils.cpp:71-128): one per textual call site
+    detail::host_predict(x, detail::recorder() ? detail::call_site_address() : std::string());
 #endif
 }
 

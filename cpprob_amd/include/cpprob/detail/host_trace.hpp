@@ -4,7 +4,11 @@
 // the host: the particle loop lives on the device.
 #ifndef CPPROB_COMPAT_DETAIL_HOST_TRACE_HPP
 #define CPPROB_COMPAT_DETAIL_HOST_TRACE_HPP
+#include <cxxabi.h>
+#include <execinfo.h>
+
 #include <cstddef>
+#include <cstdlib>
 #include <random>
 #include <string>
 #include <type_traits>
@@ -37,6 +41,50 @@ struct TraceStructure {
 private:
     std::unordered_map<std::string, std::size_t> ids_;
 };
+
+// Address of a statement that was given none: the chain of call sites from the model's entry function down to the statement, as
+// the reference derives it (src/cpprob/utils.cpp:71-128): walk the call stack, drop the innermost frames that belong to namespace
+// cpprob, keep everything up to the outermost frame of namespace models, and print "[outer+0xoff ... inner+0xoff]" with demangled
+// names -- so two textual call sites get two addresses, and a loop's iterations share one (stats_printer.hpp:106-118 then tells the
+// hits of one address apart by their order).  Host only: the device ignores addresses (hit k of a trace is column k).
+inline std::string frame_name(const char* symbol_line)
+{
+    const std::string s(symbol_line);                     // "object(mangled+0xoff) [0xaddr]"
+    const std::size_t open = s.find_last_of('('), close = s.find_last_of(')'), plus = s.find_last_of('+');
+    if (open == std::string::npos || close == std::string::npos || close < open) return s;
+    const std::size_t name_end = (plus != std::string::npos && plus > open && plus < close) ? plus : close;
+    const std::string mangled = s.substr(open + 1, name_end - open - 1);
+    int status = 1;
+    char* dem = mangled.empty() ? nullptr : abi::__cxa_demangle(mangled.c_str(), nullptr, nullptr, &status);
+    std::string out = (status == 0 && dem) ? std::string(dem) : mangled;
+    std::free(dem);
+    return out + s.substr(name_end, close - name_end);   // + "+0xoff": the return address inside the function = the call site
+}
+inline bool in_namespace(const std::string& frame, const std::string& ns)
+{
+    // a demangled name mentions its namespace at the start, or after the return type's space (templates carry their return type)
+    if (frame.compare(0, ns.size(), ns) == 0) return true;
+    for (std::size_t p = frame.find(" " + ns); p != std::string::npos; p = frame.find(" " + ns, p + 1))
+        if (p == 0 || frame[p - 1] != ',') return true;
+    return false;
+}
+inline std::string call_site_address()
+{
+    void* frames[100];
+    const int n = backtrace(frames, 100);
+    char** lines = backtrace_symbols(frames, n);
+    if (!lines) return "<predict>";
+    std::vector<std::string> names;
+    for (int i = 0; i < n; ++i) names.push_back(frame_name(lines[i]));
+    std::free(lines);
+    int inner = 0, outer = n - 1;
+    while (inner < n && in_namespace(names[(std::size_t)inner], "cpprob::")) ++inner;
+    while (outer >= 0 && !in_namespace(names[(std::size_t)outer], "models::")) --outer;
+    if (inner >= n || outer < 0) return "<predict>";       // (the model is not in namespace models: one shared address)
+    std::string out = "[";
+    for (int i = outer; i >= inner; --i) { if (i != outer) out += ' '; out += names[(std::size_t)i]; }
+    return out + "]";
+}
 
 inline TraceStructure*& recorder() { static thread_local TraceStructure* r = nullptr; return r; }
 inline std::mt19937& host_rng() { static thread_local std::mt19937 rng{20260101u}; return rng; }
