@@ -335,14 +335,14 @@ def main():
     # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
     # of this same command and committed with their correction notes; bench.py itself cannot run the profiler
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if args.workload == "hmm16_smc" and n == 1_000_000 and os.path.exists(pmc):
         with open(pmc) as f:
             for kname, rec in json.load(f)["kernels"].items():
-                if "smc_step_kernel" in kname:
+                if "smc_step_counts_kernel" in kname and "false, false" in kname:       # the 15 launches per run that are not the last step
                     traffic = rec["hbm_bytes_per_launch_corrected"]
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)" if traffic else None, "algorithmic_bytes_per_unit": bytes_per_unit, "units_per_launch": n, "avg_launch_us": avg_s * 1e6,
+                "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)" if traffic else None, "algorithmic_bytes_per_unit": bytes_per_unit, "units_per_launch": n, "avg_launch_us": avg_s * 1e6,
                 "launches": int(dom_calls),
                 "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]}}
 
