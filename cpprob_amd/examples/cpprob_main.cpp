@@ -145,6 +145,7 @@ int main(int argc, char** argv)
         if (a.model == "gaussian_2d_unk_mean") return execute(models::gaussian_2d_unk_mean<double>, a);       // observes: "[y0 y1]"
         if (a.model == "gauss_functor") return execute(models::GaussFunctor<double>{}, a);
         if (a.model == "gaussian_by_rejection") return execute(models::gaussian_by_rejection<double>, a);
+        if (a.model == "all_distr") return execute(models::all_distr<int>, a);                                   // src/models/models.cpp:13-47; observes: any two ints
         std::cerr << "unknown model " << a.model << std::endl;
         return EXIT_FAILURE;
     } catch (const std::exception& e) {

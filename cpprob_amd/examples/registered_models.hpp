@@ -17,5 +17,6 @@ extern template void hmm<128>(const std::array<double, 128>&);
 extern template void poisson_rate<double>(int, int);
 extern template void gaussian_2d_unk_mean<double>(std::vector<double>);
 extern template void gaussian_by_rejection<double>(double, double);
+extern template void all_distr<int>(int, int);
 }
 #endif

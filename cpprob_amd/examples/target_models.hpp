@@ -143,5 +143,38 @@ void poisson_rate(const int k1, const int k2)
     cpprob::predict(rate, "Rate");
 }
 
+// One statement triple -- sample, address-less predict, observe of the sampled value -- per distribution of the library
+// (restates the statement sequence of reference src/models/models.cpp:13-47; the two ints are unused there too; a template here so that
+// host programs link the model library's instantiation: registered_models.hpp).  Every predict gets
+// its address from its call site; the last triple is vector-valued (four independent normal components).
+template <class Int = int>
+void all_distr(Int, Int)
+{
+    boost::random::normal_distribution<> normal{1, 2};
+    const auto normal_val = cpprob::sample(normal, true);
+    cpprob::predict(normal_val);
+    cpprob::observe(normal, normal_val);
+
+    boost::random::uniform_smallint<> small{2, 7};
+    const auto small_val = cpprob::sample(small, true);
+    cpprob::predict(small_val);
+    cpprob::observe(small, small_val);
+
+    boost::random::uniform_real_distribution<> unif{2, 9.5};
+    const auto unif_val = cpprob::sample(unif, true);
+    cpprob::predict(unif_val);
+    cpprob::observe(unif, unif_val);
+
+    boost::random::poisson_distribution<> poisson(0.8);
+    const auto poisson_val = cpprob::sample(poisson, true);
+    cpprob::predict(poisson_val);
+    cpprob::observe(poisson, poisson_val);
+
+    cpprob::multivariate_normal_distribution<> multi{{1, 2, 3, 4}, {2, 1, 5, 3}};
+    const auto multi_val = cpprob::sample(multi, true);
+    cpprob::predict(multi_val);
+    cpprob::observe(multi, multi_val);
+}
+
 }  // namespace models
 #endif

@@ -21,6 +21,7 @@
 #include <boost/random/uniform_real_distribution.hpp>
 #include <boost/random/uniform_smallint.hpp>
 
+#include "cpprob/detail/device_vector.hpp"
 #include "cpprob/detail/rng.hpp"
 #include "cpprob/distributions/utils_distributions.hpp"
 
@@ -99,7 +100,27 @@ template <class Distribution>
 __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(Distribution& distr)
 {
     using R = typename std::decay_t<Distribution>::result_type;
-    if constexpr (!std::is_arithmetic<R>::value) {
+    if constexpr (is_dev_mvn<std::decay_t<Distribution>>::value) {
+        // vector-valued sample (multivariate_normal.hpp:268-274): the components draw one after the other, each its own trace slot
+        using T = typename R::value_type;
+        LaneCtx& c = lane_ctx();
+        R value;
+        for (std::size_t i = 0; i < distr.size(); ++i) {
+            const uint32_t j = c.n_sample++;
+            T v = T();
+            if (!c.done) {
+                if (j < c.n_stored && j < c.trace_cap) v = from_raw<T>(c.trace_in[(int64_t)j * c.ld]);
+                else v = static_cast<T>(distr.mean_at(i) + distr.sigma_at(i) * cph::draw_std_normal(c.seed, c.pid, (uint64_t)j));
+                if (c.trace_out) {
+                    if (j < c.trace_cap) c.trace_out[(int64_t)j * c.ld] = to_raw<T>(v);
+                    else if (c.overflow) *c.overflow = 1;
+                }
+                c.n_recorded = j + 1;
+            }
+            value.push_back(v);
+        }
+        return value;
+    } else if constexpr (!std::is_arithmetic<R>::value) {
         // vector-valued statements own host containers: they reach the device through built-in kernels only
         // (cpprob::inference refuses to launch this path for them, host_engine.hpp)
         __builtin_trap();
@@ -122,8 +143,15 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
 template <class Distribution, class X>
 __device__ inline void observe_impl(Distribution& distr, const X& x)
 {
-    if constexpr (!std::is_arithmetic<X>::value) {
-        __builtin_trap();                                           // vector-valued: built-in kernels only (see sample_impl)
+    if constexpr (is_dev_mvn<std::decay_t<Distribution>>::value) {
+        // ONE observe statement whose log-density is the sum over the components (utils_multivariate_normal.hpp:20-33)
+        LaneCtx& c = lane_ctx();
+        const int32_t m = (int32_t)c.n_observe++;
+        if (c.done || m < c.first_observe) return;
+        c.log_w += logpdf<std::decay_t<Distribution>>()(distr, x);
+        if (m == c.stop_after) c.done = 1;
+    } else if constexpr (!std::is_arithmetic<X>::value) {
+        __builtin_trap();                                           // heap-backed vector types: compile the model's device view (cpprob/gpu.hpp)
     } else {
         LaneCtx& c = lane_ctx();
         const int32_t m = (int32_t)c.n_observe++;
@@ -153,8 +181,18 @@ __device__ inline void predict_impl(const T& x)
             if (k < c.pred_real_cap) c.pred_real[(int64_t)k * c.ld] = static_cast<double>(x);
             else if (c.overflow) *c.overflow = 2;
         }
+    } else if constexpr (is_dev_ndarray<V>::value) {                    // state.hpp:330-337: an NDArray goes to the real list; one column per component
+        LaneCtx& c = lane_ctx();
+        if (c.done) return;
+        for (std::size_t i = 0; i < x.size(); ++i) {
+            const uint32_t k = c.n_pred_real++;
+            if (c.pred_real) {
+                if (k < c.pred_real_cap) c.pred_real[(int64_t)k * c.ld] = static_cast<double>(x[i]);
+                else if (c.overflow) *c.overflow = 2;
+            }
+        }
     } else {
-        __builtin_trap();                                               // vector-valued: built-in kernels only (see sample_impl)
+        __builtin_trap();                                               // heap-backed vector types: compile the model's device view (cpprob/gpu.hpp)
     }
 }
 

@@ -319,9 +319,9 @@ void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>
     const Entry* e = find_entry(key);
     if (!e) throw std::runtime_error("cpprob::inference: this model has no device code: compile its source with hipcc and add "
                                      "CPPROB_REGISTER_MODEL(<model>) (or CPPROB_REGISTER_BUILTIN) -- there is no CPU fallback");
-    if (st.vector_statements && e->builtin_model < 0)
-        throw std::runtime_error("cpprob::inference: vector-valued statements (multivariate_normal_distribution / NDArray) run through built-in "
-                                 "kernels only (CPPROB_REGISTER_BUILTIN): std::vector cannot live in device code");
+    if (st.vector_statements && e->builtin_model < 0 && !e->generic_vectors)
+        throw std::runtime_error("cpprob::inference: vector-valued statements (multivariate_normal_distribution / NDArray) need the model's device "
+                                 "view (CPPROB_REGISTER_MODEL_VIEW, cpprob/device_view_begin.hpp) or a built-in kernel: std::vector cannot live in device code");
     const Options& opt = options();
     Result& res = last_result();
     res = Result();
@@ -331,7 +331,8 @@ void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>
         if (e->builtin_model < 0) throw std::runtime_error("cpprob::inference: several GPUs (cpprob::gpu::options().devices) serve built-in models only");
         run_builtin_group(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
     }
-    else if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic || st.vector_statements)) run_builtin(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
+    else if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic || (st.vector_statements && !e->generic_vectors)))
+        run_builtin(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
     else if (e->generic) e->generic(algorithm, &obs, n, st, opt, res, store);
     else throw std::runtime_error("cpprob::inference: registry entry without a launcher");
     if (opt.dump) dump_posterior(file, st, hs, opt.dump_max_particles);      // finish_trace() x n + finish_infer()

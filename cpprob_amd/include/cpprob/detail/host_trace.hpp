@@ -92,6 +92,8 @@ inline std::mt19937& host_rng() { static thread_local std::mt19937 rng{20260101u
 // variates a value consumes: one per component
 template <class T> std::size_t width_of(const T&) { return 1; }
 template <class T> std::size_t width_of(const NDArray<T>& x) { return x.size(); }
+template <class V> auto width_of_sized(const V& x, int) -> decltype(x.size()) { return x.size(); }
+template <class V> std::size_t width_of_sized(const V&, long) { return 1; }
 
 template <class Distribution>
 auto host_sample(Distribution& distr)
@@ -99,7 +101,7 @@ auto host_sample(Distribution& distr)
     std::decay_t<Distribution> copy = distr;
     auto value = copy(host_rng());                      // cpprob.hpp:33-35: distr(get_rng())
     if (TraceStructure* r = recorder()) {
-        r->n_sample += width_of(value);
+        r->n_sample += std::is_arithmetic<decltype(value)>::value ? 1 : width_of_sized(value, 0);
         if (!std::is_arithmetic<decltype(value)>::value) r->vector_statements = true;
     }
     return value;
@@ -107,8 +109,17 @@ auto host_sample(Distribution& distr)
 
 inline void host_observe() { if (recorder()) ++recorder()->n_observe; }
 
+template <class V>
+auto host_predict_dispatch(const V& x, const std::string& addr, int) -> decltype((void)x.size(), (void)x.begin(), void())
+{
+    TraceStructure* r = recorder();                                                          // (a device-view NDArray: same bookkeeping as NDArray)
+    if (!r) return;
+    r->real_ids.push_back(r->id_of(addr));
+    r->real_width.push_back(x.size());
+    r->vector_statements = true;
+}
 template <class T>
-void host_predict(const T&, const std::string& addr)
+void host_predict_dispatch(const T&, const std::string& addr, long)
 {
     TraceStructure* r = recorder();
     if (!r) return;
@@ -117,6 +128,8 @@ void host_predict(const T&, const std::string& addr)
     else if (std::is_floating_point<V>::value) { r->real_ids.push_back(r->id_of(addr)); r->real_width.push_back(1); }   // state.hpp:320-326
     else { r->id_of(addr); ++r->n_other_predicts; }
 }
+template <class T>
+void host_predict(const T& x, const std::string& addr) { host_predict_dispatch(x, addr, 0); }
 template <class T>
 void host_predict(const NDArray<T>& x, const std::string& addr)                            // state.hpp:330-337: NDArray -> the real list
 {

@@ -35,6 +35,7 @@ struct Entry {
     std::string name;
     int builtin_model = -1;             // >= 0: CPPROB_HIP_MODEL_* id
     GenericLauncher generic = nullptr;
+    bool generic_vectors = false;       // the generic launcher runs the model's device view: vector-valued statements included
 };
 
 struct Key {
@@ -59,7 +60,7 @@ inline bool add_entry(const Key& k, const Entry& e)
     Entry& dst = table()[k];
     if (dst.name.empty()) dst.name = e.name;
     if (e.builtin_model >= 0) dst.builtin_model = e.builtin_model;
-    if (e.generic) dst.generic = e.generic;
+    if (e.generic && (e.generic_vectors || !dst.generic_vectors)) { dst.generic = e.generic; dst.generic_vectors = e.generic_vectors; }
     return true;
 }
 

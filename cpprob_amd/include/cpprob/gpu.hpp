@@ -32,13 +32,19 @@
 
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
 #include <vector>
 
+#include <boost/math/distributions/normal.hpp>
+
 #include "cpprob/cpprob.hpp"
+#include "cpprob/detail/device_vector.hpp"
+#include "cpprob/distributions/multivariate_normal.hpp"
+#include "cpprob/ndarray.hpp"
 
 namespace cpprob {
 namespace gpu {
@@ -132,7 +138,7 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
     hip_check(hipSetDevice(opt.device), "hipSetDevice");
     hipStream_t stream = static_cast<hipStream_t>(cpprob_hip_stream(ctx.get()));
     const int64_t ld = (int64_t)n;
-    const size_t n_real = st.real_ids.size(), n_int = st.int_ids.size();
+    const size_t n_real = st.real_rows(), n_int = st.int_ids.size();        // a vector-valued real predict owns one column per component
     const int T = (int)st.n_observe;
     const bool smc = algorithm == StateType::smc;
 
@@ -196,17 +202,22 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
     res.n_particles = n; res.log_evidence = log_z; res.log_norm = o3[1]; res.ess = o3[2]; res.n_resampled = n_resampled; res.used_builtin = false;
     fill_predict_names(res, st);
     res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();   // (the logsumexp above synchronised)
-    for (size_t k = 0; k < n_real; ++k) {
-        double o4[4];
-        ctx.check(cpprob_hip_weighted_moments(ctx.get(), d_real.p + k * n, logw[cur], n, o4), "cpprob_hip_weighted_moments");
-        res.predicts[k].mean = o4[0]; res.predicts[k].variance = o4[1];
+    for (size_t k = 0, row = 0; k < st.real_ids.size(); ++k) {
+        PredictStats& p = res.predicts[k];
+        for (size_t d = 0; d < st.real_width[k]; ++d, ++row) {
+            double o4[4];
+            ctx.check(cpprob_hip_weighted_moments(ctx.get(), d_real.p + row * n, logw[cur], n, o4), "cpprob_hip_weighted_moments");
+            p.mean_nd.push_back(o4[0]); p.variance_nd.push_back(o4[1]);
+        }
+        p.mean = p.mean_nd[0]; p.variance = p.variance_nd[0];
     }
+    const size_t n_real_hits = st.real_ids.size();
     for (size_t k = 0; k < n_int; ++k) {
         double h[8];
         ctx.check(cpprob_hip_weighted_hist(ctx.get(), d_int.p + k * n, logw[cur], n, 8, h), "cpprob_hip_weighted_hist");
         int top = 8;
         while (top > 1 && h[top - 1] == 0.0) --top;
-        res.predicts[n_real + k].probabilities.assign(h, h + top);
+        res.predicts[n_real_hits + k].probabilities.assign(h, h + top);
     }
     if (store) {
         store->n = n;
@@ -237,6 +248,30 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
                              "(data-dependent loop, e.g. rejection sampling, that rarely terminates); use StateType::sis for this model");
 }
 
+// Device view (cpprob/detail/device_vector.hpp): the launcher receives the HOST function's observes tuple (std::vector elements) and
+// hands the device the view's tuple (fixed-capacity elements), converted element by element.
+template <class To, class From, std::size_t... I>
+To convert_observes(const From& from, std::index_sequence<I...>)
+{
+    return To(typename std::tuple_element<I, To>::type(std::get<I>(from))...);
+}
+template <class HostTuple, class Caller>
+void generic_launcher_view(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
+                           Result& res, HostStore* store)
+{
+    using DevTuple = typename Caller::observes_t;
+    static_assert(std::tuple_size<HostTuple>::value == std::tuple_size<DevTuple>::value, "host model and device view take the same number of arguments");
+    const DevTuple dev = convert_observes<DevTuple>(*static_cast<const HostTuple*>(observes_v), std::make_index_sequence<std::tuple_size<DevTuple>::value>{});
+    generic_launcher<Caller>(algorithm, &dev, n, st, opt, res, store);
+}
+
+template <class HostFP, HostFP H, class DevFP, DevFP D>
+bool register_model_view(const char* name)
+{
+    Entry e; e.name = name; e.generic = &generic_launcher_view<tuple_observes_t<HostFP>, FunctionCaller<DevFP, D>>; e.generic_vectors = true;
+    return add_entry(Key{reinterpret_cast<const void*>(H), 0}, e);
+}
+
 template <class FP, FP F>
 bool register_model(const char* name)
 {
@@ -257,6 +292,9 @@ bool register_functor(const char* name)
 
 #define CPPROB_REGISTER_MODEL(fn) \
     static const bool CPPROB_PP_CAT(cpprob_reg_model_, __LINE__) = ::cpprob::gpu::register_model<decltype(&fn), &fn>(#fn)
+// host function, its instantiation inside namespace cpprob_device_view (see cpprob/device_view_begin.hpp)
+#define CPPROB_REGISTER_MODEL_VIEW(host_fn, device_fn) \
+    static const bool CPPROB_PP_CAT(cpprob_reg_view_, __LINE__) = ::cpprob::gpu::register_model_view<decltype(&host_fn), &host_fn, decltype(&device_fn), &device_fn>(#host_fn)
 #define CPPROB_REGISTER_FUNCTOR(type) \
     static const bool CPPROB_PP_CAT(cpprob_reg_functor_, __LINE__) = ::cpprob::gpu::register_functor<type>(#type)
 

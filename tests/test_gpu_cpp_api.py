@@ -260,3 +260,54 @@ def test_cpp_host_shards_one_population_over_several_ranks(tmp_path):
     assert abs(two["log_evidence"] - one["log_evidence"]) < 1e-9
     for a, b in zip(one["predicts"], two["predicts"]):
         assert abs(a["mean"] - b["mean"]) < 1e-3 and abs(a["variance"] - b["variance"]) < 1e-3
+
+
+def test_vector_statements_run_through_the_generic_device_path(tmp_path):
+    """the model's DEVICE VIEW (cpprob/device_view_begin.hpp: the same source compiled with fixed-capacity
+    containers) carries vector-valued sample / observe / predict through model_kernel -- per-particle parity with the oracle and
+    with the built-in kernel of the same model."""
+    n = 60000
+    args = ["--model", "gaussian_2d_unk_mean", "--sis", "--observes", "[3 4]", "--n_samples", n, "--seed", 9, "--json"]
+    gen, _, _ = run_main(tmp_path, *args, "--generic", "--generated_file", "gen")
+    blt, _, _ = run_main(tmp_path, *args, "--generated_file", "blt")
+    assert not gen["builtin"] and blt["builtin"]
+    ov, olw = O.sis(O.MODEL_GAUSSIAN_2D_UNKNOWN_MEAN, [3.0, 4.0], n, 9)
+    for name in ("gen", "blt"):
+        lines = open(str(tmp_path / (name + "_sis.real"))).read().splitlines()
+        assert len(lines) == n
+        vals = np.array([[float(x) for x in l[l.index("[", 3) + 1: l.index("]")].split()] for l in lines])     # ([(0 [v0 v1])] logw)
+        lw = np.array([float(l.rsplit("]", 1)[1].strip().rstrip(")")) for l in lines])
+        np.testing.assert_allclose(vals.T, ov, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(lw, olw, rtol=1e-10, atol=1e-10)
+    for a, b in zip(gen["predicts"], blt["predicts"]):
+        np.testing.assert_allclose(a["mean_nd"], b["mean_nd"], rtol=1e-9)
+        np.testing.assert_allclose(a["variance_nd"], b["variance_nd"], rtol=1e-8)
+    assert abs(gen["log_evidence"] - blt["log_evidence"]) < 1e-9
+
+
+def test_all_distr_model_and_addressless_predicts(tmp_path):
+    """the mixed-distribution model of src/models/models.cpp:13-47 (normal, uniform_smallint, uniform_real,
+    poisson, multivariate normal; every predict WITHOUT an address) through the generic path.  Addresses come from the call sites
+    (src/cpprob/utils.cpp:71-128): five predicts -> five distinct ids; the posterior is each prior reweighted by its own density."""
+    n = 400000
+    res, _, _ = run_main(tmp_path, "--model", "all_distr", "--sis", "--observes", "0 0", "--n_samples", n, "--seed", 6, "--json", "--generated_file", "ad")
+    assert not res["builtin"]
+    ids = open(str(tmp_path / "ad_sis.ids")).read().splitlines()
+    assert len(ids) == 5 and len(set(ids)) == 5 and all(a.startswith("[") and "all_distr" in a for a in ids)
+    reals = [p for p in res["predicts"] if "mean" in p]
+    ints = [p for p in res["predicts"] if "p" in p]
+    assert len(reals) == 3 and len(ints) == 2
+    # weight = product of the densities at the sampled values, which factorises: each marginal is its prior times its own density
+    # normal(1, 2) reweighted by N(x; 1, 2): N(1, sd 2/sqrt 2)
+    assert abs(reals[0]["mean"] - 1.0) < 0.02 and abs(reals[0]["variance"] - 2.0) < 0.03
+    # uniform_real(2, 9.5) reweighted by a constant: unchanged
+    assert abs(reals[1]["mean"] - 5.75) < 0.02 and abs(reals[1]["variance"] - 7.5 ** 2 / 12) < 0.05
+    # 4 independent normals (means 1..4, sd 2,1,5,3) each reweighted by its own density: variance halves
+    np.testing.assert_allclose(reals[2]["mean_nd"], [1, 2, 3, 4], atol=0.05)
+    np.testing.assert_allclose(reals[2]["variance_nd"], [2.0, 0.5, 12.5, 4.5], rtol=0.03)
+    # uniform_smallint{2..7} reweighted by a constant: uniform over 2..7
+    np.testing.assert_allclose(ints[0]["p"][2:8], [1 / 6.0] * 6, atol=5e-3)
+    # poisson(0.8) reweighted by its own pmf: p(k) ~ pmf(k)^2
+    from scipy.stats import poisson
+    pm = poisson.pmf(np.arange(8), 0.8) ** 2
+    np.testing.assert_allclose(ints[1]["p"][:6], (pm / pm.sum())[:6], atol=5e-3)
