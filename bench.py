@@ -392,6 +392,27 @@ def main():
         except Exception as e:
             out["exchange_world1"] = {"error": str(e)}
 
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "hmm16_smc":
+        # secondary: the SAME workload through the unchanged-model path -- models::hmm<16> as written against the CPProb statement API,
+        # compiled for the device (CPPROB_REGISTER_MODEL) and called through cpprob::inference from the C++14 host (cpprob_main --generic):
+        # trace replay, one launch of the model body per observe, device-side bookkeeping in between
+        try:
+            exe = os.path.join(ROOT, "cpprob_amd", "bin", "cpprob_main")
+            obs_s = "[" + " ".join(repr(float(x)) for x in spec["obs"]) + "]"
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                cmd = [exe, "--model_folder", td, "--model", "hmm16", "--smc", "--observes", obs_s, "--n_samples", str(n), "--seed", str(args.seed),
+                       "--ess_threshold", "2.0", "--generic", "--no_dump", "--json", "--repeat", "6"]
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            gj = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")][-1]
+            gst = np.array([p_["p"] for p_ in gj["predicts"]])
+            out["generic_path"] = {"ms_per_run": gj["run_seconds"] * 1e3, "particles_per_sec": n / gj["run_seconds"], "replay_window": gj["replay_window"],
+                                   "posterior_max_abs_err_vs_exact": float(np.abs(gst - spec["exact"]).max()),
+                                   "vs_fused_kernels": gj["run_seconds"] * 1e3 / (dt / args.steps * 1e3),
+                                   "note": "cpprob_main --generic --repeat 6 (last run; excludes allocation and the final per-column read-out)"}
+        except Exception as e:
+            out["generic_path"] = {"error": str(e)}
+
     if rank == 0 and world == 1 and not args.no_extras:
         # error bars: five run seeds of the headline configuration against the exact posterior
         eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])

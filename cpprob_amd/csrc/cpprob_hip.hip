@@ -110,6 +110,7 @@ struct cpprob_hip_ctx {
     Partial* d_bb_part = nullptr; double* d_bb_bc = nullptr; double* d_bb_bf = nullptr; double* d_bb_wrel = nullptr; void* d_bb_col = nullptr;
     StepCtrl* d_bb_ctrl = nullptr; size_t bb_cap_nb = 0;
     double* d_bb_stats_part = nullptr; double* d_bb_stats = nullptr; double* d_bb_cdf = nullptr; size_t bb_cdf_cap = 0;
+    int32_t* d_bb_first = nullptr; size_t bb_first_cap = 0;
 
     // optional per-kernel-class timing
     bool profile = false;
@@ -568,7 +569,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     dfree(c->d_ctrl); dfree(c->d_local_totals);
     dfree(c->d_send_src); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
-    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf);
+    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_first);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1472,6 +1473,31 @@ int cpprob_hip_smc_bookkeep(cpprob_hip_ctx* c, int32_t kind, const double* d_log
             else hipLaunchKernelGGL(resample_kernel<RS_STRATIFIED>, dim3(nb), dim3(kThreads), 0, c->stream, a);
         }
     }
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_lineage_gather(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const void* d_cols, int32_t is_int,
+                              const int32_t* h_gen, int32_t H, void* d_out)
+{
+    BB_PRELUDE(c);
+    if (!d_anc || !d_resampled || !d_cols || !h_gen || !d_out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (T < 1 || H < 0) return fail(c, CPPROB_HIP_EINVAL, "bad T / H");
+    if (n == 0 || H == 0) return 0;
+    std::vector<int32_t> first((size_t)T + 1, 0);
+    int32_t prev = 0;
+    for (int32_t h = 0; h < H; ++h) {
+        if (h_gen[h] < prev || h_gen[h] >= T) return fail(c, CPPROB_HIP_EINVAL, "h_gen must be non-decreasing and < T");
+        prev = h_gen[h];
+        first[(size_t)h_gen[h] + 1] += 1;
+    }
+    for (int t = 0; t < T; ++t) first[(size_t)t + 1] += first[(size_t)t];
+    // (a few hundred bytes: passed by value in chunks would do too; a per-context scratch keeps the call allocation-free after the first)
+    if (first.size() > c->bb_first_cap) { dfree(c->d_bb_first); HIP_TRY(c, hipMalloc(&c->d_bb_first, first.size() * sizeof(int32_t))); c->bb_first_cap = first.size(); }
+    int32_t* d_first = c->d_bb_first;
+    HIP_TRY(c, hipMemcpy(d_first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));     // (synchronous: `first` is a local)
+    if (is_int) hipLaunchKernelGGL(lineage_gather_kernel<int32_t>, GRID1(n), d_anc, d_resampled, (int)T, (int64_t)n, static_cast<const int32_t*>(d_cols), (const int32_t*)d_first, static_cast<int32_t*>(d_out));
+    else hipLaunchKernelGGL(lineage_gather_kernel<double>, GRID1(n), d_anc, d_resampled, (int)T, (int64_t)n, static_cast<const double*>(d_cols), (const int32_t*)d_first, static_cast<double*>(d_out));
     HIP_TRY(c, hipGetLastError());
     return 0;
 }

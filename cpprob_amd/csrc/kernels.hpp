@@ -1659,6 +1659,21 @@ __global__ void annex_lineages_kernel(const V* __restrict__ rec, int64_t count, 
     anc[(int64_t)t * rs + col] = (int32_t)col;
 }
 
+// Traces from per-step records (cpprob_hip_lineage_gather): lane i walks final particle i's ancestral line; first_row[t] .. first_row[t+1]
+// are the rows recorded in generation t's slots.
+template <class V>
+__global__ void lineage_gather_kernel(const int32_t* __restrict__ anc, const int32_t* __restrict__ resampled, int T, int64_t n, const V* __restrict__ cols,
+                                      const int32_t* __restrict__ first_row, V* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t idx = i;
+    for (int t = T - 1; t >= 0; --t) {
+        for (int h = first_row[t]; h < first_row[t + 1]; ++h) out[(int64_t)h * n + i] = cols[(int64_t)h * n + idx];
+        if (t > 0 && resampled[t - 1]) idx = anc[(int64_t)t * n + idx];
+    }
+}
+
 // rows of a narrow particle store widened to the model's value type ([T][rs] -> [T][ld]): copy-out through the C ABI
 template <class S, class V>
 __global__ void widen_rows_kernel(const S* __restrict__ src, int64_t rs, int T, int64_t n, int64_t ld, V* __restrict__ dst)

@@ -18,5 +18,7 @@ extern template void poisson_rate<double>(int, int);
 extern template void gaussian_2d_unk_mean<double>(std::vector<double>);
 extern template void gaussian_by_rejection<double>(double, double);
 extern template void all_distr<int>(int, int);
+extern template void second_order<12>(const std::array<double, 12>&);
+extern template void running_mean<12>(const std::array<double, 12>&);
 }
 #endif

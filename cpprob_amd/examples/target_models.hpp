@@ -143,6 +143,35 @@ void poisson_rate(const int k1, const int k2)
     cpprob::predict(rate, "Rate");
 }
 
+// Two test models for the replay machinery (not in the reference).  second_order: x_t depends on the TWO previous states;
+// running_mean: x_t depends on the mean of ALL previous states (no finite window: the whole trace has to be replayed).
+template <std::size_t N>
+void second_order(const std::array<double, N>& y)
+{
+    double x1 = 0, x2 = 0;
+    for (std::size_t t = 0; t < N; ++t) {
+        boost::random::normal_distribution<> transition{0.5 * x1 + 0.3 * x2, 1};
+        const double x = cpprob::sample(transition, true);
+        boost::random::normal_distribution<> emission{x, 1};
+        cpprob::observe(emission, y[t]);
+        cpprob::predict(x, "State");
+        x2 = x1; x1 = x;
+    }
+}
+template <std::size_t N>
+void running_mean(const std::array<double, N>& y)
+{
+    double sum = 0;
+    for (std::size_t t = 0; t < N; ++t) {
+        boost::random::normal_distribution<> transition{t ? sum / static_cast<double>(t) : 0.0, 1};
+        const double x = cpprob::sample(transition, true);
+        boost::random::normal_distribution<> emission{x, 1};
+        cpprob::observe(emission, y[t]);
+        cpprob::predict(x, "State");
+        sum += x;
+    }
+}
+
 // One statement triple -- sample, address-less predict, observe of the sampled value -- per distribution of the library
 // (restates the statement sequence of reference src/models/models.cpp:13-47; the two ints are unused there too; a template here so that
 // host programs link the model library's instantiation: registered_models.hpp).  Every predict gets

@@ -62,8 +62,7 @@ CPPROB_HD void observe(Distribution&& distr, const typename std::decay_t<Distrib
 #if defined(__HIP_DEVICE_COMPILE__)
     device::observe_impl(distr, x);
 #else
-    (void)distr; (void)x;
-    detail::host_observe();
+    detail::host_observe(distr, x);
 #endif
 }
 

@@ -47,7 +47,22 @@ struct LaneCtx {
     int32_t first_observe;        // observes with a smaller index were weighted in earlier steps
     int32_t stop_after;           // index of the observe that ends this step (-1: run to completion)
     uint32_t done;
+    // windowed replay (models that passed the Markov probe): a step replays only the ancestor's last `win` samples, kept per
+    // particle in `carry` rows (slot k <-> ordinal fresh_lo - win + k); older samples come back value-initialised, never from memory
+    uint32_t windowed, win;
+    int32_t fresh_lo;             // first ordinal this step draws itself (= samples before the previous observe)
+    int32_t next_fresh;           // first ordinal the NEXT step draws (= samples before this step's observe): what carry_out must end with
+    const uint64_t* carry_in; uint64_t* carry_out;
+    // what the kernel's epilogue needs
+    double carried; double* logw_out; int32_t* nstored_out;
 };
+
+// finish_trace() of one lane: the particle's log-weight (and, full replay, how many samples its trace holds)
+__device__ inline void finish_lane(LaneCtx& c)
+{
+    *c.logw_out = c.carried + c.log_w;
+    if (c.nstored_out) *c.nstored_out = (int32_t)c.n_recorded;
+}
 
 __device__ inline LaneCtx& lane_ctx()
 {
@@ -128,6 +143,17 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
         LaneCtx& c = lane_ctx();
         const uint32_t j = c.n_sample++;
         if (c.done) return R();
+        if (c.windowed) {
+            const int32_t jj = (int32_t)j, base = c.fresh_lo - (int32_t)c.win;
+            if (jj < base) return R();                                    // older than the window: the step does not depend on it (host probe)
+            R v;
+            if (jj < c.fresh_lo) v = from_raw<R>(c.carry_in[(int64_t)(jj - base) * c.ld]);
+            else v = draw(distr, c.seed, c.pid, (uint64_t)j);
+            const int32_t out_base = c.next_fresh - (int32_t)c.win;
+            if (c.carry_out && jj >= out_base && jj < c.next_fresh) c.carry_out[(int64_t)(jj - out_base) * c.ld] = to_raw<R>(v);
+            c.n_recorded = j + 1;
+            return v;
+        }
         R value;
         if (j < c.n_stored && j < c.trace_cap) value = from_raw<R>(c.trace_in[(int64_t)j * c.ld]);   // (beyond the rows: the run is being repeated anyway)
         else value = draw(distr, c.seed, c.pid, (uint64_t)j);
@@ -158,6 +184,8 @@ __device__ inline void observe_impl(Distribution& distr, const X& x)
         if (c.done || m < c.first_observe) return;
         c.log_w += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
         if (m == c.stop_after) c.done = 1;
+        // (ending the wave here once every lane has arrived -- finish_lane + s_endpgm -- was tried: no gain, the statements after the
+        //  frontier are the cheap ones: profiles/r02_notes.md)
     }
 }
 
@@ -169,6 +197,7 @@ __device__ inline void predict_impl(const T& x)
         LaneCtx& c = lane_ctx();
         if (c.done) return;
         const uint32_t k = c.n_pred_int++;
+        if (c.windowed && (int32_t)c.n_observe < c.first_observe) return;      // an earlier step's hit: recorded by that step's launch
         if (c.pred_int) {
             if (k < c.pred_int_cap) c.pred_int[(int64_t)k * c.ld] = static_cast<int32_t>(x);
             else if (c.overflow) *c.overflow = 2;                       // more predict hits than the dry run: data-dependent predicts
@@ -177,6 +206,7 @@ __device__ inline void predict_impl(const T& x)
         LaneCtx& c = lane_ctx();
         if (c.done) return;
         const uint32_t k = c.n_pred_real++;
+        if (c.windowed && (int32_t)c.n_observe < c.first_observe) return;
         if (c.pred_real) {
             if (k < c.pred_real_cap) c.pred_real[(int64_t)k * c.ld] = static_cast<double>(x);
             else if (c.overflow) *c.overflow = 2;

@@ -294,6 +294,46 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
     }
 }
 
+// ---- Markov probe (cpprob/detail/host_trace.hpp: ProbeState): the smallest window of past samples a step depends on, or -1 ------
+template <class Func, class ObsTuple>
+int probe_markov_window(const Func& f, const ObsTuple& obs, const detail::TraceStructure& st)
+{
+    const std::size_t T = st.n_observe;
+    if (T < 2 || st.vector_statements || st.samples_before_observe.size() != T || st.n_sample == 0) return -1;
+    auto run = [&](const detail::ProbeState& cfg) -> bool {
+        detail::ProbeState& p = detail::probe();
+        p = cfg; p.active = true; p.failed = false; p.ordinal = 0; p.n_obs = 0; p.log.clear();
+        try { call_f_tuple(f, obs); }
+        catch (const detail::ProbeAbort&) { p.active = false; return false; }
+        catch (...) { p.active = false; throw; }
+        p.active = false;
+        return !p.failed;
+    };
+    const int windows[] = {1, 2, 4, 8};
+    for (int w : windows) {
+        bool ok = true;
+        for (std::uint32_t rep = 0; rep < 3 && ok; ++rep) {
+            detail::ProbeState a;
+            a.base_seed = 1000003u * (rep + 1); a.n_steps = T; a.record_all = true; a.ordinal_cap = 64 * st.n_sample + 1024;
+            if (!run(a)) return -1;
+            const std::vector<std::vector<double>> ref = detail::probe().log;
+            const std::vector<double> values = detail::probe().values;
+            if (detail::probe().ordinal != st.n_sample || detail::probe().n_obs != T) return -1;      // sample / observe counts depend on sampled values
+            for (std::size_t step = 1; step < T && ok; ++step) {
+                const std::size_t fresh_lo = st.samples_before_observe[step - 1];
+                if (fresh_lo <= static_cast<std::size_t>(w)) continue;                                // nothing older than the window yet
+                detail::ProbeState b = a;
+                b.record_all = false; b.step = step; b.dummy_below = fresh_lo - static_cast<std::size_t>(w); b.replay_below = fresh_lo; b.values = values;
+                if (!run(b)) { ok = false; break; }
+                const auto& lg = detail::probe().log;
+                if (detail::probe().n_obs != T || lg.size() <= step || ref.size() <= step || lg[step] != ref[step]) ok = false;
+            }
+        }
+        if (ok) return w;
+    }
+    return -1;
+}
+
 // ---- the body of cpprob::inference -------------------------------------------------------------------
 template <class Func, class... Args>
 void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>& observes, std::size_t n, const std::string& file)
@@ -313,6 +353,7 @@ void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>
         State::set(saved);
     }
     if (st.n_observe == 0) throw std::runtime_error("cpprob::inference: the model executes no observe statement");
+    if (algorithm == StateType::smc && options().markov_probe) st.window = probe_markov_window(f, obs, st);
     if (st.n_other_predicts) throw std::runtime_error("cpprob::inference: non-scalar predicts (.any file) are not supported by the device engine");
 
     const Key key = key_of(f, std::integral_constant<bool, detail::fn_traits<std::remove_cv_t<std::remove_reference_t<Func>>>::is_function>{});

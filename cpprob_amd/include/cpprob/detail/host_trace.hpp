@@ -8,6 +8,7 @@
 #include <execinfo.h>
 
 #include <cstddef>
+#include <cstdint>
 #include <cstdlib>
 #include <random>
 #include <string>
@@ -15,6 +16,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "cpprob/distributions/utils_base.hpp"
 #include "cpprob/ndarray.hpp"
 
 namespace cpprob {
@@ -29,6 +31,11 @@ struct TraceStructure {
     std::size_t real_rows() const { std::size_t r = 0; for (auto w : real_width) r += w; return r; }
     std::vector<std::string> addresses;                 // id -> address (the .ids file, state.cpp:250-260)
     std::size_t n_other_predicts = 0;                   // predicts of non-scalar type (the .any file): not carried by the device engine
+    // SMC structure: samples executed before observe t is reached, and the step each predict hit (row) belongs to = observes
+    // executed before it (a predict placed after observe t reports the state that observe weighed: it runs in step t+1's launch)
+    std::vector<std::size_t> samples_before_observe;
+    std::vector<int> real_row_step, int_hit_step;
+    int window = -1;                                    // >= 0: the model passed the Markov probe -- a step needs only its ancestor's last `window` samples
     std::size_t id_of(const std::string& addr)
     {
         auto it = ids_.find(addr);
@@ -89,16 +96,65 @@ inline std::string call_site_address()
 inline TraceStructure*& recorder() { static thread_local TraceStructure* r = nullptr; return r; }
 inline std::mt19937& host_rng() { static thread_local std::mt19937 rng{20260101u}; return rng; }
 
+// Markov probe (host): does a step of the model -- the statements between two observes -- depend on anything but the last w
+// sampled values?  One execution with every sample drawn (per-ordinal seeds), one with the samples older than the window replaced
+// by value-initialised ones (what the device's windowed replay hands the model): the step's statements must see the same draws,
+// the same observe log-densities and the same predict values.  Probed for every step and several seeds by run_inference; a model
+// that passes runs SMC with O(T) instead of O(T^2) replay traffic (cpprob/gpu.hpp).
+struct ProbeState {
+    bool active = false, failed = false;
+    std::uint32_t base_seed = 0;
+    std::size_t dummy_below = 0, replay_below = 0, ordinal = 0, n_obs = 0, ordinal_cap = 0;   // ordinals < dummy_below: value-initialised; < replay_below: the reference run's
+    std::vector<double> values;                         // reference run: every drawn value, by ordinal
+    std::size_t step = 0, n_steps = 0;
+    bool record_all = false;                            // reference run: log every step; otherwise only `step`
+    std::vector<std::vector<double>> log;               // per step
+    bool in_step(std::size_t m) const { return m < n_steps ? true : false; }
+    std::size_t step_of_now() const { return n_obs < n_steps ? n_obs : n_steps - 1; }
+    void put(double v)
+    {
+        const std::size_t st = step_of_now();
+        if (record_all || st == step) { if (log.size() <= st) log.resize(st + 1); log[st].push_back(v); }
+    }
+};
+struct ProbeAbort {};
+inline ProbeState& probe() { static thread_local ProbeState p; return p; }
+
 // variates a value consumes: one per component
 template <class T> std::size_t width_of(const T&) { return 1; }
 template <class T> std::size_t width_of(const NDArray<T>& x) { return x.size(); }
 template <class V> auto width_of_sized(const V& x, int) -> decltype(x.size()) { return x.size(); }
 template <class V> std::size_t width_of_sized(const V&, long) { return 1; }
 
+template <class V> std::enable_if_t<std::is_arithmetic<V>::value> probe_put_value(ProbeState& p, const V& v) { p.put(static_cast<double>(v)); }
+template <class V> std::enable_if_t<!std::is_arithmetic<V>::value> probe_put_value(ProbeState& p, const V&) { p.failed = true; }   // vector values: full replay
+
+template <class R> std::enable_if_t<std::is_arithmetic<R>::value, R> probe_from_double(double v, ProbeState&) { return static_cast<R>(v); }
+template <class R> std::enable_if_t<!std::is_arithmetic<R>::value, R> probe_from_double(double, ProbeState& p) { p.failed = true; return R(); }
+template <class V> std::enable_if_t<std::is_arithmetic<V>::value> probe_keep_value(ProbeState& p, std::size_t j, const V& v)
+{
+    if (p.values.size() <= j) p.values.resize(j + 1, 0.0);
+    p.values[j] = static_cast<double>(v);
+}
+template <class V> std::enable_if_t<!std::is_arithmetic<V>::value> probe_keep_value(ProbeState& p, std::size_t, const V&) { p.failed = true; }
+
 template <class Distribution>
 auto host_sample(Distribution& distr)
 {
     std::decay_t<Distribution> copy = distr;
+    ProbeState& pb = probe();
+    if (pb.active) {
+        using R = decltype(copy(host_rng()));
+        const std::size_t j = pb.ordinal++;
+        if (j > pb.ordinal_cap) throw ProbeAbort{};                             // a loop that does not end on substituted values
+        if (j < pb.dummy_below) return R();
+        if (j < pb.replay_below && j < pb.values.size()) return probe_from_double<R>(pb.values[j], pb);      // the window: as the reference run drew it
+        std::mt19937 g(pb.base_seed + 7919u * static_cast<std::uint32_t>(j));   // the draw depends on the ordinal and the distribution only
+        R v = copy(g);
+        probe_put_value(pb, v);
+        if (pb.record_all) probe_keep_value(pb, j, v);
+        return v;
+    }
     auto value = copy(host_rng());                      // cpprob.hpp:33-35: distr(get_rng())
     if (TraceStructure* r = recorder()) {
         r->n_sample += std::is_arithmetic<decltype(value)>::value ? 1 : width_of_sized(value, 0);
@@ -107,25 +163,38 @@ auto host_sample(Distribution& distr)
     return value;
 }
 
-inline void host_observe() { if (recorder()) ++recorder()->n_observe; }
+template <class Distribution, class X>
+void host_observe(Distribution& distr, const X& x)
+{
+    ProbeState& pb = probe();
+    if (pb.active) {
+        pb.put(static_cast<double>(logpdf<std::decay_t<Distribution>>()(distr, x)));      // what the step adds to the weight
+        ++pb.n_obs;
+        return;
+    }
+    if (TraceStructure* r = recorder()) { r->samples_before_observe.push_back(r->n_sample); ++r->n_observe; }
+}
 
 template <class V>
 auto host_predict_dispatch(const V& x, const std::string& addr, int) -> decltype((void)x.size(), (void)x.begin(), void())
 {
+    if (probe().active) { probe().failed = true; return; }
     TraceStructure* r = recorder();                                                          // (a device-view NDArray: same bookkeeping as NDArray)
     if (!r) return;
     r->real_ids.push_back(r->id_of(addr));
     r->real_width.push_back(x.size());
+    for (std::size_t d = 0; d < x.size(); ++d) r->real_row_step.push_back(static_cast<int>(r->n_observe));
     r->vector_statements = true;
 }
 template <class T>
-void host_predict_dispatch(const T&, const std::string& addr, long)
+void host_predict_dispatch(const T& x, const std::string& addr, long)
 {
+    if (probe().active) { probe_put_value(probe(), x); return; }
     TraceStructure* r = recorder();
     if (!r) return;
     using V = std::decay_t<T>;
-    if (std::is_integral<V>::value) r->int_ids.push_back(r->id_of(addr));                  // state.hpp:312-318
-    else if (std::is_floating_point<V>::value) { r->real_ids.push_back(r->id_of(addr)); r->real_width.push_back(1); }   // state.hpp:320-326
+    if (std::is_integral<V>::value) { r->int_ids.push_back(r->id_of(addr)); r->int_hit_step.push_back(static_cast<int>(r->n_observe)); }                  // state.hpp:312-318
+    else if (std::is_floating_point<V>::value) { r->real_ids.push_back(r->id_of(addr)); r->real_width.push_back(1); r->real_row_step.push_back(static_cast<int>(r->n_observe)); }   // state.hpp:320-326
     else { r->id_of(addr); ++r->n_other_predicts; }
 }
 template <class T>
@@ -133,10 +202,12 @@ void host_predict(const T& x, const std::string& addr) { host_predict_dispatch(x
 template <class T>
 void host_predict(const NDArray<T>& x, const std::string& addr)                            // state.hpp:330-337: NDArray -> the real list
 {
+    if (probe().active) { probe().failed = true; return; }
     TraceStructure* r = recorder();
     if (!r) return;
     r->real_ids.push_back(r->id_of(addr));
     r->real_width.push_back(x.size());
+    for (std::size_t d = 0; d < x.size(); ++d) r->real_row_step.push_back(static_cast<int>(r->n_observe));
     r->vector_statements = true;
 }
 

@@ -62,6 +62,9 @@ struct ModelKernelArgs {
     int32_t first_observe, stop_after;
     uint32_t trace_cap; int32_t* overflow;
     uint32_t pred_real_cap, pred_int_cap;
+    // windowed replay (cpprob/detail/device_trace.hpp)
+    uint32_t windowed, win; int32_t fresh_lo, next_fresh;
+    const uint64_t* carry_in; uint64_t* carry_out;
 };
 
 // How the kernel reaches the model body: a function (by address, as a template argument) or a functor
@@ -97,10 +100,12 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
     c.trace_cap = a.trace_cap; c.overflow = a.overflow;
     c.pred_real_cap = a.pred_real_cap; c.pred_int_cap = a.pred_int_cap;
     c.first_observe = a.first_observe; c.stop_after = a.stop_after; c.done = 0;
+    c.windowed = a.windowed; c.win = a.win; c.fresh_lo = a.fresh_lo; c.next_fresh = a.next_fresh;
+    c.carry_in = a.carry_in ? a.carry_in + src : nullptr; c.carry_out = a.carry_out ? a.carry_out + i : nullptr;
+    c.carried = (!resampled && a.logw_in) ? a.logw_in[i] : 0.0;   // equal weights after resampling
+    c.logw_out = a.logw_out + i; c.nstored_out = a.nstored_out ? a.nstored_out + i : nullptr;
     Caller::call(*observes);                                      // the model body, cpprob.hpp:199
-    const double carried = (!resampled && a.logw_in) ? a.logw_in[i] : 0.0;         // equal weights after resampling
-    a.logw_out[i] = carried + c.log_w;                            // finish_trace(): the particle's log_w_
-    if (a.nstored_out) a.nstored_out[i] = (int32_t)c.n_recorded;
+    device::finish_lane(c);                                       // finish_trace(): the particle's log_w_
 }
 
 template <class Tuple> struct observes_bytewise_copyable;
@@ -157,6 +162,13 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
     ModelKernelArgs a{};
     a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed; a.trace_cap = (uint32_t)S; a.overflow = d_overflow.p;
     a.pred_real_cap = (uint32_t)n_real; a.pred_int_cap = (uint32_t)n_int;
+    // (windowed replay's buffers: allocated before the clock starts, like the others)
+    const bool windowed = smc && st.window >= 0;
+    const uint32_t w = (uint32_t)std::max(1, st.window);
+    DevBuf<uint64_t> d_c0(windowed ? (size_t)w * n : 0), d_c1(windowed ? (size_t)w * n : 0);
+    DevBuf<int32_t> d_anc_all(windowed ? (size_t)T * n : 0);
+    DevBuf<double> d_real_gen(windowed ? n_real * n : 0);
+    DevBuf<int32_t> d_int_gen(windowed ? n_int * n : 0);
     const auto t_start = std::chrono::steady_clock::now();
     double log_z = 0.0;
     int cur = 0, n_resampled = 0;
@@ -168,6 +180,50 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
         a.logw_out = logw[0]; a.pred_real = d_real.p; a.pred_int = d_int.p; a.first_observe = 0; a.stop_after = -1;
         hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
         hip_check(hipGetLastError(), "model_kernel");
+    } else if (windowed) {
+        // Windowed replay: the host probe found that a step depends on its ancestor's last `w` samples only.  Per step ONE gather of
+        // w carried values and one row of new ones -- the traffic of the hand-fused kernels -- instead of re-reading and re-writing
+        // the whole trace; every launch records the predicts of its own step, ancestors are kept per step, and the traces are read
+        // out once at the end by walking the lineages (cpprob_hip_lineage_gather).
+        uint64_t* carry[2] = {d_c0.p, d_c1.p};
+        a.windowed = 1; a.win = w;
+        for (int t = 0; t < T; ++t) {
+            const bool last = t + 1 == T;
+            a.anc = t > 0 ? d_anc_all.p + (size_t)t * n : nullptr;
+            a.resampled_prev = t > 0 ? d_res.p + (t - 1) : nullptr;
+            a.logw_in = t > 0 ? logw[cur] : nullptr;
+            a.logw_out = logw[cur ^ 1];
+            a.carry_in = t > 0 ? carry[cur] : nullptr; a.carry_out = last ? nullptr : carry[cur ^ 1];
+            a.fresh_lo = t > 0 ? (int32_t)st.samples_before_observe[(size_t)t - 1] : 0;
+            a.next_fresh = (int32_t)st.samples_before_observe[(size_t)t];
+            a.pred_real = d_real_gen.p; a.pred_int = d_int_gen.p;
+            a.first_observe = t; a.stop_after = last ? -1 : t;
+            hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
+            hip_check(hipGetLastError(), "model_kernel");
+            cur ^= 1;
+            ctx.check(cpprob_hip_smc_bookkeep(ctx.get(), opt.resampler, logw[cur], n, opt.seed, t, last ? 1 : 0, opt.ess_threshold,
+                                              d_ess.p, d_res.p, d_logz.p, last ? d_anc.p : d_anc_all.p + (size_t)(t + 1) * n), "cpprob_hip_smc_bookkeep");
+        }
+        // traces: hit h was recorded in the slots of generation step(h); follow every final particle's lineage back to it
+        auto gens = [&](const std::vector<int>& steps) { std::vector<int32_t> g; for (int s2 : steps) g.push_back(std::min(s2, T - 1)); return g; };
+        if (n_real) {
+            const std::vector<int32_t> g = gens(st.real_row_step);
+            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all.p, d_res.p, T, n, d_real_gen.p, 0, g.data(), (int32_t)g.size(), d_real.p), "cpprob_hip_lineage_gather");
+        }
+        if (n_int) {
+            const std::vector<int32_t> g = gens(st.int_hit_step);
+            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all.p, d_res.p, T, n, d_int_gen.p, 1, g.data(), (int32_t)g.size(), d_int.p), "cpprob_hip_lineage_gather");
+        }
+        std::vector<double> h_ess((size_t)T);
+        std::vector<int32_t> h_res((size_t)T);
+        hip_check(hipMemcpyAsync(h_ess.data(), d_ess.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, stream), "copy ess");
+        hip_check(hipMemcpyAsync(h_res.data(), d_res.p, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy decisions");
+        hip_check(hipMemcpyAsync(&log_z, d_logz.p, sizeof(double), hipMemcpyDeviceToHost, stream), "copy log evidence");
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        res.step_ess = h_ess;
+        for (int t = 0; t < T; ++t) n_resampled += h_res[(size_t)t];
+        smc_log_z_done = true;
+        res.replay_window = (int)w;
     } else {
         for (int t = 0; t < T; ++t) {
             const bool last = t + 1 == T;

@@ -24,6 +24,8 @@ struct Options {
     double ess_threshold = 0.5;                       // smc: resample when ESS < threshold * N (thesis p.37); > 1: every step
     bool dump = true;                                 // write <file>.real/.int/.ids like the reference (state.cpp:193-202)
     std::size_t dump_max_particles = 0;               // 0 = all particles
+    bool markov_probe = true;                         // smc, unchanged-model path: test on the host whether a step depends on more than the last few
+                                                      // sampled values; a model that does not is replayed from that window only (O(T) instead of O(T^2))
     bool prefer_builtin = true;                       // use the hand-fused kernels when the model is one of the built-ins
     bool progress = false;
     int replicates = 1;                               // built-in models: R independent runs (seeds seed .. seed + R - 1), up to three in
@@ -44,7 +46,8 @@ struct Result {
     int n_resampled = 0;
     bool used_builtin = false;
     int n_gpus = 1;                           // ranks the population was sharded over
-    int exchange_reruns = 0;                  // multi-GPU: runs repeated with a larger lineage transport (results never depend on it)
+    int exchange_reruns = 0;
+    int replay_window = -1;                   // unchanged-model smc: samples of the ancestor a step replays (-1: the whole trace)                  // multi-GPU: runs repeated with a larger lineage transport (results never depend on it)
     double run_seconds = 0;                   // device work of the run (launch to synchronise), excluding allocation and dumps
     std::vector<PredictStats> predicts;       // real hits first (in trace order), then int hits
     std::vector<double> step_ess;             // smc: ESS after each observe

@@ -303,6 +303,12 @@ int cpprob_hip_resample(cpprob_hip_ctx* ctx, int32_t kind, const double* d_logw,
  * as cpprob_hip_resample(seed, step + 1). */
 int cpprob_hip_smc_bookkeep(cpprob_hip_ctx* ctx, int32_t kind, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last,
                             double ess_frac, double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc);
+/* Traces from per-step records: d_anc [T][n] (row t: slot of generation t-1 that slot i of generation t extends; a row counts only where
+ * d_resampled[t-1] != 0), d_cols [H][n] with row h recorded in the slots of generation h_gen[h] (non-decreasing in h).  d_out[h][i] =
+ * d_cols[h][slot of generation h_gen[h] on the ancestral line of FINAL particle i]: the value particle i's trace holds for that row.
+ * is_int = 0: fp64 rows, 1: int32 rows.  Stream-ordered; what the unchanged-model SMC path reads its predicts out with. */
+int cpprob_hip_lineage_gather(cpprob_hip_ctx* ctx, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const void* d_cols,
+                              int32_t is_int, const int32_t* h_gen, int32_t H, void* d_out);
 /* d_dst[i] = d_src[d_idx[i]] */
 int cpprob_hip_gather_f64(cpprob_hip_ctx* ctx, const double* d_src, const int32_t* d_idx, size_t n, double* d_dst);
 int cpprob_hip_gather_i32(cpprob_hip_ctx* ctx, const int32_t* d_src, const int32_t* d_idx, size_t n, int32_t* d_dst);

@@ -311,3 +311,20 @@ def test_all_distr_model_and_addressless_predicts(tmp_path):
     from scipy.stats import poisson
     pm = poisson.pmf(np.arange(8), 0.8) ** 2
     np.testing.assert_allclose(ints[1]["p"][:6], (pm / pm.sum())[:6], atol=5e-3)
+
+
+@pytest.mark.parametrize("model,window", [("hmm16", 1), ("linear_gaussian_1d25", 1), ("second_order12", 2), ("running_mean12", -1)])
+def test_markov_probe_finds_the_replay_window_and_changes_no_number(tmp_path, model, window):
+    """Unchanged-model SMC: the host probe (cpprob/detail/host_trace.hpp) finds how many of its ancestor's samples a step depends on --
+    1 for the first-order models, 2 for second_order, none finite for running_mean (the whole trace is replayed) -- and the windowed
+    replay draws the same variates, weights and ancestors as the full replay: every reported number is identical."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    T = {"hmm16": 16, "linear_gaussian_1d25": 25}.get(model, 12)
+    obs = z["hmm16"] if model == "hmm16" else z["lgssm100"][:T]
+    common = ["--model", model, "--smc", "--observes", obs_str(obs), "--n_samples", 50000, "--seed", 8, "--ess_threshold", 0.5, "--generic", "--json", "--no_dump"]
+    a, _, _ = run_main(tmp_path, *common)
+    b, _, _ = run_main(tmp_path, *common, "--no_markov_probe")
+    assert a["replay_window"] == window and b["replay_window"] == -1 and not a["builtin"]
+    assert a["log_evidence"] == b["log_evidence"] and a["n_resampled"] == b["n_resampled"] and a["ess"] == b["ess"]
+    for pa, pb in zip(a["predicts"], b["predicts"]):
+        assert pa == pb
