@@ -258,3 +258,34 @@ int main(void) {
                            "-o", exe, drv, src, "-lm"])
     out = subprocess.check_output([exe], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1")).decode()
     assert out.strip() == "ok"
+
+
+def test_table_weight_resampler_is_order_independent_and_matches_the_cdf_form():
+    """The systematic resampler the index-work parity rests on (orc_resample_table_systematic: integer prefix counts,
+    C_k = fma(c_2, e_2, fma(c_1, e_1, c_0 e_0)), ancestor of j = min{k : ceil(fma(C_k, N/W, -u0)) > j}): equal to the
+    sequential-CDF form (thesis p.36 remark: positions (j + u0) W/N) wherever that form's sums are exact, and independent
+    of how the population is cut into shards -- the property that lets tiles, wavefronts and GPUs evaluate it in any order."""
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 3, 60000).astype(np.int32)
+    n = len(x)
+    for e in (np.array([1.0, 0.5, 0.25]), np.array([0.125, 1.0, 0.5])):            # exactly summable: both forms must agree to the last index
+        a = O.resample_table_systematic(x, e, 7, 3)
+        b = O.resample(O.RESAMPLE_SYSTEMATIC, np.log(e[x]), 7, 3)
+        assert np.array_equal(a, b)
+    e = np.array([0.3123, 1.0, 0.0712345])
+    full = O.resample_table_systematic(x, e, 11, 5)
+    assert np.all(np.diff(full) >= 0) and full[0] >= 0 and full[-1] <= n - 1
+    counts = np.bincount(full, minlength=n)
+    expect = n * e[x] / e[x].sum()
+    assert np.abs(counts - expect).max() < 1.0 + 1e-9                              # systematic: every offspring count within one of its expectation
+    total = np.bincount(x, minlength=3).astype(np.uint64)
+    for cuts in ([0, 12000, 30001, n], [0, 1, 2, 59999, n], [0, 20000, 20001, 40000, n]):
+        got = np.full(n, -1, np.int64)
+        for r in range(len(cuts) - 1):
+            before = np.bincount(x[:cuts[r]], minlength=3).astype(np.uint64)
+            ar = O.resample_table_systematic(x[cuts[r]:cuts[r + 1]], e, 11, 5, before=before, total=total, last_shard=(r == len(cuts) - 2),
+                                             j0=0, n_out=n, n_total_out=n)
+            m = ar >= 0
+            assert (got[m] == -1).all()                                            # no output is claimed by two shards
+            got[m] = ar[m] + cuts[r]
+        assert np.array_equal(got, full)                                           # ... and none is left out; the ancestors are the single-shard ones
