@@ -409,6 +409,18 @@ double host_resample_u0(uint64_t seed, uint64_t step)
     return (double)bits * 1.1102230246251565e-16;
 }
 
+// The launch-side view of one copy of the count hierarchy (levels not in use alias level 0: see step_counts.hpp).
+static void hier_view(const cpprob_hip_ctx* c, int copy, Hier& h)
+{
+    for (int l = 0; l < kHierMaxLevels; ++l) {
+        h.lvl[l] = l < c->hier.n_lev ? c->hier.lvl[copy][l] : c->hier.lvl[copy][0];
+        h.n_ent[l] = c->hier.n_ent[l];
+    }
+    h.n_lev = c->hier.n_lev; h.table = c->d_hier_table; h.copy = copy;
+    const int top = c->hier.n_lev - 1;
+    h.top = c->hier.lvl[copy][top]; h.top_n = c->hier.n_ent[top]; h.top_stride = top == 0 ? 1 : kHierStride;
+}
+
 template <class Model>
 void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int world, int rank)
 {
@@ -424,8 +436,7 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
                 c->hier_run_open = true; c->hier_phase_run = c->hier_phase;
             }
             const int kp = (t + c->hier_phase_run) % 3, kn = (kp + 1) % 3, kc = (kp + 2) % 3;
-            for (int l = 0; l < kHierMaxLevels; ++l) { a.h.lvl[l] = c->hier.lvl[kp][l]; a.h.n_ent[l] = c->hier.n_ent[l]; }
-            a.h.n_lev = c->hier.n_lev;
+            hier_view(c, kp, a.h);
             a.h.to_next = (int64_t)(kn - kp) * (int64_t)c->hier_per_copy; a.h.to_clear = (int64_t)(kc - kp) * (int64_t)c->hier_per_copy;
             if (t + 1 == c->T) {
                 // after the last step exactly one copy is dirty -- the one it read; the next run starts its rotation there, so the copy
@@ -433,7 +444,7 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
                 if (c->T >= 2) c->hier_phase = kp;
                 c->hier_run_open = false;
             }
-            a.h.table = c->d_hier_table; a.h.copy = kp;
+
         }
         a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
         a.all_totals = all_totals; a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
@@ -845,8 +856,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
         if (t + 1 < c->T) {
             Hier h{};
             const int kn = (t + 1 + c->hier_phase_run) % 3;
-            for (int l = 0; l < kHierMaxLevels; ++l) { h.lvl[l] = c->hier.lvl[kn][l]; h.n_ent[l] = c->hier.n_ent[l]; }
-            h.n_lev = c->hier.n_lev;
+            hier_view(c, kn, h);
             hipLaunchKernelGGL(counts_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals);
         } else {
             launch_scan(c, t, 1, nullptr, 1, 0);
@@ -938,8 +948,7 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid)
     if constexpr (Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1) {
         if (c->counts_mode) {
             const int kn = (t + 1 + c->hier_phase_run) % 3;            // the copy step t wrote = the one step t+1 reads
-            for (int l = 0; l < kHierMaxLevels; ++l) { a.h.lvl[l] = c->hier.lvl[kn][l]; a.h.n_ent[l] = c->hier.n_ent[l]; }
-            a.h.n_lev = c->hier.n_lev; a.h.table = c->d_hier_table; a.h.copy = kn;
+            hier_view(c, kn, a.h);
             a.pc.e0 = c->h_e_tab[(size_t)t * 4]; a.pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; a.pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
             a.pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
             hipLaunchKernelGGL((exchange_pack_kernel<Model, R, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);

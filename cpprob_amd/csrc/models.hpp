@@ -188,6 +188,30 @@ struct ModelHmm3 {
             }
         }
     }
+    // The same transition with the rows' thresholds staged in LDS ({c0, c1} of row s at words 2s, 2s + 1; visible to the caller's
+    // threads): one 16-byte LDS read per particle selects the row, where the register form above selects six 64-bit scalars
+    // through execution-mask branches (~50 scalar instructions per particle in the step kernel's build).
+    static constexpr int kStagedWords = 6;
+    __device__ static __forceinline__ void stage(const ModelParams& mp, uint64_t* lds)       // one thread
+    {
+        lds[0] = mp.hmm_thr[0][0]; lds[1] = mp.hmm_thr[0][1];
+        lds[2] = mp.hmm_thr[1][0]; lds[3] = mp.hmm_thr[1][1];
+        lds[4] = mp.hmm_thr[2][0]; lds[5] = mp.hmm_thr[2][1];
+    }
+    __device__ static __forceinline__ void apply4_staged(const uint64_t* lds, int t, const Rand& r, const value_t (&prev)[4], value_t (&x)[4])
+    {
+        const uint32_t (&w)[4] = r.w;
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = (value_t)smallint_from_word(w[k], 0, 2);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(lds + 2 * prev[k]);
+                x[k] = (value_t)(((uint64_t)w[k] >= c.x) + ((uint64_t)w[k] >= c.y));
+            }
+        }
+    }
     static constexpr bool kBounded = false;
     __device__ static __forceinline__ double logw_of_z(const ModelParams&, int, double) { return 0.0; }
     __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t s, int t, const double* __restrict__ /*obs*/)

@@ -42,7 +42,10 @@ struct Hier {                                  // what a launch carries: the cop
     int n_lev;
     int64_t to_next, to_clear;                 // word offsets from the copy read to the copy written / the copy cleared
     const HierTable* table; int copy;          // the same hierarchy in device memory
+    const uint64_t* top; int top_n, top_stride; // the last level in use (<= 64 entries): the generation's totals
 };
+// (levels beyond n_lev point at level 0, so that a load from any level is a load from valid memory: the fetches below carry no
+//  branch, and the compiler lets them travel together instead of waiting for each in turn)
 __device__ __forceinline__ constexpr int hier_stride(int level) { return level == 0 ? 1 : kHierStride; }
 
 // ---- 32-bit wavefront sums / scans (one instruction per DPP step) -------------------------------------------------------------
@@ -90,35 +93,48 @@ struct TableCdf {
 };
 
 // Exclusive prefix counts at tile c (wave-uniform result; every lane of the calling wave takes part): per level, the entries that
-// precede c's block inside its parent block.
-__device__ __forceinline__ Cnt2 hier_prefix(const Hier& h, int c)
+// precede c's block inside its parent block.  Two halves: the loads (unconditional, clamped -- issued at kernel entry, long before
+// anything needs them) and the masked sum.
+__device__ __forceinline__ void hier_prefix_fetch(const Hier& h, int c, uint64_t (&w)[kHierMaxLevels])
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int l = 0; l < kHierMaxLevels; ++l) {
+        const int blk = c >> (6 * l);                           // c's block at this level (0 at the levels not in use)
+        const int first = (blk >> 6) << 6;                      // first block of the parent
+        w[l] = h.lvl[l][(int64_t)(first + (lane < (blk & 63) ? lane : 0)) * hier_stride(l)];
+    }
+}
+__device__ __forceinline__ Cnt2 hier_prefix_sum(int c, const uint64_t (&w)[kHierMaxLevels])
 {
     const int lane = lane_id();
     uint32_t s0 = 0, s1 = 0;
 #pragma unroll
     for (int l = 0; l < kHierMaxLevels; ++l) {
-        if (l < h.n_lev) {
-            const int blk = c >> (6 * l);                       // c's block at this level
-            const int first = (blk >> 6) << 6;                  // first block of the parent
-            if (lane < (blk & 63)) {
-                const uint64_t w = h.lvl[l][(int64_t)(first + lane) * hier_stride(l)];
-                s0 += cnt_n0(w); s1 += cnt_n1(w);
-            }
-        }
+        const bool in = lane < ((c >> (6 * l)) & 63);
+        s0 += in ? cnt_n0(w[l]) : 0u; s1 += in ? cnt_n1(w[l]) : 0u;
     }
     return Cnt2{wave_sum_u32(s0), wave_sum_u32(s1)};
 }
+__device__ __forceinline__ Cnt2 hier_prefix(const Hier& h, int c)
+{
+    uint64_t w[kHierMaxLevels];
+    hier_prefix_fetch(h, c, w);
+    return hier_prefix_sum(c, w);
+}
 
 // Totals of the generation: the sum of the (<= 64) top-level entries.
-__device__ __forceinline__ Cnt2 hier_total(const Hier& h)
+__device__ __forceinline__ uint64_t hier_total_fetch(const Hier& h)
 {
     const int lane = lane_id();
-    uint64_t w = 0;
-#pragma unroll
-    for (int l = 0; l < kHierMaxLevels; ++l)
-        if (l == h.n_lev - 1 && lane < h.n_ent[l]) w = h.lvl[l][(int64_t)lane * hier_stride(l)];
+    return h.top[(int64_t)(lane < h.top_n ? lane : 0) * h.top_stride];
+}
+__device__ __forceinline__ Cnt2 hier_total_sum(const Hier& h, uint64_t w)
+{
+    if (lane_id() >= h.top_n) w = 0;
     return Cnt2{wave_sum_u32(cnt_n0(w)), wave_sum_u32(cnt_n1(w))};
 }
+__device__ __forceinline__ Cnt2 hier_total(const Hier& h) { return hier_total_sum(h, hier_total_fetch(h)); }
 
 // Largest tile c in [0, nb) whose first owned output G(prefix(c)) is <= g (0 when there is none), with its exclusive prefix
 // counts: top-down descent, one load + one scan per level.  Wave-uniform; the last resort of the ancestor search (tile masses so
@@ -149,6 +165,17 @@ __device__ __forceinline__ int hier_locate(const HierTable* __restrict__ ht, int
     return blk;
 }
 
+// What a probe of the tiles around `at` reads: the hierarchy words of tile cs = max(at - 1, 0)'s prefix and four tile entries.
+struct ProbeWords { uint64_t lvl[kHierMaxLevels]; uint64_t we; };
+__device__ __forceinline__ void probe_fetch(const Hier& h, int at, int nb, ProbeWords& w)
+{
+    const int cs = at > 0 ? at - 1 : 0;
+    hier_prefix_fetch(h, cs, w.lvl);
+    const int lane = lane_id();
+    const int i = cs + (lane < 4 ? lane : 0);
+    w.we = h.lvl[0][i < nb ? i : nb - 1];
+}
+
 struct CountsLds {
     int32_t slot[kTile];        // scatter slots of the output tile
     uint32_t scan[2][kWaves];   // packed per-wave totals of the in-tile scan, double-buffered across source tiles
@@ -159,11 +186,12 @@ struct CountsLds {
 // -1 where the ancestor belongs to a shard that precedes this one; outputs at or beyond o_hi = G(all local sources) belong to the
 // shards that follow (the caller tests that).  `guess` = a tile expected to hold the first ancestor; raw_m1 / raw_0 / raw_p1 = the
 // states of tiles guess-1, guess, guess+1 fetched at kernel entry (an output tile overlaps two of them almost surely, so no
-// load waits for the search).  Slots must hold -1 and be visible (the caller's barrier) on entry.
-template <class S>
+// load waits for the search); `first` = the words of the probe at `guess`, fetched there too (nullptr: fetched here).  Slots must
+// hold -1 and be visible (the caller's barrier) on entry.
+template <class S, bool sharded>
 __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& tc, const S* __restrict__ states, int64_t n, int nb,
-                                                 bool last_shard, double gj_first, int n_out, int guess, uint32_t raw_m1, uint32_t raw_0,
-                                                 uint32_t raw_p1, int32_t (&anc)[kPPT], CountsLds& L)
+                                                 bool last_shard, double gj_first, int n_out, int guess, const ProbeWords* first,
+                                                 uint32_t raw_m1, uint32_t raw_0, uint32_t raw_p1, int32_t (&anc)[kPPT], CountsLds& L)
 {
     static_assert(sizeof(S) == 1 && kPPT == 4, "states travel as one byte: 4 per lane = one dword");
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
@@ -172,19 +200,19 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
     // ---- which source tile owns the first output?  Probe the tiles around `at`: one hierarchical sum gives the prefix counts of
     //      tile cs = max(at - 1, 0), four tile entries those of cs+1 .. cs+4, and lane i evaluates the first output of tile cs + i.
     //      d_out = how far (in outputs) the first output lies from tile cs's: the next probe's aim when this one misses. ----
-    int c = 0;
+    //      The same five values tell the LAST source tile this output tile draws from (c_last; nb when it lies beyond them).
+    int c = 0, c_last = nb;
     Cnt2 P{0, 0};
-    auto probe = [&](int at, double& d_out) -> bool {
+    auto probe = [&](int at, const ProbeWords& pw, double& d_out) -> bool {
         const int cs = at > 0 ? at - 1 : 0;
-        const Cnt2 Pc = hier_prefix(h, cs);
-        uint64_t we = 0;
-        if (lane < 4 && cs + lane < nb) we = h.lvl[0][cs + lane];
+        const Cnt2 Pc = hier_prefix_sum(cs, pw.lvl);
+        const uint64_t we = (lane < 4 && cs + lane < nb) ? pw.we : 0ull;
         const uint32_t v0 = cnt_n0(we), v1 = cnt_n1(we);
         const uint32_t i0 = wave_incl_scan_u32(v0), i1 = wave_incl_scan_u32(v1);
-        const uint32_t x0 = Pc.n0 + i0 - v0, x1 = Pc.n1 + i1 - v1;        // lanes 0..4: the prefix at cs + lane (lanes >= 4 loaded zeros)
+        const uint32_t x0 = Pc.n0 + i0 - v0, x1 = Pc.n1 + i1 - v1;        // lanes 0..4: the prefix at cs + lane (lanes >= 4 hold zeros)
         const double gt = tc.g_at(x0, x1, nvalid_before(cs + lane));
-        const bool ok = lane < 5 && cs + lane < nb && gt <= gj_first;
-        const unsigned long long m = __ballot(ok);
+        const bool known = lane < 5 && cs + lane < nb;
+        const unsigned long long m = __ballot(known && gt <= gj_first);
         const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
         d_out = gj_first - read_lane(gt, 0);
         if ((i_lo >= 0 || cs == 0) && i_lo < 4) {
@@ -192,17 +220,26 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
             c = cs + i;
             P.n0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, i);
             P.n1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, i);
+            // (G is monotone in the tile index: the tiles that start at or before the last output form a prefix of the five)
+            const unsigned long long mh = __ballot(known && gt <= gj_last);
+            const int i_hi = mh ? (63 - __builtin_clzll(mh)) : i;
+            c_last = (i_hi >= 4 && cs + 5 < nb) ? nb : cs + (i_hi > i ? i_hi : i);
             return true;
         }
         return false;
     };
     double d;
-    if (!probe(guess, d)) {
+    bool hit;
+    if (first) hit = probe(guess, *first, d);
+    else { ProbeWords pw; probe_fetch(h, guess, nb, pw); hit = probe(guess, pw, d); }
+    if (!hit) {
         // tile masses are nearly even, so the miss distance in outputs is the miss distance in tiles (x 1024) up to a few tiles:
         // aim again (large populations: the CDF wanders sqrt(N) outputs off the diagonal), then descend from the top
         const double aim = (double)(guess > 0 ? guess - 1 : 0) + floor(d * (1.0 / kTile));
         const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
-        if (!probe(at, d)) c = hier_locate(h.table, h.copy, tc, n, gj_first, P);
+        ProbeWords pw;
+        probe_fetch(h, at, nb, pw);
+        if (!probe(at, pw, d)) { c = hier_locate(h.table, h.copy, tc, n, gj_first, P); c_last = nb; }
     }
     // ---- walk the source tiles that own outputs of this tile ----
     auto load_states = [&](int cc) -> uint32_t {
@@ -212,12 +249,13 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
         return cc < nb ? *reinterpret_cast<const uint32_t*>(states + (int64_t)cc * kTile + (int64_t)tid * kPPT) : 0u;
     };
     c = __builtin_amdgcn_readfirstlane(c);
+    c_last = __builtin_amdgcn_readfirstlane(c_last);
     uint32_t raw = load_states(c);
     int it = 0;
     while (c < nb) {
         // (wave-uniform values -- the branch is made scalar so that the barrier inside the loop sits in uniform control flow)
         if (__builtin_amdgcn_readfirstlane(tc.g_at(P.n0, P.n1, nvalid_before(c)) > gj_last ? 1 : 0)) break;   // the tile's sources start beyond this output tile
-        const uint32_t raw_next = load_states(c + 1);                    // (beyond the prefetched three: travels while this tile is processed)
+        const uint32_t raw_next = c < c_last ? load_states(c + 1) : 0u;  // (beyond the prefetched three: travels while this tile is processed)
         const int64_t i0 = (int64_t)c * kTile + (int64_t)tid * kPPT;
         // per-lane inclusive counts of states 0 / 1, packed 16 + 16 bits
         uint32_t q[kPPT];
@@ -242,15 +280,19 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
         }
         ++it;
         const uint32_t excl = off + incl - run;                           // packed exclusive prefix of this lane
-        const double b0 = tc.base0 + (double)P.n0, b1 = tc.base1 + (double)P.n1;     // (uniform)
-        const double bv = tc.basev + (double)nvalid_before(c);
+        // counts enter the CDF as exact integers: summed as integers, converted once (any association of exact integers below
+        // 2^53 is the same double, so this IS the stated arithmetic)
         const int64_t nv_tile = n - (int64_t)c * kTile;                  // valid particles from this tile on (>= 1)
         const int nvt = nv_tile < kTile ? (int)nv_tile : kTile;
+        const uint32_t nvb = (uint32_t)nvalid_before(c);                 // local particles before this tile (< 2^31)
         const int vb = tid * kPPT;                                       // particles of this tile before the lane's first
+        const double base2 = tc.basev - tc.base0 - tc.base1;             // (uniform; zero on a single shard)
         auto gk = [&](uint32_t packed, int upto) -> double {             // G after `upto` particles of the tile, `packed` of them in states 0 / 1
-            const double c0 = b0 + (double)(packed & 0xffffu), c1 = b1 + (double)(packed >> 16);
-            const double cv = bv + (double)(upto < nvt ? upto : nvt);
-            return tc.g(tc.cdf(c0, c1, cv));
+            const uint32_t n0 = P.n0 + (packed & 0xffffu), n1 = P.n1 + (packed >> 16);
+            const uint32_t n2 = nvb + (uint32_t)(upto < nvt ? upto : nvt) - n0 - n1;
+            double c0 = (double)n0, c1 = (double)n1, c2 = (double)n2;
+            if (sharded) { c0 += tc.base0; c1 += tc.base1; c2 += base2; }
+            return tc.g(fma(c2, tc.e2, fma(c1, tc.e1, __dmul_rn(c0, tc.e0))));
         };
         double g_prev = gk(excl, vb);
 #pragma unroll
@@ -340,25 +382,38 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     static_assert(Model::kWeightTable == 3, "prefix-count form: three table values (two stored counts)");
     __shared__ CountsLds L;
     __shared__ int s_cnt[kWaves * 4];
+    __shared__ __attribute__((aligned(16))) uint64_t s_model[Model::kStagedWords];
     const int tid = threadIdx.x;
     const int nb = (int)gridDim.x;
     const int bid = xcd_contiguous_tile((int)blockIdx.x, nb);
     const int64_t j0 = (int64_t)bid * kTile + (int64_t)tid * kPPT;
     const int t = a.t;
 
+    // Everything the prologue reads from memory is addressed by the launch geometry alone -- the states of the source tiles this
+    // output tile almost surely descends from (its own index and both neighbours), the generation's totals, the words of the
+    // ancestor search's first probe: fetched here, in one round trip that the random draws below cover.
+    const S* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs;
+    uint32_t raw_0 = 0, raw_m1 = 0, raw_p1 = 0;
+    uint64_t w_tot = 0;
+    ProbeWords pw0{};
+    if (t > 0) {
+        raw_0 = *reinterpret_cast<const uint32_t*>(prev_row + j0);
+        raw_m1 = *reinterpret_cast<const uint32_t*>(prev_row + (bid > 0 ? j0 - kTile : j0));
+        raw_p1 = *reinterpret_cast<const uint32_t*>(prev_row + (bid + 1 < nb ? j0 + kTile : j0));
+        w_tot = hier_total_fetch(a.h);
+        probe_fetch(a.h, bid, nb, pw0);
+    }
     typename Model::Rand rnd[kPPT / 4];
 #pragma unroll
     for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
-    const S* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs;
 
     int32_t anc[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) anc[k] = (int32_t)(j0 + k);
     if (t > 0) {
-        // the states of the source tiles this output tile almost surely descends from: its own index and both neighbours
-        const uint32_t raw_0 = *reinterpret_cast<const uint32_t*>(prev_row + j0);
-        const uint32_t raw_m1 = bid > 0 ? *reinterpret_cast<const uint32_t*>(prev_row + j0 - kTile) : 0u;
-        const uint32_t raw_p1 = bid + 1 < nb ? *reinterpret_cast<const uint32_t*>(prev_row + j0 + kTile) : 0u;
+        if (bid == 0) raw_m1 = 0u;
+        if (bid + 1 >= nb) raw_p1 = 0u;
+        if (tid == 0) Model::stage(a.mp, s_model);                 // (visible after the barrier below)
         {
             int32_t neg[kPPT];
             lane_fill(neg, (int32_t)-1);
@@ -379,7 +434,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
             tot0 = wave_sum(r0); tot1 = wave_sum(r1);              // (sums of integers below 2^53: exact in any order)
             last_shard = a.rank + 1 == a.world;
         } else {
-            const Cnt2 tl = hier_total(a.h);
+            const Cnt2 tl = hier_total_sum(a.h, w_tot);
             tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
             tot0 = (double)tl.n0; tot1 = (double)tl.n1;
         }
@@ -407,11 +462,11 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         // (a shard of a joint population draws the population's outputs; a population of its own -- islands included, whose pid0
         //  only selects RNG streams -- draws its own)
         const double gj_first = SHARDED ? (double)(a.pid0 + (uint64_t)bid * kTile) : (double)((uint64_t)bid * kTile);
-        ancestors_counts<S>(a.h, tc, prev_row, a.n, nb, last_shard, gj_first, n_out, bid, raw_m1, raw_0, raw_p1, anc, L);
+        ancestors_counts<S, SHARDED>(a.h, tc, prev_row, a.n, nb, last_shard, gj_first, n_out, bid, &pw0, raw_m1, raw_0, raw_p1, anc, L);
         if (SHARDED) {
             // outputs below o_lo / at or beyond o_hi descend from other shards' sources: their lineages arrived as annex columns,
             // in output order (cpprob_hip exchange commit)
-            const Cnt2 tl = hier_total(a.h);
+            const Cnt2 tl = hier_total_sum(a.h, w_tot);
             const double o_lo = tc.g_at(0, 0, 0), o_hi = last_shard ? a.n_pop : tc.g_at(tl.n0, tl.n1, a.n);
             const double sb = (double)a.pid0;
             const int64_t l0 = (int64_t)fmin(fmax(o_lo - sb, 0.0), (double)a.n), l1 = (int64_t)fmin(fmax(o_hi - sb, 0.0), (double)a.n);
@@ -432,7 +487,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>(prev_row[anc[k]]) : V(0);                 // ancestor's state (sorted gather)
 #pragma unroll
     for (int q = 0; q < kPPT / 4; ++q)                                                        // sample #t
-        Model::apply4(a.mp, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
+        Model::apply4_staged(s_model, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
     bool valid[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
