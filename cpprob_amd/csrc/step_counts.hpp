@@ -252,18 +252,21 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
     c_last = __builtin_amdgcn_readfirstlane(c_last);
     uint32_t raw = load_states(c);
     int it = 0;
-    while (c < nb) {
-        // (wave-uniform values -- the branch is made scalar so that the barrier inside the loop sits in uniform control flow)
-        if (__builtin_amdgcn_readfirstlane(tc.g_at(P.n0, P.n1, nvalid_before(c)) > gj_last ? 1 : 0)) break;   // the tile's sources start beyond this output tile
-        const uint32_t raw_next = c < c_last ? load_states(c + 1) : 0u;  // (beyond the prefetched three: travels while this tile is processed)
-        const int64_t i0 = (int64_t)c * kTile + (int64_t)tid * kPPT;
+    const double base2 = tc.basev - tc.base0 - tc.base1;                 // (uniform; zero on a single shard)
+    // One source tile: in-tile scan of the state counts, G at the lane's five particle boundaries, one slot per source that owns an
+    // output of this tile.  EDGE = the shard's last tile (the only one that may be partly valid or hold the population's last
+    // source): every other tile runs the form without those tests.
+    auto tile = [&](auto edge_tag, uint32_t raw_c) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const int vb = tid * kPPT;                                       // particles of this tile before the lane's first
+        const int nvt = EDGE ? (int)(n - (int64_t)c * kTile) : kTile;    // valid particles of this tile (>= 1)
         // per-lane inclusive counts of states 0 / 1, packed 16 + 16 bits
         uint32_t q[kPPT];
         uint32_t run = 0;
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
-            const uint32_t s = (raw >> (8 * k)) & 0xffu;
-            const bool valid = i0 + k < n;
+            const uint32_t s = (raw_c >> (8 * k)) & 0xffu;
+            const bool valid = !EDGE || vb + k < nvt;
             run += (valid && s == 0) ? 1u : 0u;
             run += (valid && s == 1) ? 0x10000u : 0u;
             q[k] = run;
@@ -278,34 +281,37 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
             if (w < wv) off += s;
             tot += s;
         }
-        ++it;
-        const uint32_t excl = off + incl - run;                           // packed exclusive prefix of this lane
+        const uint32_t excl = off + incl - run;                          // packed exclusive prefix of this lane
         // counts enter the CDF as exact integers: summed as integers, converted once (any association of exact integers below
-        // 2^53 is the same double, so this IS the stated arithmetic)
-        const int64_t nv_tile = n - (int64_t)c * kTile;                  // valid particles from this tile on (>= 1)
-        const int nvt = nv_tile < kTile ? (int)nv_tile : kTile;
+        // 2^53 is the same double, so this IS the stated arithmetic).  What leaves is the output's place in THIS tile, clamped to
+        // [0, kTile]: a source owns outputs here iff its clamped end exceeds its clamped start, which is then its first slot.
         const uint32_t nvb = (uint32_t)nvalid_before(c);                 // local particles before this tile (< 2^31)
-        const int vb = tid * kPPT;                                       // particles of this tile before the lane's first
-        const double base2 = tc.basev - tc.base0 - tc.base1;             // (uniform; zero on a single shard)
-        auto gk = [&](uint32_t packed, int upto) -> double {             // G after `upto` particles of the tile, `packed` of them in states 0 / 1
+        auto place = [&](double g) -> int { return (int)fmin(fmax(g - gj_first, 0.0), (double)kTile); };      // exact: integers
+        auto gk = [&](uint32_t packed, int upto) -> int {                // after `upto` particles of the tile, `packed` of them in states 0 / 1
             const uint32_t n0 = P.n0 + (packed & 0xffffu), n1 = P.n1 + (packed >> 16);
-            const uint32_t n2 = nvb + (uint32_t)(upto < nvt ? upto : nvt) - n0 - n1;
+            const uint32_t n2 = nvb + (uint32_t)(EDGE && upto > nvt ? nvt : upto) - n0 - n1;
             double c0 = (double)n0, c1 = (double)n1, c2 = (double)n2;
             if (sharded) { c0 += tc.base0; c1 += tc.base1; c2 += base2; }
-            return tc.g(fma(c2, tc.e2, fma(c1, tc.e1, __dmul_rn(c0, tc.e0))));
+            return place(tc.g(fma(c2, tc.e2, fma(c1, tc.e1, __dmul_rn(c0, tc.e0)))));
         };
-        double g_prev = gk(excl, vb);
+        const int src0 = c * kTile + vb;
+        const int p_all = EDGE && last_shard ? place(tc.n_pop) : 0;
+        int p_prev = gk(excl, vb);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
-            double g = gk(excl + q[k], vb + k + 1);
-            if (last_shard && i0 + k + 1 == n) g = tc.n_pop;             // the population's last source owns the rest
-            if (g > g_prev) {
-                const double s = g_prev - gj_first, e = g - gj_first;    // exact: integers
-                if (e > 0.0 && s < (double)kTile) L.slot[s > 0.0 ? (int)s : 0] = (int32_t)(i0 + k);
-                g_prev = g;
-            }
+            int p = gk(excl + q[k], vb + k + 1);
+            if (EDGE && last_shard && vb + k + 1 == nvt) p = p_all;      // the population's last source owns the rest
+            if (p > p_prev) { L.slot[p_prev] = src0 + k; p_prev = p; }
         }
         P.n0 += tot & 0xffffu; P.n1 += tot >> 16;
+    };
+    while (c < nb && c <= c_last) {
+        // (wave-uniform values -- the branches are made scalar so that the barrier inside the loop sits in uniform control flow)
+        if (c_last >= nb &&                                              // the last tile is not known from the probe: test where this one starts
+            __builtin_amdgcn_readfirstlane(tc.g_at(P.n0, P.n1, nvalid_before(c)) > gj_last ? 1 : 0)) break;
+        const uint32_t raw_next = c < c_last ? load_states(c + 1) : 0u;  // (beyond the prefetched three: travels while this tile is processed)
+        if (c == nb - 1) tile(std::true_type{}, raw); else tile(std::false_type{}, raw);
+        ++it;
         raw = raw_next;
         ++c;
     }
