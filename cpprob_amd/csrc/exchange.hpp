@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                     store4(Lc.slot, (int64_t)tid * kPPT, neg);
                 }
                 __syncthreads();
-                ancestors_counts<S, true>(a.h, tc, a.values + (int64_t)a.t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, -16, nullptr, 0u, 0u, 0u, anc, Lc);
+                ancestors_counts<S, true>(a.h, tc, a.values + (int64_t)a.t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, -16, anc, Lc);
             } else {
                 AncestorIn in;
                 in.wrel = a.wrel; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n;

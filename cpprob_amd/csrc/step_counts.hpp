@@ -184,23 +184,23 @@ struct CountsLds {
 
 // Ancestors of the kTile consecutive outputs starting at global output index gj_first (n_out of them), among THIS shard's sources,
 // -1 where the ancestor belongs to a shard that precedes this one; outputs at or beyond o_hi = G(all local sources) belong to the
-// shards that follow (the caller tests that).  `guess` = a tile expected to hold the first ancestor; raw_m1 / raw_0 / raw_p1 = the
-// states of tiles guess-1, guess, guess+1 fetched at kernel entry (an output tile overlaps two of them almost surely, so no
-// load waits for the search); `first` = the words of the probe at `guess`, fetched there too (nullptr: fetched here).  Slots must
-// hold -1 and be visible (the caller's barrier) on entry.
-template <class S, bool sharded>
-__device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& tc, const S* __restrict__ states, int64_t n, int nb,
-                                                 bool last_shard, double gj_first, int n_out, int guess, const ProbeWords* first,
-                                                 uint32_t raw_m1, uint32_t raw_0, uint32_t raw_p1, int32_t (&anc)[kPPT], CountsLds& L)
+// shards that follow (the caller tests that).  Two parts: the SEARCH for the source tiles involved (counts_locate: the work of one
+// wavefront, uniform over the workgroup) and the WALK over them (counts_walk: the whole workgroup).
+//
+// counts_locate.  `guess` = a tile expected to hold the first ancestor; `first` = the words of the probe at `guess`, fetched by the
+// caller ahead of time (nullptr: fetched here).  Returns the first source tile c, its exclusive prefix counts, and the last source
+// tile c_last (nb when the probe cannot tell).
+struct Located { int c, c_last; uint32_t p0, p1; };
+__device__ __forceinline__ Located counts_locate(const Hier& h, const TableCdf& tc, int64_t n, int nb, double gj_first, int n_out, int guess,
+                                                 const ProbeWords* first)
 {
-    static_assert(sizeof(S) == 1 && kPPT == 4, "states travel as one byte: 4 per lane = one dword");
-    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int lane = lane_id();
     const double gj_last = gj_first + (double)(n_out - 1);
     auto nvalid_before = [&](int c) -> int64_t { const int64_t v = (int64_t)c * kTile; return v < n ? v : n; };
-    // ---- which source tile owns the first output?  Probe the tiles around `at`: one hierarchical sum gives the prefix counts of
-    //      tile cs = max(at - 1, 0), four tile entries those of cs+1 .. cs+4, and lane i evaluates the first output of tile cs + i.
-    //      d_out = how far (in outputs) the first output lies from tile cs's: the next probe's aim when this one misses. ----
-    //      The same five values tell the LAST source tile this output tile draws from (c_last; nb when it lies beyond them).
+    // Probe the tiles around `at`: one hierarchical sum gives the prefix counts of tile cs = max(at - 1, 0), four tile entries those
+    // of cs+1 .. cs+4, and lane i evaluates the first output of tile cs + i.  d_out = how far (in outputs) the first output lies
+    // from tile cs's: the next probe's aim when this one misses.  The same five values tell the LAST source tile this output tile
+    // draws from.
     int c = 0, c_last = nb;
     Cnt2 P{0, 0};
     auto probe = [&](int at, const ProbeWords& pw, double& d_out) -> bool {
@@ -241,6 +241,23 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
         probe_fetch(h, at, nb, pw);
         if (!probe(at, pw, d)) { c = hier_locate(h.table, h.copy, tc, n, gj_first, P); c_last = nb; }
     }
+    return Located{c, c_last, P.n0, P.n1};
+}
+
+// counts_walk.  raw_m1 / raw_0 / raw_p1 = the states of tiles guess-1, guess, guess+1 fetched at kernel entry (an output tile
+// overlaps two of them almost surely, so no load waits for the search).  Slots must hold -1 and be visible (the caller's barrier)
+// on entry.
+template <class S, bool sharded>
+__device__ __forceinline__ void counts_walk(const TableCdf& tc, const S* __restrict__ states, int64_t n, int nb, bool last_shard, double gj_first,
+                                            int n_out, const Located& loc, int guess, uint32_t raw_m1, uint32_t raw_0, uint32_t raw_p1,
+                                            int32_t (&anc)[kPPT], CountsLds& L)
+{
+    static_assert(sizeof(S) == 1 && kPPT == 4, "states travel as one byte: 4 per lane = one dword");
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const double gj_last = gj_first + (double)(n_out - 1);
+    auto nvalid_before = [&](int c) -> int64_t { const int64_t v = (int64_t)c * kTile; return v < n ? v : n; };
+    int c = loc.c, c_last = loc.c_last;
+    Cnt2 P{loc.p0, loc.p1};
     // ---- walk the source tiles that own outputs of this tile ----
     auto load_states = [&](int cc) -> uint32_t {
         if (cc == guess) return raw_0;
@@ -332,6 +349,17 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
     for (int k = 0; k < kPPT; ++k) anc[k] = max(v[k], excl);
 }
 
+// Both parts in every wavefront (the exchange scope's packing, whose output tiles sit anywhere in the shard).
+template <class S, bool sharded>
+__device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& tc, const S* __restrict__ states, int64_t n, int nb,
+                                                 bool last_shard, double gj_first, int n_out, int guess, int32_t (&anc)[kPPT], CountsLds& L)
+{
+    const Located loc = counts_locate(h, tc, n, nb, gj_first, n_out, guess, nullptr);
+    counts_walk<S, sharded>(tc, states, n, nb, last_shard, gj_first, n_out, loc, guess, 0u, 0u, 0u, anc, L);
+}
+
+struct StepFound { Located loc; double inv, base0, base1, basev; int64_t l0, l1; };      // what the searching wavefront hands the other three
+
 template <class Model>
 struct StepCountsArgs {
     ModelParams mp; int t, T; int64_t n, ld, rs;
@@ -389,6 +417,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     __shared__ CountsLds L;
     __shared__ int s_cnt[kWaves * 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_model[Model::kStagedWords];
+    __shared__ __attribute__((aligned(16))) StepFound s_found;
     const int tid = threadIdx.x;
     const int nb = (int)gridDim.x;
     const int bid = xcd_contiguous_tile((int)blockIdx.x, nb);
@@ -396,18 +425,27 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     const int t = a.t;
 
     // Everything the prologue reads from memory is addressed by the launch geometry alone -- the states of the source tiles this
-    // output tile almost surely descends from (its own index and both neighbours), the generation's totals, the words of the
-    // ancestor search's first probe: fetched here, in one round trip that the random draws below cover.
+    // output tile almost surely descends from (its own index and both neighbours) and, in the workgroup's first wavefront (which
+    // searches for all four), the generation's totals and the words of the search's first probe: fetched here, in one round trip
+    // that the random draws below cover.
     const S* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs;
+    const bool searcher = wave_id() == 0;
     uint32_t raw_0 = 0, raw_m1 = 0, raw_p1 = 0;
     uint64_t w_tot = 0;
     ProbeWords pw0{};
+    double r0 = 0.0, r1 = 0.0, rv = 0.0;
     if (t > 0) {
         raw_0 = *reinterpret_cast<const uint32_t*>(prev_row + j0);
         raw_m1 = *reinterpret_cast<const uint32_t*>(prev_row + (bid > 0 ? j0 - kTile : j0));
         raw_p1 = *reinterpret_cast<const uint32_t*>(prev_row + (bid + 1 < nb ? j0 + kTile : j0));
-        w_tot = hier_total_fetch(a.h);
-        probe_fetch(a.h, bid, nb, pw0);
+        if (searcher) {
+            w_tot = hier_total_fetch(a.h);
+            probe_fetch(a.h, bid, nb, pw0);
+            if (SHARDED) {
+                const int r = tid < a.world ? tid : 0;
+                r0 = a.all_totals[3 * r]; r1 = a.all_totals[3 * r + 1]; rv = a.all_totals[3 * r + 2];
+            }
+        }
     }
     typename Model::Rand rnd[kPPT / 4];
 #pragma unroll
@@ -419,63 +457,76 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     if (t > 0) {
         if (bid == 0) raw_m1 = 0u;
         if (bid + 1 >= nb) raw_p1 = 0u;
-        if (tid == 0) Model::stage(a.mp, s_model);                 // (visible after the barrier below)
         {
             int32_t neg[kPPT];
             lane_fill(neg, (int32_t)-1);
             store4(L.slot, (int64_t)tid * kPPT, neg);
         }
-        // ---- the generation's totals and this shard's place in the joint population (every wave, identically) ----
-        const double mref = a.e_prev[3];
-        TableCdf tc;
-        tc.e0 = a.e_prev[0]; tc.e1 = a.e_prev[1]; tc.e2 = a.e_prev[2]; tc.n_pop = a.n_pop;
-        double tot0, tot1;
-        bool last_shard = true;
-        if (SHARDED) {
-            const int lane = lane_id();
-            double r0 = 0.0, r1 = 0.0, rv = 0.0;
-            if (lane < a.world) { r0 = a.all_totals[3 * lane]; r1 = a.all_totals[3 * lane + 1]; rv = a.all_totals[3 * lane + 2]; }
-            const bool before = lane < a.rank;
-            tc.base0 = wave_sum(before ? r0 : 0.0); tc.base1 = wave_sum(before ? r1 : 0.0); tc.basev = wave_sum(before ? rv : 0.0);
-            tot0 = wave_sum(r0); tot1 = wave_sum(r1);              // (sums of integers below 2^53: exact in any order)
-            last_shard = a.rank + 1 == a.world;
-        } else {
-            const Cnt2 tl = hier_total_sum(a.h, w_tot);
-            tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
-            tot0 = (double)tl.n0; tot1 = (double)tl.n1;
-        }
-        tc.e0 = in_vgpr(tc.e0); tc.e1 = in_vgpr(tc.e1); tc.e2 = in_vgpr(tc.e2);
-        const double W = tc.cdf(tot0, tot1, tc.n_pop);
-        tc.inv = in_vgpr(a.n_pop / W);
-        tc.u0 = in_vgpr(a.u0);
-        if (bid == 0 && tid == 0) {                                // bookkeeping of step t-1 for the host: ESS (thesis p.37), evidence
-            const double tot2 = a.n_pop - tot0 - tot1;
-            const double Q = fma(tot2, __dmul_rn(tc.e2, tc.e2), fma(tot1, __dmul_rn(tc.e1, tc.e1), __dmul_rn(tot0, __dmul_rn(tc.e0, tc.e0))));
-            const double ess = W * W / Q;
-            StepCtrl* c = a.ctrl;
-            c->M = mref; c->W = W; c->Q = Q; c->ess = ess; c->do_resample = 1;
-            c->cdf_lo = 0.0; c->w_local = W; c->scale = 1.0; c->u0 = tc.u0; c->inv_stepw = tc.inv; c->lw_after = 0.0; c->inv_global = tc.inv;
-            double lz = (t == 1) ? 0.0 : c->log_z;
-            int nr = (t == 1) ? 0 : c->n_resampled;
-            lz += mref + log(W / a.n_pop); nr += 1;
-            c->log_z = lz; c->n_resampled = nr;
-            if (a.ess_trace) a.ess_trace[t - 1] = ess;
-            if (a.resampled) a.resampled[t - 1] = 1;
-        }
-        __syncthreads();                                           // slots reset
         const int64_t rem = a.n - (int64_t)bid * kTile;
         const int n_out = rem < kTile ? (int)rem : kTile;
         // (a shard of a joint population draws the population's outputs; a population of its own -- islands included, whose pid0
         //  only selects RNG streams -- draws its own)
         const double gj_first = SHARDED ? (double)(a.pid0 + (uint64_t)bid * kTile) : (double)((uint64_t)bid * kTile);
-        ancestors_counts<S, SHARDED>(a.h, tc, prev_row, a.n, nb, last_shard, gj_first, n_out, bid, &pw0, raw_m1, raw_0, raw_p1, anc, L);
+        const bool last_shard = SHARDED ? a.rank + 1 == a.world : true;
+        TableCdf tc;
+        tc.e0 = in_vgpr(a.e_prev[0]); tc.e1 = in_vgpr(a.e_prev[1]); tc.e2 = in_vgpr(a.e_prev[2]); tc.n_pop = a.n_pop;
+        tc.u0 = in_vgpr(a.u0);
+        tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
+        if (searcher) {
+            // ---- one wavefront: the generation's totals, this shard's place in the joint population, the source tiles this output
+            //      tile draws from; the other three pick the results up behind the barrier ----
+            const int lane = tid;
+            double tot0, tot1;
+            if (SHARDED) {
+                if (lane >= a.world) { r0 = 0.0; r1 = 0.0; rv = 0.0; }
+                const bool before = lane < a.rank;
+                tc.base0 = wave_sum(before ? r0 : 0.0); tc.base1 = wave_sum(before ? r1 : 0.0); tc.basev = wave_sum(before ? rv : 0.0);
+                tot0 = wave_sum(r0); tot1 = wave_sum(r1);              // (sums of integers below 2^53: exact in any order)
+            } else {
+                const Cnt2 tl = hier_total_sum(a.h, w_tot);
+                tot0 = (double)tl.n0; tot1 = (double)tl.n1;
+            }
+            const double W = tc.cdf(tot0, tot1, tc.n_pop);
+            tc.inv = in_vgpr(a.n_pop / W);
+            if (bid == 0 && tid == 0) {                            // bookkeeping of step t-1 for the host: ESS (thesis p.37), evidence
+                const double mref = a.e_prev[3];
+                const double tot2 = a.n_pop - tot0 - tot1;
+                const double Q = fma(tot2, __dmul_rn(tc.e2, tc.e2), fma(tot1, __dmul_rn(tc.e1, tc.e1), __dmul_rn(tot0, __dmul_rn(tc.e0, tc.e0))));
+                const double ess = W * W / Q;
+                StepCtrl* c = a.ctrl;
+                c->M = mref; c->W = W; c->Q = Q; c->ess = ess; c->do_resample = 1;
+                c->cdf_lo = 0.0; c->w_local = W; c->scale = 1.0; c->u0 = tc.u0; c->inv_stepw = tc.inv; c->lw_after = 0.0; c->inv_global = tc.inv;
+                double lz = (t == 1) ? 0.0 : c->log_z;
+                int nr = (t == 1) ? 0 : c->n_resampled;
+                lz += mref + log(W / a.n_pop); nr += 1;
+                c->log_z = lz; c->n_resampled = nr;
+                if (a.ess_trace) a.ess_trace[t - 1] = ess;
+                if (a.resampled) a.resampled[t - 1] = 1;
+            }
+            const Located loc = counts_locate(a.h, tc, a.n, nb, gj_first, n_out, bid, &pw0);
+            int64_t l0 = 0, l1 = 0;
+            if (SHARDED) {
+                // outputs below o_lo / at or beyond o_hi descend from other shards' sources
+                const Cnt2 tl = hier_total_sum(a.h, w_tot);
+                const double o_lo = tc.g_at(0, 0, 0), o_hi = last_shard ? a.n_pop : tc.g_at(tl.n0, tl.n1, a.n);
+                const double sb = (double)a.pid0;
+                l0 = (int64_t)fmin(fmax(o_lo - sb, 0.0), (double)a.n); l1 = (int64_t)fmin(fmax(o_hi - sb, 0.0), (double)a.n);
+            }
+            if (tid == 0) {
+                s_found.loc = loc; s_found.inv = tc.inv; s_found.base0 = tc.base0; s_found.base1 = tc.base1; s_found.basev = tc.basev;
+                s_found.l0 = l0; s_found.l1 = l1;
+                Model::stage(a.mp, s_model);
+            }
+        }
+        __syncthreads();                                           // slots reset, search results and the model's table in place
+        const Located loc = s_found.loc;
+        tc.inv = s_found.inv;
+        if (SHARDED) { tc.base0 = s_found.base0; tc.base1 = s_found.base1; tc.basev = s_found.basev; }
+        counts_walk<S, SHARDED>(tc, prev_row, a.n, nb, last_shard, gj_first, n_out, loc, bid, raw_m1, raw_0, raw_p1, anc, L);
         if (SHARDED) {
-            // outputs below o_lo / at or beyond o_hi descend from other shards' sources: their lineages arrived as annex columns,
-            // in output order (cpprob_hip exchange commit)
-            const Cnt2 tl = hier_total_sum(a.h, w_tot);
-            const double o_lo = tc.g_at(0, 0, 0), o_hi = last_shard ? a.n_pop : tc.g_at(tl.n0, tl.n1, a.n);
-            const double sb = (double)a.pid0;
-            const int64_t l0 = (int64_t)fmin(fmax(o_lo - sb, 0.0), (double)a.n), l1 = (int64_t)fmin(fmax(o_hi - sb, 0.0), (double)a.n);
+            // the lineages of the outputs other shards' sources own arrived as annex columns, in output order (cpprob_hip exchange
+            // commit)
+            const int64_t l0 = s_found.l0, l1 = s_found.l1;
             const int64_t col0 = a.ld + a.annex_base[t - 1];
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
