@@ -51,6 +51,7 @@ struct cpprob_hip_ctx {
     double* d_logw[2] = {nullptr, nullptr};
     double* d_wrel[2] = {nullptr, nullptr};
     double* d_bf = nullptr;
+    bool final_from_counts = false, final_bookkeep_pending = false; int final_copy = 0;   // prefix-count form, single shard: the read-out works from the final generation's counts
     double* d_ll_tab = nullptr;     // hmm: [T][3] emission log-densities
     void* d_values = nullptr;
     int32_t* d_anc = nullptr;
@@ -428,7 +429,6 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         StepCountsArgs<Model> a{};
         a.mp = c->mp; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
         a.values = static_cast<typename Model::store_t*>(c->d_values); a.anc = c->d_anc;
-        a.logw_next = c->d_logw[0]; a.wrel_next = c->d_wrel[0]; a.part = c->d_part[0];
         {
             if (t == 0) {
                 // a run that was abandoned half-way leaves the rotation in an unknown state: start over from clean copies
@@ -438,30 +438,32 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
             const int kp = (t + c->hier_phase_run) % 3, kn = (kp + 1) % 3, kc = (kp + 2) % 3;
             hier_view(c, kp, a.h);
             a.h.to_next = (int64_t)(kn - kp) * (int64_t)c->hier_per_copy; a.h.to_clear = (int64_t)(kc - kp) * (int64_t)c->hier_per_copy;
+            if (t == 0) c->final_from_counts = false;
             if (t + 1 == c->T) {
-                // after the last step exactly one copy is dirty -- the one it read; the next run starts its rotation there, so the copy
-                // its step 0 adds into is clean without any clearing launch
-                if (c->T >= 2) c->hier_phase = kp;
+                // The last step is a step like any other (the read-out works from the counts it leaves): the copy it read and the one
+                // it wrote are dirty, the one it cleared is where the next run's step 0 writes -- the next run starts its rotation
+                // there, without any clearing launch.
+                c->hier_phase = kn; c->final_from_counts = true; c->final_copy = kn; c->final_bookkeep_pending = true;
                 c->hier_run_open = false;
             }
-
         }
         a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
         a.all_totals = all_totals; a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
-        for (int k = 0; k < 4; ++k) { a.e_prev[k] = t > 0 ? c->h_e_tab[(size_t)(t - 1) * 4 + k] : 0.0; a.e_cur[k] = c->h_e_tab[(size_t)t * 4 + k]; }
-        for (int k = 0; k < 3; ++k) a.ll_cur[k] = c->h_ll_tab[(size_t)t * 3 + k];
+        for (int k = 0; k < 4; ++k) a.e_prev[k] = t > 0 ? c->h_e_tab[(size_t)(t - 1) * 4 + k] : 0.0;
         a.u0 = t > 0 ? host_resample_u0(c->run_seed, (uint64_t)t) : 0.0;
         ProfScope ps(c, 0);
-        const bool last = t + 1 == c->T, sharded = all_totals != nullptr;
-        if (sharded) {
-            if (last) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
-            else hipLaunchKernelGGL((smc_step_counts_kernel<Model, true, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
-        } else {
-            if (last) hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
-            else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
-        }
-        if (t + 1 == c->T) { c->cur = 0; c->cur_part = 0; }        // the last step left logw / wrel / partials in buffer 0
+        if (all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        if (t + 1 == c->T) { c->cur = 0; c->cur_part = 0; }
     }
+}
+
+// The final generation's counts, as the read-out and the joint bookkeeping see them.
+static void counts_final_view(cpprob_hip_ctx* c, CountsFinal& f, bool bookkeep)
+{
+    hier_view(c, c->final_copy, f.h);
+    for (int k = 0; k < 4; ++k) f.e[k] = c->h_e_tab[(size_t)(c->T - 1) * 4 + k];
+    f.n_pop = (double)c->pop_n; f.T = c->T; f.bookkeep = bookkeep ? 1 : 0; f.ctrl = c->d_ctrl; f.ess_trace = c->d_ess; f.resampled = c->d_resampled;
 }
 
 void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, int world, int rank)
@@ -497,7 +499,17 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
     const size_t shm = (size_t)kWaves * c->T * Model::kStats * sizeof(double);
     {
         ProfScope ps(c, 2);
-        hipLaunchKernelGGL(smooth_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a);
+        bool launched = false;
+        if constexpr (Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1) {
+            if (c->final_from_counts) {
+                CountsFinal f{};
+                counts_final_view(c, f, c->final_bookkeep_pending && !with_paths);
+                if (!with_paths) c->final_bookkeep_pending = false;
+                hipLaunchKernelGGL(smooth_counts_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a, f);
+                launched = true;
+            }
+        }
+        if (!launched) hipLaunchKernelGGL(smooth_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a);
     }
     ProfScope ps(c, 3);
     hipLaunchKernelGGL(finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream,
@@ -785,6 +797,7 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     c->run_seed = c->cfg.seed + run_index;
     c->cur = 0; c->cur_part = 0;
     c->sharded = false;
+    c->final_from_counts = false;
     bool readout_done = false, sis_bounded = false;
     (void)sis_bounded;
     if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
@@ -808,7 +821,7 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
                 for (int t = 0; t < c->T; ++t) dispatch_model(c, [&](auto m) { launch_step_counts<decltype(m)>(c, t, nullptr, 1, 0); });
                 c->profile_suspended = false;
             }
-            launch_scan(c, c->T - 1, 0, nullptr, 1, 0);
+            // (no normalisation launch: the read-out works from the final generation's counts)
         } else if (fused) {
             // the T step kernels run back to back: one event pair around the group
             {
@@ -841,6 +854,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     if (sis && t != c->T - 1) return fail(c, CPPROB_HIP_EINVAL, "SIS shards run in one launch: call step_begin(T-1) only");
     if (t == 0 || sis) {
         c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; c->annex_used = 0; c->plan.t = -1; c->x_plan_t = -1;
+        c->final_from_counts = false;
         c->counts_mode = false;
         if (!sis && c->exchange) dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); });
     }
@@ -850,16 +864,14 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     c->totals_out = d_local_totals;
     if (c->counts_mode) {
         // prefix-count form: the step consumes the all-gathered counts of generation t-1 itself; what leaves is this shard's
-        // {n_0, n_1, particles} (exact doubles) -- or, after the last step, {max, sum, sum of squares} for the read-out
+        // {n_0, n_1, particles} (exact doubles), after the last step too: the read-out works from the final generation's counts
         if (t > 0 && !c->x_all_totals) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_step_end(t-1) has not run");
         dispatch_model(c, [&](auto m) { launch_step_counts<decltype(m)>(c, t, t > 0 ? c->x_all_totals : nullptr, c->x_world, c->x_rank); });
-        if (t + 1 < c->T) {
+        {
             Hier h{};
             const int kn = (t + 1 + c->hier_phase_run) % 3;
             hier_view(c, kn, h);
             hipLaunchKernelGGL(counts_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals);
-        } else {
-            launch_scan(c, t, 1, nullptr, 1, 0);
         }
     } else {
         if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c, false); });
@@ -879,7 +891,15 @@ int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_to
     if (c->exchange && world > kMaxWorld) return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope plans on one wavefront: world <= 64");
     HIP_TRY(c, hipSetDevice(c->device));
     c->x_all_totals = d_all_totals; c->x_world = world; c->x_rank = rank;
-    if (!(c->counts_mode && t + 1 < c->T)) launch_scan(c, t, 2, d_all_totals, world, rank);
+    if (!c->counts_mode) launch_scan(c, t, 2, d_all_totals, world, rank);
+    else if (t + 1 == c->T) {
+        // the final generation's bookkeeping from the population's totals (the same sums a single GPU's hierarchy would hold)
+        if (world > kWave) return fail(c, CPPROB_HIP_EUNSUPPORTED, "the prefix-count form sums the ranks' totals on one wavefront: world <= 64");
+        CountsFinal f{};
+        counts_final_view(c, f, true);
+        hipLaunchKernelGGL(counts_final_ctrl_kernel, dim3(1), dim3(kWave), 0, c->stream, f, d_all_totals, world);
+        c->final_bookkeep_pending = false;
+    }
     HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -1222,6 +1242,19 @@ int cpprob_hip_copy_logw(cpprob_hip_ctx* c, double* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (c->final_from_counts) {
+        // the run kept no log-weight array (they are a function of the final states): write it out now
+        HIP_TRY(c, hipSetDevice(c->device));
+        dispatch_model(c, [&](auto m) {
+            using M = decltype(m);
+            if constexpr (M::kWeightTable == 3 && sizeof(typename M::store_t) == 1) {
+                const double* ll = &c->h_ll_tab[(size_t)(c->T - 1) * 3];
+                hipLaunchKernelGGL(logw_from_states_kernel<M>, dim3((unsigned)((c->ld + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
+                                   static_cast<const typename M::store_t*>(c->d_values) + (int64_t)(c->T - 1) * c->rs, c->n, c->ld, ll[0], ll[1], ll[2],
+                                   c->d_logw[c->cur]);
+            }
+        });
+    }
     return copy_rows(c, h, c->d_logw[c->cur], sizeof(double), 1, n_bytes, (size_t)c->ld);
 }
 

@@ -1540,27 +1540,25 @@ struct SmoothArgs {
     typename Model::value_t* paths;   // optional [T][ld]: materialised traces (dump / tests)
 };
 
-template <class Model>
-__global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
+// weight_of(tile, i) = the final weight of slot i (zero for padding slots), in the units finalize_kernel divides by.
+template <class Model, class WeightOf>
+__device__ __forceinline__ void smooth_body(const SmoothArgs<Model>& a, double* s_stat, WeightOf weight_of)
 {
     using V = typename Model::value_t;
     constexpr int K = Model::kStats;
-    extern __shared__ __attribute__((aligned(16))) double s_stat[];   // [kWaves][T*K]
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int TK = a.T * K;
     for (int i = tid; i < kWaves * TK; i += kThreads) s_stat[i] = 0.0;
     __syncthreads();
-    const double scale = a.ctrl->scale;
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     // (one XCD's workgroups walk neighbouring tiles: their lineages converge on the same ancestor rows)
     for (int64_t tile = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const double f = a.bf[tile] * scale;
         int32_t idx[kPPT]; double w[kPPT];
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
             const int64_t i = tile * kTile + (int64_t)k * kThreads + tid;   // lane-strided: coalesced first touch
             idx[k] = (int32_t)i;
-            w[k] = a.wrel[i] * f;                                            // padding slots: wrel = 0
+            w[k] = weight_of(tile, i);
         }
         for (int t = a.T - 1; t >= 0; --t) {
             double acc[K];
@@ -1593,6 +1591,14 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
         for (int w2 = 0; w2 < kWaves; ++w2) s += s_stat[w2 * TK + i];
         a.stats_part[(int64_t)i * gridDim.x + blockIdx.x] = s;
     }
+}
+
+template <class Model>
+__global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_stat[];   // [kWaves][T*K]
+    const double scale = a.ctrl->scale;
+    smooth_body<Model>(a, s_stat, [&](int64_t tile, int64_t i) { return a.wrel[i] * (a.bf[tile] * scale); });   // padding slots: wrel = 0
 }
 
 // Sums the per-workgroup partial statistics (layout [T*K][grid]) in a fixed order (bitwise

@@ -365,11 +365,9 @@ struct StepCountsArgs {
     ModelParams mp; int t, T; int64_t n, ld, rs;
     uint64_t seed, pid0;
     typename Model::store_t* values; int32_t* anc;
-    double* logw_next; double* wrel_next; Partial* part;       // written by the last step only (the read-out's inputs)
     Hier h;                                                     // generation t-1's counts (read); generation t's are written one copy further
     // host-evaluated per-step constants (kernel arguments: no memory round trip in front of the prologue)
     double e_prev[4];                                           // exp(ll_s - max ll) of step t-1, s = 0..2, then max ll
-    double e_cur[4], ll_cur[3];                                 // the same for step t, and the log-densities themselves (last step only)
     double u0;                                                  // systematic offset of the resampling before step t (Philox, evaluated on the host)
     StepCtrl* ctrl; double n_pop; double* ess_trace; int32_t* resampled;
     // one shard of a joint population (exchange scope): the all-gathered {n_0, n_1, particles} of every rank's generation t-1,
@@ -406,9 +404,9 @@ __device__ __forceinline__ void hier_publish(const Hier& h, int bid, int nb, uin
     if (h.n_lev >= 3 && (b2 << 12) == bid) l2[h.to_clear + (int64_t)b2 * kHierStride] = 0;
 }
 
-// SHARDED: one shard of a joint population (exchange scope).  LAST: the run's final step, which leaves what the read-out wants
-// instead of counts.  Compile-time forms: each keeps only the arguments it uses in scalar registers.
-template <class Model, bool SHARDED, bool LAST>
+// SHARDED: one shard of a joint population (exchange scope).  Compile-time forms: each keeps only the arguments it uses in scalar
+// registers.  The run's last step is a step like any other: the read-out works from the counts it leaves (smooth_counts_kernel).
+template <class Model, bool SHARDED>
 __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArgs<Model> a)
 {
     using V = typename Model::value_t;
@@ -551,23 +549,6 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     store4_as(a.values + (int64_t)t * a.rs, j0, x);                                           // predict #t
     store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
 
-    if (LAST) {
-        // last step: the read-out wants log-weights, linear weights and an fp64 tile partial (observe #t: table look-ups only)
-        const double ll[3] = {a.ll_cur[0], a.ll_cur[1], a.ll_cur[2]}, et[3] = {a.e_cur[0], a.e_cur[1], a.e_cur[2]};
-        const double mref = a.e_cur[3];
-        int idx[kPPT]; double lw[kPPT], e[kPPT];
-#pragma unroll
-        for (int k = 0; k < kPPT; ++k) {
-            idx[k] = Model::weight_index(x[k]);
-            const double l = idx[k] == 0 ? ll[0] : (idx[k] == 1 ? ll[1] : ll[2]);
-            lw[k] = valid[k] ? l : -INFINITY;
-        }
-        tile_partial_table<3>(idx, valid, et, mref, e, a.part, s_cnt, false, bid);
-        store4(a.logw_next, j0, lw);
-        store4(a.wrel_next, j0, e);
-        if (tid == 0) hier_publish(a.h, bid, nb, 0, 0, false);     // (keeps the rotation's clearing duty)
-        return;
-    }
     // ---- observe #t as counts ----
     uint32_t c0 = 0, c1 = 0;
 #pragma unroll
@@ -584,6 +565,75 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         for (int w = 0; w < kWaves; ++w) { n0 += (uint32_t)s_cnt[2 * w]; n1 += (uint32_t)s_cnt[2 * w + 1]; }
         hier_publish(a.h, bid, nb, n0, n1, true);
     }
+}
+
+// Read-out of a single-shard run in the prefix-count form.  The last step is an ordinary step: it leaves its generation's counts
+// like any other, and what the read-out needs follows from them and the particles' states -- the final weight of a particle is
+// e[x] (three values), the normaliser W the same fma chain over the generation's totals that every step's prologue evaluates.  So
+// no log-weight / linear-weight arrays are written, no tile partials, and no normalisation launch sits between the last step and
+// the lineage walk: workgroup 0's first wavefront does the bookkeeping of the final generation on its way in.
+struct CountsFinal {
+    Hier h;                      // the final generation's counts (the copy the last step wrote)
+    double e[4];                 // exp(ll_s - max ll) of the last step, then max ll
+    double n_pop; int T;
+    int bookkeep;                // 0: the run's bookkeeping is done (a joint population's, by counts_final_ctrl_kernel; a repeated read-out)
+    StepCtrl* ctrl; double* ess_trace; int32_t* resampled;
+};
+
+// Bookkeeping of the final generation (scan_tail's, for a generation no resampling follows) from its totals.  One thread.
+__device__ __forceinline__ void counts_final_bookkeep(const CountsFinal& f, double tot0, double tot1)
+{
+    const double tot2 = f.n_pop - tot0 - tot1;
+    const double W = fma(tot2, f.e[2], fma(tot1, f.e[1], __dmul_rn(tot0, f.e[0])));
+    const double Q = fma(tot2, __dmul_rn(f.e[2], f.e[2]), fma(tot1, __dmul_rn(f.e[1], f.e[1]), __dmul_rn(tot0, __dmul_rn(f.e[0], f.e[0]))));
+    const double ess = W * W / Q;
+    StepCtrl* c = f.ctrl;
+    c->M = f.e[3]; c->W = W; c->Q = Q; c->ess = ess; c->do_resample = 0;
+    c->cdf_lo = 0.0; c->w_local = W; c->scale = 1.0; c->lw_after = 0.0; c->inv_stepw = f.n_pop / W; c->inv_global = f.n_pop / W;
+    const double lz = (f.T == 1) ? 0.0 : c->log_z;
+    if (f.T == 1) c->n_resampled = 0;
+    c->log_z = lz + (f.e[3] + log(W / f.n_pop));
+    if (f.ess_trace) f.ess_trace[f.T - 1] = ess;
+    if (f.resampled) f.resampled[f.T - 1] = 0;
+}
+
+// The same for one shard of a joint population, from the all-gathered {n_0, n_1, particles} of every rank (exact doubles: the sums
+// are those a single GPU's hierarchy would hold, so the evidence does not depend on how the population is sharded).  One wavefront.
+__global__ __launch_bounds__(kWave) void counts_final_ctrl_kernel(CountsFinal f, const double* __restrict__ all_totals, int world)
+{
+    const int lane = threadIdx.x;
+    double r0 = 0.0, r1 = 0.0;
+    if (lane < world) { r0 = all_totals[3 * lane]; r1 = all_totals[3 * lane + 1]; }
+    const double tot0 = wave_sum(r0), tot1 = wave_sum(r1);
+    if (lane == 0) counts_final_bookkeep(f, tot0, tot1);
+}
+
+template <class Model>
+__global__ __launch_bounds__(kThreads) void smooth_counts_kernel(SmoothArgs<Model> a, CountsFinal f)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_stat[];   // [kWaves][T*K]
+    if (f.bookkeep && blockIdx.x == 0 && wave_id() == 0) {
+        const Cnt2 tl = hier_total(f.h);
+        if (threadIdx.x == 0) counts_final_bookkeep(f, (double)tl.n0, (double)tl.n1);
+    }
+    const double e0 = f.e[0], e1 = f.e[1], e2 = f.e[2];
+    const typename Model::store_t* last = a.values + (int64_t)(a.T - 1) * a.rs;
+    const int64_t n = a.n;
+    smooth_body<Model>(a, s_stat, [last, n, e0, e1, e2](int64_t, int64_t i) {
+        const int s = Model::weight_index(static_cast<typename Model::value_t>(last[i]));
+        return i < n ? (s == 0 ? e0 : (s == 1 ? e1 : e2)) : 0.0;
+    });
+}
+
+// Log-weights of the final generation, for the callers that ask for them (cpprob_hip_copy_logw): ll[x], -inf in padding slots.
+template <class Model>
+__global__ __launch_bounds__(kThreads) void logw_from_states_kernel(const typename Model::store_t* __restrict__ last, int64_t n, int64_t ld,
+                                                                     double l0, double l1, double l2, double* __restrict__ logw)
+{
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= ld) return;
+    const int s = Model::weight_index(static_cast<typename Model::value_t>(last[i]));
+    logw[i] = i < n ? (s == 0 ? l0 : (s == 1 ? l1 : l2)) : -INFINITY;
 }
 
 // {n_0, n_1, particles} of this shard's generation as exact doubles: what a sharded run all-gathers between two steps.
