@@ -1,7 +1,7 @@
 // Device side of the statement API (hipcc only): what cpprob::sample / observe / predict do when
 // the model body runs on a GPU lane.  Replaces the reference's process-global trace record
 // (StateInfer::trace_, src/cpprob/state.cpp:148; TraceInfer, include/cpprob/trace.hpp:34-63) by a
-// per-lane record in LDS, one particle per lane.
+// per-lane record in LDS (the mutable part) and the kernel-argument segment (the rest), one particle per lane.
 //
 //   sample  #j : SIS -> a fresh draw (Philox block of (particle id, ordinal j), cpprob/detail/rng.hpp);
 //                SMC step t -> the stored value of the lane's ancestor for j < n_stored (trace replay),
@@ -30,44 +30,71 @@ namespace device {
 
 constexpr int kLaneBlock = 256;
 
-struct LaneCtx {
-    uint64_t seed, pid;
-    double log_w;
-    const uint64_t* trace_in;     // ancestor's stored sample values, stride ld (nullptr: none)
-    uint64_t* trace_out;          // this lane's new trace column, stride ld (nullptr: do not record)
-    double* pred_real;            // this lane's predict columns, stride ld (nullptr: do not record)
-    int32_t* pred_int;
-    int64_t ld;
-    uint32_t n_sample, n_observe, n_pred_real, n_pred_int;
-    uint32_t n_stored;            // samples available in trace_in
-    uint32_t trace_cap;           // rows of the trace buffers; a longer trace raises *overflow (rejection loops)
-    uint32_t pred_real_cap, pred_int_cap;   // predict columns the host allocated (hits seen by the structural dry run)
+// What every statement of a launch reads and none writes: the kernel's first argument.  A statement fetches the fields it needs
+// straight from the kernel-argument segment (scalar loads into scalar registers, wherever in the call tree it sits), so they cost
+// no LDS and no vector registers.  model_kernel (cpprob/gpu.hpp) takes this struct as its FIRST parameter.
+struct LaunchArgs {
+    int64_t n, ld;
+    uint64_t seed;
+    const int32_t* anc;            // ancestors of this generation (identity where the previous step did not resample); nullptr at step 0
+    const int32_t* resampled_prev; // device flag: did the previous step resample?  (the decision is taken on the device)
+    const double* logw_in;         // log-weights of the previous generation, carried over when it was not resampled
+    double* logw_out;
+    const uint64_t* trace_in; uint64_t* trace_out;       // stored sample values, row stride ld: the ancestor's / this lane's new column
+    const int32_t* nstored_in; int32_t* nstored_out;
+    double* pred_real; int32_t* pred_int;                 // predict columns, row stride ld (nullptr: do not record)
+    int32_t first_observe;         // observes with a smaller index were weighted in earlier steps
+    int32_t stop_after;            // index of the observe that ends this step (-1: run to completion)
+    uint32_t trace_cap;            // rows of the trace buffers; a longer trace raises *overflow (rejection loops)
     int32_t* overflow;
-    uint32_t n_recorded;          // samples executed before the lane was done
-    int32_t first_observe;        // observes with a smaller index were weighted in earlier steps
-    int32_t stop_after;           // index of the observe that ends this step (-1: run to completion)
-    uint32_t done;
+    uint32_t pred_real_cap, pred_int_cap;                 // predict columns the host allocated (hits seen by the structural dry run)
     // windowed replay (models that passed the Markov probe): a step replays only the ancestor's last `win` samples, kept per
     // particle in `carry` rows (slot k <-> ordinal fresh_lo - win + k); older samples come back value-initialised, never from memory
     uint32_t windowed, win;
-    int32_t fresh_lo;             // first ordinal this step draws itself (= samples before the previous observe)
-    int32_t next_fresh;           // first ordinal the NEXT step draws (= samples before this step's observe): what carry_out must end with
+    int32_t fresh_lo;              // first ordinal this step draws itself (= samples before the previous observe)
+    int32_t next_fresh;            // first ordinal the NEXT step draws (= samples before this step's observe): what carry_out must end with
     const uint64_t* carry_in; uint64_t* carry_out;
-    // what the kernel's epilogue needs
-    double carried; double* logw_out; int32_t* nstored_out;
 };
+typedef const LaunchArgs __attribute__((address_space(4))) * LaunchArgsPtr;
+__device__ inline LaunchArgsPtr launch_args() { return (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
 
-// finish_trace() of one lane: the particle's log-weight (and, full replay, how many samples its trace holds)
-__device__ inline void finish_lane(LaneCtx& c)
+// What a lane's statements do write: counters, the running log-weight, the frontier flag.  One workgroup's lanes side by side per
+// field (a wavefront's access to a field is one conflict-free LDS instruction); 40 bytes per lane, so the LDS does not limit how
+// many wavefronts a CU holds (the 176-byte per-lane record of the first build allowed 3 per SIMD, and every statement's chain of
+// dependent LDS round trips went unhidden: 49 us per launch at 10^6 particles).
+struct LaneState {
+    double log_w[kLaneBlock];
+    uint32_t n_sample[kLaneBlock], n_observe[kLaneBlock], n_pred_real[kLaneBlock], n_pred_int[kLaneBlock];
+    uint32_t n_recorded[kLaneBlock];      // samples executed before the lane was done
+    uint32_t n_stored[kLaneBlock];        // samples available in the ancestor's trace column
+    uint32_t done[kLaneBlock];
+    int32_t src[kLaneBlock];              // the lane's ancestor (its own index where the previous step did not resample)
+};
+__device__ inline LaneState& lane_state()
 {
-    *c.logw_out = c.carried + c.log_w;
-    if (c.nstored_out) *c.nstored_out = (int32_t)c.n_recorded;
+    __shared__ LaneState s_state;
+    return s_state;
+}
+__device__ inline int64_t lane_index() { return (int64_t)blockIdx.x * kLaneBlock + threadIdx.x; }     // = the particle id
+
+__device__ inline void begin_lane(int32_t src, uint32_t n_stored)
+{
+    LaneState& s = lane_state();
+    const int l = threadIdx.x;
+    s.log_w[l] = 0.0;
+    s.n_sample[l] = 0; s.n_observe[l] = 0; s.n_pred_real[l] = 0; s.n_pred_int[l] = 0; s.n_recorded[l] = 0;
+    s.n_stored[l] = n_stored; s.done[l] = 0; s.src[l] = src;
 }
 
-__device__ inline LaneCtx& lane_ctx()
+// finish_trace() of one lane: the particle's log-weight (and, full replay, how many samples its trace holds)
+__device__ inline void finish_lane(double carried)
 {
-    __shared__ LaneCtx s_ctx[kLaneBlock];
-    return s_ctx[threadIdx.x];
+    LaunchArgsPtr A = launch_args();
+    const LaneState& s = lane_state();
+    const int l = threadIdx.x;
+    const int64_t i = lane_index();
+    A->logw_out[i] = carried + s.log_w[l];
+    if (A->nstored_out) A->nstored_out[i] = (int32_t)s.n_recorded[l];
 }
 
 // 8-byte raw slots of the sample trace
@@ -115,22 +142,24 @@ template <class Distribution>
 __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(Distribution& distr)
 {
     using R = typename std::decay_t<Distribution>::result_type;
+    LaunchArgsPtr A = launch_args();
+    LaneState& s = lane_state();
+    const int l = threadIdx.x;
     if constexpr (is_dev_mvn<std::decay_t<Distribution>>::value) {
         // vector-valued sample (multivariate_normal.hpp:268-274): the components draw one after the other, each its own trace slot
         using T = typename R::value_type;
-        LaneCtx& c = lane_ctx();
         R value;
         for (std::size_t i = 0; i < distr.size(); ++i) {
-            const uint32_t j = c.n_sample++;
+            const uint32_t j = s.n_sample[l]++;
             T v = T();
-            if (!c.done) {
-                if (j < c.n_stored && j < c.trace_cap) v = from_raw<T>(c.trace_in[(int64_t)j * c.ld]);
-                else v = static_cast<T>(distr.mean_at(i) + distr.sigma_at(i) * cph::draw_std_normal(c.seed, c.pid, (uint64_t)j));
-                if (c.trace_out) {
-                    if (j < c.trace_cap) c.trace_out[(int64_t)j * c.ld] = to_raw<T>(v);
-                    else if (c.overflow) *c.overflow = 1;
+            if (!s.done[l]) {
+                if (j < s.n_stored[l] && j < A->trace_cap) v = from_raw<T>(A->trace_in[(int64_t)j * A->ld + s.src[l]]);
+                else v = static_cast<T>(distr.mean_at(i) + distr.sigma_at(i) * cph::draw_std_normal(A->seed, (uint64_t)lane_index(), (uint64_t)j));
+                if (A->trace_out) {
+                    if (j < A->trace_cap) A->trace_out[(int64_t)j * A->ld + lane_index()] = to_raw<T>(v);
+                    else if (A->overflow) *A->overflow = 1;
                 }
-                c.n_recorded = j + 1;
+                s.n_recorded[l] = j + 1;
             }
             value.push_back(v);
         }
@@ -140,28 +169,27 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
         // (cpprob::inference refuses to launch this path for them, host_engine.hpp)
         __builtin_trap();
     } else {
-        LaneCtx& c = lane_ctx();
-        const uint32_t j = c.n_sample++;
-        if (c.done) return R();
-        if (c.windowed) {
-            const int32_t jj = (int32_t)j, base = c.fresh_lo - (int32_t)c.win;
+        const uint32_t j = s.n_sample[l]++;
+        if (s.done[l]) return R();
+        if (A->windowed) {
+            const int32_t jj = (int32_t)j, base = A->fresh_lo - (int32_t)A->win;
             if (jj < base) return R();                                    // older than the window: the step does not depend on it (host probe)
             R v;
-            if (jj < c.fresh_lo) v = from_raw<R>(c.carry_in[(int64_t)(jj - base) * c.ld]);
-            else v = draw(distr, c.seed, c.pid, (uint64_t)j);
-            const int32_t out_base = c.next_fresh - (int32_t)c.win;
-            if (c.carry_out && jj >= out_base && jj < c.next_fresh) c.carry_out[(int64_t)(jj - out_base) * c.ld] = to_raw<R>(v);
-            c.n_recorded = j + 1;
+            if (jj < A->fresh_lo) v = from_raw<R>(A->carry_in[(int64_t)(jj - base) * A->ld + s.src[l]]);
+            else v = draw(distr, A->seed, (uint64_t)lane_index(), (uint64_t)j);
+            const int32_t out_base = A->next_fresh - (int32_t)A->win;
+            if (A->carry_out && jj >= out_base && jj < A->next_fresh) A->carry_out[(int64_t)(jj - out_base) * A->ld + lane_index()] = to_raw<R>(v);
+            s.n_recorded[l] = j + 1;
             return v;
         }
         R value;
-        if (j < c.n_stored && j < c.trace_cap) value = from_raw<R>(c.trace_in[(int64_t)j * c.ld]);   // (beyond the rows: the run is being repeated anyway)
-        else value = draw(distr, c.seed, c.pid, (uint64_t)j);
-        if (c.trace_out) {
-            if (j < c.trace_cap) c.trace_out[(int64_t)j * c.ld] = to_raw<R>(value);
-            else if (c.overflow) *c.overflow = 1;
+        if (j < s.n_stored[l] && j < A->trace_cap) value = from_raw<R>(A->trace_in[(int64_t)j * A->ld + s.src[l]]);   // (beyond the rows: the run is being repeated anyway)
+        else value = draw(distr, A->seed, (uint64_t)lane_index(), (uint64_t)j);
+        if (A->trace_out) {
+            if (j < A->trace_cap) A->trace_out[(int64_t)j * A->ld + lane_index()] = to_raw<R>(value);
+            else if (A->overflow) *A->overflow = 1;
         }
-        c.n_recorded = j + 1;
+        s.n_recorded[l] = j + 1;
         return value;
     }
 }
@@ -169,21 +197,18 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
 template <class Distribution, class X>
 __device__ inline void observe_impl(Distribution& distr, const X& x)
 {
-    if constexpr (is_dev_mvn<std::decay_t<Distribution>>::value) {
-        // ONE observe statement whose log-density is the sum over the components (utils_multivariate_normal.hpp:20-33)
-        LaneCtx& c = lane_ctx();
-        const int32_t m = (int32_t)c.n_observe++;
-        if (c.done || m < c.first_observe) return;
-        c.log_w += logpdf<std::decay_t<Distribution>>()(distr, x);
-        if (m == c.stop_after) c.done = 1;
-    } else if constexpr (!std::is_arithmetic<X>::value) {
+    constexpr bool vec = is_dev_mvn<std::decay_t<Distribution>>::value;
+    if constexpr (!vec && !std::is_arithmetic<X>::value) {
         __builtin_trap();                                           // heap-backed vector types: compile the model's device view (cpprob/gpu.hpp)
     } else {
-        LaneCtx& c = lane_ctx();
-        const int32_t m = (int32_t)c.n_observe++;
-        if (c.done || m < c.first_observe) return;
-        c.log_w += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
-        if (m == c.stop_after) c.done = 1;
+        // (vector-valued: ONE observe statement whose log-density is the sum over the components, utils_multivariate_normal.hpp:20-33)
+        LaunchArgsPtr A = launch_args();
+        LaneState& s = lane_state();
+        const int l = threadIdx.x;
+        const int32_t m = (int32_t)s.n_observe[l]++;
+        if (s.done[l] || m < A->first_observe) return;
+        s.log_w[l] += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
+        if (m == A->stop_after) s.done[l] = 1;
         // (ending the wave here once every lane has arrived -- finish_lane + s_endpgm -- was tried: no gain, the statements after the
         //  frontier are the cheap ones: profiles/r02_notes.md)
     }
@@ -193,32 +218,32 @@ template <class T>
 __device__ inline void predict_impl(const T& x)
 {
     using V = std::decay_t<T>;
+    LaunchArgsPtr A = launch_args();
+    LaneState& s = lane_state();
+    const int l = threadIdx.x;
     if constexpr (std::is_integral<V>::value) {                         // state.hpp:312-318 -> predict_int_
-        LaneCtx& c = lane_ctx();
-        if (c.done) return;
-        const uint32_t k = c.n_pred_int++;
-        if (c.windowed && (int32_t)c.n_observe < c.first_observe) return;      // an earlier step's hit: recorded by that step's launch
-        if (c.pred_int) {
-            if (k < c.pred_int_cap) c.pred_int[(int64_t)k * c.ld] = static_cast<int32_t>(x);
-            else if (c.overflow) *c.overflow = 2;                       // more predict hits than the dry run: data-dependent predicts
+        if (s.done[l]) return;
+        const uint32_t k = s.n_pred_int[l]++;
+        if (A->windowed && (int32_t)s.n_observe[l] < A->first_observe) return;      // an earlier step's hit: recorded by that step's launch
+        if (A->pred_int) {
+            if (k < A->pred_int_cap) A->pred_int[(int64_t)k * A->ld + lane_index()] = static_cast<int32_t>(x);
+            else if (A->overflow) *A->overflow = 2;                     // more predict hits than the dry run: data-dependent predicts
         }
     } else if constexpr (std::is_floating_point<V>::value) {            // state.hpp:320-326 -> predict_real_
-        LaneCtx& c = lane_ctx();
-        if (c.done) return;
-        const uint32_t k = c.n_pred_real++;
-        if (c.windowed && (int32_t)c.n_observe < c.first_observe) return;
-        if (c.pred_real) {
-            if (k < c.pred_real_cap) c.pred_real[(int64_t)k * c.ld] = static_cast<double>(x);
-            else if (c.overflow) *c.overflow = 2;
+        if (s.done[l]) return;
+        const uint32_t k = s.n_pred_real[l]++;
+        if (A->windowed && (int32_t)s.n_observe[l] < A->first_observe) return;
+        if (A->pred_real) {
+            if (k < A->pred_real_cap) A->pred_real[(int64_t)k * A->ld + lane_index()] = static_cast<double>(x);
+            else if (A->overflow) *A->overflow = 2;
         }
     } else if constexpr (is_dev_ndarray<V>::value) {                    // state.hpp:330-337: an NDArray goes to the real list; one column per component
-        LaneCtx& c = lane_ctx();
-        if (c.done) return;
+        if (s.done[l]) return;
         for (std::size_t i = 0; i < x.size(); ++i) {
-            const uint32_t k = c.n_pred_real++;
-            if (c.pred_real) {
-                if (k < c.pred_real_cap) c.pred_real[(int64_t)k * c.ld] = static_cast<double>(x[i]);
-                else if (c.overflow) *c.overflow = 2;
+            const uint32_t k = s.n_pred_real[l]++;
+            if (A->pred_real) {
+                if (k < A->pred_real_cap) A->pred_real[(int64_t)k * A->ld + lane_index()] = static_cast<double>(x[i]);
+                else if (A->overflow) *A->overflow = 2;
             }
         }
     } else {

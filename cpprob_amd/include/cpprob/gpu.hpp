@@ -49,23 +49,7 @@
 namespace cpprob {
 namespace gpu {
 
-struct ModelKernelArgs {
-    int64_t n, ld;
-    uint64_t seed;
-    const int32_t* anc;            // ancestors of this generation (identity where the previous step did not resample); nullptr at step 0
-    const int32_t* resampled_prev; // device flag: did the previous step resample?  (the decision is taken on the device)
-    const double* logw_in;         // log-weights of the previous generation, carried over when it was not resampled
-    double* logw_out;
-    const uint64_t* trace_in; uint64_t* trace_out;
-    const int32_t* nstored_in; int32_t* nstored_out;
-    double* pred_real; int32_t* pred_int;
-    int32_t first_observe, stop_after;
-    uint32_t trace_cap; int32_t* overflow;
-    uint32_t pred_real_cap, pred_int_cap;
-    // windowed replay (cpprob/detail/device_trace.hpp)
-    uint32_t windowed, win; int32_t fresh_lo, next_fresh;
-    const uint64_t* carry_in; uint64_t* carry_out;
-};
+using ModelKernelArgs = device::LaunchArgs;     // (cpprob/detail/device_trace.hpp: the statements read it from the kernel-argument segment)
 
 // How the kernel reaches the model body: a function (by address, as a template argument) or a functor
 // (by type, default-constructed on the lane -- e.g. the reference's models::Gauss<>, models.hpp:51-65).
@@ -87,25 +71,10 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
     if (i >= a.n) return;
     const bool resampled = a.resampled_prev && *a.resampled_prev != 0;
     const int64_t src = (a.anc && resampled) ? (int64_t)a.anc[i] : i;
-    device::LaneCtx& c = device::lane_ctx();
-    c.seed = a.seed; c.pid = (uint64_t)i; c.log_w = 0.0;
-    c.trace_in = a.trace_in ? a.trace_in + src : nullptr;
-    c.trace_out = a.trace_out ? a.trace_out + i : nullptr;
-    c.pred_real = a.pred_real ? a.pred_real + i : nullptr;
-    c.pred_int = a.pred_int ? a.pred_int + i : nullptr;
-    c.ld = a.ld;
-    c.n_sample = c.n_observe = c.n_pred_real = c.n_pred_int = 0;
-    c.n_stored = a.nstored_in ? (uint32_t)a.nstored_in[src] : 0u;
-    c.n_recorded = 0;
-    c.trace_cap = a.trace_cap; c.overflow = a.overflow;
-    c.pred_real_cap = a.pred_real_cap; c.pred_int_cap = a.pred_int_cap;
-    c.first_observe = a.first_observe; c.stop_after = a.stop_after; c.done = 0;
-    c.windowed = a.windowed; c.win = a.win; c.fresh_lo = a.fresh_lo; c.next_fresh = a.next_fresh;
-    c.carry_in = a.carry_in ? a.carry_in + src : nullptr; c.carry_out = a.carry_out ? a.carry_out + i : nullptr;
-    c.carried = (!resampled && a.logw_in) ? a.logw_in[i] : 0.0;   // equal weights after resampling
-    c.logw_out = a.logw_out + i; c.nstored_out = a.nstored_out ? a.nstored_out + i : nullptr;
+    device::begin_lane((int32_t)src, a.nstored_in ? (uint32_t)a.nstored_in[src] : 0u);
+    const double carried = (!resampled && a.logw_in) ? a.logw_in[i] : 0.0;   // equal weights after resampling
     Caller::call(*observes);                                      // the model body, cpprob.hpp:199
-    device::finish_lane(c);                                       // finish_trace(): the particle's log_w_
+    device::finish_lane(carried);                                 // finish_trace(): the particle's log_w_
 }
 
 template <class Tuple> struct observes_bytewise_copyable;
