@@ -64,11 +64,13 @@ __device__ inline LaunchArgsPtr launch_args() { return (LaunchArgsPtr)__builtin_
 // dependent LDS round trips went unhidden: 49 us per launch at 10^6 particles).
 struct LaneState {
     double log_w[kLaneBlock];
+    double carried[kLaneBlock];           // the log-weight the particle brought along (no resampling before this step)
     uint32_t n_sample[kLaneBlock], n_observe[kLaneBlock], n_pred_real[kLaneBlock], n_pred_int[kLaneBlock];
     uint32_t n_recorded[kLaneBlock];      // samples executed before the lane was done
     uint32_t n_stored[kLaneBlock];        // samples available in the ancestor's trace column
     uint32_t done[kLaneBlock];
     int32_t src[kLaneBlock];              // the lane's ancestor (its own index where the previous step did not resample)
+    unsigned long long active[kLaneBlock / 64];   // per wavefront: the lanes that carry a particle
 };
 __device__ inline LaneState& lane_state()
 {
@@ -77,23 +79,24 @@ __device__ inline LaneState& lane_state()
 }
 __device__ inline int64_t lane_index() { return (int64_t)blockIdx.x * kLaneBlock + threadIdx.x; }     // = the particle id
 
-__device__ inline void begin_lane(int32_t src, uint32_t n_stored)
+__device__ inline void begin_lane(int32_t src, uint32_t n_stored, double carried)
 {
     LaneState& s = lane_state();
     const int l = threadIdx.x;
-    s.log_w[l] = 0.0;
+    s.log_w[l] = 0.0; s.carried[l] = carried;
     s.n_sample[l] = 0; s.n_observe[l] = 0; s.n_pred_real[l] = 0; s.n_pred_int[l] = 0; s.n_recorded[l] = 0;
     s.n_stored[l] = n_stored; s.done[l] = 0; s.src[l] = src;
+    s.active[l / 64] = __ballot(1);        // (every lane of the wavefront writes the same word)
 }
 
 // finish_trace() of one lane: the particle's log-weight (and, full replay, how many samples its trace holds)
-__device__ inline void finish_lane(double carried)
+__device__ inline void finish_lane()
 {
     LaunchArgsPtr A = launch_args();
     const LaneState& s = lane_state();
     const int l = threadIdx.x;
     const int64_t i = lane_index();
-    A->logw_out[i] = carried + s.log_w[l];
+    A->logw_out[i] = s.carried[l] + s.log_w[l];
     if (A->nstored_out) A->nstored_out[i] = (int32_t)s.n_recorded[l];
 }
 
@@ -206,11 +209,18 @@ __device__ inline void observe_impl(Distribution& distr, const X& x)
         LaneState& s = lane_state();
         const int l = threadIdx.x;
         const int32_t m = (int32_t)s.n_observe[l]++;
-        if (s.done[l] || m < A->first_observe) return;
-        s.log_w[l] += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
-        if (m == A->stop_after) s.done[l] = 1;
-        // (ending the wave here once every lane has arrived -- finish_lane + s_endpgm -- was tried: no gain, the statements after the
-        //  frontier are the cheap ones: profiles/r02_notes.md)
+        if (!s.done[l] && m >= A->first_observe) {
+            s.log_w[l] += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
+            if (m == A->stop_after) s.done[l] = 1;
+        }
+        // Every statement behind the frontier is a no-op: once ALL of the wavefront's lanes have passed it (models whose observes do
+        // not depend on sampled values: all at this very statement) the wavefront is finished.  The test is wave-uniform (all lanes
+        // or none enter the block); the exit is written as an instruction rather than the builtin, which the compiler would turn
+        // into lane masking when it cannot prove the surrounding control flow uniform.
+        if (A->stop_after >= 0) {
+            const unsigned long long arrived = __ballot(s.done[l] != 0);
+            if (__builtin_amdgcn_readfirstlane(arrived == s.active[threadIdx.x / 64] ? 1 : 0)) { finish_lane(); asm volatile("s_endpgm" ::: "memory"); }
+        }
     }
 }
 

@@ -71,10 +71,10 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
     if (i >= a.n) return;
     const bool resampled = a.resampled_prev && *a.resampled_prev != 0;
     const int64_t src = (a.anc && resampled) ? (int64_t)a.anc[i] : i;
-    device::begin_lane((int32_t)src, a.nstored_in ? (uint32_t)a.nstored_in[src] : 0u);
     const double carried = (!resampled && a.logw_in) ? a.logw_in[i] : 0.0;   // equal weights after resampling
+    device::begin_lane((int32_t)src, a.nstored_in ? (uint32_t)a.nstored_in[src] : 0u, carried);
     Caller::call(*observes);                                      // the model body, cpprob.hpp:199
-    device::finish_lane(carried);                                 // finish_trace(): the particle's log_w_
+    device::finish_lane();                                        // finish_trace(): the particle's log_w_
 }
 
 template <class Tuple> struct observes_bytewise_copyable;
