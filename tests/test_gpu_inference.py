@@ -239,6 +239,29 @@ def test_smc_tiny_and_ragged_populations(engine, golden_dir, n):
     np.testing.assert_allclose(st.sum(axis=1), 1.0, rtol=1e-12)
 
 
+@pytest.mark.parametrize("T", [1, 2, 3])
+@pytest.mark.parametrize("n", [777, 70_000])
+def test_smc_short_traces_read_out_from_the_final_counts(engine, golden_dir, T, n):
+    """T = 1 (the only step is the last one), 2 and 3: the count form's read-out takes weights and the normaliser from the final
+    generation's counts; log-weights exist on request only (cpprob_hip_copy_logw), and asking for the traces first must not
+    book the final generation twice."""
+    obs = _obs(golden_dir, "hmm16")[:T]
+    for rep in range(2):                                    # (the hierarchy's rotation carries over from run to run)
+        engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=21 + rep, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=2.0)
+        engine.run()
+        ref = O.smc(cp.MODEL_HMM3, obs, n, 21 + rep, cp.RESAMPLE_SYSTEMATIC, 2.0)
+        paths = engine.paths()
+        assert np.array_equal(engine.ancestors(), ref["anc"]) and np.array_equal(engine.values(), ref["hist"])
+        assert np.array_equal(paths, np.take_along_axis(ref["hist"], O.lineage(ref["anc"]), axis=1))
+        s = engine.summary()
+        assert abs(s["log_evidence"] - ref["log_z"]) < 1e-10 and s["n_resampled"] == T - 1
+        np.testing.assert_allclose(engine.logw(), ref["logw"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(engine.stats(), O.smoothing(ref["hist"], ref["anc"], ref["logw"]), atol=1e-12)
+        engine.run(1)                                        # a second run on the same context, then the first again: same numbers
+        engine.run(0)
+        assert abs(engine.summary()["log_evidence"] - s["log_evidence"]) == 0.0
+
+
 def test_smc_hmm16_config3_vs_forward_backward(engine, golden_dir):
     """BASELINE.json configs[2]: hmm<16>, systematic resampling every step, 10^6 particles."""
     z = np.load(os.path.join(golden_dir, "observations.npz"))
