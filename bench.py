@@ -133,11 +133,39 @@ def timed_runs(eng, steps, warmup, world, device, island, first_index=0, exchang
     return dt, last
 
 
+def guarded(fn, what):
+    """Runs fn() on a helper thread with a deadline.  Creating an RCCL communicator and the first run over real links are
+    collective and blocking: a transport that never completes cannot be recovered in-process, so the job ends with a message
+    instead of holding the node until the launcher's own limit.  Exceptions of fn() are re-raised here."""
+    import threading
+    box = {}
+    def body():
+        try:
+            box["value"] = fn()
+        except BaseException as e:        # noqa: handed to the caller
+            box["error"] = e
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(float(os.environ.get("CPPROB_BENCH_COLLECTIVE_TIMEOUT", "180")))
+    if th.is_alive():
+        sys.stderr.write("bench.py: %s did not complete within its deadline (rank %s); exiting\n" % (what, os.environ.get("RANK", "?")))
+        sys.stderr.flush()
+        os._exit(3)
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
 def timed_group_runs(group, steps, warmup, world, device, first_index=0):
     """The same bracket for the library's own multi-GPU driver (cpprob_hip_group_run: a whole exchange-scope run per call,
     RCCL collectives on the context's stream, no host synchronisation inside)."""
     import torch
     import torch.distributed as dist
+    if world > 1:
+        def first():
+            group.run(first_index)
+            group.sync()
+        guarded(first, "the first multi-GPU run (RCCL all-gather / send / receive on the contexts' streams)")
     for i in range(warmup):
         group.run(first_index + i)
     group.sync()
@@ -282,7 +310,7 @@ def main():
     native_error = None
     if native:
         try:
-            group = make_rank_group(cp, world, rank, local)
+            group = guarded(lambda: make_rank_group(cp, world, rank, local), "creating the RCCL communicator of the library's driver")
             host = "C++ (cpprob_hip_group_run: RCCL on the context's stream, no host synchronisation inside a run)"
         except Exception as e:      # reported, never silent: the run then goes through torch.distributed's collectives
             native_error = str(e)
@@ -339,7 +367,7 @@ def main():
     if args.workload == "hmm16_smc" and n == 1_000_000 and os.path.exists(pmc):
         with open(pmc) as f:
             for kname, rec in json.load(f)["kernels"].items():
-                if "smc_step_counts_kernel" in kname and "false, false" in kname:       # the 15 launches per run that are not the last step
+                if "smc_step_counts_kernel" in kname and "ModelHmm3, false>" in kname:  # the single-shard form (all 16 launches of a run)
                     traffic = rec["hbm_bytes_per_launch_corrected"]
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)" if traffic else None, "algorithmic_bytes_per_unit": bytes_per_unit, "units_per_launch": n, "avg_launch_us": avg_s * 1e6,
