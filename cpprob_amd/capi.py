@@ -195,9 +195,12 @@ class Engine:
 
     # ---- cpprob::inference --------------------------------------------------------------
     def begin(self, algorithm, model, observes, n_particles, seed=12345, resampler=RESAMPLE_SYSTEMATIC, ess_threshold=2.0,
-              particle_offset=0, n_global=None, scope=SCOPE_GLOBAL):
+              particle_offset=0, n_global=None, scope=SCOPE_GLOBAL, keep_history=True):
+        """keep_history=False: filtering only -- two rows of the particle store and no ancestors (memory O(N) instead of
+        O(N T)); stats() then holds every predict hit's statistics under ITS generation's weights, and values() / ancestors() /
+        paths() raise."""
         obs = np.ascontiguousarray(observes, np.float64)
-        cfg = Config(algorithm, model, resampler, scope, 1, 0, float(ess_threshold), int(seed), int(n_particles), int(particle_offset),
+        cfg = Config(algorithm, model, resampler, scope, 1 if keep_history else 0, 0, float(ess_threshold), int(seed), int(n_particles), int(particle_offset),
                      int(n_particles if n_global is None else n_global))
         self._chk(self.L.cpprob_hip_infer_begin(self.h, C.byref(cfg), obs.ctypes.data_as(C.POINTER(C.c_double)), len(obs)))
         self.cfg = cfg

@@ -51,7 +51,9 @@ struct cpprob_hip_ctx {
     double* d_logw[2] = {nullptr, nullptr};
     double* d_wrel[2] = {nullptr, nullptr};
     double* d_bf = nullptr;
-    bool final_from_counts = false, final_bookkeep_pending = false; int final_copy = 0;   // prefix-count form, single shard: the read-out works from the final generation's counts
+    bool final_from_counts = false, final_bookkeep_pending = false; int final_copy = 0;
+    bool keep = true, cap_keep = true;   // keep_history: per-step values + ancestors (false: two rows, no ancestors, filtering statistics)
+    double* d_fpart = nullptr;           // filtering-only runs, floating-point form: [T][K + 2][smooth_grid] (filter_partials_kernel)   // prefix-count form, single shard: the read-out works from the final generation's counts
     double* d_ll_tab = nullptr;     // hmm: [T][3] emission log-densities
     void* d_values = nullptr;
     int32_t* d_anc = nullptr;
@@ -330,8 +332,10 @@ void launch_step(cpprob_hip_ctx* c, int t)
     a.part_prev = c->d_part[c->cur_part]; a.part = c->d_part[t == 0 ? c->cur_part : c->cur_part ^ 1];
     a.bc = c->d_bc; a.bf = c->d_bf; a.nb = c->nb; a.ctrl = c->d_ctrl; a.anc_pre = c->d_anc_pre;
     a.n_pop = (double)c->pop_n; a.ess_frac = c->cfg.ess_threshold; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
-    a.store_logw = c->cfg.ess_threshold > 1.0 ? 0 : 1;      // ESS <= N always: threshold > 1 resamples after every step
+    a.store_logw = (c->cfg.ess_threshold > 1.0 && c->keep) ? 0 : 1;      // ESS <= N always: threshold > 1 resamples after every step (a filtering-only run reads them after every step)
     a.rs = c->rs;
+    a.row_w = c->keep ? t : (t & 1); a.row_r = t > 0 ? (c->keep ? t - 1 : ((t - 1) & 1)) : 0;
+    if (!c->keep) a.anc = nullptr;
     {
         // table-weight model + every step resamples + systematic + fused: the step kernel reads states instead of wrel
         static const bool enabled = !(getenv("CPPROB_WREL_FROM_STATE") && getenv("CPPROB_WREL_FROM_STATE")[0] == '0');
@@ -379,6 +383,12 @@ void launch_step(cpprob_hip_ctx* c, int t)
 #endif
     c->cur ^= 1;
     if (t > 0) c->cur_part ^= 1;
+    if (!c->keep) {
+        // filtering only: predict hit t's sums under the weights this step just left
+        hipLaunchKernelGGL(filter_partials_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), 0, c->stream,
+                           static_cast<const typename Model::store_t*>(c->d_values) + (int64_t)a.row_w * c->rs, (const double*)c->d_logw[c->cur], c->n,
+                           c->d_fpart + (size_t)t * (Model::kStats + 2) * c->smooth_grid);
+    }
 }
 
 // The prefix-count form serves table-weight models (three values) whose every step resamples systematically: ancestors are
@@ -448,6 +458,8 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
             }
         }
         a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
+        a.row_w = c->keep ? t : (t & 1); a.row_r = t > 0 ? (c->keep ? t - 1 : ((t - 1) & 1)) : 0;
+        if (!c->keep) { a.anc = nullptr; a.filter_stats = c->d_stats; }
         a.all_totals = all_totals; a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
         for (int k = 0; k < 4; ++k) a.e_prev[k] = t > 0 ? c->h_e_tab[(size_t)(t - 1) * 4 + k] : 0.0;
         a.u0 = t > 0 ? host_resample_u0(c->run_seed, (uint64_t)t) : 0.0;
@@ -464,6 +476,7 @@ static void counts_final_view(cpprob_hip_ctx* c, CountsFinal& f, bool bookkeep)
     hier_view(c, c->final_copy, f.h);
     for (int k = 0; k < 4; ++k) f.e[k] = c->h_e_tab[(size_t)(c->T - 1) * 4 + k];
     f.n_pop = (double)c->pop_n; f.T = c->T; f.bookkeep = bookkeep ? 1 : 0; f.ctrl = c->d_ctrl; f.ess_trace = c->d_ess; f.resampled = c->d_resampled;
+    f.filter_stats = c->keep ? nullptr : c->d_stats;
 }
 
 void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, int world, int rank)
@@ -533,7 +546,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base);
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
 }
 
@@ -655,6 +668,11 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     host_model_params(c->mp, cfg->model);
     const bool smc = c->cfg.algorithm == CPPROB_HIP_ALG_SMC;
     const bool multinomial = smc && cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL;
+    // keep_history = 0: filtering only -- two rows of values, no ancestors, predict hit t's statistics under generation t's own
+    // weights.  SIS traces are their own lines (nothing to drop); a joint population's migration moves lineages (nothing to move).
+    c->keep = cfg->keep_history != 0 || !smc;
+    if (!c->keep && (exchange || (cfg->resample_scope != CPPROB_HIP_SCOPE_ISLAND && cfg->n_global != cfg->n_particles)))
+        return fail(c, CPPROB_HIP_EUNSUPPORTED, "keep_history = 0 (filtering only) serves one population per context: not a shard of a joint population");
 
     c->exchange = exchange;
     // exchange scope: room for immigrant lineages next to every row (grown on demand by cpprob_hip_exchange_commit)
@@ -663,7 +681,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     c->ssz = 8;
     dispatch_model(c, [&](auto m) { c->ssz = sizeof(typename decltype(m)::store_t); c->grid_refs = decltype(m)::kWeightTable == 0; });
     const bool realloc = (size_t)c->ld > c->cap_particles || c->T > c->cap_T || c->is_int != c->cap_int || (multinomial && !c->cap_multinomial) || !c->d_values ||
-                         annex0 != c->annex_cap;
+                         annex0 != c->annex_cap || c->keep != c->cap_keep;
     if (realloc) {
         free_run_buffers(c);
         c->annex_cap = annex0;
@@ -674,9 +692,11 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_wrel[0], ld * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_wrel[1], ld * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_bf, (size_t)c->nb * sizeof(double)));
-        HIP_TRY(c, hipMalloc(&c->d_values, T * rs * vsz));
-        HIP_TRY(c, hipMemsetAsync(c->d_values, 0, T * rs * vsz, c->stream));
-        HIP_TRY(c, hipMalloc(&c->d_anc, T * rs * sizeof(int32_t)));
+        const size_t rows = c->keep ? T : 2;
+        HIP_TRY(c, hipMalloc(&c->d_values, rows * rs * vsz));
+        HIP_TRY(c, hipMemsetAsync(c->d_values, 0, rows * rs * vsz, c->stream));
+        if (c->keep) HIP_TRY(c, hipMalloc(&c->d_anc, T * rs * sizeof(int32_t)));
+        else HIP_TRY(c, hipMalloc(&c->d_fpart, T * (8 + 2) * (size_t)c->smooth_grid * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_obound, (1024 + 2) * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
@@ -701,7 +721,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
             HIP_TRY(c, hipMalloc(&c->d_cdf, ld * sizeof(double)));
             HIP_TRY(c, hipMalloc(&c->d_anc_pre, ld * sizeof(int32_t)));
         }
-        c->cap_particles = ld; c->cap_T = c->T; c->cap_int = c->is_int; c->cap_multinomial = multinomial;
+        c->cap_particles = ld; c->cap_T = c->T; c->cap_int = c->is_int; c->cap_multinomial = multinomial; c->cap_keep = c->keep;
     }
     {
         std::memset(&c->hier, 0, sizeof c->hier);
@@ -838,7 +858,18 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
             }
         }
     }
-    if (!readout_done) dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
+    if (!c->keep) {
+        // filtering only: every step left its own statistics (count form: from the generation's totals; floating-point form:
+        // filter_partials_kernel); what remains is the final generation's bookkeeping and the normalisation
+        if (c->final_from_counts) {
+            CountsFinal f{};
+            counts_final_view(c, f, true);
+            c->final_bookkeep_pending = false;
+            hipLaunchKernelGGL(counts_filter_final_kernel, dim3(1), dim3(kWave), 0, c->stream, f);
+        } else {
+            hipLaunchKernelGGL(filter_finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream, (const double*)c->d_fpart, c->smooth_grid, c->K, c->is_int ? 1 : 0, c->d_stats);
+        }
+    } else if (!readout_done) dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
     return 0;
@@ -1218,6 +1249,7 @@ int cpprob_hip_copy_values(cpprob_hip_ctx* c, void* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (!c->keep) return fail(c, CPPROB_HIP_ESTATE, "the run kept no history (keep_history = 0): traces and ancestors do not exist; its statistics are the filtering ones");
     const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
     if (c->ssz == vsz) return copy_rows(c, h, c->d_values, vsz, (size_t)c->T, n_bytes, (size_t)c->rs);
     // narrow store: widen to the value type on the device first (d_paths doubles as the staging buffer)
@@ -1234,6 +1266,7 @@ int cpprob_hip_copy_ancestors(cpprob_hip_ctx* c, int32_t* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (!c->keep) return fail(c, CPPROB_HIP_ESTATE, "the run kept no history (keep_history = 0): traces and ancestors do not exist; its statistics are the filtering ones");
     if (c->cfg.algorithm != CPPROB_HIP_ALG_SMC) return fail(c, CPPROB_HIP_ESTATE, "SIS keeps no ancestors (every trace is its own line)");
     return copy_rows(c, h, c->d_anc, sizeof(int32_t), (size_t)c->T, n_bytes, (size_t)c->rs);
 }
@@ -1250,7 +1283,7 @@ int cpprob_hip_copy_logw(cpprob_hip_ctx* c, double* h, size_t n_bytes)
             if constexpr (M::kWeightTable == 3 && sizeof(typename M::store_t) == 1) {
                 const double* ll = &c->h_ll_tab[(size_t)(c->T - 1) * 3];
                 hipLaunchKernelGGL(logw_from_states_kernel<M>, dim3((unsigned)((c->ld + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream,
-                                   static_cast<const typename M::store_t*>(c->d_values) + (int64_t)(c->T - 1) * c->rs, c->n, c->ld, ll[0], ll[1], ll[2],
+                                   static_cast<const typename M::store_t*>(c->d_values) + (int64_t)(c->keep ? c->T - 1 : ((c->T - 1) & 1)) * c->rs, c->n, c->ld, ll[0], ll[1], ll[2],
                                    c->d_logw[c->cur]);
             }
         });
@@ -1262,6 +1295,7 @@ int cpprob_hip_copy_paths(cpprob_hip_ctx* c, void* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (!c->keep) return fail(c, CPPROB_HIP_ESTATE, "the run kept no history (keep_history = 0): traces and ancestors do not exist; its statistics are the filtering ones");
     const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
     // SIS: every trace is its own line -- the paths are the values (and a fused-read-out run keeps no linear weights to re-run the read-out on)
     if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) return cpprob_hip_copy_values(c, h, n_bytes);

@@ -1213,6 +1213,7 @@ struct StepArgs {
     int part_counts;          // with wrel_from_state in the fused form: tile partials between steps are packed per-value counts
     int wrel_from_state;      // table-weight model, every step resamples systematically: weights of generation t-1 = e_tab[t-1][state] (WeightSource)
     int64_t rs;               // row stride of values[] / anc[] (ld plus the immigrant annex)
+    int row_w, row_r;         // rows of values[] this step writes / reads: t and t - 1, or the two rows of a filtering-only run in turn
     // exchange scope (exact global resampling over shards): outputs [imm_l0, imm_l1) of this shard descend from local
     // sources, the others from immigrants whose lineages sit in annex columns imm_col0, imm_col0 + 1, ... in output order
     int exchange;
@@ -1326,7 +1327,7 @@ __global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) 
     double w_own[kPPT];
     lane_fill(w_own, 0.0);
     WeightSource<Model> ws;
-    ws.wrel = a.wrel_prev; ws.states = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs; ws.n = a.n; ws.from_states = a.wrel_from_state != 0;
+    ws.wrel = a.wrel_prev; ws.states = a.values + (int64_t)a.row_r * a.rs; ws.n = a.n; ws.from_states = a.wrel_from_state != 0;
     if (Model::kWeightTable > 0 && ws.from_states && t > 0) {
         constexpr int K = WeightSource<Model>::K;
         double ll[K], mref;
@@ -1472,7 +1473,7 @@ __global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) 
 
     CPH_STAMP(8);
     V prev[kPPT], x[kPPT];
-    const typename Model::store_t* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs;
+    const typename Model::store_t* prev_row = a.values + (int64_t)a.row_r * a.rs;
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>(prev_row[anc[k]]) : V(0);                 // ancestor's state (sorted gather)
 #pragma unroll
@@ -1486,9 +1487,9 @@ __global__ __launch_bounds__(kThreads, (FUSED == 8 && Model::kWeightTable == 0) 
         typename Model::store_t xs[kPPT];
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) xs[k] = static_cast<typename Model::store_t>(x[k]);
-        store4(a.values + (int64_t)t * a.rs, j0, xs);                                  // predict #t
+        store4(a.values + (int64_t)a.row_w * a.rs, j0, xs);                            // predict #t
     }
-    store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
+    if (a.anc) store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);                      // (a filtering-only run keeps no ancestors)
     double e[kPPT];
     const bool fresh = (t == 0) || resample;                                                  // every particle starts the step at log-weight lwa
     if (Model::kWeightTable > 0 && fresh) {
@@ -1599,6 +1600,83 @@ __global__ __launch_bounds__(kThreads) void smooth_kernel(SmoothArgs<Model> a)
     extern __shared__ __attribute__((aligned(16))) double s_stat[];   // [kWaves][T*K]
     const double scale = a.ctrl->scale;
     smooth_body<Model>(a, s_stat, [&](int64_t tile, int64_t i) { return a.wrel[i] * (a.bf[tile] * scale); });   // padding slots: wrel = 0
+}
+
+// ---------------------------------------------------------------------------------------------
+// Filtering-only runs (keep_history = 0): the particle store holds two rows and no ancestors, and predict hit t's
+// statistics are those of generation t under ITS weights -- sum_i w_t,i f(x_t,i) / sum_i w_t,i -- taken right after
+// step t.  One launch per step leaves, per workgroup, {reference m, sum e, sum e f_0 .. f_{K-1}} with e = exp(logw - m);
+// one launch per run combines the workgroups in index order and normalises (filter_finalize_kernel).
+// fpart layout: [T][K + 2][grid].
+// ---------------------------------------------------------------------------------------------
+template <class Model>
+__global__ __launch_bounds__(kThreads) void filter_partials_kernel(const typename Model::store_t* __restrict__ row, const double* __restrict__ logw,
+                                                                    int64_t n, double* __restrict__ fpart_t)
+{
+    using V = typename Model::value_t;
+    constexpr int K = Model::kStats;
+    __shared__ double s_scr[kWaves];
+    __shared__ double s_sum[(K + 1) * kWaves];
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int64_t ntiles = (n + kTile - 1) / kTile;
+    double M = -INFINITY, S = 0.0;                      // running reference; thread j <= K carries sum j (0: sum e, 1 + k: sum e f_k)
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t j0 = tile * kTile + (int64_t)tid * kPPT;
+        double lw[kPPT]; V x[kPPT];
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) { lw[k] = j0 + k < n ? logw[j0 + k] : -INFINITY; x[k] = static_cast<V>(row[j0 + k]); }
+        const double m = block_max(fmax(fmax(lw[0], lw[1]), fmax(lw[2], lw[3])), s_scr);
+        double acc[K + 1];
+#pragma unroll
+        for (int j = 0; j <= K; ++j) acc[j] = 0.0;
+        if (m != -INFINITY) {
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) {
+                const double e = lw[k] == -INFINITY ? 0.0 : exp(lw[k] - m);
+                acc[0] += e;
+                Model::accumulate(x[k], e, reinterpret_cast<double(&)[K]>(acc[1]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j <= K; ++j) { const double w = wave_sum(acc[j]); if (lane == 0) s_sum[j * kWaves + wv] = w; }
+        __syncthreads();
+        if (tid <= K && m != -INFINITY) {
+            double t = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < kWaves; ++w2) t += s_sum[tid * kWaves + w2];
+            const double nm = fmax(M, m);
+            S = S * (M == -INFINITY ? 0.0 : exp(M - nm)) + t * exp(m - nm);
+            M = nm;
+        }
+        __syncthreads();
+    }
+    if (tid <= K) fpart_t[(int64_t)(tid + 1) * gridDim.x + blockIdx.x] = S;
+    if (tid == 0) fpart_t[blockIdx.x] = M;
+}
+
+// One workgroup per predict hit t: StatsPrinter's numbers from the workgroups' partials (fixed order: bitwise reproducible).
+__global__ __launch_bounds__(kThreads) void filter_finalize_kernel(const double* __restrict__ fpart, int grid, int K, int is_int, double* __restrict__ stats)
+{
+    __shared__ double s_scr[kWaves];
+    __shared__ double s_out[9];
+    const int t = blockIdx.x;
+    const double* base = fpart + (int64_t)t * (K + 2) * grid;
+    double m = -INFINITY;
+    for (int g = threadIdx.x; g < grid; g += kThreads) m = fmax(m, base[g]);
+    const double M = block_max(m, s_scr);
+    for (int j = 0; j <= K; ++j) {
+        double s = 0.0;
+        for (int g = threadIdx.x; g < grid; g += kThreads) { const double mg = base[g]; if (mg != -INFINITY) s += base[(int64_t)(j + 1) * grid + g] * exp(mg - M); }
+        __syncthreads();
+        s = block_sum(s, s_scr);
+        if (threadIdx.x == 0) s_out[j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double W = s_out[0];
+        if (is_int) { for (int j = 0; j < K; ++j) stats[t * K + j] = s_out[j + 1] / W; }
+        else { const double mean = s_out[1] / W; stats[t * K] = mean; stats[t * K + 1] = s_out[2] / W - mean * mean; }
+    }
 }
 
 // Sums the per-workgroup partial statistics (layout [T*K][grid]) in a fixed order (bitwise

@@ -374,6 +374,8 @@ struct StepCountsArgs {
     // exact doubles; nullptr on a single shard
     const double* all_totals; int world, rank;
     const int64_t* annex_base;                                  // [T + 1]: annex columns in use before the immigrants of step t arrive
+    int row_w, row_r;                                           // rows of values[] this step writes / reads (t, t - 1; a filtering-only run: its two rows in turn)
+    double* filter_stats;                                       // filtering-only run: [T][3], generation t-1's P(x = s) from its totals (nullptr otherwise)
 };
 
 // This tile's entry of generation t's hierarchy, added into the levels above (see the header of this file), and the entries of
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     // output tile almost surely descends from (its own index and both neighbours) and, in the workgroup's first wavefront (which
     // searches for all four), the generation's totals and the words of the search's first probe: fetched here, in one round trip
     // that the random draws below cover.
-    const S* prev_row = a.values + (int64_t)(t > 0 ? t - 1 : 0) * a.rs;
+    const S* prev_row = a.values + (int64_t)a.row_r * a.rs;
     const bool searcher = wave_id() == 0;
     uint32_t raw_0 = 0, raw_m1 = 0, raw_p1 = 0;
     uint64_t w_tot = 0;
@@ -500,6 +502,10 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
                 c->log_z = lz; c->n_resampled = nr;
                 if (a.ess_trace) a.ess_trace[t - 1] = ess;
                 if (a.resampled) a.resampled[t - 1] = 1;
+                if (a.filter_stats) {                              // predict hit t-1 under generation t-1's own weights
+                    double* fs = a.filter_stats + 3 * (t - 1);
+                    fs[0] = __dmul_rn(tot0, tc.e0) / W; fs[1] = __dmul_rn(tot1, tc.e1) / W; fs[2] = __dmul_rn(tot2, tc.e2) / W;
+                }
             }
             const Located loc = counts_locate(a.h, tc, a.n, nb, gj_first, n_out, bid, &pw0);
             int64_t l0 = 0, l1 = 0;
@@ -546,8 +552,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     bool valid[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
-    store4_as(a.values + (int64_t)t * a.rs, j0, x);                                           // predict #t
-    store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
+    store4_as(a.values + (int64_t)a.row_w * a.rs, j0, x);                                     // predict #t
+    if (a.anc) store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);                      // (a filtering-only run keeps no ancestors)
 
     // ---- observe #t as counts ----
     uint32_t c0 = 0, c1 = 0;
@@ -578,6 +584,7 @@ struct CountsFinal {
     double n_pop; int T;
     int bookkeep;                // 0: the run's bookkeeping is done (a joint population's, by counts_final_ctrl_kernel; a repeated read-out)
     StepCtrl* ctrl; double* ess_trace; int32_t* resampled;
+    double* filter_stats;        // filtering-only run: [T][3]; the final generation's row is written with its bookkeeping
 };
 
 // Bookkeeping of the final generation (scan_tail's, for a generation no resampling follows) from its totals.  One thread.
@@ -595,6 +602,10 @@ __device__ __forceinline__ void counts_final_bookkeep(const CountsFinal& f, doub
     c->log_z = lz + (f.e[3] + log(W / f.n_pop));
     if (f.ess_trace) f.ess_trace[f.T - 1] = ess;
     if (f.resampled) f.resampled[f.T - 1] = 0;
+    if (f.filter_stats) {
+        double* fs = f.filter_stats + 3 * (f.T - 1);
+        fs[0] = __dmul_rn(tot0, f.e[0]) / W; fs[1] = __dmul_rn(tot1, f.e[1]) / W; fs[2] = __dmul_rn(tot2, f.e[2]) / W;
+    }
 }
 
 // The same for one shard of a joint population, from the all-gathered {n_0, n_1, particles} of every rank (exact doubles: the sums
@@ -606,6 +617,13 @@ __global__ __launch_bounds__(kWave) void counts_final_ctrl_kernel(CountsFinal f,
     if (lane < world) { r0 = all_totals[3 * lane]; r1 = all_totals[3 * lane + 1]; }
     const double tot0 = wave_sum(r0), tot1 = wave_sum(r1);
     if (lane == 0) counts_final_bookkeep(f, tot0, tot1);
+}
+
+// A filtering-only run has no lineages to walk: the final generation's bookkeeping (and its row of statistics) is the whole read-out.
+__global__ __launch_bounds__(kWave) void counts_filter_final_kernel(CountsFinal f)
+{
+    const Cnt2 tl = hier_total(f.h);
+    if (threadIdx.x == 0) counts_final_bookkeep(f, (double)tl.n0, (double)tl.n1);
 }
 
 template <class Model>

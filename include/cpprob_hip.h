@@ -86,8 +86,11 @@ typedef struct cpprob_hip_config {
                                  RNG streams); shards are combined by their evidence estimates;
                                  CPPROB_HIP_SCOPE_EXCHANGE: like GLOBAL, with particle migration
                                  (cpprob_hip_exchange_*) so that resampling is exact over shards */
-    int32_t keep_history;     /* 1: keep per-step values + ancestors (needed for smoothing /
-                                 dumps; always 1 in this version)                             */
+    int32_t keep_history;     /* 1: keep per-step values + ancestors: statistics over whole traces (what the reference's
+                                 posterior files hold), dumps.  0 (SMC, one population per context): filtering only --
+                                 two rows of values, no ancestors (memory O(N) instead of O(N T)); predict hit t's
+                                 statistics are those of generation t under its own weights; cpprob_hip_copy_values /
+                                 _ancestors / _paths return CPPROB_HIP_ESTATE                                    */
     int32_t reserved;         /* exchange scope: immigrant-annex capacity in units of 1024 columns per row (0 = default: 1/16 of
                                  the shard, at least 4096); stream-ordered runs cannot grow it mid-run and report overflow instead */
     double ess_threshold;     /* SMC: resample after a step iff ESS < ess_threshold * N_global;

@@ -262,6 +262,81 @@ def test_smc_short_traces_read_out_from_the_final_counts(engine, golden_dir, T, 
         assert abs(engine.summary()["log_evidence"] - s["log_evidence"]) == 0.0
 
 
+def _hmm_filter_from_states(hist, obs):
+    """P(x_t = s | y_0..t) estimated by a generation that entered step t equally weighted: sum_i [x = s] e_s / sum_i e_x."""
+    means = np.array([-1.0, 0.0, 1.0])
+    out = np.zeros((len(obs), 3))
+    for t, y in enumerate(obs):
+        e = np.exp(-0.5 * (y - means) ** 2)
+        cnt = np.bincount(hist[t], minlength=3).astype(np.float64)
+        out[t] = cnt * e / (cnt * e).sum()
+    return out
+
+
+@pytest.mark.parametrize("n", [5_000, 70_000, 1_000_000])
+def test_filtering_only_run_count_form(engine, golden_dir, n):
+    """keep_history = 0: two rows of values, no ancestors; predict hit t's statistics are generation t's under its own weights.
+    Count form (hmm, every-step schedule): the same particles as the history-keeping run, so the filtering marginals follow from
+    the oracle's states exactly, the evidence is the same number, and the exact forward filter is within Monte-Carlo error."""
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    obs = z["hmm16"]
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=11, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=2.0)
+    engine.run()
+    keep = engine.summary()
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=11, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=2.0, keep_history=False)
+    for rep in range(2):
+        engine.run()
+        s = engine.summary()
+        assert s["log_evidence"] == keep["log_evidence"] and s["n_resampled"] == 15 and s["ess_final"] == keep["ess_final"]
+        st = engine.stats()
+        if n <= 70_000:
+            ref = O.smc(cp.MODEL_HMM3, obs, n, 11, cp.RESAMPLE_SYSTEMATIC, 2.0)
+            np.testing.assert_allclose(st, _hmm_filter_from_states(ref["hist"], obs), rtol=0, atol=1e-13)
+            np.testing.assert_allclose(engine.logw(), ref["logw"], rtol=1e-12, atol=1e-12)
+        assert np.abs(st - z["hmm16_filter"]).max() < 4.0 / np.sqrt(n)
+    for getter in (engine.values, engine.ancestors, engine.paths):
+        with pytest.raises(cp.CpprobHipError):
+            getter()
+    # the context goes back to keeping history without residue
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=11, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=2.0)
+    engine.run()
+    assert engine.summary()["log_evidence"] == keep["log_evidence"] and engine.ancestors().shape == (16, n)
+
+
+@pytest.mark.parametrize("model,key,ess,resampler", [(cp.MODEL_HMM3, "hmm16", 0.5, cp.RESAMPLE_SYSTEMATIC),
+                                                       (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 0.5, cp.RESAMPLE_SYSTEMATIC),
+                                                       (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 2.0, cp.RESAMPLE_STRATIFIED),
+                                                       (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 2.0, cp.RESAMPLE_MULTINOMIAL)])
+def test_filtering_only_run_floating_point_form(engine, golden_dir, model, key, ess, resampler):
+    """The same for continuous weights / ESS-triggered schedules: every step leaves its own weighted sums.  Same particles as the
+    history-keeping run: the last predict hit's statistics agree (smoothing and filtering coincide there), the evidence is the
+    same number, and the exact filter (forward algorithm / Kalman) is within Monte-Carlo error at every step."""
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    obs = z[key][:30]
+    n = 300_000
+    engine.begin(cp.ALG_SMC, model, obs, n, seed=5, resampler=resampler, ess_threshold=ess)
+    engine.run()
+    keep, keep_stats = engine.summary(), engine.stats().copy()
+    engine.begin(cp.ALG_SMC, model, obs, n, seed=5, resampler=resampler, ess_threshold=ess, keep_history=False)
+    engine.run()
+    s, st = engine.summary(), engine.stats()
+    assert s["log_evidence"] == keep["log_evidence"] and s["n_resampled"] == keep["n_resampled"]
+    np.testing.assert_allclose(st[-1], keep_stats[-1], rtol=1e-9, atol=1e-12)
+    if model == cp.MODEL_HMM3:
+        assert np.abs(st - z["hmm16_filter"]).max() < 2e-2
+    else:
+        assert np.abs(st[:, 0] - z["lgssm100_filter_mean"][:30]).max() < 2e-2
+        assert np.abs(st[:, 1] - z["lgssm100_filter_var"][:30]).max() < 2e-2
+    with pytest.raises(cp.CpprobHipError):
+        engine.paths()
+
+
+def test_filtering_only_run_is_refused_for_a_shard_of_a_joint_population(engine, golden_dir):
+    obs = _obs(golden_dir, "hmm16")
+    with pytest.raises(cp.CpprobHipError):
+        engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 1000, n_global=2000, scope=cp.SCOPE_EXCHANGE, keep_history=False)
+
+
 def test_smc_hmm16_config3_vs_forward_backward(engine, golden_dir):
     """BASELINE.json configs[2]: hmm<16>, systematic resampling every step, 10^6 particles."""
     z = np.load(os.path.join(golden_dir, "observations.npz"))
