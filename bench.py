@@ -453,6 +453,17 @@ def main():
                              "log_evidence": {"mean": float(np.mean(lzs)), "sd": float(np.std(lzs, ddof=1))},
                              "exact_log_evidence": spec.get("exact_logz")}
 
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "hmm16_smc":
+        # secondary: the same particles without their history (keep_history = 0: two rows of values, no ancestors, no lineage
+        # walk); predict hit t's statistics are then the FILTERING ones -- a different estimand from the headline's whole-trace
+        # posterior, which is why this is not `value`
+        zf = np.load(os.path.join(ROOT, "tests", "golden", "observations.npz"))
+        eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"], keep_history=False)
+        fdt, _ = timed_runs(eng, args.steps, args.warmup, 1, device, False)
+        out["filtering_only"] = {"ms_per_run": fdt / args.steps * 1e3, "particles_per_sec": n * args.steps / fdt,
+                                 "filter_max_abs_err_vs_exact": float(np.abs(eng.stats() - zf["hmm16_filter"]).max()),
+                                 "note": "keep_history = 0: particle store O(N) instead of O(N T); 16 step launches + one bookkeeping wavefront"}
+
     if rank == 0 and world == 1 and not args.no_extras and spec["alg"] == cp.ALG_SMC and not exchange:
         # secondary: the same runs with several contexts in flight.  One run is a dependent chain of ~19 launches whose
         # step kernels leave CUs idle at their tails; independent runs (replicates, other observation sets) on separate
