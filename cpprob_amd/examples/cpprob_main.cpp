@@ -8,6 +8,7 @@
 //                   --generic (run the unchanged model body on the GPU instead of the fused kernels)
 //                   --gpus N | --devices a,b,...  (one joint population sharded over several GPUs: exact global resampling, RCCL over xGMI;
 //                                                  equal entries, e.g. 0,0,0: every rank on that GPU)
+//                   --filtering_only (smc, built-in models: O(N) particle store, filtering statistics, no posterior files)
 //                   --no_dump  --json (print the in-memory result as one JSON line)
 // This file never touches HIP: it calls cpprob::inference exactly as the reference's main does.
 #include <array>
@@ -121,6 +122,7 @@ int main(int argc, char** argv)
         else if (f == "--ess_threshold") opt.ess_threshold = std::stod(next());
         else if (f == "--resampler") { const std::string r = next(); opt.resampler = r == "multinomial" ? 2 : (r == "stratified" ? 1 : 0); }
         else if (f == "--generic") opt.prefer_builtin = false;
+        else if (f == "--filtering_only") { opt.keep_history = false; opt.dump = false; }   // smc, built-in models: O(N) particle store, filtering statistics
         else if (f == "--no_markov_probe") opt.markov_probe = false;          // unchanged-model smc: replay the whole trace every step
         else if (f == "--gpus") { const int k = std::stoi(next()); opt.devices.clear(); for (int d = 0; d < k; ++d) opt.devices.push_back(d); }
         else if (f == "--devices") {                        // e.g. 0,1,2,3 -- or 0,0 for two ranks on one GPU (loopback transport)

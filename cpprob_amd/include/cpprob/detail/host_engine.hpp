@@ -197,7 +197,8 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
     cfg.model = model_id;
     cfg.resampler = opt.resampler;
     cfg.resample_scope = CPPROB_HIP_SCOPE_GLOBAL;
-    cfg.keep_history = 1;
+    cfg.keep_history = (opt.keep_history || algorithm != StateType::smc) ? 1 : 0;
+    if (!cfg.keep_history && store) throw std::runtime_error("cpprob::inference: a filtering-only run (options().keep_history = false) keeps no traces to dump: set options().dump = false");
     cfg.ess_threshold = opt.ess_threshold;
     cfg.seed = opt.seed;
     cfg.n_particles = n; cfg.particle_offset = 0; cfg.n_global = n;

@@ -27,6 +27,9 @@ struct Options {
     bool markov_probe = true;                         // smc, unchanged-model path: test on the host whether a step depends on more than the last few
                                                       // sampled values; a model that does not is replayed from that window only (O(T) instead of O(T^2))
     bool prefer_builtin = true;                       // use the hand-fused kernels when the model is one of the built-ins
+    bool keep_history = true;                         // smc, built-in models on one GPU: false = filtering only -- O(N) particle store instead of O(N T),
+                                                      // every predict hit's numbers under its own generation's weights, no posterior files
+                                                      // (cpprob_hip_config::keep_history)
     bool progress = false;
     int replicates = 1;                               // built-in models: R independent runs (seeds seed .. seed + R - 1), up to three in
                                                       // flight on separate contexts; Result then carries their spread (error bars)

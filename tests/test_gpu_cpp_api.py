@@ -100,6 +100,21 @@ def test_generic_and_builtin_agree_hmm_smc(tmp_path):
     assert np.mean(vg != paths) < 2e-3
 
 
+def test_filtering_only_run_from_the_cpp_host(tmp_path):
+    """cpprob::gpu::options().keep_history = false (CLI --filtering_only): the reference's call, an O(N) particle store, the
+    filtering marginals instead of the whole-trace posterior, the same evidence."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    n = 400000
+    base = ["--model", "hmm16", "--smc", "--observes", obs_str(z["hmm16"]), "--n_samples", n, "--seed", 3, "--ess_threshold", 2.0, "--json", "--no_dump"]
+    keep, _, _ = run_main(tmp_path, *base)
+    filt, _, _ = run_main(tmp_path, *base, "--filtering_only")
+    assert filt["builtin"] and filt["log_evidence"] == keep["log_evidence"] and filt["n_resampled"] == 15
+    pf = np.array([p["p"] + [0.0] * (3 - len(p["p"])) for p in filt["predicts"]])
+    pk = np.array([p["p"] + [0.0] * (3 - len(p["p"])) for p in keep["predicts"]])
+    assert np.abs(pf - z["hmm16_filter"]).max() < 6e-3 and np.abs(pk - z["hmm16_smooth"]).max() < 2e-2
+    np.testing.assert_allclose(pf[-1], pk[-1], atol=1e-12)          # the last hit: filtering and smoothing coincide
+
+
 def test_generic_lgssm_smc_ess_triggered(tmp_path):
     z = np.load(os.path.join(GOLD, "observations.npz"))
     obs = z["lgssm100"][:25]
