@@ -139,8 +139,17 @@ def guarded(fn, what):
     instead of holding the node until the launcher's own limit.  Exceptions of fn() are re-raised here."""
     import threading
     box = {}
+    cur = None
+    try:
+        import torch
+        cur = torch.cuda.current_device() if torch.cuda.is_available() else None
+    except Exception:               # noqa
+        cur = None
     def body():
         try:
+            if cur is not None:
+                import torch
+                torch.cuda.set_device(cur)          # (the current device is a per-thread setting: a fresh thread starts on device 0)
             box["value"] = fn()
         except BaseException as e:        # noqa: handed to the caller
             box["error"] = e
@@ -390,21 +399,43 @@ def main():
     if native_error:
         out["config"]["native_driver_error"] = native_error
 
+    def emit():
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
     if world > 1 and exchange and not args.no_extras:
         # secondary, labelled: the migration-free scopes on the same shards (every rank takes part).  "island": independent
         # populations combined once per run by their evidence -- no data-path collective; "global": one joint population, per-step
         # all-gather of 3 doubles per rank, resampling local to the shard (mass share carried) -- a different estimator from the
         # headline's exact global resampling ("offer it as an option, not the default").
+        # They go through torch.distributed's collectives; the headline above is already measured, so nothing here may cost it:
+        # an error is reported under the key, and a collective that never completes ends the job AFTER the line has been written.
+        import threading
         sec = {}
-        k2, w2 = max(2, min(args.steps, 20)), max(1, min(args.warmup, 3))
-        for name, isl in (("island", True), ("global", False)):
-            eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
-                      particle_offset=rank * n, n_global=n_global, scope=cp.SCOPE_ISLAND if isl else cp.SCOPE_GLOBAL)
-            sdt, slast = timed_runs(eng, k2, w2, world, device, isl, first_index=70_000)
-            sec[name] = {"particles_per_sec": n_global * k2 / sdt, "ms_per_run": sdt / k2 * 1e3, "runs": k2,
-                         "posterior_max_abs_err_vs_exact": float(np.abs(slast[0] - spec["exact"]).max()) if slast is not None else None,
-                         "collective": "all_gather(4+T*K doubles/rank) once per run" if isl else "all_gather(3 doubles/rank) per step, no migration"}
-        out["secondary_scopes"] = sec
+        def secondary():
+            torch.cuda.set_device(local)            # (per-thread setting)
+            k2, w2 = max(2, min(args.steps, 20)), max(1, min(args.warmup, 3))
+            for name, isl in (("island", True), ("global", False)):
+                try:
+                    eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
+                              particle_offset=rank * n, n_global=n_global, scope=cp.SCOPE_ISLAND if isl else cp.SCOPE_GLOBAL)
+                    sdt, slast = timed_runs(eng, k2, w2, world, device, isl, first_index=70_000)
+                    sec[name] = {"particles_per_sec": n_global * k2 / sdt, "ms_per_run": sdt / k2 * 1e3, "runs": k2,
+                                 "posterior_max_abs_err_vs_exact": float(np.abs(slast[0] - spec["exact"]).max()) if slast is not None else None,
+                                 "collective": "all_gather(4+T*K doubles/rank) once per run" if isl else "all_gather(3 doubles/rank) per step, no migration"}
+                except Exception as e:      # noqa: reported under the key
+                    sec[name] = {"error": str(e)}
+                    return
+        th = threading.Thread(target=secondary, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("CPPROB_BENCH_SECONDARY_TIMEOUT", "240")))
+        out["secondary_scopes"] = dict(sec)
+        if th.is_alive() or any("error" in v for v in sec.values()):
+            # (a rank that failed or stalled leaves its peers inside a collective: no orderly shutdown is possible)
+            out["secondary_scopes"]["incomplete"] = "timed out" if th.is_alive() else "error"
+            emit()
+            os._exit(0)
 
     if rank == 0 and world == 1 and not args.no_extras and smc:
         # secondary: the multi-GPU protocol at world = 1 -- the library's C++ driver over RCCL with a single rank: per step the sharded
@@ -531,9 +562,7 @@ def main():
             except Exception as e:
                 out["cpu_baseline"]["as_shipped_sis_1core"] = {"error": str(e)}
 
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    emit()
     if group is not None:
         group.close()
     eng.close()
