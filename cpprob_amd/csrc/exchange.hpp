@@ -21,7 +21,7 @@ constexpr int kMaxWorld = 64;
 
 struct ExchangePlan {
     int32_t resample;                 // the step's decision (device-side)
-    int32_t overflow;                 // sticky per run: 1 = a peer segment or the annex was too small, 2 = a rank outside the peer list was needed
+    int32_t overflow;                 // sticky per run, bit set: 1 = a peer segment was too small, 2 = a rank outside the peer list was needed, 4 = the annex was too small
     int64_t l0, l1;                   // local outputs [l0, l1) descend from local sources
     int64_t n_send, n_recv;
     int64_t send_lo[kMaxWorld];       // per RANK: first global output of mine that lives there, how many, where its records start (in records)
@@ -110,7 +110,6 @@ __global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, Pl
     int64_t n_recv = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ro_incl, kWave - 1);
     const int64_t n_send = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)so_incl, kWave - 1);
     const int64_t base = t == 0 ? 0 : annex_base[t];
-    if (base + n_recv > g.annex_cap) flag = flag ? flag : 1;
     const unsigned long long any1 = __ballot(flag == 1), any2 = __ballot(flag == 2);
     if (lane < world) {
         plan->send_lo[lane] = send_lo; plan->send_cnt[lane] = send_cnt; plan->send_base[lane] = send_base;
@@ -119,8 +118,11 @@ __global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, Pl
     if (lane == 0) {
         const bool over_annex = base + n_recv > g.annex_cap;
         plan->resample = resample ? 1 : 0;
-        if (t == 0) plan->overflow = 0;
-        if (any2) plan->overflow = 2; else if (any1 && plan->overflow == 0) plan->overflow = 1;
+        int32_t ov = t == 0 ? 0 : plan->overflow;
+        if (any1) ov |= 1;
+        if (any2) ov |= 2;
+        if (over_annex) ov |= 4;
+        plan->overflow = ov;
         plan->l0 = l0; plan->l1 = l1; plan->n_send = n_send; plan->n_recv = over_annex ? 0 : n_recv;
         if (t == 0) annex_base[0] = 0;
         annex_base[t + 1] = base + (over_annex ? 0 : n_recv);

@@ -76,7 +76,8 @@ __global__ void pack_joint_kernel(const double* __restrict__ stats, int n_stats,
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_stats) out[i] = stats[i];
-    if (i == 0) out[n_stats] = plan ? (double)plan->overflow : 0.0;
+    // (the flag word's three bits travel as three base-128 digits, so that the all-reduce's SUM over <= 64 ranks keeps them apart)
+    if (i == 0) { const int ov = plan ? plan->overflow : 0; out[n_stats] = (double)((ov & 1) + 128 * ((ov >> 1) & 1) + 16384 * ((ov >> 2) & 1)); }
 }
 
 // loopback collectives: every rank lives on this device and this stream
@@ -485,15 +486,21 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, hipMemcpy(joint.data(), g->d_joint[0], joint.size() * sizeof(double), hipMemcpyDeviceToHost));
         if (joint[(size_t)g->n_stats] == 0.0) break;
-        // some rank's transport segment or annex was too small (every rank sees the same all-reduced flag and takes the same
-        // decision): repeat the run with every rank as a peer, full-shard segments and a larger annex.  Results do not depend
-        // on the transport parameters, only their validity does.
-        if (attempt >= 4) return gfail(g, CPPROB_HIP_EDEVICE, "exchange transport still too small after four enlargements");
+        // some rank's transport was too small (every rank sees the same all-reduced flags and takes the same decision): repeat
+        // the run with what overflowed enlarged -- the annex (x4), the peer segments (x4, up to a whole shard), the peer list
+        // (every rank).  Results do not depend on the transport parameters, only their validity does.
+        if (attempt >= 6) return gfail(g, CPPROB_HIP_EDEVICE, "exchange transport still too small after six enlargements");
+        const long long v = (long long)joint[(size_t)g->n_stats];
+        const bool seg = v % 128 != 0, peers = (v / 128) % 128 != 0, annex = v / 16384 != 0;
         uint64_t largest = 0;
         for (int r = 0; r < g->world; ++r) largest = std::max(largest, g->shard_begin[(size_t)r + 1] - g->shard_begin[(size_t)r]);
-        g->all_peers = 1; g->cap = largest;
-        g->annex_kcols = std::max(4, g->annex_kcols * 4);
-        while ((uint64_t)g->annex_kcols * 1024 < largest / 4) g->annex_kcols *= 2;
+        if (peers) g->all_peers = 1;
+        if (seg) g->cap = std::min<uint64_t>(largest, std::max<uint64_t>(g->cap * 4, 16384));
+        if (annex || (!seg && !peers)) {
+            // (0 = the context's default: a sixteenth of the shard, at least four tiles -- cpprob_hip_infer_begin)
+            const int in_use = g->annex_kcols > 0 ? g->annex_kcols : (int)std::max<uint64_t>(4, ((largest + 1023) / 1024) / 16);
+            g->annex_kcols = in_use * 4;
+        }
         if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
         ++g->reruns;
         if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);

@@ -219,10 +219,10 @@ int cpprob_hip_exchange_commit(cpprob_hip_ctx* ctx, int32_t t, const void* d_rec
  *     pack_async(t)    plans on the device and fills d_send;
  *     the caller moves slot s of d_send to rank h_peers[s], into the slot that rank keeps for this one, stream-ordered;
  *     commit_async(t)  turns what arrived in d_recv into annex columns;
- *   status     after the run (synchronises): overflow = 0 fine; 1 a peer segment or the immigrant annex was too small; 2 a rank
- *              outside the peer set was needed.  A non-zero value invalidates the run on EVERY rank of the group (ranks must
- *              agree on it -- all-reduce the flag): repeat it with a larger capacity / all_peers = 1.  Results do not depend on the
- *              transport parameters. */
+ *   status     after the run (synchronises): overflow = 0 fine; otherwise a set of bits: 1 a peer segment was too small, 2 a rank
+ *              outside the peer set was needed, 4 the immigrant annex was too small.  A non-zero value invalidates the run on
+ *              EVERY rank of the group (ranks must agree on it -- all-reduce the bits): repeat it with what overflowed enlarged
+ *              (records_per_peer / all_peers = 1 / cpprob_hip_config::reserved).  Results do not depend on the transport parameters. */
 int cpprob_hip_exchange_setup(cpprob_hip_ctx* ctx, int32_t world, int32_t rank, const uint64_t* h_shard_begin, int32_t all_peers, uint64_t records_per_peer);
 int cpprob_hip_exchange_transport(cpprob_hip_ctx* ctx, void** d_send, void** d_recv, int32_t* n_peers, int32_t* h_peers, uint64_t* records_per_peer,
                                   uint64_t* bytes_per_value);
