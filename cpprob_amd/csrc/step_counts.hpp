@@ -21,6 +21,12 @@
 // ONE wavefront reduction -- instead of every workgroup re-reading every tile partial (the r01 prologue: 3.9 of 12.3 us, 23 MB of
 // L2 reads per step).  No LDS table, no normalisation launch between steps, up to 64^3 tiles (2.7e8 particles) per GPU.
 // Three copies rotate: a step reads one (generation t-1), adds into the next and clears the third.
+//
+// Shape of the step kernel (profiles/r02_notes.md has the measurements behind each choice): everything the prologue reads is
+// addressed by the launch geometry, so it is fetched at kernel entry in ONE round trip under the Philox draws; the workgroup's
+// first wavefront does the search (totals, N / W, probes of the hierarchy) and hands {first source tile, its prefix counts, last
+// source tile} to the other three through LDS; all four then walk those source tiles.  The run's last step is a step like any
+// other: the read-out (smooth_counts_kernel / counts_filter_final_kernel) takes weights and normaliser from the counts it leaves.
 #pragma once
 #include "kernels.hpp"
 
