@@ -592,10 +592,12 @@ static void hmm_weight_table(double y, double e[3], double *mref)
 /* hist_anc [T][n]: slot of generation t-1 that slot i of generation t extends */
 /* (row 0 = identity).                                                         */
 /* ------------------------------------------------------------------------- */
-ORC_API int orc_smc(int model, const double *obs, size_t T, uint64_t n, uint64_t seed,
-                    int resampler, double ess_frac,
-                    double *hist_real, int32_t *hist_int, int32_t *hist_anc,
-                    double *logw_final, double *log_z, double *ess_trace, int32_t *resampled)
+/* filter_stats (optional, [T][K]): predict hit t under generation t's OWN weights -- P(x_t = s) (HMM, K = 3) or {mean, variance}
+ * (K = 2) -- what a filtering-only run (keep_history = 0) reports instead of the whole-trace posterior. */
+static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint64_t seed,
+                        int resampler, double ess_frac,
+                        double *hist_real, int32_t *hist_int, int32_t *hist_anc,
+                        double *logw_final, double *log_z, double *ess_trace, int32_t *resampled, double *filter_stats)
 {
     if (model != ORC_MODEL_LINEAR_GAUSSIAN_1D && model != ORC_MODEL_HMM3) return -2;
     if ((model == ORC_MODEL_HMM3) != (hist_int != NULL)) return -3;
@@ -644,6 +646,18 @@ ORC_API int orc_smc(int model, const double *obs, size_t T, uint64_t n, uint64_t
         for (uint64_t i = 0; i < n; ++i) { double w = exp(logw[i] - max); W += w; Q += w * w; }
         double ess = W * W / Q;
         if (ess_trace) ess_trace[t] = ess;
+        if (filter_stats) {
+            if (model == ORC_MODEL_HMM3) {
+                double acc[3] = { 0.0, 0.0, 0.0 };
+                for (uint64_t i = 0; i < n; ++i) acc[hist_int[t * n + i]] += exp(logw[i] - max);
+                for (int k = 0; k < 3; ++k) filter_stats[t * 3 + k] = acc[k] / W;
+            } else {
+                double s1 = 0.0, s2 = 0.0;
+                for (uint64_t i = 0; i < n; ++i) { const double w = exp(logw[i] - max), x = hist_real[t * n + i]; s1 += w * x; s2 += w * x * x; }
+                filter_stats[t * 2] = s1 / W;
+                filter_stats[t * 2 + 1] = s2 / W - (s1 / W) * (s1 / W);
+            }
+        }
         do_resample = (t + 1 < T) && (ess < ess_frac * (double)n);
         if (resampled) resampled[t] = do_resample;
         if (do_resample) lz += max + log(W / (double)n);
@@ -653,6 +667,22 @@ ORC_API int orc_smc(int model, const double *obs, size_t T, uint64_t n, uint64_t
     if (log_z) *log_z = lz;
     free(logw); free(cdf); free(anc);
     return 0;
+}
+
+ORC_API int orc_smc(int model, const double *obs, size_t T, uint64_t n, uint64_t seed,
+                    int resampler, double ess_frac,
+                    double *hist_real, int32_t *hist_int, int32_t *hist_anc,
+                    double *logw_final, double *log_z, double *ess_trace, int32_t *resampled)
+{
+    return orc_smc_impl(model, obs, T, n, seed, resampler, ess_frac, hist_real, hist_int, hist_anc, logw_final, log_z, ess_trace, resampled, NULL);
+}
+
+ORC_API int orc_smc_filter(int model, const double *obs, size_t T, uint64_t n, uint64_t seed,
+                           int resampler, double ess_frac,
+                           double *hist_real, int32_t *hist_int, int32_t *hist_anc,
+                           double *logw_final, double *log_z, double *ess_trace, int32_t *resampled, double *filter_stats)
+{
+    return orc_smc_impl(model, obs, T, n, seed, resampler, ess_frac, hist_real, hist_int, hist_anc, logw_final, log_z, ess_trace, resampled, filter_stats);
 }
 
 /* Lineage read-out: path[t][i] = slot of generation t on the ancestral line of

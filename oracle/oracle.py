@@ -64,6 +64,9 @@ def lib():
         L.orc_smc.restype = C.c_int
         L.orc_smc.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
                               C.POINTER(dbl), _dp, _ip]
+        L.orc_smc_filter.restype = C.c_int
+        L.orc_smc_filter.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
+                                     C.POINTER(dbl), _dp, _ip, _dp]
         L.orc_trace_lineage.argtypes = [_ip, sz, u64, _ip]
         L.orc_smoothing_real.argtypes = [_dp, _ip, _dp, sz, u64, _dp]
         L.orc_smoothing_int.argtypes = [_ip, _ip, _dp, sz, u64, C.c_int, _dp]
@@ -164,7 +167,8 @@ def resample_table_systematic(x, e, seed, step, before=None, total=None, last_sh
 
 
 def smc(model, obs, n, seed, resampler=RESAMPLE_SYSTEMATIC, ess_frac=2.0):
-    """Returns dict(hist, anc, logw, log_z, ess, resampled)."""
+    """Returns dict(hist, anc, logw, log_z, ess, resampled, filter): filter[t] = predict hit t under generation t's own weights
+    (P(x_t = s) or {mean, variance}) -- what a filtering-only run reports."""
     obs = np.ascontiguousarray(obs, np.float64)
     T = len(obs)
     anc = np.zeros((T, n), np.int32)
@@ -174,15 +178,17 @@ def smc(model, obs, n, seed, resampler=RESAMPLE_SYSTEMATIC, ess_frac=2.0):
     lz = C.c_double(0.0)
     if is_int_model(model):
         hist = np.zeros((T, n), np.int32)
-        rc = lib().orc_smc(model, obs, T, n, seed, resampler, ess_frac, None, hist.ctypes.data, anc, logw,
-                           C.byref(lz), ess, res)
+        filt = np.zeros((T, 3))
+        rc = lib().orc_smc_filter(model, obs, T, n, seed, resampler, ess_frac, None, hist.ctypes.data, anc, logw,
+                                  C.byref(lz), ess, res, filt)
     else:
         hist = np.zeros((T, n), np.float64)
-        rc = lib().orc_smc(model, obs, T, n, seed, resampler, ess_frac, hist.ctypes.data, None, anc, logw,
-                           C.byref(lz), ess, res)
+        filt = np.zeros((T, 2))
+        rc = lib().orc_smc_filter(model, obs, T, n, seed, resampler, ess_frac, hist.ctypes.data, None, anc, logw,
+                                  C.byref(lz), ess, res, filt)
     if rc:
         raise RuntimeError("orc_smc failed rc=%d" % rc)
-    return dict(hist=hist, anc=anc, logw=logw, log_z=lz.value, ess=ess, resampled=res)
+    return dict(hist=hist, anc=anc, logw=logw, log_z=lz.value, ess=ess, resampled=res, filter=filt)
 
 
 def smoothing(hist, anc, logw, k=3):

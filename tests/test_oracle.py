@@ -289,3 +289,18 @@ def test_table_weight_resampler_is_order_independent_and_matches_the_cdf_form():
             assert (got[m] == -1).all()                                            # no output is claimed by two shards
             got[m] = ar[m] + cuts[r]
         assert np.array_equal(got, full)                                           # ... and none is left out; the ancestors are the single-shard ones
+
+
+def test_oracle_filtering_statistics_against_the_exact_filters(golden_dir):
+    """What a filtering-only run reports: predict hit t under generation t's own weights.  Forward algorithm (HMM) and Kalman
+    filter (LGSSM) within Monte-Carlo error; at the last hit filtering and smoothing are the same numbers."""
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    r = O.smc(O.MODEL_HMM3, z["hmm16"], 200_000, 3, O.RESAMPLE_SYSTEMATIC, 0.5)
+    assert np.abs(r["filter"] - z["hmm16_filter"]).max() < 8e-3
+    np.testing.assert_allclose(r["filter"][-1], O.smoothing(r["hist"], r["anc"], r["logw"])[-1], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(r["filter"].sum(axis=1), 1.0, rtol=1e-10)
+    r = O.smc(O.MODEL_LINEAR_GAUSSIAN_1D, z["lgssm100"][:12], 300_000, 3, O.RESAMPLE_SYSTEMATIC, 2.0)
+    assert np.abs(r["filter"][:, 0] - z["lgssm100_filter_mean"][:12]).max() < 8e-3
+    assert np.abs(r["filter"][:, 1] - z["lgssm100_filter_var"][:12]).max() < 8e-3
+    np.testing.assert_allclose(r["filter"][-1], O.smoothing(r["hist"], r["anc"], r["logw"])[-1], rtol=1e-10, atol=1e-12)
+
