@@ -55,6 +55,31 @@ def test_random_smc_runs_keep_their_invariants(engine, golden_dir, sweep):
         assert np.array_equal(engine.stats(), st) and engine.summary()["log_evidence"] == s["log_evidence"], tag   # reproducible
 
 
+def test_count_form_stays_bit_exact_under_extreme_observations(engine):
+    """Observations far from every state mean, a best state that flips every step, one state dominating throughout: weight
+    ratios of e^-50 and source tiles whose masses differ by orders of magnitude (the ancestor search's second probe and
+    top-down descent).  States and ancestors equal the oracle's, bit for bit."""
+    rng = np.random.default_rng(2026)
+    for k in range(9):
+        T = int(rng.integers(2, 20))
+        kind = k % 3
+        if kind == 0:
+            obs = rng.normal(size=T) * 6.0
+        elif kind == 1:
+            obs = np.where(np.arange(T) % 2 == 0, 7.0, -7.0)
+        else:
+            obs = np.full(T, 9.0)
+        n = int(rng.choice([1025, 65 * 1024 + 3, 300_001, 1_048_576, 1_300_000]))
+        seed = int(rng.integers(1, 1 << 30))
+        tag = "kind %d T %d n %d seed %d" % (kind, T, n, seed)
+        engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=seed, ess_threshold=2.0)
+        engine.run()
+        ref = O.smc(cp.MODEL_HMM3, obs, n, seed, cp.RESAMPLE_SYSTEMATIC, 2.0)
+        assert np.array_equal(engine.ancestors(), ref["anc"]) and np.array_equal(engine.values(), ref["hist"]), tag
+        assert abs(engine.summary()["log_evidence"] - ref["log_z"]) < 1e-8 * max(1.0, abs(ref["log_z"])), tag
+        assert np.abs(engine.stats() - O.smoothing(ref["hist"], ref["anc"], ref["logw"])).max() < 1e-9, tag
+
+
 @pytest.mark.parametrize("sweep", [21, 22])
 def test_random_shard_layouts_exchange_scope(engine, golden_dir, sweep):
     """Exchange scope over random shard layouts (2..5 virtual ranks, sizes from 1 particle up, outlying observations that
