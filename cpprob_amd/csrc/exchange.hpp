@@ -158,8 +158,16 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
     using S = typename Model::store_t;
     __shared__ CountsLds Lc;
     __shared__ AncestorLds Lf;
+    __shared__ uint32_t s_hop[32];                              // bit tt - 1 of word (tt - 1) / 32: did step tt - 1 resample? (<= 1024 steps)
     const int tid = threadIdx.x;
     if (!a.plan->resample || a.plan->n_send == 0) return;       // workgroup-uniform
+    // (the walk below is a chain of dependent gathers: nothing else may sit on it -- the per-step flags come out of LDS, not memory)
+    if (tid < 32) {
+        uint32_t w = 0;
+        for (int b = 0; b < 32; ++b) { const int s2 = tid * 32 + b; if (s2 < a.t && a.resampled[s2] != 0) w |= 1u << b; }
+        s_hop[tid] = w;
+    }
+    __syncthreads();
     TableCdf tc;
     bool last_shard = a.rank + 1 == a.world;
     if constexpr (COUNTS) {
@@ -201,10 +209,27 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                 in.n_valid_tile = n_out; in.id0 = 0; in.bc_in_lds = 0; in.guess = -1;
                 ancestors_systematic(in, anc, Lf, WrelSource{a.wrel});
             }
+            {
+                // the lane's four lineages side by side: each is a chain of t dependent gathers (~1 us apiece: every hop is a row
+                // further away in memory), so walking them one after the other made the packing four chains long
+                int32_t idx[kPPT]; R* rec[kPPT]; bool on[kPPT];
 #pragma unroll
-            for (int k = 0; k < kPPT; ++k) {
-                const int q = tid * kPPT + k;
-                if (q < n_out) extract_lineage<S, R>(a.values, a.anc, a.rs, a.resampled, a.t, max(anc[k], 0), a.send + (base + tl * kTile + q) * len);
+                for (int k = 0; k < kPPT; ++k) {
+                    const int q = tid * kPPT + k;
+                    on[k] = q < n_out; idx[k] = max(anc[k], 0); rec[k] = a.send + (base + tl * kTile + (on[k] ? q : 0)) * len;
+                }
+                for (int tt = a.t; tt >= 0; --tt) {
+                    const bool hop = tt > 0 && ((s_hop[(tt - 1) >> 5] >> ((tt - 1) & 31)) & 1u) != 0;
+                    const typename Model::store_t* __restrict__ vrow = a.values + (int64_t)tt * a.rs;
+                    const int32_t* __restrict__ arow = a.anc + (int64_t)tt * a.rs;
+                    int32_t nxt[kPPT];
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) nxt[k] = (on[k] && hop) ? arow[idx[k]] : idx[k];      // the chain's link first
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) { if (on[k]) __builtin_nontemporal_store(static_cast<R>(vrow[idx[k]]), rec[k] + tt); }
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) idx[k] = nxt[k];
+                }
             }
             __syncthreads();                                    // LDS is reused by the next tile
         }
