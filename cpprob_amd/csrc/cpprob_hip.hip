@@ -104,6 +104,7 @@ struct cpprob_hip_ctx {
     int hier_phase_run = 0;                                // ... of the run in flight
     bool hier_run_open = false;                            // a run's steps are in flight (the rotation's state is known only at run boundaries)
     int64_t* d_annex_base = nullptr;                       // [T + 1] exchange scope: annex columns in use before each step's immigrants
+    int32_t* d_skip = nullptr;                             // [T / 8 + 1][rs] exchange scope, long traces: skip rows (exchange.hpp: skip_rows_kernel)
     bool counts_mode = false;                              // this run's steps use smc_step_counts_kernel
     std::vector<double> h_ll_tab, h_e_tab;                 // host copies of the table-weight model's per-step tables ([T][3], [T][4])
     double* d_wpart = nullptr;                             // bounded SIS: per-workgroup partial rows
@@ -546,7 +547,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart);
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_skip);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
 }
 
@@ -697,6 +698,11 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMemsetAsync(c->d_values, 0, rows * rs * vsz, c->stream));
         if (c->keep) HIP_TRY(c, hipMalloc(&c->d_anc, T * rs * sizeof(int32_t)));
         else HIP_TRY(c, hipMalloc(&c->d_fpart, T * (8 + 2) * (size_t)c->smooth_grid * sizeof(double)));
+        {
+            // long traces in the exchange scope: skip rows shorten the extraction of migrating lineages (exchange.hpp)
+            static const bool skip_on = !(getenv("CPPROB_SKIP_ROWS") && getenv("CPPROB_SKIP_ROWS")[0] == '0');
+            if (exchange && c->keep && skip_on && T >= 3 * kSkipEvery) HIP_TRY(c, hipMalloc(&c->d_skip, (T / kSkipEvery + 1) * rs * sizeof(int32_t)));
+        }
         HIP_TRY(c, hipMalloc(&c->d_obound, (1024 + 2) * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_part[1], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
@@ -909,6 +915,11 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
         else dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
         launch_scan(c, t, 1, nullptr, 1, 0);
     }
+    if (c->d_skip && t >= kSkipEvery && (t % kSkipEvery) == 0 && !sis) {
+        // every eighth step: where each local slot's lineage sat eight generations ago
+        hipLaunchKernelGGL(skip_rows_kernel, dim3((unsigned)((c->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, (const int32_t*)c->d_anc, c->rs, c->n,
+                           (const int32_t*)c->d_resampled, t, c->d_skip + (size_t)(t / kSkipEvery) * c->rs);
+    }
     HIP_TRY(c, hipGetLastError());
     c->sharded = true;
     return 0;
@@ -994,6 +1005,8 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid)
     PackArgs<Model, R> a{};
     a.values = static_cast<const typename Model::store_t*>(c->d_values); a.anc = c->d_anc; a.rs = c->rs; a.n = c->n; a.nb = c->nb;
     a.resampled = c->d_resampled; a.t = t; a.plan = c->d_xplan; a.world = c->x_world; a.rank = c->x_rank; a.send = d_send;
+    a.skip = (c->d_skip && t >= 2 * kSkipEvery) ? c->d_skip : nullptr;
+    const dim3 pgrid((unsigned)grid, a.skip ? (unsigned)(t / kSkipEvery + 1) : 1u);
     a.pc.all_totals = c->x_all_totals; a.pc.n_pop = (double)c->pop_n;
     a.wrel = c->d_wrel[c->cur]; a.bc = c->d_bc; a.bf = c->d_bf; a.ctrl = c->d_ctrl; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
     if constexpr (Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1) {
@@ -1002,11 +1015,11 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid)
             hier_view(c, kn, a.h);
             a.pc.e0 = c->h_e_tab[(size_t)t * 4]; a.pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; a.pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
             a.pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
-            hipLaunchKernelGGL((exchange_pack_kernel<Model, R, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+            hipLaunchKernelGGL((exchange_pack_kernel<Model, R, true>), pgrid, dim3(kThreads), 0, c->stream, a);
             return;
         }
     }
-    hipLaunchKernelGGL((exchange_pack_kernel<Model, R, false>), dim3(grid), dim3(kThreads), 0, c->stream, a);
+    hipLaunchKernelGGL((exchange_pack_kernel<Model, R, false>), pgrid, dim3(kThreads), 0, c->stream, a);
 }
 
 template <class Model, class R>
@@ -1014,7 +1027,7 @@ void launch_commit(cpprob_hip_ctx* c, int t, const R* d_recv, int grid)
 {
     using S = typename Model::store_t;
     hipLaunchKernelGGL((exchange_commit_kernel<S, R>), dim3(grid), dim3(kThreads), 0, c->stream, (const ExchangePlan*)c->d_xplan, c->x_world, d_recv, t,
-                       (const int64_t*)c->d_annex_base, static_cast<S*>(c->d_values), c->d_anc, c->rs, c->ld);
+                       (const int64_t*)c->d_annex_base, static_cast<S*>(c->d_values), c->d_anc, c->rs, c->ld, c->d_skip);
 }
 
 // more annex columns: re-stride values[] / anc[] (callers that synchronise per step only)
@@ -1030,6 +1043,14 @@ int grow_annex(cpprob_hip_ctx* c, int64_t need)
     HIP_TRY(c, hipMemcpy2DAsync(nv, rs_new * vsz, c->d_values, rs_old * vsz, used * vsz, (size_t)c->T, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpy2DAsync(na, rs_new * 4, c->d_anc, rs_old * 4, used * 4, (size_t)c->T, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_skip) {
+        int32_t* ns = nullptr;
+        const size_t M = T / kSkipEvery + 1;
+        HIP_TRY(c, hipMalloc(&ns, M * (ldc + (size_t)cap) * sizeof(int32_t)));
+        HIP_TRY(c, hipMemcpy2DAsync(ns, rs_new * 4, c->d_skip, rs_old * 4, used * 4, (size_t)c->T / kSkipEvery + 1, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dfree(c->d_skip); c->d_skip = ns;
+    }
     dfree(c->d_values); dfree(c->d_anc);
     c->d_values = nv; c->d_anc = na; c->annex_cap = cap; c->rs = c->ld + cap;
     return 0;

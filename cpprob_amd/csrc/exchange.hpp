@@ -129,6 +129,27 @@ __global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, Pl
     }
 }
 
+// Skip rows.  A migrating particle takes its lineage x_0 .. x_t along, and extracting a lineage is a chain of t dependent gathers
+// (~1.7 us a hop: each is a row further away in memory) that no parallelism across particles shortens -- half of a long-trace run
+// in the exchange scope (profiles/r02_notes.md).  Row m of `skip` (written after step 8m, one launch every eighth step) holds, for
+// every local slot of generation 8m, the slot of its lineage at generation 8(m-1); annex columns get the identity when they are
+// committed.  A lineage is then extracted in blocks of eight generations by different workgroups (gridDim.y of the packing launch):
+// each reaches its block by <= 7 single hops, <= t/8 skip hops and one more, and walks eight generations -- chains of ~t/8 + 16.
+constexpr int kSkipEvery = 8;
+__global__ __launch_bounds__(kThreads) void skip_rows_kernel(const int32_t* __restrict__ anc, int64_t rs, int64_t n, const int32_t* __restrict__ resampled,
+                                                             int t, int32_t* __restrict__ skip_row)
+{
+    const int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n) return;
+    bool hop[kSkipEvery];
+#pragma unroll
+    for (int d = 0; d < kSkipEvery; ++d) hop[d] = resampled[t - 1 - d] != 0;       // (off the chain: all eight flags first)
+    int32_t idx = (int32_t)j;
+#pragma unroll
+    for (int d = 0; d < kSkipEvery; ++d) { if (hop[d]) idx = anc[(int64_t)(t - d) * rs + idx]; }
+    skip_row[j] = idx;
+}
+
 // Lineage of the generation-t particle in slot `idx`: x_0 .. x_t into rec[0 .. t].
 template <class S, class R>
 __device__ __forceinline__ void extract_lineage(const S* __restrict__ values, const int32_t* __restrict__ anc, int64_t rs, const int32_t* __restrict__ resampled,
@@ -143,6 +164,7 @@ __device__ __forceinline__ void extract_lineage(const S* __restrict__ values, co
 template <class Model, class R>
 struct PackArgs {
     const typename Model::store_t* values; const int32_t* anc; int64_t rs, n; int nb; const int32_t* resampled; int t;   // generation t is the one resampled
+    const int32_t* skip;                                         // skip rows (see skip_rows_kernel) or nullptr: gridDim.y = t / 8 + 1 blocks of generations then
     const ExchangePlan* plan; int world, rank;
     R* send;                                                     // records of t + 1 values
     // prefix-count form
@@ -210,16 +232,37 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                 ancestors_systematic(in, anc, Lf, WrelSource{a.wrel});
             }
             {
-                // the lane's four lineages side by side: each is a chain of t dependent gathers (~1 us apiece: every hop is a row
-                // further away in memory), so walking them one after the other made the packing four chains long
+                // the lane's four lineages side by side: each is a chain of dependent gathers (~1.7 us apiece: every hop is a row
+                // further away in memory), so nothing but the chain's links may sit on it
                 int32_t idx[kPPT]; R* rec[kPPT]; bool on[kPPT];
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
                     const int q = tid * kPPT + k;
                     on[k] = q < n_out; idx[k] = max(anc[k], 0); rec[k] = a.send + (base + tl * kTile + (on[k] ? q : 0)) * len;
                 }
-                for (int tt = a.t; tt >= 0; --tt) {
-                    const bool hop = tt > 0 && ((s_hop[(tt - 1) >> 5] >> ((tt - 1) & 31)) & 1u) != 0;
+                auto hops = [&](int tt) { return tt > 0 && ((s_hop[(tt - 1) >> 5] >> ((tt - 1) & 31)) & 1u) != 0; };
+                auto single = [&](int tt) {                                 // generation tt -> tt - 1
+                    if (!hops(tt)) return;
+                    const int32_t* __restrict__ arow = a.anc + (int64_t)tt * a.rs;
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) { if (on[k]) idx[k] = arow[idx[k]]; }
+                };
+                // this workgroup's block of generations [lo, hi] (the whole lineage without skip rows)
+                int hi = a.t, lo = 0;
+                if (a.skip) {
+                    lo = (int)blockIdx.y * kSkipEvery; hi = lo + kSkipEvery - 1 < a.t ? lo + kSkipEvery - 1 : a.t;
+                    int g = a.t;
+                    while (g > hi && (g % kSkipEvery) != 0) { single(g); --g; }
+                    while (g - kSkipEvery >= hi) {
+                        const int32_t* __restrict__ srow = a.skip + (int64_t)(g / kSkipEvery) * a.rs;
+#pragma unroll
+                        for (int k = 0; k < kPPT; ++k) { if (on[k]) idx[k] = srow[idx[k]]; }
+                        g -= kSkipEvery;
+                    }
+                    while (g > hi) { single(g); --g; }
+                }
+                for (int tt = hi; tt >= lo; --tt) {
+                    const bool hop = tt > lo && hops(tt);
                     const typename Model::store_t* __restrict__ vrow = a.values + (int64_t)tt * a.rs;
                     const int32_t* __restrict__ arow = a.anc + (int64_t)tt * a.rs;
                     int32_t nxt[kPPT];
@@ -240,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
 template <class S, class R>
 __global__ __launch_bounds__(kThreads) void exchange_commit_kernel(const ExchangePlan* __restrict__ plan, int world, const R* __restrict__ recv, int t,
                                                                     const int64_t* __restrict__ annex_base, S* __restrict__ values, int32_t* __restrict__ anc,
-                                                                    int64_t rs, int64_t ld)
+                                                                    int64_t rs, int64_t ld, int32_t* __restrict__ skip)
 {
     if (!plan->resample || plan->n_recv == 0) return;
     const int len = t + 1;
@@ -254,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void exchange_commit_kernel(const Exchang
             const int64_t col = col0 + off + k;
             values[(int64_t)tt * rs + col] = static_cast<S>(recv[(base + k) * len + tt]);
             anc[(int64_t)tt * rs + col] = (int32_t)col;
+            if (skip && tt >= kSkipEvery && (tt % kSkipEvery) == 0) skip[(int64_t)(tt / kSkipEvery) * rs + col] = (int32_t)col;
         }
     }
 }
