@@ -52,6 +52,7 @@ struct cpprob_hip_ctx {
     double* d_wrel[2] = {nullptr, nullptr};
     double* d_bf = nullptr;
     bool final_from_counts = false, final_bookkeep_pending = false; int final_copy = 0;
+    bool scan2_deferred = false;         // exchange scope, floating-point form: step_end left the cross-rank combine to the plan launch
     bool keep = true, cap_keep = true;   // keep_history: per-step values + ancestors (false: two rows, no ancestors, filtering statistics)
     double* d_fpart = nullptr;           // filtering-only runs, floating-point form: [T][K + 2][smooth_grid] (filter_partials_kernel)   // prefix-count form, single shard: the read-out works from the final generation's counts
     double* d_ll_tab = nullptr;     // hmm: [T][3] emission log-densities
@@ -480,7 +481,7 @@ static void counts_final_view(cpprob_hip_ctx* c, CountsFinal& f, bool bookkeep)
     f.filter_stats = c->keep ? nullptr : c->d_stats;
 }
 
-void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, int world, int rank)
+ScanArgs make_scan_args(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, int world, int rank)
 {
     ScanArgs sa{};
     sa.part = c->d_part[c->cur_part]; sa.nb = c->nb; sa.bc = c->d_bc; sa.bf = c->d_bf; sa.ctrl = c->d_ctrl; sa.t = t; sa.T = c->T;
@@ -490,6 +491,12 @@ void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, 
     sa.grid_refs = c->grid_refs ? 1 : 0;
     sa.exchange = (c->exchange && phase == 2) ? 1 : 0; sa.obound = c->d_obound;
     sa.all_totals = all_totals; sa.world = world; sa.rank = rank; sa.local_totals = c->totals_out ? c->totals_out : c->d_local_totals; sa.phase = phase;
+    return sa;
+}
+
+void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, int world, int rank)
+{
+    ScanArgs sa = make_scan_args(c, t, phase, all_totals, world, rank);
     ProfScope ps(c, 1);
     if (phase != 2 && c->nb > kSlabThreshold) {
         // large population: two multi-workgroup launches instead of one single-CU pass
@@ -933,7 +940,12 @@ int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_to
     if (c->exchange && world > kMaxWorld) return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope plans on one wavefront: world <= 64");
     HIP_TRY(c, hipSetDevice(c->device));
     c->x_all_totals = d_all_totals; c->x_world = world; c->x_rank = rank;
-    if (!c->counts_mode) launch_scan(c, t, 2, d_all_totals, world, rank);
+    if (!c->counts_mode) {
+        // floating-point form: the ranks' {max, sum, sum of squares} into ctrl.  In the exchange scope the step's plan launch follows
+        // and does this on its way in (one launch less per step); the last step has no exchange
+        c->scan2_deferred = c->exchange && t + 1 < c->T;
+        if (!c->scan2_deferred) launch_scan(c, t, 2, d_all_totals, world, rank);
+    }
     else if (t + 1 == c->T) {
         // the final generation's bookkeeping from the population's totals (the same sums a single GPU's hierarchy would hold)
         if (world > kWave) return fail(c, CPPROB_HIP_EUNSUPPORTED, "the prefix-count form sums the ranks' totals on one wavefront: world <= 64");
@@ -991,9 +1003,13 @@ int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
     if (c->counts_mode) {
         pc.e0 = c->h_e_tab[(size_t)t * 4]; pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
         pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
-        hipLaunchKernelGGL(exchange_plan_kernel<true>, dim3(1), dim3(kWave), 0, c->stream, g, pc, (const double*)c->d_obound, t, c->d_annex_base, c->d_xplan);
+        hipLaunchKernelGGL((exchange_plan_kernel<true, false>), dim3(1), dim3(kWave), 0, c->stream, g, pc, (const double*)c->d_obound, t, c->d_annex_base, c->d_xplan, ScanArgs{});
+    } else if (c->scan2_deferred) {
+        const ScanArgs sa = make_scan_args(c, t, 2, c->x_all_totals, c->x_world, c->x_rank);
+        hipLaunchKernelGGL((exchange_plan_kernel<false, true>), dim3(1), dim3(kWave), 0, c->stream, g, pc, (const double*)c->d_obound, t, c->d_annex_base, c->d_xplan, sa);
+        c->scan2_deferred = false;
     } else {
-        hipLaunchKernelGGL(exchange_plan_kernel<false>, dim3(1), dim3(kWave), 0, c->stream, g, pc, (const double*)c->d_obound, t, c->d_annex_base, c->d_xplan);
+        hipLaunchKernelGGL((exchange_plan_kernel<false, false>), dim3(1), dim3(kWave), 0, c->stream, g, pc, (const double*)c->d_obound, t, c->d_annex_base, c->d_xplan, ScanArgs{});
     }
     c->x_plan_t = t;
     return 0;

@@ -47,12 +47,24 @@ struct PlanCountsIn {                 // prefix-count form: o_r from the all-gat
 
 // One wave.  COUNTS: bounds from integer counts (canonical arithmetic, the step kernel's own expressions); otherwise from obound[]
 // (scan_exchange_bounds) and its decision word.
-template <bool COUNTS>
+// SCAN2: the launch also combines the all-gathered {max, sum, sum of squares} of the ranks into ctrl and the ranks' output bounds
+// first (what scan_partials_kernel's phase 2 does on one thread): one launch less per step of a floating-point-form exchange run.
+template <bool COUNTS, bool SCAN2 = false>
 __global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, PlanCountsIn pc, const double* __restrict__ obound, int t,
-                                                              int64_t* __restrict__ annex_base, ExchangePlan* __restrict__ plan)
+                                                              int64_t* __restrict__ annex_base, ExchangePlan* __restrict__ plan, ScanArgs sa)
 {
     const int lane = lane_id();
     const int world = g.world, rank = g.rank;
+    __shared__ double s_ob[kMaxWorld + 2];
+    if (SCAN2) {
+        if (lane == 0) {
+            scan_combine_ranks(sa);
+            scan_tail(sa);
+            scan_exchange_bounds(sa);
+            for (int r = 0; r <= world + 1; ++r) s_ob[r] = sa.obound[r];      // (this thread's own stores)
+        }
+        __syncthreads();
+    }
     double o = 0.0;                                            // lane r: o_r, r = 0..world
     bool resample;
     if (COUNTS) {
@@ -69,8 +81,8 @@ __global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, Pl
         if (lane >= world) o = pc.n_pop;
         resample = true;
     } else {
-        if (lane <= world) o = obound[lane];
-        resample = obound[world + 1] != 0.0;
+        if (lane <= world) o = SCAN2 ? s_ob[lane] : obound[lane];
+        resample = (SCAN2 ? s_ob[world + 1] : obound[world + 1]) != 0.0;
     }
     // my sources' interval and what each rank's shard takes of it / gives to me
     const double my_lo = read_lane(o, rank), my_hi = read_lane(o, rank + 1);

@@ -240,6 +240,23 @@ __device__ __forceinline__ void scan_tail(const ScanArgs& a)
     if (a.log_z_out) *a.log_z_out = ctrl->log_z;
 }
 
+// Phase 2 of a sharded step: the all-gathered per-rank {max, sum, sum of squares} into ctrl (one thread).
+__device__ __forceinline__ void scan_combine_ranks(const ScanArgs& a)
+{
+    StepCtrl* ctrl = a.ctrl;
+    double M = -INFINITY;
+    for (int r = 0; r < a.world; ++r) M = fmax(M, a.all_totals[3 * r]);
+    double W = 0.0, Q = 0.0, lo = 0.0, wl = 0.0, sc = 1.0;
+    for (int r = 0; r < a.world; ++r) {
+        const double mr = a.all_totals[3 * r];
+        const double e = (mr == -INFINITY) ? 0.0 : exp(mr - M);
+        if (r == a.rank) { lo = W; wl = a.all_totals[3 * r + 1] * e; sc = e; }
+        W += a.all_totals[3 * r + 1] * e;
+        Q += a.all_totals[3 * r + 2] * (e * e);
+    }
+    ctrl->M = M; ctrl->W = W; ctrl->Q = Q; ctrl->cdf_lo = lo; ctrl->w_local = wl; ctrl->scale = sc;
+}
+
 // Exchange scope: the sources of rank s own the outputs [o_s, o_{s+1}), o_s = G(B_s) with B_s the global CDF at the
 // start of the shard -- evaluated with exactly the expression the ancestor search uses for its first tile, so the
 // tile-level clamps of every shard meet without gap or overlap.  One thread; after scan_tail.
@@ -321,19 +338,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(ScanArgs a)
         if (a.phase == 1) return;
     } else {
         // combine the all-gathered per-rank totals (tiny: world <= 64), thread 0 only
-        if (tid == 0) {
-            double M = -INFINITY;
-            for (int r = 0; r < a.world; ++r) M = fmax(M, a.all_totals[3 * r]);
-            double W = 0.0, Q = 0.0, lo = 0.0, wl = 0.0, sc = 1.0;
-            for (int r = 0; r < a.world; ++r) {
-                const double mr = a.all_totals[3 * r];
-                const double e = (mr == -INFINITY) ? 0.0 : exp(mr - M);
-                if (r == a.rank) { lo = W; wl = a.all_totals[3 * r + 1] * e; sc = e; }
-                W += a.all_totals[3 * r + 1] * e;
-                Q += a.all_totals[3 * r + 2] * (e * e);
-            }
-            ctrl->M = M; ctrl->W = W; ctrl->Q = Q; ctrl->cdf_lo = lo; ctrl->w_local = wl; ctrl->scale = sc;
-        }
+        if (tid == 0) scan_combine_ranks(a);
     }
     if (tid == 0) scan_tail(a);
     if (tid == 0 && a.phase == 2) scan_exchange_bounds(a);
