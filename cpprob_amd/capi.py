@@ -11,6 +11,8 @@ ALG_SIS, ALG_SMC = 2, 4
 MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README, MODEL_LINEAR_GAUSSIAN_1D, MODEL_HMM3, MODEL_GAUSSIAN_2D_UNKNOWN_MEAN = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
 SCOPE_GLOBAL, SCOPE_ISLAND, SCOPE_EXCHANGE = 0, 1, 2
+# cpprob_hip_config::flags (A/B forms; 0 = the measured optimum)
+FLAG_FLOATING_POINT_STEP, FLAG_NO_SKIP_ROWS, FLAG_SIS_PER_TILE, FLAG_SIS_SEPARATE_READOUT, FLAG_WREL_STORED, FLAG_FP_TILE_PARTIALS = 1, 2, 4, 8, 16, 32
 N_KERNEL_CLASSES = 6
 KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", "resample"]
 
@@ -22,12 +24,12 @@ SYMBOLS = [
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
     "cpprob_hip_smc_finish", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
     "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_group_unique_id", "cpprob_hip_group_create", "cpprob_hip_group_destroy",
-    "cpprob_hip_group_last_error", "cpprob_hip_group_begin", "cpprob_hip_group_run", "cpprob_hip_group_sync", "cpprob_hip_group_size",
+    "cpprob_hip_group_last_error", "cpprob_hip_group_begin", "cpprob_hip_group_transport", "cpprob_hip_group_run", "cpprob_hip_group_sync", "cpprob_hip_group_size",
     "cpprob_hip_group_context", "cpprob_hip_group_results", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
     "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
     "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_lineage_gather", "cpprob_hip_gather_f64",
-    "cpprob_hip_gather_i32", "cpprob_hip_profile_enable", "cpprob_hip_profile_read",
+    "cpprob_hip_gather_i32", "cpprob_hip_profile_enable", "cpprob_hip_profile_read", "cpprob_hip_fastmath",
 ]
 
 
@@ -37,7 +39,7 @@ class CpprobHipError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("algorithm", C.c_int32), ("model", C.c_int32), ("resampler", C.c_int32), ("resample_scope", C.c_int32),
-                ("keep_history", C.c_int32), ("reserved", C.c_int32),
+                ("keep_history", C.c_int32), ("annex_kcols", C.c_int32), ("flags", C.c_uint32), ("fuse_max_tiles", C.c_int32),
                 ("ess_threshold", C.c_double), ("seed", C.c_uint64), ("n_particles", C.c_uint64),
                 ("particle_offset", C.c_uint64), ("n_global", C.c_uint64)]
 
@@ -96,6 +98,7 @@ def load_library(path=None):
         "cpprob_hip_group_destroy": (None, [vp]),
         "cpprob_hip_group_last_error": (C.c_char_p, [vp]),
         "cpprob_hip_group_begin": (C.c_int, [vp, C.POINTER(Config), C.POINTER(dbl), sz, vp]),
+        "cpprob_hip_group_transport": (C.c_int, [vp, u64, i32]),
         "cpprob_hip_group_run": (C.c_int, [vp, u64]),
         "cpprob_hip_group_sync": (C.c_int, [vp]),
         "cpprob_hip_group_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
@@ -112,6 +115,7 @@ def load_library(path=None):
         "cpprob_hip_logpdf_poisson": (C.c_int, [vp, vp, vp, sz, vp]),
         "cpprob_hip_logpdf_uniform_smallint": (C.c_int, [vp, vp, i64, i64, sz, vp]),
         "cpprob_hip_logpdf_discrete": (C.c_int, [vp, vp, C.POINTER(dbl), i32, sz, vp]),
+        "cpprob_hip_fastmath": (C.c_int, [vp, i32, vp, sz, vp, vp]),
         "cpprob_hip_logsumexp_ess": (C.c_int, [vp, vp, sz, C.POINTER(dbl)]),
         "cpprob_hip_weighted_moments": (C.c_int, [vp, vp, vp, sz, C.POINTER(dbl)]),
         "cpprob_hip_weighted_hist": (C.c_int, [vp, vp, vp, sz, i32, C.POINTER(dbl)]),
@@ -127,7 +131,7 @@ def load_library(path=None):
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.cpprob_hip_abi_version() != 1:
+    if L.cpprob_hip_abi_version() != 2:
         raise CpprobHipError("ABI version mismatch")
     if p == LIB_PATH:
         # the in-tree binary must be the build of the sources next to it (a stale .so that merely looks newer is refused)
@@ -195,13 +199,13 @@ class Engine:
 
     # ---- cpprob::inference --------------------------------------------------------------
     def begin(self, algorithm, model, observes, n_particles, seed=12345, resampler=RESAMPLE_SYSTEMATIC, ess_threshold=2.0,
-              particle_offset=0, n_global=None, scope=SCOPE_GLOBAL, keep_history=True):
+              particle_offset=0, n_global=None, scope=SCOPE_GLOBAL, keep_history=True, flags=0, fuse_max_tiles=0):
         """keep_history=False: filtering only -- two rows of the particle store and no ancestors (memory O(N) instead of
         O(N T)); stats() then holds every predict hit's statistics under ITS generation's weights, and values() / ancestors() /
         paths() raise."""
         obs = np.ascontiguousarray(observes, np.float64)
-        cfg = Config(algorithm, model, resampler, scope, 1 if keep_history else 0, 0, float(ess_threshold), int(seed), int(n_particles), int(particle_offset),
-                     int(n_particles if n_global is None else n_global))
+        cfg = Config(algorithm, model, resampler, scope, 1 if keep_history else 0, 0, int(flags), int(fuse_max_tiles), float(ess_threshold), int(seed),
+                     int(n_particles), int(particle_offset), int(n_particles if n_global is None else n_global))
         self._chk(self.L.cpprob_hip_infer_begin(self.h, C.byref(cfg), obs.ctypes.data_as(C.POINTER(C.c_double)), len(obs)))
         self.cfg = cfg
         gauss = model in (MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README)
@@ -318,6 +322,10 @@ class Engine:
         w = (C.c_double * len(weights))(*weights)
         self._chk(self.L.cpprob_hip_logpdf_discrete(self.h, _dptr(x), w, len(weights), x.numel(), _dptr(out)))
 
+    def fastmath(self, which, x, out0, out1=None):
+        """which: 0 log01, 1 sincospi02 (out0 = sin, out1 = cos), 2 exp_nonpos; torch float64 tensors on this device."""
+        self._chk(self.L.cpprob_hip_fastmath(self.h, int(which), _dptr(x), x.numel(), _dptr(out0), _dptr(out1)))
+
     def logsumexp_ess(self, logw):
         out = (C.c_double * 3)()
         self._chk(self.L.cpprob_hip_logsumexp_ess(self.h, _dptr(logw), logw.numel(), out))
@@ -405,10 +413,12 @@ class Group:
             msg = self.L.cpprob_hip_group_last_error(self.h)
             raise CpprobHipError("cpprob_hip group error %d: %s" % (rc, msg.decode() if msg else "?"))
 
-    def begin(self, algorithm, model, observes, n_particles, seed=12345, resampler=RESAMPLE_SYSTEMATIC, ess_threshold=2.0, shard_sizes=None):
+    def begin(self, algorithm, model, observes, n_particles, seed=12345, resampler=RESAMPLE_SYSTEMATIC, ess_threshold=2.0, shard_sizes=None, flags=0,
+              keep_history=True):
         """n_particles = the whole population."""
         obs = np.ascontiguousarray(observes, np.float64)
-        cfg = Config(algorithm, model, resampler, SCOPE_EXCHANGE, 1, 0, float(ess_threshold), int(seed), int(n_particles), 0, int(n_particles))
+        cfg = Config(algorithm, model, resampler, SCOPE_EXCHANGE, 1 if keep_history else 0, 0, int(flags), 0, float(ess_threshold), int(seed), int(n_particles), 0,
+                     int(n_particles))
         ss = None
         if shard_sizes is not None:
             ss = np.ascontiguousarray(shard_sizes, np.uint64)
@@ -421,6 +431,10 @@ class Group:
         self.K = 3 if self.is_int else 2
         self.n = int(n_particles)
         return self
+
+    def transport(self, records_per_peer=0, all_peers=-1):
+        """Transport parameters of the next begin() (0 / -1: the defaults)."""
+        self._chk(self.L.cpprob_hip_group_transport(self.h, int(records_per_peer), int(all_peers)))
 
     def run(self, run_index=0):
         self._chk(self.L.cpprob_hip_group_run(self.h, int(run_index)))

@@ -234,8 +234,7 @@ int bb_normalise(cpprob_hip_ctx* ctx, const double* d_logw, size_t n, double n_t
 template <class Model>
 bool sis_readout_fused(const cpprob_hip_ctx* c)
 {
-    static const bool enabled = !(getenv("CPPROB_SIS_FUSED_READOUT") && getenv("CPPROB_SIS_FUSED_READOUT")[0] == '0');
-    return enabled && c->T <= kMaxReadoutT && c->T * Model::kStats <= kMaxReadoutCols;
+    return !(c->cfg.flags & CPPROB_HIP_FLAG_SIS_SEPARATE_READOUT) && c->T <= kMaxReadoutT && c->T * Model::kStats <= kMaxReadoutCols;
 }
 
 template <class Model>
@@ -268,13 +267,12 @@ void launch_sis_readout(cpprob_hip_ctx* c)
                        (const double*)c->d_gstat, n_col, (int)Model::kStats, Model::kIsInt ? 1 : 0, c->d_stats);
 }
 
-// Bounded-weight SIS (kernels.hpp: sis_bounded_kernel): the whole run in two launches.  CPPROB_SIS_BOUNDED=0 keeps the per-tile form.
+// Bounded-weight SIS (kernels.hpp: sis_bounded_kernel): the whole run in two launches.  CPPROB_HIP_FLAG_SIS_PER_TILE keeps the per-tile form.
 template <class Model>
 bool launch_sis_bounded(cpprob_hip_ctx* c)
 {
-    static const bool enabled = !(getenv("CPPROB_SIS_BOUNDED") && getenv("CPPROB_SIS_BOUNDED")[0] == '0');
     if constexpr (Model::kBounded) {
-        if (!enabled || !c->sis_bounded_ok) return false;
+        if ((c->cfg.flags & CPPROB_HIP_FLAG_SIS_PER_TILE) || !c->sis_bounded_ok) return false;
         SisBoundedArgs<Model> a{};
         a.mp = c->mp; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.nb = c->nb; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
         a.values = static_cast<typename Model::store_t*>(c->d_values); a.logw = c->d_logw[0]; a.wpart = c->d_wpart;
@@ -318,7 +316,7 @@ void launch_step_impl(cpprob_hip_ctx* c, StepArgs<Model>& a)
 // fused = the step kernel normalises the previous generation itself (no scan_partials launch between steps)
 bool step_is_fused(const cpprob_hip_ctx* c)
 {
-    static const int max_tiles = getenv("CPPROB_FUSE_MAX_TILES") ? std::min(atoi(getenv("CPPROB_FUSE_MAX_TILES")), (int)kFuseMaxTiles) : kFuseMaxTiles;
+    const int max_tiles = c->cfg.fuse_max_tiles > 0 ? std::min((int)c->cfg.fuse_max_tiles, (int)kFuseMaxTiles) : (int)kFuseMaxTiles;
     return c->nb <= max_tiles && c->cfg.resampler != CPPROB_HIP_RESAMPLE_MULTINOMIAL && !c->step_protocol;
 }
 
@@ -340,12 +338,12 @@ void launch_step(cpprob_hip_ctx* c, int t)
     if (!c->keep) a.anc = nullptr;
     {
         // table-weight model + every step resamples + systematic + fused: the step kernel reads states instead of wrel
-        static const bool enabled = !(getenv("CPPROB_WREL_FROM_STATE") && getenv("CPPROB_WREL_FROM_STATE")[0] == '0');
+        const bool enabled = !(c->cfg.flags & CPPROB_HIP_FLAG_WREL_STORED);
         // (pays from ~2.6e5 particles: below, the extra selects cost more than the halved traffic saves -- profiles/r01_ab_notes.md)
-        static const int min_tiles = getenv("CPPROB_WREL_FROM_STATE_MIN_TILES") ? atoi(getenv("CPPROB_WREL_FROM_STATE_MIN_TILES")) : 256;
+        const int min_tiles = 256;
         a.wrel_from_state = (enabled && Model::kWeightTable > 0 && c->cfg.ess_threshold > 1.0 && c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC &&
                              !c->step_protocol && c->nb >= min_tiles) ? 1 : 0;
-        static const bool counts = !(getenv("CPPROB_PART_COUNTS") && getenv("CPPROB_PART_COUNTS")[0] == '0');
+        const bool counts = !(c->cfg.flags & CPPROB_HIP_FLAG_FP_TILE_PARTIALS);
         a.part_counts = (counts && a.wrel_from_state && step_is_fused(c)) ? 1 : 0;
     }
     a.exchange = (c->exchange && c->step_protocol) ? 1 : 0; a.imm_l01 = c->d_xplan ? &c->d_xplan->l0 : nullptr; a.annex_base = c->d_annex_base;
@@ -395,12 +393,11 @@ void launch_step(cpprob_hip_ctx* c, int t)
 
 // The prefix-count form serves table-weight models (three values) whose every step resamples systematically: ancestors are
 // then a function of integer counts (bit-exact against the oracle at any size), no step needs a normalisation launch, and the
-// per-step prologue is one wavefront reduction.  CPPROB_STEP_COUNTS=0 keeps the floating-point form (A/B runs).
+// per-step prologue is one wavefront reduction.  CPPROB_HIP_FLAG_FLOATING_POINT_STEP keeps the floating-point form (A/B runs).
 template <class Model>
 bool counts_eligible(const cpprob_hip_ctx* c)
 {
-    static const bool enabled = !(getenv("CPPROB_STEP_COUNTS") && getenv("CPPROB_STEP_COUNTS")[0] == '0');
-    return enabled && c->nb <= kCountsMaxTiles && Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1 && c->cfg.algorithm == CPPROB_HIP_ALG_SMC &&
+    return !(c->cfg.flags & CPPROB_HIP_FLAG_FLOATING_POINT_STEP) && c->nb <= kCountsMaxTiles && Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1 && c->cfg.algorithm == CPPROB_HIP_ALG_SMC &&
            c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && c->cfg.ess_threshold > 1.0 &&
            (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND);
 }
@@ -684,12 +681,14 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
 
     c->exchange = exchange;
     // exchange scope: room for immigrant lineages next to every row (grown on demand by cpprob_hip_exchange_commit)
-    const int64_t annex_want = cfg->reserved > 0 ? (int64_t)cfg->reserved * 1024 : std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile);
+    const int64_t annex_want = cfg->annex_kcols > 0 ? (int64_t)cfg->annex_kcols * 1024 : std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile);
     const int64_t annex0 = exchange ? std::max<int64_t>(c->annex_cap, annex_want) : 0;
     c->ssz = 8;
     dispatch_model(c, [&](auto m) { c->ssz = sizeof(typename decltype(m)::store_t); c->grid_refs = decltype(m)::kWeightTable == 0; });
+    // long traces in the exchange scope: skip rows shorten the extraction of migrating lineages (exchange.hpp)
+    const bool want_skip = exchange && c->keep && !(cfg->flags & CPPROB_HIP_FLAG_NO_SKIP_ROWS) && c->T >= 3 * kSkipEvery;
     const bool realloc = (size_t)c->ld > c->cap_particles || c->T > c->cap_T || c->is_int != c->cap_int || (multinomial && !c->cap_multinomial) || !c->d_values ||
-                         annex0 != c->annex_cap || c->keep != c->cap_keep;
+                         annex0 != c->annex_cap || c->keep != c->cap_keep || want_skip != (c->d_skip != nullptr);
     if (realloc) {
         free_run_buffers(c);
         c->annex_cap = annex0;
@@ -703,12 +702,13 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         const size_t rows = c->keep ? T : 2;
         HIP_TRY(c, hipMalloc(&c->d_values, rows * rs * vsz));
         HIP_TRY(c, hipMemsetAsync(c->d_values, 0, rows * rs * vsz, c->stream));
-        if (c->keep) HIP_TRY(c, hipMalloc(&c->d_anc, T * rs * sizeof(int32_t)));
+        // (ancestor and skip rows start as zeros -- a valid slot: a run that overflowed its transport still walks its lineages once,
+        //  through annex columns nobody committed, before the host sees the flag and repeats it)
+        if (c->keep) { HIP_TRY(c, hipMalloc(&c->d_anc, T * rs * sizeof(int32_t))); HIP_TRY(c, hipMemsetAsync(c->d_anc, 0, T * rs * sizeof(int32_t), c->stream)); }
         else HIP_TRY(c, hipMalloc(&c->d_fpart, T * (8 + 2) * (size_t)c->smooth_grid * sizeof(double)));
-        {
-            // long traces in the exchange scope: skip rows shorten the extraction of migrating lineages (exchange.hpp)
-            static const bool skip_on = !(getenv("CPPROB_SKIP_ROWS") && getenv("CPPROB_SKIP_ROWS")[0] == '0');
-            if (exchange && c->keep && skip_on && T >= 3 * kSkipEvery) HIP_TRY(c, hipMalloc(&c->d_skip, (T / kSkipEvery + 1) * rs * sizeof(int32_t)));
+        if (want_skip) {
+            HIP_TRY(c, hipMalloc(&c->d_skip, (T / kSkipEvery + 1) * rs * sizeof(int32_t)));
+            HIP_TRY(c, hipMemsetAsync(c->d_skip, 0, (T / kSkipEvery + 1) * rs * sizeof(int32_t), c->stream));
         }
         HIP_TRY(c, hipMalloc(&c->d_obound, (1024 + 2) * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_part[0], (size_t)part_stride(c->nb) * 3 * sizeof(double)));
@@ -937,7 +937,7 @@ int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_to
     if (!c || !d_all_totals) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->begun || !c->step_protocol || t != c->step_t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_step_end(t) follows cpprob_hip_smc_step_begin(t)");
     if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank (1 <= world <= 1024)");
-    if (c->exchange && world > kMaxWorld) return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope plans on one wavefront: world <= 64");
+    if (c->exchange && world > kMaxWorld) return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope plans on one wavefront (world + 1 bounds, one per lane): world <= 63");
     HIP_TRY(c, hipSetDevice(c->device));
     c->x_all_totals = d_all_totals; c->x_world = world; c->x_rank = rank;
     if (!c->counts_mode) {
@@ -978,12 +978,12 @@ namespace {
 
 int upload_geometry(cpprob_hip_ctx* c, int world, int rank, const uint64_t* h_shard_begin)
 {
-    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank (1 <= world <= 64)");
+    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad world/rank (1 <= world <= 63)");
     if (h_shard_begin[rank] != c->cfg.particle_offset || h_shard_begin[rank + 1] - h_shard_begin[rank] != (uint64_t)c->n || h_shard_begin[world] != c->cfg.n_global)
         return fail(c, CPPROB_HIP_EINVAL, "h_shard_begin does not describe this context's shard");
     std::vector<uint64_t> sb(h_shard_begin, h_shard_begin + world + 1);
     if (sb == c->x_shard_begin && c->d_shard_begin) return 0;
-    if (!c->d_shard_begin) HIP_TRY(c, hipMalloc(&c->d_shard_begin, (kMaxWorld + 1) * sizeof(int64_t)));
+    if (!c->d_shard_begin) HIP_TRY(c, hipMalloc(&c->d_shard_begin, (kWorldSlots + 1) * sizeof(int64_t)));
     std::vector<int64_t> h(sb.begin(), sb.end());
     HIP_TRY(c, hipMemcpyAsync(c->d_shard_begin, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));           // (h is a local)
@@ -1055,6 +1055,8 @@ int grow_annex(cpprob_hip_ctx* c, int64_t need)
     void* nv = nullptr; int32_t* na = nullptr;
     HIP_TRY(c, hipMalloc(&nv, T * (ldc + (size_t)cap) * vsz));
     HIP_TRY(c, hipMalloc(&na, T * (ldc + (size_t)cap) * sizeof(int32_t)));
+    HIP_TRY(c, hipMemsetAsync(nv, 0, T * (ldc + (size_t)cap) * vsz, c->stream));
+    HIP_TRY(c, hipMemsetAsync(na, 0, T * (ldc + (size_t)cap) * sizeof(int32_t), c->stream));
     const size_t used = (size_t)(c->ld + c->annex_used);
     HIP_TRY(c, hipMemcpy2DAsync(nv, rs_new * vsz, c->d_values, rs_old * vsz, used * vsz, (size_t)c->T, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpy2DAsync(na, rs_new * 4, c->d_anc, rs_old * 4, used * 4, (size_t)c->T, hipMemcpyDeviceToDevice, c->stream));
@@ -1063,6 +1065,7 @@ int grow_annex(cpprob_hip_ctx* c, int64_t need)
         int32_t* ns = nullptr;
         const size_t M = T / kSkipEvery + 1;
         HIP_TRY(c, hipMalloc(&ns, M * (ldc + (size_t)cap) * sizeof(int32_t)));
+        HIP_TRY(c, hipMemsetAsync(ns, 0, M * (ldc + (size_t)cap) * sizeof(int32_t), c->stream));
         HIP_TRY(c, hipMemcpy2DAsync(ns, rs_new * 4, c->d_skip, rs_old * 4, used * 4, (size_t)c->T / kSkipEvery + 1, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         dfree(c->d_skip); c->d_skip = ns;
@@ -1139,14 +1142,14 @@ int cpprob_hip_exchange_setup(cpprob_hip_ctx* c, int32_t world, int32_t rank, co
     if (records_per_peer == 0) return fail(c, CPPROB_HIP_EINVAL, "records_per_peer must be > 0");
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc = upload_geometry(c, world, rank, h_shard_begin)) return rc;
-    std::vector<int32_t> slot((size_t)kMaxWorld, -1);
+    std::vector<int32_t> slot((size_t)kWorldSlots, -1);
     c->x_peers.clear();
     for (int r = 0; r < world; ++r) {
         if (r == rank) continue;
         if (all_peers || r == rank - 1 || r == rank + 1) { slot[(size_t)r] = (int32_t)c->x_peers.size(); c->x_peers.push_back(r); }
     }
-    if (!c->d_slot_of_rank) HIP_TRY(c, hipMalloc(&c->d_slot_of_rank, kMaxWorld * sizeof(int32_t)));
-    HIP_TRY(c, hipMemcpy(c->d_slot_of_rank, slot.data(), kMaxWorld * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!c->d_slot_of_rank) HIP_TRY(c, hipMalloc(&c->d_slot_of_rank, kWorldSlots * sizeof(int32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_slot_of_rank, slot.data(), kWorldSlots * sizeof(int32_t), hipMemcpyHostToDevice));
     c->x_cap = (int64_t)records_per_peer; c->x_mode = all_peers ? 1 : 0; c->x_fixed = true;
     const size_t need = std::max<size_t>(1, c->x_peers.size()) * (size_t)records_per_peer * (size_t)c->T * c->ssz;
     if (need > c->x_buf_bytes) {
@@ -1458,6 +1461,17 @@ int cpprob_hip_logpdf_discrete(cpprob_hip_ctx* c, const int32_t* x, const double
     if (int rc = make_dw(c, h_w, k, dw)) return rc;
     if (n == 0) return 0;
     hipLaunchKernelGGL(logpdf_discrete_kernel, GRID1(n), x, dw, (int64_t)n, out);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_fastmath(cpprob_hip_ctx* c, int32_t which, const double* d_x, size_t n, double* d_out0, double* d_out1)
+{
+    BB_PRELUDE(c);
+    if (which < 0 || which > 2) return fail(c, CPPROB_HIP_EINVAL, "which: 0 log01, 1 sincospi02, 2 exp_nonpos");
+    if (!d_x || !d_out0 || (which == 1 && !d_out1)) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fastmath_kernel, GRID1(n), (int)which, d_x, (int64_t)n, d_out0, d_out1);
     HIP_TRY(c, hipGetLastError());
     return 0;
 }

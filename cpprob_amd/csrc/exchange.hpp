@@ -17,19 +17,21 @@
 
 namespace cph {
 
-constexpr int kMaxWorld = 64;
+// The plan lives on ONE wavefront whose lane r holds o_r for r = 0 .. world (world + 1 bounds): world <= 63.
+constexpr int kMaxWorld = 63;
+constexpr int kWorldSlots = 64;                 // per-rank arrays (a power of two)
 
 struct ExchangePlan {
     int32_t resample;                 // the step's decision (device-side)
     int32_t overflow;                 // sticky per run, bit set: 1 = a peer segment was too small, 2 = a rank outside the peer list was needed, 4 = the annex was too small
     int64_t l0, l1;                   // local outputs [l0, l1) descend from local sources
     int64_t n_send, n_recv;
-    int64_t send_lo[kMaxWorld];       // per RANK: first global output of mine that lives there, how many, where its records start (in records)
-    int64_t send_cnt[kMaxWorld];
-    int64_t send_base[kMaxWorld];
-    int64_t recv_cnt[kMaxWorld];      // per RANK: records that arrive from it, where they sit in the receive buffer, their first annex column offset
-    int64_t recv_base[kMaxWorld];
-    int64_t recv_off[kMaxWorld];
+    int64_t send_lo[kWorldSlots];       // per RANK: first global output of mine that lives there, how many, where its records start (in records)
+    int64_t send_cnt[kWorldSlots];
+    int64_t send_base[kWorldSlots];
+    int64_t recv_cnt[kWorldSlots];      // per RANK: records that arrive from it, where they sit in the receive buffer, their first annex column offset
+    int64_t recv_base[kWorldSlots];
+    int64_t recv_off[kWorldSlots];
 };
 
 struct ExchangeGeom {
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, Pl
 {
     const int lane = lane_id();
     const int world = g.world, rank = g.rank;
-    __shared__ double s_ob[kMaxWorld + 2];
+    __shared__ double s_ob[kWorldSlots + 2];
     if (SCAN2) {
         if (lane == 0) {
             scan_combine_ranks(sa);

@@ -114,6 +114,7 @@ struct cpprob_hip_group {
     bool begun = false, exchange = false;
     int T = 0, K = 0, n_stats = 0;
     int all_peers = 0; uint64_t cap = 0; int annex_kcols = 0;
+    uint64_t user_cap = 0; int user_all_peers = -1;     // cpprob_hip_group_transport: the caller's choice (0 / -1: the defaults below)
     // per local rank device buffers
     std::vector<double*> d_local, d_all, d_joint;
     double* const* d_ptr_locals = nullptr; double* const* d_ptr_alls = nullptr; double* const* d_ptr_joints = nullptr;   // loopback: device arrays of pointers
@@ -144,6 +145,12 @@ int gkeep(cpprob_hip_group* g, int rc)                  // calling thread: make 
     return rc;
 }
 
+#define GHIP_TRY(g, expr)                                                                                              \
+    do {                                                                                                               \
+        hipError_t e__ = (expr);                                                                                       \
+        if (e__ != hipSuccess) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e__))); \
+    } while (0)
+
 #define NCCL_TRY(g, expr)                                                                                                        \
     do {                                                                                                                         \
         ncclResult_t r__ = (expr);                                                                                               \
@@ -154,7 +161,7 @@ int gkeep(cpprob_hip_group* g, int rc)                  // calling thread: make 
 int rccl_exchange(cpprob_hip_group* g, int i, int t)
 {
     cpprob_hip_ctx* c = g->ctx[(size_t)i];
-    void* d_send = nullptr; void* d_recv = nullptr; int32_t np = 0; int32_t peers[cph::kMaxWorld]; uint64_t cap = 0, bpv = 0;
+    void* d_send = nullptr; void* d_recv = nullptr; int32_t np = 0; int32_t peers[cph::kWorldSlots]; uint64_t cap = 0, bpv = 0;
     if (int rc = cpprob_hip_exchange_transport(c, &d_send, &d_recv, &np, peers, &cap, &bpv)) return gfail(g, rc, cpprob_hip_last_error(c));
     const size_t seg = (size_t)cap * (size_t)(t + 1) * (size_t)bpv;
     if (np == 0) return 0;
@@ -268,7 +275,7 @@ int group_begin_contexts(cpprob_hip_group* g)
         c.particle_offset = g->shard_begin[(size_t)rank];
         c.n_global = g->shard_begin[(size_t)g->world];
         c.resample_scope = g->exchange ? CPPROB_HIP_SCOPE_EXCHANGE : CPPROB_HIP_SCOPE_GLOBAL;
-        c.reserved = g->annex_kcols;
+        c.annex_kcols = g->annex_kcols;
         cpprob_hip_ctx* x = g->ctx[(size_t)i];
         if (int rc = cpprob_hip_infer_begin(x, &c, g->obs.data(), g->obs.size())) return gfail(g, rc, cpprob_hip_last_error(x));
         if (g->exchange)
@@ -316,7 +323,7 @@ int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t wor
     if (!out || !devices) return fail(nullptr, CPPROB_HIP_EINVAL, "NULL argument");
     *out = nullptr;
     if (n_local < 1 || world < n_local || world > cph::kMaxWorld || first_rank < 0 || first_rank + n_local > world)
-        return fail(nullptr, CPPROB_HIP_EINVAL, "need 1 <= n_local <= world <= 64 and first_rank + n_local <= world");
+        return fail(nullptr, CPPROB_HIP_EINVAL, "need 1 <= n_local <= world <= 63 and first_rank + n_local <= world");
     if (world > n_local && (n_local != 1 || !unique_id)) return fail(nullptr, CPPROB_HIP_EINVAL, "ranks in other processes: one GPU per process and the group's unique id");
     cpprob_hip_group* g = new cpprob_hip_group();
     g->world = world; g->first_rank = first_rank;
@@ -388,6 +395,7 @@ int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, co
 {
     if (!g || !cfg || !h_observes) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "NULL argument"));
     if (cfg->n_particles < (uint64_t)g->world) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "fewer particles than ranks"));
+    g->begun = false;                                   // (a failed begin leaves no half-updated configuration behind an earlier one)
     g->cfg = *cfg;
     g->obs.assign(h_observes, h_observes + n_observes);
     g->shard_begin.assign((size_t)g->world + 1, 0);
@@ -396,44 +404,44 @@ int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, co
         // contiguous shards: particle i lives on rank floor(i * world / N) unless the caller names the sizes
         const uint64_t base = cfg->n_particles / (uint64_t)g->world, rem = cfg->n_particles % (uint64_t)g->world;
         const uint64_t sz = h_shard_sizes ? h_shard_sizes[r] : base + ((uint64_t)r < rem ? 1 : 0);
-        if (sz == 0) return gfail(g, CPPROB_HIP_EINVAL, "empty shard");
+        if (sz == 0) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "empty shard"));
         g->shard_begin[(size_t)r + 1] = g->shard_begin[(size_t)r] + sz;
         largest = std::max(largest, sz);
     }
-    if (g->shard_begin[(size_t)g->world] != cfg->n_particles) return gfail(g, CPPROB_HIP_EINVAL, "shard sizes do not add up to n_particles");
+    if (g->shard_begin[(size_t)g->world] != cfg->n_particles) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "shard sizes do not add up to n_particles"));
     g->exchange = cfg->algorithm == CPPROB_HIP_ALG_SMC && cfg->resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC;
     // transport defaults: the two neighbours, room for the O(sqrt(N)) outputs a rank's offspring interval leaves its shard by
     g->all_peers = 0;
     const uint64_t guess = (uint64_t)(8.0 * std::sqrt((double)cfg->n_particles)) / kTile * kTile + 4 * kTile;
     g->cap = std::min<uint64_t>(largest, guess);
     g->annex_kcols = 0;
-    if (const char* e = getenv("CPPROB_GROUP_CAP")) g->cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
-    if (const char* e = getenv("CPPROB_GROUP_ALL_PEERS")) g->all_peers = e[0] == '1';
+    if (g->user_cap) g->cap = g->user_cap;                // cpprob_hip_group_transport
+    if (g->user_all_peers >= 0) g->all_peers = g->user_all_peers;
     if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
     g->T = g->ctx[0]->T; g->K = g->ctx[0]->K; g->n_stats = g->T * g->K;
     const int n_local = (int)g->ctx.size();
     if (g->d_local.empty()) { g->d_local.assign((size_t)n_local, nullptr); g->d_all.assign((size_t)n_local, nullptr); g->d_joint.assign((size_t)n_local, nullptr); }
     for (int i = 0; i < n_local; ++i) {
         cpprob_hip_ctx* c = g->ctx[(size_t)i];
-        HIP_TRY(c, hipSetDevice(c->device));
+        GHIP_TRY(g, hipSetDevice(c->device));
         if (g->d_local[(size_t)i]) { (void)hipFree(g->d_local[(size_t)i]); (void)hipFree(g->d_all[(size_t)i]); (void)hipFree(g->d_joint[(size_t)i]); }
-        HIP_TRY(c, hipMalloc(&g->d_local[(size_t)i], 4 * sizeof(double)));
-        HIP_TRY(c, hipMalloc(&g->d_all[(size_t)i], 3 * (size_t)g->world * sizeof(double)));
-        HIP_TRY(c, hipMalloc(&g->d_joint[(size_t)i], ((size_t)g->n_stats + 1) * sizeof(double)));
-        HIP_TRY(c, hipMemset(g->d_local[(size_t)i], 0, 4 * sizeof(double)));
-        HIP_TRY(c, hipMemset(g->d_all[(size_t)i], 0, 3 * (size_t)g->world * sizeof(double)));
-        HIP_TRY(c, hipMemset(g->d_joint[(size_t)i], 0, ((size_t)g->n_stats + 1) * sizeof(double)));
+        GHIP_TRY(g, hipMalloc(&g->d_local[(size_t)i], 4 * sizeof(double)));
+        GHIP_TRY(g, hipMalloc(&g->d_all[(size_t)i], 3 * (size_t)g->world * sizeof(double)));
+        GHIP_TRY(g, hipMalloc(&g->d_joint[(size_t)i], ((size_t)g->n_stats + 1) * sizeof(double)));
+        GHIP_TRY(g, hipMemset(g->d_local[(size_t)i], 0, 4 * sizeof(double)));
+        GHIP_TRY(g, hipMemset(g->d_all[(size_t)i], 0, 3 * (size_t)g->world * sizeof(double)));
+        GHIP_TRY(g, hipMemset(g->d_joint[(size_t)i], 0, ((size_t)g->n_stats + 1) * sizeof(double)));
     }
     if (g->loopback) {
-        cpprob_hip_ctx* c = g->ctx[0];
+        GHIP_TRY(g, hipSetDevice(g->ctx[0]->device));
         if (g->d_ptr_locals) { (void)hipFree((void*)g->d_ptr_locals); (void)hipFree((void*)g->d_ptr_alls); (void)hipFree((void*)g->d_ptr_joints); }
         void *pl = nullptr, *pa = nullptr, *pj = nullptr;
-        HIP_TRY(c, hipMalloc(&pl, (size_t)n_local * sizeof(double*)));
-        HIP_TRY(c, hipMalloc(&pa, (size_t)n_local * sizeof(double*)));
-        HIP_TRY(c, hipMalloc(&pj, (size_t)n_local * sizeof(double*)));
-        HIP_TRY(c, hipMemcpy(pl, g->d_local.data(), (size_t)n_local * sizeof(double*), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(pa, g->d_all.data(), (size_t)n_local * sizeof(double*), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(pj, g->d_joint.data(), (size_t)n_local * sizeof(double*), hipMemcpyHostToDevice));
+        GHIP_TRY(g, hipMalloc(&pl, (size_t)n_local * sizeof(double*)));
+        GHIP_TRY(g, hipMalloc(&pa, (size_t)n_local * sizeof(double*)));
+        GHIP_TRY(g, hipMalloc(&pj, (size_t)n_local * sizeof(double*)));
+        GHIP_TRY(g, hipMemcpy(pl, g->d_local.data(), (size_t)n_local * sizeof(double*), hipMemcpyHostToDevice));
+        GHIP_TRY(g, hipMemcpy(pa, g->d_all.data(), (size_t)n_local * sizeof(double*), hipMemcpyHostToDevice));
+        GHIP_TRY(g, hipMemcpy(pj, g->d_joint.data(), (size_t)n_local * sizeof(double*), hipMemcpyHostToDevice));
         g->d_ptr_locals = static_cast<double* const*>(pl); g->d_ptr_alls = static_cast<double* const*>(pa); g->d_ptr_joints = static_cast<double* const*>(pj);
     } else if (n_local > 1 && g->workers.empty()) {
         g->job_rc.assign((size_t)n_local, 0); g->job_err.assign((size_t)n_local, "");
@@ -443,10 +451,17 @@ int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, co
     return 0;
 }
 
+int cpprob_hip_group_transport(cpprob_hip_group* g, uint64_t records_per_peer, int32_t all_peers)
+{
+    if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
+    g->user_cap = records_per_peer; g->user_all_peers = all_peers < 0 ? -1 : (all_peers ? 1 : 0);
+    return 0;
+}
+
 int cpprob_hip_group_run(cpprob_hip_group* g, uint64_t run_index)
 {
     if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
-    if (!g->begun) return gfail(g, CPPROB_HIP_ESTATE, "cpprob_hip_group_begin has not been called");
+    if (!g->begun) return gkeep(g, gfail(g, CPPROB_HIP_ESTATE, "cpprob_hip_group_begin has not been called"));
     if (int rc = group_enqueue(g, run_index)) return gkeep(g, rc);
     g->last_run = run_index; g->ran = true;
     return 0;
@@ -477,19 +492,19 @@ cpprob_hip_ctx* cpprob_hip_group_context(cpprob_hip_group* g, int32_t local_inde
 int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, double* h_stats, size_t n_doubles, int32_t* h_reruns)
 {
     if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
-    if (!g->ran) return gfail(g, CPPROB_HIP_ESTATE, "no finished run");
-    if (h_stats && n_doubles < (size_t)g->n_stats) return gfail(g, CPPROB_HIP_EINVAL, "h_stats too small");
+    if (!g->ran) return gkeep(g, gfail(g, CPPROB_HIP_ESTATE, "no finished run"));
+    if (h_stats && n_doubles < (size_t)g->n_stats) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "h_stats too small"));
     std::vector<double> joint((size_t)g->n_stats + 1);
     for (int attempt = 0;; ++attempt) {
-        if (int rc = cpprob_hip_group_sync(g)) return rc;
+        if (int rc = cpprob_hip_group_sync(g)) return gkeep(g, rc);
         cpprob_hip_ctx* c = g->ctx[0];
-        HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, hipMemcpy(joint.data(), g->d_joint[0], joint.size() * sizeof(double), hipMemcpyDeviceToHost));
+        GHIP_TRY(g, hipSetDevice(c->device));
+        GHIP_TRY(g, hipMemcpy(joint.data(), g->d_joint[0], joint.size() * sizeof(double), hipMemcpyDeviceToHost));
         if (joint[(size_t)g->n_stats] == 0.0) break;
         // some rank's transport was too small (every rank sees the same all-reduced flags and takes the same decision): repeat
         // the run with what overflowed enlarged -- the annex (x4), the peer segments (x4, up to a whole shard), the peer list
         // (every rank).  Results do not depend on the transport parameters, only their validity does.
-        if (attempt >= 6) return gfail(g, CPPROB_HIP_EDEVICE, "exchange transport still too small after six enlargements");
+        if (attempt >= 6) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "exchange transport still too small after six enlargements"));
         const long long v = (long long)joint[(size_t)g->n_stats];
         const bool seg = v % 128 != 0, peers = (v / 128) % 128 != 0, annex = v / 16384 != 0;
         uint64_t largest = 0;
@@ -507,7 +522,7 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
     }
     if (h_reruns) *h_reruns = g->reruns;
     cpprob_hip_summary s{};
-    if (int rc = cpprob_hip_infer_summary(g->ctx[0], &s)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[0]));
+    if (int rc = cpprob_hip_infer_summary(g->ctx[0], &s)) return gkeep(g, gfail(g, rc, cpprob_hip_last_error(g->ctx[0])));
     if (out) *out = s;
     if (h_stats) {
         // StatsPrinter's numbers from the all-reduced un-normalised sums (relative to exp(max_logw))

@@ -1850,6 +1850,16 @@ __global__ void logpdf_discrete_kernel(const int32_t* __restrict__ x, DiscreteW 
     if (i < n) out[i] = discrete_logpdf(x[i], dw.w, dw.k);
 }
 
+// the lean elementary functions of cpprob/detail/fastmath.hpp, elementwise (which: 0 log01, 1 sincospi02 -> out0 = sin, out1 = cos, 2 exp_nonpos)
+__global__ void fastmath_kernel(int which, const double* __restrict__ x, int64_t n, double* __restrict__ out0, double* __restrict__ out1)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (which == 0) out0[i] = log01(x[i]);
+    else if (which == 1) { double sn, cs; sincospi02(x[i], sn, cs); out0[i] = sn; out1[i] = cs; }
+    else out0[i] = exp_nonpos(x[i]);
+}
+
 template <class T>
 __global__ void gather_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, int64_t n, T* __restrict__ dst)
 {

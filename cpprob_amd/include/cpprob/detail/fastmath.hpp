@@ -7,7 +7,7 @@
 //   log01(u)       u in [2^-53, 1]            (Box-Muller radius; fdlibm's e_log.c reduction and minimax polynomial)
 //   sincospi02(w)  w in (0, 2]                (Box-Muller angle;  quadrant reduction + minimax polynomials on [-1/4, 1/4])
 //   exp_nonpos(x)  x in [-745, ~0]            (linear weights exp(logw - reference); Cody-Waite reduction + minimax polynomial)
-// Error of each (against 300-bit references, emulating the fp64 operations exactly; scratch/fit_math.py regenerates the
+// Error of each (against 300-bit references, emulating the fp64 operations exactly; tools/fit_math.py regenerates the
 // coefficients and the error figures): log01 < 0.67 ulp, sincospi02 < 0.73 ulp, exp_nonpos < 0.66 ulp -- faithful rounding, as the
 // library's own; the parity tests compare draws with glibc-based values at 1e-12 relative (2 ulp = 4.4e-16).
 #pragma once

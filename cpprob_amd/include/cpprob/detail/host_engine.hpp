@@ -304,16 +304,17 @@ int probe_markov_window(const Func& f, const ObsTuple& obs, const detail::TraceS
     auto run = [&](const detail::ProbeState& cfg) -> bool {
         detail::ProbeState& p = detail::probe();
         p = cfg; p.active = true; p.failed = false; p.ordinal = 0; p.n_obs = 0; p.log.clear();
+        // (whatever the model throws on substituted values -- its own checks, a distribution's parameter check -- means "this model
+        //  does look at old samples": not Markov, full replay; never an error of a valid inference)
         try { call_f_tuple(f, obs); }
-        catch (const detail::ProbeAbort&) { p.active = false; return false; }
-        catch (...) { p.active = false; throw; }
+        catch (...) { detail::probe().active = false; return false; }
         p.active = false;
         return !p.failed;
     };
     const int windows[] = {1, 2, 4, 8};
     for (int w : windows) {
         bool ok = true;
-        for (std::uint32_t rep = 0; rep < 3 && ok; ++rep) {
+        for (std::uint32_t rep = 0; rep < 8 && ok; ++rep) {
             detail::ProbeState a;
             a.base_seed = 1000003u * (rep + 1); a.n_steps = T; a.record_all = true; a.ordinal_cap = 64 * st.n_sample + 1024;
             if (!run(a)) return -1;

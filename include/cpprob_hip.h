@@ -36,7 +36,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define CPPROB_HIP_ABI_VERSION 1
+#define CPPROB_HIP_ABI_VERSION 2
 
 /* error codes */
 #define CPPROB_HIP_OK 0
@@ -91,8 +91,12 @@ typedef struct cpprob_hip_config {
                                  two rows of values, no ancestors (memory O(N) instead of O(N T)); predict hit t's
                                  statistics are those of generation t under its own weights; cpprob_hip_copy_values /
                                  _ancestors / _paths return CPPROB_HIP_ESTATE                                    */
-    int32_t reserved;         /* exchange scope: immigrant-annex capacity in units of 1024 columns per row (0 = default: 1/16 of
+    int32_t annex_kcols;      /* exchange scope: immigrant-annex capacity in units of 1024 columns per row (0 = default: 1/16 of
                                  the shard, at least 4096); stream-ordered runs cannot grow it mid-run and report overflow instead */
+    uint32_t flags;           /* CPPROB_HIP_FLAG_* below; 0 = the measured optimum.  Every switch that selects another kernel form
+                                 lives HERE, in the caller's hands -- the library reads no environment variable */
+    int32_t fuse_max_tiles;   /* floating-point step: largest population (in 1024-particle tiles) whose step kernel normalises the
+                                 previous generation in its own prologue; 0 = default (1664), capped there */
     double ess_threshold;     /* SMC: resample after a step iff ESS < ess_threshold * N_global;
                                  > 1 resamples after every step (thesis p.37 uses 0.5)        */
     uint64_t seed;            /* Philox key                                                    */
@@ -100,6 +104,15 @@ typedef struct cpprob_hip_config {
     uint64_t particle_offset; /* global id of local particle 0 (RNG counters use global ids)   */
     uint64_t n_global;        /* total particles over all shards (= n_particles for 1 GPU)     */
 } cpprob_hip_config;
+
+/* cpprob_hip_config::flags -- A/B and diagnostic forms (results agree within the stated tolerances) */
+#define CPPROB_HIP_FLAG_FLOATING_POINT_STEP 1u   /* table-weight models on an every-step schedule: the floating-point step instead of the
+                                                    integer prefix-count step (ancestors then agree up to CDF-boundary flips, not bit for bit) */
+#define CPPROB_HIP_FLAG_NO_SKIP_ROWS 2u          /* exchange scope, long traces: extract migrating lineages hop by hop */
+#define CPPROB_HIP_FLAG_SIS_PER_TILE 4u          /* SIS of bounded-weight models through the per-tile kernel */
+#define CPPROB_HIP_FLAG_SIS_SEPARATE_READOUT 8u  /* SIS read-out as a pass over the particle store instead of riding the normalisation */
+#define CPPROB_HIP_FLAG_WREL_STORED 16u          /* floating-point step of table-weight models: read stored linear weights, not states */
+#define CPPROB_HIP_FLAG_FP_TILE_PARTIALS 32u     /* ... and fp64 tile partials instead of packed per-value counts */
 
 /* Posterior summary of a finished run -- what StatsPrinter prints
  * (include/cpprob/postprocess/stats_printer.hpp:42-79) plus SMC diagnostics. */
@@ -222,7 +235,7 @@ int cpprob_hip_exchange_commit(cpprob_hip_ctx* ctx, int32_t t, const void* d_rec
  *   status     after the run (synchronises): overflow = 0 fine; otherwise a set of bits: 1 a peer segment was too small, 2 a rank
  *              outside the peer set was needed, 4 the immigrant annex was too small.  A non-zero value invalidates the run on
  *              EVERY rank of the group (ranks must agree on it -- all-reduce the bits): repeat it with what overflowed enlarged
- *              (records_per_peer / all_peers = 1 / cpprob_hip_config::reserved).  Results do not depend on the transport parameters. */
+ *              (records_per_peer / all_peers = 1 / cpprob_hip_config::annex_kcols).  Results do not depend on the transport parameters. */
 int cpprob_hip_exchange_setup(cpprob_hip_ctx* ctx, int32_t world, int32_t rank, const uint64_t* h_shard_begin, int32_t all_peers, uint64_t records_per_peer);
 int cpprob_hip_exchange_transport(cpprob_hip_ctx* ctx, void** d_send, void** d_recv, int32_t* n_peers, int32_t* h_peers, uint64_t* records_per_peer,
                                   uint64_t* bytes_per_value);
@@ -253,6 +266,10 @@ int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t wor
 void cpprob_hip_group_destroy(cpprob_hip_group* group);
 const char* cpprob_hip_group_last_error(const cpprob_hip_group* group);
 int cpprob_hip_group_begin(cpprob_hip_group* group, const cpprob_hip_config* cfg, const double* h_observes, size_t n_observes, const uint64_t* h_shard_sizes);
+/* Transport parameters of the NEXT cpprob_hip_group_begin: records_per_peer = capacity of one peer segment (0: the default,
+ * 8 sqrt(N) + 4096), all_peers = 1: every rank is a peer, 0: the two neighbouring ranks, < 0: the default (neighbours).  Results
+ * never depend on them; a run they prove too small for is repeated with larger ones (cpprob_hip_group_results). */
+int cpprob_hip_group_transport(cpprob_hip_group* group, uint64_t records_per_peer, int32_t all_peers);
 int cpprob_hip_group_run(cpprob_hip_group* group, uint64_t run_index);
 int cpprob_hip_group_sync(cpprob_hip_group* group);
 int cpprob_hip_group_size(const cpprob_hip_group* group, int32_t* world, int32_t* n_local, int32_t* first_rank);
@@ -283,6 +300,12 @@ int cpprob_hip_logpdf_uniform_real(cpprob_hip_ctx* ctx, const double* d_x, const
 int cpprob_hip_logpdf_poisson(cpprob_hip_ctx* ctx, const int32_t* d_x, const double* d_mean, size_t n, double* d_out);
 int cpprob_hip_logpdf_uniform_smallint(cpprob_hip_ctx* ctx, const int32_t* d_x, int64_t a, int64_t b, size_t n, double* d_out);
 int cpprob_hip_logpdf_discrete(cpprob_hip_ctx* ctx, const int32_t* d_x, const double* h_weights, int32_t k, size_t n, double* d_out);
+
+/* The range-specific fp64 elementary functions the variate generators and the weight kernels use in place of the device library's
+ * (cpprob_amd/include/cpprob/detail/fastmath.hpp; they stand where the reference calls std::log / std::exp through Boost.Random and
+ * include/cpprob/distributions/utils_normal_distribution.hpp:38-41), elementwise: which = 0 log01 on [2^-53, 1], 1 sincospi02 on
+ * (0, 2] (d_out0 = sin(pi x), d_out1 = cos(pi x)), 2 exp_nonpos on [-745, 0].  Unit-parity surface: tests sweep the domain edges. */
+int cpprob_hip_fastmath(cpprob_hip_ctx* ctx, int32_t which, const double* d_x, size_t n, double* d_out0, double* d_out1);
 
 /* EmpiricalDistribution (include/cpprob/postprocess/empirical_distribution.hpp):
  * h_out[0] = max, [1] = logsumexp (:125-143), [2] = ESS = (sum W^2)^-1. */

@@ -320,3 +320,86 @@ def test_gather(engine):
     engine.gather(_t(srci), _t(idx), dsti)
     engine.sync()
     assert np.array_equal(dsti.cpu().numpy(), srci[idx])
+
+
+def _ulp_err(got, ref_ld):
+    """|got - ref| in units of the fp64 ulp of ref (ref in 80-bit long double: 11 more bits than the result it judges)."""
+    ref_ld = np.asarray(ref_ld, np.longdouble)
+    got_ld = np.asarray(got, np.float64).astype(np.longdouble)
+    ulp = np.spacing(np.abs(ref_ld.astype(np.float64))).astype(np.longdouble)
+    return np.abs(got_ld - ref_ld) / ulp
+
+
+def test_fastmath_log01_edges_and_random_points(engine):
+    """cpprob/detail/fastmath.hpp::log01 on its whole domain [2^-53, 1]: the edges, the binade boundaries, the neighbourhood of
+    sqrt(1/2) (the reduction's branch) and 10^6 random points, against 80-bit logl: <= 1 ulp (tools/fit_math.py: 0.67)."""
+    import torch
+    assert np.finfo(np.longdouble).nmant >= 63, "needs x87 extended precision for the reference"
+    rng = np.random.default_rng(11)
+    edges = [2.0 ** -53, np.nextafter(2.0 ** -53, 1), 1.0, np.nextafter(1.0, 0), 0.5, np.nextafter(0.5, 0), np.nextafter(0.5, 1),
+             np.sqrt(0.5), np.nextafter(np.sqrt(0.5), 0), np.nextafter(np.sqrt(0.5), 1)] + [2.0 ** -k for k in range(1, 54)]
+    u = np.concatenate([np.array(edges), (rng.integers(1, 2 ** 53, 600000) * 2.0 ** -53), 2.0 ** -rng.uniform(0, 53, 400000)])
+    u = np.clip(u, 2.0 ** -53, 1.0)
+    x = _t(u)
+    out = dzeros_like(x)
+    engine.fastmath(0, x, out)
+    engine.sync()
+    got = out.cpu().numpy()
+    assert got[2] == 0.0                                        # log(1) is exactly 0
+    ref = np.log(u.astype(np.longdouble))
+    err = _ulp_err(got[ref != 0], ref[ref != 0])
+    assert err.max() <= 1.0, err.max()
+
+
+def test_fastmath_sincospi02_edges_and_random_points(engine):
+    """sincospi02 on (0, 2]: the quadrant boundaries k/4 and their neighbours, 0+ and 2, 10^6 random points, against 80-bit
+    sinl / cosl of the exactly reduced argument: <= 1 ulp (0.73), exact zeros / ones where the reference has them."""
+    import torch
+    rng = np.random.default_rng(12)
+    q = np.arange(1, 9) / 4.0
+    edges = np.concatenate([[2.0 ** -53, 2.0 ** -60, 2.0], q, np.nextafter(q, 0), np.nextafter(q[:-1], 3)])
+    w = np.concatenate([edges, rng.uniform(0, 2, 700000), (rng.integers(1, 2 ** 32, 300000) * 2.0 ** -31)])
+    w = np.clip(w, 2.0 ** -60, 2.0)
+    x = _t(w)
+    sn, cs = dzeros_like(x), dzeros_like(x)
+    engine.fastmath(1, x, sn, cs)
+    engine.sync()
+    sn, cs = sn.cpu().numpy(), cs.cpu().numpy()
+    r = np.rint(w + w)
+    t = (w - 0.5 * r).astype(np.longdouble)                     # exact in fp64
+    pi = np.longdouble("3.14159265358979323846264338327950288")
+    s0, c0 = np.sin(pi * t), np.cos(pi * t)
+    i = r.astype(np.int64) & 3
+    ref_s = np.where(i == 0, s0, np.where(i == 1, c0, np.where(i == 2, -s0, -c0)))
+    ref_c = np.where(i == 0, c0, np.where(i == 1, -s0, np.where(i == 2, -c0, s0)))
+    for got, ref in ((sn, ref_s), (cs, ref_c)):
+        nz = t != 0                                              # (where the reduced argument is exactly 0 the values are exactly 0 / +-1)
+        big = np.abs(ref) > 1e-300
+        assert _ulp_err(got[nz & big], ref[nz & big]).max() <= 1.0
+    z = t == 0
+    assert np.all(np.abs(sn[z]) + np.abs(cs[z]) == 1.0) and np.all((sn[z] == 0) | (cs[z] == 0))
+    assert sn[2] == 0.0 and cs[2] == 1.0                        # w = 2
+
+
+def test_fastmath_exp_nonpos_edges_and_random_points(engine):
+    """exp_nonpos on [-745, 0]: 0, -0, the underflow edge, multiples of ln 2 / 2 (the reduction's boundaries) and 10^6 random
+    points, against 80-bit expl: <= 1 ulp in the normal range (0.66); denormal results within one denormal spacing."""
+    import torch
+    rng = np.random.default_rng(13)
+    ln2 = np.log(2.0)
+    ks = np.arange(0, 2140)
+    edges = np.concatenate([[0.0, -0.0, -745.0, -744.44, -708.39, -708.4, -1e-300, -2.0 ** -60], -ks * ln2 / 2, np.nextafter(-ks * ln2 / 2, 0), np.nextafter(-ks * ln2 / 2, -1e9)])
+    xv = np.concatenate([edges, -rng.uniform(0, 745, 500000), -rng.uniform(0, 40, 400000), -(2.0 ** -rng.uniform(0, 60, 100000))])
+    xv = np.clip(xv, -745.0, 0.0)
+    x = _t(xv)
+    out = dzeros_like(x)
+    engine.fastmath(2, x, out)
+    engine.sync()
+    got = out.cpu().numpy()
+    assert got[0] == 1.0 and got[1] == 1.0
+    ref = np.exp(xv.astype(np.longdouble))
+    normal = ref >= np.longdouble(2.0) ** -1022
+    assert _ulp_err(got[normal], ref[normal]).max() <= 1.0
+    den = ~normal
+    assert np.all(np.abs(got[den].astype(np.longdouble) - ref[den]) <= np.longdouble(2.0) ** -1074)
+    assert np.all(got >= 0) and np.all(got <= 1.0)

@@ -44,8 +44,7 @@ def test_group_hmm_every_step_is_bit_identical_to_one_gpu(engine, golden_dir, sh
 def test_group_long_traces_extract_lineages_through_skip_rows(engine, golden_dir):
     """T >= 24 in the exchange scope: a migrating particle's lineage is extracted in blocks of eight generations through the skip
     rows (csrc/exchange.hpp).  Count form, uneven shards, outlying observations that move mass between shards: every trace equals
-    the one-GPU run's, bit for bit -- and the same with the skip rows switched off (a fresh process)."""
-    import subprocess, sys
+    the one-GPU run's, bit for bit -- and the same with the skip rows switched off (CPPROB_HIP_FLAG_NO_SKIP_ROWS)."""
     obs = np.array(_obs(golden_dir, "hmm128")[:44])
     obs[[5, 23]] *= 4.0
     shards = [30000, 50001, 19999, 7]
@@ -59,16 +58,13 @@ def test_group_long_traces_extract_lineages_through_skip_rows(engine, golden_dir
     g.close()
     assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"]
     np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
-    code = (
-        "import sys, numpy as np\nsys.path.insert(0, %r)\nimport torch, cpprob_amd as cp\n"
-        "obs = np.load(%r)['hmm128'][:44].copy(); obs[[5, 23]] *= 4.0\n"
-        "g = cp.Group([0] * 4)\ng.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, %d, seed=13, ess_threshold=2.0, shard_sizes=%r)\ng.run()\n"
-        "st, s, rr = g.results()\nprint(repr(float(s['log_evidence'])), repr(float(st.sum())), repr(float((st * np.arange(st.size).reshape(st.shape)).sum())))\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(golden_dir, "observations.npz"), n, shards)
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CPPROB_SKIP_ROWS="0"), capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout + p.stderr
-    lz, s0, s1 = [float(x) for x in p.stdout.strip().splitlines()[-1].split()]
-    assert lz == s["log_evidence"] and s0 == float(stats.sum()) and s1 == float((stats * np.arange(stats.size).reshape(stats.shape)).sum())
+    g = cp.Group([0] * len(shards))
+    g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=13, ess_threshold=2.0, shard_sizes=shards, flags=cp.capi.FLAG_NO_SKIP_ROWS)
+    g.run()
+    stats2, s2, _ = g.results()
+    paths2 = np.concatenate([_ctx_paths(g, r, shards[r], len(obs), True) for r in range(len(shards))], axis=1)
+    g.close()
+    assert np.array_equal(paths2, ref_paths) and s2["log_evidence"] == s["log_evidence"] and np.array_equal(stats2, stats)
 
 
 def _ctx_paths(g, r, n_r, T, is_int):

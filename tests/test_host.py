@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (cpprob_hip_\w+)", out))
     assert set(declared) <= exported
     L = cpprob_amd.load_library()
-    assert L.cpprob_hip_abi_version() == 1
+    assert L.cpprob_hip_abi_version() == 2
     # nothing but the C ABI is exported (no C++ symbols leak)
     assert not [l for l in out.splitlines() if " T " in l and "cpprob_hip_" not in l and "_init" not in l and "_fini" not in l]
 
@@ -36,8 +36,8 @@ def test_library_exports_every_declared_symbol():
 def test_config_struct_layout_matches_header():
     import ctypes as C
     from cpprob_amd import capi
-    assert C.sizeof(capi.Config) == 6 * 4 + 8 + 4 * 8
-    assert capi.Config.ess_threshold.offset == 24 and capi.Config.seed.offset == 32
+    assert C.sizeof(capi.Config) == 8 * 4 + 8 + 4 * 8
+    assert capi.Config.flags.offset == 24 and capi.Config.ess_threshold.offset == 32 and capi.Config.seed.offset == 40
     assert C.sizeof(capi.Summary) == 4 * 8 + 4 * 4
 
 
