@@ -23,7 +23,8 @@ SYMBOLS = [
     "cpprob_hip_infer_stats", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
     "cpprob_hip_smc_finish", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
-    "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_group_unique_id", "cpprob_hip_group_create", "cpprob_hip_group_destroy",
+    "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_exchange_direct", "cpprob_hip_exchange_traffic",
+    "cpprob_hip_group_create_external", "cpprob_hip_group_traffic", "cpprob_hip_group_unique_id", "cpprob_hip_group_create", "cpprob_hip_group_destroy",
     "cpprob_hip_group_last_error", "cpprob_hip_group_begin", "cpprob_hip_group_transport", "cpprob_hip_group_run", "cpprob_hip_group_sync", "cpprob_hip_group_size",
     "cpprob_hip_group_context", "cpprob_hip_group_results", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
@@ -48,6 +49,21 @@ class Summary(C.Structure):
     _fields_ = [("log_evidence", C.c_double), ("ess_final", C.c_double), ("log_norm", C.c_double), ("max_logw", C.c_double),
                 ("n_predict", C.c_int32), ("stats_per_predict", C.c_int32), ("is_int", C.c_int32), ("n_resampled", C.c_int32)]
 
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class Collectives(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allgather", ALLGATHER_FN)]
+
+
+class Traffic(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("payload_bytes", C.c_uint64), ("wire_bytes", C.c_uint64), ("collective_bytes", C.c_uint64),
+                ("transport", C.c_int32), ("reserved", C.c_int32)]
+
+
+GROUP_SENDRECV, GROUP_WORLD1_COLLECTIVES = 1, 2
+TRANSPORT_NONE, TRANSPORT_DIRECT, TRANSPORT_SENDRECV = 0, 1, 2
 
 _lib = None
 
@@ -98,7 +114,11 @@ def load_library(path=None):
         "cpprob_hip_group_destroy": (None, [vp]),
         "cpprob_hip_group_last_error": (C.c_char_p, [vp]),
         "cpprob_hip_group_begin": (C.c_int, [vp, C.POINTER(Config), C.POINTER(dbl), sz, vp]),
-        "cpprob_hip_group_transport": (C.c_int, [vp, u64, i32]),
+        "cpprob_hip_group_transport": (C.c_int, [vp, u64, i32, C.c_uint32]),
+        "cpprob_hip_group_create_external": (C.c_int, [i32, i32, i32, C.POINTER(Collectives), C.POINTER(vp)]),
+        "cpprob_hip_group_traffic": (C.c_int, [vp, C.POINTER(Traffic)]),
+        "cpprob_hip_exchange_direct": (C.c_int, [vp, vp]),
+        "cpprob_hip_exchange_traffic": (C.c_int, [vp, vp, sz, C.POINTER(u64), C.POINTER(u64)]),
         "cpprob_hip_group_run": (C.c_int, [vp, u64]),
         "cpprob_hip_group_sync": (C.c_int, [vp]),
         "cpprob_hip_group_size": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
@@ -280,6 +300,13 @@ class Engine:
         self._chk(self.L.cpprob_hip_exchange_plan(self.h, int(t), int(world), int(rank), sb.ctypes.data, send.ctypes.data, recv.ctypes.data, C.byref(flag)))
         return bool(flag.value), send, recv
 
+    def exchange_traffic(self):
+        """(records sent after each step [T], total records, total bytes) of this rank's last exchange-scope run on a fixed transport."""
+        per = np.zeros(self.T, np.int64)
+        rec, byt = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.L.cpprob_hip_exchange_traffic(self.h, per.ctypes.data, per.size, C.byref(rec), C.byref(byt)))
+        return per, int(rec.value), int(byt.value)
+
     def exchange_pack(self, t, send):
         self._chk(self.L.cpprob_hip_exchange_pack(self.h, int(t), _dptr(send) if send is not None else None))
 
@@ -372,13 +399,29 @@ class Group:
     run.  devices: this process's GPUs.  world > len(devices): one rank of a multi-process group (unique_id from
     Group.unique_id() on rank 0, distributed by the launcher).  All devices equal: loopback (every rank on that one GPU)."""
 
-    def __init__(self, devices, world=None, first_rank=0, unique_id=None):
+    def __init__(self, devices, world=None, first_rank=0, unique_id=None, allgather=None):
+        """allgather(bytes_in) -> bytes of every rank in rank order: the caller's own collective (cpprob_hip_group_create_external);
+        then devices = [this rank's GPU], world and first_rank (= rank) as given."""
         self.L = load_library()
         devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
         world = len(devices) if world is None else int(world)
         h = C.c_void_p()
-        uid = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
-        rc = self.L.cpprob_hip_group_create(devs, len(devices), world, int(first_rank), uid, C.byref(h))
+        if allgather is not None:
+            def _cb(user, h_in, h_out, nbytes):
+                try:
+                    out = allgather(C.string_at(h_in, nbytes))
+                    if len(out) != nbytes * world:
+                        return 1
+                    C.memmove(h_out, out, len(out))
+                    return 0
+                except Exception:        # noqa: reported as a failed collective
+                    return 1
+            self._cb = ALLGATHER_FN(_cb)              # (kept alive with the group)
+            self._coll = Collectives(None, self._cb)
+            rc = self.L.cpprob_hip_group_create_external(int(devices[0]), world, int(first_rank), C.byref(self._coll), C.byref(h))
+        else:
+            uid = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+            rc = self.L.cpprob_hip_group_create(devs, len(devices), world, int(first_rank), uid, C.byref(h))
         if rc:
             msg = self.L.cpprob_hip_group_last_error(None)
             raise CpprobHipError("cpprob_hip_group_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
@@ -432,9 +475,15 @@ class Group:
         self.n = int(n_particles)
         return self
 
-    def transport(self, records_per_peer=0, all_peers=-1):
-        """Transport parameters of the next begin() (0 / -1: the defaults)."""
-        self._chk(self.L.cpprob_hip_group_transport(self.h, int(records_per_peer), int(all_peers)))
+    def transport(self, records_per_peer=0, all_peers=-1, flags=0):
+        """Transport parameters of the next begin() (0 / -1: the defaults; flags: GROUP_SENDRECV, GROUP_WORLD1_COLLECTIVES)."""
+        self._chk(self.L.cpprob_hip_group_transport(self.h, int(records_per_peer), int(all_peers), int(flags)))
+
+    def traffic(self):
+        """Of the run results() last collected: dict of records, payload_bytes, wire_bytes, collective_bytes, transport."""
+        t = Traffic()
+        self._chk(self.L.cpprob_hip_group_traffic(self.h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in Traffic._fields_ if f != "reserved"}
 
     def run(self, run_index=0):
         self._chk(self.L.cpprob_hip_group_run(self.h, int(run_index)))

@@ -92,6 +92,9 @@ struct cpprob_hip_ctx {
     const double* x_all_totals = nullptr;
     bool x_fixed = false; int64_t x_cap = 0; int x_mode = 0; std::vector<int> x_peers;   // fixed-capacity transport (cpprob_hip_exchange_setup)
     void* d_xsend = nullptr; void* d_xrecv = nullptr; size_t x_buf_bytes = 0;
+    // direct transport: the packing kernel stores records straight into the receivers' buffers (cpprob_hip_exchange_direct)
+    bool x_direct = false; void** d_peer_recv = nullptr; int32_t* d_peer_slot = nullptr;
+    int64_t* d_sent = nullptr; int sent_cap = 0;  // [T] records sent after each step of the last run (traffic accounting)
     std::vector<uint64_t> x_shard_begin;
     int x_plan_t = -1;                            // step whose plan sits in d_xplan
     struct { int t = -1; bool resample = false; std::vector<uint64_t> send_lo, send_cnt; uint64_t n_send = 0, n_recv = 0; int64_t l0 = 0, l1 = 0; } plan;
@@ -608,7 +611,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
     dfree(c->d_ctrl); dfree(c->d_local_totals);
-    dfree(c->d_send_src); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv);
+    dfree(c->d_send_src); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_first);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -998,6 +1001,7 @@ int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
     g.world = c->x_world; g.rank = c->x_rank; g.n = c->n; g.shard_begin = c->d_shard_begin;
     g.slot_of_rank = fixed_layout ? c->d_slot_of_rank : nullptr; g.cap = fixed_layout ? c->x_cap : (int64_t)1 << 40;
     g.annex_cap = fixed_layout ? c->annex_cap : (int64_t)1 << 40;      // (callers that synchronise grow the annex themselves)
+    g.bytes_per_value = (int)(fixed_layout ? c->ssz : (c->is_int ? sizeof(int32_t) : sizeof(double))); g.sent_per_step = c->d_sent;
     PlanCountsIn pc{};
     pc.all_totals = c->x_all_totals; pc.n_pop = (double)c->pop_n;
     if (c->counts_mode) {
@@ -1016,9 +1020,15 @@ int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
 }
 
 template <class Model, class R>
-void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid)
+void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid, bool plan_inside = false)
 {
     PackArgs<Model, R> a{};
+    if (c->x_direct && c->x_fixed) { a.peer_recv = c->d_peer_recv; a.peer_slot = c->d_peer_slot; a.cap = c->x_cap; }
+    if (plan_inside) {
+        a.geom.world = c->x_world; a.geom.rank = c->x_rank; a.geom.n = c->n; a.geom.shard_begin = c->d_shard_begin; a.geom.slot_of_rank = c->d_slot_of_rank;
+        a.geom.cap = c->x_cap; a.geom.annex_cap = c->annex_cap; a.geom.bytes_per_value = (int)c->ssz; a.geom.sent_per_step = c->d_sent;
+        a.annex_base = c->d_annex_base; a.plan_out = c->d_xplan;
+    }
     a.values = static_cast<const typename Model::store_t*>(c->d_values); a.anc = c->d_anc; a.rs = c->rs; a.n = c->n; a.nb = c->nb;
     a.resampled = c->d_resampled; a.t = t; a.plan = c->d_xplan; a.world = c->x_world; a.rank = c->x_rank; a.send = d_send;
     a.skip = (c->d_skip && t >= 2 * kSkipEvery) ? c->d_skip : nullptr;
@@ -1031,7 +1041,8 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid)
             hier_view(c, kn, a.h);
             a.pc.e0 = c->h_e_tab[(size_t)t * 4]; a.pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; a.pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
             a.pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
-            hipLaunchKernelGGL((exchange_pack_kernel<Model, R, true>), pgrid, dim3(kThreads), 0, c->stream, a);
+            if (plan_inside) hipLaunchKernelGGL((exchange_pack_kernel<Model, R, true, true>), pgrid, dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL((exchange_pack_kernel<Model, R, true, false>), pgrid, dim3(kThreads), 0, c->stream, a);
             return;
         }
     }
@@ -1144,8 +1155,9 @@ int cpprob_hip_exchange_setup(cpprob_hip_ctx* c, int32_t world, int32_t rank, co
     if (int rc = upload_geometry(c, world, rank, h_shard_begin)) return rc;
     std::vector<int32_t> slot((size_t)kWorldSlots, -1);
     c->x_peers.clear();
+    if (all_peers == 2 && world != 1) return fail(c, CPPROB_HIP_EINVAL, "all_peers = 2 (a rank that is its own peer) is the one-rank diagnostic");
     for (int r = 0; r < world; ++r) {
-        if (r == rank) continue;
+        if (r == rank && all_peers != 2) continue;
         if (all_peers || r == rank - 1 || r == rank + 1) { slot[(size_t)r] = (int32_t)c->x_peers.size(); c->x_peers.push_back(r); }
     }
     if (!c->d_slot_of_rank) HIP_TRY(c, hipMalloc(&c->d_slot_of_rank, kWorldSlots * sizeof(int32_t)));
@@ -1159,6 +1171,50 @@ int cpprob_hip_exchange_setup(cpprob_hip_ctx* c, int32_t world, int32_t rank, co
         c->x_buf_bytes = need;
     }
     c->x_world = world; c->x_rank = rank;
+    c->x_direct = false;                                   // (the peers' buffers may have moved: cpprob_hip_exchange_direct again)
+    if (c->T > c->sent_cap) { dfree(c->d_sent); HIP_TRY(c, hipMalloc(&c->d_sent, (size_t)c->T * sizeof(int64_t))); c->sent_cap = c->T; }
+    HIP_TRY(c, hipMemset(c->d_sent, 0, (size_t)c->sent_cap * sizeof(int64_t)));
+    return 0;
+}
+
+int cpprob_hip_exchange_direct(cpprob_hip_ctx* c, void* const* h_peer_recv)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->x_fixed) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_setup has not run");
+    if (!h_peer_recv) { c->x_direct = false; return 0; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the slot each peer keeps for this rank: its peer list is the ranks around it (or every other rank) in rank order
+    std::vector<void*> ptr((size_t)kWorldSlots, nullptr);
+    std::vector<int32_t> slot((size_t)kWorldSlots, 0);
+    for (int r : c->x_peers) {
+        if (!h_peer_recv[r]) return fail(c, CPPROB_HIP_EINVAL, "cpprob_hip_exchange_direct: no receive buffer for a peer rank");
+        ptr[(size_t)r] = h_peer_recv[r];
+        if (r == c->x_rank) slot[(size_t)r] = 0;                               // (one-rank diagnostic: its own, only, slot)
+        else if (c->x_mode) slot[(size_t)r] = c->x_rank < r ? c->x_rank : c->x_rank - 1;
+        else slot[(size_t)r] = (c->x_rank == r - 1) ? 0 : (r - 1 >= 0 ? 1 : 0);
+    }
+    if (!c->d_peer_recv) HIP_TRY(c, hipMalloc(&c->d_peer_recv, kWorldSlots * sizeof(void*)));
+    if (!c->d_peer_slot) HIP_TRY(c, hipMalloc(&c->d_peer_slot, kWorldSlots * sizeof(int32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_peer_recv, ptr.data(), kWorldSlots * sizeof(void*), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_peer_slot, slot.data(), kWorldSlots * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->x_direct = true;
+    return 0;
+}
+
+int cpprob_hip_exchange_traffic(cpprob_hip_ctx* c, int64_t* h_sent_per_step, size_t n_steps, uint64_t* h_records, uint64_t* h_bytes)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->exchange || !c->d_xplan || !c->d_sent) return fail(c, CPPROB_HIP_ESTATE, "no exchange-scope run on a fixed transport");
+    HIP_TRY(c, hipSetDevice(c->device));
+    ExchangePlan h;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_xplan, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    if (h_sent_per_step) {
+        if (n_steps < (size_t)c->T) return fail(c, CPPROB_HIP_EINVAL, "h_sent_per_step too small");
+        HIP_TRY(c, hipMemcpyAsync(h_sent_per_step, c->d_sent, (size_t)c->T * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h_records) *h_records = (uint64_t)h.run_records;
+    if (h_bytes) *h_bytes = (uint64_t)h.run_bytes;
     return 0;
 }
 
@@ -1183,10 +1239,14 @@ int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* c, int32_t t)
     if (!c->step_protocol || c->step_t != t || !c->x_all_totals) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_pack_async(t) follows cpprob_hip_smc_step_end(t)");
     if (t < 0 || t + 1 >= c->T) return fail(c, CPPROB_HIP_EINVAL, "no exchange follows the last step");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (int rc = launch_plan(c, t, true)) return rc;
+    // count form: the plan is a pure function of the all-gathered totals -- every packing workgroup derives it on its first wavefront
+    // and workgroup 0 stores it (one launch less per step); floating-point form: the plan launch also combines the ranks' totals
+    const bool plan_inside = c->counts_mode;
+    if (!plan_inside) { if (int rc = launch_plan(c, t, true)) return rc; }
+    else c->x_plan_t = t;
     // enough workgroups for a full segment per peer; those beyond the planned tiles leave at once
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(1, (c->x_cap + kTile - 1) / kTile), 256);
-    dispatch_model(c, [&](auto m) { using M = decltype(m); launch_pack<M, typename M::store_t>(c, t, static_cast<typename M::store_t*>(c->d_xsend), grid); });
+    dispatch_model(c, [&](auto m) { using M = decltype(m); launch_pack<M, typename M::store_t>(c, t, static_cast<typename M::store_t*>(c->d_xsend), grid, plan_inside); });
     HIP_TRY(c, hipGetLastError());
     c->plan.t = t;
     return 0;

@@ -32,6 +32,7 @@ struct ExchangePlan {
     int64_t recv_cnt[kWorldSlots];      // per RANK: records that arrive from it, where they sit in the receive buffer, their first annex column offset
     int64_t recv_base[kWorldSlots];
     int64_t recv_off[kWorldSlots];
+    int64_t run_records, run_bytes;   // what this rank's sources sent since step 0 of the run: lineage records, and their bytes (records x (t + 1) x value size)
 };
 
 struct ExchangeGeom {
@@ -41,54 +42,44 @@ struct ExchangeGeom {
     const int32_t* slot_of_rank;      // [world] device: transport slot of each rank (-1: not a peer in this mode); nullptr: compact layout
     int64_t cap;                      // records per slot (fixed layout)
     int64_t annex_cap;
+    int bytes_per_value;              // of the transported records (traffic accounting)
+    int64_t* sent_per_step;           // [T] device, may be nullptr: records this rank sent after each step
 };
 
 struct PlanCountsIn {                 // prefix-count form: o_r from the all-gathered {n_0, n_1, particles}
     const double* all_totals; double e0, e1, e2, u0, n_pop;
 };
 
-// One wave.  COUNTS: bounds from integer counts (canonical arithmetic, the step kernel's own expressions); otherwise from obound[]
-// (scan_exchange_bounds) and its decision word.
-// SCAN2: the launch also combines the all-gathered {max, sum, sum of squares} of the ranks into ctrl and the ranks' output bounds
-// first (what scan_partials_kernel's phase 2 does on one thread): one launch less per step of a floating-point-form exchange run.
-template <bool COUNTS, bool SCAN2 = false>
-__global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, PlanCountsIn pc, const double* __restrict__ obound, int t,
-                                                              int64_t* __restrict__ annex_base, ExchangePlan* __restrict__ plan, ScanArgs sa)
+// The plan as one wavefront holds it: lane r = what concerns rank r, plus the wave-uniform part.
+struct PlanLane { int64_t send_lo, send_cnt, send_base, recv_cnt, recv_base, recv_off; };
+struct PlanWave { int64_t l0, l1, n_send, n_recv; int32_t flags; bool resample; };
+
+// o_r (lane r, r = 0 .. world) from the all-gathered {n_0, n_1, particles} of every rank: canonical integer arithmetic, the step
+// kernel's own expressions.  One wave, every lane.
+__device__ __forceinline__ double plan_bounds_counts(const PlanCountsIn& pc, int world)
+{
+    const int lane = lane_id();
+    double r0 = 0.0, r1 = 0.0, rv = 0.0;
+    if (lane < world) { r0 = pc.all_totals[3 * lane]; r1 = pc.all_totals[3 * lane + 1]; rv = pc.all_totals[3 * lane + 2]; }
+    // exclusive prefix over ranks: sums of integers below 2^53 -- exact, so every rank (and the step kernel's masked sums) agree
+    const double i0 = wave_incl_scan(r0), i1 = wave_incl_scan(r1), iv = wave_incl_scan(rv);
+    TableCdf tc;
+    tc.e0 = pc.e0; tc.e1 = pc.e1; tc.e2 = pc.e2; tc.u0 = pc.u0; tc.n_pop = pc.n_pop;
+    tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
+    const double W = tc.cdf(read_lane(i0, kWave - 1), read_lane(i1, kWave - 1), pc.n_pop);
+    tc.inv = pc.n_pop / W;
+    double o = tc.g(tc.cdf(i0 - r0, i1 - r1, iv - rv));
+    if (lane >= world) o = pc.n_pop;
+    return o;
+}
+
+// From the bounds to the plan: my sources' interval and what each rank's shard takes of it / gives to me.  One wave, every lane.
+__device__ __forceinline__ void plan_wave(const ExchangeGeom& g, double o, bool resample, PlanLane& pl, PlanWave& pw)
 {
     const int lane = lane_id();
     const int world = g.world, rank = g.rank;
-    __shared__ double s_ob[kWorldSlots + 2];
-    if (SCAN2) {
-        if (lane == 0) {
-            scan_combine_ranks(sa);
-            scan_tail(sa);
-            scan_exchange_bounds(sa);
-            for (int r = 0; r <= world + 1; ++r) s_ob[r] = sa.obound[r];      // (this thread's own stores)
-        }
-        __syncthreads();
-    }
-    double o = 0.0;                                            // lane r: o_r, r = 0..world
-    bool resample;
-    if (COUNTS) {
-        double r0 = 0.0, r1 = 0.0, rv = 0.0;
-        if (lane < world) { r0 = pc.all_totals[3 * lane]; r1 = pc.all_totals[3 * lane + 1]; rv = pc.all_totals[3 * lane + 2]; }
-        // exclusive prefix over ranks: sums of integers below 2^53 -- exact, so every rank (and the step kernel's masked sums) agree
-        const double i0 = wave_incl_scan(r0), i1 = wave_incl_scan(r1), iv = wave_incl_scan(rv);
-        TableCdf tc;
-        tc.e0 = pc.e0; tc.e1 = pc.e1; tc.e2 = pc.e2; tc.u0 = pc.u0; tc.n_pop = pc.n_pop;
-        tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
-        const double W = tc.cdf(read_lane(i0, kWave - 1), read_lane(i1, kWave - 1), pc.n_pop);
-        tc.inv = pc.n_pop / W;
-        o = tc.g(tc.cdf(i0 - r0, i1 - r1, iv - rv));
-        if (lane >= world) o = pc.n_pop;
-        resample = true;
-    } else {
-        if (lane <= world) o = SCAN2 ? s_ob[lane] : obound[lane];
-        resample = (SCAN2 ? s_ob[world + 1] : obound[world + 1]) != 0.0;
-    }
-    // my sources' interval and what each rank's shard takes of it / gives to me
     const double my_lo = read_lane(o, rank), my_hi = read_lane(o, rank + 1);
-    const double o_next = dpp_or<0x130 /* wave_shl:1 */>(o, 0.0);        // lane r: o_{r+1}
+    const double o_next = dpp_or<0x130 /* wave_shl:1 */>(o, 0.0);        // lane r: o_{r+1} (world <= 63: lane world exists)
     auto clampd = [](double v, double lo, double hi) { return fmin(fmax(v, lo), hi); };
     int64_t send_lo = 0, send_cnt = 0, recv_cnt = 0, l0 = 0, l1 = g.n;
     int32_t flag = 0;
@@ -120,27 +111,72 @@ __global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, Pl
     }
     // (annex columns follow the receive order = rank order = output order; recomputed after any clamping)
     const uint32_t ro_incl = wave_incl_scan_u32((uint32_t)recv_cnt), so_incl = wave_incl_scan_u32((uint32_t)send_cnt);
-    const int64_t recv_off = (int64_t)(ro_incl - (uint32_t)recv_cnt);
-    int64_t n_recv = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ro_incl, kWave - 1);
-    const int64_t n_send = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)so_incl, kWave - 1);
+    pl.send_lo = send_lo; pl.send_cnt = send_cnt; pl.send_base = send_base;
+    pl.recv_cnt = recv_cnt; pl.recv_base = recv_base; pl.recv_off = (int64_t)(ro_incl - (uint32_t)recv_cnt);
+    pw.n_recv = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ro_incl, kWave - 1);
+    pw.n_send = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)so_incl, kWave - 1);
+    pw.l0 = l0; pw.l1 = l1; pw.resample = resample;
+    pw.flags = (__ballot(flag == 1) ? 1 : 0) | (__ballot(flag == 2) ? 2 : 0);
+}
+
+// The plan into memory (what the commit kernel and the next step read), the annex bookkeeping, the traffic counters.  One wave.
+__device__ __forceinline__ void plan_store(const ExchangeGeom& g, int t, const PlanLane& pl, const PlanWave& pw, int64_t* __restrict__ annex_base,
+                                           ExchangePlan* __restrict__ plan)
+{
+    const int lane = lane_id();
     const int64_t base = t == 0 ? 0 : annex_base[t];
-    const unsigned long long any1 = __ballot(flag == 1), any2 = __ballot(flag == 2);
-    if (lane < world) {
-        plan->send_lo[lane] = send_lo; plan->send_cnt[lane] = send_cnt; plan->send_base[lane] = send_base;
-        plan->recv_cnt[lane] = recv_cnt; plan->recv_base[lane] = recv_base; plan->recv_off[lane] = recv_off;
+    if (lane < g.world) {
+        plan->send_lo[lane] = pl.send_lo; plan->send_cnt[lane] = pl.send_cnt; plan->send_base[lane] = pl.send_base;
+        plan->recv_cnt[lane] = pl.recv_cnt; plan->recv_base[lane] = pl.recv_base; plan->recv_off[lane] = pl.recv_off;
     }
     if (lane == 0) {
-        const bool over_annex = base + n_recv > g.annex_cap;
-        plan->resample = resample ? 1 : 0;
+        const bool over_annex = base + pw.n_recv > g.annex_cap;
+        plan->resample = pw.resample ? 1 : 0;
         int32_t ov = t == 0 ? 0 : plan->overflow;
-        if (any1) ov |= 1;
-        if (any2) ov |= 2;
+        ov |= pw.flags;
         if (over_annex) ov |= 4;
         plan->overflow = ov;
-        plan->l0 = l0; plan->l1 = l1; plan->n_send = n_send; plan->n_recv = over_annex ? 0 : n_recv;
+        plan->l0 = pw.l0; plan->l1 = pw.l1; plan->n_send = pw.n_send; plan->n_recv = over_annex ? 0 : pw.n_recv;
         if (t == 0) annex_base[0] = 0;
-        annex_base[t + 1] = base + (over_annex ? 0 : n_recv);
+        annex_base[t + 1] = base + (over_annex ? 0 : pw.n_recv);
+        const int64_t rec0 = t == 0 ? 0 : plan->run_records, byt0 = t == 0 ? 0 : plan->run_bytes;
+        plan->run_records = rec0 + pw.n_send;
+        plan->run_bytes = byt0 + pw.n_send * (int64_t)(t + 1) * (int64_t)g.bytes_per_value;
+        if (g.sent_per_step) g.sent_per_step[t] = pw.n_send;
     }
+}
+
+// One wave.  COUNTS: bounds from integer counts (plan_bounds_counts); otherwise from obound[] (scan_exchange_bounds) and its decision word.
+// SCAN2: the launch also combines the all-gathered {max, sum, sum of squares} of the ranks into ctrl and the ranks' output bounds
+// first (what scan_partials_kernel's phase 2 does on one thread): one launch less per step of a floating-point-form exchange run.
+template <bool COUNTS, bool SCAN2 = false>
+__global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, PlanCountsIn pc, const double* __restrict__ obound, int t,
+                                                              int64_t* __restrict__ annex_base, ExchangePlan* __restrict__ plan, ScanArgs sa)
+{
+    const int lane = lane_id();
+    const int world = g.world;
+    __shared__ double s_ob[kWorldSlots + 2];
+    if (SCAN2) {
+        if (lane == 0) {
+            scan_combine_ranks(sa);
+            scan_tail(sa);
+            scan_exchange_bounds(sa);
+            for (int r = 0; r <= world + 1; ++r) s_ob[r] = sa.obound[r];      // (this thread's own stores)
+        }
+        __syncthreads();
+    }
+    double o = 0.0;                                            // lane r: o_r, r = 0..world
+    bool resample;
+    if (COUNTS) {
+        o = plan_bounds_counts(pc, world);
+        resample = true;
+    } else {
+        if (lane <= world) o = SCAN2 ? s_ob[lane] : obound[lane];
+        resample = (SCAN2 ? s_ob[world + 1] : obound[world + 1]) != 0.0;
+    }
+    PlanLane pl; PlanWave pw;
+    plan_wave(g, o, resample, pl, pw);
+    plan_store(g, t, pl, pw, annex_base, plan);
 }
 
 // Skip rows.  A migrating particle takes its lineage x_0 .. x_t along, and extracting a lineage is a chain of t dependent gathers
@@ -180,7 +216,12 @@ struct PackArgs {
     const typename Model::store_t* values; const int32_t* anc; int64_t rs, n; int nb; const int32_t* resampled; int t;   // generation t is the one resampled
     const int32_t* skip;                                         // skip rows (see skip_rows_kernel) or nullptr: gridDim.y = t / 8 + 1 blocks of generations then
     const ExchangePlan* plan; int world, rank;
-    R* send;                                                     // records of t + 1 values
+    R* send;                                                     // records of t + 1 values: this rank's own send buffer ...
+    // ... or DIRECT stores into the receivers' buffers (peer access / IPC mappings; loopback: plain device pointers): peer_recv[r] =
+    // rank r's receive buffer as THIS device addresses it, peer_slot[r] = the slot rank r keeps for this rank, cap = records per slot
+    void* const* peer_recv; const int32_t* peer_slot; int64_t cap;
+    // PLAN_INSIDE: every workgroup derives the plan itself (one wavefront, from the all-gathered totals); workgroup (0, 0) also stores it
+    ExchangeGeom geom; int64_t* annex_base; ExchangePlan* plan_out;
     // prefix-count form
     Hier h; PlanCountsIn pc;
     // floating-point form
@@ -188,15 +229,30 @@ struct PackArgs {
     uint64_t pid0;
 };
 
-template <class Model, class R, bool COUNTS>
+template <class Model, class R, bool COUNTS, bool PLAN_INSIDE = false>
 __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model, R> a)
 {
     using S = typename Model::store_t;
     __shared__ CountsLds Lc;
     __shared__ AncestorLds Lf;
     __shared__ uint32_t s_hop[32];                              // bit tt - 1 of word (tt - 1) / 32: did step tt - 1 resample? (<= 1024 steps)
+    __shared__ int64_t s_send_lo[kWorldSlots], s_send_cnt[kWorldSlots], s_send_base[kWorldSlots];
+    __shared__ int64_t s_nsend;
     const int tid = threadIdx.x;
-    if (!a.plan->resample || a.plan->n_send == 0) return;       // workgroup-uniform
+    static_assert(!PLAN_INSIDE || COUNTS, "the plan is a pure function of the all-gathered totals in the count form only");
+    if constexpr (PLAN_INSIDE) {
+        if (wave_id() == 0) {
+            PlanLane pl; PlanWave pw;
+            plan_wave(a.geom, plan_bounds_counts(a.pc, a.world), true, pl, pw);
+            s_send_lo[tid] = pl.send_lo; s_send_cnt[tid] = pl.send_cnt; s_send_base[tid] = pl.send_base;
+            if (tid == 0) s_nsend = pw.n_send;
+            if (blockIdx.x == 0 && blockIdx.y == 0) plan_store(a.geom, a.t, pl, pw, a.annex_base, a.plan_out);
+        }
+        __syncthreads();
+        if (s_nsend == 0) return;                               // workgroup-uniform
+    } else {
+        if (!a.plan->resample || a.plan->n_send == 0) return;   // workgroup-uniform
+    }
     // (the walk below is a chain of dependent gathers: nothing else may sit on it -- the per-step flags come out of LDS, not memory)
     if (tid < 32) {
         uint32_t w = 0;
@@ -220,9 +276,12 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
     }
     const int len = a.t + 1;
     for (int r = 0; r < a.world; ++r) {
-        const int64_t cnt = a.plan->send_cnt[r];
+        const int64_t cnt = PLAN_INSIDE ? s_send_cnt[r] : a.plan->send_cnt[r];
         if (r == a.rank || cnt == 0) continue;                  // uniform
-        const int64_t lo = a.plan->send_lo[r], base = a.plan->send_base[r];
+        const int64_t lo = PLAN_INSIDE ? s_send_lo[r] : a.plan->send_lo[r];
+        // where rank r's records go: its own receive slot for this rank (direct stores), or this rank's send buffer
+        R* const dst = a.peer_recv ? static_cast<R*>(a.peer_recv[r]) + (int64_t)a.peer_slot[r] * a.cap * (int64_t)(a.t + 1)
+                                   : a.send + (PLAN_INSIDE ? s_send_base[r] : a.plan->send_base[r]) * (int64_t)(a.t + 1);
         for (int64_t tl = blockIdx.x; tl * kTile < cnt; tl += gridDim.x) {
             const int64_t rem = cnt - tl * kTile;
             const int n_out = rem < kTile ? (int)rem : kTile;
@@ -252,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
                     const int q = tid * kPPT + k;
-                    on[k] = q < n_out; idx[k] = max(anc[k], 0); rec[k] = a.send + (base + tl * kTile + (on[k] ? q : 0)) * len;
+                    on[k] = q < n_out; idx[k] = max(anc[k], 0); rec[k] = dst + (tl * kTile + (on[k] ? q : 0)) * len;
                 }
                 auto hops = [&](int tt) { return tt > 0 && ((s_hop[(tt - 1) >> 5] >> ((tt - 1) & 31)) & 1u) != 0; };
                 auto single = [&](int tt) {                                 // generation tt -> tt - 1

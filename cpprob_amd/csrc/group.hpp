@@ -2,13 +2,21 @@
 // issued from C++ with no host synchronisation inside a run -- what cpprob::inference calls when cpprob::gpu::options().devices names
 // several GPUs, and what bench.py runs under torchrun.
 //
-// Transports
-//   RCCL (xGMI)  dlopen()ed (the copy the process already holds, else /opt/rocm's): per step one ncclAllGather of 3 doubles per
-//                rank and one group of ncclSend / ncclRecv of the fixed-capacity lineage segments, all on each context's own stream.
+// Collectives (who carries the per-step all-gather of 3 doubles per rank and the run's final all-reduce)
+//   RCCL (xGMI)  dlopen()ed (the copy the process already holds, else /opt/rocm's), on each context's own stream, no host in the loop.
 //                In-process form: one communicator per local GPU (ncclCommInitAll) driven by one host thread each;
 //                one-process-per-GPU form: ncclCommInitRank from a unique id the launcher distributes.
-//   loopback     every rank's context on ONE device and ONE stream; the "collectives" are device copies.  This is how a one-GPU box
-//                exercises the whole protocol, shard layouts and capacities included (RCCL refuses duplicate devices).
+//   external     the caller's own collectives over host buffers (MPI, gloo, ...): cpprob_hip_group_create_external.  Host-synchronising.
+//   loopback     every rank's context on ONE device and ONE stream; program order is the only synchronisation.  This is how a one-GPU
+//                box exercises the whole protocol, shard layouts and capacities included (RCCL refuses duplicate devices).
+// Transports (who moves the migrating lineages)
+//   direct       the packing kernel of the SENDING rank stores each record straight into the receiving rank's buffer -- peer access
+//                inside one process, hipIpc mappings between processes, plain pointers in loopback -- so the bytes that cross xGMI are
+//                the records themselves: records x (t + 1) x value size, nothing on a step that does not resample.  What orders the
+//                receiver's commit behind the senders' stores is a second, one-double all-gather per step (stream-ordered after the
+//                packing kernel on every rank: a rank's contribution cannot arrive before its stores are released).
+//   send/recv    ncclSend / ncclRecv of the fixed-capacity peer segments: the fall-back where peers cannot map each other's memory
+//                (counts must be host constants, so capacity travels, not records).
 // Included by cpprob_hip.hip (it uses the context's internals).
 #pragma once
 #include <dlfcn.h>
@@ -71,13 +79,19 @@ RcclApi* rccl_api(std::string& err)
     return &api;
 }
 
-// {raw weighted sums ..., overflow flag} of a finished sharded run into one buffer: what the final all-reduce carries
-__global__ void pack_joint_kernel(const double* __restrict__ stats, int n_stats, const cph::ExchangePlan* __restrict__ plan, double* __restrict__ out)
+// {raw weighted sums ..., overflow flag, records sent, bytes sent} of a finished sharded run into one buffer: what the final all-reduce carries
+constexpr int kJointExtra = 3;
+__global__ void pack_joint_kernel(const double* __restrict__ stats, int n_stats, const cph::ExchangePlan* __restrict__ plan, int has_traffic, double* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_stats) out[i] = stats[i];
-    // (the flag word's three bits travel as three base-128 digits, so that the all-reduce's SUM over <= 64 ranks keeps them apart)
-    if (i == 0) { const int ov = plan ? plan->overflow : 0; out[n_stats] = (double)((ov & 1) + 128 * ((ov >> 1) & 1) + 16384 * ((ov >> 2) & 1)); }
+    // (the flag word's three bits travel as three base-128 digits, so that the all-reduce's SUM over <= 63 ranks keeps them apart)
+    if (i == 0) {
+        const int ov = plan ? plan->overflow : 0;
+        out[n_stats] = (double)((ov & 1) + 128 * ((ov >> 1) & 1) + 16384 * ((ov >> 2) & 1));
+        out[n_stats + 1] = (plan && has_traffic) ? (double)plan->run_records : 0.0;     // (integers below 2^53: exact in any order)
+        out[n_stats + 2] = (plan && has_traffic) ? (double)plan->run_bytes : 0.0;
+    }
 }
 
 // loopback collectives: every rank lives on this device and this stream
@@ -98,14 +112,19 @@ __global__ void loop_allreduce_kernel(double* const* __restrict__ bufs, int worl
     for (int q = 0; q < world; ++q) bufs[q][i] = s;
 }
 
+enum { kCollLoopback = 0, kCollRccl = 1, kCollExternal = 2 };
+enum { kTransportNone = 0, kTransportDirect = 1, kTransportSendRecv = 2 };
+
 }  // namespace
 
 struct cpprob_hip_group {
     int world = 0, first_rank = 0;
     std::vector<cpprob_hip_ctx*> ctx;                  // local ranks first_rank .. first_rank + n_local - 1
-    bool loopback = false;
+    int coll = kCollRccl;
+    bool loopback() const { return coll == kCollLoopback; }
     RcclApi* rccl = nullptr;
     std::vector<ncclComm_t> comm;
+    cpprob_hip_collectives ext{};                      // kCollExternal: the caller's collectives (host buffers, blocking)
     std::string err;
     // run configuration
     cpprob_hip_config cfg{};
@@ -114,13 +133,19 @@ struct cpprob_hip_group {
     bool begun = false, exchange = false;
     int T = 0, K = 0, n_stats = 0;
     int all_peers = 0; uint64_t cap = 0; int annex_kcols = 0;
-    uint64_t user_cap = 0; int user_all_peers = -1;     // cpprob_hip_group_transport: the caller's choice (0 / -1: the defaults below)
+    uint64_t user_cap = 0; int user_all_peers = -1; uint32_t user_flags = 0;   // cpprob_hip_group_transport: the caller's choice (0 / -1: the defaults)
+    // transport of the migrating lineages
+    int transport = kTransportNone;
+    bool world1_collectives = false;                   // diagnostic: a group of one still issues every collective and exchanges with itself
+    std::vector<void*> ipc_open;                       // peers' receive buffers mapped into this process (hipIpcOpenMemHandle)
+    std::string transport_note;                        // why the direct transport was not taken
     // per local rank device buffers
-    std::vector<double*> d_local, d_all, d_joint;
+    std::vector<double*> d_local, d_all, d_joint, d_bar;
     double* const* d_ptr_locals = nullptr; double* const* d_ptr_alls = nullptr; double* const* d_ptr_joints = nullptr;   // loopback: device arrays of pointers
     std::vector<hipStream_t> own_stream;               // loopback: the streams the contexts were created with
     uint64_t last_run = 0; bool ran = false;
     int reruns = 0;
+    cpprob_hip_traffic traffic{};                      // of the run cpprob_hip_group_results last collected
     // worker threads (RCCL, several local ranks)
     std::vector<std::thread> workers;
     std::mutex m; std::condition_variable cv_job, cv_done;
@@ -157,7 +182,60 @@ int gkeep(cpprob_hip_group* g, int rc)                  // calling thread: make 
         if (r__ != ncclSuccess) return gfail(g, CPPROB_HIP_EDEVICE, std::string(#expr) + ": " + (g)->rccl->GetErrorString(r__)); \
     } while (0)
 
-// the exchange that follows step t, as seen by local rank i (RCCL form): its peers' segments
+// ---- collectives of local rank i (RCCL: stream-ordered; external: through host buffers, blocking) ----
+int coll_allgather(cpprob_hip_group* g, int i, const double* d_in, double* d_out, size_t n_doubles)
+{
+    cpprob_hip_ctx* c = g->ctx[(size_t)i];
+    if (g->coll == kCollRccl) {
+        NCCL_TRY(g, g->rccl->AllGather(d_in, d_out, n_doubles, ncclDouble, g->comm[(size_t)i], c->stream));
+        return 0;
+    }
+    std::vector<double> in(n_doubles), out(n_doubles * (size_t)g->world);
+    HIP_TRY(c, hipMemcpyAsync(in.data(), d_in, n_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (g->ext.allgather(g->ext.user, in.data(), out.data(), n_doubles * sizeof(double))) return gfail(g, CPPROB_HIP_EDEVICE, "the caller's all-gather failed");
+    HIP_TRY(c, hipMemcpyAsync(d_out, out.data(), out.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));           // (out is a local)
+    return 0;
+}
+int coll_allreduce_sum(cpprob_hip_group* g, int i, double* d_buf, size_t n_doubles)
+{
+    cpprob_hip_ctx* c = g->ctx[(size_t)i];
+    if (g->coll == kCollRccl) {
+        NCCL_TRY(g, g->rccl->AllReduce(d_buf, d_buf, n_doubles, ncclDouble, ncclSum, g->comm[(size_t)i], c->stream));
+        return 0;
+    }
+    // (rank order: the caller's all-gather, summed here -- bitwise reproducible whatever the caller's library does)
+    std::vector<double> in(n_doubles), all(n_doubles * (size_t)g->world);
+    HIP_TRY(c, hipMemcpyAsync(in.data(), d_buf, n_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (g->ext.allgather(g->ext.user, in.data(), all.data(), n_doubles * sizeof(double))) return gfail(g, CPPROB_HIP_EDEVICE, "the caller's all-gather failed");
+    for (size_t k = 0; k < n_doubles; ++k) { double sum = 0.0; for (int r = 0; r < g->world; ++r) sum += all[(size_t)r * n_doubles + k]; in[k] = sum; }
+    HIP_TRY(c, hipMemcpyAsync(d_buf, in.data(), n_doubles * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+// host bytes of every rank, rank order (set-up time only): RCCL stages them through device memory
+int coll_allgather_host(cpprob_hip_group* g, int i, const void* h_in, void* h_out, size_t bytes)
+{
+    cpprob_hip_ctx* c = g->ctx[(size_t)i];
+    if (g->coll == kCollExternal) {
+        if (g->ext.allgather(g->ext.user, h_in, h_out, bytes)) return gfail(g, CPPROB_HIP_EDEVICE, "the caller's all-gather failed");
+        return 0;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    char* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, bytes * ((size_t)g->world + 1)));
+    int rc = 0;
+    if (hipMemcpyAsync(d, h_in, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = gfail(g, CPPROB_HIP_EDEVICE, "hipMemcpyAsync (set-up all-gather)");
+    if (!rc) { const ncclResult_t r = g->rccl->AllGather(d, d + bytes, bytes, ncclInt8, g->comm[(size_t)i], c->stream); if (r != ncclSuccess) rc = gfail(g, CPPROB_HIP_EDEVICE, std::string("ncclAllGather: ") + g->rccl->GetErrorString(r)); }
+    if (!rc && hipMemcpyAsync(h_out, d + bytes, bytes * (size_t)g->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = gfail(g, CPPROB_HIP_EDEVICE, "hipMemcpyAsync (set-up all-gather)");
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = gfail(g, CPPROB_HIP_EDEVICE, "hipStreamSynchronize (set-up all-gather)");
+    (void)hipFree(d);
+    return rc;
+}
+
+// the exchange that follows step t, as seen by local rank i (send/recv transport): its peers' fixed-capacity segments
 int rccl_exchange(cpprob_hip_group* g, int i, int t)
 {
     cpprob_hip_ctx* c = g->ctx[(size_t)i];
@@ -174,28 +252,36 @@ int rccl_exchange(cpprob_hip_group* g, int i, int t)
     return 0;
 }
 
-// One whole run of local rank i (RCCL form): every collective is stream-ordered, nothing waits on the host.
-int rccl_run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
+// One whole run of local rank i (RCCL: every collective is stream-ordered, nothing waits on the host).
+int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
 {
     cpprob_hip_ctx* c = g->ctx[(size_t)i];
     const int rank = g->first_rank + i, world = g->world;
     HIP_TRY(c, hipSetDevice(c->device));
     const bool sis = g->cfg.algorithm == CPPROB_HIP_ALG_SIS;
+    // (a group of one has nobody to gather from or to exchange with: its own totals ARE the gathered totals -- unless the caller
+    //  asked for every collective to run anyway, which is how a one-GPU machine exercises them)
+    const bool talk = world > 1 || g->world1_collectives;
     for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
         if (int rc = cpprob_hip_smc_step_begin(c, t, run_index, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
-        // (a group of one has nobody to gather from: its own totals ARE the gathered totals)
-        if (world > 1) NCCL_TRY(g, g->rccl->AllGather(g->d_local[(size_t)i], g->d_all[(size_t)i], 3, ncclDouble, g->comm[(size_t)i], c->stream));
-        if (int rc = cpprob_hip_smc_step_end(c, t, world > 1 ? g->d_all[(size_t)i] : g->d_local[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
-        if (g->exchange && t + 1 < g->T) {
+        if (talk) { if (int rc = coll_allgather(g, i, g->d_local[(size_t)i], g->d_all[(size_t)i], 3)) return rc; }
+        if (int rc = cpprob_hip_smc_step_end(c, t, talk ? g->d_all[(size_t)i] : g->d_local[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
+        if (g->exchange && t + 1 < g->T && talk) {
             if (int rc = cpprob_hip_exchange_pack_async(c, t)) return gfail(g, rc, cpprob_hip_last_error(c));
-            if (int rc = rccl_exchange(g, i, t)) return rc;
+            if (g->transport == kTransportDirect) {
+                // the records are already where they belong; what remains is the order: no rank may commit before every rank's
+                // packing kernel has completed, and a rank contributes to this all-gather only behind its own packing kernel
+                if (int rc = coll_allgather(g, i, g->d_bar[(size_t)i], g->d_bar[(size_t)i] + 1, 1)) return rc;
+            } else {
+                if (int rc = rccl_exchange(g, i, t)) return rc;
+            }
             if (int rc = cpprob_hip_exchange_commit_async(c, t)) return gfail(g, rc, cpprob_hip_last_error(c));
         }
     }
     if (int rc = cpprob_hip_smc_finish(c)) return gfail(g, rc, cpprob_hip_last_error(c));
     hipLaunchKernelGGL(pack_joint_kernel, dim3((unsigned)((g->n_stats + 256) / 256)), dim3(256), 0, c->stream, (const double*)c->d_stats, g->n_stats,
-                       g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, g->d_joint[(size_t)i]);
-    NCCL_TRY(g, g->rccl->AllReduce(g->d_joint[(size_t)i], g->d_joint[(size_t)i], (size_t)g->n_stats + 1, ncclDouble, ncclSum, g->comm[(size_t)i], c->stream));
+                       g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, (g->exchange && talk && g->T > 1) ? 1 : 0, g->d_joint[(size_t)i]);
+    if (int rc = coll_allreduce_sum(g, i, g->d_joint[(size_t)i], (size_t)g->n_stats + kJointExtra)) return rc;
     HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -215,17 +301,21 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
         for (int r = 0; r < world; ++r)
             if (int rc = cpprob_hip_smc_step_end(g->ctx[(size_t)r], t, g->d_all[(size_t)r], world, r)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
         if (g->exchange && t + 1 < g->T) {
+            // direct transport: every rank's packing kernel stores into the other ranks' receive buffers; program order is the barrier
             for (int r = 0; r < world; ++r)
                 if (int rc = cpprob_hip_exchange_pack_async(g->ctx[(size_t)r], t)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
-            for (int r = 0; r < world; ++r) {
-                cpprob_hip_ctx* c = g->ctx[(size_t)r];
-                const size_t seg = (size_t)c->x_cap * (size_t)(t + 1) * c->ssz;
-                for (size_t s = 0; s < c->x_peers.size(); ++s) {
-                    cpprob_hip_ctx* p = g->ctx[(size_t)c->x_peers[s]];
-                    size_t ps = 0;                                   // the slot the peer keeps for rank r
-                    while (ps < p->x_peers.size() && p->x_peers[ps] != r) ++ps;
-                    if (ps == p->x_peers.size()) return gfail(g, CPPROB_HIP_EDEVICE, "loopback transport: asymmetric peer sets");
-                    HIP_TRY(c, hipMemcpyAsync(static_cast<char*>(p->d_xrecv) + ps * seg, static_cast<const char*>(c->d_xsend) + s * seg, seg, hipMemcpyDeviceToDevice, st));
+            if (g->transport == kTransportSendRecv) {
+                // (the fixed-capacity segments of the send/recv transport, as copies: A/B against the direct stores)
+                for (int r = 0; r < world; ++r) {
+                    cpprob_hip_ctx* c = g->ctx[(size_t)r];
+                    const size_t seg = (size_t)c->x_cap * (size_t)(t + 1) * c->ssz;
+                    for (size_t s = 0; s < c->x_peers.size(); ++s) {
+                        cpprob_hip_ctx* p = g->ctx[(size_t)c->x_peers[s]];
+                        size_t ps = 0;                                   // the slot the peer keeps for rank r
+                        while (ps < p->x_peers.size() && p->x_peers[ps] != r) ++ps;
+                        if (ps == p->x_peers.size()) return gfail(g, CPPROB_HIP_EDEVICE, "loopback transport: asymmetric peer sets");
+                        HIP_TRY(c, hipMemcpyAsync(static_cast<char*>(p->d_xrecv) + ps * seg, static_cast<const char*>(c->d_xsend) + s * seg, seg, hipMemcpyDeviceToDevice, st));
+                    }
                 }
             }
             for (int r = 0; r < world; ++r)
@@ -236,9 +326,9 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
         cpprob_hip_ctx* c = g->ctx[(size_t)r];
         if (int rc = cpprob_hip_smc_finish(c)) return gfail(g, rc, cpprob_hip_last_error(c));
         hipLaunchKernelGGL(pack_joint_kernel, dim3((unsigned)((g->n_stats + 256) / 256)), dim3(256), 0, st, (const double*)c->d_stats, g->n_stats,
-                           g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, g->d_joint[(size_t)r]);
+                           g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, (g->exchange && g->T > 1) ? 1 : 0, g->d_joint[(size_t)r]);
     }
-    hipLaunchKernelGGL(loop_allreduce_kernel, dim3((unsigned)((g->n_stats + 256) / 256)), dim3(256), 0, st, g->d_ptr_joints, world, g->n_stats + 1);
+    hipLaunchKernelGGL(loop_allreduce_kernel, dim3((unsigned)((g->n_stats + kJointExtra + 255) / 256)), dim3(256), 0, st, g->d_ptr_joints, world, g->n_stats + kJointExtra);
     HIP_TRY(c0, hipGetLastError());
     return 0;
 }
@@ -255,7 +345,7 @@ void group_worker(cpprob_hip_group* g, int i)
             seen = g->job_gen; run = g->job_run;
         }
         tl_group_err.clear();
-        const int rc = rccl_run_rank(g, i, run);
+        const int rc = run_rank(g, i, run);
         {
             std::lock_guard<std::mutex> lock(g->m);
             g->job_rc[(size_t)i] = rc;
@@ -265,9 +355,94 @@ void group_worker(cpprob_hip_group* g, int i)
     }
 }
 
+void close_direct(cpprob_hip_group* g)
+{
+    for (auto* c : g->ctx) (void)cpprob_hip_exchange_direct(c, nullptr);
+    for (void* p : g->ipc_open) (void)hipIpcCloseMemHandle(p);
+    g->ipc_open.clear();
+}
+
+// After the contexts are set up: let every rank's packing kernel store into its peers' receive buffers, where the machine allows
+// it.  Loopback: plain pointers.  Several GPUs of one process: peer access.  One process per GPU: hipIpc handles, all-gathered.
+// Every rank takes the same decision (the availability flags are all-gathered); anything short of "every rank can reach every
+// peer" selects the send/recv transport for the whole group.
+int setup_direct(cpprob_hip_group* g)
+{
+    const int n_local = (int)g->ctx.size(), world = g->world;
+    g->transport = kTransportNone; g->transport_note.clear();
+    if (!g->exchange) return 0;
+    if (world == 1 && !g->world1_collectives) return 0;
+    if (g->user_flags & CPPROB_HIP_GROUP_SENDRECV) {
+        if (g->coll == kCollExternal) return gfail(g, CPPROB_HIP_EUNSUPPORTED, "external collectives carry no point-to-point transport: the lineages move by direct stores");
+        g->transport = kTransportSendRecv; g->transport_note = "send/recv transport requested";
+        return 0;
+    }
+    if (world == n_local) {
+        // every rank in this process
+        bool ok = true;
+        if (!g->loopback()) {
+            for (int i = 0; i < n_local && ok; ++i)
+                for (int j = 0; j < n_local && ok; ++j) {
+                    if (i == j) continue;
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, g->ctx[(size_t)i]->device, g->ctx[(size_t)j]->device) != hipSuccess || !can) { ok = false; break; }
+                    (void)hipSetDevice(g->ctx[(size_t)i]->device);
+                    const hipError_t e = hipDeviceEnablePeerAccess(g->ctx[(size_t)j]->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                    (void)hipGetLastError();
+                }
+        }
+        if (!ok) { g->transport = kTransportSendRecv; g->transport_note = "no peer access between the group's devices"; return 0; }
+        for (int i = 0; i < n_local; ++i) {
+            void* tab[cph::kWorldSlots] = {nullptr};
+            for (int r = 0; r < world; ++r) tab[r] = g->ctx[(size_t)r]->d_xrecv;
+            if (int rc = cpprob_hip_exchange_direct(g->ctx[(size_t)i], tab)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)i]));
+        }
+        g->transport = kTransportDirect;
+        return 0;
+    }
+    // one rank per process: map the peers' receive buffers through hipIpc handles
+    cpprob_hip_ctx* c = g->ctx[0];
+    HIP_TRY(c, hipSetDevice(c->device));
+    struct Rec { hipIpcMemHandle_t h; int32_t ok; int32_t pad; };
+    Rec mine{};
+    mine.ok = hipIpcGetMemHandle(&mine.h, c->d_xrecv) == hipSuccess ? 1 : 0;
+    (void)hipGetLastError();
+    std::vector<Rec> all((size_t)world);
+    if (int rc = coll_allgather_host(g, 0, &mine, all.data(), sizeof(Rec))) return rc;
+    bool ok = true;
+    for (int r = 0; r < world; ++r) ok = ok && all[(size_t)r].ok;
+    void* tab[cph::kWorldSlots] = {nullptr};
+    int32_t opened = 1;
+    if (ok) {
+        for (int r : c->x_peers) {
+            if (r == g->first_rank) { tab[r] = c->d_xrecv; continue; }          // (diagnostic self-peer)
+            void* ptr = nullptr;
+            if (hipIpcOpenMemHandle(&ptr, all[(size_t)r].h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { opened = 0; (void)hipGetLastError(); break; }
+            g->ipc_open.push_back(ptr);
+            tab[r] = ptr;
+        }
+    }
+    // every rank must have mapped every peer, or nobody uses the mappings
+    std::vector<int32_t> flags((size_t)world);
+    const int32_t my_flag = ok ? opened : 0;
+    if (int rc = coll_allgather_host(g, 0, &my_flag, flags.data(), sizeof(int32_t))) return rc;
+    for (int r = 0; r < world; ++r) ok = ok && flags[(size_t)r];
+    if (!ok) {
+        close_direct(g);
+        if (g->coll == kCollExternal) return gfail(g, CPPROB_HIP_EUNSUPPORTED, "external collectives need the direct transport, and a peer's receive buffer cannot be mapped (hipIpc)");
+        g->transport = kTransportSendRecv; g->transport_note = "hipIpc mapping of a peer's receive buffer failed";
+        return 0;
+    }
+    if (int rc = cpprob_hip_exchange_direct(c, tab)) return gfail(g, rc, cpprob_hip_last_error(c));
+    g->transport = kTransportDirect;
+    return 0;
+}
+
 int group_begin_contexts(cpprob_hip_group* g)
 {
     const int n_local = (int)g->ctx.size();
+    close_direct(g);                                     // (the peers' buffers may be reallocated below)
     for (int i = 0; i < n_local; ++i) {
         const int rank = g->first_rank + i;
         cpprob_hip_config c = g->cfg;
@@ -278,16 +453,18 @@ int group_begin_contexts(cpprob_hip_group* g)
         c.annex_kcols = g->annex_kcols;
         cpprob_hip_ctx* x = g->ctx[(size_t)i];
         if (int rc = cpprob_hip_infer_begin(x, &c, g->obs.data(), g->obs.size())) return gfail(g, rc, cpprob_hip_last_error(x));
-        if (g->exchange)
-            if (int rc = cpprob_hip_exchange_setup(x, g->world, rank, g->shard_begin.data(), g->all_peers, g->cap)) return gfail(g, rc, cpprob_hip_last_error(x));
+        if (g->exchange) {
+            const int peers_mode = (g->world == 1 && g->world1_collectives) ? 2 : g->all_peers;     // 2: this rank is its own peer (diagnostic)
+            if (int rc = cpprob_hip_exchange_setup(x, g->world, rank, g->shard_begin.data(), peers_mode, g->cap)) return gfail(g, rc, cpprob_hip_last_error(x));
+        }
     }
-    return 0;
+    return setup_direct(g);
 }
 
 int group_enqueue(cpprob_hip_group* g, uint64_t run_index)
 {
-    if (g->loopback) return loopback_run(g, run_index);
-    if (g->ctx.size() == 1) return rccl_run_rank(g, 0, run_index);
+    if (g->loopback()) return loopback_run(g, run_index);
+    if (g->ctx.size() == 1) return run_rank(g, 0, run_index);
     {
         std::lock_guard<std::mutex> lock(g->m);
         g->job_run = run_index; g->job_pending = (int)g->ctx.size(); ++g->job_gen;
@@ -299,6 +476,20 @@ int group_enqueue(cpprob_hip_group* g, uint64_t run_index)
     for (size_t i = 0; i < g->ctx.size(); ++i)
         if (g->job_rc[i]) return gfail(g, g->job_rc[i], g->job_err[i]);
     return 0;
+}
+
+// bytes the transport put on the links in one run (host-side bookkeeping: the sizes of the send/recv transport are host constants)
+double sendrecv_wire_bytes(const cpprob_hip_group* g)
+{
+    double total = 0.0;
+    const double bpv = (double)g->ctx[0]->ssz;
+    for (int r = 0; r < g->world; ++r) {
+        int np = 0;
+        for (int q = 0; q < g->world; ++q) if (q != r && (g->all_peers || q == r - 1 || q == r + 1)) ++np;
+        if (g->world == 1 && g->world1_collectives) np = 1;
+        for (int t = 0; t + 1 < g->T; ++t) total += (double)np * (double)g->cap * (double)(t + 1) * bpv;
+    }
+    return total;
 }
 
 }  // namespace
@@ -318,19 +509,22 @@ int cpprob_hip_group_unique_id(void* out, size_t n_bytes)
     return 0;
 }
 
-int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t world, int32_t first_rank, const void* unique_id, cpprob_hip_group** out)
+static int group_create_impl(const int32_t* devices, int32_t n_local, int32_t world, int32_t first_rank, const void* unique_id,
+                             const cpprob_hip_collectives* ext, cpprob_hip_group** out)
 {
     if (!out || !devices) return fail(nullptr, CPPROB_HIP_EINVAL, "NULL argument");
     *out = nullptr;
     if (n_local < 1 || world < n_local || world > cph::kMaxWorld || first_rank < 0 || first_rank + n_local > world)
         return fail(nullptr, CPPROB_HIP_EINVAL, "need 1 <= n_local <= world <= 63 and first_rank + n_local <= world");
-    if (world > n_local && (n_local != 1 || !unique_id)) return fail(nullptr, CPPROB_HIP_EINVAL, "ranks in other processes: one GPU per process and the group's unique id");
+    if (!ext && world > n_local && (n_local != 1 || !unique_id)) return fail(nullptr, CPPROB_HIP_EINVAL, "ranks in other processes: one GPU per process and the group's unique id");
+    if (ext && (n_local != 1 || !ext->allgather)) return fail(nullptr, CPPROB_HIP_EINVAL, "external collectives: one rank per group handle and an all-gather callback");
     cpprob_hip_group* g = new cpprob_hip_group();
     g->world = world; g->first_rank = first_rank;
     bool same = n_local > 1;
     for (int i = 1; i < n_local; ++i) same = same && devices[i] == devices[0];
-    g->loopback = same && world == n_local;
-    if (!g->loopback && world == n_local)
+    g->coll = ext ? kCollExternal : ((same && world == n_local) ? kCollLoopback : kCollRccl);
+    if (ext) g->ext = *ext;
+    if (g->coll == kCollRccl && world == n_local)
         for (int i = 0; i < n_local; ++i)
             for (int j = 0; j < i; ++j)
                 if (devices[i] == devices[j]) { delete g; return fail(nullptr, CPPROB_HIP_EINVAL, "a device may appear once (RCCL) or every rank sits on the same device (loopback)"); }
@@ -340,11 +534,11 @@ int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t wor
         if (int rc = cpprob_hip_create(devices[i], &c)) { g->err = g_last_error; return bail(rc); }
         g->ctx.push_back(c);
     }
-    if (g->loopback) {
+    if (g->loopback()) {
         // one stream for every rank: program order is the only synchronisation the loopback collectives need
         for (auto* c : g->ctx) g->own_stream.push_back(c->stream);
         for (auto* c : g->ctx) c->stream = g->ctx[0]->stream;
-    } else {
+    } else if (g->coll == kCollRccl) {
         std::string err;
         g->rccl = rccl_api(err);
         if (!g->rccl) { g->err = err; return bail(CPPROB_HIP_EDEVICE); }
@@ -365,6 +559,17 @@ int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t wor
     return 0;
 }
 
+int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t world, int32_t first_rank, const void* unique_id, cpprob_hip_group** out)
+{
+    return group_create_impl(devices, n_local, world, first_rank, unique_id, nullptr, out);
+}
+
+int cpprob_hip_group_create_external(int32_t device, int32_t world, int32_t rank, const cpprob_hip_collectives* collectives, cpprob_hip_group** out)
+{
+    if (!collectives) return fail(nullptr, CPPROB_HIP_EINVAL, "NULL argument");
+    return group_create_impl(&device, 1, world, rank, nullptr, collectives, out);
+}
+
 void cpprob_hip_group_destroy(cpprob_hip_group* g)
 {
     if (!g) return;
@@ -377,12 +582,13 @@ void cpprob_hip_group_destroy(cpprob_hip_group* g)
         (void)hipSetDevice(g->ctx[i]->device);
         (void)hipStreamSynchronize(g->ctx[i]->stream);
     }
+    close_direct(g);
     for (size_t i = 0; i < g->comm.size(); ++i)
         if (g->comm[i]) (void)g->rccl->CommDestroy(g->comm[i]);
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         (void)hipSetDevice(g->ctx[i]->device);
-        if (i < g->d_local.size()) { (void)hipFree(g->d_local[i]); (void)hipFree(g->d_all[i]); (void)hipFree(g->d_joint[i]); }
-        if (g->loopback && i < g->own_stream.size()) g->ctx[i]->stream = g->own_stream[i];
+        if (i < g->d_local.size()) { (void)hipFree(g->d_local[i]); (void)hipFree(g->d_all[i]); (void)hipFree(g->d_joint[i]); (void)hipFree(g->d_bar[i]); }
+        if (g->loopback() && i < g->own_stream.size()) g->ctx[i]->stream = g->own_stream[i];
     }
     if (g->d_ptr_locals) { (void)hipFree((void*)g->d_ptr_locals); (void)hipFree((void*)g->d_ptr_alls); (void)hipFree((void*)g->d_ptr_joints); }
     for (auto* c : g->ctx) cpprob_hip_destroy(c);
@@ -417,22 +623,26 @@ int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, co
     g->annex_kcols = 0;
     if (g->user_cap) g->cap = g->user_cap;                // cpprob_hip_group_transport
     if (g->user_all_peers >= 0) g->all_peers = g->user_all_peers;
+    g->world1_collectives = (g->user_flags & CPPROB_HIP_GROUP_WORLD1_COLLECTIVES) && g->world == 1 && !g->loopback();
+    const int n_local = (int)g->ctx.size();
+    if (g->d_local.empty()) { g->d_local.assign((size_t)n_local, nullptr); g->d_all.assign((size_t)n_local, nullptr); g->d_joint.assign((size_t)n_local, nullptr); g->d_bar.assign((size_t)n_local, nullptr); }
     if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
     g->T = g->ctx[0]->T; g->K = g->ctx[0]->K; g->n_stats = g->T * g->K;
-    const int n_local = (int)g->ctx.size();
-    if (g->d_local.empty()) { g->d_local.assign((size_t)n_local, nullptr); g->d_all.assign((size_t)n_local, nullptr); g->d_joint.assign((size_t)n_local, nullptr); }
     for (int i = 0; i < n_local; ++i) {
         cpprob_hip_ctx* c = g->ctx[(size_t)i];
         GHIP_TRY(g, hipSetDevice(c->device));
-        if (g->d_local[(size_t)i]) { (void)hipFree(g->d_local[(size_t)i]); (void)hipFree(g->d_all[(size_t)i]); (void)hipFree(g->d_joint[(size_t)i]); }
+        if (g->d_local[(size_t)i]) { (void)hipFree(g->d_local[(size_t)i]); (void)hipFree(g->d_all[(size_t)i]); (void)hipFree(g->d_joint[(size_t)i]); (void)hipFree(g->d_bar[(size_t)i]); }
+        const size_t nj = (size_t)g->n_stats + kJointExtra;
         GHIP_TRY(g, hipMalloc(&g->d_local[(size_t)i], 4 * sizeof(double)));
         GHIP_TRY(g, hipMalloc(&g->d_all[(size_t)i], 3 * (size_t)g->world * sizeof(double)));
-        GHIP_TRY(g, hipMalloc(&g->d_joint[(size_t)i], ((size_t)g->n_stats + 1) * sizeof(double)));
+        GHIP_TRY(g, hipMalloc(&g->d_joint[(size_t)i], nj * sizeof(double)));
+        GHIP_TRY(g, hipMalloc(&g->d_bar[(size_t)i], ((size_t)g->world + 1) * sizeof(double)));
         GHIP_TRY(g, hipMemset(g->d_local[(size_t)i], 0, 4 * sizeof(double)));
         GHIP_TRY(g, hipMemset(g->d_all[(size_t)i], 0, 3 * (size_t)g->world * sizeof(double)));
-        GHIP_TRY(g, hipMemset(g->d_joint[(size_t)i], 0, ((size_t)g->n_stats + 1) * sizeof(double)));
+        GHIP_TRY(g, hipMemset(g->d_joint[(size_t)i], 0, nj * sizeof(double)));
+        GHIP_TRY(g, hipMemset(g->d_bar[(size_t)i], 0, ((size_t)g->world + 1) * sizeof(double)));
     }
-    if (g->loopback) {
+    if (g->loopback()) {
         GHIP_TRY(g, hipSetDevice(g->ctx[0]->device));
         if (g->d_ptr_locals) { (void)hipFree((void*)g->d_ptr_locals); (void)hipFree((void*)g->d_ptr_alls); (void)hipFree((void*)g->d_ptr_joints); }
         void *pl = nullptr, *pa = nullptr, *pj = nullptr;
@@ -451,10 +661,10 @@ int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, co
     return 0;
 }
 
-int cpprob_hip_group_transport(cpprob_hip_group* g, uint64_t records_per_peer, int32_t all_peers)
+int cpprob_hip_group_transport(cpprob_hip_group* g, uint64_t records_per_peer, int32_t all_peers, uint32_t flags)
 {
     if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
-    g->user_cap = records_per_peer; g->user_all_peers = all_peers < 0 ? -1 : (all_peers ? 1 : 0);
+    g->user_cap = records_per_peer; g->user_all_peers = all_peers < 0 ? -1 : (all_peers ? 1 : 0); g->user_flags = flags;
     return 0;
 }
 
@@ -494,7 +704,7 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
     if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
     if (!g->ran) return gkeep(g, gfail(g, CPPROB_HIP_ESTATE, "no finished run"));
     if (h_stats && n_doubles < (size_t)g->n_stats) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "h_stats too small"));
-    std::vector<double> joint((size_t)g->n_stats + 1);
+    std::vector<double> joint((size_t)g->n_stats + kJointExtra);
     for (int attempt = 0;; ++attempt) {
         if (int rc = cpprob_hip_group_sync(g)) return gkeep(g, rc);
         cpprob_hip_ctx* c = g->ctx[0];
@@ -521,6 +731,17 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
         if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
     }
     if (h_reruns) *h_reruns = g->reruns;
+    g->traffic.records = (uint64_t)joint[(size_t)g->n_stats + 1];
+    g->traffic.payload_bytes = (uint64_t)joint[(size_t)g->n_stats + 2];
+    g->traffic.transport = g->transport;
+    const bool talk = g->world > 1 || g->world1_collectives;
+    const double steps = (g->cfg.algorithm == CPPROB_HIP_ALG_SIS) ? 1.0 : (double)g->T;
+    g->traffic.collective_bytes = talk ? (uint64_t)((double)g->world * (double)g->world * (3.0 * 8.0 * steps + ((double)g->n_stats + kJointExtra) * 8.0)) : 0;
+    if (g->transport == kTransportDirect) {
+        g->traffic.wire_bytes = g->traffic.payload_bytes;
+        if (talk && !g->loopback()) g->traffic.collective_bytes += (uint64_t)((double)g->world * (double)g->world * 8.0 * std::max(0.0, steps - 1.0));   // the ordering all-gather
+    } else if (g->transport == kTransportSendRecv) g->traffic.wire_bytes = (uint64_t)sendrecv_wire_bytes(g);
+    else g->traffic.wire_bytes = 0;
     cpprob_hip_summary s{};
     if (int rc = cpprob_hip_infer_summary(g->ctx[0], &s)) return gkeep(g, gfail(g, rc, cpprob_hip_last_error(g->ctx[0])));
     if (out) *out = s;
@@ -536,6 +757,14 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
             }
         }
     }
+    return 0;
+}
+
+int cpprob_hip_group_traffic(cpprob_hip_group* g, cpprob_hip_traffic* out)
+{
+    if (!g || !out) return fail(nullptr, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!g->ran) return gkeep(g, gfail(g, CPPROB_HIP_ESTATE, "no finished run"));
+    *out = g->traffic;
     return 0;
 }
 

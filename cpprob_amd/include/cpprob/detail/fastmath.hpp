@@ -7,9 +7,12 @@
 //   log01(u)       u in [2^-53, 1]            (Box-Muller radius; fdlibm's e_log.c reduction and minimax polynomial)
 //   sincospi02(w)  w in (0, 2]                (Box-Muller angle;  quadrant reduction + minimax polynomials on [-1/4, 1/4])
 //   exp_nonpos(x)  x in [-745, ~0]            (linear weights exp(logw - reference); Cody-Waite reduction + minimax polynomial)
-// Error of each (against 300-bit references, emulating the fp64 operations exactly; tools/fit_math.py regenerates the
-// coefficients and the error figures): log01 < 0.67 ulp, sincospi02 < 0.73 ulp, exp_nonpos < 0.66 ulp -- faithful rounding, as the
-// library's own; the parity tests compare draws with glibc-based values at 1e-12 relative (2 ulp = 4.4e-16).
+// Error of each in ulps of the result (against 300-bit references, emulating the fp64 operations exactly; tools/fit_math.py regenerates
+// the coefficients and the figures; tests/test_gpu_blocks.py::test_fastmath_* measures them on the device against 80-bit references):
+// log01 <= 0.67, exp_nonpos <= 0.66 (faithful rounding, as the library's own), sincospi02: sin <= 0.99, cos <= 1.03 -- the cosine's
+// worst case sits at |t| -> 1/4, where 1 + s Q(s) lands just above 1/2 with s Q = -0.29 (one ulp of the Box-Muller angle's cosine;
+// a compensated last step would cost two more vector instructions per variate in a kernel bound by vector issue).  The parity tests
+// compare draws with glibc-based values at 1e-12 relative (2 ulp = 4.4e-16).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>

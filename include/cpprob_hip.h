@@ -224,7 +224,8 @@ int cpprob_hip_exchange_commit(cpprob_hip_ctx* ctx, int32_t t, const void* d_rec
  * host constants, so the transport moves fixed-capacity segments and the plan lives on the device).
  *   setup      once after cpprob_hip_infer_begin: the shards' layout, the peer set -- all_peers = 0: the two neighbouring ranks (the
  *              offspring interval of a rank's sources leaves its shard by O(sqrt(n)) outputs: neighbours are all a well-mixed run
- *              needs), all_peers = 1: every rank -- and records_per_peer, the capacity of one peer segment;
+ *              needs), all_peers = 1: every rank (2, world = 1 only: the rank itself, a diagnostic that lets one GPU run the
+ *              transport) -- and records_per_peer, the capacity of one peer segment;
  *   transport  the context-owned buffers: peer slot s (peer rank h_peers[s]) owns records_per_peer * (t + 1) values of
  *              bytes_per_value bytes at byte offset s * records_per_peer * (t + 1) * bytes_per_value of d_send / d_recv
  *              during the exchange that follows step t;
@@ -239,42 +240,84 @@ int cpprob_hip_exchange_commit(cpprob_hip_ctx* ctx, int32_t t, const void* d_rec
 int cpprob_hip_exchange_setup(cpprob_hip_ctx* ctx, int32_t world, int32_t rank, const uint64_t* h_shard_begin, int32_t all_peers, uint64_t records_per_peer);
 int cpprob_hip_exchange_transport(cpprob_hip_ctx* ctx, void** d_send, void** d_recv, int32_t* n_peers, int32_t* h_peers, uint64_t* records_per_peer,
                                   uint64_t* bytes_per_value);
+/*   direct     (optional, after setup) h_peer_recv[world]: for every peer rank r, rank r's d_recv (cpprob_hip_exchange_transport) as
+ *              THIS context's device addresses it -- the same pointer when both contexts share a device, a peer-access pointer
+ *              inside one process, a hipIpcOpenMemHandle mapping across processes; NULL elsewhere.  pack_async then stores every
+ *              record straight into the receiver's slot for this rank and d_send is not used: the caller moves nothing, it only
+ *              orders the receiver's commit_async(t) behind the senders' pack_async(t) (any collective every rank enters after its
+ *              pack_async will do).  NULL switches back.  setup() resets it (the buffers may move).
+ *   traffic    after the run (synchronises): lineage records this rank sent after each step (h_sent_per_step[n_predict], may be NULL),
+ *              their total and their bytes -- records x (t + 1) x bytes_per_value: what the direct transport puts on the links. */
+int cpprob_hip_exchange_direct(cpprob_hip_ctx* ctx, void* const* h_peer_recv);
+int cpprob_hip_exchange_traffic(cpprob_hip_ctx* ctx, int64_t* h_sent_per_step, size_t n_steps, uint64_t* h_records, uint64_t* h_bytes);
 int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* ctx, int32_t t);
 int cpprob_hip_exchange_commit_async(cpprob_hip_ctx* ctx, int32_t t);
 int cpprob_hip_exchange_status(cpprob_hip_ctx* ctx, int32_t* h_overflow, uint64_t* h_annex_used);
 
 /* ---- one joint population over several GPUs, driven from the host side of this library ------------------------------------
- * A group = one context per GPU + a transport; cpprob_hip_group_run enqueues a WHOLE exchange-scope run on every local rank --
- * per step: propagate / weigh, all-gather of 3 doubles per rank, device-side plan, send / receive of the migrating lineages,
- * commit -- with no host synchronisation inside (cpprob_amd/csrc/group.hpp).  Replaces what a caller of the reference would have
- * to build around cpprob::inference to use more than one device (the reference is single-process, src/cpprob/state.cpp:20-21).
+ * A group = one context per GPU + collectives + a transport; cpprob_hip_group_run enqueues a WHOLE exchange-scope run on every local
+ * rank -- per step: propagate / weigh, all-gather of 3 doubles per rank, device-side plan, the migrating lineages, commit -- with no
+ * host synchronisation inside (cpprob_amd/csrc/group.hpp).  Replaces what a caller of the reference would have to build around
+ * cpprob::inference to use more than one device (the reference is single-process, src/cpprob/state.cpp:20-21).
  *   create   world == n_local: every rank in this process.  Distinct devices: RCCL over xGMI, one communicator and one host
- *            thread per GPU.  All devices equal: "loopback" -- every rank's context on that one device and one stream, copies
- *            instead of collectives (how a one-GPU machine exercises the protocol; RCCL refuses duplicate devices).
+ *            thread per GPU.  All devices equal: "loopback" -- every rank's context on that one device and one stream, program
+ *            order instead of collectives (how a one-GPU machine exercises the protocol; RCCL refuses duplicate devices).
  *            world > n_local: one rank (n_local = 1) of a group spread over processes; unique_id = the 128 bytes rank 0 got from
  *            cpprob_hip_group_unique_id and handed to every rank (the launcher's job: torchrun, MPI, a file).
+ *   create_external   one rank of a group whose collectives are the CALLER's (MPI, gloo, ...): allgather(user, h_in, h_out,
+ *            bytes_per_rank) gathers host bytes of every rank in rank order and returns 0; it is called from cpprob_hip_group_begin /
+ *            _run / _results, which synchronise the stream around it.  The lineages move by direct stores (below); nothing else is
+ *            asked of the caller.
+ *   transport (before begin) records_per_peer = capacity of one peer segment (0: the default, 8 sqrt(N) + 4096); all_peers = 1: every
+ *            rank is a peer, 0: the two neighbouring ranks, < 0: the default (neighbours); flags = CPPROB_HIP_GROUP_*.  Results never
+ *            depend on any of them; a run they prove too small for is repeated with larger ones (results).
+ *            How the lineages move: DIRECT -- the sending rank's packing kernel stores every record into the receiving rank's buffer
+ *            (peer access inside a process, hipIpc mappings between processes), ordered by a one-double all-gather per step, so that
+ *            what crosses xGMI is records x (t + 1) x value size and nothing on a step that does not resample -- wherever every rank
+ *            can map its peers' buffers; otherwise SENDRECV -- ncclSend / ncclRecv of the fixed-capacity segments.
  *   begin    cfg as for cpprob_hip_infer_begin with n_particles = the WHOLE population (particle_offset / n_global / scope are
  *            set per rank by the group); shards are contiguous and equal unless h_shard_sizes[world] names them.  Systematic SMC
- *            runs in the exchange scope (exact global resampling); other resamplers and SIS in the global scope.
- *   run      asynchronous; results synchronises, all-reduces and normalises: h_stats as cpprob_hip_infer_stats of ONE GPU holding
- *            the whole population would return.  If a transport segment or the annex overflowed, results repeats the last run
- *            with a larger transport first (h_reruns counts those since begin): the numbers never depend on the transport.
+ *            runs in the exchange scope (exact global resampling); other resamplers and SIS in the global scope.  COLLECTIVE.
+ *   run      asynchronous (RCCL / loopback).
+ *   results  COLLECTIVE: every rank of the group calls it.  Synchronises, all-reduces and normalises: h_stats as
+ *            cpprob_hip_infer_stats of ONE GPU holding the whole population would return.  If a transport segment or the annex
+ *            overflowed -- every rank sees the same all-reduced flags -- it first repeats the LAST run with a larger transport
+ *            (h_reruns counts those since begin): the numbers never depend on the transport.  Runs enqueued before the last one are
+ *            not repeated: a caller that pipelines runs should settle the transport with one run + results first.
+ *   traffic  of the run results last collected.
  *   context  the rank's context, e.g. for cpprob_hip_copy_paths of its shard. */
 typedef struct cpprob_hip_group cpprob_hip_group;
+typedef struct cpprob_hip_collectives {
+    void* user;
+    int (*allgather)(void* user, const void* h_in, void* h_out, size_t bytes_per_rank);
+} cpprob_hip_collectives;
+#define CPPROB_HIP_GROUP_SENDRECV 1u            /* never map peers' buffers: ncclSend / ncclRecv of fixed-capacity segments */
+#define CPPROB_HIP_GROUP_WORLD1_COLLECTIVES 2u  /* diagnostic, world = 1: issue every collective of the multi-GPU path anyway and exchange
+                                                   (zero records) with the rank itself, so that one GPU runs all of the transport's calls */
+#define CPPROB_HIP_TRANSPORT_NONE 0
+#define CPPROB_HIP_TRANSPORT_DIRECT 1
+#define CPPROB_HIP_TRANSPORT_SENDRECV 2
+typedef struct cpprob_hip_traffic {
+    uint64_t records;          /* lineage records that changed rank, all ranks, all steps of the run                           */
+    uint64_t payload_bytes;    /* sum over steps of records x (t + 1) x value size                                             */
+    uint64_t wire_bytes;       /* what the transport put on the links for them: = payload_bytes (direct), capacity (send/recv)  */
+    uint64_t collective_bytes; /* the small collectives: all-gathers of 3 doubles (+ 1 ordering the direct stores) per step, the final all-reduce */
+    int32_t transport;         /* CPPROB_HIP_TRANSPORT_*                                                                       */
+    int32_t reserved;
+} cpprob_hip_traffic;
 int cpprob_hip_group_unique_id(void* out128, size_t n_bytes);
 int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t world, int32_t first_rank, const void* unique_id, cpprob_hip_group** out);
+int cpprob_hip_group_create_external(int32_t device, int32_t world, int32_t rank, const cpprob_hip_collectives* collectives, cpprob_hip_group** out);
 void cpprob_hip_group_destroy(cpprob_hip_group* group);
 const char* cpprob_hip_group_last_error(const cpprob_hip_group* group);
+int cpprob_hip_group_transport(cpprob_hip_group* group, uint64_t records_per_peer, int32_t all_peers, uint32_t flags);
 int cpprob_hip_group_begin(cpprob_hip_group* group, const cpprob_hip_config* cfg, const double* h_observes, size_t n_observes, const uint64_t* h_shard_sizes);
-/* Transport parameters of the NEXT cpprob_hip_group_begin: records_per_peer = capacity of one peer segment (0: the default,
- * 8 sqrt(N) + 4096), all_peers = 1: every rank is a peer, 0: the two neighbouring ranks, < 0: the default (neighbours).  Results
- * never depend on them; a run they prove too small for is repeated with larger ones (cpprob_hip_group_results). */
-int cpprob_hip_group_transport(cpprob_hip_group* group, uint64_t records_per_peer, int32_t all_peers);
 int cpprob_hip_group_run(cpprob_hip_group* group, uint64_t run_index);
 int cpprob_hip_group_sync(cpprob_hip_group* group);
 int cpprob_hip_group_size(const cpprob_hip_group* group, int32_t* world, int32_t* n_local, int32_t* first_rank);
 cpprob_hip_ctx* cpprob_hip_group_context(cpprob_hip_group* group, int32_t local_index);
 int cpprob_hip_group_results(cpprob_hip_group* group, cpprob_hip_summary* out, double* h_stats, size_t n_doubles, int32_t* h_reruns);
+int cpprob_hip_group_traffic(cpprob_hip_group* group, cpprob_hip_traffic* out);
 
 /* ---- building blocks (also the unit-parity surface) --------------------------------------
  * All pointers are device pointers; n is the element count. */

@@ -187,7 +187,13 @@ def test_config5_whole_population_over_eight_ranks(engine, golden_dir):
     g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=7, ess_threshold=0.5)
     g.run()
     stats, s, reruns = g.results()
+    tr = g.traffic()
+    per = [g.context(r).exchange_traffic() for r in range(8)]
     g.close()
+    # bytes on the links = the records themselves (direct stores): sum over ranks and steps of records x (t + 1) x 1 byte
+    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["wire_bytes"] == tr["payload_bytes"] == sum(int((p[0] * (np.arange(128) + 1)).sum()) for p in per)
+    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] <= 2 * tr["records"] * 128
+    print("configs[4] traffic", tr)
     assert reruns <= 1 and 20 <= s["n_resampled"] <= 60
     assert np.abs(stats - z["hmm128_smooth"]).max() < 3e-3
     assert abs(s["log_evidence"] - float(z["hmm128_logz"])) < 5e-3
@@ -214,10 +220,116 @@ def test_config4_whole_population_over_eight_ranks(engine, golden_dir):
     g.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=7, ess_threshold=0.5)
     g.run()
     stats, s, reruns = g.results()
+    tr = g.traffic()
+    per = [g.context(r).exchange_traffic() for r in range(8)]
     g.close()
+    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["wire_bytes"] == tr["payload_bytes"] == sum(int((p[0] * (np.arange(100) + 1)).sum()) * 8 for p in per)
+    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] <= 2 * tr["records"] * 100 * 8
+    print("configs[3] traffic", tr)
     assert reruns <= 2
     # (smoothing by ancestral lines degenerates towards t = 0: the filtering-quality end is tight, the far end Monte-Carlo-limited)
     assert np.abs(stats[-1, 0] - z["lgssm100_smooth_mean"][-1]) < 5e-3 and np.abs(stats[-1, 1] - z["lgssm100_smooth_var"][-1]) < 5e-3
     assert np.abs(stats[:, 0] - z["lgssm100_smooth_mean"]).max() < 5e-2
     assert abs(s["log_evidence"] - float(z["lgssm100_logz"])) < 2e-2
 
+
+
+def _run_group(g, alg, model, obs, n, seed, ess, shards):
+    g.begin(alg, model, obs, n, seed=seed, ess_threshold=ess, shard_sizes=shards)
+    g.run()
+    stats, s, reruns = g.results()
+    return stats, s, reruns, g.traffic()
+
+
+@pytest.mark.parametrize("model,key,T,ess", [(cp.MODEL_HMM3, "hmm16", 16, 2.0), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 30, 0.5)])
+def test_group_direct_stores_move_records_not_capacity(engine, golden_dir, model, key, T, ess):
+    """The direct transport (the packing kernel stores each migrating lineage into the receiving rank's buffer) against the
+    send/recv transport (fixed-capacity segments): identical results, and the bytes on the links are the records themselves --
+    sum over steps of records x (t + 1) x value size, nothing where a step did not resample -- instead of peers x capacity."""
+    import torch  # noqa: F401
+    obs = _obs(golden_dir, key)[:T]
+    shards = [30000, 50001, 19999, 40000]
+    n = int(sum(shards))
+    vsz = 1 if model == cp.MODEL_HMM3 else 8
+    g = cp.Group([0] * len(shards))
+    stats, s, reruns, tr = _run_group(g, cp.ALG_SMC, model, obs, n, 21, ess, shards)
+    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and reruns == 0
+    per_rank = [g.context(r).exchange_traffic() for r in range(len(shards))]
+    _, resampled = g.context(0).step_trace()
+    records = sum(p[1] for p in per_rank)
+    payload = sum(int((p[0] * (np.arange(T) + 1)).sum()) * vsz for p in per_rank)
+    assert tr["records"] == records > 0 and tr["payload_bytes"] == payload == sum(p[2] for p in per_rank) == tr["wire_bytes"]
+    for p in per_rank:
+        assert np.all(p[0][:T - 1][resampled[:T - 1] == 0] == 0) and p[0][T - 1] == 0        # a step that does not resample sends nothing
+    g.close()
+    g2 = cp.Group([0] * len(shards))
+    g2.transport(flags=cp.capi.GROUP_SENDRECV)
+    stats2, s2, reruns2, tr2 = _run_group(g2, cp.ALG_SMC, model, obs, n, 21, ess, shards)
+    g2.close()
+    assert np.array_equal(stats, stats2) and s == s2 and reruns2 == 0
+    assert tr2["transport"] == cp.capi.TRANSPORT_SENDRECV and tr2["records"] == records and tr2["payload_bytes"] == payload
+    cap = (int(8.0 * np.sqrt(n)) // 1024) * 1024 + 4096
+    assert tr2["wire_bytes"] == (2 * len(shards) - 2) * min(cap, max(shards)) * vsz * (T - 1) * T // 2
+    assert tr["wire_bytes"] * 10 < tr2["wire_bytes"]
+
+
+@pytest.mark.parametrize("flags", [cp.capi.GROUP_WORLD1_COLLECTIVES, cp.capi.GROUP_WORLD1_COLLECTIVES | cp.capi.GROUP_SENDRECV])
+def test_group_of_one_rank_runs_every_rccl_call_of_the_multi_gpu_path(engine, golden_dir, flags):
+    """world = 1 over the real library: with CPPROB_HIP_GROUP_WORLD1_COLLECTIVES the rank is its own peer, so the per-step
+    ncclAllGather, the ordering all-gather of the direct transport -- or, with CPPROB_HIP_GROUP_SENDRECV, the grouped ncclSend /
+    ncclRecv of a whole segment to and from itself -- and the final ncclAllReduce all execute on this GPU; results are bit-identical
+    to the plain run, count form and floating-point form."""
+    import torch  # noqa: F401
+    for model, key, T, ess in ((cp.MODEL_HMM3, "hmm16", 16, 2.0), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 12, 0.5)):
+        obs = _obs(golden_dir, key)[:T]
+        n = 150000
+        ref_stats, ref_sum, _, _ = _single(engine, cp.ALG_SMC, model, obs, n, 4, ess)
+        g = cp.Group([0])
+        g.transport(flags=flags)
+        g.begin(cp.ALG_SMC, model, obs, n, seed=4, ess_threshold=ess)
+        for i in range(3):
+            g.run(i)
+        g.run(0)
+        stats, s, reruns = g.results()
+        tr = g.traffic()
+        g.close()
+        np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
+        assert s["log_evidence"] == ref_sum["log_evidence"] and reruns == 0
+        assert tr["transport"] == (cp.capi.TRANSPORT_SENDRECV if flags & cp.capi.GROUP_SENDRECV else cp.capi.TRANSPORT_DIRECT)
+        assert tr["records"] == 0 and tr["collective_bytes"] > 0
+        if flags & cp.capi.GROUP_SENDRECV:
+            assert tr["wire_bytes"] > 0          # the stale segment did travel (to itself)
+
+
+def test_group_world_limit_is_63_ranks(engine, golden_dir):
+    """The plan lives on one wavefront whose lane r holds the bound o_r, r = 0 .. world: 63 ranks are served, 64 refused."""
+    obs = _obs(golden_dir, "hmm16")[:6]
+    with pytest.raises(cp.CpprobHipError):
+        cp.Group([0] * 64)
+    world = 63
+    shards = [1500 + 7 * (r % 5) for r in range(world)]
+    n = int(sum(shards))
+    ref_stats, ref_sum, ref_paths, _ = _single(engine, cp.ALG_SMC, cp.MODEL_HMM3, obs, n, 17, 2.0)
+    g = cp.Group([0] * world)
+    g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=17, ess_threshold=2.0, shard_sizes=shards)
+    g.run()
+    stats, s, reruns = g.results()
+    paths = np.concatenate([_ctx_paths(g, r, shards[r], len(obs), True) for r in range(world)], axis=1)
+    g.close()
+    assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"]
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
+
+
+def test_group_over_two_processes_maps_the_peer_buffers_through_hipipc(golden_dir):
+    """One rank per PROCESS, both on this GPU, the caller's collectives (gloo through cpprob_hip_group_create_external): each
+    process maps the other's receive buffer with hipIpcOpenMemHandle and its packing kernel stores the migrating lineages there --
+    the transport of the one-process-per-GPU form (bench.py under torchrun), minus RCCL, which refuses two ranks on one device.
+    Bit-identical to one context holding all particles (count form) / within boundary flips (floating-point form)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "ext_group_worker.py"), os.path.join(golden_dir, "observations.npz")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "EXT_GROUP_OK" in p.stdout

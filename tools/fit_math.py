@@ -82,16 +82,21 @@ def cospi_core(t):
     r = Qd[6]
     for c in Qd[5::-1]: r = fma(r, s, c)
     return fma(r, s, 1.0)
+import math
 random.seed(1)
-ms = mc = 0
-for i in range(20000):
+ms = mc = us = uc = 0
+for i in range(60000):
     t = random.uniform(-0.25, 0.25)
+    if i % 5 == 0: t = math.copysign(0.25 - random.random()*1e-3, t)     # the interval's ends, where cos(pi t) sits just above a binade boundary
     a = sinpi_core(t); b = cospi_core(t)
     ra = mp.sin(mp.pi*mp.mpf(t)); rb = mp.cos(mp.pi*mp.mpf(t))
     ulp_a = abs(mp.mpf(a)-ra)/abs(ra)*2**53 if ra != 0 else 0
     ulp_b = abs(mp.mpf(b)-rb)/abs(rb)*2**53
     ms = max(ms, ulp_a); mc = max(mc, ulp_b)
+    if ra != 0: us = max(us, abs(mp.mpf(a)-ra)/mp.mpf(math.ulp(float(ra))))
+    uc = max(uc, abs(mp.mpf(b)-rb)/mp.mpf(math.ulp(float(rb))))
 print("sinpi max rel err (2^-53 units)", mp.nstr(ms, 4), " cospi", mp.nstr(mc, 4))
+print("sinpi max err in ulps of the result", mp.nstr(us, 4), " cospi", mp.nstr(uc, 4), " (cospi's worst sits at |t| -> 1/4: 1 + s Q(s) with s Q = -0.29)")
 
 # ---- exp(r) = 1 + r + r^2*E(r), |r| <= ln2/2
 def Ef(r):
