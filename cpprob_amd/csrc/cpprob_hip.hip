@@ -1242,6 +1242,13 @@ int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* c, int32_t t)
     // count form: the plan is a pure function of the all-gathered totals -- every packing workgroup derives it on its first wavefront
     // and workgroup 0 stores it (one launch less per step); floating-point form: the plan launch also combines the ranks' totals
     const bool plan_inside = c->counts_mode;
+    if (c->x_peers.empty()) {
+        // nobody to exchange with (a group of one): the count form's step derives everything it needs from the totals; the
+        // floating-point form's plan launch still combines the ranks' totals into ctrl
+        if (!plan_inside) { if (int rc = launch_plan(c, t, true)) return rc; HIP_TRY(c, hipGetLastError()); }
+        c->x_plan_t = t; c->plan.t = t;
+        return 0;
+    }
     if (!plan_inside) { if (int rc = launch_plan(c, t, true)) return rc; }
     else c->x_plan_t = t;
     // enough workgroups for a full segment per peer; those beyond the planned tiles leave at once
@@ -1256,6 +1263,7 @@ int cpprob_hip_exchange_commit_async(cpprob_hip_ctx* c, int32_t t)
 {
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
     if (!c->exchange || !c->x_fixed || c->x_plan_t != t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_pack_async(t) has not run");
+    if (c->x_peers.empty()) return 0;
     HIP_TRY(c, hipSetDevice(c->device));
     dispatch_model(c, [&](auto m) { using M = decltype(m); launch_commit<M, typename M::store_t>(c, t, static_cast<const typename M::store_t*>(c->d_xrecv), 256); });
     HIP_TRY(c, hipGetLastError());

@@ -266,9 +266,11 @@ int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
         if (int rc = cpprob_hip_smc_step_begin(c, t, run_index, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
         if (talk) { if (int rc = coll_allgather(g, i, g->d_local[(size_t)i], g->d_all[(size_t)i], 3)) return rc; }
         if (int rc = cpprob_hip_smc_step_end(c, t, talk ? g->d_all[(size_t)i] : g->d_local[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
-        if (g->exchange && t + 1 < g->T && talk) {
+        if (g->exchange && t + 1 < g->T) {
+            // (a context without peers plans at most: cpprob_hip_exchange_pack_async / _commit_async launch nothing for it)
             if (int rc = cpprob_hip_exchange_pack_async(c, t)) return gfail(g, rc, cpprob_hip_last_error(c));
-            if (g->transport == kTransportDirect) {
+            if (!talk) {}
+            else if (g->transport == kTransportDirect) {
                 // the records are already where they belong; what remains is the order: no rank may commit before every rank's
                 // packing kernel has completed, and a rank contributes to this all-gather only behind its own packing kernel
                 if (int rc = coll_allgather(g, i, g->d_bar[(size_t)i], g->d_bar[(size_t)i] + 1, 1)) return rc;

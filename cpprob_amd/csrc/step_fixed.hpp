@@ -1,0 +1,594 @@
+// SMC step on FIXED-POINT weights: continuous-weight models and ESS-triggered schedules, systematic resampling.
+//
+// What step_counts.hpp does for table weights, for any weight: the linear weight of particle i of generation t is the INTEGER
+//        q_i = min(rint(exp(lw_i - R_t) * 2^32), 2^32 - 1),
+// taken against a reference R_t >= max_i lw_i that every workgroup knows before it has seen a single weight:
+//        R_t = B_t                   when every particle enters step t at log-weight 0 (t = 0, or step t-1 resampled),
+//        R_t = M_{t-1} + B_t         otherwise (weights carried),
+// B_t = the host-known upper bound of the step's incremental log-weight (the Gaussian emission's density at its mode; the
+// largest table value), M_{t-1} = the exact maximum of generation t-1's log-weights (a maximum is order-free).  Sums of integers
+// are exact in any order, so
+//        the inclusive CDF  C_k = sum_{i <= k} q_i                                   (exact, 64-bit),
+//        the first output   G_k = ceil(fma(double(C_k), N / double(C_N), -u0)),      ancestor of output j = min{k : G_k > j},
+//        the normaliser     W = C_N * 2^-32,   ESS = (C_N * 2^-16)^2 / sum_i (q_i >> 16)^2   (the sum of squares on 16-bit weights:
+//                                                                                             exact in 64 bits up to 2^28 particles)
+// are the same integers however tiles, wavefronts and shards are laid out: the resampling decision, every ancestor and the
+// evidence of a sharded run equal the single-GPU run's bit for bit, and no workgroup has to re-derive a floating-point CDF from
+// every tile partial (kernels.hpp: the fused prologue) or wait for a normalisation launch (scan_partials_kernel).  The CPU
+// restatement (oracle/cpprob_oracle.c: orc_resample_fixed_systematic) states the same arithmetic.
+//
+// The prefix masses live in the 64-ary hierarchy of step_counts.hpp (same layout, same rotation of three copies): the word of a
+// tile / block is its mass S (levels >= 1: | arrivals << 56), and the line of a block also holds Q = sum (q >> 16)^2 and the
+// order key of M = max lw (atomic add / add / max: all order-free); tiles keep their Q and M in two arrays beside level 0.
+// Resolution: weights below 2^-33 of the reference are zero -- 23 nats under the heaviest admissible particle.
+#pragma once
+#include "step_counts.hpp"
+
+namespace cph {
+
+constexpr double kFixScale = 4294967296.0;                  // 2^32
+constexpr double kFixInv = 1.0 / 4294967296.0;
+constexpr uint64_t kMassMask = (1ull << 56) - 1;
+
+// ---- 64-bit wavefront sums / scans / maxima -----------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t read_lane_u64(uint64_t v, int lane)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
+{
+    v += dpp_u64<kDppRowShr1>(v);
+    v += dpp_u64<kDppRowShr2>(v);
+    v += dpp_u64<kDppRowShr4>(v);
+    v += dpp_u64<kDppRowShr8>(v);
+    v += dpp_u64<kDppRowBcast15, 0xA>(v);
+    v += dpp_u64<kDppRowBcast31, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return read_lane_u64(wave_incl_scan_u64(v), kWave - 1); }
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
+{
+    v = umax64(v, dpp_u64<kDppRowShr1>(v));
+    v = umax64(v, dpp_u64<kDppRowShr2>(v));
+    v = umax64(v, dpp_u64<kDppRowShr4>(v));
+    v = umax64(v, dpp_u64<kDppRowShr8>(v));
+    v = umax64(v, dpp_u64<kDppRowBcast15, 0xA>(v));
+    v = umax64(v, dpp_u64<kDppRowBcast31, 0xC>(v));
+    return read_lane_u64(v, kWave - 1);
+}
+
+// order-preserving key of a double (an unsigned maximum of keys is the maximum of the doubles; 0 lies below every key: "empty")
+__host__ __device__ __forceinline__ uint64_t dkey(double x)
+{
+    union { double d; uint64_t u; } c; c.d = x;
+    return (c.u >> 63) ? ~c.u : (c.u | (1ull << 63));
+}
+__host__ __device__ __forceinline__ double dkey_inv(uint64_t k)
+{
+    if (k == 0) return -INFINITY;
+    union { double d; uint64_t u; } c;
+    c.u = (k >> 63) ? (k & ~(1ull << 63)) : ~k;
+    return c.d;
+}
+// an exact integer below 2^64 as the nearest double (one rounding: what a C cast does)
+__device__ __forceinline__ double u64_to_double(uint64_t c) { return fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c); }
+
+// the weight as an integer (see the header of this file); lw <= ref, or -inf (padding slots): 0
+__device__ __forceinline__ uint32_t fix_weight(double lw, double ref)
+{
+    const double e = exp_nonpos(fmax(lw - ref, -1000.0));
+    const double s = rint(e * kFixScale);
+    return s >= 4294967295.0 ? 0xffffffffu : (uint32_t)s;
+}
+
+// ---- the hierarchy's fixed-point view ------------------------------------------------------------------------------------------
+struct FHier {
+    Hier h;                                    // the S words: laid out, rotated and searched like the count hierarchy
+    const uint64_t* q0; const uint64_t* m0;    // tiles' Q and M keys of the copy read (the copy written sits h.to_next words further)
+};
+struct FTotWords { uint64_t s, q, m; };
+struct FTot { uint64_t S, Q; double M; };      // a generation's totals: mass, sum of squared 16-bit weights, largest log-weight
+
+__device__ __forceinline__ void ftot_fetch(const FHier& f, FTotWords& w)
+{
+    const int lane = lane_id();
+    const int64_t i = (int64_t)(lane < f.h.top_n ? lane : 0) * f.h.top_stride;
+    w.s = f.h.top[i];
+    w.q = f.h.n_lev == 1 ? f.q0[i] : f.h.top[i + 1];
+    w.m = f.h.n_lev == 1 ? f.m0[i] : f.h.top[i + 2];
+}
+__device__ __forceinline__ FTot ftot_sum(const FHier& f, FTotWords w)
+{
+    if (lane_id() >= f.h.top_n) { w.s = 0; w.q = 0; w.m = 0; }
+    FTot t;
+    t.S = wave_sum_u64(w.s & kMassMask); t.Q = wave_sum_u64(w.q); t.M = dkey_inv(wave_max_u64(w.m));
+    return t;
+}
+__device__ __forceinline__ FTot ftot(const FHier& f) { FTotWords w; ftot_fetch(f, w); return ftot_sum(f, w); }
+
+// exclusive prefix mass at tile c (wave-uniform; every lane of the calling wave takes part)
+__device__ __forceinline__ uint64_t fhier_prefix_sum(int c, const uint64_t (&w)[kHierMaxLevels])
+{
+    const int lane = lane_id();
+    uint64_t s = 0;
+#pragma unroll
+    for (int l = 0; l < kHierMaxLevels; ++l) s += lane < ((c >> (6 * l)) & 63) ? (w[l] & kMassMask) : 0ull;
+    return wave_sum_u64(s);
+}
+
+// The systematic comb on integer masses.  base = mass of the shards that precede this one (0 on one GPU).
+struct FixedCdf {
+    double inv, u0, n_pop; uint64_t base;
+    // first output owned by the sources that follow a LOCAL inclusive mass C
+    __device__ __forceinline__ double g(uint64_t C) const { return ceil(fma(u64_to_double(base + C), inv, -u0)); }
+};
+
+// This tile's words of generation t's hierarchy, added into the levels above, and the entries of the third copy this tile is
+// responsible for clearing.  One thread.  (step_counts.hpp: hier_publish -- here a block's line carries three words, and the last
+// tile of a block reads the two it did not get back from its own add.)
+__device__ __forceinline__ void fhier_publish(const FHier& f, int bid, int nb, uint64_t S, uint64_t Q, uint64_t mkey)
+{
+    const Hier& h = f.h;
+    uint64_t* l0 = const_cast<uint64_t*>(h.lvl[0]);
+    uint64_t* l1 = const_cast<uint64_t*>(h.lvl[1]);
+    uint64_t* l2 = const_cast<uint64_t*>(h.lvl[2]);
+    using ull = unsigned long long;
+    const int b1 = bid >> 6, b2 = bid >> 12;
+    l0[h.to_next + bid] = S;
+    const_cast<uint64_t*>(f.q0)[h.to_next + bid] = Q;
+    const_cast<uint64_t*>(f.m0)[h.to_next + bid] = mkey;
+    if (h.n_lev == 2) {
+        ull* e = reinterpret_cast<ull*>(l1 + h.to_next + (int64_t)b1 * kHierStride);
+        atomicAdd(e, (ull)S); atomicAdd(e + 1, (ull)Q); atomicMax(e + 2, (ull)mkey);
+    } else if (h.n_lev == 3) {
+        ull* e = reinterpret_cast<ull*>(l1 + h.to_next + (int64_t)b1 * kHierStride);
+        atomicAdd(e + 1, (ull)Q); atomicMax(e + 2, (ull)mkey);
+        __threadfence();                                           // both have landed before this tile's arrival is counted
+        const ull old = atomicAdd(e, (ull)(S + (1ull << 56)));
+        const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
+        if ((int)(old >> 56) == tiles_in_block - 1) {
+            __threadfence();
+            const uint64_t totS = (old + S) & kMassMask;
+            const ull totQ = atomicAdd(e + 1, (ull)0), totM = atomicMax(e + 2, (ull)0);       // (read where the adds were performed)
+            ull* e2 = reinterpret_cast<ull*>(l2 + h.to_next + (int64_t)b2 * kHierStride);
+            atomicAdd(e2, (ull)totS); atomicAdd(e2 + 1, totQ); atomicMax(e2 + 2, totM);
+        }
+    }
+    if (h.n_lev >= 2 && (b1 << 6) == bid) { uint64_t* e = l1 + h.to_clear + (int64_t)b1 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; }
+    if (h.n_lev >= 3 && (b2 << 12) == bid) { uint64_t* e = l2 + h.to_clear + (int64_t)b2 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; }
+}
+
+// Largest tile c in [0, nb) whose first owned output G(prefix(c)) is <= g (0 when there is none), with its exclusive prefix mass:
+// top-down descent, one load + one scan per level (step_counts.hpp: hier_locate).
+__device__ __forceinline__ int fhier_locate(const HierTable* __restrict__ ht, int copy, const FixedCdf& fc, double g, uint64_t& P)
+{
+    const int lane = lane_id();
+    int blk = 0;
+    uint64_t p = 0;
+    for (int l = ht->n_lev - 1; l >= 0; --l) {
+        const int idx = (blk << 6) + lane;
+        uint64_t w = 0;
+        const bool in = idx < ht->n_ent[l];
+        if (in) w = ht->lvl[copy][l][(int64_t)idx * (l == 0 ? 1 : kHierStride)] & kMassMask;
+        const uint64_t incl = wave_incl_scan_u64(w);
+        const uint64_t x = p + incl - w;                                                       // exclusive prefix at child `lane`
+        const bool ok = in && fc.g(x) <= g;
+        const unsigned long long m = __ballot(ok);
+        const int child = m ? (63 - __builtin_clzll(m)) : 0;                                     // (G is monotone: the set is a prefix)
+        p = read_lane_u64(x, child);
+        blk = (blk << 6) + child;
+    }
+    P = p;
+    return blk;
+}
+
+struct FLocated { int c, c_last; uint64_t P; };
+
+// The SEARCH (one wavefront): first source tile of the output tile that starts at global output gj_first, its exclusive prefix
+// mass, and the last source tile (nb when the probe cannot tell).  As counts_locate.
+__device__ __forceinline__ FLocated fixed_locate(const FHier& f, const FixedCdf& fc, int nb, double gj_first, int n_out, int guess, const ProbeWords* first)
+{
+    const int lane = lane_id();
+    const double gj_last = gj_first + (double)(n_out - 1);
+    int c = 0, c_last = nb;
+    uint64_t P = 0;
+    auto probe = [&](int at, const ProbeWords& pw, double& d_out) -> bool {
+        const int cs = at > 0 ? at - 1 : 0;
+        const uint64_t Pc = fhier_prefix_sum(cs, pw.lvl);
+        const uint64_t we = (lane < 4 && cs + lane < nb) ? (pw.we & kMassMask) : 0ull;
+        const uint64_t incl = wave_incl_scan_u64(we);
+        const uint64_t x = Pc + incl - we;                               // lanes 0..4: the prefix at cs + lane
+        const double gt = fc.g(x);
+        const bool known = lane < 5 && cs + lane < nb;
+        const unsigned long long m = __ballot(known && gt <= gj_first);
+        const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
+        d_out = gj_first - read_lane(gt, 0);
+        if ((i_lo >= 0 || cs == 0) && i_lo < 4) {
+            const int i = i_lo < 0 ? 0 : i_lo;
+            c = cs + i;
+            P = read_lane_u64(x, i);
+            const unsigned long long mh = __ballot(known && gt <= gj_last);
+            const int i_hi = mh ? (63 - __builtin_clzll(mh)) : i;
+            c_last = (i_hi >= 4 && cs + 5 < nb) ? nb : cs + (i_hi > i ? i_hi : i);
+            return true;
+        }
+        return false;
+    };
+    double d;
+    bool hit;
+    if (first) hit = probe(guess, *first, d);
+    else { ProbeWords pw; probe_fetch(f.h, guess, nb, pw); hit = probe(guess, pw, d); }
+    if (!hit) {
+        // tile masses are comparable, so the miss distance in outputs approximates the miss distance in tiles (x 1024): aim again,
+        // then descend from the top (weights so uneven that two local probes miss)
+        const double aim = (double)(guess > 0 ? guess - 1 : 0) + floor(d * (1.0 / kTile));
+        const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
+        ProbeWords pw;
+        probe_fetch(f.h, at, nb, pw);
+        if (!probe(at, pw, d)) { c = fhier_locate(f.h.table, f.h.copy, fc, gj_first, P); c_last = nb; }
+    }
+    return FLocated{c, c_last, P};
+}
+
+struct FixedLds {
+    int32_t slot[kTile];          // scatter slots of the output tile
+    uint64_t scan[2][kWaves];     // per-wave totals of the in-tile scan, double-buffered across source tiles
+    int iscr[kWaves];
+};
+
+// The WALK (the whole workgroup): every source tile that owns outputs of this tile rebuilds its prefix masses (one scan), each
+// source with a non-empty range writes its index into the slot of its FIRST output, one prefix-max hands every output its
+// ancestor; -1 where the ancestor belongs to a shard that precedes this one.  q_m1 / q_0 / q_p1 = the weights of tiles guess-1,
+// guess, guess+1 fetched by the caller (have = false: none were).  Slots must hold -1 and be visible on entry.
+using U4 = unsigned int __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fixed_walk(const FixedCdf& fc, const uint32_t* __restrict__ qprev, int64_t n, int nb, bool last_shard, double gj_first,
+                                           int n_out, const FLocated& loc, int guess, bool have, U4 q_m1, U4 q_0, U4 q_p1, int32_t (&anc)[kPPT], FixedLds& L)
+{
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const double gj_last = gj_first + (double)(n_out - 1);
+    int c = __builtin_amdgcn_readfirstlane(loc.c), c_last = __builtin_amdgcn_readfirstlane(loc.c_last);
+    uint64_t P = loc.P;
+    auto load_q = [&](int cc) -> U4 {
+        if (have && cc == guess) return q_0;
+        if (have && cc == guess - 1) return q_m1;
+        if (have && cc == guess + 1) return q_p1;
+        U4 z = {0u, 0u, 0u, 0u};
+        return cc < nb ? *reinterpret_cast<const U4*>(qprev + (int64_t)cc * kTile + (int64_t)tid * kPPT) : z;
+    };
+    auto place = [&](double g) -> int { return (int)fmin(fmax(g - gj_first, 0.0), (double)kTile); };      // exact: integers
+    U4 raw = load_q(c);
+    int it = 0;
+    while (c < nb && c <= c_last) {
+        // (wave-uniform values -- the branches are made scalar so that the barrier inside the loop sits in uniform control flow)
+        if (c_last >= nb && __builtin_amdgcn_readfirstlane(fc.g(P) > gj_last ? 1 : 0)) break;      // the last tile is not known from the probe
+        const U4 raw_next = c < c_last ? load_q(c + 1) : U4{0u, 0u, 0u, 0u};
+        const bool edge = c == nb - 1;
+        const int nvt = edge ? (int)(n - (int64_t)c * kTile) : kTile;   // valid particles of this tile (padding slots weigh 0)
+        const int vb = tid * kPPT;
+        uint64_t pre[kPPT];
+        uint64_t run = 0;
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) { run += (uint64_t)raw[k]; pre[k] = run; }
+        const uint64_t incl = wave_incl_scan_u64(run);
+        if (lane == kWave - 1) L.scan[it & 1][wv] = incl;
+        __syncthreads();
+        uint64_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { const uint64_t s = L.scan[it & 1][w]; if (w < wv) off += s; tot += s; }
+        const uint64_t excl = P + off + incl - run;                     // mass before this lane's first particle
+        const int src0 = c * kTile + vb;
+        const int p_all = (edge && last_shard) ? place(fc.n_pop) : 0;
+        int p_prev = place(fc.g(excl));
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            int p = place(fc.g(excl + pre[k]));
+            if (edge && last_shard && vb + k + 1 == nvt) p = p_all;      // the population's last source owns the rest
+            if (edge && vb + k + 1 > nvt) p = p_prev;                   // padding slots own nothing
+            if (p > p_prev) { L.slot[p_prev] = src0 + k; p_prev = p; }
+        }
+        P += tot;
+        ++it;
+        raw = raw_next;
+        ++c;
+    }
+    __syncthreads();
+    // inclusive prefix-max over the slots
+    int32_t v[kPPT];
+    load4(L.slot, (int64_t)tid * kPPT, v);
+    lane_prefix_max(v);
+    int32_t incl = wave_incl_max_i32(v[kPPT - 1]);
+    if (lane == kWave - 1) L.iscr[wv] = incl;
+    int32_t excl = dpp_or_i32<0x138 /* wave_shr:1 */>(incl, -1);
+    if (lane == 0) excl = -1;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+        if (w < wv) excl = max(excl, L.iscr[w]);
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) anc[k] = max(v[k], excl);
+}
+
+// Both parts in every wavefront (the exchange scope's packing, whose output tiles sit anywhere in the shard).
+__device__ __forceinline__ void ancestors_fixed(const FHier& f, const FixedCdf& fc, const uint32_t* __restrict__ qprev, int64_t n, int nb, bool last_shard,
+                                                double gj_first, int n_out, int guess, int32_t (&anc)[kPPT], FixedLds& L)
+{
+    const FLocated loc = fixed_locate(f, fc, nb, gj_first, n_out, guess, nullptr);
+    const U4 z = {0u, 0u, 0u, 0u};
+    fixed_walk(fc, qprev, n, nb, last_shard, gj_first, n_out, loc, guess, false, z, z, z, anc, L);
+}
+
+// What every rank derives from a generation's totals, identically: the decision, the comb, the next reference.
+struct FixedDecision { double W, Qd, ess, inv; bool resample; };
+__device__ __forceinline__ FixedDecision fixed_decide(uint64_t S, uint64_t Q, double n_pop, double ess_frac, bool may_resample)
+{
+    FixedDecision d;
+    const double Sd = u64_to_double(S);
+    d.W = Sd * kFixInv;                                      // sum of exp(lw - R)
+    d.Qd = u64_to_double(Q) * kFixInv;                        // sum of exp(2 (lw - R)) on 16-bit weights: (q >> 16)^2 = e^2 2^32
+    d.ess = d.W * d.W / d.Qd;                                 // thesis p.37
+    d.resample = may_resample && d.ess < ess_frac * n_pop;
+    d.inv = n_pop / Sd;
+    return d;
+}
+
+// all-gathered totals of the ranks: 3 words per rank {S, Q, key(M)} (they travel as 24 bytes, whatever the collective calls them)
+struct FixedRanks { uint64_t S, Q; double M; uint64_t before; };
+__device__ __forceinline__ FixedRanks fixed_ranks(const uint64_t* __restrict__ all, int world, int rank)
+{
+    const int lane = lane_id();
+    uint64_t s = 0, q = 0, m = 0;
+    if (lane < world) { s = all[3 * lane]; q = all[3 * lane + 1]; m = all[3 * lane + 2]; }
+    FixedRanks r;
+    r.S = wave_sum_u64(s); r.Q = wave_sum_u64(q); r.M = dkey_inv(wave_max_u64(m)); r.before = wave_sum_u64(lane < rank ? s : 0ull);
+    return r;
+}
+
+struct FixedFound { FLocated loc; double inv, ref; uint64_t base; int64_t l0, l1; int resample; };     // the searching wavefront's hand-over
+
+template <class Model>
+struct StepFixedArgs {
+    ModelParams mp; const double* obs; int t, T; int64_t n, ld, rs;
+    uint64_t seed, pid0;
+    typename Model::store_t* values; int32_t* anc;
+    FHier f;                                   // generation t-1's masses (read); generation t's are written one copy further
+    const uint32_t* q_prev; uint32_t* q_next;  // [ld] integer weights, ping-pong
+    const double* logw_prev; double* logw_next;
+    double u0;                                 // systematic offset of the resampling before step t (Philox, evaluated on the host)
+    double bound_prev, bound;                  // B_{t-1}, B_t
+    double ess_frac; int may_carry;            // may_carry = 0: every step resamples (known on the host): no log-weight ever carries
+    StepCtrl* ctrl; double n_pop; double* ess_trace; int32_t* resampled;
+    const uint64_t* all_totals; int world, rank;       // one shard of a joint population (exchange scope): every rank's {S, Q, key(M)} of generation t-1
+    const int64_t* annex_base;
+    int row_w, row_r;
+};
+
+// Reference of generation t from what is known before it exists.
+__device__ __forceinline__ double fixed_reference(bool fresh, double m_prev, double bound) { return fresh ? bound : m_prev + bound; }
+
+// Bookkeeping of generation t-1 for the host (one thread): ESS, decision, evidence.  ref_prev = R_{t-1}.
+__device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const FixedDecision& d, double ref_prev, double n_pop, double u0, double* ess_trace,
+                                               int32_t* resampled, bool last)
+{
+    c->M = ref_prev; c->W = d.W; c->Q = d.Qd; c->ess = d.ess; c->do_resample = d.resample ? 1 : 0;
+    c->cdf_lo = 0.0; c->w_local = d.W; c->scale = 1.0; c->u0 = u0; c->inv_stepw = d.inv * kFixScale; c->lw_after = 0.0; c->inv_global = d.inv * kFixScale;
+    double lz = (t_prev == 0) ? 0.0 : c->log_z;
+    int nr = (t_prev == 0) ? 0 : c->n_resampled;
+    if (d.resample || last) lz += ref_prev + log(d.W / n_pop);
+    if (d.resample) nr += 1;
+    c->log_z = lz; c->n_resampled = nr;
+    if (ess_trace) ess_trace[t_prev] = d.ess;
+    if (resampled) resampled[t_prev] = d.resample ? 1 : 0;
+}
+
+template <class Model, bool SHARDED>
+__global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<Model> a)
+{
+    using V = typename Model::value_t;
+    using S = typename Model::store_t;
+    __shared__ FixedLds L;
+    __shared__ __attribute__((aligned(16))) FixedFound s_found;
+    __shared__ uint64_t s_red[3 * kWaves];
+    const int tid = threadIdx.x;
+    const int nb = (int)gridDim.x;
+    const int bid = xcd_contiguous_tile((int)blockIdx.x, nb);
+    const int64_t j0 = (int64_t)bid * kTile + (int64_t)tid * kPPT;
+    const int t = a.t;
+    const bool searcher = wave_id() == 0;
+
+    // everything the prologue reads is addressed by the launch geometry: fetched here, in one round trip under the random draws
+    U4 q_0 = {0u, 0u, 0u, 0u}, q_m1 = q_0, q_p1 = q_0;
+    FTotWords tw{};
+    ProbeWords pw0{};
+    uint64_t rs_ = 0, rq_ = 0, rm_ = 0;
+    double lw_carry[kPPT];
+    lane_fill(lw_carry, 0.0);
+    if (t > 0) {
+        q_0 = *reinterpret_cast<const U4*>(a.q_prev + j0);
+        q_m1 = *reinterpret_cast<const U4*>(a.q_prev + (bid > 0 ? j0 - kTile : j0));
+        q_p1 = *reinterpret_cast<const U4*>(a.q_prev + (bid + 1 < nb ? j0 + kTile : j0));
+        if (a.may_carry) load4(a.logw_prev, j0, lw_carry);
+        if (searcher) {
+            ftot_fetch(a.f, tw);
+            probe_fetch(a.f.h, bid, nb, pw0);
+            if (SHARDED) { const int r = tid < a.world ? tid : 0; rs_ = a.all_totals[3 * r]; rq_ = a.all_totals[3 * r + 1]; rm_ = a.all_totals[3 * r + 2]; }
+        }
+    }
+    typename Model::Rand rnd[kPPT / 4];
+#pragma unroll
+    for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+
+    int32_t anc[kPPT];
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) anc[k] = (int32_t)(j0 + k);
+    bool resample = false;
+    double ref = a.bound;                                              // R_0 = B_0
+    if (t > 0) {
+        if (bid == 0) q_m1 = U4{0u, 0u, 0u, 0u};
+        if (bid + 1 >= nb) q_p1 = U4{0u, 0u, 0u, 0u};
+        {
+            int32_t neg[kPPT];
+            lane_fill(neg, (int32_t)-1);
+            store4(L.slot, (int64_t)tid * kPPT, neg);
+        }
+        const int64_t rem = a.n - (int64_t)bid * kTile;
+        const int n_out = rem < kTile ? (int)rem : kTile;
+        const double gj_first = SHARDED ? (double)(a.pid0 + (uint64_t)bid * kTile) : (double)((uint64_t)bid * kTile);
+        const bool last_shard = SHARDED ? a.rank + 1 == a.world : true;
+        FixedCdf fc;
+        fc.u0 = a.u0; fc.n_pop = a.n_pop; fc.base = 0; fc.inv = 0.0;
+        if (searcher) {
+            uint64_t St, Qt; double Mt; uint64_t before = 0;
+            const FTot own = ftot_sum(a.f, tw);
+            if (SHARDED) {
+                const int lane = tid;
+                if (lane >= a.world) { rs_ = 0; rq_ = 0; rm_ = 0; }
+                St = wave_sum_u64(rs_); Qt = wave_sum_u64(rq_); Mt = dkey_inv(wave_max_u64(rm_)); before = wave_sum_u64(lane < a.rank ? rs_ : 0ull);
+            } else { St = own.S; Qt = own.Q; Mt = own.M; }
+            const FixedDecision d = fixed_decide(St, Qt, a.n_pop, a.ess_frac, true);        // (generation t-1 is never the last one here)
+            fc.inv = d.inv; fc.base = before;
+            const double r_t = fixed_reference(d.resample, Mt, a.bound);
+            if (bid == 0 && tid == 0) {
+                StepCtrl* c = a.ctrl;
+                fixed_bookkeep(c, t - 1, d, c->ref_cur, a.n_pop, a.u0, a.ess_trace, a.resampled, false);
+                c->ref_cur = r_t;
+            }
+            FLocated loc{0, 0, 0};
+            int64_t l0 = 0, l1 = a.n;
+            if (d.resample) {
+                loc = fixed_locate(a.f, fc, nb, gj_first, n_out, bid, &pw0);
+                if (SHARDED) {
+                    // outputs below o_lo / at or beyond o_hi descend from other shards' sources
+                    const double o_lo = fc.g(0), o_hi = last_shard ? a.n_pop : fc.g(own.S);
+                    const double sb = (double)a.pid0;
+                    l0 = (int64_t)fmin(fmax(o_lo - sb, 0.0), (double)a.n); l1 = (int64_t)fmin(fmax(o_hi - sb, 0.0), (double)a.n);
+                }
+            }
+            if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.ref = r_t; s_found.base = before; s_found.l0 = l0; s_found.l1 = l1; s_found.resample = d.resample ? 1 : 0; }
+        }
+        __syncthreads();                                               // slots reset, search results in place
+        resample = s_found.resample != 0;
+        ref = s_found.ref;
+        if (resample) {
+            fc.inv = s_found.inv; fc.base = s_found.base;
+            fixed_walk(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, bid, true, q_m1, q_0, q_p1, anc, L);
+            if (SHARDED) {
+                const int64_t l0 = s_found.l0, l1 = s_found.l1;
+                const int64_t col0 = a.ld + a.annex_base[t - 1];
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) {
+                    const int64_t j = j0 + k;
+                    if (j < l0) anc[k] = (int32_t)(col0 + j);
+                    else if (j >= l1 && j < a.n) anc[k] = (int32_t)(col0 + l0 + (j - l1));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) anc[k] = max(anc[k], 0);   // padding outputs of the last tile
+            lane_fill(lw_carry, 0.0);                                   // equal weights after resampling
+        }
+    } else if (bid == 0 && tid == 0) {
+        a.ctrl->ref_cur = ref;
+    }
+
+    const S* prev_row = a.values + (int64_t)a.row_r * a.rs;
+    V prev[kPPT], x[kPPT];
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>(prev_row[anc[k]]) : V(0);                 // ancestor's state (sorted gather)
+#pragma unroll
+    for (int q = 0; q < kPPT / 4; ++q)                                                        // sample #t
+        Model::apply4(a.mp, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
+    store4_as(a.values + (int64_t)a.row_w * a.rs, j0, x);                                     // predict #t
+    if (a.anc) store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
+
+    // ---- observe #t: log-weights, integer weights, the tile's mass / squares / maximum ----
+    double lw[kPPT];
+    U4 q;
+    uint64_t s_l = 0, q_l = 0;
+    double m_l = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        lw[k] = lw_carry[k] + Model::loglik(a.mp, x[k], t, a.obs);
+        if (j0 + k >= a.n) lw[k] = -INFINITY;                                                  // padding slots
+        const uint32_t w = fix_weight(lw[k], ref);
+        q[k] = w;
+        s_l += w; q_l += (uint64_t)(w >> 16) * (uint64_t)(w >> 16);
+        m_l = fmax(m_l, lw[k]);
+    }
+    *reinterpret_cast<U4*>(a.q_next + j0) = q;
+    if (a.may_carry || t + 1 == a.T) store4(a.logw_next, j0, lw);
+    const uint64_t s_w = wave_sum_u64(s_l), q_w = wave_sum_u64(q_l), m_w = wave_max_u64(dkey(m_l));
+    if (lane_id() == 0) { s_red[wave_id()] = s_w; s_red[kWaves + wave_id()] = q_w; s_red[2 * kWaves + wave_id()] = m_w; }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t St = 0, Qt = 0, Mk = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { St += s_red[w]; Qt += s_red[kWaves + w]; Mk = umax64(Mk, s_red[2 * kWaves + w]); }
+        fhier_publish(a.f, bid, nb, St, Qt, Mk);
+    }
+}
+
+// ---- the run's last generation ------------------------------------------------------------------------------------------------
+struct FixedFinal {
+    FHier f;                     // the final generation's masses (the copy the last step wrote)
+    double n_pop, ess_frac; int T;
+    int bookkeep;
+    StepCtrl* ctrl; double* ess_trace; int32_t* resampled;
+};
+__device__ __forceinline__ void fixed_final_bookkeep(const FixedFinal& ff, uint64_t S, uint64_t Q)
+{
+    const FixedDecision d = fixed_decide(S, Q, ff.n_pop, ff.ess_frac, false);
+    fixed_bookkeep(ff.ctrl, ff.T - 1, d, ff.ctrl->ref_cur, ff.n_pop, 0.0, ff.ess_trace, ff.resampled, true);
+}
+// one shard of a joint population: from the all-gathered totals (the sums a single GPU's hierarchy would hold)
+__global__ __launch_bounds__(kWave) void fixed_final_ctrl_kernel(FixedFinal ff, const uint64_t* __restrict__ all_totals, int world)
+{
+    const FixedRanks r = fixed_ranks(all_totals, world, 0);
+    if (threadIdx.x == 0) fixed_final_bookkeep(ff, r.S, r.Q);
+}
+// {S, Q, key(M)} of this shard's generation: what a sharded run all-gathers between two steps (24 bytes)
+__global__ __launch_bounds__(kWave) void fixed_totals_kernel(FHier f, uint64_t* __restrict__ out)
+{
+    const FTot t = ftot(f);
+    if (threadIdx.x == 0) { out[0] = t.S; out[1] = t.Q; out[2] = dkey(t.M); }
+}
+
+// Read-out: the final weight of particle i is q_i 2^-32 (relative to exp(R)); the normaliser is the final generation's mass.
+template <class Model>
+__global__ __launch_bounds__(kThreads) void smooth_fixed_kernel(SmoothArgs<Model> a, FixedFinal ff, const uint32_t* __restrict__ q_last)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_stat[];   // [kWaves][T*K]
+    if (ff.bookkeep && blockIdx.x == 0 && wave_id() == 0) {
+        const FTot t = ftot(ff.f);
+        if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q);
+    }
+    smooth_body<Model>(a, s_stat, [q_last](int64_t, int64_t i) { return (double)q_last[i] * kFixInv; });        // padding slots: q = 0
+}
+
+// Offspring bounds of the ranks (lane r: o_r, r = 0 .. world) and the decision, from the all-gathered totals.  One wave.
+struct PlanFixedIn { const uint64_t* all_totals; double u0, n_pop, ess_frac; };
+__device__ __forceinline__ double plan_bounds_fixed(const PlanFixedIn& pf, int world, bool& resample)
+{
+    const int lane = lane_id();
+    uint64_t s = 0, q = 0;
+    if (lane < world) { s = pf.all_totals[3 * lane]; q = pf.all_totals[3 * lane + 1]; }
+    const uint64_t incl = wave_incl_scan_u64(s);
+    const uint64_t St = read_lane_u64(incl, kWave - 1), Qt = wave_sum_u64(q);
+    const FixedDecision d = fixed_decide(St, Qt, pf.n_pop, pf.ess_frac, true);
+    resample = d.resample;
+    FixedCdf fc;
+    fc.inv = d.inv; fc.u0 = pf.u0; fc.n_pop = pf.n_pop; fc.base = 0;
+    double o = fc.g(incl - s);
+    if (lane >= world) o = pf.n_pop;
+    return o;
+}
+
+}  // namespace cph
