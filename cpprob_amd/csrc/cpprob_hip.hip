@@ -13,6 +13,7 @@
 
 #include "kernels.hpp"
 #include "step_counts.hpp"
+#include "step_fixed.hpp"
 #include "exchange.hpp"
 
 using namespace cph;
@@ -110,6 +111,11 @@ struct cpprob_hip_ctx {
     int64_t* d_annex_base = nullptr;                       // [T + 1] exchange scope: annex columns in use before each step's immigrants
     int32_t* d_skip = nullptr;                             // [T / 8 + 1][rs] exchange scope, long traces: skip rows (exchange.hpp: skip_rows_kernel)
     bool counts_mode = false;                              // this run's steps use smc_step_counts_kernel
+    bool fixed_mode = false;                               // ... or smc_step_fixed_kernel (fixed-point weights, step_fixed.hpp)
+    bool final_from_fixed = false;                         // the read-out takes its weights from the final generation's integer weights
+    uint32_t* d_q[2] = {nullptr, nullptr};                 // [ld] integer weights of the fixed-point form, ping-pong
+    std::vector<double> h_bound;                           // [T] upper bound of each step's incremental log-weight (host-evaluated)
+    size_t hier_q0_off = 0, hier_m0_off = 0;               // the tiles' Q / M arrays inside one copy of the hierarchy
     std::vector<double> h_ll_tab, h_e_tab;                 // host copies of the table-weight model's per-step tables ([T][3], [T][4])
     double* d_wpart = nullptr;                             // bounded SIS: per-workgroup partial rows
     bool sis_bounded_ok = false;                           // this run's model / observes admit the bounded-weight SIS kernel
@@ -434,6 +440,8 @@ static void hier_view(const cpprob_hip_ctx* c, int copy, Hier& h)
     h.top = c->hier.lvl[copy][top]; h.top_n = c->hier.n_ent[top]; h.top_stride = top == 0 ? 1 : kHierStride;
 }
 
+static void hier_rotation(cpprob_hip_ctx* c, int t, int& kp, int& kn, int& kc);
+
 template <class Model>
 void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int world, int rank)
 {
@@ -442,12 +450,8 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         a.mp = c->mp; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
         a.values = static_cast<typename Model::store_t*>(c->d_values); a.anc = c->d_anc;
         {
-            if (t == 0) {
-                // a run that was abandoned half-way leaves the rotation in an unknown state: start over from clean copies
-                if (c->hier_run_open) { (void)hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream); c->hier_phase = 0; }
-                c->hier_run_open = true; c->hier_phase_run = c->hier_phase;
-            }
-            const int kp = (t + c->hier_phase_run) % 3, kn = (kp + 1) % 3, kc = (kp + 2) % 3;
+            int kp, kn, kc;
+            hier_rotation(c, t, kp, kn, kc);
             hier_view(c, kp, a.h);
             a.h.to_next = (int64_t)(kn - kp) * (int64_t)c->hier_per_copy; a.h.to_clear = (int64_t)(kc - kp) * (int64_t)c->hier_per_copy;
             if (t == 0) c->final_from_counts = false;
@@ -470,6 +474,80 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         if (t + 1 == c->T) { c->cur = 0; c->cur_part = 0; }
     }
+}
+
+// The fixed-point form (step_fixed.hpp) serves what the prefix-count form does not: continuous weights and ESS-triggered schedules
+// under systematic resampling, one population per context or one shard of an exchange-scope population.  Same hierarchy, same
+// rotation; ancestors, decisions and evidence are integer-exact across tilings and shardings.
+template <class Model>
+bool fixed_eligible(const cpprob_hip_ctx* c)
+{
+    constexpr bool model_ok = std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value;
+    return model_ok && !(c->cfg.flags & CPPROB_HIP_FLAG_FLOATING_POINT_STEP) && c->nb <= kCountsMaxTiles && c->pop_n <= (1ull << 28) &&
+           c->cfg.algorithm == CPPROB_HIP_ALG_SMC && c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && !counts_eligible<Model>(c) &&
+           (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND);
+}
+
+static void fhier_view(const cpprob_hip_ctx* c, int copy, FHier& f)
+{
+    hier_view(c, copy, f.h);
+    f.q0 = c->d_hier + (size_t)copy * c->hier_per_copy + c->hier_q0_off;
+    f.m0 = c->d_hier + (size_t)copy * c->hier_per_copy + c->hier_m0_off;
+}
+
+// the copies step t reads / writes / clears (shared by both integer forms)
+static void hier_rotation(cpprob_hip_ctx* c, int t, int& kp, int& kn, int& kc)
+{
+    if (t == 0) {
+        // a run that was abandoned half-way leaves the rotation in an unknown state: start over from clean copies
+        if (c->hier_run_open) { (void)hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream); c->hier_phase = 0; }
+        c->hier_run_open = true; c->hier_phase_run = c->hier_phase;
+    }
+    kp = (t + c->hier_phase_run) % 3; kn = (kp + 1) % 3; kc = (kp + 2) % 3;
+}
+
+template <class Model>
+void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int world, int rank)
+{
+    if constexpr (std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value) {
+        StepFixedArgs<Model> a{};
+        a.mp = c->mp; a.obs = c->d_obs; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
+        a.values = static_cast<typename Model::store_t*>(c->d_values); a.anc = c->d_anc;
+        int kp, kn, kc;
+        hier_rotation(c, t, kp, kn, kc);
+        fhier_view(c, kp, a.f);
+        a.f.h.to_next = (int64_t)(kn - kp) * (int64_t)c->hier_per_copy; a.f.h.to_clear = (int64_t)(kc - kp) * (int64_t)c->hier_per_copy;
+        if (t == 0) { c->final_from_fixed = false; c->cur = 0; }
+        if (t + 1 == c->T) { c->hier_phase = kn; c->final_from_fixed = true; c->final_copy = kn; c->final_bookkeep_pending = true; c->hier_run_open = false; }
+        a.q_prev = c->d_q[c->cur]; a.q_next = c->d_q[c->cur ^ 1];
+        a.logw_prev = c->d_logw[c->cur]; a.logw_next = c->d_logw[c->cur ^ 1];
+        a.u0 = t > 0 ? host_resample_u0(c->run_seed, (uint64_t)t) : 0.0;
+        a.bound = c->h_bound[(size_t)t]; a.bound_prev = t > 0 ? c->h_bound[(size_t)t - 1] : 0.0;
+        a.ess_frac = c->cfg.ess_threshold; a.may_carry = c->cfg.ess_threshold > 1.0 ? 0 : 1;
+        a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
+        a.all_totals = reinterpret_cast<const uint64_t*>(all_totals); a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
+        a.row_w = c->keep ? t : (t & 1); a.row_r = t > 0 ? (c->keep ? t - 1 : ((t - 1) & 1)) : 0;
+        if (!c->keep) a.anc = nullptr;
+        {
+            ProfScope ps(c, 0);
+            if (all_totals) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        }
+        c->cur ^= 1;
+        if (!c->keep) {
+            // filtering only: predict hit t's sums under the integer weights this step just left
+            hipLaunchKernelGGL(filter_partials_fixed_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), 0, c->stream,
+                               static_cast<const typename Model::store_t*>(c->d_values) + (int64_t)a.row_w * c->rs, (const uint32_t*)c->d_q[c->cur], c->n,
+                               c->d_fpart + (size_t)t * (Model::kStats + 2) * c->smooth_grid);
+        }
+    }
+}
+
+static void fixed_final_view(cpprob_hip_ctx* c, FixedFinal& ff, bool bookkeep)
+{
+    fhier_view(c, c->final_copy, ff.f);
+    ff.n_pop = (double)c->pop_n; ff.ess_frac = c->cfg.ess_threshold; ff.T = c->T; ff.bookkeep = bookkeep ? 1 : 0;
+    ff.ctrl = c->d_ctrl; ff.ess_trace = c->d_ess; ff.resampled = c->d_resampled;
 }
 
 // The final generation's counts, as the read-out and the joint bookkeeping see them.
@@ -530,6 +608,13 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
                 launched = true;
             }
         }
+        if (!launched && c->final_from_fixed) {
+            FixedFinal ff{};
+            fixed_final_view(c, ff, c->final_bookkeep_pending && !with_paths);
+            if (!with_paths) c->final_bookkeep_pending = false;
+            hipLaunchKernelGGL(smooth_fixed_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a, ff, (const uint32_t*)c->d_q[c->cur]);
+            launched = true;
+        }
         if (!launched) hipLaunchKernelGGL(smooth_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a);
     }
     ProfScope ps(c, 3);
@@ -554,7 +639,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_skip);
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
 }
 
@@ -728,7 +813,10 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
             // 64-ary hierarchy of per-tile state counts, three rotating copies (step_counts.hpp); levels >= 1 one line per entry
             size_t per_copy = 0; int lev = 0;
             for (size_t e = (size_t)c->nb;; e = (e + 63) / 64, ++lev) { per_copy += e * (lev == 0 ? 1 : kHierStride); if (e <= 64) break; }
+            per_copy += 2 * (size_t)c->nb;                          // fixed-point form: the tiles' Q and M arrays
             c->hier_entries = 3 * per_copy;
+            HIP_TRY(c, hipMalloc(&c->d_q[0], ld * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_q[1], ld * sizeof(uint32_t)));
             HIP_TRY(c, hipMalloc(&c->d_hier, c->hier_entries * sizeof(uint64_t)));
             HIP_TRY(c, hipMalloc(&c->d_annex_base, (T + 1) * sizeof(int64_t)));
             HIP_TRY(c, hipMemsetAsync(c->d_annex_base, 0, (T + 1) * sizeof(int64_t), c->stream));
@@ -748,6 +836,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
             off[nl] = per_copy; c->hier.n_ent[nl] = (int)e; per_copy += e * (nl == 0 ? 1 : kHierStride); ++nl;
             if (e <= 64) break;
         }
+        c->hier_q0_off = per_copy; c->hier_m0_off = per_copy + (size_t)c->nb; per_copy += 2 * (size_t)c->nb;
         c->hier.n_lev = nl; c->hier_per_copy = per_copy;
         for (int k = 0; k < 3; ++k)
             for (int l = 0; l < nl; ++l) c->hier.lvl[k][l] = c->d_hier + (size_t)k * per_copy + off[l];
@@ -818,6 +907,14 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMemcpy(c->d_e_tab, et.data(), et.size() * sizeof(double), hipMemcpyHostToDevice));
         c->mp.e_tab = c->d_e_tab;
     }
+    {
+        // fixed-point form: the upper bound of each step's incremental log-weight, with the very expressions the kernels evaluate
+        c->h_bound.assign((size_t)c->T, 0.0);
+        for (int t = 0; t < c->T; ++t) {
+            if (cfg->model == CPPROB_HIP_MODEL_HMM3) c->h_bound[(size_t)t] = c->h_e_tab[(size_t)t * 4 + 3];                       // the largest table value
+            else if (cfg->model == CPPROB_HIP_MODEL_LINEAR_GAUSSIAN_1D) c->h_bound[(size_t)t] = normal_logpdf_hoisted(h_obs[t], h_obs[t], 1.0, c->mp.log_norm_unit);   // the emission's density at its mode
+        }
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->begun = true; c->ran = false;
     return 0;
@@ -833,7 +930,7 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     c->run_seed = c->cfg.seed + run_index;
     c->cur = 0; c->cur_part = 0;
     c->sharded = false;
-    c->final_from_counts = false;
+    c->final_from_counts = false; c->final_from_fixed = false;
     bool readout_done = false, sis_bounded = false;
     (void)sis_bounded;
     if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
@@ -847,10 +944,16 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
         if (!readout_done) launch_scan(c, c->T - 1, 0, nullptr, 1, 0);
     } else {
         c->step_protocol = false;
-        c->counts_mode = false;
-        dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); });
+        c->counts_mode = false; c->fixed_mode = false;
+        dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); c->fixed_mode = fixed_eligible<decltype(m)>(c); });
         const bool fused = step_is_fused(c);
-        if (c->counts_mode) {
+        if (c->fixed_mode) {
+            ProfScope group(c, 0, c->T);
+            c->profile_suspended = true;
+            for (int t = 0; t < c->T; ++t) dispatch_model(c, [&](auto m) { launch_step_fixed<decltype(m)>(c, t, nullptr, 1, 0); });
+            c->profile_suspended = false;
+            // (no normalisation launch at any size: the read-out works from the final generation's masses)
+        } else if (c->counts_mode) {
             {
                 ProfScope group(c, 0, c->T);
                 c->profile_suspended = true;
@@ -883,6 +986,12 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
             c->final_bookkeep_pending = false;
             hipLaunchKernelGGL(counts_filter_final_kernel, dim3(1), dim3(kWave), 0, c->stream, f);
         } else {
+            if (c->final_from_fixed) {
+                FixedFinal ff{};
+                fixed_final_view(c, ff, true);
+                c->final_bookkeep_pending = false;
+                hipLaunchKernelGGL(fixed_filter_final_kernel, dim3(1), dim3(kWave), 0, c->stream, ff);
+            }
             hipLaunchKernelGGL(filter_finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream, (const double*)c->d_fpart, c->smooth_grid, c->K, c->is_int ? 1 : 0, c->d_stats);
         }
     } else if (!readout_done) dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
@@ -901,9 +1010,12 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     if (sis && t != c->T - 1) return fail(c, CPPROB_HIP_EINVAL, "SIS shards run in one launch: call step_begin(T-1) only");
     if (t == 0 || sis) {
         c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; c->annex_used = 0; c->plan.t = -1; c->x_plan_t = -1;
-        c->final_from_counts = false;
-        c->counts_mode = false;
-        if (!sis && c->exchange) dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); });
+        c->final_from_counts = false; c->final_from_fixed = false;
+        c->counts_mode = false; c->fixed_mode = false;
+        // the integer forms serve exact joint resampling (exchange scope) and a population held by this context alone; a shard that
+        // resamples locally (global scope, several ranks) keeps the floating-point form and its mass-share bookkeeping
+        if (!sis && (c->exchange || c->cfg.n_global == c->cfg.n_particles))
+            dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); c->fixed_mode = fixed_eligible<decltype(m)>(c); });
     }
     if (c->exchange && t > 0 && c->x_plan_t != t - 1)
         return fail(c, CPPROB_HIP_ESTATE, "exchange scope: the exchange of the previous step (plan / pack / commit) must run before the next step_begin");
@@ -919,6 +1031,16 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
             const int kn = (t + 1 + c->hier_phase_run) % 3;
             hier_view(c, kn, h);
             hipLaunchKernelGGL(counts_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals);
+        }
+    } else if (c->fixed_mode) {
+        // fixed-point form: likewise; what leaves is this shard's {mass, squares, key of the largest log-weight}: 24 bytes
+        if (t > 0 && !c->x_all_totals) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_step_end(t-1) has not run");
+        dispatch_model(c, [&](auto m) { launch_step_fixed<decltype(m)>(c, t, t > 0 ? c->x_all_totals : nullptr, c->x_world, c->x_rank); });
+        {
+            FHier f{};
+            const int kn = (t + 1 + c->hier_phase_run) % 3;
+            fhier_view(c, kn, f);
+            hipLaunchKernelGGL(fixed_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local_totals));
         }
     } else {
         if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c, false); });
@@ -943,7 +1065,15 @@ int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_to
     if (c->exchange && world > kMaxWorld) return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope plans on one wavefront (world + 1 bounds, one per lane): world <= 63");
     HIP_TRY(c, hipSetDevice(c->device));
     c->x_all_totals = d_all_totals; c->x_world = world; c->x_rank = rank;
-    if (!c->counts_mode) {
+    if (c->fixed_mode) {
+        if (t + 1 == c->T) {
+            if (world > kWave) return fail(c, CPPROB_HIP_EUNSUPPORTED, "the fixed-point form sums the ranks' totals on one wavefront: world <= 64");
+            FixedFinal ff{};
+            fixed_final_view(c, ff, true);
+            hipLaunchKernelGGL(fixed_final_ctrl_kernel, dim3(1), dim3(kWave), 0, c->stream, ff, reinterpret_cast<const uint64_t*>(d_all_totals), world);
+            c->final_bookkeep_pending = false;
+        }
+    } else if (!c->counts_mode) {
         // floating-point form: the ranks' {max, sum, sum of squares} into ctrl.  In the exchange scope the step's plan launch follows
         // and does this on its way in (one launch less per step); the last step has no exchange
         c->scan2_deferred = c->exchange && t + 1 < c->T;
@@ -1004,7 +1134,12 @@ int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
     g.bytes_per_value = (int)(fixed_layout ? c->ssz : (c->is_int ? sizeof(int32_t) : sizeof(double))); g.sent_per_step = c->d_sent;
     PlanCountsIn pc{};
     pc.all_totals = c->x_all_totals; pc.n_pop = (double)c->pop_n;
-    if (c->counts_mode) {
+    if (c->fixed_mode) {
+        PlanFixedIn pf{};
+        pf.all_totals = reinterpret_cast<const uint64_t*>(c->x_all_totals); pf.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1); pf.n_pop = (double)c->pop_n;
+        pf.ess_frac = c->cfg.ess_threshold;
+        hipLaunchKernelGGL(exchange_plan_fixed_kernel, dim3(1), dim3(kWave), 0, c->stream, g, pf, t, c->d_annex_base, c->d_xplan);
+    } else if (c->counts_mode) {
         pc.e0 = c->h_e_tab[(size_t)t * 4]; pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
         pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
         hipLaunchKernelGGL((exchange_plan_kernel<true, false>), dim3(1), dim3(kWave), 0, c->stream, g, pc, (const double*)c->d_obound, t, c->d_annex_base, c->d_xplan, ScanArgs{});
@@ -1041,12 +1176,22 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid, bool plan_inside
             hier_view(c, kn, a.h);
             a.pc.e0 = c->h_e_tab[(size_t)t * 4]; a.pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; a.pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
             a.pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
-            if (plan_inside) hipLaunchKernelGGL((exchange_pack_kernel<Model, R, true, true>), pgrid, dim3(kThreads), 0, c->stream, a);
-            else hipLaunchKernelGGL((exchange_pack_kernel<Model, R, true, false>), pgrid, dim3(kThreads), 0, c->stream, a);
+            if (plan_inside) hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackCounts, true>), pgrid, dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackCounts, false>), pgrid, dim3(kThreads), 0, c->stream, a);
             return;
         }
     }
-    hipLaunchKernelGGL((exchange_pack_kernel<Model, R, false>), pgrid, dim3(kThreads), 0, c->stream, a);
+    if (c->fixed_mode) {
+        const int kn = (t + 1 + c->hier_phase_run) % 3;
+        fhier_view(c, kn, a.f);
+        a.pf.all_totals = reinterpret_cast<const uint64_t*>(c->x_all_totals); a.pf.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1); a.pf.n_pop = (double)c->pop_n;
+        a.pf.ess_frac = c->cfg.ess_threshold;
+        a.q_prev = c->d_q[c->cur];                                     // the weights of the generation step t just produced
+        if (plan_inside) hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackFixed, true>), pgrid, dim3(kThreads), 0, c->stream, a);
+        else hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackFixed, false>), pgrid, dim3(kThreads), 0, c->stream, a);
+        return;
+    }
+    hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackFloat, false>), pgrid, dim3(kThreads), 0, c->stream, a);
 }
 
 template <class Model, class R>
@@ -1241,7 +1386,7 @@ int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* c, int32_t t)
     HIP_TRY(c, hipSetDevice(c->device));
     // count form: the plan is a pure function of the all-gathered totals -- every packing workgroup derives it on its first wavefront
     // and workgroup 0 stores it (one launch less per step); floating-point form: the plan launch also combines the ranks' totals
-    const bool plan_inside = c->counts_mode;
+    const bool plan_inside = c->counts_mode || c->fixed_mode;
     if (c->x_peers.empty()) {
         // nobody to exchange with (a group of one): the count form's step derives everything it needs from the totals; the
         // floating-point form's plan launch still combines the ranks' totals into ctrl

@@ -14,6 +14,7 @@
 #pragma once
 #include "kernels.hpp"
 #include "step_counts.hpp"
+#include "step_fixed.hpp"
 
 namespace cph {
 
@@ -179,6 +180,16 @@ __global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, Pl
     plan_store(g, t, pl, pw, annex_base, plan);
 }
 
+// The same from the ranks' integer masses (fixed-point form): bounds and decision are pure functions of the all-gathered totals.
+__global__ __launch_bounds__(kWave) void exchange_plan_fixed_kernel(ExchangeGeom g, PlanFixedIn pf, int t, int64_t* __restrict__ annex_base, ExchangePlan* __restrict__ plan)
+{
+    bool resample;
+    const double o = plan_bounds_fixed(pf, g.world, resample);
+    PlanLane pl; PlanWave pw;
+    plan_wave(g, o, resample, pl, pw);
+    plan_store(g, t, pl, pw, annex_base, plan);
+}
+
 // Skip rows.  A migrating particle takes its lineage x_0 .. x_t along, and extracting a lineage is a chain of t dependent gathers
 // (~1.7 us a hop: each is a row further away in memory) that no parallelism across particles shortens -- half of a long-trace run
 // in the exchange scope (profiles/r02_notes.md).  Row m of `skip` (written after step 8m, one launch every eighth step) holds, for
@@ -224,26 +235,36 @@ struct PackArgs {
     ExchangeGeom geom; int64_t* annex_base; ExchangePlan* plan_out;
     // prefix-count form
     Hier h; PlanCountsIn pc;
+    // fixed-point form
+    FHier f; PlanFixedIn pf; const uint32_t* q_prev;
     // floating-point form
     const double* wrel; const double* bc; const double* bf; const StepCtrl* ctrl; uint64_t seed;
     uint64_t pid0;
 };
 
-template <class Model, class R, bool COUNTS, bool PLAN_INSIDE = false>
+enum { kPackFloat = 0, kPackCounts = 1, kPackFixed = 2 };
+
+template <class Model, class R, int MODE, bool PLAN_INSIDE = false>
 __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model, R> a)
 {
     using S = typename Model::store_t;
+    constexpr bool COUNTS = MODE == kPackCounts, FIXED = MODE == kPackFixed;
     __shared__ CountsLds Lc;
     __shared__ AncestorLds Lf;
+    __shared__ FixedLds Lx;
     __shared__ uint32_t s_hop[32];                              // bit tt - 1 of word (tt - 1) / 32: did step tt - 1 resample? (<= 1024 steps)
     __shared__ int64_t s_send_lo[kWorldSlots], s_send_cnt[kWorldSlots], s_send_base[kWorldSlots];
     __shared__ int64_t s_nsend;
     const int tid = threadIdx.x;
-    static_assert(!PLAN_INSIDE || COUNTS, "the plan is a pure function of the all-gathered totals in the count form only");
+    static_assert(!PLAN_INSIDE || COUNTS || FIXED, "the plan is a pure function of the all-gathered totals in the integer forms only");
     if constexpr (PLAN_INSIDE) {
         if (wave_id() == 0) {
             PlanLane pl; PlanWave pw;
-            plan_wave(a.geom, plan_bounds_counts(a.pc, a.world), true, pl, pw);
+            bool rs_ = true;
+            double o;
+            if constexpr (FIXED) o = plan_bounds_fixed(a.pf, a.world, rs_);
+            else o = plan_bounds_counts(a.pc, a.world);
+            plan_wave(a.geom, o, rs_, pl, pw);
             s_send_lo[tid] = pl.send_lo; s_send_cnt[tid] = pl.send_cnt; s_send_base[tid] = pl.send_base;
             if (tid == 0) s_nsend = pw.n_send;
             if (blockIdx.x == 0 && blockIdx.y == 0) plan_store(a.geom, a.t, pl, pw, a.annex_base, a.plan_out);
@@ -261,7 +282,13 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
     }
     __syncthreads();
     TableCdf tc;
+    FixedCdf fc;
     bool last_shard = a.rank + 1 == a.world;
+    if constexpr (FIXED) {
+        const FixedRanks rk = fixed_ranks(a.pf.all_totals, a.world, a.rank);
+        const FixedDecision d = fixed_decide(rk.S, rk.Q, a.pf.n_pop, a.pf.ess_frac, true);
+        fc.inv = d.inv; fc.u0 = a.pf.u0; fc.n_pop = a.pf.n_pop; fc.base = rk.before;
+    }
     if constexpr (COUNTS) {
         const int lane = lane_id();
         double r0 = 0.0, r1 = 0.0, rv = 0.0;
@@ -287,7 +314,15 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
             const int n_out = rem < kTile ? (int)rem : kTile;
             const uint64_t gj0 = (uint64_t)(lo + tl * kTile);
             int32_t anc[kPPT];
-            if constexpr (COUNTS) {
+            if constexpr (FIXED) {
+                {
+                    int32_t neg[kPPT];
+                    lane_fill(neg, (int32_t)-1);
+                    store4(Lx.slot, (int64_t)tid * kPPT, neg);
+                }
+                __syncthreads();
+                ancestors_fixed(a.f, fc, a.q_prev, a.n, a.nb, last_shard, (double)gj0, n_out, -16, anc, Lx);
+            } else if constexpr (COUNTS) {
                 {
                     int32_t neg[kPPT];
                     lane_fill(neg, (int32_t)-1);

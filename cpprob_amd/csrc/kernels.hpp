@@ -65,7 +65,7 @@ struct StepCtrl {
     double g_end;     // first output index owned by the NEXT shard's sources (+inf on the last shard and on a single shard)
     int32_t do_resample;  // decision taken after the last weighted step
     int32_t n_resampled;
-    int32_t pad[2];
+    double ref_cur;       // fixed-point form (step_fixed.hpp): the reference R_t of the generation just produced
 };
 
 enum { RS_SYSTEMATIC = 0, RS_STRATIFIED = 1, RS_PRECOMPUTED = 2 };

@@ -561,6 +561,49 @@ __global__ __launch_bounds__(kWave) void fixed_totals_kernel(FHier f, uint64_t* 
     if (threadIdx.x == 0) { out[0] = t.S; out[1] = t.Q; out[2] = dkey(t.M); }
 }
 
+// A filtering-only run has no lineages to walk: the final generation's bookkeeping is the whole read-out.
+__global__ __launch_bounds__(kWave) void fixed_filter_final_kernel(FixedFinal ff)
+{
+    const FTot t = ftot(ff.f);
+    if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q);
+}
+
+// Filtering-only runs: predict hit t's sums under generation t's own integer weights, per workgroup {0, sum q, sum q f_0 .. f_{K-1}}
+// in filter_partials_kernel's layout (kernels.hpp; every workgroup's reference is the same, so filter_finalize_kernel's rescaling is 1).
+template <class Model>
+__global__ __launch_bounds__(kThreads) void filter_partials_fixed_kernel(const typename Model::store_t* __restrict__ row, const uint32_t* __restrict__ q,
+                                                                          int64_t n, double* __restrict__ fpart_t)
+{
+    using V = typename Model::value_t;
+    constexpr int K = Model::kStats;
+    __shared__ double s_sum[(K + 1) * kWaves];
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int64_t ntiles = (n + kTile - 1) / kTile;
+    double acc[K + 1];
+#pragma unroll
+    for (int j = 0; j <= K; ++j) acc[j] = 0.0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t j0 = tile * kTile + (int64_t)tid * kPPT;
+        const U4 w = *reinterpret_cast<const U4*>(q + j0);                 // padding slots: 0
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const double e = (double)w[k] * kFixInv;
+            acc[0] += e;
+            Model::accumulate(static_cast<V>(row[j0 + k]), e, reinterpret_cast<double(&)[K]>(acc[1]));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j <= K; ++j) { const double w = wave_sum(acc[j]); if (lane == 0) s_sum[j * kWaves + wv] = w; }
+    __syncthreads();
+    if (tid <= K) {
+        double t = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kWaves; ++w2) t += s_sum[tid * kWaves + w2];
+        fpart_t[(int64_t)(tid + 1) * gridDim.x + blockIdx.x] = t;
+    }
+    if (tid == 0) fpart_t[blockIdx.x] = 0.0;
+}
+
 // Read-out: the final weight of particle i is q_i 2^-32 (relative to exp(R)); the normaliser is the final generation's mass.
 template <class Model>
 __global__ __launch_bounds__(kThreads) void smooth_fixed_kernel(SmoothArgs<Model> a, FixedFinal ff, const uint32_t* __restrict__ q_last)

@@ -571,6 +571,76 @@ ORC_API int orc_resample_table_systematic(const int32_t *x, uint64_t n_in, const
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Systematic resampling on FIXED-POINT weights, order-independent form for     */
+/* continuous weights and ESS-triggered schedules (the build's own arithmetic:   */
+/* the reference has no SMC; cpprob_amd/csrc/step_fixed.hpp).          */
+/* The linear weight of particle i is the integer                                */
+/*     q_i = min(rint(exp(lw_i - R) * 2^32), 2^32 - 1),                           */
+/* R >= max lw known before the generation exists: R_t = B_t when every particle  */
+/* enters step t at log-weight 0 (t = 0, or the previous step resampled), else    */
+/* R_t = M_{t-1} + B_t, with B_t the upper bound of the step's incremental        */
+/* log-weight (the emission's density at its mode, models.hpp:76-77,130-139) and  */
+/* M_{t-1} the exact maximum of the previous log-weights.  Inclusive CDF          */
+/* C_k = sum_{i<=k} q_i (exact, 64-bit), G_k = ceil(fma((double)C_k, N/(double)C_N,*/
+/* -u0)), ancestor of output j = min{k : G_k > j}, G of the last source = N;       */
+/* W = C_N 2^-32, ESS = W^2 / (2^-32 sum (q_i >> 16)^2).  Integers sum exactly in  */
+/* any order: tiles, wavefronts and shards all produce these ancestors.            */
+/* exp() is the kernel's own range-specific form (fma arithmetic, so that the      */
+/* integers agree bit for bit): cpprob/detail/fastmath.hpp exp_nonpos.             */
+/* ------------------------------------------------------------------------- */
+static double orc_exp_nonpos(double x)
+{
+    static const double c[11] = { 0x1.1f8b4cd99e7aap-29, 0x1.af4dea2bc3f25p-26, 0x1.27e4cccda6fcfp-22, 0x1.71de023137276p-19, 0x1.a01a01acfae99p-16,
+                                  0x1.a01a01abe8206p-13, 0x1.6c16c16c151fcp-10, 0x1.11111111100dbp-7, 0x1.5555555555558p-5, 0x1.5555555555557p-3, 0.5 };
+    const double k = rint(x * 0x1.71547652b82fep+0);
+    double r = fma(-k, 0x1.62e42fefa3800p-1, x);
+    r = fma(-k, 0x1.ef35793c76730p-45, r);
+    double p = c[0];
+    for (int i = 1; i < 11; ++i) p = fma(p, r, c[i]);
+    p = fma(p, r * r, r);
+    return ldexp(p + 1.0, (int)k);
+}
+
+ORC_API uint32_t orc_fix_weight(double lw, double ref)
+{
+    double d = lw - ref;
+    if (!(d > -1000.0)) d = -1000.0;                    /* -inf (and the clamp of the kernel): an exact 0 */
+    const double s = rint(orc_exp_nonpos(d) * 4294967296.0);
+    return s >= 4294967295.0 ? 0xffffffffu : (uint32_t)s;
+}
+
+ORC_API void orc_fix_weights(const double *logw, uint64_t n, double ref, uint32_t *q)
+{
+    for (uint64_t i = 0; i < n; ++i) q[i] = orc_fix_weight(logw[i], ref);
+}
+
+/* before = mass of the shards that precede this one (0 on one GPU), total = mass of the whole population;
+ * outputs [j0, j0 + n_out); outputs whose ancestor is not among these n_in sources get -1. */
+ORC_API int orc_resample_fixed_systematic(const uint32_t *q, uint64_t n_in, uint64_t before, uint64_t total, int last_shard,
+                                          uint64_t seed, uint64_t step, uint64_t j0, uint64_t n_out, uint64_t n_total_out, int32_t *anc)
+{
+    const double N = (double)n_total_out;
+    const double inv = N / (double)total;
+    const double u0 = resample_u0(seed, step);
+    uint64_t c = before;
+    for (uint64_t jj = 0; jj < n_out; ++jj) anc[jj] = -1;
+    double g_prev = ceil(fma((double)c, inv, -u0));
+    if (g_prev < 0.0 || before == 0) g_prev = 0.0;
+    if (g_prev > N) g_prev = N;
+    for (uint64_t k = 0; k < n_in; ++k) {
+        c += q[k];
+        double g = ceil(fma((double)c, inv, -u0));
+        if (g < 0.0) g = 0.0;
+        if (g > N) g = N;
+        if (last_shard && k + 1 == n_in) g = N;
+        for (double j = g_prev; j < g; j += 1.0)
+            if (j >= (double)j0 && j < (double)(j0 + n_out)) anc[(uint64_t)j - j0] = (int32_t)k;
+        if (g > g_prev) g_prev = g;
+    }
+    return 0;
+}
+
 /* e[s] = exp(ll_s - max ll) of step t of the HMM: the table the weights of generation t are drawn from */
 static void hmm_weight_table(double y, double e[3], double *mref)
 {
@@ -607,8 +677,15 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
     if (!logw || !cdf || !anc) return -1;
     double lz = 0.0;
     int do_resample = 0;
+    /* systematic resampling of continuous weights / on an ESS-triggered schedule: the fixed-point form (above) */
+    const int fixed = resampler == ORC_RESAMPLE_SYSTEMATIC && !(model == ORC_MODEL_HMM3 && ess_frac > 1.0);
+    uint32_t *qw = fixed ? (uint32_t *)malloc(n * sizeof(uint32_t)) : NULL;
+    uint64_t q_total = 0;
+    double m_prev = 0.0;
     for (size_t t = 0; t < T; ++t) {
-        if (do_resample && model == ORC_MODEL_HMM3 && resampler == ORC_RESAMPLE_SYSTEMATIC && ess_frac > 1.0) {
+        if (do_resample && fixed) {
+            if (orc_resample_fixed_systematic(qw, n, 0, q_total, 1, seed, (uint64_t)t, 0, n, n, anc)) return -4;
+        } else if (do_resample && model == ORC_MODEL_HMM3 && resampler == ORC_RESAMPLE_SYSTEMATIC && ess_frac > 1.0) {
             /* every step resamples: generation t-1 carries table weights -> the order-independent form */
             double e[3];
             uint64_t before[3] = { 0, 0, 0 }, total[3] = { 0, 0, 0 };
@@ -645,15 +722,30 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
         double W = 0.0, Q = 0.0;
         for (uint64_t i = 0; i < n; ++i) { double w = exp(logw[i] - max); W += w; Q += w * w; }
         double ess = W * W / Q;
+        if (fixed) {
+            /* reference known before the generation exists; integer weights, masses and squares */
+            double bound;
+            if (model == ORC_MODEL_LINEAR_GAUSSIAN_1D) bound = orc_normal_logpdf(obs[t], obs[t], 1);
+            else { double e3[3]; hmm_weight_table(obs[t], e3, &bound); }
+            const double ref = (t == 0 || do_resample) ? bound : m_prev + bound;
+            uint64_t S = 0, Q16 = 0;
+            for (uint64_t i = 0; i < n; ++i) { qw[i] = orc_fix_weight(logw[i], ref); S += qw[i]; Q16 += (uint64_t)(qw[i] >> 16) * (uint64_t)(qw[i] >> 16); }
+            q_total = S;
+            m_prev = max;
+            max = ref;                                   /* sums below are relative to exp(ref) */
+            W = (double)S * (1.0 / 4294967296.0);
+            Q = (double)Q16 * (1.0 / 4294967296.0);
+            ess = W * W / Q;
+        }
         if (ess_trace) ess_trace[t] = ess;
         if (filter_stats) {
             if (model == ORC_MODEL_HMM3) {
                 double acc[3] = { 0.0, 0.0, 0.0 };
-                for (uint64_t i = 0; i < n; ++i) acc[hist_int[t * n + i]] += exp(logw[i] - max);
+                for (uint64_t i = 0; i < n; ++i) acc[hist_int[t * n + i]] += fixed ? (double)qw[i] * (1.0 / 4294967296.0) : exp(logw[i] - max);
                 for (int k = 0; k < 3; ++k) filter_stats[t * 3 + k] = acc[k] / W;
             } else {
                 double s1 = 0.0, s2 = 0.0;
-                for (uint64_t i = 0; i < n; ++i) { const double w = exp(logw[i] - max), x = hist_real[t * n + i]; s1 += w * x; s2 += w * x * x; }
+                for (uint64_t i = 0; i < n; ++i) { const double w = fixed ? (double)qw[i] * (1.0 / 4294967296.0) : exp(logw[i] - max), x = hist_real[t * n + i]; s1 += w * x; s2 += w * x * x; }
                 filter_stats[t * 2] = s1 / W;
                 filter_stats[t * 2 + 1] = s2 / W - (s1 / W) * (s1 / W);
             }
@@ -665,7 +757,7 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
     }
     memcpy(logw_final, logw, n * sizeof(double));
     if (log_z) *log_z = lz;
-    free(logw); free(cdf); free(anc);
+    free(logw); free(cdf); free(anc); free(qw);
     return 0;
 }
 

@@ -61,6 +61,10 @@ def lib():
         L.orc_resample.argtypes = [C.c_int, _dp, u64, u64, u64, u64, u64, u64, _ip, C.c_void_p]
         L.orc_resample_table_systematic.restype = C.c_int
         L.orc_resample_table_systematic.argtypes = [_ip, u64, _dp, _u64p, _u64p, C.c_int, u64, u64, u64, u64, u64, _ip]
+        L.orc_fix_weight.restype = C.c_uint32; L.orc_fix_weight.argtypes = [dbl, dbl]
+        L.orc_fix_weights.argtypes = [_dp, u64, dbl, _up]
+        L.orc_resample_fixed_systematic.restype = C.c_int
+        L.orc_resample_fixed_systematic.argtypes = [_up, u64, u64, u64, C.c_int, u64, u64, u64, u64, u64, _ip]
         L.orc_smc.restype = C.c_int
         L.orc_smc.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
                               C.POINTER(dbl), _dp, _ip]
@@ -164,6 +168,41 @@ def resample_table_systematic(x, e, seed, step, before=None, total=None, last_sh
     if rc:
         raise RuntimeError("orc_resample_table_systematic failed rc=%d" % rc)
     return anc
+
+
+def fix_weights(logw, ref):
+    """The fixed-point form's integer weights q_i = min(rint(exp(lw_i - ref) 2^32), 2^32 - 1) (orc_fix_weight)."""
+    logw = np.ascontiguousarray(logw, np.float64)
+    q = np.zeros(len(logw), np.uint32)
+    lib().orc_fix_weights(logw, len(logw), float(ref), q)
+    return q
+
+
+def resample_fixed_systematic(q, seed, step, before=0, total=None, last_shard=True, j0=0, n_out=None, n_total_out=None):
+    """Order-independent systematic resampling on integer weights: ancestors of the outputs [j0, j0 + n_out) among the sources q;
+    -1 where the ancestor is on another shard."""
+    q = np.ascontiguousarray(q, np.uint32)
+    total = int(q.astype(np.uint64).sum()) if total is None else int(total)
+    n_out = len(q) if n_out is None else n_out
+    n_total_out = len(q) if n_total_out is None else n_total_out
+    anc = np.zeros(n_out, np.int32)
+    rc = lib().orc_resample_fixed_systematic(q, len(q), int(before), total, int(bool(last_shard)), seed, step, j0, n_out, n_total_out, anc)
+    if rc:
+        raise RuntimeError("orc_resample_fixed_systematic failed rc=%d" % rc)
+    return anc
+
+
+def smoothing_linear(hist, anc, w, k=3):
+    """StatsPrinter's numbers over the lineages for given LINEAR final weights (the fixed-point form's q)."""
+    path = lineage(np.ascontiguousarray(anc))
+    col = np.take_along_axis(hist, path, axis=1)
+    w = np.asarray(w, np.float64)
+    W = w.sum()
+    if hist.dtype == np.int32:
+        return np.stack([[(w * (col[t] == s2)).sum() / W for s2 in range(k)] for t in range(hist.shape[0])])
+    m1 = (col * w).sum(axis=1) / W
+    m2 = (col * col * w).sum(axis=1) / W
+    return np.stack([m1, m2 - m1 * m1], axis=1)
 
 
 def smc(model, obs, n, seed, resampler=RESAMPLE_SYSTEMATIC, ess_frac=2.0):

@@ -50,10 +50,7 @@ def main():
             eng.close()
             allp = np.concatenate(gathered, axis=1)
             differ = int((allp != ref_paths).any(axis=0).sum())
-            if model == cp.MODEL_HMM3:
-                ok = ok and differ == 0 and s["log_evidence"] == ref_sum["log_evidence"] and np.abs(stats - ref_stats).max() < 1e-13
-            else:
-                ok = ok and differ <= 2 and abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-9
+            ok = ok and differ == 0 and s["log_evidence"] == ref_sum["log_evidence"] and np.abs(stats - ref_stats).max() < 1e-13
             print("case", key, T, "differ", differ, "records", tr["records"], "bytes", tr["wire_bytes"], "reruns", reruns, flush=True)
     flag = [ok]
     dist.broadcast_object_list(flag, src=0)

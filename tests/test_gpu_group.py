@@ -76,8 +76,8 @@ def _ctx_paths(g, r, n_r, T, is_int):
 
 @pytest.mark.parametrize("ess", [2.0, 0.5])
 def test_group_lgssm_matches_one_gpu(engine, golden_dir, ess):
-    """Continuous weights (floating-point form of the step, device-side decision when ESS-triggered): the sharded run's
-    CDF is evaluated in a different order, so at most a couple of boundary offspring may differ."""
+    """Continuous weights, device-side decision when ESS-triggered: the fixed-point form (integer weights, exact 64-bit prefix
+    masses) makes the sharded run draw EXACTLY the ancestors one GPU would -- every trace, the decisions, the evidence, bit for bit."""
     import torch  # noqa: F401
     obs = _obs(golden_dir, "lgssm100")[:20]
     shards = [40000, 40001, 39999]
@@ -88,10 +88,9 @@ def test_group_lgssm_matches_one_gpu(engine, golden_dir, ess):
     g.run()
     stats, s, _ = g.results()
     paths = np.concatenate([_ctx_paths(g, r, shards[r], len(obs), False) for r in range(3)], axis=1)
-    differ = (paths != ref_paths).any(axis=0).sum()
-    assert differ <= 2
-    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if differ else 1e-11)
-    assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-11 and s["n_resampled"] == ref_sum["n_resampled"]
+    assert np.array_equal(paths, ref_paths)
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
+    assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
     g.close()
 
 
@@ -106,9 +105,8 @@ def test_group_hmm128_ess_triggered_matches_one_gpu(engine, golden_dir):
     g.run()
     stats, s, _ = g.results()
     paths = np.concatenate([_ctx_paths(g, r, shards[r], len(obs), True) for r in range(2)], axis=1)
-    differ = (paths != ref_paths).any(axis=0).sum()
-    assert differ <= 2
-    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if differ else 1e-11)
+    assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"]
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
     assert s["n_resampled"] == ref_sum["n_resampled"] and 0 < s["n_resampled"] < 127
     g.close()
 
@@ -129,9 +127,8 @@ def test_group_repopulation_from_one_rank_enlarges_the_transport(engine, golden_
     stats, s, reruns = g.results()
     assert reruns >= 1
     paths = np.concatenate([_ctx_paths(g, r, shards[r], len(obs), False) for r in range(3)], axis=1)
-    differ = (paths != ref_paths).any(axis=0).sum()
-    assert differ <= 2
-    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if differ else 1e-11)
+    assert np.array_equal(paths, ref_paths)
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
     g.close()
 
 
@@ -200,13 +197,9 @@ def test_config5_whole_population_over_eight_ranks(engine, golden_dir):
     engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=7, ess_threshold=0.5)
     engine.run()
     one, one_stats = engine.summary(), engine.stats()
-    # Floating-point form: the sharded CDF is summed in another order.  Up to ~3e7 particles the two runs are the same run; at this
-    # size some offspring flips across a CDF boundary within the first resamplings, and a single flip shifts the systematic comb
-    # against every later source (ancestors move to NEIGHBOURING slots, whose states are unrelated): from there on the two are
-    # different, equally valid samples of the same posterior -- Monte-Carlo-close, not bit-close.  (The count form of the
-    # every-step schedule is integer arithmetic and has no such sensitivity: test_group_hmm_every_step_is_bit_identical_to_one_gpu.)
-    assert one["n_resampled"] == s["n_resampled"] and abs(one["log_evidence"] - s["log_evidence"]) < 2e-3
-    np.testing.assert_allclose(stats, one_stats, rtol=0, atol=4e-3)
+    # fixed-point form: integer weights and exact 64-bit prefix masses -- the eight-rank run IS the one-GPU run, at 10^8 particles too
+    assert one["n_resampled"] == s["n_resampled"] and one["log_evidence"] == s["log_evidence"]
+    np.testing.assert_allclose(stats, one_stats, rtol=0, atol=1e-12)
     assert np.abs(one_stats - z["hmm128_smooth"]).max() < 3e-3
     engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, z["hmm16"], 1000, seed=1)          # (hand the 68 GB back)
 

@@ -144,9 +144,12 @@ def _compare_smc(engine, model, obs, n, seed, resampler, ess):
     # summation order of the parallel scan; a flipped particle stays different afterwards.
     frac_anc = np.mean(anc != ref["anc"])
     assert frac_anc < 2e-4, frac_anc
-    if model == cp.MODEL_HMM3 and resampler == cp.RESAMPLE_SYSTEMATIC and ess > 1.0:
-        # table weights on an every-step schedule: integer prefix counts, bit-exact index work
-        assert np.array_equal(anc, ref["anc"]) and np.array_equal(vals, ref["hist"])
+    if resampler == cp.RESAMPLE_SYSTEMATIC:
+        # systematic resampling runs on integers -- prefix counts (table weights, every-step schedule) or fixed-point weights
+        # (continuous weights, ESS-triggered schedules): the index work is bit-exact against the oracle's statement of the same arithmetic
+        assert np.array_equal(anc, ref["anc"])
+        if model == cp.MODEL_HMM3:
+            assert np.array_equal(vals, ref["hist"])
     if vals.dtype == np.int32:
         assert np.mean(vals != ref["hist"]) < 1e-3
     else:
@@ -157,8 +160,14 @@ def _compare_smc(engine, model, obs, n, seed, resampler, ess):
     sm_ref = O.smoothing(ref["hist"], ref["anc"], ref["logw"])
     np.testing.assert_allclose(engine.stats(), sm_ref, atol=2e-3)
     # internal consistency, exact: device smoothing == oracle estimator applied to the DEVICE's own store
-    sm_self = O.smoothing(vals, anc, logw)
-    np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-9, atol=1e-11)
+    fixed = resampler == cp.RESAMPLE_SYSTEMATIC and not (model == cp.MODEL_HMM3 and ess > 1.0)
+    if fixed:
+        # fixed-point form: the final weights ARE the integers q_i = rint(exp(lw_i - R) 2^32), R = summary()["max_logw"]
+        sm_self = O.smoothing_linear(vals, anc, O.fix_weights(logw, s["max_logw"]).astype(np.float64))
+        np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-11, atol=1e-13)
+    else:
+        sm_self = O.smoothing(vals, anc, logw)
+        np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-9, atol=1e-11)
     # paths == lineage read-out of the device store (index work: bit-exact)
     path_idx = O.lineage(anc)
     expect = np.take_along_axis(vals, path_idx, axis=1)
@@ -300,7 +309,7 @@ def test_filtering_only_run_count_form(engine, golden_dir, n):
                                                        (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 0.5, cp.RESAMPLE_SYSTEMATIC),
                                                        (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 2.0, cp.RESAMPLE_STRATIFIED),
                                                        (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 2.0, cp.RESAMPLE_MULTINOMIAL)])
-def test_filtering_only_run_floating_point_form(engine, golden_dir, model, key, ess, resampler):
+def test_filtering_only_run_weight_sums_form(engine, golden_dir, model, key, ess, resampler):
     """The same for continuous weights / ESS-triggered schedules: every step leaves its own weighted sums.  Same particles as the
     history-keeping run: the last predict hit's statistics agree (smoothing and filtering coincide there), the evidence is the
     same number, and the exact filter (forward algorithm / Kalman) is within Monte-Carlo error at every step."""
