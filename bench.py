@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample")
     p.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (pipelined runs, gaussian SIS)")
     p.add_argument("--in-flight", type=int, default=3, help="contexts in flight for the secondary pipelined measurement")
+    p.add_argument("--loopback-ranks", type=int, default=0, help="N = 1 only: run the library's multi-GPU driver with this many ranks on the one GPU "
+                   "(loopback transport: the whole exchange protocol, program order instead of collectives); --particles is then the WHOLE population")
     p.add_argument("--python-host", action="store_true", help="N > 1: drive the exchange scope from Python / torch.distributed instead of the library's C++ driver")
     return p.parse_args()
 
@@ -170,11 +172,12 @@ def timed_group_runs(group, steps, warmup, world, device, first_index=0):
     RCCL collectives on the context's stream, no host synchronisation inside)."""
     import torch
     import torch.distributed as dist
-    if world > 1:
-        def first():
-            group.run(first_index)
-            group.sync()
-        guarded(first, "the first multi-GPU run (RCCL all-gather / send / receive on the contexts' streams)")
+    # settle the transport before anything is timed: one run + results() (collective: every rank enters it), which repeats the run
+    # with larger segments / annex if they proved too small -- a pipelined batch is never repeated, so it must not overflow
+    def first():
+        group.run(first_index)
+        return group.results()[2]
+    settle = guarded(first, "the first multi-GPU run (RCCL all-gather / direct stores or send / receive on the contexts' streams)") if world > 1 else first()
     for i in range(warmup):
         group.run(first_index + i)
     group.sync()
@@ -194,7 +197,7 @@ def timed_group_runs(group, steps, warmup, world, device, first_index=0):
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, stats, summ, reruns
+    return dt, stats, summ, {"settling": settle, "timed_batch": reruns - settle}
 
 
 def make_rank_group(cp, world, rank, local):
@@ -325,9 +328,15 @@ def main():
             native_error = str(e)
     moved = {}
     reruns = 0
+    traffic = None
+    if world == 1 and args.loopback_ranks > 1 and smc:
+        group = cp.Group([local] * args.loopback_ranks)
+        n_global, exchange, scope = n, True, "exchange"
+        host = "C++ (cpprob_hip_group_run), %d loopback ranks on one GPU" % args.loopback_ranks
     if group is not None:
         group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
         dt, stats, summ, reruns = timed_group_runs(group, args.steps, args.warmup, world, device)
+        traffic = group.traffic()
         last = (stats,)
     else:
         eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
@@ -346,16 +355,20 @@ def main():
         summ = eng.summary()
     if last is not None and len(last) == 3:
         summ["log_evidence"] = last[1]          # evidence of the joint population (shards combined), not of this rank's shard
-    if exchange:
-        collective = "all_gather(3 doubles/rank) + all_to_all_v of the migrating lineages (ncclSend/ncclRecv of per-peer segments) per step; all_reduce(T*K+1 doubles) per run"
+    if exchange and traffic is not None:
+        tname = {0: "none", 1: "direct stores into the receiving rank's buffer (peer access / hipIpc), ordered by a 1-double all_gather", 2: "ncclSend/ncclRecv of fixed-capacity segments"}[traffic["transport"]]
+        collective = "all_gather(24 bytes/rank) per step; migrating lineages: %s; all_reduce(T*K+3 doubles) per run" % tname
+    elif exchange:
+        collective = "all_gather(3 doubles/rank) + all_to_all_v of the migrating lineages per step (torch.distributed host); all_reduce(T*K+1 doubles) per run"
     else:
         collective = "none" if world == 1 else ("all_gather(4+T*K doubles/rank) once per run, asynchronous (no host synchronisation between runs)" if island else "all_gather(3 doubles/rank) per step + all_reduce(T*K doubles) per run")
 
     # profiled pass: same K steps with HIP events around every launch on the engine's stream
     # (per-shard kernels only: on several GPUs each rank profiles its own shard as an island)
+    n_prof = n if args.loopback_ranks <= 1 else max(1, n // args.loopback_ranks)       # (one loopback rank's shard)
     if (world > 1 and not island) or exchange or group is not None:
-        eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
-                  particle_offset=rank * n, n_global=world * n, scope=cp.SCOPE_ISLAND)
+        eng.begin(spec["alg"], spec["model"], spec["obs"], n_prof, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
+                  particle_offset=rank * n_prof, n_global=world * n_prof, scope=cp.SCOPE_ISLAND)
     eng.profile_enable(True)
     eng.profile_read(reset=True)
     for i in range(args.steps):
@@ -365,22 +378,50 @@ def main():
     dom = "sis" if spec["alg"] == cp.ALG_SIS else "smc_step"
     dom_ms, dom_calls = prof[dom]
     avg_s = dom_ms * 1e-3 / max(dom_calls, 1)
+    n_res_prof = eng.summary()["n_resampled"]
+    # the floor of a launch of this chain: the same run at 4096 particles (the same launches with nothing in them)
+    eng.begin(spec["alg"], spec["model"], spec["obs"], 4096, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
+    for i in range(3):
+        eng.run(i)
+    eng.profile_enable(True)
+    eng.profile_read(reset=True)
+    for i in range(max(5, min(args.steps, 20))):
+        eng.run(11_000 + i)
+    floor = eng.profile_read(reset=True)
+    eng.profile_enable(False)
+    floor_us = floor[dom][0] * 1e3 / max(floor[dom][1], 1)
     bytes_per_unit = ALGO_BYTES[spec["bytes_key"]]
+    light = {"hmm": 24, "lgssm": 32}.get(spec["bytes_key"], bytes_per_unit)      # a step that does not resample moves 2s + 2w
     if spec["alg"] == cp.ALG_SIS:
         bytes_per_unit = 16  # the sis kernel's own share of the 32 B: it writes value + logw; the read-out pass reads them back
-    achieved = bytes_per_unit * n / avg_s / 1e9 if avg_s > 0 else 0.0
-    # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
-    # of this same command and committed with their correction notes; bench.py itself cannot run the profiler
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if args.workload == "hmm16_smc" and n == 1_000_000 and os.path.exists(pmc):
-        with open(pmc) as f:
-            for kname, rec in json.load(f)["kernels"].items():
-                if "smc_step_counts_kernel" in kname and "ModelHmm3, false>" in kname:  # the single-shard form (all 16 launches of a run)
-                    traffic = rec["hbm_bytes_per_launch_corrected"]
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)" if traffic else None, "algorithmic_bytes_per_unit": bytes_per_unit, "units_per_launch": n, "avg_launch_us": avg_s * 1e6,
-                "launches": int(dom_calls),
+        bytes_per_launch = bytes_per_unit * n_prof
+    else:
+        # launches of a run: step 0 and the steps behind a generation that was not resampled move the light figure, the others the full one
+        full_launches = n_res_prof
+        bytes_per_launch = n_prof * (full_launches * bytes_per_unit + (T - full_launches) * light) / T
+    achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+    # HBM bytes per launch and issue counters from the PMC passes: collected by separate rocprofv3 --pmc runs of this same command
+    # (tools/profile_round.sh) and committed with their correction notes; bench.py itself cannot run the profiler
+    traffic, traffic_src, valu_frac, wait_frac = None, None, None, None
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if pmcs and spec["alg"] == cp.ALG_SMC and args.loopback_ranks <= 1:
+        with open(pmcs[-1]) as f:
+            pj = json.load(f)
+        rec = pj.get("workloads", {}).get("%s@%d" % (args.workload, n_prof))
+        if rec:
+            traffic = rec["step_kernel"]["hbm_bytes_per_launch_corrected"]
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)" % os.path.basename(pmcs[-1])
+            valu_frac = rec["step_kernel"].get("valu_issue_frac")
+            wait_frac = rec["step_kernel"].get("wait_frac")
+    hbm_frac_measured = (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_s > 0) else None
+    # what bounds the dominant kernel at THIS size: within 2x of an empty launch of the same chain it is the chain's latency
+    # (kernel boundary, first round trip to memory, search, gather), whatever the byte convention says
+    bound = "latency" if (avg_s * 1e6 <= 2.0 * floor_us) else "hbm"
+    roofline = {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_src, "hbm_frac_measured": hbm_frac_measured, "valu_issue_frac": valu_frac, "wait_frac": wait_frac,
+                "launch_floor_us": floor_us, "algorithmic_bytes_per_unit": bytes_per_unit, "algorithmic_bytes_per_unit_no_resampling": light if spec["alg"] == cp.ALG_SMC else None,
+                "units_per_launch": n_prof, "avg_launch_us": avg_s * 1e6, "launches": int(dom_calls), "resampling_launches_per_run": n_res_prof if spec["alg"] == cp.ALG_SMC else None,
                 "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]}}
 
     out = {
@@ -390,7 +431,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s, %d particles per GPU" % (spec["desc"], n), "particles_per_gpu": n, "T": T,
                    "resampler": "systematic", "ess_threshold": spec["ess"], "scope": scope, "n_global": n_global, "collective": collective,
-                   "host": host if world > 1 else "one context, one stream", "exchange_reruns": reruns},
+                   "host": host if (world > 1 or group is not None) else "one context, one stream", "exchange_reruns": reruns},
         "particle_steps_per_sec": value * T,
         "roofline": roofline,
         "posterior_max_abs_err_vs_exact": err, "log_evidence": summ["log_evidence"], "n_resampled": summ["n_resampled"],
@@ -398,6 +439,11 @@ def main():
 
     if native_error:
         out["config"]["native_driver_error"] = native_error
+    if traffic is not None:
+        # bytes of ONE run (the last one collected): what crossed the links for the migrating lineages, and the small collectives
+        out["exchange_traffic_per_run"] = {"records": traffic["records"], "payload_bytes": traffic["payload_bytes"], "wire_bytes": traffic["wire_bytes"],
+                                           "collective_bytes": traffic["collective_bytes"],
+                                           "transport": {0: "none", 1: "direct", 2: "sendrecv"}[traffic["transport"]]}
 
     def emit():
         if rank == 0:
@@ -437,19 +483,22 @@ def main():
             emit()
             os._exit(0)
 
-    if rank == 0 and world == 1 and not args.no_extras and smc:
-        # secondary: the multi-GPU protocol at world = 1 -- the library's C++ driver over RCCL with a single rank: per step the sharded
-        # step kernel, the 3-double all-gather and the device-side bookkeeping, no peers to exchange with
-        try:
-            g1 = cp.Group([local])
-            g1.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
-            gdt, gstats, _, grr = timed_group_runs(g1, args.steps, args.warmup, 1, device, first_index=60_000)
-            out["exchange_world1"] = {"ms_per_run": gdt / args.steps * 1e3, "particles_per_sec": n * args.steps / gdt, "reruns": grr,
-                                      "posterior_max_abs_err_vs_exact": float(np.abs(gstats - spec["exact"]).max()),
-                                      "note": "cpprob_hip_group_run, world = 1, RCCL all-gather per step on the context's stream"}
-            g1.close()
-        except Exception as e:
-            out["exchange_world1"] = {"error": str(e)}
+    if rank == 0 and world == 1 and not args.no_extras and smc and group is None:
+        # secondary: the multi-GPU protocol at world = 1 -- the library's C++ driver with a single rank: per step the sharded step
+        # kernel and the shard totals (a group of one has nobody to gather from or exchange with); then the same with EVERY call of
+        # the multi-GPU path issued anyway (ncclAllGather per step, the ordering all-gather of the direct transport, ncclAllReduce)
+        for key, flags in (("exchange_world1", 0), ("exchange_world1_all_collectives", cp.capi.GROUP_WORLD1_COLLECTIVES)):
+            try:
+                g1 = cp.Group([local])
+                g1.transport(flags=flags)
+                g1.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
+                gdt, gstats, _, grr = timed_group_runs(g1, args.steps, args.warmup, 1, device, first_index=60_000)
+                out[key] = {"ms_per_run": gdt / args.steps * 1e3, "particles_per_sec": n * args.steps / gdt, "reruns": grr,
+                            "posterior_max_abs_err_vs_exact": float(np.abs(gstats - spec["exact"]).max()),
+                            "note": "cpprob_hip_group_run, world = 1" + (", every RCCL collective of the multi-GPU path issued on the context's stream" if flags else "")}
+                g1.close()
+            except Exception as e:
+                out[key] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not args.no_extras and args.workload == "hmm16_smc":
         # secondary: the SAME workload through the unchanged-model path -- models::hmm<16> as written against the CPProb statement API,

@@ -15,7 +15,7 @@
 // are the same integers however tiles, wavefronts and shards are laid out: the resampling decision, every ancestor and the
 // evidence of a sharded run equal the single-GPU run's bit for bit, and no workgroup has to re-derive a floating-point CDF from
 // every tile partial (kernels.hpp: the fused prologue) or wait for a normalisation launch (scan_partials_kernel).  The CPU
-// restatement (oracle/cpprob_oracle.c: orc_resample_fixed_systematic) states the same arithmetic.
+// restatement the parity tests compare with states the same arithmetic.
 //
 // The prefix masses live in the 64-ary hierarchy of step_counts.hpp (same layout, same rotation of three copies): the word of a
 // tile / block is its mass S (levels >= 1: | arrivals << 56), and the line of a block also holds Q = sum (q >> 16)^2 and the

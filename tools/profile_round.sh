@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collects one round's evidence on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r03
+# bench line(s), rocprofv3 kernel stats of the headline and the other BASELINE configs, PMC traffic / SQ counters of the step
+# kernels -- each counter set in a run of its own (kernel-trace / stats only next to --pmc, as the pool requires).  Raw output goes to
+# gpurun_out/<tag>_*; tools/summarise_profiles.py turns it into profiles/<tag>_* on the build machine.
+TAG=${1:-r03}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+for W in "hmm16_smc 1000000" "lgssm100_smc 1250000" "lgssm100_smc 10000000" "hmm128_smc_ess 12500000"; do
+  set -- $W
+  D=$O/${TAG}_prof_$1_$2
+  rm -rf $D
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --workload $1 --particles $2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $D.log 2>&1
+  python3 $R/bench.py --workload $1 --particles $2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $D.json 2>> $D.log
+done
+for W in "hmm16_smc 1000000" "lgssm100_smc 1250000"; do
+  set -- $W
+  for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES"; do
+    N=$(echo $C | cut -d' ' -f1)
+    D=$O/${TAG}_pmc_$1_$2_$N
+    rm -rf $D
+    rocprofv3 --pmc $C --output-format csv -d $D -- python3 $R/bench.py --workload $1 --particles $2 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $D.log 2>&1
+  done
+done
+# the two 8-GPU configs whole, eight loopback ranks on this one GPU (the full exchange protocol, program order instead of collectives)
+python3 $R/bench.py --workload lgssm100_smc --particles 10000000 --loopback-ranks 8 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_loop_c4.json 2> $O/${TAG}_loop_c4.err
+python3 $R/bench.py --workload hmm128_smc_ess --particles 100000000 --loopback-ranks 8 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_loop_c5.json 2> $O/${TAG}_loop_c5.err
+python3 $R/bench.py --workload hmm16_smc --particles 8000000 --loopback-ranks 8 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/${TAG}_loop_c3x8.json 2> $O/${TAG}_loop_c3x8.err
+ls $O | grep ${TAG}_ | head -50
+cut -c1-900 $O/${TAG}_bench.json
