@@ -1,0 +1,181 @@
+// SMC bookkeeping of ONE step on fixed-point weights, for callers that produce the log-weights themselves (the unchanged-model
+// path: cpprob/gpu.hpp launches the model body, then cpprob_hip_smc_bookkeep_fixed).  Same arithmetic as step_fixed.hpp with the
+// reference taken from the generation itself -- R = the exact maximum of the log-weights, found by an order-free reduction first:
+//   bbf_max_kernel        tile maxima -> the hierarchy's M words (atomic max, a block's last tile forwards)
+//   bbf_quantize_kernel   q_i = min(rint(exp(lw_i - R) 2^32), 2^32 - 1); tile masses / squares -> the hierarchy (atomic adds)
+//   bbf_ancestors_kernel  totals -> ESS, decision, evidence (one thread); ancestors of the next generation by the integer comb
+//                         (fixed_locate / fixed_walk), the identity when the step does not resample
+// Three short launches in place of weights_partials + scan_partials + resample (kernels.hpp), no floating-point CDF anywhere.
+// Two copies of the hierarchy alternate: a step writes one and clears the upper levels of the other.
+#pragma once
+#include "step_fixed.hpp"
+
+namespace cph {
+
+// A block line here: word 0 S | arrivals << 56, word 1 Q, word 2 key(M), word 3 arrivals of the maximum pass.
+__device__ __forceinline__ void bbf_publish_max(const FHier& f, int bid, int nb, uint64_t mkey)
+{
+    const Hier& h = f.h;
+    using ull = unsigned long long;
+    uint64_t* l1 = const_cast<uint64_t*>(h.lvl[1]);
+    uint64_t* l2 = const_cast<uint64_t*>(h.lvl[2]);
+    const int b1 = bid >> 6, b2 = bid >> 12;
+    const_cast<uint64_t*>(f.m0)[bid] = mkey;
+    if (h.n_lev == 2) {
+        atomicMax(reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride + 2), (ull)mkey);
+    } else if (h.n_lev == 3) {
+        ull* e = reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride);
+        atomicMax(e + 2, (ull)mkey);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // performed before the arrival is counted (no cache write-back: step_fixed.hpp)
+        const ull old = atomicAdd(e + 3, (ull)1);
+        const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
+        if ((int)old == tiles_in_block - 1) {
+            const ull totM = atomicMax(e + 2, (ull)0);
+            atomicMax(reinterpret_cast<ull*>(l2 + (int64_t)b2 * kHierStride + 2), totM);
+        }
+    }
+    // the other copy's upper levels: clean for the next step
+    if (h.n_lev >= 2 && (b1 << 6) == bid) { uint64_t* e = l1 + h.to_clear + (int64_t)b1 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; }
+    if (h.n_lev >= 3 && (b2 << 12) == bid) { uint64_t* e = l2 + h.to_clear + (int64_t)b2 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; }
+}
+
+__global__ __launch_bounds__(kThreads) void bbf_max_kernel(const double* __restrict__ logw, int64_t n, FHier f)
+{
+    __shared__ uint64_t s_red[kWaves];
+    const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
+    double m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) if (j0 + k < n) m = fmax(m, logw[j0 + k]);
+    const uint64_t mw = wave_max_u64(dkey(m));
+    if (lane_id() == 0) s_red[wave_id()] = mw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t mk = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) mk = umax64(mk, s_red[w]);
+        bbf_publish_max(f, (int)blockIdx.x, (int)gridDim.x, mk);
+    }
+}
+
+// the generation's largest log-weight from the top level's M words (wave-uniform)
+__device__ __forceinline__ double bbf_top_max(const FHier& f)
+{
+    const int lane = lane_id();
+    const int64_t i = (int64_t)(lane < f.h.top_n ? lane : 0) * f.h.top_stride;
+    uint64_t m = f.h.n_lev == 1 ? f.m0[i] : f.h.top[i + 2];
+    if (lane >= f.h.top_n) m = 0;
+    return dkey_inv(wave_max_u64(m));
+}
+
+__device__ __forceinline__ void bbf_publish_mass(const FHier& f, int bid, int nb, uint64_t S, uint64_t Q)
+{
+    const Hier& h = f.h;
+    using ull = unsigned long long;
+    uint64_t* l0 = const_cast<uint64_t*>(h.lvl[0]);
+    uint64_t* l1 = const_cast<uint64_t*>(h.lvl[1]);
+    uint64_t* l2 = const_cast<uint64_t*>(h.lvl[2]);
+    const int b1 = bid >> 6, b2 = bid >> 12;
+    l0[bid] = S;
+    const_cast<uint64_t*>(f.q0)[bid] = Q;
+    if (h.n_lev == 2) {
+        ull* e = reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride);
+        atomicAdd(e, (ull)S); atomicAdd(e + 1, (ull)Q);
+    } else if (h.n_lev == 3) {
+        ull* e = reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride);
+        atomicAdd(e + 1, (ull)Q);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const ull old = atomicAdd(e, (ull)(S + (1ull << 56)));
+        const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
+        if ((int)(old >> 56) == tiles_in_block - 1) {
+            const ull totQ = atomicAdd(e + 1, (ull)0);
+            ull* e2 = reinterpret_cast<ull*>(l2 + (int64_t)b2 * kHierStride);
+            atomicAdd(e2, (ull)((old + S) & kMassMask)); atomicAdd(e2 + 1, totQ);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bbf_quantize_kernel(const double* __restrict__ logw, int64_t n, FHier f, uint32_t* __restrict__ q)
+{
+    __shared__ uint64_t s_red[2 * kWaves];
+    __shared__ double s_ref;
+    if (wave_id() == 0) { const double r = bbf_top_max(f); if (threadIdx.x == 0) s_ref = r; }
+    __syncthreads();
+    const double ref = s_ref;
+    const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
+    U4 w;
+    uint64_t s_l = 0, q_l = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const uint32_t v = j0 + k < n ? fix_weight(logw[j0 + k], ref) : 0u;
+        w[k] = v; s_l += v; q_l += (uint64_t)(v >> 16) * (uint64_t)(v >> 16);
+    }
+    *reinterpret_cast<U4*>(q + j0) = w;
+    const uint64_t sw = wave_sum_u64(s_l), qw = wave_sum_u64(q_l);
+    if (lane_id() == 0) { s_red[wave_id()] = sw; s_red[kWaves + wave_id()] = qw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t St = 0, Qt = 0;
+#pragma unroll
+        for (int k = 0; k < kWaves; ++k) { St += s_red[k]; Qt += s_red[kWaves + k]; }
+        bbf_publish_mass(f, (int)blockIdx.x, (int)gridDim.x, St, Qt);
+    }
+}
+
+struct BbfArgs {
+    FHier f; const uint32_t* q; int64_t n; int nb;
+    double u0, ess_frac; int step, last;
+    double* ess; int32_t* resampled; double* log_z; int32_t* anc;
+};
+
+__global__ __launch_bounds__(kThreads) void bbf_ancestors_kernel(BbfArgs a)
+{
+    __shared__ FixedLds L;
+    __shared__ __attribute__((aligned(16))) FixedFound s_found;
+    const int tid = threadIdx.x;
+    const int bid = (int)blockIdx.x, nb = a.nb;
+    const int64_t j0 = (int64_t)bid * kTile + (int64_t)tid * kPPT;
+    const int64_t rem = a.n - (int64_t)bid * kTile;
+    const int n_out = rem < kTile ? (int)rem : kTile;
+    const double gj_first = (double)((int64_t)bid * kTile);
+    {
+        int32_t neg[kPPT];
+        lane_fill(neg, (int32_t)-1);
+        store4(L.slot, (int64_t)tid * kPPT, neg);
+    }
+    FixedCdf fc;
+    fc.u0 = a.u0; fc.n_pop = (double)a.n; fc.base = 0; fc.inv = 0.0;
+    if (wave_id() == 0) {
+        FTotWords tw; ftot_fetch(a.f, tw);
+        const FTot tot = ftot_sum(a.f, tw);
+        const double ref = tot.M;
+        const FixedDecision d = fixed_decide(tot.S, tot.Q, (double)a.n, a.ess_frac, !a.last);
+        fc.inv = d.inv;
+        if (bid == 0 && tid == 0) {
+            a.ess[a.step] = d.ess;
+            a.resampled[a.step] = d.resample ? 1 : 0;
+            double lz = a.step == 0 ? 0.0 : *a.log_z;
+            if (d.resample || a.last) lz += ref + log(d.W / (double)a.n);
+            *a.log_z = lz;
+        }
+        FLocated loc{0, 0, 0};
+        if (d.resample) loc = fixed_locate(a.f, fc, nb, gj_first, n_out, bid, nullptr);
+        if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.resample = d.resample ? 1 : 0; }
+    }
+    __syncthreads();
+    if (a.last) return;
+    int32_t anc[kPPT];
+    if (s_found.resample) {
+        fc.inv = s_found.inv;
+        const U4 z = {0u, 0u, 0u, 0u};
+        fixed_walk(fc, a.q, a.n, nb, true, gj_first, n_out, s_found.loc, bid, false, z, z, z, anc, L);
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) anc[k] = max(anc[k], 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) anc[k] = (int32_t)(j0 + k);
+    }
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) if (j0 + k < a.n) a.anc[j0 + k] = anc[k];
+}
+
+}  // namespace cph

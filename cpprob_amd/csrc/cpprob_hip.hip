@@ -15,6 +15,7 @@
 #include "step_counts.hpp"
 #include "step_fixed.hpp"
 #include "exchange.hpp"
+#include "bookkeep_fixed.hpp"
 
 using namespace cph;
 
@@ -125,6 +126,10 @@ struct cpprob_hip_ctx {
     StepCtrl* d_bb_ctrl = nullptr; size_t bb_cap_nb = 0;
     double* d_bb_stats_part = nullptr; double* d_bb_stats = nullptr; double* d_bb_cdf = nullptr; size_t bb_cdf_cap = 0;
     int32_t* d_bb_first = nullptr; size_t bb_first_cap = 0;
+
+    // cpprob_hip_smc_bookkeep_fixed: two alternating copies of a mass hierarchy + the integer weights
+    uint64_t* d_bbf_hier = nullptr; HierTable* d_bbf_table = nullptr; HierTable bbf_table{}; uint32_t* d_bbf_q = nullptr;
+    size_t bbf_per_copy = 0, bbf_q0_off = 0, bbf_m0_off = 0; int bbf_nb = 0, bbf_phase = 0; size_t bbf_cap_nb = 0;
 
     // optional per-kernel-class timing
     bool profile = false;
@@ -698,7 +703,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     dfree(c->d_ctrl); dfree(c->d_local_totals);
     dfree(c->d_send_src); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
-    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_first);
+    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1813,6 +1818,73 @@ int cpprob_hip_smc_bookkeep(cpprob_hip_ctx* c, int32_t kind, const double* d_log
             else hipLaunchKernelGGL(resample_kernel<RS_STRATIFIED>, dim3(nb), dim3(kThreads), 0, c->stream, a);
         }
     }
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
+namespace {
+// (re)lays the two-copy hierarchy out for populations of nb tiles
+int ensure_bbf(cpprob_hip_ctx* c, int nb)
+{
+    if (nb == c->bbf_nb && c->d_bbf_hier) return 0;
+    size_t per_copy = 0, off[kHierMaxLevels] = {0, 0, 0};
+    int nl = 0;
+    HierTable t{};
+    for (size_t e = (size_t)nb;; e = (e + 63) / 64) {
+        if (nl >= kHierMaxLevels) return fail(c, CPPROB_HIP_EUNSUPPORTED, "population too large for the three-level mass hierarchy");
+        off[nl] = per_copy; t.n_ent[nl] = (int)e; per_copy += e * (nl == 0 ? 1 : kHierStride); ++nl;
+        if (e <= 64) break;
+    }
+    t.n_lev = nl;
+    c->bbf_q0_off = per_copy; c->bbf_m0_off = per_copy + (size_t)nb; per_copy += 2 * (size_t)nb;
+    if ((size_t)nb > c->bbf_cap_nb || !c->d_bbf_hier) {
+        dfree(c->d_bbf_hier); dfree(c->d_bbf_q);
+        HIP_TRY(c, hipMalloc(&c->d_bbf_hier, 2 * per_copy * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc(&c->d_bbf_q, (size_t)nb * kTile * sizeof(uint32_t)));
+        c->bbf_cap_nb = (size_t)nb;
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < nl; ++l) t.lvl[k][l] = c->d_bbf_hier + (size_t)(k & 1) * per_copy + off[l];
+    if (!c->d_bbf_table) HIP_TRY(c, hipMalloc(&c->d_bbf_table, sizeof(HierTable)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bbf_table, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_bbf_hier, 0, 2 * per_copy * sizeof(uint64_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));               // (t is a local)
+    c->bbf_table = t; c->bbf_per_copy = per_copy; c->bbf_nb = nb; c->bbf_phase = 0;
+    return 0;
+}
+void bbf_view(const cpprob_hip_ctx* c, int copy, FHier& f)
+{
+    const HierTable& t = c->bbf_table;
+    for (int l = 0; l < kHierMaxLevels; ++l) { f.h.lvl[l] = l < t.n_lev ? t.lvl[copy][l] : t.lvl[copy][0]; f.h.n_ent[l] = t.n_ent[l]; }
+    f.h.n_lev = t.n_lev; f.h.table = c->d_bbf_table; f.h.copy = copy;
+    const int top = t.n_lev - 1;
+    f.h.top = t.lvl[copy][top]; f.h.top_n = t.n_ent[top]; f.h.top_stride = top == 0 ? 1 : kHierStride;
+    f.h.to_next = 0; f.h.to_clear = (int64_t)((copy ^ 1) - copy) * (int64_t)c->bbf_per_copy;
+    f.q0 = c->d_bbf_hier + (size_t)copy * c->bbf_per_copy + c->bbf_q0_off;
+    f.m0 = c->d_bbf_hier + (size_t)copy * c->bbf_per_copy + c->bbf_m0_off;
+}
+}  // namespace
+extern "C" {
+
+int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* c, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last, double ess_frac,
+                                  double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc)
+{
+    BB_PRELUDE(c);
+    if (!d_logw || !d_ess || !d_resampled || !d_log_z || (!last && !d_anc)) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (n == 0 || n > (size_t)(1ull << 28)) return fail(c, CPPROB_HIP_EINVAL, "population size out of range (1 .. 2^28: the squares' 64-bit sum)");
+    if (step < 0) return fail(c, CPPROB_HIP_EINVAL, "step out of range");
+    const int nb = (int)((n + kTile - 1) / kTile);
+    if (int rc = ensure_bbf(c, nb)) return rc;
+    FHier f{};
+    bbf_view(c, c->bbf_phase, f);
+    c->bbf_phase ^= 1;
+    hipLaunchKernelGGL(bbf_max_kernel, dim3(nb), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f);
+    hipLaunchKernelGGL(bbf_quantize_kernel, dim3(nb), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, c->d_bbf_q);
+    BbfArgs a{};
+    a.f = f; a.q = c->d_bbf_q; a.n = (int64_t)n; a.nb = nb; a.u0 = host_resample_u0(seed, (uint64_t)step + 1); a.ess_frac = ess_frac; a.step = step; a.last = last ? 1 : 0;
+    a.ess = d_ess; a.resampled = d_resampled; a.log_z = d_log_z; a.anc = d_anc;
+    hipLaunchKernelGGL(bbf_ancestors_kernel, dim3(last ? 1 : nb), dim3(kThreads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return 0;
 }

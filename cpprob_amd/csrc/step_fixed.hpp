@@ -153,11 +153,13 @@ __device__ __forceinline__ void fhier_publish(const FHier& f, int bid, int nb, u
     } else if (h.n_lev == 3) {
         ull* e = reinterpret_cast<ull*>(l1 + h.to_next + (int64_t)b1 * kHierStride);
         atomicAdd(e + 1, (ull)Q); atomicMax(e + 2, (ull)mkey);
-        __threadfence();                                           // both have landed before this tile's arrival is counted
+        // both have been PERFORMED (device-scope atomics execute where every XCD sees them; the counter waits for their
+        // acknowledgement) before this tile's arrival is counted -- no cache write-back: a __threadfence() here flushes the whole
+        // L2 of dirty particle rows once per workgroup (measured: 695 us per step at 10^7 particles instead of 60)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const ull old = atomicAdd(e, (ull)(S + (1ull << 56)));
         const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
         if ((int)(old >> 56) == tiles_in_block - 1) {
-            __threadfence();
             const uint64_t totS = (old + S) & kMassMask;
             const ull totQ = atomicAdd(e + 1, (ull)0), totM = atomicMax(e + 2, (ull)0);       // (read where the adds were performed)
             ull* e2 = reinterpret_cast<ull*>(l2 + h.to_next + (int64_t)b2 * kHierStride);
@@ -416,7 +418,6 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
         q_0 = *reinterpret_cast<const U4*>(a.q_prev + j0);
         q_m1 = *reinterpret_cast<const U4*>(a.q_prev + (bid > 0 ? j0 - kTile : j0));
         q_p1 = *reinterpret_cast<const U4*>(a.q_prev + (bid + 1 < nb ? j0 + kTile : j0));
-        if (a.may_carry) load4(a.logw_prev, j0, lw_carry);
         if (searcher) {
             ftot_fetch(a.f, tw);
             probe_fetch(a.f.h, bid, nb, pw0);
@@ -493,7 +494,9 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
             }
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) anc[k] = max(anc[k], 0);   // padding outputs of the last tile
-            lane_fill(lw_carry, 0.0);                                   // equal weights after resampling
+            // (equal weights after resampling: lw_carry stays 0)
+        } else if (a.may_carry) {
+            load4(a.logw_prev, j0, lw_carry);                           // weights carry over (a launch that resamples never reads them)
         }
     } else if (bid == 0 && tid == 0) {
         a.ctrl->ref_cur = ref;
@@ -525,6 +528,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
     }
     *reinterpret_cast<U4*>(a.q_next + j0) = q;
     if (a.may_carry || t + 1 == a.T) store4(a.logw_next, j0, lw);
+    // (the tile's totals by DPP reductions: three same-address 64-bit LDS atomics per lane were measured at 1.7x the whole step)
     const uint64_t s_w = wave_sum_u64(s_l), q_w = wave_sum_u64(q_l), m_w = wave_max_u64(dkey(m_l));
     if (lane_id() == 0) { s_red[wave_id()] = s_w; s_red[kWaves + wave_id()] = q_w; s_red[2 * kWaves + wave_id()] = m_w; }
     __syncthreads();

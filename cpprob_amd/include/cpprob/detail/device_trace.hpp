@@ -54,6 +54,7 @@ struct LaunchArgs {
     int32_t fresh_lo;              // first ordinal this step draws itself (= samples before the previous observe)
     int32_t next_fresh;            // first ordinal the NEXT step draws (= samples before this step's observe): what carry_out must end with
     const uint64_t* carry_in; uint64_t* carry_out;
+    uint64_t pid0;                 // global id of lane 0's particle (shards of one population draw from the population's streams)
 };
 typedef const LaunchArgs __attribute__((address_space(4))) * LaunchArgsPtr;
 __device__ inline LaunchArgsPtr launch_args() { return (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
@@ -71,7 +72,20 @@ struct LaneState {
     uint32_t done[kLaneBlock];
     int32_t src[kLaneBlock];              // the lane's ancestor (its own index where the previous step did not resample)
     unsigned long long active[kLaneBlock / 64];   // per wavefront: the lanes that carry a particle
+    // Windowed replay (the model passed the Markov probe: statement counts do not depend on sampled values): every lane of a
+    // wavefront executes the same statements, so the counters are WAVE-UNIFORM -- one packed word per lane, read back through the
+    // scalar unit (readfirstlane), and every test on it a scalar branch: a statement behind or before the live window costs one LDS
+    // round trip and a handful of scalar instructions instead of a chain of execution-mask regions.
+    // bits 0..23 samples, 24..39 observes, 40..49 int predicts, 50..59 real predicts, 63 done
+    unsigned long long w[kLaneBlock];
 };
+constexpr unsigned long long kWSample = 1ull, kWObserve = 1ull << 24, kWPredInt = 1ull << 40, kWPredReal = 1ull << 50, kWDone = 1ull << 63;
+__device__ inline unsigned long long wave_uniform(unsigned long long v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
 __device__ inline LaneState& lane_state()
 {
     __shared__ LaneState s_state;
@@ -85,7 +99,7 @@ __device__ inline void begin_lane(int32_t src, uint32_t n_stored, double carried
     const int l = threadIdx.x;
     s.log_w[l] = 0.0; s.carried[l] = carried;
     s.n_sample[l] = 0; s.n_observe[l] = 0; s.n_pred_real[l] = 0; s.n_pred_int[l] = 0; s.n_recorded[l] = 0;
-    s.n_stored[l] = n_stored; s.done[l] = 0; s.src[l] = src;
+    s.n_stored[l] = n_stored; s.done[l] = 0; s.src[l] = src; s.w[l] = 0;
     s.active[l / 64] = __ballot(1);        // (every lane of the wavefront writes the same word)
 }
 
@@ -157,7 +171,7 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
             T v = T();
             if (!s.done[l]) {
                 if (j < s.n_stored[l] && j < A->trace_cap) v = from_raw<T>(A->trace_in[(int64_t)j * A->ld + s.src[l]]);
-                else v = static_cast<T>(distr.mean_at(i) + distr.sigma_at(i) * cph::draw_std_normal(A->seed, (uint64_t)lane_index(), (uint64_t)j));
+                else v = static_cast<T>(distr.mean_at(i) + distr.sigma_at(i) * cph::draw_std_normal(A->seed, (uint64_t)lane_index() + A->pid0, (uint64_t)j));
                 if (A->trace_out) {
                     if (j < A->trace_cap) A->trace_out[(int64_t)j * A->ld + lane_index()] = to_raw<T>(v);
                     else if (A->overflow) *A->overflow = 1;
@@ -172,22 +186,25 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
         // (cpprob::inference refuses to launch this path for them, host_engine.hpp)
         __builtin_trap();
     } else {
-        const uint32_t j = s.n_sample[l]++;
-        if (s.done[l]) return R();
         if (A->windowed) {
-            const int32_t jj = (int32_t)j, base = A->fresh_lo - (int32_t)A->win;
+            // (scalar control flow: see LaneState::w)
+            const unsigned long long w = wave_uniform(s.w[l]);
+            s.w[l] = w + kWSample;
+            if (w & kWDone) return R();
+            const int32_t jj = (int32_t)(w & 0xffffffu), base = A->fresh_lo - (int32_t)A->win;
             if (jj < base) return R();                                    // older than the window: the step does not depend on it (host probe)
             R v;
             if (jj < A->fresh_lo) v = from_raw<R>(A->carry_in[(int64_t)(jj - base) * A->ld + s.src[l]]);
-            else v = draw(distr, A->seed, (uint64_t)lane_index(), (uint64_t)j);
+            else v = draw(distr, A->seed, (uint64_t)lane_index() + A->pid0, (uint64_t)jj);
             const int32_t out_base = A->next_fresh - (int32_t)A->win;
             if (A->carry_out && jj >= out_base && jj < A->next_fresh) A->carry_out[(int64_t)(jj - out_base) * A->ld + lane_index()] = to_raw<R>(v);
-            s.n_recorded[l] = j + 1;
             return v;
         }
+        const uint32_t j = s.n_sample[l]++;
+        if (s.done[l]) return R();
         R value;
         if (j < s.n_stored[l] && j < A->trace_cap) value = from_raw<R>(A->trace_in[(int64_t)j * A->ld + s.src[l]]);   // (beyond the rows: the run is being repeated anyway)
-        else value = draw(distr, A->seed, (uint64_t)lane_index(), (uint64_t)j);
+        else value = draw(distr, A->seed, (uint64_t)lane_index() + A->pid0, (uint64_t)j);
         if (A->trace_out) {
             if (j < A->trace_cap) A->trace_out[(int64_t)j * A->ld + lane_index()] = to_raw<R>(value);
             else if (A->overflow) *A->overflow = 1;
@@ -208,6 +225,20 @@ __device__ inline void observe_impl(Distribution& distr, const X& x)
         LaunchArgsPtr A = launch_args();
         LaneState& s = lane_state();
         const int l = threadIdx.x;
+        if (A->windowed) {
+            const unsigned long long own = s.w[l];
+            const unsigned long long w = wave_uniform(own);
+            s.w[l] = w + kWObserve;
+            // (a lane whose counters differ from its wavefront's executed other statements: the counts DO depend on sampled values,
+            //  the probe notwithstanding -- reported, and the host repeats the run with full replay)
+            if (__ballot(own != w) != 0ull && A->overflow) *A->overflow = 3;
+            const int32_t m = (int32_t)((w >> 24) & 0xffffu);
+            if (!(w & kWDone) && m >= A->first_observe) {
+                s.log_w[l] += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
+                if (m == A->stop_after) { finish_lane(); asm volatile("s_endpgm" ::: "memory"); }      // every lane of the wavefront is here
+            }
+            return;
+        }
         const int32_t m = (int32_t)s.n_observe[l]++;
         if (!s.done[l] && m >= A->first_observe) {
             s.log_w[l] += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
@@ -231,6 +262,22 @@ __device__ inline void predict_impl(const T& x)
     LaunchArgsPtr A = launch_args();
     LaneState& s = lane_state();
     const int l = threadIdx.x;
+    if constexpr (std::is_integral<V>::value || std::is_floating_point<V>::value) {
+        if (A->windowed) {
+            constexpr bool is_int = std::is_integral<V>::value;
+            const unsigned long long w = wave_uniform(s.w[l]);
+            if (w & kWDone) return;
+            s.w[l] = w + (is_int ? kWPredInt : kWPredReal);
+            if ((int32_t)((w >> 24) & 0xffffu) < A->first_observe) return;           // an earlier step's hit: recorded by that step's launch
+            const uint32_t k = (uint32_t)((w >> (is_int ? 40 : 50)) & 0x3ffu);
+            if constexpr (is_int) {
+                if (A->pred_int) { if (k < A->pred_int_cap) A->pred_int[(int64_t)k * A->ld + lane_index()] = static_cast<int32_t>(x); else if (A->overflow) *A->overflow = 2; }
+            } else {
+                if (A->pred_real) { if (k < A->pred_real_cap) A->pred_real[(int64_t)k * A->ld + lane_index()] = static_cast<double>(x); else if (A->overflow) *A->overflow = 2; }
+            }
+            return;
+        }
+    }
     if constexpr (std::is_integral<V>::value) {                         // state.hpp:312-318 -> predict_int_
         if (s.done[l]) return;
         const uint32_t k = s.n_pred_int[l]++;

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -295,6 +296,74 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
     }
 }
 
+// ---- unchanged models over several GPUs: StateType::sis ------------------------------------------------------------------------
+// Importance sampling needs no communication until the shards' sums meet: every device runs the model body for its
+// contiguous block of particles -- global particle ids select the random streams, so the traces are those ONE device would have
+// drawn -- on a host thread of its own, and the shards' self-normalised numbers are combined by their evidence:
+//   w_r = exp(L_r - L), L = logsumexp_r L_r;  mean = sum w_r mean_r;  E[x^2] = sum w_r (var_r + mean_r^2);  P = sum w_r P_r;
+//   ESS = 1 / sum_r w_r^2 / ESS_r;  log evidence = L - log N.
+inline void run_generic_sharded_sis(const Entry& e, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
+                                    Result& res, HostStore* store)
+{
+    const std::size_t world = opt.devices.size();
+    std::vector<Result> rr(world);
+    std::vector<HostStore> hs(world);
+    std::vector<std::string> errs(world);
+    std::vector<std::size_t> begin(world + 1, 0);
+    for (std::size_t r = 0; r < world; ++r) begin[r + 1] = begin[r] + n / world + (r < n % world ? 1 : 0);
+    std::vector<std::thread> th;
+    for (std::size_t r = 0; r < world; ++r)
+        th.emplace_back([&, r] {
+            try {
+                Options o = opt;
+                o.device = opt.devices[r]; o.devices.clear(); o.particle_offset = begin[r]; o.dump = false;
+                e.generic(StateType::sis, observes_v, begin[r + 1] - begin[r], st, o, rr[r], store ? &hs[r] : nullptr);
+            } catch (const std::exception& ex) { errs[r] = ex.what(); }
+        });
+    for (auto& t : th) t.join();
+    for (std::size_t r = 0; r < world; ++r)
+        if (!errs[r].empty()) throw std::runtime_error("cpprob::inference (shard " + std::to_string(r) + "): " + errs[r]);
+    double L = -std::numeric_limits<double>::infinity();
+    for (const auto& x : rr) L = std::max(L, x.log_norm);
+    double acc = 0;
+    for (const auto& x : rr) acc += std::exp(x.log_norm - L);
+    L += std::log(acc);
+    res = rr[0];
+    res.n_particles = n; res.log_norm = L; res.log_evidence = L - std::log(static_cast<double>(n)); res.n_gpus = static_cast<int>(world);
+    double inv_ess = 0, secs = 0;
+    for (const auto& x : rr) { const double w = std::exp(x.log_norm - L); inv_ess += w * w / x.ess; secs = std::max(secs, x.run_seconds); }
+    res.ess = 1.0 / inv_ess; res.run_seconds = secs;
+    for (std::size_t k = 0; k < res.predicts.size(); ++k) {
+        PredictStats& p = res.predicts[k];
+        if (p.is_int) {
+            std::size_t top = 0;
+            for (const auto& x : rr) top = std::max(top, x.predicts[k].probabilities.size());
+            p.probabilities.assign(top, 0.0);
+            for (const auto& x : rr) { const double w = std::exp(x.log_norm - L); for (std::size_t s2 = 0; s2 < x.predicts[k].probabilities.size(); ++s2) p.probabilities[s2] += w * x.predicts[k].probabilities[s2]; }
+        } else {
+            const std::size_t D = p.mean_nd.size();
+            std::vector<double> m1(D, 0.0), m2(D, 0.0);
+            for (const auto& x : rr) {
+                const double w = std::exp(x.log_norm - L);
+                for (std::size_t d = 0; d < D; ++d) { const double m = x.predicts[k].mean_nd[d]; m1[d] += w * m; m2[d] += w * (x.predicts[k].variance_nd[d] + m * m); }
+            }
+            for (std::size_t d = 0; d < D; ++d) { p.mean_nd[d] = m1[d]; p.variance_nd[d] = m2[d] - m1[d] * m1[d]; }
+            p.mean = p.mean_nd[0]; p.variance = p.variance_nd[0];
+        }
+    }
+    if (store) {
+        // the shards' traces side by side, in global particle order
+        const std::size_t n_real = st.real_rows(), n_int = st.int_ids.size();
+        store->n = n; store->logw.resize(n); store->real.resize(n_real * n); store->ints.resize(n_int * n);
+        for (std::size_t r = 0; r < world; ++r) {
+            const std::size_t nr = begin[r + 1] - begin[r];
+            std::copy(hs[r].logw.begin(), hs[r].logw.end(), store->logw.begin() + begin[r]);
+            for (std::size_t row = 0; row < n_real; ++row) std::copy(hs[r].real.begin() + row * nr, hs[r].real.begin() + (row + 1) * nr, store->real.begin() + row * n + begin[r]);
+            for (std::size_t row = 0; row < n_int; ++row) std::copy(hs[r].ints.begin() + row * nr, hs[r].ints.begin() + (row + 1) * nr, store->ints.begin() + row * n + begin[r]);
+        }
+    }
+}
+
 // ---- Markov probe (cpprob/detail/host_trace.hpp: ProbeState): the smallest window of past samples a step depends on, or -1 ------
 template <class Func, class ObsTuple>
 int probe_markov_window(const Func& f, const ObsTuple& obs, const detail::TraceStructure& st)
@@ -371,8 +440,12 @@ void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>
     HostStore hs;
     HostStore* store = opt.dump ? &hs : nullptr;
     if (opt.devices.size() > 1) {
-        if (e->builtin_model < 0) throw std::runtime_error("cpprob::inference: several GPUs (cpprob::gpu::options().devices) serve built-in models only");
-        run_builtin_group(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
+        const bool builtin = e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic);
+        if (builtin) run_builtin_group(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
+        else if (algorithm == StateType::sis && e->generic) run_generic_sharded_sis(*e, &obs, n, st, opt, res, store);
+        else throw std::runtime_error("cpprob::inference: over several GPUs (cpprob::gpu::options().devices) an unchanged model runs under StateType::sis "
+                                      "(shards need no communication); StateType::smc over several GPUs serves the built-in models -- the joint "
+                                      "resampling of replayed traces is not built");
     }
     else if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic || (st.vector_statements && !e->generic_vectors)))
         run_builtin(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);

@@ -98,9 +98,11 @@ inline void hip_check(hipError_t e, const char* what)
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
-// One attempt with S trace rows per particle; returns true when some particle needed more (nothing in res is valid then).
+// One attempt with S trace rows per particle; returns 0, or -- nothing in res is valid then -- 1 when some particle needed more rows,
+// 3 when the lanes of a wavefront executed different statements under windowed replay (the model's statement counts do depend on
+// sampled values: the caller repeats the run with full replay).
 template <class Caller>
-bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
+int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
                      Result& res, HostStore* store, const std::size_t S)
 {
     using Tuple = typename Caller::observes_t;
@@ -129,7 +131,7 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
     const dim3 grid((unsigned)((n + device::kLaneBlock - 1) / device::kLaneBlock)), block(device::kLaneBlock);
 
     ModelKernelArgs a{};
-    a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed; a.trace_cap = (uint32_t)S; a.overflow = d_overflow.p;
+    a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed; a.trace_cap = (uint32_t)S; a.overflow = d_overflow.p; a.pid0 = opt.particle_offset;
     a.pred_real_cap = (uint32_t)n_real; a.pred_int_cap = (uint32_t)n_int;
     // (windowed replay's buffers: allocated before the clock starts, like the others)
     const bool windowed = smc && st.window >= 0;
@@ -138,6 +140,14 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
     DevBuf<int32_t> d_anc_all(windowed ? (size_t)T * n : 0);
     DevBuf<double> d_real_gen(windowed ? n_real * n : 0);
     DevBuf<int32_t> d_int_gen(windowed ? n_int * n : 0);
+    // SMC bookkeeping between two launches of the model body, on the device: systematic resampling runs on fixed-point weights
+    // (integer masses: three short launches, cpprob_amd/csrc/bookkeep_fixed.hpp), the other resamplers on the floating-point CDF
+    auto bookkeep = [&](const double* lw, int t, bool last, int32_t* anc_out, double* ess, int32_t* resd, double* logz) {
+        if (opt.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && n <= (std::size_t(1) << 28))
+            ctx.check(cpprob_hip_smc_bookkeep_fixed(ctx.get(), lw, n, opt.seed, t, last ? 1 : 0, opt.ess_threshold, ess, resd, logz, anc_out), "cpprob_hip_smc_bookkeep_fixed");
+        else
+            ctx.check(cpprob_hip_smc_bookkeep(ctx.get(), opt.resampler, lw, n, opt.seed, t, last ? 1 : 0, opt.ess_threshold, ess, resd, logz, anc_out), "cpprob_hip_smc_bookkeep");
+    };
     const auto t_start = std::chrono::steady_clock::now();
     double log_z = 0.0;
     int cur = 0, n_resampled = 0;
@@ -170,8 +180,7 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
             hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
             hip_check(hipGetLastError(), "model_kernel");
             cur ^= 1;
-            ctx.check(cpprob_hip_smc_bookkeep(ctx.get(), opt.resampler, logw[cur], n, opt.seed, t, last ? 1 : 0, opt.ess_threshold,
-                                              d_ess.p, d_res.p, d_logz.p, last ? d_anc.p : d_anc_all.p + (size_t)(t + 1) * n), "cpprob_hip_smc_bookkeep");
+            bookkeep(logw[cur], t, last, last ? d_anc.p : d_anc_all.p + (size_t)(t + 1) * n, d_ess.p, d_res.p, d_logz.p);
         }
         // traces: hit h was recorded in the slots of generation step(h); follow every final particle's lineage back to it
         auto gens = [&](const std::vector<int>& steps) { std::vector<int32_t> g; for (int s2 : steps) g.push_back(std::min(s2, T - 1)); return g; };
@@ -208,8 +217,7 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
             hip_check(hipGetLastError(), "model_kernel");
             cur ^= 1;
             // normalise, ESS test (thesis p.37), evidence, ancestors of the next generation: all on the device
-            ctx.check(cpprob_hip_smc_bookkeep(ctx.get(), opt.resampler, logw[cur], n, opt.seed, t, last ? 1 : 0, opt.ess_threshold,
-                                              d_ess.p, d_res.p, d_logz.p, d_anc.p), "cpprob_hip_smc_bookkeep");
+            bookkeep(logw[cur], t, last, d_anc.p, d_ess.p, d_res.p, d_logz.p);
         }
         std::vector<double> h_ess((size_t)T);
         std::vector<int32_t> h_res((size_t)T);
@@ -257,7 +265,7 @@ bool generic_attempt(StateType algorithm, const void* observes_v, std::size_t n,
     if (overflow == 2)
         throw std::runtime_error("cpprob::inference: a particle executed more predict statements than the model's dry run did; the number "
                                  "and order of observe / predict statements must not depend on sampled values on the device path");
-    return overflow != 0;
+    return overflow == 3 ? 3 : (overflow != 0 ? 1 : 0);
 }
 
 template <class Caller>
@@ -267,8 +275,14 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     // trace rows: the structural dry run saw st.n_sample sample statements; particles of models with data-dependent loops
     // (rejection sampling) may execute more -- start with head-room, and on overflow repeat the run with 4x the rows
     std::size_t S = 4 * st.n_sample + 16;
-    for (int attempt = 0; attempt < 4; ++attempt, S *= 4)
-        if (!generic_attempt<Caller>(algorithm, observes_v, n, st, opt, res, store, S)) return;
+    detail::TraceStructure st_full = st;
+    const detail::TraceStructure* use = &st;
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        const int rc = generic_attempt<Caller>(algorithm, observes_v, n, *use, opt, res, store, S);
+        if (rc == 0) return;
+        if (rc == 3) { st_full.window = -1; use = &st_full; }      // the device saw what the host probe did not: replay the whole trace
+        else S *= 4;
+    }
     throw std::runtime_error("cpprob::inference(smc): a particle executed more than " + std::to_string(S / 4) + " sample statements "
                              "(data-dependent loop, e.g. rejection sampling, that rarely terminates); use StateType::sis for this model");
 }

@@ -18,7 +18,8 @@ struct Options {
                                                       // one GPU holding every particle would (exchange scope: per step an RCCL all-gather of the
                                                       // rank totals and the redistribution of offspring over xGMI; cpprob_hip_group_*).  All
                                                       // entries equal: every rank on that one GPU (loopback transport; a one-GPU machine's way
-                                                      // to run the protocol).  Built-in models only.
+                                                      // to run the protocol).  Built-in models; unchanged models (CPPROB_REGISTER_MODEL) under
+                                                      // StateType::sis, whose shards need no communication until their sums are combined.
     std::uint64_t seed = 12345;
     int resampler = CPPROB_HIP_RESAMPLE_SYSTEMATIC;   // smc
     double ess_threshold = 0.5;                       // smc: resample when ESS < threshold * N (thesis p.37); > 1: every step
@@ -30,6 +31,7 @@ struct Options {
     bool keep_history = true;                         // smc, built-in models on one GPU: false = filtering only -- O(N) particle store instead of O(N T),
                                                       // every predict hit's numbers under its own generation's weights, no posterior files
                                                       // (cpprob_hip_config::keep_history)
+    std::uint64_t particle_offset = 0;                // (set by the engine when it shards a population: global id of this shard's first particle)
     bool progress = false;
     int replicates = 1;                               // built-in models: R independent runs (seeds seed .. seed + R - 1), up to three in
                                                       // flight on separate contexts; Result then carries their spread (error bars)

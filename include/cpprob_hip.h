@@ -372,6 +372,11 @@ int cpprob_hip_resample(cpprob_hip_ctx* ctx, int32_t kind, const double* d_logw,
  * as cpprob_hip_resample(seed, step + 1). */
 int cpprob_hip_smc_bookkeep(cpprob_hip_ctx* ctx, int32_t kind, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last,
                             double ess_frac, double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc);
+/* The same bookkeeping for SYSTEMATIC resampling on fixed-point weights (cpprob_amd/csrc/step_fixed.hpp, bookkeep_fixed.hpp): the
+ * weights become integers q_i = min(rint(exp(logw_i - max logw) 2^32), 2^32 - 1), sums and the resampling comb run on exact 64-bit
+ * masses -- three short launches, no floating-point CDF; uniforms as above.  d_anc may be NULL when last != 0.  n <= 2^28. */
+int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* ctx, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last, double ess_frac,
+                                  double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc);
 /* Traces from per-step records: d_anc [T][n] (row t: slot of generation t-1 that slot i of generation t extends; a row counts only where
  * d_resampled[t-1] != 0), d_cols [H][n] with row h recorded in the slots of generation h_gen[h] (non-decreasing in h).  d_out[h][i] =
  * d_cols[h][slot of generation h_gen[h] on the ancestral line of FINAL particle i]: the value particle i's trace holds for that row.

@@ -255,7 +255,7 @@ def test_cpp_host_shards_one_population_over_several_ranks(tmp_path):
     """SURVEY 8(e) from the C++14 host: cpprob::gpu::options().devices (cpprob_main --devices) makes cpprob::inference run ONE
     joint population over several ranks -- here three on this GPU (loopback transport; distinct devices take RCCL over xGMI) --
     through cpprob_hip_group_*: the answers, the dump and the estimators are those of the single-GPU call, bit for bit (hmm<16>,
-    every-step schedule: integer prefix counts), and within a couple of boundary offspring for continuous weights."""
+    every-step schedule: integer prefix counts; continuous weights, ESS-triggered: fixed-point weights)."""
     obs = np.load(os.path.join(GOLD, "observations.npz"))["hmm16"]
     n = 150001
     common = ["--model", "hmm16", "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 3, "--ess_threshold", 2.0, "--json"]
@@ -272,9 +272,39 @@ def test_cpp_host_shards_one_population_over_several_ranks(tmp_path):
     one, _, _ = run_main(tmp_path, *common)
     two, _, _ = run_main(tmp_path, *common, "--devices", "0,0")
     assert two["n_gpus"] == 2 and two["n_resampled"] == one["n_resampled"]
-    assert abs(two["log_evidence"] - one["log_evidence"]) < 1e-9
+    assert two["log_evidence"] == one["log_evidence"]                 # fixed-point weights: the two-rank run IS the one-GPU run
     for a, b in zip(one["predicts"], two["predicts"]):
-        assert abs(a["mean"] - b["mean"]) < 1e-3 and abs(a["variance"] - b["variance"]) < 1e-3
+        assert abs(a["mean"] - b["mean"]) < 1e-12 and abs(a["variance"] - b["variance"]) < 1e-12
+
+
+@pytest.mark.parametrize("model,obs", [("hmm16", None), ("poisson_rate", "3 5"), ("gaussian_by_rejection", "3.0 4.0")])
+def test_unchanged_model_shards_over_several_devices_under_sis(tmp_path, model, obs):
+    """SURVEY 8(e) for the unchanged-model path: under StateType::sis the shards of a population need no communication, so
+    cpprob::gpu::options().devices (cpprob_main --generic --devices) runs the model body for contiguous blocks of particles on every
+    device -- global particle ids select the random streams -- and combines the shards by their evidence.  Three shards on this GPU:
+    every trace and every weight of the dump equals the one-device run's (per-particle parity), the estimators agree to rounding;
+    StateType::smc over several devices is refused for unchanged models with a message that says what does run."""
+    if obs is None:
+        obs = obs_str(np.load(os.path.join(GOLD, "observations.npz"))["hmm16"])
+    n = 50001
+    common = ["--model", model, "--sis", "--observes", obs, "--n_samples", n, "--seed", 9, "--json", "--generic"]
+    one, _, _ = run_main(tmp_path, *common, "--generated_file", "one")
+    many, _, _ = run_main(tmp_path, *common, "--generated_file", "many", "--devices", "0,0,0")
+    assert not one["builtin"] and not many["builtin"] and many["n_gpus"] == 3 and one["n_gpus"] == 1
+    assert abs(many["log_evidence"] - one["log_evidence"]) < 1e-10 and abs(many["ess"] - one["ess"]) < 1e-6 * one["ess"]
+    for a, b in zip(one["predicts"], many["predicts"]):
+        if "p" in a:
+            np.testing.assert_allclose(a["p"], b["p"], rtol=0, atol=1e-12)
+        else:
+            assert abs(a["mean"] - b["mean"]) < 1e-11 and abs(a["variance"] - b["variance"]) < 1e-11
+    for ext in ("int", "real"):
+        f1, f2 = tmp_path / ("one_sis." + ext), tmp_path / ("many_sis." + ext)
+        assert f1.exists() == f2.exists()
+        if f1.exists():
+            assert open(str(f1)).read() == open(str(f2)).read()
+    if model == "hmm16":
+        _, out, err = run_main(tmp_path, "--model", model, "--smc", "--observes", obs, "--n_samples", n, "--generic", "--devices", "0,0", expect_rc=2)
+        assert "StateType::sis" in err and "built-in" in err
 
 
 def test_vector_statements_run_through_the_generic_device_path(tmp_path):
