@@ -529,6 +529,7 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         a.u0 = t > 0 ? host_resample_u0(c->run_seed, (uint64_t)t) : 0.0;
         a.bound = c->h_bound[(size_t)t]; a.bound_prev = t > 0 ? c->h_bound[(size_t)t - 1] : 0.0;
         a.ess_frac = c->cfg.ess_threshold; a.may_carry = c->cfg.ess_threshold > 1.0 ? 0 : 1;
+        a.prefetch = (!a.may_carry || c->nb <= 2048) ? 1 : 0;
         a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
         a.all_totals = reinterpret_cast<const uint64_t*>(all_totals); a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
         a.row_w = c->keep ? t : (t & 1); a.row_r = t > 0 ? (c->keep ? t - 1 : ((t - 1) & 1)) : 0;
@@ -1526,7 +1527,15 @@ int cpprob_hip_copy_ancestors(cpprob_hip_ctx* c, int32_t* h, size_t n_bytes)
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
     if (!c->keep) return fail(c, CPPROB_HIP_ESTATE, "the run kept no history (keep_history = 0): traces and ancestors do not exist; its statistics are the filtering ones");
     if (c->cfg.algorithm != CPPROB_HIP_ALG_SMC) return fail(c, CPPROB_HIP_ESTATE, "SIS keeps no ancestors (every trace is its own line)");
-    return copy_rows(c, h, c->d_anc, sizeof(int32_t), (size_t)c->T, n_bytes, (size_t)c->rs);
+    if (int rc = copy_rows(c, h, c->d_anc, sizeof(int32_t), (size_t)c->T, n_bytes, (size_t)c->rs)) return rc;
+    if (c->final_from_fixed) {
+        // the fixed-point step stores a row only where it resampled: the identity of the other rows is written here
+        std::vector<int32_t> res((size_t)c->T, 0);
+        HIP_TRY(c, hipMemcpy(res.data(), c->d_resampled, (size_t)c->T * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int t = 1; t < c->T; ++t)
+            if (!res[(size_t)t - 1]) for (int64_t i = 0; i < c->n; ++i) h[(size_t)t * (size_t)c->n + (size_t)i] = (int32_t)i;
+    }
+    return 0;
 }
 
 int cpprob_hip_copy_logw(cpprob_hip_ctx* c, double* h, size_t n_bytes)

@@ -368,6 +368,9 @@ struct StepFixedArgs {
     double u0;                                 // systematic offset of the resampling before step t (Philox, evaluated on the host)
     double bound_prev, bound;                  // B_{t-1}, B_t
     double ess_frac; int may_carry;            // may_carry = 0: every step resamples (known on the host): no log-weight ever carries
+    int prefetch;                              // fetch the three likely source tiles' weights at kernel entry (a round trip saved where the
+                                               // launch is latency-bound or always resamples; 12 wasted bytes per particle on a large
+                                               // population's steps that do not resample)
     StepCtrl* ctrl; double n_pop; double* ess_trace; int32_t* resampled;
     const uint64_t* all_totals; int world, rank;       // one shard of a joint population (exchange scope): every rank's {S, Q, key(M)} of generation t-1
     const int64_t* annex_base;
@@ -415,9 +418,11 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
     double lw_carry[kPPT];
     lane_fill(lw_carry, 0.0);
     if (t > 0) {
-        q_0 = *reinterpret_cast<const U4*>(a.q_prev + j0);
-        q_m1 = *reinterpret_cast<const U4*>(a.q_prev + (bid > 0 ? j0 - kTile : j0));
-        q_p1 = *reinterpret_cast<const U4*>(a.q_prev + (bid + 1 < nb ? j0 + kTile : j0));
+        if (a.prefetch) {
+            q_0 = *reinterpret_cast<const U4*>(a.q_prev + j0);
+            q_m1 = *reinterpret_cast<const U4*>(a.q_prev + (bid > 0 ? j0 - kTile : j0));
+            q_p1 = *reinterpret_cast<const U4*>(a.q_prev + (bid + 1 < nb ? j0 + kTile : j0));
+        }
         if (searcher) {
             ftot_fetch(a.f, tw);
             probe_fetch(a.f.h, bid, nb, pw0);
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
         ref = s_found.ref;
         if (resample) {
             fc.inv = s_found.inv; fc.base = s_found.base;
-            fixed_walk(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, bid, true, q_m1, q_0, q_p1, anc, L);
+            fixed_walk(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, bid, a.prefetch != 0, q_m1, q_0, q_p1, anc, L);
             if (SHARDED) {
                 const int64_t l0 = s_found.l0, l1 = s_found.l1;
                 const int64_t col0 = a.ld + a.annex_base[t - 1];
@@ -510,7 +515,9 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
     for (int q = 0; q < kPPT / 4; ++q)                                                        // sample #t
         Model::apply4(a.mp, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
     store4_as(a.values + (int64_t)a.row_w * a.rs, j0, x);                                     // predict #t
-    if (a.anc) store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
+    // (a step that follows no resampling extends every slot by itself: nobody walks that row -- the read-out, the exchange packing
+    //  and the skip rows test resampled[t-1] first, and cpprob_hip_copy_ancestors writes the identity on its way out)
+    if (a.anc && (t == 0 || resample)) store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
 
     // ---- observe #t: log-weights, integer weights, the tile's mass / squares / maximum ----
     double lw[kPPT];
@@ -526,9 +533,9 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
         s_l += w; q_l += (uint64_t)(w >> 16) * (uint64_t)(w >> 16);
         m_l = fmax(m_l, lw[k]);
     }
-    *reinterpret_cast<U4*>(a.q_next + j0) = q;
-    if (a.may_carry || t + 1 == a.T) store4(a.logw_next, j0, lw);
-    // (the tile's totals by DPP reductions: three same-address 64-bit LDS atomics per lane were measured at 1.7x the whole step)
+    // (the tile's totals by DPP reductions: three same-address 64-bit LDS atomics per lane were measured at 1.7x the whole step);
+    // published BEFORE this workgroup's weight / log-weight stores are issued: the hierarchy's atomics -- and, above 4096 tiles, the
+    // wait in front of the arrival count -- travel under them instead of behind them
     const uint64_t s_w = wave_sum_u64(s_l), q_w = wave_sum_u64(q_l), m_w = wave_max_u64(dkey(m_l));
     if (lane_id() == 0) { s_red[wave_id()] = s_w; s_red[kWaves + wave_id()] = q_w; s_red[2 * kWaves + wave_id()] = m_w; }
     __syncthreads();
@@ -538,6 +545,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
         for (int w = 0; w < kWaves; ++w) { St += s_red[w]; Qt += s_red[kWaves + w]; Mk = umax64(Mk, s_red[2 * kWaves + w]); }
         fhier_publish(a.f, bid, nb, St, Qt, Mk);
     }
+    *reinterpret_cast<U4*>(a.q_next + j0) = q;
+    if (a.may_carry || t + 1 == a.T) store4(a.logw_next, j0, lw);
 }
 
 // ---- the run's last generation ------------------------------------------------------------------------------------------------
