@@ -56,6 +56,7 @@ struct cpprob_hip_ctx {
     bool final_from_counts = false, final_bookkeep_pending = false; int final_copy = 0;
     bool scan2_deferred = false;         // exchange scope, floating-point form: step_end left the cross-rank combine to the plan launch
     bool keep = true, cap_keep = true;   // keep_history: per-step values + ancestors (false: two rows, no ancestors, filtering statistics)
+    double* d_filter_w = nullptr;        // filtering-only shards: [T] this shard's mass of generation t (the joint normaliser is their sum over ranks)
     double* d_fpart = nullptr;           // filtering-only runs, floating-point form: [T][K + 2][smooth_grid] (filter_partials_kernel)   // prefix-count form, single shard: the read-out works from the final generation's counts
     double* d_ll_tab = nullptr;     // hmm: [T][3] emission log-densities
     void* d_values = nullptr;
@@ -114,6 +115,10 @@ struct cpprob_hip_ctx {
     bool counts_mode = false;                              // this run's steps use smc_step_counts_kernel
     bool fixed_mode = false;                               // ... or smc_step_fixed_kernel (fixed-point weights, step_fixed.hpp)
     bool final_from_fixed = false;                         // the read-out takes its weights from the final generation's integer weights
+    // The fixed-point weights are taken against a reference fixed before the generation exists (step_fixed.hpp); where some
+    // generation's heaviest particle sat far below it (an observation many standard deviations from every particle) they lose bits.
+    // The first call that reads a run's results checks the run's largest gap and repeats the run in the floating-point form.
+    bool force_fp = false, fixed_check_pending = false, last_was_infer_run = false; uint64_t last_run_index = 0;
     uint32_t* d_q[2] = {nullptr, nullptr};                 // [ld] integer weights of the fixed-point form, ping-pong
     std::vector<double> h_bound;                           // [T] upper bound of each step's incremental log-weight (host-evaluated)
     size_t hier_q0_off = 0, hier_m0_off = 0;               // the tiles' Q / M arrays inside one copy of the hierarchy
@@ -488,7 +493,7 @@ template <class Model>
 bool fixed_eligible(const cpprob_hip_ctx* c)
 {
     constexpr bool model_ok = std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value;
-    return model_ok && !(c->cfg.flags & CPPROB_HIP_FLAG_FLOATING_POINT_STEP) && c->nb <= kCountsMaxTiles && c->pop_n <= (1ull << 28) &&
+    return model_ok && !c->force_fp && !(c->cfg.flags & CPPROB_HIP_FLAG_FLOATING_POINT_STEP) && c->nb <= kCountsMaxTiles && c->pop_n <= (1ull << 28) &&
            c->cfg.algorithm == CPPROB_HIP_ALG_SMC && c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && !counts_eligible<Model>(c) &&
            (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND);
 }
@@ -645,7 +650,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]);
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
 }
 
@@ -755,7 +760,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     c->pop_n = island ? cfg->n_particles : cfg->n_global;
     c->T = model_T(cfg->model, n_obs);
     c->n_obs = (int)n_obs;
-    c->begun = false; c->step_protocol = false; c->step_t = -1;
+    c->begun = false; c->step_protocol = false; c->step_t = -1; c->force_fp = false; c->fixed_check_pending = false;
     // the read-out keeps kWaves * T * kStats accumulators in LDS (smooth_kernel)
     if ((size_t)kWaves * (size_t)c->T * 3 * sizeof(double) > 64 * 1024) return fail(c, CPPROB_HIP_EUNSUPPORTED, "too many predict hits per trace for the read-out kernel's LDS accumulators (T <= 682)");
     c->is_int = cfg->model == CPPROB_HIP_MODEL_HMM3;
@@ -770,12 +775,17 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     // keep_history = 0: filtering only -- two rows of values, no ancestors, predict hit t's statistics under generation t's own
     // weights.  SIS traces are their own lines (nothing to drop); a joint population's migration moves lineages (nothing to move).
     c->keep = cfg->keep_history != 0 || !smc;
-    if (!c->keep && (exchange || (cfg->resample_scope != CPPROB_HIP_SCOPE_ISLAND && cfg->n_global != cfg->n_particles)))
-        return fail(c, CPPROB_HIP_EUNSUPPORTED, "keep_history = 0 (filtering only) serves one population per context: not a shard of a joint population");
+    // (a shard of a joint population keeps no history in the exchange scope only: its migrants are then their current state alone)
+    if (!c->keep && !exchange && cfg->resample_scope != CPPROB_HIP_SCOPE_ISLAND && cfg->n_global != cfg->n_particles)
+        return fail(c, CPPROB_HIP_EUNSUPPORTED, "keep_history = 0 (filtering only) serves one population per context or a shard in the exchange scope: not a locally resampled shard");
 
     c->exchange = exchange;
     // exchange scope: room for immigrant lineages next to every row (grown on demand by cpprob_hip_exchange_commit)
-    const int64_t annex_want = cfg->annex_kcols > 0 ? (int64_t)cfg->annex_kcols * 1024 : std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile);
+    // default: what a well-mixed run needs -- a rank's offspring interval leaves its shard by O(sqrt(N)) outputs per resampling, so
+    // ~sqrt(n_global) immigrants per step and T steps of them (measured 0.5 sqrt(N) per rank-step on BASELINE configs[3]) -- and at
+    // least a sixteenth of the shard; a run that needs more reports overflow and is repeated with four times as much
+    const int64_t annex_mixed = (int64_t)(std::sqrt((double)cfg->n_global) * (double)c->T) / kTile * kTile;
+    const int64_t annex_want = cfg->annex_kcols > 0 ? (int64_t)cfg->annex_kcols * 1024 : std::max<int64_t>(std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile), annex_mixed);
     const int64_t annex0 = exchange ? std::max<int64_t>(c->annex_cap, annex_want) : 0;
     c->ssz = 8;
     dispatch_model(c, [&](auto m) { c->ssz = sizeof(typename decltype(m)::store_t); c->grid_refs = decltype(m)::kWeightTable == 0; });
@@ -799,7 +809,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         // (ancestor and skip rows start as zeros -- a valid slot: a run that overflowed its transport still walks its lineages once,
         //  through annex columns nobody committed, before the host sees the flag and repeats it)
         if (c->keep) { HIP_TRY(c, hipMalloc(&c->d_anc, T * rs * sizeof(int32_t))); HIP_TRY(c, hipMemsetAsync(c->d_anc, 0, T * rs * sizeof(int32_t), c->stream)); }
-        else HIP_TRY(c, hipMalloc(&c->d_fpart, T * (8 + 2) * (size_t)c->smooth_grid * sizeof(double)));
+        else { HIP_TRY(c, hipMalloc(&c->d_fpart, T * (8 + 2) * (size_t)c->smooth_grid * sizeof(double))); HIP_TRY(c, hipMalloc(&c->d_filter_w, T * sizeof(double))); }
         if (want_skip) {
             HIP_TRY(c, hipMalloc(&c->d_skip, (T / kSkipEvery + 1) * rs * sizeof(int32_t)));
             HIP_TRY(c, hipMemsetAsync(c->d_skip, 0, (T / kSkipEvery + 1) * rs * sizeof(int32_t), c->stream));
@@ -998,13 +1008,39 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
                 c->final_bookkeep_pending = false;
                 hipLaunchKernelGGL(fixed_filter_final_kernel, dim3(1), dim3(kWave), 0, c->stream, ff);
             }
-            hipLaunchKernelGGL(filter_finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream, (const double*)c->d_fpart, c->smooth_grid, c->K, c->is_int ? 1 : 0, c->d_stats);
+            hipLaunchKernelGGL(filter_finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream, (const double*)c->d_fpart, c->smooth_grid, c->K, c->is_int ? 1 : 0, c->d_stats, 1, (double*)nullptr);
         }
     } else if (!readout_done) dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
+    c->fixed_check_pending = c->fixed_mode && c->cfg.algorithm == CPPROB_HIP_ALG_SMC; c->last_was_infer_run = true; c->last_run_index = run_index;
     return 0;
 }
+
+}  // extern "C"
+namespace {
+// 6 nats = 9 of the 32 bits: the heaviest particle of every generation carried at least a 23-bit weight (a gap opens where an
+// observation lies more than ~3.5 standard deviations from EVERY particle: populations of thousands and more never see one)
+constexpr double kFixGapLimit = 6.0;
+// Before a run's results leave the library: did the fixed-point weights keep their bits?  If not the run is repeated in the
+// floating-point form (runs the caller drives step by step cannot be repeated here: CPPROB_HIP_EPRECISION).
+int settle_fixed(cpprob_hip_ctx* c)
+{
+    if (!c->fixed_check_pending) return 0;
+    c->fixed_check_pending = false;
+    StepCtrl h{};
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h.fix_gap <= kFixGapLimit) return 0;
+    if (!c->last_was_infer_run)
+        return fail(c, CPPROB_HIP_EPRECISION, "some generation's heaviest particle sat more than 6 nats below the fixed-point reference (an observation far from every particle): "
+                                               "repeat the run with CPPROB_HIP_FLAG_FLOATING_POINT_STEP");
+    c->force_fp = true;
+    return cpprob_hip_infer_run(c, c->last_run_index);
+}
+}  // namespace
+extern "C" {
 
 int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, double* d_local_totals)
 {
@@ -1102,9 +1138,23 @@ int cpprob_hip_smc_finish(cpprob_hip_ctx* c)
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
     if (!c->begun || !c->step_protocol || c->step_t != c->T - 1) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_finish follows the last step's cpprob_hip_smc_step_end");
     HIP_TRY(c, hipSetDevice(c->device));
-    dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
+    if (!c->keep) {
+        // filtering-only shard: every step left its statistics -- the count form the JOINT population's probabilities (from the
+        // all-gathered totals: nothing to combine), the fixed-point form this shard's raw sums and masses (the caller adds them
+        // over ranks and divides: cpprob_hip_filter_masses)
+        if (c->fixed_mode) hipLaunchKernelGGL(filter_finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream, (const double*)c->d_fpart, c->smooth_grid, c->K, c->is_int ? 1 : 0, c->d_stats, 0, c->d_filter_w);
+    } else dispatch_model(c, [&](auto m) { launch_smooth<decltype(m)>(c, false); });
     HIP_TRY(c, hipGetLastError());
     c->ran = true;
+    c->fixed_check_pending = c->fixed_mode; c->last_was_infer_run = false;
+    return 0;
+}
+
+int cpprob_hip_filter_masses(cpprob_hip_ctx* c, double** d_masses, int32_t* joint_already)
+{
+    if (!c || !d_masses || !joint_already) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->begun || c->keep) return fail(c, CPPROB_HIP_ESTATE, "not a filtering-only run (keep_history = 0)");
+    *d_masses = c->d_filter_w; *joint_already = c->counts_mode ? 1 : 0;
     return 0;
 }
 
@@ -1138,6 +1188,7 @@ int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
     g.slot_of_rank = fixed_layout ? c->d_slot_of_rank : nullptr; g.cap = fixed_layout ? c->x_cap : (int64_t)1 << 40;
     g.annex_cap = fixed_layout ? c->annex_cap : (int64_t)1 << 40;      // (callers that synchronise grow the annex themselves)
     g.bytes_per_value = (int)(fixed_layout ? c->ssz : (c->is_int ? sizeof(int32_t) : sizeof(double))); g.sent_per_step = c->d_sent;
+    g.no_history = c->keep ? 0 : 1;
     PlanCountsIn pc{};
     pc.all_totals = c->x_all_totals; pc.n_pop = (double)c->pop_n;
     if (c->fixed_mode) {
@@ -1165,14 +1216,15 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid, bool plan_inside
 {
     PackArgs<Model, R> a{};
     if (c->x_direct && c->x_fixed) { a.peer_recv = c->d_peer_recv; a.peer_slot = c->d_peer_slot; a.cap = c->x_cap; }
+    a.geom.no_history = c->keep ? 0 : 1;
     if (plan_inside) {
         a.geom.world = c->x_world; a.geom.rank = c->x_rank; a.geom.n = c->n; a.geom.shard_begin = c->d_shard_begin; a.geom.slot_of_rank = c->d_slot_of_rank;
-        a.geom.cap = c->x_cap; a.geom.annex_cap = c->annex_cap; a.geom.bytes_per_value = (int)c->ssz; a.geom.sent_per_step = c->d_sent;
+        a.geom.cap = c->x_cap; a.geom.annex_cap = c->annex_cap; a.geom.bytes_per_value = (int)c->ssz; a.geom.sent_per_step = c->d_sent; a.geom.no_history = c->keep ? 0 : 1;
         a.annex_base = c->d_annex_base; a.plan_out = c->d_xplan;
     }
     a.values = static_cast<const typename Model::store_t*>(c->d_values); a.anc = c->d_anc; a.rs = c->rs; a.n = c->n; a.nb = c->nb;
     a.resampled = c->d_resampled; a.t = t; a.plan = c->d_xplan; a.world = c->x_world; a.rank = c->x_rank; a.send = d_send;
-    a.skip = (c->d_skip && t >= 2 * kSkipEvery) ? c->d_skip : nullptr;
+    a.skip = (c->keep && c->d_skip && t >= 2 * kSkipEvery) ? c->d_skip : nullptr;
     const dim3 pgrid((unsigned)grid, a.skip ? (unsigned)(t / kSkipEvery + 1) : 1u);
     a.pc.all_totals = c->x_all_totals; a.pc.n_pop = (double)c->pop_n;
     a.wrel = c->d_wrel[c->cur]; a.bc = c->d_bc; a.bf = c->d_bf; a.ctrl = c->d_ctrl; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
@@ -1390,6 +1442,7 @@ int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* c, int32_t t)
     if (!c->step_protocol || c->step_t != t || !c->x_all_totals) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_pack_async(t) follows cpprob_hip_smc_step_end(t)");
     if (t < 0 || t + 1 >= c->T) return fail(c, CPPROB_HIP_EINVAL, "no exchange follows the last step");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->keep && !c->counts_mode && !c->fixed_mode) return fail(c, CPPROB_HIP_EUNSUPPORTED, "filtering-only shards run on the integer forms of the step (systematic resampling)");
     // count form: the plan is a pure function of the all-gathered totals -- every packing workgroup derives it on its first wavefront
     // and workgroup 0 stores it (one launch less per step); floating-point form: the plan launch also combines the ranks' totals
     const bool plan_inside = c->counts_mode || c->fixed_mode;
@@ -1440,6 +1493,7 @@ int cpprob_hip_infer_summary(cpprob_hip_ctx* c, cpprob_hip_summary* out)
 {
     if (!c || !out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (int rc = settle_fixed(c)) return rc;
     StepCtrl h{};
     HIP_TRY(c, hipMemcpyAsync(&h, c->d_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1451,6 +1505,8 @@ int cpprob_hip_infer_summary(cpprob_hip_ctx* c, cpprob_hip_summary* out)
     out->stats_per_predict = c->K;
     out->is_int = c->is_int ? 1 : 0;
     out->n_resampled = h.n_resampled;
+    out->step_form = c->cfg.algorithm != CPPROB_HIP_ALG_SMC ? CPPROB_HIP_FORM_FLOAT : (c->fixed_mode ? CPPROB_HIP_FORM_FIXED : (c->counts_mode ? CPPROB_HIP_FORM_COUNTS : CPPROB_HIP_FORM_FLOAT));
+    out->reserved = 0;
     return 0;
 }
 
@@ -1458,6 +1514,7 @@ int cpprob_hip_infer_stats(cpprob_hip_ctx* c, double* h_stats, size_t n_doubles)
 {
     if (!c || !h_stats) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (int rc = settle_fixed(c)) return rc;
     const size_t need = (size_t)c->T * c->K;
     if (n_doubles < need) return fail(c, CPPROB_HIP_EINVAL, "h_stats too small");
     HIP_TRY(c, hipMemcpyAsync(h_stats, c->d_stats, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1482,6 +1539,7 @@ int cpprob_hip_infer_step_trace(cpprob_hip_ctx* c, double* h_ess, int32_t* h_res
 {
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (int rc = settle_fixed(c)) return rc;
     if (c->cfg.algorithm == CPPROB_HIP_ALG_SIS) {
         // one weighting pass: only the final entry is defined
         if (h_ess) { for (int t = 0; t < c->T; ++t) h_ess[t] = 0.0; }
@@ -1508,6 +1566,7 @@ int cpprob_hip_copy_values(cpprob_hip_ctx* c, void* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (int rc = settle_fixed(c)) return rc;
     if (!c->keep) return fail(c, CPPROB_HIP_ESTATE, "the run kept no history (keep_history = 0): traces and ancestors do not exist; its statistics are the filtering ones");
     const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
     if (c->ssz == vsz) return copy_rows(c, h, c->d_values, vsz, (size_t)c->T, n_bytes, (size_t)c->rs);
@@ -1525,6 +1584,7 @@ int cpprob_hip_copy_ancestors(cpprob_hip_ctx* c, int32_t* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (int rc = settle_fixed(c)) return rc;
     if (!c->keep) return fail(c, CPPROB_HIP_ESTATE, "the run kept no history (keep_history = 0): traces and ancestors do not exist; its statistics are the filtering ones");
     if (c->cfg.algorithm != CPPROB_HIP_ALG_SMC) return fail(c, CPPROB_HIP_ESTATE, "SIS keeps no ancestors (every trace is its own line)");
     if (int rc = copy_rows(c, h, c->d_anc, sizeof(int32_t), (size_t)c->T, n_bytes, (size_t)c->rs)) return rc;
@@ -1542,6 +1602,7 @@ int cpprob_hip_copy_logw(cpprob_hip_ctx* c, double* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (int rc = settle_fixed(c)) return rc;
     if (c->final_from_counts) {
         // the run kept no log-weight array (they are a function of the final states): write it out now
         HIP_TRY(c, hipSetDevice(c->device));
@@ -1562,6 +1623,7 @@ int cpprob_hip_copy_paths(cpprob_hip_ctx* c, void* h, size_t n_bytes)
 {
     if (!c || !h) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    if (int rc = settle_fixed(c)) return rc;
     if (!c->keep) return fail(c, CPPROB_HIP_ESTATE, "the run kept no history (keep_history = 0): traces and ancestors do not exist; its statistics are the filtering ones");
     const size_t vsz = c->is_int ? sizeof(int32_t) : sizeof(double);
     // SIS: every trace is its own line -- the paths are the values (and a fused-read-out run keeps no linear weights to re-run the read-out on)

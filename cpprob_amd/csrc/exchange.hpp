@@ -44,6 +44,8 @@ struct ExchangeGeom {
     int64_t cap;                      // records per slot (fixed layout)
     int64_t annex_cap;
     int bytes_per_value;              // of the transported records (traffic accounting)
+    int no_history;                   // filtering-only shards (keep_history = 0): a migrant is its current state alone -- records of ONE
+                                      // value, and the annex is reused by every step's immigrants
     int64_t* sent_per_step;           // [T] device, may be nullptr: records this rank sent after each step
 };
 
@@ -125,7 +127,7 @@ __device__ __forceinline__ void plan_store(const ExchangeGeom& g, int t, const P
                                            ExchangePlan* __restrict__ plan)
 {
     const int lane = lane_id();
-    const int64_t base = t == 0 ? 0 : annex_base[t];
+    const int64_t base = (t == 0 || g.no_history) ? 0 : annex_base[t];
     if (lane < g.world) {
         plan->send_lo[lane] = pl.send_lo; plan->send_cnt[lane] = pl.send_cnt; plan->send_base[lane] = pl.send_base;
         plan->recv_cnt[lane] = pl.recv_cnt; plan->recv_base[lane] = pl.recv_base; plan->recv_off[lane] = pl.recv_off;
@@ -139,10 +141,10 @@ __device__ __forceinline__ void plan_store(const ExchangeGeom& g, int t, const P
         plan->overflow = ov;
         plan->l0 = pw.l0; plan->l1 = pw.l1; plan->n_send = pw.n_send; plan->n_recv = over_annex ? 0 : pw.n_recv;
         if (t == 0) annex_base[0] = 0;
-        annex_base[t + 1] = base + (over_annex ? 0 : pw.n_recv);
+        annex_base[t + 1] = g.no_history ? 0 : base + (over_annex ? 0 : pw.n_recv);
         const int64_t rec0 = t == 0 ? 0 : plan->run_records, byt0 = t == 0 ? 0 : plan->run_bytes;
         plan->run_records = rec0 + pw.n_send;
-        plan->run_bytes = byt0 + pw.n_send * (int64_t)(t + 1) * (int64_t)g.bytes_per_value;
+        plan->run_bytes = byt0 + pw.n_send * (int64_t)(g.no_history ? 1 : t + 1) * (int64_t)g.bytes_per_value;
         if (g.sent_per_step) g.sent_per_step[t] = pw.n_send;
     }
 }
@@ -301,14 +303,16 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
         const double W = tc.cdf(t0, t1, a.pc.n_pop);
         tc.inv = a.pc.n_pop / W;
     }
-    const int len = a.t + 1;
+    const bool no_history = a.geom.no_history != 0;
+    const int len = no_history ? 1 : a.t + 1;
+    const int row_t = no_history ? (a.t & 1) : a.t;              // where generation t's values sit
     for (int r = 0; r < a.world; ++r) {
         const int64_t cnt = PLAN_INSIDE ? s_send_cnt[r] : a.plan->send_cnt[r];
         if (r == a.rank || cnt == 0) continue;                  // uniform
         const int64_t lo = PLAN_INSIDE ? s_send_lo[r] : a.plan->send_lo[r];
         // where rank r's records go: its own receive slot for this rank (direct stores), or this rank's send buffer
-        R* const dst = a.peer_recv ? static_cast<R*>(a.peer_recv[r]) + (int64_t)a.peer_slot[r] * a.cap * (int64_t)(a.t + 1)
-                                   : a.send + (PLAN_INSIDE ? s_send_base[r] : a.plan->send_base[r]) * (int64_t)(a.t + 1);
+        R* const dst = a.peer_recv ? static_cast<R*>(a.peer_recv[r]) + (int64_t)a.peer_slot[r] * a.cap * (int64_t)len
+                                   : a.send + (PLAN_INSIDE ? s_send_base[r] : a.plan->send_base[r]) * (int64_t)len;
         for (int64_t tl = blockIdx.x; tl * kTile < cnt; tl += gridDim.x) {
             const int64_t rem = cnt - tl * kTile;
             const int n_out = rem < kTile ? (int)rem : kTile;
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                     store4(Lc.slot, (int64_t)tid * kPPT, neg);
                 }
                 __syncthreads();
-                ancestors_counts<S, true>(a.h, tc, a.values + (int64_t)a.t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, -16, anc, Lc);
+                ancestors_counts<S, true>(a.h, tc, a.values + (int64_t)row_t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, -16, anc, Lc);
             } else {
                 AncestorIn in;
                 in.wrel = a.wrel; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n;
@@ -355,6 +359,14 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) { if (on[k]) idx[k] = arow[idx[k]]; }
                 };
+                if (no_history) {
+                    // the migrant is its current state
+                    const typename Model::store_t* __restrict__ vrow = a.values + (int64_t)row_t * a.rs;
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) { if (on[k]) __builtin_nontemporal_store(static_cast<R>(vrow[idx[k]]), rec[k]); }
+                    __syncthreads();
+                    continue;
+                }
                 // this workgroup's block of generations [lo, hi] (the whole lineage without skip rows)
                 int hi = a.t, lo = 0;
                 if (a.skip) {
@@ -394,6 +406,17 @@ __global__ __launch_bounds__(kThreads) void exchange_commit_kernel(const Exchang
                                                                     int64_t rs, int64_t ld, int32_t* __restrict__ skip)
 {
     if (!plan->resample || plan->n_recv == 0) return;
+    if (!anc) {
+        // filtering-only shards: records of one value into the row of generation t; the annex starts over every step
+        for (int r = 0; r < world; ++r) {
+            const int64_t cnt = plan->recv_cnt[r];
+            if (cnt == 0) continue;
+            const int64_t base = plan->recv_base[r], off = plan->recv_off[r];
+            for (int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * kThreads)
+                values[(int64_t)(t & 1) * rs + ld + off + k] = static_cast<S>(recv[base + k]);
+        }
+        return;
+    }
     const int len = t + 1;
     const int64_t col0 = ld + annex_base[t];
     for (int r = 0; r < world; ++r) {

@@ -81,10 +81,14 @@ RcclApi* rccl_api(std::string& err)
 
 // {raw weighted sums ..., overflow flag, records sent, bytes sent} of a finished sharded run into one buffer: what the final all-reduce carries
 constexpr int kJointExtra = 3;
-__global__ void pack_joint_kernel(const double* __restrict__ stats, int n_stats, const cph::ExchangePlan* __restrict__ plan, int has_traffic, double* __restrict__ out)
+// Filtering-only shards append their per-step masses (the joint normalisers are the sums over ranks); where the statistics are the
+// joint population's already (count form: they come from the all-gathered totals) only rank 0 contributes them to the sum.
+__global__ void pack_joint_kernel(const double* __restrict__ stats, int n_stats, const cph::ExchangePlan* __restrict__ plan, int has_traffic, double* __restrict__ out,
+                                  const double* __restrict__ masses, int n_masses, int contribute_stats)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_stats) out[i] = stats[i];
+    if (i < n_stats) out[i] = contribute_stats ? stats[i] : 0.0;
+    if (i < n_masses) out[n_stats + kJointExtra + i] = masses ? masses[i] : 0.0;
     // (the flag word's three bits travel as three base-128 digits, so that the all-reduce's SUM over <= 63 ranks keeps them apart)
     if (i == 0) {
         const int ov = plan ? plan->overflow : 0;
@@ -235,13 +239,26 @@ int coll_allgather_host(cpprob_hip_group* g, int i, const void* h_in, void* h_ou
     return rc;
 }
 
+bool group_filtering(const cpprob_hip_group* g) { return g->cfg.keep_history == 0 && g->cfg.algorithm == CPPROB_HIP_ALG_SMC; }
+size_t group_joint_len(const cpprob_hip_group* g) { return (size_t)g->n_stats + kJointExtra + (group_filtering(g) ? (size_t)g->T : 0); }
+int group_record_len(const cpprob_hip_group* g, int t) { return group_filtering(g) ? 1 : t + 1; }      // values per migrating record after step t
+void launch_pack_joint(cpprob_hip_group* g, cpprob_hip_ctx* c, int rank, bool traffic, double* d_joint, hipStream_t st)
+{
+    const bool filt = group_filtering(g);
+    const bool joint_already = filt && c->counts_mode;
+    const int n_threads = (int)group_joint_len(g);
+    hipLaunchKernelGGL(pack_joint_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, st, (const double*)c->d_stats, g->n_stats,
+                       g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, traffic ? 1 : 0, d_joint,
+                       (filt && !joint_already) ? (const double*)c->d_filter_w : nullptr, filt ? g->T : 0, (!joint_already || rank == 0) ? 1 : 0);
+}
+
 // the exchange that follows step t, as seen by local rank i (send/recv transport): its peers' fixed-capacity segments
 int rccl_exchange(cpprob_hip_group* g, int i, int t)
 {
     cpprob_hip_ctx* c = g->ctx[(size_t)i];
     void* d_send = nullptr; void* d_recv = nullptr; int32_t np = 0; int32_t peers[cph::kWorldSlots]; uint64_t cap = 0, bpv = 0;
     if (int rc = cpprob_hip_exchange_transport(c, &d_send, &d_recv, &np, peers, &cap, &bpv)) return gfail(g, rc, cpprob_hip_last_error(c));
-    const size_t seg = (size_t)cap * (size_t)(t + 1) * (size_t)bpv;
+    const size_t seg = (size_t)cap * (size_t)group_record_len(g, t) * (size_t)bpv;
     if (np == 0) return 0;
     NCCL_TRY(g, g->rccl->GroupStart());
     for (int s = 0; s < np; ++s) {
@@ -281,9 +298,8 @@ int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
         }
     }
     if (int rc = cpprob_hip_smc_finish(c)) return gfail(g, rc, cpprob_hip_last_error(c));
-    hipLaunchKernelGGL(pack_joint_kernel, dim3((unsigned)((g->n_stats + 256) / 256)), dim3(256), 0, c->stream, (const double*)c->d_stats, g->n_stats,
-                       g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, (g->exchange && talk && g->T > 1) ? 1 : 0, g->d_joint[(size_t)i]);
-    if (int rc = coll_allreduce_sum(g, i, g->d_joint[(size_t)i], (size_t)g->n_stats + kJointExtra)) return rc;
+    launch_pack_joint(g, c, rank, g->exchange && talk && g->T > 1, g->d_joint[(size_t)i], c->stream);
+    if (int rc = coll_allreduce_sum(g, i, g->d_joint[(size_t)i], group_joint_len(g))) return rc;
     HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -310,7 +326,7 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
                 // (the fixed-capacity segments of the send/recv transport, as copies: A/B against the direct stores)
                 for (int r = 0; r < world; ++r) {
                     cpprob_hip_ctx* c = g->ctx[(size_t)r];
-                    const size_t seg = (size_t)c->x_cap * (size_t)(t + 1) * c->ssz;
+                    const size_t seg = (size_t)c->x_cap * (size_t)group_record_len(g, t) * c->ssz;
                     for (size_t s = 0; s < c->x_peers.size(); ++s) {
                         cpprob_hip_ctx* p = g->ctx[(size_t)c->x_peers[s]];
                         size_t ps = 0;                                   // the slot the peer keeps for rank r
@@ -327,10 +343,9 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
     for (int r = 0; r < world; ++r) {
         cpprob_hip_ctx* c = g->ctx[(size_t)r];
         if (int rc = cpprob_hip_smc_finish(c)) return gfail(g, rc, cpprob_hip_last_error(c));
-        hipLaunchKernelGGL(pack_joint_kernel, dim3((unsigned)((g->n_stats + 256) / 256)), dim3(256), 0, st, (const double*)c->d_stats, g->n_stats,
-                           g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, (g->exchange && g->T > 1) ? 1 : 0, g->d_joint[(size_t)r]);
+        launch_pack_joint(g, c, r, g->exchange && g->T > 1, g->d_joint[(size_t)r], st);
     }
-    hipLaunchKernelGGL(loop_allreduce_kernel, dim3((unsigned)((g->n_stats + kJointExtra + 255) / 256)), dim3(256), 0, st, g->d_ptr_joints, world, g->n_stats + kJointExtra);
+    hipLaunchKernelGGL(loop_allreduce_kernel, dim3((unsigned)((group_joint_len(g) + 255) / 256)), dim3(256), 0, st, g->d_ptr_joints, world, (int)group_joint_len(g));
     HIP_TRY(c0, hipGetLastError());
     return 0;
 }
@@ -489,7 +504,7 @@ double sendrecv_wire_bytes(const cpprob_hip_group* g)
         int np = 0;
         for (int q = 0; q < g->world; ++q) if (q != r && (g->all_peers || q == r - 1 || q == r + 1)) ++np;
         if (g->world == 1 && g->world1_collectives) np = 1;
-        for (int t = 0; t + 1 < g->T; ++t) total += (double)np * (double)g->cap * (double)(t + 1) * bpv;
+        for (int t = 0; t + 1 < g->T; ++t) total += (double)np * (double)g->cap * (double)group_record_len(g, t) * bpv;
     }
     return total;
 }
@@ -634,7 +649,7 @@ int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, co
         cpprob_hip_ctx* c = g->ctx[(size_t)i];
         GHIP_TRY(g, hipSetDevice(c->device));
         if (g->d_local[(size_t)i]) { (void)hipFree(g->d_local[(size_t)i]); (void)hipFree(g->d_all[(size_t)i]); (void)hipFree(g->d_joint[(size_t)i]); (void)hipFree(g->d_bar[(size_t)i]); }
-        const size_t nj = (size_t)g->n_stats + kJointExtra;
+        const size_t nj = group_joint_len(g);
         GHIP_TRY(g, hipMalloc(&g->d_local[(size_t)i], 4 * sizeof(double)));
         GHIP_TRY(g, hipMalloc(&g->d_all[(size_t)i], 3 * (size_t)g->world * sizeof(double)));
         GHIP_TRY(g, hipMalloc(&g->d_joint[(size_t)i], nj * sizeof(double)));
@@ -706,12 +721,29 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
     if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
     if (!g->ran) return gkeep(g, gfail(g, CPPROB_HIP_ESTATE, "no finished run"));
     if (h_stats && n_doubles < (size_t)g->n_stats) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "h_stats too small"));
-    std::vector<double> joint((size_t)g->n_stats + kJointExtra);
+    std::vector<double> joint(group_joint_len(g));
     for (int attempt = 0;; ++attempt) {
         if (int rc = cpprob_hip_group_sync(g)) return gkeep(g, rc);
         cpprob_hip_ctx* c = g->ctx[0];
         GHIP_TRY(g, hipSetDevice(c->device));
         GHIP_TRY(g, hipMemcpy(joint.data(), g->d_joint[0], joint.size() * sizeof(double), hipMemcpyDeviceToHost));
+        // fixed-point form: did the weights keep their bits (cpprob_hip.hip: settle_fixed)?  Every rank holds the same gap (it comes
+        // from the all-gathered totals), so every rank takes the same decision: repeat the run in the floating-point form
+        bool imprecise = false;
+        if (c->fixed_check_pending) {
+            cph::StepCtrl hc{};
+            GHIP_TRY(g, hipMemcpy(&hc, c->d_ctrl, sizeof hc, hipMemcpyDeviceToHost));
+            imprecise = !(hc.fix_gap <= kFixGapLimit);
+        }
+        for (auto* x : g->ctx) x->fixed_check_pending = false;
+        if (imprecise) {
+            if (attempt >= 6) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "run repeated too often"));
+            g->cfg.flags |= CPPROB_HIP_FLAG_FLOATING_POINT_STEP;
+            if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
+            ++g->reruns;
+            if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
+            continue;
+        }
         if (joint[(size_t)g->n_stats] == 0.0) break;
         // some rank's transport was too small (every rank sees the same all-reduced flags and takes the same decision): repeat
         // the run with what overflowed enlarged -- the annex (x4), the peer segments (x4, up to a whole shard), the peer list
@@ -724,8 +756,9 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
         if (peers) g->all_peers = 1;
         if (seg) g->cap = std::min<uint64_t>(largest, std::max<uint64_t>(g->cap * 4, 16384));
         if (annex || (!seg && !peers)) {
-            // (0 = the context's default: a sixteenth of the shard, at least four tiles -- cpprob_hip_infer_begin)
-            const int in_use = g->annex_kcols > 0 ? g->annex_kcols : (int)std::max<uint64_t>(4, ((largest + 1023) / 1024) / 16);
+            // (0 = the context's default: max(a sixteenth of the shard, sqrt(N) T, four tiles) -- cpprob_hip_infer_begin)
+            const uint64_t mixed = (uint64_t)(std::sqrt((double)g->cfg.n_particles) * (double)g->T) / 1024;
+            const int in_use = g->annex_kcols > 0 ? g->annex_kcols : (int)std::max<uint64_t>(std::max<uint64_t>(4, ((largest + 1023) / 1024) / 16), mixed);
             g->annex_kcols = in_use * 4;
         }
         if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
@@ -747,7 +780,20 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
     cpprob_hip_summary s{};
     if (int rc = cpprob_hip_infer_summary(g->ctx[0], &s)) return gkeep(g, gfail(g, rc, cpprob_hip_last_error(g->ctx[0])));
     if (out) *out = s;
-    if (h_stats) {
+    if (h_stats && group_filtering(g)) {
+        // filtering-only shards: predict hit t under generation t's own weights -- the joint population's numbers as they are (count
+        // form), or the ranks' raw sums over the ranks' masses of that generation
+        const bool joint_already = g->ctx[0]->counts_mode;
+        for (int t = 0; t < g->T; ++t) {
+            const double W = joint_already ? 1.0 : joint[(size_t)g->n_stats + kJointExtra + (size_t)t];
+            if (s.is_int || joint_already) { for (int k = 0; k < g->K; ++k) h_stats[t * g->K + k] = joint[(size_t)(t * g->K + k)] / W; }
+            else {
+                const double mean = joint[(size_t)(t * g->K)] / W;
+                h_stats[t * g->K] = mean;
+                h_stats[t * g->K + 1] = joint[(size_t)(t * g->K + 1)] / W - mean * mean;
+            }
+        }
+    } else if (h_stats) {
         // StatsPrinter's numbers from the all-reduced un-normalised sums (relative to exp(max_logw))
         const double W = std::exp(s.log_norm - s.max_logw);
         for (int t = 0; t < g->T; ++t) {

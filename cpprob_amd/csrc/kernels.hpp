@@ -66,6 +66,8 @@ struct StepCtrl {
     int32_t do_resample;  // decision taken after the last weighted step
     int32_t n_resampled;
     double ref_cur;       // fixed-point form (step_fixed.hpp): the reference R_t of the generation just produced
+    double fix_gap;       // ... and the largest R_t - max_i lw_i of the run: how far below its reference the heaviest particle of
+                          // some generation sat (each 0.69 of it costs the integer weights one of their 32 bits)
 };
 
 enum { RS_SYSTEMATIC = 0, RS_STRATIFIED = 1, RS_PRECOMPUTED = 2 };
@@ -1660,7 +1662,9 @@ __global__ __launch_bounds__(kThreads) void filter_partials_kernel(const typenam
 }
 
 // One workgroup per predict hit t: StatsPrinter's numbers from the workgroups' partials (fixed order: bitwise reproducible).
-__global__ __launch_bounds__(kThreads) void filter_finalize_kernel(const double* __restrict__ fpart, int grid, int K, int is_int, double* __restrict__ stats)
+// normalise = 0 (a shard of a joint population): raw sums into stats, this shard's mass of generation t into masses[t].
+__global__ __launch_bounds__(kThreads) void filter_finalize_kernel(const double* __restrict__ fpart, int grid, int K, int is_int, double* __restrict__ stats,
+                                                                    int normalise, double* __restrict__ masses)
 {
     __shared__ double s_scr[kWaves];
     __shared__ double s_out[9];
@@ -1679,7 +1683,8 @@ __global__ __launch_bounds__(kThreads) void filter_finalize_kernel(const double*
     __syncthreads();
     if (threadIdx.x == 0) {
         const double W = s_out[0];
-        if (is_int) { for (int j = 0; j < K; ++j) stats[t * K + j] = s_out[j + 1] / W; }
+        if (!normalise) { for (int j = 0; j < K; ++j) stats[t * K + j] = s_out[j + 1]; if (masses) masses[t] = W; }
+        else if (is_int) { for (int j = 0; j < K; ++j) stats[t * K + j] = s_out[j + 1] / W; }
         else { const double mean = s_out[1] / W; stats[t * K] = mean; stats[t * K + 1] = s_out[2] / W - mean * mean; }
     }
 }

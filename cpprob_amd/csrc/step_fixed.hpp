@@ -382,8 +382,12 @@ __device__ __forceinline__ double fixed_reference(bool fresh, double m_prev, dou
 
 // Bookkeeping of generation t-1 for the host (one thread): ESS, decision, evidence.  ref_prev = R_{t-1}.
 __device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const FixedDecision& d, double ref_prev, double n_pop, double u0, double* ess_trace,
-                                               int32_t* resampled, bool last)
+                                               int32_t* resampled, bool last, double m_prev)
 {
+    // how far the generation's heaviest particle sat below the reference its weights were taken against (NaN-proof: an empty
+    // mass counts as the whole range) -- the host repeats a run whose gap cost too many bits in the floating-point form
+    const double gap = (d.W > 0.0) ? ref_prev - m_prev : 1e300;
+    c->fix_gap = (t_prev == 0) ? gap : fmax(c->fix_gap, gap);
     c->M = ref_prev; c->W = d.W; c->Q = d.Qd; c->ess = d.ess; c->do_resample = d.resample ? 1 : 0;
     c->cdf_lo = 0.0; c->w_local = d.W; c->scale = 1.0; c->u0 = u0; c->inv_stepw = d.inv * kFixScale; c->lw_after = 0.0; c->inv_global = d.inv * kFixScale;
     double lz = (t_prev == 0) ? 0.0 : c->log_z;
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
             const double r_t = fixed_reference(d.resample, Mt, a.bound);
             if (bid == 0 && tid == 0) {
                 StepCtrl* c = a.ctrl;
-                fixed_bookkeep(c, t - 1, d, c->ref_cur, a.n_pop, a.u0, a.ess_trace, a.resampled, false);
+                fixed_bookkeep(c, t - 1, d, c->ref_cur, a.n_pop, a.u0, a.ess_trace, a.resampled, false, Mt);
                 c->ref_cur = r_t;
             }
             FLocated loc{0, 0, 0};
@@ -556,16 +560,16 @@ struct FixedFinal {
     int bookkeep;
     StepCtrl* ctrl; double* ess_trace; int32_t* resampled;
 };
-__device__ __forceinline__ void fixed_final_bookkeep(const FixedFinal& ff, uint64_t S, uint64_t Q)
+__device__ __forceinline__ void fixed_final_bookkeep(const FixedFinal& ff, uint64_t S, uint64_t Q, double M)
 {
     const FixedDecision d = fixed_decide(S, Q, ff.n_pop, ff.ess_frac, false);
-    fixed_bookkeep(ff.ctrl, ff.T - 1, d, ff.ctrl->ref_cur, ff.n_pop, 0.0, ff.ess_trace, ff.resampled, true);
+    fixed_bookkeep(ff.ctrl, ff.T - 1, d, ff.ctrl->ref_cur, ff.n_pop, 0.0, ff.ess_trace, ff.resampled, true, M);
 }
 // one shard of a joint population: from the all-gathered totals (the sums a single GPU's hierarchy would hold)
 __global__ __launch_bounds__(kWave) void fixed_final_ctrl_kernel(FixedFinal ff, const uint64_t* __restrict__ all_totals, int world)
 {
     const FixedRanks r = fixed_ranks(all_totals, world, 0);
-    if (threadIdx.x == 0) fixed_final_bookkeep(ff, r.S, r.Q);
+    if (threadIdx.x == 0) fixed_final_bookkeep(ff, r.S, r.Q, r.M);
 }
 // {S, Q, key(M)} of this shard's generation: what a sharded run all-gathers between two steps (24 bytes)
 __global__ __launch_bounds__(kWave) void fixed_totals_kernel(FHier f, uint64_t* __restrict__ out)
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(kWave) void fixed_totals_kernel(FHier f, uint64_t* 
 __global__ __launch_bounds__(kWave) void fixed_filter_final_kernel(FixedFinal ff)
 {
     const FTot t = ftot(ff.f);
-    if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q);
+    if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q, t.M);
 }
 
 // Filtering-only runs: predict hit t's sums under generation t's own integer weights, per workgroup {0, sum q, sum q f_0 .. f_{K-1}}
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(kThreads) void smooth_fixed_kernel(SmoothArgs<Model
     extern __shared__ __attribute__((aligned(16))) double s_stat[];   // [kWaves][T*K]
     if (ff.bookkeep && blockIdx.x == 0 && wave_id() == 0) {
         const FTot t = ftot(ff.f);
-        if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q);
+        if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q, t.M);
     }
     smooth_body<Model>(a, s_stat, [q_last](int64_t, int64_t i) { return (double)q_last[i] * kFixInv; });        // padding slots: q = 0
 }

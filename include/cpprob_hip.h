@@ -44,6 +44,8 @@ extern "C" {
 #define CPPROB_HIP_EDEVICE (-2)    /* HIP runtime error (no GPU, launch failure, OOM) */
 #define CPPROB_HIP_ESTATE (-3)     /* call out of order (e.g. stats before run)       */
 #define CPPROB_HIP_EUNSUPPORTED (-4)
+#define CPPROB_HIP_EPRECISION (-5)  /* a caller-driven sharded run (step protocol) left the fixed-point weights too few bits: repeat it
+                                        with CPPROB_HIP_FLAG_FLOATING_POINT_STEP (runs the library drives itself are repeated by it) */
 
 /* StateType -- reference include/cpprob/state.hpp:28-33 {compile, csis, sis, dryrun}; smc is new. */
 #define CPPROB_HIP_ALG_SIS 2
@@ -87,12 +89,14 @@ typedef struct cpprob_hip_config {
                                  CPPROB_HIP_SCOPE_EXCHANGE: like GLOBAL, with particle migration
                                  (cpprob_hip_exchange_*) so that resampling is exact over shards */
     int32_t keep_history;     /* 1: keep per-step values + ancestors: statistics over whole traces (what the reference's
-                                 posterior files hold), dumps.  0 (SMC, one population per context): filtering only --
+                                 posterior files hold), dumps.  0 (SMC; one population per context, or a shard of a joint
+                                 population in the exchange scope, whose migrants are then their current state alone): filtering only --
                                  two rows of values, no ancestors (memory O(N) instead of O(N T)); predict hit t's
                                  statistics are those of generation t under its own weights; cpprob_hip_copy_values /
                                  _ancestors / _paths return CPPROB_HIP_ESTATE                                    */
-    int32_t annex_kcols;      /* exchange scope: immigrant-annex capacity in units of 1024 columns per row (0 = default: 1/16 of
-                                 the shard, at least 4096); stream-ordered runs cannot grow it mid-run and report overflow instead */
+    int32_t annex_kcols;      /* exchange scope: immigrant-annex capacity in units of 1024 columns per row (0 = default: the larger of
+                                 1/16 of the shard and sqrt(n_global) x T -- what a well-mixed run's O(sqrt N) immigrants per step
+                                 add up to --, at least 4096); stream-ordered runs cannot grow it mid-run and report overflow instead */
     uint32_t flags;           /* CPPROB_HIP_FLAG_* below; 0 = the measured optimum.  Every switch that selects another kernel form
                                  lives HERE, in the caller's hands -- the library reads no environment variable */
     int32_t fuse_max_tiles;   /* floating-point step: largest population (in 1024-particle tiles) whose step kernel normalises the
@@ -126,7 +130,13 @@ typedef struct cpprob_hip_summary {
     int32_t stats_per_predict; /* 2 for real predicts (mean, variance); k for int predicts (P(x=s)) */
     int32_t is_int;       /* 1: predicts are integral (.int file), 0: real (.real)                */
     int32_t n_resampled;  /* number of steps after which resampling happened                      */
+    int32_t step_form;    /* arithmetic the run's steps ran in: CPPROB_HIP_FORM_*                          */
+    int32_t reserved;
 } cpprob_hip_summary;
+#define CPPROB_HIP_FORM_FLOAT 0   /* fp64 linear weights, floating-point CDF (stratified / multinomial resampling, locally resampled
+                                     shards, SIS, runs repeated because the fixed-point weights lost their bits)          */
+#define CPPROB_HIP_FORM_COUNTS 1  /* integer prefix counts of the states (table-weight models, every-step schedule)        */
+#define CPPROB_HIP_FORM_FIXED 2   /* fixed-point weights q = rint(exp(lw - max_logw) 2^32), exact 64-bit prefix masses     */
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 int cpprob_hip_abi_version(void);
@@ -199,6 +209,11 @@ int cpprob_hip_copy_paths(cpprob_hip_ctx* ctx, void* h_paths, size_t n_bytes);
 int cpprob_hip_smc_step_begin(cpprob_hip_ctx* ctx, int32_t t, uint64_t run_index, double* d_local_totals);
 int cpprob_hip_smc_step_end(cpprob_hip_ctx* ctx, int32_t t, const double* d_all_totals, int32_t world, int32_t rank);
 int cpprob_hip_smc_finish(cpprob_hip_ctx* ctx);
+/* Filtering-only shards (keep_history = 0) after finish: *joint_already = 1 -- cpprob_hip_infer_stats holds the JOINT population's
+ * numbers (prefix-count form: they come from the all-gathered totals), nothing to combine; 0 -- it holds this shard's raw sums of
+ * weight x f(x_t) per predict hit t and *d_masses (device, n_predict doubles) this shard's mass of generation t: the caller adds both
+ * over ranks and divides (real predicts: mean = sum / mass, variance = second sum / mass - mean^2). */
+int cpprob_hip_filter_masses(cpprob_hip_ctx* ctx, double** d_masses, int32_t* joint_already);
 
 /* Exchange scope (cfg.resample_scope = CPPROB_HIP_SCOPE_EXCHANGE, systematic resampling): the sharded run draws the
  * SAME ancestors a single GPU holding all n_global particles would (one shared offset u makes every

@@ -50,7 +50,7 @@ def test_random_smc_runs_keep_their_invariants(engine, golden_dir, sweep):
         if n <= 300000:
             # read-out == the oracle's estimator applied to the device's own store; paths == lineages of that store
             logw = engine.logw()
-            if rs == cp.RESAMPLE_SYSTEMATIC and not (model == cp.MODEL_HMM3 and ess > 1.0):
+            if s["step_form"] == cp.capi.FORM_FIXED:
                 # fixed-point form: the estimator's weights are the integers q_i = rint(exp(lw_i - R) 2^32), R = max_logw of the summary
                 # (against the fp64 weights: the 2^-32 resolution, relative to the heaviest particle -- visible where a handful of
                 #  particles carry the mass, e.g. runs that never resample)

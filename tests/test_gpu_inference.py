@@ -160,8 +160,7 @@ def _compare_smc(engine, model, obs, n, seed, resampler, ess):
     sm_ref = O.smoothing(ref["hist"], ref["anc"], ref["logw"])
     np.testing.assert_allclose(engine.stats(), sm_ref, atol=2e-3)
     # internal consistency, exact: device smoothing == oracle estimator applied to the DEVICE's own store
-    fixed = resampler == cp.RESAMPLE_SYSTEMATIC and not (model == cp.MODEL_HMM3 and ess > 1.0)
-    if fixed:
+    if s["step_form"] == cp.capi.FORM_FIXED:
         # fixed-point form: the final weights ARE the integers q_i = rint(exp(lw_i - R) 2^32), R = summary()["max_logw"]
         sm_self = O.smoothing_linear(vals, anc, O.fix_weights(logw, s["max_logw"]).astype(np.float64))
         np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-11, atol=1e-13)
@@ -337,10 +336,65 @@ def test_filtering_only_run_weight_sums_form(engine, golden_dir, model, key, ess
         engine.paths()
 
 
-def test_filtering_only_run_is_refused_for_a_shard_of_a_joint_population(engine, golden_dir):
-    obs = _obs(golden_dir, "hmm16")
+@pytest.mark.parametrize("model,key,T,ess", [(cp.MODEL_HMM3, "hmm16", 16, 2.0), (cp.MODEL_HMM3, "hmm128", 48, 0.5), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 30, 0.5)])
+def test_filtering_only_shards_of_a_joint_population_match_one_context(engine, golden_dir, model, key, T, ess):
+    """keep_history = 0 for shards in the exchange scope: a migrating particle is its current state alone (records of one value,
+    an annex that starts over every step), each rank holds two rows of its shard -- BASELINE configs[4] filtering-only fits 0.5 GB
+    per GPU.  Four uneven shards on this GPU against ONE filtering-only context: the same evidence and decisions bit for bit, the
+    same filtering statistics (prefix-count form: the very numbers; fixed-point form: the ranks' sums over the ranks' masses)."""
+    obs = _obs(golden_dir, key)[:T]
+    shards = [30000, 50001, 19999, 40000]
+    n = int(sum(shards))
+    engine.begin(cp.ALG_SMC, model, obs, n, seed=21, ess_threshold=ess, keep_history=False)
+    engine.run()
+    ref_stats, ref_sum = engine.stats().copy(), engine.summary()
+    g = cp.Group([0] * len(shards))
+    g.begin(cp.ALG_SMC, model, obs, n, seed=21, ess_threshold=ess, shard_sizes=shards, keep_history=False)
+    g.run()
+    stats, s, reruns = g.results()
+    tr = g.traffic()
+    e0 = g.context(0)
+    e0.n = shards[0]
     with pytest.raises(cp.CpprobHipError):
-        engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 1000, n_global=2000, scope=cp.SCOPE_EXCHANGE, keep_history=False)
+        e0.paths()
+    g.close()
+    assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"] and reruns == 0
+    if model == cp.MODEL_HMM3 and ess > 1.0:
+        assert np.array_equal(stats, ref_stats)
+    else:
+        np.testing.assert_allclose(stats, ref_stats, rtol=1e-12, atol=1e-13)
+    vsz = 1 if model == cp.MODEL_HMM3 else 8
+    assert tr["records"] > 0 and tr["wire_bytes"] == tr["payload_bytes"] == tr["records"] * vsz        # one value per migrant
+    with pytest.raises(cp.CpprobHipError):
+        engine.begin(cp.ALG_SMC, model, obs, 1000, n_global=2000, scope=cp.SCOPE_GLOBAL, keep_history=False)      # a locally resampled shard keeps its history
+
+
+def test_fixed_point_run_that_loses_its_bits_is_repeated_in_the_floating_point_form(engine, golden_dir):
+    """The fixed-point weights are taken against a reference known before the generation exists (the emission's density at its
+    mode).  An observation many standard deviations from EVERY particle leaves the heaviest particle far below it -- 0.69 nats per
+    lost bit, nothing left at 22 -- so the engine tracks the largest such gap of a run and, past 6 nats, repeats the run in the
+    floating-point form before any result leaves the library: the numbers are those of CPPROB_HIP_FLAG_FLOATING_POINT_STEP, bit for
+    bit, and match the oracle's estimator; a run without such a step is not repeated."""
+    obs = np.array(_obs(golden_dir, "lgssm100")[:14])
+    obs[6] = 40.0                                              # ~30 standard deviations from every particle
+    n = 5000
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, ess_threshold=0.5)
+    engine.run()
+    st, s = engine.stats().copy(), engine.summary()
+    assert np.isfinite(st).all() and np.isfinite(s["log_evidence"])
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, ess_threshold=0.5, flags=cp.capi.FLAG_FLOATING_POINT_STEP)
+    engine.run()
+    s2 = engine.summary()
+    assert np.array_equal(engine.stats(), st) and s["step_form"] == s2["step_form"] == cp.capi.FORM_FLOAT and s2 == s
+    np.testing.assert_allclose(st, O.smoothing(engine.values(), engine.ancestors(), engine.logw()), rtol=1e-8, atol=1e-10)
+    # the same through the group driver (two loopback ranks): repeated once, the same answer within boundary flips
+    g = cp.Group([0, 0])
+    g.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, ess_threshold=0.5)
+    g.run()
+    gst, gs, reruns = g.results()
+    g.close()
+    assert 1 <= reruns <= 3 and abs(gs["log_evidence"] - s["log_evidence"]) < 1e-9      # (the mass sits on a few particles: the transport may be enlarged too)
+    np.testing.assert_allclose(gst, st, rtol=0, atol=5e-3)
 
 
 def test_smc_hmm16_config3_vs_forward_backward(engine, golden_dir):

@@ -38,7 +38,7 @@ def test_config_struct_layout_matches_header():
     from cpprob_amd import capi
     assert C.sizeof(capi.Config) == 8 * 4 + 8 + 4 * 8
     assert capi.Config.flags.offset == 24 and capi.Config.ess_threshold.offset == 32 and capi.Config.seed.offset == 40
-    assert C.sizeof(capi.Summary) == 4 * 8 + 4 * 4
+    assert C.sizeof(capi.Summary) == 4 * 8 + 6 * 4
 
 
 def test_fails_loudly_without_gpu():
