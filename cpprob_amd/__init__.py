@@ -7,7 +7,7 @@ There is no CPU fallback: without the built library or without a GPU, calls fail
 """
 from . import capi  # noqa: F401
 from .capi import (ALG_SIS, ALG_SMC, MODEL_GAUSSIAN_README, MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_2D_UNKNOWN_MEAN, MODEL_HMM3,  # noqa: F401
-                   MODEL_LINEAR_GAUSSIAN_1D, RESAMPLE_MULTINOMIAL, RESAMPLE_STRATIFIED, RESAMPLE_SYSTEMATIC,
+                   MODEL_LINEAR_GAUSSIAN_1D, MODEL_HMM_TABLE, RESAMPLE_MULTINOMIAL, RESAMPLE_STRATIFIED, RESAMPLE_SYSTEMATIC,
                    SCOPE_GLOBAL, SCOPE_ISLAND, SCOPE_EXCHANGE, Engine, Group, CpprobHipError, load_library)
 
 __version__ = "0.1.0"

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcpprob_hip.so")
 
 ALG_SIS, ALG_SMC = 2, 4
-MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README, MODEL_LINEAR_GAUSSIAN_1D, MODEL_HMM3, MODEL_GAUSSIAN_2D_UNKNOWN_MEAN = 0, 1, 2, 3, 4
+MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README, MODEL_LINEAR_GAUSSIAN_1D, MODEL_HMM3, MODEL_GAUSSIAN_2D_UNKNOWN_MEAN, MODEL_HMM_TABLE = 0, 1, 2, 3, 4, 5
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
 SCOPE_GLOBAL, SCOPE_ISLAND, SCOPE_EXCHANGE = 0, 1, 2
 # cpprob_hip_config::flags (A/B forms; 0 = the measured optimum)
@@ -19,7 +19,7 @@ KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", 
 # every symbol include/cpprob_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "cpprob_hip_abi_version", "cpprob_hip_build_id", "cpprob_hip_device_count", "cpprob_hip_create", "cpprob_hip_destroy", "cpprob_hip_last_error",
-    "cpprob_hip_stream", "cpprob_hip_sync", "cpprob_hip_infer_begin", "cpprob_hip_infer_run", "cpprob_hip_infer_summary",
+    "cpprob_hip_stream", "cpprob_hip_sync", "cpprob_hip_set_hmm", "cpprob_hip_infer_begin", "cpprob_hip_infer_run", "cpprob_hip_infer_summary",
     "cpprob_hip_infer_stats", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
     "cpprob_hip_smc_finish", "cpprob_hip_filter_masses", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
@@ -36,6 +36,9 @@ SYMBOLS = [
 
 class CpprobHipError(RuntimeError):
     pass
+
+
+EPRECISION = -5
 
 
 class Config(C.Structure):
@@ -92,6 +95,7 @@ def load_library(path=None):
         "cpprob_hip_last_error": (C.c_char_p, [vp]),
         "cpprob_hip_stream": (vp, [vp]),
         "cpprob_hip_sync": (C.c_int, [vp]),
+        "cpprob_hip_set_hmm": (C.c_int, [vp, i32, C.POINTER(dbl), C.POINTER(dbl)]),
         "cpprob_hip_infer_begin": (C.c_int, [vp, C.POINTER(Config), C.POINTER(dbl), sz]),
         "cpprob_hip_infer_run": (C.c_int, [vp, u64]),
         "cpprob_hip_infer_summary": (C.c_int, [vp, C.POINTER(Summary)]),
@@ -214,7 +218,9 @@ class Engine:
     def _chk(self, rc):
         if rc:
             msg = self.L.cpprob_hip_last_error(self.h)
-            raise CpprobHipError("cpprob_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+            e = CpprobHipError("cpprob_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+            e.code = rc
+            raise e
 
     @property
     def stream_ptr(self):
@@ -223,6 +229,13 @@ class Engine:
     def sync(self):
         self._chk(self.L.cpprob_hip_sync(self.h))
 
+    def set_hmm(self, means, trans):
+        """The table of MODEL_HMM_TABLE: k = len(means) states (2..8), emission N(means[s], 1), transition rows trans[s] (weights)."""
+        m = np.ascontiguousarray(means, np.float64)
+        tr = np.ascontiguousarray(trans, np.float64)
+        assert tr.shape == (len(m), len(m))
+        self._chk(self.L.cpprob_hip_set_hmm(self.h, len(m), m.ctypes.data_as(C.POINTER(C.c_double)), tr.ctypes.data_as(C.POINTER(C.c_double))))
+
     # ---- cpprob::inference --------------------------------------------------------------
     def begin(self, algorithm, model, observes, n_particles, seed=12345, resampler=RESAMPLE_SYSTEMATIC, ess_threshold=2.0,
               particle_offset=0, n_global=None, scope=SCOPE_GLOBAL, keep_history=True, flags=0, fuse_max_tiles=0):
@@ -230,16 +243,24 @@ class Engine:
         O(N T)); stats() then holds every predict hit's statistics under ITS generation's weights, and values() / ancestors() /
         paths() raise."""
         obs = np.ascontiguousarray(observes, np.float64)
+        self._begin_args = dict(algorithm=algorithm, model=model, observes=obs.copy(), n_particles=n_particles, seed=seed, resampler=resampler, ess_threshold=ess_threshold,
+                                particle_offset=particle_offset, n_global=n_global, scope=scope, keep_history=keep_history, flags=flags, fuse_max_tiles=fuse_max_tiles)
         cfg = Config(algorithm, model, resampler, scope, 1 if keep_history else 0, 0, int(flags), int(fuse_max_tiles), float(ess_threshold), int(seed),
                      int(n_particles), int(particle_offset), int(n_particles if n_global is None else n_global))
         self._chk(self.L.cpprob_hip_infer_begin(self.h, C.byref(cfg), obs.ctypes.data_as(C.POINTER(C.c_double)), len(obs)))
         self.cfg = cfg
         gauss = model in (MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README)
         self.T = 1 if gauss else len(obs)
-        self.is_int = model == MODEL_HMM3
-        self.K = 3 if self.is_int else 2
+        self.is_int = model in (MODEL_HMM3, MODEL_HMM_TABLE)
+        self.K = 8 if model == MODEL_HMM_TABLE else (3 if self.is_int else 2)
         self.n = int(n_particles)
         return self
+
+    def rebegin(self, extra_flags):
+        """begin() again with the same arguments and further cpprob_hip_config::flags."""
+        a = dict(self._begin_args)
+        a["flags"] = int(a["flags"]) | int(extra_flags)
+        return self.begin(**a)
 
     def run(self, run_index=0):
         self._chk(self.L.cpprob_hip_infer_run(self.h, int(run_index)))
@@ -481,8 +502,8 @@ class Group:
                                                 ss.ctypes.data if ss is not None else None))
         gauss = model in (MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README)
         self.T = 1 if gauss else len(obs)
-        self.is_int = model == MODEL_HMM3
-        self.K = 3 if self.is_int else 2
+        self.is_int = model in (MODEL_HMM3, MODEL_HMM_TABLE)
+        self.K = 8 if model == MODEL_HMM_TABLE else (3 if self.is_int else 2)
         self.n = int(n_particles)
         return self
 

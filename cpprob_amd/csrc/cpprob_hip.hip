@@ -121,6 +121,8 @@ struct cpprob_hip_ctx {
     bool force_fp = false, fixed_check_pending = false, last_was_infer_run = false; uint64_t last_run_index = 0;
     uint32_t* d_q[2] = {nullptr, nullptr};                 // [ld] integer weights of the fixed-point form, ping-pong
     std::vector<double> h_bound;                           // [T] upper bound of each step's incremental log-weight (host-evaluated)
+    int hk = 0; std::vector<double> hk_mean, hk_trans;     // cpprob_hip_set_hmm: the table of CPPROB_HIP_MODEL_HMM_TABLE
+    uint64_t* d_hk_thr = nullptr; double* d_hk_ll = nullptr;
     size_t hier_q0_off = 0, hier_m0_off = 0;               // the tiles' Q / M arrays inside one copy of the hierarchy
     std::vector<double> h_ll_tab, h_e_tab;                 // host copies of the table-weight model's per-step tables ([T][3], [T][4])
     double* d_wpart = nullptr;                             // bounded SIS: per-workgroup partial rows
@@ -492,7 +494,7 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
 template <class Model>
 bool fixed_eligible(const cpprob_hip_ctx* c)
 {
-    constexpr bool model_ok = std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value;
+    constexpr bool model_ok = std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value || std::is_same<Model, ModelHmmK>::value;
     return model_ok && !c->force_fp && !(c->cfg.flags & CPPROB_HIP_FLAG_FLOATING_POINT_STEP) && c->nb <= kCountsMaxTiles && c->pop_n <= (1ull << 28) &&
            c->cfg.algorithm == CPPROB_HIP_ALG_SMC && c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && !counts_eligible<Model>(c) &&
            (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND);
@@ -519,7 +521,7 @@ static void hier_rotation(cpprob_hip_ctx* c, int t, int& kp, int& kn, int& kc)
 template <class Model>
 void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int world, int rank)
 {
-    if constexpr (std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value) {
+    if constexpr (std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value || std::is_same<Model, ModelHmmK>::value) {
         StepFixedArgs<Model> a{};
         a.mp = c->mp; a.obs = c->d_obs; a.t = t; a.T = c->T; a.n = c->n; a.ld = c->ld; a.rs = c->rs; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
         a.values = static_cast<typename Model::store_t*>(c->d_values); a.anc = c->d_anc;
@@ -642,6 +644,7 @@ int dispatch_model(cpprob_hip_ctx* c, F&& f)
     case CPPROB_HIP_MODEL_LINEAR_GAUSSIAN_1D: f(ModelLinearGaussian1D{}); return 0;
     case CPPROB_HIP_MODEL_HMM3: f(ModelHmm3{}); return 0;
     case CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN: f(ModelGaussianND{}); return 0;
+    case CPPROB_HIP_MODEL_HMM_TABLE: f(ModelHmmK{}); return 0;
     }
     return fail(c, CPPROB_HIP_EINVAL, "unknown model id");
 }
@@ -707,7 +710,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
     dfree(c->d_ctrl); dfree(c->d_local_totals);
-    dfree(c->d_send_src); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent);
+    dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -725,12 +728,28 @@ int cpprob_hip_sync(cpprob_hip_ctx* c)
     return 0;
 }
 
+int cpprob_hip_set_hmm(cpprob_hip_ctx* c, int32_t k, const double* h_means, const double* h_transition)
+{
+    if (!c || !h_means || !h_transition) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (k < 2 || k > 8) return fail(c, CPPROB_HIP_EINVAL, "the table model holds 2 .. 8 states");
+    for (int s2 = 0; s2 < k; ++s2) {
+        double tot = 0.0;
+        for (int j = 0; j < k; ++j) { const double w = h_transition[(size_t)s2 * k + j]; if (!(w >= 0.0) || !std::isfinite(w)) return fail(c, CPPROB_HIP_EINVAL, "transition weights must be finite and >= 0"); tot += w; }
+        if (!(tot > 0.0)) return fail(c, CPPROB_HIP_EINVAL, "a transition row without mass");
+        if (!std::isfinite(h_means[s2])) return fail(c, CPPROB_HIP_EINVAL, "state means must be finite");
+    }
+    c->hk = k; c->hk_mean.assign(h_means, h_means + k); c->hk_trans.assign(h_transition, h_transition + (size_t)k * k);
+    c->begun = false;                                   // (a run in flight keeps the tables it was begun with; the next begin takes these)
+    return 0;
+}
+
 int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, const double* h_obs, size_t n_obs)
 {
     if (!c || !cfg || !h_obs) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (cfg->algorithm != CPPROB_HIP_ALG_SIS && cfg->algorithm != CPPROB_HIP_ALG_SMC)
         return fail(c, CPPROB_HIP_EUNSUPPORTED, "algorithm must be sis or smc (compile/csis/dryrun are outside this engine)");
-    if (cfg->model < 0 || cfg->model > CPPROB_HIP_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN) return fail(c, CPPROB_HIP_EINVAL, "unknown model id");
+    if (cfg->model < 0 || cfg->model > CPPROB_HIP_MODEL_HMM_TABLE) return fail(c, CPPROB_HIP_EINVAL, "unknown model id");
+    if (cfg->model == CPPROB_HIP_MODEL_HMM_TABLE && c->hk < 2) return fail(c, CPPROB_HIP_ESTATE, "CPPROB_HIP_MODEL_HMM_TABLE: call cpprob_hip_set_hmm first");
     if (n_obs == 0) return fail(c, CPPROB_HIP_EINVAL, "the model has to receive the observed values (cpprob.hpp:182)");
     const bool gauss = cfg->model == CPPROB_HIP_MODEL_GAUSSIAN_UNKNOWN_MEAN || cfg->model == CPPROB_HIP_MODEL_GAUSSIAN_README;
     if (gauss && n_obs != 2) return fail(c, CPPROB_HIP_EINVAL, "gaussian_unknown_mean takes exactly two observes");
@@ -762,9 +781,10 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     c->n_obs = (int)n_obs;
     c->begun = false; c->step_protocol = false; c->step_t = -1; c->force_fp = false; c->fixed_check_pending = false;
     // the read-out keeps kWaves * T * kStats accumulators in LDS (smooth_kernel)
-    if ((size_t)kWaves * (size_t)c->T * 3 * sizeof(double) > 64 * 1024) return fail(c, CPPROB_HIP_EUNSUPPORTED, "too many predict hits per trace for the read-out kernel's LDS accumulators (T <= 682)");
-    c->is_int = cfg->model == CPPROB_HIP_MODEL_HMM3;
-    c->K = c->is_int ? 3 : 2;
+    c->is_int = cfg->model == CPPROB_HIP_MODEL_HMM3 || cfg->model == CPPROB_HIP_MODEL_HMM_TABLE;
+    c->K = cfg->model == CPPROB_HIP_MODEL_HMM_TABLE ? 8 : (c->is_int ? 3 : 2);
+    if ((size_t)kWaves * (size_t)c->T * (size_t)std::max(c->K, 3) * sizeof(double) > 64 * 1024)
+        return fail(c, CPPROB_HIP_EUNSUPPORTED, "too many predict hits per trace for the read-out kernel's LDS accumulators (T x statistics per hit <= 2048)");
     c->n = (int64_t)cfg->n_particles;
     c->nb = (int)((c->n + kTile - 1) / kTile);
     c->ld = (int64_t)c->nb * kTile;                 // padded to the tile: no ragged tails in any kernel
@@ -923,12 +943,35 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMemcpy(c->d_e_tab, et.data(), et.size() * sizeof(double), hipMemcpyHostToDevice));
         c->mp.e_tab = c->d_e_tab;
     }
+    c->mp.hk = 0; c->mp.hk_thr = nullptr; c->mp.hk_ll = nullptr;
+    if (cfg->model == CPPROB_HIP_MODEL_HMM_TABLE) {
+        // thresholds of the rows' inverse CDFs (u >= c  <=>  word >= ceil(c 2^32), as for the three-state model) and the
+        // emission log-densities of every step
+        const int k = c->hk;
+        std::vector<uint64_t> thr((size_t)k * 8, ~0ull);
+        for (int s2 = 0; s2 < k; ++s2) {
+            double tot = 0.0, acc = 0.0;
+            for (int j = 0; j < k; ++j) tot += c->hk_trans[(size_t)s2 * k + j];
+            for (int j = 0; j + 1 < k; ++j) { acc += c->hk_trans[(size_t)s2 * k + j]; thr[(size_t)s2 * 8 + j] = (uint64_t)std::ceil((acc / tot) * 4294967296.0); }
+        }
+        std::vector<double> ll((size_t)c->T * 8, -INFINITY);
+        for (int t = 0; t < c->T; ++t)
+            for (int s2 = 0; s2 < k; ++s2) ll[(size_t)t * 8 + s2] = normal_logpdf(h_obs[t], c->hk_mean[(size_t)s2], 1.0);
+        dfree(c->d_hk_thr); dfree(c->d_hk_ll);
+        HIP_TRY(c, hipMalloc(&c->d_hk_thr, thr.size() * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc(&c->d_hk_ll, ll.size() * sizeof(double)));
+        HIP_TRY(c, hipMemcpy(c->d_hk_thr, thr.data(), thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_hk_ll, ll.data(), ll.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->mp.hk = k; c->mp.hk_thr = c->d_hk_thr; c->mp.hk_ll = c->d_hk_ll;
+        c->h_ll_tab = ll;                                   // (host copy: the bounds below)
+    }
     {
         // fixed-point form: the upper bound of each step's incremental log-weight, with the very expressions the kernels evaluate
         c->h_bound.assign((size_t)c->T, 0.0);
         for (int t = 0; t < c->T; ++t) {
             if (cfg->model == CPPROB_HIP_MODEL_HMM3) c->h_bound[(size_t)t] = c->h_e_tab[(size_t)t * 4 + 3];                       // the largest table value
             else if (cfg->model == CPPROB_HIP_MODEL_LINEAR_GAUSSIAN_1D) c->h_bound[(size_t)t] = normal_logpdf_hoisted(h_obs[t], h_obs[t], 1.0, c->mp.log_norm_unit);   // the emission's density at its mode
+            else if (cfg->model == CPPROB_HIP_MODEL_HMM_TABLE) { double b = -INFINITY; for (int s2 = 0; s2 < c->hk; ++s2) b = std::max(b, c->h_ll_tab[(size_t)t * 8 + s2]); c->h_bound[(size_t)t] = b; }
         }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -30,6 +30,10 @@ struct ModelParams {
     // point {k ln 2} above its maximum over z: a reference every particle's weight can be taken against BEFORE any is known
     double quad[2][3];
     double lw_ref;
+    // hmm over a caller-given table (cpprob_hip_set_hmm): k states, device tables
+    int hk;                                       // 2..8
+    const uint64_t* hk_thr;                       // [k][8]: ceil(2^32 * cumulative probability) of row s, entries 0..k-2
+    const double* hk_ll;                          // [T][8] log N(y_t; mean[s], 1)
 };
 
 // reference include/models/models.hpp:22-35 and src/models/gaussian.cpp:6-17 (same body,
@@ -226,6 +230,49 @@ struct ModelHmm3 {
         acc[0] += x == 0 ? w : 0.0;
         acc[1] += x == 1 ? w : 0.0;
         acc[2] += x == 2 ? w : 0.0;
+    }
+};
+
+// The body of include/models/models.hpp:114-141 over a caller-given table: k states (2..8), uniform initial state, emission
+// N(mean[s], 1), transition rows as weights (normalised like discrete_distribution does); predict(state, "State") before the
+// observe.  Rows and emission log-densities live in device tables (a run-time index into kernel arguments would go through
+// scratch memory).  Its steps run on fixed-point weights (step_fixed.hpp): bit-exact index work for any number of states.
+struct ModelHmmK {
+    using value_t = int32_t;
+    using store_t = int8_t;
+    static constexpr bool kIsInt = true;
+    static constexpr int kStats = 8;
+    static constexpr int kWeightTable = 0;        // (the prefix-count form is specialised for three values: models.hpp ModelHmm3)
+    __device__ static __forceinline__ void weight_table(const ModelParams&, int, double (&)[1], double (&)[1], double&) {}
+    __device__ static __forceinline__ int weight_index(value_t) { return 0; }
+    struct Rand { uint32_t w[4]; };
+    __device__ static __forceinline__ void draw4(uint64_t seed, uint64_t pid0, int t, Rand& r) { draw_words4(seed, pid0, (uint64_t)t, r.w); }
+    __device__ static __forceinline__ void apply4(const ModelParams& mp, int t, const Rand& r, const value_t (&prev)[4], value_t (&x)[4])
+    {
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = (value_t)smallint_from_word(r.w[k], 0, (uint64_t)mp.hk - 1);      // uniform_smallint{0, k-1}
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t* row = mp.hk_thr + 8 * prev[k];
+                int v = 0;
+                for (int j = 0; j + 1 < mp.hk; ++j) v += (uint64_t)r.w[k] >= row[j] ? 1 : 0;                      // discrete_distribution{T[state]}
+                x[k] = v;
+            }
+        }
+    }
+    __device__ static __forceinline__ void propagate4(const ModelParams& mp, uint64_t seed, uint64_t pid0, int t, const value_t (&prev)[4], value_t (&x)[4])
+    {
+        Rand r; draw4(seed, pid0, t, r); apply4(mp, t, r, prev, x);
+    }
+    static constexpr bool kBounded = false;
+    __device__ static __forceinline__ double logw_of_z(const ModelParams&, int, double) { return 0.0; }
+    __device__ static __forceinline__ double loglik(const ModelParams& mp, value_t s, int t, const double* __restrict__ /*obs*/) { return mp.hk_ll[8 * t + s]; }
+    __device__ static __forceinline__ void accumulate(value_t x, double w, double (&acc)[kStats])
+    {
+#pragma unroll
+        for (int s = 0; s < kStats; ++s) acc[s] += x == s ? w : 0.0;
     }
 };
 

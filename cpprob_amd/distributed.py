@@ -293,6 +293,19 @@ def normalise_joint_stats(raw, log_norm, max_logw, is_int):
 
 
 def run_joint(engine, collective, run_index=0, buffers=None, slot=None):
+    """run_joint_once; a single-rank population whose fixed-point weights lost too many bits is repeated in the floating-point form
+    (several locally resampling ranks run in that form anyway).  With `slot` nothing is read back and nothing is checked."""
+    from . import capi
+    try:
+        return run_joint_once(engine, collective, run_index, buffers, slot)
+    except capi.CpprobHipError as e:
+        if getattr(e, "code", 0) != capi.EPRECISION:
+            raise
+    engine.rebegin(capi.FLAG_FLOATING_POINT_STEP)
+    return run_joint_once(engine, collective, run_index, buffers, slot)
+
+
+def run_joint_once(engine, collective, run_index=0, buffers=None, slot=None):
     """One run of a joint population sharded over `collective.world` ranks (engine begun with
     scope=SCOPE_GLOBAL, n_global = sum of shards).  Returns (stats[T, K], summary dict)."""
     import torch
@@ -341,6 +354,19 @@ def shard_begins(n_global, world):
 
 
 def run_exchange(engine, collective, run_index=0, counters=None):
+    """run_exchange_once, repeated in the floating-point form when the fixed-point weights of the run lost too many bits (every
+    rank holds the same gap -- it comes from the all-gathered totals -- so every rank takes the same decision)."""
+    from . import capi
+    try:
+        return run_exchange_once(engine, collective, run_index, counters)
+    except capi.CpprobHipError as e:
+        if getattr(e, "code", 0) != capi.EPRECISION:
+            raise
+    engine.rebegin(capi.FLAG_FLOATING_POINT_STEP)
+    return run_exchange_once(engine, collective, run_index, counters)
+
+
+def run_exchange_once(engine, collective, run_index=0, counters=None):
     """One run of a joint population with EXACT global resampling (engine begun with scope=SCOPE_EXCHANGE on the shard
     shard_bounds(n_global, world, rank)).  Returns (stats[T, K], summary).  counters (dict) receives the number of
     lineage records this rank sent / received."""

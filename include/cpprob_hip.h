@@ -62,6 +62,11 @@ extern "C" {
                                                     n_predict = 2 = one predict hit of width 2, stats row d = component d.
                                                     One observe statement => smc runs as sis.                             */
 
+#define CPPROB_HIP_MODEL_HMM_TABLE 5             /* the model body of include/models/models.hpp:114-141 over a caller-given table
+                                                    (cpprob_hip_set_hmm before cpprob_hip_infer_begin): k states, 2 <= k <= 8, uniform
+                                                    initial state, emission N(mean[s], 1), transition row s as weights; predict "State"
+                                                    before every observe.  stats_per_predict = 8 (P(x_t = s), zeros beyond k)        */
+
 /* Resamplers (thesis Alg. 1 p.36: multinomial; remark p.36: systematic / stratified). */
 #define CPPROB_HIP_RESAMPLE_SYSTEMATIC 0
 #define CPPROB_HIP_RESAMPLE_STRATIFIED 1
@@ -166,6 +171,9 @@ int cpprob_hip_sync(cpprob_hip_ctx* ctx);
  *         real -> {mean, variance} (raw_moment(2) - mean^2, empirical_distribution.hpp:78-81);
  *         int  -> {P(x_t = 0), ..., P(x_t = k-1)} (distribution(), :30-40).
  */
+/* The table of CPPROB_HIP_MODEL_HMM_TABLE: h_means[k], h_transition[k * k] (row s = the weights discrete_distribution{T[s]} of
+ * models.hpp:135 would be built from).  Kept by the context until the next call. */
+int cpprob_hip_set_hmm(cpprob_hip_ctx* ctx, int32_t k, const double* h_means, const double* h_transition);
 int cpprob_hip_infer_begin(cpprob_hip_ctx* ctx, const cpprob_hip_config* cfg, const double* h_observes, size_t n_observes);
 int cpprob_hip_infer_run(cpprob_hip_ctx* ctx, uint64_t run_index);
 int cpprob_hip_infer_summary(cpprob_hip_ctx* ctx, cpprob_hip_summary* out);

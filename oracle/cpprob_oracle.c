@@ -43,7 +43,8 @@ enum { ORC_MODEL_GAUSSIAN_UNKNOWN_MEAN = 0, /* include/models/models.hpp:22-35 *
        ORC_MODEL_GAUSSIAN_README = 1,       /* src/models/gaussian.cpp:6-17    */
        ORC_MODEL_LINEAR_GAUSSIAN_1D = 2,    /* include/models/models.hpp:67-80 */
        ORC_MODEL_HMM3 = 3,                  /* include/models/models.hpp:114-141 */
-       ORC_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN = 4 }; /* include/models/models.hpp:38-49 (vector-valued statements) */
+       ORC_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN = 4, /* include/models/models.hpp:38-49 (vector-valued statements) */
+       ORC_MODEL_HMM_TABLE = 5 };           /* the body of models.hpp:114-141 with a caller-given table: k states (2..8), means, transition rows (orc_set_hmm) */
 enum { ORC_RESAMPLE_SYSTEMATIC = 0, ORC_RESAMPLE_STRATIFIED = 1, ORC_RESAMPLE_MULTINOMIAL = 2 };
 
 #define ORC_RESAMPLE_DRAW_BASE (1ull << 40) /* draw index of the resampling uniforms */
@@ -312,6 +313,29 @@ static void model_linear_gaussian_1d(orc_trace *tr, const double *obs, size_t T)
 /* include/models/models.hpp:114-141 */
 static const double HMM_MEAN[3] = { -1, 0, 1 };                               /* :122 */
 static const double HMM_T[3][3] = { { 0.1, 0.5, 0.4 }, { 0.2, 0.2, 0.6 }, { 0.15, 0.15, 0.7 } }; /* :123-125 */
+/* the same model body over a caller-given table (k states, emission means, transition rows): orc_set_hmm */
+static int HMMK_K = 0;
+static double HMMK_MEAN[8], HMMK_T[8][8];
+ORC_API int orc_set_hmm(int k, const double *means, const double *trans)
+{
+    if (k < 2 || k > 8) return -1;
+    HMMK_K = k;
+    for (int s = 0; s < k; ++s) { HMMK_MEAN[s] = means[s]; for (int j = 0; j < k; ++j) HMMK_T[s][j] = trans[s * k + j]; }
+    return 0;
+}
+static int is_hmm(int model) { return model == ORC_MODEL_HMM3 || model == ORC_MODEL_HMM_TABLE; }
+static int hmm_k(int model) { return model == ORC_MODEL_HMM3 ? 3 : HMMK_K; }
+static void model_hmm_table(orc_trace *tr, const double *obs, size_t T)
+{
+    uint64_t state = tr_sample_smallint(tr, 0, (uint64_t)HMMK_K - 1);     /* :126-127 with k states */
+    tr_predict_int(tr, state);
+    tr_observe_normal(tr, HMMK_MEAN[state], 1, obs[0]);
+    for (size_t t = 1; t < T; ++t) {
+        state = tr_sample_discrete(tr, HMMK_T[state], HMMK_K);
+        tr_predict_int(tr, state);
+        tr_observe_normal(tr, HMMK_MEAN[state], 1, obs[t]);
+    }
+}
 static void model_hmm3(orc_trace *tr, const double *obs, size_t T)
 {
     uint64_t state = tr_sample_smallint(tr, 0, 2);         /* :126-127 */
@@ -339,7 +363,7 @@ static void model_gaussian_2d_unk_mean(orc_trace *tr, const double *y)
     for (int d = 0; d < 2; ++d) tr_predict_real(tr, mu[d]);                   /* :48 "Mu" */
 }
 
-static int model_is_int(int model) { return model == ORC_MODEL_HMM3; }
+static int model_is_int(int model) { return model == ORC_MODEL_HMM3 || model == ORC_MODEL_HMM_TABLE; }
 ORC_API int orc_model_num_predicts(int model, size_t n_obs)
 { return (model == ORC_MODEL_GAUSSIAN_UNKNOWN_MEAN || model == ORC_MODEL_GAUSSIAN_README) ? 1 : (int)n_obs; }   /* 2-D model: one hit of 2 columns */
 
@@ -350,6 +374,7 @@ static int run_model(int model, orc_trace *tr, const double *obs, size_t n_obs)
     case ORC_MODEL_GAUSSIAN_README:       if (n_obs != 2) return -1; model_gaussian_readme(tr, obs); return 0;
     case ORC_MODEL_LINEAR_GAUSSIAN_1D:    if (n_obs < 1) return -1;  model_linear_gaussian_1d(tr, obs, n_obs); return 0;
     case ORC_MODEL_HMM3:                  if (n_obs < 1) return -1;  model_hmm3(tr, obs, n_obs); return 0;
+    case ORC_MODEL_HMM_TABLE:             if (n_obs < 1 || HMMK_K < 2) return -1;  model_hmm_table(tr, obs, n_obs); return 0;
     case ORC_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN: if (n_obs != 2) return -1; model_gaussian_2d_unk_mean(tr, obs); return 0;
     }
     return -2;
@@ -669,8 +694,11 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
                         double *hist_real, int32_t *hist_int, int32_t *hist_anc,
                         double *logw_final, double *log_z, double *ess_trace, int32_t *resampled, double *filter_stats)
 {
-    if (model != ORC_MODEL_LINEAR_GAUSSIAN_1D && model != ORC_MODEL_HMM3) return -2;
-    if ((model == ORC_MODEL_HMM3) != (hist_int != NULL)) return -3;
+    if (model != ORC_MODEL_LINEAR_GAUSSIAN_1D && !is_hmm(model)) return -2;
+    if (is_hmm(model) != (hist_int != NULL)) return -3;
+    if (model == ORC_MODEL_HMM_TABLE && HMMK_K < 2) return -5;
+    const int K = is_hmm(model) ? hmm_k(model) : 0;
+    const double *hmean = model == ORC_MODEL_HMM3 ? HMM_MEAN : HMMK_MEAN;
     double *logw = (double *)calloc(n, sizeof(double));
     double *cdf = (double *)malloc(n * sizeof(double));
     int32_t *anc = (int32_t *)malloc(n * sizeof(int32_t));
@@ -708,10 +736,10 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
                 lw += orc_normal_logpdf(obs[t], x, 1);
             } else {
                 uint64_t s;
-                if (t == 0) s = orc_draw_smallint(seed, i, 0, 0, 2);
-                else s = orc_draw_discrete(seed, i, (uint64_t)t, HMM_T[hist_int[(t - 1) * n + a]], 3);
+                if (t == 0) s = orc_draw_smallint(seed, i, 0, 0, (uint64_t)K - 1);
+                else s = orc_draw_discrete(seed, i, (uint64_t)t, model == ORC_MODEL_HMM3 ? HMM_T[hist_int[(t - 1) * n + a]] : HMMK_T[hist_int[(t - 1) * n + a]], K);
                 hist_int[t * n + i] = (int32_t)s;
-                lw += orc_normal_logpdf(obs[t], HMM_MEAN[s], 1);
+                lw += orc_normal_logpdf(obs[t], hmean[s], 1);
             }
             cdf[i] = lw;                                  /* staging: new logw */
         }
@@ -726,7 +754,7 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
             /* reference known before the generation exists; integer weights, masses and squares */
             double bound;
             if (model == ORC_MODEL_LINEAR_GAUSSIAN_1D) bound = orc_normal_logpdf(obs[t], obs[t], 1);
-            else { double e3[3]; hmm_weight_table(obs[t], e3, &bound); }
+            else { bound = orc_normal_logpdf(obs[t], hmean[0], 1); for (int s2 = 1; s2 < K; ++s2) { const double l = orc_normal_logpdf(obs[t], hmean[s2], 1); if (l > bound) bound = l; } }
             const double ref = (t == 0 || do_resample) ? bound : m_prev + bound;
             uint64_t S = 0, Q16 = 0;
             for (uint64_t i = 0; i < n; ++i) { qw[i] = orc_fix_weight(logw[i], ref); S += qw[i]; Q16 += (uint64_t)(qw[i] >> 16) * (uint64_t)(qw[i] >> 16); }
@@ -739,10 +767,10 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
         }
         if (ess_trace) ess_trace[t] = ess;
         if (filter_stats) {
-            if (model == ORC_MODEL_HMM3) {
-                double acc[3] = { 0.0, 0.0, 0.0 };
+            if (is_hmm(model)) {
+                double acc[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
                 for (uint64_t i = 0; i < n; ++i) acc[hist_int[t * n + i]] += fixed ? (double)qw[i] * (1.0 / 4294967296.0) : exp(logw[i] - max);
-                for (int k = 0; k < 3; ++k) filter_stats[t * 3 + k] = acc[k] / W;
+                for (int k = 0; k < K; ++k) filter_stats[t * K + k] = acc[k] / W;
             } else {
                 double s1 = 0.0, s2 = 0.0;
                 for (uint64_t i = 0; i < n; ++i) { const double w = fixed ? (double)qw[i] * (1.0 / 4294967296.0) : exp(logw[i] - max), x = hist_real[t * n + i]; s1 += w * x; s2 += w * x * x; }

@@ -65,6 +65,7 @@ def lib():
         L.orc_fix_weights.argtypes = [_dp, u64, dbl, _up]
         L.orc_resample_fixed_systematic.restype = C.c_int
         L.orc_resample_fixed_systematic.argtypes = [_up, u64, u64, u64, C.c_int, u64, u64, u64, u64, u64, _ip]
+        L.orc_set_hmm.restype = C.c_int; L.orc_set_hmm.argtypes = [C.c_int, _dp, _dp]
         L.orc_smc.restype = C.c_int
         L.orc_smc.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
                               C.POINTER(dbl), _dp, _ip]
@@ -96,8 +97,25 @@ def box_muller(words):
     return out
 
 
+MODEL_HMM_TABLE = 5
+
+
+def set_hmm(means, trans):
+    """The table of MODEL_HMM_TABLE: k = len(means) states (2..8), emission N(means[s], 1), transition rows trans[s] (weights)."""
+    means = np.ascontiguousarray(means, np.float64)
+    trans = np.ascontiguousarray(trans, np.float64)
+    assert trans.shape == (len(means), len(means))
+    if lib().orc_set_hmm(len(means), means, trans.reshape(-1)):
+        raise RuntimeError("orc_set_hmm failed")
+    global _HMM_K
+    _HMM_K = len(means)
+
+
+_HMM_K = 3
+
+
 def is_int_model(model):
-    return model == MODEL_HMM3
+    return model in (MODEL_HMM3, MODEL_HMM_TABLE)
 
 
 def sis(model, obs, n, seed, pid0=0):
@@ -217,7 +235,7 @@ def smc(model, obs, n, seed, resampler=RESAMPLE_SYSTEMATIC, ess_frac=2.0):
     lz = C.c_double(0.0)
     if is_int_model(model):
         hist = np.zeros((T, n), np.int32)
-        filt = np.zeros((T, 3))
+        filt = np.zeros((T, 3 if model == MODEL_HMM3 else _HMM_K))
         rc = lib().orc_smc_filter(model, obs, T, n, seed, resampler, ess_frac, None, hist.ctypes.data, anc, logw,
                                   C.byref(lz), ess, res, filt)
     else:

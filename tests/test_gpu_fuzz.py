@@ -55,7 +55,8 @@ def test_random_smc_runs_keep_their_invariants(engine, golden_dir, sweep):
                 # (against the fp64 weights: the 2^-32 resolution, relative to the heaviest particle -- visible where a handful of
                 #  particles carry the mass, e.g. runs that never resample)
                 assert np.allclose(st, O.smoothing_linear(vals, anc, O.fix_weights(logw, s["max_logw"]).astype(np.float64)), rtol=1e-10, atol=1e-12), tag
-                assert np.allclose(st, O.smoothing(vals, anc, logw), rtol=1e-5, atol=1e-7), tag
+                # (23 bits or more per weight; the variance column is a difference of moments, hence the looser bound)
+                assert np.allclose(st, O.smoothing(vals, anc, logw), rtol=1e-3, atol=1e-6), tag
             else:
                 assert np.allclose(st, O.smoothing(vals, anc, logw), rtol=1e-8, atol=1e-10), tag
             assert np.array_equal(engine.paths(), np.take_along_axis(vals, O.lineage(anc), axis=1)), tag

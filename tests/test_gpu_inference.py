@@ -890,3 +890,64 @@ def test_bench_two_ranks_on_one_gpu(scope, workload):
         key = "hmm128_logz" if workload == "hmm128_smc_ess" else "lgssm100_logz"
         assert abs(d["log_evidence"] - float(z[key])) < 0.05 and 0 < d["n_resampled"] < len(z[key.replace("_logz", "")]) - 1
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+HMM2 = ([-1.5, 1.0], [[0.85, 0.15], [0.3, 0.7]])
+HMM5 = ([-2.0, -1.0, 0.0, 1.0, 2.5], [[4, 2, 1, 1, 2], [1, 5, 2, 1, 1], [1, 1, 6, 1, 1], [2, 1, 1, 5, 1], [1, 1, 2, 2, 4]])
+
+
+@pytest.mark.parametrize("table", [HMM2, HMM5], ids=["2-state", "5-state"])
+@pytest.mark.parametrize("ess", [2.0, 0.5])
+@pytest.mark.parametrize("n", [30_000, 1_300_000])
+def test_table_hmm_of_any_size_is_bit_exact_against_the_oracle(engine, golden_dir, table, ess, n):
+    """CPPROB_HIP_MODEL_HMM_TABLE: the model body of models.hpp:114-141 over a caller-given table (here 2 and 5 states; transition
+    rows as un-normalised weights).  Its steps run on fixed-point weights, so the index work is integer arithmetic whatever the number
+    of states and the schedule: states and ancestors equal the oracle's, bit for bit, the estimator agrees with the oracle's applied
+    to the same integers, and the posterior matches forward-backward for that table."""
+    means, trans = np.array(table[0], float), np.array(table[1], float)
+    rng = np.random.default_rng(5)
+    T = 12
+    P = trans / trans.sum(1, keepdims=True)
+    st = rng.integers(0, len(means))
+    obs = np.zeros(T)
+    for t in range(T):
+        if t:
+            st = rng.choice(len(means), p=P[st])
+        obs[t] = means[st] + rng.standard_normal()
+    engine.set_hmm(means, trans)
+    O.set_hmm(means, trans)
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM_TABLE, obs, n, seed=19, ess_threshold=ess)
+    engine.run()
+    s, stats = engine.summary(), engine.stats()
+    assert s["step_form"] == cp.capi.FORM_FIXED and s["stats_per_predict"] == 8
+    ref = O.smc(O.MODEL_HMM_TABLE, obs, n, 19, O.RESAMPLE_SYSTEMATIC, ess)
+    vals, anc = engine.values(), engine.ancestors()
+    assert np.array_equal(vals, ref["hist"]) and np.array_equal(anc, ref["anc"])
+    gess, gres = engine.step_trace()
+    assert np.array_equal(gres, ref["resampled"]) and abs(s["log_evidence"] - ref["log_z"]) < 1e-9
+    np.testing.assert_allclose(gess, ref["ess"], rtol=1e-9)
+    k = len(means)
+    assert np.all(stats[:, k:] == 0.0)
+    q = O.fix_weights(engine.logw(), s["max_logw"]).astype(np.float64)
+    np.testing.assert_allclose(stats[:, :k], O.smoothing_linear(vals, anc, q, k=k), rtol=1e-11, atol=1e-13)
+    # exact smoothing marginals of this table (forward-backward)
+    lik = np.exp(-0.5 * ((obs[:, None] - means[None, :]) ** 2 + np.log(2 * np.pi)))
+    alpha = np.zeros((T, k)); c = np.zeros(T)
+    a = np.full(k, 1.0 / k) * lik[0]; c[0] = a.sum(); alpha[0] = a / c[0]
+    for t in range(1, T):
+        a = (alpha[t - 1] @ P) * lik[t]; c[t] = a.sum(); alpha[t] = a / c[t]
+    beta = np.ones((T, k))
+    for t in range(T - 2, -1, -1):
+        beta[t] = (P @ (lik[t + 1] * beta[t + 1])) / c[t + 1]
+    gamma = alpha * beta
+    gamma /= gamma.sum(1, keepdims=True)
+    assert np.abs(stats[:, :k] - gamma).max() < (4e-2 if n < 100_000 else 8e-3)
+    assert abs(s["log_evidence"] - np.log(c).sum()) < (5e-2 if n < 100_000 else 1e-2)
+    # SIS of the same model: every particle's trace and weight against the oracle's
+    engine.begin(cp.ALG_SIS, cp.MODEL_HMM_TABLE, obs, 20_000, seed=4)
+    engine.run()
+    v0, lw0 = O.sis(O.MODEL_HMM_TABLE, obs, 20_000, 4)
+    assert np.array_equal(engine.values(), v0)
+    np.testing.assert_allclose(engine.logw(), lw0, rtol=1e-12, atol=1e-12)
+    with pytest.raises(cp.CpprobHipError):
+        engine.set_hmm([0.0], [[1.0]])
