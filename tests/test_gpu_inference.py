@@ -549,7 +549,7 @@ def _run_joint_virtual(model, alg, obs, n_per, world, seed, ess):
     return stats, summ, traces
 
 
-def _run_exchange_virtual(model, obs, n_pers, seed, ess):
+def _run_exchange_virtual(model, obs, n_pers, seed, ess, flags=0):
     """EXCHANGE scope over virtual ranks: plan / pack / (in-process all-to-all) / commit.  Returns the joint stats, the
     summary, every shard's materialised traces [T, n_r] and the number of migrated lineage records per step."""
     import torch
@@ -558,7 +558,7 @@ def _run_exchange_virtual(model, obs, n_pers, seed, ess):
     begins = np.concatenate([[0], np.cumsum(n_pers)]).astype(np.uint64)
     engines = [cp.Engine(0) for _ in range(world)]
     for r, e in enumerate(engines):
-        e.begin(cp.ALG_SMC, model, obs, n_pers[r], seed=seed, ess_threshold=ess, particle_offset=int(begins[r]), n_global=int(begins[-1]), scope=cp.SCOPE_EXCHANGE)
+        e.begin(cp.ALG_SMC, model, obs, n_pers[r], seed=seed, ess_threshold=ess, particle_offset=int(begins[r]), n_global=int(begins[-1]), scope=cp.SCOPE_EXCHANGE, flags=flags)
     T, K = engines[0].T, engines[0].K
     vdt = torch.int32 if engines[0].is_int else torch.float64
     locals_ = [dzeros(4, dtype=torch.float64) for _ in range(world)]
@@ -647,7 +647,13 @@ def test_exchange_scope_survives_extreme_imbalance_and_grows_the_annex(engine, g
     engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=5, ess_threshold=0.5)
     engine.run()
     ref_paths, ref_stats, ref_sum = engine.paths(), engine.stats().copy(), engine.summary()
-    stats, s, paths, _, moved = _run_exchange_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n_pers, 5, 0.5)
+    # the observation lies ~5 standard deviations from every particle: the fixed-point weights lose their bits there, the single
+    # context repeated its run in the floating-point form by itself, a caller that drives the steps is told to
+    assert ref_sum["step_form"] == cp.capi.FORM_FLOAT
+    with pytest.raises(cp.CpprobHipError) as err:
+        _run_exchange_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n_pers, 5, 0.5)
+    assert err.value.code == cp.capi.EPRECISION
+    stats, s, paths, _, moved = _run_exchange_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n_pers, 5, 0.5, flags=cp.capi.FLAG_FLOATING_POINT_STEP)
     got = np.concatenate(paths, axis=1)
     assert (got != ref_paths).any(axis=0).sum() <= 2
     np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if (got != ref_paths).any() else 1e-11)
