@@ -34,6 +34,8 @@ struct ExchangePlan {
     int64_t recv_base[kWorldSlots];
     int64_t recv_off[kWorldSlots];
     int64_t run_records, run_bytes;   // what this rank's sources sent since step 0 of the run: lineage records, and their bytes (records x (t + 1) x value size)
+    int64_t src_shift;                // tiles by which this shard's outputs sit off its sources: output tile b draws from source tile ~ b + src_shift
+                                      // (the next step kernel aims its first probe and its prefetch there: a sharded CDF's offset is O(sqrt N) outputs)
 };
 
 struct ExchangeGeom {
@@ -55,7 +57,7 @@ struct PlanCountsIn {                 // prefix-count form: o_r from the all-gat
 
 // The plan as one wavefront holds it: lane r = what concerns rank r, plus the wave-uniform part.
 struct PlanLane { int64_t send_lo, send_cnt, send_base, recv_cnt, recv_base, recv_off; };
-struct PlanWave { int64_t l0, l1, n_send, n_recv; int32_t flags; bool resample; };
+struct PlanWave { int64_t l0, l1, n_send, n_recv, src_shift; int32_t flags; bool resample; };
 
 // o_r (lane r, r = 0 .. world) from the all-gathered {n_0, n_1, particles} of every rank: canonical integer arithmetic, the step
 // kernel's own expressions.  One wave, every lane.
@@ -97,6 +99,7 @@ __device__ __forceinline__ void plan_wave(const ExchangeGeom& g, double o, bool 
         }
     }
     if (resample) { l0 = (int64_t)(clampd(my_lo, mb, me) - mb); l1 = (int64_t)(clampd(my_hi, mb, me) - mb); }
+    pw.src_shift = resample ? (int64_t)floor((mb - my_lo) * (1.0 / kTile)) : 0;        // output mb is my sources' output number mb - my_lo
     // layout: fixed slots (capacity-checked) or compact blocks in rank order
     int64_t send_base = 0, recv_base = 0;
     const uint32_t rs_incl = wave_incl_scan_u32((uint32_t)recv_cnt), ss_incl = wave_incl_scan_u32((uint32_t)send_cnt);
@@ -139,7 +142,7 @@ __device__ __forceinline__ void plan_store(const ExchangeGeom& g, int t, const P
         ov |= pw.flags;
         if (over_annex) ov |= 4;
         plan->overflow = ov;
-        plan->l0 = pw.l0; plan->l1 = pw.l1; plan->n_send = pw.n_send; plan->n_recv = over_annex ? 0 : pw.n_recv;
+        plan->l0 = pw.l0; plan->l1 = pw.l1; plan->n_send = pw.n_send; plan->n_recv = over_annex ? 0 : pw.n_recv; plan->src_shift = pw.src_shift;
         if (t == 0) annex_base[0] = 0;
         annex_base[t + 1] = g.no_history ? 0 : base + (over_annex ? 0 : pw.n_recv);
         const int64_t rec0 = t == 0 ? 0 : plan->run_records, byt0 = t == 0 ? 0 : plan->run_bytes;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                     store4(Lx.slot, (int64_t)tid * kPPT, neg);
                 }
                 __syncthreads();
-                ancestors_fixed(a.f, fc, a.q_prev, a.n, a.nb, last_shard, (double)gj0, n_out, -16, anc, Lx);
+                ancestors_fixed(a.f, fc, a.q_prev, a.n, a.nb, last_shard, (double)gj0, n_out, r < a.rank ? 0 : a.nb - 1, anc, Lx);
             } else if constexpr (COUNTS) {
                 {
                     int32_t neg[kPPT];
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                     store4(Lc.slot, (int64_t)tid * kPPT, neg);
                 }
                 __syncthreads();
-                ancestors_counts<S, true>(a.h, tc, a.values + (int64_t)row_t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, -16, anc, Lc);
+                ancestors_counts<S, true>(a.h, tc, a.values + (int64_t)row_t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, r < a.rank ? 0 : a.nb - 1, anc, Lc);
             } else {
                 AncestorIn in;
                 in.wrel = a.wrel; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n;

@@ -361,7 +361,7 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
                                                  bool last_shard, double gj_first, int n_out, int guess, int32_t (&anc)[kPPT], CountsLds& L)
 {
     const Located loc = counts_locate(h, tc, n, nb, gj_first, n_out, guess, nullptr);
-    counts_walk<S, sharded>(tc, states, n, nb, last_shard, gj_first, n_out, loc, guess, 0u, 0u, 0u, anc, L);
+    counts_walk<S, sharded>(tc, states, n, nb, last_shard, gj_first, n_out, loc, /* no tile was prefetched */ -16, 0u, 0u, 0u, anc, L);
 }
 
 struct StepFound { Located loc; double inv, base0, base1, basev; int64_t l0, l1; };      // what the searching wavefront hands the other three
@@ -380,6 +380,7 @@ struct StepCountsArgs {
     // exact doubles; nullptr on a single shard
     const double* all_totals; int world, rank;
     const int64_t* annex_base;                                  // [T + 1]: annex columns in use before the immigrants of step t arrive
+    const int64_t* src_shift;                                   // exchange scope: tiles by which this shard's outputs sit off its sources (the previous exchange's plan)
     int row_w, row_r;                                           // rows of values[] this step writes / reads (t, t - 1; a filtering-only run: its two rows in turn)
     double* filter_stats;                                       // filtering-only run: [T][3], generation t-1's P(x = s) from its totals (nullptr otherwise)
 };
@@ -440,13 +441,17 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     uint64_t w_tot = 0;
     ProbeWords pw0{};
     double r0 = 0.0, r1 = 0.0, rv = 0.0;
+    // the source tile this output tile is expected to start in: its own index, moved by the shard's offset in a sharded run
+    int guess = bid;
+    if (SHARDED && t > 0 && a.src_shift) { const int64_t g2 = (int64_t)bid + *a.src_shift; guess = (int)(g2 < 0 ? 0 : (g2 >= nb ? nb - 1 : g2)); }
     if (t > 0) {
-        raw_0 = *reinterpret_cast<const uint32_t*>(prev_row + j0);
-        raw_m1 = *reinterpret_cast<const uint32_t*>(prev_row + (bid > 0 ? j0 - kTile : j0));
-        raw_p1 = *reinterpret_cast<const uint32_t*>(prev_row + (bid + 1 < nb ? j0 + kTile : j0));
+        const int64_t g0 = (int64_t)guess * kTile + (int64_t)tid * kPPT;
+        raw_0 = *reinterpret_cast<const uint32_t*>(prev_row + g0);
+        raw_m1 = *reinterpret_cast<const uint32_t*>(prev_row + (guess > 0 ? g0 - kTile : g0));
+        raw_p1 = *reinterpret_cast<const uint32_t*>(prev_row + (guess + 1 < nb ? g0 + kTile : g0));
         if (searcher) {
             w_tot = hier_total_fetch(a.h);
-            probe_fetch(a.h, bid, nb, pw0);
+            probe_fetch(a.h, guess, nb, pw0);
             if (SHARDED) {
                 const int r = tid < a.world ? tid : 0;
                 r0 = a.all_totals[3 * r]; r1 = a.all_totals[3 * r + 1]; rv = a.all_totals[3 * r + 2];
@@ -461,8 +466,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) anc[k] = (int32_t)(j0 + k);
     if (t > 0) {
-        if (bid == 0) raw_m1 = 0u;
-        if (bid + 1 >= nb) raw_p1 = 0u;
+        if (guess == 0) raw_m1 = 0u;
+        if (guess + 1 >= nb) raw_p1 = 0u;
         {
             int32_t neg[kPPT];
             lane_fill(neg, (int32_t)-1);
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
                     fs[0] = __dmul_rn(tot0, tc.e0) / W; fs[1] = __dmul_rn(tot1, tc.e1) / W; fs[2] = __dmul_rn(tot2, tc.e2) / W;
                 }
             }
-            const Located loc = counts_locate(a.h, tc, a.n, nb, gj_first, n_out, bid, &pw0);
+            const Located loc = counts_locate(a.h, tc, a.n, nb, gj_first, n_out, guess, &pw0);
             int64_t l0 = 0, l1 = 0;
             if (SHARDED) {
                 // outputs below o_lo / at or beyond o_hi descend from other shards' sources
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         const Located loc = s_found.loc;
         tc.inv = s_found.inv;
         if (SHARDED) { tc.base0 = s_found.base0; tc.base1 = s_found.base1; tc.basev = s_found.basev; }
-        counts_walk<S, SHARDED>(tc, prev_row, a.n, nb, last_shard, gj_first, n_out, loc, bid, raw_m1, raw_0, raw_p1, anc, L);
+        counts_walk<S, SHARDED>(tc, prev_row, a.n, nb, last_shard, gj_first, n_out, loc, guess, raw_m1, raw_0, raw_p1, anc, L);
         if (SHARDED) {
             // the lineages of the outputs other shards' sources own arrived as annex columns, in output order (cpprob_hip exchange
             // commit)

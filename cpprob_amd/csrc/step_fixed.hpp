@@ -374,6 +374,7 @@ struct StepFixedArgs {
     StepCtrl* ctrl; double n_pop; double* ess_trace; int32_t* resampled;
     const uint64_t* all_totals; int world, rank;       // one shard of a joint population (exchange scope): every rank's {S, Q, key(M)} of generation t-1
     const int64_t* annex_base;
+    const int64_t* src_shift;                  // exchange scope: where the previous exchange's plan left the offset of this shard's outputs against its sources (tiles)
     int row_w, row_r;
 };
 
@@ -421,15 +422,19 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
     uint64_t rs_ = 0, rq_ = 0, rm_ = 0;
     double lw_carry[kPPT];
     lane_fill(lw_carry, 0.0);
+    // the source tile this output tile is expected to start in: its own index, moved by the shard's offset in a sharded run
+    int guess = bid;
+    if (SHARDED && t > 0 && a.src_shift) { const int64_t g2 = (int64_t)bid + *a.src_shift; guess = (int)(g2 < 0 ? 0 : (g2 >= nb ? nb - 1 : g2)); }
     if (t > 0) {
         if (a.prefetch) {
-            q_0 = *reinterpret_cast<const U4*>(a.q_prev + j0);
-            q_m1 = *reinterpret_cast<const U4*>(a.q_prev + (bid > 0 ? j0 - kTile : j0));
-            q_p1 = *reinterpret_cast<const U4*>(a.q_prev + (bid + 1 < nb ? j0 + kTile : j0));
+            const int64_t g0 = (int64_t)guess * kTile + (int64_t)tid * kPPT;
+            q_0 = *reinterpret_cast<const U4*>(a.q_prev + g0);
+            q_m1 = *reinterpret_cast<const U4*>(a.q_prev + (guess > 0 ? g0 - kTile : g0));
+            q_p1 = *reinterpret_cast<const U4*>(a.q_prev + (guess + 1 < nb ? g0 + kTile : g0));
         }
         if (searcher) {
             ftot_fetch(a.f, tw);
-            probe_fetch(a.f.h, bid, nb, pw0);
+            probe_fetch(a.f.h, guess, nb, pw0);
             if (SHARDED) { const int r = tid < a.world ? tid : 0; rs_ = a.all_totals[3 * r]; rq_ = a.all_totals[3 * r + 1]; rm_ = a.all_totals[3 * r + 2]; }
         }
     }
@@ -443,8 +448,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
     bool resample = false;
     double ref = a.bound;                                              // R_0 = B_0
     if (t > 0) {
-        if (bid == 0) q_m1 = U4{0u, 0u, 0u, 0u};
-        if (bid + 1 >= nb) q_p1 = U4{0u, 0u, 0u, 0u};
+        if (guess == 0) q_m1 = U4{0u, 0u, 0u, 0u};
+        if (guess + 1 >= nb) q_p1 = U4{0u, 0u, 0u, 0u};
         {
             int32_t neg[kPPT];
             lane_fill(neg, (int32_t)-1);
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
             FLocated loc{0, 0, 0};
             int64_t l0 = 0, l1 = a.n;
             if (d.resample) {
-                loc = fixed_locate(a.f, fc, nb, gj_first, n_out, bid, &pw0);
+                loc = fixed_locate(a.f, fc, nb, gj_first, n_out, guess, &pw0);
                 if (SHARDED) {
                     // outputs below o_lo / at or beyond o_hi descend from other shards' sources
                     const double o_lo = fc.g(0), o_hi = last_shard ? a.n_pop : fc.g(own.S);
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
         ref = s_found.ref;
         if (resample) {
             fc.inv = s_found.inv; fc.base = s_found.base;
-            fixed_walk(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, bid, a.prefetch != 0, q_m1, q_0, q_p1, anc, L);
+            fixed_walk(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, guess, a.prefetch != 0, q_m1, q_0, q_p1, anc, L);
             if (SHARDED) {
                 const int64_t l0 = s_found.l0, l1 = s_found.l1;
                 const int64_t col0 = a.ld + a.annex_base[t - 1];

@@ -647,18 +647,31 @@ def test_exchange_scope_survives_extreme_imbalance_and_grows_the_annex(engine, g
     engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=5, ess_threshold=0.5)
     engine.run()
     ref_paths, ref_stats, ref_sum = engine.paths(), engine.stats().copy(), engine.summary()
-    # the observation lies ~5 standard deviations from every particle: the fixed-point weights lose their bits there, the single
-    # context repeated its run in the floating-point form by itself, a caller that drives the steps is told to
-    assert ref_sum["step_form"] == cp.capi.FORM_FLOAT
-    with pytest.raises(cp.CpprobHipError) as err:
-        _run_exchange_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n_pers, 5, 0.5)
-    assert err.value.code == cp.capi.EPRECISION
-    stats, s, paths, _, moved = _run_exchange_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n_pers, 5, 0.5, flags=cp.capi.FLAG_FLOATING_POINT_STEP)
+    stats, s, paths, _, moved = _run_exchange_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n_pers, 5, 0.5)
     got = np.concatenate(paths, axis=1)
     assert (got != ref_paths).any(axis=0).sum() <= 2
     np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-4 if (got != ref_paths).any() else 1e-11)
     assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-11
     assert max(moved) > 40000 // 16 + 4096                                      # beyond the initial annex: it grew
+
+
+def test_caller_driven_run_is_told_when_the_fixed_point_weights_lost_their_bits(engine, golden_dir):
+    """The step protocol cannot be repeated by the library: a run whose heaviest particle sat more than 6 nats below the reference
+    (an observation ~30 standard deviations from every particle) returns CPPROB_HIP_EPRECISION from the first call that reads its
+    results; with CPPROB_HIP_FLAG_FLOATING_POINT_STEP it runs, and matches the single context (which repeated itself)."""
+    obs = np.array(_obs(golden_dir, "lgssm100")[:10])
+    obs[4] = 40.0
+    n_pers = [3000, 2000]
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, sum(n_pers), seed=5, ess_threshold=0.5)
+    engine.run()
+    ref_stats, ref_sum = engine.stats().copy(), engine.summary()
+    assert ref_sum["step_form"] == cp.capi.FORM_FLOAT
+    with pytest.raises(cp.CpprobHipError) as err:
+        _run_exchange_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n_pers, 5, 0.5)
+    assert err.value.code == cp.capi.EPRECISION
+    stats, s, _, _, _ = _run_exchange_virtual(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n_pers, 5, 0.5, flags=cp.capi.FLAG_FLOATING_POINT_STEP)
+    assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-9
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=5e-3)
 
 
 def test_exchange_scope_world1_is_bit_identical_to_run(engine, golden_dir):
