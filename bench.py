@@ -328,7 +328,7 @@ def main():
             native_error = str(e)
     moved = {}
     reruns = 0
-    traffic = None
+    xtraffic = None
     if world == 1 and args.loopback_ranks > 1 and smc:
         group = cp.Group([local] * args.loopback_ranks)
         n_global, exchange, scope = n, True, "exchange"
@@ -336,7 +336,7 @@ def main():
     if group is not None:
         group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
         dt, stats, summ, reruns = timed_group_runs(group, args.steps, args.warmup, world, device)
-        traffic = group.traffic()
+        xtraffic = group.traffic()
         last = (stats,)
     else:
         eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
@@ -355,8 +355,8 @@ def main():
         summ = eng.summary()
     if last is not None and len(last) == 3:
         summ["log_evidence"] = last[1]          # evidence of the joint population (shards combined), not of this rank's shard
-    if exchange and traffic is not None:
-        tname = {0: "none", 1: "direct stores into the receiving rank's buffer (peer access / hipIpc), ordered by a 1-double all_gather", 2: "ncclSend/ncclRecv of fixed-capacity segments"}[traffic["transport"]]
+    if exchange and xtraffic is not None:
+        tname = {0: "none", 1: "direct stores into the receiving rank's buffer (peer access / hipIpc), ordered by a 1-double all_gather", 2: "ncclSend/ncclRecv of fixed-capacity segments"}[xtraffic["transport"]]
         collective = "all_gather(24 bytes/rank) per step; migrating lineages: %s; all_reduce(T*K+3 doubles) per run" % tname
     elif exchange:
         collective = "all_gather(3 doubles/rank) + all_to_all_v of the migrating lineages per step (torch.distributed host); all_reduce(T*K+1 doubles) per run"
@@ -439,11 +439,11 @@ def main():
 
     if native_error:
         out["config"]["native_driver_error"] = native_error
-    if traffic is not None:
+    if xtraffic is not None:
         # bytes of ONE run (the last one collected): what crossed the links for the migrating lineages, and the small collectives
-        out["exchange_traffic_per_run"] = {"records": traffic["records"], "payload_bytes": traffic["payload_bytes"], "wire_bytes": traffic["wire_bytes"],
-                                           "collective_bytes": traffic["collective_bytes"],
-                                           "transport": {0: "none", 1: "direct", 2: "sendrecv"}[traffic["transport"]]}
+        out["exchange_traffic_per_run"] = {"records": xtraffic["records"], "payload_bytes": xtraffic["payload_bytes"], "wire_bytes": xtraffic["wire_bytes"],
+                                           "collective_bytes": xtraffic["collective_bytes"],
+                                           "transport": {0: "none", 1: "direct", 2: "sendrecv"}[xtraffic["transport"]]}
 
     def emit():
         if rank == 0:
