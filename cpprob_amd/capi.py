@@ -23,7 +23,7 @@ SYMBOLS = [
     "cpprob_hip_infer_stats", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
     "cpprob_hip_smc_finish", "cpprob_hip_filter_masses", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
-    "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_exchange_direct", "cpprob_hip_exchange_traffic",
+    "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_exchange_direct", "cpprob_hip_exchange_traffic", "cpprob_hip_exchange_store", "cpprob_hip_exchange_remote",
     "cpprob_hip_group_create_external", "cpprob_hip_group_traffic", "cpprob_hip_group_unique_id", "cpprob_hip_group_create", "cpprob_hip_group_destroy",
     "cpprob_hip_group_last_error", "cpprob_hip_group_begin", "cpprob_hip_group_transport", "cpprob_hip_group_run", "cpprob_hip_group_sync", "cpprob_hip_group_size",
     "cpprob_hip_group_context", "cpprob_hip_group_results", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
@@ -66,10 +66,10 @@ class Collectives(C.Structure):
 
 class Traffic(C.Structure):
     _fields_ = [("records", C.c_uint64), ("payload_bytes", C.c_uint64), ("wire_bytes", C.c_uint64), ("collective_bytes", C.c_uint64),
-                ("transport", C.c_int32), ("reserved", C.c_int32)]
+                ("transport", C.c_int32), ("remote_lineages", C.c_int32)]
 
 
-GROUP_SENDRECV, GROUP_WORLD1_COLLECTIVES = 1, 2
+GROUP_SENDRECV, GROUP_WORLD1_COLLECTIVES, GROUP_SHIP_LINEAGES = 1, 2, 4
 TRANSPORT_NONE, TRANSPORT_DIRECT, TRANSPORT_SENDRECV = 0, 1, 2
 
 _lib = None
@@ -127,6 +127,8 @@ def load_library(path=None):
         "cpprob_hip_group_create_external": (C.c_int, [i32, i32, i32, C.POINTER(Collectives), C.POINTER(vp)]),
         "cpprob_hip_group_traffic": (C.c_int, [vp, C.POINTER(Traffic)]),
         "cpprob_hip_exchange_direct": (C.c_int, [vp, vp]),
+        "cpprob_hip_exchange_store": (C.c_int, [vp, vp]),
+        "cpprob_hip_exchange_remote": (C.c_int, [vp, vp]),
         "cpprob_hip_exchange_traffic": (C.c_int, [vp, vp, sz, C.POINTER(u64), C.POINTER(u64)]),
         "cpprob_hip_group_run": (C.c_int, [vp, u64]),
         "cpprob_hip_group_sync": (C.c_int, [vp]),
@@ -515,7 +517,7 @@ class Group:
         """Of the run results() last collected: dict of records, payload_bytes, wire_bytes, collective_bytes, transport."""
         t = Traffic()
         self._chk(self.L.cpprob_hip_group_traffic(self.h, C.byref(t)))
-        return {f: getattr(t, f) for f, _ in Traffic._fields_ if f != "reserved"}
+        return {f: getattr(t, f) for f, _ in Traffic._fields_}
 
     def run(self, run_index=0):
         self._chk(self.L.cpprob_hip_group_run(self.h, int(run_index)))

@@ -98,6 +98,8 @@ struct cpprob_hip_ctx {
     // direct transport: the packing kernel stores records straight into the receivers' buffers (cpprob_hip_exchange_direct)
     bool x_direct = false; void** d_peer_recv = nullptr; int32_t* d_peer_slot = nullptr;
     int64_t* d_sent = nullptr; int sent_cap = 0;  // [T] records sent after each step of the last run (traffic accounting)
+    // remote lineages (cpprob_hip_exchange_remote): migrants leave their history where it is; d_origin[annex column] = (rank << 32) | slot
+    bool x_remote = false; int64_t* d_origin = nullptr; int64_t origin_cap = 0; RemoteStores* d_remote = nullptr;
     std::vector<uint64_t> x_shard_begin;
     int x_plan_t = -1;                            // step whose plan sits in d_xplan
     struct { int t = -1; bool resample = false; std::vector<uint64_t> send_lo, send_cnt; uint64_t n_send = 0, n_recv = 0; int64_t l0 = 0, l1 = 0; } plan;
@@ -610,6 +612,7 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
     a.identity = c->cfg.algorithm == CPPROB_HIP_ALG_SIS ? 1 : 0;
     a.stats_part = c->d_stats_part;
     a.paths = with_paths ? static_cast<typename Model::value_t*>(c->d_paths) : nullptr;
+    a.rem = (c->x_remote && c->sharded) ? c->d_remote : nullptr;
     const size_t shm = (size_t)kWaves * c->T * Model::kStats * sizeof(double);
     {
         ProfScope ps(c, 2);
@@ -712,7 +715,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
     dfree(c->d_ctrl); dfree(c->d_local_totals);
-    dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent);
+    dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent); dfree(c->d_origin); dfree(c->d_remote);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -1134,7 +1137,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
         else dispatch_model(c, [&](auto m) { launch_step<decltype(m)>(c, t); });
         launch_scan(c, t, 1, nullptr, 1, 0);
     }
-    if (c->d_skip && t >= kSkipEvery && (t % kSkipEvery) == 0 && !sis) {
+    if (c->d_skip && !c->x_remote && t >= kSkipEvery && (t % kSkipEvery) == 0 && !sis) {
         // every eighth step: where each local slot's lineage sat eight generations ago
         hipLaunchKernelGGL(skip_rows_kernel, dim3((unsigned)((c->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, (const int32_t*)c->d_anc, c->rs, c->n,
                            (const int32_t*)c->d_resampled, t, c->d_skip + (size_t)(t / kSkipEvery) * c->rs);
@@ -1233,7 +1236,7 @@ int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
     g.slot_of_rank = fixed_layout ? c->d_slot_of_rank : nullptr; g.cap = fixed_layout ? c->x_cap : (int64_t)1 << 40;
     g.annex_cap = fixed_layout ? c->annex_cap : (int64_t)1 << 40;      // (callers that synchronise grow the annex themselves)
     g.bytes_per_value = (int)(fixed_layout ? c->ssz : (c->is_int ? sizeof(int32_t) : sizeof(double))); g.sent_per_step = c->d_sent;
-    g.no_history = c->keep ? 0 : 1;
+    g.no_history = c->keep ? 0 : 1; g.remote = (c->x_remote && c->keep && fixed_layout) ? 1 : 0;
     PlanCountsIn pc{};
     pc.all_totals = c->x_all_totals; pc.n_pop = (double)c->pop_n;
     if (c->fixed_mode) {
@@ -1261,15 +1264,15 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid, bool plan_inside
 {
     PackArgs<Model, R> a{};
     if (c->x_direct && c->x_fixed) { a.peer_recv = c->d_peer_recv; a.peer_slot = c->d_peer_slot; a.cap = c->x_cap; }
-    a.geom.no_history = c->keep ? 0 : 1;
+    a.geom.no_history = c->keep ? 0 : 1; a.geom.remote = (c->x_remote && c->keep && c->x_fixed) ? 1 : 0;
     if (plan_inside) {
         a.geom.world = c->x_world; a.geom.rank = c->x_rank; a.geom.n = c->n; a.geom.shard_begin = c->d_shard_begin; a.geom.slot_of_rank = c->d_slot_of_rank;
-        a.geom.cap = c->x_cap; a.geom.annex_cap = c->annex_cap; a.geom.bytes_per_value = (int)c->ssz; a.geom.sent_per_step = c->d_sent; a.geom.no_history = c->keep ? 0 : 1;
+        a.geom.cap = c->x_cap; a.geom.annex_cap = c->annex_cap; a.geom.bytes_per_value = (int)c->ssz; a.geom.sent_per_step = c->d_sent;
         a.annex_base = c->d_annex_base; a.plan_out = c->d_xplan;
     }
     a.values = static_cast<const typename Model::store_t*>(c->d_values); a.anc = c->d_anc; a.rs = c->rs; a.n = c->n; a.nb = c->nb;
     a.resampled = c->d_resampled; a.t = t; a.plan = c->d_xplan; a.world = c->x_world; a.rank = c->x_rank; a.send = d_send;
-    a.skip = (c->keep && c->d_skip && t >= 2 * kSkipEvery) ? c->d_skip : nullptr;
+    a.skip = (c->keep && !a.geom.remote && c->d_skip && t >= 2 * kSkipEvery) ? c->d_skip : nullptr;
     const dim3 pgrid((unsigned)grid, a.skip ? (unsigned)(t / kSkipEvery + 1) : 1u);
     a.pc.all_totals = c->x_all_totals; a.pc.n_pop = (double)c->pop_n;
     a.wrel = c->d_wrel[c->cur]; a.bc = c->d_bc; a.bf = c->d_bf; a.ctrl = c->d_ctrl; a.seed = c->run_seed; a.pid0 = c->cfg.particle_offset;
@@ -1301,8 +1304,9 @@ template <class Model, class R>
 void launch_commit(cpprob_hip_ctx* c, int t, const R* d_recv, int grid)
 {
     using S = typename Model::store_t;
+    const bool remote = c->x_remote && c->keep && c->x_fixed;
     hipLaunchKernelGGL((exchange_commit_kernel<S, R>), dim3(grid), dim3(kThreads), 0, c->stream, (const ExchangePlan*)c->d_xplan, c->x_world, d_recv, t,
-                       (const int64_t*)c->d_annex_base, static_cast<S*>(c->d_values), c->d_anc, c->rs, c->ld, c->d_skip);
+                       (const int64_t*)c->d_annex_base, static_cast<S*>(c->d_values), c->d_anc, c->rs, c->ld, c->d_skip, remote ? c->d_origin : nullptr, c->x_cap);
 }
 
 // more annex columns: re-stride values[] / anc[] (callers that synchronise per step only)
@@ -1411,7 +1415,7 @@ int cpprob_hip_exchange_setup(cpprob_hip_ctx* c, int32_t world, int32_t rank, co
     if (!c->d_slot_of_rank) HIP_TRY(c, hipMalloc(&c->d_slot_of_rank, kWorldSlots * sizeof(int32_t)));
     HIP_TRY(c, hipMemcpy(c->d_slot_of_rank, slot.data(), kWorldSlots * sizeof(int32_t), hipMemcpyHostToDevice));
     c->x_cap = (int64_t)records_per_peer; c->x_mode = all_peers ? 1 : 0; c->x_fixed = true;
-    const size_t need = std::max<size_t>(1, c->x_peers.size()) * (size_t)records_per_peer * (size_t)c->T * c->ssz;
+    const size_t need = std::max<size_t>(1, c->x_peers.size()) * (size_t)records_per_peer * std::max<size_t>((size_t)c->T * c->ssz, c->ssz + 4);
     if (need > c->x_buf_bytes) {
         dfree(c->d_xsend); dfree(c->d_xrecv);
         HIP_TRY(c, hipMalloc(&c->d_xsend, need));
@@ -1419,7 +1423,7 @@ int cpprob_hip_exchange_setup(cpprob_hip_ctx* c, int32_t world, int32_t rank, co
         c->x_buf_bytes = need;
     }
     c->x_world = world; c->x_rank = rank;
-    c->x_direct = false;                                   // (the peers' buffers may have moved: cpprob_hip_exchange_direct again)
+    c->x_direct = false; c->x_remote = false;              // (the peers' buffers may have moved: cpprob_hip_exchange_direct / _remote again)
     if (c->T > c->sent_cap) { dfree(c->d_sent); HIP_TRY(c, hipMalloc(&c->d_sent, (size_t)c->T * sizeof(int64_t))); c->sent_cap = c->T; }
     HIP_TRY(c, hipMemset(c->d_sent, 0, (size_t)c->sent_cap * sizeof(int64_t)));
     return 0;
@@ -1446,6 +1450,40 @@ int cpprob_hip_exchange_direct(cpprob_hip_ctx* c, void* const* h_peer_recv)
     HIP_TRY(c, hipMemcpy(c->d_peer_recv, ptr.data(), kWorldSlots * sizeof(void*), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_peer_slot, slot.data(), kWorldSlots * sizeof(int32_t), hipMemcpyHostToDevice));
     c->x_direct = true;
+    return 0;
+}
+
+int cpprob_hip_exchange_store(cpprob_hip_ctx* c, cpprob_hip_store* out)
+{
+    if (!c || !out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->begun || !c->exchange || !c->keep) return fail(c, CPPROB_HIP_ESTATE, "no history-keeping exchange-scope run begun");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->annex_cap > c->origin_cap || !c->d_origin) {
+        dfree(c->d_origin);
+        HIP_TRY(c, hipMalloc(&c->d_origin, (size_t)std::max<int64_t>(c->annex_cap, 1) * sizeof(int64_t)));
+        c->origin_cap = c->annex_cap;
+    }
+    out->d_values = c->d_values; out->d_ancestors = c->d_anc; out->d_origin = c->d_origin; out->row_stride = (uint64_t)c->rs; out->n_local_columns = (uint64_t)c->ld;
+    return 0;
+}
+
+int cpprob_hip_exchange_remote(cpprob_hip_ctx* c, const cpprob_hip_store* h_stores)
+{
+    if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
+    if (!c->x_fixed || !c->x_direct) return fail(c, CPPROB_HIP_ESTATE, "remote lineages ride the direct transport: cpprob_hip_exchange_setup and _direct first");
+    if (!h_stores) { c->x_remote = false; return 0; }
+    if (!c->keep) return 0;                                 // (a filtering-only shard has no lineages to leave anywhere)
+    HIP_TRY(c, hipSetDevice(c->device));
+    RemoteStores rs{};
+    rs.world = c->x_world; rs.rank = c->x_rank;
+    for (int r = 0; r < c->x_world; ++r) {
+        if (!h_stores[r].d_values || !h_stores[r].d_ancestors || !h_stores[r].d_origin) return fail(c, CPPROB_HIP_EINVAL, "cpprob_hip_exchange_remote: a rank's store is missing");
+        rs.values[r] = h_stores[r].d_values; rs.anc[r] = static_cast<const int32_t*>(h_stores[r].d_ancestors); rs.origin[r] = static_cast<const int64_t*>(h_stores[r].d_origin);
+        rs.rs[r] = (int64_t)h_stores[r].row_stride; rs.ld[r] = (int64_t)h_stores[r].n_local_columns;
+    }
+    if (!c->d_remote) HIP_TRY(c, hipMalloc(&c->d_remote, sizeof(RemoteStores)));
+    HIP_TRY(c, hipMemcpy(c->d_remote, &rs, sizeof rs, hipMemcpyHostToDevice));
+    c->x_remote = true;
     return 0;
 }
 

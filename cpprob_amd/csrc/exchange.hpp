@@ -48,6 +48,9 @@ struct ExchangeGeom {
     int bytes_per_value;              // of the transported records (traffic accounting)
     int no_history;                   // filtering-only shards (keep_history = 0): a migrant is its current state alone -- records of ONE
                                       // value, and the annex is reused by every step's immigrants
+    int remote;                       // remote lineages: a migrant is its current state and the slot it sits in on the rank it leaves --
+                                      // its history STAYS there, and whoever walks the lineage later (read-out, trace dump) continues in
+                                      // that rank's particle store through the peer mapping (cpprob_hip_exchange_remote)
     int64_t* sent_per_step;           // [T] device, may be nullptr: records this rank sent after each step
 };
 
@@ -147,7 +150,7 @@ __device__ __forceinline__ void plan_store(const ExchangeGeom& g, int t, const P
         annex_base[t + 1] = g.no_history ? 0 : base + (over_annex ? 0 : pw.n_recv);
         const int64_t rec0 = t == 0 ? 0 : plan->run_records, byt0 = t == 0 ? 0 : plan->run_bytes;
         plan->run_records = rec0 + pw.n_send;
-        plan->run_bytes = byt0 + pw.n_send * (int64_t)(g.no_history ? 1 : t + 1) * (int64_t)g.bytes_per_value;
+        plan->run_bytes = byt0 + pw.n_send * (g.remote ? (int64_t)g.bytes_per_value + 4 : (int64_t)(g.no_history ? 1 : t + 1) * (int64_t)g.bytes_per_value);
         if (g.sent_per_step) g.sent_per_step[t] = pw.n_send;
     }
 }
@@ -306,16 +309,19 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
         const double W = tc.cdf(t0, t1, a.pc.n_pop);
         tc.inv = a.pc.n_pop / W;
     }
-    const bool no_history = a.geom.no_history != 0;
-    const int len = no_history ? 1 : a.t + 1;
+    const bool no_history = a.geom.no_history != 0, remote = a.geom.remote != 0;
+    const int len = (no_history || remote) ? 1 : a.t + 1;
     const int row_t = no_history ? (a.t & 1) : a.t;              // where generation t's values sit
     for (int r = 0; r < a.world; ++r) {
         const int64_t cnt = PLAN_INSIDE ? s_send_cnt[r] : a.plan->send_cnt[r];
         if (r == a.rank || cnt == 0) continue;                  // uniform
         const int64_t lo = PLAN_INSIDE ? s_send_lo[r] : a.plan->send_lo[r];
         // where rank r's records go: its own receive slot for this rank (direct stores), or this rank's send buffer
-        R* const dst = a.peer_recv ? static_cast<R*>(a.peer_recv[r]) + (int64_t)a.peer_slot[r] * a.cap * (int64_t)len
+        // (remote lineages: a slot of the receiver's buffer is cap values followed by cap int32 origin slots)
+        R* const dst = remote ? reinterpret_cast<R*>(static_cast<char*>(a.peer_recv[r]) + (int64_t)a.peer_slot[r] * a.cap * (int64_t)(sizeof(R) + 4))
+                     : a.peer_recv ? static_cast<R*>(a.peer_recv[r]) + (int64_t)a.peer_slot[r] * a.cap * (int64_t)len
                                    : a.send + (PLAN_INSIDE ? s_send_base[r] : a.plan->send_base[r]) * (int64_t)len;
+        int32_t* const dst_slot = remote ? reinterpret_cast<int32_t*>(reinterpret_cast<char*>(dst) + a.cap * (int64_t)sizeof(R)) : nullptr;
         for (int64_t tl = blockIdx.x; tl * kTile < cnt; tl += gridDim.x) {
             const int64_t rem = cnt - tl * kTile;
             const int n_out = rem < kTile ? (int)rem : kTile;
@@ -362,11 +368,15 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) { if (on[k]) idx[k] = arow[idx[k]]; }
                 };
-                if (no_history) {
-                    // the migrant is its current state
+                if (no_history || remote) {
+                    // the migrant is its current state (and, with remote lineages, the slot its history stays in)
                     const typename Model::store_t* __restrict__ vrow = a.values + (int64_t)row_t * a.rs;
 #pragma unroll
-                    for (int k = 0; k < kPPT; ++k) { if (on[k]) __builtin_nontemporal_store(static_cast<R>(vrow[idx[k]]), rec[k]); }
+                    for (int k = 0; k < kPPT; ++k) {
+                        if (!on[k]) continue;
+                        __builtin_nontemporal_store(static_cast<R>(vrow[idx[k]]), rec[k]);
+                        if (remote) __builtin_nontemporal_store(idx[k], dst_slot + (tl * kTile + tid * kPPT + k));
+                    }
                     __syncthreads();
                     continue;
                 }
@@ -406,9 +416,27 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
 template <class S, class R>
 __global__ __launch_bounds__(kThreads) void exchange_commit_kernel(const ExchangePlan* __restrict__ plan, int world, const R* __restrict__ recv, int t,
                                                                     const int64_t* __restrict__ annex_base, S* __restrict__ values, int32_t* __restrict__ anc,
-                                                                    int64_t rs, int64_t ld, int32_t* __restrict__ skip)
+                                                                    int64_t rs, int64_t ld, int32_t* __restrict__ skip, int64_t* __restrict__ origin = nullptr, int64_t cap = 0)
 {
     if (!plan->resample || plan->n_recv == 0) return;
+    if (origin) {
+        // remote lineages: the immigrant's state into row t of its annex column, and where its history sits: (rank << 32) | slot
+        const int64_t col0 = ld + annex_base[t];
+        for (int r = 0; r < world; ++r) {
+            const int64_t cnt = plan->recv_cnt[r];
+            if (cnt == 0) continue;
+            const int64_t slot = plan->recv_base[r] / cap, off = plan->recv_off[r];
+            const char* seg = reinterpret_cast<const char*>(recv) + slot * cap * (int64_t)(sizeof(R) + 4);
+            const R* v = reinterpret_cast<const R*>(seg);
+            const int32_t* o = reinterpret_cast<const int32_t*>(seg + cap * (int64_t)sizeof(R));
+            for (int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * kThreads) {
+                const int64_t col = col0 + off + k;
+                values[(int64_t)t * rs + col] = static_cast<S>(v[k]);
+                origin[col - ld] = ((int64_t)r << 32) | (int64_t)(uint32_t)o[k];
+            }
+        }
+        return;
+    }
     if (!anc) {
         // filtering-only shards: records of one value into the row of generation t; the annex starts over every step
         for (int r = 0; r < world; ++r) {

@@ -142,6 +142,7 @@ struct cpprob_hip_group {
     int transport = kTransportNone;
     bool world1_collectives = false;                   // diagnostic: a group of one still issues every collective and exchanges with itself
     std::vector<void*> ipc_open;                       // peers' receive buffers mapped into this process (hipIpcOpenMemHandle)
+    bool remote = false;                               // remote lineages: every rank addresses every rank's particle store
     std::string transport_note;                        // why the direct transport was not taken
     // per local rank device buffers
     std::vector<double*> d_local, d_all, d_joint, d_bar;
@@ -374,7 +375,8 @@ void group_worker(cpprob_hip_group* g, int i)
 
 void close_direct(cpprob_hip_group* g)
 {
-    for (auto* c : g->ctx) (void)cpprob_hip_exchange_direct(c, nullptr);
+    g->remote = false;
+    for (auto* c : g->ctx) { (void)cpprob_hip_exchange_remote(c, nullptr); (void)cpprob_hip_exchange_direct(c, nullptr); }
     for (void* p : g->ipc_open) (void)hipIpcCloseMemHandle(p);
     g->ipc_open.clear();
 }
@@ -456,6 +458,70 @@ int setup_direct(cpprob_hip_group* g)
     return 0;
 }
 
+// Remote lineages on top of the direct transport: every rank learns where every rank's particle store sits (same process: the
+// pointers; other processes: hipIpc mappings of values / ancestors / origin table).  All or nobody: the availability is all-gathered.
+int setup_remote(cpprob_hip_group* g)
+{
+    const int n_local = (int)g->ctx.size(), world = g->world;
+    g->remote = false;
+    if (g->transport != kTransportDirect || !g->exchange || g->cfg.keep_history == 0 || (g->user_flags & CPPROB_HIP_GROUP_SHIP_LINEAGES)) return 0;
+    std::vector<cpprob_hip_store> st((size_t)world);
+    if (world == n_local) {
+        for (int r = 0; r < world; ++r)
+            if (int rc = cpprob_hip_exchange_store(g->ctx[(size_t)r], &st[(size_t)r])) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+        for (int i = 0; i < n_local; ++i)
+            if (int rc = cpprob_hip_exchange_remote(g->ctx[(size_t)i], st.data())) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)i]));
+        g->remote = true;
+        return 0;
+    }
+    cpprob_hip_ctx* c = g->ctx[0];
+    HIP_TRY(c, hipSetDevice(c->device));
+    struct Rec { hipIpcMemHandle_t hv, ha, ho; uint64_t rs, ld; int32_t ok, pad; };
+    Rec mine{};
+    cpprob_hip_store own{};
+    mine.ok = cpprob_hip_exchange_store(c, &own) == 0 ? 1 : 0;
+    if (mine.ok) {
+        mine.ok = hipIpcGetMemHandle(&mine.hv, const_cast<void*>(own.d_values)) == hipSuccess && hipIpcGetMemHandle(&mine.ha, const_cast<void*>(own.d_ancestors)) == hipSuccess &&
+                  hipIpcGetMemHandle(&mine.ho, const_cast<void*>(own.d_origin)) == hipSuccess ? 1 : 0;
+        (void)hipGetLastError();
+        mine.rs = own.row_stride; mine.ld = own.n_local_columns;
+    }
+    std::vector<Rec> all((size_t)world);
+    if (int rc = coll_allgather_host(g, 0, &mine, all.data(), sizeof(Rec))) return rc;
+    bool ok = true;
+    for (int r = 0; r < world; ++r) ok = ok && all[(size_t)r].ok;
+    int32_t opened = 1;
+    const size_t n_before = g->ipc_open.size();
+    if (ok) {
+        for (int r = 0; r < world && opened; ++r) {
+            if (r == g->first_rank) { st[(size_t)r] = own; continue; }
+            void* pv = nullptr; void* pa = nullptr; void* po = nullptr;
+            if (hipIpcOpenMemHandle(&pv, all[(size_t)r].hv, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { opened = 0; break; }
+            g->ipc_open.push_back(pv);
+            if (hipIpcOpenMemHandle(&pa, all[(size_t)r].ha, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { opened = 0; break; }
+            g->ipc_open.push_back(pa);
+            if (hipIpcOpenMemHandle(&po, all[(size_t)r].ho, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { opened = 0; break; }
+            g->ipc_open.push_back(po);
+            st[(size_t)r].d_values = pv; st[(size_t)r].d_ancestors = pa; st[(size_t)r].d_origin = po;
+            st[(size_t)r].row_stride = all[(size_t)r].rs; st[(size_t)r].n_local_columns = all[(size_t)r].ld;
+        }
+        (void)hipGetLastError();
+    }
+    std::vector<int32_t> flags((size_t)world);
+    const int32_t my_flag = ok ? opened : 0;
+    if (int rc = coll_allgather_host(g, 0, &my_flag, flags.data(), sizeof(int32_t))) return rc;
+    for (int r = 0; r < world; ++r) ok = ok && flags[(size_t)r];
+    if (!ok) {
+        // (the direct transport stays; migrants keep taking their lineages along)
+        while (g->ipc_open.size() > n_before) { (void)hipIpcCloseMemHandle(g->ipc_open.back()); g->ipc_open.pop_back(); }
+        g->transport_note = "remote lineages unavailable: a rank's particle store cannot be mapped (hipIpc)";
+        return 0;
+    }
+    if (int rc = cpprob_hip_exchange_remote(c, st.data())) return gfail(g, rc, cpprob_hip_last_error(c));
+    g->remote = true;
+    return 0;
+}
+
 int group_begin_contexts(cpprob_hip_group* g)
 {
     const int n_local = (int)g->ctx.size();
@@ -475,7 +541,8 @@ int group_begin_contexts(cpprob_hip_group* g)
             if (int rc = cpprob_hip_exchange_setup(x, g->world, rank, g->shard_begin.data(), peers_mode, g->cap)) return gfail(g, rc, cpprob_hip_last_error(x));
         }
     }
-    return setup_direct(g);
+    if (int rc = setup_direct(g)) return rc;
+    return setup_remote(g);
 }
 
 int group_enqueue(cpprob_hip_group* g, uint64_t run_index)
@@ -768,7 +835,7 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
     if (h_reruns) *h_reruns = g->reruns;
     g->traffic.records = (uint64_t)joint[(size_t)g->n_stats + 1];
     g->traffic.payload_bytes = (uint64_t)joint[(size_t)g->n_stats + 2];
-    g->traffic.transport = g->transport;
+    g->traffic.transport = g->transport; g->traffic.remote_lineages = g->remote ? 1 : 0;
     const bool talk = g->world > 1 || g->world1_collectives;
     const double steps = (g->cfg.algorithm == CPPROB_HIP_ALG_SIS) ? 1.0 : (double)g->T;
     g->traffic.collective_bytes = talk ? (uint64_t)((double)g->world * (double)g->world * (3.0 * 8.0 * steps + ((double)g->n_stats + kJointExtra) * 8.0)) : 0;

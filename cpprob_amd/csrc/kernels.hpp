@@ -1546,12 +1546,28 @@ struct SmoothArgs {
     const int32_t* resampled; int T; int64_t n, ld, rs; int identity;   // rs: row stride of values[] / anc[]
     double* stats_part;   // [T * kStats][gridDim.x]
     typename Model::value_t* paths;   // optional [T][ld]: materialised traces (dump / tests)
+    const struct RemoteStores* rem;   // exchange scope with remote lineages (device pointer), or nullptr
+};
+
+template <class Model> struct SmoothArgs;
+struct RemoteStores;
+template <class Model, class WeightOf>
+__device__ __forceinline__ void smooth_body_remote(const SmoothArgs<Model>& a, double* s_stat, WeightOf weight_of, const RemoteStores* __restrict__ rem);
+
+// Remote lineages (exchange scope over peer-mapped stores): a lineage that reaches an annex column continues in the particle store
+// of the rank the particle came from -- same generation, the slot recorded at its arrival.  One entry per rank, as THIS device
+// addresses that rank's memory.
+struct RemoteStores {
+    const void* values[64]; const int32_t* anc[64]; const int64_t* origin[64];
+    int64_t rs[64], ld[64];
+    int world, rank;
 };
 
 // weight_of(tile, i) = the final weight of slot i (zero for padding slots), in the units finalize_kernel divides by.
 template <class Model, class WeightOf>
 __device__ __forceinline__ void smooth_body(const SmoothArgs<Model>& a, double* s_stat, WeightOf weight_of)
 {
+    if (a.rem) { smooth_body_remote<Model>(a, s_stat, weight_of, a.rem); return; }       // (workgroup-uniform)
     using V = typename Model::value_t;
     constexpr int K = Model::kStats;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
@@ -1589,6 +1605,67 @@ __device__ __forceinline__ void smooth_body(const SmoothArgs<Model>& a, double* 
                 const int32_t* arow = a.anc + (int64_t)t * a.rs;
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) idx[k] = arow[idx[k]];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < TK; i += kThreads) {
+        double s = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kWaves; ++w2) s += s_stat[w2 * TK + i];
+        a.stats_part[(int64_t)i * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+template <class Model, class WeightOf>
+__device__ __forceinline__ void smooth_body_remote(const SmoothArgs<Model>& a, double* s_stat, WeightOf weight_of, const RemoteStores* __restrict__ rem)
+{
+    using V = typename Model::value_t;
+    using S = typename Model::store_t;
+    constexpr int K = Model::kStats;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int TK = a.T * K;
+    for (int i = tid; i < kWaves * TK; i += kThreads) s_stat[i] = 0.0;
+    __syncthreads();
+    const int64_t ntiles = (a.n + kTile - 1) / kTile;
+    const int me = rem->rank;
+    // (smooth_body's tile order: the workgroups' partial sums are then the very same numbers whichever way the lineages travelled)
+    for (int64_t tile = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int32_t idx[kPPT], rk[kPPT]; double w[kPPT];
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const int64_t i = tile * kTile + (int64_t)k * kThreads + tid;
+            idx[k] = (int32_t)i; rk[k] = me;
+            w[k] = weight_of(tile, i);
+        }
+        for (int t = a.T - 1; t >= 0; --t) {
+            double acc[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = 0.0;
+            const bool hop = t > 0 && !a.identity && a.resampled[t - 1];
+#pragma unroll
+            for (int k = 0; k < kPPT; ++k) {
+                const int r = rk[k];
+                const int64_t at = (int64_t)t * rem->rs[r] + idx[k];
+                const V x = static_cast<V>(static_cast<const S*>(rem->values[r])[at]);
+                Model::accumulate(x, w[k], acc);
+                if (a.paths) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)k * kThreads + tid] = x;
+                if (hop) {
+                    // (a run whose transport overflowed is repeated, but its read-out still runs: whatever the tables hold then, the
+                    //  walk stays inside the stores)
+                    const int64_t p = min(max((int64_t)rem->anc[r][at], (int64_t)0), rem->rs[r] - 1);
+                    if (p >= rem->ld[r]) {                                // an immigrant of that rank: its history sits where it came from
+                        const int64_t o = rem->origin[r][p - rem->ld[r]];
+                        const int ro = min(max((int)(o >> 32), 0), rem->world - 1);
+                        rk[k] = ro; idx[k] = (int32_t)min((int64_t)(uint32_t)o, rem->rs[ro] - 1);
+                    } else idx[k] = (int32_t)p;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = wave_sum(acc[j]);
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) s_stat[wv * TK + t * K + j] += acc[j];
             }
         }
     }

@@ -271,6 +271,19 @@ int cpprob_hip_exchange_transport(cpprob_hip_ctx* ctx, void** d_send, void** d_r
  *              pack_async will do).  NULL switches back.  setup() resets it (the buffers may move).
  *   traffic    after the run (synchronises): lineage records this rank sent after each step (h_sent_per_step[n_predict], may be NULL),
  *              their total and their bytes -- records x (t + 1) x bytes_per_value: what the direct transport puts on the links. */
+/*   remote     (optional, after direct) REMOTE LINEAGES: with every rank's particle store addressable from this device, a migrating
+ *              particle takes only its current state and the slot it leaves along (value + 4 bytes per record); its history stays
+ *              where it is, and whoever walks the lineage later -- the read-out, cpprob_hip_copy_paths -- continues in that rank's
+ *              store.  store() fills this context's own entry (and sizes its origin table); remote() takes h_stores[world], entry r =
+ *              rank r's store as THIS device addresses it (peer access / hipIpcOpenMemHandle of the three arrays).  Every rank of the
+ *              group must be in the same mode.  No lineage is extracted, shipped or committed any more: the exchange of a step costs
+ *              what its migrants' states cost. */
+typedef struct cpprob_hip_store {
+    const void* d_values; const void* d_ancestors; const void* d_origin;     /* [T][row_stride] values, [T][row_stride] int32, [annex] int64 */
+    uint64_t row_stride, n_local_columns;
+} cpprob_hip_store;
+int cpprob_hip_exchange_store(cpprob_hip_ctx* ctx, cpprob_hip_store* out);
+int cpprob_hip_exchange_remote(cpprob_hip_ctx* ctx, const cpprob_hip_store* h_stores);
 int cpprob_hip_exchange_direct(cpprob_hip_ctx* ctx, void* const* h_peer_recv);
 int cpprob_hip_exchange_traffic(cpprob_hip_ctx* ctx, int64_t* h_sent_per_step, size_t n_steps, uint64_t* h_records, uint64_t* h_bytes);
 int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* ctx, int32_t t);
@@ -317,6 +330,9 @@ typedef struct cpprob_hip_collectives {
 #define CPPROB_HIP_GROUP_SENDRECV 1u            /* never map peers' buffers: ncclSend / ncclRecv of fixed-capacity segments */
 #define CPPROB_HIP_GROUP_WORLD1_COLLECTIVES 2u  /* diagnostic, world = 1: issue every collective of the multi-GPU path anyway and exchange
                                                    (zero records) with the rank itself, so that one GPU runs all of the transport's calls */
+#define CPPROB_HIP_GROUP_SHIP_LINEAGES 4u      /* direct transport: migrants still take their whole lineage along (records of t + 1 values)
+                                                   instead of leaving it on the rank they come from (remote lineages, the default where
+                                                   every rank can address every rank's particle store) */
 #define CPPROB_HIP_TRANSPORT_NONE 0
 #define CPPROB_HIP_TRANSPORT_DIRECT 1
 #define CPPROB_HIP_TRANSPORT_SENDRECV 2
@@ -326,7 +342,7 @@ typedef struct cpprob_hip_traffic {
     uint64_t wire_bytes;       /* what the transport put on the links for them: = payload_bytes (direct), capacity (send/recv)  */
     uint64_t collective_bytes; /* the small collectives: all-gathers of 3 doubles (+ 1 ordering the direct stores) per step, the final all-reduce */
     int32_t transport;         /* CPPROB_HIP_TRANSPORT_*                                                                       */
-    int32_t reserved;
+    int32_t remote_lineages;   /* 1: migrants left their history on the rank they came from (records of value + 4 bytes)          */
 } cpprob_hip_traffic;
 int cpprob_hip_group_unique_id(void* out128, size_t n_bytes);
 int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t world, int32_t first_rank, const void* unique_id, cpprob_hip_group** out);

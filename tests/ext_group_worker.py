@@ -38,7 +38,7 @@ def main():
         e.n = shards[rank]
         paths = e.paths()
         g.close()
-        assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["records"] > 0 and tr["wire_bytes"] == tr["payload_bytes"], tr
+        assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 1 and tr["records"] > 0 and tr["wire_bytes"] == tr["payload_bytes"], tr
         # every rank's shard of the traces, gathered on rank 0, against ONE context holding all particles
         gathered = [None] * world
         dist.all_gather_object(gathered, paths)

@@ -111,7 +111,13 @@ def test_random_shard_layouts_exchange_scope(engine, golden_dir, sweep):
         engine.begin(cp.ALG_SMC, model, obs, n, seed=seed, ess_threshold=ess)
         engine.run()
         ref_paths, ref_stats, ref_sum = engine.paths(), engine.stats().copy(), engine.summary()
-        stats, s, paths, _, moved = _run_exchange_virtual(model, obs, n_pers, seed, ess)
+        try:
+            stats, s, paths, _, moved = _run_exchange_virtual(model, obs, n_pers, seed, ess)
+        except cp.capi.CpprobHipError as err:
+            # the outlier cost the fixed-point weights their bits: the step protocol says so (the single context repeated its run in
+            # the floating-point form by itself) and the caller repeats in that form
+            assert err.code == cp.capi.EPRECISION and ref_sum["step_form"] == cp.capi.FORM_FLOAT, tag
+            stats, s, paths, _, moved = _run_exchange_virtual(model, obs, n_pers, seed, ess, flags=cp.capi.FLAG_FLOATING_POINT_STEP)
         got = np.concatenate(paths, axis=1)
         differing = (got != ref_paths).any(axis=0).sum()
         assert differing <= max(2, n // 20000), tag                                  # isolated CDF-boundary flips only

@@ -191,9 +191,9 @@ def test_config5_whole_population_over_eight_ranks(engine, golden_dir):
     tr = g.traffic()
     per = [g.context(r).exchange_traffic() for r in range(8)]
     g.close()
-    # bytes on the links = the records themselves (direct stores): sum over ranks and steps of records x (t + 1) x 1 byte
-    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["wire_bytes"] == tr["payload_bytes"] == sum(int((p[0] * (np.arange(128) + 1)).sum()) for p in per)
-    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] <= 2 * tr["records"] * 128
+    # bytes on the links = the migrants' states and origin slots (remote lineages): records x (1 + 4) bytes
+    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 1
+    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] == tr["payload_bytes"] == tr["records"] * 5
     print("configs[4] traffic", tr)
     assert reruns <= 1 and 20 <= s["n_resampled"] <= 60
     assert np.abs(stats - z["hmm128_smooth"]).max() < 3e-3
@@ -220,8 +220,8 @@ def test_config4_whole_population_over_eight_ranks(engine, golden_dir):
     tr = g.traffic()
     per = [g.context(r).exchange_traffic() for r in range(8)]
     g.close()
-    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["wire_bytes"] == tr["payload_bytes"] == sum(int((p[0] * (np.arange(100) + 1)).sum()) * 8 for p in per)
-    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] <= 2 * tr["records"] * 100 * 8
+    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 1
+    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] == tr["payload_bytes"] == tr["records"] * 12
     print("configs[3] traffic", tr)
     assert reruns == 0                 # (the default annex holds a well-mixed run's immigrants: sqrt(N) per step, T steps)
     # (smoothing by ancestral lines degenerates towards t = 0: the filtering-quality end is tight, the far end Monte-Carlo-limited)
@@ -238,36 +238,47 @@ def _run_group(g, alg, model, obs, n, seed, ess, shards):
     return stats, s, reruns, g.traffic()
 
 
-@pytest.mark.parametrize("model,key,T,ess", [(cp.MODEL_HMM3, "hmm16", 16, 2.0), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 30, 0.5)])
-def test_group_direct_stores_move_records_not_capacity(engine, golden_dir, model, key, T, ess):
-    """The direct transport (the packing kernel stores each migrating lineage into the receiving rank's buffer) against the
-    send/recv transport (fixed-capacity segments): identical results, and the bytes on the links are the records themselves --
-    sum over steps of records x (t + 1) x value size, nothing where a step did not resample -- instead of peers x capacity."""
+@pytest.mark.parametrize("model,key,T,ess", [(cp.MODEL_HMM3, "hmm16", 16, 2.0), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 30, 0.5), (cp.MODEL_HMM3, "hmm128", 40, 0.5)])
+def test_group_transports_agree_and_account_their_bytes(engine, golden_dir, model, key, T, ess):
+    """Three ways to move a migrating particle, identical results (every trace of every shard, the evidence, the posterior):
+    REMOTE LINEAGES (default where every rank can address every rank's store): the migrant takes its state and the slot it leaves
+    along -- value + 4 bytes per record -- and its history stays where it is; the read-out walks into that rank's store;
+    DIRECT + shipped lineages: the packing kernel stores the whole lineage (t + 1 values) into the receiving rank's buffer;
+    SEND/RECV: fixed-capacity segments of lineages (the fall-back).  A step that does not resample moves nothing."""
     import torch  # noqa: F401
     obs = _obs(golden_dir, key)[:T]
     shards = [30000, 50001, 19999, 40000]
     n = int(sum(shards))
     vsz = 1 if model == cp.MODEL_HMM3 else 8
-    g = cp.Group([0] * len(shards))
-    stats, s, reruns, tr = _run_group(g, cp.ALG_SMC, model, obs, n, 21, ess, shards)
-    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and reruns == 0
-    per_rank = [g.context(r).exchange_traffic() for r in range(len(shards))]
-    _, resampled = g.context(0).step_trace()
-    records = sum(p[1] for p in per_rank)
-    payload = sum(int((p[0] * (np.arange(T) + 1)).sum()) * vsz for p in per_rank)
-    assert tr["records"] == records > 0 and tr["payload_bytes"] == payload == sum(p[2] for p in per_rank) == tr["wire_bytes"]
-    for p in per_rank:
-        assert np.all(p[0][:T - 1][resampled[:T - 1] == 0] == 0) and p[0][T - 1] == 0        # a step that does not resample sends nothing
-    g.close()
-    g2 = cp.Group([0] * len(shards))
-    g2.transport(flags=cp.capi.GROUP_SENDRECV)
-    stats2, s2, reruns2, tr2 = _run_group(g2, cp.ALG_SMC, model, obs, n, 21, ess, shards)
-    g2.close()
-    assert np.array_equal(stats, stats2) and s == s2 and reruns2 == 0
-    assert tr2["transport"] == cp.capi.TRANSPORT_SENDRECV and tr2["records"] == records and tr2["payload_bytes"] == payload
+    ref_stats, ref_sum, ref_paths, _ = _single(engine, cp.ALG_SMC, model, obs, n, 21, ess)
+    out = {}
+    for name, flags in (("remote", 0), ("ship", cp.capi.GROUP_SHIP_LINEAGES), ("sendrecv", cp.capi.GROUP_SENDRECV)):
+        g = cp.Group([0] * len(shards))
+        g.transport(flags=flags)
+        stats, s, reruns, tr = _run_group(g, cp.ALG_SMC, model, obs, n, 21, ess, shards)
+        per_rank = [g.context(r).exchange_traffic() for r in range(len(shards))]
+        _, resampled = g.context(0).step_trace()
+        paths = np.concatenate([_ctx_paths(g, r, shards[r], T, model == cp.MODEL_HMM3) for r in range(len(shards))], axis=1)
+        g.close()
+        assert reruns == 0 and np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"], name
+        np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
+        out[name] = (stats, tr, per_rank)
+        for p in per_rank:
+            assert np.all(p[0][:T - 1][resampled[:T - 1] == 0] == 0) and p[0][T - 1] == 0        # a step that does not resample sends nothing
+    records = sum(p[1] for p in out["remote"][2])
+    lineage_bytes = sum(int((p[0] * (np.arange(T) + 1)).sum()) * vsz for p in out["ship"][2])
+    tr = out["remote"][1]
+    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 1
+    assert tr["records"] == records > 0 and tr["payload_bytes"] == tr["wire_bytes"] == records * (vsz + 4)
+    tr = out["ship"][1]
+    assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 0
+    assert tr["records"] == records and tr["payload_bytes"] == tr["wire_bytes"] == lineage_bytes
+    tr = out["sendrecv"][1]
     cap = (int(8.0 * np.sqrt(n)) // 1024) * 1024 + 4096
-    assert tr2["wire_bytes"] == (2 * len(shards) - 2) * min(cap, max(shards)) * vsz * (T - 1) * T // 2
-    assert tr["wire_bytes"] * 10 < tr2["wire_bytes"]
+    assert tr["transport"] == cp.capi.TRANSPORT_SENDRECV and tr["records"] == records and tr["payload_bytes"] == lineage_bytes
+    assert tr["wire_bytes"] == (2 * len(shards) - 2) * min(cap, max(shards)) * vsz * (T - 1) * T // 2
+    assert np.array_equal(out["remote"][0], out["ship"][0]) and np.array_equal(out["remote"][0], out["sendrecv"][0])
+    assert out["remote"][1]["wire_bytes"] < out["ship"][1]["wire_bytes"] < out["sendrecv"][1]["wire_bytes"] // 10
 
 
 @pytest.mark.parametrize("flags", [cp.capi.GROUP_WORLD1_COLLECTIVES, cp.capi.GROUP_WORLD1_COLLECTIVES | cp.capi.GROUP_SENDRECV])
