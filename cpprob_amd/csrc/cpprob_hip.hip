@@ -99,7 +99,7 @@ struct cpprob_hip_ctx {
     bool x_direct = false; void** d_peer_recv = nullptr; int32_t* d_peer_slot = nullptr;
     int64_t* d_sent = nullptr; int sent_cap = 0;  // [T] records sent after each step of the last run (traffic accounting)
     // remote lineages (cpprob_hip_exchange_remote): migrants leave their history where it is; d_origin[annex column] = (rank << 32) | slot
-    bool x_remote = false; int64_t* d_origin = nullptr; int64_t origin_cap = 0; RemoteStores* d_remote = nullptr;
+    bool x_remote = false; int64_t* d_origin = nullptr; int64_t origin_cap = 0; RemoteStores* d_remote = nullptr; int64_t* d_annex_all = nullptr; int annex_all_T = 0;
     std::vector<uint64_t> x_shard_begin;
     int x_plan_t = -1;                            // step whose plan sits in d_xplan
     struct { int t = -1; bool resample = false; std::vector<uint64_t> send_lo, send_cnt; uint64_t n_send = 0, n_recv = 0; int64_t l0 = 0, l1 = 0; } plan;
@@ -715,7 +715,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
     dfree(c->d_ctrl); dfree(c->d_local_totals);
-    dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent); dfree(c->d_origin); dfree(c->d_remote);
+    dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent); dfree(c->d_origin); dfree(c->d_remote); dfree(c->d_annex_all);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -1237,6 +1237,7 @@ int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
     g.annex_cap = fixed_layout ? c->annex_cap : (int64_t)1 << 40;      // (callers that synchronise grow the annex themselves)
     g.bytes_per_value = (int)(fixed_layout ? c->ssz : (c->is_int ? sizeof(int32_t) : sizeof(double))); g.sent_per_step = c->d_sent;
     g.no_history = c->keep ? 0 : 1; g.remote = (c->x_remote && c->keep && fixed_layout) ? 1 : 0;
+    if (g.remote) { g.rem = c->d_remote; g.annex_all = c->d_annex_all; g.slot_of_rank = nullptr; g.cap = (int64_t)1 << 40; }
     PlanCountsIn pc{};
     pc.all_totals = c->x_all_totals; pc.n_pop = (double)c->pop_n;
     if (c->fixed_mode) {
@@ -1265,10 +1266,12 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid, bool plan_inside
     PackArgs<Model, R> a{};
     if (c->x_direct && c->x_fixed) { a.peer_recv = c->d_peer_recv; a.peer_slot = c->d_peer_slot; a.cap = c->x_cap; }
     a.geom.no_history = c->keep ? 0 : 1; a.geom.remote = (c->x_remote && c->keep && c->x_fixed) ? 1 : 0;
+    if (a.geom.remote) { a.geom.rem = c->d_remote; a.geom.annex_all = c->d_annex_all; a.peer_recv = nullptr; }
     if (plan_inside) {
         a.geom.world = c->x_world; a.geom.rank = c->x_rank; a.geom.n = c->n; a.geom.shard_begin = c->d_shard_begin; a.geom.slot_of_rank = c->d_slot_of_rank;
         a.geom.cap = c->x_cap; a.geom.annex_cap = c->annex_cap; a.geom.bytes_per_value = (int)c->ssz; a.geom.sent_per_step = c->d_sent;
         a.annex_base = c->d_annex_base; a.plan_out = c->d_xplan;
+        if (a.geom.remote) { a.geom.slot_of_rank = nullptr; a.geom.cap = (int64_t)1 << 40; }     // (no segments: straight into the receivers' annexes)
     }
     a.values = static_cast<const typename Model::store_t*>(c->d_values); a.anc = c->d_anc; a.rs = c->rs; a.n = c->n; a.nb = c->nb;
     a.resampled = c->d_resampled; a.t = t; a.plan = c->d_xplan; a.world = c->x_world; a.rank = c->x_rank; a.send = d_send;
@@ -1304,9 +1307,8 @@ template <class Model, class R>
 void launch_commit(cpprob_hip_ctx* c, int t, const R* d_recv, int grid)
 {
     using S = typename Model::store_t;
-    const bool remote = c->x_remote && c->keep && c->x_fixed;
     hipLaunchKernelGGL((exchange_commit_kernel<S, R>), dim3(grid), dim3(kThreads), 0, c->stream, (const ExchangePlan*)c->d_xplan, c->x_world, d_recv, t,
-                       (const int64_t*)c->d_annex_base, static_cast<S*>(c->d_values), c->d_anc, c->rs, c->ld, c->d_skip, remote ? c->d_origin : nullptr, c->x_cap);
+                       (const int64_t*)c->d_annex_base, static_cast<S*>(c->d_values), c->d_anc, c->rs, c->ld, c->d_skip);
 }
 
 // more annex columns: re-stride values[] / anc[] (callers that synchronise per step only)
@@ -1415,7 +1417,7 @@ int cpprob_hip_exchange_setup(cpprob_hip_ctx* c, int32_t world, int32_t rank, co
     if (!c->d_slot_of_rank) HIP_TRY(c, hipMalloc(&c->d_slot_of_rank, kWorldSlots * sizeof(int32_t)));
     HIP_TRY(c, hipMemcpy(c->d_slot_of_rank, slot.data(), kWorldSlots * sizeof(int32_t), hipMemcpyHostToDevice));
     c->x_cap = (int64_t)records_per_peer; c->x_mode = all_peers ? 1 : 0; c->x_fixed = true;
-    const size_t need = std::max<size_t>(1, c->x_peers.size()) * (size_t)records_per_peer * std::max<size_t>((size_t)c->T * c->ssz, c->ssz + 4);
+    const size_t need = std::max<size_t>(1, c->x_peers.size()) * (size_t)records_per_peer * (size_t)c->T * c->ssz;
     if (need > c->x_buf_bytes) {
         dfree(c->d_xsend); dfree(c->d_xrecv);
         HIP_TRY(c, hipMalloc(&c->d_xsend, need));
@@ -1482,6 +1484,11 @@ int cpprob_hip_exchange_remote(cpprob_hip_ctx* c, const cpprob_hip_store* h_stor
         rs.rs[r] = (int64_t)h_stores[r].row_stride; rs.ld[r] = (int64_t)h_stores[r].n_local_columns;
     }
     if (!c->d_remote) HIP_TRY(c, hipMalloc(&c->d_remote, sizeof(RemoteStores)));
+    if (c->T + 1 > c->annex_all_T || !c->d_annex_all) {
+        dfree(c->d_annex_all);
+        HIP_TRY(c, hipMalloc(&c->d_annex_all, (size_t)(c->T + 1) * kWorldSlots * sizeof(int64_t)));
+        c->annex_all_T = c->T + 1;
+    }
     HIP_TRY(c, hipMemcpy(c->d_remote, &rs, sizeof rs, hipMemcpyHostToDevice));
     c->x_remote = true;
     return 0;
@@ -1551,6 +1558,7 @@ int cpprob_hip_exchange_commit_async(cpprob_hip_ctx* c, int32_t t)
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
     if (!c->exchange || !c->x_fixed || c->x_plan_t != t) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_pack_async(t) has not run");
     if (c->x_peers.empty()) return 0;
+    if (c->x_remote && c->keep) return 0;                  // (remote lineages: the senders stored into this rank's annex themselves)
     HIP_TRY(c, hipSetDevice(c->device));
     dispatch_model(c, [&](auto m) { using M = decltype(m); launch_commit<M, typename M::store_t>(c, t, static_cast<const typename M::store_t*>(c->d_xrecv), 256); });
     HIP_TRY(c, hipGetLastError());

@@ -36,6 +36,7 @@ struct ExchangePlan {
     int64_t run_records, run_bytes;   // what this rank's sources sent since step 0 of the run: lineage records, and their bytes (records x (t + 1) x value size)
     int64_t src_shift;                // tiles by which this shard's outputs sit off its sources: output tile b draws from source tile ~ b + src_shift
                                       // (the next step kernel aims its first probe and its prefetch there: a sharded CDF's offset is O(sqrt N) outputs)
+    int64_t dst_col[kWorldSlots];     // remote lineages, per RANK: the annex column of THAT rank my first record for it goes to
 };
 
 struct ExchangeGeom {
@@ -50,7 +51,12 @@ struct ExchangeGeom {
                                       // value, and the annex is reused by every step's immigrants
     int remote;                       // remote lineages: a migrant is its current state and the slot it sits in on the rank it leaves --
                                       // its history STAYS there, and whoever walks the lineage later (read-out, trace dump) continues in
-                                      // that rank's particle store through the peer mapping (cpprob_hip_exchange_remote)
+                                      // that rank's particle store through the peer mapping (cpprob_hip_exchange_remote).  The packing
+                                      // kernel stores both straight into the receiving rank's annex column and origin table: every rank
+                                      // keeps every rank's annex fill (a function of the all-gathered totals), so no receive buffer, no
+                                      // segment capacity, no peer list and no commit launch
+    const RemoteStores* rem;          // (remote) every rank's store as this device addresses it
+    int64_t* annex_all;               // (remote) [T + 1][kWorldSlots] device: annex columns in use on every rank before each step's exchange
     int64_t* sent_per_step;           // [T] device, may be nullptr: records this rank sent after each step
 };
 
@@ -59,7 +65,7 @@ struct PlanCountsIn {                 // prefix-count form: o_r from the all-gat
 };
 
 // The plan as one wavefront holds it: lane r = what concerns rank r, plus the wave-uniform part.
-struct PlanLane { int64_t send_lo, send_cnt, send_base, recv_cnt, recv_base, recv_off; };
+struct PlanLane { int64_t send_lo, send_cnt, send_base, recv_cnt, recv_base, recv_off, dst_col, fill_next; };
 struct PlanWave { int64_t l0, l1, n_send, n_recv, src_shift; int32_t flags; bool resample; };
 
 // o_r (lane r, r = 0 .. world) from the all-gathered {n_0, n_1, particles} of every rank: canonical integer arithmetic, the step
@@ -82,7 +88,7 @@ __device__ __forceinline__ double plan_bounds_counts(const PlanCountsIn& pc, int
 }
 
 // From the bounds to the plan: my sources' interval and what each rank's shard takes of it / gives to me.  One wave, every lane.
-__device__ __forceinline__ void plan_wave(const ExchangeGeom& g, double o, bool resample, PlanLane& pl, PlanWave& pw)
+__device__ __forceinline__ void plan_wave(const ExchangeGeom& g, int t, double o, bool resample, PlanLane& pl, PlanWave& pw)
 {
     const int lane = lane_id();
     const int world = g.world, rank = g.rank;
@@ -102,6 +108,18 @@ __device__ __forceinline__ void plan_wave(const ExchangeGeom& g, double o, bool 
         }
     }
     if (resample) { l0 = (int64_t)(clampd(my_lo, mb, me) - mb); l1 = (int64_t)(clampd(my_hi, mb, me) - mb); }
+    pl.dst_col = 0; pl.fill_next = 0;
+    if (g.remote && lane < world) {
+        // rank `lane`'s annex: what it holds (every rank keeps the same table), what this step adds -- its shard less the outputs its
+        // own sources keep there -- and where my records land in it: behind those of the ranks before me (receive order = rank order)
+        const double sb = (double)g.shard_begin[lane], se = (double)g.shard_begin[lane + 1];
+        const int64_t fill = t == 0 ? 0 : g.annex_all[(int64_t)t * kWorldSlots + lane];
+        const int64_t kept = resample ? (int64_t)(clampd(o_next, sb, se) - clampd(o, sb, se)) : 0;
+        const int64_t arrive = resample ? (int64_t)(se - sb) - kept : 0;
+        const int64_t room = g.rem->rs[lane] - g.rem->ld[lane];
+        pl.fill_next = fill + (fill + arrive > room ? 0 : arrive);
+        if (resample && lane != rank) pl.dst_col = fill + (int64_t)(clampd(my_lo, sb, se) - sb) - (lane < rank ? kept : 0);
+    }
     pw.src_shift = resample ? (int64_t)floor((mb - my_lo) * (1.0 / kTile)) : 0;        // output mb is my sources' output number mb - my_lo
     // layout: fixed slots (capacity-checked) or compact blocks in rank order
     int64_t send_base = 0, recv_base = 0;
@@ -137,6 +155,8 @@ __device__ __forceinline__ void plan_store(const ExchangeGeom& g, int t, const P
     if (lane < g.world) {
         plan->send_lo[lane] = pl.send_lo; plan->send_cnt[lane] = pl.send_cnt; plan->send_base[lane] = pl.send_base;
         plan->recv_cnt[lane] = pl.recv_cnt; plan->recv_base[lane] = pl.recv_base; plan->recv_off[lane] = pl.recv_off;
+        plan->dst_col[lane] = pl.dst_col;
+        if (g.remote) g.annex_all[(int64_t)(t + 1) * kWorldSlots + lane] = pl.fill_next;
     }
     if (lane == 0) {
         const bool over_annex = base + pw.n_recv > g.annex_cap;
@@ -150,7 +170,7 @@ __device__ __forceinline__ void plan_store(const ExchangeGeom& g, int t, const P
         annex_base[t + 1] = g.no_history ? 0 : base + (over_annex ? 0 : pw.n_recv);
         const int64_t rec0 = t == 0 ? 0 : plan->run_records, byt0 = t == 0 ? 0 : plan->run_bytes;
         plan->run_records = rec0 + pw.n_send;
-        plan->run_bytes = byt0 + pw.n_send * (g.remote ? (int64_t)g.bytes_per_value + 4 : (int64_t)(g.no_history ? 1 : t + 1) * (int64_t)g.bytes_per_value);
+        plan->run_bytes = byt0 + pw.n_send * (g.remote ? (int64_t)g.bytes_per_value + 8 : (int64_t)(g.no_history ? 1 : t + 1) * (int64_t)g.bytes_per_value);
         if (g.sent_per_step) g.sent_per_step[t] = pw.n_send;
     }
 }
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(kWave) void exchange_plan_kernel(ExchangeGeom g, Pl
         resample = (SCAN2 ? s_ob[world + 1] : obound[world + 1]) != 0.0;
     }
     PlanLane pl; PlanWave pw;
-    plan_wave(g, o, resample, pl, pw);
+    plan_wave(g, t, o, resample, pl, pw);
     plan_store(g, t, pl, pw, annex_base, plan);
 }
 
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(kWave) void exchange_plan_fixed_kernel(ExchangeGeom
     bool resample;
     const double o = plan_bounds_fixed(pf, g.world, resample);
     PlanLane pl; PlanWave pw;
-    plan_wave(g, o, resample, pl, pw);
+    plan_wave(g, t, o, resample, pl, pw);
     plan_store(g, t, pl, pw, annex_base, plan);
 }
 
@@ -261,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
     __shared__ AncestorLds Lf;
     __shared__ FixedLds Lx;
     __shared__ uint32_t s_hop[32];                              // bit tt - 1 of word (tt - 1) / 32: did step tt - 1 resample? (<= 1024 steps)
-    __shared__ int64_t s_send_lo[kWorldSlots], s_send_cnt[kWorldSlots], s_send_base[kWorldSlots];
+    __shared__ int64_t s_send_lo[kWorldSlots], s_send_cnt[kWorldSlots], s_send_base[kWorldSlots], s_dst_col[kWorldSlots];
     __shared__ int64_t s_nsend;
     const int tid = threadIdx.x;
     static_assert(!PLAN_INSIDE || COUNTS || FIXED, "the plan is a pure function of the all-gathered totals in the integer forms only");
@@ -272,8 +292,8 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
             double o;
             if constexpr (FIXED) o = plan_bounds_fixed(a.pf, a.world, rs_);
             else o = plan_bounds_counts(a.pc, a.world);
-            plan_wave(a.geom, o, rs_, pl, pw);
-            s_send_lo[tid] = pl.send_lo; s_send_cnt[tid] = pl.send_cnt; s_send_base[tid] = pl.send_base;
+            plan_wave(a.geom, a.t, o, rs_, pl, pw);
+            s_send_lo[tid] = pl.send_lo; s_send_cnt[tid] = pl.send_cnt; s_send_base[tid] = pl.send_base; s_dst_col[tid] = pl.dst_col;
             if (tid == 0) s_nsend = pw.n_send;
             if (blockIdx.x == 0 && blockIdx.y == 0) plan_store(a.geom, a.t, pl, pw, a.annex_base, a.plan_out);
         }
@@ -316,12 +336,18 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
         const int64_t cnt = PLAN_INSIDE ? s_send_cnt[r] : a.plan->send_cnt[r];
         if (r == a.rank || cnt == 0) continue;                  // uniform
         const int64_t lo = PLAN_INSIDE ? s_send_lo[r] : a.plan->send_lo[r];
-        // where rank r's records go: its own receive slot for this rank (direct stores), or this rank's send buffer
-        // (remote lineages: a slot of the receiver's buffer is cap values followed by cap int32 origin slots)
-        R* const dst = remote ? reinterpret_cast<R*>(static_cast<char*>(a.peer_recv[r]) + (int64_t)a.peer_slot[r] * a.cap * (int64_t)(sizeof(R) + 4))
+        // where rank r's records go: its own receive slot for this rank (direct stores), or this rank's send buffer; remote
+        // lineages: row t of rank r's annex columns and its origin table, from the column the plan worked out
+        R* const dst = remote ? nullptr
                      : a.peer_recv ? static_cast<R*>(a.peer_recv[r]) + (int64_t)a.peer_slot[r] * a.cap * (int64_t)len
                                    : a.send + (PLAN_INSIDE ? s_send_base[r] : a.plan->send_base[r]) * (int64_t)len;
-        int32_t* const dst_slot = remote ? reinterpret_cast<int32_t*>(reinterpret_cast<char*>(dst) + a.cap * (int64_t)sizeof(R)) : nullptr;
+        S* annex_row = nullptr; int64_t* origin = nullptr; int64_t col0 = 0, room = 0;
+        if (remote) {
+            const RemoteStores* __restrict__ rem = a.geom.rem;
+            annex_row = static_cast<S*>(const_cast<void*>(rem->values[r])) + (int64_t)a.t * rem->rs[r] + rem->ld[r];
+            origin = const_cast<int64_t*>(rem->origin[r]);
+            col0 = PLAN_INSIDE ? s_dst_col[r] : a.plan->dst_col[r]; room = rem->rs[r] - rem->ld[r];
+        }
         for (int64_t tl = blockIdx.x; tl * kTile < cnt; tl += gridDim.x) {
             const int64_t rem = cnt - tl * kTile;
             const int n_out = rem < kTile ? (int)rem : kTile;
@@ -359,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
 #pragma unroll
                 for (int k = 0; k < kPPT; ++k) {
                     const int q = tid * kPPT + k;
-                    on[k] = q < n_out; idx[k] = max(anc[k], 0); rec[k] = dst + (tl * kTile + (on[k] ? q : 0)) * len;
+                    on[k] = q < n_out; idx[k] = max(anc[k], 0); rec[k] = remote ? nullptr : dst + (tl * kTile + (on[k] ? q : 0)) * len;
                 }
                 auto hops = [&](int tt) { return tt > 0 && ((s_hop[(tt - 1) >> 5] >> ((tt - 1) & 31)) & 1u) != 0; };
                 auto single = [&](int tt) {                                 // generation tt -> tt - 1
@@ -374,8 +400,13 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
 #pragma unroll
                     for (int k = 0; k < kPPT; ++k) {
                         if (!on[k]) continue;
-                        __builtin_nontemporal_store(static_cast<R>(vrow[idx[k]]), rec[k]);
-                        if (remote) __builtin_nontemporal_store(idx[k], dst_slot + (tl * kTile + tid * kPPT + k));
+                        if (remote) {
+                            const int64_t col = col0 + tl * kTile + tid * kPPT + k;
+                            if (col < room) {                    // (an annex too small is flagged by its owner and the run repeated)
+                                __builtin_nontemporal_store(vrow[idx[k]], annex_row + col);
+                                __builtin_nontemporal_store(((int64_t)a.rank << 32) | (int64_t)idx[k], origin + col);
+                            }
+                        } else __builtin_nontemporal_store(static_cast<R>(vrow[idx[k]]), rec[k]);
                     }
                     __syncthreads();
                     continue;
@@ -416,27 +447,9 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
 template <class S, class R>
 __global__ __launch_bounds__(kThreads) void exchange_commit_kernel(const ExchangePlan* __restrict__ plan, int world, const R* __restrict__ recv, int t,
                                                                     const int64_t* __restrict__ annex_base, S* __restrict__ values, int32_t* __restrict__ anc,
-                                                                    int64_t rs, int64_t ld, int32_t* __restrict__ skip, int64_t* __restrict__ origin = nullptr, int64_t cap = 0)
+                                                                    int64_t rs, int64_t ld, int32_t* __restrict__ skip)
 {
     if (!plan->resample || plan->n_recv == 0) return;
-    if (origin) {
-        // remote lineages: the immigrant's state into row t of its annex column, and where its history sits: (rank << 32) | slot
-        const int64_t col0 = ld + annex_base[t];
-        for (int r = 0; r < world; ++r) {
-            const int64_t cnt = plan->recv_cnt[r];
-            if (cnt == 0) continue;
-            const int64_t slot = plan->recv_base[r] / cap, off = plan->recv_off[r];
-            const char* seg = reinterpret_cast<const char*>(recv) + slot * cap * (int64_t)(sizeof(R) + 4);
-            const R* v = reinterpret_cast<const R*>(seg);
-            const int32_t* o = reinterpret_cast<const int32_t*>(seg + cap * (int64_t)sizeof(R));
-            for (int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * kThreads) {
-                const int64_t col = col0 + off + k;
-                values[(int64_t)t * rs + col] = static_cast<S>(v[k]);
-                origin[col - ld] = ((int64_t)r << 32) | (int64_t)(uint32_t)o[k];
-            }
-        }
-        return;
-    }
     if (!anc) {
         // filtering-only shards: records of one value into the row of generation t; the annex starts over every step
         for (int r = 0; r < world; ++r) {

@@ -272,12 +272,16 @@ int cpprob_hip_exchange_transport(cpprob_hip_ctx* ctx, void** d_send, void** d_r
  *   traffic    after the run (synchronises): lineage records this rank sent after each step (h_sent_per_step[n_predict], may be NULL),
  *              their total and their bytes -- records x (t + 1) x bytes_per_value: what the direct transport puts on the links. */
 /*   remote     (optional, after direct) REMOTE LINEAGES: with every rank's particle store addressable from this device, a migrating
- *              particle takes only its current state and the slot it leaves along (value + 4 bytes per record); its history stays
- *              where it is, and whoever walks the lineage later -- the read-out, cpprob_hip_copy_paths -- continues in that rank's
- *              store.  store() fills this context's own entry (and sizes its origin table); remote() takes h_stores[world], entry r =
- *              rank r's store as THIS device addresses it (peer access / hipIpcOpenMemHandle of the three arrays).  Every rank of the
- *              group must be in the same mode.  No lineage is extracted, shipped or committed any more: the exchange of a step costs
- *              what its migrants' states cost. */
+ *              particle takes only its current state and the slot it leaves along -- value + 8 bytes per record -- and pack_async
+ *              stores both straight into the RECEIVING rank's annex column and origin table: every rank keeps every rank's annex
+ *              fill (a function of the all-gathered totals), so there is no receive buffer, no segment capacity, no peer set and
+ *              commit_async launches nothing (what remains of the overflow bits is 4: an annex too small).  The particle's history
+ *              stays where it is, and whoever walks the lineage later -- the read-out, cpprob_hip_copy_paths -- continues in that
+ *              rank's store.  store() fills this context's own entry (and sizes its origin table); remote() takes h_stores[world],
+ *              entry r = rank r's store as THIS device addresses it (peer access / hipIpcOpenMemHandle of the three arrays: they
+ *              are written AND read through the mapping).  Every rank of the group must be in the same mode, and the caller still
+ *              orders step_begin(t + 1) of every rank behind pack_async(t) of every rank.  No lineage is extracted, shipped or
+ *              committed any more: the exchange of a step costs what its migrants' states cost. */
 typedef struct cpprob_hip_store {
     const void* d_values; const void* d_ancestors; const void* d_origin;     /* [T][row_stride] values, [T][row_stride] int32, [annex] int64 */
     uint64_t row_stride, n_local_columns;
@@ -342,7 +346,7 @@ typedef struct cpprob_hip_traffic {
     uint64_t wire_bytes;       /* what the transport put on the links for them: = payload_bytes (direct), capacity (send/recv)  */
     uint64_t collective_bytes; /* the small collectives: all-gathers of 3 doubles (+ 1 ordering the direct stores) per step, the final all-reduce */
     int32_t transport;         /* CPPROB_HIP_TRANSPORT_*                                                                       */
-    int32_t remote_lineages;   /* 1: migrants left their history on the rank they came from (records of value + 4 bytes)          */
+    int32_t remote_lineages;   /* 1: migrants left their history on the rank they came from (records of value + 8 bytes)           */
 } cpprob_hip_traffic;
 int cpprob_hip_group_unique_id(void* out128, size_t n_bytes);
 int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t world, int32_t first_rank, const void* unique_id, cpprob_hip_group** out);

@@ -191,9 +191,9 @@ def test_config5_whole_population_over_eight_ranks(engine, golden_dir):
     tr = g.traffic()
     per = [g.context(r).exchange_traffic() for r in range(8)]
     g.close()
-    # bytes on the links = the migrants' states and origin slots (remote lineages): records x (1 + 4) bytes
+    # bytes on the links = the migrants' states and origin slots (remote lineages): records x (1 + 8) bytes
     assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 1
-    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] == tr["payload_bytes"] == tr["records"] * 5
+    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] == tr["payload_bytes"] == tr["records"] * 9
     print("configs[4] traffic", tr)
     assert reruns <= 1 and 20 <= s["n_resampled"] <= 60
     assert np.abs(stats - z["hmm128_smooth"]).max() < 3e-3
@@ -221,7 +221,7 @@ def test_config4_whole_population_over_eight_ranks(engine, golden_dir):
     per = [g.context(r).exchange_traffic() for r in range(8)]
     g.close()
     assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 1
-    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] == tr["payload_bytes"] == tr["records"] * 12
+    assert tr["records"] == sum(p[1] for p in per) and tr["wire_bytes"] == tr["payload_bytes"] == tr["records"] * 16
     print("configs[3] traffic", tr)
     assert reruns == 0                 # (the default annex holds a well-mixed run's immigrants: sqrt(N) per step, T steps)
     # (smoothing by ancestral lines degenerates towards t = 0: the filtering-quality end is tight, the far end Monte-Carlo-limited)
@@ -242,7 +242,7 @@ def _run_group(g, alg, model, obs, n, seed, ess, shards):
 def test_group_transports_agree_and_account_their_bytes(engine, golden_dir, model, key, T, ess):
     """Three ways to move a migrating particle, identical results (every trace of every shard, the evidence, the posterior):
     REMOTE LINEAGES (default where every rank can address every rank's store): the migrant takes its state and the slot it leaves
-    along -- value + 4 bytes per record -- and its history stays where it is; the read-out walks into that rank's store;
+    along -- value + 8 bytes per record, stored straight into the receiving rank's annex column and origin table -- and its history stays where it is; the read-out walks into that rank's store;
     DIRECT + shipped lineages: the packing kernel stores the whole lineage (t + 1 values) into the receiving rank's buffer;
     SEND/RECV: fixed-capacity segments of lineages (the fall-back).  A step that does not resample moves nothing."""
     import torch  # noqa: F401
@@ -269,7 +269,7 @@ def test_group_transports_agree_and_account_their_bytes(engine, golden_dir, mode
     lineage_bytes = sum(int((p[0] * (np.arange(T) + 1)).sum()) * vsz for p in out["ship"][2])
     tr = out["remote"][1]
     assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 1
-    assert tr["records"] == records > 0 and tr["payload_bytes"] == tr["wire_bytes"] == records * (vsz + 4)
+    assert tr["records"] == records > 0 and tr["payload_bytes"] == tr["wire_bytes"] == records * (vsz + 8)
     tr = out["ship"][1]
     assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 0
     assert tr["records"] == records and tr["payload_bytes"] == tr["wire_bytes"] == lineage_bytes
@@ -278,7 +278,8 @@ def test_group_transports_agree_and_account_their_bytes(engine, golden_dir, mode
     assert tr["transport"] == cp.capi.TRANSPORT_SENDRECV and tr["records"] == records and tr["payload_bytes"] == lineage_bytes
     assert tr["wire_bytes"] == (2 * len(shards) - 2) * min(cap, max(shards)) * vsz * (T - 1) * T // 2
     assert np.array_equal(out["remote"][0], out["ship"][0]) and np.array_equal(out["remote"][0], out["sendrecv"][0])
-    assert out["remote"][1]["wire_bytes"] < out["ship"][1]["wire_bytes"] < out["sendrecv"][1]["wire_bytes"] // 10
+    assert out["ship"][1]["wire_bytes"] < out["sendrecv"][1]["wire_bytes"] // 10
+    if T * vsz > 2 * (vsz + 8): assert out["remote"][1]["wire_bytes"] < out["ship"][1]["wire_bytes"]      # (short traces of bytes: the lineage is smaller than the origin word)
 
 
 @pytest.mark.parametrize("flags", [cp.capi.GROUP_WORLD1_COLLECTIVES, cp.capi.GROUP_WORLD1_COLLECTIVES | cp.capi.GROUP_SENDRECV])
