@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--workload", default="hmm16_smc", choices=["hmm16_smc", "hmm128_smc_ess", "lgssm100_smc", "gaussian_sis"])
     p.add_argument("--scope", default="auto", choices=["auto", "global", "global-deferred", "island", "exchange"])
     p.add_argument("--seed", type=int, default=12345)
+    p.add_argument("--flags", type=int, default=0, help="cpprob_hip_config::flags of the timed context (A/B forms, include/cpprob_hip.h); recorded in config")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample")
     p.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (pipelined runs, gaussian SIS)")
@@ -340,7 +341,7 @@ def main():
         last = (stats,)
     else:
         eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
-                  particle_offset=rank * n, n_global=n_global, scope=cp.SCOPE_ISLAND if island else (cp.SCOPE_EXCHANGE if exchange else cp.SCOPE_GLOBAL))
+                  particle_offset=rank * n, n_global=n_global, scope=cp.SCOPE_ISLAND if island else (cp.SCOPE_EXCHANGE if exchange else cp.SCOPE_GLOBAL), flags=args.flags)
         dt, last = timed_runs(eng, args.steps, args.warmup, world, device, island, exchange=exchange, counters=moved)
         summ = None
     value = n_global * args.steps / dt
@@ -431,7 +432,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s, %d particles per GPU" % (spec["desc"], n), "particles_per_gpu": n, "T": T,
                    "resampler": "systematic", "ess_threshold": spec["ess"], "scope": scope, "n_global": n_global, "collective": collective,
-                   "host": host if (world > 1 or group is not None) else "one context, one stream", "exchange_reruns": reruns},
+                   "host": host if (world > 1 or group is not None) else "one context, one stream", "exchange_reruns": reruns, "flags": args.flags},
         "particle_steps_per_sec": value * T,
         "roofline": roofline,
         "posterior_max_abs_err_vs_exact": err, "log_evidence": summ["log_evidence"], "n_resampled": summ["n_resampled"],

@@ -16,6 +16,7 @@
 #include "step_fixed.hpp"
 #include "exchange.hpp"
 #include "bookkeep_fixed.hpp"
+#include "trace_words.hpp"
 
 using namespace cph;
 
@@ -121,7 +122,9 @@ struct cpprob_hip_ctx {
     // generation's heaviest particle sat far below it (an observation many standard deviations from every particle) they lose bits.
     // The first call that reads a run's results checks the run's largest gap and repeats the run in the floating-point form.
     bool force_fp = false, fixed_check_pending = false, last_was_infer_run = false; uint64_t last_run_index = 0;
-    uint32_t* d_q[2] = {nullptr, nullptr};                 // [ld] integer weights of the fixed-point form, ping-pong
+    uint32_t* d_q[2] = {nullptr, nullptr};                 // [ld] integer weights of the fixed-point form, ping-pong; the count form's trace words
+    // trace words (trace_words.hpp): a single population's short discrete traces ride with the particles; the read-out streams them
+    bool trace_mode = false; uint32_t* d_trace_cnt = nullptr; unsigned long long* d_trace_arrive = nullptr;
     std::vector<double> h_bound;                           // [T] upper bound of each step's incremental log-weight (host-evaluated)
     int hk = 0; std::vector<double> hk_mean, hk_trans;     // cpprob_hip_set_hmm: the table of CPPROB_HIP_MODEL_HMM_TABLE
     uint64_t* d_hk_thr = nullptr; double* d_hk_ll = nullptr;
@@ -484,6 +487,7 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         a.src_shift = (c->exchange && c->x_fixed && !c->x_peers.empty() && c->d_xplan) ? &c->d_xplan->src_shift : nullptr;
         for (int k = 0; k < 4; ++k) a.e_prev[k] = t > 0 ? c->h_e_tab[(size_t)(t - 1) * 4 + k] : 0.0;
         a.u0 = t > 0 ? host_resample_u0(c->run_seed, (uint64_t)t) : 0.0;
+        if (c->trace_mode && !all_totals) { a.trace_prev = c->d_q[(t + 1) & 1]; a.trace_next = c->d_q[t & 1]; }
         ProfScope ps(c, 0);
         if (all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
@@ -618,6 +622,17 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
         ProfScope ps(c, 2);
         bool launched = false;
         if constexpr (Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1) {
+            if (c->final_from_counts && c->trace_mode && !with_paths) {
+                // every particle carries its trace: one streaming pass, integer counts, statistics written by the last workgroup
+                TraceReadoutArgs ta{};
+                ta.trace = c->d_q[(c->T - 1) & 1]; ta.n = c->n; ta.T = c->T;
+                counts_final_view(c, ta.f, c->final_bookkeep_pending);
+                c->final_bookkeep_pending = false;
+                ta.counters = c->d_trace_cnt; ta.arrive = c->d_trace_arrive; ta.stats = c->d_stats;
+                const int grid = (int)std::min<int64_t>((c->n + kTile - 1) / kTile, 256);
+                hipLaunchKernelGGL(trace_readout_kernel, dim3(grid), dim3(kThreads), 0, c->stream, ta);
+                return;
+            }
             if (c->final_from_counts) {
                 CountsFinal f{};
                 counts_final_view(c, f, c->final_bookkeep_pending && !with_paths);
@@ -635,6 +650,7 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
         }
         if (!launched) hipLaunchKernelGGL(smooth_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a);
     }
+    if (with_paths && c->trace_mode && c->final_from_counts) return;     // (the statistics came from the trace words: the walk only materialises traces)
     ProfScope ps(c, 3);
     hipLaunchKernelGGL(finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream,
                        c->d_stats_part, c->smooth_grid, c->T, Model::kStats, Model::kIsInt ? 1 : 0, c->d_ctrl, c->d_stats, c->sharded ? 0 : 1);
@@ -658,7 +674,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]);
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]); dfree(c->d_trace_cnt); dfree(c->d_trace_arrive);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
 }
 
@@ -1010,6 +1026,15 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
         c->step_protocol = false;
         c->counts_mode = false; c->fixed_mode = false;
         dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); c->fixed_mode = fixed_eligible<decltype(m)>(c); });
+        // a population of its own, short traces of a few states: the particles carry their traces (trace_words.hpp)
+        c->trace_mode = c->counts_mode && c->keep && !c->exchange && c->T <= kTraceMaxT && c->cfg.model == CPPROB_HIP_MODEL_HMM3 &&
+                        !(c->cfg.flags & CPPROB_HIP_FLAG_WALK_READOUT);
+        if (c->trace_mode && !c->d_trace_cnt) {
+            HIP_TRY(c, hipMalloc(&c->d_trace_cnt, kTraceCounterWords * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_trace_arrive, sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemsetAsync(c->d_trace_cnt, 0, kTraceCounterWords * sizeof(uint32_t), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_trace_arrive, 0, sizeof(unsigned long long), c->stream));
+        }
         const bool fused = step_is_fused(c);
         if (c->fixed_mode) {
             ProfScope group(c, 0, c->T);
@@ -1109,7 +1134,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     }
     if (c->exchange && t > 0 && c->x_plan_t != t - 1)
         return fail(c, CPPROB_HIP_ESTATE, "exchange scope: the exchange of the previous step (plan / pack / commit) must run before the next step_begin");
-    c->step_protocol = true; c->step_t = t;
+    c->step_protocol = true; c->step_t = t; c->trace_mode = false;
     c->totals_out = d_local_totals;
     if (c->counts_mode) {
         // prefix-count form: the step consumes the all-gathered counts of generation t-1 itself; what leaves is this shard's

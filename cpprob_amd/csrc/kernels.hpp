@@ -79,6 +79,7 @@ template <class T> struct Vec4;
 template <> struct Vec4<double> { using type = double __attribute__((ext_vector_type(4))); };
 template <> struct Vec4<int32_t> { using type = int __attribute__((ext_vector_type(4))); };
 template <> struct Vec4<int8_t> { using type = signed char __attribute__((ext_vector_type(4))); };
+template <> struct Vec4<uint32_t> { using type = unsigned int __attribute__((ext_vector_type(4))); };
 
 template <class T>
 __device__ __forceinline__ void load4(const T* __restrict__ p, int64_t i, T (&v)[kPPT])

@@ -162,6 +162,7 @@ struct ModelHmm3 {
     // the incremental weight of a step takes one of 3 values: log N(y_t; mean[s], 1).  ll_tab row t holds them,
     // e_tab row t holds {exp(ll - max ll)} and max ll (host-computed once per run)
     static constexpr int kWeightTable = 3;
+    static constexpr int kTraceBits = 2;   // a state in a trace word (trace_words.hpp: T <= 16 states ride in 32 bits)
     __device__ static __forceinline__ void weight_table(const ModelParams& mp, int t, double (&ll)[3], double (&e)[3], double& mref)
     {
         const double* r = mp.ll_tab + 3 * t;

@@ -383,6 +383,7 @@ struct StepCountsArgs {
     const int64_t* src_shift;                                   // exchange scope: tiles by which this shard's outputs sit off its sources (the previous exchange's plan)
     int row_w, row_r;                                           // rows of values[] this step writes / reads (t, t - 1; a filtering-only run: its two rows in turn)
     double* filter_stats;                                       // filtering-only run: [T][3], generation t-1's P(x = s) from its totals (nullptr otherwise)
+    const uint32_t* trace_prev; uint32_t* trace_next;           // trace words (trace_words.hpp) of generations t-1 / t, or nullptr: a single population's short traces
 };
 
 // This tile's entry of generation t's hierarchy, added into the levels above (see the header of this file), and the entries of
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     // the source tile this output tile is expected to start in: its own index, moved by the shard's offset in a sharded run
     int guess = bid;
     if (SHARDED && t > 0 && a.src_shift) { const int64_t g2 = (int64_t)bid + *a.src_shift; guess = (int)(g2 < 0 ? 0 : (g2 >= nb ? nb - 1 : g2)); }
+    const bool traced = !SHARDED && a.trace_next != nullptr;                                  // (kernel-uniform; trace_words.hpp)
     if (t > 0) {
         const int64_t g0 = (int64_t)guess * kTile + (int64_t)tid * kPPT;
         raw_0 = *reinterpret_cast<const uint32_t*>(prev_row + g0);
@@ -555,8 +557,17 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     }
 
     V prev[kPPT], x[kPPT];
+    uint32_t tw[kPPT];
+    if (traced) {
+        // the ancestor's trace word where its state byte would be gathered: the same dependent load, and the state is its top field
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>(prev_row[anc[k]]) : V(0);                 // ancestor's state (sorted gather)
+        for (int k = 0; k < kPPT; ++k) tw[k] = t > 0 ? a.trace_prev[anc[k]] : 0u;
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>((tw[k] >> (Model::kTraceBits * (t - 1))) & ((1u << Model::kTraceBits) - 1u)) : V(0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>(prev_row[anc[k]]) : V(0);             // ancestor's state (sorted gather)
+    }
 #pragma unroll
     for (int q = 0; q < kPPT / 4; ++q)                                                        // sample #t
         Model::apply4_staged(s_model, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
@@ -564,6 +575,11 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) valid[k] = j0 + k < a.n;
     store4_as(a.values + (int64_t)a.row_w * a.rs, j0, x);                                     // predict #t
+    if (traced) {
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) tw[k] |= (uint32_t)x[k] << (Model::kTraceBits * t);
+        store4(a.trace_next, j0, tw);
+    }
     if (a.anc) store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);                      // (a filtering-only run keeps no ancestors)
 
     // ---- observe #t as counts ----

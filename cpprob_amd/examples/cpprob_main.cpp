@@ -36,7 +36,7 @@ void print_json(const cpprob::gpu::Result& r)
     std::cout.precision(17);
     std::cout << "{\"n\": " << r.n_particles << ", \"log_evidence\": " << r.log_evidence << ", \"ess\": " << r.ess
               << ", \"n_resampled\": " << r.n_resampled << ", \"run_seconds\": " << r.run_seconds << ", \"builtin\": " << (r.used_builtin ? "true" : "false")
-              << ", \"n_gpus\": " << r.n_gpus << ", \"exchange_reruns\": " << r.exchange_reruns << ", \"replay_window\": " << r.replay_window << ", \"predicts\": [";
+              << ", \"n_gpus\": " << r.n_gpus << ", \"exchange_reruns\": " << r.exchange_reruns << ", \"replay_window\": " << r.replay_window << ", \"markov_crosscheck\": " << r.markov_crosscheck << ", \"predicts\": [";
     for (std::size_t i = 0; i < r.predicts.size(); ++i) {
         const auto& p = r.predicts[i];
         if (i) std::cout << ", ";
@@ -124,6 +124,7 @@ int main(int argc, char** argv)
         else if (f == "--generic") opt.prefer_builtin = false;
         else if (f == "--filtering_only") { opt.keep_history = false; opt.dump = false; }   // smc, built-in models: O(N) particle store, filtering statistics
         else if (f == "--no_markov_probe") opt.markov_probe = false;          // unchanged-model smc: replay the whole trace every step
+        else if (f == "--no_markov_crosscheck") opt.markov_crosscheck = false; // ... trust the host probe's window without the device pilot
         else if (f == "--gpus") { const int k = std::stoi(next()); opt.devices.clear(); for (int d = 0; d < k; ++d) opt.devices.push_back(d); }
         else if (f == "--devices") {                        // e.g. 0,1,2,3 -- or 0,0 for two ranks on one GPU (loopback transport)
             const std::string v = next(); opt.devices.clear();
@@ -150,6 +151,7 @@ int main(int argc, char** argv)
         if (a.model == "gaussian_by_rejection") return execute(models::gaussian_by_rejection<double>, a);
         if (a.model == "second_order12") return execute(models::second_order<12>, a);
         if (a.model == "running_mean12") return execute(models::running_mean<12>, a);
+        if (a.model == "rare_memory12") return execute(models::rare_memory<12>, a);
         if (a.model == "all_distr") return execute(models::all_distr<int>, a);                                   // src/models/models.cpp:13-47; observes: any two ints
         std::cerr << "unknown model " << a.model << std::endl;
         return EXIT_FAILURE;

@@ -20,5 +20,6 @@ extern template void gaussian_by_rejection<double>(double, double);
 extern template void all_distr<int>(int, int);
 extern template void second_order<12>(const std::array<double, 12>&);
 extern template void running_mean<12>(const std::array<double, 12>&);
+extern template void rare_memory<12>(const std::array<double, 12>&);
 }
 #endif

@@ -172,6 +172,23 @@ void running_mean(const std::array<double, N>& y)
     }
 }
 
+// rare_memory: first order on almost every trace -- but a state beyond 3.6 drags the FIRST state back in.  A handful of host traces
+// (the Markov probe) will not see that happen; thousands of particles on the device do, every run.
+template <std::size_t N>
+void rare_memory(const std::array<double, N>& y)
+{
+    double x0 = 0, x1 = 0;
+    for (std::size_t t = 0; t < N; ++t) {
+        boost::random::normal_distribution<> transition{0.6 * x1 + (std::fabs(x1) > 3.6 ? 0.8 * x0 : 0.0), 1};
+        const double x = cpprob::sample(transition, true);
+        boost::random::normal_distribution<> emission{x, 2};
+        cpprob::observe(emission, y[t]);
+        cpprob::predict(x, "State");
+        if (t == 0) x0 = x;
+        x1 = x;
+    }
+}
+
 // One statement triple -- sample, address-less predict, observe of the sampled value -- per distribution of the library
 // (restates the statement sequence of reference src/models/models.cpp:13-47; the two ints are unused there too; a template here so that
 // host programs link the model library's instantiation: registered_models.hpp).  Every predict gets

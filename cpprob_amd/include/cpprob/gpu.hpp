@@ -32,11 +32,15 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <array>
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
+#include <tuple>
 #include <vector>
 
 #include <boost/math/distributions/normal.hpp>
@@ -276,11 +280,40 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     // (rejection sampling) may execute more -- start with head-room, and on overflow repeat the run with 4x the rows
     std::size_t S = 4 * st.n_sample + 16;
     detail::TraceStructure st_full = st;
+    st_full.window = -1;
     const detail::TraceStructure* use = &st;
+    res.markov_crosscheck = 0;
+    if (algorithm == StateType::smc && st.window >= 0 && opt.markov_crosscheck) {
+        // The host probe saw a handful of traces; a dependence on older samples that shows on one trace in a thousand passes it.  So
+        // the window is certified on the device before it is used: a pilot population under windowed replay and under full replay
+        // -- same particle ids, same seed, hence the same variates, weights and ancestors if the window is right -- must agree in
+        // every bit of every weight and predict.  Once per model, trace shape and window in this process.
+        static std::mutex mu;
+        static std::map<std::tuple<std::size_t, std::size_t, int>, bool> certified;
+        const auto key = std::make_tuple((std::size_t)st.n_observe, (std::size_t)st.n_sample, st.window);
+        bool known = false, ok = false;
+        { std::lock_guard<std::mutex> lock(mu); const auto it = certified.find(key); if (it != certified.end()) { known = true; ok = it->second; } }
+        if (!known) {
+            const std::size_t n_pilot = std::min<std::size_t>(n, 8192);
+            Result r_win, r_full;
+            HostStore s_win, s_full;
+            const int rc_win = generic_attempt<Caller>(algorithm, observes_v, n_pilot, st, opt, r_win, &s_win, S);
+            const int rc_full = rc_win == 0 ? generic_attempt<Caller>(algorithm, observes_v, n_pilot, st_full, opt, r_full, &s_full, S) : 1;
+            auto same = [](const std::vector<double>& x, const std::vector<double>& y) {
+                return x.size() == y.size() && (x.empty() || std::memcmp(x.data(), y.data(), x.size() * sizeof(double)) == 0);
+            };
+            ok = rc_win == 0 && rc_full == 0 && same(s_win.logw, s_full.logw) && same(s_win.real, s_full.real) && s_win.ints == s_full.ints &&
+                 std::memcmp(&r_win.log_evidence, &r_full.log_evidence, sizeof(double)) == 0;
+            std::lock_guard<std::mutex> lock(mu);
+            certified[key] = ok;
+        }
+        res.markov_crosscheck = ok ? 1 : -1;
+        if (!ok) use = &st_full;
+    }
     for (int attempt = 0; attempt < 5; ++attempt) {
         const int rc = generic_attempt<Caller>(algorithm, observes_v, n, *use, opt, res, store, S);
         if (rc == 0) return;
-        if (rc == 3) { st_full.window = -1; use = &st_full; }      // the device saw what the host probe did not: replay the whole trace
+        if (rc == 3) use = &st_full;                               // the device saw what the host probe did not: replay the whole trace
         else S *= 4;
     }
     throw std::runtime_error("cpprob::inference(smc): a particle executed more than " + std::to_string(S / 4) + " sample statements "

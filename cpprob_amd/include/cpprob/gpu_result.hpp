@@ -27,6 +27,8 @@ struct Options {
     std::size_t dump_max_particles = 0;               // 0 = all particles
     bool markov_probe = true;                         // smc, unchanged-model path: test on the host whether a step depends on more than the last few
                                                       // sampled values; a model that does not is replayed from that window only (O(T) instead of O(T^2))
+    bool markov_crosscheck = true;                    // ... and certify the probe's window on the device before using it: a pilot population under windowed
+                                                      // and under full replay must agree bit for bit (once per model and trace shape), else full replay
     bool prefer_builtin = true;                       // use the hand-fused kernels when the model is one of the built-ins
     bool keep_history = true;                         // smc, built-in models on one GPU: false = filtering only -- O(N) particle store instead of O(N T),
                                                       // every predict hit's numbers under its own generation's weights, no posterior files
@@ -52,6 +54,7 @@ struct Result {
     bool used_builtin = false;
     int n_gpus = 1;                           // ranks the population was sharded over
     int exchange_reruns = 0;
+    int markov_crosscheck = 0;                // unchanged-model smc: 1 the device pilot certified the probe's window, -1 it refuted it (full replay), 0 not run
     int replay_window = -1;                   // unchanged-model smc: samples of the ancestor a step replays (-1: the whole trace)                  // multi-GPU: runs repeated with a larger lineage transport (results never depend on it)
     double run_seconds = 0;                   // device work of the run (launch to synchronise), excluding allocation and dumps
     std::vector<PredictStats> predicts;       // real hits first (in trace order), then int hits

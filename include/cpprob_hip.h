@@ -122,6 +122,7 @@ typedef struct cpprob_hip_config {
 #define CPPROB_HIP_FLAG_SIS_SEPARATE_READOUT 8u  /* SIS read-out as a pass over the particle store instead of riding the normalisation */
 #define CPPROB_HIP_FLAG_WREL_STORED 16u          /* floating-point step of table-weight models: read stored linear weights, not states */
 #define CPPROB_HIP_FLAG_FP_TILE_PARTIALS 32u     /* ... and fp64 tile partials instead of packed per-value counts */
+#define CPPROB_HIP_FLAG_WALK_READOUT 64u         /* short discrete traces: read the posterior out by the lineage walk, not from trace words */
 
 /* Posterior summary of a finished run -- what StatsPrinter prints
  * (include/cpprob/postprocess/stats_printer.hpp:42-79) plus SMC diagnostics. */

@@ -373,3 +373,25 @@ def test_markov_probe_finds_the_replay_window_and_changes_no_number(tmp_path, mo
     assert a["log_evidence"] == b["log_evidence"] and a["n_resampled"] == b["n_resampled"] and a["ess"] == b["ess"]
     for pa, pb in zip(a["predicts"], b["predicts"]):
         assert pa == pb
+
+
+def test_device_pilot_refutes_a_window_the_host_probe_lets_through(tmp_path):
+    """rare_memory is first order on almost every trace; a state beyond 3.6 drags the first state back in.  Whatever the host probe's
+    handful of traces concluded, the window is certified on the device -- a pilot population under windowed and under full replay
+    must agree bit for bit -- and is refuted here: the run replays whole traces, and every number is the full replay's.  The
+    first-order models keep their certified window (the other tests of this file)."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    obs = 1.5 * z["lgssm100"][:12]
+    common = ["--model", "rare_memory12", "--smc", "--observes", obs_str(obs), "--n_samples", 50000, "--seed", 8, "--ess_threshold", 0.5, "--generic", "--json", "--no_dump"]
+    a, _, _ = run_main(tmp_path, *common)
+    b, _, _ = run_main(tmp_path, *common, "--no_markov_probe")
+    c, _, _ = run_main(tmp_path, *common, "--no_markov_crosscheck")
+    assert a["replay_window"] == -1 and b["replay_window"] == -1
+    assert a["log_evidence"] == b["log_evidence"] and a["n_resampled"] == b["n_resampled"] and a["ess"] == b["ess"]
+    for pa, pb in zip(a["predicts"], b["predicts"]):
+        assert pa == pb
+    if c["replay_window"] >= 0:
+        # the host probe alone was fooled (and its run's numbers are those of another model): the pilot is what caught it
+        assert a["markov_crosscheck"] == -1 and c["log_evidence"] != b["log_evidence"]
+    h, _, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(z["hmm16"]), "--n_samples", 20000, "--generic", "--json", "--no_dump")
+    assert h["replay_window"] == 1 and h["markov_crosscheck"] == 1

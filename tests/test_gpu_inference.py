@@ -970,3 +970,35 @@ def test_table_hmm_of_any_size_is_bit_exact_against_the_oracle(engine, golden_di
     np.testing.assert_allclose(engine.logw(), lw0, rtol=1e-12, atol=1e-12)
     with pytest.raises(cp.CpprobHipError):
         engine.set_hmm([0.0], [[1.0]])
+
+
+@pytest.mark.parametrize("n,T", [(100000, 16), (1000003, 16), (5000, 1), (3, 7), (40000, 9)])
+def test_trace_word_readout_is_the_lineage_walk_in_integers(engine, golden_dir, n, T):
+    """Short discrete traces ride with the particles (csrc/trace_words.hpp): the default read-out of hmm<T <= 16> counts
+    (x_t, x_T-1) pairs over the final particles' trace words -- integers -- where CPPROB_HIP_FLAG_WALK_READOUT walks anc[]
+    backwards and sums weights in floating point.  Same traces, same evidence; the statistics are those the materialised
+    traces give, to the last bits of the final division."""
+    obs = _obs(golden_dir, "hmm16")[:T]
+    out = {}
+    for name, flags in (("words", 0), ("walk", cp.capi.FLAG_WALK_READOUT)):
+        engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=77, ess_threshold=2.0, flags=flags)
+        engine.run()
+        stats = engine.stats().copy()
+        s = engine.summary()
+        paths = engine.paths()
+        assert np.array_equal(engine.stats(), stats)                   # (materialising the traces leaves the statistics alone)
+        out[name] = (stats, s, paths, engine.logw())
+    assert out["words"][1]["step_form"] == cp.capi.FORM_COUNTS
+    assert np.array_equal(out["words"][2], out["walk"][2]) and out["words"][1]["log_evidence"] == out["walk"][1]["log_evidence"]
+    np.testing.assert_allclose(out["words"][0], out["walk"][0], rtol=0, atol=2e-15)
+    # from the traces themselves
+    paths, lw = out["words"][2], out["words"][3]
+    w = np.exp(lw - lw.max())
+    ref = np.stack([[w[paths[t] == s].sum() for s in range(3)] for t in range(T)]) / w.sum()
+    np.testing.assert_allclose(out["words"][0], ref, rtol=0, atol=1e-13)
+    # twice the same run: the same bits
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=77, ess_threshold=2.0)
+    engine.run()
+    assert np.array_equal(engine.stats(), out["words"][0])
+    engine.run(0)
+    assert np.array_equal(engine.stats(), out["words"][0])
