@@ -551,9 +551,36 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         if (!c->keep) a.anc = nullptr;
         {
             ProfScope ps(c, 0);
-            if (all_totals) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
-            else hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            if (all_totals) hipLaunchKernelGGL(smc_step_fixed_sharded_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL(smc_step_fixed_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         }
+#ifdef CPPROB_STAMPS
+        {
+            static unsigned long long* d_st = nullptr;
+            if (!d_st) { (void)hipMalloc(&d_st, (size_t)131072 * 16 * 8); (void)hipMemset(d_st, 0, (size_t)131072 * 16 * 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)); }
+            if (t >= 40 && t < 48 && getenv("CPPROB_STAMP_DUMP")) {
+                (void)hipStreamSynchronize(c->stream);
+                std::vector<unsigned long long> h((size_t)c->nb * 16);
+                (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+                int32_t rs_prev = 0; (void)hipMemcpy(&rs_prev, c->d_resampled + (t - 1), 4, hipMemcpyDeviceToHost);
+                unsigned long long t0 = ~0ull; for (int b2 = 0; b2 < c->nb; ++b2) t0 = std::min(t0, h[(size_t)b2 * 16]);
+                fprintf(stderr, "STAMPS fixed t=%d resampled=%d n=%lld (us since first workgroup start) mean/max:", t, rs_prev, (long long)c->n);
+                for (int k = 0; k < 8; ++k) {
+                    double acc = 0, mx = 0;
+                    for (int b2 = 0; b2 < c->nb; ++b2) { const double v = (double)(h[(size_t)b2 * 16 + k] - t0) * 0.01; acc += v; mx = std::max(mx, v); }
+                    fprintf(stderr, " [%d] %.2f/%.2f", k, acc / c->nb, mx);
+                }
+                fprintf(stderr, "\n");
+                for (int k : {0, 7}) {
+                    std::vector<double> v((size_t)c->nb);
+                    for (int b2 = 0; b2 < c->nb; ++b2) v[(size_t)b2] = (double)(h[(size_t)b2 * 16 + k] - t0) * 0.01;
+                    std::sort(v.begin(), v.end());
+                    fprintf(stderr, "   stamp %d percentiles 10/25/50/75/80/85/90/95/99/100: %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f\n", k, v[v.size() / 10], v[v.size() / 4], v[v.size() / 2],
+                            v[v.size() * 3 / 4], v[v.size() * 8 / 10], v[v.size() * 85 / 100], v[v.size() * 9 / 10], v[v.size() * 95 / 100], v[v.size() * 99 / 100], v.back());
+                }
+            }
+        }
+#endif
         c->cur ^= 1;
         if (!c->keep) {
             // filtering only: predict hit t's sums under the integer weights this step just left

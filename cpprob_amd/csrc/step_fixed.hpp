@@ -401,7 +401,7 @@ __device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const Fi
 }
 
 template <class Model, bool SHARDED>
-__global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<Model> a)
+__device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& a)
 {
     using V = typename Model::value_t;
     using S = typename Model::store_t;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
     const int64_t j0 = (int64_t)bid * kTile + (int64_t)tid * kPPT;
     const int t = a.t;
     const bool searcher = wave_id() == 0;
-
+    CPH_STAMP(0);
     // everything the prologue reads is addressed by the launch geometry: fetched here, in one round trip under the random draws
     U4 q_0 = {0u, 0u, 0u, 0u}, q_m1 = q_0, q_p1 = q_0;
     FTotWords tw{};
@@ -441,6 +441,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
     typename Model::Rand rnd[kPPT / 4];
 #pragma unroll
     for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+    CPH_STAMP(1);
 
     int32_t anc[kPPT];
 #pragma unroll
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
             if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.ref = r_t; s_found.base = before; s_found.l0 = l0; s_found.l1 = l1; s_found.resample = d.resample ? 1 : 0; }
         }
         __syncthreads();                                               // slots reset, search results in place
+    CPH_STAMP(2);
         resample = s_found.resample != 0;
         ref = s_found.ref;
         if (resample) {
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
         a.ctrl->ref_cur = ref;
     }
 
+    CPH_STAMP(3);
     const S* prev_row = a.values + (int64_t)a.row_r * a.rs;
     V prev[kPPT], x[kPPT];
 #pragma unroll
@@ -524,6 +527,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
     for (int q = 0; q < kPPT / 4; ++q)                                                        // sample #t
         Model::apply4(a.mp, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
     store4_as(a.values + (int64_t)a.row_w * a.rs, j0, x);                                     // predict #t
+    CPH_STAMP(4);
     // (a step that follows no resampling extends every slot by itself: nobody walks that row -- the read-out, the exchange packing
     //  and the skip rows test resampled[t-1] first, and cpprob_hip_copy_ancestors writes the identity on its way out)
     if (a.anc && (t == 0 || resample)) store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);
@@ -545,6 +549,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
     // (the tile's totals by DPP reductions: three same-address 64-bit LDS atomics per lane were measured at 1.7x the whole step);
     // published BEFORE this workgroup's weight / log-weight stores are issued: the hierarchy's atomics -- and, above 4096 tiles, the
     // wait in front of the arrival count -- travel under them instead of behind them
+    CPH_STAMP(5);
     const uint64_t s_w = wave_sum_u64(s_l), q_w = wave_sum_u64(q_l), m_w = wave_max_u64(dkey(m_l));
     if (lane_id() == 0) { s_red[wave_id()] = s_w; s_red[kWaves + wave_id()] = q_w; s_red[2 * kWaves + wave_id()] = m_w; }
     __syncthreads();
@@ -554,9 +559,23 @@ __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<
         for (int w = 0; w < kWaves; ++w) { St += s_red[w]; Qt += s_red[kWaves + w]; Mk = umax64(Mk, s_red[2 * kWaves + w]); }
         fhier_publish(a.f, bid, nb, St, Qt, Mk);
     }
+    CPH_STAMP(6);
     *reinterpret_cast<U4*>(a.q_next + j0) = q;
     if (a.may_carry || t + 1 == a.T) store4(a.logw_next, j0, lw);
+#ifdef CPPROB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CPH_STAMP(7);
+#endif
 }
+
+// One population on this GPU.
+template <class Model>
+__global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, false>(a); }
+// One shard of a joint population.  Five wavefronts a SIMD (96 registers; the continuous models' build wants 138 and spills ~25
+// of them): configs[3]'s shard of 1.25 10^6 particles is 1221 workgroups, and 256 CUs hold 1280 of them at five a CU but 768 at
+// three -- a second pass of workgroups behind the first costs more than the spills (profiles/r03_notes.md).
+template <class Model>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void smc_step_fixed_sharded_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, true>(a); }
 
 // ---- the run's last generation ------------------------------------------------------------------------------------------------
 struct FixedFinal {
