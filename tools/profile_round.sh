@@ -29,5 +29,9 @@ done
 python3 $R/bench.py --workload lgssm100_smc --particles 10000000 --loopback-ranks 8 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_loop_c4.json 2> $O/${TAG}_loop_c4.err
 python3 $R/bench.py --workload hmm128_smc_ess --particles 100000000 --loopback-ranks 8 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_loop_c5.json 2> $O/${TAG}_loop_c5.err
 python3 $R/bench.py --workload hmm16_smc --particles 8000000 --loopback-ranks 8 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/${TAG}_loop_c3x8.json 2> $O/${TAG}_loop_c3x8.err
+# A/B of the headline's read-out (trace words vs the lineage walk), and the host's share of an exchange-scope run
+python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --flags 64 > $O/${TAG}_bench_walk_readout.json 2>> $O/${TAG}_bench.err
+python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $O/${TAG}_bench_trace_words.json 2>> $O/${TAG}_bench.err
+python3 $R/tools/enqueue_vs_gpu.py > $O/${TAG}_enqueue_vs_gpu.jsonl 2>> $O/${TAG}_bench.err
 ls $O | grep ${TAG}_ | head -50
 cut -c1-900 $O/${TAG}_bench.json

@@ -39,7 +39,7 @@ for wl, n in (("hmm16_smc", 1000000), ("lgssm100_smc", 1250000)):
     fe, wr, sq = counters("%s_pmc_%s_%d_FETCH_SIZE" % (src_tag, wl, n)), counters("%s_pmc_%s_%d_WRITE_SIZE" % (src_tag, wl, n)), counters("%s_pmc_%s_%d_SQ_WAVE_CYCLES" % (src_tag, wl, n))
     rec = {}
     for k in fe:
-        name = "step_kernel" if "smc_step" in k else ("smooth_kernel" if "smooth" in k else None)
+        name = "step_kernel" if "smc_step" in k else ("smooth_kernel" if ("smooth" in k or "trace_readout" in k) else None)
         if not name:
             continue
         f = fe[k]["FETCH_SIZE"][0]
