@@ -70,7 +70,10 @@ for wl, n in (("hmm16_smc", 1000000), ("lgssm100_smc", 1250000), ("lgssm100_smc"
     for r in rows[:12]:
         md += "| `%s` | %s | %.1f | %.2f | %.2f | %.2f | %s |\n" % (r["Name"][:110], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"])
     if tr:
-        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr)) if "smc_step" in r["Kernel_Name"]]
+        # (the step launches of THIS population: bench.py's launch-floor run -- 4096 particles, four workgroups -- is in the same trace)
+        full_grid = ((n + 1023) // 1024) * 256
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr))
+                if "smc_step" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == full_grid]
         if durs:
             import statistics
             srt = sorted(durs)
