@@ -488,7 +488,8 @@ def main():
         # secondary: the multi-GPU protocol at world = 1 -- the library's C++ driver with a single rank: per step the sharded step
         # kernel and the shard totals (a group of one has nobody to gather from or exchange with); then the same with EVERY call of
         # the multi-GPU path issued anyway (ncclAllGather per step, the ordering all-gather of the direct transport, ncclAllReduce)
-        for key, flags in (("exchange_world1", 0), ("exchange_world1_all_collectives", cp.capi.GROUP_WORLD1_COLLECTIVES)):
+        for key, flags in (("exchange_world1", 0), ("exchange_world1_all_collectives", cp.capi.GROUP_WORLD1_COLLECTIVES | cp.capi.GROUP_LIBRARY_COLLECTIVES),
+                           ("exchange_world1_mailbox_collectives", cp.capi.GROUP_WORLD1_COLLECTIVES)):
             try:
                 g1 = cp.Group([local])
                 g1.transport(flags=flags)
@@ -496,7 +497,8 @@ def main():
                 gdt, gstats, _, grr = timed_group_runs(g1, args.steps, args.warmup, 1, device, first_index=60_000)
                 out[key] = {"ms_per_run": gdt / args.steps * 1e3, "particles_per_sec": n * args.steps / gdt, "reruns": grr,
                             "posterior_max_abs_err_vs_exact": float(np.abs(gstats - spec["exact"]).max()),
-                            "note": "cpprob_hip_group_run, world = 1" + (", every RCCL collective of the multi-GPU path issued on the context's stream" if flags else "")}
+                            "note": "cpprob_hip_group_run, world = 1" + ("" if not flags else (", every RCCL collective of the multi-GPU path issued on the context's stream" if flags & cp.capi.GROUP_LIBRARY_COLLECTIVES
+                                                                                       else ", the per-step collectives as stores into the rank's own mailbox (what ranks that can map each other's memory run by default)"))}
                 g1.close()
             except Exception as e:
                 out[key] = {"error": str(e)}

@@ -66,10 +66,10 @@ class Collectives(C.Structure):
 
 class Traffic(C.Structure):
     _fields_ = [("records", C.c_uint64), ("payload_bytes", C.c_uint64), ("wire_bytes", C.c_uint64), ("collective_bytes", C.c_uint64),
-                ("transport", C.c_int32), ("remote_lineages", C.c_int32)]
+                ("transport", C.c_int32), ("remote_lineages", C.c_int32), ("mailbox_collectives", C.c_int32), ("reserved", C.c_int32)]
 
 
-GROUP_SENDRECV, GROUP_WORLD1_COLLECTIVES, GROUP_SHIP_LINEAGES = 1, 2, 4
+GROUP_SENDRECV, GROUP_WORLD1_COLLECTIVES, GROUP_SHIP_LINEAGES, GROUP_LIBRARY_COLLECTIVES, GROUP_MAILBOX_COLLECTIVES = 1, 2, 4, 8, 16
 TRANSPORT_NONE, TRANSPORT_DIRECT, TRANSPORT_SENDRECV = 0, 1, 2
 
 _lib = None

@@ -9,6 +9,9 @@
 //   external     the caller's own collectives over host buffers (MPI, gloo, ...): cpprob_hip_group_create_external.  Host-synchronising.
 //   loopback     every rank's context on ONE device and ONE stream; program order is the only synchronisation.  This is how a one-GPU
 //                box exercises the whole protocol, shard layouts and capacities included (RCCL refuses duplicate devices).
+//   mailboxes    (the PER-STEP collectives of RCCL and external groups, wherever the ranks can map each other's memory) stores into
+//                the peers' mailboxes and a spin on this rank's own: device_collectives.hpp.  The library / the caller's all-gather
+//                then carries the set-up exchanges and the run's final all-reduce only.
 // Transports (who moves the migrating lineages)
 //   direct       the packing kernel of the SENDING rank stores each record straight into the receiving rank's buffer -- peer access
 //                inside one process, hipIpc mappings between processes, plain pointers in loopback -- so the bytes that cross xGMI are
@@ -25,6 +28,8 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+
+#include "device_collectives.hpp"
 
 namespace {
 
@@ -79,12 +84,12 @@ RcclApi* rccl_api(std::string& err)
     return &api;
 }
 
-// {raw weighted sums ..., overflow flag, records sent, bytes sent} of a finished sharded run into one buffer: what the final all-reduce carries
-constexpr int kJointExtra = 3;
+// {raw weighted sums ..., overflow flag, records sent, bytes sent, mailbox time-outs} of a finished sharded run into one buffer: what the final all-reduce carries
+constexpr int kJointExtra = 4;
 // Filtering-only shards append their per-step masses (the joint normalisers are the sums over ranks); where the statistics are the
 // joint population's already (count form: they come from the all-gathered totals) only rank 0 contributes them to the sum.
 __global__ void pack_joint_kernel(const double* __restrict__ stats, int n_stats, const cph::ExchangePlan* __restrict__ plan, int has_traffic, double* __restrict__ out,
-                                  const double* __restrict__ masses, int n_masses, int contribute_stats)
+                                  const double* __restrict__ masses, int n_masses, int contribute_stats, const int32_t* __restrict__ dc_status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_stats) out[i] = contribute_stats ? stats[i] : 0.0;
@@ -95,6 +100,7 @@ __global__ void pack_joint_kernel(const double* __restrict__ stats, int n_stats,
         out[n_stats] = (double)((ov & 1) + 128 * ((ov >> 1) & 1) + 16384 * ((ov >> 2) & 1));
         out[n_stats + 1] = (plan && has_traffic) ? (double)plan->run_records : 0.0;     // (integers below 2^53: exact in any order)
         out[n_stats + 2] = (plan && has_traffic) ? (double)plan->run_bytes : 0.0;
+        out[n_stats + 3] = (dc_status && *dc_status != 0) ? 1.0 : 0.0;                  // a mailbox collective of this rank gave up waiting
     }
 }
 
@@ -144,6 +150,10 @@ struct cpprob_hip_group {
     std::vector<void*> ipc_open;                       // peers' receive buffers mapped into this process (hipIpcOpenMemHandle)
     bool remote = false;                               // remote lineages: every rank addresses every rank's particle store
     std::string transport_note;                        // why the direct transport was not taken
+    // mailbox collectives (device_collectives.hpp)
+    bool dev_coll = false, dc_tried = false; std::string dc_note; uint64_t dc_serial = 0;
+    std::vector<cph::Mailbox*> d_box; std::vector<cph::MailboxPeers*> d_box_peers; std::vector<int32_t*> d_dc_status;
+    std::vector<void*> ipc_box_open;
     // per local rank device buffers
     std::vector<double*> d_local, d_all, d_joint, d_bar;
     double* const* d_ptr_locals = nullptr; double* const* d_ptr_alls = nullptr; double* const* d_ptr_joints = nullptr;   // loopback: device arrays of pointers
@@ -245,12 +255,14 @@ size_t group_joint_len(const cpprob_hip_group* g) { return (size_t)g->n_stats + 
 int group_record_len(const cpprob_hip_group* g, int t) { return group_filtering(g) ? 1 : t + 1; }      // values per migrating record after step t
 void launch_pack_joint(cpprob_hip_group* g, cpprob_hip_ctx* c, int rank, bool traffic, double* d_joint, hipStream_t st)
 {
+    const size_t li = (size_t)(rank - g->first_rank);
+    const int32_t* dc_status = (g->dev_coll && li < g->d_dc_status.size()) ? g->d_dc_status[li] : nullptr;
     const bool filt = group_filtering(g);
     const bool joint_already = filt && c->counts_mode;
     const int n_threads = (int)group_joint_len(g);
     hipLaunchKernelGGL(pack_joint_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, st, (const double*)c->d_stats, g->n_stats,
                        g->exchange ? (const cph::ExchangePlan*)c->d_xplan : nullptr, traffic ? 1 : 0, d_joint,
-                       (filt && !joint_already) ? (const double*)c->d_filter_w : nullptr, filt ? g->T : 0, (!joint_already || rank == 0) ? 1 : 0);
+                       (filt && !joint_already) ? (const double*)c->d_filter_w : nullptr, filt ? g->T : 0, (!joint_already || rank == 0) ? 1 : 0, dc_status);
 }
 
 // the exchange that follows step t, as seen by local rank i (send/recv transport): its peers' fixed-capacity segments
@@ -270,6 +282,24 @@ int rccl_exchange(cpprob_hip_group* g, int i, int t)
     return 0;
 }
 
+// ---- mailbox collectives of local rank i (device_collectives.hpp): one short launch on the rank's stream ----
+constexpr long long kDcTimeoutTicks = 500000000ll;          // 5 s of the 100 MHz wall clock
+void dc_allgather(cpprob_hip_group* g, int i, int t, int phases, hipStream_t st)
+{
+    const int rank = g->first_rank + i;
+    const unsigned long long seq = (unsigned long long)(g->dc_serial << 12) | (unsigned long long)(t + 1);
+    hipLaunchKernelGGL(cph::dc_allgather_kernel, dim3(1), dim3(cph::kWave), 0, st, reinterpret_cast<const unsigned long long*>(g->d_local[(size_t)i]),
+                       (const cph::MailboxPeers*)g->d_box_peers[(size_t)i], g->d_box[(size_t)i], g->world, rank, t & 1, seq, phases,
+                       reinterpret_cast<unsigned long long*>(g->d_all[(size_t)i]), g->d_dc_status[(size_t)i], kDcTimeoutTicks);
+}
+void dc_barrier(cpprob_hip_group* g, int i, int t, int phases, hipStream_t st)
+{
+    const int rank = g->first_rank + i;
+    const unsigned long long seq = (unsigned long long)(g->dc_serial << 12) | (unsigned long long)(t + 1);
+    hipLaunchKernelGGL(cph::dc_barrier_kernel, dim3(1), dim3(cph::kWave), 0, st, (const cph::MailboxPeers*)g->d_box_peers[(size_t)i], g->d_box[(size_t)i], g->world, rank,
+                       t & 1, seq, phases, g->d_dc_status[(size_t)i], kDcTimeoutTicks);
+}
+
 // One whole run of local rank i (RCCL: every collective is stream-ordered, nothing waits on the host).
 int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
 {
@@ -282,7 +312,8 @@ int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
     const bool talk = world > 1 || g->world1_collectives;
     for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
         if (int rc = cpprob_hip_smc_step_begin(c, t, run_index, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
-        if (talk) { if (int rc = coll_allgather(g, i, g->d_local[(size_t)i], g->d_all[(size_t)i], 3)) return rc; }
+        if (talk && g->dev_coll) dc_allgather(g, i, t, cph::kDcPost | cph::kDcWait, c->stream);
+        else if (talk) { if (int rc = coll_allgather(g, i, g->d_local[(size_t)i], g->d_all[(size_t)i], 3)) return rc; }
         if (int rc = cpprob_hip_smc_step_end(c, t, talk ? g->d_all[(size_t)i] : g->d_local[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
         if (g->exchange && t + 1 < g->T) {
             // (a context without peers plans at most: cpprob_hip_exchange_pack_async / _commit_async launch nothing for it)
@@ -291,7 +322,8 @@ int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
             else if (g->transport == kTransportDirect) {
                 // the records are already where they belong; what remains is the order: no rank may commit before every rank's
                 // packing kernel has completed, and a rank contributes to this all-gather only behind its own packing kernel
-                if (int rc = coll_allgather(g, i, g->d_bar[(size_t)i], g->d_bar[(size_t)i] + 1, 1)) return rc;
+                if (g->dev_coll) dc_barrier(g, i, t, cph::kDcPost | cph::kDcWait, c->stream);
+                else if (int rc = coll_allgather(g, i, g->d_bar[(size_t)i], g->d_bar[(size_t)i] + 1, 1)) return rc;
             } else {
                 if (int rc = rccl_exchange(g, i, t)) return rc;
             }
@@ -316,7 +348,11 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
     for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
         for (int r = 0; r < world; ++r)
             if (int rc = cpprob_hip_smc_step_begin(g->ctx[(size_t)r], t, run_index, g->d_local[(size_t)r])) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
-        hipLaunchKernelGGL(loop_allgather_kernel, dim3(1), dim3(192), 0, st, g->d_ptr_locals, g->d_ptr_alls, world);
+        if (g->dev_coll) {
+            // (mailboxes on one stream: every rank posts, then every rank finds what it waits for already there)
+            for (int r = 0; r < world; ++r) dc_allgather(g, r, t, cph::kDcPost, st);
+            for (int r = 0; r < world; ++r) dc_allgather(g, r, t, cph::kDcWait, st);
+        } else hipLaunchKernelGGL(loop_allgather_kernel, dim3(1), dim3(192), 0, st, g->d_ptr_locals, g->d_ptr_alls, world);
         for (int r = 0; r < world; ++r)
             if (int rc = cpprob_hip_smc_step_end(g->ctx[(size_t)r], t, g->d_all[(size_t)r], world, r)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
         if (g->exchange && t + 1 < g->T) {
@@ -336,6 +372,10 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
                         HIP_TRY(c, hipMemcpyAsync(static_cast<char*>(p->d_xrecv) + ps * seg, static_cast<const char*>(c->d_xsend) + s * seg, seg, hipMemcpyDeviceToDevice, st));
                     }
                 }
+            }
+            if (g->dev_coll && g->transport == kTransportDirect) {
+                for (int r = 0; r < world; ++r) dc_barrier(g, r, t, cph::kDcPost, st);
+                for (int r = 0; r < world; ++r) dc_barrier(g, r, t, cph::kDcWait, st);
             }
             for (int r = 0; r < world; ++r)
                 if (int rc = cpprob_hip_exchange_commit_async(g->ctx[(size_t)r], t)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
@@ -522,6 +562,117 @@ int setup_remote(cpprob_hip_group* g)
     return 0;
 }
 
+// Mailboxes for the per-step collectives: one per rank, mapped into every rank like the direct transport's buffers, tried once per
+// group and proven by a round trip before any run relies on them.  All or nobody (the outcome is all-gathered).
+int setup_mailboxes(cpprob_hip_group* g)
+{
+    if (g->dc_tried) return 0;
+    g->dc_tried = true; g->dev_coll = false;
+    const int n_local = (int)g->ctx.size(), world = g->world;
+    const bool talk = world > 1 || g->world1_collectives;
+    if (!talk) return 0;
+    if (g->user_flags & CPPROB_HIP_GROUP_LIBRARY_COLLECTIVES) { g->dc_note = "library collectives requested"; return 0; }
+    if (g->loopback() && !(g->user_flags & CPPROB_HIP_GROUP_MAILBOX_COLLECTIVES)) return 0;       // (one launch gathers for every loopback rank)
+    g->d_box.assign((size_t)n_local, nullptr); g->d_box_peers.assign((size_t)n_local, nullptr); g->d_dc_status.assign((size_t)n_local, nullptr);
+    bool ok = true;
+    for (int i = 0; i < n_local && ok; ++i) {
+        cpprob_hip_ctx* c = g->ctx[(size_t)i];
+        GHIP_TRY(g, hipSetDevice(c->device));
+        void* p = nullptr;
+        // (fine-grained: the peers' stores and this rank's spinning loads meet in memory, not in a cache)
+        if (hipExtMallocWithFlags(&p, sizeof(cph::Mailbox), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); if (hipMalloc(&p, sizeof(cph::Mailbox)) != hipSuccess) { ok = false; break; } }
+        g->d_box[(size_t)i] = static_cast<cph::Mailbox*>(p);
+        GHIP_TRY(g, hipMemset(p, 0, sizeof(cph::Mailbox)));
+        GHIP_TRY(g, hipMalloc(&g->d_box_peers[(size_t)i], sizeof(cph::MailboxPeers)));
+        GHIP_TRY(g, hipMalloc(&g->d_dc_status[(size_t)i], sizeof(int32_t)));
+        GHIP_TRY(g, hipMemset(g->d_dc_status[(size_t)i], 0, sizeof(int32_t)));
+    }
+    std::vector<cph::MailboxPeers> tab((size_t)n_local);
+    if (ok && world == n_local) {
+        if (!g->loopback())
+            for (int i = 0; i < n_local && ok; ++i)
+                for (int j = 0; j < n_local && ok; ++j) {
+                    if (i == j) continue;
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, g->ctx[(size_t)i]->device, g->ctx[(size_t)j]->device) != hipSuccess || !can) { ok = false; break; }
+                    (void)hipSetDevice(g->ctx[(size_t)i]->device);
+                    const hipError_t e = hipDeviceEnablePeerAccess(g->ctx[(size_t)j]->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                    (void)hipGetLastError();
+                }
+        for (int i = 0; i < n_local; ++i)
+            for (int r = 0; r < world; ++r) tab[(size_t)i].box[r] = g->d_box[(size_t)r];
+    } else if (world != n_local) {
+        // one rank per process: hipIpc handles of the mailboxes, all-gathered
+        cpprob_hip_ctx* c = g->ctx[0];
+        struct Rec { hipIpcMemHandle_t h; int32_t ok; int32_t pad; };
+        Rec mine{};
+        mine.ok = (ok && hipIpcGetMemHandle(&mine.h, g->d_box[0]) == hipSuccess) ? 1 : 0;
+        (void)hipGetLastError();
+        std::vector<Rec> all((size_t)world);
+        if (int rc = coll_allgather_host(g, 0, &mine, all.data(), sizeof(Rec))) return rc;
+        for (int r = 0; r < world; ++r) ok = ok && all[(size_t)r].ok;
+        int32_t opened = ok ? 1 : 0;
+        if (ok) {
+            GHIP_TRY(g, hipSetDevice(c->device));
+            for (int r = 0; r < world; ++r) {
+                if (r == g->first_rank) { tab[0].box[r] = g->d_box[0]; continue; }
+                void* ptr = nullptr;
+                if (hipIpcOpenMemHandle(&ptr, all[(size_t)r].h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { opened = 0; (void)hipGetLastError(); break; }
+                g->ipc_box_open.push_back(ptr);
+                tab[0].box[r] = static_cast<cph::Mailbox*>(ptr);
+            }
+        }
+        std::vector<int32_t> flags((size_t)world);
+        if (int rc = coll_allgather_host(g, 0, &opened, flags.data(), sizeof(int32_t))) return rc;
+        for (int r = 0; r < world; ++r) ok = ok && flags[(size_t)r];
+    }
+    if (ok)
+        for (int i = 0; i < n_local; ++i) {
+            GHIP_TRY(g, hipSetDevice(g->ctx[(size_t)i]->device));
+            GHIP_TRY(g, hipMemcpy(g->d_box_peers[(size_t)i], &tab[(size_t)i], sizeof(cph::MailboxPeers), hipMemcpyHostToDevice));
+        }
+    // the proof: one all-gather of {rank + 1, 7, 9} through the mailboxes, checked on the host
+    int32_t proven = ok ? 1 : 0;
+    if (ok) {
+        g->dc_serial = 1;
+        std::vector<unsigned long long> got((size_t)3 * (size_t)world);
+        for (int i = 0; i < n_local; ++i) {
+            const unsigned long long w[3] = {(unsigned long long)(g->first_rank + i + 1), 7ull, 9ull};
+            GHIP_TRY(g, hipSetDevice(g->ctx[(size_t)i]->device));
+            GHIP_TRY(g, hipMemcpy(g->d_local[(size_t)i], w, sizeof w, hipMemcpyHostToDevice));
+        }
+        const int t_probe = 4094;                               // (a step number no run uses)
+        if (g->loopback()) {
+            for (int i = 0; i < n_local; ++i) dc_allgather(g, i, t_probe, cph::kDcPost, g->ctx[0]->stream);
+            for (int i = 0; i < n_local; ++i) dc_allgather(g, i, t_probe, cph::kDcWait, g->ctx[0]->stream);
+        } else {
+            for (int i = 0; i < n_local; ++i) { GHIP_TRY(g, hipSetDevice(g->ctx[(size_t)i]->device)); dc_allgather(g, i, t_probe, cph::kDcPost | cph::kDcWait, g->ctx[(size_t)i]->stream); }
+        }
+        for (int i = 0; i < n_local; ++i) {
+            cpprob_hip_ctx* c = g->ctx[(size_t)i];
+            GHIP_TRY(g, hipSetDevice(c->device));
+            int32_t st = 0;
+            GHIP_TRY(g, hipMemcpyAsync(got.data(), g->d_all[(size_t)i], got.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            GHIP_TRY(g, hipMemcpyAsync(&st, g->d_dc_status[(size_t)i], sizeof st, hipMemcpyDeviceToHost, c->stream));
+            GHIP_TRY(g, hipStreamSynchronize(c->stream));
+            if (st != 0) proven = 0;
+            for (int r = 0; r < world; ++r)
+                if (got[(size_t)3 * r] != (unsigned long long)(r + 1) || got[(size_t)3 * r + 1] != 7ull || got[(size_t)3 * r + 2] != 9ull) proven = 0;
+            GHIP_TRY(g, hipMemset(g->d_dc_status[(size_t)i], 0, sizeof(int32_t)));
+            GHIP_TRY(g, hipMemset(g->d_local[(size_t)i], 0, 4 * sizeof(double)));
+        }
+    }
+    if (world != n_local) {
+        std::vector<int32_t> flags((size_t)world);
+        if (int rc = coll_allgather_host(g, 0, &proven, flags.data(), sizeof(int32_t))) return rc;
+        for (int r = 0; r < world; ++r) proven = proven && flags[(size_t)r];
+    }
+    g->dev_coll = proven != 0;
+    if (!g->dev_coll) g->dc_note = ok ? "the mailbox round trip failed: the library's collectives carry the steps" : "a rank's mailbox cannot be mapped: the library's collectives carry the steps";
+    return 0;
+}
+
 int group_begin_contexts(cpprob_hip_group* g)
 {
     const int n_local = (int)g->ctx.size();
@@ -547,6 +698,7 @@ int group_begin_contexts(cpprob_hip_group* g)
 
 int group_enqueue(cpprob_hip_group* g, uint64_t run_index)
 {
+    ++g->dc_serial;                                     // (every rank enqueues the same runs in the same order: the mailboxes' sequence numbers agree)
     if (g->loopback()) return loopback_run(g, run_index);
     if (g->ctx.size() == 1) return run_rank(g, 0, run_index);
     {
@@ -667,6 +819,13 @@ void cpprob_hip_group_destroy(cpprob_hip_group* g)
         (void)hipStreamSynchronize(g->ctx[i]->stream);
     }
     close_direct(g);
+    for (void* p : g->ipc_box_open) (void)hipIpcCloseMemHandle(p);
+    for (size_t i = 0; i < g->d_box.size(); ++i) {
+        (void)hipSetDevice(g->ctx[i]->device);
+        if (g->d_box[i]) (void)hipFree(g->d_box[i]);
+        if (g->d_box_peers[i]) (void)hipFree(g->d_box_peers[i]);
+        if (g->d_dc_status[i]) (void)hipFree(g->d_dc_status[i]);
+    }
     for (size_t i = 0; i < g->comm.size(); ++i)
         if (g->comm[i]) (void)g->rccl->CommDestroy(g->comm[i]);
     for (size_t i = 0; i < g->ctx.size(); ++i) {
@@ -726,6 +885,7 @@ int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, co
         GHIP_TRY(g, hipMemset(g->d_joint[(size_t)i], 0, nj * sizeof(double)));
         GHIP_TRY(g, hipMemset(g->d_bar[(size_t)i], 0, ((size_t)g->world + 1) * sizeof(double)));
     }
+    if (int rc = setup_mailboxes(g)) return gkeep(g, rc);    // (once per group; uses the buffers above for its proof)
     if (g->loopback()) {
         GHIP_TRY(g, hipSetDevice(g->ctx[0]->device));
         if (g->d_ptr_locals) { (void)hipFree((void*)g->d_ptr_locals); (void)hipFree((void*)g->d_ptr_alls); (void)hipFree((void*)g->d_ptr_joints); }
@@ -811,6 +971,16 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
             if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
             continue;
         }
+        if (joint[(size_t)g->n_stats + 3] != 0.0) {
+            // some rank's mailbox wait gave up (every rank sees the all-reduced count): the library's collectives carry the steps from
+            // here on, and the run is repeated on them
+            if (attempt >= 6) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "run repeated too often"));
+            g->dev_coll = false; g->dc_note = "a mailbox collective timed out: the library's collectives carry the steps";
+            for (size_t i = 0; i < g->d_dc_status.size(); ++i) { GHIP_TRY(g, hipSetDevice(g->ctx[i]->device)); GHIP_TRY(g, hipMemset(g->d_dc_status[i], 0, sizeof(int32_t))); }
+            ++g->reruns;
+            if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
+            continue;
+        }
         if (joint[(size_t)g->n_stats] == 0.0) break;
         // some rank's transport was too small (every rank sees the same all-reduced flags and takes the same decision): repeat
         // the run with what overflowed enlarged -- the annex (x4), the peer segments (x4, up to a whole shard), the peer list
@@ -838,10 +1008,12 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
     g->traffic.transport = g->transport; g->traffic.remote_lineages = g->remote ? 1 : 0;
     const bool talk = g->world > 1 || g->world1_collectives;
     const double steps = (g->cfg.algorithm == CPPROB_HIP_ALG_SIS) ? 1.0 : (double)g->T;
-    g->traffic.collective_bytes = talk ? (uint64_t)((double)g->world * (double)g->world * (3.0 * 8.0 * steps + ((double)g->n_stats + kJointExtra) * 8.0)) : 0;
+    // (mailboxes: three words and a sequence number per rank pair and step)
+    g->traffic.collective_bytes = talk ? (uint64_t)((double)g->world * (double)g->world * ((g->dev_coll ? 4.0 : 3.0) * 8.0 * steps + ((double)g->n_stats + kJointExtra) * 8.0)) : 0;
+    g->traffic.mailbox_collectives = g->dev_coll ? 1 : 0;
     if (g->transport == kTransportDirect) {
         g->traffic.wire_bytes = g->traffic.payload_bytes;
-        if (talk && !g->loopback()) g->traffic.collective_bytes += (uint64_t)((double)g->world * (double)g->world * 8.0 * std::max(0.0, steps - 1.0));   // the ordering all-gather
+        if (talk && (!g->loopback() || g->dev_coll)) g->traffic.collective_bytes += (uint64_t)((double)g->world * (double)g->world * 8.0 * std::max(0.0, steps - 1.0));   // the ordering all-gather
     } else if (g->transport == kTransportSendRecv) g->traffic.wire_bytes = (uint64_t)sendrecv_wire_bytes(g);
     else g->traffic.wire_bytes = 0;
     cpprob_hip_summary s{};

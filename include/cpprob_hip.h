@@ -316,6 +316,11 @@ int cpprob_hip_exchange_status(cpprob_hip_ctx* ctx, int32_t* h_overflow, uint64_
  *            (peer access inside a process, hipIpc mappings between processes), ordered by a one-double all-gather per step, so that
  *            what crosses xGMI is records x (t + 1) x value size and nothing on a step that does not resample -- wherever every rank
  *            can map its peers' buffers; otherwise SENDRECV -- ncclSend / ncclRecv of the fixed-capacity segments.
+ *            The per-step collectives (24 bytes of totals per rank; the ordering of the direct stores): MAILBOXES wherever the ranks
+ *            can map each other's memory -- a rank stores its words and the step's sequence number into every peer's mailbox and spins
+ *            on its own, one short launch, no library call and no host inside a run (csrc/device_collectives.hpp); proven by a round
+ *            trip at the first begin, and a wait that times out (5 s) makes results() repeat the run on the library's collectives.
+ *            Otherwise RCCL calls / the caller's all-gather.  The collectives flags are read at the first begin.
  *   begin    cfg as for cpprob_hip_infer_begin with n_particles = the WHOLE population (particle_offset / n_global / scope are
  *            set per rank by the group); shards are contiguous and equal unless h_shard_sizes[world] names them.  Systematic SMC
  *            runs in the exchange scope (exact global resampling); other resamplers and SIS in the global scope.  COLLECTIVE.
@@ -338,6 +343,9 @@ typedef struct cpprob_hip_collectives {
 #define CPPROB_HIP_GROUP_SHIP_LINEAGES 4u      /* direct transport: migrants still take their whole lineage along (records of t + 1 values)
                                                    instead of leaving it on the rank they come from (remote lineages, the default where
                                                    every rank can address every rank's particle store) */
+#define CPPROB_HIP_GROUP_LIBRARY_COLLECTIVES 8u /* the per-step collectives through RCCL / the caller's all-gather even where the ranks can map
+                                                   each other's memory (default there: stores into the peers' mailboxes, no call inside a run) */
+#define CPPROB_HIP_GROUP_MAILBOX_COLLECTIVES 16u /* loopback groups too (they gather for every rank in one launch by default) */
 #define CPPROB_HIP_TRANSPORT_NONE 0
 #define CPPROB_HIP_TRANSPORT_DIRECT 1
 #define CPPROB_HIP_TRANSPORT_SENDRECV 2
@@ -348,6 +356,8 @@ typedef struct cpprob_hip_traffic {
     uint64_t collective_bytes; /* the small collectives: all-gathers of 3 doubles (+ 1 ordering the direct stores) per step, the final all-reduce */
     int32_t transport;         /* CPPROB_HIP_TRANSPORT_*                                                                       */
     int32_t remote_lineages;   /* 1: migrants left their history on the rank they came from (records of value + 8 bytes)           */
+    int32_t mailbox_collectives; /* 1: the per-step collectives were stores into the peers' mailboxes, not library calls            */
+    int32_t reserved;
 } cpprob_hip_traffic;
 int cpprob_hip_group_unique_id(void* out128, size_t n_bytes);
 int cpprob_hip_group_create(const int32_t* devices, int32_t n_local, int32_t world, int32_t first_rank, const void* unique_id, cpprob_hip_group** out);

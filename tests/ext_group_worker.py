@@ -39,6 +39,8 @@ def main():
         paths = e.paths()
         g.close()
         assert tr["transport"] == cp.capi.TRANSPORT_DIRECT and tr["remote_lineages"] == 1 and tr["records"] > 0 and tr["wire_bytes"] == tr["payload_bytes"], tr
+        # the per-step collectives went through the mailboxes (two processes spinning on each other's stores), not through gloo
+        assert tr["mailbox_collectives"] == 1 and reruns == 0, (tr, reruns)
         # every rank's shard of the traces, gathered on rank 0, against ONE context holding all particles
         gathered = [None] * world
         dist.all_gather_object(gathered, paths)

@@ -16,9 +16,9 @@ def _obs(golden_dir, key):
     return np.load(os.path.join(golden_dir, "observations.npz"))[key]
 
 
-def _single(engine, alg, model, obs, n, seed, ess):
+def _single(engine, alg, model, obs, n, seed, ess, run_index=0):
     engine.begin(alg, model, obs, n, seed=seed, ess_threshold=ess)
-    engine.run()
+    engine.run(run_index)
     return engine.stats().copy(), engine.summary(), engine.paths(), engine.logw()
 
 
@@ -282,12 +282,14 @@ def test_group_transports_agree_and_account_their_bytes(engine, golden_dir, mode
     if T * vsz > 2 * (vsz + 8): assert out["remote"][1]["wire_bytes"] < out["ship"][1]["wire_bytes"]      # (short traces of bytes: the lineage is smaller than the origin word)
 
 
-@pytest.mark.parametrize("flags", [cp.capi.GROUP_WORLD1_COLLECTIVES, cp.capi.GROUP_WORLD1_COLLECTIVES | cp.capi.GROUP_SENDRECV])
+W1 = cp.capi.GROUP_WORLD1_COLLECTIVES
+@pytest.mark.parametrize("flags", [W1 | cp.capi.GROUP_LIBRARY_COLLECTIVES, W1 | cp.capi.GROUP_LIBRARY_COLLECTIVES | cp.capi.GROUP_SENDRECV, W1, W1 | cp.capi.GROUP_SHIP_LINEAGES])
 def test_group_of_one_rank_runs_every_rccl_call_of_the_multi_gpu_path(engine, golden_dir, flags):
     """world = 1 over the real library: with CPPROB_HIP_GROUP_WORLD1_COLLECTIVES the rank is its own peer, so the per-step
-    ncclAllGather, the ordering all-gather of the direct transport -- or, with CPPROB_HIP_GROUP_SENDRECV, the grouped ncclSend /
-    ncclRecv of a whole segment to and from itself -- and the final ncclAllReduce all execute on this GPU; results are bit-identical
-    to the plain run, count form and floating-point form."""
+    collectives and the final ncclAllReduce all execute on this GPU.  LIBRARY_COLLECTIVES: ncclAllGather per step and the ordering
+    all-gather of the direct transport -- or, with SENDRECV, the grouped ncclSend / ncclRecv of a whole segment to and from itself.
+    Without it (the default wherever ranks can map each other's memory): the mailbox collectives -- the rank posts into and spins on
+    its own mailbox.  Results are bit-identical to the plain run, count form and fixed-point form."""
     import torch  # noqa: F401
     for model, key, T, ess in ((cp.MODEL_HMM3, "hmm16", 16, 2.0), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 12, 0.5)):
         obs = _obs(golden_dir, key)[:T]
@@ -306,8 +308,34 @@ def test_group_of_one_rank_runs_every_rccl_call_of_the_multi_gpu_path(engine, go
         assert s["log_evidence"] == ref_sum["log_evidence"] and reruns == 0
         assert tr["transport"] == (cp.capi.TRANSPORT_SENDRECV if flags & cp.capi.GROUP_SENDRECV else cp.capi.TRANSPORT_DIRECT)
         assert tr["records"] == 0 and tr["collective_bytes"] > 0
+        assert tr["mailbox_collectives"] == (0 if flags & cp.capi.GROUP_LIBRARY_COLLECTIVES else 1)
         if flags & cp.capi.GROUP_SENDRECV:
             assert tr["wire_bytes"] > 0          # the stale segment did travel (to itself)
+
+
+@pytest.mark.parametrize("model,key,T,ess,extra", [(cp.MODEL_HMM3, "hmm16", 16, 2.0, 0), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 30, 0.5, 0),
+                                                  (cp.MODEL_HMM3, "hmm128", 40, 0.5, cp.capi.GROUP_SHIP_LINEAGES)])
+def test_group_mailbox_collectives_on_loopback_ranks(engine, golden_dir, model, key, T, ess, extra):
+    """The per-step collectives as stores into the peers' mailboxes (csrc/device_collectives.hpp), on loopback ranks: every rank posts,
+    then every rank finds what it waits for (one stream: program order delivered it) -- sequence numbers, parities, the ordering
+    barrier of the direct stores and the proof round at begin all run; the answer is the one-GPU answer, run after run."""
+    import torch  # noqa: F401
+    obs = _obs(golden_dir, key)[:T]
+    shards = [30000, 50001, 19999, 40000, 2048]
+    n = int(sum(shards))
+    g = cp.Group([0] * len(shards))
+    g.transport(flags=cp.capi.GROUP_MAILBOX_COLLECTIVES | extra)
+    g.begin(cp.ALG_SMC, model, obs, n, seed=21, ess_threshold=ess, shard_sizes=shards)
+    for run in (0, 1, 2, 1):
+        g.run(run)
+        stats, s, reruns = g.results()
+        tr = g.traffic()
+        ref_stats, ref_sum, ref_paths, _ = _single(engine, cp.ALG_SMC, model, obs, n, 21, ess, run_index=run)
+        paths = np.concatenate([_ctx_paths(g, r, shards[r], T, model == cp.MODEL_HMM3) for r in range(len(shards))], axis=1)
+        assert reruns == 0 and tr["mailbox_collectives"] == 1 and tr["records"] > 0
+        assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"]
+        np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
+    g.close()
 
 
 def test_group_world_limit_is_63_ranks(engine, golden_dir):
