@@ -210,6 +210,27 @@ def make_rank_group(cp, world, rank, local):
     return cp.Group([local], world=world, first_rank=rank, unique_id=box[0])
 
 
+def make_external_group(cp, world, rank, local, device):
+    """This process's rank of a group whose set-up exchanges and final reduction go through torch.distributed (the launcher's own
+    process group: gloo or nccl); inside a run the ranks talk through their mapped mailboxes and direct stores
+    (cpprob_hip_group_create_external)."""
+    import torch
+    import torch.distributed as dist
+    on_host = dist.get_backend() == "gloo"
+
+    def allgather(b):
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+        if on_host:
+            outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            return b"".join(bytes(o.numpy().tobytes()) for o in outs)
+        t = t.to(device)
+        out = torch.empty(world * t.numel(), dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(out, t)
+        return bytes(out.cpu().numpy().tobytes())
+    return cp.Group([local], world=world, first_rank=rank, allgather=allgather)
+
+
 def _oracle_run(args):
     """One oracle run (worker of the all-cores baseline; top-level so that multiprocessing can pickle it)."""
     alg_is_sis, model, obs, n_sample, seed, ess = args
@@ -324,9 +345,17 @@ def main():
     if native:
         try:
             group = guarded(lambda: make_rank_group(cp, world, rank, local), "creating the RCCL communicator of the library's driver")
-            host = "C++ (cpprob_hip_group_run: RCCL on the context's stream, no host synchronisation inside a run)"
-        except Exception as e:      # reported, never silent: the run then goes through torch.distributed's collectives
+            host = "C++ (cpprob_hip_group_run: RCCL for set-up and the final reduction, mailboxes per step, no host synchronisation inside a run)"
+        except Exception as e:      # reported, never silent: the next rung is the same driver on torch.distributed's collectives
             native_error = str(e)
+    if exchange and world > 1 and group is None and not args.python_host:
+        # the library's driver with the launcher's process group for the set-up exchanges and the final reduction (several ranks on
+        # one GPU -- the gloo test hook -- come here directly: RCCL refuses duplicate devices)
+        try:
+            group = guarded(lambda: make_external_group(cp, world, rank, local, device), "creating the library's driver on torch.distributed's collectives")
+            host = "C++ (cpprob_hip_group_run: torch.distributed %s for set-up and the final reduction, mailboxes per step)" % torch.distributed.get_backend()
+        except Exception as e:
+            native_error = (native_error + "; " if native_error else "") + str(e)
     moved = {}
     reruns = 0
     xtraffic = None
@@ -444,7 +473,8 @@ def main():
         # bytes of ONE run (the last one collected): what crossed the links for the migrating lineages, and the small collectives
         out["exchange_traffic_per_run"] = {"records": xtraffic["records"], "payload_bytes": xtraffic["payload_bytes"], "wire_bytes": xtraffic["wire_bytes"],
                                            "collective_bytes": xtraffic["collective_bytes"],
-                                           "transport": {0: "none", 1: "direct", 2: "sendrecv"}[xtraffic["transport"]]}
+                                           "transport": {0: "none", 1: "direct", 2: "sendrecv"}[xtraffic["transport"]],
+                                           "remote_lineages": bool(xtraffic["remote_lineages"]), "mailbox_collectives": bool(xtraffic["mailbox_collectives"])}
 
     def emit():
         if rank == 0:

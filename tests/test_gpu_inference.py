@@ -909,6 +909,12 @@ def test_bench_two_ranks_on_one_gpu(scope, workload):
         key = "hmm128_logz" if workload == "hmm128_smc_ess" else "lgssm100_logz"
         assert abs(d["log_evidence"] - float(z[key])) < 0.05 and 0 < d["n_resampled"] < len(z[key.replace("_logz", "")]) - 1
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+    if d["config"]["scope"] == "exchange":
+        # the library's own driver, one rank per process: set-up and the final reduction through torch.distributed (gloo here), the
+        # steps through mailboxes and direct stores between the two processes
+        assert d["config"]["host"].startswith("C++ (cpprob_hip_group_run: torch.distributed gloo"), d["config"]
+        assert d["exchange_traffic_per_run"]["transport"] == "direct" and d["exchange_traffic_per_run"]["records"] > 0
+        assert d["config"]["exchange_reruns"]["timed_batch"] == 0
 
 
 HMM2 = ([-1.5, 1.0], [[0.85, 0.15], [0.3, 0.7]])
