@@ -370,3 +370,31 @@ def test_group_over_two_processes_maps_the_peer_buffers_through_hipipc(golden_di
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "EXT_GROUP_OK" in p.stdout
+
+
+@pytest.mark.parametrize("model,key,T,ess,n", [(cp.MODEL_HMM3, "hmm16", 6, 2.0, 13_000_777), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 8, 0.5, 9_000_001),
+                                               (cp.MODEL_HMM3, "hmm128", 8, 0.5, 16_700_000), (cp.MODEL_HMM3, "hmm16", 5, 2.0, 20_000_000)])
+def test_three_level_hierarchy_against_sharded_runs(engine, golden_dir, model, key, T, ess, n):
+    """Above 4096 tiles the hierarchy has three levels (a block's last arriver forwards its totals).  One context holding everything
+    and eight loopback shards (two-level hierarchies of their own) must draw the very same traces: totals, prefix sums, probes and
+    the descent all take part."""
+    import torch  # noqa: F401
+    obs = _obs(golden_dir, key)[:T]
+    world = 8
+    ref_stats, ref_sum, ref_paths, _ = _single(engine, cp.ALG_SMC, model, obs, n, 41, ess)
+    engine.begin(cp.ALG_SMC, model, obs, 1024, seed=1)              # (give the big store back before the shards allocate theirs)
+    g = cp.Group([0] * world)
+    g.begin(cp.ALG_SMC, model, obs, n, seed=41, ess_threshold=ess)
+    g.run()
+    stats, s, reruns = g.results()
+    base, rem = divmod(n, world)
+    sizes = [base + (1 if r < rem else 0) for r in range(world)]
+    ok = True
+    off = 0
+    for r in range(world):
+        p = _ctx_paths(g, r, sizes[r], T, model == cp.MODEL_HMM3)
+        ok = ok and np.array_equal(p, ref_paths[:, off:off + sizes[r]])
+        off += sizes[r]
+    g.close()
+    assert ok and s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
