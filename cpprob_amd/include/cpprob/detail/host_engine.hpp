@@ -296,15 +296,20 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
     }
 }
 
-// ---- unchanged models over several GPUs: StateType::sis ------------------------------------------------------------------------
+// ---- unchanged models over several GPUs ----------------------------------------------------------------------------------------
 // Importance sampling needs no communication until the shards' sums meet: every device runs the model body for its
 // contiguous block of particles -- global particle ids select the random streams, so the traces are those ONE device would have
 // drawn -- on a host thread of its own, and the shards' self-normalised numbers are combined by their evidence:
 //   w_r = exp(L_r - L), L = logsumexp_r L_r;  mean = sum w_r mean_r;  E[x^2] = sum w_r (var_r + mean_r^2);  P = sum w_r P_r;
 //   ESS = 1 / sum_r w_r^2 / ESS_r;  log evidence = L - log N.
-inline void run_generic_sharded_sis(const Entry& e, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
-                                    Result& res, HostStore* store)
+// StateType::smc: every shard is an ISLAND -- an independent SMC run of its own particles, resampled among themselves -- and the
+// islands are combined the same way with L_r = log(n_r Z_r), Z_r the island's evidence estimate: a consistent estimator of the same
+// posterior, but not the joint population's resampling (that needs the replayed traces to migrate: not built; the built-in models
+// have it, cpprob_hip_group_*).
+inline void run_generic_sharded(StateType algorithm, const Entry& e, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
+                                Result& res, HostStore* store)
 {
+    const bool smc = algorithm == StateType::smc;
     const std::size_t world = opt.devices.size();
     std::vector<Result> rr(world);
     std::vector<HostStore> hs(world);
@@ -317,18 +322,22 @@ inline void run_generic_sharded_sis(const Entry& e, const void* observes_v, std:
             try {
                 Options o = opt;
                 o.device = opt.devices[r]; o.devices.clear(); o.particle_offset = begin[r]; o.dump = false;
-                e.generic(StateType::sis, observes_v, begin[r + 1] - begin[r], st, o, rr[r], store ? &hs[r] : nullptr);
+                e.generic(algorithm, observes_v, begin[r + 1] - begin[r], st, o, rr[r], store ? &hs[r] : nullptr);
             } catch (const std::exception& ex) { errs[r] = ex.what(); }
         });
     for (auto& t : th) t.join();
     for (std::size_t r = 0; r < world; ++r)
         if (!errs[r].empty()) throw std::runtime_error("cpprob::inference (shard " + std::to_string(r) + "): " + errs[r]);
+    // (an island's mass: its particles times its evidence estimate; an SIS shard's: the sum of its weights -- the same thing)
+    if (smc)
+        for (std::size_t r = 0; r < world; ++r) rr[r].log_norm = rr[r].log_evidence + std::log(static_cast<double>(begin[r + 1] - begin[r]));
     double L = -std::numeric_limits<double>::infinity();
     for (const auto& x : rr) L = std::max(L, x.log_norm);
     double acc = 0;
     for (const auto& x : rr) acc += std::exp(x.log_norm - L);
     L += std::log(acc);
     res = rr[0];
+    if (smc) { res.n_resampled = 0; for (const auto& x : rr) res.n_resampled = std::max(res.n_resampled, x.n_resampled); res.step_ess.clear(); }
     res.n_particles = n; res.log_norm = L; res.log_evidence = L - std::log(static_cast<double>(n)); res.n_gpus = static_cast<int>(world);
     double inv_ess = 0, secs = 0;
     for (const auto& x : rr) { const double w = std::exp(x.log_norm - L); inv_ess += w * w / x.ess; secs = std::max(secs, x.run_seconds); }
@@ -442,10 +451,8 @@ void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>
     if (opt.devices.size() > 1) {
         const bool builtin = e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic);
         if (builtin) run_builtin_group(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
-        else if (algorithm == StateType::sis && e->generic) run_generic_sharded_sis(*e, &obs, n, st, opt, res, store);
-        else throw std::runtime_error("cpprob::inference: over several GPUs (cpprob::gpu::options().devices) an unchanged model runs under StateType::sis "
-                                      "(shards need no communication); StateType::smc over several GPUs serves the built-in models -- the joint "
-                                      "resampling of replayed traces is not built");
+        else if (e->generic) run_generic_sharded(algorithm, *e, &obs, n, st, opt, res, store);      // (smc: islands, see there)
+        else throw std::runtime_error("cpprob::inference: registry entry without a launcher");
     }
     else if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic || (st.vector_statements && !e->generic_vectors)))
         run_builtin(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);

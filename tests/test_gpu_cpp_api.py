@@ -282,8 +282,9 @@ def test_unchanged_model_shards_over_several_devices_under_sis(tmp_path, model, 
     """SURVEY 8(e) for the unchanged-model path: under StateType::sis the shards of a population need no communication, so
     cpprob::gpu::options().devices (cpprob_main --generic --devices) runs the model body for contiguous blocks of particles on every
     device -- global particle ids select the random streams -- and combines the shards by their evidence.  Three shards on this GPU:
-    every trace and every weight of the dump equals the one-device run's (per-particle parity), the estimators agree to rounding;
-    StateType::smc over several devices is refused for unchanged models with a message that says what does run."""
+    every trace and every weight of the dump equals the one-device run's (per-particle parity), the estimators agree to rounding.
+    StateType::smc over several devices runs unchanged models as ISLANDS (independent SMC per device, combined by their evidence):
+    a consistent estimator of the same posterior, checked against forward-backward."""
     if obs is None:
         obs = obs_str(np.load(os.path.join(GOLD, "observations.npz"))["hmm16"])
     n = 50001
@@ -303,8 +304,12 @@ def test_unchanged_model_shards_over_several_devices_under_sis(tmp_path, model, 
         if f1.exists():
             assert open(str(f1)).read() == open(str(f2)).read()
     if model == "hmm16":
-        _, out, err = run_main(tmp_path, "--model", model, "--smc", "--observes", obs, "--n_samples", n, "--generic", "--devices", "0,0", expect_rc=2)
-        assert "StateType::sis" in err and "built-in" in err
+        z = np.load(os.path.join(GOLD, "observations.npz"))
+        isl, _, _ = run_main(tmp_path, "--model", model, "--smc", "--observes", obs, "--n_samples", 150000, "--seed", 9, "--generic", "--devices", "0,0,0", "--json", "--no_dump")
+        assert isl["n_gpus"] == 3 and not isl["builtin"] and isl["n_resampled"] > 0
+        assert abs(isl["log_evidence"] - float(z["hmm16_logz"])) < 0.02
+        got = np.array([p["p"][:3] + [0.0] * (3 - len(p["p"][:3])) for p in isl["predicts"]])
+        assert np.abs(got - z["hmm16_smooth"]).max() < 0.01
 
 
 def test_vector_statements_run_through_the_generic_device_path(tmp_path):
