@@ -18,8 +18,10 @@ struct Options {
                                                       // one GPU holding every particle would (exchange scope: per step an RCCL all-gather of the
                                                       // rank totals and the redistribution of offspring over xGMI; cpprob_hip_group_*).  All
                                                       // entries equal: every rank on that one GPU (loopback transport; a one-GPU machine's way
-                                                      // to run the protocol).  Built-in models; unchanged models (CPPROB_REGISTER_MODEL) under
-                                                      // StateType::sis, whose shards need no communication until their sums are combined.
+                                                      // to run the protocol).  Built-in models; unchanged models (CPPROB_REGISTER_MODEL): under
+                                                      // StateType::sis the shards need no communication until their sums are combined (the
+                                                      // one-device run, exactly); under StateType::smc every device runs an ISLAND of its own
+                                                      // and the islands are combined by their evidence estimates.
     std::uint64_t seed = 12345;
     int resampler = CPPROB_HIP_RESAMPLE_SYSTEMATIC;   // smc
     double ess_threshold = 0.5;                       // smc: resample when ESS < threshold * N (thesis p.37); > 1: every step
