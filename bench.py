@@ -364,7 +364,10 @@ def main():
         n_global, exchange, scope = n, True, "exchange"
         host = "C++ (cpprob_hip_group_run), %d loopback ranks on one GPU" % args.loopback_ranks
     if group is not None:
-        group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
+        def begin_group():
+            group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
+        # (begin is collective over real links: it all-gathers hipIpc handles and proves the mailboxes by a round trip)
+        guarded(begin_group, "cpprob_hip_group_begin (peer mappings, mailbox round trip)") if world > 1 else begin_group()
         dt, stats, summ, reruns = timed_group_runs(group, args.steps, args.warmup, world, device)
         xtraffic = group.traffic()
         last = (stats,)
