@@ -438,9 +438,15 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
             if (SHARDED) { const int r = tid < a.world ? tid : 0; rs_ = a.all_totals[3 * r]; rq_ = a.all_totals[3 * r + 1]; rm_ = a.all_totals[3 * r + 2]; }
         }
     }
+    // The variates: drawn here, under the round trip of the entry loads, where they are expensive (Box-Muller in fp64: the latency buys
+    // them); behind the walk where they are a few integer operations (the discrete models), so that nothing of them is live across
+    // the search and the walk -- measured both ways for both (profiles/r03_notes.md section 3).
+    constexpr bool kDrawEarly = !Model::kIsInt;
     typename Model::Rand rnd[kPPT / 4];
+    if constexpr (kDrawEarly) {
 #pragma unroll
-    for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+        for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+    }
     CPH_STAMP(1);
 
     int32_t anc[kPPT];
@@ -520,6 +526,10 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
 
     CPH_STAMP(3);
     const S* prev_row = a.values + (int64_t)a.row_r * a.rs;
+    if constexpr (!kDrawEarly) {
+#pragma unroll
+        for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+    }
     V prev[kPPT], x[kPPT];
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>(prev_row[anc[k]]) : V(0);                 // ancestor's state (sorted gather)
