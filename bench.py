@@ -553,7 +553,7 @@ def main():
             out["generic_path"] = {"ms_per_run": gj["run_seconds"] * 1e3, "particles_per_sec": n / gj["run_seconds"], "replay_window": gj["replay_window"],
                                    "posterior_max_abs_err_vs_exact": float(np.abs(gst - spec["exact"]).max()),
                                    "vs_fused_kernels": gj["run_seconds"] * 1e3 / (dt / args.steps * 1e3),
-                                   "note": "cpprob_main --generic --repeat 6 (last run; excludes allocation and the final per-column read-out)"}
+                                   "note": "cpprob_main --generic --repeat 6 (last run; allocation excluded, the read-out of every predict hit included)"}
         except Exception as e:
             out["generic_path"] = {"error": str(e)}
 

@@ -29,7 +29,7 @@ SYMBOLS = [
     "cpprob_hip_group_context", "cpprob_hip_group_results", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
     "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
-    "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_smc_bookkeep_fixed", "cpprob_hip_lineage_gather", "cpprob_hip_gather_f64",
+    "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_weighted_moments_columns", "cpprob_hip_weighted_hist_columns", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_smc_bookkeep_fixed", "cpprob_hip_lineage_gather", "cpprob_hip_gather_f64",
     "cpprob_hip_gather_i32", "cpprob_hip_profile_enable", "cpprob_hip_profile_read", "cpprob_hip_fastmath",
 ]
 
@@ -150,6 +150,8 @@ def load_library(path=None):
         "cpprob_hip_logsumexp_ess": (C.c_int, [vp, vp, sz, C.POINTER(dbl)]),
         "cpprob_hip_weighted_moments": (C.c_int, [vp, vp, vp, sz, C.POINTER(dbl)]),
         "cpprob_hip_weighted_hist": (C.c_int, [vp, vp, vp, sz, i32, C.POINTER(dbl)]),
+        "cpprob_hip_weighted_moments_columns": (C.c_int, [vp, vp, sz, sz, vp, sz, C.POINTER(dbl)]),
+        "cpprob_hip_weighted_hist_columns": (C.c_int, [vp, vp, sz, sz, vp, sz, i32, C.POINTER(dbl)]),
         "cpprob_hip_resample": (C.c_int, [vp, i32, vp, sz, u64, u64, u64, sz, u64, vp]),
         "cpprob_hip_smc_bookkeep": (C.c_int, [vp, i32, vp, sz, u64, i32, i32, dbl, vp, vp, vp, vp]),
         "cpprob_hip_smc_bookkeep_fixed": (C.c_int, [vp, vp, sz, u64, i32, i32, dbl, vp, vp, vp, vp]),
@@ -396,6 +398,20 @@ class Engine:
         out = (C.c_double * 8)()
         self._chk(self.L.cpprob_hip_weighted_hist(self.h, _dptr(x), _dptr(logw), logw.numel(), k, out))
         return np.array(out[:k])
+
+    def weighted_moments_columns(self, x, logw):
+        """x: [n_cols, n] device tensor (contiguous rows) -> array [n_cols, 4] of (mean, variance, logsumexp, ess)."""
+        n_cols, n = int(x.shape[0]), int(x.shape[1])
+        out = (C.c_double * (4 * n_cols))()
+        self._chk(self.L.cpprob_hip_weighted_moments_columns(self.h, _dptr(x), n_cols, n, _dptr(logw), n, out))
+        return np.array(out[:]).reshape(n_cols, 4)
+
+    def weighted_hist_columns(self, x, logw, k):
+        """x: [n_cols, n] int32 device tensor -> array [n_cols, k] of P(x = s)."""
+        n_cols, n = int(x.shape[0]), int(x.shape[1])
+        out = (C.c_double * (k * n_cols))()
+        self._chk(self.L.cpprob_hip_weighted_hist_columns(self.h, _dptr(x), n_cols, n, _dptr(logw), n, k, out))
+        return np.array(out[:]).reshape(n_cols, k)
 
     def resample(self, kind, logw, seed, step, anc_out, j0=0, n_total_out=None):
         n_out = anc_out.numel()

@@ -137,6 +137,7 @@ struct cpprob_hip_ctx {
     Partial* d_bb_part = nullptr; double* d_bb_bc = nullptr; double* d_bb_bf = nullptr; double* d_bb_wrel = nullptr; void* d_bb_col = nullptr;
     StepCtrl* d_bb_ctrl = nullptr; size_t bb_cap_nb = 0;
     double* d_bb_stats_part = nullptr; double* d_bb_stats = nullptr; double* d_bb_cdf = nullptr; size_t bb_cdf_cap = 0;
+    void* d_bb_cols = nullptr; double* d_bb_cols_part = nullptr; double* d_bb_cols_stat = nullptr; size_t bb_cols_bytes = 0, bb_cols_part = 0, bb_cols_stat = 0;   // several columns at once
     int32_t* d_bb_first = nullptr; size_t bb_first_cap = 0;
 
     // cpprob_hip_smc_bookkeep_fixed: two alternating copies of a mass hierarchy + the integer weights
@@ -760,7 +761,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     dfree(c->d_ctrl); dfree(c->d_local_totals);
     dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent); dfree(c->d_origin); dfree(c->d_remote); dfree(c->d_annex_all);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
-    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q);
+    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_cols); dfree(c->d_bb_cols_part); dfree(c->d_bb_cols_stat); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1946,7 +1947,74 @@ static int column_stats(cpprob_hip_ctx* c, const typename Col::value_t* d_x, con
     h_lse_ess[0] = h.M + std::log(h.W); h_lse_ess[1] = h.ess;
     return 0;
 }
+// The same for `n_cols` columns against ONE log-weight array: one normalisation, the columns as the rows of a T = n_cols "trace" (the
+// read-out kernel with identity ancestors), one finalize, one copy -- five launches and one synchronisation, whatever the number of
+// predict hits (the per-column form costs six launches and a synchronisation each: 0.75 ms for the 16 hits of hmm<16>).
+template <class Col>
+static int columns_stats(cpprob_hip_ctx* c, const typename Col::value_t* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, double* h_raw /*[n_cols][kStats]*/,
+                         double* h_lse_ess)
+{
+    using V = typename Col::value_t;
+    constexpr size_t kChunk = 64;                                  // columns per launch: LDS of the read-out = 4 waves x columns x kStats doubles
+    if (int rc = bb_normalise(c, d_logw, n, (double)n)) return rc;
+    const int nb = (int)((n + kTile - 1) / kTile);
+    const int64_t ld = (int64_t)nb * kTile;
+    const int grid = std::min(nb, 2048);
+    const size_t chunk = std::min(n_cols, kChunk);
+    const size_t col_bytes = chunk * (size_t)ld * sizeof(V), part_doubles = chunk * Col::kStats * (size_t)grid, stat_doubles = chunk * Col::kStats;
+    if (col_bytes > c->bb_cols_bytes) { dfree(c->d_bb_cols); HIP_TRY(c, hipMalloc(&c->d_bb_cols, col_bytes)); c->bb_cols_bytes = col_bytes; }
+    if (part_doubles > c->bb_cols_part) { dfree(c->d_bb_cols_part); HIP_TRY(c, hipMalloc(&c->d_bb_cols_part, part_doubles * sizeof(double))); c->bb_cols_part = part_doubles; }
+    if (stat_doubles > c->bb_cols_stat) { dfree(c->d_bb_cols_stat); HIP_TRY(c, hipMalloc(&c->d_bb_cols_stat, stat_doubles * sizeof(double))); c->bb_cols_stat = stat_doubles; }
+    for (size_t k0 = 0; k0 < n_cols; k0 += chunk) {
+        const size_t nk = std::min(chunk, n_cols - k0);
+        V* cols = static_cast<V*>(c->d_bb_cols);
+        hipLaunchKernelGGL(pad_copy_cols_kernel<V>, dim3((unsigned)((ld + 255) / 256), (unsigned)nk), dim3(256), 0, c->stream, d_x + k0 * col_stride, (int64_t)n, (int64_t)col_stride, ld, cols);
+        SmoothArgs<Col> a{};
+        a.values = cols; a.anc = nullptr; a.wrel = c->d_bb_wrel; a.bf = c->d_bb_bf; a.ctrl = c->d_bb_ctrl; a.resampled = nullptr; a.T = (int)nk; a.n = (int64_t)n; a.ld = ld; a.rs = ld;
+        a.identity = 1; a.stats_part = c->d_bb_cols_part; a.paths = nullptr;
+        hipLaunchKernelGGL(smooth_kernel<Col>, dim3(grid), dim3(kThreads), (size_t)kWaves * nk * Col::kStats * sizeof(double), c->stream, a);
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nk), dim3(kThreads), 0, c->stream, c->d_bb_cols_part, grid, (int)nk, Col::kStats, 1, c->d_bb_ctrl, c->d_bb_cols_stat, 1);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(h_raw + k0 * Col::kStats, c->d_bb_cols_stat, nk * Col::kStats * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (k0 + chunk < n_cols) HIP_TRY(c, hipStreamSynchronize(c->stream));     // (the scratch is reused by the next chunk)
+    }
+    StepCtrl h{};
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_bb_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    h_lse_ess[0] = h.M + std::log(h.W); h_lse_ess[1] = h.ess;
+    return 0;
+}
 extern "C" {
+
+int cpprob_hip_weighted_moments_columns(cpprob_hip_ctx* c, const double* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, double* h_out4)
+{
+    BB_PRELUDE(c);
+    if (!d_x || !d_logw || !h_out4) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (n == 0 || n_cols == 0 || col_stride < n) return fail(c, CPPROB_HIP_EINVAL, "empty distribution / columns closer than their length");
+    std::vector<double> raw(n_cols * 2);
+    double le[2];
+    if (int rc = columns_stats<ColumnReal>(c, d_x, n_cols, col_stride, d_logw, n, raw.data(), le)) return rc;
+    for (size_t k = 0; k < n_cols; ++k) {
+        h_out4[4 * k] = raw[2 * k];
+        h_out4[4 * k + 1] = raw[2 * k + 1] - raw[2 * k] * raw[2 * k];     // variance(mean) = raw_moment(2) - mean*mean  (:78-81)
+        h_out4[4 * k + 2] = le[0]; h_out4[4 * k + 3] = le[1];
+    }
+    return 0;
+}
+
+int cpprob_hip_weighted_hist_columns(cpprob_hip_ctx* c, const int32_t* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, int32_t k, double* h_out)
+{
+    BB_PRELUDE(c);
+    if (!d_x || !d_logw || !h_out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (k < 1 || k > 8) return fail(c, CPPROB_HIP_EINVAL, "need 1 <= k <= 8");
+    if (n == 0 || n_cols == 0 || col_stride < n) return fail(c, CPPROB_HIP_EINVAL, "empty distribution / columns closer than their length");
+    std::vector<double> raw(n_cols * 8);
+    double le[2];
+    if (int rc = columns_stats<ColumnInt8>(c, d_x, n_cols, col_stride, d_logw, n, raw.data(), le)) return rc;
+    for (size_t j = 0; j < n_cols; ++j)
+        for (int s2 = 0; s2 < k; ++s2) h_out[j * (size_t)k + s2] = raw[j * 8 + s2];
+    return 0;
+}
 
 int cpprob_hip_weighted_moments(cpprob_hip_ctx* c, const double* d_x, const double* d_logw, size_t n, double* h_out4)
 {

@@ -1958,6 +1958,15 @@ __global__ void pad_copy_kernel(const T* __restrict__ src, int64_t n, int64_t ld
     if (i < ld) dst[i] = i < n ? src[i] : T(0);
 }
 
+// The same for several columns at once: column k of src (k * src_stride) into row k of dst (k * ld).  grid = (ceil(ld / 256), columns).
+template <class T>
+__global__ void pad_copy_cols_kernel(const T* __restrict__ src, int64_t n, int64_t src_stride, int64_t ld, T* __restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t k = blockIdx.y;
+    if (i < ld) dst[k * ld + i] = i < n ? src[k * src_stride + i] : T(0);
+}
+
 // Weighted moments / histogram of one column against one log-weight array (EmpiricalDistribution
 // on device): the column is a 1-step "trace", so this is smooth_kernel with T = 1.
 struct ColumnReal { using value_t = double; using store_t = double; static constexpr int kStats = 2;

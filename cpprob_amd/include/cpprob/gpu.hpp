@@ -238,24 +238,27 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     if (!smc_log_z_done) log_z += o3[1] - std::log((double)n);       // SIS: evidence = mean weight
     res.n_particles = n; res.log_evidence = log_z; res.log_norm = o3[1]; res.ess = o3[2]; res.n_resampled = n_resampled; res.used_builtin = false;
     fill_predict_names(res, st);
-    res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();   // (the logsumexp above synchronised)
-    for (size_t k = 0, row = 0; k < st.real_ids.size(); ++k) {
-        PredictStats& p = res.predicts[k];
-        for (size_t d = 0; d < st.real_width[k]; ++d, ++row) {
-            double o4[4];
-            ctx.check(cpprob_hip_weighted_moments(ctx.get(), d_real.p + row * n, logw[cur], n, o4), "cpprob_hip_weighted_moments");
-            p.mean_nd.push_back(o4[0]); p.variance_nd.push_back(o4[1]);
+    // StatsPrinter's numbers of every predict hit: all columns of a kind in one device pass against the final weights
+    if (n_real) {
+        std::vector<double> o4(4 * n_real);
+        ctx.check(cpprob_hip_weighted_moments_columns(ctx.get(), d_real.p, n_real, n, logw[cur], n, o4.data()), "cpprob_hip_weighted_moments_columns");
+        for (size_t k = 0, row = 0; k < st.real_ids.size(); ++k) {
+            PredictStats& p = res.predicts[k];
+            for (size_t d = 0; d < st.real_width[k]; ++d, ++row) { p.mean_nd.push_back(o4[4 * row]); p.variance_nd.push_back(o4[4 * row + 1]); }
+            p.mean = p.mean_nd[0]; p.variance = p.variance_nd[0];
         }
-        p.mean = p.mean_nd[0]; p.variance = p.variance_nd[0];
     }
     const size_t n_real_hits = st.real_ids.size();
-    for (size_t k = 0; k < n_int; ++k) {
-        double h[8];
-        ctx.check(cpprob_hip_weighted_hist(ctx.get(), d_int.p + k * n, logw[cur], n, 8, h), "cpprob_hip_weighted_hist");
-        int top = 8;
-        while (top > 1 && h[top - 1] == 0.0) --top;
-        res.predicts[n_real_hits + k].probabilities.assign(h, h + top);
+    if (n_int) {
+        std::vector<double> h(8 * n_int);
+        ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int.p, n_int, n, logw[cur], n, 8, h.data()), "cpprob_hip_weighted_hist_columns");
+        for (size_t k = 0; k < n_int; ++k) {
+            int top = 8;
+            while (top > 1 && h[8 * k + top - 1] == 0.0) --top;
+            res.predicts[n_real_hits + k].probabilities.assign(h.begin() + 8 * k, h.begin() + 8 * k + top);
+        }
     }
+    res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();   // (everything StatsPrinter prints; the calls above synchronised)
     if (store) {
         store->n = n;
         store->logw.resize(n); store->real.resize(n_real * n); store->ints.resize(n_int * n);

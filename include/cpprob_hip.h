@@ -411,6 +411,10 @@ int cpprob_hip_logsumexp_ess(cpprob_hip_ctx* ctx, const double* d_logw, size_t n
 int cpprob_hip_weighted_moments(cpprob_hip_ctx* ctx, const double* d_x, const double* d_logw, size_t n, double* h_out4);
 /* h_out[s] = sum_i W_i [x_i == s], s < k <= 8  (distribution(), :30-40). */
 int cpprob_hip_weighted_hist(cpprob_hip_ctx* ctx, const int32_t* d_x, const double* d_logw, size_t n, int32_t k, double* h_out);
+/* ... and of n_cols columns (column j at d_x + j * col_stride, col_stride >= n) against ONE log-weight array: one normalisation, one
+ * read-out launch, one synchronisation for all of them.  h_out4: [n_cols][4] as cpprob_hip_weighted_moments; h_out: [n_cols][k]. */
+int cpprob_hip_weighted_moments_columns(cpprob_hip_ctx* ctx, const double* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, double* h_out4);
+int cpprob_hip_weighted_hist_columns(cpprob_hip_ctx* ctx, const int32_t* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, int32_t k, double* h_out);
 
 /* Resampling: d_anc[jj] = ancestor (index into d_logw[0..n_in)) of output j0 + jj, for n_out
  * consecutive outputs of a population of n_total_out positions.  Uniforms come from

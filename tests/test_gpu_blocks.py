@@ -404,3 +404,23 @@ def test_fastmath_exp_nonpos_edges_and_random_points(engine):
     den = ~normal
     assert np.all(np.abs(got[den].astype(np.longdouble) - ref[den]) <= np.longdouble(2.0) ** -1074)
     assert np.all(got >= 0) and np.all(got <= 1.0)
+
+
+@pytest.mark.parametrize("n,n_cols", [(1, 1), (1000, 3), (70001, 16), (4097, 130)])
+def test_weighted_columns_equal_the_per_column_calls(engine, n, n_cols):
+    """EmpiricalDistribution on the device for many predict hits at once (cpprob_hip_weighted_moments_columns / _hist_columns: one
+    normalisation, one read-out launch, one synchronisation): the same numbers, bit for bit, as one call per column, and the
+    oracle's (empirical_distribution.hpp:30-81) to rounding.  130 columns: more than one chunk of 64."""
+    rng = np.random.default_rng(n + n_cols)
+    logw = rng.normal(size=n) * 3.0 - 50.0
+    x = rng.normal(size=(n_cols, n)) * 2.0 + 1.0
+    xi = rng.integers(0, 5, size=(n_cols, n)).astype(np.int32)
+    got = engine.weighted_moments_columns(_t(x), _t(logw))
+    goth = engine.weighted_hist_columns(_t(xi), _t(logw), 5)
+    for k in range(n_cols):
+        one = engine.weighted_moments(_t(x[k]), _t(logw))
+        assert np.array_equal(got[k], np.array(one))
+        assert np.array_equal(goth[k], engine.weighted_hist(_t(xi[k]), _t(logw), 5))
+    ref = np.array([O.weighted_moments(x[k], logw) for k in range(min(n_cols, 4))])
+    np.testing.assert_allclose(got[:len(ref), :2], ref[:, :2], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(goth[0], O.weighted_hist(xi[0], logw, 5), rtol=1e-10, atol=1e-12)
