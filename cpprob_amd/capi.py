@@ -151,7 +151,7 @@ def load_library(path=None):
         "cpprob_hip_weighted_moments": (C.c_int, [vp, vp, vp, sz, C.POINTER(dbl)]),
         "cpprob_hip_weighted_hist": (C.c_int, [vp, vp, vp, sz, i32, C.POINTER(dbl)]),
         "cpprob_hip_weighted_moments_columns": (C.c_int, [vp, vp, sz, sz, vp, sz, C.POINTER(dbl)]),
-        "cpprob_hip_weighted_hist_columns": (C.c_int, [vp, vp, sz, sz, vp, sz, i32, C.POINTER(dbl)]),
+        "cpprob_hip_weighted_hist_columns": (C.c_int, [vp, vp, sz, sz, vp, sz, i32, C.POINTER(dbl), C.POINTER(dbl)]),
         "cpprob_hip_resample": (C.c_int, [vp, i32, vp, sz, u64, u64, u64, sz, u64, vp]),
         "cpprob_hip_smc_bookkeep": (C.c_int, [vp, i32, vp, sz, u64, i32, i32, dbl, vp, vp, vp, vp]),
         "cpprob_hip_smc_bookkeep_fixed": (C.c_int, [vp, vp, sz, u64, i32, i32, dbl, vp, vp, vp, vp]),
@@ -410,7 +410,7 @@ class Engine:
         """x: [n_cols, n] int32 device tensor -> array [n_cols, k] of P(x = s)."""
         n_cols, n = int(x.shape[0]), int(x.shape[1])
         out = (C.c_double * (k * n_cols))()
-        self._chk(self.L.cpprob_hip_weighted_hist_columns(self.h, _dptr(x), n_cols, n, _dptr(logw), n, k, out))
+        self._chk(self.L.cpprob_hip_weighted_hist_columns(self.h, _dptr(x), n_cols, n, _dptr(logw), n, k, out, None))
         return np.array(out[:]).reshape(n_cols, k)
 
     def resample(self, kind, logw, seed, step, anc_out, j0=0, n_total_out=None):

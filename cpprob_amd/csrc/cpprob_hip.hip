@@ -2002,7 +2002,8 @@ int cpprob_hip_weighted_moments_columns(cpprob_hip_ctx* c, const double* d_x, si
     return 0;
 }
 
-int cpprob_hip_weighted_hist_columns(cpprob_hip_ctx* c, const int32_t* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, int32_t k, double* h_out)
+int cpprob_hip_weighted_hist_columns(cpprob_hip_ctx* c, const int32_t* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, int32_t k, double* h_out,
+                                     double* h_lse_ess)
 {
     BB_PRELUDE(c);
     if (!d_x || !d_logw || !h_out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
@@ -2013,6 +2014,7 @@ int cpprob_hip_weighted_hist_columns(cpprob_hip_ctx* c, const int32_t* d_x, size
     if (int rc = columns_stats<ColumnInt8>(c, d_x, n_cols, col_stride, d_logw, n, raw.data(), le)) return rc;
     for (size_t j = 0; j < n_cols; ++j)
         for (int s2 = 0; s2 < k; ++s2) h_out[j * (size_t)k + s2] = raw[j * 8 + s2];
+    if (h_lse_ess) { h_lse_ess[0] = le[0]; h_lse_ess[1] = le[1]; }
     return 0;
 }
 

@@ -233,15 +233,14 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         for (int t = 0; t < T; ++t) n_resampled += h_res[(size_t)t];
         smc_log_z_done = true;
     }
-    double o3[3];
-    ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), logw[cur], n, o3), "cpprob_hip_logsumexp_ess");
-    if (!smc_log_z_done) log_z += o3[1] - std::log((double)n);       // SIS: evidence = mean weight
-    res.n_particles = n; res.log_evidence = log_z; res.log_norm = o3[1]; res.ess = o3[2]; res.n_resampled = n_resampled; res.used_builtin = false;
     fill_predict_names(res, st);
+    double lse_ess[2] = {0.0, 0.0};
+    bool have_norm = false;
     // StatsPrinter's numbers of every predict hit: all columns of a kind in one device pass against the final weights
     if (n_real) {
         std::vector<double> o4(4 * n_real);
         ctx.check(cpprob_hip_weighted_moments_columns(ctx.get(), d_real.p, n_real, n, logw[cur], n, o4.data()), "cpprob_hip_weighted_moments_columns");
+        lse_ess[0] = o4[2]; lse_ess[1] = o4[3]; have_norm = true;
         for (size_t k = 0, row = 0; k < st.real_ids.size(); ++k) {
             PredictStats& p = res.predicts[k];
             for (size_t d = 0; d < st.real_width[k]; ++d, ++row) { p.mean_nd.push_back(o4[4 * row]); p.variance_nd.push_back(o4[4 * row + 1]); }
@@ -251,13 +250,21 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     const size_t n_real_hits = st.real_ids.size();
     if (n_int) {
         std::vector<double> h(8 * n_int);
-        ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int.p, n_int, n, logw[cur], n, 8, h.data()), "cpprob_hip_weighted_hist_columns");
+        ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int.p, n_int, n, logw[cur], n, 8, h.data(), have_norm ? nullptr : lse_ess), "cpprob_hip_weighted_hist_columns");
+        have_norm = true;
         for (size_t k = 0; k < n_int; ++k) {
             int top = 8;
             while (top > 1 && h[8 * k + top - 1] == 0.0) --top;
             res.predicts[n_real_hits + k].probabilities.assign(h.begin() + 8 * k, h.begin() + 8 * k + top);
         }
     }
+    if (!have_norm) {                                                  // (a model without predicts: the weights' own pass)
+        double o3[3];
+        ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), logw[cur], n, o3), "cpprob_hip_logsumexp_ess");
+        lse_ess[0] = o3[1]; lse_ess[1] = o3[2];
+    }
+    if (!smc_log_z_done) log_z += lse_ess[0] - std::log((double)n);   // SIS: evidence = mean weight
+    res.n_particles = n; res.log_evidence = log_z; res.log_norm = lse_ess[0]; res.ess = lse_ess[1]; res.n_resampled = n_resampled; res.used_builtin = false;
     res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();   // (everything StatsPrinter prints; the calls above synchronised)
     if (store) {
         store->n = n;

@@ -414,7 +414,8 @@ int cpprob_hip_weighted_hist(cpprob_hip_ctx* ctx, const int32_t* d_x, const doub
 /* ... and of n_cols columns (column j at d_x + j * col_stride, col_stride >= n) against ONE log-weight array: one normalisation, one
  * read-out launch, one synchronisation for all of them.  h_out4: [n_cols][4] as cpprob_hip_weighted_moments; h_out: [n_cols][k]. */
 int cpprob_hip_weighted_moments_columns(cpprob_hip_ctx* ctx, const double* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, double* h_out4);
-int cpprob_hip_weighted_hist_columns(cpprob_hip_ctx* ctx, const int32_t* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, int32_t k, double* h_out);
+int cpprob_hip_weighted_hist_columns(cpprob_hip_ctx* ctx, const int32_t* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, int32_t k, double* h_out,
+                                     double* h_lse_ess /* may be NULL: {logsumexp of the weights, ESS} */);
 
 /* Resampling: d_anc[jj] = ancestor (index into d_logw[0..n_in)) of output j0 + jj, for n_out
  * consecutive outputs of a population of n_total_out positions.  Uniforms come from
