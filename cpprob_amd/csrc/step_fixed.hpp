@@ -531,8 +531,11 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
         for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
     }
     V prev[kPPT], x[kPPT];
+    if (t > 0 && !resample) load4_as(prev_row, j0, prev);                                    // every slot extends itself: one vector load
+    else {
 #pragma unroll
-    for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>(prev_row[anc[k]]) : V(0);                 // ancestor's state (sorted gather)
+        for (int k = 0; k < kPPT; ++k) prev[k] = t > 0 ? static_cast<V>(prev_row[anc[k]]) : V(0);             // ancestor's state (sorted gather)
+    }
 #pragma unroll
     for (int q = 0; q < kPPT / 4; ++q)                                                        // sample #t
         Model::apply4(a.mp, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
