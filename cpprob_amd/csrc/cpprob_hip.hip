@@ -125,6 +125,9 @@ struct cpprob_hip_ctx {
     uint32_t* d_q[2] = {nullptr, nullptr};                 // [ld] integer weights of the fixed-point form, ping-pong; the count form's trace words
     // trace words (trace_words.hpp): a single population's short discrete traces ride with the particles; the read-out streams them
     bool trace_mode = false; uint32_t* d_trace_cnt = nullptr; unsigned long long* d_trace_arrive = nullptr;
+    // ... and of one shard of a joint population (remote lineages): the words by the step's parity, [rs] each -- annex columns included,
+    // a migrant's word arrives with its state; trace_shard: every rank of the group has them
+    uint32_t* d_tr[2] = {nullptr, nullptr}; size_t tr_cap = 0; bool trace_shard = false, trace_shard_run = false;
     std::vector<double> h_bound;                           // [T] upper bound of each step's incremental log-weight (host-evaluated)
     int hk = 0; std::vector<double> hk_mean, hk_trans;     // cpprob_hip_set_hmm: the table of CPPROB_HIP_MODEL_HMM_TABLE
     uint64_t* d_hk_thr = nullptr; double* d_hk_ll = nullptr;
@@ -489,6 +492,7 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         for (int k = 0; k < 4; ++k) a.e_prev[k] = t > 0 ? c->h_e_tab[(size_t)(t - 1) * 4 + k] : 0.0;
         a.u0 = t > 0 ? host_resample_u0(c->run_seed, (uint64_t)t) : 0.0;
         if (c->trace_mode && !all_totals) { a.trace_prev = c->d_q[(t + 1) & 1]; a.trace_next = c->d_q[t & 1]; }
+        if (c->step_protocol && c->trace_shard_run) { a.trace_prev = c->d_tr[(t + 1) & 1]; a.trace_next = c->d_tr[t & 1]; }
         ProfScope ps(c, 0);
         if (all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
@@ -650,6 +654,17 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
         ProfScope ps(c, 2);
         bool launched = false;
         if constexpr (Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1) {
+            if (c->final_from_counts && c->sharded && c->trace_shard_run && !with_paths) {
+                // one shard of a joint population: the same counting over this shard's words, un-normalised (the ranks' sums meet in the
+                // run's final all-reduce); the final generation's bookkeeping came from the all-gathered totals
+                TraceReadoutArgs ta{};
+                ta.trace = c->d_tr[(c->T - 1) & 1]; ta.n = c->n; ta.T = c->T;
+                counts_final_view(c, ta.f, false);
+                ta.counters = c->d_trace_cnt; ta.arrive = c->d_trace_arrive; ta.stats = c->d_stats; ta.raw = 1; ta.n_local = (double)c->n;
+                const int grid = (int)std::min<int64_t>((c->n + kTile - 1) / kTile, 256);
+                hipLaunchKernelGGL(trace_readout_kernel, dim3(grid), dim3(kThreads), 0, c->stream, ta);
+                return;
+            }
             if (c->final_from_counts && c->trace_mode && !with_paths) {
                 // every particle carries its trace: one streaming pass, integer counts, statistics written by the last workgroup
                 TraceReadoutArgs ta{};
@@ -702,7 +717,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]); dfree(c->d_trace_cnt); dfree(c->d_trace_arrive);
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]); dfree(c->d_trace_cnt); dfree(c->d_trace_arrive); dfree(c->d_tr[0]); dfree(c->d_tr[1]);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
 }
 
@@ -1163,6 +1178,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     if (c->exchange && t > 0 && c->x_plan_t != t - 1)
         return fail(c, CPPROB_HIP_ESTATE, "exchange scope: the exchange of the previous step (plan / pack / commit) must run before the next step_begin");
     c->step_protocol = true; c->step_t = t; c->trace_mode = false;
+    if (t == 0 || sis) c->trace_shard_run = c->trace_shard && c->x_remote && c->counts_mode && c->keep && !c->x_peers.empty();
     c->totals_out = d_local_totals;
     if (c->counts_mode) {
         // prefix-count form: the step consumes the all-gathered counts of generation t-1 itself; what leaves is this shard's
@@ -1290,7 +1306,7 @@ int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
     g.annex_cap = fixed_layout ? c->annex_cap : (int64_t)1 << 40;      // (callers that synchronise grow the annex themselves)
     g.bytes_per_value = (int)(fixed_layout ? c->ssz : (c->is_int ? sizeof(int32_t) : sizeof(double))); g.sent_per_step = c->d_sent;
     g.no_history = c->keep ? 0 : 1; g.remote = (c->x_remote && c->keep && fixed_layout) ? 1 : 0;
-    if (g.remote) { g.rem = c->d_remote; g.annex_all = c->d_annex_all; g.slot_of_rank = nullptr; g.cap = (int64_t)1 << 40; }
+    if (g.remote) { g.rem = c->d_remote; g.annex_all = c->d_annex_all; g.slot_of_rank = nullptr; g.cap = (int64_t)1 << 40; g.trace_words = c->trace_shard_run ? 1 : 0; }
     PlanCountsIn pc{};
     pc.all_totals = c->x_all_totals; pc.n_pop = (double)c->pop_n;
     if (c->fixed_mode) {
@@ -1320,6 +1336,7 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid, bool plan_inside
     if (c->x_direct && c->x_fixed) { a.peer_recv = c->d_peer_recv; a.peer_slot = c->d_peer_slot; a.cap = c->x_cap; }
     a.geom.no_history = c->keep ? 0 : 1; a.geom.remote = (c->x_remote && c->keep && c->x_fixed) ? 1 : 0;
     if (a.geom.remote) { a.geom.rem = c->d_remote; a.geom.annex_all = c->d_annex_all; a.peer_recv = nullptr; }
+    if (a.geom.remote && c->trace_shard_run) { a.trace_cur = c->d_tr[t & 1]; a.trace_par = t & 1; a.geom.trace_words = 1; }
     if (plan_inside) {
         a.geom.world = c->x_world; a.geom.rank = c->x_rank; a.geom.n = c->n; a.geom.shard_begin = c->d_shard_begin; a.geom.slot_of_rank = c->d_slot_of_rank;
         a.geom.cap = c->x_cap; a.geom.annex_cap = c->annex_cap; a.geom.bytes_per_value = (int)c->ssz; a.geom.sent_per_step = c->d_sent;
@@ -1478,7 +1495,7 @@ int cpprob_hip_exchange_setup(cpprob_hip_ctx* c, int32_t world, int32_t rank, co
         c->x_buf_bytes = need;
     }
     c->x_world = world; c->x_rank = rank;
-    c->x_direct = false; c->x_remote = false;              // (the peers' buffers may have moved: cpprob_hip_exchange_direct / _remote again)
+    c->x_direct = false; c->x_remote = false; c->trace_shard = false;   // (the peers' buffers may have moved: cpprob_hip_exchange_direct / _remote again)
     if (c->T > c->sent_cap) { dfree(c->d_sent); HIP_TRY(c, hipMalloc(&c->d_sent, (size_t)c->T * sizeof(int64_t))); c->sent_cap = c->T; }
     HIP_TRY(c, hipMemset(c->d_sent, 0, (size_t)c->sent_cap * sizeof(int64_t)));
     return 0;
@@ -1519,6 +1536,28 @@ int cpprob_hip_exchange_store(cpprob_hip_ctx* c, cpprob_hip_store* out)
         c->origin_cap = c->annex_cap;
     }
     out->d_values = c->d_values; out->d_ancestors = c->d_anc; out->d_origin = c->d_origin; out->row_stride = (uint64_t)c->rs; out->n_local_columns = (uint64_t)c->ld;
+    // short discrete traces on the count form: the particles carry their traces across ranks too (trace_words.hpp)
+    out->d_trace[0] = nullptr; out->d_trace[1] = nullptr;
+    bool words = false;
+    dispatch_model(c, [&](auto m) { words = counts_eligible<decltype(m)>(c); });
+    words = words && c->cfg.model == CPPROB_HIP_MODEL_HMM3 && c->T <= kTraceMaxT && !(c->cfg.flags & CPPROB_HIP_FLAG_WALK_READOUT);
+    if (words) {
+        if ((size_t)c->rs > c->tr_cap) {
+            dfree(c->d_tr[0]); dfree(c->d_tr[1]);
+            HIP_TRY(c, hipMalloc(&c->d_tr[0], (size_t)c->rs * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_tr[1], (size_t)c->rs * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(c->d_tr[0], 0, (size_t)c->rs * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(c->d_tr[1], 0, (size_t)c->rs * sizeof(uint32_t)));
+            c->tr_cap = (size_t)c->rs;
+        }
+        out->d_trace[0] = c->d_tr[0]; out->d_trace[1] = c->d_tr[1];
+        if (!c->d_trace_cnt) {
+            HIP_TRY(c, hipMalloc(&c->d_trace_cnt, kTraceCounterWords * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_trace_arrive, sizeof(unsigned long long)));
+            HIP_TRY(c, hipMemset(c->d_trace_cnt, 0, kTraceCounterWords * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemset(c->d_trace_arrive, 0, sizeof(unsigned long long)));
+        }
+    }
     return 0;
 }
 
@@ -1526,7 +1565,7 @@ int cpprob_hip_exchange_remote(cpprob_hip_ctx* c, const cpprob_hip_store* h_stor
 {
     if (!c) return fail(nullptr, CPPROB_HIP_EINVAL, "ctx is NULL");
     if (!c->x_fixed || !c->x_direct) return fail(c, CPPROB_HIP_ESTATE, "remote lineages ride the direct transport: cpprob_hip_exchange_setup and _direct first");
-    if (!h_stores) { c->x_remote = false; return 0; }
+    if (!h_stores) { c->x_remote = false; c->trace_shard = false; return 0; }
     if (!c->keep) return 0;                                 // (a filtering-only shard has no lineages to leave anywhere)
     HIP_TRY(c, hipSetDevice(c->device));
     RemoteStores rs{};
@@ -1536,6 +1575,11 @@ int cpprob_hip_exchange_remote(cpprob_hip_ctx* c, const cpprob_hip_store* h_stor
         rs.values[r] = h_stores[r].d_values; rs.anc[r] = static_cast<const int32_t*>(h_stores[r].d_ancestors); rs.origin[r] = static_cast<const int64_t*>(h_stores[r].d_origin);
         rs.rs[r] = (int64_t)h_stores[r].row_stride; rs.ld[r] = (int64_t)h_stores[r].n_local_columns;
     }
+    bool words = true;
+    for (int r = 0; r < c->x_world; ++r) words = words && h_stores[r].d_trace[0] && h_stores[r].d_trace[1];
+    for (int r = 0; r < c->x_world; ++r)
+        for (int k = 0; k < 2; ++k) rs.trace[k][r] = words ? static_cast<uint32_t*>(const_cast<void*>(h_stores[r].d_trace[k])) : nullptr;
+    c->trace_shard = words && c->d_tr[0] != nullptr;
     if (!c->d_remote) HIP_TRY(c, hipMalloc(&c->d_remote, sizeof(RemoteStores)));
     if (c->T + 1 > c->annex_all_T || !c->d_annex_all) {
         dfree(c->d_annex_all);

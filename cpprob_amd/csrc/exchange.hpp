@@ -55,6 +55,7 @@ struct ExchangeGeom {
                                       // kernel stores both straight into the receiving rank's annex column and origin table: every rank
                                       // keeps every rank's annex fill (a function of the all-gathered totals), so no receive buffer, no
                                       // segment capacity, no peer list and no commit launch
+    int trace_words;                  // (remote) a migrant also takes its 4-byte trace word along (trace_words.hpp)
     const RemoteStores* rem;          // (remote) every rank's store as this device addresses it
     int64_t* annex_all;               // (remote) [T + 1][kWorldSlots] device: annex columns in use on every rank before each step's exchange
     int64_t* sent_per_step;           // [T] device, may be nullptr: records this rank sent after each step
@@ -170,7 +171,7 @@ __device__ __forceinline__ void plan_store(const ExchangeGeom& g, int t, const P
         annex_base[t + 1] = g.no_history ? 0 : base + (over_annex ? 0 : pw.n_recv);
         const int64_t rec0 = t == 0 ? 0 : plan->run_records, byt0 = t == 0 ? 0 : plan->run_bytes;
         plan->run_records = rec0 + pw.n_send;
-        plan->run_bytes = byt0 + pw.n_send * (g.remote ? (int64_t)g.bytes_per_value + 8 : (int64_t)(g.no_history ? 1 : t + 1) * (int64_t)g.bytes_per_value);
+        plan->run_bytes = byt0 + pw.n_send * (g.remote ? (int64_t)g.bytes_per_value + 8 + (g.trace_words ? 4 : 0) : (int64_t)(g.no_history ? 1 : t + 1) * (int64_t)g.bytes_per_value);
         if (g.sent_per_step) g.sent_per_step[t] = pw.n_send;
     }
 }
@@ -268,6 +269,7 @@ struct PackArgs {
     // floating-point form
     const double* wrel; const double* bc; const double* bf; const StepCtrl* ctrl; uint64_t seed;
     uint64_t pid0;
+    const uint32_t* trace_cur; int trace_par;                    // remote lineages with trace words: this rank's words of generation t, and t's parity
 };
 
 enum { kPackFloat = 0, kPackCounts = 1, kPackFixed = 2 };
@@ -342,10 +344,12 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                      : a.peer_recv ? static_cast<R*>(a.peer_recv[r]) + (int64_t)a.peer_slot[r] * a.cap * (int64_t)len
                                    : a.send + (PLAN_INSIDE ? s_send_base[r] : a.plan->send_base[r]) * (int64_t)len;
         S* annex_row = nullptr; int64_t* origin = nullptr; int64_t col0 = 0, room = 0;
+        uint32_t* annex_trace = nullptr;
         if (remote) {
             const RemoteStores* __restrict__ rem = a.geom.rem;
             annex_row = static_cast<S*>(const_cast<void*>(rem->values[r])) + (int64_t)a.t * rem->rs[r] + rem->ld[r];
             origin = const_cast<int64_t*>(rem->origin[r]);
+            if (a.trace_cur) annex_trace = rem->trace[a.trace_par][r] + rem->ld[r];
             col0 = PLAN_INSIDE ? s_dst_col[r] : a.plan->dst_col[r]; room = rem->rs[r] - rem->ld[r];
         }
         for (int64_t tl = blockIdx.x; tl * kTile < cnt; tl += gridDim.x) {
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                             if (col < room) {                    // (an annex too small is flagged by its owner and the run repeated)
                                 __builtin_nontemporal_store(vrow[idx[k]], annex_row + col);
                                 __builtin_nontemporal_store(((int64_t)a.rank << 32) | (int64_t)idx[k], origin + col);
+                                if (annex_trace) annex_trace[col] = a.trace_cur[idx[k]];          // the migrant's whole trace so far
                             }
                         } else __builtin_nontemporal_store(static_cast<R>(vrow[idx[k]]), rec[k]);
                     }

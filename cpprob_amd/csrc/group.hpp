@@ -516,7 +516,7 @@ int setup_remote(cpprob_hip_group* g)
     }
     cpprob_hip_ctx* c = g->ctx[0];
     HIP_TRY(c, hipSetDevice(c->device));
-    struct Rec { hipIpcMemHandle_t hv, ha, ho; uint64_t rs, ld; int32_t ok, pad; };
+    struct Rec { hipIpcMemHandle_t hv, ha, ho, ht0, ht1; uint64_t rs, ld; int32_t ok, words; };
     Rec mine{};
     cpprob_hip_store own{};
     mine.ok = cpprob_hip_exchange_store(c, &own) == 0 ? 1 : 0;
@@ -525,16 +525,20 @@ int setup_remote(cpprob_hip_group* g)
                   hipIpcGetMemHandle(&mine.ho, const_cast<void*>(own.d_origin)) == hipSuccess ? 1 : 0;
         (void)hipGetLastError();
         mine.rs = own.row_stride; mine.ld = own.n_local_columns;
+        // (trace words are optional: every rank or none -- a rank that cannot export them switches them off for the group)
+        mine.words = (own.d_trace[0] && own.d_trace[1] && hipIpcGetMemHandle(&mine.ht0, const_cast<void*>(own.d_trace[0])) == hipSuccess &&
+                      hipIpcGetMemHandle(&mine.ht1, const_cast<void*>(own.d_trace[1])) == hipSuccess) ? 1 : 0;
+        (void)hipGetLastError();
     }
     std::vector<Rec> all((size_t)world);
     if (int rc = coll_allgather_host(g, 0, &mine, all.data(), sizeof(Rec))) return rc;
-    bool ok = true;
-    for (int r = 0; r < world; ++r) ok = ok && all[(size_t)r].ok;
+    bool ok = true, words = true;
+    for (int r = 0; r < world; ++r) { ok = ok && all[(size_t)r].ok; words = words && all[(size_t)r].words; }
     int32_t opened = 1;
     const size_t n_before = g->ipc_open.size();
     if (ok) {
         for (int r = 0; r < world && opened; ++r) {
-            if (r == g->first_rank) { st[(size_t)r] = own; continue; }
+            if (r == g->first_rank) { st[(size_t)r] = own; if (!words) { st[(size_t)r].d_trace[0] = nullptr; st[(size_t)r].d_trace[1] = nullptr; } continue; }
             void* pv = nullptr; void* pa = nullptr; void* po = nullptr;
             if (hipIpcOpenMemHandle(&pv, all[(size_t)r].hv, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { opened = 0; break; }
             g->ipc_open.push_back(pv);
@@ -544,6 +548,15 @@ int setup_remote(cpprob_hip_group* g)
             g->ipc_open.push_back(po);
             st[(size_t)r].d_values = pv; st[(size_t)r].d_ancestors = pa; st[(size_t)r].d_origin = po;
             st[(size_t)r].row_stride = all[(size_t)r].rs; st[(size_t)r].n_local_columns = all[(size_t)r].ld;
+            st[(size_t)r].d_trace[0] = nullptr; st[(size_t)r].d_trace[1] = nullptr;
+            if (words) {
+                void* p0 = nullptr; void* p1 = nullptr;
+                if (hipIpcOpenMemHandle(&p0, all[(size_t)r].ht0, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { opened = 0; break; }
+                g->ipc_open.push_back(p0);
+                if (hipIpcOpenMemHandle(&p1, all[(size_t)r].ht1, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { opened = 0; break; }
+                g->ipc_open.push_back(p1);
+                st[(size_t)r].d_trace[0] = p0; st[(size_t)r].d_trace[1] = p1;
+            }
         }
         (void)hipGetLastError();
     }

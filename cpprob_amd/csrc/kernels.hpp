@@ -1562,6 +1562,7 @@ struct RemoteStores {
     const void* values[64]; const int32_t* anc[64]; const int64_t* origin[64];
     int64_t rs[64], ld[64];
     int world, rank;
+    uint32_t* trace[2][64];              // trace words of every rank by the step's parity (trace_words.hpp), nullptr where not in use
 };
 
 // weight_of(tile, i) = the final weight of slot i (zero for padding slots), in the units finalize_kernel divides by.

@@ -383,7 +383,7 @@ struct StepCountsArgs {
     const int64_t* src_shift;                                   // exchange scope: tiles by which this shard's outputs sit off its sources (the previous exchange's plan)
     int row_w, row_r;                                           // rows of values[] this step writes / reads (t, t - 1; a filtering-only run: its two rows in turn)
     double* filter_stats;                                       // filtering-only run: [T][3], generation t-1's P(x = s) from its totals (nullptr otherwise)
-    const uint32_t* trace_prev; uint32_t* trace_next;           // trace words (trace_words.hpp) of generations t-1 / t, or nullptr: a single population's short traces
+    const uint32_t* trace_prev; uint32_t* trace_next;           // trace words (trace_words.hpp) of generations t-1 / t, or nullptr: short discrete traces (shards: [rs], annex included)
 };
 
 // This tile's entry of generation t's hierarchy, added into the levels above (see the header of this file), and the entries of
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     // the source tile this output tile is expected to start in: its own index, moved by the shard's offset in a sharded run
     int guess = bid;
     if (SHARDED && t > 0 && a.src_shift) { const int64_t g2 = (int64_t)bid + *a.src_shift; guess = (int)(g2 < 0 ? 0 : (g2 >= nb ? nb - 1 : g2)); }
-    const bool traced = !SHARDED && a.trace_next != nullptr;                                  // (kernel-uniform; trace_words.hpp)
+    const bool traced = a.trace_next != nullptr;                                              // (kernel-uniform; trace_words.hpp)
     if (t > 0) {
         const int64_t g0 = (int64_t)guess * kTile + (int64_t)tid * kPPT;
         raw_0 = *reinterpret_cast<const uint32_t*>(prev_row + g0);

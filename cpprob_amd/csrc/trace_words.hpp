@@ -32,6 +32,8 @@ struct TraceReadoutArgs {
     uint32_t* counters;                          // [kTraceSlots][kTraceMaxT * kTraceKeys] lines, zero between two launches
     unsigned long long* arrive;                  // zero between two launches
     double* stats;                               // [T][3]
+    int raw; double n_local;                     // one shard of a joint population: un-normalised sums over THIS shard's n_local particles (the ranks'
+                                                 // sums are all-reduced and divided by the joint normaliser: group.hpp), no bookkeeping here
 };
 
 __global__ __launch_bounds__(kThreads) void trace_readout_kernel(TraceReadoutArgs a)
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(kThreads) void trace_readout_kernel(TraceReadoutArg
     __shared__ unsigned long long s_n[kTraceMaxT * kTraceKeys];  // (last workgroup) the population's counts
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    if (a.f.bookkeep && blockIdx.x == 0 && wv == 0) {
+    if (a.f.bookkeep && !a.raw && blockIdx.x == 0 && wv == 0) {
         const Cnt2 tl = hier_total(a.f.h);
         if (tid == 0) counts_final_bookkeep(a.f, (double)tl.n0, (double)tl.n1);
     }
@@ -116,13 +118,14 @@ __global__ __launch_bounds__(kThreads) void trace_readout_kernel(TraceReadoutArg
         const double e0 = a.f.e[0], e1 = a.f.e[1], e2 = a.f.e[2];
         // the class sizes -- x_{T-1} = c pairs with itself -- and the normaliser as counts_final_bookkeep takes it
         const unsigned long long* last = s_n + (a.T - 1) * kTraceKeys;
-        const double N1 = (double)last[1], N2 = (double)last[5], N0 = a.f.n_pop - N1 - N2;
+        const double N1 = (double)last[1], N2 = (double)last[5], N0 = (a.raw ? a.n_local : a.f.n_pop) - N1 - N2;
         const double W = fma(N2, e2, fma(N1, e1, __dmul_rn(N0, e0)));
         const unsigned long long* row = s_n + t * kTraceKeys;
         double n0, n1, n2;                                        // particles of class 0 / 1 / 2 whose trace held s at t
         if (s == 0) { n0 = N0 - (double)(row[0] + row[3]); n1 = N1 - (double)(row[1] + row[4]); n2 = N2 - (double)(row[2] + row[5]); }
         else { n0 = (double)row[3 * (s - 1)]; n1 = (double)row[3 * (s - 1) + 1]; n2 = (double)row[3 * (s - 1) + 2]; }
-        a.stats[t * 3 + s] = fma(n2, e2, fma(n1, e1, __dmul_rn(n0, e0))) / W;
+        const double num = fma(n2, e2, fma(n1, e1, __dmul_rn(n0, e0)));
+        a.stats[t * 3 + s] = a.raw ? num : num / W;
     }
 }
 

@@ -273,7 +273,8 @@ int cpprob_hip_exchange_transport(cpprob_hip_ctx* ctx, void** d_send, void** d_r
  *   traffic    after the run (synchronises): lineage records this rank sent after each step (h_sent_per_step[n_predict], may be NULL),
  *              their total and their bytes -- records x (t + 1) x bytes_per_value: what the direct transport puts on the links. */
 /*   remote     (optional, after direct) REMOTE LINEAGES: with every rank's particle store addressable from this device, a migrating
- *              particle takes only its current state and the slot it leaves along -- value + 8 bytes per record -- and pack_async
+ *              particle takes only its current state and the slot it leaves along -- value + 8 bytes per record (+ 4 where the particles carry
+ *              trace words: short discrete traces) -- and pack_async
  *              stores both straight into the RECEIVING rank's annex column and origin table: every rank keeps every rank's annex
  *              fill (a function of the all-gathered totals), so there is no receive buffer, no segment capacity, no peer set and
  *              commit_async launches nothing (what remains of the overflow bits is 4: an annex too small).  The particle's history
@@ -286,6 +287,8 @@ int cpprob_hip_exchange_transport(cpprob_hip_ctx* ctx, void** d_send, void** d_r
 typedef struct cpprob_hip_store {
     const void* d_values; const void* d_ancestors; const void* d_origin;     /* [T][row_stride] values, [T][row_stride] int32, [annex] int64 */
     uint64_t row_stride, n_local_columns;
+    const void* d_trace[2];    /* short discrete traces (hmm<T <= 16>): the particles' trace words, [row_stride] uint32 each, by the step's
+                                  parity -- a migrant's word is stored into the receiving rank's with its state; NULL where not in use */
 } cpprob_hip_store;
 int cpprob_hip_exchange_store(cpprob_hip_ctx* ctx, cpprob_hip_store* out);
 int cpprob_hip_exchange_remote(cpprob_hip_ctx* ctx, const cpprob_hip_store* h_stores);
