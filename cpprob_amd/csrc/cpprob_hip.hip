@@ -1158,6 +1158,8 @@ int settle_fixed(cpprob_hip_ctx* c)
 }  // namespace
 extern "C" {
 
+static int ensure_shard_trace(cpprob_hip_ctx* c, bool& words);
+
 int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, double* d_local_totals)
 {
     if (!c || !d_local_totals) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
@@ -1178,7 +1180,15 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     if (c->exchange && t > 0 && c->x_plan_t != t - 1)
         return fail(c, CPPROB_HIP_ESTATE, "exchange scope: the exchange of the previous step (plan / pack / commit) must run before the next step_begin");
     c->step_protocol = true; c->step_t = t; c->trace_mode = false;
-    if (t == 0 || sis) c->trace_shard_run = c->trace_shard && c->x_remote && c->counts_mode && c->keep && !c->x_peers.empty();
+    if (t == 0 || sis) {
+        c->trace_shard_run = c->trace_shard && c->x_remote && c->counts_mode && c->keep && !c->x_peers.empty();
+        if (c->exchange && c->x_fixed && c->x_peers.empty() && c->counts_mode && c->keep) {
+            // (a shard with nobody to exchange with -- a group of one -- needs nobody's consent)
+            bool words = false;
+            if (int rc = ensure_shard_trace(c, words)) return rc;
+            c->trace_shard_run = words;
+        }
+    }
     c->totals_out = d_local_totals;
     if (c->counts_mode) {
         // prefix-count form: the step consumes the all-gathered counts of generation t-1 itself; what leaves is this shard's
@@ -1525,6 +1535,31 @@ int cpprob_hip_exchange_direct(cpprob_hip_ctx* c, void* const* h_peer_recv)
     return 0;
 }
 
+// trace words of an exchange-scope shard (hmm<T <= 16> on the count form): the two word arrays over local + annex columns and the
+// read-out's counters; `words` = this shard can carry them
+static int ensure_shard_trace(cpprob_hip_ctx* c, bool& words)
+{
+    words = false;
+    dispatch_model(c, [&](auto m) { words = counts_eligible<decltype(m)>(c); });
+    words = words && c->keep && c->cfg.model == CPPROB_HIP_MODEL_HMM3 && c->T <= kTraceMaxT && !(c->cfg.flags & CPPROB_HIP_FLAG_WALK_READOUT);
+    if (!words) return 0;
+    if ((size_t)c->rs > c->tr_cap) {
+        dfree(c->d_tr[0]); dfree(c->d_tr[1]);
+        HIP_TRY(c, hipMalloc(&c->d_tr[0], (size_t)c->rs * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_tr[1], (size_t)c->rs * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->d_tr[0], 0, (size_t)c->rs * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->d_tr[1], 0, (size_t)c->rs * sizeof(uint32_t)));
+        c->tr_cap = (size_t)c->rs;
+    }
+    if (!c->d_trace_cnt) {
+        HIP_TRY(c, hipMalloc(&c->d_trace_cnt, kTraceCounterWords * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_trace_arrive, sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->d_trace_cnt, 0, kTraceCounterWords * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->d_trace_arrive, 0, sizeof(unsigned long long)));
+    }
+    return 0;
+}
+
 int cpprob_hip_exchange_store(cpprob_hip_ctx* c, cpprob_hip_store* out)
 {
     if (!c || !out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
@@ -1539,25 +1574,8 @@ int cpprob_hip_exchange_store(cpprob_hip_ctx* c, cpprob_hip_store* out)
     // short discrete traces on the count form: the particles carry their traces across ranks too (trace_words.hpp)
     out->d_trace[0] = nullptr; out->d_trace[1] = nullptr;
     bool words = false;
-    dispatch_model(c, [&](auto m) { words = counts_eligible<decltype(m)>(c); });
-    words = words && c->cfg.model == CPPROB_HIP_MODEL_HMM3 && c->T <= kTraceMaxT && !(c->cfg.flags & CPPROB_HIP_FLAG_WALK_READOUT);
-    if (words) {
-        if ((size_t)c->rs > c->tr_cap) {
-            dfree(c->d_tr[0]); dfree(c->d_tr[1]);
-            HIP_TRY(c, hipMalloc(&c->d_tr[0], (size_t)c->rs * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc(&c->d_tr[1], (size_t)c->rs * sizeof(uint32_t)));
-            HIP_TRY(c, hipMemset(c->d_tr[0], 0, (size_t)c->rs * sizeof(uint32_t)));
-            HIP_TRY(c, hipMemset(c->d_tr[1], 0, (size_t)c->rs * sizeof(uint32_t)));
-            c->tr_cap = (size_t)c->rs;
-        }
-        out->d_trace[0] = c->d_tr[0]; out->d_trace[1] = c->d_tr[1];
-        if (!c->d_trace_cnt) {
-            HIP_TRY(c, hipMalloc(&c->d_trace_cnt, kTraceCounterWords * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc(&c->d_trace_arrive, sizeof(unsigned long long)));
-            HIP_TRY(c, hipMemset(c->d_trace_cnt, 0, kTraceCounterWords * sizeof(uint32_t)));
-            HIP_TRY(c, hipMemset(c->d_trace_arrive, 0, sizeof(unsigned long long)));
-        }
-    }
+    if (int rc = ensure_shard_trace(c, words)) return rc;
+    if (words) { out->d_trace[0] = c->d_tr[0]; out->d_trace[1] = c->d_tr[1]; }
     return 0;
 }
 

@@ -8,7 +8,10 @@
 // exchange_plan_kernel   o_r -> per-peer send / receive intervals, offsets into the transport buffers, annex bookkeeping, overflow flag
 // exchange_pack_kernel   ancestors of the outputs this shard's sources own elsewhere (the step kernels' own search) + their lineages
 // exchange_commit_kernel received lineages -> annex columns of the particle store (identity ancestors): later kernels see ordinary particles
-// Transport buffers hold one fixed-capacity segment per peer slot (sizes are host constants: RCCL send/recv counts cannot depend on
+// With remote lineages (the default where every rank can address every rank's store: ExchangeGeom::remote) a migrant is its current
+// state, an (origin rank, slot) word and -- short discrete traces -- its trace word, stored by the packing kernel straight into the
+// RECEIVING rank's annex: no transport buffer, no commit launch, and the lineage is followed across ranks only when somebody reads it.
+// Otherwise: transport buffers hold one fixed-capacity segment per peer slot (sizes are host constants: RCCL send/recv counts cannot depend on
 // device data), or -- for callers that synchronise and size their buffers exactly -- one compact block per rank (cpprob_hip_exchange_*).
 // A step that does not resample, or whose shards' masses happen to match, plans zero records; its transfers carry stale bytes nobody reads.
 #pragma once
