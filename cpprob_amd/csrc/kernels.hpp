@@ -1648,16 +1648,22 @@ __device__ __forceinline__ void smooth_body_remote(const SmoothArgs<Model>& a, d
 #pragma unroll
             for (int k = 0; k < kPPT; ++k) {
                 const int r = rk[k];
-                const int64_t at = (int64_t)t * rem->rs[r] + idx[k];
-                const V x = static_cast<V>(static_cast<const S*>(rem->values[r])[at]);
+                // (nearly every hop stays on this rank -- O(sqrt N) lineages ever cross: its store comes from the launch's own arguments,
+                //  not through the table of the ranks' stores, which would put a second dependent load on every hop)
+                const bool here = r == me;
+                const int64_t rs_r = here ? a.rs : rem->rs[r], ld_r = here ? a.ld : rem->ld[r];
+                const S* vals = here ? a.values : static_cast<const S*>(rem->values[r]);
+                const int32_t* ancs = here ? a.anc : rem->anc[r];
+                const int64_t at = (int64_t)t * rs_r + idx[k];
+                const V x = static_cast<V>(vals[at]);
                 Model::accumulate(x, w[k], acc);
                 if (a.paths) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)k * kThreads + tid] = x;
                 if (hop) {
                     // (a run whose transport overflowed is repeated, but its read-out still runs: whatever the tables hold then, the
                     //  walk stays inside the stores)
-                    const int64_t p = min(max((int64_t)rem->anc[r][at], (int64_t)0), rem->rs[r] - 1);
-                    if (p >= rem->ld[r]) {                                // an immigrant of that rank: its history sits where it came from
-                        const int64_t o = rem->origin[r][p - rem->ld[r]];
+                    const int64_t p = min(max((int64_t)ancs[at], (int64_t)0), rs_r - 1);
+                    if (p >= ld_r) {                                      // an immigrant of that rank: its history sits where it came from
+                        const int64_t o = rem->origin[r][p - ld_r];
                         const int ro = min(max((int)(o >> 32), 0), rem->world - 1);
                         rk[k] = ro; idx[k] = (int32_t)min((int64_t)(uint32_t)o, rem->rs[ro] - 1);
                     } else idx[k] = (int32_t)p;
