@@ -307,13 +307,16 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
     } else {
         if (!a.plan->resample || a.plan->n_send == 0) return;   // workgroup-uniform
     }
-    // (the walk below is a chain of dependent gathers: nothing else may sit on it -- the per-step flags come out of LDS, not memory)
-    if (tid < 32) {
-        uint32_t w = 0;
-        for (int b = 0; b < 32; ++b) { const int s2 = tid * 32 + b; if (s2 < a.t && a.resampled[s2] != 0) w |= 1u << b; }
-        s_hop[tid] = w;
+    // (the walk below is a chain of dependent gathers: nothing else may sit on it -- the per-step flags come out of LDS, not memory;
+    //  a migrant that travels as its current state alone walks nothing)
+    if (!(a.geom.no_history != 0 || a.geom.remote != 0)) {
+        if (tid < 32) {
+            uint32_t w = 0;
+            for (int b = 0; b < 32; ++b) { const int s2 = tid * 32 + b; if (s2 < a.t && a.resampled[s2] != 0) w |= 1u << b; }
+            s_hop[tid] = w;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     TableCdf tc;
     FixedCdf fc;
     bool last_shard = a.rank + 1 == a.world;
