@@ -551,7 +551,6 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         a.prefetch = (!a.may_carry || c->nb <= 2048) ? 1 : 0;
         a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
         a.all_totals = reinterpret_cast<const uint64_t*>(all_totals); a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
-        a.src_shift = (c->exchange && c->x_fixed && !c->x_peers.empty() && c->d_xplan) ? &c->d_xplan->src_shift : nullptr;
         a.row_w = c->keep ? t : (t & 1); a.row_r = t > 0 ? (c->keep ? t - 1 : ((t - 1) & 1)) : 0;
         if (!c->keep) a.anc = nullptr;
         {

@@ -374,7 +374,6 @@ struct StepFixedArgs {
     StepCtrl* ctrl; double n_pop; double* ess_trace; int32_t* resampled;
     const uint64_t* all_totals; int world, rank;       // one shard of a joint population (exchange scope): every rank's {S, Q, key(M)} of generation t-1
     const int64_t* annex_base;
-    const int64_t* src_shift;                  // exchange scope: where the previous exchange's plan left the offset of this shard's outputs against its sources (tiles)
     int row_w, row_r;
 };
 
@@ -422,9 +421,11 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
     uint64_t rs_ = 0, rq_ = 0, rm_ = 0;
     double lw_carry[kPPT];
     lane_fill(lw_carry, 0.0);
-    // the source tile this output tile is expected to start in: its own index, moved by the shard's offset in a sharded run
-    int guess = bid;
-    if (SHARDED && t > 0 && a.src_shift) { const int64_t g2 = (int64_t)bid + *a.src_shift; guess = (int)(g2 < 0 ? 0 : (g2 >= nb ? nb - 1 : g2)); }
+    // the source tile this output tile is expected to start in: its own index
+    const int guess = bid;
+    // (the count form moves this guess by the offset the previous exchange's plan left -- a dependent load in front of the entry
+    //  fetches: here it costs more than the better aim returns: same-call A/B, eight loopback ranks, configs[3] 29.3 -> 28.1 ms,
+    //  configs[4] 150.6 -> 143.0; the second probe aims by the miss distance anyway)
     if (t > 0) {
         if (a.prefetch) {
             const int64_t g0 = (int64_t)guess * kTile + (int64_t)tid * kPPT;
