@@ -548,7 +548,7 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         a.u0 = t > 0 ? host_resample_u0(c->run_seed, (uint64_t)t) : 0.0;
         a.bound = c->h_bound[(size_t)t]; a.bound_prev = t > 0 ? c->h_bound[(size_t)t - 1] : 0.0;
         a.ess_frac = c->cfg.ess_threshold; a.may_carry = c->cfg.ess_threshold > 1.0 ? 0 : 1;
-        a.prefetch = (!a.may_carry || c->nb <= 2048) ? 1 : 0;
+        a.prefetch = a.may_carry ? 0 : 1;                        // (a schedule on which steps may not resample: the fetch is wasted on those, and costs registers on all)
         a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
         a.all_totals = reinterpret_cast<const uint64_t*>(all_totals); a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
         a.row_w = c->keep ? t : (t & 1); a.row_r = t > 0 ? (c->keep ? t - 1 : ((t - 1) & 1)) : 0;

@@ -368,9 +368,9 @@ struct StepFixedArgs {
     double u0;                                 // systematic offset of the resampling before step t (Philox, evaluated on the host)
     double bound_prev, bound;                  // B_{t-1}, B_t
     double ess_frac; int may_carry;            // may_carry = 0: every step resamples (known on the host): no log-weight ever carries
-    int prefetch;                              // fetch the three likely source tiles' weights at kernel entry (a round trip saved where the
-                                               // launch is latency-bound or always resamples; 12 wasted bytes per particle on a large
-                                               // population's steps that do not resample)
+    int prefetch;                              // fetch the three likely source tiles' weights at kernel entry: a round trip saved where every
+                                               // step resamples; off where steps may not (12 wasted bytes per particle on those, twelve
+                                               // registers on all: -1 % at 1.25e6 particles of the LGSSM, same-call A/B)
     StepCtrl* ctrl; double n_pop; double* ess_trace; int32_t* resampled;
     const uint64_t* all_totals; int world, rank;       // one shard of a joint population (exchange scope): every rank's {S, Q, key(M)} of generation t-1
     const int64_t* annex_base;
