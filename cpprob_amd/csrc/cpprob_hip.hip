@@ -555,8 +555,11 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         if (!c->keep) a.anc = nullptr;
         {
             ProfScope ps(c, 0);
-            if (all_totals) hipLaunchKernelGGL(smc_step_fixed_sharded_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
-            else hipLaunchKernelGGL(smc_step_fixed_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            if (all_totals && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (all_totals) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (a.prefetch) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (!Model::kIsInt) hipLaunchKernelGGL(smc_step_fixed_five_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         }
 #ifdef CPPROB_STAMPS
         {

@@ -399,7 +399,7 @@ __device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const Fi
     if (resampled) resampled[t_prev] = d.resample ? 1 : 0;
 }
 
-template <class Model, bool SHARDED>
+template <class Model, bool SHARDED, bool PREFETCH>
 __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& a)
 {
     using V = typename Model::value_t;
@@ -427,7 +427,7 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
     //  fetches: here it costs more than the better aim returns: same-call A/B, eight loopback ranks, configs[3] 29.3 -> 28.1 ms,
     //  configs[4] 150.6 -> 143.0; the second probe aims by the miss distance anyway)
     if (t > 0) {
-        if (a.prefetch) {
+        if (PREFETCH) {
             const int64_t g0 = (int64_t)guess * kTile + (int64_t)tid * kPPT;
             q_0 = *reinterpret_cast<const U4*>(a.q_prev + g0);
             q_m1 = *reinterpret_cast<const U4*>(a.q_prev + (guess > 0 ? g0 - kTile : g0));
@@ -504,7 +504,7 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
         ref = s_found.ref;
         if (resample) {
             fc.inv = s_found.inv; fc.base = s_found.base;
-            fixed_walk(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, guess, a.prefetch != 0, q_m1, q_0, q_p1, anc, L);
+            fixed_walk(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, guess, PREFETCH, q_m1, q_0, q_p1, anc, L);
             if (SHARDED) {
                 const int64_t l0 = s_found.l0, l1 = s_found.l1;
                 const int64_t col0 = a.ld + a.annex_base[t - 1];
@@ -582,14 +582,18 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
 #endif
 }
 
-// One population on this GPU.
+// One population on this GPU.  PREFETCH: the three likely source tiles' weights are fetched at kernel entry (every-step schedules).
+template <class Model, bool PREFETCH>
+__global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, false, PREFETCH>(a); }
+// The continuous models without the prefetch sit one register above five wavefronts a SIMD: told to fit (one spilled dword), 1221
+// workgroups -- 1.25 10^6 particles -- run in one pass.
 template <class Model>
-__global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, false>(a); }
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void smc_step_fixed_five_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, false, false>(a); }
 // One shard of a joint population.  Five wavefronts a SIMD (96 registers; the continuous models' build wants 138 and spills ~25
 // of them): configs[3]'s shard of 1.25 10^6 particles is 1221 workgroups, and 256 CUs hold 1280 of them at five a CU but 768 at
 // three -- a second pass of workgroups behind the first costs more than the spills (profiles/r03_notes.md).
-template <class Model>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void smc_step_fixed_sharded_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, true>(a); }
+template <class Model, bool PREFETCH>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void smc_step_fixed_sharded_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, true, PREFETCH>(a); }
 
 // ---- the run's last generation ------------------------------------------------------------------------------------------------
 struct FixedFinal {
