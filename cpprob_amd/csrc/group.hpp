@@ -579,7 +579,10 @@ int setup_remote(cpprob_hip_group* g)
 // group and proven by a round trip before any run relies on them.  All or nobody (the outcome is all-gathered).
 int setup_mailboxes(cpprob_hip_group* g)
 {
-    if (g->dc_tried) return 0;
+    if (g->dc_tried) {                                   // (asking for the library's collectives later switches the mailboxes off; nothing switches them back on)
+        if (g->user_flags & CPPROB_HIP_GROUP_LIBRARY_COLLECTIVES) { g->dev_coll = false; g->dc_note = "library collectives requested"; }
+        return 0;
+    }
     g->dc_tried = true; g->dev_coll = false;
     const int n_local = (int)g->ctx.size(), world = g->world;
     const bool talk = world > 1 || g->world1_collectives;

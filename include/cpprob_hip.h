@@ -323,7 +323,8 @@ int cpprob_hip_exchange_status(cpprob_hip_ctx* ctx, int32_t* h_overflow, uint64_
  *            can map each other's memory -- a rank stores its words and the step's sequence number into every peer's mailbox and spins
  *            on its own, one short launch, no library call and no host inside a run (csrc/device_collectives.hpp); proven by a round
  *            trip at the first begin, and a wait that times out (5 s) makes results() repeat the run on the library's collectives.
- *            Otherwise RCCL calls / the caller's all-gather.  The collectives flags are read at the first begin.
+ *            Otherwise RCCL calls / the caller's all-gather.  The collectives flags are read at the first begin (LIBRARY_COLLECTIVES at
+ *            any later begin still switches the mailboxes off).
  *   begin    cfg as for cpprob_hip_infer_begin with n_particles = the WHOLE population (particle_offset / n_global / scope are
  *            set per rank by the group); shards are contiguous and equal unless h_shard_sizes[world] names them.  Systematic SMC
  *            runs in the exchange scope (exact global resampling); other resamplers and SIS in the global scope.  COLLECTIVE.

@@ -343,6 +343,31 @@ def test_group_mailbox_collectives_on_loopback_ranks(engine, golden_dir, model, 
     g.close()
 
 
+def test_group_can_fall_back_to_the_conservative_transport_after_a_run(engine, golden_dir):
+    """What bench.py does when the default transport's answer is not the posterior on hardware it has never seen: the same group
+    object, begun again with library collectives, shipped lineages and the walk read-out -- here on one GPU (RCCL world 1 with the rank
+    as its own peer), where both transports give the one-GPU answer."""
+    import torch  # noqa: F401
+    obs = _obs(golden_dir, "hmm16")
+    n = 120000
+    ref_stats, ref_sum, _, _ = _single(engine, cp.ALG_SMC, cp.MODEL_HMM3, obs, n, 4, 2.0)
+    g = cp.Group([0])
+    g.transport(flags=cp.capi.GROUP_WORLD1_COLLECTIVES)
+    g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, ess_threshold=2.0)
+    g.run()
+    stats, s, _ = g.results()
+    assert g.traffic()["mailbox_collectives"] == 1 and s["log_evidence"] == ref_sum["log_evidence"]
+    g.transport(flags=cp.capi.GROUP_WORLD1_COLLECTIVES | cp.capi.GROUP_LIBRARY_COLLECTIVES | cp.capi.GROUP_SHIP_LINEAGES)
+    g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, ess_threshold=2.0, flags=cp.capi.FLAG_WALK_READOUT)
+    g.run()
+    stats2, s2, _ = g.results()
+    tr = g.traffic()
+    g.close()
+    assert tr["mailbox_collectives"] == 0 and tr["remote_lineages"] == 0 and s2["log_evidence"] == ref_sum["log_evidence"]
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(stats2, ref_stats, rtol=0, atol=1e-13)
+
+
 def test_group_world_limit_is_63_ranks(engine, golden_dir):
     """The plan lives on one wavefront whose lane r holds the bound o_r, r = 0 .. world: 63 ranks are served, 64 refused."""
     obs = _obs(golden_dir, "hmm16")[:6]
