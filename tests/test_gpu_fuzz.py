@@ -125,3 +125,41 @@ def test_random_shard_layouts_exchange_scope(engine, golden_dir, sweep):
         if differing == 0:
             np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-11, err_msg=tag)
             assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-11, tag
+
+
+@pytest.mark.parametrize("sweep", [31, 32, 33])
+def test_random_groups_transports_and_collectives(engine, golden_dir, sweep):
+    """The library's own multi-GPU driver on loopback ranks over random shard layouts, models, schedules and transport switches
+    (remote lineages / shipped lineages / send-recv segments; mailbox collectives on or off; trace words where they apply): every
+    shard's traces, the evidence and the number of resampling steps are the single-context run's, bit for bit, whatever moved the
+    migrants."""
+    import torch  # noqa: F401
+    from test_gpu_group import _ctx_paths
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    rng = np.random.default_rng(sweep)
+    for _ in range(5):
+        kind = int(rng.integers(0, 3))
+        model, key, ess = [(cp.MODEL_HMM3, "hmm16", 2.0), (cp.MODEL_HMM3, "hmm128", 0.5), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 0.5)][kind]
+        T = int(rng.integers(3, 17))
+        obs = np.array(z[key][:T])
+        world = int(rng.integers(2, 7))
+        shards = [int(rng.integers(1500, 60000)) for _ in range(world)]
+        n = int(sum(shards))
+        seed = int(rng.integers(0, 2**31))
+        flags = int(rng.choice([0, cp.capi.GROUP_MAILBOX_COLLECTIVES, cp.capi.GROUP_SHIP_LINEAGES, cp.capi.GROUP_SENDRECV,
+                                cp.capi.GROUP_MAILBOX_COLLECTIVES | cp.capi.GROUP_SHIP_LINEAGES]))
+        tag = "model %d T %d shards %s ess %.1f seed %d flags %d" % (model, T, shards, ess, seed, flags)
+        engine.begin(cp.ALG_SMC, model, obs, n, seed=seed, ess_threshold=ess)
+        engine.run()
+        ref_paths, ref_stats, ref_sum = engine.paths(), engine.stats().copy(), engine.summary()
+        g = cp.Group([0] * world)
+        g.transport(flags=flags)
+        g.begin(cp.ALG_SMC, model, obs, n, seed=seed, ess_threshold=ess, shard_sizes=shards)
+        g.run()
+        stats, s, reruns = g.results()
+        paths = np.concatenate([_ctx_paths(g, r, shards[r], T, model == cp.MODEL_HMM3) for r in range(world)], axis=1)
+        g.close()
+        assert s["step_form"] == ref_sum["step_form"], tag
+        if s["step_form"] != cp.capi.FORM_FLOAT:
+            assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"], tag
+            np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13, err_msg=tag)
