@@ -29,7 +29,7 @@ SYMBOLS = [
     "cpprob_hip_group_context", "cpprob_hip_group_results", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
     "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
-    "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_weighted_moments_columns", "cpprob_hip_weighted_hist_columns", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_smc_bookkeep_fixed", "cpprob_hip_lineage_gather", "cpprob_hip_gather_f64",
+    "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_weighted_moments_columns", "cpprob_hip_weighted_hist_columns", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_smc_bookkeep_fixed", "cpprob_hip_lineage_gather", "cpprob_hip_lineage_moments", "cpprob_hip_lineage_hist", "cpprob_hip_gather_f64",
     "cpprob_hip_gather_i32", "cpprob_hip_profile_enable", "cpprob_hip_profile_read", "cpprob_hip_fastmath",
 ]
 
@@ -156,6 +156,8 @@ def load_library(path=None):
         "cpprob_hip_smc_bookkeep": (C.c_int, [vp, i32, vp, sz, u64, i32, i32, dbl, vp, vp, vp, vp]),
         "cpprob_hip_smc_bookkeep_fixed": (C.c_int, [vp, vp, sz, u64, i32, i32, dbl, vp, vp, vp, vp]),
         "cpprob_hip_lineage_gather": (C.c_int, [vp, vp, vp, i32, sz, vp, i32, vp, i32, vp]),
+        "cpprob_hip_lineage_moments": (C.c_int, [vp, vp, vp, i32, sz, vp, vp, i32, vp, vp]),
+        "cpprob_hip_lineage_hist": (C.c_int, [vp, vp, vp, i32, sz, vp, vp, i32, vp, i32, vp, vp]),
         "cpprob_hip_gather_f64": (C.c_int, [vp, vp, vp, sz, vp]),
         "cpprob_hip_gather_i32": (C.c_int, [vp, vp, vp, sz, vp]),
         "cpprob_hip_profile_enable": (C.c_int, [vp, i32]),
@@ -412,6 +414,28 @@ class Engine:
         out = (C.c_double * (k * n_cols))()
         self._chk(self.L.cpprob_hip_weighted_hist_columns(self.h, _dptr(x), n_cols, n, _dptr(logw), n, k, out, None))
         return np.array(out[:]).reshape(n_cols, k)
+
+    def lineage_gather(self, anc, resampled, cols, gens, out):
+        """anc [T, n] int32, resampled [T] int32, cols [H, n] (fp64 / int32) recorded in generations gens[h]; out [H, n]: the traces."""
+        T, n = int(anc.shape[0]), int(anc.shape[1])
+        g = (C.c_int32 * len(gens))(*gens)
+        self._chk(self.L.cpprob_hip_lineage_gather(self.h, _dptr(anc), _dptr(resampled), T, n, _dptr(cols), 0 if cols.dtype.is_floating_point else 1, g, len(gens), _dptr(out)))
+
+    def lineage_moments(self, anc, resampled, cols, gens, logw):
+        """-> array [H, 4] = {mean, variance, logsumexp, ess} of every record along the final particles' lineages."""
+        T, n = int(anc.shape[0]), int(anc.shape[1])
+        g = (C.c_int32 * len(gens))(*gens)
+        out = (C.c_double * (4 * len(gens)))()
+        self._chk(self.L.cpprob_hip_lineage_moments(self.h, _dptr(anc), _dptr(resampled), T, n, _dptr(cols), g, len(gens), _dptr(logw), out))
+        return np.array(out[:]).reshape(len(gens), 4)
+
+    def lineage_hist(self, anc, resampled, cols, gens, logw, k):
+        """-> array [H, k] of P(record h = s) along the final particles' lineages."""
+        T, n = int(anc.shape[0]), int(anc.shape[1])
+        g = (C.c_int32 * len(gens))(*gens)
+        out = (C.c_double * (k * len(gens)))()
+        self._chk(self.L.cpprob_hip_lineage_hist(self.h, _dptr(anc), _dptr(resampled), T, n, _dptr(cols), g, len(gens), _dptr(logw), k, out, None))
+        return np.array(out[:]).reshape(len(gens), k)
 
     def resample(self, kind, logw, seed, step, anc_out, j0=0, n_total_out=None):
         n_out = anc_out.numel()

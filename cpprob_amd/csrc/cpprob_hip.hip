@@ -142,6 +142,7 @@ struct cpprob_hip_ctx {
     double* d_bb_stats_part = nullptr; double* d_bb_stats = nullptr; double* d_bb_cdf = nullptr; size_t bb_cdf_cap = 0;
     void* d_bb_cols = nullptr; double* d_bb_cols_part = nullptr; double* d_bb_cols_stat = nullptr; size_t bb_cols_bytes = 0, bb_cols_part = 0, bb_cols_stat = 0;   // several columns at once
     int32_t* d_bb_first = nullptr; size_t bb_first_cap = 0;
+    std::vector<int32_t> bb_first_host;                              // what d_bb_first holds (an unchanged table is not uploaded again)
 
     // cpprob_hip_smc_bookkeep_fixed: two alternating copies of a mass hierarchy + the integer weights
     uint64_t* d_bbf_hier = nullptr; HierTable* d_bbf_table = nullptr; HierTable bbf_table{}; uint32_t* d_bbf_q = nullptr;
@@ -2048,7 +2049,99 @@ static int columns_stats(cpprob_hip_ctx* c, const typename Col::value_t* d_x, si
     h_lse_ess[0] = h.M + std::log(h.W); h_lse_ess[1] = h.ess;
     return 0;
 }
+// first_row[t] .. first_row[t + 1]: the records made in generation t's slots (h_gen[h] = the generation of record h, non-decreasing)
+static int upload_first_rows(cpprob_hip_ctx* c, const int32_t* h_gen, int32_t H, int32_t T)
+{
+    std::vector<int32_t> first((size_t)T + 1, 0);
+    int32_t prev = 0;
+    for (int32_t h = 0; h < H; ++h) {
+        if (h_gen[h] < prev || h_gen[h] >= T) return fail(c, CPPROB_HIP_EINVAL, "h_gen must be non-decreasing and < T");
+        prev = h_gen[h];
+        first[(size_t)h_gen[h] + 1] += 1;
+    }
+    for (int t = 0; t < T; ++t) first[(size_t)t + 1] += first[(size_t)t];
+    if (first == c->bb_first_host) return 0;
+    c->bb_first_host.clear();
+    if (first.size() > c->bb_first_cap) { dfree(c->d_bb_first); HIP_TRY(c, hipMalloc(&c->d_bb_first, first.size() * sizeof(int32_t))); c->bb_first_cap = first.size(); }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                                                                       // (a launch in flight may still read the old table)
+    HIP_TRY(c, hipMemcpy(c->d_bb_first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));     // (synchronous: `first` is a local)
+    c->bb_first_host = first;
+    return 0;
+}
+
+// statistics of per-step records along the final particles' lineages against the final weights (lineage_stats_kernel)
+template <class Col>
+static int lineage_stats(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const typename Col::value_t* d_cols, const int32_t* h_gen,
+                         int32_t H, const double* d_logw, double* h_raw /*[H][kStats]*/, double* h_lse_ess)
+{
+    constexpr int kChunk = 64;
+    if (int rc = upload_first_rows(c, h_gen, H, T)) return rc;
+    if (int rc = bb_normalise(c, d_logw, n, (double)n)) return rc;
+    const int nb = (int)((n + kTile - 1) / kTile);
+    const int grid = std::min(nb, 2048);
+    const int chunk = std::min<int>(H, kChunk);
+    const size_t part_doubles = (size_t)chunk * Col::kStats * (size_t)grid, stat_doubles = (size_t)chunk * Col::kStats;
+    if (part_doubles > c->bb_cols_part) { dfree(c->d_bb_cols_part); HIP_TRY(c, hipMalloc(&c->d_bb_cols_part, part_doubles * sizeof(double))); c->bb_cols_part = part_doubles; }
+    if (stat_doubles > c->bb_cols_stat) { dfree(c->d_bb_cols_stat); HIP_TRY(c, hipMalloc(&c->d_bb_cols_stat, stat_doubles * sizeof(double))); c->bb_cols_stat = stat_doubles; }
+    for (int h0 = 0; h0 < H; h0 += chunk) {
+        const int nk = std::min(chunk, H - h0);
+        LineageStatsArgs<Col> a{};
+        a.anc = d_anc; a.resampled = d_resampled; a.T = T; a.n = (int64_t)n; a.cols = d_cols; a.first_row = c->d_bb_first; a.h0 = h0; a.h1 = h0 + nk;
+        a.wrel = c->d_bb_wrel; a.bf = c->d_bb_bf; a.ctrl = c->d_bb_ctrl; a.stats_part = c->d_bb_cols_part;
+        hipLaunchKernelGGL(lineage_stats_kernel<Col>, dim3(grid), dim3(kThreads), (size_t)kWaves * nk * Col::kStats * sizeof(double), c->stream, a);
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nk), dim3(kThreads), 0, c->stream, c->d_bb_cols_part, grid, nk, Col::kStats, 1, c->d_bb_ctrl, c->d_bb_cols_stat, 1);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(h_raw + (size_t)h0 * Col::kStats, c->d_bb_cols_stat, (size_t)nk * Col::kStats * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (h0 + chunk < H) HIP_TRY(c, hipStreamSynchronize(c->stream));     // (the scratch is reused by the next chunk)
+    }
+    StepCtrl h{};
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_bb_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    h_lse_ess[0] = h.M + std::log(h.W); h_lse_ess[1] = h.ess;
+    return 0;
+}
+
+static int lineage_args_ok(cpprob_hip_ctx* c, const void* d_anc, const void* d_resampled, int32_t T, size_t n, const void* d_cols, const int32_t* h_gen, int32_t H,
+                           const void* d_logw, const void* h_out)
+{
+    if (!d_anc || !d_resampled || !d_cols || !h_gen || !d_logw || !h_out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (T < 1 || H < 1 || n == 0) return fail(c, CPPROB_HIP_EINVAL, "need T >= 1, H >= 1 and a non-empty population");
+    if (n > (size_t)INT32_MAX - kTile) return fail(c, CPPROB_HIP_EINVAL, "population too large for int32 ancestors");
+    return 0;
+}
+
 extern "C" {
+
+int cpprob_hip_lineage_moments(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const double* d_cols, const int32_t* h_gen, int32_t H,
+                               const double* d_logw, double* h_out4)
+{
+    BB_PRELUDE(c);
+    if (int rc = lineage_args_ok(c, d_anc, d_resampled, T, n, d_cols, h_gen, H, d_logw, h_out4)) return rc;
+    std::vector<double> raw((size_t)H * 2);
+    double le[2];
+    if (int rc = lineage_stats<ColumnReal>(c, d_anc, d_resampled, T, n, d_cols, h_gen, H, d_logw, raw.data(), le)) return rc;
+    for (int32_t k = 0; k < H; ++k) {
+        h_out4[4 * k] = raw[2 * k];
+        h_out4[4 * k + 1] = raw[2 * k + 1] - raw[2 * k] * raw[2 * k];     // variance(mean) = raw_moment(2) - mean*mean  (stats_printer.hpp:78-81)
+        h_out4[4 * k + 2] = le[0]; h_out4[4 * k + 3] = le[1];
+    }
+    return 0;
+}
+
+int cpprob_hip_lineage_hist(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const int32_t* d_cols, const int32_t* h_gen, int32_t H,
+                            const double* d_logw, int32_t k, double* h_out, double* h_lse_ess)
+{
+    BB_PRELUDE(c);
+    if (int rc = lineage_args_ok(c, d_anc, d_resampled, T, n, d_cols, h_gen, H, d_logw, h_out)) return rc;
+    if (k < 1 || k > 8) return fail(c, CPPROB_HIP_EINVAL, "need 1 <= k <= 8");
+    std::vector<double> raw((size_t)H * 8);
+    double le[2];
+    if (int rc = lineage_stats<ColumnInt8>(c, d_anc, d_resampled, T, n, d_cols, h_gen, H, d_logw, raw.data(), le)) return rc;
+    for (int32_t j = 0; j < H; ++j)
+        for (int s2 = 0; s2 < k; ++s2) h_out[(size_t)j * (size_t)k + s2] = raw[(size_t)j * 8 + s2];
+    if (h_lse_ess) { h_lse_ess[0] = le[0]; h_lse_ess[1] = le[1]; }
+    return 0;
+}
 
 int cpprob_hip_weighted_moments_columns(cpprob_hip_ctx* c, const double* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, double* h_out4)
 {
@@ -2244,18 +2337,8 @@ int cpprob_hip_lineage_gather(cpprob_hip_ctx* c, const int32_t* d_anc, const int
     if (!d_anc || !d_resampled || !d_cols || !h_gen || !d_out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (T < 1 || H < 0) return fail(c, CPPROB_HIP_EINVAL, "bad T / H");
     if (n == 0 || H == 0) return 0;
-    std::vector<int32_t> first((size_t)T + 1, 0);
-    int32_t prev = 0;
-    for (int32_t h = 0; h < H; ++h) {
-        if (h_gen[h] < prev || h_gen[h] >= T) return fail(c, CPPROB_HIP_EINVAL, "h_gen must be non-decreasing and < T");
-        prev = h_gen[h];
-        first[(size_t)h_gen[h] + 1] += 1;
-    }
-    for (int t = 0; t < T; ++t) first[(size_t)t + 1] += first[(size_t)t];
-    // (a few hundred bytes: passed by value in chunks would do too; a per-context scratch keeps the call allocation-free after the first)
-    if (first.size() > c->bb_first_cap) { dfree(c->d_bb_first); HIP_TRY(c, hipMalloc(&c->d_bb_first, first.size() * sizeof(int32_t))); c->bb_first_cap = first.size(); }
+    if (int rc = upload_first_rows(c, h_gen, H, T)) return rc;
     int32_t* d_first = c->d_bb_first;
-    HIP_TRY(c, hipMemcpy(d_first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));     // (synchronous: `first` is a local)
     if (is_int) hipLaunchKernelGGL(lineage_gather_kernel<int32_t>, GRID1(n), d_anc, d_resampled, (int)T, (int64_t)n, static_cast<const int32_t*>(d_cols), (const int32_t*)d_first, static_cast<int32_t*>(d_out));
     else hipLaunchKernelGGL(lineage_gather_kernel<double>, GRID1(n), d_anc, d_resampled, (int)T, (int64_t)n, static_cast<const double*>(d_cols), (const int32_t*)d_first, static_cast<double*>(d_out));
     HIP_TRY(c, hipGetLastError());

@@ -1976,11 +1976,78 @@ __global__ void pad_copy_cols_kernel(const T* __restrict__ src, int64_t n, int64
 
 // Weighted moments / histogram of one column against one log-weight array (EmpiricalDistribution
 // on device): the column is a 1-step "trace", so this is smooth_kernel with T = 1.
-struct ColumnReal { using value_t = double; using store_t = double; static constexpr int kStats = 2;
-    __device__ static __forceinline__ void accumulate(double x, double w, double (&acc)[2]) { acc[0] += w * x; acc[1] += w * (x * x); } };
-struct ColumnInt8 { using value_t = int32_t; using store_t = int32_t; static constexpr int kStats = 8;
+struct ColumnReal { using value_t = double; using store_t = double; static constexpr int kStats = 2; static constexpr bool kBins = false;
+    __device__ static __forceinline__ void accumulate(double x, double w, double (&acc)[2]) { acc[0] += w * x; acc[1] += w * (x * x); }
+    __device__ static __forceinline__ bool holds(const double (&)[kPPT], int) { return true; } };
+struct ColumnInt8 { using value_t = int32_t; using store_t = int32_t; static constexpr int kStats = 8; static constexpr bool kBins = true;
     __device__ static __forceinline__ void accumulate(int32_t x, double w, double (&acc)[8]) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc[s] += x == s ? w : 0.0; } };
+        for (int s = 0; s < 8; ++s) acc[s] += x == s ? w : 0.0; }
+    __device__ static __forceinline__ bool holds(const int32_t (&x)[kPPT], int s) { return x[0] == s || x[1] == s || x[2] == s || x[3] == s; } };
+static_assert(kPPT == 4, "ColumnInt8::holds names its particles");
+
+// Statistics of per-step records along the lineages (cpprob_hip_lineage_moments / _hist): lineage_gather_kernel's walk with the
+// columns' statistics taken on the way, in smooth_body's tile order and with its sums -- the numbers are those of gathering the
+// traces first and reading the gathered columns (cpprob_hip_weighted_*_columns), without the traces' round trip through memory.
+template <class Col>
+struct LineageStatsArgs {
+    const int32_t* anc; const int32_t* resampled; int T; int64_t n;
+    const typename Col::value_t* cols; const int32_t* first_row; int h0, h1;        // records h0 .. h1 - 1 are this launch's
+    const double* wrel; const double* bf; const StepCtrl* ctrl;
+    double* stats_part;                                                             // [(h1 - h0) * kStats][gridDim.x]
+};
+
+template <class Col>
+__global__ __launch_bounds__(kThreads) void lineage_stats_kernel(LineageStatsArgs<Col> a)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_stat[];                 // [kWaves][(h1 - h0) * K]
+    constexpr int K = Col::kStats;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int HK = (a.h1 - a.h0) * K;
+    const double scale = a.ctrl->scale;
+    for (int i = tid; i < kWaves * HK; i += kThreads) s_stat[i] = 0.0;
+    __syncthreads();
+    const int64_t ntiles = (a.n + kTile - 1) / kTile;
+    for (int64_t tile = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int64_t idx[kPPT]; double w[kPPT];
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const int64_t i = tile * kTile + (int64_t)k * kThreads + tid;
+            idx[k] = i < a.n ? i : a.n - 1;                                          // (padding slots: wrel = 0)
+            w[k] = a.wrel[i] * (a.bf[tile] * scale);
+        }
+        for (int t = a.T - 1; t >= 0; --t) {
+            const int hb = max(a.first_row[t], a.h0), he = min(a.first_row[t + 1], a.h1);
+            for (int h = hb; h < he; ++h) {
+                double acc[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc[j] = 0.0;
+                const typename Col::value_t* row = a.cols + (int64_t)h * a.n;
+                typename Col::value_t x[kPPT];
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) { x[k] = row[idx[k]]; Col::accumulate(x[k], w[k], acc); }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    // (a histogram bin no lane of the wavefront holds: its sum is an exact zero, not taken)
+                    if (Col::kBins && __ballot(Col::holds(x, j)) == 0) continue;
+                    const double sj = wave_sum(acc[j]);
+                    if (lane == 0) s_stat[wv * HK + (h - a.h0) * K + j] += sj;
+                }
+            }
+            if (t > 0 && a.resampled[t - 1]) {
+                const int32_t* arow = a.anc + (int64_t)t * a.n;
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) idx[k] = arow[idx[k]];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < HK; i += kThreads) {
+        double s = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kWaves; ++w2) s += s_stat[w2 * HK + i];
+        a.stats_part[(int64_t)i * gridDim.x + blockIdx.x] = s;
+    }
+}
 
 }  // namespace cph

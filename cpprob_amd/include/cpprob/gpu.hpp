@@ -127,15 +127,28 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     DevBuf<double> d_real(n_real * n), d_logw0(n), d_logw1(smc ? n : 0);
     DevBuf<int32_t> d_int(n_int * n), d_anc(smc ? n : 0), d_ns0(smc ? n : 0), d_ns1(smc ? n : 0);
     DevBuf<uint64_t> d_tr0(smc ? S * n : 0), d_tr1(smc ? S * n : 0);
-    DevBuf<int32_t> d_overflow(1);
-    hip_check(hipMemsetAsync(d_overflow.p, 0, sizeof(int32_t), stream), "hipMemsetAsync");   // on the launches' own (non-blocking) stream
+    // what the host reads when the run is over, side by side -- one copy: [T] step ESS, log evidence | [T] resampling decisions, overflow flag
+    const size_t tail_doubles = (size_t)T + 1, tail_ints = (size_t)T + 1, tail_bytes = tail_doubles * sizeof(double) + tail_ints * sizeof(int32_t);
+    DevBuf<unsigned char> d_tail(tail_bytes);
+    double* const d_ess_p = reinterpret_cast<double*>(d_tail.p);
+    double* const d_logz_p = d_ess_p + T;
+    int32_t* const d_res_p = reinterpret_cast<int32_t*>(d_tail.p + tail_doubles * sizeof(double));
+    int32_t* const d_overflow_p = d_res_p + T;
+    hip_check(hipMemsetAsync(d_tail.p, 0, tail_bytes, stream), "hipMemsetAsync");   // on the launches' own (non-blocking) stream
+    std::vector<unsigned char> h_tail(tail_bytes);
+    auto read_tail = [&]() {
+        hip_check(hipMemcpyAsync(h_tail.data(), d_tail.p, tail_bytes, hipMemcpyDeviceToHost, stream), "copy the run's tail");
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    };
+    const double* const h_ess_p = reinterpret_cast<const double*>(h_tail.data());
+    const int32_t* const h_res_p = reinterpret_cast<const int32_t*>(h_tail.data() + tail_doubles * sizeof(double));
     double* logw[2] = {d_logw0.p, d_logw1.p};
     int32_t* ns[2] = {d_ns0.p, d_ns1.p};
     uint64_t* tr[2] = {d_tr0.p, d_tr1.p};
     const dim3 grid((unsigned)((n + device::kLaneBlock - 1) / device::kLaneBlock)), block(device::kLaneBlock);
 
     ModelKernelArgs a{};
-    a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed; a.trace_cap = (uint32_t)S; a.overflow = d_overflow.p; a.pid0 = opt.particle_offset;
+    a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed; a.trace_cap = (uint32_t)S; a.overflow = d_overflow_p; a.pid0 = opt.particle_offset;
     a.pred_real_cap = (uint32_t)n_real; a.pred_int_cap = (uint32_t)n_int;
     // (windowed replay's buffers: allocated before the clock starts, like the others)
     const bool windowed = smc && st.window >= 0;
@@ -155,9 +168,10 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     const auto t_start = std::chrono::steady_clock::now();
     double log_z = 0.0;
     int cur = 0, n_resampled = 0;
+    bool stats_on_walk = false;                                       // windowed SMC without a particle store: the read-out rode the lineage walk
+    std::vector<double> walk_real, walk_int;
+    double walk_lse_ess[2] = {0.0, 0.0};
     bool smc_log_z_done = false;
-    DevBuf<double> d_ess(smc ? (size_t)T : 0), d_logz(smc ? 1 : 0);
-    DevBuf<int32_t> d_res(smc ? (size_t)T : 0);
     res.step_ess.clear();
     if (!smc) {
         a.logw_out = logw[0]; a.pred_real = d_real.p; a.pred_int = d_int.p; a.first_observe = 0; a.stop_after = -1;
@@ -173,7 +187,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         for (int t = 0; t < T; ++t) {
             const bool last = t + 1 == T;
             a.anc = t > 0 ? d_anc_all.p + (size_t)t * n : nullptr;
-            a.resampled_prev = t > 0 ? d_res.p + (t - 1) : nullptr;
+            a.resampled_prev = t > 0 ? d_res_p + (t - 1) : nullptr;
             a.logw_in = t > 0 ? logw[cur] : nullptr;
             a.logw_out = logw[cur ^ 1];
             a.carry_in = t > 0 ? carry[cur] : nullptr; a.carry_out = last ? nullptr : carry[cur ^ 1];
@@ -184,33 +198,44 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
             hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
             hip_check(hipGetLastError(), "model_kernel");
             cur ^= 1;
-            bookkeep(logw[cur], t, last, last ? d_anc.p : d_anc_all.p + (size_t)(t + 1) * n, d_ess.p, d_res.p, d_logz.p);
+            bookkeep(logw[cur], t, last, last ? d_anc.p : d_anc_all.p + (size_t)(t + 1) * n, d_ess_p, d_res_p, d_logz_p);
         }
-        // traces: hit h was recorded in the slots of generation step(h); follow every final particle's lineage back to it
+        // traces: hit h was recorded in the slots of generation step(h); follow every final particle's lineage back to it.  When
+        // nobody asked for the traces themselves, StatsPrinter's numbers are taken on that walk (cpprob_hip_lineage_moments / _hist).
         auto gens = [&](const std::vector<int>& steps) { std::vector<int32_t> g; for (int s2 : steps) g.push_back(std::min(s2, T - 1)); return g; };
+        if (!store) {
+            if (n_real) {
+                const std::vector<int32_t> g = gens(st.real_row_step);
+                walk_real.resize(4 * n_real);
+                ctx.check(cpprob_hip_lineage_moments(ctx.get(), d_anc_all.p, d_res_p, T, n, d_real_gen.p, g.data(), (int32_t)g.size(), logw[cur], walk_real.data()), "cpprob_hip_lineage_moments");
+            }
+            if (n_int) {
+                const std::vector<int32_t> g = gens(st.int_hit_step);
+                walk_int.resize(8 * n_int);
+                ctx.check(cpprob_hip_lineage_hist(ctx.get(), d_anc_all.p, d_res_p, T, n, d_int_gen.p, g.data(), (int32_t)g.size(), logw[cur], 8, walk_int.data(), walk_lse_ess), "cpprob_hip_lineage_hist");
+            }
+            stats_on_walk = true;
+        } else {
         if (n_real) {
             const std::vector<int32_t> g = gens(st.real_row_step);
-            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all.p, d_res.p, T, n, d_real_gen.p, 0, g.data(), (int32_t)g.size(), d_real.p), "cpprob_hip_lineage_gather");
+            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all.p, d_res_p, T, n, d_real_gen.p, 0, g.data(), (int32_t)g.size(), d_real.p), "cpprob_hip_lineage_gather");
         }
         if (n_int) {
             const std::vector<int32_t> g = gens(st.int_hit_step);
-            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all.p, d_res.p, T, n, d_int_gen.p, 1, g.data(), (int32_t)g.size(), d_int.p), "cpprob_hip_lineage_gather");
+            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all.p, d_res_p, T, n, d_int_gen.p, 1, g.data(), (int32_t)g.size(), d_int.p), "cpprob_hip_lineage_gather");
         }
-        std::vector<double> h_ess((size_t)T);
-        std::vector<int32_t> h_res((size_t)T);
-        hip_check(hipMemcpyAsync(h_ess.data(), d_ess.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, stream), "copy ess");
-        hip_check(hipMemcpyAsync(h_res.data(), d_res.p, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy decisions");
-        hip_check(hipMemcpyAsync(&log_z, d_logz.p, sizeof(double), hipMemcpyDeviceToHost, stream), "copy log evidence");
-        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-        res.step_ess = h_ess;
-        for (int t = 0; t < T; ++t) n_resampled += h_res[(size_t)t];
+        }
+        read_tail();
+        res.step_ess.assign(h_ess_p, h_ess_p + T);
+        log_z = h_ess_p[T];
+        for (int t = 0; t < T; ++t) n_resampled += h_res_p[t];
         smc_log_z_done = true;
         res.replay_window = (int)w;
     } else {
         for (int t = 0; t < T; ++t) {
             const bool last = t + 1 == T;
             a.anc = t > 0 ? d_anc.p : nullptr;
-            a.resampled_prev = t > 0 ? d_res.p + (t - 1) : nullptr;
+            a.resampled_prev = t > 0 ? d_res_p + (t - 1) : nullptr;
             a.logw_in = t > 0 ? logw[cur] : nullptr;
             a.logw_out = logw[cur ^ 1];
             a.trace_in = t > 0 ? tr[cur] : nullptr; a.trace_out = tr[cur ^ 1];
@@ -221,16 +246,12 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
             hip_check(hipGetLastError(), "model_kernel");
             cur ^= 1;
             // normalise, ESS test (thesis p.37), evidence, ancestors of the next generation: all on the device
-            bookkeep(logw[cur], t, last, d_anc.p, d_ess.p, d_res.p, d_logz.p);
+            bookkeep(logw[cur], t, last, d_anc.p, d_ess_p, d_res_p, d_logz_p);
         }
-        std::vector<double> h_ess((size_t)T);
-        std::vector<int32_t> h_res((size_t)T);
-        hip_check(hipMemcpyAsync(h_ess.data(), d_ess.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, stream), "copy ess");
-        hip_check(hipMemcpyAsync(h_res.data(), d_res.p, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy decisions");
-        hip_check(hipMemcpyAsync(&log_z, d_logz.p, sizeof(double), hipMemcpyDeviceToHost, stream), "copy log evidence");
-        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-        res.step_ess = h_ess;
-        for (int t = 0; t < T; ++t) n_resampled += h_res[(size_t)t];
+        read_tail();
+        res.step_ess.assign(h_ess_p, h_ess_p + T);
+        log_z = h_ess_p[T];
+        for (int t = 0; t < T; ++t) n_resampled += h_res_p[t];
         smc_log_z_done = true;
     }
     fill_predict_names(res, st);
@@ -239,7 +260,8 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     // StatsPrinter's numbers of every predict hit: all columns of a kind in one device pass against the final weights
     if (n_real) {
         std::vector<double> o4(4 * n_real);
-        ctx.check(cpprob_hip_weighted_moments_columns(ctx.get(), d_real.p, n_real, n, logw[cur], n, o4.data()), "cpprob_hip_weighted_moments_columns");
+        if (stats_on_walk) o4 = walk_real;
+        else ctx.check(cpprob_hip_weighted_moments_columns(ctx.get(), d_real.p, n_real, n, logw[cur], n, o4.data()), "cpprob_hip_weighted_moments_columns");
         lse_ess[0] = o4[2]; lse_ess[1] = o4[3]; have_norm = true;
         for (size_t k = 0, row = 0; k < st.real_ids.size(); ++k) {
             PredictStats& p = res.predicts[k];
@@ -250,7 +272,8 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     const size_t n_real_hits = st.real_ids.size();
     if (n_int) {
         std::vector<double> h(8 * n_int);
-        ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int.p, n_int, n, logw[cur], n, 8, h.data(), have_norm ? nullptr : lse_ess), "cpprob_hip_weighted_hist_columns");
+        if (stats_on_walk) { h = walk_int; if (!have_norm) { lse_ess[0] = walk_lse_ess[0]; lse_ess[1] = walk_lse_ess[1]; } }
+        else ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int.p, n_int, n, logw[cur], n, 8, h.data(), have_norm ? nullptr : lse_ess), "cpprob_hip_weighted_hist_columns");
         have_norm = true;
         for (size_t k = 0; k < n_int; ++k) {
             int top = 8;
@@ -273,9 +296,8 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         if (n_real) hip_check(hipMemcpyAsync(store->real.data(), d_real.p, n_real * n * sizeof(double), hipMemcpyDeviceToHost, stream), "copy real predicts");
         if (n_int) hip_check(hipMemcpyAsync(store->ints.data(), d_int.p, n_int * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy int predicts");
     }
-    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-    int32_t overflow = 0;
-    hip_check(hipMemcpy(&overflow, d_overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost), "read overflow flag");
+    if (!smc) read_tail(); else hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");    // (SMC: the tail was read when the last launch had been issued)
+    const int32_t overflow = h_res_p[T];
     if (overflow == 2)
         throw std::runtime_error("cpprob::inference: a particle executed more predict statements than the model's dry run did; the number "
                                  "and order of observe / predict statements must not depend on sampled values on the device path");

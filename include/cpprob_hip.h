@@ -446,6 +446,14 @@ int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* ctx, const double* d_logw, siz
  * is_int = 0: fp64 rows, 1: int32 rows.  Stream-ordered; what the unchanged-model SMC path reads its predicts out with. */
 int cpprob_hip_lineage_gather(cpprob_hip_ctx* ctx, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const void* d_cols,
                               int32_t is_int, const int32_t* h_gen, int32_t H, void* d_out);
+/* The same walk with the rows' statistics taken on the way -- what cpprob_hip_lineage_gather followed by cpprob_hip_weighted_moments_columns /
+ * _hist_columns against d_logw (the FINAL generation's log-weights, n of them) returns, bit for bit, without the traces' round trip through
+ * memory (StatsPrinter's numbers, reference stats_printer.hpp:68-120, when nobody asked for the traces themselves).  h_out4: [H][4] =
+ * {mean, variance, logsumexp, ess}; h_out: [H][k] probabilities, 1 <= k <= 8; h_lse_ess (may be NULL): {logsumexp, ess}.  Synchronises. */
+int cpprob_hip_lineage_moments(cpprob_hip_ctx* ctx, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const double* d_cols,
+                               const int32_t* h_gen, int32_t H, const double* d_logw, double* h_out4);
+int cpprob_hip_lineage_hist(cpprob_hip_ctx* ctx, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const int32_t* d_cols,
+                            const int32_t* h_gen, int32_t H, const double* d_logw, int32_t k, double* h_out, double* h_lse_ess);
 /* d_dst[i] = d_src[d_idx[i]] */
 int cpprob_hip_gather_f64(cpprob_hip_ctx* ctx, const double* d_src, const int32_t* d_idx, size_t n, double* d_dst);
 int cpprob_hip_gather_i32(cpprob_hip_ctx* ctx, const int32_t* d_src, const int32_t* d_idx, size_t n, int32_t* d_dst);

@@ -424,3 +424,41 @@ def test_weighted_columns_equal_the_per_column_calls(engine, n, n_cols):
     ref = np.array([O.weighted_moments(x[k], logw) for k in range(min(n_cols, 4))])
     np.testing.assert_allclose(got[:len(ref), :2], ref[:, :2], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(goth[0], O.weighted_hist(xi[0], logw, 5), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,T,hits", [(1, 1, [0]), (1000, 5, [0, 1, 1, 3, 4]), (70001, 16, list(range(16))), (4097, 7, [0] * 40 + [2] * 50 + [6] * 40)])
+def test_lineage_statistics_equal_gather_then_columns(engine, n, T, hits):
+    """cpprob_hip_lineage_moments / _hist: the statistics of per-step records along the final particles' lineages, taken on the walk.
+    Bit for bit what gathering the traces (cpprob_hip_lineage_gather) and reading the gathered columns returns, and the traces
+    themselves are a numpy walk's.  Records per generation: none, one, several; 130 records: more than one chunk of 64; one of the
+    ancestor rows does not count (its step did not resample)."""
+    rng = np.random.default_rng(n + T)
+    H = len(hits)
+    anc = rng.integers(0, n, size=(T, n)).astype(np.int32)
+    res = np.ones(T, dtype=np.int32)
+    if T > 2:
+        res[1] = 0
+    logw = rng.normal(size=n) * 3.0 - 50.0
+    x = rng.normal(size=(H, n)) * 2.0 + 1.0
+    xi = rng.integers(0, 5, size=(H, n)).astype(np.int32)
+    d_anc, d_res, d_x, d_xi, d_lw = _t(anc), _t(res), _t(x), _t(xi), _t(logw)
+    out_x, out_xi = dzeros_like(d_x), dzeros_like(d_xi)
+    engine.lineage_gather(d_anc, d_res, d_x, hits, out_x)
+    engine.lineage_gather(d_anc, d_res, d_xi, hits, out_xi)
+    engine.sync()
+    # the walk in numpy
+    idx = np.arange(n)
+    want_x, want_xi = np.empty_like(x), np.empty_like(xi)
+    for t in range(T - 1, -1, -1):
+        for h in range(H):
+            if hits[h] == t:
+                want_x[h] = x[h, idx]
+                want_xi[h] = xi[h, idx]
+        if t > 0 and res[t - 1]:
+            idx = anc[t, idx]
+    assert np.array_equal(out_x.cpu().numpy(), want_x) and np.array_equal(out_xi.cpu().numpy(), want_xi)
+    got = engine.lineage_moments(d_anc, d_res, d_x, hits, d_lw)
+    goth = engine.lineage_hist(d_anc, d_res, d_xi, hits, d_lw, 5)
+    assert np.array_equal(got, engine.weighted_moments_columns(out_x, d_lw))
+    assert np.array_equal(goth, engine.weighted_hist_columns(out_xi, d_lw, 5))
+    np.testing.assert_allclose(got[0, :2], np.array(O.weighted_moments(want_x[0], logw))[:2], rtol=1e-9, atol=1e-10)
