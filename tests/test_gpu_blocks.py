@@ -462,3 +462,27 @@ def test_lineage_statistics_equal_gather_then_columns(engine, n, T, hits):
     assert np.array_equal(got, engine.weighted_moments_columns(out_x, d_lw))
     assert np.array_equal(goth, engine.weighted_hist_columns(out_xi, d_lw, 5))
     np.testing.assert_allclose(got[0, :2], np.array(O.weighted_moments(want_x[0], logw))[:2], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("n", [1, 1000, 70001, 1_000_000, 5_000_000])
+def test_fixed_point_bookkeeping_matches_the_integer_comb(engine, n):
+    """cpprob_hip_smc_bookkeep_fixed (what the unchanged-model path runs between two launches of the model body): decisions as the
+    ESS test asks, the identity where the step does not resample, and the ancestors of a resampling step `array_equal` to the oracle's
+    integer comb on q_i = min(rint(exp(lw_i - max lw) 2^32), 2^32 - 1).  One, two and three levels of the hierarchy of sums."""
+    import torch
+    rng = np.random.default_rng(n)
+    ess = dzeros(3, dtype=torch.float64)
+    res = dzeros(3, dtype=torch.int32)
+    lz = dzeros(1, dtype=torch.float64)
+    anc = dzeros(n, dtype=torch.int32)
+    for step, (spread, last) in enumerate([(2.0, False), (0.01, False), (1.0, True)]):
+        logw = rng.normal(size=n) * spread - 30.0
+        engine.smc_bookkeep_fixed(_t(logw), 77, step, last, 0.5, ess, res, lz, anc)
+        engine.sync()
+        got = anc.cpu().numpy()
+        if step == 0:
+            assert np.array_equal(got, O.resample_fixed_systematic(O.fix_weights(logw, logw.max()), 77, 1))
+            assert n == 1 or int(res[0]) == 1
+        elif step == 1 and n > 1:
+            assert int(res[1]) == 0 and np.array_equal(got, np.arange(n))
+    assert int(res[2]) == 0
