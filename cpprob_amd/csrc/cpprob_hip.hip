@@ -17,6 +17,7 @@
 #include "exchange.hpp"
 #include "bookkeep_fixed.hpp"
 #include "trace_words.hpp"
+#include "device_collectives.hpp"
 
 using namespace cph;
 
@@ -142,7 +143,9 @@ struct cpprob_hip_ctx {
     double* d_bb_stats_part = nullptr; double* d_bb_stats = nullptr; double* d_bb_cdf = nullptr; size_t bb_cdf_cap = 0;
     void* d_bb_cols = nullptr; double* d_bb_cols_part = nullptr; double* d_bb_cols_stat = nullptr; size_t bb_cols_bytes = 0, bb_cols_part = 0, bb_cols_stat = 0;   // several columns at once
     int32_t* d_bb_first = nullptr; size_t bb_first_cap = 0;
-    std::vector<int32_t> bb_first_host;                              // what d_bb_first holds (an unchanged table is not uploaded again)
+    std::vector<int32_t> bb_first_host;
+    // exchange scope, mailbox collectives (group.hpp): the step's shard-totals launch carries the all-gather (device_collectives.hpp)
+    bool x_gather_on = false, x_gather_done = false; TotalsGather x_gather{}; unsigned long long x_gather_serial = 0;                              // what d_bb_first holds (an unchanged table is not uploaded again)
 
     // cpprob_hip_smc_bookkeep_fixed: two alternating copies of a mass hierarchy + the integer weights
     uint64_t* d_bbf_hier = nullptr; HierTable* d_bbf_table = nullptr; HierTable bbf_table{}; uint32_t* d_bbf_q = nullptr;
@@ -1193,6 +1196,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
         }
     }
     c->totals_out = d_local_totals;
+    c->x_gather_done = c->x_gather_on && (c->counts_mode || c->fixed_mode);
     if (c->counts_mode) {
         // prefix-count form: the step consumes the all-gathered counts of generation t-1 itself; what leaves is this shard's
         // {n_0, n_1, particles} (exact doubles), after the last step too: the read-out works from the final generation's counts
@@ -1202,7 +1206,9 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
             Hier h{};
             const int kn = (t + 1 + c->hier_phase_run) % 3;
             hier_view(c, kn, h);
-            hipLaunchKernelGGL(counts_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals);
+            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = t & 1; d.seq = (c->x_gather_serial << 12) | (unsigned long long)(t + 1);
+                                  hipLaunchKernelGGL(counts_totals_gather_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals, d); }
+            else hipLaunchKernelGGL(counts_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals);
         }
     } else if (c->fixed_mode) {
         // fixed-point form: likewise; what leaves is this shard's {mass, squares, key of the largest log-weight}: 24 bytes
@@ -1212,7 +1218,9 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
             FHier f{};
             const int kn = (t + 1 + c->hier_phase_run) % 3;
             fhier_view(c, kn, f);
-            hipLaunchKernelGGL(fixed_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local_totals));
+            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = t & 1; d.seq = (c->x_gather_serial << 12) | (unsigned long long)(t + 1);
+                                  hipLaunchKernelGGL(fixed_totals_gather_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local_totals), d); }
+            else hipLaunchKernelGGL(fixed_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local_totals));
         }
     } else {
         if (sis) dispatch_model(c, [&](auto m) { launch_sis<decltype(m)>(c, false); });

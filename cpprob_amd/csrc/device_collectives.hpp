@@ -39,14 +39,13 @@ __device__ __forceinline__ bool dc_spin(const unsigned long long* flag, unsigned
 }
 
 // all-gather of three 64-bit words per rank; one wavefront, lane r = rank r
-__global__ __launch_bounds__(kWave) void dc_allgather_kernel(const unsigned long long* __restrict__ local3, const MailboxPeers* __restrict__ peers, Mailbox* mine,
-                                                             int world, int rank, int parity, unsigned long long seq, int phases,
-                                                             unsigned long long* __restrict__ all_out, int32_t* status, long long timeout)
+__device__ __forceinline__ void dc_allgather_body(unsigned long long w0, unsigned long long w1, unsigned long long w2, const MailboxPeers* __restrict__ peers, Mailbox* mine,
+                                                  int world, int rank, int parity, unsigned long long seq, int phases,
+                                                  unsigned long long* __restrict__ all_out, int32_t* status, long long timeout)
 {
     const int lane = threadIdx.x;
     if ((phases & kDcPost) && lane < world) {
         unsigned long long* slot = peers->box[lane]->tot[parity][rank];
-        const unsigned long long w0 = local3[0], w1 = local3[1], w2 = local3[2];
         __hip_atomic_store(slot + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(slot + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(slot + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -62,6 +61,38 @@ __global__ __launch_bounds__(kWave) void dc_allgather_kernel(const unsigned long
         }
         if (!ok) atomicOr(status, kDcTimedOut);
     }
+}
+
+__global__ __launch_bounds__(kWave) void dc_allgather_kernel(const unsigned long long* __restrict__ local3, const MailboxPeers* __restrict__ peers, Mailbox* mine,
+                                                             int world, int rank, int parity, unsigned long long seq, int phases,
+                                                             unsigned long long* __restrict__ all_out, int32_t* status, long long timeout)
+{
+    dc_allgather_body(local3[0], local3[1], local3[2], peers, mine, world, rank, parity, seq, phases, all_out, status, timeout);
+}
+
+// The shard-totals launch of a step (counts_totals_kernel / fixed_totals_kernel: one wavefront sums the hierarchy's top level) carrying
+// the all-gather of what it has just summed: a rank with a stream of its own posts and waits where it stands -- one launch a step less.
+// (Loopback ranks share a stream: they post in one pass and wait in the next, dc_allgather_kernel.)
+struct TotalsGather {
+    const MailboxPeers* peers; Mailbox* mine; int world, rank, parity; unsigned long long seq;
+    unsigned long long* all_out; int32_t* status; long long timeout;
+};
+
+__global__ __launch_bounds__(kWave) void counts_totals_gather_kernel(Hier h, double n_local, double* __restrict__ out, TotalsGather d)
+{
+    const Cnt2 t = hier_total(h);
+    const double v0 = (double)t.n0, v1 = (double)t.n1;
+    if (threadIdx.x == 0) { out[0] = v0; out[1] = v1; out[2] = n_local; }
+    dc_allgather_body((unsigned long long)__double_as_longlong(v0), (unsigned long long)__double_as_longlong(v1), (unsigned long long)__double_as_longlong(n_local),
+                      d.peers, d.mine, d.world, d.rank, d.parity, d.seq, kDcPost | kDcWait, d.all_out, d.status, d.timeout);
+}
+
+__global__ __launch_bounds__(kWave) void fixed_totals_gather_kernel(FHier f, uint64_t* __restrict__ out, TotalsGather d)
+{
+    const FTot t = ftot(f);
+    const uint64_t km = dkey(t.M);
+    if (threadIdx.x == 0) { out[0] = t.S; out[1] = t.Q; out[2] = km; }
+    dc_allgather_body(t.S, t.Q, km, d.peers, d.mine, d.world, d.rank, d.parity, d.seq, kDcPost | kDcWait, d.all_out, d.status, d.timeout);
 }
 
 // "every rank's packing kernel of this step has completed": stream-ordered behind the local packing launch on every rank

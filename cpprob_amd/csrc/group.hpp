@@ -310,9 +310,20 @@ int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
     // (a group of one has nobody to gather from or to exchange with: its own totals ARE the gathered totals -- unless the caller
     //  asked for every collective to run anyway, which is how a one-GPU machine exercises them)
     const bool talk = world > 1 || g->world1_collectives;
+    // mailbox collectives: the shard-totals launch of the integer forms posts and waits itself (the floating-point form's totals come
+    // out of its scan launch: a launch of their own gathers them)
+    const bool gather_in_totals = talk && g->dev_coll && !sis;
+    c->x_gather_on = gather_in_totals;
+    if (gather_in_totals) {
+        c->x_gather = cph::TotalsGather{(const cph::MailboxPeers*)g->d_box_peers[(size_t)i], g->d_box[(size_t)i], world, rank, 0, 0ull,
+                                        reinterpret_cast<unsigned long long*>(g->d_all[(size_t)i]), g->d_dc_status[(size_t)i], kDcTimeoutTicks};
+        c->x_gather_serial = (unsigned long long)g->dc_serial;
+    }
+    struct GatherOff { cpprob_hip_ctx* c; ~GatherOff() { c->x_gather_on = false; } } gather_off{c};
     for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
         if (int rc = cpprob_hip_smc_step_begin(c, t, run_index, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
-        if (talk && g->dev_coll) dc_allgather(g, i, t, cph::kDcPost | cph::kDcWait, c->stream);
+        if (gather_in_totals && c->x_gather_done) {}
+        else if (talk && g->dev_coll) dc_allgather(g, i, t, cph::kDcPost | cph::kDcWait, c->stream);
         else if (talk) { if (int rc = coll_allgather(g, i, g->d_local[(size_t)i], g->d_all[(size_t)i], 3)) return rc; }
         if (int rc = cpprob_hip_smc_step_end(c, t, talk ? g->d_all[(size_t)i] : g->d_local[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
         if (g->exchange && t + 1 < g->T) {
