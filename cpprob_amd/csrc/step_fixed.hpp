@@ -337,7 +337,8 @@ __device__ __forceinline__ FixedDecision fixed_decide(uint64_t S, uint64_t Q, do
     const double Sd = u64_to_double(S);
     d.W = Sd * kFixInv;                                      // sum of exp(lw - R)
     d.Qd = u64_to_double(Q) * kFixInv;                        // sum of exp(2 (lw - R)) on 16-bit weights: (q >> 16)^2 = e^2 2^32
-    d.ess = d.W * d.W / d.Qd;                                 // thesis p.37
+    const double e = d.W * d.W / d.Qd;                        // thesis p.37
+    d.ess = e > n_pop ? n_pop : e;                            // (the 16-bit squares under-count Q by up to 2^-15: equal weights would report ESS = N (1 + 3e-5))
     d.resample = may_resample && d.ess < ess_frac * n_pop;
     d.inv = n_pop / Sd;
     return d;

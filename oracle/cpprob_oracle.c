@@ -609,7 +609,7 @@ ORC_API int orc_resample_table_systematic(const int32_t *x, uint64_t n_in, const
 /* M_{t-1} the exact maximum of the previous log-weights.  Inclusive CDF          */
 /* C_k = sum_{i<=k} q_i (exact, 64-bit), G_k = ceil(fma((double)C_k, N/(double)C_N,*/
 /* -u0)), ancestor of output j = min{k : G_k > j}, G of the last source = N;       */
-/* W = C_N 2^-32, ESS = W^2 / (2^-32 sum (q_i >> 16)^2).  Integers sum exactly in  */
+/* W = C_N 2^-32, ESS = min(N, W^2 / (2^-32 sum (q_i >> 16)^2)).  Integers sum exactly in */
 /* any order: tiles, wavefronts and shards all produce these ancestors.            */
 /* exp() is the kernel's own range-specific form (fma arithmetic, so that the      */
 /* integers agree bit for bit): cpprob/detail/fastmath.hpp exp_nonpos.             */
@@ -764,6 +764,7 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
             W = (double)S * (1.0 / 4294967296.0);
             Q = (double)Q16 * (1.0 / 4294967296.0);
             ess = W * W / Q;
+            if (ess > (double)n) ess = (double)n;        /* (q >> 16)^2 under-counts Q by up to 2^-15: the estimate is kept in [.., N] */
         }
         if (ess_trace) ess_trace[t] = ess;
         if (filter_stats) {

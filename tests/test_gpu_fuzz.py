@@ -163,3 +163,22 @@ def test_random_groups_transports_and_collectives(engine, golden_dir, sweep):
         if s["step_form"] != cp.capi.FORM_FLOAT:
             assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"], tag
             np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13, err_msg=tag)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7])
+def test_tiny_populations_report_an_ess_within_the_population(engine, golden_dir, n):
+    """A handful of particles in the same state have equal weights: ESS = N exactly.  The fixed-point form's 16-bit squares under-count
+    the denominator by up to 2^-15, so the estimate is kept at N (found by an extended-seed run of the sweeps above: ESS 3.000088 of
+    3 particles); decisions and traces stay the oracle's."""
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    obs = z["hmm128"][:17]                                      # 17 steps: no trace words, ESS-triggered schedule: the fixed-point form
+    for seed in (368387191, 2082797052, 855669616, 5):
+        for ess in (0.1, 0.5, 0.9):
+            engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=ess)
+            engine.run(0)
+            ess_tr, res = engine.step_trace()
+            assert (ess_tr > 0).all() and (ess_tr <= n).all(), (n, seed, ess, ess_tr)
+            r = O.smc(cp.MODEL_HMM3, obs, n, seed, O.RESAMPLE_SYSTEMATIC, ess)
+            if engine.summary()["step_form"] == cp.capi.FORM_FIXED:
+                assert np.array_equal(res, r["resampled"]) and np.array_equal(engine.ancestors(), r["anc"]) and np.array_equal(engine.values(), r["hist"])
+                assert np.allclose(ess_tr, r["ess"], rtol=1e-12)
