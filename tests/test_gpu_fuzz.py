@@ -162,7 +162,9 @@ def test_random_groups_transports_and_collectives(engine, golden_dir, sweep):
         assert s["step_form"] == ref_sum["step_form"], tag
         if s["step_form"] != cp.capi.FORM_FLOAT:
             assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"], tag
-            np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-13, err_msg=tag)
+            # (traces, evidence and decisions: bit for bit.  The statistics are floating-point sums of per-workgroup partials whose
+            #  grouping follows the shard layout: 1.5e-13 seen in 460 extended-seed sweeps, on means of order 2)
+            np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-12, err_msg=tag)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 7])
