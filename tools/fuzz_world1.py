@@ -1,0 +1,49 @@
+# world = 1 groups with every collective executed (the rank is its own peer; the shard-totals launch carries the mailbox all-gather): random
+# models / sizes / schedules / transports against the plain run (not part of the suite; needs the GPU):
+#   python tools/fuzz_world1.py SEED COUNT                  e.g. 1 150: ~1.5 min on the box
+# (filtering-only LGSSM shards whose weights fall more than 6 nats below the step's bound are REFUSED with a message: there is no
+#  floating-point form to fall back to for them)
+import os, sys, traceback
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+import torch  # noqa
+import cpprob_amd as cp
+z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "observations.npz"))
+eng = cp.Engine(0)
+W1 = cp.capi.GROUP_WORLD1_COLLECTIVES
+bad = 0
+rng = np.random.default_rng(int(sys.argv[1]))
+for it in range(int(sys.argv[2])):
+    model, key = [(cp.MODEL_HMM3, "hmm128"), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100")][int(rng.integers(0, 2))]
+    T = int(rng.integers(1, 40))
+    obs = z[key][:T] * (1.0 + 3.0 * (rng.random() < 0.2))
+    n = int(rng.choice([1, 2, 1023, 1025, 4097, 70001, 262145, int(rng.integers(1, 1_200_000))]))
+    ess = float(rng.choice([2.0, 0.5, 0.9, 0.1]))
+    seed = int(rng.integers(0, 2**31))
+    flags = W1 | int(rng.choice([0, 0, cp.capi.GROUP_LIBRARY_COLLECTIVES, cp.capi.GROUP_SHIP_LINEAGES, cp.capi.GROUP_LIBRARY_COLLECTIVES | cp.capi.GROUP_SENDRECV]))
+    keep = 1 if rng.random() < 0.8 else 0
+    tag = "it %d model %d T %d n %d ess %.1f seed %d flags %d keep %d" % (it, model, T, n, ess, seed, flags, keep)
+    try:
+        eng.begin(cp.ALG_SMC, model, obs, n, seed=seed, ess_threshold=ess, keep_history=keep)
+        eng.run(2)
+        ref_stats, ref_sum = eng.stats().copy(), eng.summary()
+        g = cp.Group([0])
+        g.transport(flags=flags)
+        g.begin(cp.ALG_SMC, model, obs, n, seed=seed, ess_threshold=ess, keep_history=keep)
+        g.run(1); g.run(2)
+        stats, s, reruns = g.results()
+        g.close()
+        if s["step_form"] == ref_sum["step_form"] and s["step_form"] != cp.capi.FORM_FLOAT:
+            assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"], tag + " %r %r" % (s, ref_sum)
+            np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-12, err_msg=tag)
+        else:
+            assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-6 * max(1.0, abs(ref_sum["log_evidence"])) + 5.0 / np.sqrt(n), tag + " forms %d %d" % (s["step_form"], ref_sum["step_form"])
+        print("ok", tag, s["step_form"], ref_sum["step_form"], flush=True)
+    except cp.capi.CpprobHipError as e:
+        if not keep and "filtering-only shards run on the integer forms" in str(e):
+            print("refused (documented)", tag, flush=True)
+        else:
+            bad += 1; print("FAIL", tag, e, flush=True)
+    except Exception:
+        bad += 1; print("FAIL", tag, flush=True); traceback.print_exc()
+print("failures:", bad)
