@@ -165,6 +165,17 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         else
             ctx.check(cpprob_hip_smc_bookkeep(ctx.get(), opt.resampler, lw, n, opt.seed, t, last ? 1 : 0, opt.ess_threshold, ess, resd, logz, anc_out), "cpprob_hip_smc_bookkeep");
     };
+    // The context sizes its own scratch (hierarchy of sums, integer weights, normalisation partials) at the first call that needs it:
+    // one bookkeeping pass and one normalisation over zeroed log-weights before the clock starts -- allocation, like the buffers above.
+    // (Their outputs are overwritten: step 0 starts the evidence, the flag word is cleared again.)
+    if (smc && T > 0) {
+        hip_check(hipMemsetAsync(d_logw0.p, 0, n * sizeof(double), stream), "hipMemsetAsync");
+        bookkeep(d_logw0.p, 0, true, d_anc.p, d_ess_p, d_res_p, d_logz_p);
+        double warm[3];
+        ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), d_logw0.p, n, warm), "cpprob_hip_logsumexp_ess");      // (synchronises)
+        hip_check(hipMemsetAsync(d_tail.p, 0, tail_bytes, stream), "hipMemsetAsync");
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    }
     const auto t_start = std::chrono::steady_clock::now();
     double log_z = 0.0;
     int cur = 0, n_resampled = 0;
