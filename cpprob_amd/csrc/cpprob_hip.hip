@@ -2120,6 +2120,13 @@ static int lineage_args_ok(cpprob_hip_ctx* c, const void* d_anc, const void* d_r
 
 extern "C" {
 
+int cpprob_hip_lineage_prepare(cpprob_hip_ctx* c, const int32_t* h_gen, int32_t H, int32_t T)
+{
+    BB_PRELUDE(c);
+    if (!h_gen || T < 1 || H < 1) return fail(c, CPPROB_HIP_EINVAL, "need h_gen, T >= 1 and H >= 1");
+    return upload_first_rows(c, h_gen, H, T);
+}
+
 int cpprob_hip_lineage_moments(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const double* d_cols, const int32_t* h_gen, int32_t H,
                                const double* d_logw, double* h_out4)
 {

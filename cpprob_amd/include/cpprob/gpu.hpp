@@ -175,6 +175,11 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), d_logw0.p, n, warm), "cpprob_hip_logsumexp_ess");      // (synchronises)
         hip_check(hipMemsetAsync(d_tail.p, 0, tail_bytes, stream), "hipMemsetAsync");
         hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        if (windowed && !store) {                                  // (the read-out's table of which record belongs to which generation: known from the dry run)
+            std::vector<int32_t> g;
+            for (int s2 : (n_real ? st.real_row_step : st.int_hit_step)) g.push_back(std::min(s2, T - 1));
+            if (!g.empty()) ctx.check(cpprob_hip_lineage_prepare(ctx.get(), g.data(), (int32_t)g.size(), T), "cpprob_hip_lineage_prepare");
+        }
     }
     const auto t_start = std::chrono::steady_clock::now();
     double log_z = 0.0;

@@ -450,6 +450,9 @@ int cpprob_hip_lineage_gather(cpprob_hip_ctx* ctx, const int32_t* d_anc, const i
  * _hist_columns against d_logw (the FINAL generation's log-weights, n of them) returns, bit for bit, without the traces' round trip through
  * memory (StatsPrinter's numbers, reference stats_printer.hpp:68-120, when nobody asked for the traces themselves).  h_out4: [H][4] =
  * {mean, variance, logsumexp, ess}; h_out: [H][k] probabilities, 1 <= k <= 8; h_lse_ess (may be NULL): {logsumexp, ess}.  Synchronises. */
+/* Optional: uploads the records' generation table of the three calls above / below ahead of time (it is uploaded at their first use
+ * otherwise, with a synchronisation; an unchanged table is never uploaded twice). */
+int cpprob_hip_lineage_prepare(cpprob_hip_ctx* ctx, const int32_t* h_gen, int32_t H, int32_t T);
 int cpprob_hip_lineage_moments(cpprob_hip_ctx* ctx, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const double* d_cols,
                                const int32_t* h_gen, int32_t H, const double* d_logw, double* h_out4);
 int cpprob_hip_lineage_hist(cpprob_hip_ctx* ctx, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const int32_t* d_cols,
