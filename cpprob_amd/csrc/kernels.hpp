@@ -1785,12 +1785,24 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(const double* __rest
     __shared__ double s_out[8];
     const int t = blockIdx.x;
     const double W = normalise ? ctrl->W : 1.0;
+    // (the K columns' loads travel together -- unconditional, from a valid column -- instead of one round trip per column; every
+    //  thread's partial sums and the block's sums are those of one column after the other)
+    double s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.0;
+    for (int g = threadIdx.x; g < grid; g += kThreads) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = stats_part[(int64_t)(t * K + (j < K ? j : 0)) * grid + g];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
     for (int j = 0; j < K; ++j) {
-        const double* col = stats_part + (int64_t)(t * K + j) * grid;
-        double s = 0.0;
-        for (int g = threadIdx.x; g < grid; g += kThreads) s += col[g];
-        s = block_sum(s, s_scr[j]);
-        if (threadIdx.x == 0) s_out[j] = s;
+        double sj = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sj = q == j ? s[q] : sj;
+        sj = block_sum(sj, s_scr[j]);
+        if (threadIdx.x == 0) s_out[j] = sj;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
