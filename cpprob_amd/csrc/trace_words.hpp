@@ -21,7 +21,8 @@ namespace cph {
 
 constexpr int kTraceMaxT = 16;                  // 2 bits a state in a 32-bit word
 constexpr int kTraceKeys = 6;                   // (x_t, x_{T-1}) pairs with x_t in {1, 2}: key = 3 (x_t - 1) + x_{T-1}
-constexpr int kTraceSlots = 8;                  // counter sets the workgroups spread their atomic adds over
+constexpr int kTraceSlots = 2;                  // counter sets the workgroups spread their atomic adds over (same-call A/B, read-out us:
+                                                // 8 sets 14.9, 4 13.3, 2 12.4, 1 12.9 -- the last workgroup's collect is one exchange per set)
 constexpr int kTraceLine = 32;                  // 32-bit words between two counters: a 128-byte line each
 constexpr int kTraceBatch = 4;                  // tiles a workgroup has in flight: 16 particles a lane between two flushes (5-bit counters hold 31)
 constexpr size_t kTraceCounterWords = (size_t)kTraceSlots * kTraceMaxT * kTraceKeys * kTraceLine;
