@@ -300,3 +300,47 @@ int main() {
     assert p.returncode == 0, p.stderr[-3000:]
     out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "0 failed" in out.stdout, out.stdout
+
+
+_DISCRETE_PROG = r"""
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+#include <boost/random/discrete_distribution.hpp>
+int main()
+{
+    const std::array<double, 3> w{{0.2, 0.2, 0.6}};
+    boost::random::discrete_distribution<std::size_t> d{w.begin(), w.end()};
+    const auto pr = d.probabilities();
+    const double tot = (0.2 + 0.2) + 0.6;
+    if (pr.size() != 3 || pr[0] != 0.2 / tot || pr[1] != 0.2 / tot || pr[2] != 0.6 / tot) return 1;       // normalised on demand, the engine's order of sums
+    if (d.weights()[2] != 0.6 || d.min() != 0 || d.max() != 2) return 2;                                   // the weights as given
+    const std::vector<double> big{3, 1};
+    boost::random::discrete_distribution<int> e{big.begin(), big.end()};
+    if (e.probabilities()[0] != 0.75 || e.probabilities()[1] != 0.25) return 3;
+    boost::random::discrete_distribution<int> one;                                                         // boost's default: a single outcome
+    if (one.max() != 0 || one.probabilities()[0] != 1.0) return 4;
+    boost::random::discrete_distribution<int> il{1.0, 1.0, 2.0};
+    std::mt19937 g(5);
+    int cnt[3] = {0, 0, 0};
+    for (int i = 0; i < 40000; ++i) cnt[il(g)]++;
+    if (std::fabs(cnt[2] / 40000.0 - 0.5) > 0.02 || std::fabs(cnt[0] / 40000.0 - 0.25) > 0.02) return 5;
+    std::puts("ok");
+    return 0;
+}
+"""
+
+
+def test_discrete_distribution_stand_in_normalises_on_demand(tmp_path):
+    """cpprob_amd/include/boost/random/discrete_distribution.hpp (clean-room interface stand-in): construction copies the weights and
+    nothing else (a distribution built in a replayed, dead iteration of a model's loop costs no division on the device),
+    probabilities() normalises when asked -- the same numbers as normalising at construction -- and the host draw follows them."""
+    src = tmp_path / "dd.cpp"
+    src.write_text(_DISCRETE_PROG)
+    exe = str(tmp_path / "dd")
+    p = subprocess.run(["g++", "-std=c++14", "-Wall", "-I", os.path.join(ROOT, "cpprob_amd", "include"), str(src), "-o", exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
