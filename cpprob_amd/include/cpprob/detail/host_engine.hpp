@@ -134,6 +134,7 @@ inline void run_builtin_group(StateType algorithm, int model_id, const std::vect
     cfg.seed = opt.seed;
     cfg.n_particles = n; cfg.particle_offset = 0; cfg.n_global = n;
     grp.check(cpprob_hip_group_begin(grp.get(), &cfg, obs.data(), obs.size(), nullptr), "cpprob_hip_group_begin");
+    grp.check(cpprob_hip_group_sync(grp.get()), "cpprob_hip_group_sync");   // (begin's buffer clears are allocation: not the run's time)
     const auto t0 = std::chrono::steady_clock::now();
     grp.check(cpprob_hip_group_run(grp.get(), 0), "cpprob_hip_group_run");
     cpprob_hip_summary s{};
@@ -204,6 +205,7 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
     cfg.seed = opt.seed;
     cfg.n_particles = n; cfg.particle_offset = 0; cfg.n_global = n;
     ctx.check(cpprob_hip_infer_begin(ctx.get(), &cfg, obs.data(), obs.size()), "cpprob_hip_infer_begin");
+    ctx.check(cpprob_hip_sync(ctx.get()), "cpprob_hip_sync");          // (begin's buffer clears are allocation: not the run's time)
     const auto t0 = std::chrono::steady_clock::now();
     ctx.check(cpprob_hip_infer_run(ctx.get(), 0), "cpprob_hip_infer_run");
     cpprob_hip_summary s{};
