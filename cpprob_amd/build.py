@@ -30,7 +30,7 @@ def _newer(target, sources):
 def lib_sources():
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
     srcs.append(os.path.join(ROOT, "include", "cpprob_hip.h"))
-    srcs += [os.path.join(HERE, "include", "cpprob", "detail", f) for f in ("rng.hpp", "dist.hpp", "hd.hpp", "fastmath.hpp")]
+    srcs += [os.path.join(HERE, "include", "cpprob", "detail", f) for f in ("rng.hpp", "dist.hpp", "hd.hpp", "fastmath.hpp", "wave.hpp", "fixed_mass.hpp")]
     return srcs
 
 

@@ -12,33 +12,7 @@
 
 namespace cph {
 
-// A block line here: word 0 S | arrivals << 56, word 1 Q, word 2 key(M), word 3 arrivals of the maximum pass.
-__device__ __forceinline__ void bbf_publish_max(const FHier& f, int bid, int nb, uint64_t mkey)
-{
-    const Hier& h = f.h;
-    using ull = unsigned long long;
-    uint64_t* l1 = const_cast<uint64_t*>(h.lvl[1]);
-    uint64_t* l2 = const_cast<uint64_t*>(h.lvl[2]);
-    const int b1 = bid >> 6, b2 = bid >> 12;
-    const_cast<uint64_t*>(f.m0)[bid] = mkey;
-    if (h.n_lev == 2) {
-        atomicMax(reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride + 2), (ull)mkey);
-    } else if (h.n_lev == 3) {
-        ull* e = reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride);
-        atomicMax(e + 2, (ull)mkey);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // performed before the arrival is counted (no cache write-back: step_fixed.hpp)
-        const ull old = atomicAdd(e + 3, (ull)1);
-        const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
-        if ((int)old == tiles_in_block - 1) {
-            const ull totM = atomicMax(e + 2, (ull)0);
-            atomicMax(reinterpret_cast<ull*>(l2 + (int64_t)b2 * kHierStride + 2), totM);
-        }
-    }
-    // the other copy's upper levels: clean for the next step
-    if (h.n_lev >= 2 && (b1 << 6) == bid) { uint64_t* e = l1 + h.to_clear + (int64_t)b1 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; }
-    if (h.n_lev >= 3 && (b2 << 12) == bid) { uint64_t* e = l2 + h.to_clear + (int64_t)b2 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; }
-}
-
+// (bbf_publish_max, bbf_top_max, bbf_publish_mass: cpprob/detail/fixed_mass.hpp -- the unchanged-model step kernel publishes through them too)
 __global__ __launch_bounds__(kThreads) void bbf_max_kernel(const double* __restrict__ logw, int64_t n, FHier f)
 {
     __shared__ uint64_t s_red[kWaves];
@@ -54,43 +28,6 @@ __global__ __launch_bounds__(kThreads) void bbf_max_kernel(const double* __restr
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) mk = umax64(mk, s_red[w]);
         bbf_publish_max(f, (int)blockIdx.x, (int)gridDim.x, mk);
-    }
-}
-
-// the generation's largest log-weight from the top level's M words (wave-uniform)
-__device__ __forceinline__ double bbf_top_max(const FHier& f)
-{
-    const int lane = lane_id();
-    const int64_t i = (int64_t)(lane < f.h.top_n ? lane : 0) * f.h.top_stride;
-    uint64_t m = f.h.n_lev == 1 ? f.m0[i] : f.h.top[i + 2];
-    if (lane >= f.h.top_n) m = 0;
-    return dkey_inv(wave_max_u64(m));
-}
-
-__device__ __forceinline__ void bbf_publish_mass(const FHier& f, int bid, int nb, uint64_t S, uint64_t Q)
-{
-    const Hier& h = f.h;
-    using ull = unsigned long long;
-    uint64_t* l0 = const_cast<uint64_t*>(h.lvl[0]);
-    uint64_t* l1 = const_cast<uint64_t*>(h.lvl[1]);
-    uint64_t* l2 = const_cast<uint64_t*>(h.lvl[2]);
-    const int b1 = bid >> 6, b2 = bid >> 12;
-    l0[bid] = S;
-    const_cast<uint64_t*>(f.q0)[bid] = Q;
-    if (h.n_lev == 2) {
-        ull* e = reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride);
-        atomicAdd(e, (ull)S); atomicAdd(e + 1, (ull)Q);
-    } else if (h.n_lev == 3) {
-        ull* e = reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride);
-        atomicAdd(e + 1, (ull)Q);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const ull old = atomicAdd(e, (ull)(S + (1ull << 56)));
-        const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
-        if ((int)(old >> 56) == tiles_in_block - 1) {
-            const ull totQ = atomicAdd(e + 1, (ull)0);
-            ull* e2 = reinterpret_cast<ull*>(l2 + (int64_t)b2 * kHierStride);
-            atomicAdd(e2, (ull)((old + S) & kMassMask)); atomicAdd(e2 + 1, totQ);
-        }
     }
 }
 

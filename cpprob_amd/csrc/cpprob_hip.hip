@@ -150,6 +150,9 @@ struct cpprob_hip_ctx {
     // cpprob_hip_smc_bookkeep_fixed: two alternating copies of a mass hierarchy + the integer weights
     uint64_t* d_bbf_hier = nullptr; HierTable* d_bbf_table = nullptr; HierTable bbf_table{}; uint32_t* d_bbf_q = nullptr;
     size_t bbf_per_copy = 0, bbf_q0_off = 0, bbf_m0_off = 0; int bbf_nb = 0, bbf_phase = 0; size_t bbf_cap_nb = 0;
+    // cpprob_hip_generic_*: three rotating copies of a mass hierarchy, two generations of integer weights, a control block
+    uint64_t* d_gen_hier = nullptr; HierTable* d_gen_table = nullptr; HierTable gen_table{}; uint32_t* d_gen_q[2] = {nullptr, nullptr}; void* d_gen_ctrl = nullptr;
+    size_t gen_per_copy = 0, gen_q0_off = 0, gen_m0_off = 0, gen_off[3] = {0, 0, 0}; int gen_nb = 0; size_t gen_cap_nb = 0;
 
     // optional per-kernel-class timing
     bool profile = false;
@@ -783,6 +786,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent); dfree(c->d_origin); dfree(c->d_remote); dfree(c->d_annex_all);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_cols); dfree(c->d_bb_cols_part); dfree(c->d_bb_cols_stat); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q);
+    dfree(c->d_gen_hier); dfree(c->d_gen_table); dfree(c->d_gen_q[0]); dfree(c->d_gen_q[1]); dfree(c->d_gen_ctrl);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2344,6 +2348,150 @@ int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* c, const double* d_logw, size_
     HIP_TRY(c, hipGetLastError());
     return 0;
 }
+
+// ---- the unchanged-model step with the resampling inside the model's launch (include/cpprob_hip.h; cpprob/gpu.hpp) ----
+}  // extern "C"
+namespace {
+struct GenericCtrlBlock { double ref_cur, gap_max; };      // (= cpprob::device::StepCtrl2)
+
+__global__ __launch_bounds__(kThreads) void generic_quantize_kernel(const double* __restrict__ logw, int64_t n, FHier f, uint32_t* __restrict__ q, GenericCtrlBlock* ctrl)
+{
+    __shared__ uint64_t s_red[2 * kWaves];
+    __shared__ double s_ref;
+    if (wave_id() == 0) { const double r = bbf_top_max(f); if (threadIdx.x == 0) { s_ref = r; if (blockIdx.x == 0) ctrl->ref_cur = r; } }
+    __syncthreads();
+    const double ref = s_ref;
+    const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
+    U4 w;
+    uint64_t s_l = 0, q_l = 0;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const uint32_t v = j0 + k < n ? fix_weight(logw[j0 + k], ref) : 0u;
+        w[k] = v; s_l += v; q_l += (uint64_t)(v >> 16) * (uint64_t)(v >> 16);
+    }
+    *reinterpret_cast<U4*>(q + j0) = w;
+    const uint64_t sw = wave_sum_u64(s_l), qw = wave_sum_u64(q_l);
+    if (lane_id() == 0) { s_red[wave_id()] = sw; s_red[kWaves + wave_id()] = qw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t St = 0, Qt = 0;
+#pragma unroll
+        for (int k = 0; k < kWaves; ++k) { St += s_red[k]; Qt += s_red[kWaves + k]; }
+        bbf_publish_mass(f, (int)blockIdx.x, (int)gridDim.x, St, Qt);
+    }
+}
+
+__global__ __launch_bounds__(kWave) void generic_finish_kernel(FHier f, int T, double n_pop, double gap_limit, GenericCtrlBlock* ctrl, double* ess, int32_t* resampled,
+                                                               double* log_z, int32_t* flags)
+{
+    const FTot t = ftot(f);
+    if (threadIdx.x != 0) return;
+    const FixedDecision d = fixed_decide(t.S, t.Q, n_pop, 0.0, false);
+    const double ref = ctrl->ref_cur;
+    const double gap = d.W > 0.0 ? ref - t.M : 1e300;
+    ctrl->gap_max = T == 1 ? gap : fmax(ctrl->gap_max, gap);
+    if (gap < 0.0) *flags = 4;
+    else if (gap > gap_limit && *flags == 0) *flags = 5;
+    ess[T - 1] = d.ess;
+    resampled[T - 1] = 0;
+    const double lz = T == 1 ? 0.0 : *log_z;
+    *log_z = lz + ref + log(d.W / n_pop);
+}
+
+// (re)lays the three-copy hierarchy out for populations of nb tiles
+int ensure_generic(cpprob_hip_ctx* c, int nb)
+{
+    if (nb != c->gen_nb || !c->d_gen_hier) {
+        size_t per_copy = 0, off[kHierMaxLevels] = {0, 0, 0};
+        int nl = 0;
+        HierTable t{};
+        for (size_t e = (size_t)nb;; e = (e + 63) / 64) {
+            if (nl >= kHierMaxLevels) return fail(c, CPPROB_HIP_EUNSUPPORTED, "population too large for the three-level mass hierarchy");
+            off[nl] = per_copy; t.n_ent[nl] = (int)e; per_copy += e * (nl == 0 ? 1 : kHierStride); ++nl;
+            if (e <= 64) break;
+        }
+        t.n_lev = nl;
+        c->gen_q0_off = per_copy; c->gen_m0_off = per_copy + (size_t)nb; per_copy += 2 * (size_t)nb;
+        if ((size_t)nb > c->gen_cap_nb || !c->d_gen_hier) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            dfree(c->d_gen_hier); dfree(c->d_gen_q[0]); dfree(c->d_gen_q[1]);
+            HIP_TRY(c, hipMalloc(&c->d_gen_hier, 3 * per_copy * sizeof(uint64_t)));
+            for (int k = 0; k < 2; ++k) HIP_TRY(c, hipMalloc(&c->d_gen_q[k], (size_t)nb * kTile * sizeof(uint32_t)));
+            c->gen_cap_nb = (size_t)nb;
+        }
+        for (int k = 0; k < 3; ++k)
+            for (int l = 0; l < kHierMaxLevels; ++l) t.lvl[k][l] = c->d_gen_hier + (size_t)k * per_copy + off[l < nl ? l : 0];
+        if (!c->d_gen_table) HIP_TRY(c, hipMalloc(&c->d_gen_table, sizeof(HierTable)));
+        if (!c->d_gen_ctrl) HIP_TRY(c, hipMalloc(&c->d_gen_ctrl, sizeof(GenericCtrlBlock)));
+        HIP_TRY(c, hipMemcpyAsync(c->d_gen_table, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));               // (t is a local)
+        c->gen_table = t; c->gen_per_copy = per_copy; c->gen_nb = nb;
+        for (int l = 0; l < kHierMaxLevels; ++l) c->gen_off[l] = off[l];
+    }
+    return 0;
+}
+// copy `read` as the launch's view; the copy written sits `to_next` words further, the copy cleared `to_clear`
+void generic_view(const cpprob_hip_ctx* c, int read, int next, int clear, FHier& f)
+{
+    const HierTable& t = c->gen_table;
+    for (int l = 0; l < kHierMaxLevels; ++l) { f.h.lvl[l] = t.lvl[read][l]; f.h.n_ent[l] = t.n_ent[l]; }
+    f.h.n_lev = t.n_lev; f.h.table = c->d_gen_table; f.h.copy = read;
+    const int top = t.n_lev - 1;
+    f.h.top = t.lvl[read][top]; f.h.top_n = t.n_ent[top]; f.h.top_stride = top == 0 ? 1 : kHierStride;
+    f.h.to_next = (int64_t)(next - read) * (int64_t)c->gen_per_copy; f.h.to_clear = (int64_t)(clear - read) * (int64_t)c->gen_per_copy;
+    f.q0 = c->d_gen_hier + (size_t)read * c->gen_per_copy + c->gen_q0_off;
+    f.m0 = c->d_gen_hier + (size_t)read * c->gen_per_copy + c->gen_m0_off;
+}
+}  // namespace
+extern "C" {
+
+int cpprob_hip_generic_begin(cpprob_hip_ctx* c, size_t n, cpprob_hip_generic_layout* out)
+{
+    BB_PRELUDE(c);
+    if (!out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (n == 0 || n > (size_t)(1ull << 28)) return fail(c, CPPROB_HIP_EINVAL, "population size out of range (1 .. 2^28: the squares' 64-bit sum)");
+    const int nb = (int)((n + kTile - 1) / kTile);
+    if (int rc = ensure_generic(c, nb)) return rc;
+    // a run starts from clean upper levels in every copy; the weight arrays' padding slots are zero from the first step on
+    HIP_TRY(c, hipMemsetAsync(c->d_gen_hier, 0, 3 * c->gen_per_copy * sizeof(uint64_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_gen_ctrl, 0, sizeof(GenericCtrlBlock), c->stream));
+    std::memset(out, 0, sizeof *out);
+    out->hier = c->d_gen_hier; out->per_copy = c->gen_per_copy;
+    for (int l = 0; l < kHierMaxLevels; ++l) { out->lvl_off[l] = c->gen_off[l < c->gen_table.n_lev ? l : 0]; out->n_ent[l] = c->gen_table.n_ent[l]; }
+    out->n_lev = c->gen_table.n_lev; out->q0_off = c->gen_q0_off; out->m0_off = c->gen_m0_off;
+    out->table = c->d_gen_table; out->q[0] = c->d_gen_q[0]; out->q[1] = c->d_gen_q[1]; out->ctrl = c->d_gen_ctrl; out->tiles = nb;
+    return 0;
+}
+
+int cpprob_hip_generic_quantize(cpprob_hip_ctx* c, int32_t t, const double* d_logw, size_t n)
+{
+    BB_PRELUDE(c);
+    if (!d_logw || t < 0) return fail(c, CPPROB_HIP_EINVAL, "bad argument");
+    const int nb = (int)((n + kTile - 1) / kTile);
+    if (nb != c->gen_nb || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
+    FHier f{};
+    generic_view(c, t % 3, t % 3, (t + 1) % 3, f);
+    hipLaunchKernelGGL(generic_quantize_kernel, dim3(nb), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, c->d_gen_q[t & 1], static_cast<GenericCtrlBlock*>(c->d_gen_ctrl));
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int cpprob_hip_generic_finish(cpprob_hip_ctx* c, int32_t T, size_t n, double gap_limit, double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_flags)
+{
+    BB_PRELUDE(c);
+    if (!d_ess || !d_resampled || !d_log_z || !d_flags || T < 1) return fail(c, CPPROB_HIP_EINVAL, "bad argument");
+    const int nb = (int)((n + kTile - 1) / kTile);
+    if (nb != c->gen_nb || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
+    FHier f{};
+    const int k = (T - 1) % 3;
+    generic_view(c, k, k, k, f);
+    hipLaunchKernelGGL(generic_finish_kernel, dim3(1), dim3(kWave), 0, c->stream, f, (int)T, (double)n, gap_limit, static_cast<GenericCtrlBlock*>(c->d_gen_ctrl), d_ess, d_resampled,
+                       d_log_z, d_flags);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+double cpprob_hip_systematic_offset(uint64_t seed, uint64_t step) { return host_resample_u0(seed, step); }
 
 int cpprob_hip_lineage_gather(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const void* d_cols, int32_t is_int,
                               const int32_t* h_gen, int32_t H, void* d_out)

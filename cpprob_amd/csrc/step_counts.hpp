@@ -29,46 +29,11 @@
 // other: the read-out (smooth_counts_kernel / counts_filter_final_kernel) takes weights and normaliser from the counts it leaves.
 #pragma once
 #include "kernels.hpp"
+#include "cpprob/detail/fixed_mass.hpp"
 
 namespace cph {
 
-constexpr int kHierMaxLevels = 3;
-constexpr int kHierStride = 16;                // 64-bit words between entries of the levels >= 1: one 128-byte line each
-constexpr int64_t kCountsMaxTiles = 64LL * 64 * 64;
-constexpr uint64_t kCntMask = (1ull << 28) - 1;
-
-struct HierTable {                             // device-resident: every copy, every level (run-time indexed by the rare paths)
-    uint64_t* lvl[3][kHierMaxLevels];
-    int n_ent[kHierMaxLevels];                 // entries per level; n_ent[0] = tiles
-    int n_lev;                                 // levels in use: the last one has <= 64 entries
-};
-struct Hier {                                  // what a launch carries: the copy it reads, by level (compile-time indices only -- a
-    const uint64_t* lvl[kHierMaxLevels];       // run-time index into a kernel-argument array would send the struct through scratch
-    int n_ent[kHierMaxLevels];                 // memory) and where the other two copies sit relative to it
-    int n_lev;
-    int64_t to_next, to_clear;                 // word offsets from the copy read to the copy written / the copy cleared
-    const HierTable* table; int copy;          // the same hierarchy in device memory
-    const uint64_t* top; int top_n, top_stride; // the last level in use (<= 64 entries): the generation's totals
-};
-// (levels beyond n_lev point at level 0, so that a load from any level is a load from valid memory: the fetches below carry no
-//  branch, and the compiler lets them travel together instead of waiting for each in turn)
-__device__ __forceinline__ constexpr int hier_stride(int level) { return level == 0 ? 1 : kHierStride; }
-
-// ---- 32-bit wavefront sums / scans (one instruction per DPP step) -------------------------------------------------------------
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
-{
-    v += dpp_u32<kDppRowShr1>(v);
-    v += dpp_u32<kDppRowShr2>(v);
-    v += dpp_u32<kDppRowShr4>(v);
-    v += dpp_u32<kDppRowShr8>(v);
-    v += dpp_u32<kDppRowBcast15, 0xA>(v);
-    v += dpp_u32<kDppRowBcast31, 0xC>(v);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), kWave - 1); }
-
+// (hierarchy layout, 32-bit wavefront scans, prefix / probe fetches: cpprob/detail/fixed_mass.hpp)
 // Wave-uniform doubles the compiler would otherwise keep in scalar registers: the step kernel has more of them than the 102 SGPRs
 // a wave owns (58 spilled, each reloaded ~10 times, in the first build).  Laundering a value through an empty asm with a vector
 // constraint parks it in a VGPR and its arithmetic stays on the vector unit.
@@ -98,19 +63,6 @@ struct TableCdf {
     }
 };
 
-// Exclusive prefix counts at tile c (wave-uniform result; every lane of the calling wave takes part): per level, the entries that
-// precede c's block inside its parent block.  Two halves: the loads (unconditional, clamped -- issued at kernel entry, long before
-// anything needs them) and the masked sum.
-__device__ __forceinline__ void hier_prefix_fetch(const Hier& h, int c, uint64_t (&w)[kHierMaxLevels])
-{
-    const int lane = lane_id();
-#pragma unroll
-    for (int l = 0; l < kHierMaxLevels; ++l) {
-        const int blk = c >> (6 * l);                           // c's block at this level (0 at the levels not in use)
-        const int first = (blk >> 6) << 6;                      // first block of the parent
-        w[l] = h.lvl[l][(int64_t)(first + (lane < (blk & 63) ? lane : 0)) * hier_stride(l)];
-    }
-}
 __device__ __forceinline__ Cnt2 hier_prefix_sum(int c, const uint64_t (&w)[kHierMaxLevels])
 {
     const int lane = lane_id();
@@ -169,17 +121,6 @@ __device__ __forceinline__ int hier_locate(const HierTable* __restrict__ ht, int
     }
     P = Cnt2{p0, p1};
     return blk;
-}
-
-// What a probe of the tiles around `at` reads: the hierarchy words of tile cs = max(at - 1, 0)'s prefix and four tile entries.
-struct ProbeWords { uint64_t lvl[kHierMaxLevels]; uint64_t we; };
-__device__ __forceinline__ void probe_fetch(const Hier& h, int at, int nb, ProbeWords& w)
-{
-    const int cs = at > 0 ? at - 1 : 0;
-    hier_prefix_fetch(h, cs, w.lvl);
-    const int lane = lane_id();
-    const int i = cs + (lane < 4 ? lane : 0);
-    w.we = h.lvl[0][i < nb ? i : nb - 1];
 }
 
 struct CountsLds {

@@ -26,222 +26,7 @@
 
 namespace cph {
 
-constexpr double kFixScale = 4294967296.0;                  // 2^32
-constexpr double kFixInv = 1.0 / 4294967296.0;
-constexpr uint64_t kMassMask = (1ull << 56) - 1;
-
-// ---- 64-bit wavefront sums / scans / maxima -----------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ uint64_t dpp_u64(uint64_t v)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
-    return (uint64_t)lo | ((uint64_t)hi << 32);
-}
-__device__ __forceinline__ uint64_t read_lane_u64(uint64_t v, int lane)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
-    return (uint64_t)lo | ((uint64_t)hi << 32);
-}
-__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
-{
-    v += dpp_u64<kDppRowShr1>(v);
-    v += dpp_u64<kDppRowShr2>(v);
-    v += dpp_u64<kDppRowShr4>(v);
-    v += dpp_u64<kDppRowShr8>(v);
-    v += dpp_u64<kDppRowBcast15, 0xA>(v);
-    v += dpp_u64<kDppRowBcast31, 0xC>(v);
-    return v;
-}
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return read_lane_u64(wave_incl_scan_u64(v), kWave - 1); }
-__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
-{
-    v = umax64(v, dpp_u64<kDppRowShr1>(v));
-    v = umax64(v, dpp_u64<kDppRowShr2>(v));
-    v = umax64(v, dpp_u64<kDppRowShr4>(v));
-    v = umax64(v, dpp_u64<kDppRowShr8>(v));
-    v = umax64(v, dpp_u64<kDppRowBcast15, 0xA>(v));
-    v = umax64(v, dpp_u64<kDppRowBcast31, 0xC>(v));
-    return read_lane_u64(v, kWave - 1);
-}
-
-// order-preserving key of a double (an unsigned maximum of keys is the maximum of the doubles; 0 lies below every key: "empty")
-__host__ __device__ __forceinline__ uint64_t dkey(double x)
-{
-    union { double d; uint64_t u; } c; c.d = x;
-    return (c.u >> 63) ? ~c.u : (c.u | (1ull << 63));
-}
-__host__ __device__ __forceinline__ double dkey_inv(uint64_t k)
-{
-    if (k == 0) return -INFINITY;
-    union { double d; uint64_t u; } c;
-    c.u = (k >> 63) ? (k & ~(1ull << 63)) : ~k;
-    return c.d;
-}
-// an exact integer below 2^64 as the nearest double (one rounding: what a C cast does)
-__device__ __forceinline__ double u64_to_double(uint64_t c) { return fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c); }
-
-// the weight as an integer (see the header of this file); lw <= ref, or -inf (padding slots): 0
-__device__ __forceinline__ uint32_t fix_weight(double lw, double ref)
-{
-    const double e = exp_nonpos(fmax(lw - ref, -1000.0));
-    const double s = rint(e * kFixScale);
-    return s >= 4294967295.0 ? 0xffffffffu : (uint32_t)s;
-}
-
-// ---- the hierarchy's fixed-point view ------------------------------------------------------------------------------------------
-struct FHier {
-    Hier h;                                    // the S words: laid out, rotated and searched like the count hierarchy
-    const uint64_t* q0; const uint64_t* m0;    // tiles' Q and M keys of the copy read (the copy written sits h.to_next words further)
-};
-struct FTotWords { uint64_t s, q, m; };
-struct FTot { uint64_t S, Q; double M; };      // a generation's totals: mass, sum of squared 16-bit weights, largest log-weight
-
-__device__ __forceinline__ void ftot_fetch(const FHier& f, FTotWords& w)
-{
-    const int lane = lane_id();
-    const int64_t i = (int64_t)(lane < f.h.top_n ? lane : 0) * f.h.top_stride;
-    w.s = f.h.top[i];
-    w.q = f.h.n_lev == 1 ? f.q0[i] : f.h.top[i + 1];
-    w.m = f.h.n_lev == 1 ? f.m0[i] : f.h.top[i + 2];
-}
-__device__ __forceinline__ FTot ftot_sum(const FHier& f, FTotWords w)
-{
-    if (lane_id() >= f.h.top_n) { w.s = 0; w.q = 0; w.m = 0; }
-    FTot t;
-    t.S = wave_sum_u64(w.s & kMassMask); t.Q = wave_sum_u64(w.q); t.M = dkey_inv(wave_max_u64(w.m));
-    return t;
-}
-__device__ __forceinline__ FTot ftot(const FHier& f) { FTotWords w; ftot_fetch(f, w); return ftot_sum(f, w); }
-
-// exclusive prefix mass at tile c (wave-uniform; every lane of the calling wave takes part)
-__device__ __forceinline__ uint64_t fhier_prefix_sum(int c, const uint64_t (&w)[kHierMaxLevels])
-{
-    const int lane = lane_id();
-    uint64_t s = 0;
-#pragma unroll
-    for (int l = 0; l < kHierMaxLevels; ++l) s += lane < ((c >> (6 * l)) & 63) ? (w[l] & kMassMask) : 0ull;
-    return wave_sum_u64(s);
-}
-
-// The systematic comb on integer masses.  base = mass of the shards that precede this one (0 on one GPU).
-struct FixedCdf {
-    double inv, u0, n_pop; uint64_t base;
-    // first output owned by the sources that follow a LOCAL inclusive mass C
-    __device__ __forceinline__ double g(uint64_t C) const { return ceil(fma(u64_to_double(base + C), inv, -u0)); }
-};
-
-// This tile's words of generation t's hierarchy, added into the levels above, and the entries of the third copy this tile is
-// responsible for clearing.  One thread.  (step_counts.hpp: hier_publish -- here a block's line carries three words, and the last
-// tile of a block reads the two it did not get back from its own add.)
-__device__ __forceinline__ void fhier_publish(const FHier& f, int bid, int nb, uint64_t S, uint64_t Q, uint64_t mkey)
-{
-    const Hier& h = f.h;
-    uint64_t* l0 = const_cast<uint64_t*>(h.lvl[0]);
-    uint64_t* l1 = const_cast<uint64_t*>(h.lvl[1]);
-    uint64_t* l2 = const_cast<uint64_t*>(h.lvl[2]);
-    using ull = unsigned long long;
-    const int b1 = bid >> 6, b2 = bid >> 12;
-    l0[h.to_next + bid] = S;
-    const_cast<uint64_t*>(f.q0)[h.to_next + bid] = Q;
-    const_cast<uint64_t*>(f.m0)[h.to_next + bid] = mkey;
-    if (h.n_lev == 2) {
-        ull* e = reinterpret_cast<ull*>(l1 + h.to_next + (int64_t)b1 * kHierStride);
-        atomicAdd(e, (ull)S); atomicAdd(e + 1, (ull)Q); atomicMax(e + 2, (ull)mkey);
-    } else if (h.n_lev == 3) {
-        ull* e = reinterpret_cast<ull*>(l1 + h.to_next + (int64_t)b1 * kHierStride);
-        atomicAdd(e + 1, (ull)Q); atomicMax(e + 2, (ull)mkey);
-        // both have been PERFORMED (device-scope atomics execute where every XCD sees them; the counter waits for their
-        // acknowledgement) before this tile's arrival is counted -- no cache write-back: a __threadfence() here flushes the whole
-        // L2 of dirty particle rows once per workgroup (measured: 695 us per step at 10^7 particles instead of 60)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const ull old = atomicAdd(e, (ull)(S + (1ull << 56)));
-        const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
-        if ((int)(old >> 56) == tiles_in_block - 1) {
-            const uint64_t totS = (old + S) & kMassMask;
-            const ull totQ = atomicAdd(e + 1, (ull)0), totM = atomicMax(e + 2, (ull)0);       // (read where the adds were performed)
-            ull* e2 = reinterpret_cast<ull*>(l2 + h.to_next + (int64_t)b2 * kHierStride);
-            atomicAdd(e2, (ull)totS); atomicAdd(e2 + 1, totQ); atomicMax(e2 + 2, totM);
-        }
-    }
-    if (h.n_lev >= 2 && (b1 << 6) == bid) { uint64_t* e = l1 + h.to_clear + (int64_t)b1 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; }
-    if (h.n_lev >= 3 && (b2 << 12) == bid) { uint64_t* e = l2 + h.to_clear + (int64_t)b2 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; }
-}
-
-// Largest tile c in [0, nb) whose first owned output G(prefix(c)) is <= g (0 when there is none), with its exclusive prefix mass:
-// top-down descent, one load + one scan per level (step_counts.hpp: hier_locate).
-__device__ __forceinline__ int fhier_locate(const HierTable* __restrict__ ht, int copy, const FixedCdf& fc, double g, uint64_t& P)
-{
-    const int lane = lane_id();
-    int blk = 0;
-    uint64_t p = 0;
-    for (int l = ht->n_lev - 1; l >= 0; --l) {
-        const int idx = (blk << 6) + lane;
-        uint64_t w = 0;
-        const bool in = idx < ht->n_ent[l];
-        if (in) w = ht->lvl[copy][l][(int64_t)idx * (l == 0 ? 1 : kHierStride)] & kMassMask;
-        const uint64_t incl = wave_incl_scan_u64(w);
-        const uint64_t x = p + incl - w;                                                       // exclusive prefix at child `lane`
-        const bool ok = in && fc.g(x) <= g;
-        const unsigned long long m = __ballot(ok);
-        const int child = m ? (63 - __builtin_clzll(m)) : 0;                                     // (G is monotone: the set is a prefix)
-        p = read_lane_u64(x, child);
-        blk = (blk << 6) + child;
-    }
-    P = p;
-    return blk;
-}
-
-struct FLocated { int c, c_last; uint64_t P; };
-
-// The SEARCH (one wavefront): first source tile of the output tile that starts at global output gj_first, its exclusive prefix
-// mass, and the last source tile (nb when the probe cannot tell).  As counts_locate.
-__device__ __forceinline__ FLocated fixed_locate(const FHier& f, const FixedCdf& fc, int nb, double gj_first, int n_out, int guess, const ProbeWords* first)
-{
-    const int lane = lane_id();
-    const double gj_last = gj_first + (double)(n_out - 1);
-    int c = 0, c_last = nb;
-    uint64_t P = 0;
-    auto probe = [&](int at, const ProbeWords& pw, double& d_out) -> bool {
-        const int cs = at > 0 ? at - 1 : 0;
-        const uint64_t Pc = fhier_prefix_sum(cs, pw.lvl);
-        const uint64_t we = (lane < 4 && cs + lane < nb) ? (pw.we & kMassMask) : 0ull;
-        const uint64_t incl = wave_incl_scan_u64(we);
-        const uint64_t x = Pc + incl - we;                               // lanes 0..4: the prefix at cs + lane
-        const double gt = fc.g(x);
-        const bool known = lane < 5 && cs + lane < nb;
-        const unsigned long long m = __ballot(known && gt <= gj_first);
-        const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
-        d_out = gj_first - read_lane(gt, 0);
-        if ((i_lo >= 0 || cs == 0) && i_lo < 4) {
-            const int i = i_lo < 0 ? 0 : i_lo;
-            c = cs + i;
-            P = read_lane_u64(x, i);
-            const unsigned long long mh = __ballot(known && gt <= gj_last);
-            const int i_hi = mh ? (63 - __builtin_clzll(mh)) : i;
-            c_last = (i_hi >= 4 && cs + 5 < nb) ? nb : cs + (i_hi > i ? i_hi : i);
-            return true;
-        }
-        return false;
-    };
-    double d;
-    bool hit;
-    if (first) hit = probe(guess, *first, d);
-    else { ProbeWords pw; probe_fetch(f.h, guess, nb, pw); hit = probe(guess, pw, d); }
-    if (!hit) {
-        // tile masses are comparable, so the miss distance in outputs approximates the miss distance in tiles (x 1024): aim again,
-        // then descend from the top (weights so uneven that two local probes miss)
-        const double aim = (double)(guess > 0 ? guess - 1 : 0) + floor(d * (1.0 / kTile));
-        const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
-        ProbeWords pw;
-        probe_fetch(f.h, at, nb, pw);
-        if (!probe(at, pw, d)) { c = fhier_locate(f.h.table, f.h.copy, fc, gj_first, P); c_last = nb; }
-    }
-    return FLocated{c, c_last, P};
-}
-
+// (fixed-point weights, 64-bit wavefront scans, the mass hierarchy, search and decision: cpprob/detail/fixed_mass.hpp)
 struct FixedLds {
     int32_t slot[kTile];          // scatter slots of the output tile
     uint64_t scan[2][kWaves];     // per-wave totals of the in-tile scan, double-buffered across source tiles
@@ -329,21 +114,6 @@ __device__ __forceinline__ void ancestors_fixed(const FHier& f, const FixedCdf& 
     fixed_walk(fc, qprev, n, nb, last_shard, gj_first, n_out, loc, guess, false, z, z, z, anc, L);
 }
 
-// What every rank derives from a generation's totals, identically: the decision, the comb, the next reference.
-struct FixedDecision { double W, Qd, ess, inv; bool resample; };
-__device__ __forceinline__ FixedDecision fixed_decide(uint64_t S, uint64_t Q, double n_pop, double ess_frac, bool may_resample)
-{
-    FixedDecision d;
-    const double Sd = u64_to_double(S);
-    d.W = Sd * kFixInv;                                      // sum of exp(lw - R)
-    d.Qd = u64_to_double(Q) * kFixInv;                        // sum of exp(2 (lw - R)) on 16-bit weights: (q >> 16)^2 = e^2 2^32
-    const double e = d.W * d.W / d.Qd;                        // thesis p.37
-    d.ess = e > n_pop ? n_pop : e;                            // (the 16-bit squares under-count Q by up to 2^-15: equal weights would report ESS = N (1 + 3e-5))
-    d.resample = may_resample && d.ess < ess_frac * n_pop;
-    d.inv = n_pop / Sd;
-    return d;
-}
-
 // all-gathered totals of the ranks: 3 words per rank {S, Q, key(M)} (they travel as 24 bytes, whatever the collective calls them)
 struct FixedRanks { uint64_t S, Q; double M; uint64_t before; };
 __device__ __forceinline__ FixedRanks fixed_ranks(const uint64_t* __restrict__ all, int world, int rank)
@@ -377,9 +147,6 @@ struct StepFixedArgs {
     const int64_t* annex_base;
     int row_w, row_r;
 };
-
-// Reference of generation t from what is known before it exists.
-__device__ __forceinline__ double fixed_reference(bool fresh, double m_prev, double bound) { return fresh ? bound : m_prev + bound; }
 
 // Bookkeeping of generation t-1 for the host (one thread): ESS, decision, evidence.  ref_prev = R_{t-1}.
 __device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const FixedDecision& d, double ref_prev, double n_pop, double u0, double* ess_trace,

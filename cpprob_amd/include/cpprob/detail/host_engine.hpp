@@ -391,6 +391,9 @@ int probe_markov_window(const Func& f, const ObsTuple& obs, const detail::TraceS
         p.active = false;
         return !p.failed;
     };
+    detail::BoundProbe& bp = detail::bound_probe();
+    bp.expected = &st.observe_bound; bp.varies = false;
+    struct BoundGuard { detail::BoundProbe& b; ~BoundGuard() { b.expected = nullptr; } } guard{bp};
     const int windows[] = {1, 2, 4, 8};
     for (int w : windows) {
         bool ok = true;
@@ -435,7 +438,12 @@ void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>
         State::set(saved);
     }
     if (st.n_observe == 0) throw std::runtime_error("cpprob::inference: the model executes no observe statement");
-    if (algorithm == StateType::smc && options().markov_probe) st.window = probe_markov_window(f, obs, st);
+    if (algorithm == StateType::smc && options().markov_probe) {
+        st.window = probe_markov_window(f, obs, st);
+        bool known = st.observe_bound.size() == st.n_observe;
+        for (double b : st.observe_bound) if (!(b == b) || b == std::numeric_limits<double>::infinity() || b == -std::numeric_limits<double>::infinity()) known = false;
+        st.bounds_fixed = st.window >= 0 && known && !detail::bound_probe().varies;
+    }
     if (st.n_other_predicts) throw std::runtime_error("cpprob::inference: non-scalar predicts (.any file) are not supported by the device engine");
 
     const Key key = key_of(f, std::integral_constant<bool, detail::fn_traits<std::remove_cv_t<std::remove_reference_t<Func>>>::is_function>{});

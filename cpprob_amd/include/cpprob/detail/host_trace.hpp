@@ -10,6 +10,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <string>
 #include <type_traits>
@@ -36,6 +37,11 @@ struct TraceStructure {
     std::vector<std::size_t> samples_before_observe;
     std::vector<int> real_row_step, int_hit_step;
     int window = -1;                                    // >= 0: the model passed the Markov probe -- a step needs only its ancestor's last `window` samples
+    // observe #m's largest possible log-density (the distribution's density at its mode, logpdf_max) as the dry run saw it; NaN where
+    // unknown.  bounds_fixed: every trace of the Markov probe saw the same values (the distributions' scale parameters do not depend
+    // on sampled values) -- the device engine then takes its fixed-point weights against them, and verifies each generation
+    std::vector<double> observe_bound;
+    bool bounds_fixed = false;
     std::size_t id_of(const std::string& addr)
     {
         auto it = ids_.find(addr);
@@ -119,6 +125,10 @@ struct ProbeState {
 };
 struct ProbeAbort {};
 inline ProbeState& probe() { static thread_local ProbeState p; return p; }
+// (kept across the probe's runs: every run's observe #m must see the bound the structural dry run recorded)
+struct BoundProbe { const std::vector<double>* expected = nullptr; bool varies = false; };
+inline BoundProbe& bound_probe() { static thread_local BoundProbe b; return b; }
+inline bool same_bits(double a, double b) { return std::memcmp(&a, &b, sizeof a) == 0; }
 
 // variates a value consumes: one per component
 template <class T> std::size_t width_of(const T&) { return 1; }
@@ -169,10 +179,15 @@ void host_observe(Distribution& distr, const X& x)
     ProbeState& pb = probe();
     if (pb.active) {
         pb.put(static_cast<double>(logpdf<std::decay_t<Distribution>>()(distr, x)));      // what the step adds to the weight
+        BoundProbe& bp = bound_probe();
+        if (bp.expected && (pb.n_obs >= bp.expected->size() || !same_bits((*bp.expected)[pb.n_obs], logpdf_max<std::decay_t<Distribution>>()(distr)))) bp.varies = true;
         ++pb.n_obs;
         return;
     }
-    if (TraceStructure* r = recorder()) { r->samples_before_observe.push_back(r->n_sample); ++r->n_observe; }
+    if (TraceStructure* r = recorder()) {
+        r->samples_before_observe.push_back(r->n_sample); ++r->n_observe;
+        r->observe_bound.push_back(logpdf_max<std::decay_t<Distribution>>()(distr));
+    }
 }
 
 template <class V>

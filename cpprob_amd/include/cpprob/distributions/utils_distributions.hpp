@@ -52,5 +52,39 @@ struct logpdf<boost::random::poisson_distribution<IntType, RealType>> {   // uti
     { return static_cast<RealType>(cph::poisson_logpdf(static_cast<int64_t>(x), distr.mean())); }
 };
 
+// ---- the densities' maxima (utils_base.hpp: logpdf_max) -- each the functor above evaluated at the distribution's mode ----
+template <class RealType>
+struct logpdf_max<boost::random::normal_distribution<RealType>> {
+    double operator()(const boost::random::normal_distribution<RealType>& d) const
+    { return static_cast<double>(logpdf<boost::random::normal_distribution<RealType>>()(d, d.mean())); }
+};
+template <class IntType>
+struct logpdf_max<boost::random::uniform_smallint<IntType>> {
+    double operator()(const boost::random::uniform_smallint<IntType>& d) const
+    { return logpdf<boost::random::uniform_smallint<IntType>>()(d, d.min()); }
+};
+template <class IntType, class WeightType>
+struct logpdf_max<boost::random::discrete_distribution<IntType, WeightType>> {
+    double operator()(const boost::random::discrete_distribution<IntType, WeightType>& d) const
+    {
+        double m = -INFINITY;
+        for (IntType x = d.min(); x <= d.max(); ++x) { const double l = static_cast<double>(logpdf<boost::random::discrete_distribution<IntType, WeightType>>()(d, x)); if (l > m) m = l; }
+        return m;
+    }
+};
+template <class RealType>
+struct logpdf_max<boost::random::uniform_real_distribution<RealType>> {
+    double operator()(const boost::random::uniform_real_distribution<RealType>& d) const
+    { return static_cast<double>(logpdf<boost::random::uniform_real_distribution<RealType>>()(d, d.a())); }
+};
+template <class IntType, class RealType>
+struct logpdf_max<boost::random::poisson_distribution<IntType, RealType>> {
+    double operator()(const boost::random::poisson_distribution<IntType, RealType>& d) const
+    {
+        if (!(d.mean() > 0)) return __builtin_nan("");
+        return static_cast<double>(logpdf<boost::random::poisson_distribution<IntType, RealType>>()(d, static_cast<IntType>(d.mean())));   // mode = floor(mean)
+    }
+};
+
 }  // namespace cpprob
 #endif

@@ -60,17 +60,19 @@ using ModelKernelArgs = device::LaunchArgs;     // (cpprob/detail/device_trace.h
 template <class FP, FP F>
 struct FunctionCaller {
     using observes_t = tuple_observes_t<FP>;
-    CPPROB_HD static void call(const observes_t& obs) { call_f_tuple(F, obs); }
+    CPPROB_HD __attribute__((always_inline)) static void call(const observes_t& obs) { call_f_tuple(F, obs); }
 };
 template <class Functor>
 struct FunctorCaller {
     using observes_t = tuple_observes_t<Functor>;
-    CPPROB_HD static void call(const observes_t& obs) { call_f_tuple(Functor{}, obs); }
+    CPPROB_HD __attribute__((always_inline)) static void call(const observes_t& obs) { call_f_tuple(Functor{}, obs); }
 };
 
 template <class Caller, class Tuple>
 __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelArgs a, const Tuple* __restrict__ observes)
 {
+    // (what the statements may take for granted in this kernel: they read the launch's mode from the kernel-argument segment)
+    { const uint32_t fused = device::launch_args()->fused, lanes = device::launch_args()->lane_block; __builtin_assume(fused == 0u); __builtin_assume(lanes == (uint32_t)device::kLaneBlock); }
     const int64_t i = (int64_t)blockIdx.x * device::kLaneBlock + threadIdx.x;
     if (i >= a.n) return;
     const bool resampled = a.resampled_prev && *a.resampled_prev != 0;
@@ -81,20 +83,27 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
     device::finish_lane();                                        // finish_trace(): the particle's log_w_
 }
 
+// One SMC step of a model under windowed replay, the resampling INSIDE the launch (cpprob/detail/device_trace.hpp: step_prologue /
+// step_epilogue; the shape of the built-in smc_step_fixed_kernel with the model body where its propagate4 / loglik sit): ancestors by
+// the integer comb over generation t-1's fixed-point masses, the ancestor's window replayed, the step's statements, the new weight
+// quantised and the tile's mass published -- one launch per observe instead of four.  One 1024-particle tile per workgroup.
+template <class Caller, class Tuple>
+__global__ __launch_bounds__(device::kStepBlock) void model_step_kernel(ModelKernelArgs a, const Tuple* __restrict__ observes)
+{
+    (void)a;                                                      // (the statements read it where it lies: the kernel-argument segment)
+    {
+        const uint32_t fused = device::launch_args()->fused, win = device::launch_args()->windowed, lanes = device::launch_args()->lane_block;
+        __builtin_assume(fused == 1u); __builtin_assume(win == 1u); __builtin_assume(lanes == (uint32_t)device::kStepBlock);
+    }
+    device::step_prologue();
+    Caller::call(*observes);
+    device::step_epilogue();                                      // the run's last step: the body ran to completion
+}
+
 template <class Tuple> struct observes_bytewise_copyable;
 template <class... A> struct observes_bytewise_copyable<std::tuple<A...>>
 {
     static constexpr bool value = (std::is_trivially_copyable<A>::value && ...);
-};
-
-template <class T>
-struct DevBuf {
-    T* p = nullptr;
-    DevBuf() = default;
-    explicit DevBuf(size_t count) { if (count && hipMalloc(&p, count * sizeof(T)) != hipSuccess) throw std::runtime_error("hipMalloc failed"); }
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
 };
 
 inline void hip_check(hipError_t e, const char* what)
@@ -102,61 +111,173 @@ inline void hip_check(hipError_t e, const char* what)
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// ---- a context and ONE block of device memory per device, kept across cpprob::inference calls ------------------------------------
+// The reference's call is `inference(...)`, again and again (src/main.cpp:96-100): a context, its stream and every buffer of a run
+// created per call cost more than the run (hipMalloc of ~20 buffers: milliseconds).  A workspace is leased for the length of an
+// attempt; the block grows to the largest run seen and is carved anew by every attempt.  Workspaces live until
+// cpprob::gpu::release_workspaces() (or the process ends: they are deliberately not torn down by static destructors, which run when
+// the HIP runtime may already be gone).
+struct Workspace {
+    int device;
+    Context ctx;
+    char* block = nullptr; std::size_t cap = 0;
+    explicit Workspace(int d) : device(d), ctx(d) {}
+    ~Workspace() { if (block) (void)hipFree(block); }
+    bool reserve(std::size_t bytes)                                   // true: (re)allocated
+    {
+        if (bytes <= cap) return false;
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        if (block) { hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); (void)hipFree(block); block = nullptr; cap = 0; }
+        const std::size_t want = bytes + bytes / 8;
+        if (hipMalloc(reinterpret_cast<void**>(&block), want) != hipSuccess) throw std::runtime_error("hipMalloc of " + std::to_string(want) + " bytes failed");
+        cap = want;
+        return true;
+    }
+};
+struct WorkspacePool { std::mutex mu; std::vector<std::unique_ptr<Workspace>> idle; };
+inline WorkspacePool& workspace_pool() { static WorkspacePool* p = new WorkspacePool; return *p; }
+inline void release_workspaces()
+{
+    WorkspacePool& p = workspace_pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    p.idle.clear();
+}
+class WorkspaceLease {
+public:
+    explicit WorkspaceLease(int device)
+    {
+        WorkspacePool& p = workspace_pool();
+        {
+            std::lock_guard<std::mutex> lock(p.mu);
+            for (auto it = p.idle.begin(); it != p.idle.end(); ++it)
+                if ((*it)->device == device) { w_ = std::move(*it); p.idle.erase(it); break; }
+        }
+        if (!w_) { w_.reset(new Workspace(device)); fresh_ = true; }
+    }
+    ~WorkspaceLease()
+    {
+        WorkspacePool& p = workspace_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        p.idle.push_back(std::move(w_));
+    }
+    Workspace& operator*() const { return *w_; }
+    Workspace* operator->() const { return w_.get(); }
+    bool fresh() const { return fresh_; }
+private:
+    std::unique_ptr<Workspace> w_;
+    bool fresh_ = false;
+};
+// the attempt's buffers: registered with their sizes, then carved out of the workspace's block (256-byte aligned)
+class Carver {
+public:
+    template <class T> void add(T** p, std::size_t count) { items_.push_back(Item{reinterpret_cast<void**>(p), count * sizeof(T)}); }
+    bool commit(Workspace& w)
+    {
+        std::size_t total = 0;
+        for (const Item& it : items_) total += (it.bytes + 255) / 256 * 256;
+        const bool grown = w.reserve(total ? total : 256);
+        std::size_t off = 0;
+        for (const Item& it : items_) { *it.p = it.bytes ? w.block + off : nullptr; off += (it.bytes + 255) / 256 * 256; }
+        return grown;
+    }
+private:
+    struct Item { void** p; std::size_t bytes; };
+    std::vector<Item> items_;
+};
+
+// how an SMC attempt resamples
+enum class StepForm {
+    unfused,        // model launch + cpprob_hip_smc_bookkeep(_fixed): full replay, the other resamplers, the Markov pilot
+    fused_bounded,  // model_step_kernel, fixed-point weights against the dry run's per-observe bounds: ONE launch per observe
+    fused_exact     // model_step_kernel + cpprob_hip_generic_quantize against the generation's exact maximum: two launches per observe
+};
+constexpr double kFixGapLimit = 6.0;            // nats a generation's heaviest particle may sit below its reference (csrc/step_fixed.hpp: the same contract)
+
+// the launch's view of the library's mass hierarchy (include/cpprob_hip.h: cpprob_hip_generic_layout): copy `read`, where the copy
+// written / the copy cleared sit relative to it
+inline cph::FHier fused_view(const cpprob_hip_generic_layout& L, int read, int next, int clear)
+{
+    cph::FHier f{};
+    auto lvl = [&](int copy, int l) { return L.hier + (std::size_t)copy * L.per_copy + L.lvl_off[l < L.n_lev ? l : 0]; };
+    for (int l = 0; l < cph::kHierMaxLevels; ++l) { f.h.lvl[l] = lvl(read, l); f.h.n_ent[l] = L.n_ent[l]; }
+    f.h.n_lev = L.n_lev; f.h.table = static_cast<const cph::HierTable*>(L.table); f.h.copy = read;
+    const int top = L.n_lev - 1;
+    f.h.top = lvl(read, top); f.h.top_n = L.n_ent[top]; f.h.top_stride = top == 0 ? 1 : cph::kHierStride;
+    f.h.to_next = (int64_t)(next - read) * (int64_t)L.per_copy; f.h.to_clear = (int64_t)(clear - read) * (int64_t)L.per_copy;
+    f.q0 = L.hier + (std::size_t)read * L.per_copy + L.q0_off;
+    f.m0 = L.hier + (std::size_t)read * L.per_copy + L.m0_off;
+    return f;
+}
+
 // One attempt with S trace rows per particle; returns 0, or -- nothing in res is valid then -- 1 when some particle needed more rows,
 // 3 when the lanes of a wavefront executed different statements under windowed replay (the model's statement counts do depend on
-// sampled values: the caller repeats the run with full replay).
+// sampled values: the caller repeats the run with full replay), 4 when a generation's weights did not fit the reference they were
+// taken against (fused_bounded: a bound that was not one, or one so loose that the integers lost their bits: the caller repeats the
+// run in the fused_exact form).
 template <class Caller>
 int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
-                     Result& res, HostStore* store, const std::size_t S)
+                     Result& res, HostStore* store, const std::size_t S, StepForm form)
 {
     using Tuple = typename Caller::observes_t;
     // (std::tuple itself is not trivially copyable in libstdc++ even when every element is: check the elements)
     static_assert(observes_bytewise_copyable<Tuple>::value,
                   "CPPROB_REGISTER_MODEL: the observes tuple is copied to the device bytewise, so every model argument must be trivially "
                   "copyable (arithmetic types, std::array of them); models with std::vector / NDArray arguments own host heap memory");
-    Context ctx(opt.device);
+    const auto t_setup = std::chrono::steady_clock::now();
+    WorkspaceLease ws(opt.device);
+    Context& ctx = ws->ctx;
     hip_check(hipSetDevice(opt.device), "hipSetDevice");
     hipStream_t stream = static_cast<hipStream_t>(cpprob_hip_stream(ctx.get()));
     const int64_t ld = (int64_t)n;
     const size_t n_real = st.real_rows(), n_int = st.int_ids.size();        // a vector-valued real predict owns one column per component
     const int T = (int)st.n_observe;
     const bool smc = algorithm == StateType::smc;
+    const bool windowed = smc && st.window >= 0;
+    const uint32_t w = (uint32_t)std::max(1, st.window);
+    if (!(windowed && opt.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && n <= (std::size_t(1) << 28) && T > 0)) form = StepForm::unfused;
+    const bool fused = form != StepForm::unfused;
 
-    DevBuf<Tuple> d_obs(1);
-    hip_check(hipMemcpy(d_obs.p, observes_v, sizeof(Tuple), hipMemcpyHostToDevice), "copy observes");
-    DevBuf<double> d_real(n_real * n), d_logw0(n), d_logw1(smc ? n : 0);
-    DevBuf<int32_t> d_int(n_int * n), d_anc(smc ? n : 0), d_ns0(smc ? n : 0), d_ns1(smc ? n : 0);
-    DevBuf<uint64_t> d_tr0(smc ? S * n : 0), d_tr1(smc ? S * n : 0);
-    // what the host reads when the run is over, side by side -- one copy: [T] step ESS, log evidence | [T] resampling decisions, overflow flag
+    // what the host reads when the run is over, side by side -- one copy: [T] step ESS, log evidence | [T] resampling decisions, flag word
     const size_t tail_doubles = (size_t)T + 1, tail_ints = (size_t)T + 1, tail_bytes = tail_doubles * sizeof(double) + tail_ints * sizeof(int32_t);
-    DevBuf<unsigned char> d_tail(tail_bytes);
-    double* const d_ess_p = reinterpret_cast<double*>(d_tail.p);
+    Tuple* d_obs = nullptr;
+    double *d_real = nullptr, *d_logw0 = nullptr, *d_logw1 = nullptr, *d_real_gen = nullptr;
+    int32_t *d_int = nullptr, *d_anc = nullptr, *d_ns0 = nullptr, *d_ns1 = nullptr, *d_anc_all = nullptr, *d_int_gen = nullptr;
+    uint64_t *d_tr0 = nullptr, *d_tr1 = nullptr, *d_c0 = nullptr, *d_c1 = nullptr;
+    unsigned char* d_tail = nullptr;
+    Carver carve;
+    carve.add(&d_obs, 1); carve.add(&d_tail, tail_bytes);
+    carve.add(&d_real, n_real * n); carve.add(&d_logw0, n); carve.add(&d_logw1, smc ? n : 0);
+    carve.add(&d_int, n_int * n); carve.add(&d_anc, smc && !fused ? n : 0);
+    carve.add(&d_ns0, smc && !windowed ? n : 0); carve.add(&d_ns1, smc && !windowed ? n : 0);
+    carve.add(&d_tr0, smc && !windowed ? S * n : 0); carve.add(&d_tr1, smc && !windowed ? S * n : 0);
+    // (windowed replay's buffers)
+    carve.add(&d_c0, windowed ? (size_t)w * n : 0); carve.add(&d_c1, windowed ? (size_t)w * n : 0);
+    carve.add(&d_anc_all, windowed ? (size_t)T * n : 0);
+    carve.add(&d_real_gen, windowed ? n_real * n : 0); carve.add(&d_int_gen, windowed ? n_int * n : 0);
+    const bool grown = carve.commit(*ws);
+    hip_check(hipMemcpyAsync(d_obs, observes_v, sizeof(Tuple), hipMemcpyHostToDevice, stream), "copy observes");
+
+    double* const d_ess_p = reinterpret_cast<double*>(d_tail);
     double* const d_logz_p = d_ess_p + T;
-    int32_t* const d_res_p = reinterpret_cast<int32_t*>(d_tail.p + tail_doubles * sizeof(double));
+    int32_t* const d_res_p = reinterpret_cast<int32_t*>(d_tail + tail_doubles * sizeof(double));
     int32_t* const d_overflow_p = d_res_p + T;
-    hip_check(hipMemsetAsync(d_tail.p, 0, tail_bytes, stream), "hipMemsetAsync");   // on the launches' own (non-blocking) stream
+    hip_check(hipMemsetAsync(d_tail, 0, tail_bytes, stream), "hipMemsetAsync");   // on the launches' own (non-blocking) stream
     std::vector<unsigned char> h_tail(tail_bytes);
     auto read_tail = [&]() {
-        hip_check(hipMemcpyAsync(h_tail.data(), d_tail.p, tail_bytes, hipMemcpyDeviceToHost, stream), "copy the run's tail");
+        hip_check(hipMemcpyAsync(h_tail.data(), d_tail, tail_bytes, hipMemcpyDeviceToHost, stream), "copy the run's tail");
         hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
     };
     const double* const h_ess_p = reinterpret_cast<const double*>(h_tail.data());
     const int32_t* const h_res_p = reinterpret_cast<const int32_t*>(h_tail.data() + tail_doubles * sizeof(double));
-    double* logw[2] = {d_logw0.p, d_logw1.p};
-    int32_t* ns[2] = {d_ns0.p, d_ns1.p};
-    uint64_t* tr[2] = {d_tr0.p, d_tr1.p};
+    double* logw[2] = {d_logw0, d_logw1};
+    int32_t* ns[2] = {d_ns0, d_ns1};
+    uint64_t* tr[2] = {d_tr0, d_tr1};
     const dim3 grid((unsigned)((n + device::kLaneBlock - 1) / device::kLaneBlock)), block(device::kLaneBlock);
+    const size_t lane_lds = device::lane_lds_bytes(device::kLaneBlock, false);
 
     ModelKernelArgs a{};
     a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed; a.trace_cap = (uint32_t)S; a.overflow = d_overflow_p; a.pid0 = opt.particle_offset;
-    a.pred_real_cap = (uint32_t)n_real; a.pred_int_cap = (uint32_t)n_int;
-    // (windowed replay's buffers: allocated before the clock starts, like the others)
-    const bool windowed = smc && st.window >= 0;
-    const uint32_t w = (uint32_t)std::max(1, st.window);
-    DevBuf<uint64_t> d_c0(windowed ? (size_t)w * n : 0), d_c1(windowed ? (size_t)w * n : 0);
-    DevBuf<int32_t> d_anc_all(windowed ? (size_t)T * n : 0);
-    DevBuf<double> d_real_gen(windowed ? n_real * n : 0);
-    DevBuf<int32_t> d_int_gen(windowed ? n_int * n : 0);
+    a.pred_real_cap = (uint32_t)n_real; a.pred_int_cap = (uint32_t)n_int; a.lane_block = device::kLaneBlock;
     // SMC bookkeeping between two launches of the model body, on the device: systematic resampling runs on fixed-point weights
     // (integer masses: three short launches, cpprob_amd/csrc/bookkeep_fixed.hpp), the other resamplers on the floating-point CDF
     auto bookkeep = [&](const double* lw, int t, bool last, int32_t* anc_out, double* ess, int32_t* resd, double* logz) {
@@ -165,23 +286,28 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         else
             ctx.check(cpprob_hip_smc_bookkeep(ctx.get(), opt.resampler, lw, n, opt.seed, t, last ? 1 : 0, opt.ess_threshold, ess, resd, logz, anc_out), "cpprob_hip_smc_bookkeep");
     };
-    // The context sizes its own scratch (hierarchy of sums, integer weights, normalisation partials) at the first call that needs it:
-    // one bookkeeping pass and one normalisation over zeroed log-weights before the clock starts -- allocation, like the buffers above.
-    // (Their outputs are overwritten: step 0 starts the evidence, the flag word is cleared again.)
-    if (smc && T > 0) {
-        hip_check(hipMemsetAsync(d_logw0.p, 0, n * sizeof(double), stream), "hipMemsetAsync");
-        bookkeep(d_logw0.p, 0, true, d_anc.p, d_ess_p, d_res_p, d_logz_p);
+    cpprob_hip_generic_layout lay{};
+    if (fused) {
+        ctx.check(cpprob_hip_generic_begin(ctx.get(), n, &lay), "cpprob_hip_generic_begin");      // (sizes at the first call; clears are stream-ordered)
+    } else if (smc && T > 0) {
+        // The context sizes its own scratch (hierarchy of sums, integer weights, normalisation partials) at the first call that needs it:
+        // one bookkeeping pass and one normalisation over zeroed log-weights before the clock starts -- allocation, like the buffers above.
+        // (Their outputs are overwritten: step 0 starts the evidence, the flag word is cleared again.)
+        hip_check(hipMemsetAsync(d_logw0, 0, n * sizeof(double), stream), "hipMemsetAsync");
+        bookkeep(d_logw0, 0, true, d_anc, d_ess_p, d_res_p, d_logz_p);
         double warm[3];
-        ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), d_logw0.p, n, warm), "cpprob_hip_logsumexp_ess");      // (synchronises)
-        hip_check(hipMemsetAsync(d_tail.p, 0, tail_bytes, stream), "hipMemsetAsync");
-        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-        if (windowed && !store) {                                  // (the read-out's table of which record belongs to which generation: known from the dry run)
-            std::vector<int32_t> g;
-            for (int s2 : (n_real ? st.real_row_step : st.int_hit_step)) g.push_back(std::min(s2, T - 1));
-            if (!g.empty()) ctx.check(cpprob_hip_lineage_prepare(ctx.get(), g.data(), (int32_t)g.size(), T), "cpprob_hip_lineage_prepare");
-        }
+        ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), d_logw0, n, warm), "cpprob_hip_logsumexp_ess");      // (synchronises)
+        hip_check(hipMemsetAsync(d_tail, 0, tail_bytes, stream), "hipMemsetAsync");
     }
+    if (windowed && !store && T > 0) {                             // (the read-out's table of which record belongs to which generation: known from the dry run)
+        std::vector<int32_t> g;
+        for (int s2 : (n_real ? st.real_row_step : st.int_hit_step)) g.push_back(std::min(s2, T - 1));
+        if (!g.empty()) ctx.check(cpprob_hip_lineage_prepare(ctx.get(), g.data(), (int32_t)g.size(), T), "cpprob_hip_lineage_prepare");
+    }
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
     const auto t_start = std::chrono::steady_clock::now();
+    res.setup_seconds += std::chrono::duration<double>(t_start - t_setup).count();
+    res.workspace_grown = res.workspace_grown || grown || ws.fresh();
     double log_z = 0.0;
     int cur = 0, n_resampled = 0;
     bool stats_on_walk = false;                                       // windowed SMC without a particle store: the read-out rode the lineage walk
@@ -189,33 +315,57 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     double walk_lse_ess[2] = {0.0, 0.0};
     bool smc_log_z_done = false;
     res.step_ess.clear();
+    res.launches_per_step = 1;
     if (!smc) {
-        a.logw_out = logw[0]; a.pred_real = d_real.p; a.pred_int = d_int.p; a.first_observe = 0; a.stop_after = -1;
-        hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
+        a.logw_out = logw[0]; a.pred_real = d_real; a.pred_int = d_int; a.first_observe = 0; a.stop_after = -1;
+        hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, lane_lds, stream, a, (const Tuple*)d_obs);
         hip_check(hipGetLastError(), "model_kernel");
     } else if (windowed) {
         // Windowed replay: the host probe found that a step depends on its ancestor's last `w` samples only.  Per step ONE gather of
         // w carried values and one row of new ones -- the traffic of the hand-fused kernels -- instead of re-reading and re-writing
         // the whole trace; every launch records the predicts of its own step, ancestors are kept per step, and the traces are read
         // out once at the end by walking the lineages (cpprob_hip_lineage_gather).
-        uint64_t* carry[2] = {d_c0.p, d_c1.p};
+        uint64_t* carry[2] = {d_c0, d_c1};
         a.windowed = 1; a.win = w;
+        const dim3 sgrid((unsigned)lay.tiles), sblock(device::kStepBlock);
+        const size_t step_lds = device::lane_lds_bytes(device::kStepBlock, true);
+        if (fused) {
+            a.lane_block = device::kStepBlock; a.fused = 1;
+            a.fs.ess_frac = opt.ess_threshold; a.fs.n_pop = (double)n; a.fs.T = T; a.fs.nb = lay.tiles;
+            a.fs.may_carry = opt.ess_threshold > 1.0 ? 0 : 1; a.fs.exact_ref = form == StepForm::fused_exact ? 1 : 0;
+            a.fs.ctrl = static_cast<device::StepCtrl2*>(lay.ctrl); a.fs.ess = d_ess_p; a.fs.resampled = d_res_p; a.fs.log_z = d_logz_p;
+            a.fs.gap_limit = kFixGapLimit;
+            res.launches_per_step = form == StepForm::fused_exact ? 2 : 1;
+        } else res.launches_per_step = 4;
         for (int t = 0; t < T; ++t) {
             const bool last = t + 1 == T;
-            a.anc = t > 0 ? d_anc_all.p + (size_t)t * n : nullptr;
-            a.resampled_prev = t > 0 ? d_res_p + (t - 1) : nullptr;
             a.logw_in = t > 0 ? logw[cur] : nullptr;
             a.logw_out = logw[cur ^ 1];
             a.carry_in = t > 0 ? carry[cur] : nullptr; a.carry_out = last ? nullptr : carry[cur ^ 1];
             a.fresh_lo = t > 0 ? (int32_t)st.samples_before_observe[(size_t)t - 1] : 0;
             a.next_fresh = (int32_t)st.samples_before_observe[(size_t)t];
-            a.pred_real = d_real_gen.p; a.pred_int = d_int_gen.p;
+            a.pred_real = d_real_gen; a.pred_int = d_int_gen;
             a.first_observe = t; a.stop_after = last ? -1 : t;
-            hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
+            if (fused) {
+                a.fs.f = fused_view(lay, (t + 2) % 3, t % 3, (t + 1) % 3);
+                a.fs.q_prev = lay.q[(t + 1) & 1]; a.fs.q_next = lay.q[t & 1];
+                a.fs.u0 = cpprob_hip_systematic_offset(opt.seed, (uint64_t)t);
+                a.fs.bound = form == StepForm::fused_bounded ? st.observe_bound[(size_t)t] : 0.0;
+                a.fs.t = t; a.fs.anc_row = d_anc_all + (size_t)t * n;
+                hipLaunchKernelGGL((model_step_kernel<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+                hip_check(hipGetLastError(), "model_step_kernel");
+                cur ^= 1;
+                if (form == StepForm::fused_exact) ctx.check(cpprob_hip_generic_quantize(ctx.get(), t, logw[cur], n), "cpprob_hip_generic_quantize");
+                continue;
+            }
+            a.anc = t > 0 ? d_anc_all + (size_t)t * n : nullptr;
+            a.resampled_prev = t > 0 ? d_res_p + (t - 1) : nullptr;
+            hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, lane_lds, stream, a, (const Tuple*)d_obs);
             hip_check(hipGetLastError(), "model_kernel");
             cur ^= 1;
-            bookkeep(logw[cur], t, last, last ? d_anc.p : d_anc_all.p + (size_t)(t + 1) * n, d_ess_p, d_res_p, d_logz_p);
+            bookkeep(logw[cur], t, last, last ? d_anc : d_anc_all + (size_t)(t + 1) * n, d_ess_p, d_res_p, d_logz_p);
         }
+        if (fused) ctx.check(cpprob_hip_generic_finish(ctx.get(), T, n, kFixGapLimit, d_ess_p, d_res_p, d_logz_p, d_overflow_p), "cpprob_hip_generic_finish");
         // traces: hit h was recorded in the slots of generation step(h); follow every final particle's lineage back to it.  When
         // nobody asked for the traces themselves, StatsPrinter's numbers are taken on that walk (cpprob_hip_lineage_moments / _hist).
         auto gens = [&](const std::vector<int>& steps) { std::vector<int32_t> g; for (int s2 : steps) g.push_back(std::min(s2, T - 1)); return g; };
@@ -223,22 +373,22 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
             if (n_real) {
                 const std::vector<int32_t> g = gens(st.real_row_step);
                 walk_real.resize(4 * n_real);
-                ctx.check(cpprob_hip_lineage_moments(ctx.get(), d_anc_all.p, d_res_p, T, n, d_real_gen.p, g.data(), (int32_t)g.size(), logw[cur], walk_real.data()), "cpprob_hip_lineage_moments");
+                ctx.check(cpprob_hip_lineage_moments(ctx.get(), d_anc_all, d_res_p, T, n, d_real_gen, g.data(), (int32_t)g.size(), logw[cur], walk_real.data()), "cpprob_hip_lineage_moments");
             }
             if (n_int) {
                 const std::vector<int32_t> g = gens(st.int_hit_step);
                 walk_int.resize(8 * n_int);
-                ctx.check(cpprob_hip_lineage_hist(ctx.get(), d_anc_all.p, d_res_p, T, n, d_int_gen.p, g.data(), (int32_t)g.size(), logw[cur], 8, walk_int.data(), walk_lse_ess), "cpprob_hip_lineage_hist");
+                ctx.check(cpprob_hip_lineage_hist(ctx.get(), d_anc_all, d_res_p, T, n, d_int_gen, g.data(), (int32_t)g.size(), logw[cur], 8, walk_int.data(), walk_lse_ess), "cpprob_hip_lineage_hist");
             }
             stats_on_walk = true;
         } else {
         if (n_real) {
             const std::vector<int32_t> g = gens(st.real_row_step);
-            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all.p, d_res_p, T, n, d_real_gen.p, 0, g.data(), (int32_t)g.size(), d_real.p), "cpprob_hip_lineage_gather");
+            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all, d_res_p, T, n, d_real_gen, 0, g.data(), (int32_t)g.size(), d_real), "cpprob_hip_lineage_gather");
         }
         if (n_int) {
             const std::vector<int32_t> g = gens(st.int_hit_step);
-            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all.p, d_res_p, T, n, d_int_gen.p, 1, g.data(), (int32_t)g.size(), d_int.p), "cpprob_hip_lineage_gather");
+            ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all, d_res_p, T, n, d_int_gen, 1, g.data(), (int32_t)g.size(), d_int), "cpprob_hip_lineage_gather");
         }
         }
         read_tail();
@@ -248,21 +398,22 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         smc_log_z_done = true;
         res.replay_window = (int)w;
     } else {
+        res.launches_per_step = 4;
         for (int t = 0; t < T; ++t) {
             const bool last = t + 1 == T;
-            a.anc = t > 0 ? d_anc.p : nullptr;
+            a.anc = t > 0 ? d_anc : nullptr;
             a.resampled_prev = t > 0 ? d_res_p + (t - 1) : nullptr;
             a.logw_in = t > 0 ? logw[cur] : nullptr;
             a.logw_out = logw[cur ^ 1];
             a.trace_in = t > 0 ? tr[cur] : nullptr; a.trace_out = tr[cur ^ 1];
             a.nstored_in = t > 0 ? ns[cur] : nullptr; a.nstored_out = ns[cur ^ 1];
-            a.pred_real = last ? d_real.p : nullptr; a.pred_int = last ? d_int.p : nullptr;
+            a.pred_real = last ? d_real : nullptr; a.pred_int = last ? d_int : nullptr;
             a.first_observe = t; a.stop_after = last ? -1 : t;
-            hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, 0, stream, a, (const Tuple*)d_obs.p);
+            hipLaunchKernelGGL((model_kernel<Caller, Tuple>), grid, block, lane_lds, stream, a, (const Tuple*)d_obs);
             hip_check(hipGetLastError(), "model_kernel");
             cur ^= 1;
             // normalise, ESS test (thesis p.37), evidence, ancestors of the next generation: all on the device
-            bookkeep(logw[cur], t, last, d_anc.p, d_ess_p, d_res_p, d_logz_p);
+            bookkeep(logw[cur], t, last, d_anc, d_ess_p, d_res_p, d_logz_p);
         }
         read_tail();
         res.step_ess.assign(h_ess_p, h_ess_p + T);
@@ -270,6 +421,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         for (int t = 0; t < T; ++t) n_resampled += h_res_p[t];
         smc_log_z_done = true;
     }
+    res.step_form = fused ? (form == StepForm::fused_exact ? 2 : 1) : 0;
     fill_predict_names(res, st);
     double lse_ess[2] = {0.0, 0.0};
     bool have_norm = false;
@@ -277,7 +429,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     if (n_real) {
         std::vector<double> o4(4 * n_real);
         if (stats_on_walk) o4 = walk_real;
-        else ctx.check(cpprob_hip_weighted_moments_columns(ctx.get(), d_real.p, n_real, n, logw[cur], n, o4.data()), "cpprob_hip_weighted_moments_columns");
+        else ctx.check(cpprob_hip_weighted_moments_columns(ctx.get(), d_real, n_real, n, logw[cur], n, o4.data()), "cpprob_hip_weighted_moments_columns");
         lse_ess[0] = o4[2]; lse_ess[1] = o4[3]; have_norm = true;
         for (size_t k = 0, row = 0; k < st.real_ids.size(); ++k) {
             PredictStats& p = res.predicts[k];
@@ -289,7 +441,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     if (n_int) {
         std::vector<double> h(8 * n_int);
         if (stats_on_walk) { h = walk_int; if (!have_norm) { lse_ess[0] = walk_lse_ess[0]; lse_ess[1] = walk_lse_ess[1]; } }
-        else ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int.p, n_int, n, logw[cur], n, 8, h.data(), have_norm ? nullptr : lse_ess), "cpprob_hip_weighted_hist_columns");
+        else ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int, n_int, n, logw[cur], n, 8, h.data(), have_norm ? nullptr : lse_ess), "cpprob_hip_weighted_hist_columns");
         have_norm = true;
         for (size_t k = 0; k < n_int; ++k) {
             int top = 8;
@@ -309,15 +461,17 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         store->n = n;
         store->logw.resize(n); store->real.resize(n_real * n); store->ints.resize(n_int * n);
         hip_check(hipMemcpyAsync(store->logw.data(), logw[cur], n * sizeof(double), hipMemcpyDeviceToHost, stream), "copy logw");
-        if (n_real) hip_check(hipMemcpyAsync(store->real.data(), d_real.p, n_real * n * sizeof(double), hipMemcpyDeviceToHost, stream), "copy real predicts");
-        if (n_int) hip_check(hipMemcpyAsync(store->ints.data(), d_int.p, n_int * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy int predicts");
+        if (n_real) hip_check(hipMemcpyAsync(store->real.data(), d_real, n_real * n * sizeof(double), hipMemcpyDeviceToHost, stream), "copy real predicts");
+        if (n_int) hip_check(hipMemcpyAsync(store->ints.data(), d_int, n_int * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy int predicts");
     }
     if (!smc) read_tail(); else hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");    // (SMC: the tail was read when the last launch had been issued)
     const int32_t overflow = h_res_p[T];
     if (overflow == 2)
         throw std::runtime_error("cpprob::inference: a particle executed more predict statements than the model's dry run did; the number "
                                  "and order of observe / predict statements must not depend on sampled values on the device path");
-    return overflow == 3 ? 3 : (overflow != 0 ? 1 : 0);
+    if (overflow == 3) return 3;
+    if (overflow == 4 || overflow == 5) return 4;
+    return overflow != 0 ? 1 : 0;
 }
 
 template <class Caller>
@@ -334,8 +488,9 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     if (algorithm == StateType::smc && st.window >= 0 && opt.markov_crosscheck) {
         // The host probe saw a handful of traces; a dependence on older samples that shows on one trace in a thousand passes it.  So
         // the window is certified on the device before it is used: a pilot population under windowed replay and under full replay
-        // -- same particle ids, same seed, hence the same variates, weights and ancestors if the window is right -- must agree in
-        // every bit of every weight and predict.  Once per model, trace shape and window in this process.
+        // -- same particle ids, same seed, same bookkeeping between the launches, hence the same variates, weights and ancestors if
+        // the window is right -- must agree in every bit of every weight and predict.  Once per model, trace shape and window in
+        // this process.
         static std::mutex mu;
         static std::map<std::tuple<std::size_t, std::size_t, int>, bool> certified;
         const auto key = std::make_tuple((std::size_t)st.n_observe, (std::size_t)st.n_sample, st.window);
@@ -345,23 +500,32 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
             const std::size_t n_pilot = std::min<std::size_t>(n, 8192);
             Result r_win, r_full;
             HostStore s_win, s_full;
-            const int rc_win = generic_attempt<Caller>(algorithm, observes_v, n_pilot, st, opt, r_win, &s_win, S);
-            const int rc_full = rc_win == 0 ? generic_attempt<Caller>(algorithm, observes_v, n_pilot, st_full, opt, r_full, &s_full, S) : 1;
+            // (a pilot that runs out of trace rows -- rejection-sampling loops -- says nothing about the window: more rows, again)
+            std::size_t Sp = S;
+            int rc_win = 1, rc_full = 1;
+            for (int k = 0; k < 4 && (rc_win == 1 || rc_full == 1); ++k, Sp *= 4) {
+                rc_win = generic_attempt<Caller>(algorithm, observes_v, n_pilot, st, opt, r_win, &s_win, Sp, StepForm::unfused);
+                rc_full = (rc_win == 0 || rc_win == 1) ? generic_attempt<Caller>(algorithm, observes_v, n_pilot, st_full, opt, r_full, &s_full, Sp, StepForm::unfused) : rc_win;
+            }
             auto same = [](const std::vector<double>& x, const std::vector<double>& y) {
                 return x.size() == y.size() && (x.empty() || std::memcmp(x.data(), y.data(), x.size() * sizeof(double)) == 0);
             };
+            const bool decided = (rc_win == 0 && rc_full == 0) || rc_win == 3;
             ok = rc_win == 0 && rc_full == 0 && same(s_win.logw, s_full.logw) && same(s_win.real, s_full.real) && s_win.ints == s_full.ints &&
                  std::memcmp(&r_win.log_evidence, &r_full.log_evidence, sizeof(double)) == 0;
-            std::lock_guard<std::mutex> lock(mu);
-            certified[key] = ok;
+            res.setup_seconds += r_win.setup_seconds + r_win.run_seconds + r_full.setup_seconds + r_full.run_seconds;
+            if (decided) { std::lock_guard<std::mutex> lock(mu); certified[key] = ok; }      // (only a verdict is remembered: a refuted window, or a certified one)
         }
         res.markov_crosscheck = ok ? 1 : -1;
         if (!ok) use = &st_full;
     }
-    for (int attempt = 0; attempt < 5; ++attempt) {
-        const int rc = generic_attempt<Caller>(algorithm, observes_v, n, *use, opt, res, store, S);
+    StepForm form = st.bounds_fixed ? StepForm::fused_bounded : StepForm::fused_exact;
+    if (opt.step_form_override >= 0) form = static_cast<StepForm>(opt.step_form_override);
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        const int rc = generic_attempt<Caller>(algorithm, observes_v, n, *use, opt, res, store, S, form);
         if (rc == 0) return;
         if (rc == 3) use = &st_full;                               // the device saw what the host probe did not: replay the whole trace
+        else if (rc == 4) form = StepForm::fused_exact;             // a generation did not fit its bound: references from exact maxima
         else S *= 4;
     }
     throw std::runtime_error("cpprob::inference(smc): a particle executed more than " + std::to_string(S / 4) + " sample statements "

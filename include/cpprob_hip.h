@@ -36,7 +36,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define CPPROB_HIP_ABI_VERSION 2
+#define CPPROB_HIP_ABI_VERSION 3
 
 /* error codes */
 #define CPPROB_HIP_OK 0
@@ -440,6 +440,37 @@ int cpprob_hip_smc_bookkeep(cpprob_hip_ctx* ctx, int32_t kind, const double* d_l
  * masses -- three short launches, no floating-point CDF; uniforms as above.  d_anc may be NULL when last != 0.  n <= 2^28. */
 int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* ctx, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last, double ess_frac,
                                   double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc);
+/* ---- SMC step of an UNCHANGED model with the resampling inside the model's own launch (cpprob_amd/include/cpprob/gpu.hpp:
+ * model_step_kernel; replaces the loop body of reference include/cpprob/cpprob.hpp:194-201 for StateType::smc) ----------------------
+ * The model translation unit owns the kernel (it is a template over the model function); the library owns what the kernel's
+ * prologue and epilogue work on: three rotating copies of the 64-ary mass hierarchy (cpprob_amd/include/cpprob/detail/fixed_mass.hpp),
+ * the integer weights of two generations and a small control block.  cpprob_hip_generic_begin sizes them for a population of n
+ * particles (1024-particle tiles; first call and growth allocate), clears them on the context's stream and describes them in *out;
+ * step t of the run reads copy (t + 2) % 3 of the hierarchy, publishes into copy t % 3 and clears the upper levels of copy
+ * (t + 1) % 3; integer weights: generation t in q[t & 1].  n <= 2^28. */
+typedef struct cpprob_hip_generic_layout {
+    uint64_t* hier;            /* [3][per_copy] 64-bit words */
+    uint64_t per_copy;
+    uint64_t lvl_off[3];       /* word offset of each level inside a copy */
+    int32_t n_ent[3];          /* entries per level (n_ent[0] = tiles) */
+    int32_t n_lev;
+    uint64_t q0_off, m0_off;   /* the tiles' squares / maxima inside a copy */
+    void* table;               /* the same layout in device memory (fixed_mass.hpp: HierTable) */
+    uint32_t* q[2];            /* [tiles * 1024] integer weights, by the step's parity */
+    void* ctrl;                /* device_trace.hpp: StepCtrl2 */
+    int32_t tiles;
+    int32_t reserved;
+} cpprob_hip_generic_layout;
+int cpprob_hip_generic_begin(cpprob_hip_ctx* ctx, size_t n, cpprob_hip_generic_layout* out);
+/* Exact-reference form (no host-known bound of a step's log-likelihood): the step's launch published the tiles' maxima into copy
+ * t % 3; this launch quantises d_logw[0..n) against the generation's exact maximum into q[t & 1] and publishes the masses. */
+int cpprob_hip_generic_quantize(cpprob_hip_ctx* ctx, int32_t t, const double* d_logw, size_t n);
+/* Bookkeeping of the run's LAST generation (T - 1: the copy (T - 1) % 3): d_ess[T-1], d_resampled[T-1] = 0, the final term of
+ * *d_log_z; *d_flags gets 4 / 5 where the generation's heaviest particle sat above / more than gap_limit below its reference. */
+int cpprob_hip_generic_finish(cpprob_hip_ctx* ctx, int32_t T, size_t n, double gap_limit, double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_flags);
+/* The systematic offset in [0, 1) of the resampling that precedes step `step`: Philox draw (1 << 40) + step of group 0 --
+ * a pure function of (seed, step), evaluated on the host so that launches carry it as an argument. */
+double cpprob_hip_systematic_offset(uint64_t seed, uint64_t step);
 /* Traces from per-step records: d_anc [T][n] (row t: slot of generation t-1 that slot i of generation t extends; a row counts only where
  * d_resampled[t-1] != 0), d_cols [H][n] with row h recorded in the slots of generation h_gen[h] (non-decreasing in h).  d_out[h][i] =
  * d_cols[h][slot of generation h_gen[h] on the ancestral line of FINAL particle i]: the value particle i's trace holds for that row.

@@ -69,6 +69,9 @@ def lib():
         L.orc_smc.restype = C.c_int
         L.orc_smc.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
                               C.POINTER(dbl), _dp, _ip]
+        L.orc_smc_ref.restype = C.c_int
+        L.orc_smc_ref.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_int, C.c_void_p, C.c_void_p, _ip, _dp,
+                                  C.POINTER(dbl), _dp, _ip]
         L.orc_smc_filter.restype = C.c_int
         L.orc_smc_filter.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
                                      C.POINTER(dbl), _dp, _ip, _dp]
@@ -246,6 +249,28 @@ def smc(model, obs, n, seed, resampler=RESAMPLE_SYSTEMATIC, ess_frac=2.0):
     if rc:
         raise RuntimeError("orc_smc failed rc=%d" % rc)
     return dict(hist=hist, anc=anc, logw=logw, log_z=lz.value, ess=ess, resampled=res, filter=filt)
+
+
+REF_MODEL_BOUND, REF_STATEMENT_BOUND, REF_EXACT_MAX = 0, 1, 2
+
+
+def smc_ref(model, obs, n, seed, ref_mode, resampler=RESAMPLE_SYSTEMATIC, ess_frac=2.0):
+    """SMC with the fixed-point reference chosen as the unchanged-model path chooses it (cpprob/gpu.hpp: StepForm):
+    REF_STATEMENT_BOUND = the observe statement's density at its mode, REF_EXACT_MAX = the generation's exact maximum."""
+    obs = np.ascontiguousarray(obs, np.float64)
+    T = len(obs)
+    anc = np.zeros((T, n), np.int32)
+    logw = np.zeros(n)
+    ess = np.zeros(T)
+    res = np.zeros(T, np.int32)
+    lz = C.c_double(0.0)
+    is_int = is_int_model(model)
+    hist = np.zeros((T, n), np.int32 if is_int else np.float64)
+    rc = lib().orc_smc_ref(model, obs, T, n, seed, resampler, ess_frac, ref_mode, None if is_int else hist.ctypes.data, hist.ctypes.data if is_int else None,
+                           anc, logw, C.byref(lz), ess, res)
+    if rc:
+        raise RuntimeError("orc_smc_ref failed rc=%d" % rc)
+    return dict(hist=hist, anc=anc, logw=logw, log_z=lz.value, ess=ess, resampled=res)
 
 
 def smoothing(hist, anc, logw, k=3):

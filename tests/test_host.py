@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (cpprob_hip_\w+)", out))
     assert set(declared) <= exported
     L = cpprob_amd.load_library()
-    assert L.cpprob_hip_abi_version() == 2
+    assert L.cpprob_hip_abi_version() == 3
     # nothing but the C ABI is exported (no C++ symbols leak)
     assert not [l for l in out.splitlines() if " T " in l and "cpprob_hip_" not in l and "_init" not in l and "_fini" not in l]
 
