@@ -2354,13 +2354,24 @@ int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* c, const double* d_logw, size_
 namespace {
 struct GenericCtrlBlock { double ref_cur, gap_max; };      // (= cpprob::device::StepCtrl2)
 
-__global__ __launch_bounds__(kThreads) void generic_quantize_kernel(const double* __restrict__ logw, int64_t n, FHier f, uint32_t* __restrict__ q, GenericCtrlBlock* ctrl)
+// Exact-reference form of the unchanged-model step: the hierarchy's entries are 256-particle BLOCKS (one per workgroup of the model's
+// step kernel); these two passes run a 1024-particle tile per workgroup, so every wavefront owns one block and publishes it itself.
+constexpr int kGenBlock = 256;
+__global__ __launch_bounds__(kThreads) void generic_max_kernel(const double* __restrict__ logw, int64_t n, FHier f, int n_blocks)
 {
-    __shared__ uint64_t s_red[2 * kWaves];
-    __shared__ double s_ref;
-    if (wave_id() == 0) { const double r = bbf_top_max(f); if (threadIdx.x == 0) { s_ref = r; if (blockIdx.x == 0) ctrl->ref_cur = r; } }
-    __syncthreads();
-    const double ref = s_ref;
+    const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
+    double m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) if (j0 + k < n) m = fmax(m, logw[j0 + k]);
+    const uint64_t mw = wave_max_u64(dkey(m));
+    const int blk = (int)blockIdx.x * kWaves + wave_id();
+    if (lane_id() == 0 && blk < n_blocks) bbf_publish_max(f, blk, n_blocks, mw);
+}
+
+__global__ __launch_bounds__(kThreads) void generic_quantize_kernel(const double* __restrict__ logw, int64_t n, FHier f, int n_blocks, uint32_t* __restrict__ q, GenericCtrlBlock* ctrl)
+{
+    const double ref = bbf_top_max(f);                                  // (every wavefront: the same <= 64 words)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->ref_cur = ref;
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
     U4 w;
     uint64_t s_l = 0, q_l = 0;
@@ -2371,14 +2382,8 @@ __global__ __launch_bounds__(kThreads) void generic_quantize_kernel(const double
     }
     *reinterpret_cast<U4*>(q + j0) = w;
     const uint64_t sw = wave_sum_u64(s_l), qw = wave_sum_u64(q_l);
-    if (lane_id() == 0) { s_red[wave_id()] = sw; s_red[kWaves + wave_id()] = qw; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t St = 0, Qt = 0;
-#pragma unroll
-        for (int k = 0; k < kWaves; ++k) { St += s_red[k]; Qt += s_red[kWaves + k]; }
-        bbf_publish_mass(f, (int)blockIdx.x, (int)gridDim.x, St, Qt);
-    }
+    const int blk = (int)blockIdx.x * kWaves + wave_id();
+    if (lane_id() == 0 && blk < n_blocks) bbf_publish_mass(f, blk, n_blocks, sw, qw);
 }
 
 __global__ __launch_bounds__(kWave) void generic_finish_kernel(FHier f, int T, double n_pop, double gap_limit, GenericCtrlBlock* ctrl, double* ess, int32_t* resampled,
@@ -2398,7 +2403,7 @@ __global__ __launch_bounds__(kWave) void generic_finish_kernel(FHier f, int T, d
     *log_z = lz + ref + log(d.W / n_pop);
 }
 
-// (re)lays the three-copy hierarchy out for populations of nb tiles
+// (re)lays the three-copy hierarchy out for populations of nb 256-particle blocks
 int ensure_generic(cpprob_hip_ctx* c, int nb)
 {
     if (nb != c->gen_nb || !c->d_gen_hier) {
@@ -2416,7 +2421,9 @@ int ensure_generic(cpprob_hip_ctx* c, int nb)
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             dfree(c->d_gen_hier); dfree(c->d_gen_q[0]); dfree(c->d_gen_q[1]);
             HIP_TRY(c, hipMalloc(&c->d_gen_hier, 3 * per_copy * sizeof(uint64_t)));
-            for (int k = 0; k < 2; ++k) HIP_TRY(c, hipMalloc(&c->d_gen_q[k], (size_t)nb * kTile * sizeof(uint32_t)));
+            // (whole tiles, and one more: the step kernel's walk reads 1024-particle chunks that start at any block)
+            const size_t q_words = ((size_t)nb * kGenBlock + kTile - 1) / kTile * kTile + kTile;
+            for (int k = 0; k < 2; ++k) { HIP_TRY(c, hipMalloc(&c->d_gen_q[k], q_words * sizeof(uint32_t))); HIP_TRY(c, hipMemsetAsync(c->d_gen_q[k], 0, q_words * sizeof(uint32_t), c->stream)); }
             c->gen_cap_nb = (size_t)nb;
         }
         for (int k = 0; k < 3; ++k)
@@ -2450,16 +2457,17 @@ int cpprob_hip_generic_begin(cpprob_hip_ctx* c, size_t n, cpprob_hip_generic_lay
     BB_PRELUDE(c);
     if (!out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (n == 0 || n > (size_t)(1ull << 28)) return fail(c, CPPROB_HIP_EINVAL, "population size out of range (1 .. 2^28: the squares' 64-bit sum)");
-    const int nb = (int)((n + kTile - 1) / kTile);
+    if (n > (size_t)kCountsMaxTiles * kGenBlock) return fail(c, CPPROB_HIP_EINVAL, "population too large for the three-level mass hierarchy of 256-particle blocks (64^3 blocks)");
+    const int nb = (int)((n + kGenBlock - 1) / kGenBlock);
     if (int rc = ensure_generic(c, nb)) return rc;
-    // a run starts from clean upper levels in every copy; the weight arrays' padding slots are zero from the first step on
+    // a run starts from clean upper levels in every copy
     HIP_TRY(c, hipMemsetAsync(c->d_gen_hier, 0, 3 * c->gen_per_copy * sizeof(uint64_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_gen_ctrl, 0, sizeof(GenericCtrlBlock), c->stream));
     std::memset(out, 0, sizeof *out);
     out->hier = c->d_gen_hier; out->per_copy = c->gen_per_copy;
     for (int l = 0; l < kHierMaxLevels; ++l) { out->lvl_off[l] = c->gen_off[l < c->gen_table.n_lev ? l : 0]; out->n_ent[l] = c->gen_table.n_ent[l]; }
     out->n_lev = c->gen_table.n_lev; out->q0_off = c->gen_q0_off; out->m0_off = c->gen_m0_off;
-    out->table = c->d_gen_table; out->q[0] = c->d_gen_q[0]; out->q[1] = c->d_gen_q[1]; out->ctrl = c->d_gen_ctrl; out->tiles = nb;
+    out->table = c->d_gen_table; out->q[0] = c->d_gen_q[0]; out->q[1] = c->d_gen_q[1]; out->ctrl = c->d_gen_ctrl; out->blocks = nb; out->block = kGenBlock;
     return 0;
 }
 
@@ -2467,11 +2475,12 @@ int cpprob_hip_generic_quantize(cpprob_hip_ctx* c, int32_t t, const double* d_lo
 {
     BB_PRELUDE(c);
     if (!d_logw || t < 0) return fail(c, CPPROB_HIP_EINVAL, "bad argument");
-    const int nb = (int)((n + kTile - 1) / kTile);
+    const int nb = (int)((n + kGenBlock - 1) / kGenBlock), nt = (int)((n + kTile - 1) / kTile);
     if (nb != c->gen_nb || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
     FHier f{};
     generic_view(c, t % 3, t % 3, (t + 1) % 3, f);
-    hipLaunchKernelGGL(generic_quantize_kernel, dim3(nb), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, c->d_gen_q[t & 1], static_cast<GenericCtrlBlock*>(c->d_gen_ctrl));
+    hipLaunchKernelGGL(generic_max_kernel, dim3(nt), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, nb);
+    hipLaunchKernelGGL(generic_quantize_kernel, dim3(nt), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, nb, c->d_gen_q[t & 1], static_cast<GenericCtrlBlock*>(c->d_gen_ctrl));
     HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -2480,7 +2489,7 @@ int cpprob_hip_generic_finish(cpprob_hip_ctx* c, int32_t T, size_t n, double gap
 {
     BB_PRELUDE(c);
     if (!d_ess || !d_resampled || !d_log_z || !d_flags || T < 1) return fail(c, CPPROB_HIP_EINVAL, "bad argument");
-    const int nb = (int)((n + kTile - 1) / kTile);
+    const int nb = (int)((n + kGenBlock - 1) / kGenBlock);
     if (nb != c->gen_nb || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
     FHier f{};
     const int k = (T - 1) % 3;

@@ -30,8 +30,13 @@ namespace cpprob {
 namespace device {
 
 constexpr int kLaneBlock = 256;              // threads per workgroup of model_kernel (one launch runs the whole model body: SIS, full replay)
-constexpr int kStepBlock = 1024;             // ... of model_step_kernel (windowed replay with the resampling inside the launch): one 1024-particle
-constexpr int kStepWaves = kStepBlock / 64;  //     tile of the mass hierarchy per workgroup, one particle per lane
+constexpr int kStepBlock = 256;              // ... of model_step_kernel (windowed replay with the resampling inside the launch), one particle per lane:
+constexpr int kStepWaves = kStepBlock / 64;  //     one entry of the mass hierarchy per workgroup
+constexpr int kStepPass = 2;                 // source blocks the walk scans per pass (one particle per lane and block)
+constexpr int kStepFetch = 6;                // source blocks whose weights are fetched at kernel entry ...
+constexpr int kStepFetchBack = 2;            // ... starting this many blocks before the workgroup's own
+constexpr int kStepProbe = 16;               // blocks whose boundaries the search's probe evaluates at once
+constexpr int kStepProbeBack = 7;            // ... starting this many blocks before the workgroup's own
 
 // What the fused SMC step of an unchanged model carries (cpprob/gpu.hpp: model_step_kernel): generation t-1's fixed-point masses
 // for the ancestor search in the launch's prologue, and where generation t's go in its epilogue (cpprob/detail/fixed_mass.hpp).
@@ -85,26 +90,28 @@ __device__ inline LaunchArgsPtr launch_args() { return (LaunchArgsPtr)__builtin_
 // What a lane's statements do write: counters, the running log-weight, the frontier flag -- in LDS, sized by the launch (dynamic:
 // 36 bytes per lane under windowed replay, 64 + 1/8 otherwise), one workgroup's lanes side by side per field (a wavefront's access
 // to a field is one conflict-free LDS instruction).  B = lanes per workgroup:
-//   [ 0, 16B)  WinRec  windowed replay: {w, lim}, read by every statement in ONE 16-byte load
+//   [ 0, 16B)  WinRec  windowed replay: four words per lane (below), a statement reads two of them
 //   [16B, 24B) log_w   the step's incremental log-weight          [24B, 32B) carried  the log-weight the particle brought along
 //   [32B, 36B) src     the lane's ancestor (its own index where the previous step did not resample)
 //   [36B, 64B) full replay: n_sample, n_observe, n_pred_real, n_pred_int, n_recorded, n_stored, done
 //   [64B, ..)  full replay: per wavefront, the lanes that carry a particle
 // Windowed replay (the model passed the Markov probe: statement counts do not depend on sampled values): every lane of a
-// wavefront executes the same statements, so the counters are WAVE-UNIFORM -- one packed word per lane, read back through the
-// scalar unit (readfirstlane), and every test on it a scalar branch: a statement behind or before the live window costs one LDS
-// round trip and a handful of scalar instructions.  The launch's own thresholds ride in the same 16 bytes (`lim`: written once
-// by begin_lane), so a dead statement waits for nothing but that one load -- no kernel-argument fetch behind it.
-//   w   bits 0..23 samples, 24..39 observes, 40..49 int predicts, 50..59 real predicts, 63 done
-//   lim bits 0..23 first sample ordinal inside the window, 24..39 first_observe, 40..55 stop_after + 1 (0: run to completion)
-struct alignas(16) WinRec { unsigned long long w, lim; };
-constexpr unsigned long long kWSample = 1ull, kWObserve = 1ull << 24, kWPredInt = 1ull << 40, kWPredReal = 1ull << 50, kWDone = 1ull << 63;
-__device__ inline unsigned long long wave_uniform(unsigned long long v)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (unsigned long long)lo | ((unsigned long long)hi << 32);
-}
+// wavefront executes the same statements, so the counters are WAVE-UNIFORM -- packed words per lane, read back through the scalar
+// unit (readfirstlane), and every test on them a scalar branch: a statement behind or before the live window costs one LDS round
+// trip and a handful of scalar instructions.  The launch's own thresholds ride in the same 16 bytes (written once by begin_lane),
+// so a dead statement waits for nothing but that one load -- no kernel-argument fetch behind it -- and each kind of statement
+// touches ONE counter word and ONE threshold word (a CU has one scalar unit for its four SIMDs: the dead iterations of a model's
+// loop are bound by scalar issue -- 65 instructions an iteration of hmm<N> cost 1.07 us per launch at 10^6 particles):
+//   n_sample   samples executed                          lim_sample   first sample ordinal inside the window
+//   n_other    bits 0..11 observes, 12..21 int predicts, 22..31 real predicts (kWinMaxObserves / kWinMaxPredicts: the host replays
+//              the whole trace for models beyond them)
+//   lim_other  bits 0..11 first_observe, 16..31 stop_after + 1 (0: run to completion)
+// Four arrays of one word per lane (lane stride 4 bytes: conflict-free; the four words of a lane side by side put a wavefront's 64
+// accesses to one of them on eight LDS banks: measured 25 % slower on the 100-observe linear-Gaussian model).
+struct WinRec { uint32_t &n_sample, &n_other, &lim_sample, &lim_other; };
+constexpr uint32_t kWObserve = 1u, kWPredInt = 1u << 12, kWPredReal = 1u << 22;
+constexpr uint32_t kWinMaxObserves = 4095u, kWinMaxPredicts = 1023u;
+__device__ inline uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ inline char* lane_lds()
 {
     extern __shared__ __attribute__((aligned(16))) char cpprob_lane_lds[];
@@ -112,11 +119,16 @@ __device__ inline char* lane_lds()
 }
 __host__ __device__ inline size_t lane_lds_bytes(uint32_t lanes, bool windowed_only) { return windowed_only ? (size_t)36 * lanes : (size_t)64 * lanes + lanes / 8 + 8; }
 struct LaneState {                                   // (pointers to this lane's slots: address arithmetic on one scalar, B)
-    WinRec* win; double* log_w; double* carried; int32_t* src;
+    double* log_w; double* carried; int32_t* src;
     uint32_t *n_sample, *n_observe, *n_pred_real, *n_pred_int, *n_recorded, *n_stored, *done;
     unsigned long long* active;
 };
-__device__ inline WinRec& win_rec() { return reinterpret_cast<WinRec*>(lane_lds())[threadIdx.x]; }
+__device__ inline WinRec win_rec()
+{
+    uint32_t* p = reinterpret_cast<uint32_t*>(lane_lds()) + threadIdx.x;
+    const uint32_t B = launch_args()->lane_block;
+    return WinRec{p[0], p[B], p[2 * B], p[3 * B]};
+}
 __device__ inline double& lane_log_w() { return reinterpret_cast<double*>(lane_lds() + (size_t)16 * launch_args()->lane_block)[threadIdx.x]; }
 __device__ inline double& lane_carried() { return reinterpret_cast<double*>(lane_lds() + (size_t)24 * launch_args()->lane_block)[threadIdx.x]; }
 __device__ inline int32_t& lane_src() { return reinterpret_cast<int32_t*>(lane_lds() + (size_t)32 * launch_args()->lane_block)[threadIdx.x]; }
@@ -126,7 +138,6 @@ __device__ __forceinline__ LaneState lane_state()
     char* p = lane_lds();
     const int l = threadIdx.x;
     LaneState s;
-    s.win = reinterpret_cast<WinRec*>(p) + l;
     s.log_w = reinterpret_cast<double*>(p + 16 * B) + l; s.carried = reinterpret_cast<double*>(p + 24 * B) + l;
     s.src = reinterpret_cast<int32_t*>(p + 32 * B) + l;
     uint32_t* u = reinterpret_cast<uint32_t*>(p + 36 * B) + l;
@@ -149,11 +160,10 @@ __device__ __forceinline__ void begin_lane(int32_t src, uint32_t n_stored, doubl
     lane_log_w() = 0.0; lane_carried() = carried; lane_src() = src;
     if (A->windowed) {
         const int32_t base = A->fresh_lo - (int32_t)A->win;
-        WinRec r;
-        r.w = 0;
-        r.lim = (unsigned long long)(uint32_t)(base > 0 ? base : 0) | ((unsigned long long)(uint32_t)A->first_observe << 24) |
-                ((unsigned long long)(uint32_t)(A->stop_after + 1) << 40);
-        win_rec() = r;
+        const WinRec r = win_rec();
+        r.n_sample = 0; r.n_other = 0;
+        r.lim_sample = (uint32_t)(base > 0 ? base : 0);
+        r.lim_other = (uint32_t)A->first_observe | ((uint32_t)(A->stop_after + 1) << 16);
         return;
     }
     const LaneState s = lane_state();
@@ -215,74 +225,177 @@ __device__ inline I draw(const boost::random::poisson_distribution<I, R>& d, uin
 // ---- the fused SMC step (model_step_kernel, cpprob/gpu.hpp) ---------------------------------------------------------------------
 // Shape of smc_step_fixed_kernel (csrc/step_fixed.hpp) with the model body in the middle: everything the prologue reads is
 // addressed by the launch geometry and fetched at kernel entry in one round trip; the workgroup's first wavefront takes generation
-// t-1's totals, decides (ESS), fixes the reference R_t and searches the hierarchy for the source tiles this output tile draws from;
-// all sixteen walk them (one particle per lane); the lane then replays its ancestor's window and runs the step.  The step's observe
-// statement -- every wavefront of the workgroup arrives there: windowed replay is wave-uniform -- quantises the log-weight, reduces
-// the tile's {mass, squares, maximum} and publishes them into generation t's hierarchy before it ends the wavefront.
-struct StepFound { cph::FLocated loc; double inv, ref; int resample; };
+// t-1's totals, decides (ESS), fixes the reference R_t and searches the hierarchy for the source blocks this workgroup's 256 outputs
+// draw from; all four walk them; the lane then replays its ancestor's window and runs the step.  The step's observe statement --
+// every wavefront of the workgroup arrives there: windowed replay is wave-uniform -- quantises the log-weight, reduces the
+// workgroup's {mass, squares, maximum} and publishes them as its entry of generation t's hierarchy before it ends the wavefront.
+// Geometry: the hierarchy's entries are 256-particle blocks, one per workgroup -- plain stores at level 0, fire-and-forget atomics
+// above, so no workgroup waits for an atomic's return below 64^2 blocks -- and many small workgroups are resident per CU, so one's
+// search and barriers run under the others' model bodies.  (Measured on the way here, hmm<16>, 10^6 particles, per launch: a
+// 1024-lane workgroup per 1024-particle tile -- one resident per CU at the model's register count, every phase of its prologue
+// exposed -- 42 us against the unfused launch's 13; four 256-lane workgroups adding into a shared tile entry and counting arrivals:
+// 35 us, each workgroup's lifetime extended by two dependent atomic round trips.)
+struct StepLocated { int c, c_last; uint64_t P; };           // first source block, last source block (>= n_blocks: not known), mass before block c
+struct StepFound { StepLocated loc; double inv, ref; int resample; };
 struct StepLds {
-    int32_t slot[kStepBlock];            // scatter slots of the output tile
-    uint64_t scan[2][kStepWaves];        // per-wave totals of the in-tile scan, double-buffered across source tiles
+    int32_t slot[kStepBlock];                    // scatter slots of the workgroup's outputs
+    uint64_t scan[2][kStepPass][kStepWaves];     // per-wave totals of the in-block scans, double-buffered across passes
     int32_t iscr[kStepWaves];
     uint64_t red[3 * kStepWaves];
     StepFound found;
 };
-__device__ inline StepLds& step_lds()
+__device__ __forceinline__ StepLds& step_lds()
 {
     __shared__ __attribute__((aligned(16))) StepLds s_step;
     return s_step;
 }
 
-// The WALK, one particle per lane (csrc/step_fixed.hpp: fixed_walk states it for four): every source tile that owns outputs of
-// this tile rebuilds its prefix masses (one scan), each source with a non-empty range writes its index into the slot of its FIRST
-// output, one prefix-max hands every output its ancestor.  Slots must hold -1 and be visible on entry.  Integers throughout: the
-// same ancestors as any other tiling of the same masses.
-__device__ __forceinline__ int32_t step_walk(const cph::FixedCdf& fc, const uint32_t* __restrict__ qprev, int64_t n, int nb, double gj_first, int n_out,
-                                    const cph::FLocated& loc, int guess, uint32_t q_m1, uint32_t q_0, uint32_t q_p1, StepLds& L)
+// Wavefront sums of 32-bit weights as TWO 16-bit halves: each half's sum over 64 lanes fits 22 bits, so a scan step is one
+// v_add_u32_dpp per half (a 64-bit scan step is four instructions: the DPP moves carry no 64-bit add).
+__device__ __forceinline__ uint64_t wave_incl_scan_q(uint32_t q)
+{
+    const uint32_t lo = cph::wave_incl_scan_u32(q & 0xffffu), hi = cph::wave_incl_scan_u32(q >> 16);
+    return ((uint64_t)hi << 16) + lo;
+}
+__device__ __forceinline__ uint64_t wave_sum_q(uint32_t q)
+{
+    const uint32_t lo = cph::wave_sum_u32(q & 0xffffu), hi = cph::wave_sum_u32(q >> 16);
+    return ((uint64_t)hi << 16) + lo;
+}
+// ... and the maximum of 64-bit keys as two 32-bit maxima: the high words, then the low words of the lanes that hold the high maximum
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, cph::dpp_u32<cph::kDppRowShr1>(v));
+    v = max(v, cph::dpp_u32<cph::kDppRowShr2>(v));
+    v = max(v, cph::dpp_u32<cph::kDppRowShr4>(v));
+    v = max(v, cph::dpp_u32<cph::kDppRowShr8>(v));
+    v = max(v, cph::dpp_u32<cph::kDppRowBcast15, 0xA>(v));
+    v = max(v, cph::dpp_u32<cph::kDppRowBcast31, 0xC>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint64_t wave_max_key(uint64_t k)
+{
+    const uint32_t hi = wave_max_u32((uint32_t)(k >> 32));
+    const uint32_t lo = wave_max_u32((uint32_t)(k >> 32) == hi ? (uint32_t)k : 0u);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// What the search's probe reads: the hierarchy words of block cs = max(own - kStepProbeBack, 0)'s prefix and kStepProbe block entries.
+struct StepProbeWords { uint64_t lvl[cph::kHierMaxLevels]; uint64_t we; };
+__device__ __forceinline__ int step_probe_start(int own) { return own > kStepProbeBack ? own - kStepProbeBack : 0; }
+__device__ __forceinline__ void step_probe_fetch(const cph::Hier& h, int own, int nb, StepProbeWords& w)
+{
+    const int cs = step_probe_start(own);
+    cph::hier_prefix_fetch(h, cs, w.lvl);
+    const int lane = threadIdx.x & 63;
+    const int i = cs + (lane < kStepProbe ? lane : 0);
+    w.we = h.lvl[0][i < nb ? i : nb - 1];
+}
+
+// The SEARCH (one wavefront; csrc/step_fixed.hpp: fixed_locate, with a wider probe over smaller entries): lane i evaluates the first
+// output G owned by the sources from block cs + i on; the first source block of this workgroup's outputs is the last one whose G
+// does not exceed the first output.  A miss descends the hierarchy from the top.
+__device__ __forceinline__ StepLocated step_locate(const cph::FHier& f, const cph::FixedCdf& fc, int nb, double gj_first, int n_out, int own, const StepProbeWords& pw)
+{
+    using namespace cph;
+    const int lane = threadIdx.x & 63;
+    const double gj_last = gj_first + (double)(n_out - 1);
+    const int cs = step_probe_start(own);
+    const uint64_t Pc = fhier_prefix_sum(cs, pw.lvl);
+    const uint64_t we = (lane < kStepProbe && cs + lane < nb) ? (pw.we & kMassMask) : 0ull;
+    const uint64_t incl = wave_incl_scan_u64(we);
+    const uint64_t x = Pc + incl - we;                                   // lanes 0..kStepProbe: the mass before block cs + lane
+    const double gt = fc.g(x);
+    const bool known = lane <= kStepProbe && cs + lane < nb;
+    const unsigned long long m = __ballot(known && gt <= gj_first);
+    const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
+    StepLocated r;
+    if ((i_lo >= 0 || cs == 0) && i_lo < kStepProbe) {
+        const int i = i_lo < 0 ? 0 : i_lo;
+        // (G is monotone in the block index: the blocks that start at or before the last output form a prefix of the window)
+        const unsigned long long mh = __ballot(known && gt <= gj_last);
+        const int i_hi = mh ? (63 - __builtin_clzll(mh)) : i;
+        r.c = cs + i;
+        r.P = read_lane_u64(x, i);
+        r.c_last = (i_hi >= kStepProbe && cs + kStepProbe < nb) ? nb : cs + (i_hi > i ? i_hi : i);
+        return r;
+    }
+    r.c = fhier_locate(f.h.table, f.h.copy, fc, gj_first, r.P);
+    r.c_last = nb;
+    return r;
+}
+
+// Inclusive prefix-max over the slots (visible on entry): within the wavefront by DPP, over the wavefronts in front of it by reading
+// their slots directly -- no barrier of its own.
+__device__ __forceinline__ int32_t step_prefix_max(StepLds& L)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double gj_last = gj_first + (double)(n_out - 1);
-    int c = __builtin_amdgcn_readfirstlane(loc.c), c_last = __builtin_amdgcn_readfirstlane(loc.c_last);
-    uint64_t P = loc.P;
-    auto load_q = [&](int cc) -> uint32_t {
-        if (cc == guess) return q_0;
-        if (cc == guess - 1) return q_m1;
-        if (cc == guess + 1) return q_p1;
-        return cc < nb ? qprev[(int64_t)cc * kStepBlock + tid] : 0u;
-    };
-    auto place = [&](double g) -> int { return (int)fmin(fmax(g - gj_first, 0.0), (double)kStepBlock); };      // exact: integers
-    uint32_t raw = load_q(c);
-    int it = 0;
-    while (c < nb && c <= c_last) {
-        // (wave-uniform values -- the branches are made scalar so that the barrier inside the loop sits in uniform control flow)
-        if (c_last >= nb && __builtin_amdgcn_readfirstlane(fc.g(P) > gj_last ? 1 : 0)) break;      // the last tile is not known from the probe
-        const uint32_t raw_next = c < c_last ? load_q(c + 1) : 0u;
-        const bool edge = c == nb - 1;
-        const int nvt = edge ? (int)(n - (int64_t)c * kStepBlock) : kStepBlock;     // valid particles of this tile (padding slots weigh 0)
-        const uint64_t incl = cph::wave_incl_scan_u64((uint64_t)raw);
-        if (lane == 63) L.scan[it & 1][wv] = incl;
-        __syncthreads();
-        const uint64_t s = lane < kStepWaves ? L.scan[it & 1][lane] : 0ull;
-        const uint64_t off = cph::wave_sum_u64(lane < wv ? s : 0ull), tot = cph::wave_sum_u64(s);
-        const uint64_t excl = P + off + incl - raw;                    // mass before this lane's particle
-        const int p_prev = place(fc.g(excl));
-        int p = place(fc.g(excl + raw));
-        if (edge && tid + 1 == nvt) p = place(fc.n_pop);               // the population's last source owns the rest
-        if (edge && tid + 1 > nvt) p = p_prev;                         // padding slots own nothing
-        if (p > p_prev) L.slot[p_prev] = c * kStepBlock + tid;
-        P += tot;
-        ++it;
-        raw = raw_next;
-        ++c;
-    }
-    __syncthreads();
-    const int32_t incl = cph::wave_incl_max_i32(L.slot[tid]);        // inclusive prefix-max over the slots
-    if (lane == 63) L.iscr[wv] = incl;
-    __syncthreads();
-    int32_t before = (lane < kStepWaves && lane < wv) ? L.iscr[lane] : -1;
+    const int32_t incl = cph::wave_incl_max_i32(L.slot[tid]);
+    int32_t before = -1;
+#pragma unroll
+    for (int w2 = 0; w2 < kStepWaves - 1; ++w2) if (w2 < wv) before = max(before, L.slot[w2 * 64 + lane]);
     before = cph::wave_incl_max_i32(before);
     before = __builtin_amdgcn_readlane(before, 63);
     return max(incl, before);
+}
+
+// The WALK (csrc/step_fixed.hpp: fixed_walk, one source particle per lane and block, kStepPass blocks per pass): every source
+// block that may own outputs of this workgroup rebuilds its prefix masses (one scan), each source with a non-empty range writes its
+// index into the slot of its FIRST output, one prefix-max hands every output its ancestor.  Slots must hold -1 and be visible on
+// entry.  Integers throughout: the same ancestors as any other tiling of the same masses.
+struct StepFetched { uint32_t q[kStepFetch]; int first; };      // the weights of blocks first .. first + kStepFetch - 1 (lane's particle of each), fetched at entry
+__device__ __forceinline__ int32_t step_walk(const cph::FixedCdf& fc, const uint32_t* __restrict__ qprev, int64_t n, int nb, double gj_first, int n_out,
+                                             const StepLocated& loc, const StepFetched& pf, StepLds& L)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double gj_last = gj_first + (double)(n_out - 1);
+    int c = __builtin_amdgcn_readfirstlane(loc.c);
+    const int c_last = __builtin_amdgcn_readfirstlane(loc.c_last);
+    uint64_t P = loc.P;
+    auto load_q = [&](int cc) -> uint32_t {                            // (uniform cc: a scalar switch over the fetched registers)
+        const int k = cc - pf.first;
+        uint32_t v = 0u;
+        bool have = false;
+#pragma unroll
+        for (int j = 0; j < kStepFetch; ++j) if (k == j) { v = pf.q[j]; have = true; }
+        if (!have && cc < nb) v = qprev[(int64_t)cc * kStepBlock + tid];
+        return ((int64_t)cc * kStepBlock + tid < n && cc <= c_last) ? v : 0u;      // slots beyond the population (and blocks beyond the last source) weigh nothing
+    };
+    auto place = [&](double g) -> int { return (int)fmin(fmax(g - gj_first, 0.0), (double)kStepBlock); };      // exact: integers
+    uint32_t raw[kStepPass];
+#pragma unroll
+    for (int k = 0; k < kStepPass; ++k) raw[k] = load_q(c + k);
+    int it = 0;
+    while (c < nb && c <= c_last) {
+        // (wave-uniform values -- the branches are made scalar so that the barrier inside the loop sits in uniform control flow)
+        if (c_last >= nb && __builtin_amdgcn_readfirstlane(fc.g(P) > gj_last ? 1 : 0)) break;      // the last block is not known from the probe
+        uint32_t raw_next[kStepPass];
+#pragma unroll
+        for (int k = 0; k < kStepPass; ++k) raw_next[k] = c + kStepPass <= c_last ? load_q(c + kStepPass + k) : 0u;
+        uint64_t incl[kStepPass];
+#pragma unroll
+        for (int k = 0; k < kStepPass; ++k) { incl[k] = wave_incl_scan_q(raw[k]); if (lane == 63) L.scan[it & 1][k][wv] = incl[k]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kStepPass; ++k) {
+            uint64_t off = 0, tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < kStepWaves; ++w2) { const uint64_t sw = L.scan[it & 1][k][w2]; if (w2 < wv) off += sw; tot += sw; }
+            const uint64_t excl = P + off + incl[k] - raw[k];          // mass before this lane's particle
+            const int64_t src = (int64_t)(c + k) * kStepBlock + tid;
+            const int p_prev = place(fc.g(excl));
+            int p = place(fc.g(excl + raw[k]));
+            if (src + 1 == n) p = place(fc.n_pop);                     // the population's last source owns the rest
+            if (p > p_prev && src < n) L.slot[p_prev] = (int32_t)src;
+            P += tot;
+        }
+        ++it;
+#pragma unroll
+        for (int k = 0; k < kStepPass; ++k) raw[k] = raw_next[k];
+        c += kStepPass;
+    }
+    __syncthreads();
+    return step_prefix_max(L);
 }
 
 // the hierarchy's view, field by field out of the kernel-argument segment (scalar loads)
@@ -310,25 +423,22 @@ __device__ __forceinline__ void step_prologue()
     const int64_t n = A->n;
     const int64_t i = lane_index();
     const FHier f = step_hier();
-    uint32_t q_0 = 0u, q_m1 = 0u, q_p1 = 0u;
+    StepFetched pf{};
     FTotWords tw{};
-    ProbeWords pw0{};
+    StepProbeWords pw0{};
     double lw_carry = 0.0;
-    const int guess = bid;                                             // the source tile this output tile is expected to start in
+    pf.first = bid > kStepFetchBack ? bid - kStepFetchBack : 0;        // the sources of these outputs are expected around the workgroup's own block
     if (t > 0) {
-        const uint32_t* qp = A->fs.q_prev;
-        const int64_t g0 = (int64_t)guess * kStepBlock + tid;
-        q_0 = qp[g0];
-        q_m1 = qp[guess > 0 ? g0 - kStepBlock : g0];
-        q_p1 = qp[guess + 1 < nb ? g0 + kStepBlock : g0];
-        if (wv == 0) { ftot_fetch(f, tw); probe_fetch(f.h, guess, nb, pw0); }
+        // (the weight arrays reach a tile beyond the last block: the loads need no bound)
+        const uint32_t* qp = A->fs.q_prev + (int64_t)pf.first * kStepBlock + tid;
+#pragma unroll
+        for (int k = 0; k < kStepFetch; ++k) pf.q[k] = qp[k * kStepBlock];
+        if (wv == 0) { ftot_fetch(f, tw); step_probe_fetch(f.h, bid, nb, pw0); }
         if (A->fs.may_carry) lw_carry = A->logw_in[i];                  // (speculative: a launch that resamples drops it)
     }
     int32_t anc = (int32_t)i;
     bool resample = false;
     if (t > 0) {
-        if (guess == 0) q_m1 = 0u;
-        if (guess + 1 >= nb) q_p1 = 0u;
         L.slot[tid] = -1;
         const int64_t rem = n - (int64_t)bid * kStepBlock;
         const int n_out = rem < kStepBlock ? (int)rem : kStepBlock;
@@ -355,18 +465,18 @@ __device__ __forceinline__ void step_prologue()
                 *A->fs.log_z = lz;
                 if (!A->fs.exact_ref) c->ref_cur = r_t;
             }
-            FLocated loc{0, 0, 0};
-            if (d.resample) loc = fixed_locate(f, fc, nb, gj_first, n_out, guess, &pw0);
+            StepLocated loc{0, 0, 0};
+            if (d.resample) loc = step_locate(f, fc, nb, gj_first, n_out, bid, pw0);
             if (tid == 0) { L.found.loc = loc; L.found.inv = d.inv; L.found.ref = r_t; L.found.resample = d.resample ? 1 : 0; }
         }
         __syncthreads();                                               // slots reset, search results in place
         resample = L.found.resample != 0;
         if (resample) {
             fc.inv = L.found.inv;
-            anc = step_walk(fc, A->fs.q_prev, n, nb, gj_first, n_out, L.found.loc, guess, q_m1, q_0, q_p1, L);
+            anc = step_walk(fc, A->fs.q_prev, n, nb, gj_first, n_out, L.found.loc, pf, L);
             anc = max(anc, 0);
             lw_carry = 0.0;                                            // equal weights after resampling
-            if ((int64_t)bid * kStepBlock + tid < n) __builtin_nontemporal_store(anc, A->fs.anc_row + i);
+            if ((int64_t)bid * kStepBlock + tid < n) A->fs.anc_row[i] = anc;
         }
     } else if (bid == 0 && tid == 0 && !A->fs.exact_ref) {
         A->fs.ctrl->ref_cur = A->fs.bound;                             // R_0 = B_0
@@ -375,46 +485,49 @@ __device__ __forceinline__ void step_prologue()
 }
 
 // Epilogue of the fused step (every lane of the workgroup, in uniform control flow): observe #t's weight as an integer, the
-// tile's totals into generation t's hierarchy.  exact_ref: the tile's maximum only -- the masses follow in a launch of their own,
-// against the generation's exact maximum (cpprob_hip_generic_quantize).
+// workgroup's totals as its entry of generation t's hierarchy.  exact_ref: the log-weights only -- maxima and masses follow
+// in launches of their own, against the generation's exact maximum (cpprob_hip_generic_quantize).
 __device__ __forceinline__ void step_epilogue()
 {
     using namespace cph;
     LaunchArgsPtr A = launch_args();
     StepLds& L = step_lds();
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t i_raw = (int64_t)blockIdx.x * kStepBlock + tid;
+    const int bid = (int)blockIdx.x;
+    const int64_t i_raw = (int64_t)bid * kStepBlock + tid;
     const bool valid = i_raw < A->n;
     const int t = A->fs.t;
     double lw = lane_carried() + lane_log_w();
     if (!valid) lw = -INFINITY;                                        // padding lanes weigh nothing
-    const FHier f = step_hier();
     if (A->fs.exact_ref) {
-        const uint64_t m_w = wave_max_u64(dkey(lw));
-        if (lane == 0) L.red[wv] = m_w;
-        __syncthreads();
-        if (tid == 0) {
-            uint64_t Mk = 0;
-#pragma unroll
-            for (int w = 0; w < kStepWaves; ++w) Mk = umax64(Mk, L.red[w]);
-            FHier fn = f;                                              // the copy written
-            for (int l = 0; l < kHierMaxLevels; ++l) fn.h.lvl[l] = f.h.lvl[l] + f.h.to_next;
-            fn.m0 = f.m0 + f.h.to_next; fn.q0 = f.q0 + f.h.to_next; fn.h.to_clear = f.h.to_clear - f.h.to_next;
-            bbf_publish_max(fn, (int)blockIdx.x, A->fs.nb, Mk);
-        }
         if (valid) A->logw_out[i_raw] = lw;
         return;
     }
+#if defined(CPPROB_EXP_EPI) && CPPROB_EXP_EPI == 3
+    if (valid) A->logw_out[i_raw] = lw;
+    return;
+#endif
     const double ref = t == 0 ? A->fs.bound : L.found.ref;
     const uint32_t q = fix_weight(lw, ref);
-    const uint64_t s_w = wave_sum_u64((uint64_t)q), q_w = wave_sum_u64((uint64_t)(q >> 16) * (uint64_t)(q >> 16)), m_w = wave_max_u64(dkey(lw));
+#if defined(CPPROB_EXP_EPI) && CPPROB_EXP_EPI == 2
+    A->fs.q_next[i_raw] = q;
+    if (valid) A->logw_out[i_raw] = lw;
+    return;
+#endif
+    const uint64_t s_w = wave_sum_q(q), q_w = wave_sum_q((q >> 16) * (q >> 16)), m_w = wave_max_key(dkey(lw));
     if (lane == 0) { L.red[wv] = s_w; L.red[kStepWaves + wv] = q_w; L.red[2 * kStepWaves + wv] = m_w; }
     __syncthreads();
     if (tid == 0) {
         uint64_t St = 0, Qt = 0, Mk = 0;
 #pragma unroll
-        for (int w = 0; w < kStepWaves; ++w) { St += L.red[w]; Qt += L.red[kStepWaves + w]; Mk = umax64(Mk, L.red[2 * kStepWaves + w]); }
-        fhier_publish(f, (int)blockIdx.x, A->fs.nb, St, Qt, Mk);
+        for (int w2 = 0; w2 < kStepWaves; ++w2) { St += L.red[w2]; Qt += L.red[kStepWaves + w2]; Mk = umax64(Mk, L.red[2 * kStepWaves + w2]); }
+#if defined(CPPROB_EXP_EPI) && CPPROB_EXP_EPI == 1
+        if (St == 12345) A->fs.q_next[0] = (uint32_t)(Qt + Mk);
+#elif defined(CPPROB_EXP_EPI) && CPPROB_EXP_EPI == 4
+        { const cph::FHier f4 = step_hier(); const_cast<uint64_t*>(f4.h.lvl[0])[f4.h.to_next + bid] = St; const_cast<uint64_t*>(f4.q0)[f4.h.to_next + bid] = Qt; const_cast<uint64_t*>(f4.m0)[f4.h.to_next + bid] = Mk; }
+#else
+        fhier_publish(step_hier(), bid, A->fs.nb, St, Qt, Mk);
+#endif
     }
     A->fs.q_next[i_raw] = q;                                           // (the weight arrays are padded to whole tiles)
     if (valid && (A->fs.may_carry || t + 1 == A->fs.T)) A->logw_out[i_raw] = lw;
@@ -458,13 +571,11 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
     } else {
         if (A->windowed) {
             // (scalar control flow: see WinRec)
-            WinRec& rec = win_rec();
-            const WinRec own = rec;
-            const unsigned long long w = wave_uniform(own.w), lim = wave_uniform(own.lim);
-            rec.w = w + kWSample;
-            if (w & kWDone) return R();
-            const int32_t jj = (int32_t)(w & 0xffffffu);
-            if (jj < (int32_t)(lim & 0xffffffu)) return R();              // older than the window: the step does not depend on it (host probe)
+            const WinRec rec = win_rec();
+            const int32_t jj = (int32_t)wave_uniform(rec.n_sample);
+            const uint32_t lim = wave_uniform(rec.lim_sample);
+            rec.n_sample = (uint32_t)jj + 1u;
+            if ((uint32_t)jj < lim) return R();                           // older than the window: the step does not depend on it (host probe)
             const int32_t base = A->fresh_lo - (int32_t)A->win;
             R v;
             if (jj < A->fresh_lo) v = from_raw<R>(A->carry_in[(int64_t)(jj - base) * A->ld + lane_src()]);
@@ -498,17 +609,18 @@ __device__ inline void observe_impl(Distribution& distr, const X& x)
         // (vector-valued: ONE observe statement whose log-density is the sum over the components, utils_multivariate_normal.hpp:20-33)
         LaunchArgsPtr A = launch_args();
         if (A->windowed) {
-            WinRec& rec = win_rec();
-            const WinRec own = rec;
-            const unsigned long long w = wave_uniform(own.w), lim = wave_uniform(own.lim);
-            rec.w = w + kWObserve;
-            // (a lane whose counters differ from its wavefront's executed other statements: the counts DO depend on sampled values,
-            //  the probe notwithstanding -- reported, and the host repeats the run with full replay)
-            if (__ballot(own.w != w) != 0ull && A->overflow) *A->overflow = 3;
-            const uint32_t m = (uint32_t)((w >> 24) & 0xffffu);
-            if (!(w & kWDone) && m >= (uint32_t)((lim >> 24) & 0xffffu)) {
+            const WinRec rec = win_rec();
+            const uint32_t own = rec.n_other;
+            const uint32_t w = wave_uniform(own), lim = wave_uniform(rec.lim_other);
+            rec.n_other = w + kWObserve;
+            const uint32_t m = w & 0xfffu;
+            if (m >= (lim & 0xfffu)) {
+                // (a lane whose counters differ from its wavefront's executed other statements: the counts DO depend on sampled values,
+                //  the probe notwithstanding -- reported, and the host repeats the run with full replay; counters only grow, so the
+                //  step's live observe sees whatever went apart before it)
+                if (__ballot(own != w || rec.n_sample != wave_uniform(rec.n_sample)) != 0ull && A->overflow) *A->overflow = 3;
                 lane_log_w() += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
-                if (m + 1 == (uint32_t)((lim >> 40) & 0xffffu)) { finish_step(); asm volatile("s_endpgm" ::: "memory"); }      // every lane of the wavefront is here
+                if (m + 1 == (lim >> 16)) { finish_step(); asm volatile("s_endpgm" ::: "memory"); }      // every lane of the wavefront is here
             }
             return;
         }
@@ -537,13 +649,11 @@ __device__ inline void predict_impl(const T& x)
     if constexpr (std::is_integral<V>::value || std::is_floating_point<V>::value) {
         if (A->windowed) {
             constexpr bool is_int = std::is_integral<V>::value;
-            WinRec& rec = win_rec();
-            const WinRec own = rec;
-            const unsigned long long w = wave_uniform(own.w), lim = wave_uniform(own.lim);
-            if (w & kWDone) return;
-            rec.w = w + (is_int ? kWPredInt : kWPredReal);
-            if ((uint32_t)((w >> 24) & 0xffffu) < (uint32_t)((lim >> 24) & 0xffffu)) return;           // an earlier step's hit: recorded by that step's launch
-            const uint32_t k = (uint32_t)((w >> (is_int ? 40 : 50)) & 0x3ffu);
+            const WinRec rec = win_rec();
+            const uint32_t w = wave_uniform(rec.n_other), lim = wave_uniform(rec.lim_other);
+            rec.n_other = w + (is_int ? kWPredInt : kWPredReal);
+            if ((w & 0xfffu) < (lim & 0xfffu)) return;                                                // an earlier step's hit: recorded by that step's launch
+            const uint32_t k = (w >> (is_int ? 12 : 22)) & 0x3ffu;
             if constexpr (is_int) {
                 if (A->pred_int) { if (k < A->pred_int_cap) A->pred_int[(int64_t)k * A->ld + lane_index()] = static_cast<int32_t>(x); else if (A->overflow) *A->overflow = 2; }
             } else {

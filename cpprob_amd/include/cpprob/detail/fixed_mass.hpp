@@ -14,7 +14,20 @@
 namespace cph {
 
 constexpr int kHierMaxLevels = 3;
-constexpr int kHierStride = 16;                // 64-bit words between entries of the levels >= 1: one 128-byte line each
+// 64-bit words between entries of the levels >= 1: two 128-byte lines each.  A fixed-point entry is three words: {mass | arrivals}
+// on the first line, {squares, maximum key} on the second (kHierQ, kHierM).  Where the words sit decides what the publishing atomics
+// cost: the unchanged-model step (3907 workgroups at 10^6 particles, three atomics each) paid 5.7 us per launch with all three on
+// one line and 4.3 with one line per word, and nothing measurable with this split (profiles/r04_notes.md); the count form's single
+// word uses the first line.
+#ifndef CPPROB_HIER_STRIDE
+#define CPPROB_HIER_STRIDE 32
+#endif
+constexpr int kHierStride = CPPROB_HIER_STRIDE;
+#ifndef CPPROB_HIER_Q
+#define CPPROB_HIER_Q 16
+#endif
+constexpr int kHierQ = CPPROB_HIER_Q, kHierM = CPPROB_HIER_Q + 1;        // word offsets of the squares / the maximum key inside an entry
+constexpr int kHierArrM = kHierM + 1;                  // arrivals of the exact-maximum pass
 constexpr int64_t kCountsMaxTiles = 64LL * 64 * 64;
 constexpr uint64_t kCntMask = (1ull << 28) - 1;
 
@@ -155,8 +168,8 @@ __device__ __forceinline__ void ftot_fetch(const FHier& f, FTotWords& w)
     const int lane = lane_id();
     const int64_t i = (int64_t)(lane < f.h.top_n ? lane : 0) * f.h.top_stride;
     w.s = f.h.top[i];
-    w.q = f.h.n_lev == 1 ? f.q0[i] : f.h.top[i + 1];
-    w.m = f.h.n_lev == 1 ? f.m0[i] : f.h.top[i + 2];
+    w.q = f.h.n_lev == 1 ? f.q0[i] : f.h.top[i + kHierQ];
+    w.m = f.h.n_lev == 1 ? f.m0[i] : f.h.top[i + kHierM];
 }
 __device__ __forceinline__ FTot ftot_sum(const FHier& f, FTotWords w)
 {
@@ -186,24 +199,22 @@ struct FixedCdf {
 
 // This tile's words of generation t's hierarchy, added into the levels above, and the entries of the third copy this tile is
 // responsible for clearing.  One thread.  (step_counts.hpp: hier_publish -- here a block's line carries three words, and the last
-// tile of a block reads the two it did not get back from its own add.)
-__device__ __forceinline__ void fhier_publish(const FHier& f, int bid, int nb, uint64_t S, uint64_t Q, uint64_t mkey)
+// tile of a block reads the two it did not get back from its own add.)  Two parts: the levels >= 1 (fhier_forward), and the
+// tile's own entries in front of them (fhier_publish) -- a tile that is produced by several workgroups adds into its entries
+// itself and lets its last arriver forward (cpprob/detail/device_trace.hpp: the unchanged-model step).
+__device__ __forceinline__ void fhier_forward(const FHier& f, int bid, int nb, uint64_t S, uint64_t Q, uint64_t mkey)
 {
     const Hier& h = f.h;
-    uint64_t* l0 = const_cast<uint64_t*>(h.lvl[0]);
     uint64_t* l1 = const_cast<uint64_t*>(h.lvl[1]);
     uint64_t* l2 = const_cast<uint64_t*>(h.lvl[2]);
     using ull = unsigned long long;
     const int b1 = bid >> 6, b2 = bid >> 12;
-    l0[h.to_next + bid] = S;
-    const_cast<uint64_t*>(f.q0)[h.to_next + bid] = Q;
-    const_cast<uint64_t*>(f.m0)[h.to_next + bid] = mkey;
     if (h.n_lev == 2) {
         ull* e = reinterpret_cast<ull*>(l1 + h.to_next + (int64_t)b1 * kHierStride);
-        atomicAdd(e, (ull)S); atomicAdd(e + 1, (ull)Q); atomicMax(e + 2, (ull)mkey);
+        atomicAdd(e, (ull)S); atomicAdd(e + kHierQ, (ull)Q); atomicMax(e + kHierM, (ull)mkey);
     } else if (h.n_lev == 3) {
         ull* e = reinterpret_cast<ull*>(l1 + h.to_next + (int64_t)b1 * kHierStride);
-        atomicAdd(e + 1, (ull)Q); atomicMax(e + 2, (ull)mkey);
+        atomicAdd(e + kHierQ, (ull)Q); atomicMax(e + kHierM, (ull)mkey);
         // both have been PERFORMED (device-scope atomics execute where every XCD sees them; the counter waits for their
         // acknowledgement) before this tile's arrival is counted -- no cache write-back: a __threadfence() here flushes the whole
         // L2 of dirty particle rows once per workgroup (measured: 695 us per step at 10^7 particles instead of 60)
@@ -212,13 +223,43 @@ __device__ __forceinline__ void fhier_publish(const FHier& f, int bid, int nb, u
         const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
         if ((int)(old >> 56) == tiles_in_block - 1) {
             const uint64_t totS = (old + S) & kMassMask;
-            const ull totQ = atomicAdd(e + 1, (ull)0), totM = atomicMax(e + 2, (ull)0);       // (read where the adds were performed)
+            const ull totQ = atomicAdd(e + kHierQ, (ull)0), totM = atomicMax(e + kHierM, (ull)0);       // (read where the adds were performed)
             ull* e2 = reinterpret_cast<ull*>(l2 + h.to_next + (int64_t)b2 * kHierStride);
-            atomicAdd(e2, (ull)totS); atomicAdd(e2 + 1, totQ); atomicMax(e2 + 2, totM);
+            atomicAdd(e2, (ull)totS); atomicAdd(e2 + kHierQ, totQ); atomicMax(e2 + kHierM, totM);
         }
     }
-    if (h.n_lev >= 2 && (b1 << 6) == bid) { uint64_t* e = l1 + h.to_clear + (int64_t)b1 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; }
-    if (h.n_lev >= 3 && (b2 << 12) == bid) { uint64_t* e = l2 + h.to_clear + (int64_t)b2 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; }
+    if (h.n_lev >= 2 && (b1 << 6) == bid) { uint64_t* e = l1 + h.to_clear + (int64_t)b1 * kHierStride; e[0] = 0; e[kHierQ] = 0; e[kHierM] = 0; }
+    if (h.n_lev >= 3 && (b2 << 12) == bid) { uint64_t* e = l2 + h.to_clear + (int64_t)b2 * kHierStride; e[0] = 0; e[kHierQ] = 0; e[kHierM] = 0; }
+}
+__device__ __forceinline__ void fhier_publish(const FHier& f, int bid, int nb, uint64_t S, uint64_t Q, uint64_t mkey)
+{
+    const Hier& h = f.h;
+    const_cast<uint64_t*>(h.lvl[0])[h.to_next + bid] = S;
+    const_cast<uint64_t*>(f.q0)[h.to_next + bid] = Q;
+    const_cast<uint64_t*>(f.m0)[h.to_next + bid] = mkey;
+    fhier_forward(f, bid, nb, S, Q, mkey);
+}
+// One of `parts` workgroups that produce tile `bid` together: its share {S, Q, max} is added into the tile's entries (level 0 then
+// carries an arrival count in its top byte, like the levels above: readers mask it), the last one to arrive forwards the tile's
+// totals, part 0 clears the tile's entries of the third copy.  One thread.
+__device__ __forceinline__ void fhier_publish_part(const FHier& f, int bid, int nb, int part, int parts, uint64_t S, uint64_t Q, uint64_t mkey)
+{
+    const Hier& h = f.h;
+    using ull = unsigned long long;
+    ull* e0 = reinterpret_cast<ull*>(const_cast<uint64_t*>(h.lvl[0]) + h.to_next + bid);
+    ull* eq = reinterpret_cast<ull*>(const_cast<uint64_t*>(f.q0) + h.to_next + bid);
+    ull* em = reinterpret_cast<ull*>(const_cast<uint64_t*>(f.m0) + h.to_next + bid);
+    atomicAdd(eq, (ull)Q); atomicMax(em, (ull)mkey);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // performed before this part's arrival is counted (see fhier_forward)
+    const ull old = atomicAdd(e0, (ull)(S + (1ull << 56)));
+    if ((int)(old >> 56) == parts - 1) {
+        const uint64_t totS = (old + S) & kMassMask;
+        const ull totQ = atomicAdd(eq, (ull)0), totM = atomicMax(em, (ull)0);
+        fhier_forward(f, bid, nb, totS, totQ, totM);
+    }
+    if (part == 0) {
+        const_cast<uint64_t*>(h.lvl[0])[h.to_clear + bid] = 0; const_cast<uint64_t*>(f.q0)[h.to_clear + bid] = 0; const_cast<uint64_t*>(f.m0)[h.to_clear + bid] = 0;
+    }
 }
 
 // Largest tile c in [0, nb) whose first owned output G(prefix(c)) is <= g (0 when there is none), with its exclusive prefix mass:
@@ -314,7 +355,7 @@ __device__ __forceinline__ FixedDecision fixed_decide(uint64_t S, uint64_t Q, do
 __device__ __forceinline__ double fixed_reference(bool fresh, double m_prev, double bound) { return fresh ? bound : m_prev + bound; }
 
 // ---- exact-maximum reference (callers without a host-known bound of the step's log-likelihood): maximum pass, then masses ----
-// A block line here: word 0 S | arrivals << 56, word 1 Q, word 2 key(M), word 3 arrivals of the maximum pass.
+// A block entry here: word 0 S | arrivals << 56, word kHierQ Q, word kHierM key(M), word kHierArrM arrivals of the maximum pass.
 __device__ __forceinline__ void bbf_publish_max(const FHier& f, int bid, int nb, uint64_t mkey)
 {
     const Hier& h = f.h;
@@ -324,21 +365,21 @@ __device__ __forceinline__ void bbf_publish_max(const FHier& f, int bid, int nb,
     const int b1 = bid >> 6, b2 = bid >> 12;
     const_cast<uint64_t*>(f.m0)[bid] = mkey;
     if (h.n_lev == 2) {
-        atomicMax(reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride + 2), (ull)mkey);
+        atomicMax(reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride + kHierM), (ull)mkey);
     } else if (h.n_lev == 3) {
         ull* e = reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride);
-        atomicMax(e + 2, (ull)mkey);
+        atomicMax(e + kHierM, (ull)mkey);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // performed before the arrival is counted (no cache write-back: step_fixed.hpp)
-        const ull old = atomicAdd(e + 3, (ull)1);
+        const ull old = atomicAdd(e + kHierArrM, (ull)1);
         const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
         if ((int)old == tiles_in_block - 1) {
-            const ull totM = atomicMax(e + 2, (ull)0);
-            atomicMax(reinterpret_cast<ull*>(l2 + (int64_t)b2 * kHierStride + 2), totM);
+            const ull totM = atomicMax(e + kHierM, (ull)0);
+            atomicMax(reinterpret_cast<ull*>(l2 + (int64_t)b2 * kHierStride + kHierM), totM);
         }
     }
     // the other copy's upper levels: clean for the next step
-    if (h.n_lev >= 2 && (b1 << 6) == bid) { uint64_t* e = l1 + h.to_clear + (int64_t)b1 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; }
-    if (h.n_lev >= 3 && (b2 << 12) == bid) { uint64_t* e = l2 + h.to_clear + (int64_t)b2 * kHierStride; e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; }
+    if (h.n_lev >= 2 && (b1 << 6) == bid) { uint64_t* e = l1 + h.to_clear + (int64_t)b1 * kHierStride; e[0] = 0; e[kHierQ] = 0; e[kHierM] = 0; e[kHierArrM] = 0; }
+    if (h.n_lev >= 3 && (b2 << 12) == bid) { uint64_t* e = l2 + h.to_clear + (int64_t)b2 * kHierStride; e[0] = 0; e[kHierQ] = 0; e[kHierM] = 0; e[kHierArrM] = 0; }
 }
 
 // the generation's largest log-weight from the top level's M words (wave-uniform)
@@ -346,7 +387,7 @@ __device__ __forceinline__ double bbf_top_max(const FHier& f)
 {
     const int lane = lane_id();
     const int64_t i = (int64_t)(lane < f.h.top_n ? lane : 0) * f.h.top_stride;
-    uint64_t m = f.h.n_lev == 1 ? f.m0[i] : f.h.top[i + 2];
+    uint64_t m = f.h.n_lev == 1 ? f.m0[i] : f.h.top[i + kHierM];
     if (lane >= f.h.top_n) m = 0;
     return dkey_inv(wave_max_u64(m));
 }
@@ -363,17 +404,17 @@ __device__ __forceinline__ void bbf_publish_mass(const FHier& f, int bid, int nb
     const_cast<uint64_t*>(f.q0)[bid] = Q;
     if (h.n_lev == 2) {
         ull* e = reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride);
-        atomicAdd(e, (ull)S); atomicAdd(e + 1, (ull)Q);
+        atomicAdd(e, (ull)S); atomicAdd(e + kHierQ, (ull)Q);
     } else if (h.n_lev == 3) {
         ull* e = reinterpret_cast<ull*>(l1 + (int64_t)b1 * kHierStride);
-        atomicAdd(e + 1, (ull)Q);
+        atomicAdd(e + kHierQ, (ull)Q);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const ull old = atomicAdd(e, (ull)(S + (1ull << 56)));
         const int tiles_in_block = nb - (b1 << 6) < 64 ? nb - (b1 << 6) : 64;
         if ((int)(old >> 56) == tiles_in_block - 1) {
-            const ull totQ = atomicAdd(e + 1, (ull)0);
+            const ull totQ = atomicAdd(e + kHierQ, (ull)0);
             ull* e2 = reinterpret_cast<ull*>(l2 + (int64_t)b2 * kHierStride);
-            atomicAdd(e2, (ull)((old + S) & kMassMask)); atomicAdd(e2 + 1, totQ);
+            atomicAdd(e2, (ull)((old + S) & kMassMask)); atomicAdd(e2 + kHierQ, totQ);
         }
     }
 }

@@ -86,11 +86,27 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
 // One SMC step of a model under windowed replay, the resampling INSIDE the launch (cpprob/detail/device_trace.hpp: step_prologue /
 // step_epilogue; the shape of the built-in smc_step_fixed_kernel with the model body where its propagate4 / loglik sit): ancestors by
 // the integer comb over generation t-1's fixed-point masses, the ancestor's window replayed, the step's statements, the new weight
-// quantised and the tile's mass published -- one launch per observe instead of four.  One 1024-particle tile per workgroup.
+// quantised and the workgroup's mass published -- one launch per observe instead of four.
+// Two builds of it: FULL asks the compiler for eight wavefronts a SIMD (64 registers: 2048 workgroups resident, two passes of 3907 at
+// 10^6 particles instead of three) and is used when that costs a few spilled registers; models whose body needs more (fp64 Box-Muller:
+// ~90) run the build that takes what it needs (the host asks the runtime which is which: step_kernel_full).
+template <class Caller, class Tuple, bool FULL>
+__device__ __forceinline__ void model_step_body(const Tuple* __restrict__ observes);
+template <class Caller, class Tuple>
+__global__ __launch_bounds__(device::kStepBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void model_step_kernel_full(ModelKernelArgs a, const Tuple* __restrict__ observes)
+{
+    (void)a;
+    model_step_body<Caller, Tuple, true>(observes);
+}
 template <class Caller, class Tuple>
 __global__ __launch_bounds__(device::kStepBlock) void model_step_kernel(ModelKernelArgs a, const Tuple* __restrict__ observes)
 {
     (void)a;                                                      // (the statements read it where it lies: the kernel-argument segment)
+    model_step_body<Caller, Tuple, false>(observes);
+}
+template <class Caller, class Tuple, bool FULL>
+__device__ __forceinline__ void model_step_body(const Tuple* __restrict__ observes)
+{
     {
         const uint32_t fused = device::launch_args()->fused, win = device::launch_args()->windowed, lanes = device::launch_args()->lane_block;
         __builtin_assume(fused == 1u); __builtin_assume(win == 1u); __builtin_assume(lanes == (uint32_t)device::kStepBlock);
@@ -98,6 +114,18 @@ __global__ __launch_bounds__(device::kStepBlock) void model_step_kernel(ModelKer
     device::step_prologue();
     Caller::call(*observes);
     device::step_epilogue();                                      // the run's last step: the body ran to completion
+}
+
+// which build of the step kernel this model runs: the eight-wavefront build unless it spills more than a handful of registers
+template <class Caller, class Tuple>
+bool step_kernel_full()
+{
+    static const bool full = [] {
+        hipFuncAttributes fa{};
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&model_step_kernel_full<Caller, Tuple>)) != hipSuccess) return false;
+        return fa.localSizeBytes <= 96;                           // (scratch bytes per lane: spilled registers)
+    }();
+    return full;
 }
 
 template <class Tuple> struct observes_bytewise_copyable;
@@ -234,7 +262,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     const bool smc = algorithm == StateType::smc;
     const bool windowed = smc && st.window >= 0;
     const uint32_t w = (uint32_t)std::max(1, st.window);
-    if (!(windowed && opt.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && n <= (std::size_t(1) << 28) && T > 0)) form = StepForm::unfused;
+    if (!(windowed && opt.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && n <= (std::size_t(64) * 64 * 64 * device::kStepBlock) && T > 0)) form = StepForm::unfused;
     const bool fused = form != StepForm::unfused;
 
     // what the host reads when the run is over, side by side -- one copy: [T] step ESS, log evidence | [T] resampling decisions, flag word
@@ -327,11 +355,12 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         // out once at the end by walking the lineages (cpprob_hip_lineage_gather).
         uint64_t* carry[2] = {d_c0, d_c1};
         a.windowed = 1; a.win = w;
-        const dim3 sgrid((unsigned)lay.tiles), sblock(device::kStepBlock);
+        const dim3 sgrid((unsigned)((n + device::kStepBlock - 1) / device::kStepBlock)), sblock(device::kStepBlock);
         const size_t step_lds = device::lane_lds_bytes(device::kStepBlock, true);
+        const bool step_full = fused && step_kernel_full<Caller, Tuple>();
         if (fused) {
             a.lane_block = device::kStepBlock; a.fused = 1;
-            a.fs.ess_frac = opt.ess_threshold; a.fs.n_pop = (double)n; a.fs.T = T; a.fs.nb = lay.tiles;
+            a.fs.ess_frac = opt.ess_threshold; a.fs.n_pop = (double)n; a.fs.T = T; a.fs.nb = lay.blocks;
             a.fs.may_carry = opt.ess_threshold > 1.0 ? 0 : 1; a.fs.exact_ref = form == StepForm::fused_exact ? 1 : 0;
             a.fs.ctrl = static_cast<device::StepCtrl2*>(lay.ctrl); a.fs.ess = d_ess_p; a.fs.resampled = d_res_p; a.fs.log_z = d_logz_p;
             a.fs.gap_limit = kFixGapLimit;
@@ -352,7 +381,8 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
                 a.fs.u0 = cpprob_hip_systematic_offset(opt.seed, (uint64_t)t);
                 a.fs.bound = form == StepForm::fused_bounded ? st.observe_bound[(size_t)t] : 0.0;
                 a.fs.t = t; a.fs.anc_row = d_anc_all + (size_t)t * n;
-                hipLaunchKernelGGL((model_step_kernel<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+                if (step_full) hipLaunchKernelGGL((model_step_kernel_full<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+                else hipLaunchKernelGGL((model_step_kernel<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
                 hip_check(hipGetLastError(), "model_step_kernel");
                 cur ^= 1;
                 if (form == StepForm::fused_exact) ctx.check(cpprob_hip_generic_quantize(ctx.get(), t, logw[cur], n), "cpprob_hip_generic_quantize");
@@ -469,6 +499,9 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     if (overflow == 2)
         throw std::runtime_error("cpprob::inference: a particle executed more predict statements than the model's dry run did; the number "
                                  "and order of observe / predict statements must not depend on sampled values on the device path");
+#ifdef CPPROB_EXP_IGNORE_FLAGS
+    return 0;
+#endif
     if (overflow == 3) return 3;
     if (overflow == 4 || overflow == 5) return 4;
     return overflow != 0 ? 1 : 0;
@@ -484,8 +517,10 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     detail::TraceStructure st_full = st;
     st_full.window = -1;
     const detail::TraceStructure* use = &st;
+    // (windowed replay packs its statement counters into one word per lane: cpprob/detail/device_trace.hpp, WinRec)
+    if (st.n_observe > device::kWinMaxObserves || st.real_rows() > device::kWinMaxPredicts || st.int_ids.size() > device::kWinMaxPredicts) use = &st_full;
     res.markov_crosscheck = 0;
-    if (algorithm == StateType::smc && st.window >= 0 && opt.markov_crosscheck) {
+    if (algorithm == StateType::smc && use->window >= 0 && opt.markov_crosscheck) {
         // The host probe saw a handful of traces; a dependence on older samples that shows on one trace in a thousand passes it.  So
         // the window is certified on the device before it is used: a pilot population under windowed replay and under full replay
         // -- same particle ids, same seed, same bookkeeping between the launches, hence the same variates, weights and ancestors if

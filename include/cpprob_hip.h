@@ -445,25 +445,26 @@ int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* ctx, const double* d_logw, siz
  * The model translation unit owns the kernel (it is a template over the model function); the library owns what the kernel's
  * prologue and epilogue work on: three rotating copies of the 64-ary mass hierarchy (cpprob_amd/include/cpprob/detail/fixed_mass.hpp),
  * the integer weights of two generations and a small control block.  cpprob_hip_generic_begin sizes them for a population of n
- * particles (1024-particle tiles; first call and growth allocate), clears them on the context's stream and describes them in *out;
- * step t of the run reads copy (t + 2) % 3 of the hierarchy, publishes into copy t % 3 and clears the upper levels of copy
- * (t + 1) % 3; integer weights: generation t in q[t & 1].  n <= 2^28. */
+ * particles (one hierarchy entry per 256-particle block = per workgroup of the step kernel; first call and growth allocate), clears
+ * them on the context's stream and describes them in *out; step t of the run reads copy (t + 2) % 3 of the hierarchy, publishes
+ * into copy t % 3 and clears the upper levels of copy (t + 1) % 3; integer weights: generation t in q[t & 1].  n <= 64^3 * 256. */
 typedef struct cpprob_hip_generic_layout {
     uint64_t* hier;            /* [3][per_copy] 64-bit words */
     uint64_t per_copy;
     uint64_t lvl_off[3];       /* word offset of each level inside a copy */
-    int32_t n_ent[3];          /* entries per level (n_ent[0] = tiles) */
+    int32_t n_ent[3];          /* entries per level (n_ent[0] = blocks) */
     int32_t n_lev;
-    uint64_t q0_off, m0_off;   /* the tiles' squares / maxima inside a copy */
+    uint64_t q0_off, m0_off;   /* the blocks' squares / maxima inside a copy */
     void* table;               /* the same layout in device memory (fixed_mass.hpp: HierTable) */
-    uint32_t* q[2];            /* [tiles * 1024] integer weights, by the step's parity */
+    uint32_t* q[2];            /* integer weights, by the step's parity: padded to whole 1024-particle tiles, and one tile more */
     void* ctrl;                /* device_trace.hpp: StepCtrl2 */
-    int32_t tiles;
-    int32_t reserved;
+    int32_t blocks;
+    int32_t block;             /* particles per hierarchy entry: 256 */
 } cpprob_hip_generic_layout;
 int cpprob_hip_generic_begin(cpprob_hip_ctx* ctx, size_t n, cpprob_hip_generic_layout* out);
-/* Exact-reference form (no host-known bound of a step's log-likelihood): the step's launch published the tiles' maxima into copy
- * t % 3; this launch quantises d_logw[0..n) against the generation's exact maximum into q[t & 1] and publishes the masses. */
+/* Exact-reference form (no host-known bound of a step's log-likelihood): the step's launch stored the log-weights only; two short
+ * launches find the generation's exact maximum, quantise d_logw[0..n) against it into q[t & 1] and publish maxima and masses into
+ * copy t % 3. */
 int cpprob_hip_generic_quantize(cpprob_hip_ctx* ctx, int32_t t, const double* d_logw, size_t n);
 /* Bookkeeping of the run's LAST generation (T - 1: the copy (T - 1) % 3): d_ess[T-1], d_resampled[T-1] = 0, the final term of
  * *d_log_z; *d_flags gets 4 / 5 where the generation's heaviest particle sat above / more than gap_limit below its reference. */
