@@ -446,8 +446,17 @@ __device__ __forceinline__ void step_prologue()
         FixedCdf fc;
         fc.u0 = A->fs.u0; fc.n_pop = A->fs.n_pop; fc.base = 0; fc.inv = 0.0;
         if (wv == 0) {
-            const FTot tot = ftot_sum(f, tw);
-            const FixedDecision d = fixed_decide(tot.S, tot.Q, A->fs.n_pop, A->fs.ess_frac, true);        // (generation t-1 is never the last one here)
+            // (where every step resamples -- a threshold above 1 -- the decision and the reference need the generation's mass alone:
+            //  squares and maximum are the bookkeeping's, summed by workgroup 0 only: two wavefront reductions off everyone else's search)
+            FTot tot;
+            FixedDecision d;
+            if (A->fs.may_carry || bid == 0) {
+                tot = ftot_sum(f, tw);
+                d = fixed_decide(tot.S, tot.Q, A->fs.n_pop, A->fs.ess_frac, true);        // (generation t-1 is never the last one here)
+            } else {
+                tot.S = wave_sum_u64((tid < f.h.top_n ? tw.s : 0ull) & kMassMask); tot.Q = 0; tot.M = 0.0;
+                d.resample = tot.S > 0; d.inv = A->fs.n_pop / u64_to_double(tot.S); d.W = 0.0; d.Qd = 0.0; d.ess = 0.0;
+            }
             fc.inv = d.inv;
             const double r_t = fixed_reference(d.resample, tot.M, A->fs.bound);
             if (bid == 0 && tid == 0) {
@@ -572,10 +581,12 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
         if (A->windowed) {
             // (scalar control flow: see WinRec)
             const WinRec rec = win_rec();
-            const int32_t jj = (int32_t)wave_uniform(rec.n_sample);
-            const uint32_t lim = wave_uniform(rec.lim_sample);
-            rec.n_sample = (uint32_t)jj + 1u;
-            if ((uint32_t)jj < lim) return R();                           // older than the window: the step does not depend on it (host probe)
+            const uint32_t n_own = rec.n_sample;
+            rec.n_sample = n_own + 1u;
+            // (the test on the lanes' own words, made uniform by the ballot: one vector compare and a scalar branch -- the scalar
+            //  unit, shared by the CU's four SIMDs, is what bounds the dead iterations; the ordinal goes through it on the live path only)
+            if (__ballot(n_own < rec.lim_sample) != 0ull) return R();     // older than the window: the step does not depend on it (host probe)
+            const int32_t jj = (int32_t)wave_uniform(n_own);
             const int32_t base = A->fresh_lo - (int32_t)A->win;
             R v;
             if (jj < A->fresh_lo) v = from_raw<R>(A->carry_in[(int64_t)(jj - base) * A->ld + lane_src()]);
@@ -610,11 +621,11 @@ __device__ inline void observe_impl(Distribution& distr, const X& x)
         LaunchArgsPtr A = launch_args();
         if (A->windowed) {
             const WinRec rec = win_rec();
-            const uint32_t own = rec.n_other;
-            const uint32_t w = wave_uniform(own), lim = wave_uniform(rec.lim_other);
-            rec.n_other = w + kWObserve;
-            const uint32_t m = w & 0xfffu;
-            if (m >= (lim & 0xfffu)) {
+            const uint32_t own = rec.n_other, lim_own = rec.lim_other;
+            rec.n_other = own + kWObserve;
+            if (__ballot((own & 0xfffu) >= (lim_own & 0xfffu)) != 0ull) {
+                const uint32_t w = wave_uniform(own), lim = wave_uniform(lim_own);
+                const uint32_t m = w & 0xfffu;
                 // (a lane whose counters differ from its wavefront's executed other statements: the counts DO depend on sampled values,
                 //  the probe notwithstanding -- reported, and the host repeats the run with full replay; counters only grow, so the
                 //  step's live observe sees whatever went apart before it)
@@ -650,9 +661,10 @@ __device__ inline void predict_impl(const T& x)
         if (A->windowed) {
             constexpr bool is_int = std::is_integral<V>::value;
             const WinRec rec = win_rec();
-            const uint32_t w = wave_uniform(rec.n_other), lim = wave_uniform(rec.lim_other);
-            rec.n_other = w + (is_int ? kWPredInt : kWPredReal);
-            if ((w & 0xfffu) < (lim & 0xfffu)) return;                                                // an earlier step's hit: recorded by that step's launch
+            const uint32_t own = rec.n_other;
+            rec.n_other = own + (is_int ? kWPredInt : kWPredReal);
+            if (__ballot((own & 0xfffu) < (rec.lim_other & 0xfffu)) != 0ull) return;                    // an earlier step's hit: recorded by that step's launch
+            const uint32_t w = wave_uniform(own);
             const uint32_t k = (w >> (is_int ? 12 : 22)) & 0x3ffu;
             if constexpr (is_int) {
                 if (A->pred_int) { if (k < A->pred_int_cap) A->pred_int[(int64_t)k * A->ld + lane_index()] = static_cast<int32_t>(x); else if (A->overflow) *A->overflow = 2; }
