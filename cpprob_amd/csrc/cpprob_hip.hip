@@ -2400,7 +2400,7 @@ __global__ __launch_bounds__(kWave) void generic_finish_kernel(FHier f, int T, d
     ess[T - 1] = d.ess;
     resampled[T - 1] = 0;
     const double lz = T == 1 ? 0.0 : *log_z;
-    *log_z = lz + ref + log(d.W / n_pop);
+    *log_z = lz + (ref + log(d.W / n_pop));
 }
 
 // (re)lays the three-copy hierarchy out for populations of nb 256-particle blocks

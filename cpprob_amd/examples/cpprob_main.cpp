@@ -155,6 +155,7 @@ int main(int argc, char** argv)
         if (a.model == "second_order12") return execute(models::second_order<12>, a);
         if (a.model == "running_mean12") return execute(models::running_mean<12>, a);
         if (a.model == "rare_memory12") return execute(models::rare_memory<12>, a);
+        if (a.model == "random_scale12") return execute(models::random_scale<12>, a);
         if (a.model == "all_distr") return execute(models::all_distr<int>, a);                                   // src/models/models.cpp:13-47; observes: any two ints
         std::cerr << "unknown model " << a.model << std::endl;
         return EXIT_FAILURE;

@@ -47,6 +47,7 @@ CPPROB_REGISTER_MODEL(models::gaussian_by_rejection<double>);
 CPPROB_REGISTER_MODEL(models::second_order<12>);
 CPPROB_REGISTER_MODEL(models::running_mean<12>);
 CPPROB_REGISTER_MODEL(models::rare_memory<12>);
+CPPROB_REGISTER_MODEL(models::random_scale<12>);
 CPPROB_REGISTER_BUILTIN(models::gaussian_readme<double>, CPPROB_HIP_MODEL_GAUSSIAN_README);
 #endif
 // vector-valued statements through the generic path: the device view of the same function

@@ -189,6 +189,24 @@ void rare_memory(const std::array<double, N>& y)
     }
 }
 
+// random_scale: the emission's standard deviation is itself sampled, so the density at the observe statement's mode differs from
+// particle to particle -- there is no host-known bound of a step's log-likelihood (the engine's fixed-point weights then take the
+// generation's exact maximum as their reference).
+template <std::size_t N>
+void random_scale(const std::array<double, N>& y)
+{
+    double x = 0;
+    for (std::size_t t = 0; t < N; ++t) {
+        boost::random::uniform_real_distribution<> scale{0.5, 2.0};
+        const double sd = cpprob::sample(scale, true);
+        boost::random::normal_distribution<> transition{x, 1};
+        x = cpprob::sample(transition, true);
+        boost::random::normal_distribution<> emission{x, sd};
+        cpprob::observe(emission, y[t]);
+        cpprob::predict(x, "State");
+    }
+}
+
 // One statement triple -- sample, address-less predict, observe of the sampled value -- per distribution of the library
 // (restates the statement sequence of reference src/models/models.cpp:13-47; the two ints are unused there too; a template here so that
 // host programs link the model library's instantiation: registered_models.hpp).  Every predict gets

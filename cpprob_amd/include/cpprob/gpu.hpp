@@ -217,7 +217,7 @@ private:
 enum class StepForm {
     unfused,        // model launch + cpprob_hip_smc_bookkeep(_fixed): full replay, the other resamplers, the Markov pilot
     fused_bounded,  // model_step_kernel, fixed-point weights against the dry run's per-observe bounds: ONE launch per observe
-    fused_exact     // model_step_kernel + cpprob_hip_generic_quantize against the generation's exact maximum: two launches per observe
+    fused_exact     // model_step_kernel + cpprob_hip_generic_quantize (maximum pass, masses) against the generation's exact maximum: three launches per observe
 };
 constexpr double kFixGapLimit = 6.0;            // nats a generation's heaviest particle may sit below its reference (csrc/step_fixed.hpp: the same contract)
 
@@ -364,7 +364,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
             a.fs.may_carry = opt.ess_threshold > 1.0 ? 0 : 1; a.fs.exact_ref = form == StepForm::fused_exact ? 1 : 0;
             a.fs.ctrl = static_cast<device::StepCtrl2*>(lay.ctrl); a.fs.ess = d_ess_p; a.fs.resampled = d_res_p; a.fs.log_z = d_logz_p;
             a.fs.gap_limit = kFixGapLimit;
-            res.launches_per_step = form == StepForm::fused_exact ? 2 : 1;
+            res.launches_per_step = form == StepForm::fused_exact ? 3 : 1;
         } else res.launches_per_step = 4;
         for (int t = 0; t < T; ++t) {
             const bool last = t + 1 == T;

@@ -88,16 +88,92 @@ def test_generic_and_builtin_agree_hmm_smc(tmp_path):
     assert pb.shape == (16, 3)
     np.testing.assert_allclose(pb, pg, atol=2e-3)
     assert np.abs(pb - z["hmm16_smooth"]).max() < 0.04
-    # full traces of the surviving particles: identical files except for rare CDF-boundary flips
+    # the two paths resample on DIFFERENT integer arithmetic (the built-in kernel: prefix counts of three table weights; the unchanged
+    # model: fixed-point masses against the observe statement's bound), so their files agree up to rare CDF-boundary flips ...
     vb, lwb = read_dump(str(tmp_path / "b_smc.int"), True)
     vg, lwg = read_dump(str(tmp_path / "g_smc.int"), True)
     assert vb.shape == vg.shape == (16, n)
     assert np.mean(vb != vg) < 2e-3
     np.testing.assert_allclose(np.sort(lwb), np.sort(lwg), atol=1e-9)
-    # and the oracle
-    r = O.smc(O.MODEL_HMM3, z["hmm16"], n, 3, O.RESAMPLE_SYSTEMATIC, 2.0)
+    # ... and EACH equals the oracle's statement of its own arithmetic, trace for trace
+    assert rg["step_form"] == 1 and rg["launches_per_step"] == 1 and rg["replay_window"] == 1 and rg["markov_crosscheck"] == 1
+    r = O.smc_ref(O.MODEL_HMM3, z["hmm16"], n, 3, O.REF_STATEMENT_BOUND, O.RESAMPLE_SYSTEMATIC, 2.0)
+    assert np.array_equal(vg, np.take_along_axis(r["hist"], O.lineage(r["anc"]), axis=1))
+    np.testing.assert_allclose(lwg, r["logw"], atol=1e-12)
+    assert abs(rg["log_evidence"] - r["log_z"]) < 1e-12
+    rt = O.smc(O.MODEL_HMM3, z["hmm16"], n, 3, O.RESAMPLE_SYSTEMATIC, 2.0)
+    assert np.array_equal(vb, np.take_along_axis(rt["hist"], O.lineage(rt["anc"]), axis=1))
+
+
+@pytest.mark.parametrize("model,key,T,ess,oid,is_int", [("hmm16", "hmm16", 16, 2.0, O.MODEL_HMM3, True), ("hmm16", "hmm16", 16, 0.5, O.MODEL_HMM3, True),
+                                                        ("linear_gaussian_1d25", "lgssm100", 25, 0.5, O.MODEL_LINEAR_GAUSSIAN_1D, False)])
+@pytest.mark.parametrize("form,ref_mode,launches", [(1, O.REF_STATEMENT_BOUND, 1), (2, O.REF_EXACT_MAX, 3), (0, O.REF_EXACT_MAX, 4)])
+def test_unchanged_model_smc_equals_the_oracle_in_every_step_form(tmp_path, model, key, T, ess, oid, is_int, form, ref_mode, launches):
+    """cpprob::inference(StateType::smc, <unchanged model>) (reference cpprob.hpp:173-203 with models.hpp:67-80,114-141 as the model):
+    the resampling inside the model's own launch against the dry run's bounds (1), against exact maxima (2), and as separate
+    bookkeeping launches (0) -- each the oracle's fixed-point SMC with the same reference rule: surviving traces array_equal."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    obs = z[key][:T]
+    n = 40000
+    res, _, _ = run_main(tmp_path, "--model", model, "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 3, "--ess_threshold", ess, "--json",
+                         "--generic", "--generated_file", "g", "--step_form", form)
+    assert res["step_form"] == form and res["launches_per_step"] == launches and res["replay_window"] == 1
+    vg, lwg = read_dump(str(tmp_path / ("g_smc.int" if is_int else "g_smc.real")), is_int)
+    r = O.smc_ref(oid, obs, n, 3, ref_mode, O.RESAMPLE_SYSTEMATIC, ess)
     paths = np.take_along_axis(r["hist"], O.lineage(r["anc"]), axis=1)
-    assert np.mean(vg != paths) < 2e-3
+    assert res["n_resampled"] == int(r["resampled"].sum())
+    if is_int:
+        assert np.array_equal(vg, paths)
+    else:
+        np.testing.assert_allclose(vg, paths, rtol=0, atol=1e-10)     # lean vs libm normal draws (1e-11), the same ancestors
+        assert np.array_equal(np.argsort(vg[-1], kind="stable"), np.argsort(paths[-1], kind="stable"))
+    np.testing.assert_allclose(lwg, r["logw"], atol=1e-10)
+    assert abs(res["log_evidence"] - r["log_z"]) < 1e-9
+
+
+def test_unchanged_model_step_falls_back_to_exact_maxima_when_a_generation_leaves_its_bound(tmp_path):
+    """An observation 30 sigma from every state: the observe statement's bound lies > 6 nats above every particle, the integer
+    weights would lose their bits -- the device flags the generation and the run is repeated against exact maxima (two launches per
+    observe); the result is the oracle's exact-maximum form."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    obs = np.array(z["hmm16"], dtype=float)
+    obs[5] = 31.0
+    n = 30000
+    res, _, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 11, "--ess_threshold", 2.0, "--json",
+                         "--generic", "--generated_file", "g")
+    assert res["step_form"] == 2 and res["launches_per_step"] == 3
+    vg, lwg = read_dump(str(tmp_path / "g_smc.int"), True)
+    r = O.smc_ref(O.MODEL_HMM3, obs, n, 11, O.REF_EXACT_MAX, O.RESAMPLE_SYSTEMATIC, 2.0)
+    assert np.array_equal(vg, np.take_along_axis(r["hist"], O.lineage(r["anc"]), axis=1))
+    assert abs(res["log_evidence"] - r["log_z"]) < 1e-9
+
+
+def test_unchanged_model_without_a_likelihood_bound_takes_exact_maxima(tmp_path):
+    """random_scale samples the emission's standard deviation: the observe statement's density at its mode differs from trace to trace,
+    the host probe sees that, and the step takes its references from exact maxima -- the same integers as the separate bookkeeping
+    launches, so the two forms' files are identical."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    obs = z["lgssm100"][:12]
+    n = 40000
+    base = ["--model", "random_scale12", "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 6, "--ess_threshold", 0.5, "--json", "--generic"]
+    a, _, _ = run_main(tmp_path, *base, "--generated_file", "a")
+    b, _, _ = run_main(tmp_path, *base, "--generated_file", "b", "--step_form", 0)
+    assert a["step_form"] == 2 and b["step_form"] == 0 and a["replay_window"] == 1 and a["markov_crosscheck"] == 1
+    va, lwa = read_dump(str(tmp_path / "a_smc.real"), False)
+    vb, lwb = read_dump(str(tmp_path / "b_smc.real"), False)
+    assert np.array_equal(va, vb) and np.array_equal(lwa, lwb) and a["log_evidence"] == b["log_evidence"] and a["n_resampled"] == b["n_resampled"]
+    assert 0 < a["n_resampled"] < 11
+
+
+def test_unchanged_model_keeps_its_context_and_workspace_across_inference_calls(tmp_path):
+    """--repeat calls cpprob::inference again and again, as src/main.cpp would in a loop: the first call creates the context and
+    sizes the device workspace, the later ones find both (set-up in the tens of microseconds)."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    res, out, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(z["hmm16"]), "--n_samples", 200000, "--seed", 3, "--ess_threshold", 2.0,
+                           "--json", "--generic", "--no_dump", "--repeat", 4)
+    setups = [float(l.split("set-up")[1].split("ms")[0]) for l in out.splitlines() if l.startswith("run ")]
+    assert len(setups) == 4 and setups[0] > 5.0 and max(setups[1:]) < 2.0
+    assert res["workspace_grown"] is False and res["step_form"] == 1
 
 
 def test_filtering_only_run_from_the_cpp_host(tmp_path):
@@ -372,12 +448,20 @@ def test_markov_probe_finds_the_replay_window_and_changes_no_number(tmp_path, mo
     T = {"hmm16": 16, "linear_gaussian_1d25": 25}.get(model, 12)
     obs = z["hmm16"] if model == "hmm16" else z["lgssm100"][:T]
     common = ["--model", model, "--smc", "--observes", obs_str(obs), "--n_samples", 50000, "--seed", 8, "--ess_threshold", 0.5, "--generic", "--json", "--no_dump"]
-    a, _, _ = run_main(tmp_path, *common)
+    # (same bookkeeping between the launches on both sides -- step form 0 -- so that the replay is the only difference)
+    a, _, _ = run_main(tmp_path, *common, "--step_form", 0)
     b, _, _ = run_main(tmp_path, *common, "--no_markov_probe")
     assert a["replay_window"] == window and b["replay_window"] == -1 and not a["builtin"]
     assert a["log_evidence"] == b["log_evidence"] and a["n_resampled"] == b["n_resampled"] and a["ess"] == b["ess"]
     for pa, pb in zip(a["predicts"], b["predicts"]):
         assert pa == pb
+    # the default form (resampling inside the model's launch, its own reference rule): the same posterior up to Monte-Carlo error
+    d, _, _ = run_main(tmp_path, *common)
+    assert d["replay_window"] == window and d["step_form"] == (1 if window >= 0 else 0)
+    assert abs(d["log_evidence"] - b["log_evidence"]) < 0.05
+    for pd, pb in zip(d["predicts"], b["predicts"]):
+        if "mean" in pd: assert abs(pd["mean"] - pb["mean"]) < 0.05
+        else: assert np.abs(np.array(pd["p"]) - np.array(pb["p"][:len(pd["p"])])).max() < 0.02
 
 
 def test_device_pilot_refutes_a_window_the_host_probe_lets_through(tmp_path):
