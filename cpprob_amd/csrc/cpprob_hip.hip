@@ -2368,9 +2368,10 @@ __global__ __launch_bounds__(kThreads) void generic_max_kernel(const double* __r
     if (lane_id() == 0 && blk < n_blocks) bbf_publish_max(f, blk, n_blocks, mw);
 }
 
-__global__ __launch_bounds__(kThreads) void generic_quantize_kernel(const double* __restrict__ logw, int64_t n, FHier f, int n_blocks, uint32_t* __restrict__ q, GenericCtrlBlock* ctrl)
+__global__ __launch_bounds__(kThreads) void generic_quantize_kernel(const double* __restrict__ logw, int64_t n, FHier f, int n_blocks, uint32_t* __restrict__ q, GenericCtrlBlock* ctrl,
+                                                                int given, double ref_given)
 {
-    const double ref = bbf_top_max(f);                                  // (every wavefront: the same <= 64 words)
+    const double ref = given ? ref_given : bbf_top_max(f);              // (every wavefront: the same <= 64 words)
     if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->ref_cur = ref;
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;
     U4 w;
@@ -2471,16 +2472,42 @@ int cpprob_hip_generic_begin(cpprob_hip_ctx* c, size_t n, cpprob_hip_generic_lay
     return 0;
 }
 
-int cpprob_hip_generic_quantize(cpprob_hip_ctx* c, int32_t t, const double* d_logw, size_t n)
+static int generic_exact_passes(cpprob_hip_ctx* c, int32_t t, const double* d_logw, size_t n, bool max_pass, bool mass_pass, int given, double ref)
 {
-    BB_PRELUDE(c);
     if (!d_logw || t < 0) return fail(c, CPPROB_HIP_EINVAL, "bad argument");
     const int nb = (int)((n + kGenBlock - 1) / kGenBlock), nt = (int)((n + kTile - 1) / kTile);
     if (nb != c->gen_nb || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
     FHier f{};
     generic_view(c, t % 3, t % 3, (t + 1) % 3, f);
-    hipLaunchKernelGGL(generic_max_kernel, dim3(nt), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, nb);
-    hipLaunchKernelGGL(generic_quantize_kernel, dim3(nt), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, nb, c->d_gen_q[t & 1], static_cast<GenericCtrlBlock*>(c->d_gen_ctrl));
+    if (max_pass) hipLaunchKernelGGL(generic_max_kernel, dim3(nt), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, nb);
+    if (mass_pass) hipLaunchKernelGGL(generic_quantize_kernel, dim3(nt), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, nb, c->d_gen_q[t & 1], static_cast<GenericCtrlBlock*>(c->d_gen_ctrl), given, ref);
+    HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+int cpprob_hip_generic_quantize(cpprob_hip_ctx* c, int32_t t, const double* d_logw, size_t n)
+{
+    BB_PRELUDE(c);
+    return generic_exact_passes(c, t, d_logw, n, true, true, 0, 0.0);
+}
+int cpprob_hip_generic_max(cpprob_hip_ctx* c, int32_t t, const double* d_logw, size_t n)
+{
+    BB_PRELUDE(c);
+    return generic_exact_passes(c, t, d_logw, n, true, false, 0, 0.0);
+}
+int cpprob_hip_generic_quantize_ref(cpprob_hip_ctx* c, int32_t t, const double* d_logw, size_t n, double ref)
+{
+    BB_PRELUDE(c);
+    return generic_exact_passes(c, t, d_logw, n, false, true, 1, ref);
+}
+int cpprob_hip_generic_totals(cpprob_hip_ctx* c, int32_t t, size_t n, uint64_t* d_out3)
+{
+    BB_PRELUDE(c);
+    if (!d_out3 || t < 0) return fail(c, CPPROB_HIP_EINVAL, "bad argument");
+    const int nb = (int)((n + kGenBlock - 1) / kGenBlock);
+    if (nb != c->gen_nb || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
+    FHier f{};
+    generic_view(c, t % 3, t % 3, t % 3, f);
+    hipLaunchKernelGGL(fixed_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, f, d_out3);
     HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -55,6 +55,26 @@ struct FusedStep {
     double gap_limit;                          // a generation whose heaviest particle sits further below its reference raises flag 5
 };
 
+// One shard of a JOINT population (cpprob/gpu.hpp: generic_joint): the resampling is the whole population's -- ancestors are searched
+// in the hierarchy and the weights of whichever rank owns them and their windows are read from that rank's store through its mapping
+// (peer access between the GPUs of a process; plain pointers when several ranks share one GPU) -- the migration is a PULL by the
+// receiving rank's step launch: no packing launch on the sender, no remote writes.  The 24 bytes a rank contributes to a generation's
+// totals travel through the host between two launches (an all-gather among the ranks' host threads), which therefore takes the
+// decision and hands it to the next launch ready-made.
+constexpr int kMaxShards = 16;
+constexpr int kShardIndexBits = 26;                                    // an ancestor's code: rank << 26 | slot on that rank (shards up to 6.7e7 particles)
+struct ShardPeer {                                                     // rank r's generation t-1 as every rank addresses it
+    cph::FHier f; const uint32_t* q; const uint64_t* carry; int64_t n; int32_t nb, pad;
+};
+struct ShardArgs {
+    int32_t world, rank;                                               // world = 0: a population of its own
+    const ShardPeer* peers;                                            // [world], device memory of this rank
+    double obound[kMaxShards + 1];                                     // o_r = first output owned by rank r's sources (o_world = N): G(mass before rank r)
+    uint64_t before[kMaxShards];                                       // mass of the ranks before r
+    uint64_t first[kMaxShards + 1];                                    // global id of rank r's first particle
+    double inv, ref; int32_t resample, pad;                            // generation t-1's decision and generation t's reference, taken on the host
+};
+
 // What every statement of a launch reads and none writes: the kernel's first argument.  A statement fetches the fields it needs
 // straight from the kernel-argument segment (scalar loads into scalar registers, wherever in the call tree it sits), so they cost
 // no LDS and no vector registers.  model_kernel / model_step_kernel (cpprob/gpu.hpp) take this struct as their FIRST parameter.
@@ -83,6 +103,7 @@ struct LaunchArgs {
     uint32_t lane_block;           // lanes per workgroup: kLaneBlock or kStepBlock (the lanes' LDS state is laid out by it)
     uint32_t fused;                // model_step_kernel: the step's observe quantises the weight and publishes the tile's mass before it ends the wavefront
     FusedStep fs;
+    ShardArgs sh;
 };
 typedef const LaunchArgs __attribute__((address_space(4))) * LaunchArgsPtr;
 __device__ inline LaunchArgsPtr launch_args() { return (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
@@ -295,11 +316,10 @@ __device__ __forceinline__ void step_probe_fetch(const cph::Hier& h, int own, in
 // The SEARCH (one wavefront; csrc/step_fixed.hpp: fixed_locate, with a wider probe over smaller entries): lane i evaluates the first
 // output G owned by the sources from block cs + i on; the first source block of this workgroup's outputs is the last one whose G
 // does not exceed the first output.  A miss descends the hierarchy from the top.
-__device__ __forceinline__ StepLocated step_locate(const cph::FHier& f, const cph::FixedCdf& fc, int nb, double gj_first, int n_out, int own, const StepProbeWords& pw)
+__device__ __forceinline__ StepLocated step_locate(const cph::FHier& f, const cph::FixedCdf& fc, int nb, double gj_first, double gj_last, int own, const StepProbeWords& pw)
 {
     using namespace cph;
     const int lane = threadIdx.x & 63;
-    const double gj_last = gj_first + (double)(n_out - 1);
     const int cs = step_probe_start(own);
     const uint64_t Pc = fhier_prefix_sum(cs, pw.lvl);
     const uint64_t we = (lane < kStepProbe && cs + lane < nb) ? (pw.we & kMassMask) : 0ull;
@@ -344,11 +364,15 @@ __device__ __forceinline__ int32_t step_prefix_max(StepLds& L)
 // index into the slot of its FIRST output, one prefix-max hands every output its ancestor.  Slots must hold -1 and be visible on
 // entry.  Integers throughout: the same ancestors as any other tiling of the same masses.
 struct StepFetched { uint32_t q[kStepFetch]; int first; };      // the weights of blocks first .. first + kStepFetch - 1 (lane's particle of each), fetched at entry
-__device__ __forceinline__ int32_t step_walk(const cph::FixedCdf& fc, const uint32_t* __restrict__ qprev, int64_t n, int nb, double gj_first, int n_out,
-                                             const StepLocated& loc, const StepFetched& pf, StepLds& L)
+// One pass over ONE rank's sources: gj_first = the workgroup's first output (slots are relative to it), gj_last = the last output
+// these sources may own (n_out = the workgroup's outputs: a source's range is cut there -- the lanes behind a shard's last particle
+// redo that particle and must find ITS ancestor, not that of an output another workgroup owns); last_rank: the population's last source
+// owns the rest; code_hi = the rank's bits of an ancestor's code.
+// The final prefix-max (step_prefix_max, behind a barrier) is the caller's: a workgroup at a shard boundary makes several passes.
+__device__ __forceinline__ void step_walk(const cph::FixedCdf& fc, const uint32_t* __restrict__ qprev, int64_t n, int nb, double gj_first, int n_out, double gj_last,
+                                          bool last_rank, int32_t code_hi, const StepLocated& loc, const StepFetched& pf, StepLds& L)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double gj_last = gj_first + (double)(n_out - 1);
     int c = __builtin_amdgcn_readfirstlane(loc.c);
     const int c_last = __builtin_amdgcn_readfirstlane(loc.c_last);
     uint64_t P = loc.P;
@@ -361,7 +385,7 @@ __device__ __forceinline__ int32_t step_walk(const cph::FixedCdf& fc, const uint
         if (!have && cc < nb) v = qprev[(int64_t)cc * kStepBlock + tid];
         return ((int64_t)cc * kStepBlock + tid < n && cc <= c_last) ? v : 0u;      // slots beyond the population (and blocks beyond the last source) weigh nothing
     };
-    auto place = [&](double g) -> int { return (int)fmin(fmax(g - gj_first, 0.0), (double)kStepBlock); };      // exact: integers
+    auto place = [&](double g) -> int { return (int)fmin(fmax(g - gj_first, 0.0), (double)n_out); };      // exact: integers
     uint32_t raw[kStepPass];
 #pragma unroll
     for (int k = 0; k < kStepPass; ++k) raw[k] = load_q(c + k);
@@ -385,8 +409,8 @@ __device__ __forceinline__ int32_t step_walk(const cph::FixedCdf& fc, const uint
             const int64_t src = (int64_t)(c + k) * kStepBlock + tid;
             const int p_prev = place(fc.g(excl));
             int p = place(fc.g(excl + raw[k]));
-            if (src + 1 == n) p = place(fc.n_pop);                     // the population's last source owns the rest
-            if (p > p_prev && src < n) L.slot[p_prev] = (int32_t)src;
+            if (last_rank && src + 1 == n) p = place(fc.n_pop);         // the population's last source owns the rest
+            if (p > p_prev && src < n) L.slot[p_prev] = (int32_t)src | code_hi;
             P += tot;
         }
         ++it;
@@ -394,8 +418,6 @@ __device__ __forceinline__ int32_t step_walk(const cph::FixedCdf& fc, const uint
         for (int k = 0; k < kStepPass; ++k) raw[k] = raw_next[k];
         c += kStepPass;
     }
-    __syncthreads();
-    return step_prefix_max(L);
 }
 
 // the hierarchy's view, field by field out of the kernel-argument segment (scalar loads)
@@ -410,6 +432,46 @@ __device__ __forceinline__ cph::FHier step_hier()
     f.h.top = A->fs.f.h.top; f.h.top_n = A->fs.f.h.top_n; f.h.top_stride = A->fs.f.h.top_stride;
     f.q0 = A->fs.f.q0; f.m0 = A->fs.f.m0;
     return f;
+}
+
+// A joint population's resampling for this workgroup's outputs [g0, g0 + n_out): for every rank whose sources own some of them, the
+// search in THAT rank's hierarchy and the walk over THAT rank's weights; the decision, the comb's scale and the ranks' offspring
+// bounds come ready-made from the host (ShardArgs).  Returns the ancestor's code.
+__device__ __forceinline__ int32_t step_resample_joint(const StepFetched& pf, StepLds& L)
+{
+    using namespace cph;
+    LaunchArgsPtr A = launch_args();
+    const int tid = threadIdx.x, wv = tid >> 6;
+    const int world = A->sh.world, rank = A->sh.rank;
+    const int bid = (int)blockIdx.x;
+    const int64_t rem = A->n - (int64_t)bid * kStepBlock;
+    const int n_out = rem < kStepBlock ? (int)rem : kStepBlock;
+    const double g0 = (double)(A->sh.first[rank] + (uint64_t)bid * kStepBlock), g_end = g0 + (double)n_out;
+    FixedCdf fc;
+    fc.u0 = A->fs.u0; fc.n_pop = A->fs.n_pop; fc.inv = A->sh.inv; fc.base = 0;
+    for (int r = 0; r < world; ++r) {
+        const double o_lo = A->sh.obound[r], o_hi = A->sh.obound[r + 1];
+        if (o_hi <= g0 || o_lo >= g_end || o_hi <= o_lo) continue;     // (uniform) none of these outputs descends from rank r
+        const ShardPeer* pr = A->sh.peers + r;
+        const double lo = fmax(g0, o_lo), hi_last = fmin(g_end, o_hi) - 1.0;
+        fc.base = A->sh.before[r];
+        const int nb_r = pr->nb;
+        // the first output's ancestor is expected where the output itself sits in the population (equal shards: the same block of rank r)
+        const double at = lo - (double)A->sh.first[r];
+        const int guess = (int)fmin(fmax(floor(at * (1.0 / kStepBlock)), 0.0), (double)(nb_r - 1));
+        if (wv == 0) {
+            StepProbeWords pw;
+            step_probe_fetch(pr->f.h, guess, nb_r, pw);
+            const StepLocated loc = step_locate(pr->f, fc, nb_r, lo, hi_last, guess, pw);
+            if (tid == 0) L.found.loc = loc;
+        }
+        __syncthreads();
+        StepFetched none{};
+        none.first = -(1 << 28);
+        step_walk(fc, pr->q, pr->n, nb_r, g0, n_out, hi_last, r + 1 == world, r << kShardIndexBits, L.found.loc, r == rank ? pf : none, L);
+        __syncthreads();                                               // (the next pass overwrites the hand-over)
+    }
+    return step_prefix_max(L);
 }
 
 // Prologue of model_step_kernel: the lane's ancestor and carried log-weight; bookkeeping of generation t-1 (one thread).
@@ -438,11 +500,21 @@ __device__ __forceinline__ void step_prologue()
     }
     int32_t anc = (int32_t)i;
     bool resample = false;
-    if (t > 0) {
+    const bool joint = A->sh.world != 0;
+    if (joint) anc |= A->sh.rank << kShardIndexBits;                   // (an ancestor's code names its rank)
+    if (t > 0 && joint) {
+        L.slot[tid] = -1;
+        resample = A->sh.resample != 0;
+        if (resample) {
+            anc = step_resample_joint(pf, L);
+            lw_carry = 0.0;
+            if ((int64_t)bid * kStepBlock + tid < n) A->fs.anc_row[i] = anc;
+        }
+    } else if (t > 0) {
         L.slot[tid] = -1;
         const int64_t rem = n - (int64_t)bid * kStepBlock;
         const int n_out = rem < kStepBlock ? (int)rem : kStepBlock;
-        const double gj_first = (double)((uint64_t)bid * kStepBlock);
+        const double gj_first = (double)((uint64_t)bid * kStepBlock), gj_last = gj_first + (double)(n_out - 1);
         FixedCdf fc;
         fc.u0 = A->fs.u0; fc.n_pop = A->fs.n_pop; fc.base = 0; fc.inv = 0.0;
         if (wv == 0) {
@@ -475,19 +547,20 @@ __device__ __forceinline__ void step_prologue()
                 if (!A->fs.exact_ref) c->ref_cur = r_t;
             }
             StepLocated loc{0, 0, 0};
-            if (d.resample) loc = step_locate(f, fc, nb, gj_first, n_out, bid, pw0);
+            if (d.resample) loc = step_locate(f, fc, nb, gj_first, gj_last, bid, pw0);
             if (tid == 0) { L.found.loc = loc; L.found.inv = d.inv; L.found.ref = r_t; L.found.resample = d.resample ? 1 : 0; }
         }
         __syncthreads();                                               // slots reset, search results in place
         resample = L.found.resample != 0;
         if (resample) {
             fc.inv = L.found.inv;
-            anc = step_walk(fc, A->fs.q_prev, n, nb, gj_first, n_out, L.found.loc, pf, L);
-            anc = max(anc, 0);
+            step_walk(fc, A->fs.q_prev, n, nb, gj_first, n_out, gj_last, true, 0, L.found.loc, pf, L);
+            __syncthreads();
+            anc = max(step_prefix_max(L), 0);
             lw_carry = 0.0;                                            // equal weights after resampling
             if ((int64_t)bid * kStepBlock + tid < n) A->fs.anc_row[i] = anc;
         }
-    } else if (bid == 0 && tid == 0 && !A->fs.exact_ref) {
+    } else if (bid == 0 && tid == 0 && !A->fs.exact_ref && !joint) {
         A->fs.ctrl->ref_cur = A->fs.bound;                             // R_0 = B_0
     }
     begin_lane(anc, 0u, lw_carry);
@@ -512,17 +585,8 @@ __device__ __forceinline__ void step_epilogue()
         if (valid) A->logw_out[i_raw] = lw;
         return;
     }
-#if defined(CPPROB_EXP_EPI) && CPPROB_EXP_EPI == 3
-    if (valid) A->logw_out[i_raw] = lw;
-    return;
-#endif
-    const double ref = t == 0 ? A->fs.bound : L.found.ref;
+    const double ref = t == 0 ? A->fs.bound : (A->sh.world ? A->sh.ref : L.found.ref);
     const uint32_t q = fix_weight(lw, ref);
-#if defined(CPPROB_EXP_EPI) && CPPROB_EXP_EPI == 2
-    A->fs.q_next[i_raw] = q;
-    if (valid) A->logw_out[i_raw] = lw;
-    return;
-#endif
     const uint64_t s_w = wave_sum_q(q), q_w = wave_sum_q((q >> 16) * (q >> 16)), m_w = wave_max_key(dkey(lw));
     if (lane == 0) { L.red[wv] = s_w; L.red[kStepWaves + wv] = q_w; L.red[2 * kStepWaves + wv] = m_w; }
     __syncthreads();
@@ -530,13 +594,7 @@ __device__ __forceinline__ void step_epilogue()
         uint64_t St = 0, Qt = 0, Mk = 0;
 #pragma unroll
         for (int w2 = 0; w2 < kStepWaves; ++w2) { St += L.red[w2]; Qt += L.red[kStepWaves + w2]; Mk = umax64(Mk, L.red[2 * kStepWaves + w2]); }
-#if defined(CPPROB_EXP_EPI) && CPPROB_EXP_EPI == 1
-        if (St == 12345) A->fs.q_next[0] = (uint32_t)(Qt + Mk);
-#elif defined(CPPROB_EXP_EPI) && CPPROB_EXP_EPI == 4
-        { const cph::FHier f4 = step_hier(); const_cast<uint64_t*>(f4.h.lvl[0])[f4.h.to_next + bid] = St; const_cast<uint64_t*>(f4.q0)[f4.h.to_next + bid] = Qt; const_cast<uint64_t*>(f4.m0)[f4.h.to_next + bid] = Mk; }
-#else
         fhier_publish(step_hier(), bid, A->fs.nb, St, Qt, Mk);
-#endif
     }
     A->fs.q_next[i_raw] = q;                                           // (the weight arrays are padded to whole tiles)
     if (valid && (A->fs.may_carry || t + 1 == A->fs.T)) A->logw_out[i_raw] = lw;
@@ -589,7 +647,13 @@ __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(D
             const int32_t jj = (int32_t)wave_uniform(n_own);
             const int32_t base = A->fresh_lo - (int32_t)A->win;
             R v;
-            if (jj < A->fresh_lo) v = from_raw<R>(A->carry_in[(int64_t)(jj - base) * A->ld + lane_src()]);
+            if (jj < A->fresh_lo) {
+                const int32_t src = lane_src();
+                if (A->sh.world) {                                    // the ancestor's window lies in its rank's store
+                    const ShardPeer* pr = A->sh.peers + (src >> kShardIndexBits);
+                    v = from_raw<R>(pr->carry[(int64_t)(jj - base) * pr->n + (src & ((1 << kShardIndexBits) - 1))]);
+                } else v = from_raw<R>(A->carry_in[(int64_t)(jj - base) * A->ld + src]);
+            }
             else v = draw(distr, A->seed, (uint64_t)lane_index() + A->pid0, (uint64_t)jj);
             const int32_t out_base = A->next_fresh - (int32_t)A->win;
             if (A->carry_out && jj >= out_base && jj < A->next_fresh) A->carry_out[(int64_t)(jj - out_base) * A->ld + lane_index()] = to_raw<R>(v);

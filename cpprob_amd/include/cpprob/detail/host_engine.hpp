@@ -308,6 +308,8 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
 // islands are combined the same way with L_r = log(n_r Z_r), Z_r the island's evidence estimate: a consistent estimator of the same
 // posterior, but not the joint population's resampling (that needs the replayed traces to migrate: not built; the built-in models
 // have it, cpprob_hip_group_*).
+inline void combine_shards(std::vector<Result>& rr, const std::vector<HostStore>* hs, const std::vector<std::size_t>& begin, std::size_t n,
+                           const detail::TraceStructure& st, bool islands, Result& res, HostStore* store);
 inline void run_generic_sharded(StateType algorithm, const Entry& e, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt,
                                 Result& res, HostStore* store)
 {
@@ -330,6 +332,29 @@ inline void run_generic_sharded(StateType algorithm, const Entry& e, const void*
     for (auto& t : th) t.join();
     for (std::size_t r = 0; r < world; ++r)
         if (!errs[r].empty()) throw std::runtime_error("cpprob::inference (shard " + std::to_string(r) + "): " + errs[r]);
+    combine_shards(rr, store ? &hs : nullptr, begin, n, st, smc, res, store);
+    if (smc && store) {
+        // an island's log-weights are relative to ITS last resampling: on the population's common scale island r's particles carry
+        // log(n_r Z_r) - logsumexp(its weights) more -- what the combined statistics above weigh it by, so that the files say what Result says
+        for (std::size_t r = 0; r < world; ++r) {
+            double mx = -std::numeric_limits<double>::infinity(), acc = 0;
+            for (double v : hs[r].logw) mx = std::max(mx, v);
+            for (double v : hs[r].logw) acc += std::exp(v - mx);
+            const double shift = rr[r].log_norm - (mx + std::log(acc));
+            for (std::size_t i = begin[r]; i < begin[r + 1]; ++i) store->logw[i] += shift;
+        }
+    }
+}
+
+// The shards' self-normalised numbers combined by their masses (log_norm = log of the shard's weight sum on the population's common
+// scale): w_r = exp(L_r - L), L = logsumexp_r L_r;  mean = sum w_r mean_r;  E[x^2] = sum w_r (var_r + mean_r^2);  P = sum w_r P_r;
+// ESS = 1 / sum_r w_r^2 / ESS_r.  islands: the shards are independent SMC runs, L_r = log(n_r Z_r) and the evidence is the combination's;
+// otherwise (SIS shards; the shards of a joint SMC population, whose evidence the caller holds) the shards' weights already share a scale.
+inline void combine_shards(std::vector<Result>& rr, const std::vector<HostStore>* hs, const std::vector<std::size_t>& begin, std::size_t n,
+                           const detail::TraceStructure& st, bool islands, Result& res, HostStore* store)
+{
+    const std::size_t world = rr.size();
+    const bool smc = islands;
     // (an island's mass: its particles times its evidence estimate; an SIS shard's: the sum of its weights -- the same thing)
     if (smc)
         for (std::size_t r = 0; r < world; ++r) rr[r].log_norm = rr[r].log_evidence + std::log(static_cast<double>(begin[r + 1] - begin[r]));
@@ -351,6 +376,7 @@ inline void run_generic_sharded(StateType algorithm, const Entry& e, const void*
             for (const auto& x : rr) top = std::max(top, x.predicts[k].probabilities.size());
             p.probabilities.assign(top, 0.0);
             for (const auto& x : rr) { const double w = std::exp(x.log_norm - L); for (std::size_t s2 = 0; s2 < x.predicts[k].probabilities.size(); ++s2) p.probabilities[s2] += w * x.predicts[k].probabilities[s2]; }
+            while (p.probabilities.size() > 1 && p.probabilities.back() == 0.0) p.probabilities.pop_back();
         } else {
             const std::size_t D = p.mean_nd.size();
             std::vector<double> m1(D, 0.0), m2(D, 0.0);
@@ -362,15 +388,15 @@ inline void run_generic_sharded(StateType algorithm, const Entry& e, const void*
             p.mean = p.mean_nd[0]; p.variance = p.variance_nd[0];
         }
     }
-    if (store) {
+    if (store && hs) {
         // the shards' traces side by side, in global particle order
         const std::size_t n_real = st.real_rows(), n_int = st.int_ids.size();
         store->n = n; store->logw.resize(n); store->real.resize(n_real * n); store->ints.resize(n_int * n);
         for (std::size_t r = 0; r < world; ++r) {
             const std::size_t nr = begin[r + 1] - begin[r];
-            std::copy(hs[r].logw.begin(), hs[r].logw.end(), store->logw.begin() + begin[r]);
-            for (std::size_t row = 0; row < n_real; ++row) std::copy(hs[r].real.begin() + row * nr, hs[r].real.begin() + (row + 1) * nr, store->real.begin() + row * n + begin[r]);
-            for (std::size_t row = 0; row < n_int; ++row) std::copy(hs[r].ints.begin() + row * nr, hs[r].ints.begin() + (row + 1) * nr, store->ints.begin() + row * n + begin[r]);
+            std::copy((*hs)[r].logw.begin(), (*hs)[r].logw.end(), store->logw.begin() + begin[r]);
+            for (std::size_t row = 0; row < n_real; ++row) std::copy((*hs)[r].real.begin() + row * nr, (*hs)[r].real.begin() + (row + 1) * nr, store->real.begin() + row * n + begin[r]);
+            for (std::size_t row = 0; row < n_int; ++row) std::copy((*hs)[r].ints.begin() + row * nr, (*hs)[r].ints.begin() + (row + 1) * nr, store->ints.begin() + row * n + begin[r]);
         }
     }
 }
@@ -461,7 +487,13 @@ void run_inference(StateType algorithm, const Func& f, const std::tuple<Args...>
     if (opt.devices.size() > 1) {
         const bool builtin = e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic);
         if (builtin) run_builtin_group(algorithm, e->builtin_model, flatten(obs), n, st, opt, res, store);
-        else if (e->generic) run_generic_sharded(algorithm, *e, &obs, n, st, opt, res, store);      // (smc: islands, see there)
+        else if (e->generic) {
+            // smc: ONE joint population where the model has a joint form (a replay window, systematic resampling: cpprob/gpu.hpp,
+            // generic_joint_launcher); otherwise islands -- a different estimator, reported as such (Result::joint)
+            bool joint = false;
+            if (algorithm == StateType::smc && e->generic_joint && !opt.islands) joint = e->generic_joint(algorithm, &obs, n, st, opt, res, store);
+            if (!joint) run_generic_sharded(algorithm, *e, &obs, n, st, opt, res, store);
+        }
         else throw std::runtime_error("cpprob::inference: registry entry without a launcher");
     }
     else if (e->builtin_model >= 0 && (opt.prefer_builtin || !e->generic || (st.vector_statements && !e->generic_vectors)))

@@ -31,10 +31,15 @@ struct HostStore {                      // host copy of the particle store, for 
 using GenericLauncher = void (*)(StateType algorithm, const void* observes, std::size_t n, const detail::TraceStructure& st,
                                  const Options& opt, Result& res, HostStore* store);
 
+// ... one joint population over options().devices (cpprob/gpu.hpp: generic_joint_launcher); false: no joint form for this model / these options
+using GenericJointLauncher = bool (*)(StateType algorithm, const void* observes, std::size_t n, const detail::TraceStructure& st,
+                                      const Options& opt, Result& res, HostStore* store);
+
 struct Entry {
     std::string name;
     int builtin_model = -1;             // >= 0: CPPROB_HIP_MODEL_* id
     GenericLauncher generic = nullptr;
+    GenericJointLauncher generic_joint = nullptr;
     bool generic_vectors = false;       // the generic launcher runs the model's device view: vector-valued statements included
 };
 
@@ -60,7 +65,7 @@ inline bool add_entry(const Key& k, const Entry& e)
     Entry& dst = table()[k];
     if (dst.name.empty()) dst.name = e.name;
     if (e.builtin_model >= 0) dst.builtin_model = e.builtin_model;
-    if (e.generic && (e.generic_vectors || !dst.generic_vectors)) { dst.generic = e.generic; dst.generic_vectors = e.generic_vectors; }
+    if (e.generic && (e.generic_vectors || !dst.generic_vectors)) { dst.generic = e.generic; dst.generic_vectors = e.generic_vectors; dst.generic_joint = e.generic_joint; }
     return true;
 }
 

@@ -36,7 +36,10 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <limits>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -499,9 +502,6 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     if (overflow == 2)
         throw std::runtime_error("cpprob::inference: a particle executed more predict statements than the model's dry run did; the number "
                                  "and order of observe / predict statements must not depend on sampled values on the device path");
-#ifdef CPPROB_EXP_IGNORE_FLAGS
-    return 0;
-#endif
     if (overflow == 3) return 3;
     if (overflow == 4 || overflow == 5) return 4;
     return overflow != 0 ? 1 : 0;
@@ -567,6 +567,351 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
                              "(data-dependent loop, e.g. rejection sampling, that rarely terminates); use StateType::sis for this model");
 }
 
+// ---- ONE joint population over several GPUs (or several ranks on one: loopback) ------------------------------------------------------
+// cpprob::inference(StateType::smc, <unchanged model>, ...) with options().devices = {d0, d1, ...}: particle i lives on rank
+// floor(i R / N) (contiguous shards, global ids select the random streams), every step resamples the WHOLE population -- the same
+// integers as one GPU holding every particle (the masses are exact, the comb is evaluated on exact integers: cpprob/detail/
+// fixed_mass.hpp), so the traces are the single-device run's, bit for bit.  One host thread per rank.  Per step and rank: the step
+// launch (its prologue PULLS: it searches the hierarchy and walks the weights of whichever rank owns an output's ancestor and reads
+// the ancestor's window from that rank's store -- peer access / one address space; nothing is packed or sent), a one-wavefront launch
+// that sums the rank's {mass, squares, maximum} and 24 bytes to the host; the ranks' threads all-gather them (a barrier), and each
+// takes the generation's decision -- ESS, resample or not, the comb's scale, the ranks' offspring bounds, the next reference, the
+// evidence -- with the arithmetic the device uses on one GPU (IEEE fma / ceil on exact integers: the same bits).  What this costs is a
+// host round trip per step (the hand-fused models' group driver keeps its collectives on the device: csrc/group.hpp); what it buys
+// is the joint estimator for ANY registered model, with no code of the model's own.
+struct JointBarrier {
+    std::mutex mu; std::condition_variable cv; int world, waiting = 0; unsigned long long generation = 0; bool broken = false;
+    explicit JointBarrier(int w) : world(w) {}
+    void wait()
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        if (broken) throw std::runtime_error("another rank of the joint population failed");
+        const unsigned long long g = generation;
+        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); return; }
+        cv.wait(lock, [&] { return generation != g || broken; });
+        if (broken) throw std::runtime_error("another rank of the joint population failed");
+    }
+    void fail() { std::lock_guard<std::mutex> lock(mu); broken = true; cv.notify_all(); }
+};
+struct JointRankPointers {
+    cpprob_hip_generic_layout lay{}; const uint64_t* carry[2] = {nullptr, nullptr};
+    const int32_t* anc_all = nullptr; const double* real_gen = nullptr; const int32_t* int_gen = nullptr; std::size_t n = 0;
+};
+struct JointShared {
+    int world; std::size_t n_total; std::vector<std::size_t> begin;
+    JointBarrier bar;
+    std::vector<JointRankPointers> ptrs;
+    std::vector<std::array<std::uint64_t, 3>> totals[2];               // by the step's parity
+    std::vector<Result> rr; std::vector<HostStore> hs; std::vector<std::string> errs;
+    std::vector<int> devices;
+    JointShared(int w, std::size_t n) : world(w), n_total(n), begin((std::size_t)w + 1, 0), bar(w), ptrs((std::size_t)w), rr((std::size_t)w), hs((std::size_t)w), errs((std::size_t)w)
+    { totals[0].resize((std::size_t)w); totals[1].resize((std::size_t)w); }
+};
+// lineage of one rank's final particles through every rank's per-step records (ancestor codes: rank << kShardIndexBits | slot)
+struct JointStore { const int32_t* anc_all; const double* real_gen; const int32_t* int_gen; int64_t n; };
+template <class V>
+__global__ __launch_bounds__(256) void joint_lineage_gather_kernel(const JointStore* __restrict__ stores, int rank, const int32_t* __restrict__ resampled, int T, int64_t n,
+                                                                   const int32_t* __restrict__ hit_gen, int H, V* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int32_t code = (int32_t)i | (rank << device::kShardIndexBits);
+    int h = H - 1;
+    for (int t = T - 1; t >= 0; --t) {
+        const JointStore st = stores[code >> device::kShardIndexBits];
+        const int64_t idx = code & ((1 << device::kShardIndexBits) - 1);
+        for (; h >= 0 && hit_gen[h] == t; --h) {
+            if (std::is_same<V, double>::value) out[(int64_t)h * n + i] = (V)st.real_gen[(int64_t)h * st.n + idx];
+            else out[(int64_t)h * n + i] = (V)st.int_gen[(int64_t)h * st.n + idx];
+        }
+        if (t > 0 && resampled[t - 1]) code = st.anc_all[(int64_t)t * st.n + idx];
+    }
+}
+
+// the device's decision arithmetic on the host (cpprob/detail/fixed_mass.hpp: u64_to_double, fixed_decide, FixedCdf::g): exact
+// integers, one rounding per IEEE operation -- the same bits on both sides
+inline double joint_u64_to_double(std::uint64_t c) { return std::fma((double)(std::uint32_t)(c >> 32), 4294967296.0, (double)(std::uint32_t)c); }
+inline double joint_key_inv(std::uint64_t k)
+{
+    if (k == 0) return -std::numeric_limits<double>::infinity();
+    union { double d; std::uint64_t u; } c;
+    c.u = (k >> 63) ? (k & ~(1ull << 63)) : ~k;
+    return c.d;
+}
+
+template <class Caller>
+void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const void* observes_v, const detail::TraceStructure& st, const Options& opt, StepForm form)
+{
+    using Tuple = typename Caller::observes_t;
+    (void)algorithm;
+    const int world = sh.world;
+    const std::size_t n = sh.begin[(std::size_t)rank + 1] - sh.begin[(std::size_t)rank], N = sh.n_total;
+    const int device_id = sh.devices[(std::size_t)rank];
+    Result& res = sh.rr[(std::size_t)rank];
+    const auto t_setup = std::chrono::steady_clock::now();
+    WorkspaceLease ws(device_id);
+    Context& ctx = ws->ctx;
+    hip_check(hipSetDevice(device_id), "hipSetDevice");
+    for (int r = 0; r < world; ++r)                                   // every rank reads every rank's store
+        if (sh.devices[(std::size_t)r] != device_id) {
+            const hipError_t e = hipDeviceEnablePeerAccess(sh.devices[(std::size_t)r], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_check(e, "hipDeviceEnablePeerAccess");
+            (void)hipGetLastError();
+        }
+    hipStream_t stream = static_cast<hipStream_t>(cpprob_hip_stream(ctx.get()));
+    const size_t n_real = st.real_rows(), n_int = st.int_ids.size();
+    const int T = (int)st.n_observe;
+    const uint32_t w = (uint32_t)std::max(1, st.window);
+    const bool exact = form == StepForm::fused_exact;
+
+    Tuple* d_obs = nullptr;
+    double *d_real = nullptr, *d_logw0 = nullptr, *d_logw1 = nullptr, *d_real_gen = nullptr;
+    int32_t *d_int = nullptr, *d_anc_all = nullptr, *d_int_gen = nullptr, *d_res = nullptr, *d_flag = nullptr, *d_hit_real = nullptr, *d_hit_int = nullptr;
+    uint64_t *d_c0 = nullptr, *d_c1 = nullptr, *d_tot = nullptr;
+    device::ShardPeer* d_peers = nullptr;
+    JointStore* d_stores = nullptr;
+    Carver carve;
+    carve.add(&d_obs, 1); carve.add(&d_res, (size_t)T + 1); carve.add(&d_flag, 1); carve.add(&d_tot, 4);
+    carve.add(&d_real, n_real * n); carve.add(&d_logw0, n); carve.add(&d_logw1, n); carve.add(&d_int, n_int * n);
+    carve.add(&d_c0, (size_t)w * n); carve.add(&d_c1, (size_t)w * n); carve.add(&d_anc_all, (size_t)T * n);
+    carve.add(&d_real_gen, n_real * n); carve.add(&d_int_gen, n_int * n);
+    carve.add(&d_peers, (size_t)6 * world); carve.add(&d_stores, (size_t)world);
+    carve.add(&d_hit_real, n_real + 1); carve.add(&d_hit_int, n_int + 1);
+    const bool grown = carve.commit(*ws);
+    hip_check(hipMemcpyAsync(d_obs, observes_v, sizeof(Tuple), hipMemcpyHostToDevice, stream), "copy observes");
+    hip_check(hipMemsetAsync(d_flag, 0, sizeof(int32_t), stream), "hipMemsetAsync");
+    cpprob_hip_generic_layout lay{};
+    ctx.check(cpprob_hip_generic_begin(ctx.get(), n, &lay), "cpprob_hip_generic_begin");
+    double* logw[2] = {d_logw0, d_logw1};
+    uint64_t* carry[2] = {d_c0, d_c1};
+    {
+        JointRankPointers& me = sh.ptrs[(std::size_t)rank];
+        me.lay = lay; me.carry[0] = d_c0; me.carry[1] = d_c1; me.anc_all = d_anc_all; me.real_gen = d_real_gen; me.int_gen = d_int_gen; me.n = n;
+    }
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    sh.bar.wait();                                                     // every rank's buffers exist
+    // the ranks' stores as this rank's launches address them: step t reads hierarchy copy (t + 2) % 3, weights q[(t + 1) & 1] and
+    // windows carry[t & 1] -- six combinations, uploaded once
+    std::vector<device::ShardPeer> peers((size_t)6 * world);
+    std::vector<JointStore> stores((size_t)world);
+    for (int k = 0; k < 6; ++k)
+        for (int r = 0; r < world; ++r) {
+            const JointRankPointers& p = sh.ptrs[(size_t)r];
+            device::ShardPeer& e = peers[(size_t)k * world + r];
+            e.f = fused_view(p.lay, (k + 2) % 3, k % 3, (k + 1) % 3); e.q = p.lay.q[(k + 1) & 1]; e.carry = p.carry[k & 1]; e.n = (int64_t)p.n; e.nb = p.lay.blocks; e.pad = 0;
+        }
+    for (int r = 0; r < world; ++r) { const JointRankPointers& p = sh.ptrs[(size_t)r]; stores[(size_t)r] = JointStore{p.anc_all, p.real_gen, p.int_gen, (int64_t)p.n}; }
+    hip_check(hipMemcpyAsync(d_peers, peers.data(), peers.size() * sizeof(device::ShardPeer), hipMemcpyHostToDevice, stream), "copy the peer tables");
+    hip_check(hipMemcpyAsync(d_stores, stores.data(), stores.size() * sizeof(JointStore), hipMemcpyHostToDevice, stream), "copy the peer tables");
+    auto gens = [&](const std::vector<int>& steps) { std::vector<int32_t> g; for (int s2 : steps) g.push_back(std::min(s2, T - 1)); return g; };
+    const std::vector<int32_t> g_real = gens(st.real_row_step), g_int = gens(st.int_hit_step);
+    if (n_real) hip_check(hipMemcpyAsync(d_hit_real, g_real.data(), n_real * sizeof(int32_t), hipMemcpyHostToDevice, stream), "copy the hit table");
+    if (n_int) hip_check(hipMemcpyAsync(d_hit_int, g_int.data(), n_int * sizeof(int32_t), hipMemcpyHostToDevice, stream), "copy the hit table");
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    const auto t_start = std::chrono::steady_clock::now();
+    res.setup_seconds = std::chrono::duration<double>(t_start - t_setup).count();
+    res.workspace_grown = grown || ws.fresh();
+
+    ModelKernelArgs a{};
+    a.n = (int64_t)n; a.ld = (int64_t)n; a.seed = opt.seed; a.overflow = d_flag; a.pid0 = sh.begin[(size_t)rank];
+    a.pred_real_cap = (uint32_t)n_real; a.pred_int_cap = (uint32_t)n_int;
+    a.windowed = 1; a.win = w; a.lane_block = device::kStepBlock; a.fused = 1;
+    a.fs.ess_frac = opt.ess_threshold; a.fs.n_pop = (double)N; a.fs.T = T; a.fs.nb = lay.blocks;
+    a.fs.may_carry = opt.ess_threshold > 1.0 ? 0 : 1; a.fs.exact_ref = exact ? 1 : 0; a.fs.gap_limit = kFixGapLimit;
+    a.sh.world = world; a.sh.rank = rank;
+    for (int r = 0; r <= world; ++r) a.sh.first[r] = sh.begin[(size_t)r];
+    const dim3 sgrid((unsigned)((n + device::kStepBlock - 1) / device::kStepBlock)), sblock(device::kStepBlock);
+    const size_t step_lds = device::lane_lds_bytes(device::kStepBlock, true);
+    const bool step_full = step_kernel_full<Caller, Tuple>();
+    std::array<std::uint64_t, 3> h_tot{};
+    auto gather_totals = [&](int t) -> std::array<std::vector<std::uint64_t>, 3> {
+        ctx.check(cpprob_hip_generic_totals(ctx.get(), t, n, d_tot), "cpprob_hip_generic_totals");
+        hip_check(hipMemcpyAsync(h_tot.data(), d_tot, 3 * sizeof(std::uint64_t), hipMemcpyDeviceToHost, stream), "copy the shard's totals");
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        sh.totals[t & 1][(size_t)rank] = h_tot;
+        sh.bar.wait();                                                // the generation's all-gather; every rank's step t is complete behind it
+        std::array<std::vector<std::uint64_t>, 3> all;
+        for (int k = 0; k < 3; ++k) { all[(size_t)k].resize((size_t)world); for (int r = 0; r < world; ++r) all[(size_t)k][(size_t)r] = sh.totals[t & 1][(size_t)r][(size_t)k]; }
+        return all;
+    };
+    // generation t-1's decision (taken identically by every rank's thread) and the run's bookkeeping
+    std::vector<double> ess((size_t)T, 0.0);
+    std::vector<int32_t> resd((size_t)T + 1, 0);
+    double lz = 0.0, ref_prev = 0.0, gap_max = 0.0;
+    int flag = 0;
+    bool resample = false;
+    double M_prev = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const bool last = t + 1 == T;
+        a.logw_in = t > 0 ? logw[t & 1] : nullptr; a.logw_out = logw[(t + 1) & 1];
+        a.carry_in = t > 0 ? carry[t & 1] : nullptr; a.carry_out = last ? nullptr : carry[(t + 1) & 1];
+        a.fresh_lo = t > 0 ? (int32_t)st.samples_before_observe[(size_t)t - 1] : 0;
+        a.next_fresh = (int32_t)st.samples_before_observe[(size_t)t];
+        a.pred_real = d_real_gen; a.pred_int = d_int_gen;
+        a.first_observe = t; a.stop_after = last ? -1 : t;
+        a.fs.f = fused_view(lay, (t + 2) % 3, t % 3, (t + 1) % 3);
+        a.fs.q_prev = lay.q[(t + 1) & 1]; a.fs.q_next = lay.q[t & 1];
+        a.fs.u0 = cpprob_hip_systematic_offset(opt.seed, (uint64_t)t);
+        a.fs.bound = exact ? 0.0 : st.observe_bound[(size_t)t];
+        a.fs.t = t; a.fs.anc_row = d_anc_all + (size_t)t * n;
+        a.sh.peers = d_peers + (size_t)(t % 6) * world;
+        a.sh.resample = resample ? 1 : 0;
+        const double ref_t = exact ? 0.0 : ((t == 0 || resample) ? a.fs.bound : M_prev + a.fs.bound);
+        a.sh.ref = ref_t;
+        if (step_full) hipLaunchKernelGGL((model_step_kernel_full<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+        else hipLaunchKernelGGL((model_step_kernel<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+        hip_check(hipGetLastError(), "model_step_kernel");
+        double ref_gen = ref_t;
+        if (exact) {
+            // the generation's exact maximum over every rank first, then the masses against it
+            ctx.check(cpprob_hip_generic_max(ctx.get(), t, logw[(t + 1) & 1], n), "cpprob_hip_generic_max");
+            const auto mx = gather_totals(t);
+            std::uint64_t key = 0;
+            for (int r = 0; r < world; ++r) key = std::max(key, mx[2][(size_t)r]);
+            ref_gen = joint_key_inv(key);
+            ctx.check(cpprob_hip_generic_quantize_ref(ctx.get(), t, logw[(t + 1) & 1], n, ref_gen), "cpprob_hip_generic_quantize_ref");
+            sh.bar.wait();                                            // (the totals' buffer of this parity is written again below)
+        }
+        const auto all = gather_totals(t);
+        std::uint64_t S = 0, Q = 0, key = 0;
+        for (int r = 0; r < world; ++r) { S += all[0][(size_t)r]; Q += all[1][(size_t)r]; key = std::max(key, all[2][(size_t)r]); }
+        const double M = joint_key_inv(key);
+        const double Sd = joint_u64_to_double(S), W = Sd * (1.0 / 4294967296.0), Qd = joint_u64_to_double(Q) * (1.0 / 4294967296.0);
+        const double e = W * W / Qd;
+        const double ess_t = e > (double)N ? (double)N : e;
+        resample = !last && ess_t < opt.ess_threshold * (double)N;
+        const double gap = W > 0.0 ? ref_gen - M : 1e300;
+        gap_max = t == 0 ? gap : std::max(gap_max, gap);
+        if (gap < 0.0) flag = 4; else if (gap > kFixGapLimit && flag == 0) flag = 5;
+        ess[(size_t)t] = ess_t; resd[(size_t)t] = resample ? 1 : 0;
+        if (resample || last) lz += ref_gen + std::log(W / (double)N);
+        M_prev = M; ref_prev = ref_gen;
+        if (resample) {
+            const double inv = (double)N / Sd, u0 = cpprob_hip_systematic_offset(opt.seed, (uint64_t)t + 1);
+            a.sh.inv = inv;
+            std::uint64_t before = 0;
+            for (int r = 0; r < world; ++r) {
+                a.sh.before[r] = before;
+                a.sh.obound[r] = std::ceil(std::fma(joint_u64_to_double(before), inv, -u0));
+                before += all[0][(size_t)r];
+            }
+            a.sh.obound[0] = 0.0;                                      // (u0 < 1: ceil(-u0) is -0 or 0)
+            a.sh.obound[world] = (double)N;
+        }
+    }
+    (void)ref_prev;
+    int32_t dev_flag = 0;
+    hip_check(hipMemcpyAsync(&dev_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy the flag word");
+    hip_check(hipMemcpyAsync(d_res, resd.data(), ((size_t)T + 1) * sizeof(int32_t), hipMemcpyHostToDevice, stream), "copy the decisions");
+    // traces: follow every final particle of this rank back through whichever rank recorded each step
+    const dim3 ggrid((unsigned)((n + 255) / 256)), gblock(256);
+    if (n_real) hipLaunchKernelGGL((joint_lineage_gather_kernel<double>), ggrid, gblock, 0, stream, (const JointStore*)d_stores, rank, (const int32_t*)d_res, T, (int64_t)n, (const int32_t*)d_hit_real, (int)n_real, d_real);
+    if (n_int) hipLaunchKernelGGL((joint_lineage_gather_kernel<int32_t>), ggrid, gblock, 0, stream, (const JointStore*)d_stores, rank, (const int32_t*)d_res, T, (int64_t)n, (const int32_t*)d_hit_int, (int)n_int, d_int);
+    hip_check(hipGetLastError(), "joint_lineage_gather_kernel");
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    double* const lw_final = logw[T & 1];
+    fill_predict_names(res, st);
+    double lse_ess[2] = {0.0, 0.0};
+    bool have_norm = false;
+    if (n_real) {
+        std::vector<double> o4(4 * n_real);
+        ctx.check(cpprob_hip_weighted_moments_columns(ctx.get(), d_real, n_real, n, lw_final, n, o4.data()), "cpprob_hip_weighted_moments_columns");
+        lse_ess[0] = o4[2]; lse_ess[1] = o4[3]; have_norm = true;
+        for (size_t k = 0, row = 0; k < st.real_ids.size(); ++k) {
+            PredictStats& p = res.predicts[k];
+            for (size_t d = 0; d < st.real_width[k]; ++d, ++row) { p.mean_nd.push_back(o4[4 * row]); p.variance_nd.push_back(o4[4 * row + 1]); }
+            p.mean = p.mean_nd[0]; p.variance = p.variance_nd[0];
+        }
+    }
+    if (n_int) {
+        std::vector<double> h(8 * n_int);
+        ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int, n_int, n, lw_final, n, 8, h.data(), have_norm ? nullptr : lse_ess), "cpprob_hip_weighted_hist_columns");
+        have_norm = true;
+        for (size_t k = 0; k < n_int; ++k) res.predicts[st.real_ids.size() + k].probabilities.assign(h.begin() + 8 * k, h.begin() + 8 * k + 8);
+    }
+    if (!have_norm) {
+        double o3[3];
+        ctx.check(cpprob_hip_logsumexp_ess(ctx.get(), lw_final, n, o3), "cpprob_hip_logsumexp_ess");
+        lse_ess[0] = o3[1]; lse_ess[1] = o3[2];
+    }
+    int n_resampled = 0;
+    for (int t = 0; t < T; ++t) n_resampled += resd[(size_t)t];
+    res.n_particles = n; res.log_evidence = lz; res.log_norm = lse_ess[0]; res.ess = lse_ess[1]; res.n_resampled = n_resampled; res.used_builtin = false;
+    res.step_ess = ess; res.replay_window = (int)w; res.step_form = exact ? 2 : 1; res.launches_per_step = exact ? 4 : 2;
+    res.joint_flag = dev_flag == 2 || dev_flag == 3 ? dev_flag : flag;
+    res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    HostStore& hs = sh.hs[(size_t)rank];
+    hs.n = n; hs.logw.resize(n); hs.real.resize(n_real * n); hs.ints.resize(n_int * n);
+    hip_check(hipMemcpyAsync(hs.logw.data(), lw_final, n * sizeof(double), hipMemcpyDeviceToHost, stream), "copy logw");
+    if (n_real) hip_check(hipMemcpyAsync(hs.real.data(), d_real, n_real * n * sizeof(double), hipMemcpyDeviceToHost, stream), "copy real predicts");
+    if (n_int) hip_check(hipMemcpyAsync(hs.ints.data(), d_int, n_int * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy int predicts");
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    sh.bar.wait();                                                     // nobody's store is released while a peer may still read it
+}
+
+// returns 0, or 3 / 4 as generic_attempt does (the caller falls back / repeats on exact maxima); rr / hs of `sh` hold the ranks' shares
+template <class Caller>
+int generic_joint_attempt(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt, StepForm form, JointShared& sh)
+{
+    std::vector<std::thread> th;
+    for (int r = 0; r < sh.world; ++r)
+        th.emplace_back([&, r] {
+            try { generic_joint_rank<Caller>(sh, r, algorithm, observes_v, st, opt, form); }
+            catch (const std::exception& ex) { sh.errs[(size_t)r] = ex.what(); sh.bar.fail(); }
+        });
+    for (auto& t : th) t.join();
+    std::string first;
+    for (int r = 0; r < sh.world; ++r)
+        if (!sh.errs[(size_t)r].empty() && sh.errs[(size_t)r] != "another rank of the joint population failed") { first = "shard " + std::to_string(r) + ": " + sh.errs[(size_t)r]; break; }
+    if (first.empty()) for (int r = 0; r < sh.world; ++r) if (!sh.errs[(size_t)r].empty()) { first = sh.errs[(size_t)r]; break; }
+    if (!first.empty()) throw std::runtime_error("cpprob::inference (joint population): " + first);
+    (void)n;
+    int flag = 0;
+    for (const Result& r : sh.rr) flag = std::max(flag, r.joint_flag);
+    if (flag == 2)
+        throw std::runtime_error("cpprob::inference: a particle executed more predict statements than the model's dry run did; the number "
+                                 "and order of observe / predict statements must not depend on sampled values on the device path");
+    return flag == 3 ? 3 : (flag ? 4 : 0);
+}
+
+// Type-erased entry of the joint run (cpprob/detail/host_engine.hpp calls it when options().devices names several ranks): false when this
+// model / these options have no joint form (no replay window, another resampler) -- the caller then runs islands and says so.
+template <class Caller>
+bool generic_joint_launcher(StateType algorithm, const void* observes_v, std::size_t n, const detail::TraceStructure& st, const Options& opt, Result& res, HostStore* store)
+{
+    const int world = (int)opt.devices.size();
+    if (algorithm != StateType::smc || st.window < 0 || opt.resampler != CPPROB_HIP_RESAMPLE_SYSTEMATIC || world < 2 || world > device::kMaxShards) return false;
+    if (st.n_observe > device::kWinMaxObserves || st.real_rows() > device::kWinMaxPredicts || st.int_ids.size() > device::kWinMaxPredicts) return false;
+    if ((n + world - 1) / world >= (std::size_t(1) << device::kShardIndexBits) || n >= (std::size_t(1) << 31)) return false;
+    // the replay window is certified on one device first (generic_launcher's pilot: once per model and trace shape)
+    {
+        Options po = opt; po.devices.clear(); po.device = opt.devices[0]; po.dump = false;
+        Result pr;
+        generic_launcher<Caller>(algorithm, observes_v, std::min<std::size_t>(n, 8192), st, po, pr, nullptr);
+        if (pr.replay_window < 0) return false;                        // the pilot refuted the window: no joint form for this model
+        res.markov_crosscheck = pr.markov_crosscheck;
+    }
+    StepForm form = st.bounds_fixed ? StepForm::fused_bounded : StepForm::fused_exact;
+    if (opt.step_form_override == 2) form = StepForm::fused_exact;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        JointShared sh(world, n);
+        sh.devices = opt.devices;
+        for (int r = 0; r < world; ++r) sh.begin[(size_t)r + 1] = sh.begin[(size_t)r] + n / (size_t)world + ((size_t)r < n % (size_t)world ? 1 : 0);
+        const int rc = generic_joint_attempt<Caller>(algorithm, observes_v, n, st, opt, form, sh);
+        if (rc == 3) return false;
+        if (rc == 4 && form == StepForm::fused_bounded) { form = StepForm::fused_exact; continue; }
+        combine_shards(sh.rr, store ? &sh.hs : nullptr, sh.begin, n, st, false, res, store);
+        const Result& r0 = sh.rr[0];
+        res.log_evidence = r0.log_evidence; res.n_resampled = r0.n_resampled; res.step_ess = r0.step_ess; res.replay_window = r0.replay_window;
+        res.step_form = r0.step_form; res.launches_per_step = r0.launches_per_step; res.joint = true; res.n_gpus = world;
+        double setup = 0; bool grown = false;
+        for (const Result& r : sh.rr) { setup = std::max(setup, r.setup_seconds); grown = grown || r.workspace_grown; }
+        res.setup_seconds = setup; res.workspace_grown = grown;
+        return true;
+    }
+    throw std::runtime_error("cpprob::inference (joint population): a generation's weights left even their exact maximum's range");
+}
+
 // Device view (cpprob/detail/device_vector.hpp): the launcher receives the HOST function's observes tuple (std::vector elements) and
 // hands the device the view's tuple (fixed-capacity elements), converted element by element.
 template <class To, class From, std::size_t... I>
@@ -587,14 +932,14 @@ void generic_launcher_view(StateType algorithm, const void* observes_v, std::siz
 template <class HostFP, HostFP H, class DevFP, DevFP D>
 bool register_model_view(const char* name)
 {
-    Entry e; e.name = name; e.generic = &generic_launcher_view<tuple_observes_t<HostFP>, FunctionCaller<DevFP, D>>; e.generic_vectors = true;
+    Entry e; e.name = name; e.generic = &generic_launcher_view<tuple_observes_t<HostFP>, FunctionCaller<DevFP, D>>; e.generic_vectors = true;   // (vector-valued statements: no replay window, no joint form)
     return add_entry(Key{reinterpret_cast<const void*>(H), 0}, e);
 }
 
 template <class FP, FP F>
 bool register_model(const char* name)
 {
-    Entry e; e.name = name; e.generic = &generic_launcher<FunctionCaller<FP, F>>;
+    Entry e; e.name = name; e.generic = &generic_launcher<FunctionCaller<FP, F>>; e.generic_joint = &generic_joint_launcher<FunctionCaller<FP, F>>;
     return add_entry(Key{reinterpret_cast<const void*>(F), 0}, e);
 }
 
@@ -602,7 +947,7 @@ bool register_model(const char* name)
 template <class Functor>
 bool register_functor(const char* name)
 {
-    Entry e; e.name = name; e.generic = &generic_launcher<FunctorCaller<Functor>>;
+    Entry e; e.name = name; e.generic = &generic_launcher<FunctorCaller<Functor>>; e.generic_joint = &generic_joint_launcher<FunctorCaller<Functor>>;
     return add_entry(Key{nullptr, typeid(Functor).hash_code()}, e);
 }
 

@@ -37,6 +37,8 @@ struct Options {
                                                       // (cpprob_hip_config::keep_history)
     std::uint64_t particle_offset = 0;                // (set by the engine when it shards a population: global id of this shard's first particle)
     bool progress = false;
+    bool islands = false;                             // smc over several ranks, unchanged models: independent SMC runs combined by their evidence instead of
+                                                      // the joint population (the default wherever the model has a joint form)
     int step_form_override = -1;                      // smc, unchanged-model path: -1 the engine chooses; 0 model launch + separate bookkeeping launches,
                                                       // 1 the resampling inside the model's launch against the dry run's bounds, 2 ... against exact maxima
     int replicates = 1;                               // built-in models: R independent runs (seeds seed .. seed + R - 1), up to three in
@@ -60,6 +62,8 @@ struct Result {
     int exchange_reruns = 0;
     int markov_crosscheck = 0;                // unchanged-model smc: 1 the device pilot certified the probe's window, -1 it refuted it (full replay), 0 not run
     int replay_window = -1;                   // unchanged-model smc: samples of the ancestor a step replays (-1: the whole trace)                  // multi-GPU: runs repeated with a larger lineage transport (results never depend on it)
+    bool joint = false;                       // unchanged-model smc over several ranks: ONE joint population (false: islands combined by their evidence)
+    int joint_flag = 0;                       // (a rank's share of a joint run: the flag its generations raised)
     int step_form = 0;                        // unchanged-model smc: 0 separate bookkeeping launches, 1 fused step on bounded references, 2 fused step + exact-maximum pass
     int launches_per_step = 0;                // unchanged-model smc: dependent launches per observe
     double setup_seconds = 0;                 // unchanged-model path: context / workspace / scratch set-up and the Markov pilot of THIS call (0.0x ms once the workspace is warm)

@@ -466,6 +466,13 @@ int cpprob_hip_generic_begin(cpprob_hip_ctx* ctx, size_t n, cpprob_hip_generic_l
  * launches find the generation's exact maximum, quantise d_logw[0..n) against it into q[t & 1] and publish maxima and masses into
  * copy t % 3. */
 int cpprob_hip_generic_quantize(cpprob_hip_ctx* ctx, int32_t t, const double* d_logw, size_t n);
+/* The same in two halves, for one shard of a JOINT population whose host threads combine the ranks' numbers between the launches:
+ * the maximum pass alone (into copy t % 3), and the masses against a reference the caller supplies (the population's exact maximum). */
+int cpprob_hip_generic_max(cpprob_hip_ctx* ctx, int32_t t, const double* d_logw, size_t n);
+int cpprob_hip_generic_quantize_ref(cpprob_hip_ctx* ctx, int32_t t, const double* d_logw, size_t n, double ref);
+/* {mass, squares, order key of the maximum} of generation t as copy t % 3 holds them: 24 bytes into d_out3 (device memory; stream-ordered):
+ * what a shard of a joint population contributes to the generation's totals. */
+int cpprob_hip_generic_totals(cpprob_hip_ctx* ctx, int32_t t, size_t n, uint64_t* d_out3);
 /* Bookkeeping of the run's LAST generation (T - 1: the copy (T - 1) % 3): d_ess[T-1], d_resampled[T-1] = 0, the final term of
  * *d_log_z; *d_flags gets 4 / 5 where the generation's heaviest particle sat above / more than gap_limit below its reference. */
 int cpprob_hip_generic_finish(cpprob_hip_ctx* ctx, int32_t T, size_t n, double gap_limit, double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_flags);
