@@ -359,8 +359,9 @@ def test_unchanged_model_shards_over_several_devices_under_sis(tmp_path, model, 
     cpprob::gpu::options().devices (cpprob_main --generic --devices) runs the model body for contiguous blocks of particles on every
     device -- global particle ids select the random streams -- and combines the shards by their evidence.  Three shards on this GPU:
     every trace and every weight of the dump equals the one-device run's (per-particle parity), the estimators agree to rounding.
-    StateType::smc over several devices runs unchanged models as ISLANDS (independent SMC per device, combined by their evidence):
-    a consistent estimator of the same posterior, checked against forward-backward."""
+    StateType::smc over several devices: the joint population (next test); --islands keeps the independent-runs form, a consistent
+    estimator of the same posterior, checked against forward-backward -- and its dumped files carry every island's mass in the
+    particles' log-weights, so that an estimate re-derived from the files is the one Result reports."""
     if obs is None:
         obs = obs_str(np.load(os.path.join(GOLD, "observations.npz"))["hmm16"])
     n = 50001
@@ -381,11 +382,46 @@ def test_unchanged_model_shards_over_several_devices_under_sis(tmp_path, model, 
             assert open(str(f1)).read() == open(str(f2)).read()
     if model == "hmm16":
         z = np.load(os.path.join(GOLD, "observations.npz"))
-        isl, _, _ = run_main(tmp_path, "--model", model, "--smc", "--observes", obs, "--n_samples", 150000, "--seed", 9, "--generic", "--devices", "0,0,0", "--json", "--no_dump")
-        assert isl["n_gpus"] == 3 and not isl["builtin"] and isl["n_resampled"] > 0
+        isl, _, _ = run_main(tmp_path, "--model", model, "--smc", "--observes", obs, "--n_samples", 150000, "--seed", 9, "--generic", "--devices", "0,0,0", "--json",
+                             "--islands", "--generated_file", "isl")
+        assert isl["n_gpus"] == 3 and not isl["builtin"] and isl["n_resampled"] > 0 and isl["joint"] is False
         assert abs(isl["log_evidence"] - float(z["hmm16_logz"])) < 0.02
         got = np.array([p["p"][:3] + [0.0] * (3 - len(p["p"][:3])) for p in isl["predicts"]])
         assert np.abs(got - z["hmm16_smooth"]).max() < 0.01
+        vi, lwi = read_dump(str(tmp_path / "isl_smc.int"), True)
+        w = np.exp(lwi - lwi.max())
+        from_files = np.array([[(w * (vi[t] == s2)).sum() / w.sum() for s2 in range(3)] for t in range(16)])
+        np.testing.assert_allclose(from_files, got, atol=1e-9)        # the files weigh the islands as the combined statistics do
+        assert abs(lwi.max() + np.log(w.sum()) - np.log(150000) - isl["log_evidence"]) < 1e-9
+
+
+@pytest.mark.parametrize("model,key,T,ess,is_int,n", [("hmm16", "hmm16", 16, 2.0, True, 50001), ("hmm16", "hmm16", 16, 0.5, True, 30000),
+                                                     ("linear_gaussian_1d25", "lgssm100", 25, 0.5, False, 40000), ("random_scale12", "lgssm100", 12, 0.5, False, 30000)])
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])
+def test_unchanged_model_smc_over_several_ranks_is_the_single_device_population(tmp_path, model, key, T, ess, is_int, n, devices):
+    """north_star: "particles shard across the GPUs ... global weight sum and ancestor redistribution" for models that "compile
+    unchanged".  cpprob::inference(StateType::smc, <unchanged model>) with options().devices naming several ranks (here: all on this
+    GPU, the loopback form) runs ONE joint population: every step resamples all particles together -- the receiving rank's launch
+    searches and walks the masses of whichever rank owns an ancestor and reads its window from that rank's store -- and since masses
+    are exact integers, every surviving trace, every log-weight and the evidence equal the single-context run's, bit for bit (uneven
+    shards, shards that end inside a 256-particle block, ESS-triggered schedules, the exact-maximum form included)."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    obs = z[key][:T]
+    base = ["--model", model, "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 3, "--ess_threshold", ess, "--json", "--generic"]
+    one, _, _ = run_main(tmp_path, *base, "--generated_file", "one")
+    many, _, _ = run_main(tmp_path, *base, "--generated_file", "many", "--devices", devices)
+    assert many["joint"] is True and many["n_gpus"] == len(devices.split(",")) and not many["builtin"] and one["joint"] is False
+    assert many["step_form"] == one["step_form"] == (2 if model == "random_scale12" else 1)
+    ext = "int" if is_int else "real"
+    v1, lw1 = read_dump(str(tmp_path / ("one_smc." + ext)), is_int)
+    vm, lwm = read_dump(str(tmp_path / ("many_smc." + ext)), is_int)
+    assert np.array_equal(v1, vm) and np.array_equal(lw1, lwm)
+    assert many["log_evidence"] == one["log_evidence"] and many["n_resampled"] == one["n_resampled"]
+    for a, b in zip(one["predicts"], many["predicts"]):
+        if "p" in a:
+            np.testing.assert_allclose(a["p"], b["p"], rtol=0, atol=1e-12)
+        else:
+            assert abs(a["mean"] - b["mean"]) < 1e-11 and abs(a["variance"] - b["variance"]) < 1e-11
 
 
 def test_vector_statements_run_through_the_generic_device_path(tmp_path):
