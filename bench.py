@@ -31,6 +31,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES = {"hmm": 56, "lgssm": 72, "gaussian_sis": 32}  # SURVEY 8(d) per particle(-step)
+# What THIS data layout has to move through HBM per particle-step (every array read or written once, reads of
+# neighbouring tiles and gathers of distinct ancestors served by the L2), by step form -- the bytes `frac_layout` prices a launch
+# against; it cannot exceed 1 by construction, unlike the SURVEY 8(d) convention (`frac`), which prices arrays the layout does not have.
+#   counts (headline)  : write state 1 + ancestor 4 + trace word 4; read source states 1 + ancestor's trace word 4
+#   fixed, int8 states : write state 1 + ancestor 4 (resampling launches) + integer weight 4 + log-weight 8; read state 1 + weight 4 / log-weight 8
+#   fixed, fp64 states : write value 8 + ancestor 4 + integer weight 4 + log-weight 8; read value 8 + weight 4 (or the carried log-weight 8)
+LAYOUT_BYTES = {("hmm", 1): 14, ("hmm", 2): 22, ("hmm", 0): 56, ("lgssm", 2): 36, ("lgssm", 0): 72, ("gaussian_sis", 0): 16, ("gaussian_sis", 1): 16, ("gaussian_sis", 2): 16}
+FORM_NAMES = {0: "floating-point", 1: "prefix counts (table weights, every-step schedule)", 2: "fixed-point masses"}
 
 
 def parse():
@@ -198,7 +206,21 @@ def timed_group_runs(group, steps, warmup, world, device, first_index=0):
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, stats, summ, {"settling": settle, "timed_batch": reruns - settle}
+    # behind the timed region: ONE more run with HIP events between the launches of every step -- where a rank-step's time goes
+    # (step + totals, all-gather, pack, barrier, commit; how long the mailbox waits spun) and which transports the group settled on
+    breakdown = None
+    try:
+        group.profile(True)
+        group.run(first_index + warmup + steps)
+        group.results()
+        breakdown = group.profile_read()
+        group.profile(False)
+        breakdown["note"] = ("HIP events around the launches of one extra run (us per rank-step, the slowest local rank; a loopback group: the sum over its "
+                             "ranks, which share a stream); mailbox_wait = of all that, the time the waits spun on their peers' sequence numbers")
+        breakdown["transport_note"] = group.note()
+    except Exception as e:        # noqa: reported under the key
+        breakdown = {"error": str(e)}
+    return dt, stats, summ, {"settling": settle, "timed_batch": reruns - settle, "rank_step_breakdown_us": breakdown}
 
 
 def make_rank_group(cp, world, rank, local):
@@ -427,6 +449,7 @@ def main():
     dom_ms, dom_calls = prof[dom]
     avg_s = dom_ms * 1e-3 / max(dom_calls, 1)
     n_res_prof = eng.summary()["n_resampled"]
+    step_form = int(eng.summary().get("step_form", 0))
     # the floor of a launch of this chain: the same run at 4096 particles (the same launches with nothing in them)
     eng.begin(spec["alg"], spec["model"], spec["obs"], 4096, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
     for i in range(3):
@@ -459,15 +482,19 @@ def main():
         rec = pj.get("workloads", {}).get("%s@%d" % (args.workload, n_prof))
         if rec:
             traffic = rec["step_kernel"]["hbm_bytes_per_launch_corrected"]
-            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)" % os.path.basename(pmcs[-1])
+            traffic_src = "committed profile profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on another box, gfx950-corrected): NOT measured in this run" % os.path.basename(pmcs[-1])
             valu_frac = rec["step_kernel"].get("valu_issue_frac")
             wait_frac = rec["step_kernel"].get("wait_frac")
     hbm_frac_measured = (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_s > 0) else None
     # what bounds the dominant kernel at THIS size: within 2x of an empty launch of the same chain it is the chain's latency
     # (kernel boundary, first round trip to memory, search, gather), whatever the byte convention says
     bound = "latency" if (avg_s * 1e6 <= 2.0 * floor_us) else "hbm"
+    layout_bytes = LAYOUT_BYTES.get((spec["bytes_key"], step_form), bytes_per_unit)
+    achieved_layout = layout_bytes * n_prof / avg_s / 1e9 if avg_s > 0 else 0.0
     roofline = {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "hbm_frac_measured": hbm_frac_measured, "valu_issue_frac": valu_frac, "wait_frac": wait_frac,
+                "step_form": FORM_NAMES.get(step_form, str(step_form)) if spec["alg"] == cp.ALG_SMC else None,
+                "layout_bytes_per_unit": layout_bytes, "achieved_layout": achieved_layout, "frac_layout": achieved_layout / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_measured_in": traffic_src, "hbm_frac_measured": hbm_frac_measured, "valu_issue_frac": valu_frac, "wait_frac": wait_frac,
                 "launch_floor_us": floor_us, "algorithmic_bytes_per_unit": bytes_per_unit, "algorithmic_bytes_per_unit_no_resampling": light if spec["alg"] == cp.ALG_SMC else None,
                 "units_per_launch": n_prof, "avg_launch_us": avg_s * 1e6, "launches": int(dom_calls), "resampling_launches_per_run": n_res_prof if spec["alg"] == cp.ALG_SMC else None,
                 "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]}}
@@ -476,7 +503,7 @@ def main():
         "metric": "particles/sec (whole node) + achieved HBM GB/s, HMM T=16 SMC" if args.workload == "hmm16_smc" else "particles/sec (whole node), " + args.workload,
         "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64 log-weights, 32-bit fixed-point masses" if (spec["alg"] == cp.ALG_SMC and step_form == 2) else "f64", "data": "synthetic",
         "config": {"workload": "%s, %d particles per GPU" % (spec["desc"], n), "particles_per_gpu": n, "T": T,
                    "resampler": "systematic", "ess_threshold": spec["ess"], "scope": scope, "n_global": n_global, "collective": collective,
                    "host": host if (world > 1 or group is not None) else "one context, one stream", "exchange_reruns": reruns, "flags": args.flags},
@@ -485,6 +512,11 @@ def main():
         "posterior_max_abs_err_vs_exact": err, "log_evidence": summ["log_evidence"], "n_resampled": summ["n_resampled"],
     }
 
+    if isinstance(reruns, dict) and "rank_step_breakdown_us" in reruns:
+        bd = reruns.pop("rank_step_breakdown_us")
+        if bd is not None:
+            out["rank_step_breakdown_us"] = bd
+            out["transport_note"] = bd.get("transport_note") if isinstance(bd, dict) else None
     if native_error:
         out["config"]["native_driver_error"] = native_error
     if xtraffic is not None:
@@ -565,10 +597,24 @@ def main():
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             gj = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")][-1]
             gst = np.array([p_["p"] for p_ in gj["predicts"]])
+            runs = [l for l in pr.stdout.splitlines() if l.startswith("run ")]
+            first = runs[0].split()
             out["generic_path"] = {"ms_per_run": gj["run_seconds"] * 1e3, "particles_per_sec": n / gj["run_seconds"], "replay_window": gj["replay_window"],
+                                   "step_form": {0: "model launch + three bookkeeping launches", 1: "resampling inside the model's launch (dry-run bounds)", 2: "resampling inside the model's launch + exact-maximum passes"}[gj["step_form"]],
+                                   "launches_per_step": gj["launches_per_step"],
+                                   "ms_first_call": float(first[2]) + float(first[5]), "ms_setup_first_call": float(first[5]), "ms_setup_warm_call": gj["setup_seconds"] * 1e3,
                                    "posterior_max_abs_err_vs_exact": float(np.abs(gst - spec["exact"]).max()),
                                    "vs_fused_kernels": gj["run_seconds"] * 1e3 / (dt / args.steps * 1e3),
-                                   "note": "cpprob_main --generic --repeat 6 (last run; allocation excluded, the read-out of every predict hit included)"}
+                                   "note": "cpprob_main --generic --repeat 6: ms_per_run = the last call's device work (the read-out of every predict hit included), ms_first_call = "
+                                           "the first cpprob::inference call whole (context, workspace, Markov pilot, run), ms_setup_warm_call = what a later call adds to its run"}
+            # the same population as FOUR ranks of one joint population on this GPU (loopback: the pull migration and the per-step host all-gather at work)
+            with tempfile.TemporaryDirectory() as td:
+                cmd = [exe, "--model_folder", td, "--model", "hmm16", "--smc", "--observes", obs_s, "--n_samples", str(n), "--seed", str(args.seed),
+                       "--ess_threshold", "2.0", "--generic", "--no_dump", "--json", "--repeat", "4", "--devices", "0,0,0,0"]
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            jj = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")][-1]
+            out["generic_path"]["joint_4_loopback_ranks"] = {"ms_per_run": jj["run_seconds"] * 1e3, "joint": jj["joint"], "log_evidence_equals_one_rank": jj["log_evidence"] == gj["log_evidence"],
+                                                             "note": "cpprob_main --generic --devices 0,0,0,0: one joint population, four ranks on this one GPU"}
         except Exception as e:
             out["generic_path"] = {"error": str(e)}
 

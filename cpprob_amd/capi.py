@@ -24,7 +24,7 @@ SYMBOLS = [
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
     "cpprob_hip_smc_finish", "cpprob_hip_filter_masses", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
     "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_exchange_direct", "cpprob_hip_exchange_traffic", "cpprob_hip_exchange_store", "cpprob_hip_exchange_remote",
-    "cpprob_hip_group_create_external", "cpprob_hip_group_traffic", "cpprob_hip_group_unique_id", "cpprob_hip_group_create", "cpprob_hip_group_destroy",
+    "cpprob_hip_group_create_external", "cpprob_hip_group_traffic", "cpprob_hip_group_profile", "cpprob_hip_group_profile_read", "cpprob_hip_group_note", "cpprob_hip_group_unique_id", "cpprob_hip_group_create", "cpprob_hip_group_destroy",
     "cpprob_hip_group_last_error", "cpprob_hip_group_begin", "cpprob_hip_group_transport", "cpprob_hip_group_run", "cpprob_hip_group_sync", "cpprob_hip_group_size",
     "cpprob_hip_group_context", "cpprob_hip_group_results", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
@@ -126,6 +126,9 @@ def load_library(path=None):
         "cpprob_hip_group_transport": (C.c_int, [vp, u64, i32, C.c_uint32]),
         "cpprob_hip_group_create_external": (C.c_int, [i32, i32, i32, C.POINTER(Collectives), C.POINTER(vp)]),
         "cpprob_hip_group_traffic": (C.c_int, [vp, C.POINTER(Traffic)]),
+        "cpprob_hip_group_profile": (C.c_int, [vp, i32]),
+        "cpprob_hip_group_profile_read": (C.c_int, [vp, C.POINTER(dbl)]),
+        "cpprob_hip_group_note": (C.c_char_p, [vp]),
         "cpprob_hip_exchange_direct": (C.c_int, [vp, vp]),
         "cpprob_hip_exchange_store": (C.c_int, [vp, vp]),
         "cpprob_hip_exchange_remote": (C.c_int, [vp, vp]),
@@ -560,6 +563,24 @@ class Group:
     def transport(self, records_per_peer=0, all_peers=-1, flags=0):
         """Transport parameters of the next begin() (0 / -1: the defaults; flags: GROUP_SENDRECV, GROUP_WORLD1_COLLECTIVES)."""
         self._chk(self.L.cpprob_hip_group_transport(self.h, int(records_per_peer), int(all_peers), int(flags)))
+
+    PHASES = ["step_and_totals", "allgather", "totals_handover", "pack", "barrier", "commit", "mailbox_wait"]
+
+    def profile(self, on=True):
+        """HIP events between the launches of every step of the following runs (cpprob_hip_group_profile)."""
+        self._chk(self.L.cpprob_hip_group_profile(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        """Microseconds per rank-step of the last (profiled) run, by phase; 'steps' = steps timed."""
+        out = (C.c_double * 8)()
+        self._chk(self.L.cpprob_hip_group_profile_read(self.h, out))
+        d = {k: out[i] for i, k in enumerate(self.PHASES)}
+        d["steps"] = int(out[7])
+        return d
+
+    def note(self):
+        """Which collectives / transport the group settled on, and why."""
+        return self.L.cpprob_hip_group_note(self.h).decode()
 
     def traffic(self):
         """Of the run results() last collected: dict of records, payload_bytes, wire_bytes, collective_bytes, transport."""

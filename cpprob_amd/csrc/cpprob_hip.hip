@@ -1210,7 +1210,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
             Hier h{};
             const int kn = (t + 1 + c->hier_phase_run) % 3;
             hier_view(c, kn, h);
-            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = t & 1; d.seq = (c->x_gather_serial << 12) | (unsigned long long)(t + 1);
+            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = t & 1; d.seq = (c->x_gather_serial << 32) | (unsigned long long)(uint32_t)(t + 1);
                                   hipLaunchKernelGGL(counts_totals_gather_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals, d); }
             else hipLaunchKernelGGL(counts_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals);
         }
@@ -1222,7 +1222,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
             FHier f{};
             const int kn = (t + 1 + c->hier_phase_run) % 3;
             fhier_view(c, kn, f);
-            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = t & 1; d.seq = (c->x_gather_serial << 12) | (unsigned long long)(t + 1);
+            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = t & 1; d.seq = (c->x_gather_serial << 32) | (unsigned long long)(uint32_t)(t + 1);
                                   hipLaunchKernelGGL(fixed_totals_gather_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local_totals), d); }
             else hipLaunchKernelGGL(fixed_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local_totals));
         }

@@ -9,7 +9,7 @@
 //     wait   lane r spins on the sequence number rank r left in THIS rank's mailbox (acquire, system scope), then reads its words.
 // Nothing on the host, no library call inside a run.  Slots alternate with the step's parity: a rank can be at most one collective
 // ahead of a peer (its next wait needs that peer's next post), so two copies never collide.  Sequence numbers never repeat within a
-// group (run serial << 12 | step), so a stale slot is never mistaken for a fresh one.  A wait that sees nothing for `timeout` ticks
+// group (run serial << 32 | step + 1), so a stale slot is never mistaken for a fresh one.  A wait that sees nothing for `timeout` ticks
 // of the 100 MHz wall clock gives up, sets a sticky status bit and lets the run finish on whatever it holds: the bit travels with the
 // run's final all-reduce and the driver repeats the run on the library's collectives (group.hpp).
 // Loopback ranks (one device, one stream) post in one pass and wait in the next: program order has already delivered everything.
@@ -38,6 +38,14 @@ __device__ __forceinline__ bool dc_spin(const unsigned long long* flag, unsigned
     return true;
 }
 
+// how long the wavefront's wait took (its slowest lane), added to the rank's clock of spun ticks: status + 2, 64 bits (group.hpp reads it
+// for cpprob_hip_group_profile_read: what a step spends waiting for its peers, as opposed to launching)
+__device__ __forceinline__ void dc_waited(int32_t* status, long long t_begin)
+{
+    const long long dt = wall_clock64() - t_begin;                 // (behind the reconvergence of the lanes' spins)
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(status + 2), (unsigned long long)dt);
+}
+
 // all-gather of three 64-bit words per rank; one wavefront, lane r = rank r
 __device__ __forceinline__ void dc_allgather_body(unsigned long long w0, unsigned long long w1, unsigned long long w2, const MailboxPeers* __restrict__ peers, Mailbox* mine,
                                                   int world, int rank, int parity, unsigned long long seq, int phases,
@@ -53,6 +61,7 @@ __device__ __forceinline__ void dc_allgather_body(unsigned long long w0, unsigne
     }
     if (phases & kDcWait) {
         bool ok = true;
+        const long long tb = wall_clock64();
         if (lane < world) {
             const unsigned long long* slot = mine->tot[parity][lane];
             ok = dc_spin(slot + 3, seq, timeout, status);
@@ -60,6 +69,7 @@ __device__ __forceinline__ void dc_allgather_body(unsigned long long w0, unsigne
             for (int k = 0; k < 3; ++k) all_out[3 * lane + k] = __hip_atomic_load(slot + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (!ok) atomicOr(status, kDcTimedOut);
+        dc_waited(status, tb);
     }
 }
 
@@ -104,8 +114,10 @@ __global__ __launch_bounds__(kWave) void dc_barrier_kernel(const MailboxPeers* _
         __hip_atomic_store(&peers->box[lane]->bar[parity][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (phases & kDcWait) {
         bool ok = true;
+        const long long tb = wall_clock64();
         if (lane < world) ok = dc_spin(&mine->bar[parity][lane], seq, timeout, status);
         if (!ok) atomicOr(status, kDcTimedOut);
+        dc_waited(status, tb);
     }
 }
 

@@ -152,6 +152,8 @@ struct cpprob_hip_group {
     std::string transport_note;                        // why the direct transport was not taken
     // mailbox collectives (device_collectives.hpp)
     bool dev_coll = false, dc_tried = false; std::string dc_note; uint64_t dc_serial = 0;
+    // phase timing (cpprob_hip_group_profile): HIP events between the launches of a step, per local rank (loopback: one stream, rank 0's)
+    bool phase_profile = false; std::vector<std::vector<hipEvent_t>> ph_ev; std::vector<int> ph_used; int ph_steps = 0;
     std::vector<cph::Mailbox*> d_box; std::vector<cph::MailboxPeers*> d_box_peers; std::vector<int32_t*> d_dc_status;
     std::vector<void*> ipc_box_open;
     // per local rank device buffers
@@ -287,7 +289,7 @@ constexpr long long kDcTimeoutTicks = 500000000ll;          // 5 s of the 100 MH
 void dc_allgather(cpprob_hip_group* g, int i, int t, int phases, hipStream_t st)
 {
     const int rank = g->first_rank + i;
-    const unsigned long long seq = (unsigned long long)(g->dc_serial << 12) | (unsigned long long)(t + 1);
+    const unsigned long long seq = (unsigned long long)(g->dc_serial << 32) | (unsigned long long)(uint32_t)(t + 1);
     hipLaunchKernelGGL(cph::dc_allgather_kernel, dim3(1), dim3(cph::kWave), 0, st, reinterpret_cast<const unsigned long long*>(g->d_local[(size_t)i]),
                        (const cph::MailboxPeers*)g->d_box_peers[(size_t)i], g->d_box[(size_t)i], g->world, rank, t & 1, seq, phases,
                        reinterpret_cast<unsigned long long*>(g->d_all[(size_t)i]), g->d_dc_status[(size_t)i], kDcTimeoutTicks);
@@ -295,12 +297,33 @@ void dc_allgather(cpprob_hip_group* g, int i, int t, int phases, hipStream_t st)
 void dc_barrier(cpprob_hip_group* g, int i, int t, int phases, hipStream_t st)
 {
     const int rank = g->first_rank + i;
-    const unsigned long long seq = (unsigned long long)(g->dc_serial << 12) | (unsigned long long)(t + 1);
+    const unsigned long long seq = (unsigned long long)(g->dc_serial << 32) | (unsigned long long)(uint32_t)(t + 1);
     hipLaunchKernelGGL(cph::dc_barrier_kernel, dim3(1), dim3(cph::kWave), 0, st, (const cph::MailboxPeers*)g->d_box_peers[(size_t)i], g->d_box[(size_t)i], g->world, rank,
                        t & 1, seq, phases, g->d_dc_status[(size_t)i], kDcTimeoutTicks);
 }
 
 // One whole run of local rank i (RCCL: every collective is stream-ordered, nothing waits on the host).
+// ---- phase timing of a run: which part of a rank-step the time goes to (what the first multi-GPU run has to explain) ----
+// boundaries of one step, in launch order: before the step | after step + shard totals (+ the all-gather where the totals launch
+// carries it) | after a separate all-gather | after step_end (plan hand-over) | after the packing launch | after the barrier | after the commit
+enum { kPhStepTotals = 0, kPhGather, kPhStepEnd, kPhPack, kPhBarrier, kPhCommit, kPhCount };
+constexpr int kPhMarks = kPhCount + 1;
+void ph_mark(cpprob_hip_group* g, int i, hipStream_t st)
+{
+    if (!g->phase_profile) return;
+    std::vector<hipEvent_t>& ev = g->ph_ev[(size_t)i];
+    int& used = g->ph_used[(size_t)i];
+    if ((size_t)used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev.push_back(e); }
+    (void)hipEventRecord(ev[(size_t)used++], st);
+}
+void ph_begin(cpprob_hip_group* g)
+{
+    if (!g->phase_profile) return;
+    g->ph_ev.resize(g->ctx.size()); g->ph_used.assign(g->ctx.size(), 0); g->ph_steps = 0;
+    for (size_t i = 0; i < g->d_dc_status.size(); ++i)
+        if (g->d_dc_status[i]) { (void)hipSetDevice(g->ctx[i]->device); (void)hipMemsetAsync(g->d_dc_status[i] + 2, 0, sizeof(unsigned long long), g->ctx[i]->stream); }
+}
+
 int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
 {
     cpprob_hip_ctx* c = g->ctx[(size_t)i];
@@ -321,14 +344,20 @@ int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
     }
     struct GatherOff { cpprob_hip_ctx* c; ~GatherOff() { c->x_gather_on = false; } } gather_off{c};
     for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
+        const bool timed = g->phase_profile && g->exchange && t + 1 < g->T;       // (the steps that run every phase)
+        if (timed) ph_mark(g, i, c->stream);
         if (int rc = cpprob_hip_smc_step_begin(c, t, run_index, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
+        if (timed) ph_mark(g, i, c->stream);
         if (gather_in_totals && c->x_gather_done) {}
         else if (talk && g->dev_coll) dc_allgather(g, i, t, cph::kDcPost | cph::kDcWait, c->stream);
         else if (talk) { if (int rc = coll_allgather(g, i, g->d_local[(size_t)i], g->d_all[(size_t)i], 3)) return rc; }
+        if (timed) ph_mark(g, i, c->stream);
         if (int rc = cpprob_hip_smc_step_end(c, t, talk ? g->d_all[(size_t)i] : g->d_local[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
+        if (timed) ph_mark(g, i, c->stream);
         if (g->exchange && t + 1 < g->T) {
             // (a context without peers plans at most: cpprob_hip_exchange_pack_async / _commit_async launch nothing for it)
             if (int rc = cpprob_hip_exchange_pack_async(c, t)) return gfail(g, rc, cpprob_hip_last_error(c));
+            if (timed) ph_mark(g, i, c->stream);
             if (!talk) {}
             else if (g->transport == kTransportDirect) {
                 // the records are already where they belong; what remains is the order: no rank may commit before every rank's
@@ -338,7 +367,9 @@ int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
             } else {
                 if (int rc = rccl_exchange(g, i, t)) return rc;
             }
+            if (timed) ph_mark(g, i, c->stream);
             if (int rc = cpprob_hip_exchange_commit_async(c, t)) return gfail(g, rc, cpprob_hip_last_error(c));
+            if (timed) { ph_mark(g, i, c->stream); if (i == 0) ++g->ph_steps; }
         }
     }
     if (int rc = cpprob_hip_smc_finish(c)) return gfail(g, rc, cpprob_hip_last_error(c));
@@ -357,19 +388,26 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
     hipStream_t st = c0->stream;
     const bool sis = g->cfg.algorithm == CPPROB_HIP_ALG_SIS;
     for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
+        // (phase timing of a loopback run: the SUM over the ranks' launches of each phase -- they share the one stream)
+        const bool timed = g->phase_profile && g->exchange && t + 1 < g->T;
+        if (timed) ph_mark(g, 0, st);
         for (int r = 0; r < world; ++r)
             if (int rc = cpprob_hip_smc_step_begin(g->ctx[(size_t)r], t, run_index, g->d_local[(size_t)r])) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+        if (timed) ph_mark(g, 0, st);
         if (g->dev_coll) {
             // (mailboxes on one stream: every rank posts, then every rank finds what it waits for already there)
             for (int r = 0; r < world; ++r) dc_allgather(g, r, t, cph::kDcPost, st);
             for (int r = 0; r < world; ++r) dc_allgather(g, r, t, cph::kDcWait, st);
         } else hipLaunchKernelGGL(loop_allgather_kernel, dim3(1), dim3(192), 0, st, g->d_ptr_locals, g->d_ptr_alls, world);
+        if (timed) ph_mark(g, 0, st);
         for (int r = 0; r < world; ++r)
             if (int rc = cpprob_hip_smc_step_end(g->ctx[(size_t)r], t, g->d_all[(size_t)r], world, r)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+        if (timed) ph_mark(g, 0, st);
         if (g->exchange && t + 1 < g->T) {
             // direct transport: every rank's packing kernel stores into the other ranks' receive buffers; program order is the barrier
             for (int r = 0; r < world; ++r)
                 if (int rc = cpprob_hip_exchange_pack_async(g->ctx[(size_t)r], t)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+            if (timed) ph_mark(g, 0, st);
             if (g->transport == kTransportSendRecv) {
                 // (the fixed-capacity segments of the send/recv transport, as copies: A/B against the direct stores)
                 for (int r = 0; r < world; ++r) {
@@ -388,8 +426,10 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
                 for (int r = 0; r < world; ++r) dc_barrier(g, r, t, cph::kDcPost, st);
                 for (int r = 0; r < world; ++r) dc_barrier(g, r, t, cph::kDcWait, st);
             }
+            if (timed) ph_mark(g, 0, st);
             for (int r = 0; r < world; ++r)
                 if (int rc = cpprob_hip_exchange_commit_async(g->ctx[(size_t)r], t)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+            if (timed) { ph_mark(g, 0, st); ++g->ph_steps; }
         }
     }
     for (int r = 0; r < world; ++r) {
@@ -607,12 +647,18 @@ int setup_mailboxes(cpprob_hip_group* g)
         GHIP_TRY(g, hipSetDevice(c->device));
         void* p = nullptr;
         // (fine-grained: the peers' stores and this rank's spinning loads meet in memory, not in a cache)
-        if (hipExtMallocWithFlags(&p, sizeof(cph::Mailbox), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); if (hipMalloc(&p, sizeof(cph::Mailbox)) != hipSuccess) { ok = false; break; } }
+        if (hipExtMallocWithFlags(&p, sizeof(cph::Mailbox), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            // ranks on ONE device and ONE stream (loopback) meet in that device's cache hierarchy: ordinary memory serves them.  Between
+            // devices a spin on coarse-grained memory may never see the peer's store (it would end in the wait's time-out, run after run):
+            // without fine-grained memory the mailboxes stay off and the library's collectives carry the steps -- said in the traffic record
+            if (!g->loopback() || hipMalloc(&p, sizeof(cph::Mailbox)) != hipSuccess) { (void)hipGetLastError(); ok = false; g->dc_note = "no fine-grained device memory for the mailboxes: the library's collectives carry the steps"; break; }
+        }
         g->d_box[(size_t)i] = static_cast<cph::Mailbox*>(p);
         GHIP_TRY(g, hipMemset(p, 0, sizeof(cph::Mailbox)));
         GHIP_TRY(g, hipMalloc(&g->d_box_peers[(size_t)i], sizeof(cph::MailboxPeers)));
-        GHIP_TRY(g, hipMalloc(&g->d_dc_status[(size_t)i], sizeof(int32_t)));
-        GHIP_TRY(g, hipMemset(g->d_dc_status[(size_t)i], 0, sizeof(int32_t)));
+        GHIP_TRY(g, hipMalloc(&g->d_dc_status[(size_t)i], 4 * sizeof(int32_t)));         // {status, -, ticks the waits spun: 64 bits}
+        GHIP_TRY(g, hipMemset(g->d_dc_status[(size_t)i], 0, 4 * sizeof(int32_t)));
     }
     std::vector<cph::MailboxPeers> tab((size_t)n_local);
     if (ok && world == n_local) {
@@ -669,7 +715,7 @@ int setup_mailboxes(cpprob_hip_group* g)
             GHIP_TRY(g, hipSetDevice(g->ctx[(size_t)i]->device));
             GHIP_TRY(g, hipMemcpy(g->d_local[(size_t)i], w, sizeof w, hipMemcpyHostToDevice));
         }
-        const int t_probe = 4094;                               // (a step number no run uses)
+        const int t_probe = 0x7ffffffd;                         // (a step number no run uses: the step field of a sequence number is 32 bits wide)
         if (g->loopback()) {
             for (int i = 0; i < n_local; ++i) dc_allgather(g, i, t_probe, cph::kDcPost, g->ctx[0]->stream);
             for (int i = 0; i < n_local; ++i) dc_allgather(g, i, t_probe, cph::kDcWait, g->ctx[0]->stream);
@@ -725,6 +771,7 @@ int group_begin_contexts(cpprob_hip_group* g)
 
 int group_enqueue(cpprob_hip_group* g, uint64_t run_index)
 {
+    ph_begin(g);
     ++g->dc_serial;                                     // (every rank enqueues the same runs in the same order: the mailboxes' sequence numbers agree)
     if (g->loopback()) return loopback_run(g, run_index);
     if (g->ctx.size() == 1) return run_rank(g, 0, run_index);
@@ -981,8 +1028,23 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
         cpprob_hip_ctx* c = g->ctx[0];
         GHIP_TRY(g, hipSetDevice(c->device));
         GHIP_TRY(g, hipMemcpy(joint.data(), g->d_joint[0], joint.size() * sizeof(double), hipMemcpyDeviceToHost));
-        // fixed-point form: did the weights keep their bits (cpprob_hip.hip: settle_fixed)?  Every rank holds the same gap (it comes
-        // from the all-gathered totals), so every rank takes the same decision: repeat the run in the floating-point form
+        // First the flag that is the same on every rank by construction (all-reduced with the run's results): some rank's mailbox
+        // wait gave up.  That rank planned its steps on stale totals, so its gap, masses and squares may differ from its peers' -- every
+        // rank discards the run, the library's collectives carry the steps from here on, and the run is repeated on them.  (Testing
+        // the per-rank precision gap first could send the ranks down different branches -- one into begin + a host all-gather of
+        // hipIpc records, another into a 24-byte all-gather: mismatched collectives, a hang where a fall-back was meant.)
+        if (joint[(size_t)g->n_stats + 3] != 0.0) {
+            if (attempt >= 6) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "run repeated too often"));
+            g->dev_coll = false; g->dc_note = "a mailbox collective timed out: the library's collectives carry the steps";
+            for (size_t i = 0; i < g->d_dc_status.size(); ++i) { GHIP_TRY(g, hipSetDevice(g->ctx[i]->device)); GHIP_TRY(g, hipMemset(g->d_dc_status[i], 0, sizeof(int32_t))); }
+            for (auto* x : g->ctx) x->fixed_check_pending = false;
+            ++g->reruns;
+            if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
+            continue;
+        }
+        // fixed-point form: did the weights keep their bits (cpprob_hip.hip: settle_fixed)?  On a run whose collectives all completed
+        // every rank holds the same gap (it comes from the all-gathered totals), so every rank takes the same decision: repeat the run
+        // in the floating-point form
         bool imprecise = false;
         if (c->fixed_check_pending) {
             cph::StepCtrl hc{};
@@ -994,16 +1056,6 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
             if (attempt >= 6) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "run repeated too often"));
             g->cfg.flags |= CPPROB_HIP_FLAG_FLOATING_POINT_STEP;
             if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
-            ++g->reruns;
-            if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
-            continue;
-        }
-        if (joint[(size_t)g->n_stats + 3] != 0.0) {
-            // some rank's mailbox wait gave up (every rank sees the all-reduced count): the library's collectives carry the steps from
-            // here on, and the run is repeated on them
-            if (attempt >= 6) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "run repeated too often"));
-            g->dev_coll = false; g->dc_note = "a mailbox collective timed out: the library's collectives carry the steps";
-            for (size_t i = 0; i < g->d_dc_status.size(); ++i) { GHIP_TRY(g, hipSetDevice(g->ctx[i]->device)); GHIP_TRY(g, hipMemset(g->d_dc_status[i], 0, sizeof(int32_t))); }
             ++g->reruns;
             if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
             continue;
@@ -1072,6 +1124,58 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
         }
     }
     return 0;
+}
+
+int cpprob_hip_group_profile(cpprob_hip_group* g, int32_t on)
+{
+    if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
+    g->phase_profile = on != 0;
+    if (!on) {
+        for (size_t i = 0; i < g->ph_ev.size(); ++i) { if (i < g->ctx.size()) (void)hipSetDevice(g->ctx[i]->device); for (hipEvent_t e : g->ph_ev[i]) (void)hipEventDestroy(e); }
+        g->ph_ev.clear(); g->ph_used.clear();
+    }
+    return 0;
+}
+
+int cpprob_hip_group_profile_read(cpprob_hip_group* g, double* h_out8)
+{
+    if (!g || !h_out8) return fail(nullptr, CPPROB_HIP_EINVAL, "NULL argument");
+    for (int k = 0; k < 8; ++k) h_out8[k] = 0.0;
+    if (!g->phase_profile || !g->ran) return gkeep(g, gfail(g, CPPROB_HIP_ESTATE, "no profiled run (cpprob_hip_group_profile, then a run)"));
+    if (int rc = cpprob_hip_group_sync(g)) return gkeep(g, rc);
+    const int steps = g->ph_steps;
+    h_out8[7] = (double)steps;
+    if (steps == 0) return 0;
+    for (size_t i = 0; i < g->ph_ev.size(); ++i) {
+        if ((int)g->ph_used[i] < steps * kPhMarks) continue;
+        GHIP_TRY(g, hipSetDevice(g->ctx[i]->device));
+        double sum[kPhCount] = {0, 0, 0, 0, 0, 0};
+        for (int s2 = 0; s2 < steps; ++s2)
+            for (int k = 0; k < kPhCount; ++k) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, g->ph_ev[i][(size_t)(s2 * kPhMarks + k)], g->ph_ev[i][(size_t)(s2 * kPhMarks + k + 1)]) == hipSuccess) sum[k] += ms;
+            }
+        for (int k = 0; k < kPhCount; ++k) h_out8[k] = std::max(h_out8[k], sum[k] * 1e3 / steps);      // us per rank-step, the slowest local rank
+    }
+    for (size_t i = 0; i < g->d_dc_status.size(); ++i) {
+        if (!g->d_dc_status[i]) continue;
+        unsigned long long ticks = 0;
+        GHIP_TRY(g, hipSetDevice(g->ctx[i]->device));
+        GHIP_TRY(g, hipMemcpy(&ticks, g->d_dc_status[i] + 2, sizeof ticks, hipMemcpyDeviceToHost));
+        h_out8[6] = std::max(h_out8[6], (double)ticks * 0.01 / steps);                                  // 100 MHz wall clock -> us per rank-step
+    }
+    return 0;
+}
+
+const char* cpprob_hip_group_note(const cpprob_hip_group* g)
+{
+    if (!g) return "";
+    static thread_local std::string note;
+    note = std::string("collectives: ") + (g->coll == kCollLoopback ? "loopback (one device, one stream: program order)" : (g->coll == kCollExternal ? "the caller's all-gather" : "RCCL"));
+    note += g->dev_coll ? "; per-step collectives: mailbox stores over the peer mappings" : "; per-step collectives: the library's";
+    if (!g->dc_note.empty()) note += " (" + g->dc_note + ")";
+    note += std::string("; migrants: ") + (g->transport == kTransportDirect ? (g->remote ? "direct stores, remote lineages" : "direct stores, lineages shipped") : (g->transport == kTransportSendRecv ? "send/recv segments" : "none"));
+    return note.c_str();
 }
 
 int cpprob_hip_group_traffic(cpprob_hip_group* g, cpprob_hip_traffic* out)

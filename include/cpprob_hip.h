@@ -376,6 +376,17 @@ int cpprob_hip_group_size(const cpprob_hip_group* group, int32_t* world, int32_t
 cpprob_hip_ctx* cpprob_hip_group_context(cpprob_hip_group* group, int32_t local_index);
 int cpprob_hip_group_results(cpprob_hip_group* group, cpprob_hip_summary* out, double* h_stats, size_t n_doubles, int32_t* h_reruns);
 int cpprob_hip_group_traffic(cpprob_hip_group* group, cpprob_hip_traffic* out);
+/* Where a rank-step's time goes (what the first run over real links has to explain).  profile(on): HIP events between the launches of
+ * every step of the following runs, on every local rank's stream.  profile_read: of the last run, microseconds per rank-step (mean over
+ * the steps that run every phase, the slowest local rank; a loopback group: the SUM over its ranks, which share one stream):
+ * [0] step kernel + shard totals (+ the mailbox all-gather where the totals launch carries it), [1] a separate all-gather (mailbox
+ * launch or library call), [2] the hand-over of the gathered totals, [3] the packing launch, [4] the barrier that orders the commits
+ * behind every rank's stores, [5] the commit, [6] of all that, the time mailbox waits spun (device wall clock), [7] steps timed. */
+int cpprob_hip_group_profile(cpprob_hip_group* group, int32_t on);
+int cpprob_hip_group_profile_read(cpprob_hip_group* group, double* h_out8);
+/* Which collectives and which migrant transport the group settled on, and why (fall-back rungs included), as one line of text; valid
+ * until the calling thread's next call. */
+const char* cpprob_hip_group_note(const cpprob_hip_group* group);
 
 /* ---- building blocks (also the unit-parity surface) --------------------------------------
  * All pointers are device pointers; n is the element count. */

@@ -915,6 +915,12 @@ def test_bench_two_ranks_on_one_gpu(scope, workload):
         assert d["config"]["host"].startswith("C++ (cpprob_hip_group_run: torch.distributed gloo"), d["config"]
         assert d["exchange_traffic_per_run"]["transport"] == "direct" and d["exchange_traffic_per_run"]["records"] > 0
         assert d["config"]["exchange_reruns"]["timed_batch"] == 0
+        # where a rank-step's time goes, and which transports carried it (what the first run over real links has to explain)
+        bd = d["rank_step_breakdown_us"]
+        for key in ("step_and_totals", "allgather", "totals_handover", "pack", "barrier", "commit", "mailbox_wait", "steps", "transport_note"):
+            assert key in bd, bd
+        assert bd["steps"] > 0 and bd["step_and_totals"] > 0 and bd["pack"] > 0 and "migrants: direct stores" in d["transport_note"]
+        assert d["roofline"]["frac_layout"] <= 1.0 and d["roofline"]["layout_bytes_per_unit"] > 0 and "step_form" in d["roofline"]
 
 
 HMM2 = ([-1.5, 1.0], [[0.85, 0.15], [0.3, 0.7]])
