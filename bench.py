@@ -610,7 +610,7 @@ def main():
             # the same population as FOUR ranks of one joint population on this GPU (loopback: the pull migration and the per-step host all-gather at work)
             with tempfile.TemporaryDirectory() as td:
                 cmd = [exe, "--model_folder", td, "--model", "hmm16", "--smc", "--observes", obs_s, "--n_samples", str(n), "--seed", str(args.seed),
-                       "--ess_threshold", "2.0", "--generic", "--no_dump", "--json", "--repeat", "4", "--devices", "0,0,0,0"]
+                       "--ess_threshold", "2.0", "--generic", "--no_dump", "--json", "--repeat", "6", "--devices", "0,0,0,0"]
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             jj = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")][-1]
             out["generic_path"]["joint_4_loopback_ranks"] = {"ms_per_run": jj["run_seconds"] * 1e3, "joint": jj["joint"], "log_evidence_equals_one_rank": jj["log_evidence"] == gj["log_evidence"],

@@ -349,6 +349,48 @@ def joint_results(engine, slot):
     return stats, s
 
 
+def offspring_bounds_fixed(masses, n_global, u0):
+    """Offspring bounds of the ranks in the fixed-point form, as the device derives them from the all-gathered totals
+    (cpprob_amd/csrc/step_fixed.hpp: plan_bounds_fixed): rank r's sources own the outputs [o[r], o[r + 1]),
+    o[r] = ceil(fma(double(mass before rank r), N / double(total mass), -u0)), o[0] = 0, o[world] = N.  masses: one integer per rank."""
+    import math
+    from fractions import Fraction
+    masses = [int(m) for m in masses]
+    total = sum(masses)
+    n = float(int(n_global))
+    inv = n / float(total)
+    o, before = [], 0
+    for m in masses:
+        # fma(double(before), inv, -u0) with ONE rounding: the exact rational value, correctly rounded (float(Fraction) is)
+        fused = float(Fraction(float(before)) * Fraction(inv) - Fraction(float(u0)))
+        o.append(max(0.0, float(math.ceil(fused))))
+        before += m
+    o[0] = 0.0
+    o.append(n)
+    return np.array(o, np.float64)
+
+
+def exchange_counts(o, begins, rank):
+    """The exchange plan of one resampling step from the ranks' offspring bounds o[0..world] and shard begins[0..world] (what
+    cpprob_hip_exchange_plan computes on the device, cpprob_amd/csrc/exchange.hpp: exchange_plan_*): rank `rank`'s sources own the
+    outputs [o[rank], o[rank + 1]); those inside another rank p's shard [begins[p], begins[p + 1]) are the lineages it SENDS to p
+    (in output order), and it RECEIVES from q the outputs of its own shard that q's sources own.  Returns (send_first[world] -- the
+    first such output per destination --, send_counts[world], recv_counts[world]); the diagonal is zero."""
+    world = len(begins) - 1
+    o = [int(x) for x in o]
+    b = [int(x) for x in begins]
+    def overlap(src, dst):
+        lo, hi = max(o[src], b[dst]), min(o[src + 1], b[dst + 1])
+        return lo, max(hi - lo, 0)
+    send_first, send_counts, recv_counts = np.zeros(world, np.int64), np.zeros(world, np.int64), np.zeros(world, np.int64)
+    for p in range(world):
+        if p == rank:
+            continue
+        send_first[p], send_counts[p] = overlap(rank, p)
+        recv_counts[p] = overlap(p, rank)[1]
+    return send_first, send_counts, recv_counts
+
+
 def shard_begins(n_global, world):
     return np.array([shard_bounds(n_global, world, r)[0] for r in range(world)] + [int(n_global)], np.uint64)
 

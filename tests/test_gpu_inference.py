@@ -233,7 +233,7 @@ def test_smc_lgssm_matches_oracle(engine, golden_dir, resampler, ess):
 @pytest.mark.parametrize("n", [1, 2, 1023, 1025, 4095, 4097, 12289])
 def test_smc_tiny_and_ragged_populations(engine, golden_dir, n):
     obs = _obs(golden_dir, "hmm16")[:5]
-    _compare_smc(engine, cp.MODEL_HMM3, obs, n, 3, cp.RESAMPLE_SYSTEMATIC, 2.0) if n > 2 else None
+    _compare_smc(engine, cp.MODEL_HMM3, obs, n, 3, cp.RESAMPLE_SYSTEMATIC, 2.0)          # (one and two particles included: ancestors, states, evidence)
     engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=3)
     engine.run()
     st = engine.stats()

@@ -153,6 +153,98 @@ def test_gloo_world2_island_combine(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+_GLOO_EXCHANGE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from cpprob_amd import distributed as D, capi
+from oracle import oracle as O
+world, rank, local = D.init_process_group(device_is_gpu=False)
+assert dist.get_backend() == "gloo" and world == %(world)d
+# DEFAULT scope of a sharded run (exchange: one joint population, exact global resampling).  Every process holds ONE shard of a
+# population whose generations come from the single-process oracle run (so that a rank's sources carry the right weights and
+# lineages); the oracle's SHARDED resampler stands in for the device on each rank, the ranks' offspring bounds and the plan of who
+# sends how many lineages to whom are the product's host statements (D.offspring_bounds_fixed, D.exchange_counts), the lineages
+# travel through D.host_all_to_all -- and what every rank ends up holding for its outputs must be, output for output, the lineage
+# of the ancestor the single-process run drew.
+z = np.load(os.path.join(%(root)r, "tests", "golden", "observations.npz"))
+obs = z["lgssm100"][:12]
+N, seed = %(n)d, 17
+ref = O.smc_ref(O.MODEL_LINEAR_GAUSSIAN_1D, obs, N, seed, O.REF_STATEMENT_BOUND, O.RESAMPLE_SYSTEMATIC, 2.0)       # every step resamples
+paths_all = [np.take_along_axis(ref["hist"][: t + 1], O.lineage(ref["anc"][: t + 1]), axis=1) for t in range(len(obs))]   # [t + 1][N]: lineages of generation t
+sizes = %(sizes)r
+begins = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+assert int(begins[-1]) == N
+lo, hi = int(begins[rank]), int(begins[rank + 1])
+bound = -0.5 * np.log(2 * np.pi)
+L = capi.load_library()
+n_moved = 0
+for t in range(len(obs) - 1):
+    # generation t's weights on this rank's sources (every step resamples: they start from zero), as integers
+    lw = -0.5 * ((obs[t] - ref["hist"][t][lo:hi]) ** 2 + np.log(2 * np.pi))
+    q = O.fix_weights(lw, bound)
+    mine = np.array([int(q.astype(np.uint64).sum())], np.float64)                 # (exact below 2^53)
+    masses = D.allgather_vector(mine)[:, 0]
+    total, before = int(masses.sum()), int(masses[:rank].sum())
+    u0 = L.cpprob_hip_systematic_offset(seed, t + 1)
+    # the stand-in for the device: ancestors of EVERY output among this rank's sources (-1: another rank's)
+    anc = O.resample_fixed_systematic(q, seed, t + 1, before=before, total=total, last_shard=(rank + 1 == world), j0=0, n_out=N, n_total_out=N)
+    owned = np.flatnonzero(anc >= 0)
+    o = D.offspring_bounds_fixed(masses, N, u0)
+    assert len(owned) == 0 or (owned[0] == int(o[rank]) and owned[-1] + 1 == int(o[rank + 1]) and len(owned) == int(o[rank + 1] - o[rank]))    # the host's bounds = what the resampler drew
+    first, sc, rc = D.exchange_counts(o, begins, rank)
+    width = t + 1
+    send = []
+    for p in range(world):
+        j = np.arange(first[p], first[p] + sc[p])
+        assert np.all(anc[j] >= 0)
+        send.append(paths_all[t][:, lo + anc[j]].T.reshape(-1))                   # records: the lineage x_0..x_t of each ancestor, in output order
+    h_send = torch.from_numpy(np.concatenate(send) if send else np.zeros(0))
+    h_recv = D.host_all_to_all(h_send, [int(c) * width for c in sc], [int(c) * width for c in rc]).numpy()
+    n_moved += int(sc.sum())
+    # assemble this rank's outputs: own sources where it owns the output, else the record of the rank that does, in source-rank order
+    got = np.zeros((width, hi - lo))
+    off = 0
+    for src in range(world):
+        if src == rank:
+            j = np.arange(max(int(o[rank]), lo), min(int(o[rank + 1]), hi))
+            got[:, j - lo] = paths_all[t][:, lo + anc[j]]
+            continue
+        olo = max(int(o[src]), lo)
+        recs = h_recv[off: off + int(rc[src]) * width].reshape(int(rc[src]), width)
+        got[:, olo - lo: olo - lo + int(rc[src])] = recs.T
+        off += int(rc[src]) * width
+    want = paths_all[t][:, ref["anc"][t + 1][lo:hi]]                                # the lineages the single-process run's ancestors carry
+    assert np.array_equal(got, want), (rank, t)
+tot = torch.tensor([n_moved]); dist.all_reduce(tot)
+assert int(tot) > 0                                                              # (lineages did cross ranks)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("world,sizes", [(2, [3000, 3000]), (3, [2500, 1700, 1801])])
+def test_gloo_exchange_scope_moves_the_single_process_lineages(tmp_path, world, sizes):
+    """The N > 1 path's DEFAULT scope across real processes, on CPU: plan, counts and ordering of the migration (cpprob_amd/distributed.py)
+    against the single-process oracle run -- world 2, and world 3 with uneven shards."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_EXCHANGE_WORKER % {"root": ROOT, "world": world, "sizes": sizes, "n": sum(sizes)})
+    import socket
+    for attempt in range(2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(script)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        if out.returncode == 0:
+            break
+    assert out.returncode == 0, out.stdout[-2500:] + out.stderr[-2500:]
+    assert out.stdout.count("ok") == world
+
+
 def test_bench_cli_parses_and_graft_entry_builds():
     import importlib
     ge = importlib.import_module("__graft_entry__")
