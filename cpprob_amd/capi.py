@@ -394,7 +394,7 @@ class Engine:
         self._chk(self.L.cpprob_hip_logpdf_discrete(self.h, _dptr(x), w, len(weights), x.numel(), _dptr(out)))
 
     def fastmath(self, which, x, out0, out1=None):
-        """which: 0 log01, 1 sincospi02 (out0 = sin, out1 = cos), 2 exp_nonpos; torch float64 tensors on this device."""
+        """which: 0 log01, 1 sincospi02 (out0 = sin, out1 = cos), 2 exp_nonpos, 3 fix_weight against reference 0; torch float64 tensors on this device."""
         self._chk(self.L.cpprob_hip_fastmath(self.h, int(which), _dptr(x), x.numel(), _dptr(out0), _dptr(out1)))
 
     def logsumexp_ess(self, logw):

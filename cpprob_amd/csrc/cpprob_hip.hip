@@ -1975,13 +1975,24 @@ int cpprob_hip_logpdf_discrete(cpprob_hip_ctx* c, const int32_t* x, const double
     return 0;
 }
 
+}  // extern "C"
+namespace {
+// the fixed-point weight of a log-weight x against the reference 0, as a double (cpprob/detail/fixed_mass.hpp: fix_weight)
+__global__ void fix_weight_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)fix_weight(x[i], 0.0);
+}
+}  // namespace
+extern "C" {
 int cpprob_hip_fastmath(cpprob_hip_ctx* c, int32_t which, const double* d_x, size_t n, double* d_out0, double* d_out1)
 {
     BB_PRELUDE(c);
-    if (which < 0 || which > 2) return fail(c, CPPROB_HIP_EINVAL, "which: 0 log01, 1 sincospi02, 2 exp_nonpos");
+    if (which < 0 || which > 3) return fail(c, CPPROB_HIP_EINVAL, "which: 0 log01, 1 sincospi02, 2 exp_nonpos, 3 fix_weight");
     if (!d_x || !d_out0 || (which == 1 && !d_out1)) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(fastmath_kernel, GRID1(n), (int)which, d_x, (int64_t)n, d_out0, d_out1);
+    if (which == 3) hipLaunchKernelGGL(fix_weight_kernel, GRID1(n), d_x, (int64_t)n, d_out0);
+    else hipLaunchKernelGGL(fastmath_kernel, GRID1(n), (int)which, d_x, (int64_t)n, d_out0, d_out1);
     HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -416,7 +416,8 @@ int cpprob_hip_logpdf_discrete(cpprob_hip_ctx* ctx, const int32_t* d_x, const do
 /* The range-specific fp64 elementary functions the variate generators and the weight kernels use in place of the device library's
  * (cpprob_amd/include/cpprob/detail/fastmath.hpp; they stand where the reference calls std::log / std::exp through Boost.Random and
  * include/cpprob/distributions/utils_normal_distribution.hpp:38-41), elementwise: which = 0 log01 on [2^-53, 1], 1 sincospi02 on
- * (0, 2] (d_out0 = sin(pi x), d_out1 = cos(pi x)), 2 exp_nonpos on [-745, 0].  Unit-parity surface: tests sweep the domain edges. */
+ * (0, 2] (d_out0 = sin(pi x), d_out1 = cos(pi x)), 2 exp_nonpos on [-745, 0]; 3: the fixed-point weight min(rint(exp(x) 2^32), 2^32 - 1)
+ * of a log-weight x <= 0 against the reference 0 (fixed_mass.hpp: fix_weight), as a double.  Unit-parity surface: tests sweep the domain edges. */
 int cpprob_hip_fastmath(cpprob_hip_ctx* ctx, int32_t which, const double* d_x, size_t n, double* d_out0, double* d_out1);
 
 /* EmpiricalDistribution (include/cpprob/postprocess/empirical_distribution.hpp):

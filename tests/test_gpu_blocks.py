@@ -382,6 +382,37 @@ def test_fastmath_sincospi02_edges_and_random_points(engine):
     assert sn[2] == 0.0 and cs[2] == 1.0                        # w = 2
 
 
+def test_fix_weight_against_extended_precision_and_the_oracle(engine):
+    """The integer weight q = min(rint(exp(lw - R) 2^32), 2^32 - 1) (cpprob/detail/fixed_mass.hpp: fix_weight).  Two references: the
+    oracle's restatement -- which shares the kernel's exp polynomial, so the two must agree bit for bit -- and, independently of that
+    polynomial, rint(expl(x) 2^32) in x87 extended precision: exp_nonpos is faithfully rounded (<= 0.66 ulp), so the integers can
+    differ only where exp(x) 2^32 lies within ~2^-21 of a half-integer, and then by ONE unit.  10^6 random points over the 23 nats
+    the form resolves, the clamps at both ends, exact zeros and the neighbourhoods of small half-integers."""
+    import torch
+    assert np.finfo(np.longdouble).nmant >= 63, "needs x87 extended precision for the reference"
+    rng = np.random.default_rng(14)
+    halves = np.log((np.arange(0, 4000) + 0.5) * 2.0 ** -32)            # exp(x) 2^32 = k + 1/2: the rounding boundaries of the small integers
+    edges = np.concatenate([[0.0, -0.0, -1e-300, -2.0 ** -53, -2.0 ** -33, -2.0 ** -32, -22.18, -22.1807, -23.0, -24.0, -40.0, -745.0, -1000.0, -1e9, -np.inf],
+                            halves, np.nextafter(halves, 0), np.nextafter(halves, -1e9)])
+    xv = np.concatenate([edges, -rng.uniform(0, 23, 700000), -rng.uniform(0, 6, 200000), -(2.0 ** -rng.uniform(0, 40, 100000))])
+    x = _t(xv)
+    out = dzeros_like(x)
+    engine.fastmath(3, x, out)
+    engine.sync()
+    got = out.cpu().numpy()
+    assert np.array_equal(got, O.fix_weights(xv, 0.0).astype(np.float64))                      # the oracle states the same arithmetic
+    assert got[0] == 4294967295.0 and got[1] == 4294967295.0 and got[13] == 0.0 and got[14] == 0.0       # 0, -0 | -1e9, -inf
+    ref = np.rint(np.exp(np.maximum(xv, -1000.0).astype(np.longdouble)) * np.longdouble(4294967296.0))
+    ref = np.minimum(ref, np.longdouble(4294967295.0)).astype(np.float64)
+    d = np.abs(got - ref)
+    assert d.max() <= 1.0, d.max()
+    # how many: among the points placed ON the rounding boundaries (x = log((k + 1/2) 2^-32) and its neighbours) a tie may fall either
+    # way; among the 10^6 random points only where exp(x) 2^32 happens to lie within the polynomial's error of a half-integer
+    n_edge, n_rand = int(np.count_nonzero(d[: len(edges)])), int(np.count_nonzero(d[len(edges):]))
+    assert n_rand <= 20, (n_rand, n_edge)
+    print("fix_weight: %d of %d random points and %d of %d boundary points differ by one unit from the x87 reference" % (n_rand, len(xv) - len(edges), n_edge, len(edges)))
+
+
 def test_fastmath_exp_nonpos_edges_and_random_points(engine):
     """exp_nonpos on [-745, 0]: 0, -0, the underflow edge, multiples of ln 2 / 2 (the reduction's boundaries) and 10^6 random
     points, against 80-bit expl: <= 1 ulp in the normal range (0.66); denormal results within one denormal spacing."""

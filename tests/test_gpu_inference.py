@@ -397,6 +397,58 @@ def test_fixed_point_run_that_loses_its_bits_is_repeated_in_the_floating_point_f
     np.testing.assert_allclose(gst, st, rtol=0, atol=5e-3)
 
 
+@pytest.mark.parametrize("workload", ["configs[3]: linear_gaussian_1d<100>, 10^7 particles", "configs[4] per-GPU shard: hmm<128>, 1.25 10^7 particles"])
+def test_fixed_point_masses_at_full_size_arithmetic_bound_and_posterior(engine, golden_dir, workload):
+    """The fixed-point form's arithmetic is narrower than the reference's `double log_w_` (include/cpprob/trace.hpp:59): a weight is
+    an integer multiple of 2^-32 of exp(R_t).  What that costs, where BASELINE.json quotes the two multi-GPU configs:
+
+    (1) THE ARITHMETIC, generation by generation (runs cut after 1, 7, 40 and all observes: the same particles as the full run's).
+        Every weight is off by at most half a unit, so a generation's mass S (in units) is off by at most N / 2 and its logarithm --
+        a factor of the evidence, the normaliser of every posterior sum -- by at most N / (2 S); measured against an fp64
+        recomputation from the stored log-weights.  ESS: the squares are taken on 16-bit weights (q >> 16), which under-counts
+        their sum by at most 2^-15 at full scale: the integer ESS is never below the fp64 one and at most 1e-4 above it.
+    (2) THE POSTERIOR.  Fixed-point against CPPROB_HIP_FLAG_FLOATING_POINT_STEP (fp64 weights, fp64 CDF) on the same seed is NOT a
+        clean measure of (1): the floating-point form's CDF-boundary flips make the two runs different genealogies after a few
+        steps, i.e. different Monte-Carlo realisations.  So their difference is compared with what it would have to exceed to mean
+        anything -- the difference between two SEEDS of the fixed-point form -- and each form with the exact posterior (Kalman + RTS /
+        forward-backward).  (north_star's 1e-3 is stated for the Gaussian SIS config at 10^7; the Monte-Carlo error of a T = 100 / 128
+        smoothing trace at these sizes is several times that, in either arithmetic.)"""
+    z = np.load(os.path.join(golden_dir, "observations.npz"))
+    if workload.startswith("configs[3]"):
+        model, obs, n, exact, tol = cp.MODEL_LINEAR_GAUSSIAN_1D, z["lgssm100"], 10_000_000, np.stack([z["lgssm100_smooth_mean"], z["lgssm100_smooth_var"]], 1), 1.2e-2
+    else:
+        model, obs, n, exact, tol = cp.MODEL_HMM3, z["hmm128"], 12_500_000, z["hmm128_smooth"], 5e-3
+    # (1)
+    for Tt in (1, 7, 40, len(obs)):
+        engine.begin(cp.ALG_SMC, model, obs[:Tt], n, seed=31, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=0.5)
+        engine.run()
+        s = engine.summary()
+        assert s["step_form"] == cp.capi.FORM_FIXED
+        lw = engine.logw()
+        m = lw.max()
+        w = np.exp(lw - m)
+        lse, ess = m + np.log(w.sum()), w.sum() ** 2 / (w * w).sum()
+        units = np.exp(s["log_norm"] - s["max_logw"]) * 2.0 ** 32                 # the generation's mass in units of 2^-32 exp(R)
+        assert abs(s["log_norm"] - lse) <= n / (2.0 * units) + 1e-12, (Tt, s["log_norm"] - lse, n / (2.0 * units))
+        assert 0.0 <= s["ess_final"] / ess - 1.0 <= 1e-4, (Tt, s["ess_final"], ess)
+    # (2)
+    out = {}
+    for name, flags, seed in (("fixed", 0, 31), ("float", cp.capi.FLAG_FLOATING_POINT_STEP, 31), ("fixed, another seed", 0, 32)):
+        engine.begin(cp.ALG_SMC, model, obs, n, seed=seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=0.5, flags=flags)
+        engine.run()
+        s = engine.summary()
+        out[name] = (engine.stats().copy(), s["log_evidence"], s["step_form"], s["n_resampled"])
+    assert out["fixed"][2] == cp.capi.FORM_FIXED and out["float"][2] == cp.capi.FORM_FLOAT and out["fixed"][3] == out["float"][3] > 0
+    d_forms = float(np.abs(out["fixed"][0] - out["float"][0]).max())
+    d_seeds = float(np.abs(out["fixed"][0] - out["fixed, another seed"][0]).max())
+    z_forms, z_seeds = abs(out["fixed"][1] - out["float"][1]), abs(out["fixed"][1] - out["fixed, another seed"][1])
+    assert d_forms <= 2.0 * d_seeds + 1e-3 and z_forms <= 2.0 * z_seeds + 2e-3, (d_forms, d_seeds, z_forms, z_seeds)
+    for name in out:
+        assert float(np.abs(out[name][0] - exact).max()) < tol, name
+        assert float(np.abs(out[name][0] - exact)[-10:].max()) < tol / 3, name       # the last ten hits: hardly any path degeneracy
+    print("%s: max |fixed - float| %.2e (two seeds of the fixed form: %.2e), log evidence %.2e (%.2e)" % (workload, d_forms, d_seeds, z_forms, z_seeds))
+
+
 def test_smc_hmm16_config3_vs_forward_backward(engine, golden_dir):
     """BASELINE.json configs[2]: hmm<16>, systematic resampling every step, 10^6 particles."""
     z = np.load(os.path.join(golden_dir, "observations.npz"))
