@@ -34,8 +34,8 @@ def counters(d):
 pmc = {"_comment": "rocprofv3 --pmc, one counter set per run (tools/profile_round.sh).  hbm_bytes_per_launch_corrected = 2 x FETCH_SIZE KB x 1024 + "
                    "WRITE_SIZE KB x 1024 (MI355X_MICROARCH.md: FETCH_SIZE counts 64-byte requests in units that read half on gfx950; WRITE_SIZE in KB).  "
                    "Per-wave issue counters are SQ sums over the chip divided by the launch's wavefronts (workgroups x 4).", "workloads": {}}
-ALGO = {"hmm16_smc": 56, "lgssm100_smc": 72, "hmm128_smc_ess": 56}
-for wl, n in (("hmm16_smc", 1000000), ("lgssm100_smc", 1250000)):
+ALGO = {"hmm16_smc": 56, "lgssm100_smc": 72, "hmm128_smc_ess": 56, "gaussian_sis": 16}
+for wl, n in (("hmm16_smc", 1000000), ("hmm16_smc", 10000000), ("lgssm100_smc", 1250000), ("lgssm100_smc", 10000000), ("hmm128_smc_ess", 12500000)):
     fe, wr, sq = counters("%s_pmc_%s_%d_FETCH_SIZE" % (src_tag, wl, n)), counters("%s_pmc_%s_%d_WRITE_SIZE" % (src_tag, wl, n)), counters("%s_pmc_%s_%d_SQ_WAVE_CYCLES" % (src_tag, wl, n))
     rec = {}
     for k in fe:
@@ -57,7 +57,7 @@ for wl, n in (("hmm16_smc", 1000000), ("lgssm100_smc", 1250000)):
 json.dump(pmc, open("profiles/%s_pmc_traffic.json" % out_tag, "w"), indent=1)
 
 notes = []
-for wl, n in (("hmm16_smc", 1000000), ("lgssm100_smc", 1250000), ("lgssm100_smc", 10000000), ("hmm128_smc_ess", 12500000)):
+for wl, n in (("hmm16_smc", 1000000), ("hmm16_smc", 10000000), ("lgssm100_smc", 1250000), ("lgssm100_smc", 10000000), ("hmm128_smc_ess", 12500000), ("gaussian_sis", 10000000)):
     d = "%s_prof_%s_%d" % (src_tag, wl, n)
     ks, tr = newest("%s/%s/*/*kernel_stats.csv" % (G, d)), newest("%s/%s/*/*kernel_trace.csv" % (G, d))
     if not ks:
@@ -73,7 +73,7 @@ for wl, n in (("hmm16_smc", 1000000), ("lgssm100_smc", 1250000), ("lgssm100_smc"
         # (the step launches of THIS population: bench.py's launch-floor run -- 4096 particles, four workgroups -- is in the same trace)
         full_grid = ((n + 1023) // 1024) * 256
         durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr))
-                if "smc_step" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == full_grid]
+                if ("smc_step" in r["Kernel_Name"] or (wl == "gaussian_sis" and "sis_" in r["Kernel_Name"] and "finish" not in r["Kernel_Name"])) and (wl == "gaussian_sis" or int(r["Grid_Size_X"]) == full_grid)]
         if durs:
             import statistics
             srt = sorted(durs)
@@ -82,7 +82,7 @@ for wl, n in (("hmm16_smc", 1000000), ("lgssm100_smc", 1250000), ("lgssm100_smc"
             thr = (lo + hi) / 2
             a, b = [x for x in durs if x < thr], [x for x in durs if x >= thr]
             by = ALGO[wl]
-            light = {"hmm16_smc": 24, "hmm128_smc_ess": 24, "lgssm100_smc": 32}[wl]
+            light = {"hmm16_smc": 24, "hmm128_smc_ess": 24, "lgssm100_smc": 32, "gaussian_sis": 16}[wl]
             md += "\nStep launches in the kernel trace: %d, average %.2f us.  " % (len(durs), sum(durs) / len(durs))
             if a and b and hi > 1.3 * lo:
                 md += "Launches that resample (>= %.1f us): %d, average %.2f us = %d B x %d / %.2f us = %.0f GB/s = **%.2f** of 8 TB/s; launches that do not (step 0, steps behind a generation that kept its weights): %d, average %.2f us = %d B x %d / that = %.0f GB/s = %.2f.\n" % (
@@ -104,10 +104,36 @@ if os.path.exists(bp):
     rec = pmc["workloads"].get("hmm16_smc@1000000", {}).get("step_kernel")
     if rec:
         b["roofline"]["traffic"] = rec["hbm_bytes_per_launch_corrected"]
-        b["roofline"]["traffic_source"] = "profiles/%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)" % out_tag
+        b["roofline"]["traffic_measured_in"] = "profiles/%s_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command in the SAME gpurun call, gfx950-corrected)" % out_tag
         b["roofline"]["hbm_frac_measured"] = rec["hbm_bytes_per_launch_corrected"] / (b["roofline"]["avg_launch_us"] * 1e-6) / 1e9 / 8000.0
         b["roofline"]["valu_issue_frac"] = rec.get("valu_issue_frac"); b["roofline"]["wait_frac"] = rec.get("wait_frac")
     json.dump(b, open("profiles/%s_bench_n1.json" % out_tag, "w"))
+
+for form in (1, 0):
+    d = "%s_generic_form%d" % (src_tag, form)
+    ks = newest("%s/%s/*kernel_stats.csv" % (G, d)) or newest("%s/%s/*/*kernel_stats.csv" % (G, d))
+    tr = newest("%s/%s/*kernel_trace.csv" % (G, d)) or newest("%s/%s/*/*kernel_trace.csv" % (G, d))
+    if not ks:
+        continue
+    rows = list(csv.DictReader(open(ks)))
+    gmd = "# rocprofv3 --kernel-trace --stats -- cpprob_main --generic --model hmm16 --smc --n_samples 1000000 --repeat 8 --step_form %d (MI355X, %s; tools/profile_generic.sh)\n\n" % (form, out_tag)
+    gmd += "step form %d = %s.  Eight cpprob::inference calls + the Markov pilot (8192 particles, both replay forms) in one process.\n\n" % (form, "the resampling inside the model's launch (model_step_kernel)" if form else "model launch + three bookkeeping launches (the r03 form)")
+    gmd += "| kernel | calls | total us | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n"
+    for r in rows[:10]:
+        gmd += "| `%s` | %s | %.1f | %.2f | %.2f | %.2f | %s |\n" % (r["Name"][:120], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"])
+    if tr:
+        mk = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in csv.DictReader(open(tr)) if "model_" in r["Kernel_Name"])
+        last = [x for _, x in mk[-16:]]
+        gmd += "\nThe last call's 16 model launches, t = 0 .. 15 (us): %s -- sum %.1f us; launch t runs t dead iterations of the model's own loop before the live one.\n" % (" ".join("%.1f" % x for x in last), sum(last))
+    up = "%s/%s/unprofiled.json" % (G, d)
+    if os.path.exists(up) and os.path.getsize(up):
+        try:
+            u = json.loads(open(up).read().strip())
+            gmd += "\nThe same command un-profiled, same gpurun call: %.4f ms per run (the last call's device work, read-out included).\n" % (u["run_seconds"] * 1e3)
+        except Exception:
+            pass
+    open("profiles/%s_generic_hmm16_form%d_kernel_stats.md" % (out_tag, form), "w").write(gmd)
+    notes.append("profiles/%s_generic_hmm16_form%d_kernel_stats.md" % (out_tag, form))
 
 md = "# The two 8-GPU configs (and the headline shape x 8) whole, eight loopback ranks on ONE MI355X (%s)\n\n" % out_tag
 md += "`python bench.py --workload W --particles N --loopback-ranks 8` -- the library's multi-GPU driver with every rank's context on this GPU and one stream: the whole exchange protocol, program order instead of collectives, so a run is the SUM of the eight ranks' steps.\n\n"
