@@ -1552,6 +1552,10 @@ struct SmoothArgs {
 
 template <class Model> struct SmoothArgs;
 struct RemoteStores;
+#ifndef CPPROB_SMOOTH_TILES
+#define CPPROB_SMOOTH_TILES 2
+#endif
+constexpr int kSmoothTiles = CPPROB_SMOOTH_TILES;      // tiles a workgroup of the lineage walk follows at a time
 template <class Model, class WeightOf>
 __device__ __forceinline__ void smooth_body_remote(const SmoothArgs<Model>& a, double* s_stat, WeightOf weight_of, const RemoteStores* __restrict__ rem);
 
@@ -1578,13 +1582,21 @@ __device__ __forceinline__ void smooth_body(const SmoothArgs<Model>& a, double* 
     __syncthreads();
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     // (one XCD's workgroups walk neighbouring tiles: their lineages converge on the same ancestor rows)
-    for (int64_t tile = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int32_t idx[kPPT]; double w[kPPT];
+    // Two tiles at a time (kSmoothTiles): eight lineages a lane -- a hop is a dependent gather, and what the walk is short of is loads
+    // in flight (wait_frac 0.6-0.8 at four a lane: profiles/r04_pmc_traffic.json), not registers; the per-hop wavefront reduction is
+    // shared by both tiles.
+    auto walk = [&](auto tiles_tag) {
+    constexpr int NT = decltype(tiles_tag)::value;
+    for (int64_t tile0 = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile0 < ntiles; tile0 += (int64_t)NT * gridDim.x) {
+        constexpr int L = NT * kPPT;
+        int32_t idx[L]; double w[L];
 #pragma unroll
-        for (int k = 0; k < kPPT; ++k) {
-            const int64_t i = tile * kTile + (int64_t)k * kThreads + tid;   // lane-strided: coalesced first touch
-            idx[k] = (int32_t)i;
-            w[k] = weight_of(tile, i);
+        for (int k = 0; k < L; ++k) {
+            const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
+            const int64_t i = tile * kTile + (int64_t)(k % kPPT) * kThreads + tid;   // lane-strided: coalesced first touch
+            const bool on = tile < ntiles;
+            idx[k] = on ? (int32_t)i : 0;
+            w[k] = on ? weight_of(tile, i) : 0.0;
         }
         for (int t = a.T - 1; t >= 0; --t) {
             double acc[K];
@@ -1592,10 +1604,11 @@ __device__ __forceinline__ void smooth_body(const SmoothArgs<Model>& a, double* 
             for (int j = 0; j < K; ++j) acc[j] = 0.0;
             const typename Model::store_t* row = a.values + (int64_t)t * a.rs;
 #pragma unroll
-            for (int k = 0; k < kPPT; ++k) {
+            for (int k = 0; k < L; ++k) {
                 const V x = static_cast<V>(row[idx[k]]);
                 Model::accumulate(x, w[k], acc);
-                if (a.paths) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)k * kThreads + tid] = x;
+                const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
+                if (a.paths && tile < ntiles) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)(k % kPPT) * kThreads + tid] = x;
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) acc[j] = wave_sum(acc[j]);
@@ -1606,10 +1619,15 @@ __device__ __forceinline__ void smooth_body(const SmoothArgs<Model>& a, double* 
             if (t > 0 && !a.identity && a.resampled[t - 1]) {
                 const int32_t* arow = a.anc + (int64_t)t * a.rs;
 #pragma unroll
-                for (int k = 0; k < kPPT; ++k) idx[k] = arow[idx[k]];
+                for (int k = 0; k < L; ++k) idx[k] = arow[idx[k]];
             }
         }
     }
+    };
+    // (pairs where a workgroup has several tiles to follow and a hop moves little -- one-byte states: measured on hmm<128> at
+    //  1.25e7 particles 1.73 -> 1.40 ms; 8-byte values are bound by the bytes they gather: linear_gaussian_1d<100> at 1e7 1.14 -> 1.32 ms)
+    if (kSmoothTiles > 1 && sizeof(typename Model::store_t) == 1 && ntiles > (int64_t)gridDim.x) walk(std::integral_constant<int, kSmoothTiles>{});
+    else walk(std::integral_constant<int, 1>{});
     __syncthreads();
     for (int i = tid; i < TK; i += kThreads) {
         double s = 0.0;
@@ -1631,14 +1649,19 @@ __device__ __forceinline__ void smooth_body_remote(const SmoothArgs<Model>& a, d
     __syncthreads();
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     const int me = rem->rank;
-    // (smooth_body's tile order: the workgroups' partial sums are then the very same numbers whichever way the lineages travelled)
-    for (int64_t tile = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int32_t idx[kPPT], rk[kPPT]; double w[kPPT];
+    // (smooth_body's tile order and pairing: the workgroups' partial sums are then the very same numbers whichever way the lineages travelled)
+    auto walk = [&](auto tiles_tag) {
+    constexpr int NT = decltype(tiles_tag)::value;
+    for (int64_t tile0 = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile0 < ntiles; tile0 += (int64_t)NT * gridDim.x) {
+        constexpr int L = NT * kPPT;
+        int32_t idx[L], rk[L]; double w[L];
 #pragma unroll
-        for (int k = 0; k < kPPT; ++k) {
-            const int64_t i = tile * kTile + (int64_t)k * kThreads + tid;
-            idx[k] = (int32_t)i; rk[k] = me;
-            w[k] = weight_of(tile, i);
+        for (int k = 0; k < L; ++k) {
+            const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
+            const int64_t i = tile * kTile + (int64_t)(k % kPPT) * kThreads + tid;
+            const bool on = tile < ntiles;
+            idx[k] = on ? (int32_t)i : 0; rk[k] = me;
+            w[k] = on ? weight_of(tile, i) : 0.0;
         }
         for (int t = a.T - 1; t >= 0; --t) {
             double acc[K];
@@ -1646,7 +1669,7 @@ __device__ __forceinline__ void smooth_body_remote(const SmoothArgs<Model>& a, d
             for (int j = 0; j < K; ++j) acc[j] = 0.0;
             const bool hop = t > 0 && !a.identity && a.resampled[t - 1];
 #pragma unroll
-            for (int k = 0; k < kPPT; ++k) {
+            for (int k = 0; k < L; ++k) {
                 const int r = rk[k];
                 // (nearly every hop stays on this rank -- O(sqrt N) lineages ever cross: its store comes from the launch's own arguments,
                 //  not through the table of the ranks' stores, which would put a second dependent load on every hop)
@@ -1657,7 +1680,8 @@ __device__ __forceinline__ void smooth_body_remote(const SmoothArgs<Model>& a, d
                 const int64_t at = (int64_t)t * rs_r + idx[k];
                 const V x = static_cast<V>(vals[at]);
                 Model::accumulate(x, w[k], acc);
-                if (a.paths) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)k * kThreads + tid] = x;
+                const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
+                if (a.paths && tile < ntiles) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)(k % kPPT) * kThreads + tid] = x;
                 if (hop) {
                     // (a run whose transport overflowed is repeated, but its read-out still runs: whatever the tables hold then, the
                     //  walk stays inside the stores)
@@ -1677,6 +1701,9 @@ __device__ __forceinline__ void smooth_body_remote(const SmoothArgs<Model>& a, d
             }
         }
     }
+    };
+    if (kSmoothTiles > 1 && sizeof(typename Model::store_t) == 1 && ntiles > (int64_t)gridDim.x) walk(std::integral_constant<int, kSmoothTiles>{});
+    else walk(std::integral_constant<int, 1>{});
     __syncthreads();
     for (int i = tid; i < TK; i += kThreads) {
         double s = 0.0;
