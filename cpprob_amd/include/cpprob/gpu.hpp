@@ -76,6 +76,7 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
 {
     // (what the statements may take for granted in this kernel: they read the launch's mode from the kernel-argument segment)
     { const uint32_t fused = device::launch_args()->fused, lanes = device::launch_args()->lane_block; __builtin_assume(fused == 0u); __builtin_assume(lanes == (uint32_t)device::kLaneBlock); }
+    { const int32_t world = device::launch_args()->sh.world; __builtin_assume(world == 0); }
     const int64_t i = (int64_t)blockIdx.x * device::kLaneBlock + threadIdx.x;
     if (i >= a.n) return;
     const bool resampled = a.resampled_prev && *a.resampled_prev != 0;
@@ -93,13 +94,14 @@ __global__ __launch_bounds__(device::kLaneBlock) void model_kernel(ModelKernelAr
 // Two builds of it: FULL asks the compiler for eight wavefronts a SIMD (64 registers: 2048 workgroups resident, two passes of 3907 at
 // 10^6 particles instead of three) and is used when that costs a few spilled registers; models whose body needs more (fp64 Box-Muller:
 // ~90) run the build that takes what it needs (the host asks the runtime which is which: step_kernel_full).
-template <class Caller, class Tuple, bool FULL>
+// ... and a third for a shard of a joint population (JOINT: the statements' and the prologue's sharded branches exist only there).
+template <class Caller, class Tuple, bool JOINT>
 __device__ __forceinline__ void model_step_body(const Tuple* __restrict__ observes);
 template <class Caller, class Tuple>
 __global__ __launch_bounds__(device::kStepBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void model_step_kernel_full(ModelKernelArgs a, const Tuple* __restrict__ observes)
 {
     (void)a;
-    model_step_body<Caller, Tuple, true>(observes);
+    model_step_body<Caller, Tuple, false>(observes);
 }
 template <class Caller, class Tuple>
 __global__ __launch_bounds__(device::kStepBlock) void model_step_kernel(ModelKernelArgs a, const Tuple* __restrict__ observes)
@@ -107,12 +109,20 @@ __global__ __launch_bounds__(device::kStepBlock) void model_step_kernel(ModelKer
     (void)a;                                                      // (the statements read it where it lies: the kernel-argument segment)
     model_step_body<Caller, Tuple, false>(observes);
 }
-template <class Caller, class Tuple, bool FULL>
+template <class Caller, class Tuple>
+__global__ __launch_bounds__(device::kStepBlock) void model_step_kernel_joint(ModelKernelArgs a, const Tuple* __restrict__ observes)
+{
+    (void)a;
+    model_step_body<Caller, Tuple, true>(observes);
+}
+template <class Caller, class Tuple, bool JOINT>
 __device__ __forceinline__ void model_step_body(const Tuple* __restrict__ observes)
 {
     {
         const uint32_t fused = device::launch_args()->fused, win = device::launch_args()->windowed, lanes = device::launch_args()->lane_block;
         __builtin_assume(fused == 1u); __builtin_assume(win == 1u); __builtin_assume(lanes == (uint32_t)device::kStepBlock);
+        const int32_t world = device::launch_args()->sh.world;
+        if (JOINT) __builtin_assume(world > 0); else __builtin_assume(world == 0);
     }
     device::step_prologue();
     Caller::call(*observes);
@@ -722,7 +732,6 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
     for (int r = 0; r <= world; ++r) a.sh.first[r] = sh.begin[(size_t)r];
     const dim3 sgrid((unsigned)((n + device::kStepBlock - 1) / device::kStepBlock)), sblock(device::kStepBlock);
     const size_t step_lds = device::lane_lds_bytes(device::kStepBlock, true);
-    const bool step_full = step_kernel_full<Caller, Tuple>();
     std::array<std::uint64_t, 3> h_tot{};
     auto gather_totals = [&](int t) -> std::array<std::vector<std::uint64_t>, 3> {
         ctx.check(cpprob_hip_generic_totals(ctx.get(), t, n, d_tot), "cpprob_hip_generic_totals");
@@ -758,8 +767,7 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
         a.sh.resample = resample ? 1 : 0;
         const double ref_t = exact ? 0.0 : ((t == 0 || resample) ? a.fs.bound : M_prev + a.fs.bound);
         a.sh.ref = ref_t;
-        if (step_full) hipLaunchKernelGGL((model_step_kernel_full<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
-        else hipLaunchKernelGGL((model_step_kernel<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+        hipLaunchKernelGGL((model_step_kernel_joint<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
         hip_check(hipGetLastError(), "model_step_kernel");
         double ref_gen = ref_t;
         if (exact) {
