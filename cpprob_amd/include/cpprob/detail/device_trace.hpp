@@ -59,12 +59,16 @@ struct FusedStep {
 // in the hierarchy and the weights of whichever rank owns them and their windows are read from that rank's store through its mapping
 // (peer access between the GPUs of a process; plain pointers when several ranks share one GPU) -- the migration is a PULL by the
 // receiving rank's step launch: no packing launch on the sender, no remote writes.  The 24 bytes a rank contributes to a generation's
-// totals travel through the host between two launches (an all-gather among the ranks' host threads), which therefore takes the
-// decision and hands it to the next launch ready-made.
+// totals are pulled the same way: a one-wavefront launch behind every step leaves them in the rank's memory and the next step's first
+// wavefront reads every rank's (lane r = rank r: the all-gather is three loads a lane) and takes the generation's decision as a
+// single device's prologue does.  What orders a rank's step t + 1 behind every rank's step t is a stream wait on the peers' events.
+// In the exact-maximum form a pass over the log-weights lies between two launches anyway: there the ranks' host threads combine the
+// numbers and hand the decision to the launch ready-made (ShardArgs::host_decided).
 constexpr int kMaxShards = 16;
 constexpr int kShardIndexBits = 26;                                    // an ancestor's code: rank << 26 | slot on that rank (shards up to 6.7e7 particles)
 struct ShardPeer {                                                     // rank r's generation t-1 as every rank addresses it
     cph::FHier f; const uint32_t* q; const uint64_t* carry; int64_t n; int32_t nb, pad;
+    const uint64_t* totals;                                            // {mass, squares, key of the maximum} of that rank's generation t-1 (cpprob_hip_generic_totals)
 };
 struct ShardArgs {
     int32_t world, rank;                                               // world = 0: a population of its own
@@ -72,8 +76,9 @@ struct ShardArgs {
     double obound[kMaxShards + 1];                                     // o_r = first output owned by rank r's sources (o_world = N): G(mass before rank r)
     uint64_t before[kMaxShards];                                       // mass of the ranks before r
     uint64_t first[kMaxShards + 1];                                    // global id of rank r's first particle
-    double inv, ref; int32_t resample, pad;                            // generation t-1's decision and generation t's reference, taken on the host
-};
+    double inv, ref; int32_t resample;                                 // generation t-1's decision and generation t's reference, where the host took them
+    int32_t host_decided;                                              // 1: obound / before / inv / ref / resample above are valid (exact-maximum form); 0: the launch
+};                                                                     //    derives them from the ranks' totals itself (ShardPeer::totals): no host round trip between two steps
 
 // What every statement of a launch reads and none writes: the kernel's first argument.  A statement fetches the fields it needs
 // straight from the kernel-argument segment (scalar loads into scalar registers, wherever in the call tree it sits), so they cost
@@ -264,6 +269,8 @@ struct StepLds {
     int32_t iscr[kStepWaves];
     uint64_t red[3 * kStepWaves];
     StepFound found;
+    // a joint population's decision for this step (from the ranks' totals, or copied from the launch's arguments)
+    double obound[kMaxShards + 1]; uint64_t before[kMaxShards]; double j_inv, j_ref; int j_resample;
 };
 __device__ __forceinline__ StepLds& step_lds()
 {
@@ -448,13 +455,13 @@ __device__ __forceinline__ int32_t step_resample_joint(const StepFetched& pf, St
     const int n_out = rem < kStepBlock ? (int)rem : kStepBlock;
     const double g0 = (double)(A->sh.first[rank] + (uint64_t)bid * kStepBlock), g_end = g0 + (double)n_out;
     FixedCdf fc;
-    fc.u0 = A->fs.u0; fc.n_pop = A->fs.n_pop; fc.inv = A->sh.inv; fc.base = 0;
+    fc.u0 = A->fs.u0; fc.n_pop = A->fs.n_pop; fc.inv = L.j_inv; fc.base = 0;
     for (int r = 0; r < world; ++r) {
-        const double o_lo = A->sh.obound[r], o_hi = A->sh.obound[r + 1];
+        const double o_lo = L.obound[r], o_hi = L.obound[r + 1];
         if (o_hi <= g0 || o_lo >= g_end || o_hi <= o_lo) continue;     // (uniform) none of these outputs descends from rank r
         const ShardPeer* pr = A->sh.peers + r;
         const double lo = fmax(g0, o_lo), hi_last = fmin(g_end, o_hi) - 1.0;
-        fc.base = A->sh.before[r];
+        fc.base = L.before[r];
         const int nb_r = pr->nb;
         // the first output's ancestor is expected where the output itself sits in the population (equal shards: the same block of rank r)
         const double at = lo - (double)A->sh.first[r];
@@ -504,7 +511,45 @@ __device__ __forceinline__ void step_prologue()
     if (joint) anc |= A->sh.rank << kShardIndexBits;                   // (an ancestor's code names its rank)
     if (t > 0 && joint) {
         L.slot[tid] = -1;
-        resample = A->sh.resample != 0;
+        if (wv == 0) {
+            const int world = A->sh.world, lane = tid;
+            if (A->sh.host_decided) {
+                if (lane <= world) L.obound[lane] = A->sh.obound[lane];
+                if (lane < world) L.before[lane] = A->sh.before[lane];
+                if (lane == 0) { L.j_inv = A->sh.inv; L.j_ref = A->sh.ref; L.j_resample = A->sh.resample; }
+            } else {
+                // the generation's totals: every rank's 24 bytes, read where they lie (lane r = rank r)
+                uint64_t s_r = 0, q_r = 0, m_r = 0;
+                if (lane < world) { const uint64_t* tp = A->sh.peers[lane].totals; s_r = tp[0]; q_r = tp[1]; m_r = tp[2]; }
+                const uint64_t incl = wave_incl_scan_u64(s_r);
+                const uint64_t S = read_lane_u64(incl, 63), Q = wave_sum_u64(q_r);
+                const double M = dkey_inv(wave_max_u64(m_r));
+                const FixedDecision d = fixed_decide(S, Q, A->fs.n_pop, A->fs.ess_frac, true);
+                const double r_t = fixed_reference(d.resample, M, A->fs.bound);
+                FixedCdf fc;
+                fc.u0 = A->fs.u0; fc.n_pop = A->fs.n_pop; fc.inv = d.inv; fc.base = 0;
+                if (lane < world) { L.before[lane] = incl - s_r; L.obound[lane] = lane == 0 ? 0.0 : fc.g(incl - s_r); }
+                if (lane == world) L.obound[lane] = A->fs.n_pop;
+                if (lane == 0) { L.j_inv = d.inv; L.j_ref = r_t; L.j_resample = d.resample ? 1 : 0; }
+                if (bid == 0 && lane == 0) {
+                    // every rank keeps the run's books (the same numbers on each: they come from the same totals)
+                    StepCtrl2* c = A->fs.ctrl;
+                    const double ref_prev = c->ref_cur;
+                    const double gap = d.W > 0.0 ? ref_prev - M : 1e300;
+                    c->gap_max = t == 1 ? gap : fmax(c->gap_max, gap);
+                    if (gap < 0.0) *A->overflow = 4;
+                    else if (gap > A->fs.gap_limit && *A->overflow == 0) *A->overflow = 5;
+                    A->fs.ess[t - 1] = d.ess;
+                    A->fs.resampled[t - 1] = d.resample ? 1 : 0;
+                    double lz = t == 1 ? 0.0 : *A->fs.log_z;
+                    if (d.resample) lz += ref_prev + log(d.W / A->fs.n_pop);
+                    *A->fs.log_z = lz;
+                    c->ref_cur = r_t;
+                }
+            }
+        }
+        __syncthreads();
+        resample = L.j_resample != 0;
         if (resample) {
             anc = step_resample_joint(pf, L);
             lw_carry = 0.0;
@@ -560,7 +605,7 @@ __device__ __forceinline__ void step_prologue()
             lw_carry = 0.0;                                            // equal weights after resampling
             if ((int64_t)bid * kStepBlock + tid < n) A->fs.anc_row[i] = anc;
         }
-    } else if (bid == 0 && tid == 0 && !A->fs.exact_ref && !joint) {
+    } else if (bid == 0 && tid == 0 && !A->fs.exact_ref && !(joint && A->sh.host_decided)) {
         A->fs.ctrl->ref_cur = A->fs.bound;                             // R_0 = B_0
     }
     begin_lane(anc, 0u, lw_carry);
@@ -585,7 +630,7 @@ __device__ __forceinline__ void step_epilogue()
         if (valid) A->logw_out[i_raw] = lw;
         return;
     }
-    const double ref = t == 0 ? A->fs.bound : (A->sh.world ? A->sh.ref : L.found.ref);
+    const double ref = t == 0 ? A->fs.bound : (A->sh.world ? L.j_ref : L.found.ref);
     const uint32_t q = fix_weight(lw, ref);
     const uint64_t s_w = wave_sum_q(q), q_w = wave_sum_q((q >> 16) * (q >> 16)), m_w = wave_max_key(dkey(lw));
     if (lane == 0) { L.red[wv] = s_w; L.red[kStepWaves + wv] = q_w; L.red[2 * kStepWaves + wv] = m_w; }

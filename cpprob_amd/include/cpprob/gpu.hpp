@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -583,14 +584,18 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
 // integers as one GPU holding every particle (the masses are exact, the comb is evaluated on exact integers: cpprob/detail/
 // fixed_mass.hpp), so the traces are the single-device run's, bit for bit.  One host thread per rank.  Per step and rank: the step
 // launch (its prologue PULLS: it searches the hierarchy and walks the weights of whichever rank owns an output's ancestor and reads
-// the ancestor's window from that rank's store -- peer access / one address space; nothing is packed or sent), a one-wavefront launch
-// that sums the rank's {mass, squares, maximum} and 24 bytes to the host; the ranks' threads all-gather them (a barrier), and each
-// takes the generation's decision -- ESS, resample or not, the comb's scale, the ranks' offspring bounds, the next reference, the
-// evidence -- with the arithmetic the device uses on one GPU (IEEE fma / ceil on exact integers: the same bits).  What this costs is a
-// host round trip per step (the hand-fused models' group driver keeps its collectives on the device: csrc/group.hpp); what it buys
-// is the joint estimator for ANY registered model, with no code of the model's own.
+// the ancestor's window from that rank's store -- peer access / one address space; nothing is packed or sent) and a one-wavefront launch
+// that leaves the rank's {mass, squares, maximum} in its memory.  The NEXT step's first wavefront reads all ranks' 24 bytes and takes
+// the generation's decision -- ESS, resample or not, the comb's scale, the ranks' offspring bounds, the next reference, the evidence --
+// exactly as one GPU's prologue does; the launch is ordered behind every rank's previous step by stream waits on the peers' events
+// (two events a rank; the threads only poll one another's enqueue counters).  Nothing returns to the host between two steps.  Where a
+// model's likelihood has no bound (exact-maximum form) the reference needs a pass between two launches: there the ranks' threads
+// all-gather maxima and totals through the host (two round trips a step) and take the decision with the device's arithmetic (IEEE fma /
+// ceil on exact integers: the same bits).  What this buys is the joint estimator for ANY registered model, with no code of the
+// model's own.
 struct JointBarrier {
     std::mutex mu; std::condition_variable cv; int world, waiting = 0; unsigned long long generation = 0; bool broken = false;
+    std::atomic<bool> failed{false};                                   // (what a thread polling a peer's progress looks at)
     explicit JointBarrier(int w) : world(w) {}
     void wait()
     {
@@ -601,11 +606,14 @@ struct JointBarrier {
         cv.wait(lock, [&] { return generation != g || broken; });
         if (broken) throw std::runtime_error("another rank of the joint population failed");
     }
-    void fail() { std::lock_guard<std::mutex> lock(mu); broken = true; cv.notify_all(); }
+    void fail() { failed.store(true); std::lock_guard<std::mutex> lock(mu); broken = true; cv.notify_all(); }
 };
 struct JointRankPointers {
     cpprob_hip_generic_layout lay{}; const uint64_t* carry[2] = {nullptr, nullptr};
     const int32_t* anc_all = nullptr; const double* real_gen = nullptr; const int32_t* int_gen = nullptr; std::size_t n = 0;
+    const uint64_t* totals = nullptr;                                  // two generations' {mass, squares, key of the maximum}: 3 words by the step's parity
+    hipEvent_t stepped[2] = {nullptr, nullptr};                        // by the step's parity: the rank's step launch + totals launch have completed
+    std::atomic<int> recorded{0};                                      // steps whose event the rank's thread has recorded
 };
 struct JointShared {
     int world; std::size_t n_total; std::vector<std::size_t> begin;
@@ -678,10 +686,12 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
     double *d_real = nullptr, *d_logw0 = nullptr, *d_logw1 = nullptr, *d_real_gen = nullptr;
     int32_t *d_int = nullptr, *d_anc_all = nullptr, *d_int_gen = nullptr, *d_res = nullptr, *d_flag = nullptr, *d_hit_real = nullptr, *d_hit_int = nullptr;
     uint64_t *d_c0 = nullptr, *d_c1 = nullptr, *d_tot = nullptr;
+    double* d_book = nullptr;                                          // the launches' own books (device-decided form): T x ESS, the evidence
     device::ShardPeer* d_peers = nullptr;
     JointStore* d_stores = nullptr;
     Carver carve;
-    carve.add(&d_obs, 1); carve.add(&d_res, (size_t)T + 1); carve.add(&d_flag, 1); carve.add(&d_tot, 4);
+    carve.add(&d_obs, 1); carve.add(&d_res, (size_t)T + 1); carve.add(&d_flag, 1); carve.add(&d_tot, 8);
+    carve.add(&d_book, (size_t)T + 1);
     carve.add(&d_real, n_real * n); carve.add(&d_logw0, n); carve.add(&d_logw1, n); carve.add(&d_int, n_int * n);
     carve.add(&d_c0, (size_t)w * n); carve.add(&d_c1, (size_t)w * n); carve.add(&d_anc_all, (size_t)T * n);
     carve.add(&d_real_gen, n_real * n); carve.add(&d_int_gen, n_int * n);
@@ -697,7 +707,10 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
     {
         JointRankPointers& me = sh.ptrs[(std::size_t)rank];
         me.lay = lay; me.carry[0] = d_c0; me.carry[1] = d_c1; me.anc_all = d_anc_all; me.real_gen = d_real_gen; me.int_gen = d_int_gen; me.n = n;
+        me.totals = d_tot; me.recorded.store(0);
+        for (int k = 0; k < 2; ++k) hip_check(hipEventCreateWithFlags(&me.stepped[k], hipEventDisableTiming), "hipEventCreateWithFlags");
     }
+    struct EventGuard { hipEvent_t* e; ~EventGuard() { for (int k = 0; k < 2; ++k) if (e[k]) (void)hipEventDestroy(e[k]); } } event_guard{sh.ptrs[(std::size_t)rank].stepped};
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
     sh.bar.wait();                                                     // every rank's buffers exist
     // the ranks' stores as this rank's launches address them: step t reads hierarchy copy (t + 2) % 3, weights q[(t + 1) & 1] and
@@ -709,6 +722,7 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
             const JointRankPointers& p = sh.ptrs[(size_t)r];
             device::ShardPeer& e = peers[(size_t)k * world + r];
             e.f = fused_view(p.lay, (k + 2) % 3, k % 3, (k + 1) % 3); e.q = p.lay.q[(k + 1) & 1]; e.carry = p.carry[k & 1]; e.n = (int64_t)p.n; e.nb = p.lay.blocks; e.pad = 0;
+            e.totals = p.totals + 4 * ((k + 1) & 1);                    // step t reads generation t-1's
         }
     for (int r = 0; r < world; ++r) { const JointRankPointers& p = sh.ptrs[(size_t)r]; stores[(size_t)r] = JointStore{p.anc_all, p.real_gen, p.int_gen, (int64_t)p.n}; }
     hip_check(hipMemcpyAsync(d_peers, peers.data(), peers.size() * sizeof(device::ShardPeer), hipMemcpyHostToDevice, stream), "copy the peer tables");
@@ -734,8 +748,8 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
     const size_t step_lds = device::lane_lds_bytes(device::kStepBlock, true);
     std::array<std::uint64_t, 3> h_tot{};
     auto gather_totals = [&](int t) -> std::array<std::vector<std::uint64_t>, 3> {
-        ctx.check(cpprob_hip_generic_totals(ctx.get(), t, n, d_tot), "cpprob_hip_generic_totals");
-        hip_check(hipMemcpyAsync(h_tot.data(), d_tot, 3 * sizeof(std::uint64_t), hipMemcpyDeviceToHost, stream), "copy the shard's totals");
+        ctx.check(cpprob_hip_generic_totals(ctx.get(), t, n, d_tot + 4 * (t & 1)), "cpprob_hip_generic_totals");
+        hip_check(hipMemcpyAsync(h_tot.data(), d_tot + 4 * (t & 1), 3 * sizeof(std::uint64_t), hipMemcpyDeviceToHost, stream), "copy the shard's totals");
         hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
         sh.totals[t & 1][(size_t)rank] = h_tot;
         sh.bar.wait();                                                // the generation's all-gather; every rank's step t is complete behind it
@@ -743,13 +757,27 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
         for (int k = 0; k < 3; ++k) { all[(size_t)k].resize((size_t)world); for (int r = 0; r < world; ++r) all[(size_t)k][(size_t)r] = sh.totals[t & 1][(size_t)r][(size_t)k]; }
         return all;
     };
-    // generation t-1's decision (taken identically by every rank's thread) and the run's bookkeeping
+    // generation t-1's decision (taken identically by every rank) and the run's bookkeeping
     std::vector<double> ess((size_t)T, 0.0);
     std::vector<int32_t> resd((size_t)T + 1, 0);
     double lz = 0.0, ref_prev = 0.0, gap_max = 0.0;
     int flag = 0;
     bool resample = false;
     double M_prev = 0.0;
+    a.sh.host_decided = exact ? 1 : 0;
+    a.fs.ctrl = static_cast<device::StepCtrl2*>(lay.ctrl); a.fs.ess = d_book; a.fs.log_z = d_book + T; a.fs.resampled = d_res;
+    if (!exact) hip_check(hipMemsetAsync(d_res, 0, ((size_t)T + 1) * sizeof(int32_t), stream), "hipMemsetAsync");
+    // one generation's totals summed on the host, and what follows from them (the device's arithmetic: fixed_decide)
+    struct Totals { std::uint64_t S = 0, Q = 0; double M = 0.0, Sd = 0.0, W = 0.0, ess = 0.0; };
+    auto sum_totals = [&](const std::array<std::vector<std::uint64_t>, 3>& all) {
+        Totals g; std::uint64_t key = 0;
+        for (int r = 0; r < world; ++r) { g.S += all[0][(size_t)r]; g.Q += all[1][(size_t)r]; key = std::max(key, all[2][(size_t)r]); }
+        g.M = joint_key_inv(key);
+        g.Sd = joint_u64_to_double(g.S); g.W = g.Sd * (1.0 / 4294967296.0);
+        const double Qd = joint_u64_to_double(g.Q) * (1.0 / 4294967296.0), e = g.W * g.W / Qd;
+        g.ess = e > (double)N ? (double)N : e;
+        return g;
+    };
     for (int t = 0; t < T; ++t) {
         const bool last = t + 1 == T;
         a.logw_in = t > 0 ? logw[t & 1] : nullptr; a.logw_out = logw[(t + 1) & 1];
@@ -764,38 +792,50 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
         a.fs.bound = exact ? 0.0 : st.observe_bound[(size_t)t];
         a.fs.t = t; a.fs.anc_row = d_anc_all + (size_t)t * n;
         a.sh.peers = d_peers + (size_t)(t % 6) * world;
+        if (!exact) {
+            // bounded form: nothing comes back between two steps.  The step's first wavefront reads every rank's totals of generation
+            // t-1 and takes the decision itself; what it needs is that every rank's step t-1 has completed: a stream wait on their events.
+            hipLaunchKernelGGL((model_step_kernel_joint<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+            hip_check(hipGetLastError(), "model_step_kernel");
+            ctx.check(cpprob_hip_generic_totals(ctx.get(), t, n, d_tot + 4 * (t & 1)), "cpprob_hip_generic_totals");
+            hip_check(hipEventRecord(sh.ptrs[(size_t)rank].stepped[t & 1], stream), "hipEventRecord");
+            sh.ptrs[(size_t)rank].recorded.store(t + 1, std::memory_order_release);
+            if (last) continue;
+            for (int r = 0; r < world; ++r) {
+                if (r == rank) continue;
+                // (a peer's thread is an enqueue or two away: poll.  Its record of step t + 2 on the same event comes behind its own poll
+                //  of THIS rank's step t + 1, i.e. behind this wait: two events a rank are enough)
+                while (sh.ptrs[(size_t)r].recorded.load(std::memory_order_acquire) < t + 1) {
+                    if (sh.bar.failed.load()) throw std::runtime_error("another rank of the joint population failed");
+                    std::this_thread::yield();
+                }
+                hip_check(hipStreamWaitEvent(stream, sh.ptrs[(size_t)r].stepped[t & 1], 0), "hipStreamWaitEvent");
+            }
+            continue;
+        }
         a.sh.resample = resample ? 1 : 0;
-        const double ref_t = exact ? 0.0 : ((t == 0 || resample) ? a.fs.bound : M_prev + a.fs.bound);
-        a.sh.ref = ref_t;
+        a.sh.ref = 0.0;
         hipLaunchKernelGGL((model_step_kernel_joint<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
         hip_check(hipGetLastError(), "model_step_kernel");
-        double ref_gen = ref_t;
-        if (exact) {
-            // the generation's exact maximum over every rank first, then the masses against it
-            ctx.check(cpprob_hip_generic_max(ctx.get(), t, logw[(t + 1) & 1], n), "cpprob_hip_generic_max");
-            const auto mx = gather_totals(t);
-            std::uint64_t key = 0;
-            for (int r = 0; r < world; ++r) key = std::max(key, mx[2][(size_t)r]);
-            ref_gen = joint_key_inv(key);
-            ctx.check(cpprob_hip_generic_quantize_ref(ctx.get(), t, logw[(t + 1) & 1], n, ref_gen), "cpprob_hip_generic_quantize_ref");
-            sh.bar.wait();                                            // (the totals' buffer of this parity is written again below)
-        }
+        // the generation's exact maximum over every rank first, then the masses against it
+        ctx.check(cpprob_hip_generic_max(ctx.get(), t, logw[(t + 1) & 1], n), "cpprob_hip_generic_max");
+        const auto mx = gather_totals(t);
+        std::uint64_t key = 0;
+        for (int r = 0; r < world; ++r) key = std::max(key, mx[2][(size_t)r]);
+        const double ref_gen = joint_key_inv(key);
+        ctx.check(cpprob_hip_generic_quantize_ref(ctx.get(), t, logw[(t + 1) & 1], n, ref_gen), "cpprob_hip_generic_quantize_ref");
+        sh.bar.wait();                                                // (the totals' buffer of this parity is written again below)
         const auto all = gather_totals(t);
-        std::uint64_t S = 0, Q = 0, key = 0;
-        for (int r = 0; r < world; ++r) { S += all[0][(size_t)r]; Q += all[1][(size_t)r]; key = std::max(key, all[2][(size_t)r]); }
-        const double M = joint_key_inv(key);
-        const double Sd = joint_u64_to_double(S), W = Sd * (1.0 / 4294967296.0), Qd = joint_u64_to_double(Q) * (1.0 / 4294967296.0);
-        const double e = W * W / Qd;
-        const double ess_t = e > (double)N ? (double)N : e;
-        resample = !last && ess_t < opt.ess_threshold * (double)N;
-        const double gap = W > 0.0 ? ref_gen - M : 1e300;
+        const Totals g = sum_totals(all);
+        resample = !last && g.ess < opt.ess_threshold * (double)N;
+        const double gap = g.W > 0.0 ? ref_gen - g.M : 1e300;
         gap_max = t == 0 ? gap : std::max(gap_max, gap);
         if (gap < 0.0) flag = 4; else if (gap > kFixGapLimit && flag == 0) flag = 5;
-        ess[(size_t)t] = ess_t; resd[(size_t)t] = resample ? 1 : 0;
-        if (resample || last) lz += ref_gen + std::log(W / (double)N);
-        M_prev = M; ref_prev = ref_gen;
+        ess[(size_t)t] = g.ess; resd[(size_t)t] = resample ? 1 : 0;
+        if (resample || last) lz += ref_gen + std::log(g.W / (double)N);
+        M_prev = g.M; ref_prev = ref_gen;
         if (resample) {
-            const double inv = (double)N / Sd, u0 = cpprob_hip_systematic_offset(opt.seed, (uint64_t)t + 1);
+            const double inv = (double)N / g.Sd, u0 = cpprob_hip_systematic_offset(opt.seed, (uint64_t)t + 1);
             a.sh.inv = inv;
             std::uint64_t before = 0;
             for (int r = 0; r < world; ++r) {
@@ -807,10 +847,34 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
             a.sh.obound[world] = (double)N;
         }
     }
+    (void)M_prev;
+    if (!exact) {
+        // the last generation's books: its totals and what the launches kept come back once, behind the last step
+        std::vector<double> book((size_t)T + 1);
+        device::StepCtrl2 ctrl{};
+        const int tl = T - 1;
+        hip_check(hipMemcpyAsync(h_tot.data(), d_tot + 4 * (tl & 1), 3 * sizeof(std::uint64_t), hipMemcpyDeviceToHost, stream), "copy the shard's totals");
+        hip_check(hipMemcpyAsync(book.data(), d_book, ((size_t)T + 1) * sizeof(double), hipMemcpyDeviceToHost, stream), "copy the run's books");
+        hip_check(hipMemcpyAsync(resd.data(), d_res, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy the decisions");
+        hip_check(hipMemcpyAsync(&ctrl, lay.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, stream), "copy the run's books");
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        sh.totals[tl & 1][(size_t)rank] = h_tot;
+        sh.bar.wait();
+        std::array<std::vector<std::uint64_t>, 3> all;
+        for (int k = 0; k < 3; ++k) { all[(size_t)k].resize((size_t)world); for (int r = 0; r < world; ++r) all[(size_t)k][(size_t)r] = sh.totals[tl & 1][(size_t)r][(size_t)k]; }
+        const Totals g = sum_totals(all);
+        ref_prev = T > 1 ? ctrl.ref_cur : st.observe_bound[0];
+        const double gap = g.W > 0.0 ? ref_prev - g.M : 1e300;
+        gap_max = T > 1 ? std::max(ctrl.gap_max, gap) : gap;
+        if (gap < 0.0) flag = 4; else if (gap > kFixGapLimit) flag = 5;
+        for (int t = 0; t < tl; ++t) ess[(size_t)t] = book[(size_t)t];
+        ess[(size_t)tl] = g.ess; resd[(size_t)tl] = 0;
+        lz = (T > 1 ? book[(size_t)T] : 0.0) + (ref_prev + std::log(g.W / (double)N));
+    }
     (void)ref_prev;
     int32_t dev_flag = 0;
     hip_check(hipMemcpyAsync(&dev_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy the flag word");
-    hip_check(hipMemcpyAsync(d_res, resd.data(), ((size_t)T + 1) * sizeof(int32_t), hipMemcpyHostToDevice, stream), "copy the decisions");
+    if (exact) hip_check(hipMemcpyAsync(d_res, resd.data(), ((size_t)T + 1) * sizeof(int32_t), hipMemcpyHostToDevice, stream), "copy the decisions");
     // traces: follow every final particle of this rank back through whichever rank recorded each step
     const dim3 ggrid((unsigned)((n + 255) / 256)), gblock(256);
     if (n_real) hipLaunchKernelGGL((joint_lineage_gather_kernel<double>), ggrid, gblock, 0, stream, (const JointStore*)d_stores, rank, (const int32_t*)d_res, T, (int64_t)n, (const int32_t*)d_hit_real, (int)n_real, d_real);
@@ -846,7 +910,7 @@ void generic_joint_rank(JointShared& sh, int rank, StateType algorithm, const vo
     for (int t = 0; t < T; ++t) n_resampled += resd[(size_t)t];
     res.n_particles = n; res.log_evidence = lz; res.log_norm = lse_ess[0]; res.ess = lse_ess[1]; res.n_resampled = n_resampled; res.used_builtin = false;
     res.step_ess = ess; res.replay_window = (int)w; res.step_form = exact ? 2 : 1; res.launches_per_step = exact ? 4 : 2;
-    res.joint_flag = dev_flag == 2 || dev_flag == 3 ? dev_flag : flag;
+    res.joint_flag = dev_flag == 2 || dev_flag == 3 ? dev_flag : (dev_flag == 4 || flag == 4 ? 4 : (dev_flag == 5 || flag == 5 ? 5 : 0));
     res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     HostStore& hs = sh.hs[(size_t)rank];
     hs.n = n; hs.logw.resize(n); hs.real.resize(n_real * n); hs.ints.resize(n_int * n);
