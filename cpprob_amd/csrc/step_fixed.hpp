@@ -66,7 +66,7 @@ __device__ __forceinline__ void fixed_walk(const FixedCdf& fc, const uint32_t* _
         uint64_t run = 0;
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) { run += (uint64_t)raw[k]; pre[k] = run; }
-        const uint64_t incl = wave_incl_scan_u64(run);
+        const uint64_t incl = wave_incl_scan_u34(run);                 // (four 32-bit weights: below 2^34)
         if (lane == kWave - 1) L.scan[it & 1][wv] = incl;
         __syncthreads();
         uint64_t off = 0, tot = 0;
@@ -325,14 +325,14 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
         if (j0 + k >= a.n) lw[k] = -INFINITY;                                                  // padding slots
         const uint32_t w = fix_weight(lw[k], ref);
         q[k] = w;
-        s_l += w; q_l += (uint64_t)(w >> 16) * (uint64_t)(w >> 16);
+        s_l += w; q_l += (uint64_t)(uint32_t)__umul24(w >> 16, w >> 16);       // (16 x 16 bits: one full-rate multiply; HIP declares the result int)
         m_l = fmax(m_l, lw[k]);
     }
     // (the tile's totals by DPP reductions: three same-address 64-bit LDS atomics per lane were measured at 1.7x the whole step);
     // published BEFORE this workgroup's weight / log-weight stores are issued: the hierarchy's atomics -- and, above 4096 tiles, the
     // wait in front of the arrival count -- travel under them instead of behind them
     CPH_STAMP(5);
-    const uint64_t s_w = wave_sum_u64(s_l), q_w = wave_sum_u64(q_l), m_w = wave_max_u64(dkey(m_l));
+    const uint64_t s_w = wave_sum_u34(s_l), q_w = wave_sum_u34(q_l), m_w = wave_max_key(dkey(m_l));     // (sums of four 32-bit terms)
     if (lane_id() == 0) { s_red[wave_id()] = s_w; s_red[kWaves + wave_id()] = q_w; s_red[2 * kWaves + wave_id()] = m_w; }
     __syncthreads();
     if (tid == 0) {

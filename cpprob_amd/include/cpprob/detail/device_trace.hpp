@@ -290,23 +290,7 @@ __device__ __forceinline__ uint64_t wave_sum_q(uint32_t q)
     const uint32_t lo = cph::wave_sum_u32(q & 0xffffu), hi = cph::wave_sum_u32(q >> 16);
     return ((uint64_t)hi << 16) + lo;
 }
-// ... and the maximum of 64-bit keys as two 32-bit maxima: the high words, then the low words of the lanes that hold the high maximum
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-    v = max(v, cph::dpp_u32<cph::kDppRowShr1>(v));
-    v = max(v, cph::dpp_u32<cph::kDppRowShr2>(v));
-    v = max(v, cph::dpp_u32<cph::kDppRowShr4>(v));
-    v = max(v, cph::dpp_u32<cph::kDppRowShr8>(v));
-    v = max(v, cph::dpp_u32<cph::kDppRowBcast15, 0xA>(v));
-    v = max(v, cph::dpp_u32<cph::kDppRowBcast31, 0xC>(v));
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ uint64_t wave_max_key(uint64_t k)
-{
-    const uint32_t hi = wave_max_u32((uint32_t)(k >> 32));
-    const uint32_t lo = wave_max_u32((uint32_t)(k >> 32) == hi ? (uint32_t)k : 0u);
-    return ((uint64_t)hi << 32) | lo;
-}
+using cph::wave_max_key;                                              // (the maximum of 64-bit keys as two 32-bit maxima: fixed_mass.hpp)
 
 // What the search's probe reads: the hierarchy words of block cs = max(own - kStepProbeBack, 0)'s prefix and kStepProbe block entries.
 struct StepProbeWords { uint64_t lvl[cph::kHierMaxLevels]; uint64_t we; };

@@ -131,6 +131,36 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
     return read_lane_u64(v, kWave - 1);
 }
 
+// Values below 2^34 -- a lane's four 32-bit weights, four squares of 16-bit halves -- as two 17-bit halves: each half's sum over 64
+// lanes fits 23 bits, so a scan step is ONE v_add_u32_dpp per half (a 64-bit step is two DPP moves and a two-instruction add).
+__device__ __forceinline__ uint64_t wave_incl_scan_u34(uint64_t v)
+{
+    const uint32_t lo = wave_incl_scan_u32((uint32_t)v & 0x1ffffu), hi = wave_incl_scan_u32((uint32_t)(v >> 17));
+    return ((uint64_t)hi << 17) + lo;
+}
+__device__ __forceinline__ uint64_t wave_sum_u34(uint64_t v)
+{
+    const uint32_t lo = wave_sum_u32((uint32_t)v & 0x1ffffu), hi = wave_sum_u32((uint32_t)(v >> 17));
+    return ((uint64_t)hi << 17) + lo;
+}
+// ... and the maximum of 64-bit keys as two 32-bit maxima: the high words, then the low words of the lanes that hold the high maximum
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, dpp_u32<kDppRowShr1>(v));
+    v = max(v, dpp_u32<kDppRowShr2>(v));
+    v = max(v, dpp_u32<kDppRowShr4>(v));
+    v = max(v, dpp_u32<kDppRowShr8>(v));
+    v = max(v, dpp_u32<kDppRowBcast15, 0xA>(v));
+    v = max(v, dpp_u32<kDppRowBcast31, 0xC>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, kWave - 1);
+}
+__device__ __forceinline__ uint64_t wave_max_key(uint64_t k)
+{
+    const uint32_t hi = wave_max_u32((uint32_t)(k >> 32));
+    const uint32_t lo = wave_max_u32((uint32_t)(k >> 32) == hi ? (uint32_t)k : 0u);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // order-preserving key of a double (an unsigned maximum of keys is the maximum of the doubles; 0 lies below every key: "empty")
 __host__ __device__ __forceinline__ uint64_t dkey(double x)
 {
@@ -175,7 +205,7 @@ __device__ __forceinline__ FTot ftot_sum(const FHier& f, FTotWords w)
 {
     if (lane_id() >= f.h.top_n) { w.s = 0; w.q = 0; w.m = 0; }
     FTot t;
-    t.S = wave_sum_u64(w.s & kMassMask); t.Q = wave_sum_u64(w.q); t.M = dkey_inv(wave_max_u64(w.m));
+    t.S = wave_sum_u64(w.s & kMassMask); t.Q = wave_sum_u64(w.q); t.M = dkey_inv(wave_max_key(w.m));
     return t;
 }
 __device__ __forceinline__ FTot ftot(const FHier& f) { FTotWords w; ftot_fetch(f, w); return ftot_sum(f, w); }
