@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kThreads) void bbf_quantize_kernel(const double* __
 #pragma unroll
     for (int k = 0; k < kPPT; ++k) {
         const uint32_t v = j0 + k < n ? fix_weight(logw[j0 + k], ref) : 0u;
-        w[k] = v; s_l += v; q_l += (uint64_t)(v >> 16) * (uint64_t)(v >> 16);
+        w[k] = v; s_l += v; q_l += fix_square(v);
     }
     *reinterpret_cast<U4*>(q + j0) = w;
     const uint64_t sw = wave_sum_u64(s_l), qw = wave_sum_u64(q_l);

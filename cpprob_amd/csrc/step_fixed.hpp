@@ -10,7 +10,7 @@
 // are exact in any order, so
 //        the inclusive CDF  C_k = sum_{i <= k} q_i                                   (exact, 64-bit),
 //        the first output   G_k = ceil(fma(double(C_k), N / double(C_N), -u0)),      ancestor of output j = min{k : G_k > j},
-//        the normaliser     W = C_N * 2^-32,   ESS = (C_N * 2^-16)^2 / sum_i (q_i >> 16)^2   (the sum of squares on 16-bit weights:
+//        the normaliser     W = C_N * 2^-32,   ESS = (C_N * 2^-16)^2 / sum_i fix_square(q_i)    (squares of 24-bit weights, 32 bits each:
 //                                                                                             exact in 64 bits up to 2^28 particles)
 // are the same integers however tiles, wavefronts and shards are laid out: the resampling decision, every ancestor and the
 // evidence of a sharded run equal the single-GPU run's bit for bit, and no workgroup has to re-derive a floating-point CDF from
@@ -18,7 +18,7 @@
 // restatement the parity tests compare with states the same arithmetic.
 //
 // The prefix masses live in the 64-ary hierarchy of step_counts.hpp (same layout, same rotation of three copies): the word of a
-// tile / block is its mass S (levels >= 1: | arrivals << 56), and the line of a block also holds Q = sum (q >> 16)^2 and the
+// tile / block is its mass S (levels >= 1: | arrivals << 56), and the line of a block also holds Q = sum fix_square(q) and the
 // order key of M = max lw (atomic add / add / max: all order-free); tiles keep their Q and M in two arrays beside level 0.
 // Resolution: weights below 2^-33 of the reference are zero -- 23 nats under the heaviest admissible particle.
 #pragma once
@@ -325,7 +325,7 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
         if (j0 + k >= a.n) lw[k] = -INFINITY;                                                  // padding slots
         const uint32_t w = fix_weight(lw[k], ref);
         q[k] = w;
-        s_l += w; q_l += (uint64_t)(uint32_t)__umul24(w >> 16, w >> 16);       // (16 x 16 bits: one full-rate multiply; HIP declares the result int)
+        s_l += w; q_l += fix_square(w);
         m_l = fmax(m_l, lw[k]);
     }
     // (the tile's totals by DPP reductions: three same-address 64-bit LDS atomics per lane were measured at 1.7x the whole step);

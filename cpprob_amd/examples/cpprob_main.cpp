@@ -99,6 +99,7 @@ int execute(const F& model, const Args& a)
         std::cout << "Posterior Distribution Estimators" << std::endl;                                                      // main.cpp:104
         std::cout << cpprob::StatsPrinter{post};
     }
+    cpprob::gpu::release_device_resources();                         // (contexts and workspaces kept between calls: freed while the runtime is alive)
     return EXIT_SUCCESS;
 }
 

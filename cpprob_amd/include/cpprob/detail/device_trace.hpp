@@ -616,7 +616,7 @@ __device__ __forceinline__ void step_epilogue()
     }
     const double ref = t == 0 ? A->fs.bound : (A->sh.world ? L.j_ref : L.found.ref);
     const uint32_t q = fix_weight(lw, ref);
-    const uint64_t s_w = wave_sum_q(q), q_w = wave_sum_q((q >> 16) * (q >> 16)), m_w = wave_max_key(dkey(lw));
+    const uint64_t s_w = wave_sum_q(q), q_w = wave_sum_q(cph::fix_square(q)), m_w = wave_max_key(dkey(lw));
     if (lane == 0) { L.red[wv] = s_w; L.red[kStepWaves + wv] = q_w; L.red[2 * kStepWaves + wv] = m_w; }
     __syncthreads();
     if (tid == 0) {

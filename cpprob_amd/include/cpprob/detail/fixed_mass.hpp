@@ -365,6 +365,16 @@ __device__ __forceinline__ FLocated fixed_locate(const FHier& f, const FixedCdf&
 }
 
 
+// A weight's square for the ESS, in units of 2^-32 of exp(2 R): floor(floor(q / 2^8)^2 / 2^16).  Below 2^32, so a tile's sum and the
+// hierarchy's stay in 64 bits up to 2^28 particles.  What the two floors lose: at most 2^9 / q + 2^32 / q^2 of a term -- 1.2e-7 for a
+// particle at the reference, 1.2e-4 for the heaviest particle of a generation that sits 6 nats below it (the gap at which a run is
+// repeated), nothing that moves a decision.  (r03 squared q >> 16: 2^17 / q, i.e. 1.6 % at that gap, always downward.)
+__host__ __device__ __forceinline__ uint32_t fix_square(uint32_t q)
+{
+    const uint32_t h = q >> 8;
+    return (uint32_t)(((uint64_t)h * h) >> 16);
+}
+
 // What every rank derives from a generation's totals, identically: the decision, the comb, the next reference.
 struct FixedDecision { double W, Qd, ess, inv; bool resample; };
 __device__ __forceinline__ FixedDecision fixed_decide(uint64_t S, uint64_t Q, double n_pop, double ess_frac, bool may_resample)
@@ -372,9 +382,9 @@ __device__ __forceinline__ FixedDecision fixed_decide(uint64_t S, uint64_t Q, do
     FixedDecision d;
     const double Sd = u64_to_double(S);
     d.W = Sd * kFixInv;                                      // sum of exp(lw - R)
-    d.Qd = u64_to_double(Q) * kFixInv;                        // sum of exp(2 (lw - R)) on 16-bit weights: (q >> 16)^2 = e^2 2^32
+    d.Qd = u64_to_double(Q) * kFixInv;                        // sum of exp(2 (lw - R)): fix_square(q) = e^2 2^32
     const double e = d.W * d.W / d.Qd;                        // thesis p.37
-    d.ess = e > n_pop ? n_pop : e;                            // (the 16-bit squares under-count Q by up to 2^-15: equal weights would report ESS = N (1 + 3e-5))
+    d.ess = e > n_pop ? n_pop : e;                            // (fix_square under-counts: the estimate is kept in [.., N])
     d.resample = may_resample && d.ess < ess_frac * n_pop;
     d.inv = n_pop / Sd;
     return d;

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <typeinfo>
+#include <vector>
 
 #include "cpprob/detail/host_trace.hpp"
 #include "cpprob/gpu_result.hpp"
@@ -67,6 +68,26 @@ inline bool add_entry(const Key& k, const Entry& e)
     if (e.builtin_model >= 0) dst.builtin_model = e.builtin_model;
     if (e.generic && (e.generic_vectors || !dst.generic_vectors)) { dst.generic = e.generic; dst.generic_vectors = e.generic_vectors; dst.generic_joint = e.generic_joint; }
     return true;
+}
+
+// What the device paths keep between two cpprob::inference calls (contexts, streams, workspaces) is released by hooks the model
+// translation units leave here.  A program may call release_device_resources() before it returns from main: otherwise those objects
+// are simply never torn down (static destructors run when the HIP runtime may already be gone) -- which is harmless but leaves the
+// runtime to end a process with live streams.
+using ReleaseHook = void (*)();
+CPPROB_REGISTRY_VISIBLE inline std::vector<ReleaseHook>& release_hooks() { static std::vector<ReleaseHook> h; return h; }
+inline bool add_release_hook(ReleaseHook f)
+{
+    std::lock_guard<std::mutex> lock(table_mutex());
+    for (ReleaseHook g : release_hooks()) if (g == f) return true;
+    release_hooks().push_back(f);
+    return true;
+}
+inline void release_device_resources()
+{
+    std::vector<ReleaseHook> hooks;
+    { std::lock_guard<std::mutex> lock(table_mutex()); hooks = release_hooks(); }
+    for (ReleaseHook f : hooks) f();
 }
 
 inline const Entry* find_entry(const Key& k)

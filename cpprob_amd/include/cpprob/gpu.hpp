@@ -1005,6 +1005,7 @@ template <class HostFP, HostFP H, class DevFP, DevFP D>
 bool register_model_view(const char* name)
 {
     Entry e; e.name = name; e.generic = &generic_launcher_view<tuple_observes_t<HostFP>, FunctionCaller<DevFP, D>>; e.generic_vectors = true;   // (vector-valued statements: no replay window, no joint form)
+    add_release_hook(&release_workspaces);
     return add_entry(Key{reinterpret_cast<const void*>(H), 0}, e);
 }
 
@@ -1012,6 +1013,7 @@ template <class FP, FP F>
 bool register_model(const char* name)
 {
     Entry e; e.name = name; e.generic = &generic_launcher<FunctionCaller<FP, F>>; e.generic_joint = &generic_joint_launcher<FunctionCaller<FP, F>>;
+    add_release_hook(&release_workspaces);
     return add_entry(Key{reinterpret_cast<const void*>(F), 0}, e);
 }
 
@@ -1020,6 +1022,7 @@ template <class Functor>
 bool register_functor(const char* name)
 {
     Entry e; e.name = name; e.generic = &generic_launcher<FunctorCaller<Functor>>; e.generic_joint = &generic_joint_launcher<FunctorCaller<Functor>>;
+    add_release_hook(&release_workspaces);
     return add_entry(Key{nullptr, typeid(Functor).hash_code()}, e);
 }
 

@@ -609,7 +609,7 @@ ORC_API int orc_resample_table_systematic(const int32_t *x, uint64_t n_in, const
 /* M_{t-1} the exact maximum of the previous log-weights.  Inclusive CDF          */
 /* C_k = sum_{i<=k} q_i (exact, 64-bit), G_k = ceil(fma((double)C_k, N/(double)C_N,*/
 /* -u0)), ancestor of output j = min{k : G_k > j}, G of the last source = N;       */
-/* W = C_N 2^-32, ESS = min(N, W^2 / (2^-32 sum (q_i >> 16)^2)).  Integers sum exactly in */
+/* W = C_N 2^-32, ESS = min(N, W^2 / (2^-32 sum floor(floor(q_i / 2^8)^2 / 2^16))).  Integers sum exactly in */
 /* any order: tiles, wavefronts and shards all produce these ancestors.            */
 /* exp() is the kernel's own range-specific form (fma arithmetic, so that the      */
 /* integers agree bit for bit): cpprob/detail/fastmath.hpp exp_nonpos.             */
@@ -625,6 +625,13 @@ static double orc_exp_nonpos(double x)
     for (int i = 1; i < 11; ++i) p = fma(p, r, c[i]);
     p = fma(p, r * r, r);
     return ldexp(p + 1.0, (int)k);
+}
+
+/* a weight's square for the ESS: cpprob/detail/fixed_mass.hpp fix_square */
+static uint64_t orc_fix_square(uint32_t q)
+{
+    const uint64_t h = q >> 8;
+    return (h * h) >> 16;
 }
 
 ORC_API uint32_t orc_fix_weight(double lw, double ref)
@@ -765,14 +772,14 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
             double ref = (t == 0 || do_resample) ? bound : m_prev + bound;
             if (ref_mode == 2) ref = max;
             uint64_t S = 0, Q16 = 0;
-            for (uint64_t i = 0; i < n; ++i) { qw[i] = orc_fix_weight(logw[i], ref); S += qw[i]; Q16 += (uint64_t)(qw[i] >> 16) * (uint64_t)(qw[i] >> 16); }
+            for (uint64_t i = 0; i < n; ++i) { qw[i] = orc_fix_weight(logw[i], ref); S += qw[i]; Q16 += orc_fix_square(qw[i]); }
             q_total = S;
             m_prev = max;
             max = ref;                                   /* sums below are relative to exp(ref) */
             W = (double)S * (1.0 / 4294967296.0);
             Q = (double)Q16 * (1.0 / 4294967296.0);
             ess = W * W / Q;
-            if (ess > (double)n) ess = (double)n;        /* (q >> 16)^2 under-counts Q by up to 2^-15: the estimate is kept in [.., N] */
+            if (ess > (double)n) ess = (double)n;        /* the floored squares under-count Q: the estimate is kept in [.., N] */
         }
         if (ess_trace) ess_trace[t] = ess;
         if (filter_stats) {

@@ -405,8 +405,8 @@ def test_fixed_point_masses_at_full_size_arithmetic_bound_and_posterior(engine, 
     (1) THE ARITHMETIC, generation by generation (runs cut after 1, 7, 40 and all observes: the same particles as the full run's).
         Every weight is off by at most half a unit, so a generation's mass S (in units) is off by at most N / 2 and its logarithm --
         a factor of the evidence, the normaliser of every posterior sum -- by at most N / (2 S); measured against an fp64
-        recomputation from the stored log-weights.  ESS: the squares are taken on 16-bit weights (q >> 16), which under-counts
-        their sum by at most 2^-15 at full scale: the integer ESS is never below the fp64 one and at most 1e-4 above it.
+        recomputation from the stored log-weights.  ESS: a weight's square is floor(floor(q / 2^8)^2 / 2^16), which under-counts
+        a term by at most 2^9 / q + 2^32 / q^2: the integer ESS is never below the fp64 one and at most 1e-4 above it.
     (2) THE POSTERIOR.  Fixed-point against CPPROB_HIP_FLAG_FLOATING_POINT_STEP (fp64 weights, fp64 CDF) on the same seed is NOT a
         clean measure of (1): the floating-point form's CDF-boundary flips make the two runs different genealogies after a few
         steps, i.e. different Monte-Carlo realisations.  So their difference is compared with what it would have to exceed to mean
