@@ -46,6 +46,7 @@ struct cpprob_hip_ctx {
     size_t ssz = 8;         // bytes per element of values[] (Model::store_t; may be narrower than the model's value type)
     int nb = 0;             // tiles
     int smooth_grid = 0;
+    int walk_cap = 0, walk_grid = 0, n_cu = 0;    // lineage walk: partials allocated for walk_cap workgroups; the grid of this configuration's walk (0: not chosen yet)
     ModelParams mp{};
     uint64_t run_seed = 0;
     uint64_t pop_n = 0;     // size of the population this shard is resampled with (n_global, or n for islands)
@@ -659,6 +660,35 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
     a.paths = with_paths ? static_cast<typename Model::value_t*>(c->d_paths) : nullptr;
     a.rem = (c->x_remote && c->sharded) ? c->d_remote : nullptr;
     const size_t shm = (size_t)kWaves * c->T * Model::kStats * sizeof(double);
+    // The walk's grid.  Its workgroups loop over tiles (kSmoothTiles at a time for one-byte states), so what a launch costs is
+    // passes x rounds: a grid that is not a multiple of what the chip holds at once leaves its last round part-empty (2048 workgroups
+    // at six a CU: 1536 + 512), and one that divides the tiles badly gives some workgroups a pass more than others.  Chosen once per
+    // configuration: k x residency, k = 1 .. 4, with the least padded capacity (ties: the larger grid -- shorter chains per workgroup).
+    // hmm<128> at 1.25e7 particles: 2048 -> 6144 workgroups, 1.38 -> 1.20 ms; linear_gaussian_1d<100> at 1e7 keeps 2048 (eight a CU).
+    auto choose_grid = [&](auto kernel) -> int {
+        if (c->walk_grid > 0) return c->walk_grid;
+        int grid = c->smooth_grid, occ = 0;
+        if (c->n_cu == 0) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess) c->n_cu = v; }
+        if (c->n_cu > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kThreads, shm) == hipSuccess && occ > 0) {
+            const int64_t R = (int64_t)occ * c->n_cu, nt = c->nb;
+            if (nt <= R) grid = (int)nt;
+            else {
+                double best = 1e300;
+                for (int k = 1; k <= 4; ++k) {
+                    const int64_t g = R * k;
+                    if (g > c->walk_cap) break;
+                    const int64_t per = (sizeof(typename Model::store_t) == 1 && kSmoothTiles > 1 && nt > g) ? kSmoothTiles : 1;
+                    const int64_t passes = (nt + g * per - 1) / (g * per);
+                    const double waste = (double)(passes * g * per) / (double)nt;
+                    if (waste <= best * 1.01) { best = std::min(best, waste); grid = (int)std::min<int64_t>(g, nt); }
+                }
+            }
+        }
+        (void)hipGetLastError();
+        c->walk_grid = grid;
+        return grid;
+    };
+    int grid_used = c->smooth_grid;
     {
         ProfScope ps(c, 2);
         bool launched = false;
@@ -689,7 +719,8 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
                 CountsFinal f{};
                 counts_final_view(c, f, c->final_bookkeep_pending && !with_paths);
                 if (!with_paths) c->final_bookkeep_pending = false;
-                hipLaunchKernelGGL(smooth_counts_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a, f);
+                grid_used = choose_grid(smooth_counts_kernel<Model>);
+                hipLaunchKernelGGL(smooth_counts_kernel<Model>, dim3(grid_used), dim3(kThreads), shm, c->stream, a, f);
                 launched = true;
             }
         }
@@ -697,15 +728,16 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
             FixedFinal ff{};
             fixed_final_view(c, ff, c->final_bookkeep_pending && !with_paths);
             if (!with_paths) c->final_bookkeep_pending = false;
-            hipLaunchKernelGGL(smooth_fixed_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a, ff, (const uint32_t*)c->d_q[c->cur]);
+            grid_used = choose_grid(smooth_fixed_kernel<Model>);
+            hipLaunchKernelGGL(smooth_fixed_kernel<Model>, dim3(grid_used), dim3(kThreads), shm, c->stream, a, ff, (const uint32_t*)c->d_q[c->cur]);
             launched = true;
         }
-        if (!launched) hipLaunchKernelGGL(smooth_kernel<Model>, dim3(c->smooth_grid), dim3(kThreads), shm, c->stream, a);
+        if (!launched) { grid_used = choose_grid(smooth_kernel<Model>); hipLaunchKernelGGL(smooth_kernel<Model>, dim3(grid_used), dim3(kThreads), shm, c->stream, a); }
     }
     if (with_paths && c->trace_mode && c->final_from_counts) return;     // (the statistics came from the trace words: the walk only materialises traces)
     ProfScope ps(c, 3);
     hipLaunchKernelGGL(finalize_kernel, dim3(c->T), dim3(kThreads), 0, c->stream,
-                       c->d_stats_part, c->smooth_grid, c->T, Model::kStats, Model::kIsInt ? 1 : 0, c->d_ctrl, c->d_stats, c->sharded ? 0 : 1);
+                       c->d_stats_part, grid_used, c->T, Model::kStats, Model::kIsInt ? 1 : 0, c->d_ctrl, c->d_stats, c->sharded ? 0 : 1);
 }
 
 template <class F>
@@ -863,6 +895,8 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     c->nb = (int)((c->n + kTile - 1) / kTile);
     c->ld = (int64_t)c->nb * kTile;                 // padded to the tile: no ragged tails in any kernel
     c->smooth_grid = std::min(c->nb, 2048);
+    c->walk_cap = std::min(c->nb, 8192);
+    c->walk_grid = 0;
     host_model_params(c->mp, cfg->model);
     const bool smc = c->cfg.algorithm == CPPROB_HIP_ALG_SMC;
     const bool multinomial = smc && cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL;
@@ -917,7 +951,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_gstat, (size_t)kMaxReadoutCols * kMaxSlabs * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_ess, T * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_resampled, T * sizeof(int32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_stats_part, (size_t)c->smooth_grid * T * 8 * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_stats_part, (size_t)c->walk_cap * T * 8 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_stats, T * 8 * sizeof(double)));
         {
             // 64-ary hierarchy of per-tile state counts, three rotating copies (step_counts.hpp); levels >= 1 one line per entry
