@@ -649,6 +649,16 @@ void launch_scan(cpprob_hip_ctx* c, int t, int phase, const double* all_totals, 
     }
 }
 
+
+// Workgroups of the trace-word read-out: each adds its counts into the shared counters (~100 atomics), so few of them while the pass
+// is short -- 256 up to 4e6 particles (10^6: 12.6 us; 1024 workgroups: 21) -- and one per sixteen tiles beyond, up to 2048
+// (10^8 particles: 430 -> 244 us).
+static int trace_readout_grid(int64_t n)
+{
+    const int64_t tiles = (n + kTile - 1) / kTile;
+    return (int)std::min<int64_t>(tiles, std::max<int64_t>(256, std::min<int64_t>(2048, tiles / 16)));
+}
+
 template <class Model>
 void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
 {
@@ -700,7 +710,7 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
                 ta.trace = c->d_tr[(c->T - 1) & 1]; ta.n = c->n; ta.T = c->T;
                 counts_final_view(c, ta.f, false);
                 ta.counters = c->d_trace_cnt; ta.arrive = c->d_trace_arrive; ta.stats = c->d_stats; ta.raw = 1; ta.n_local = (double)c->n;
-                const int grid = (int)std::min<int64_t>((c->n + kTile - 1) / kTile, 256);
+                const int grid = trace_readout_grid(c->n);
                 hipLaunchKernelGGL(trace_readout_kernel, dim3(grid), dim3(kThreads), 0, c->stream, ta);
                 return;
             }
@@ -711,7 +721,7 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
                 counts_final_view(c, ta.f, c->final_bookkeep_pending);
                 c->final_bookkeep_pending = false;
                 ta.counters = c->d_trace_cnt; ta.arrive = c->d_trace_arrive; ta.stats = c->d_stats;
-                const int grid = (int)std::min<int64_t>((c->n + kTile - 1) / kTile, 256);
+                const int grid = trace_readout_grid(c->n);
                 hipLaunchKernelGGL(trace_readout_kernel, dim3(grid), dim3(kThreads), 0, c->stream, ta);
                 return;
             }
