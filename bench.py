@@ -593,27 +593,30 @@ def main():
             import tempfile
             with tempfile.TemporaryDirectory() as td:
                 cmd = [exe, "--model_folder", td, "--model", "hmm16", "--smc", "--observes", obs_s, "--n_samples", str(n), "--seed", str(args.seed),
-                       "--ess_threshold", "2.0", "--generic", "--no_dump", "--json", "--repeat", "6"]
+                       "--ess_threshold", "2.0", "--generic", "--no_dump", "--json", "--repeat", "12"]
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             gj = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")][-1]
             gst = np.array([p_["p"] for p_ in gj["predicts"]])
             runs = [l for l in pr.stdout.splitlines() if l.startswith("run ")]
             first = runs[0].split()
-            out["generic_path"] = {"ms_per_run": gj["run_seconds"] * 1e3, "particles_per_sec": n / gj["run_seconds"], "replay_window": gj["replay_window"],
+            warm = sorted(float(l.split()[2]) for l in runs[1:])          # (every call but the first: each a run of its own seed)
+            g_ms = warm[len(warm) // 2]
+            out["generic_path"] = {"ms_per_run": g_ms, "ms_per_run_min": warm[0], "ms_per_run_max": warm[-1], "particles_per_sec": n / (g_ms * 1e-3), "replay_window": gj["replay_window"],
                                    "step_form": {0: "model launch + three bookkeeping launches", 1: "resampling inside the model's launch (dry-run bounds)", 2: "resampling inside the model's launch + exact-maximum passes"}[gj["step_form"]],
                                    "launches_per_step": gj["launches_per_step"],
                                    "ms_first_call": float(first[2]) + float(first[5]), "ms_setup_first_call": float(first[5]), "ms_setup_warm_call": gj["setup_seconds"] * 1e3,
                                    "posterior_max_abs_err_vs_exact": float(np.abs(gst - spec["exact"]).max()),
-                                   "vs_fused_kernels": gj["run_seconds"] * 1e3 / (dt / args.steps * 1e3),
-                                   "note": "cpprob_main --generic --repeat 6: ms_per_run = the last call's device work (the read-out of every predict hit included), ms_first_call = "
+                                   "vs_fused_kernels": g_ms / (dt / args.steps * 1e3),
+                                   "note": "cpprob_main --generic --repeat 12: ms_per_run = the median over the eleven warm calls of a call's device work (the read-out of every predict hit included), ms_first_call = "
                                            "the first cpprob::inference call whole (context, workspace, Markov pilot, run), ms_setup_warm_call = what a later call adds to its run"}
             # the same population as FOUR ranks of one joint population on this GPU (loopback: the pull migration and the per-step host all-gather at work)
             with tempfile.TemporaryDirectory() as td:
                 cmd = [exe, "--model_folder", td, "--model", "hmm16", "--smc", "--observes", obs_s, "--n_samples", str(n), "--seed", str(args.seed),
-                       "--ess_threshold", "2.0", "--generic", "--no_dump", "--json", "--repeat", "6", "--devices", "0,0,0,0"]
+                       "--ess_threshold", "2.0", "--generic", "--no_dump", "--json", "--repeat", "12", "--devices", "0,0,0,0"]
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             jj = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")][-1]
-            out["generic_path"]["joint_4_loopback_ranks"] = {"ms_per_run": jj["run_seconds"] * 1e3, "joint": jj["joint"], "log_evidence_equals_one_rank": jj["log_evidence"] == gj["log_evidence"],
+            jwarm = sorted(float(l.split()[2]) for l in pr.stdout.splitlines() if l.startswith("run "))[:-1]       # (the first call is the slowest)
+            out["generic_path"]["joint_4_loopback_ranks"] = {"ms_per_run": jwarm[len(jwarm) // 2], "joint": jj["joint"], "log_evidence_equals_one_rank": jj["log_evidence"] == gj["log_evidence"],
                                                              "note": "cpprob_main --generic --devices 0,0,0,0: one joint population, four ranks on this one GPU"}
         except Exception as e:
             out["generic_path"] = {"error": str(e)}
