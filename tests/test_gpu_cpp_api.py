@@ -146,6 +146,13 @@ def test_unchanged_model_step_falls_back_to_exact_maxima_when_a_generation_leave
     r = O.smc_ref(O.MODEL_HMM3, obs, n, 11, O.REF_EXACT_MAX, O.RESAMPLE_SYSTEMATIC, 2.0)
     assert np.array_equal(vg, np.take_along_axis(r["hist"], O.lineage(r["anc"]), axis=1))
     assert abs(res["log_evidence"] - r["log_z"]) < 1e-9
+    # the same as three shards of one joint population: every rank's launch takes the decision from all ranks' totals, every rank
+    # sees the generation leave its bound, and the run is repeated on exact maxima -- the single-context answer, bit for bit
+    many, _, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 11, "--ess_threshold", 2.0, "--json",
+                          "--generic", "--generated_file", "m", "--devices", "0,0,0")
+    assert many["joint"] is True and many["step_form"] == 2 and many["log_evidence"] == res["log_evidence"]
+    vm, lwm = read_dump(str(tmp_path / "m_smc.int"), True)
+    assert np.array_equal(vm, vg) and np.array_equal(lwm, lwg)
 
 
 def test_unchanged_model_without_a_likelihood_bound_takes_exact_maxima(tmp_path):
