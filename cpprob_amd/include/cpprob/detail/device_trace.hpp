@@ -504,7 +504,13 @@ __device__ __forceinline__ void step_prologue()
             } else {
                 // the generation's totals: every rank's 24 bytes, read where they lie (lane r = rank r)
                 uint64_t s_r = 0, q_r = 0, m_r = 0;
-                if (lane < world) { const uint64_t* tp = A->sh.peers[lane].totals; s_r = tp[0]; q_r = tp[1]; m_r = tp[2]; }
+                if (lane < world) {
+                    // (system scope: the words lie in another rank's memory and were written since this device last read that line)
+                    const uint64_t* tp = A->sh.peers[lane].totals;
+                    s_r = __hip_atomic_load(tp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    q_r = __hip_atomic_load(tp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    m_r = __hip_atomic_load(tp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 const uint64_t incl = wave_incl_scan_u64(s_r);
                 const uint64_t S = read_lane_u64(incl, 63), Q = wave_sum_u64(q_r);
                 const double M = dkey_inv(wave_max_u64(m_r));
