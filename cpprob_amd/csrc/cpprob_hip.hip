@@ -769,7 +769,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
     dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]); dfree(c->d_trace_cnt); dfree(c->d_trace_arrive); dfree(c->d_tr[0]); dfree(c->d_tr[1]);
-    c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0;
+    c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0; c->tr_cap = 0;
 }
 
 }  // namespace
@@ -1602,7 +1602,7 @@ static int ensure_shard_trace(cpprob_hip_ctx* c, bool& words)
     dispatch_model(c, [&](auto m) { words = counts_eligible<decltype(m)>(c); });
     words = words && c->keep && c->cfg.model == CPPROB_HIP_MODEL_HMM3 && c->T <= kTraceMaxT && !(c->cfg.flags & CPPROB_HIP_FLAG_WALK_READOUT);
     if (!words) return 0;
-    if ((size_t)c->rs > c->tr_cap) {
+    if ((size_t)c->rs > c->tr_cap || !c->d_tr[0]) {
         dfree(c->d_tr[0]); dfree(c->d_tr[1]);
         HIP_TRY(c, hipMalloc(&c->d_tr[0], (size_t)c->rs * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->d_tr[1], (size_t)c->rs * sizeof(uint32_t)));
