@@ -515,9 +515,12 @@ template <class Model>
 bool fixed_eligible(const cpprob_hip_ctx* c)
 {
     constexpr bool model_ok = std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value || std::is_same<Model, ModelHmmK>::value;
+    // (stratified and multinomial resampling run on the same integer masses: one population per context)
+    const bool own = c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND;
+    const bool systematic = c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC;
     return model_ok && !c->force_fp && !(c->cfg.flags & CPPROB_HIP_FLAG_FLOATING_POINT_STEP) && c->nb <= kCountsMaxTiles && c->pop_n <= (1ull << 28) &&
-           c->cfg.algorithm == CPPROB_HIP_ALG_SMC && c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && !counts_eligible<Model>(c) &&
-           (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND);
+           c->cfg.algorithm == CPPROB_HIP_ALG_SMC && !counts_eligible<Model>(c) &&
+           (systematic ? (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || own) : (own && c->cfg.resample_scope != CPPROB_HIP_SCOPE_EXCHANGE));
 }
 
 static void fhier_view(const cpprob_hip_ctx* c, int copy, FHier& f)
@@ -557,13 +560,29 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         a.bound = c->h_bound[(size_t)t]; a.bound_prev = t > 0 ? c->h_bound[(size_t)t - 1] : 0.0;
         a.ess_frac = c->cfg.ess_threshold; a.may_carry = c->cfg.ess_threshold > 1.0 ? 0 : 1;
         a.prefetch = a.may_carry ? 0 : 1;                        // (a schedule on which steps may not resample: the fetch is wasted on those, and costs registers on all)
+        const int rs = c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED ? kFixStratified : (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL ? kFixMultinomial : kFixSystematic);
+        if (rs == kFixMultinomial) {
+            // the lanes' in-tile prefixes travel with the weights (ping-pong, in the halves of the floating-point form's CDF array);
+            // the tiles' prefix masses of generation t-1 come from one short launch in front of the step
+            uint64_t* lp = reinterpret_cast<uint64_t*>(c->d_cdf);
+            a.lane_prefix_prev = lp + (size_t)c->cur * (size_t)(c->ld / kPPT); a.lane_prefix_next = lp + (size_t)(c->cur ^ 1) * (size_t)(c->ld / kPPT);
+            a.tile_prefix = reinterpret_cast<const uint64_t*>(c->d_bc);
+            a.prefetch = 0;
+            if (t > 0) {
+                ProfScope ps(c, 5);
+                hipLaunchKernelGGL(fixed_tile_prefix_kernel, dim3(1), dim3(kTilePrefixThreads), 0, c->stream, a.f.h.lvl[0], c->nb, reinterpret_cast<uint64_t*>(c->d_bc));
+            }
+        }
         a.ctrl = c->d_ctrl; a.n_pop = (double)c->pop_n; a.ess_trace = c->d_ess; a.resampled = c->d_resampled;
         a.all_totals = reinterpret_cast<const uint64_t*>(all_totals); a.world = world; a.rank = rank; a.annex_base = c->d_annex_base;
         a.row_w = c->keep ? t : (t & 1); a.row_r = t > 0 ? (c->keep ? t - 1 : ((t - 1) & 1)) : 0;
         if (!c->keep) a.anc = nullptr;
         {
             ProfScope ps(c, 0);
-            if (all_totals && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            if (rs == kFixMultinomial) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (rs == kFixStratified && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (rs == kFixStratified) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (all_totals && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (all_totals) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (a.prefetch) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (!Model::kIsInt) hipLaunchKernelGGL(smc_step_fixed_five_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);

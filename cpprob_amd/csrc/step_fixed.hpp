@@ -27,19 +27,33 @@
 namespace cph {
 
 // (fixed-point weights, 64-bit wavefront scans, the mass hierarchy, search and decision: cpprob/detail/fixed_mass.hpp)
-struct FixedLds {
+template <int RS>
+struct FixedLdsT {
     int32_t slot[kTile];          // scatter slots of the output tile
     uint64_t scan[2][kWaves];     // per-wave totals of the in-tile scan, double-buffered across source tiles
     int iscr[kWaves];
+    uint32_t ustrat[RS == kFixStratified ? kTile : 1];   // stratified: the 32-bit uniforms of the output tile's outputs
 };
+using FixedLds = FixedLdsT<kFixSystematic>;
+
+// Stratified resampling: the uniforms of the kTile outputs that start at output id `uid_first` (= FixedCdf::uid0 + the tile's first
+// output), four per lane -- one Philox block when the id is a multiple of four.  Visible behind the caller's barrier.
+__device__ __forceinline__ void stratified_stage(FixedLdsT<kFixStratified>& L, uint64_t seed, uint64_t draw, uint64_t uid_first)
+{
+    uint32_t w[kPPT];
+    draw_words4(seed, uid_first + (uint64_t)threadIdx.x * kPPT, draw, w);
+    store4(L.ustrat, (int64_t)threadIdx.x * kPPT, w);
+}
 
 // The WALK (the whole workgroup): every source tile that owns outputs of this tile rebuilds its prefix masses (one scan), each
 // source with a non-empty range writes its index into the slot of its FIRST output, one prefix-max hands every output its
 // ancestor; -1 where the ancestor belongs to a shard that precedes this one.  q_m1 / q_0 / q_p1 = the weights of tiles guess-1,
 // guess, guess+1 fetched by the caller (have = false: none were).  Slots must hold -1 and be visible on entry.
+// Stratified: L.ustrat holds the outputs' uniforms (stratified_stage), and a boundary's place in the tile is F - gj_first + [u_F < H - F].
 using U4 = unsigned int __attribute__((ext_vector_type(4)));
+template <int RS = kFixSystematic>
 __device__ __forceinline__ void fixed_walk(const FixedCdf& fc, const uint32_t* __restrict__ qprev, int64_t n, int nb, bool last_shard, double gj_first,
-                                           int n_out, const FLocated& loc, int guess, bool have, U4 q_m1, U4 q_0, U4 q_p1, int32_t (&anc)[kPPT], FixedLds& L)
+                                           int n_out, const FLocated& loc, int guess, bool have, U4 q_m1, U4 q_0, U4 q_p1, int32_t (&anc)[kPPT], FixedLdsT<RS>& L)
 {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const double gj_last = gj_first + (double)(n_out - 1);
@@ -53,11 +67,21 @@ __device__ __forceinline__ void fixed_walk(const FixedCdf& fc, const uint32_t* _
         return cc < nb ? *reinterpret_cast<const U4*>(qprev + (int64_t)cc * kTile + (int64_t)tid * kPPT) : z;
     };
     auto place = [&](double g) -> int { return (int)fmin(fmax(g - gj_first, 0.0), (double)kTile); };      // exact: integers
+    // the place, in this output tile, of the first output the sources beyond inclusive mass C own
+    auto place_of = [&](uint64_t C) -> int {
+        if constexpr (RS == kFixStratified) {
+            const double H = fc.h(C), F = floor(H), d = F - gj_first;
+            if (!(d >= 0.0)) return 0;
+            if (d >= (double)kTile) return kTile;
+            const int i = (int)d;
+            return i + (u01_32(L.ustrat[i]) < H - F ? 1 : 0);
+        } else return place(fc.g(C));
+    };
     U4 raw = load_q(c);
     int it = 0;
     while (c < nb && c <= c_last) {
         // (wave-uniform values -- the branches are made scalar so that the barrier inside the loop sits in uniform control flow)
-        if (c_last >= nb && __builtin_amdgcn_readfirstlane(fc.g(P) > gj_last ? 1 : 0)) break;      // the last tile is not known from the probe
+        if (c_last >= nb && __builtin_amdgcn_readfirstlane(fc.template first<RS>(P) > gj_last ? 1 : 0)) break;      // the last tile is not known from the probe
         const U4 raw_next = c < c_last ? load_q(c + 1) : U4{0u, 0u, 0u, 0u};
         const bool edge = c == nb - 1;
         const int nvt = edge ? (int)(n - (int64_t)c * kTile) : kTile;   // valid particles of this tile (padding slots weigh 0)
@@ -75,10 +99,10 @@ __device__ __forceinline__ void fixed_walk(const FixedCdf& fc, const uint32_t* _
         const uint64_t excl = P + off + incl - run;                     // mass before this lane's first particle
         const int src0 = c * kTile + vb;
         const int p_all = (edge && last_shard) ? place(fc.n_pop) : 0;
-        int p_prev = place(fc.g(excl));
+        int p_prev = place_of(excl);
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) {
-            int p = place(fc.g(excl + pre[k]));
+            int p = place_of(excl + pre[k]);
             if (edge && last_shard && vb + k + 1 == nvt) p = p_all;      // the population's last source owns the rest
             if (edge && vb + k + 1 > nvt) p = p_prev;                   // padding slots own nothing
             if (p > p_prev) { L.slot[p_prev] = src0 + k; p_prev = p; }
@@ -126,7 +150,7 @@ __device__ __forceinline__ FixedRanks fixed_ranks(const uint64_t* __restrict__ a
     return r;
 }
 
-struct FixedFound { FLocated loc; double inv, ref; uint64_t base; int64_t l0, l1; int resample; };     // the searching wavefront's hand-over
+struct FixedFound { FLocated loc; double inv, ref; uint64_t base, S; int64_t l0, l1; int resample; };     // the searching wavefront's hand-over
 
 template <class Model>
 struct StepFixedArgs {
@@ -146,7 +170,89 @@ struct StepFixedArgs {
     const uint64_t* all_totals; int world, rank;       // one shard of a joint population (exchange scope): every rank's {S, Q, key(M)} of generation t-1
     const int64_t* annex_base;
     int row_w, row_r;
+    // multinomial resampling: exclusive prefix masses of generation t-1's tiles ([nb + 1]: fixed_tile_prefix_kernel) and the
+    // in-tile inclusive prefix at the end of every lane's four particles ([ld / 4]), read for generation t-1 / written for generation t
+    const uint64_t* tile_prefix; const uint64_t* lane_prefix_prev; uint64_t* lane_prefix_next;
 };
+
+// ---- multinomial resampling on integer masses (thesis Alg. 1 p.36: a_j ~ Categorical(W)) ---------------------------------------
+// Output j draws its own 53-bit uniform u = b 2^-53 (the words draw_u01_53 takes: pair id & 1 of block id >> 1) and its threshold is
+// the INTEGER tau_j = floor(u C_N) = mulhi64(b << 11, C_N); its ancestor is min{k : C_k > tau_j}.  No rounding anywhere, tau_j < C_N
+// always.  The thresholds are unsorted, so every output searches on its own: the tile by a binary search of the tiles' exclusive
+// prefix masses, the lane inside the tile by a binary search of the lanes' inclusive prefixes (what the producing step left beside
+// the weights: 2 bytes a particle), the particle among the lane's four weights.
+// Exclusive prefix masses of the tiles of one generation: out[c] = mass of tiles 0 .. c-1, out[nb] = C_N.  One workgroup.
+constexpr int kTilePrefixThreads = 1024;
+__global__ __launch_bounds__(kTilePrefixThreads) void fixed_tile_prefix_kernel(const uint64_t* __restrict__ tile_mass, int nb, uint64_t* __restrict__ out)
+{
+    __shared__ uint64_t s_w[kTilePrefixThreads / kWave];
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    uint64_t carry = 0;
+    for (int base = 0; base < nb; base += kTilePrefixThreads) {
+        const int i = base + tid;
+        const uint64_t v = i < nb ? (tile_mass[i] & kMassMask) : 0ull;
+        const uint64_t incl = wave_incl_scan_u64(v);
+        if (lane == kWave - 1) s_w[wv] = incl;
+        __syncthreads();
+        uint64_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kTilePrefixThreads / kWave; ++w) { const uint64_t x = s_w[w]; if (w < wv) off += x; tot += x; }
+        if (i < nb) out[i] = carry + off + incl - v;
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) out[nb] = carry;
+}
+
+// Ancestors of the four outputs whose ids start at `uid` (a multiple of four).  S = C_N > 0.
+__device__ __forceinline__ void fixed_multinomial_ancestors(uint64_t S, uint64_t seed, uint64_t draw, uint64_t uid, const uint64_t* __restrict__ tile_prefix, int nb,
+                                                            const uint64_t* __restrict__ lane_prefix, const uint32_t* __restrict__ q, int32_t (&anc)[kPPT])
+{
+    static_assert(kPPT == 4, "two Philox blocks a lane");
+    const u32x4 b0 = draw_block(seed, uid >> 1, draw), b1 = draw_block(seed, (uid >> 1) + 1, draw);
+    uint64_t tau[kPPT];
+    tau[0] = __umul64hi(bits53(b0.x, b0.y) << 11, S); tau[1] = __umul64hi(bits53(b0.z, b0.w) << 11, S);
+    tau[2] = __umul64hi(bits53(b1.x, b1.y) << 11, S); tau[3] = __umul64hi(bits53(b1.z, b1.w) << 11, S);
+    // the tile: the largest c with prefix[c] <= tau (prefix[0] = 0 <= tau < prefix[nb] = S); four searches side by side
+    int lo[kPPT], hi[kPPT];
+    uint64_t at[kPPT];
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) { lo[k] = 0; hi[k] = nb; at[k] = 0; }
+    const int iters = nb > 1 ? 32 - __builtin_clz((unsigned)(nb - 1)) : 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const int mid = (lo[k] + hi[k]) >> 1;
+            const uint64_t v = tile_prefix[mid];
+            if (v <= tau[k]) { lo[k] = mid; at[k] = v; } else hi[k] = mid;
+        }
+    }
+    // the lane: the first l with P[l] > rem (P[255] = the tile's mass > rem)
+    int a[kPPT], b[kPPT];
+    uint64_t rem[kPPT], below[kPPT];
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) { a[k] = 0; b[k] = kThreads - 1; rem[k] = tau[k] - at[k]; below[k] = 0; }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) {
+            const int mid = (a[k] + b[k]) >> 1;
+            const uint64_t v = lane_prefix[(int64_t)lo[k] * kThreads + mid];
+            if (v > rem[k]) b[k] = mid; else { a[k] = mid + 1; below[k] = v; }
+        }
+    }
+    static_assert(kThreads == 256, "eight halvings of a tile's 256 lanes");
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        const int l = a[k] < kThreads ? a[k] : kThreads - 1;                 // (a population without mass: nothing to find)
+        const int64_t i0 = (int64_t)lo[k] * kTile + (int64_t)l * kPPT;
+        const U4 w = *reinterpret_cast<const U4*>(q + i0);
+        uint64_t r = rem[k] - below[k];
+        int j = 0;
+        if (r >= w[0]) { r -= w[0]; j = 1; if (r >= w[1]) { r -= w[1]; j = 2; if (r >= w[2]) j = 3; } }
+        anc[k] = (int32_t)(i0 + j);
+    }
+}
 
 // Bookkeeping of generation t-1 for the host (one thread): ESS, decision, evidence.  ref_prev = R_{t-1}.
 __device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const FixedDecision& d, double ref_prev, double n_pop, double u0, double* ess_trace,
@@ -167,12 +273,13 @@ __device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const Fi
     if (resampled) resampled[t_prev] = d.resample ? 1 : 0;
 }
 
-template <class Model, bool SHARDED, bool PREFETCH>
+template <class Model, bool SHARDED, bool PREFETCH, int RS = kFixSystematic>
 __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& a)
 {
     using V = typename Model::value_t;
     using S = typename Model::store_t;
-    __shared__ FixedLds L;
+    static_assert(!(RS == kFixMultinomial && (SHARDED || PREFETCH)), "multinomial resampling: one population per context, no source tiles to fetch ahead");
+    __shared__ FixedLdsT<RS> L;
     __shared__ __attribute__((aligned(16))) FixedFound s_found;
     __shared__ uint64_t s_red[3 * kWaves];
     const int tid = threadIdx.x;
@@ -237,6 +344,10 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
         const bool last_shard = SHARDED ? a.rank + 1 == a.world : true;
         FixedCdf fc;
         fc.u0 = a.u0; fc.n_pop = a.n_pop; fc.base = 0; fc.inv = 0.0;
+        // (the resampling's own uniforms: ids are population-wide in a sharded run; a population of its own offsets them by pid0,
+        //  which there only selects streams)
+        fc.seed = a.seed; fc.draw = kResampleDrawBase + (uint64_t)t; fc.uid0 = SHARDED ? 0 : a.pid0;
+        if constexpr (RS == kFixStratified) stratified_stage(L, fc.seed, fc.draw, fc.uid0 + (uint64_t)gj_first);
         if (searcher) {
             uint64_t St, Qt; double Mt; uint64_t before = 0;
             const FTot own = ftot_sum(a.f, tw);
@@ -255,24 +366,26 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
             }
             FLocated loc{0, 0, 0};
             int64_t l0 = 0, l1 = a.n;
-            if (d.resample) {
-                loc = fixed_locate(a.f, fc, nb, gj_first, n_out, guess, &pw0);
+            if (d.resample && RS != kFixMultinomial) {
+                loc = fixed_locate<RS>(a.f, fc, nb, gj_first, n_out, guess, &pw0);
                 if (SHARDED) {
                     // outputs below o_lo / at or beyond o_hi descend from other shards' sources
-                    const double o_lo = fc.g(0), o_hi = last_shard ? a.n_pop : fc.g(own.S);
+                    const double o_lo = fc.template first<RS>(0), o_hi = last_shard ? a.n_pop : fc.template first<RS>(own.S);
                     const double sb = (double)a.pid0;
                     l0 = (int64_t)fmin(fmax(o_lo - sb, 0.0), (double)a.n); l1 = (int64_t)fmin(fmax(o_hi - sb, 0.0), (double)a.n);
                 }
             }
-            if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.ref = r_t; s_found.base = before; s_found.l0 = l0; s_found.l1 = l1; s_found.resample = d.resample ? 1 : 0; }
+            if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.ref = r_t; s_found.base = before; s_found.S = St; s_found.l0 = l0; s_found.l1 = l1; s_found.resample = d.resample ? 1 : 0; }
         }
         __syncthreads();                                               // slots reset, search results in place
     CPH_STAMP(2);
         resample = s_found.resample != 0;
         ref = s_found.ref;
-        if (resample) {
+        if (resample && RS == kFixMultinomial) {
+            fixed_multinomial_ancestors(s_found.S, fc.seed, fc.draw, fc.uid0 + (uint64_t)j0, a.tile_prefix, nb, a.lane_prefix_prev, a.q_prev, anc);
+        } else if (resample) {
             fc.inv = s_found.inv; fc.base = s_found.base;
-            fixed_walk(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, guess, PREFETCH, q_m1, q_0, q_p1, anc, L);
+            fixed_walk<RS>(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, guess, PREFETCH, q_m1, q_0, q_p1, anc, L);
             if (SHARDED) {
                 const int64_t l0 = s_found.l0, l1 = s_found.l1;
                 const int64_t col0 = a.ld + a.annex_base[t - 1];
@@ -332,9 +445,17 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
     // published BEFORE this workgroup's weight / log-weight stores are issued: the hierarchy's atomics -- and, above 4096 tiles, the
     // wait in front of the arrival count -- travel under them instead of behind them
     CPH_STAMP(5);
-    const uint64_t s_w = wave_sum_u34(s_l), q_w = wave_sum_u34(q_l), m_w = wave_max_key(dkey(m_l));     // (sums of four 32-bit terms)
+    const uint64_t s_incl = RS == kFixMultinomial ? wave_incl_scan_u34(s_l) : 0ull;                     // (multinomial: the lanes' prefixes)
+    const uint64_t s_w = RS == kFixMultinomial ? read_lane_u64(s_incl, kWave - 1) : wave_sum_u34(s_l);
+    const uint64_t q_w = wave_sum_u34(q_l), m_w = wave_max_key(dkey(m_l));                              // (sums of four 32-bit terms)
     if (lane_id() == 0) { s_red[wave_id()] = s_w; s_red[kWaves + wave_id()] = q_w; s_red[2 * kWaves + wave_id()] = m_w; }
     __syncthreads();
+    if constexpr (RS == kFixMultinomial) {
+        uint64_t off = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) if (w < wave_id()) off += s_red[w];
+        a.lane_prefix_next[(int64_t)bid * kThreads + tid] = off + s_incl;
+    }
     if (tid == 0) {
         uint64_t St = 0, Qt = 0, Mk = 0;
 #pragma unroll
@@ -351,8 +472,8 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
 }
 
 // One population on this GPU.  PREFETCH: the three likely source tiles' weights are fetched at kernel entry (every-step schedules).
-template <class Model, bool PREFETCH>
-__global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, false, PREFETCH>(a); }
+template <class Model, bool PREFETCH, int RS = kFixSystematic>
+__global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, false, PREFETCH, RS>(a); }
 // The continuous models without the prefetch sit one register above five wavefronts a SIMD: told to fit (one spilled dword), 1221
 // workgroups -- 1.25 10^6 particles -- run in one pass.
 template <class Model>

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "cpprob/detail/fastmath.hpp"
+#include "cpprob/detail/rng.hpp"
 #include "cpprob/detail/wave.hpp"
 
 namespace cph {
@@ -220,11 +221,35 @@ __device__ __forceinline__ uint64_t fhier_prefix_sum(int c, const uint64_t (&w)[
     return wave_sum_u64(s);
 }
 
-// The systematic comb on integer masses.  base = mass of the shards that precede this one (0 on one GPU).
+// Which outputs a prefix of the sources owns, on integer masses.  base = mass of the shards that precede this one (0 on one GPU).
+//   systematic (kFixSystematic): one shared offset u0; the sources up to inclusive mass C own the outputs below
+//        G = ceil(fma(double(C), N / double(C_N), -u0));
+//   stratified (kFixStratified): output j sits at j + u_j, u_j = the 32-bit uniform of OUTPUT j (word id & 3 of Philox block id >> 2,
+//        id = uid0 + j, draw kResampleDrawBase + step); the sources up to C reach H = double(C) * (N / double(C_N)) (one rounded
+//        product) and own the outputs with j + u_j < H -- a prefix, because j + u_j increases with j:
+//        A = F + [u_F < H - F],  F = floor(H)   (H - F and the comparison are exact);
+//   multinomial (kFixMultinomial): no prefix structure -- fixed_multinomial_* below.
+// Both are functions of the exact integer C alone, so tiles, wavefronts and shards may evaluate them in any order.
+constexpr int kFixSystematic = 0, kFixStratified = 1, kFixMultinomial = 2;
 struct FixedCdf {
     double inv, u0, n_pop; uint64_t base;
-    // first output owned by the sources that follow a LOCAL inclusive mass C
+    uint64_t seed, draw, uid0;                 // stratified: the run's Philox key, the resampling's draw index, the id of output 0
+    // first output NOT owned by the sources up to a LOCAL inclusive mass C = first output owned by the sources that follow
     __device__ __forceinline__ double g(uint64_t C) const { return ceil(fma(u64_to_double(base + C), inv, -u0)); }
+    __device__ __forceinline__ double h(uint64_t C) const { return __dmul_rn(u64_to_double(base + C), inv); }
+    __device__ __forceinline__ double first_stratified(uint64_t C) const
+    {
+        const double H = h(C), F = floor(H);
+        if (F >= n_pop) return n_pop;
+        const double u = u01_32(draw_word(seed, uid0 + (uint64_t)F, draw));
+        return u < H - F ? F + 1.0 : F;
+    }
+    template <int RS>
+    __device__ __forceinline__ double first(uint64_t C) const
+    {
+        if constexpr (RS == kFixStratified) return first_stratified(C);
+        else return g(C);
+    }
 };
 
 // This tile's words of generation t's hierarchy, added into the levels above, and the entries of the third copy this tile is
@@ -294,6 +319,7 @@ __device__ __forceinline__ void fhier_publish_part(const FHier& f, int bid, int 
 
 // Largest tile c in [0, nb) whose first owned output G(prefix(c)) is <= g (0 when there is none), with its exclusive prefix mass:
 // top-down descent, one load + one scan per level (step_counts.hpp: hier_locate).
+template <int RS = kFixSystematic>
 __device__ __forceinline__ int fhier_locate(const HierTable* __restrict__ ht, int copy, const FixedCdf& fc, double g, uint64_t& P)
 {
     const int lane = lane_id();
@@ -306,7 +332,7 @@ __device__ __forceinline__ int fhier_locate(const HierTable* __restrict__ ht, in
         if (in) w = ht->lvl[copy][l][(int64_t)idx * (l == 0 ? 1 : kHierStride)] & kMassMask;
         const uint64_t incl = wave_incl_scan_u64(w);
         const uint64_t x = p + incl - w;                                                       // exclusive prefix at child `lane`
-        const bool ok = in && fc.g(x) <= g;
+        const bool ok = in && fc.template first<RS>(x) <= g;
         const unsigned long long m = __ballot(ok);
         const int child = m ? (63 - __builtin_clzll(m)) : 0;                                     // (G is monotone: the set is a prefix)
         p = read_lane_u64(x, child);
@@ -320,6 +346,7 @@ struct FLocated { int c, c_last; uint64_t P; };
 
 // The SEARCH (one wavefront): first source tile of the output tile that starts at global output gj_first, its exclusive prefix
 // mass, and the last source tile (nb when the probe cannot tell).  As counts_locate.
+template <int RS = kFixSystematic>
 __device__ __forceinline__ FLocated fixed_locate(const FHier& f, const FixedCdf& fc, int nb, double gj_first, int n_out, int guess, const ProbeWords* first)
 {
     const int lane = lane_id();
@@ -332,7 +359,7 @@ __device__ __forceinline__ FLocated fixed_locate(const FHier& f, const FixedCdf&
         const uint64_t we = (lane < 4 && cs + lane < nb) ? (pw.we & kMassMask) : 0ull;
         const uint64_t incl = wave_incl_scan_u64(we);
         const uint64_t x = Pc + incl - we;                               // lanes 0..4: the prefix at cs + lane
-        const double gt = fc.g(x);
+        const double gt = fc.template first<RS>(x);
         const bool known = lane < 5 && cs + lane < nb;
         const unsigned long long m = __ballot(known && gt <= gj_first);
         const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
@@ -359,7 +386,7 @@ __device__ __forceinline__ FLocated fixed_locate(const FHier& f, const FixedCdf&
         const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
         ProbeWords pw;
         probe_fetch(f.h, at, nb, pw);
-        if (!probe(at, pw, d)) { c = fhier_locate(f.h.table, f.h.copy, fc, gj_first, P); c_last = nb; }
+        if (!probe(at, pw, d)) { c = fhier_locate<RS>(f.h.table, f.h.copy, fc, gj_first, P); c_last = nb; }
     }
     return FLocated{c, c_last, P};
 }

@@ -673,6 +673,84 @@ ORC_API int orc_resample_fixed_systematic(const uint32_t *q, uint64_t n_in, uint
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Stratified resampling on the same integer masses (thesis p.36 remark; the   */
+/* build's own arithmetic, cpprob_amd/include/cpprob/detail/fixed_mass.hpp).    */
+/* Output j sits at position j + u_j, u_j = word_j 2^-32 the 32-bit uniform of  */
+/* OUTPUT j (word j & 3 of block j >> 2, draw RESAMPLE_BASE + step), and source */
+/* k reaches up to H_k = double(C_k) * (N / double(C_N)) (one rounded product). */
+/* j + u_j increases with j, so the outputs below H_k form a prefix:            */
+/*     A_k = #{j : j + u_j < H_k} = F + [u_F < H_k - F],  F = floor(H_k)         */
+/* (H_k - F is exact, the comparison is exact), ancestor of j = min{k : A_k > j},*/
+/* A of the population's last source = N.  A_k is a function of the exact        */
+/* integer C_k alone: tiles, wavefronts and shards may take the sources in any   */
+/* order.  The sequential-CDF form this restates: orc_resample(STRATIFIED).      */
+/* ------------------------------------------------------------------------- */
+static double fixed_stratified_first(uint64_t c, double inv, double N, uint64_t seed, uint64_t step)
+{
+    const double H = (double)c * inv;
+    const double F = floor(H);
+    if (F >= N) return N;
+    const double u = orc_u01_32(orc_draw_word(seed, (uint64_t)F, ORC_RESAMPLE_DRAW_BASE + step));
+    return u < H - F ? F + 1.0 : F;
+}
+
+ORC_API int orc_resample_fixed_stratified(const uint32_t *q, uint64_t n_in, uint64_t before, uint64_t total, int last_shard,
+                                          uint64_t seed, uint64_t step, uint64_t j0, uint64_t n_out, uint64_t n_total_out, int32_t *anc)
+{
+    const double N = (double)n_total_out;
+    const double inv = N / (double)total;
+    uint64_t c = before;
+    for (uint64_t jj = 0; jj < n_out; ++jj) anc[jj] = -1;
+    double g_prev = fixed_stratified_first(c, inv, N, seed, step);
+    for (uint64_t k = 0; k < n_in; ++k) {
+        c += q[k];
+        double g = fixed_stratified_first(c, inv, N, seed, step);
+        if (last_shard && k + 1 == n_in) g = N;
+        for (double j = g_prev; j < g; j += 1.0)
+            if (j >= (double)j0 && j < (double)(j0 + n_out)) anc[(uint64_t)j - j0] = (int32_t)k;
+        if (g > g_prev) g_prev = g;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Multinomial resampling (thesis Alg. 1 p.36: a_j ~ Categorical(W)) on the     */
+/* same integer masses.  Output j draws the 53-bit uniform of OUTPUT j           */
+/* (orc_draw_u01_53's words: u = b 2^-53) and its threshold is the integer       */
+/*     tau_j = floor(u C_N) = floor(b C_N / 2^53)     (a 128-bit product),        */
+/* ancestor of j = min{k : C_k > tau_j}: no rounding anywhere, tau_j < C_N       */
+/* always.  before = mass of the shards that precede these n_in sources; outputs */
+/* whose ancestor is not among them get -1.  The sequential-CDF form:            */
+/* orc_resample(MULTINOMIAL).                                                    */
+/* ------------------------------------------------------------------------- */
+ORC_API uint64_t orc_multinomial_threshold(uint64_t seed, uint64_t j, uint64_t step, uint64_t total)
+{
+    uint32_t r[4];
+    orc_draw_block(seed, j >> 1, ORC_RESAMPLE_DRAW_BASE + step, r);
+    const uint64_t b = (j & 1) ? bits53(r[2], r[3]) : bits53(r[0], r[1]);
+    return (uint64_t)(((unsigned __int128)(b << 11) * total) >> 64);
+}
+
+ORC_API int orc_resample_fixed_multinomial(const uint32_t *q, uint64_t n_in, uint64_t before, uint64_t total,
+                                           uint64_t seed, uint64_t step, uint64_t j0, uint64_t n_out, int32_t *anc)
+{
+    uint64_t *cdf = (uint64_t *)malloc((n_in ? n_in : 1) * sizeof(uint64_t));
+    if (!cdf) return -1;
+    uint64_t c = before;
+    for (uint64_t k = 0; k < n_in; ++k) { c += q[k]; cdf[k] = c; }
+    for (uint64_t jj = 0; jj < n_out; ++jj) {
+        const uint64_t tau = orc_multinomial_threshold(seed, j0 + jj, step, total);
+        anc[jj] = -1;
+        if (tau < before || tau >= c) continue;
+        uint64_t lo = 0, hi = n_in;               /* first k with cdf[k] > tau */
+        while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (cdf[mid] > tau) hi = mid; else lo = mid + 1; }
+        anc[jj] = (int32_t)lo;
+    }
+    free(cdf);
+    return 0;
+}
+
 /* e[s] = exp(ll_s - max ll) of step t of the HMM: the table the weights of generation t are drawn from */
 static void hmm_weight_table(double y, double e[3], double *mref)
 {
@@ -696,12 +774,14 @@ static void hmm_weight_table(double y, double e[3], double *mref)
 /* ------------------------------------------------------------------------- */
 /* filter_stats (optional, [T][K]): predict hit t under generation t's OWN weights -- P(x_t = s) (HMM, K = 3) or {mean, variance}
  * (K = 2) -- what a filtering-only run (keep_history = 0) reports instead of the whole-trace posterior. */
-/* ref_mode (systematic resampling only; cpprob_amd/include/cpprob/gpu.hpp: the unchanged-model path's step forms):
+/* ref_mode (cpprob_amd/include/cpprob/gpu.hpp: the unchanged-model path's step forms):
  *   0  as above: the model's own bound (table form for the 3-state HMM on an every-step schedule);
  *   1  fixed-point form for every model, B_t = the observe statement's density at its mode, logpdf(N(m, 1), m) -- what the host's
  *      structural dry run records for `observe(normal_distribution<>{m, 1}, y_t)` (models.hpp:76-77,138-139);
  *   2  fixed-point form for every model, R_t = the generation's exact maximum (no bound: cpprob_hip_smc_bookkeep_fixed,
- *      cpprob_hip_generic_quantize). */
+ *      cpprob_hip_generic_quantize);
+ *   3  the floating-point form of every resampler (orc_resample: a sequential fp64 CDF) -- what CPPROB_HIP_FLAG_FLOATING_POINT_STEP
+ *      runs, up to the summation order of its parallel scan. */
 static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint64_t seed,
                         int resampler, double ess_frac,
                         double *hist_real, int32_t *hist_int, int32_t *hist_anc,
@@ -718,15 +798,21 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
     if (!logw || !cdf || !anc) return -1;
     double lz = 0.0;
     int do_resample = 0;
-    /* systematic resampling of continuous weights / on an ESS-triggered schedule: the fixed-point form (above) */
-    const int fixed = resampler == ORC_RESAMPLE_SYSTEMATIC && (ref_mode != 0 || !(model == ORC_MODEL_HMM3 && ess_frac > 1.0));
+    /* every resampler runs on integer masses (the fixed-point forms above) -- except systematic resampling of the 3-state HMM on an
+     * every-step schedule, which runs on integer prefix COUNTS (the table form), and ref_mode 3, the floating-point CDF */
+    const int table = resampler == ORC_RESAMPLE_SYSTEMATIC && model == ORC_MODEL_HMM3 && ess_frac > 1.0 && ref_mode == 0;
+    const int fixed = ref_mode != 3 && !table;
     uint32_t *qw = fixed ? (uint32_t *)malloc(n * sizeof(uint32_t)) : NULL;
     uint64_t q_total = 0;
     double m_prev = 0.0;
     for (size_t t = 0; t < T; ++t) {
         if (do_resample && fixed) {
-            if (orc_resample_fixed_systematic(qw, n, 0, q_total, 1, seed, (uint64_t)t, 0, n, n, anc)) return -4;
-        } else if (do_resample && model == ORC_MODEL_HMM3 && resampler == ORC_RESAMPLE_SYSTEMATIC && ess_frac > 1.0 && ref_mode == 0) {
+            int rc;
+            if (resampler == ORC_RESAMPLE_SYSTEMATIC) rc = orc_resample_fixed_systematic(qw, n, 0, q_total, 1, seed, (uint64_t)t, 0, n, n, anc);
+            else if (resampler == ORC_RESAMPLE_STRATIFIED) rc = orc_resample_fixed_stratified(qw, n, 0, q_total, 1, seed, (uint64_t)t, 0, n, n, anc);
+            else rc = orc_resample_fixed_multinomial(qw, n, 0, q_total, seed, (uint64_t)t, 0, n, anc);
+            if (rc) return -4;
+        } else if (do_resample && table) {
             /* every step resamples: generation t-1 carries table weights -> the order-independent form */
             double e[3];
             uint64_t before[3] = { 0, 0, 0 }, total[3] = { 0, 0, 0 };
@@ -818,7 +904,7 @@ ORC_API int orc_smc_ref(int model, const double *obs, size_t T, uint64_t n, uint
                         double *hist_real, int32_t *hist_int, int32_t *hist_anc,
                         double *logw_final, double *log_z, double *ess_trace, int32_t *resampled)
 {
-    if (ref_mode < 0 || ref_mode > 2) return -6;
+    if (ref_mode < 0 || ref_mode > 3) return -6;
     return orc_smc_impl(model, obs, T, n, seed, resampler, ess_frac, hist_real, hist_int, hist_anc, logw_final, log_z, ess_trace, resampled, NULL, ref_mode);
 }
 

@@ -65,6 +65,11 @@ def lib():
         L.orc_fix_weights.argtypes = [_dp, u64, dbl, _up]
         L.orc_resample_fixed_systematic.restype = C.c_int
         L.orc_resample_fixed_systematic.argtypes = [_up, u64, u64, u64, C.c_int, u64, u64, u64, u64, u64, _ip]
+        L.orc_resample_fixed_stratified.restype = C.c_int
+        L.orc_resample_fixed_stratified.argtypes = [_up, u64, u64, u64, C.c_int, u64, u64, u64, u64, u64, _ip]
+        L.orc_resample_fixed_multinomial.restype = C.c_int
+        L.orc_resample_fixed_multinomial.argtypes = [_up, u64, u64, u64, u64, u64, u64, u64, _ip]
+        L.orc_multinomial_threshold.restype = u64; L.orc_multinomial_threshold.argtypes = [u64, u64, u64, u64]
         L.orc_set_hmm.restype = C.c_int; L.orc_set_hmm.argtypes = [C.c_int, _dp, _dp]
         L.orc_smc.restype = C.c_int
         L.orc_smc.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
@@ -213,6 +218,37 @@ def resample_fixed_systematic(q, seed, step, before=0, total=None, last_shard=Tr
     return anc
 
 
+def resample_fixed_stratified(q, seed, step, before=0, total=None, last_shard=True, j0=0, n_out=None, n_total_out=None):
+    """Stratified resampling on integer weights (orc_resample_fixed_stratified): ancestors of the outputs [j0, j0 + n_out) among the
+    sources q; -1 where the ancestor is on another shard."""
+    q = np.ascontiguousarray(q, np.uint32)
+    total = int(q.astype(np.uint64).sum()) if total is None else int(total)
+    n_out = len(q) if n_out is None else n_out
+    n_total_out = len(q) if n_total_out is None else n_total_out
+    anc = np.zeros(n_out, np.int32)
+    rc = lib().orc_resample_fixed_stratified(q, len(q), int(before), total, int(bool(last_shard)), seed, step, j0, n_out, n_total_out, anc)
+    if rc:
+        raise RuntimeError("orc_resample_fixed_stratified failed rc=%d" % rc)
+    return anc
+
+
+def resample_fixed_multinomial(q, seed, step, before=0, total=None, j0=0, n_out=None):
+    """Multinomial resampling on integer weights (orc_resample_fixed_multinomial): tau_j = floor(u_j C_N), ancestor = min{k : C_k > tau_j};
+    -1 where the ancestor is on another shard."""
+    q = np.ascontiguousarray(q, np.uint32)
+    total = int(q.astype(np.uint64).sum()) if total is None else int(total)
+    n_out = len(q) if n_out is None else n_out
+    anc = np.zeros(n_out, np.int32)
+    rc = lib().orc_resample_fixed_multinomial(q, len(q), int(before), total, seed, step, j0, n_out, anc)
+    if rc:
+        raise RuntimeError("orc_resample_fixed_multinomial failed rc=%d" % rc)
+    return anc
+
+
+def multinomial_threshold(seed, j, step, total):
+    return int(lib().orc_multinomial_threshold(seed, j, step, int(total)))
+
+
 def smoothing_linear(hist, anc, w, k=3):
     """StatsPrinter's numbers over the lineages for given LINEAR final weights (the fixed-point form's q)."""
     path = lineage(np.ascontiguousarray(anc))
@@ -251,7 +287,7 @@ def smc(model, obs, n, seed, resampler=RESAMPLE_SYSTEMATIC, ess_frac=2.0):
     return dict(hist=hist, anc=anc, logw=logw, log_z=lz.value, ess=ess, resampled=res, filter=filt)
 
 
-REF_MODEL_BOUND, REF_STATEMENT_BOUND, REF_EXACT_MAX = 0, 1, 2
+REF_MODEL_BOUND, REF_STATEMENT_BOUND, REF_EXACT_MAX, REF_FLOATING_POINT = 0, 1, 2, 3
 
 
 def smc_ref(model, obs, n, seed, ref_mode, resampler=RESAMPLE_SYSTEMATIC, ess_frac=2.0):

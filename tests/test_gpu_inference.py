@@ -140,20 +140,14 @@ def _compare_smc(engine, model, obs, n, seed, resampler, ess):
     assert np.array_equal(gres, ref["resampled"])
     np.testing.assert_allclose(gess, ref["ess"], rtol=1e-6)
     T = len(obs)
-    # ancestors / states: identical except for (rare) CDF-boundary flips caused by the different
-    # summation order of the parallel scan; a flipped particle stays different afterwards.
-    frac_anc = np.mean(anc != ref["anc"])
-    assert frac_anc < 2e-4, frac_anc
-    if resampler == cp.RESAMPLE_SYSTEMATIC:
-        # systematic resampling runs on integers -- prefix counts (table weights, every-step schedule) or fixed-point weights
-        # (continuous weights, ESS-triggered schedules): the index work is bit-exact against the oracle's statement of the same arithmetic
-        assert np.array_equal(anc, ref["anc"])
-        if model == cp.MODEL_HMM3:
-            assert np.array_equal(vals, ref["hist"])
-    if vals.dtype == np.int32:
-        assert np.mean(vals != ref["hist"]) < 1e-3
+    # every resampler runs on integers -- prefix counts (table weights, every-step schedule, systematic) or fixed-point masses
+    # (everything else: systematic comb, stratified positions j + u_j, multinomial thresholds floor(u_j C_N)): the index work is
+    # bit-exact against the oracle's statement of the same arithmetic
+    assert np.array_equal(anc, ref["anc"]), np.mean(anc != ref["anc"])
+    if model == cp.MODEL_HMM3:
+        assert np.array_equal(vals, ref["hist"])
     else:
-        assert np.mean(np.abs(vals - ref["hist"]) > 1e-9) < 1e-3
+        np.testing.assert_allclose(vals, ref["hist"], rtol=0, atol=1e-9)
     s = engine.summary()
     assert abs(s["log_evidence"] - ref["log_z"]) < 1e-6
     assert s["n_resampled"] == int(ref["resampled"].sum())
@@ -223,11 +217,42 @@ def test_smc_hmm_every_step_floating_point_form_stays_within_its_flip_bound(engi
     assert np.abs(engine.stats() - O.smoothing(ref["hist"], ref["anc"], ref["logw"])).max() < 5e-3
 
 
-@pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_MULTINOMIAL])
+@pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_STRATIFIED, cp.RESAMPLE_MULTINOMIAL])
 @pytest.mark.parametrize("ess", [2.0, 0.5])
 def test_smc_lgssm_matches_oracle(engine, golden_dir, resampler, ess):
     obs = _obs(golden_dir, "lgssm100")[:25]
     _compare_smc(engine, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, 20000, 5, resampler, ess)
+
+
+@pytest.mark.parametrize("resampler", [cp.RESAMPLE_STRATIFIED, cp.RESAMPLE_MULTINOMIAL])
+@pytest.mark.parametrize("model,key,T,ess,n", [(cp.MODEL_HMM3, "hmm16", 16, 2.0, 30_000), (cp.MODEL_HMM3, "hmm16", 16, 2.0, 1_200_000),
+                                               (cp.MODEL_HMM3, "hmm16", 8, 0.5, 4_300_000), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 12, 2.0, 1_250_000),
+                                               (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 20, 0.5, 300_001)])
+def test_smc_stratified_and_multinomial_are_bit_exact_against_the_oracle(engine, golden_dir, resampler, model, key, T, ess, n):
+    """Stratified and multinomial resampling (thesis Alg. 1 p.36 is multinomial) on the integer masses of the fixed-point form
+    (cpprob/detail/fixed_mass.hpp: FixedCdf::first_stratified, csrc/step_fixed.hpp: fixed_multinomial_ancestors; oracle:
+    orc_resample_fixed_stratified / orc_resample_fixed_multinomial): ancestors, decisions and the HMM's states equal the oracle's
+    at one, two and three levels of the mass hierarchy, on every-step and ESS-triggered schedules."""
+    obs = _obs(golden_dir, key)[:T]
+    engine.begin(cp.ALG_SMC, model, obs, n, seed=13, resampler=resampler, ess_threshold=ess)
+    engine.run()
+    s = engine.summary()
+    assert s["step_form"] == cp.capi.FORM_FIXED
+    ref = O.smc(model, obs, n, 13, resampler, ess)
+    anc, vals = engine.ancestors(), engine.values()
+    gess, gres = engine.step_trace()
+    assert np.array_equal(gres, ref["resampled"])
+    assert np.array_equal(anc, ref["anc"]), [int(np.count_nonzero(anc[t] != ref["anc"][t])) for t in range(T)]
+    if model == cp.MODEL_HMM3:
+        assert np.array_equal(vals, ref["hist"])
+    else:
+        np.testing.assert_allclose(vals, ref["hist"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gess, ref["ess"], rtol=1e-9)
+    assert abs(s["log_evidence"] - ref["log_z"]) < 1e-9
+    if resampler == cp.RESAMPLE_STRATIFIED:
+        assert all(np.all(np.diff(anc[t]) >= 0) for t in range(1, T))
+    sm_self = O.smoothing_linear(vals, anc, O.fix_weights(engine.logw(), s["max_logw"]).astype(np.float64))
+    np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-10, atol=1e-12)
 
 
 @pytest.mark.parametrize("n", [1, 2, 1023, 1025, 4095, 4097, 12289])
@@ -323,10 +348,9 @@ def test_filtering_only_run_weight_sums_form(engine, golden_dir, model, key, ess
     s, st = engine.summary(), engine.stats()
     assert s["log_evidence"] == keep["log_evidence"] and s["n_resampled"] == keep["n_resampled"]
     np.testing.assert_allclose(st[-1], keep_stats[-1], rtol=1e-9, atol=1e-12)
-    # the oracle's filtering statistics of the same particles (a boundary flip of the parallel CDF moves one particle in 3e5;
-    # the multinomial draw's search differs by more)
+    # the oracle's filtering statistics of the same particles (every resampler runs on integer masses: the very same particles)
     ref = O.smc(model, obs, n, 5, resampler, ess)
-    np.testing.assert_allclose(st, ref["filter"], rtol=0, atol=2e-3 if resampler == cp.RESAMPLE_MULTINOMIAL else 3e-5)
+    np.testing.assert_allclose(st, ref["filter"], rtol=0, atol=1e-9)
     if model == cp.MODEL_HMM3:
         assert np.abs(st - z["hmm16_filter"]).max() < 2e-2
     else:
