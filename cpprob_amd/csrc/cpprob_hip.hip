@@ -77,6 +77,8 @@ struct cpprob_hip_ctx {
     int32_t* d_resampled = nullptr;
     double* d_stats_part = nullptr;
     double* d_stats = nullptr;
+    uint32_t* d_strata = nullptr;   // multinomial, strata form: [T - 1][2^k + 1] first outputs of the strata, every step of the run
+    uint32_t* d_strata_top = nullptr; int strata_phase = 0;   // ... [2][T][64] totals of the level-6 nodes (the set in use alternates run by run)
     double* d_cdf = nullptr;        // multinomial only
     int32_t* d_anc_pre = nullptr;   // multinomial only
     double* d_local_totals = nullptr;
@@ -436,8 +438,12 @@ template <class Model>
 bool counts_eligible(const cpprob_hip_ctx* c)
 {
     return !(c->cfg.flags & CPPROB_HIP_FLAG_FLOATING_POINT_STEP) && c->nb <= kCountsMaxTiles && Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1 && c->cfg.algorithm == CPPROB_HIP_ALG_SMC &&
-           c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && c->cfg.ess_threshold > 1.0 &&
-           (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND);
+           c->cfg.ess_threshold > 1.0 &&
+           (c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC
+                ? (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)
+                // (stratified resampling: the same walk with the outputs' own uniforms; one population per context)
+                : (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED && c->cfg.resample_scope != CPPROB_HIP_SCOPE_EXCHANGE &&
+                   (c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)));
 }
 
 // Philox4x32-10 on the host (cpprob/detail/rng.hpp's draw_block): the systematic offset of a resampling step is a pure function of
@@ -502,7 +508,8 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         if (c->trace_mode && !all_totals) { a.trace_prev = c->d_q[(t + 1) & 1]; a.trace_next = c->d_q[t & 1]; }
         if (c->step_protocol && c->trace_shard_run) { a.trace_prev = c->d_tr[(t + 1) & 1]; a.trace_next = c->d_tr[t & 1]; }
         ProfScope ps(c, 0);
-        if (all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED) hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        else if (all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         if (t + 1 == c->T) { c->cur = 0; c->cur_part = 0; }
     }
@@ -560,8 +567,30 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         a.bound = c->h_bound[(size_t)t]; a.bound_prev = t > 0 ? c->h_bound[(size_t)t - 1] : 0.0;
         a.ess_frac = c->cfg.ess_threshold; a.may_carry = c->cfg.ess_threshold > 1.0 ? 0 : 1;
         a.prefetch = a.may_carry ? 0 : 1;                        // (a schedule on which steps may not resample: the fetch is wasted on those, and costs registers on all)
-        const int rs = c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED ? kFixStratified : (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL ? kFixMultinomial : kFixSystematic);
+        const int rs = c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED ? kFixStratified
+                     : (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL ? ((c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL) ? kFixMultinomialLiteral : kFixMultinomial) : kFixSystematic);
         if (rs == kFixMultinomial) {
+            // strata form: how many thresholds fall into each stratum does not depend on the weights -- every step's counts in ONE
+            // launch in front of the run's first step
+            a.prefetch = 0;
+            a.strata_k = strata_levels(c->nb);
+            const size_t per_step = ((size_t)1 << a.strata_k) + 1;
+            if (t == 0 && c->T > 1) {
+                ProfScope ps(c, 5);
+                StrataArgs sa{};
+                sa.seed = c->run_seed; sa.t0 = 1; sa.k = a.strata_k; sa.n_out = (uint32_t)c->n; sa.offs = c->d_strata;
+                if (a.strata_k <= kStrataTop) hipLaunchKernelGGL(multinomial_strata_kernel, dim3(1, c->T - 1), dim3(kThreads), 0, c->stream, sa);
+                else {
+                    // (two sets of the steps' level-6 totals: the bottom launch clears the set the NEXT run adds into)
+                    sa.top = c->d_strata_top + (size_t)c->strata_phase * (size_t)c->T * 64; sa.top_clear = c->d_strata_top + (size_t)(c->strata_phase ^ 1) * (size_t)c->T * 64;
+                    c->strata_phase ^= 1;
+                    hipLaunchKernelGGL(multinomial_strata_top_kernel, dim3(strata_groups(a.strata_k), c->T - 1), dim3(kThreads), 0, c->stream, sa);
+                    hipLaunchKernelGGL(multinomial_strata_bottom_kernel, dim3(64, c->T - 1), dim3(kThreads), 0, c->stream, sa);
+                }
+            }
+            a.strata_offs = t > 0 ? c->d_strata + (size_t)(t - 1) * per_step : nullptr;
+        }
+        if (rs == kFixMultinomialLiteral) {
             // the lanes' in-tile prefixes travel with the weights (ping-pong, in the halves of the floating-point form's CDF array);
             // the tiles' prefix masses of generation t-1 come from one short launch in front of the step
             uint64_t* lp = reinterpret_cast<uint64_t*>(c->d_cdf);
@@ -580,6 +609,7 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         {
             ProfScope ps(c, 0);
             if (rs == kFixMultinomial) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (rs == kFixMultinomialLiteral) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomialLiteral>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixStratified && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixStratified) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (all_totals && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
@@ -787,7 +817,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]); dfree(c->d_trace_cnt); dfree(c->d_trace_arrive); dfree(c->d_tr[0]); dfree(c->d_tr[1]);
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_strata); dfree(c->d_strata_top); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]); dfree(c->d_trace_cnt); dfree(c->d_trace_arrive); dfree(c->d_tr[0]); dfree(c->d_tr[1]);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0; c->tr_cap = 0;
 }
 
@@ -995,6 +1025,10 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
             HIP_TRY(c, hipMemsetAsync(c->d_annex_base, 0, (T + 1) * sizeof(int64_t), c->stream));
         }
         if (multinomial) {
+            HIP_TRY(c, hipMalloc(&c->d_strata, (size_t)T * (((size_t)1 << strata_levels(c->nb)) + 1) * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_strata_top, (size_t)2 * T * 64 * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemsetAsync(c->d_strata_top, 0, (size_t)2 * T * 64 * sizeof(uint32_t), c->stream));
+            c->strata_phase = 0;
             HIP_TRY(c, hipMalloc(&c->d_cdf, ld * sizeof(double)));
             HIP_TRY(c, hipMalloc(&c->d_anc_pre, ld * sizeof(int32_t)));
         }
@@ -1026,6 +1060,10 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     HIP_TRY(c, hipMalloc(&c->d_obs, n_obs * sizeof(double)));
     HIP_TRY(c, hipMemcpyAsync(c->d_obs, h_obs, n_obs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_resampled, 0, (size_t)c->T * sizeof(int32_t), c->stream));
+    if (multinomial && c->d_strata_top) {                      // (its layout follows T; a run abandoned between its two launches leaves totals behind)
+        HIP_TRY(c, hipMemsetAsync(c->d_strata_top, 0, (size_t)2 * c->T * 64 * sizeof(uint32_t), c->stream));
+        c->strata_phase = 0;
+    }
     {
         // Gaussian models: the log-weight as a quadratic in the prior's standard-normal variate (extended precision on the host),
         // and the grid point above its maximum

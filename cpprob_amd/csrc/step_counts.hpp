@@ -48,6 +48,7 @@ __device__ __forceinline__ uint32_t cnt_n1(uint64_t w) { return (uint32_t)((w >>
 struct TableCdf {
     double e0, e1, e2, inv, u0, n_pop;
     double base0, base1, basev;                // states 0 / 1 and particles before this shard
+    uint64_t seed, draw, uid0;                 // stratified resampling (cpprob/detail/fixed_mass.hpp: FixedCdf): Philox key, draw index, id of output 0
     __device__ __forceinline__ double cdf(double c0, double c1, double cv) const      // c*: GLOBAL inclusive counts
     {
         const double c2 = cv - c0 - c1;
@@ -56,10 +57,28 @@ struct TableCdf {
     // (never negative: C >= 0 and u0 < 1; may exceed n_pop by rounding only for the population's last sources, whose surplus
     //  outputs nobody consumes -- the clamp of the stated arithmetic changes no ancestor)
     __device__ __forceinline__ double g(double C) const { return ceil(fma(C, inv, -u0)); }
+    // Stratified: output j sits at j + u_j (u_j = the 32-bit uniform of OUTPUT j), the sources up to CDF value C reach H = C * (N / W)
+    // (one rounded product) and own the outputs with j + u_j < H: A = F + [u_F < H - F], F = floor(H) -- FixedCdf::first_stratified
+    // with the table CDF in place of the integer mass; the CPU restatement: orc_resample_table_stratified.
+    __device__ __forceinline__ double h(double C) const { return __dmul_rn(C, inv); }
+    __device__ __forceinline__ double first_stratified(double C) const
+    {
+        const double H = h(C), F = floor(H);
+        if (F >= n_pop) return n_pop;
+        const double u = u01_32(draw_word(seed, uid0 + (uint64_t)F, draw));
+        return u < H - F ? F + 1.0 : F;
+    }
+    template <int RS>
+    __device__ __forceinline__ double first(double C) const
+    {
+        if constexpr (RS == kFixStratified) return first_stratified(C);
+        else return g(C);
+    }
     // first output owned by the sources that follow `n0, n1` state-0/1 particles among `nv` local particles
+    template <int RS = kFixSystematic>
     __device__ __forceinline__ double g_at(uint32_t n0, uint32_t n1, int64_t nv) const
     {
-        return g(cdf(base0 + (double)n0, base1 + (double)n1, basev + (double)nv));
+        return first<RS>(cdf(base0 + (double)n0, base1 + (double)n1, basev + (double)nv));
     }
 };
 
@@ -97,6 +116,7 @@ __device__ __forceinline__ Cnt2 hier_total(const Hier& h) { return hier_total_su
 // Largest tile c in [0, nb) whose first owned output G(prefix(c)) is <= g (0 when there is none), with its exclusive prefix
 // counts: top-down descent, one load + one scan per level.  Wave-uniform; the last resort of the ancestor search (tile masses so
 // uneven that two local probes miss) and the exchange scope's packing, whose outputs sit at the ends of the shard.
+template <int RS = kFixSystematic>
 __device__ __forceinline__ int hier_locate(const HierTable* __restrict__ ht, int copy, const TableCdf& tc, int64_t n, double g, Cnt2& P)
 {
     const int lane = lane_id();
@@ -112,7 +132,7 @@ __device__ __forceinline__ int hier_locate(const HierTable* __restrict__ ht, int
         const uint32_t x0 = p0 + i0 - v0, x1 = p1 + i1 - v1;                                   // exclusive prefix at child `lane`
         const int64_t tile0 = (int64_t)idx << (6 * l);                                         // first tile of the child
         const int64_t nv = tile0 * kTile < n ? tile0 * kTile : n;
-        const bool ok = in && tc.g_at(x0, x1, nv) <= g;
+        const bool ok = in && tc.template g_at<RS>(x0, x1, nv) <= g;
         const unsigned long long m = __ballot(ok);
         const int child = m ? (63 - __builtin_clzll(m)) : 0;                                     // (G is monotone: the set is a prefix)
         p0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, child);
@@ -123,11 +143,14 @@ __device__ __forceinline__ int hier_locate(const HierTable* __restrict__ ht, int
     return blk;
 }
 
-struct CountsLds {
+template <int RS>
+struct CountsLdsT {
     int32_t slot[kTile];        // scatter slots of the output tile
     uint32_t scan[2][kWaves];   // packed per-wave totals of the in-tile scan, double-buffered across source tiles
     int iscr[kWaves];
+    uint32_t ustrat[RS == kFixStratified ? kTile : 1];   // stratified: the 32-bit uniforms of the output tile's outputs
 };
+using CountsLds = CountsLdsT<kFixSystematic>;
 
 // Ancestors of the kTile consecutive outputs starting at global output index gj_first (n_out of them), among THIS shard's sources,
 // -1 where the ancestor belongs to a shard that precedes this one; outputs at or beyond o_hi = G(all local sources) belong to the
@@ -138,6 +161,7 @@ struct CountsLds {
 // caller ahead of time (nullptr: fetched here).  Returns the first source tile c, its exclusive prefix counts, and the last source
 // tile c_last (nb when the probe cannot tell).
 struct Located { int c, c_last; uint32_t p0, p1; };
+template <int RS = kFixSystematic>
 __device__ __forceinline__ Located counts_locate(const Hier& h, const TableCdf& tc, int64_t n, int nb, double gj_first, int n_out, int guess,
                                                  const ProbeWords* first)
 {
@@ -157,7 +181,7 @@ __device__ __forceinline__ Located counts_locate(const Hier& h, const TableCdf& 
         const uint32_t v0 = cnt_n0(we), v1 = cnt_n1(we);
         const uint32_t i0 = wave_incl_scan_u32(v0), i1 = wave_incl_scan_u32(v1);
         const uint32_t x0 = Pc.n0 + i0 - v0, x1 = Pc.n1 + i1 - v1;        // lanes 0..4: the prefix at cs + lane (lanes >= 4 hold zeros)
-        const double gt = tc.g_at(x0, x1, nvalid_before(cs + lane));
+        const double gt = tc.template g_at<RS>(x0, x1, nvalid_before(cs + lane));
         const bool known = lane < 5 && cs + lane < nb;
         const unsigned long long m = __ballot(known && gt <= gj_first);
         const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
@@ -186,7 +210,7 @@ __device__ __forceinline__ Located counts_locate(const Hier& h, const TableCdf& 
         const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
         ProbeWords pw;
         probe_fetch(h, at, nb, pw);
-        if (!probe(at, pw, d)) { c = hier_locate(h.table, h.copy, tc, n, gj_first, P); c_last = nb; }
+        if (!probe(at, pw, d)) { c = hier_locate<RS>(h.table, h.copy, tc, n, gj_first, P); c_last = nb; }
     }
     return Located{c, c_last, P.n0, P.n1};
 }
@@ -194,10 +218,10 @@ __device__ __forceinline__ Located counts_locate(const Hier& h, const TableCdf& 
 // counts_walk.  raw_m1 / raw_0 / raw_p1 = the states of tiles guess-1, guess, guess+1 fetched at kernel entry (an output tile
 // overlaps two of them almost surely, so no load waits for the search).  Slots must hold -1 and be visible (the caller's barrier)
 // on entry.
-template <class S, bool sharded>
+template <class S, bool sharded, int RS = kFixSystematic>
 __device__ __forceinline__ void counts_walk(const TableCdf& tc, const S* __restrict__ states, int64_t n, int nb, bool last_shard, double gj_first,
                                             int n_out, const Located& loc, int guess, uint32_t raw_m1, uint32_t raw_0, uint32_t raw_p1,
-                                            int32_t (&anc)[kPPT], CountsLds& L)
+                                            int32_t (&anc)[kPPT], CountsLdsT<RS>& L)
 {
     static_assert(sizeof(S) == 1 && kPPT == 4, "states travel as one byte: 4 per lane = one dword");
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
@@ -256,7 +280,15 @@ __device__ __forceinline__ void counts_walk(const TableCdf& tc, const S* __restr
             const uint32_t n2 = nvb + (uint32_t)(EDGE && upto > nvt ? nvt : upto) - n0 - n1;
             double c0 = (double)n0, c1 = (double)n1, c2 = (double)n2;
             if (sharded) { c0 += tc.base0; c1 += tc.base1; c2 += base2; }
-            return place(tc.g(fma(c2, tc.e2, fma(c1, tc.e1, __dmul_rn(c0, tc.e0)))));
+            const double C = fma(c2, tc.e2, fma(c1, tc.e1, __dmul_rn(c0, tc.e0)));
+            if constexpr (RS == kFixStratified) {
+                // (L.ustrat: the outputs' uniforms, staged by the caller)
+                const double H = tc.h(C), F = floor(H), d = F - gj_first;
+                if (!(d >= 0.0)) return 0;
+                if (d >= (double)kTile) return kTile;
+                const int i = (int)d;
+                return i + (u01_32(L.ustrat[i]) < H - F ? 1 : 0);
+            } else return place(tc.g(C));
         };
         const int src0 = c * kTile + vb;
         const int p_all = EDGE && last_shard ? place(tc.n_pop) : 0;
@@ -272,7 +304,7 @@ __device__ __forceinline__ void counts_walk(const TableCdf& tc, const S* __restr
     while (c < nb && c <= c_last) {
         // (wave-uniform values -- the branches are made scalar so that the barrier inside the loop sits in uniform control flow)
         if (c_last >= nb &&                                              // the last tile is not known from the probe: test where this one starts
-            __builtin_amdgcn_readfirstlane(tc.g_at(P.n0, P.n1, nvalid_before(c)) > gj_last ? 1 : 0)) break;
+            __builtin_amdgcn_readfirstlane(tc.template g_at<RS>(P.n0, P.n1, nvalid_before(c)) > gj_last ? 1 : 0)) break;
         const uint32_t raw_next = c < c_last ? load_states(c + 1) : 0u;  // (beyond the prefetched three: travels while this tile is processed)
         if (c == nb - 1) tile(std::true_type{}, raw); else tile(std::false_type{}, raw);
         ++it;
@@ -357,13 +389,14 @@ __device__ __forceinline__ void hier_publish(const Hier& h, int bid, int nb, uin
 
 // SHARDED: one shard of a joint population (exchange scope).  Compile-time forms: each keeps only the arguments it uses in scalar
 // registers.  The run's last step is a step like any other: the read-out works from the counts it leaves (smooth_counts_kernel).
-template <class Model, bool SHARDED>
+template <class Model, bool SHARDED, int RS = kFixSystematic>
 __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArgs<Model> a)
 {
     using V = typename Model::value_t;
     using S = typename Model::store_t;
     static_assert(Model::kWeightTable == 3, "prefix-count form: three table values (two stored counts)");
-    __shared__ CountsLds L;
+    static_assert(RS == kFixSystematic || RS == kFixStratified, "prefix-count form: systematic or stratified resampling");
+    __shared__ CountsLdsT<RS> L;
     __shared__ int s_cnt[kWaves * 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_model[Model::kStagedWords];
     __shared__ __attribute__((aligned(16))) StepFound s_found;
@@ -426,6 +459,12 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         tc.e0 = in_vgpr(a.e_prev[0]); tc.e1 = in_vgpr(a.e_prev[1]); tc.e2 = in_vgpr(a.e_prev[2]); tc.n_pop = a.n_pop;
         tc.u0 = in_vgpr(a.u0);
         tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
+        tc.seed = a.seed; tc.draw = kResampleDrawBase + (uint64_t)t; tc.uid0 = SHARDED ? 0 : a.pid0;
+        if constexpr (RS == kFixStratified) {
+            uint32_t w[kPPT];
+            draw_words4(tc.seed, tc.uid0 + (uint64_t)gj_first + (uint64_t)tid * kPPT, tc.draw, w);
+            store4(L.ustrat, (int64_t)tid * kPPT, w);
+        }
         if (searcher) {
             // ---- one wavefront: the generation's totals, this shard's place in the joint population, the source tiles this output
             //      tile draws from; the other three pick the results up behind the barrier ----
@@ -461,12 +500,12 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
                     fs[0] = __dmul_rn(tot0, tc.e0) / W; fs[1] = __dmul_rn(tot1, tc.e1) / W; fs[2] = __dmul_rn(tot2, tc.e2) / W;
                 }
             }
-            const Located loc = counts_locate(a.h, tc, a.n, nb, gj_first, n_out, guess, &pw0);
+            const Located loc = counts_locate<RS>(a.h, tc, a.n, nb, gj_first, n_out, guess, &pw0);
             int64_t l0 = 0, l1 = 0;
             if (SHARDED) {
                 // outputs below o_lo / at or beyond o_hi descend from other shards' sources
                 const Cnt2 tl = hier_total_sum(a.h, w_tot);
-                const double o_lo = tc.g_at(0, 0, 0), o_hi = last_shard ? a.n_pop : tc.g_at(tl.n0, tl.n1, a.n);
+                const double o_lo = tc.template g_at<RS>(0, 0, 0), o_hi = last_shard ? a.n_pop : tc.template g_at<RS>(tl.n0, tl.n1, a.n);
                 const double sb = (double)a.pid0;
                 l0 = (int64_t)fmin(fmax(o_lo - sb, 0.0), (double)a.n); l1 = (int64_t)fmin(fmax(o_hi - sb, 0.0), (double)a.n);
             }
@@ -480,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         const Located loc = s_found.loc;
         tc.inv = s_found.inv;
         if (SHARDED) { tc.base0 = s_found.base0; tc.base1 = s_found.base1; tc.basev = s_found.basev; }
-        counts_walk<S, SHARDED>(tc, prev_row, a.n, nb, last_shard, gj_first, n_out, loc, guess, raw_m1, raw_0, raw_p1, anc, L);
+        counts_walk<S, SHARDED, RS>(tc, prev_row, a.n, nb, last_shard, gj_first, n_out, loc, guess, raw_m1, raw_0, raw_p1, anc, L);
         if (SHARDED) {
             // the lineages of the outputs other shards' sources own arrived as annex columns, in output order (cpprob_hip exchange
             // commit)

@@ -29,10 +29,11 @@ namespace cph {
 // (fixed-point weights, 64-bit wavefront scans, the mass hierarchy, search and decision: cpprob/detail/fixed_mass.hpp)
 template <int RS>
 struct FixedLdsT {
-    int32_t slot[kTile];          // scatter slots of the output tile
+    int32_t slot[RS == kFixMultinomial || RS == kFixMultinomialLiteral ? kPPT : kTile];          // scatter slots of the output tile
     uint64_t scan[2][kWaves];     // per-wave totals of the in-tile scan, double-buffered across source tiles
     int iscr[kWaves];
     uint32_t ustrat[RS == kFixStratified ? kTile : 1];   // stratified: the 32-bit uniforms of the output tile's outputs
+    uint64_t mp[RS == kFixMultinomial ? 2 * kTile : 1];  // multinomial, strata form: a source tile's prefix masses (per wavefront), double-buffered
 };
 using FixedLds = FixedLdsT<kFixSystematic>;
 
@@ -150,7 +151,7 @@ __device__ __forceinline__ FixedRanks fixed_ranks(const uint64_t* __restrict__ a
     return r;
 }
 
-struct FixedFound { FLocated loc; double inv, ref; uint64_t base, S; int64_t l0, l1; int resample; };     // the searching wavefront's hand-over
+struct FixedFound { FLocated loc; double inv, ref; uint64_t base, S; int64_t l0, l1; int resample, w0, w1; };     // the searching wavefront's hand-over
 
 template <class Model>
 struct StepFixedArgs {
@@ -173,6 +174,7 @@ struct StepFixedArgs {
     // multinomial resampling: exclusive prefix masses of generation t-1's tiles ([nb + 1]: fixed_tile_prefix_kernel) and the
     // in-tile inclusive prefix at the end of every lane's four particles ([ld / 4]), read for generation t-1 / written for generation t
     const uint64_t* tile_prefix; const uint64_t* lane_prefix_prev; uint64_t* lane_prefix_next;
+    const uint32_t* strata_offs; int strata_k; // multinomial, strata form: [2^k + 1] first output of every stratum's thresholds at this step (multinomial_strata_kernel)
 };
 
 // ---- multinomial resampling on integer masses (thesis Alg. 1 p.36: a_j ~ Categorical(W)) ---------------------------------------
@@ -254,6 +256,332 @@ __device__ __forceinline__ void fixed_multinomial_ancestors(uint64_t S, uint64_t
     }
 }
 
+// ---- multinomial resampling, STRATA form: the form that runs by default --------------------------------------------------------
+// The literal form above is N searches of the whole population at random addresses (19 dependent scattered loads an output at 10^6
+// particles: 6 - 8 x the systematic step, 25 x at 10^7).  The same law -- N iid uniform thresholds on [0, C_N) -- generated in nearly
+// sorted order keeps an output's ancestor next to it, as under systematic resampling:
+//      N iid uniforms  =  how many fall into each of K = 2^k equal strata, (m_w) ~ Multinomial(N; 1/K .. 1/K),
+//                         and iid uniforms inside each stratum.
+//   1  The counts do not depend on the weights: multinomial_strata_kernel draws them for every step of a run in ONE launch at the
+//      run's start -- a binary tree over the strata, the n thresholds of a node go left with probability 1/2 each: left = popcount of
+//      the first n bits of the node's own Philox stream, an exact Binomial(n, 1/2) in integers.  o_w = m_0 + .. + m_w-1.
+//   2  The step launch: output s in [o_w, o_w+1) draws the 53-bit uniform of OUTPUT s (draw kResampleDrawBase2 + step);
+//          tau_s = B_w + floor(v_s (B_w+1 - B_w)),   B_w = floor(C_N w / K),   ancestor = min{k : C_k > tau_s}.
+//      An output tile's thresholds lie in two or three neighbouring strata, i.e. in the two or three source tiles around its own
+//      index: each of them rebuilds its prefix masses in LDS and the outputs search there.  No atomics, no launch between two steps.
+// K = the smallest power of two >= the number of tiles.  Integers throughout (the CPU restatement: orc_resample_fixed_multinomial_strata).
+constexpr uint64_t kResampleDrawBase3 = kResampleDrawBase + (1ull << 38);
+__host__ __device__ inline int strata_levels(int64_t nb) { int k = 0; while (((int64_t)1 << k) < nb) ++k; return k; }
+__device__ __forceinline__ uint64_t strata_bound(uint64_t S, uint64_t w, int k)
+{
+    if (k == 0) return w ? S : 0ull;
+    return (__umul64hi(S, w) << (64 - k)) | ((S * w) >> k);
+}
+
+// The counts are spread over the chip in two parts for k > 6 (the sum of independent multinomial counts is multinomial):
+//   top     the outputs are dealt to G = clamp(K / 128, 1, 64) groups of consecutive outputs; every group sends its own through the top
+//           six levels of a tree of ITS OWN (workgroup = (group, step); stream of node `node` of group g: block group
+//           1 << 63 | g << 40 | node << 32 | chunk) and adds its counts of the 64 level-6 nodes to the step's totals (64 atomics a workgroup);
+//   bottom  workgroup (i, step) splits the total of level-6 node i down the remaining k - 6 levels (streams by heap index) and writes
+//           the first outputs of its K / 64 strata: its own prefix sums on top of the nodes' before it.
+// k <= 6 (<= 64 tiles): one workgroup a step does the whole tree.
+constexpr int kStrataTop = 6;
+__host__ __device__ inline int strata_groups(int k)
+{
+    if (k <= kStrataTop) return 1;
+    const int64_t g = ((int64_t)1 << k) / 128;
+    return (int)(g < 1 ? 1 : (g > 64 ? 64 : g));
+}
+struct StrataArgs { uint64_t seed; int t0, k; uint32_t n_out; uint32_t* offs; uint32_t* top; uint32_t* top_clear; };   // offs: [steps][2^k + 1], top: [steps][64]; blockIdx.y = step t0 + y
+
+// popcount of the bits [128 chunk, 128 chunk + 128) of a node's stream, cut at its n-th bit
+__device__ __forceinline__ uint32_t strata_chunk_bits(uint64_t seed, uint64_t draw, uint64_t node_key, uint64_t chunk, uint64_t n)
+{
+    const u32x4 r = draw_block(seed, (node_key << 32) | chunk, draw);
+    const uint64_t rem = n - chunk * 128;
+    if (rem >= 128) return (uint32_t)(__popc(r.x) + __popc(r.y) + __popc(r.z) + __popc(r.w));
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    uint32_t c = 0, left = (uint32_t)rem;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t take = left >= 32u ? 32u : left;
+        const uint32_t m = take == 32u ? 0xffffffffu : ((1u << take) - 1u);
+        c += (uint32_t)__popc(w[j] & m);
+        left -= take;
+    }
+    return c;
+}
+
+// One workgroup splits the count in cnt[0] down `levels` levels, in place: node i of level l sits at cnt[i (stride >> l)], its heap
+// index is (heap0 << l) + i, the n thresholds of a node go left with probability 1/2 each (left = popcount of the first n bits of the
+// node's stream).  s_left: kThreads words of LDS.  cnt may be LDS or global memory (read and written by this workgroup alone).
+__device__ __forceinline__ void strata_split(uint64_t seed, uint64_t draw, uint64_t key_hi, uint64_t heap0, int levels, uint64_t stride, uint32_t* cnt, uint32_t* s_left)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int l = 0; l < levels; ++l) {
+        const uint64_t nodes = 1ull << l, span = stride >> l, half = span >> 1;
+        if (nodes <= (uint64_t)kThreads) {
+            // a group of threads per node, chunks dealt round-robin, the group's popcounts meet in an LDS word
+            const int G = kThreads >> l;
+            const int i = tid / G, sub = tid % G;
+            s_left[tid] = 0u;
+            __syncthreads();
+            const uint64_t n = cnt[(uint64_t)i * span];
+            uint32_t part = 0;
+            for (uint64_t ch = (uint64_t)sub; ch * 128 < n; ch += (uint64_t)G) part += strata_chunk_bits(seed, draw, key_hi | ((heap0 << l) + (uint64_t)i), ch, n);
+            if (part) atomicAdd(&s_left[i], part);
+            __syncthreads();
+            if (sub == 0) { const uint32_t left = s_left[i]; cnt[(uint64_t)i * span] = left; cnt[(uint64_t)i * span + half] = (uint32_t)n - left; }
+            __syncthreads();
+        } else {
+            for (uint64_t i = (uint64_t)tid; i < nodes; i += (uint64_t)kThreads) {
+                const uint64_t n = cnt[i * span];
+                uint32_t left = 0;
+                for (uint64_t ch = 0; ch * 128 < n; ++ch) left += strata_chunk_bits(seed, draw, key_hi | ((heap0 << l) + i), ch, n);
+                cnt[i * span] = left; cnt[i * span + half] = (uint32_t)n - left;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// counts -> first outputs: exclusive prefix sums of cnt[0 .. m) in place, on top of `base`; returns base + the sum (every thread)
+__device__ __forceinline__ uint32_t strata_prefix(uint32_t* cnt, uint64_t m, uint32_t base, uint32_t* s_w)
+{
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    uint32_t carry = base;
+    for (uint64_t b0 = 0; b0 < m; b0 += (uint64_t)kThreads) {
+        const uint64_t i = b0 + (uint64_t)tid;
+        const uint32_t v = i < m ? cnt[i] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(v);
+        if (lane == kWave - 1) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { const uint32_t x = s_w[w]; if (w < wv) off += x; tot += x; }
+        if (i < m) cnt[i] = carry + off + incl - v;
+        carry += tot;
+        __syncthreads();
+    }
+    return carry;
+}
+
+// k <= 6: the whole tree of a step in one workgroup.  grid (1, steps)
+__global__ __launch_bounds__(kThreads) void multinomial_strata_kernel(StrataArgs a)
+{
+    __shared__ uint32_t s_left[kThreads];
+    __shared__ uint32_t s_w[kWaves];
+    const uint64_t K = 1ull << a.k;
+    uint32_t* o = a.offs + (size_t)blockIdx.y * (size_t)(K + 1);
+    const uint64_t draw = kResampleDrawBase3 + (uint64_t)(a.t0 + (int)blockIdx.y);
+    if (threadIdx.x == 0) o[0] = a.n_out;
+    strata_split(a.seed, draw, 0, 1, a.k, K, o, s_left);
+    const uint32_t tot = strata_prefix(o, K, 0u, s_w);
+    if (threadIdx.x == 0) o[K] = tot;
+}
+// k > 6, top: grid (groups, steps)
+__global__ __launch_bounds__(kThreads) void multinomial_strata_top_kernel(StrataArgs a)
+{
+    __shared__ uint32_t s_left[kThreads];
+    __shared__ uint32_t s_cnt[64];
+    const int g = (int)blockIdx.x, G = (int)gridDim.x;
+    const uint64_t draw = kResampleDrawBase3 + (uint64_t)(a.t0 + (int)blockIdx.y);
+    // outputs [g n / G, (g + 1) n / G)   (n < 2^32, G <= 64: the products fit 64 bits)
+    const uint64_t n_g = ((uint64_t)a.n_out * (uint64_t)(g + 1)) / (uint64_t)G - ((uint64_t)a.n_out * (uint64_t)g) / (uint64_t)G;
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = threadIdx.x == 0 ? (uint32_t)n_g : 0u;
+    strata_split(a.seed, draw, (1ull << 31) | ((uint64_t)g << 8), 1, kStrataTop, 64, s_cnt, s_left);
+    if (threadIdx.x < 64 && s_cnt[threadIdx.x]) atomicAdd(a.top + (size_t)blockIdx.y * 64 + threadIdx.x, s_cnt[threadIdx.x]);
+}
+// k > 6, bottom: grid (64, steps)
+__global__ __launch_bounds__(kThreads) void multinomial_strata_bottom_kernel(StrataArgs a)
+{
+    __shared__ uint32_t s_left[kThreads];
+    __shared__ uint32_t s_w[kWaves];
+    __shared__ uint32_t s_base[2];
+    const int i = (int)blockIdx.x;
+    const uint64_t K = 1ull << a.k, sub = K >> kStrataTop;
+    uint32_t* o = a.offs + (size_t)blockIdx.y * (size_t)(K + 1) + (size_t)i * sub;
+    const uint64_t draw = kResampleDrawBase3 + (uint64_t)(a.t0 + (int)blockIdx.y);
+    if (wave_id() == 0) {
+        const uint32_t v = a.top[(size_t)blockIdx.y * 64 + threadIdx.x];
+        const uint32_t incl = wave_incl_scan_u32(v);
+        if ((int)threadIdx.x == i) { s_base[0] = incl - v; s_base[1] = v; }
+        // (the totals of the run after this one: cleared here, one word a workgroup)
+        if ((int)threadIdx.x == i && a.top_clear) a.top_clear[(size_t)blockIdx.y * 64 + i] = 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) o[0] = s_base[1];
+    strata_split(a.seed, draw, 0, 64 + (uint64_t)i, a.k - kStrataTop, sub, o, s_left);
+    const uint32_t end = strata_prefix(o, sub, s_base[0], s_w);
+    if (i == 63 && threadIdx.x == 0) o[sub] = end;                        // offs[K] = the number of outputs
+}
+
+// Largest tile c whose exclusive prefix mass is <= x (the tile that holds mass unit x), with that prefix: top-down descent.
+__device__ __forceinline__ int fhier_locate_mass(const HierTable* __restrict__ ht, int copy, uint64_t x, uint64_t& P)
+{
+    const int lane = lane_id();
+    int blk = 0;
+    uint64_t p = 0;
+    for (int l = ht->n_lev - 1; l >= 0; --l) {
+        const int idx = (blk << 6) + lane;
+        uint64_t w = 0;
+        const bool in = idx < ht->n_ent[l];
+        if (in) w = ht->lvl[copy][l][(int64_t)idx * (l == 0 ? 1 : kHierStride)] & kMassMask;
+        const uint64_t incl = wave_incl_scan_u64(w);
+        const uint64_t e = p + incl - w;
+        const unsigned long long m = __ballot(in && e <= x);
+        const int child = m ? (63 - __builtin_clzll(m)) : 0;
+        p = read_lane_u64(e, child);
+        blk = (blk << 6) + child;
+    }
+    P = p;
+    return blk;
+}
+
+// The SEARCH of the strata form (one wavefront): the strata w0 .. w1 of the outputs [s_first, s_last] -- the largest w with
+// o_w <= s: a window of 64 offsets around the output tile's own place almost surely holds both -- and the source tiles that hold
+// their mass range [B_w0, B_w1+1): probed around the output tile's own index like the systematic search (fixed_locate).
+struct StrataLocated { FLocated loc; int w0, w1; };
+__device__ __forceinline__ StrataLocated strata_locate(const FHier& f, const uint32_t* __restrict__ offs, int k, int nb, int bid, uint32_t s_first, uint32_t s_last,
+                                                       uint64_t S, const ProbeWords& first)
+{
+    const int lane = lane_id();
+    const int K = 1 << k;
+    StrataLocated r;
+    {
+        int w_at = (int)(((int64_t)bid << k) / nb) - 31;
+        if (w_at > K + 1 - kWave) w_at = K + 1 - kWave;
+        if (w_at < 0) w_at = 0;
+        const int idx = w_at + lane;
+        const bool valid = idx <= K;
+        const uint32_t o = offs[valid ? idx : K];
+        const unsigned long long m_lo = __ballot(valid && o <= s_first), m_hi = __ballot(valid && o <= s_last);
+        const int top = K - w_at < kWave - 1 ? K - w_at : kWave - 1;          // the window's last valid lane
+        const bool ok_lo = (m_lo & 1ull) && (63 - __builtin_clzll(m_lo | 1ull)) < top;
+        const bool ok_hi = (m_hi & 1ull) && (63 - __builtin_clzll(m_hi | 1ull)) < top;
+        auto search = [&](uint32_t s) -> int {
+            int lo = 0, hi = K;                                           // offs[0] = 0 <= s < offs[K]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= s) lo = mid; else hi = mid; }
+            return lo;
+        };
+        r.w0 = ok_lo ? w_at + (63 - __builtin_clzll(m_lo)) : search(s_first);
+        r.w1 = ok_hi ? w_at + (63 - __builtin_clzll(m_hi)) : search(s_last);
+    }
+    const uint64_t x_lo = strata_bound(S, (uint64_t)r.w0, k), b_hi = strata_bound(S, (uint64_t)r.w1 + 1, k);
+    const uint64_t x_hi = b_hi > x_lo ? b_hi - 1 : x_lo;
+    int c = 0, c_last = nb;
+    uint64_t P = 0;
+    auto probe = [&](int at, const ProbeWords& pw) -> bool {
+        const int cs = at > 0 ? at - 1 : 0;
+        const uint64_t Pc = fhier_prefix_sum(cs, pw.lvl);
+        const uint64_t we = (lane < 4 && cs + lane < nb) ? (pw.we & kMassMask) : 0ull;
+        const uint64_t incl = wave_incl_scan_u64(we);
+        const uint64_t x = Pc + incl - we;                               // lanes 0..4: the prefix at cs + lane
+        const bool known = lane < 5 && cs + lane < nb;
+        const unsigned long long m = __ballot(known && x <= x_lo);
+        const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
+        if ((i_lo >= 0 || cs == 0) && i_lo < 4) {
+            const int i = i_lo < 0 ? 0 : i_lo;
+            c = cs + i;
+            P = read_lane_u64(x, i);
+            const unsigned long long mh = __ballot(known && x <= x_hi);
+            const int i_hi = mh ? (63 - __builtin_clzll(mh)) : i;
+            c_last = (i_hi >= 4 && cs + 5 < nb) ? nb : cs + (i_hi > i ? i_hi : i);
+            return true;
+        }
+        return false;
+    };
+    if (!probe(bid, first)) {
+        // aim by the mass (tile masses are comparable), then descend from the top
+        const double aim = u64_to_double(x_lo) * ((double)nb / u64_to_double(S > 0 ? S : 1));
+        const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
+        ProbeWords pw;
+        probe_fetch(f.h, at, nb, pw);
+        if (!probe(at, pw)) { c = fhier_locate_mass(f.h.table, f.h.copy, x_lo, P); c_last = nb; }
+    }
+    r.loc = FLocated{c, c_last, P};
+    return r;
+}
+
+// The WALK of the strata form (the whole workgroup): the lane's four outputs take their thresholds, every source tile of the range
+// rebuilds its prefix masses in LDS (per wavefront: one scan, one barrier a tile), and the outputs whose threshold lies in the tile
+// search them.  uid = the id of the lane's first output (a multiple of four); j0 = its index in the population.
+__device__ __forceinline__ void strata_walk(const uint32_t* __restrict__ offs, int k, const uint32_t* __restrict__ qprev, int nb, const StrataLocated& sl, uint64_t S,
+                                            int64_t j0, uint64_t seed, uint64_t draw, uint64_t uid, int32_t (&anc)[kPPT], FixedLdsT<kFixMultinomial>& L)
+{
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const u32x4 b0 = draw_block(seed, uid >> 1, draw), b1 = draw_block(seed, (uid >> 1) + 1, draw);
+    uint64_t v[kPPT], tau[kPPT];
+    v[0] = bits53(b0.x, b0.y) << 11; v[1] = bits53(b0.z, b0.w) << 11; v[2] = bits53(b1.x, b1.y) << 11; v[3] = bits53(b1.z, b1.w) << 11;
+    bool live[kPPT];
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i) { live[i] = false; tau[i] = 0; }
+    const int w0 = __builtin_amdgcn_readfirstlane(sl.w0), w1 = __builtin_amdgcn_readfirstlane(sl.w1);
+    {
+        uint32_t o_lo = offs[w0];
+        uint64_t b_lo = strata_bound(S, (uint64_t)w0, k);
+        for (int w = w0; w <= w1; ++w) {
+            const uint32_t o_hi = offs[w + 1];
+            const uint64_t b_hi = strata_bound(S, (uint64_t)w + 1, k);
+#pragma unroll
+            for (int i = 0; i < kPPT; ++i) {
+                const int64_t s = j0 + i;
+                if (s >= (int64_t)o_lo && s < (int64_t)o_hi) { tau[i] = b_lo + __umul64hi(v[i], b_hi - b_lo); live[i] = true; }
+            }
+            o_lo = o_hi; b_lo = b_hi;
+        }
+    }
+    const uint64_t b_end = strata_bound(S, (uint64_t)w1 + 1, k), x_first = strata_bound(S, (uint64_t)w0, k);
+    const uint64_t x_hi = b_end > x_first ? b_end - 1 : x_first;
+    int c = __builtin_amdgcn_readfirstlane(sl.loc.c);
+    const int c_last = __builtin_amdgcn_readfirstlane(sl.loc.c_last);
+    uint64_t P = sl.loc.P;
+    int it = 0;
+    while (c < nb && c <= c_last) {
+        if (c_last >= nb && __builtin_amdgcn_readfirstlane(P > x_hi ? 1 : 0)) break;          // the last tile is not known from the probe
+        const U4 raw = *reinterpret_cast<const U4*>(qprev + (int64_t)c * kTile + (int64_t)tid * kPPT);
+        uint64_t pre[kPPT];
+        uint64_t run = 0;
+#pragma unroll
+        for (int i = 0; i < kPPT; ++i) { run += (uint64_t)raw[i]; pre[i] = run; }
+        const uint64_t incl = wave_incl_scan_u34(run);
+        const uint64_t excl = incl - run;
+        uint64_t* Pm = L.mp + (size_t)(it & 1) * kTile;
+        {
+            using UL2 = unsigned long long __attribute__((ext_vector_type(2)));
+            UL2 a0, a1;
+            a0[0] = excl + pre[0]; a0[1] = excl + pre[1]; a1[0] = excl + pre[2]; a1[1] = excl + pre[3];
+            *reinterpret_cast<UL2*>(Pm + (size_t)tid * kPPT) = a0;
+            *reinterpret_cast<UL2*>(Pm + (size_t)tid * kPPT + 2) = a1;
+        }
+        if (lane == kWave - 1) L.scan[it & 1][wv] = incl;
+        __syncthreads();
+        uint64_t wsum[kWaves];
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) wsum[w] = L.scan[it & 1][w];
+        static_assert(kWaves == 4, "four wavefront segments");
+        const uint64_t M = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+#pragma unroll
+        for (int i = 0; i < kPPT; ++i) {
+            if (live[i] && tau[i] >= P && tau[i] - P < M) {
+                uint64_t r = tau[i] - P;
+                int seg = 0;
+                if (r >= wsum[0]) { r -= wsum[0]; seg = 1; if (r >= wsum[1]) { r -= wsum[1]; seg = 2; if (r >= wsum[2]) { r -= wsum[2]; seg = 3; } } }
+                const uint64_t* Ps = Pm + seg * (kTile / kWaves);
+                int a = 0, b = kTile / kWaves - 1;                         // the first j with Ps[j] > r (Ps[255] = the segment's mass > r)
+#pragma unroll
+                for (int h = 0; h < 8; ++h) { const int mid = (a + b) >> 1; if (Ps[mid] > r) b = mid; else a = mid + 1; }
+                static_assert(kTile / kWaves == 256, "eight halvings of a wavefront's 256 particles");
+                anc[i] = c * kTile + seg * (kTile / kWaves) + (a < kTile / kWaves ? a : kTile / kWaves - 1);
+                live[i] = false;
+            }
+        }
+        P += M;
+        ++c; ++it;
+    }
+}
+
 // Bookkeeping of generation t-1 for the host (one thread): ESS, decision, evidence.  ref_prev = R_{t-1}.
 __device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const FixedDecision& d, double ref_prev, double n_pop, double u0, double* ess_trace,
                                                int32_t* resampled, bool last, double m_prev)
@@ -278,7 +606,8 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
 {
     using V = typename Model::value_t;
     using S = typename Model::store_t;
-    static_assert(!(RS == kFixMultinomial && (SHARDED || PREFETCH)), "multinomial resampling: one population per context, no source tiles to fetch ahead");
+    constexpr bool kMulti = RS == kFixMultinomial || RS == kFixMultinomialLiteral;
+    static_assert(!(kMulti && (SHARDED || PREFETCH)), "multinomial resampling: one population per context, no source tiles to fetch ahead");
     __shared__ FixedLdsT<RS> L;
     __shared__ __attribute__((aligned(16))) FixedFound s_found;
     __shared__ uint64_t s_red[3 * kWaves];
@@ -333,7 +662,7 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
     if (t > 0) {
         if (guess == 0) q_m1 = U4{0u, 0u, 0u, 0u};
         if (guess + 1 >= nb) q_p1 = U4{0u, 0u, 0u, 0u};
-        {
+        if constexpr (!kMulti) {
             int32_t neg[kPPT];
             lane_fill(neg, (int32_t)-1);
             store4(L.slot, (int64_t)tid * kPPT, neg);
@@ -366,7 +695,11 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
             }
             FLocated loc{0, 0, 0};
             int64_t l0 = 0, l1 = a.n;
-            if (d.resample && RS != kFixMultinomial) {
+            int sw0 = 0, sw1 = 0;
+            if (d.resample && RS == kFixMultinomial) {
+                const StrataLocated sl = strata_locate(a.f, a.strata_offs, a.strata_k, nb, bid, (uint32_t)((int64_t)bid * kTile), (uint32_t)((int64_t)bid * kTile + n_out - 1), St, pw0);
+                loc = sl.loc; sw0 = sl.w0; sw1 = sl.w1;
+            } else if (d.resample && !kMulti) {
                 loc = fixed_locate<RS>(a.f, fc, nb, gj_first, n_out, guess, &pw0);
                 if (SHARDED) {
                     // outputs below o_lo / at or beyond o_hi descend from other shards' sources
@@ -375,14 +708,20 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
                     l0 = (int64_t)fmin(fmax(o_lo - sb, 0.0), (double)a.n); l1 = (int64_t)fmin(fmax(o_hi - sb, 0.0), (double)a.n);
                 }
             }
-            if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.ref = r_t; s_found.base = before; s_found.S = St; s_found.l0 = l0; s_found.l1 = l1; s_found.resample = d.resample ? 1 : 0; }
+            if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.ref = r_t; s_found.base = before; s_found.S = St; s_found.l0 = l0; s_found.l1 = l1; s_found.resample = d.resample ? 1 : 0; s_found.w0 = sw0; s_found.w1 = sw1; }
         }
         __syncthreads();                                               // slots reset, search results in place
     CPH_STAMP(2);
         resample = s_found.resample != 0;
         ref = s_found.ref;
-        if (resample && RS == kFixMultinomial) {
+        if (resample && RS == kFixMultinomialLiteral) {
             fixed_multinomial_ancestors(s_found.S, fc.seed, fc.draw, fc.uid0 + (uint64_t)j0, a.tile_prefix, nb, a.lane_prefix_prev, a.q_prev, anc);
+        } else if (resample && RS == kFixMultinomial) {
+            if constexpr (RS == kFixMultinomial) {
+                StrataLocated sl;
+                sl.loc = s_found.loc; sl.w0 = s_found.w0; sl.w1 = s_found.w1;
+                strata_walk(a.strata_offs, a.strata_k, a.q_prev, nb, sl, s_found.S, j0, fc.seed, kResampleDrawBase2 + (uint64_t)t, fc.uid0 + (uint64_t)j0, anc, L);
+            }
         } else if (resample) {
             fc.inv = s_found.inv; fc.base = s_found.base;
             fixed_walk<RS>(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, guess, PREFETCH, q_m1, q_0, q_p1, anc, L);
@@ -445,12 +784,12 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
     // published BEFORE this workgroup's weight / log-weight stores are issued: the hierarchy's atomics -- and, above 4096 tiles, the
     // wait in front of the arrival count -- travel under them instead of behind them
     CPH_STAMP(5);
-    const uint64_t s_incl = RS == kFixMultinomial ? wave_incl_scan_u34(s_l) : 0ull;                     // (multinomial: the lanes' prefixes)
-    const uint64_t s_w = RS == kFixMultinomial ? read_lane_u64(s_incl, kWave - 1) : wave_sum_u34(s_l);
+    const uint64_t s_incl = RS == kFixMultinomialLiteral ? wave_incl_scan_u34(s_l) : 0ull;              // (literal multinomial: the lanes' prefixes)
+    const uint64_t s_w = RS == kFixMultinomialLiteral ? read_lane_u64(s_incl, kWave - 1) : wave_sum_u34(s_l);
     const uint64_t q_w = wave_sum_u34(q_l), m_w = wave_max_key(dkey(m_l));                              // (sums of four 32-bit terms)
     if (lane_id() == 0) { s_red[wave_id()] = s_w; s_red[kWaves + wave_id()] = q_w; s_red[2 * kWaves + wave_id()] = m_w; }
     __syncthreads();
-    if constexpr (RS == kFixMultinomial) {
+    if constexpr (RS == kFixMultinomialLiteral) {
         uint64_t off = 0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) if (w < wave_id()) off += s_red[w];

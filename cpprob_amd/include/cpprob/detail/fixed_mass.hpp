@@ -228,9 +228,10 @@ __device__ __forceinline__ uint64_t fhier_prefix_sum(int c, const uint64_t (&w)[
 //        id = uid0 + j, draw kResampleDrawBase + step); the sources up to C reach H = double(C) * (N / double(C_N)) (one rounded
 //        product) and own the outputs with j + u_j < H -- a prefix, because j + u_j increases with j:
 //        A = F + [u_F < H - F],  F = floor(H)   (H - F and the comparison are exact);
-//   multinomial (kFixMultinomial): no prefix structure -- fixed_multinomial_* below.
+//   multinomial (kFixMultinomial: binned, kFixMultinomialLiteral: one search per output): thresholds, not a comb -- csrc/step_fixed.hpp.
 // Both are functions of the exact integer C alone, so tiles, wavefronts and shards may evaluate them in any order.
-constexpr int kFixSystematic = 0, kFixStratified = 1, kFixMultinomial = 2;
+constexpr int kFixSystematic = 0, kFixStratified = 1, kFixMultinomial = 2, kFixMultinomialLiteral = 3;
+constexpr uint64_t kResampleDrawBase2 = kResampleDrawBase + (1ull << 39);   // second stage of the binned multinomial form
 struct FixedCdf {
     double inv, u0, n_pop; uint64_t base;
     uint64_t seed, draw, uid0;                 // stratified: the run's Philox key, the resampling's draw index, the id of output 0

@@ -67,7 +67,14 @@ extern "C" {
                                                     initial state, emission N(mean[s], 1), transition row s as weights; predict "State"
                                                     before every observe.  stats_per_predict = 8 (P(x_t = s), zeros beyond k)        */
 
-/* Resamplers (thesis Alg. 1 p.36: multinomial; remark p.36: systematic / stratified). */
+/* Resamplers (thesis Alg. 1 p.36: multinomial; remark p.36: systematic / stratified).  One population per context: all three run on
+ * integers inside the step launch (prefix counts or fixed-point masses), bit-identical over tilings.
+ *   SYSTEMATIC   one shared offset u0: output j at j + u0;
+ *   STRATIFIED   output j at j + u_j, u_j the 32-bit uniform of output j;
+ *   MULTINOMIAL  a_j ~ Categorical(W) iid, evaluated in two stages so that offspring stay next to their parent: per-tile offspring
+ *                counts from N iid thresholds floor(u_j C_N), then each tile's offspring drawn from the tile's own weights
+ *                (CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL: one threshold per output searched against the whole population -- the same
+ *                law, N scattered searches). */
 #define CPPROB_HIP_RESAMPLE_SYSTEMATIC 0
 #define CPPROB_HIP_RESAMPLE_STRATIFIED 1
 #define CPPROB_HIP_RESAMPLE_MULTINOMIAL 2
@@ -123,6 +130,7 @@ typedef struct cpprob_hip_config {
 #define CPPROB_HIP_FLAG_WREL_STORED 16u          /* floating-point step of table-weight models: read stored linear weights, not states */
 #define CPPROB_HIP_FLAG_FP_TILE_PARTIALS 32u     /* ... and fp64 tile partials instead of packed per-value counts */
 #define CPPROB_HIP_FLAG_WALK_READOUT 64u         /* short discrete traces: read the posterior out by the lineage walk, not from trace words */
+#define CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL 128u /* multinomial resampling: ancestor of output j = min{k : C_k > floor(u_j C_N)}, one search per output */
 
 /* Posterior summary of a finished run -- what StatsPrinter prints
  * (include/cpprob/postprocess/stats_printer.hpp:42-79) plus SMC diagnostics. */

@@ -45,9 +45,13 @@ enum { ORC_MODEL_GAUSSIAN_UNKNOWN_MEAN = 0, /* include/models/models.hpp:22-35 *
        ORC_MODEL_HMM3 = 3,                  /* include/models/models.hpp:114-141 */
        ORC_MODEL_GAUSSIAN_2D_UNKNOWN_MEAN = 4, /* include/models/models.hpp:38-49 (vector-valued statements) */
        ORC_MODEL_HMM_TABLE = 5 };           /* the body of models.hpp:114-141 with a caller-given table: k states (2..8), means, transition rows (orc_set_hmm) */
-enum { ORC_RESAMPLE_SYSTEMATIC = 0, ORC_RESAMPLE_STRATIFIED = 1, ORC_RESAMPLE_MULTINOMIAL = 2 };
+enum { ORC_RESAMPLE_SYSTEMATIC = 0, ORC_RESAMPLE_STRATIFIED = 1, ORC_RESAMPLE_MULTINOMIAL = 2,
+       ORC_RESAMPLE_MULTINOMIAL_LITERAL = 3 }; /* (oracle-side name of CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL: one threshold per output against the whole CDF) */
 
 #define ORC_RESAMPLE_DRAW_BASE (1ull << 40) /* draw index of the resampling uniforms */
+#define ORC_RESAMPLE_DRAW_BASE2 ((1ull << 40) + (1ull << 39)) /* strata form of multinomial resampling: the outputs' uniforms inside their strata */
+#define ORC_RESAMPLE_DRAW_BASE3 ((1ull << 40) + (1ull << 38)) /* ... and the bits that split the thresholds over the strata */
+#define ORC_TILE 1024u                      /* sources per tile (cpprob_amd/include/cpprob/detail/wave.hpp: kTile): the strata form has one stratum per tile, rounded up to a power of two */
 
 /* ------------------------------------------------------------------------- */
 /* Philox4x32-10 (Salmon et al., SC'11; same constants as Random123/rocRAND)  */
@@ -596,6 +600,41 @@ ORC_API int orc_resample_table_systematic(const int32_t *x, uint64_t n_in, const
     return 0;
 }
 
+/* The same generation under STRATIFIED resampling (positions j + u_j, u_j the   */
+/* 32-bit uniform of output j): the sources up to CDF value C_k reach            */
+/* H_k = C_k * (N / W) (one rounded product) and own the outputs with            */
+/* j + u_j < H_k, a prefix of A_k = F + [u_F < H_k - F] outputs, F = floor(H_k)  */
+/* (orc_resample_fixed_stratified with the table CDF in place of the mass).      */
+static double table_stratified_first(const uint64_t c[3], const double e[3], double inv, double N, uint64_t seed, uint64_t step)
+{
+    const double H = table_cdf(c, e) * inv;
+    const double F = floor(H);
+    if (F >= N) return N;
+    const double u = orc_u01_32(orc_draw_word(seed, (uint64_t)F, ORC_RESAMPLE_DRAW_BASE + step));
+    return u < H - F ? F + 1.0 : F;
+}
+
+ORC_API int orc_resample_table_stratified(const int32_t *x, uint64_t n_in, const double e[3], const uint64_t before[3],
+                                          const uint64_t total[3], int last_shard, uint64_t seed, uint64_t step,
+                                          uint64_t j0, uint64_t n_out, uint64_t n_total_out, int32_t *anc)
+{
+    const double N = (double)n_total_out;
+    const double inv = N / table_cdf(total, e);
+    uint64_t c[3] = { before[0], before[1], before[2] };
+    for (uint64_t jj = 0; jj < n_out; ++jj) anc[jj] = -1;
+    double g_prev = table_stratified_first(c, e, inv, N, seed, step);
+    for (uint64_t k = 0; k < n_in; ++k) {
+        if (x[k] < 0 || x[k] > 2) return -2;
+        c[x[k]] += 1;
+        double g = table_stratified_first(c, e, inv, N, seed, step);
+        if (last_shard && k + 1 == n_in) g = N;
+        for (double j = g_prev; j < g; j += 1.0)
+            if (j >= (double)j0 && j < (double)(j0 + n_out)) anc[(uint64_t)j - j0] = (int32_t)k;
+        if (g > g_prev) g_prev = g;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Systematic resampling on FIXED-POINT weights, order-independent form for     */
 /* continuous weights and ESS-triggered schedules (the build's own arithmetic:   */
@@ -751,6 +790,140 @@ ORC_API int orc_resample_fixed_multinomial(const uint32_t *q, uint64_t n_in, uin
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Multinomial resampling, STRATA form: the same law -- N iid uniform           */
+/* thresholds on [0, C_N) -- generated in nearly sorted order, so that an        */
+/* output's ancestor sits next to it as under systematic resampling.  The form    */
+/* the device runs by default (csrc/step_fixed.hpp: multinomial_strata_kernel,   */
+/* strata_walk); the literal form above is N searches of the whole population    */
+/* at random addresses.                                                          */
+/*   N iid uniforms = how many fall into each of K = 2^k equal strata            */
+/*   (m_w) ~ Multinomial(N; 1/K, .., 1/K), and iid uniforms inside each stratum.  */
+/*   1  the counts do not depend on the weights: a binary tree over the strata,   */
+/*      the n thresholds of a node go left with probability 1/2 each --           */
+/*      left = popcount of the first n bits of the node's own Philox stream       */
+/*      (block group = (2^l + i) << 32 | chunk, draw BASE3 + step): exact          */
+/*      Binomial(n, 1/2) in integers.  o_w = m_0 + .. + m_w-1.                     */
+/*   2  output s in [o_w, o_w+1) draws the 53-bit uniform v_s of OUTPUT s          */
+/*      (draw BASE2 + step) and its threshold is                                   */
+/*          tau_s = B_w + floor(v_s (B_w+1 - B_w)),  B_w = floor(C_N w / K),        */
+/*      ancestor = min{k : C_k > tau_s}.                                          */
+/* K = the smallest power of two >= the number of 1024-source tiles (a stratum    */
+/* holds 512 .. 1024 thresholds on average).  Integers throughout.                */
+/* ------------------------------------------------------------------------- */
+ORC_API int orc_strata_levels(uint64_t n_particles)
+{
+    const uint64_t nb = (n_particles + ORC_TILE - 1) / ORC_TILE;
+    int k = 0;
+    while (((uint64_t)1 << k) < nb) ++k;
+    return k;
+}
+
+/* popcount of the first n bits of the stream of tree node `node` (heap order: 2^l + i): words x, y, z, w of block (node << 32 | chunk), low bits first */
+static uint64_t strata_left(uint64_t seed, uint64_t draw, uint64_t node, uint64_t n)
+{
+    uint64_t left = 0;
+    for (uint64_t chunk = 0; chunk * 128 < n; ++chunk) {
+        uint32_t r[4];
+        orc_draw_block(seed, (node << 32) | chunk, draw, r);
+        uint64_t rem = n - chunk * 128;
+        for (int j = 0; j < 4 && rem > 0; ++j) {
+            const uint32_t take = rem >= 32 ? 32u : (uint32_t)rem;
+            const uint32_t m = take == 32 ? 0xffffffffu : ((1u << take) - 1u);
+            left += (uint64_t)__builtin_popcount(r[j] & m);
+            rem -= take;
+        }
+    }
+    return left;
+}
+
+/* offs[0 .. K]: first output of every stratum's thresholds (offs[K] = n_out).
+ * k <= 6: one tree over all n_out thresholds.  Beyond, two parts (the sum of independent multinomial counts is multinomial):
+ *   top     the thresholds are dealt to G = clamp(K / 64 / 2, 1, 64) groups of consecutive outputs [g n / G, (g + 1) n / G); every group
+ *           sends its own through the top 6 levels of a tree of ITS OWN (stream of node `node` of group g: block group
+ *           1 << 63 | g << 40 | node << 32 | chunk); the groups' counts of the 64 level-6 nodes are added;
+ *   bottom  each level-6 node splits its total down the remaining k - 6 levels (streams by heap index, as in the one-tree form).
+ * (That is how the device spreads the work over the chip: groups x steps workgroups for the top, 64 x steps for the bottom.) */
+#define ORC_STRATA_TOP 6
+ORC_API int orc_strata_groups(int k)
+{
+    if (k <= ORC_STRATA_TOP) return 1;
+    const int64_t g = ((int64_t)1 << k) / 128;
+    return (int)(g < 1 ? 1 : (g > 64 ? 64 : g));
+}
+
+static void strata_split(uint64_t seed, uint64_t draw, uint64_t key_hi, uint64_t heap0, int levels, uint64_t stride, uint32_t *cnt)
+{
+    /* cnt[0] holds the root's count; node i of level l sits at index i * (stride >> l); heap index of the root: heap0 */
+    for (int l = 0; l < levels; ++l) {
+        const uint64_t span = stride >> l, half = span >> 1;
+        for (uint64_t i = 0; i < ((uint64_t)1 << l); ++i) {
+            const uint64_t n = cnt[i * span];
+            const uint64_t left = strata_left(seed, draw, key_hi | ((heap0 << l) + i), n);
+            cnt[i * span] = (uint32_t)left;
+            cnt[i * span + half] = (uint32_t)(n - left);
+        }
+    }
+}
+
+ORC_API void orc_multinomial_strata(uint64_t seed, uint64_t step, uint64_t n_out, int k, uint32_t *offs)
+{
+    const uint64_t K = (uint64_t)1 << k;
+    const uint64_t draw = ORC_RESAMPLE_DRAW_BASE3 + step;
+    if (k <= ORC_STRATA_TOP) {
+        offs[0] = (uint32_t)n_out;
+        strata_split(seed, draw, 0, 1, k, K, offs);
+    } else {
+        const int G = orc_strata_groups(k);
+        const uint64_t sub = K >> ORC_STRATA_TOP;               /* strata below a level-6 node */
+        uint32_t top[64], acc[64];
+        memset(acc, 0, sizeof acc);
+        for (int g = 0; g < G; ++g) {
+            const uint64_t n_g = (uint64_t)(((unsigned __int128)n_out * (uint64_t)(g + 1)) / (uint64_t)G) - (uint64_t)(((unsigned __int128)n_out * (uint64_t)g) / (uint64_t)G);
+            memset(top, 0, sizeof top);
+            top[0] = (uint32_t)n_g;
+            strata_split(seed, draw, ((uint64_t)1 << 31) | ((uint64_t)g << 8), 1, ORC_STRATA_TOP, 64, top);
+            for (int i = 0; i < 64; ++i) acc[i] += top[i];
+        }
+        for (uint64_t i = 0; i < 64; ++i) {
+            offs[i * sub] = acc[i];
+            strata_split(seed, draw, 0, 64 + i, k - ORC_STRATA_TOP, sub, offs + i * sub);
+        }
+    }
+    uint64_t a = 0;
+    for (uint64_t w = 0; w < K; ++w) { const uint64_t m = offs[w]; offs[w] = (uint32_t)a; a += m; }
+    offs[K] = (uint32_t)a;
+}
+
+static uint64_t strata_bound(uint64_t total, uint64_t w, int k) { return (uint64_t)(((unsigned __int128)total * w) >> k); }
+
+ORC_API int orc_resample_fixed_multinomial_strata(const uint32_t *q, uint64_t n_in, uint64_t seed, uint64_t step, uint64_t n_out, int32_t *anc)
+{
+    const int k = orc_strata_levels(n_in);
+    const uint64_t K = (uint64_t)1 << k;
+    uint64_t *cdf = (uint64_t *)malloc((n_in ? n_in : 1) * sizeof(uint64_t));
+    uint32_t *offs = (uint32_t *)malloc((K + 1) * sizeof(uint32_t));
+    if (!cdf || !offs) { free(cdf); free(offs); return -1; }
+    uint64_t c = 0;
+    for (uint64_t i = 0; i < n_in; ++i) { c += q[i]; cdf[i] = c; }
+    const uint64_t total = c;
+    orc_multinomial_strata(seed, step, n_out, k, offs);
+    for (uint64_t w = 0; w < K; ++w) {
+        const uint64_t b0 = strata_bound(total, w, k), b1 = strata_bound(total, w + 1, k);
+        for (uint64_t s = offs[w]; s < offs[w + 1]; ++s) {
+            uint32_t r[4];
+            orc_draw_block(seed, s >> 1, ORC_RESAMPLE_DRAW_BASE2 + step, r);
+            const uint64_t v = (s & 1) ? bits53(r[2], r[3]) : bits53(r[0], r[1]);
+            const uint64_t tau = b0 + (uint64_t)(((unsigned __int128)(v << 11) * (b1 - b0)) >> 64);
+            uint64_t lo = 0, hi = n_in;               /* first i with cdf[i] > tau */
+            while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (cdf[mid] > tau) hi = mid; else lo = mid + 1; }
+            anc[s] = (int32_t)(lo < n_in ? lo : n_in - 1);
+        }
+    }
+    free(cdf); free(offs);
+    return 0;
+}
+
 /* e[s] = exp(ll_s - max ll) of step t of the HMM: the table the weights of generation t are drawn from */
 static void hmm_weight_table(double y, double e[3], double *mref)
 {
@@ -798,9 +971,9 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
     if (!logw || !cdf || !anc) return -1;
     double lz = 0.0;
     int do_resample = 0;
-    /* every resampler runs on integer masses (the fixed-point forms above) -- except systematic resampling of the 3-state HMM on an
-     * every-step schedule, which runs on integer prefix COUNTS (the table form), and ref_mode 3, the floating-point CDF */
-    const int table = resampler == ORC_RESAMPLE_SYSTEMATIC && model == ORC_MODEL_HMM3 && ess_frac > 1.0 && ref_mode == 0;
+    /* every resampler runs on integer masses (the fixed-point forms above) -- except systematic / stratified resampling of the 3-state
+     * HMM on an every-step schedule, which run on integer prefix COUNTS (the table forms), and ref_mode 3, the floating-point CDF */
+    const int table = (resampler == ORC_RESAMPLE_SYSTEMATIC || resampler == ORC_RESAMPLE_STRATIFIED) && model == ORC_MODEL_HMM3 && ess_frac > 1.0 && ref_mode == 0;
     const int fixed = ref_mode != 3 && !table;
     uint32_t *qw = fixed ? (uint32_t *)malloc(n * sizeof(uint32_t)) : NULL;
     uint64_t q_total = 0;
@@ -810,6 +983,7 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
             int rc;
             if (resampler == ORC_RESAMPLE_SYSTEMATIC) rc = orc_resample_fixed_systematic(qw, n, 0, q_total, 1, seed, (uint64_t)t, 0, n, n, anc);
             else if (resampler == ORC_RESAMPLE_STRATIFIED) rc = orc_resample_fixed_stratified(qw, n, 0, q_total, 1, seed, (uint64_t)t, 0, n, n, anc);
+            else if (resampler == ORC_RESAMPLE_MULTINOMIAL) rc = orc_resample_fixed_multinomial_strata(qw, n, seed, (uint64_t)t, n, anc);
             else rc = orc_resample_fixed_multinomial(qw, n, 0, q_total, seed, (uint64_t)t, 0, n, anc);
             if (rc) return -4;
         } else if (do_resample && table) {
@@ -818,9 +992,10 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
             uint64_t before[3] = { 0, 0, 0 }, total[3] = { 0, 0, 0 };
             hmm_weight_table(obs[t - 1], e, NULL);
             for (uint64_t i = 0; i < n; ++i) total[hist_int[(t - 1) * n + i]] += 1;
-            if (orc_resample_table_systematic(hist_int + (t - 1) * n, n, e, before, total, 1, seed, (uint64_t)t, 0, n, n, anc)) return -4;
+            if (resampler == ORC_RESAMPLE_SYSTEMATIC ? orc_resample_table_systematic(hist_int + (t - 1) * n, n, e, before, total, 1, seed, (uint64_t)t, 0, n, n, anc)
+                                                      : orc_resample_table_stratified(hist_int + (t - 1) * n, n, e, before, total, 1, seed, (uint64_t)t, 0, n, n, anc)) return -4;
         } else if (do_resample) {
-            orc_resample(resampler, logw, n, seed, (uint64_t)t, 0, n, n, anc, cdf);
+            orc_resample(resampler == ORC_RESAMPLE_MULTINOMIAL_LITERAL ? ORC_RESAMPLE_MULTINOMIAL : resampler, logw, n, seed, (uint64_t)t, 0, n, n, anc, cdf);
         } else {
             for (uint64_t i = 0; i < n; ++i) anc[i] = (int32_t)i;
         }

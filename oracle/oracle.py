@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 MODEL_GAUSSIAN_UNKNOWN_MEAN, MODEL_GAUSSIAN_README, MODEL_LINEAR_GAUSSIAN_1D, MODEL_HMM3, MODEL_GAUSSIAN_2D_UNKNOWN_MEAN = 0, 1, 2, 3, 4
-RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
+RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINOMIAL_LITERAL = 0, 1, 2, 3
 RESAMPLE_DRAW_BASE = 1 << 40
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -61,6 +61,8 @@ def lib():
         L.orc_resample.argtypes = [C.c_int, _dp, u64, u64, u64, u64, u64, u64, _ip, C.c_void_p]
         L.orc_resample_table_systematic.restype = C.c_int
         L.orc_resample_table_systematic.argtypes = [_ip, u64, _dp, _u64p, _u64p, C.c_int, u64, u64, u64, u64, u64, _ip]
+        L.orc_resample_table_stratified.restype = C.c_int
+        L.orc_resample_table_stratified.argtypes = [_ip, u64, _dp, _u64p, _u64p, C.c_int, u64, u64, u64, u64, u64, _ip]
         L.orc_fix_weight.restype = C.c_uint32; L.orc_fix_weight.argtypes = [dbl, dbl]
         L.orc_fix_weights.argtypes = [_dp, u64, dbl, _up]
         L.orc_resample_fixed_systematic.restype = C.c_int
@@ -70,6 +72,10 @@ def lib():
         L.orc_resample_fixed_multinomial.restype = C.c_int
         L.orc_resample_fixed_multinomial.argtypes = [_up, u64, u64, u64, u64, u64, u64, u64, _ip]
         L.orc_multinomial_threshold.restype = u64; L.orc_multinomial_threshold.argtypes = [u64, u64, u64, u64]
+        L.orc_resample_fixed_multinomial_strata.restype = C.c_int
+        L.orc_resample_fixed_multinomial_strata.argtypes = [_up, u64, u64, u64, u64, _ip]
+        L.orc_strata_levels.restype = C.c_int; L.orc_strata_levels.argtypes = [u64]
+        L.orc_multinomial_strata.argtypes = [u64, u64, u64, C.c_int, _up]
         L.orc_set_hmm.restype = C.c_int; L.orc_set_hmm.argtypes = [C.c_int, _dp, _dp]
         L.orc_smc.restype = C.c_int
         L.orc_smc.argtypes = [C.c_int, _dp, sz, u64, u64, C.c_int, dbl, C.c_void_p, C.c_void_p, _ip, _dp,
@@ -179,7 +185,7 @@ def resample(kind, logw, seed, step, j0=0, n_out=None, n_total_out=None):
     return anc
 
 
-def resample_table_systematic(x, e, seed, step, before=None, total=None, last_shard=True, j0=0, n_out=None, n_total_out=None):
+def resample_table_systematic(x, e, seed, step, before=None, total=None, last_shard=True, j0=0, n_out=None, n_total_out=None, stratified=False):
     """Order-independent systematic resampling of a table-weight generation (integer prefix counts): ancestors of the
     outputs [j0, j0 + n_out) among the sources x (states 0..2, weights e[state]); -1 where the ancestor is on another shard."""
     x = np.ascontiguousarray(x, np.int32)
@@ -190,10 +196,16 @@ def resample_table_systematic(x, e, seed, step, before=None, total=None, last_sh
     n_out = len(x) if n_out is None else n_out
     n_total_out = len(x) if n_total_out is None else n_total_out
     anc = np.zeros(n_out, np.int32)
-    rc = lib().orc_resample_table_systematic(x, len(x), e, before, total, int(bool(last_shard)), seed, step, j0, n_out, n_total_out, anc)
+    fn = lib().orc_resample_table_stratified if stratified else lib().orc_resample_table_systematic
+    rc = fn(x, len(x), e, before, total, int(bool(last_shard)), seed, step, j0, n_out, n_total_out, anc)
     if rc:
-        raise RuntimeError("orc_resample_table_systematic failed rc=%d" % rc)
+        raise RuntimeError("orc_resample_table_%s failed rc=%d" % ("stratified" if stratified else "systematic", rc))
     return anc
+
+
+def resample_table_stratified(x, e, seed, step, **kw):
+    """Stratified resampling of a table-weight generation on integer prefix counts (orc_resample_table_stratified)."""
+    return resample_table_systematic(x, e, seed, step, stratified=True, **kw)
 
 
 def fix_weights(logw, ref):
@@ -243,6 +255,26 @@ def resample_fixed_multinomial(q, seed, step, before=0, total=None, j0=0, n_out=
     if rc:
         raise RuntimeError("orc_resample_fixed_multinomial failed rc=%d" % rc)
     return anc
+
+
+def resample_fixed_multinomial_strata(q, seed, step, n_out=None):
+    """Multinomial resampling on integer weights, strata form (orc_resample_fixed_multinomial_strata): N iid thresholds as counts per
+    equal stratum (popcounts of Philox bits down a binary tree) and iid uniforms inside each stratum; ancestor = min{k : C_k > tau}."""
+    q = np.ascontiguousarray(q, np.uint32)
+    n_out = len(q) if n_out is None else n_out
+    anc = np.zeros(n_out, np.int32)
+    rc = lib().orc_resample_fixed_multinomial_strata(q, len(q), seed, step, n_out, anc)
+    if rc:
+        raise RuntimeError("orc_resample_fixed_multinomial_strata failed rc=%d" % rc)
+    return anc
+
+
+def multinomial_strata(seed, step, n_out, n_particles=None):
+    """offs[0 .. K]: the first output of every stratum (K = 2^k strata, k = strata_levels(n_particles))."""
+    k = lib().orc_strata_levels(n_out if n_particles is None else n_particles)
+    offs = np.zeros((1 << k) + 1, np.uint32)
+    lib().orc_multinomial_strata(seed, step, n_out, k, offs)
+    return offs
 
 
 def multinomial_threshold(seed, j, step, total):

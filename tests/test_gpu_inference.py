@@ -224,25 +224,32 @@ def test_smc_lgssm_matches_oracle(engine, golden_dir, resampler, ess):
     _compare_smc(engine, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, 20000, 5, resampler, ess)
 
 
-@pytest.mark.parametrize("resampler", [cp.RESAMPLE_STRATIFIED, cp.RESAMPLE_MULTINOMIAL])
+@pytest.mark.parametrize("kind", ["stratified", "multinomial", "multinomial_literal"])
 @pytest.mark.parametrize("model,key,T,ess,n", [(cp.MODEL_HMM3, "hmm16", 16, 2.0, 30_000), (cp.MODEL_HMM3, "hmm16", 16, 2.0, 1_200_000),
                                                (cp.MODEL_HMM3, "hmm16", 8, 0.5, 4_300_000), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 12, 2.0, 1_250_000),
                                                (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 20, 0.5, 300_001)])
-def test_smc_stratified_and_multinomial_are_bit_exact_against_the_oracle(engine, golden_dir, resampler, model, key, T, ess, n):
-    """Stratified and multinomial resampling (thesis Alg. 1 p.36 is multinomial) on the integer masses of the fixed-point form
-    (cpprob/detail/fixed_mass.hpp: FixedCdf::first_stratified, csrc/step_fixed.hpp: fixed_multinomial_ancestors; oracle:
-    orc_resample_fixed_stratified / orc_resample_fixed_multinomial): ancestors, decisions and the HMM's states equal the oracle's
-    at one, two and three levels of the mass hierarchy, on every-step and ESS-triggered schedules."""
+def test_smc_stratified_and_multinomial_are_bit_exact_against_the_oracle(engine, golden_dir, kind, model, key, T, ess, n):
+    """Stratified and multinomial resampling (thesis Alg. 1 p.36 is multinomial) on integers -- the masses of the fixed-point form
+    (cpprob/detail/fixed_mass.hpp: FixedCdf::first_stratified; csrc/step_fixed.hpp: multinomial_bin_kernel + binned_walk, and under
+    CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL fixed_multinomial_ancestors) or the prefix counts of the table form (stratified, 3-state HMM,
+    every-step schedule); oracle: orc_resample_fixed_stratified / _multinomial_binned / _multinomial, orc_resample_table_stratified.
+    Ancestors, decisions and the HMM's states equal the oracle's at one, two and three levels of the mass hierarchy, on every-step
+    and ESS-triggered schedules."""
     obs = _obs(golden_dir, key)[:T]
-    engine.begin(cp.ALG_SMC, model, obs, n, seed=13, resampler=resampler, ess_threshold=ess)
+    resampler = cp.RESAMPLE_STRATIFIED if kind == "stratified" else cp.RESAMPLE_MULTINOMIAL
+    engine.begin(cp.ALG_SMC, model, obs, n, seed=13, resampler=resampler, ess_threshold=ess, flags=cp.capi.FLAG_MULTINOMIAL_LITERAL if kind == "multinomial_literal" else 0)
     engine.run()
     s = engine.summary()
-    assert s["step_form"] == cp.capi.FORM_FIXED
-    ref = O.smc(model, obs, n, 13, resampler, ess)
+    # (the three-state HMM on an every-step schedule: stratified resampling runs on integer prefix COUNTS like systematic)
+    counts = model == cp.MODEL_HMM3 and ess > 1.0 and resampler == cp.RESAMPLE_STRATIFIED
+    assert s["step_form"] == (cp.capi.FORM_COUNTS if counts else cp.capi.FORM_FIXED)
+    ref = O.smc(model, obs, n, 13, O.RESAMPLE_MULTINOMIAL_LITERAL if kind == "multinomial_literal" else resampler, ess)
     anc, vals = engine.ancestors(), engine.values()
     gess, gres = engine.step_trace()
     assert np.array_equal(gres, ref["resampled"])
     assert np.array_equal(anc, ref["anc"]), [int(np.count_nonzero(anc[t] != ref["anc"][t])) for t in range(T)]
+    if kind == "multinomial":                                   # strata form: an output's ancestor sits near it (thresholds sorted stratum by stratum)
+        assert all(np.max(np.maximum.accumulate(anc[t]) - anc[t]) < 8192 for t in range(1, T) if gres[t - 1])
     if model == cp.MODEL_HMM3:
         assert np.array_equal(vals, ref["hist"])
     else:
@@ -251,8 +258,11 @@ def test_smc_stratified_and_multinomial_are_bit_exact_against_the_oracle(engine,
     assert abs(s["log_evidence"] - ref["log_z"]) < 1e-9
     if resampler == cp.RESAMPLE_STRATIFIED:
         assert all(np.all(np.diff(anc[t]) >= 0) for t in range(1, T))
-    sm_self = O.smoothing_linear(vals, anc, O.fix_weights(engine.logw(), s["max_logw"]).astype(np.float64))
-    np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-10, atol=1e-12)
+    if counts:
+        np.testing.assert_allclose(engine.stats(), O.smoothing(ref["hist"], ref["anc"], ref["logw"]), atol=1e-12)
+    else:
+        sm_self = O.smoothing_linear(vals, anc, O.fix_weights(engine.logw(), s["max_logw"]).astype(np.float64))
+        np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-10, atol=1e-12)
 
 
 @pytest.mark.parametrize("n", [1, 2, 1023, 1025, 4095, 4097, 12289])
