@@ -78,7 +78,7 @@ struct cpprob_hip_ctx {
     double* d_stats_part = nullptr;
     double* d_stats = nullptr;
     uint32_t* d_strata = nullptr;   // multinomial, strata form: [T - 1][2^k + 1] first outputs of the strata, every step of the run
-    uint32_t* d_strata_top = nullptr; int strata_phase = 0;   // ... [2][T][64] totals of the level-6 nodes (the set in use alternates run by run)
+    uint32_t* d_strata_top = nullptr; int strata_phase = 0; bool strata_pending = false;   // ... [2][T][64] totals of the level-6 nodes (the set in use alternates run by run)
     double* d_cdf = nullptr;        // multinomial only
     int32_t* d_anc_pre = nullptr;   // multinomial only
     double* d_local_totals = nullptr;
@@ -548,6 +548,26 @@ static void hier_rotation(cpprob_hip_ctx* c, int t, int& kp, int& kn, int& kc)
     kp = (t + c->hier_phase_run) % 3; kn = (kp + 1) % 3; kc = (kp + 2) % 3;
 }
 
+// Multinomial resampling, strata form (step_fixed.hpp): how many thresholds fall into each stratum does not depend on the weights --
+// every step's counts in ONE launch (two above 64 tiles) in front of the run's first step.
+static void launch_strata(cpprob_hip_ctx* c)
+{
+    if (!c->strata_pending) return;
+    c->strata_pending = false;
+    if (c->T < 2 || !c->d_strata) return;
+    ProfScope ps(c, 5);
+    StrataArgs sa{};
+    sa.seed = c->run_seed; sa.t0 = 1; sa.k = strata_levels(c->nb); sa.n_out = (uint32_t)c->n; sa.offs = c->d_strata;
+    if (sa.k <= kStrataTop) hipLaunchKernelGGL(multinomial_strata_kernel, dim3(1, c->T - 1), dim3(kThreads), 0, c->stream, sa);
+    else {
+        // (two sets of the steps' level-6 totals: the bottom launch clears the set the NEXT run adds into)
+        sa.top = c->d_strata_top + (size_t)c->strata_phase * (size_t)c->T * 64; sa.top_clear = c->d_strata_top + (size_t)(c->strata_phase ^ 1) * (size_t)c->T * 64;
+        c->strata_phase ^= 1;
+        hipLaunchKernelGGL(multinomial_strata_top_kernel, dim3(strata_groups(sa.k), c->T - 1), dim3(kThreads), 0, c->stream, sa);
+        hipLaunchKernelGGL(multinomial_strata_bottom_kernel, dim3(64, c->T - 1), dim3(kThreads), 0, c->stream, sa);
+    }
+}
+
 template <class Model>
 void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int world, int rank)
 {
@@ -570,25 +590,10 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         const int rs = c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED ? kFixStratified
                      : (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL ? ((c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL) ? kFixMultinomialLiteral : kFixMultinomial) : kFixSystematic);
         if (rs == kFixMultinomial) {
-            // strata form: how many thresholds fall into each stratum does not depend on the weights -- every step's counts in ONE
-            // launch in front of the run's first step
             a.prefetch = 0;
             a.strata_k = strata_levels(c->nb);
-            const size_t per_step = ((size_t)1 << a.strata_k) + 1;
-            if (t == 0 && c->T > 1) {
-                ProfScope ps(c, 5);
-                StrataArgs sa{};
-                sa.seed = c->run_seed; sa.t0 = 1; sa.k = a.strata_k; sa.n_out = (uint32_t)c->n; sa.offs = c->d_strata;
-                if (a.strata_k <= kStrataTop) hipLaunchKernelGGL(multinomial_strata_kernel, dim3(1, c->T - 1), dim3(kThreads), 0, c->stream, sa);
-                else {
-                    // (two sets of the steps' level-6 totals: the bottom launch clears the set the NEXT run adds into)
-                    sa.top = c->d_strata_top + (size_t)c->strata_phase * (size_t)c->T * 64; sa.top_clear = c->d_strata_top + (size_t)(c->strata_phase ^ 1) * (size_t)c->T * 64;
-                    c->strata_phase ^= 1;
-                    hipLaunchKernelGGL(multinomial_strata_top_kernel, dim3(strata_groups(a.strata_k), c->T - 1), dim3(kThreads), 0, c->stream, sa);
-                    hipLaunchKernelGGL(multinomial_strata_bottom_kernel, dim3(64, c->T - 1), dim3(kThreads), 0, c->stream, sa);
-                }
-            }
-            a.strata_offs = t > 0 ? c->d_strata + (size_t)(t - 1) * per_step : nullptr;
+            if (t == 0) launch_strata(c);
+            a.strata_offs = t > 0 ? c->d_strata + (size_t)(t - 1) * (((size_t)1 << a.strata_k) + 1) : nullptr;
         }
         if (rs == kFixMultinomialLiteral) {
             // the lanes' in-tile prefixes travel with the weights (ping-pong, in the halves of the floating-point form's CDF array);
@@ -1191,6 +1196,8 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
         }
         const bool fused = step_is_fused(c);
         if (c->fixed_mode) {
+            c->strata_pending = c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && !(c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL);
+            launch_strata(c);
             ProfScope group(c, 0, c->T);
             c->profile_suspended = true;
             for (int t = 0; t < c->T; ++t) dispatch_model(c, [&](auto m) { launch_step_fixed<decltype(m)>(c, t, nullptr, 1, 0); });
@@ -1280,6 +1287,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     const bool sis = c->cfg.algorithm == CPPROB_HIP_ALG_SIS;
     if (sis && t != c->T - 1) return fail(c, CPPROB_HIP_EINVAL, "SIS shards run in one launch: call step_begin(T-1) only");
     if (t == 0 || sis) {
+        c->strata_pending = !sis && c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && !(c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL);
         c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; c->annex_used = 0; c->plan.t = -1; c->x_plan_t = -1;
         c->final_from_counts = false; c->final_from_fixed = false;
         c->counts_mode = false; c->fixed_mode = false;

@@ -505,7 +505,13 @@ __device__ __forceinline__ void step_prologue()
                 // the generation's totals: every rank's 24 bytes, read where they lie (lane r = rank r)
                 uint64_t s_r = 0, q_r = 0, m_r = 0;
                 if (lane < world) {
-                    // (system scope: the words lie in another rank's memory and were written since this device last read that line)
+                    // (system scope: the words lie in another rank's memory and were written since this device last read that line.
+                    //  The RULE for every other peer read of this prologue -- the peers' hierarchy words, integer weights and carry
+                    //  windows -- is the kernel boundary: they are written by launches that completed before this one began (stream waits
+                    //  on the peers' events), this launch starts with invalidated L1 / L2 lines for memory it does not own, and they are
+                    //  plain loads.  That rule has only ever been exercised between loopback ranks of ONE device, which is why
+                    //  generic_joint_launcher (cpprob/gpu.hpp) runs islands across physical devices unless Options::joint_across_devices
+                    //  asks for the joint form; the totals, read in the launch's first instructions, keep the stronger form.)
                     const uint64_t* tp = A->sh.peers[lane].totals;
                     s_r = __hip_atomic_load(tp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     q_r = __hip_atomic_load(tp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

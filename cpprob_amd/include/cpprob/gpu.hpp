@@ -266,6 +266,8 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
                   "CPPROB_REGISTER_MODEL: the observes tuple is copied to the device bytewise, so every model argument must be trivially "
                   "copyable (arithmetic types, std::array of them); models with std::vector / NDArray arguments own host heap memory");
     const auto t_setup = std::chrono::steady_clock::now();
+    // (what an earlier attempt of the same call reported is not this attempt's: a refuted window must not outlive its refutation)
+    res.replay_window = -1; res.step_ess.clear(); res.n_resampled = 0;
     WorkspaceLease ws(opt.device);
     Context& ctx = ws->ctx;
     hip_check(hipSetDevice(opt.device), "hipSetDevice");
@@ -566,14 +568,25 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
         if (!ok) use = &st_full;
     }
     StepForm form = st.bounds_fixed ? StepForm::fused_bounded : StepForm::fused_exact;
-    if (opt.step_form_override >= 0) form = static_cast<StepForm>(opt.step_form_override);
+    if (opt.step_form_override >= 0) {
+        if (opt.step_form_override > 2) throw std::invalid_argument("cpprob::gpu::Options::step_form_override: 0 (unfused), 1 (bounded) or 2 (exact maximum)");
+        form = static_cast<StepForm>(opt.step_form_override);
+    }
+    bool rows_exhausted = false;
     for (int attempt = 0; attempt < 6; ++attempt) {
         const int rc = generic_attempt<Caller>(algorithm, observes_v, n, *use, opt, res, store, S, form);
         if (rc == 0) return;
         if (rc == 3) use = &st_full;                               // the device saw what the host probe did not: replay the whole trace
-        else if (rc == 4) form = StepForm::fused_exact;             // a generation did not fit its bound: references from exact maxima
-        else S *= 4;
+        else if (rc == 4) {
+            // a generation did not fit its reference: bounded -> exact maxima -> the three-launch form (its own maximum pass); a
+            // generation that has no mass in ANY form (every likelihood -inf) is the model's, not a form's
+            if (form == StepForm::fused_bounded) form = StepForm::fused_exact;
+            else if (form == StepForm::fused_exact) form = StepForm::unfused;
+            else throw std::runtime_error("cpprob::inference(smc): a generation carries no mass (every particle's likelihood is zero at some observe statement)");
+        }
+        else { S *= 4; rows_exhausted = true; }
     }
+    if (!rows_exhausted) throw std::runtime_error("cpprob::inference(smc): no step form completed the run (replay window and references were refuted in turn)");
     throw std::runtime_error("cpprob::inference(smc): a particle executed more than " + std::to_string(S / 4) + " sample statements "
                              "(data-dependent loop, e.g. rejection sampling, that rarely terminates); use StateType::sis for this model");
 }
@@ -955,6 +968,17 @@ bool generic_joint_launcher(StateType algorithm, const void* observes_v, std::si
     if (algorithm != StateType::smc || st.window < 0 || opt.resampler != CPPROB_HIP_RESAMPLE_SYSTEMATIC || world < 2 || world > device::kMaxShards) return false;
     if (st.n_observe > device::kWinMaxObserves || st.real_rows() > device::kWinMaxPredicts || st.int_ids.size() > device::kWinMaxPredicts) return false;
     if ((n + world - 1) / world >= (std::size_t(1) << device::kShardIndexBits) || n >= (std::size_t(1) << 31)) return false;
+    if (n < (std::size_t)world) return false;                          // (a shard would be empty: the caller runs islands)
+    // Ranks on DIFFERENT physical devices: every peer read of the step's prologue (totals, hierarchy words, integer weights, carry
+    // windows) relies on a kernel boundary refreshing lines another device rewrote, and on peer access covering workspace blocks
+    // allocated before it was enabled.  Neither has met a real link (every run so far: loopback ranks of one device), so the joint
+    // form is offered there only on request (Options::joint_across_devices) and the caller runs islands otherwise -- said in Result.
+    {
+        bool distinct = false;
+        for (int r = 1; r < world; ++r) distinct = distinct || opt.devices[(size_t)r] != opt.devices[0];
+        if (distinct && !opt.joint_across_devices) { res.joint_note = "joint population across physical devices is unvalidated on real links: islands (set Options::joint_across_devices to run it)"; return false; }
+        if (distinct) res.joint_note = "joint population across physical devices: not yet validated against the single-device run on real links";
+    }
     // the replay window is certified on one device first (generic_launcher's pilot: once per model and trace shape)
     {
         Options po = opt; po.devices.clear(); po.device = opt.devices[0]; po.dump = false;

@@ -43,6 +43,8 @@ struct Options {
                                                       // 1 the resampling inside the model's launch against the dry run's bounds, 2 ... against exact maxima
     int replicates = 1;                               // built-in models: R independent runs (seeds seed .. seed + R - 1), up to three in
                                                       // flight on separate contexts; Result then carries their spread (error bars)
+    bool joint_across_devices = false;                // smc, unchanged models, `devices` naming DIFFERENT GPUs: run the joint population (its peer reads have
+                                                      // only ever run between loopback ranks of one device) instead of islands; Result::joint_note says so
 };
 
 struct PredictStats {            // one per predict hit, StatsPrinter's numbers
@@ -64,6 +66,7 @@ struct Result {
     int replay_window = -1;                   // unchanged-model smc: samples of the ancestor a step replays (-1: the whole trace)                  // multi-GPU: runs repeated with a larger lineage transport (results never depend on it)
     bool joint = false;                       // unchanged-model smc over several ranks: ONE joint population (false: islands combined by their evidence)
     int joint_flag = 0;                       // (a rank's share of a joint run: the flag its generations raised)
+    std::string joint_note;                   // why a multi-device smc call of an unchanged model ran islands, or that its joint run is unvalidated on real links
     int step_form = 0;                        // unchanged-model smc: 0 separate bookkeeping launches, 1 fused step on bounded references, 2 fused step + exact-maximum pass
     int launches_per_step = 0;                // unchanged-model smc: dependent launches per observe
     double setup_seconds = 0;                 // unchanged-model path: context / workspace / scratch set-up and the Markov pilot of THIS call (0.0x ms once the workspace is warm)

@@ -150,7 +150,9 @@ def test_unchanged_model_step_falls_back_to_exact_maxima_when_a_generation_leave
     # sees the generation leave its bound, and the run is repeated on exact maxima -- the single-context answer, bit for bit
     many, _, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 11, "--ess_threshold", 2.0, "--json",
                           "--generic", "--generated_file", "m", "--devices", "0,0,0")
-    assert many["joint"] is True and many["step_form"] == 2 and many["log_evidence"] == res["log_evidence"]
+    # (traces, weights and ancestors are the same integers; the joint form's evidence takes its logarithms on the host -- glibc against
+    #  the device's log: a few units in the last place, not a guaranteed tie)
+    assert many["joint"] is True and many["step_form"] == 2 and abs(many["log_evidence"] - res["log_evidence"]) <= 16 * np.spacing(abs(res["log_evidence"]))
     vm, lwm = read_dump(str(tmp_path / "m_smc.int"), True)
     assert np.array_equal(vm, vg) and np.array_equal(lwm, lwg)
 
@@ -423,7 +425,9 @@ def test_unchanged_model_smc_over_several_ranks_is_the_single_device_population(
     v1, lw1 = read_dump(str(tmp_path / ("one_smc." + ext)), is_int)
     vm, lwm = read_dump(str(tmp_path / ("many_smc." + ext)), is_int)
     assert np.array_equal(v1, vm) and np.array_equal(lw1, lwm)
-    assert many["log_evidence"] == one["log_evidence"] and many["n_resampled"] == one["n_resampled"]
+    # (the exact-maximum form of the joint run takes the evidence's logarithms on the host: a few units in the last place of the device's)
+    assert abs(many["log_evidence"] - one["log_evidence"]) <= (16 * np.spacing(abs(one["log_evidence"])) if model == "random_scale12" else 0.0)
+    assert many["n_resampled"] == one["n_resampled"]
     for a, b in zip(one["predicts"], many["predicts"]):
         if "p" in a:
             np.testing.assert_allclose(a["p"], b["p"], rtol=0, atol=1e-12)
