@@ -13,7 +13,7 @@ RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
 SCOPE_GLOBAL, SCOPE_ISLAND, SCOPE_EXCHANGE = 0, 1, 2
 # cpprob_hip_config::flags (A/B forms; 0 = the measured optimum)
 FLAG_FLOATING_POINT_STEP, FLAG_NO_SKIP_ROWS, FLAG_SIS_PER_TILE, FLAG_SIS_SEPARATE_READOUT, FLAG_WREL_STORED, FLAG_FP_TILE_PARTIALS, FLAG_WALK_READOUT = 1, 2, 4, 8, 16, 32, 64
-FLAG_MULTINOMIAL_LITERAL = 128
+FLAG_MULTINOMIAL_LITERAL, FLAG_PAIRED_STEP_LAUNCH = 128, 512
 N_KERNEL_CLASSES = 6
 KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", "resample"]
 

@@ -613,14 +613,28 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
         if (!c->keep) a.anc = nullptr;
         {
             ProfScope ps(c, 0);
-            if (rs == kFixMultinomial) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            // A/B form (CPPROB_HIP_FLAG_PAIRED_STEP_LAUNCH): on schedules where a step may not resample, the step as two launches, each ending
+            // at once when the step is the other's (step_fixed.hpp: smc_step_fixed_carry_body).  Measured at configs[4]'s shard: the carry
+            // launch takes 70 us where the two-form kernel's non-resampling launches take 81, and the second launch costs what that saves.
+            const bool paired = a.may_carry && t > 0 && (c->cfg.flags & CPPROB_HIP_FLAG_PAIRED_STEP_LAUNCH) && rs != kFixMultinomialLiteral;
+            if (paired) {
+                const bool sh = all_totals != nullptr;
+                if (sh) hipLaunchKernelGGL((smc_step_fixed_carry_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+                else hipLaunchKernelGGL((smc_step_fixed_carry_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+                if (rs == kFixMultinomial) hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+                else if (rs == kFixStratified) hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+                else if (sh) hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, true, kFixSystematic>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+                else hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, false, kFixSystematic>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            }
+            else if (rs == kFixMultinomial) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixMultinomialLiteral) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomialLiteral>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixStratified && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (rs == kFixStratified && !Model::kIsInt) hipLaunchKernelGGL((smc_step_fixed_five_kernel<Model, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixStratified) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (all_totals && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (all_totals) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (a.prefetch) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
-            else if (!Model::kIsInt) hipLaunchKernelGGL(smc_step_fixed_five_kernel<Model>, dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (!Model::kIsInt) hipLaunchKernelGGL((smc_step_fixed_five_kernel<Model>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         }
 #ifdef CPPROB_STAMPS

@@ -601,7 +601,12 @@ __device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const Fi
     if (resampled) resampled[t_prev] = d.resample ? 1 : 0;
 }
 
-template <class Model, bool SHARDED, bool PREFETCH, int RS = kFixSystematic>
+// PAIRED launches (CPPROB_HIP_FLAG_PAIRED_STEP_LAUNCH: an A/B form, measured and NOT the default -- profiles/r05_notes.md): a step is TWO launches back to back -- this body with
+// RESAMPLING_ONLY, and smc_step_fixed_carry_body below, the step that resamples nothing -- each of which takes generation t-1's
+// decision from its totals in every workgroup's first instructions and ends at once when the step is the other one's.  What that buys:
+// the carry form has no search, walk, gather or ancestor row in it (half the registers, eight wavefronts a SIMD) and streams; what it
+// costs: one launch of workgroups that read 24 bytes and leave.
+template <class Model, bool SHARDED, bool PREFETCH, int RS = kFixSystematic, bool RESAMPLING_ONLY = false>
 __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& a)
 {
     using V = typename Model::value_t;
@@ -676,7 +681,9 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
         // (the resampling's own uniforms: ids are population-wide in a sharded run; a population of its own offsets them by pid0,
         //  which there only selects streams)
         fc.seed = a.seed; fc.draw = kResampleDrawBase + (uint64_t)t; fc.uid0 = SHARDED ? 0 : a.pid0;
-        if constexpr (RS == kFixStratified) stratified_stage(L, fc.seed, fc.draw, fc.uid0 + (uint64_t)gj_first);
+        // (stratified: the outputs' uniforms are staged here, under the entry loads, where every step resamples; on a schedule where steps
+        //  may not, behind the decision -- a second barrier on the steps that do resample, no Philox block on those that do not)
+        if constexpr (RS == kFixStratified) { if (!a.may_carry) stratified_stage(L, fc.seed, fc.draw, fc.uid0 + (uint64_t)gj_first); }
         if (searcher) {
             uint64_t St, Qt; double Mt; uint64_t before = 0;
             const FTot own = ftot_sum(a.f, tw);
@@ -688,7 +695,7 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
             const FixedDecision d = fixed_decide(St, Qt, a.n_pop, a.ess_frac, true);        // (generation t-1 is never the last one here)
             fc.inv = d.inv; fc.base = before;
             const double r_t = fixed_reference(d.resample, Mt, a.bound);
-            if (bid == 0 && tid == 0) {
+            if (bid == 0 && tid == 0 && (!RESAMPLING_ONLY || d.resample)) {          // (paired launches: the books are kept by the launch whose step it is)
                 StepCtrl* c = a.ctrl;
                 fixed_bookkeep(c, t - 1, d, c->ref_cur, a.n_pop, a.u0, a.ess_trace, a.resampled, false, Mt);
                 c->ref_cur = r_t;
@@ -713,6 +720,7 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
         __syncthreads();                                               // slots reset, search results in place
     CPH_STAMP(2);
         resample = s_found.resample != 0;
+        if (RESAMPLING_ONLY && !resample) return;                      // this step carries its weights: the other launch's
         ref = s_found.ref;
         if (resample && RS == kFixMultinomialLiteral) {
             fixed_multinomial_ancestors(s_found.S, fc.seed, fc.draw, fc.uid0 + (uint64_t)j0, a.tile_prefix, nb, a.lane_prefix_prev, a.q_prev, anc);
@@ -724,6 +732,7 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
             }
         } else if (resample) {
             fc.inv = s_found.inv; fc.base = s_found.base;
+            if constexpr (RS == kFixStratified) { if (a.may_carry) { stratified_stage(L, fc.seed, fc.draw, fc.uid0 + (uint64_t)gj_first); __syncthreads(); } }
             fixed_walk<RS>(fc, a.q_prev, a.n, nb, last_shard, gj_first, n_out, s_found.loc, guess, PREFETCH, q_m1, q_0, q_p1, anc, L);
             if (SHARDED) {
                 const int64_t l0 = s_found.l0, l1 = s_found.l1;
@@ -810,13 +819,84 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
 #endif
 }
 
+// The step that resamples nothing (t > 0, a schedule on which weights may carry): every slot extends itself.  Each wavefront takes the
+// decision itself (no barrier in front of it), then streams: states and log-weights in, states, integer weights and log-weights out.
+// (A form whose workgroups follow several tiles with the next tile's inputs in flight was built and measured: the loop keeps the
+//  polynomial constants live -- 40 -> 94 registers -- and the launch took 87 us against this form's 70: profiles/r05_notes.md.)
+template <class Model, bool SHARDED>
+__device__ __forceinline__ void smc_step_fixed_carry_body(const StepFixedArgs<Model>& a)
+{
+    using V = typename Model::value_t;
+    __shared__ uint64_t s_red[3 * kWaves];
+    const int tid = threadIdx.x, lane = lane_id();
+    const int nb = (int)gridDim.x;
+    const int bid = xcd_contiguous_tile((int)blockIdx.x, nb);
+    const int64_t j0 = (int64_t)bid * kTile + (int64_t)tid * kPPT;
+    const int t = a.t;
+    uint64_t St, Qt; double Mt;
+    if (SHARDED) {
+        uint64_t rs_ = 0, rq_ = 0, rm_ = 0;
+        if (lane < a.world) { rs_ = a.all_totals[3 * lane]; rq_ = a.all_totals[3 * lane + 1]; rm_ = a.all_totals[3 * lane + 2]; }
+        St = wave_sum_u64(rs_); Qt = wave_sum_u64(rq_); Mt = dkey_inv(wave_max_u64(rm_));
+    } else { const FTot own = ftot(a.f); St = own.S; Qt = own.Q; Mt = own.M; }
+    const FixedDecision d = fixed_decide(St, Qt, a.n_pop, a.ess_frac, true);
+    if (d.resample) return;                                            // this step resamples: the other launch's
+    const double ref = fixed_reference(false, Mt, a.bound);
+    if (bid == 0 && tid == 0) {
+        StepCtrl* c = a.ctrl;
+        fixed_bookkeep(c, t - 1, d, c->ref_cur, a.n_pop, a.u0, a.ess_trace, a.resampled, false, Mt);
+        c->ref_cur = ref;
+    }
+    double lw_carry[kPPT];
+    load4(a.logw_prev, j0, lw_carry);
+    V prev[kPPT], x[kPPT];
+    load4_as(a.values + (int64_t)a.row_r * a.rs, j0, prev);
+    typename Model::Rand rnd[kPPT / 4];
+#pragma unroll
+    for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+#pragma unroll
+    for (int q = 0; q < kPPT / 4; ++q)
+        Model::apply4(a.mp, t, rnd[q], reinterpret_cast<const V(&)[4]>(prev[4 * q]), reinterpret_cast<V(&)[4]>(x[4 * q]));
+    store4_as(a.values + (int64_t)a.row_w * a.rs, j0, x);
+    double lw[kPPT];
+    U4 q;
+    uint64_t s_l = 0, q_l = 0;
+    double m_l = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) {
+        lw[k] = lw_carry[k] + Model::loglik(a.mp, x[k], t, a.obs);
+        if (j0 + k >= a.n) lw[k] = -INFINITY;
+        const uint32_t w = fix_weight(lw[k], ref);
+        q[k] = w;
+        s_l += w; q_l += fix_square(w);
+        m_l = fmax(m_l, lw[k]);
+    }
+    const uint64_t s_w = wave_sum_u34(s_l), q_w = wave_sum_u34(q_l), m_w = wave_max_key(dkey(m_l));
+    if (lane == 0) { s_red[wave_id()] = s_w; s_red[kWaves + wave_id()] = q_w; s_red[2 * kWaves + wave_id()] = m_w; }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t S2 = 0, Q2 = 0, Mk = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { S2 += s_red[w]; Q2 += s_red[kWaves + w]; Mk = umax64(Mk, s_red[2 * kWaves + w]); }
+        fhier_publish(a.f, bid, nb, S2, Q2, Mk);
+    }
+    *reinterpret_cast<U4*>(a.q_next + j0) = q;
+    store4(a.logw_next, j0, lw);
+}
+template <class Model, bool SHARDED>
+__global__ __launch_bounds__(kThreads) void smc_step_fixed_carry_kernel(StepFixedArgs<Model> a) { smc_step_fixed_carry_body<Model, SHARDED>(a); }
+// ... and its partner: the step that does resample (systematic / stratified / strata-form multinomial), no prefetch of source tiles
+template <class Model, bool SHARDED, int RS>
+__global__ __launch_bounds__(kThreads) void smc_step_fixed_resampling_kernel(StepFixedArgs<Model> a)
+{ smc_step_fixed_body<Model, SHARDED, false, RS, true>(a); }
+
 // One population on this GPU.  PREFETCH: the three likely source tiles' weights are fetched at kernel entry (every-step schedules).
 template <class Model, bool PREFETCH, int RS = kFixSystematic>
 __global__ __launch_bounds__(kThreads) void smc_step_fixed_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, false, PREFETCH, RS>(a); }
 // The continuous models without the prefetch sit one register above five wavefronts a SIMD: told to fit (one spilled dword), 1221
 // workgroups -- 1.25 10^6 particles -- run in one pass.
-template <class Model>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void smc_step_fixed_five_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, false, false>(a); }
+template <class Model, int RS = kFixSystematic>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void smc_step_fixed_five_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, false, false, RS>(a); }
 // One shard of a joint population.  Five wavefronts a SIMD (96 registers; the continuous models' build wants 138 and spills ~25
 // of them): configs[3]'s shard of 1.25 10^6 particles is 1221 workgroups, and 256 CUs hold 1280 of them at five a CU but 768 at
 // three -- a second pass of workgroups behind the first costs more than the spills (profiles/r03_notes.md).

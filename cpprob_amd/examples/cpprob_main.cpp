@@ -37,7 +37,7 @@ void print_json(const cpprob::gpu::Result& r)
     std::cout << "{\"n\": " << r.n_particles << ", \"log_evidence\": " << r.log_evidence << ", \"ess\": " << r.ess
               << ", \"n_resampled\": " << r.n_resampled << ", \"run_seconds\": " << r.run_seconds << ", \"builtin\": " << (r.used_builtin ? "true" : "false")
               << ", \"n_gpus\": " << r.n_gpus << ", \"exchange_reruns\": " << r.exchange_reruns << ", \"replay_window\": " << r.replay_window << ", \"markov_crosscheck\": " << r.markov_crosscheck
-              << ", \"joint\": " << (r.joint ? "true" : "false") << ", \"step_form\": " << r.step_form << ", \"launches_per_step\": " << r.launches_per_step << ", \"setup_seconds\": " << r.setup_seconds
+              << ", \"joint\": " << (r.joint ? "true" : "false") << ", \"joint_note\": \"" << r.joint_note << "\"" << ", \"step_form\": " << r.step_form << ", \"launches_per_step\": " << r.launches_per_step << ", \"setup_seconds\": " << r.setup_seconds
               << ", \"workspace_grown\": " << (r.workspace_grown ? "true" : "false") << ", \"predicts\": [";
     for (std::size_t i = 0; i < r.predicts.size(); ++i) {
         const auto& p = r.predicts[i];
@@ -127,6 +127,7 @@ int main(int argc, char** argv)
         else if (f == "--generic") opt.prefer_builtin = false;
         else if (f == "--filtering_only") { opt.keep_history = false; opt.dump = false; }   // smc, built-in models: O(N) particle store, filtering statistics
         else if (f == "--islands") opt.islands = true;                          // unchanged-model smc over several ranks: independent runs combined by evidence
+        else if (f == "--joint_across_devices") opt.joint_across_devices = true; // ... or the joint population even across physical GPUs (unvalidated on real links)
         else if (f == "--step_form") opt.step_form_override = std::stoi(next());   // unchanged-model smc: 0 separate bookkeeping launches, 1 fused (bounds), 2 fused (exact maxima)
         else if (f == "--no_markov_probe") opt.markov_probe = false;          // unchanged-model smc: replay the whole trace every step
         else if (f == "--no_markov_crosscheck") opt.markov_crosscheck = false; // ... trust the host probe's window without the device pilot

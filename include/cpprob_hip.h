@@ -130,6 +130,7 @@ typedef struct cpprob_hip_config {
 #define CPPROB_HIP_FLAG_WREL_STORED 16u          /* floating-point step of table-weight models: read stored linear weights, not states */
 #define CPPROB_HIP_FLAG_FP_TILE_PARTIALS 32u     /* ... and fp64 tile partials instead of packed per-value counts */
 #define CPPROB_HIP_FLAG_WALK_READOUT 64u         /* short discrete traces: read the posterior out by the lineage walk, not from trace words */
+#define CPPROB_HIP_FLAG_PAIRED_STEP_LAUNCH 512u  /* fixed-point form, ESS-triggered schedules (A/B): a step as two launches {carry, resampling} of which one ends at once */
 #define CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL 128u /* multinomial resampling: ancestor of output j = min{k : C_k > floor(u_j C_N)}, one search per output */
 
 /* Posterior summary of a finished run -- what StatsPrinter prints

@@ -265,6 +265,28 @@ def test_smc_stratified_and_multinomial_are_bit_exact_against_the_oracle(engine,
         np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("model,key,T", [(cp.MODEL_HMM3, "hmm128", 40), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 30)])
+@pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_STRATIFIED, cp.RESAMPLE_MULTINOMIAL])
+def test_paired_step_launches_are_the_single_launch_bit_for_bit(engine, golden_dir, model, key, T, resampler):
+    """CPPROB_HIP_FLAG_PAIRED_STEP_LAUNCH (an A/B form): on ESS-triggered schedules a step as two launches -- the carry form (no
+    search, walk or gather in it) and the resampling form -- each of which ends at once when the step is the other's (csrc/step_fixed.hpp:
+    smc_step_fixed_carry_body).  Against the single launch: the same decisions, ancestors, values, weights, evidence and posterior,
+    and the oracle's."""
+    obs = _obs(golden_dir, key)[:T]
+    n = 70_001
+    out = {}
+    for name, flags in (("paired", cp.capi.FLAG_PAIRED_STEP_LAUNCH), ("single", 0)):
+        engine.begin(cp.ALG_SMC, model, obs, n, seed=17, resampler=resampler, ess_threshold=0.5, flags=flags)
+        engine.run()
+        out[name] = (engine.ancestors(), engine.values(), engine.logw(), engine.summary(), engine.stats().copy(), engine.step_trace())
+    a, b = out["paired"], out["single"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+    assert a[3]["log_evidence"] == b[3]["log_evidence"] and a[3]["n_resampled"] == b[3]["n_resampled"] and 0 < a[3]["n_resampled"] < T - 1
+    assert np.array_equal(a[5][0], b[5][0]) and np.array_equal(a[5][1], b[5][1])
+    ref = O.smc(model, obs, n, 17, resampler, 0.5)
+    assert np.array_equal(a[0], ref["anc"]) and np.array_equal(a[5][1], ref["resampled"])
+
+
 @pytest.mark.parametrize("n", [1, 2, 1023, 1025, 4095, 4097, 12289])
 def test_smc_tiny_and_ragged_populations(engine, golden_dir, n):
     obs = _obs(golden_dir, "hmm16")[:5]
