@@ -13,7 +13,7 @@ RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
 SCOPE_GLOBAL, SCOPE_ISLAND, SCOPE_EXCHANGE = 0, 1, 2
 # cpprob_hip_config::flags (A/B forms; 0 = the measured optimum)
 FLAG_FLOATING_POINT_STEP, FLAG_NO_SKIP_ROWS, FLAG_SIS_PER_TILE, FLAG_SIS_SEPARATE_READOUT, FLAG_WREL_STORED, FLAG_FP_TILE_PARTIALS, FLAG_WALK_READOUT = 1, 2, 4, 8, 16, 32, 64
-FLAG_MULTINOMIAL_LITERAL, FLAG_PAIRED_STEP_LAUNCH = 128, 512
+FLAG_MULTINOMIAL_LITERAL, FLAG_REPEAT_IN_FLOATING_POINT, FLAG_PAIRED_STEP_LAUNCH = 128, 256, 512
 N_KERNEL_CLASSES = 6
 KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", "resample"]
 
@@ -52,7 +52,7 @@ class Config(C.Structure):
 class Summary(C.Structure):
     _fields_ = [("log_evidence", C.c_double), ("ess_final", C.c_double), ("log_norm", C.c_double), ("max_logw", C.c_double),
                 ("n_predict", C.c_int32), ("stats_per_predict", C.c_int32), ("is_int", C.c_int32), ("n_resampled", C.c_int32),
-                ("step_form", C.c_int32), ("reserved", C.c_int32)]
+                ("step_form", C.c_int32), ("n_requantised", C.c_int32)]
 
 
 FORM_FLOAT, FORM_COUNTS, FORM_FIXED = 0, 1, 2

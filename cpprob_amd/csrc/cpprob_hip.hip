@@ -126,6 +126,7 @@ struct cpprob_hip_ctx {
     // generation's heaviest particle sat far below it (an observation many standard deviations from every particle) they lose bits.
     // The first call that reads a run's results checks the run's largest gap and repeats the run in the floating-point form.
     bool force_fp = false, fixed_check_pending = false, last_was_infer_run = false; uint64_t last_run_index = 0;
+    double* d_lz_trace = nullptr; int n_requantised = 0;    // fixed-point form: the evidence before each generation's books (what a repair rewinds to); generations repaired in the last run
     uint32_t* d_q[2] = {nullptr, nullptr};                 // [ld] integer weights of the fixed-point form, ping-pong; the count form's trace words
     // trace words (trace_words.hpp): a single population's short discrete traces ride with the particles; the read-out streams them
     bool trace_mode = false; uint32_t* d_trace_cnt = nullptr; unsigned long long* d_trace_arrive = nullptr;
@@ -836,7 +837,7 @@ void free_run_buffers(cpprob_hip_ctx* c)
 {
     dfree(c->d_obs); dfree(c->d_logw[0]); dfree(c->d_logw[1]); dfree(c->d_wrel[0]); dfree(c->d_wrel[1]); dfree(c->d_bf); dfree(c->d_ll_tab); dfree(c->d_values); dfree(c->d_anc); dfree(c->d_paths);
     dfree(c->d_part[0]); dfree(c->d_part[1]); dfree(c->d_e_tab); dfree(c->d_gpart); dfree(c->d_stile); dfree(c->d_gstat); dfree(c->d_bc); dfree(c->d_ess); dfree(c->d_resampled); dfree(c->d_stats_part); dfree(c->d_stats);
-    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_strata); dfree(c->d_strata_top); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]); dfree(c->d_trace_cnt); dfree(c->d_trace_arrive); dfree(c->d_tr[0]); dfree(c->d_tr[1]);
+    dfree(c->d_cdf); dfree(c->d_anc_pre); dfree(c->d_strata); dfree(c->d_strata_top); dfree(c->d_lz_trace); dfree(c->d_obound); dfree(c->d_hier); dfree(c->d_annex_base); dfree(c->d_fpart); dfree(c->d_filter_w); dfree(c->d_skip); dfree(c->d_q[0]); dfree(c->d_q[1]); dfree(c->d_trace_cnt); dfree(c->d_trace_arrive); dfree(c->d_tr[0]); dfree(c->d_tr[1]);
     c->cap_particles = 0; c->cap_T = 0; c->annex_cap = 0; c->tr_cap = 0;
 }
 
@@ -1028,6 +1029,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMalloc(&c->d_stile, (size_t)kMaxReadoutCols * c->nb * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_gstat, (size_t)kMaxReadoutCols * kMaxSlabs * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_ess, T * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_lz_trace, T * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_resampled, T * sizeof(int32_t)));
         HIP_TRY(c, hipMalloc(&c->d_stats_part, (size_t)c->walk_cap * T * 8 * sizeof(double)));
         HIP_TRY(c, hipMalloc(&c->d_stats, T * 8 * sizeof(double)));
@@ -1079,6 +1081,7 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     HIP_TRY(c, hipMalloc(&c->d_obs, n_obs * sizeof(double)));
     HIP_TRY(c, hipMemcpyAsync(c->d_obs, h_obs, n_obs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_resampled, 0, (size_t)c->T * sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&c->d_ctrl->lz_trace, &c->d_lz_trace, sizeof(double*), hipMemcpyHostToDevice, c->stream));
     if (multinomial && c->d_strata_top) {                      // (its layout follows T; a run abandoned between its two launches leaves totals behind)
         HIP_TRY(c, hipMemsetAsync(c->d_strata_top, 0, (size_t)2 * c->T * 64 * sizeof(uint32_t), c->stream));
         c->strata_phase = 0;
@@ -1183,6 +1186,7 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
     c->run_seed = c->cfg.seed + run_index;
     c->cur = 0; c->cur_part = 0;
     c->sharded = false;
+    if (!c->force_fp) c->n_requantised = 0;
     c->final_from_counts = false; c->final_from_fixed = false;
     bool readout_done = false, sis_bounded = false;
     (void)sis_bounded;
@@ -1267,11 +1271,47 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
 
 }  // extern "C"
 namespace {
-// 6 nats = 9 of the 32 bits: the heaviest particle of every generation carried at least a 23-bit weight (a gap opens where an
-// observation lies more than ~3.5 standard deviations from EVERY particle: populations of thousands and more never see one)
-constexpr double kFixGapLimit = 6.0;
-// Before a run's results leave the library: did the fixed-point weights keep their bits?  If not the run is repeated in the
-// floating-point form (runs the caller drives step by step cannot be repeated here: CPPROB_HIP_EPRECISION).
+// A generation whose heaviest particle sat more than kFixGapLimit nats below its reference kept too few of its 32 bits (an observation
+// far from EVERY particle).  Repair, in integers: the offending generation g is weighed again against its EXACT maximum -- its
+// log-weights recomputed from the particle store (fixed_relogw_kernel), maximum and masses by the two order-free passes of
+// bookkeep_fixed.hpp -- the books are rewound to where they stood before g (StepCtrl::lz_trace), and the steps behind g run again;
+// repeated while a later generation trips (each round starts later).  The CPU restatement states the same rule (orc_smc_impl), so a
+// repaired run still equals it index for index, and no floating-point CDF enters.
+template <class Model>
+int repair_fixed_generation(cpprob_hip_ctx* c, int g)
+{
+    if constexpr (std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value || std::is_same<Model, ModelHmmK>::value) {
+        std::vector<int32_t> res((size_t)c->T);
+        HIP_TRY(c, hipMemcpyAsync(res.data(), c->d_resampled, res.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        int s0 = 0;
+        for (int s2 = g - 1; s2 >= 0; --s2) if (res[(size_t)s2]) { s0 = s2 + 1; break; }
+        c->cur = (g + 1) & 1;                                        // (where step g left its weights: the buffers alternate step by step)
+        double* lw = c->d_logw[c->cur];
+        uint32_t* q = c->d_q[c->cur];
+        hipLaunchKernelGGL(fixed_relogw_kernel<Model>, dim3((unsigned)((c->ld + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, c->mp, (const double*)c->d_obs,
+                           static_cast<const typename Model::store_t*>(c->d_values), c->rs, s0, g, c->n, c->ld, lw);
+        // the hierarchy: every copy clean, generation g's masses in the copy step g + 1 reads
+        HIP_TRY(c, hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream));
+        const int ka = (g + 1 + c->hier_phase_run) % 3, kb = (ka + 1) % 3;
+        FHier f{};
+        fhier_view(c, ka, f);
+        f.h.to_next = 0; f.h.to_clear = (int64_t)(kb - ka) * (int64_t)c->hier_per_copy;
+        hipLaunchKernelGGL(bbf_max_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, (const double*)lw, c->n, f);
+        hipLaunchKernelGGL(bbf_quantize_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, (const double*)lw, c->n, f, q);
+        hipLaunchKernelGGL(fixed_repair_ctrl_kernel, dim3(1), dim3(kWave), 0, c->stream, c->d_ctrl, f, g, (const int32_t*)c->d_resampled);
+        for (int t = g + 1; t < c->T; ++t) launch_step_fixed<Model>(c, t, nullptr, 1, 0);
+        if (g + 1 == c->T) { c->final_from_fixed = true; c->final_copy = ka; c->final_bookkeep_pending = true; }
+        launch_smooth<Model>(c, false);
+        HIP_TRY(c, hipGetLastError());
+        return 0;
+    }
+    return fail(c, CPPROB_HIP_ESTATE, "the fixed-point form serves the state-space models");
+}
+
+// Before a run's results leave the library: did the fixed-point weights keep their bits?  If not the offending generations are
+// repaired as above; where that is not possible (a shard of a joint population, a filtering-only run, a generation without mass) the
+// run is repeated in the floating-point form (runs the caller drives step by step cannot be repeated here: CPPROB_HIP_EPRECISION).
 int settle_fixed(cpprob_hip_ctx* c)
 {
     if (!c->fixed_check_pending) return 0;
@@ -1281,6 +1321,21 @@ int settle_fixed(cpprob_hip_ctx* c)
     HIP_TRY(c, hipMemcpyAsync(&h, c->d_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (h.fix_gap <= kFixGapLimit) return 0;
+    if (c->last_was_infer_run && c->keep && !c->exchange && c->d_lz_trace && !(c->cfg.flags & CPPROB_HIP_FLAG_REPEAT_IN_FLOATING_POINT)) {
+        int g_prev = -1;
+        for (int round = 0; round <= c->T; ++round) {
+            const int g = h.first_bad;
+            if (g < 0 || g >= c->T || g <= g_prev) break;                // (no progress: a generation without any mass)
+            int rc = 0;
+            dispatch_model(c, [&](auto m) { rc = repair_fixed_generation<decltype(m)>(c, g); });
+            if (rc) return rc;
+            c->n_requantised += 1;
+            g_prev = g;
+            HIP_TRY(c, hipMemcpyAsync(&h, c->d_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (h.fix_gap <= kFixGapLimit) return 0;
+        }
+    }
     if (!c->last_was_infer_run)
         return fail(c, CPPROB_HIP_EPRECISION, "some generation's heaviest particle sat more than 6 nats below the fixed-point reference (an observation far from every particle): "
                                                "repeat the run with CPPROB_HIP_FLAG_FLOATING_POINT_STEP");
@@ -1850,7 +1905,7 @@ int cpprob_hip_infer_summary(cpprob_hip_ctx* c, cpprob_hip_summary* out)
     out->is_int = c->is_int ? 1 : 0;
     out->n_resampled = h.n_resampled;
     out->step_form = c->cfg.algorithm != CPPROB_HIP_ALG_SMC ? CPPROB_HIP_FORM_FLOAT : (c->fixed_mode ? CPPROB_HIP_FORM_FIXED : (c->counts_mode ? CPPROB_HIP_FORM_COUNTS : CPPROB_HIP_FORM_FLOAT));
-    out->reserved = 0;
+    out->n_requantised = c->fixed_mode ? c->n_requantised : 0;
     return 0;
 }
 

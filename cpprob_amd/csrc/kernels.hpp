@@ -68,6 +68,9 @@ struct StepCtrl {
     double ref_cur;       // fixed-point form (step_fixed.hpp): the reference R_t of the generation just produced
     double fix_gap;       // ... and the largest R_t - max_i lw_i of the run: how far below its reference the heaviest particle of
                           // some generation sat (each 0.69 of it costs the integer weights one of their 32 bits)
+    double* lz_trace;     // [T] (or nullptr): the evidence accumulated BEFORE generation t's books were kept -- what a repair of that generation rewinds to
+    int32_t first_bad;    // the first generation whose gap exceeded kFixGapLimit (-1: none): where the host's repair starts (cpprob_hip.hip: settle_fixed)
+    int32_t pad_;
 };
 
 enum { RS_SYSTEMATIC = 0, RS_STRATIFIED = 1, RS_PRECOMPUTED = 2 };

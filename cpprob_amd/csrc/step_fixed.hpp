@@ -590,10 +590,13 @@ __device__ __forceinline__ void fixed_bookkeep(StepCtrl* c, int t_prev, const Fi
     // mass counts as the whole range) -- the host repeats a run whose gap cost too many bits in the floating-point form
     const double gap = (d.W > 0.0) ? ref_prev - m_prev : 1e300;
     c->fix_gap = (t_prev == 0) ? gap : fmax(c->fix_gap, gap);
+    if (t_prev == 0) c->first_bad = -1;
+    if (gap > kFixGapLimit && c->first_bad < 0) c->first_bad = t_prev;
     c->M = ref_prev; c->W = d.W; c->Q = d.Qd; c->ess = d.ess; c->do_resample = d.resample ? 1 : 0;
     c->cdf_lo = 0.0; c->w_local = d.W; c->scale = 1.0; c->u0 = u0; c->inv_stepw = d.inv * kFixScale; c->lw_after = 0.0; c->inv_global = d.inv * kFixScale;
     double lz = (t_prev == 0) ? 0.0 : c->log_z;
     int nr = (t_prev == 0) ? 0 : c->n_resampled;
+    if (c->lz_trace) c->lz_trace[t_prev] = lz;
     if (d.resample || last) lz += ref_prev + log(d.W / n_pop);
     if (d.resample) nr += 1;
     c->log_z = lz; c->n_resampled = nr;
@@ -981,6 +984,35 @@ __global__ __launch_bounds__(kThreads) void smooth_fixed_kernel(SmoothArgs<Model
         if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q, t.M);
     }
     smooth_body<Model>(a, s_stat, [q_last](int64_t, int64_t i) { return (double)q_last[i] * kFixInv; });        // padding slots: q = 0
+}
+
+// ---- repair of a generation whose weights lost their bits (cpprob_hip.hip: settle_fixed) -------------------------------------------
+// Generation g's log-weights again, from the particle store: lw_i = sum over the steps s = s0 .. g since the last resampling of the
+// step's log-likelihood at values[s][i] (slots extend themselves between two resamplings) -- the very sums the step kernels carried,
+// in their order.  Padding slots: -inf.
+template <class Model>
+__global__ __launch_bounds__(kThreads) void fixed_relogw_kernel(ModelParams mp, const double* __restrict__ obs, const typename Model::store_t* __restrict__ values, int64_t rs,
+                                                                 int s0, int g, int64_t n, int64_t ld, double* __restrict__ logw)
+{
+    using V = typename Model::value_t;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= ld) return;
+    double lw = 0.0;
+    for (int s = s0; s <= g; ++s) lw = lw + Model::loglik(mp, static_cast<V>(values[(int64_t)s * rs + i]), s, obs);
+    logw[i] = i < n ? lw : -INFINITY;
+}
+// The books as they stood before generation g was weighed against its reference, with the exact maximum in that reference's place.
+__global__ __launch_bounds__(kWave) void fixed_repair_ctrl_kernel(StepCtrl* c, FHier f, int g, const int32_t* __restrict__ resampled)
+{
+    const double m = bbf_top_max(f);
+    if (threadIdx.x == 0) {
+        c->ref_cur = m;
+        c->log_z = c->lz_trace[g];
+        int nr = 0;
+        for (int s = 0; s < g; ++s) nr += resampled[s];
+        c->n_resampled = nr;
+        c->fix_gap = 0.0; c->first_bad = -1;                        // (the generations before g kept their bits: that is what first_bad said)
+    }
 }
 
 // Offspring bounds of the ranks (lane r: o_r, r = 0 .. world) and the decision, from the all-gathered totals.  One wave.

@@ -91,6 +91,10 @@ __device__ __forceinline__ void probe_fetch(const Hier& h, int at, int nb, Probe
 }
 
 
+// 6 nats = 9 of the 32 bits: the heaviest particle of every generation carries at least a 23-bit weight (a gap opens where an
+// observation lies more than ~3.5 standard deviations from EVERY particle: populations of thousands and more never see one).  A
+// generation beyond it is requantised against its exact maximum before anything is drawn from it (cpprob_hip.hip: settle_fixed).
+constexpr double kFixGapLimit = 6.0;
 constexpr double kFixScale = 4294967296.0;                  // 2^32
 constexpr double kFixInv = 1.0 / 4294967296.0;
 constexpr uint64_t kMassMask = (1ull << 56) - 1;

@@ -131,6 +131,8 @@ typedef struct cpprob_hip_config {
 #define CPPROB_HIP_FLAG_FP_TILE_PARTIALS 32u     /* ... and fp64 tile partials instead of packed per-value counts */
 #define CPPROB_HIP_FLAG_WALK_READOUT 64u         /* short discrete traces: read the posterior out by the lineage walk, not from trace words */
 #define CPPROB_HIP_FLAG_PAIRED_STEP_LAUNCH 512u  /* fixed-point form, ESS-triggered schedules (A/B): a step as two launches {carry, resampling} of which one ends at once */
+#define CPPROB_HIP_FLAG_REPEAT_IN_FLOATING_POINT 256u /* fixed-point form: a run with a generation that lost its bits is repeated whole in the floating-point form
+                                                        (the r03 / r04 behaviour) instead of being repaired from that generation on, in integers */
 #define CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL 128u /* multinomial resampling: ancestor of output j = min{k : C_k > floor(u_j C_N)}, one search per output */
 
 /* Posterior summary of a finished run -- what StatsPrinter prints
@@ -146,7 +148,8 @@ typedef struct cpprob_hip_summary {
     int32_t is_int;       /* 1: predicts are integral (.int file), 0: real (.real)                */
     int32_t n_resampled;  /* number of steps after which resampling happened                      */
     int32_t step_form;    /* arithmetic the run's steps ran in: CPPROB_HIP_FORM_*                          */
-    int32_t reserved;
+    int32_t n_requantised; /* fixed-point form: generations whose weights were taken again against their exact maximum, because their heaviest
+                              particle sat more than 6 nats below the reference known in advance (the steps behind such a generation ran again) */
 } cpprob_hip_summary;
 #define CPPROB_HIP_FORM_FLOAT 0   /* fp64 linear weights, floating-point CDF (stratified / multinomial resampling, locally resampled
                                      shards, SIS, runs repeated because the fixed-point weights lost their bits)          */

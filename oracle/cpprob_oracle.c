@@ -1032,6 +1032,9 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
             if (ref_mode == 1) bound = orc_normal_logpdf(0.0, 0.0, 1);
             double ref = (t == 0 || do_resample) ? bound : m_prev + bound;
             if (ref_mode == 2) ref = max;
+            /* a generation whose heaviest particle sits more than 6 nats below the reference known in advance keeps too few of its 32
+             * bits: it is weighed against its exact maximum instead (cpprob_hip.hip: settle_fixed / repair_fixed_generation) */
+            if (ref - max > 6.0 && max > -INFINITY) ref = max;
             uint64_t S = 0, Q16 = 0;
             for (uint64_t i = 0; i < n; ++i) { qw[i] = orc_fix_weight(logw[i], ref); S += qw[i]; Q16 += orc_fix_square(qw[i]); }
             q_total = S;

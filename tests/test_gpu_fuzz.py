@@ -114,17 +114,19 @@ def test_random_shard_layouts_exchange_scope(engine, golden_dir, sweep):
         try:
             stats, s, paths, _, moved = _run_exchange_virtual(model, obs, n_pers, seed, ess)
         except cp.capi.CpprobHipError as err:
-            # the outlier cost the fixed-point weights their bits: the step protocol says so (the single context repeated its run in
-            # the floating-point form by itself) and the caller repeats in that form
-            assert err.code == cp.capi.EPRECISION and ref_sum["step_form"] == cp.capi.FORM_FLOAT, tag
+            # the outlier cost the fixed-point weights their bits: the step protocol says so (the single context repaired its run from
+            # the offending generation on, in integers) and the caller repeats in the floating-point form
+            assert err.code == cp.capi.EPRECISION and ref_sum["n_requantised"] >= 1, tag
             stats, s, paths, _, moved = _run_exchange_virtual(model, obs, n_pers, seed, ess, flags=cp.capi.FLAG_FLOATING_POINT_STEP)
         got = np.concatenate(paths, axis=1)
         differing = (got != ref_paths).any(axis=0).sum()
         assert differing <= max(2, n // 20000), tag                                  # isolated CDF-boundary flips only
         assert s["n_resampled"] == ref_sum["n_resampled"], tag
         if differing == 0:
-            np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-11, err_msg=tag)
-            assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-11, tag
+            # (a repaired generation's masses are integers against its exact maximum, the floating-point form's are not: 2e-8 seen on a variance)
+            tol = 1e-6 if ref_sum["n_requantised"] else 1e-11
+            np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=tol, err_msg=tag)
+            assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < tol, tag
 
 
 @pytest.mark.parametrize("sweep", [31, 32, 33])

@@ -425,32 +425,68 @@ def test_filtering_only_shards_of_a_joint_population_match_one_context(engine, g
         engine.begin(cp.ALG_SMC, model, obs, 1000, n_global=2000, scope=cp.SCOPE_GLOBAL, keep_history=False)      # a locally resampled shard keeps its history
 
 
-def test_fixed_point_run_that_loses_its_bits_is_repeated_in_the_floating_point_form(engine, golden_dir):
+@pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_STRATIFIED, cp.RESAMPLE_MULTINOMIAL])
+def test_fixed_point_run_that_loses_its_bits_is_repaired_from_the_offending_generation(engine, golden_dir, resampler):
     """The fixed-point weights are taken against a reference known before the generation exists (the emission's density at its
     mode).  An observation many standard deviations from EVERY particle leaves the heaviest particle far below it -- 0.69 nats per
-    lost bit, nothing left at 22 -- so the engine tracks the largest such gap of a run and, past 6 nats, repeats the run in the
-    floating-point form before any result leaves the library: the numbers are those of CPPROB_HIP_FLAG_FLOATING_POINT_STEP, bit for
-    bit, and match the oracle's estimator; a run without such a step is not repeated."""
+    lost bit, nothing left at 22 -- so every generation's gap is tracked and, past 6 nats, the OFFENDING generation is weighed again
+    against its exact maximum (log-weights recomputed from the particle store, two order-free passes), the books are rewound to where
+    they stood before it, and the steps behind it run again: the run stays in integers (no rerun of the whole run, no floating-point
+    CDF), says so (n_requantised), and still equals the oracle -- which states the same rule -- ancestor for ancestor.  A run without
+    such a generation repairs nothing.  CPPROB_HIP_FLAG_REPEAT_IN_FLOATING_POINT keeps the r03 / r04 behaviour: the whole run again
+    in the floating-point form, bit for bit CPPROB_HIP_FLAG_FLOATING_POINT_STEP's numbers."""
     obs = np.array(_obs(golden_dir, "lgssm100")[:14])
     obs[6] = 40.0                                              # ~30 standard deviations from every particle
     n = 5000
-    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, ess_threshold=0.5)
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, resampler=resampler, ess_threshold=0.5)
     engine.run()
     st, s = engine.stats().copy(), engine.summary()
-    assert np.isfinite(st).all() and np.isfinite(s["log_evidence"])
+    assert s["step_form"] == cp.capi.FORM_FIXED and s["n_requantised"] >= 1
+    ref = O.smc(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, 8, resampler, 0.5)
+    anc, vals = engine.ancestors(), engine.values()
+    gess, gres = engine.step_trace()
+    assert np.array_equal(gres, ref["resampled"]) and np.array_equal(anc, ref["anc"])
+    np.testing.assert_allclose(vals, ref["hist"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gess, ref["ess"], rtol=1e-9)
+    assert abs(s["log_evidence"] - ref["log_z"]) < 1e-9 and s["n_resampled"] == int(ref["resampled"].sum())
+    sm_self = O.smoothing_linear(vals, anc, O.fix_weights(engine.logw(), s["max_logw"]).astype(np.float64))
+    np.testing.assert_allclose(st, sm_self, rtol=1e-10, atol=1e-12)
+    engine.run(1)                                               # the context is as good as new behind a repair
+    engine.run(0)
+    assert np.array_equal(engine.stats(), st) and engine.summary() == s
+    # a last generation that trips (nothing behind it to run again) and a first one
+    for at in (13, 0):
+        o2 = np.array(_obs(golden_dir, "lgssm100")[:14])
+        o2[at] = 35.0 if at else 9.0
+        engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, o2, n, seed=8, resampler=resampler, ess_threshold=0.5)
+        engine.run()
+        s2 = engine.summary()
+        r2 = O.smc(cp.MODEL_LINEAR_GAUSSIAN_1D, o2, n, 8, resampler, 0.5)
+        assert s2["n_requantised"] >= 1 and np.array_equal(engine.ancestors(), r2["anc"]) and abs(s2["log_evidence"] - r2["log_z"]) < 1e-9, at
+    if resampler != cp.RESAMPLE_SYSTEMATIC:
+        return
+    # no such generation: nothing repaired
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, _obs(golden_dir, "lgssm100")[:14], n, seed=8, ess_threshold=0.5)
+    engine.run()
+    assert engine.summary()["n_requantised"] == 0
+    # the whole run again in the floating-point form, on request
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, ess_threshold=0.5, flags=cp.capi.FLAG_REPEAT_IN_FLOATING_POINT)
+    engine.run()
+    stf, sf = engine.stats().copy(), engine.summary()
     engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, ess_threshold=0.5, flags=cp.capi.FLAG_FLOATING_POINT_STEP)
     engine.run()
     s2 = engine.summary()
-    assert np.array_equal(engine.stats(), st) and s["step_form"] == s2["step_form"] == cp.capi.FORM_FLOAT and s2 == s
-    np.testing.assert_allclose(st, O.smoothing(engine.values(), engine.ancestors(), engine.logw()), rtol=1e-8, atol=1e-10)
-    # the same through the group driver (two loopback ranks): repeated once, the same answer within boundary flips
+    assert np.array_equal(engine.stats(), stf) and sf["step_form"] == s2["step_form"] == cp.capi.FORM_FLOAT and s2 == sf
+    np.testing.assert_allclose(stf, O.smoothing(engine.values(), engine.ancestors(), engine.logw()), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(stf, st, rtol=0, atol=5e-3)      # the two repairs agree as two arithmetic forms of one run do
+    # the group driver (two loopback ranks) still repeats in the floating-point form: the same answer within boundary flips
     g = cp.Group([0, 0])
     g.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, ess_threshold=0.5)
     g.run()
     gst, gs, reruns = g.results()
     g.close()
-    assert 1 <= reruns <= 3 and abs(gs["log_evidence"] - s["log_evidence"]) < 1e-9      # (the mass sits on a few particles: the transport may be enlarged too)
-    np.testing.assert_allclose(gst, st, rtol=0, atol=5e-3)
+    assert 1 <= reruns <= 3 and abs(gs["log_evidence"] - sf["log_evidence"]) < 1e-9      # (the mass sits on a few particles: the transport may be enlarged too)
+    np.testing.assert_allclose(gst, stf, rtol=0, atol=5e-3)
 
 
 @pytest.mark.parametrize("workload", ["configs[3]: linear_gaussian_1d<100>, 10^7 particles", "configs[4] per-GPU shard: hmm<128>, 1.25 10^7 particles"])
@@ -766,11 +802,11 @@ def test_exchange_scope_survives_extreme_imbalance_and_grows_the_annex(engine, g
 def test_caller_driven_run_is_told_when_the_fixed_point_weights_lost_their_bits(engine, golden_dir):
     """The step protocol cannot be repeated by the library: a run whose heaviest particle sat more than 6 nats below the reference
     (an observation ~30 standard deviations from every particle) returns CPPROB_HIP_EPRECISION from the first call that reads its
-    results; with CPPROB_HIP_FLAG_FLOATING_POINT_STEP it runs, and matches the single context (which repeated itself)."""
+    results; with CPPROB_HIP_FLAG_FLOATING_POINT_STEP it runs, and matches the single context repeated in that form."""
     obs = np.array(_obs(golden_dir, "lgssm100")[:10])
     obs[4] = 40.0
     n_pers = [3000, 2000]
-    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, sum(n_pers), seed=5, ess_threshold=0.5)
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, sum(n_pers), seed=5, ess_threshold=0.5, flags=cp.capi.FLAG_REPEAT_IN_FLOATING_POINT)
     engine.run()
     ref_stats, ref_sum = engine.stats().copy(), engine.summary()
     assert ref_sum["step_form"] == cp.capi.FORM_FLOAT
