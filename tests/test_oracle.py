@@ -345,3 +345,161 @@ def test_oracle_filtering_statistics_against_the_exact_filters(golden_dir):
     assert np.abs(r["filter"][:, 1] - z["lgssm100_filter_var"][:12]).max() < 1.5e-2
     np.testing.assert_allclose(r["filter"][-1], O.smoothing(r["hist"], r["anc"], r["logw"])[-1], rtol=1e-8, atol=1e-10)
 
+
+
+def test_integer_stratified_and_literal_multinomial_match_the_cdf_forms_and_are_order_independent():
+    """The integer forms every resampler runs in on the device (stratified: A_k = F + [u_F < H_k - F], H_k = double(C_k) N / double(C_N);
+    literal multinomial: tau_j = floor(u_j C_N), ancestor = min{k : C_k > tau_j}; stratified on prefix counts for table weights):
+    equal to the sequential floating-point CDF forms (orc_resample) wherever those sums are exact, and independent of how the
+    population is cut into shards."""
+    rng = np.random.default_rng(2)
+    n = 50000
+    lw = rng.normal(size=n) * 2.5 - 3.0
+    q = O.fix_weights(lw, lw.max() + 0.25)
+    tot = int(q.astype(np.uint64).sum())
+    for f, kind in ((O.resample_fixed_stratified, O.RESAMPLE_STRATIFIED), (O.resample_fixed_multinomial, O.RESAMPLE_MULTINOMIAL)):
+        full = f(q, 11, 5)
+        assert np.array_equal(full, O.resample(kind, np.log(q.astype(np.float64)), 11, 5))
+        assert full.min() >= 0 and full.max() <= n - 1 and q[full].min() > 0                  # a weightless particle is nobody's ancestor
+        if kind == O.RESAMPLE_STRATIFIED:
+            assert np.all(np.diff(full) >= 0)
+            counts = np.bincount(full, minlength=n)
+            qd = q.astype(np.float64)
+            assert np.abs(counts - n * qd / qd.sum()).max() < 2.0 + 1e-9                        # stratified: every offspring count within two of its expectation
+        for cuts in ([0, 12000, 30001, n], [0, 1, 2, n - 1, n], [0, 20000, 20001, 40000, n]):
+            got = np.full(n, -1, np.int64)
+            for r in range(len(cuts) - 1):
+                kw = dict(before=int(q[:cuts[r]].astype(np.uint64).sum()), total=tot, j0=0, n_out=n)
+                if kind == O.RESAMPLE_STRATIFIED:
+                    kw.update(last_shard=(r == len(cuts) - 2), n_total_out=n)
+                ar = f(q[cuts[r]:cuts[r + 1]], 11, 5, **kw)
+                m = ar >= 0
+                assert (got[m] == -1).all()
+                got[m] = ar[m] + cuts[r]
+            assert np.array_equal(got, full)
+    x = rng.integers(0, 3, 60000).astype(np.int32)
+    for e in (np.array([1.0, 0.5, 0.25]), np.array([0.125, 1.0, 0.5])):
+        assert np.array_equal(O.resample_table_stratified(x, e, 7, 3), O.resample(O.RESAMPLE_STRATIFIED, np.log(e[x]), 7, 3))
+    e = np.array([0.3123, 1.0, 0.0712345])
+    full = O.resample_table_stratified(x, e, 11, 5)
+    total = np.bincount(x, minlength=3).astype(np.uint64)
+    for cuts in ([0, 12000, 30001, len(x)], [0, 1, 2, 59999, len(x)]):
+        got = np.full(len(x), -1, np.int64)
+        for r in range(len(cuts) - 1):
+            ar = O.resample_table_stratified(x[cuts[r]:cuts[r + 1]], e, 11, 5, before=np.bincount(x[:cuts[r]], minlength=3).astype(np.uint64), total=total,
+                                             last_shard=(r == len(cuts) - 2), j0=0, n_out=len(x), n_total_out=len(x))
+            m = ar >= 0
+            assert (got[m] == -1).all()
+            got[m] = ar[m] + cuts[r]
+        assert np.array_equal(got, full)
+
+
+def _strata_offsets_in_python(seed, step, n_out, k):
+    """orc_multinomial_strata restated with numpy + the oracle's Philox blocks only: a binary tree over 2^k strata, the n thresholds of
+    a node go left with probability 1/2 each (popcount of the first n bits of the node's stream); above 6 levels the outputs are
+    dealt to groups that run the top six levels each and add up, and every level-6 node splits its total further."""
+    base3 = (1 << 40) + (1 << 38)
+
+    def left_of(node_key, n):
+        left = 0
+        for chunk in range((n + 127) // 128):
+            r = O.draw_block(seed, (node_key << 32) | chunk, base3 + step)
+            bits = int(r[0]) | (int(r[1]) << 32) | (int(r[2]) << 64) | (int(r[3]) << 96)
+            rem = min(128, n - chunk * 128)
+            left += bin(bits & ((1 << rem) - 1)).count("1")
+        return left
+
+    def split(cnt, key_hi, heap0, levels, stride):
+        for l in range(levels):
+            span = stride >> l
+            for i in range(1 << l):
+                nn = cnt[i * span]
+                le = left_of(key_hi | ((heap0 << l) + i), nn)
+                cnt[i * span], cnt[i * span + span // 2] = le, nn - le
+    K = 1 << k
+    cnt = [0] * K
+    if k <= 6:
+        cnt[0] = n_out
+        split(cnt, 0, 1, k, K)
+    else:
+        G = max(1, min(64, K // 128))
+        acc = [0] * 64
+        for g in range(G):
+            top = [0] * 64
+            top[0] = n_out * (g + 1) // G - n_out * g // G
+            split(top, (1 << 31) | (g << 8), 1, 6, 64)
+            acc = [a + b for a, b in zip(acc, top)]
+        sub = K >> 6
+        for i in range(64):
+            part = [0] * sub
+            part[0] = acc[i]
+            split(part, 0, 64 + i, k - 6, sub)
+            cnt[i * sub:(i + 1) * sub] = part
+    return np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+
+
+def test_strata_form_of_multinomial_resampling_is_multinomial_and_nearly_sorted():
+    """Multinomial resampling as the device runs it by default (orc_resample_fixed_multinomial_strata): N iid uniform thresholds =
+    counts per equal stratum ~ Multinomial(N; 1/K ..) -- popcounts of Philox bits down a binary tree, independent of the weights --
+    and iid uniforms inside each stratum.  The counts against an independent restatement (both the one-tree and the two-part form);
+    their law (chi-square); the ancestors against the definition evaluated in numpy; offspring counts with multinomial, not
+    systematic, variance; ancestors sorted stratum by stratum."""
+    for n_out, k in ((5000, 3), (40000, 6), (150_000, 8)):
+        assert O.lib().orc_strata_levels(n_out) == k
+        assert np.array_equal(O.multinomial_strata(5, 3, n_out), _strata_offsets_in_python(5, 3, n_out, k))
+    ch = []
+    for st in range(40):
+        m = np.diff(O.multinomial_strata(9, st, 200000).astype(np.int64))
+        ex = 200000 / len(m)
+        ch.append(((m - ex) ** 2 / ex).sum() / (len(m) - 1))
+    assert abs(np.mean(ch) - 1.0) < 0.05                                             # (sd of the mean of 40 reduced chi-squares with 255 dof: 0.014)
+    rng = np.random.default_rng(3)
+    n = 20000
+    lw = rng.normal(size=n) * 2.0
+    q = O.fix_weights(lw, lw.max() + 0.1)
+    anc = O.resample_fixed_multinomial_strata(q, 11, 5)
+    # the definition, in numpy: output s of stratum w takes tau = B_w + floor(v_s (B_w+1 - B_w)), B_w = floor(S w / K)
+    k = O.lib().orc_strata_levels(n)
+    offs = O.multinomial_strata(11, 5, n)
+    S = int(q.astype(np.uint64).sum())
+    cdf = np.cumsum(q.astype(np.uint64)).astype(object)
+    base2 = (1 << 40) + (1 << 39)
+    want = np.zeros(n, np.int64)
+    for w in range(1 << k):
+        b0, b1 = (S * w) >> k, (S * (w + 1)) >> k
+        for s2 in range(int(offs[w]), int(offs[w + 1])):
+            r = O.draw_block(11, s2 >> 1, base2 + 5)
+            lo, hi = (int(r[2]), int(r[3])) if s2 & 1 else (int(r[0]), int(r[1]))
+            v = (lo | ((hi >> 11) << 32)) << 11
+            tau = b0 + ((v * (b1 - b0)) >> 64)
+            lo_i, hi_i = 0, n
+            while lo_i < hi_i:
+                mid = (lo_i + hi_i) // 2
+                if cdf[mid] > tau:
+                    hi_i = mid
+                else:
+                    lo_i = mid + 1
+            want[s2] = lo_i
+    assert np.array_equal(anc, want)
+    assert np.max(np.maximum.accumulate(anc) - anc) < 4096                              # nearly sorted: only inside a stratum's range
+    counts = np.zeros(n)
+    reps = 120
+    for r in range(reps):
+        counts += np.bincount(O.resample_fixed_multinomial_strata(q, 5, r), minlength=n)
+    wgt = q / q.sum()
+    big = n * wgt > 0.5
+    zsc = (counts[big] / reps - n * wgt[big]) / np.sqrt(n * wgt[big] * (1 - wgt[big]) / reps)
+    assert abs(zsc.std() - 1.0) < 0.05 and abs(zsc.mean()) < 0.05 and np.abs(zsc).max() < 6.0    # (systematic resampling would give sd << 1)
+
+
+def test_oracle_repairs_a_generation_that_loses_its_bits():
+    """The rule both sides state for the fixed-point form: a generation whose heaviest particle sits more than 6 nats below the
+    reference known in advance is weighed against its exact maximum instead.  With an observation ~30 sd from every particle the
+    evidence stays finite and equals the floating-point form's to the weights' resolution; without one nothing changes."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    obs = np.array(z["lgssm100"][:14])
+    obs[6] = 40.0
+    a = O.smc(O.MODEL_LINEAR_GAUSSIAN_1D, obs, 5000, 8, O.RESAMPLE_SYSTEMATIC, 0.5)
+    b = O.smc_ref(O.MODEL_LINEAR_GAUSSIAN_1D, obs, 5000, 8, O.REF_FLOATING_POINT, O.RESAMPLE_SYSTEMATIC, 0.5)
+    assert np.isfinite(a["log_z"]) and abs(a["log_z"] - b["log_z"]) < 1e-6 and np.array_equal(a["resampled"], b["resampled"])
+    assert np.mean(a["anc"] != b["anc"]) < 1e-3
