@@ -439,6 +439,52 @@ def main():
         group = cp.Group([local] * args.loopback_ranks)
         n_global, exchange, scope = n, True, "exchange"
         host = "C++ (cpprob_hip_group_run), %d loopback ranks on one GPU" % args.loopback_ranks
+    preflight = None
+    if group is not None and world > 1:
+        # Before anything is timed over real links: the transport the group settles on, and a small exchange-scope run whose every
+        # surviving trace is compared, bit for bit, with the same population run on THIS rank's GPU alone (the integer forms of the
+        # step make that an exact test: any stale peer read, lost remote store or mis-ordered flag shows as a different trace).  On a
+        # mismatch the conservative rungs are tried in turn and the line says which one produced the single-GPU answer.
+        def run_preflight():
+            n_pf = 200_000
+            n_tot = n_pf * world
+            eng.begin(spec["alg"], spec["model"], spec["obs"], n_tot, seed=args.seed + 7, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
+            eng.run()
+            ref_paths = eng.paths()[:, rank * n_pf:(rank + 1) * n_pf]
+            ref_lz = eng.summary()["log_evidence"]
+            rungs = [("default", 0), ("library collectives", cp.capi.GROUP_LIBRARY_COLLECTIVES), ("library collectives + shipped lineages", cp.capi.GROUP_LIBRARY_COLLECTIVES | cp.capi.GROUP_SHIP_LINEAGES),
+                     ("send / receive", cp.capi.GROUP_LIBRARY_COLLECTIVES | cp.capi.GROUP_SENDRECV)]
+            rep = {"particles_per_rank": n_pf, "rungs": []}
+            for name, fl in rungs:
+                group.transport(flags=fl)
+                group.begin(spec["alg"], spec["model"], spec["obs"], n_tot, seed=args.seed + 7, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"], shard_sizes=[n_pf] * world)
+                t0 = time.perf_counter()
+                group.run(0)
+                _, gs, rr = group.results()
+                ms = (time.perf_counter() - t0) * 1e3
+                e = group.context(0); e.n = n_pf; e.T = T
+                same = bool(np.array_equal(e.paths(), ref_paths)) and gs["log_evidence"] == ref_lz
+                flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else device)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                ok = bool(flag.item() > 0.5)
+                rep["rungs"].append({"transport": name, "traces_equal_single_gpu_run_on_every_rank": ok, "first_run_ms": ms, "reruns": rr, "note": group.note()})
+                if ok:
+                    rep["settled_on"] = name
+                    break
+            else:
+                rep["settled_on"] = None
+            try:
+                import torch.cuda as tc
+                rep["peer_access"] = [[bool(a == b or tc.can_device_access_peer(a, b)) for b in range(tc.device_count())] for a in range(tc.device_count())] if rank == 0 else None
+            except Exception as e2:      # noqa
+                rep["peer_access"] = str(e2)
+            return rep
+        try:
+            preflight = guarded(run_preflight, "the multi-GPU preflight (a 2e5-particle-per-rank exchange-scope run against the single-GPU run)")
+        except Exception as e:          # noqa: reported under the key, never a reason to lose the line
+            preflight = {"error": str(e)}
+        if isinstance(preflight, dict) and preflight.get("settled_on") not in (None, "default"):
+            native_error = (native_error + "; " if native_error else "") + "preflight: the default transport did not reproduce the single-GPU traces; measuring '%s'" % preflight["settled_on"]
     if group is not None:
         def begin_group():
             group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
@@ -571,6 +617,8 @@ def main():
         if bd is not None:
             out["rank_step_breakdown_us"] = bd
             out["transport_note"] = bd.get("transport_note") if isinstance(bd, dict) else None
+    if preflight is not None:
+        out["preflight"] = preflight
     if native_error:
         out["config"]["native_driver_error"] = native_error
     if xtraffic is not None:

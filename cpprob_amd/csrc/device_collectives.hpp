@@ -110,6 +110,12 @@ __global__ __launch_bounds__(kWave) void dc_barrier_kernel(const MailboxPeers* _
                                                            unsigned long long seq, int phases, int32_t* status, long long timeout)
 {
     const int lane = threadIdx.x;
+    // The migrants were stored into the peers' (coarse-grained) particle stores by the packing launch in front of this one; the flag
+    // lives in the peers' fine-grained mailboxes.  What orders the two for the peer: the packing launch has completed (stream order),
+    // and a system-scope release fence here writes back whatever of those stores this device still holds before the flag leaves --
+    // stated explicitly rather than left to the release store's own scope, because the two allocations differ in coherence and this
+    // path has never met a real link.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     if ((phases & kDcPost) && lane < world)
         __hip_atomic_store(&peers->box[lane]->bar[parity][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (phases & kDcWait) {

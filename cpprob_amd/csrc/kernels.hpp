@@ -1559,6 +1559,11 @@ struct RemoteStores;
 #define CPPROB_SMOOTH_TILES 2
 #endif
 constexpr int kSmoothTiles = CPPROB_SMOOTH_TILES;      // tiles a workgroup of the lineage walk follows at a time
+#ifndef CPPROB_SMOOTH_ROWS
+#define CPPROB_SMOOTH_ROWS 2
+#endif
+constexpr int kSmoothRows = CPPROB_SMOOTH_ROWS;        // rows of the store fetched together between two resamplings
+constexpr int kSmoothMaxT = 2048;                       // (the read-out's LDS accumulators bound T x statistics per hit by 2048: cpprob_hip_infer_begin)
 template <class Model, class WeightOf>
 __device__ __forceinline__ void smooth_body_remote(const SmoothArgs<Model>& a, double* s_stat, WeightOf weight_of, const RemoteStores* __restrict__ rem);
 
@@ -1582,6 +1587,12 @@ __device__ __forceinline__ void smooth_body(const SmoothArgs<Model>& a, double* 
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int TK = a.T * K;
     for (int i = tid; i < kWaves * TK; i += kThreads) s_stat[i] = 0.0;
+    // run[t]: how many rows, from t downwards, the lineages stay in their slots (no resampling between them)
+    __shared__ uint16_t s_run[kSmoothMaxT];
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < a.T; ++t) { run = (t > 0 && !a.identity && a.resampled[t - 1]) ? 1 : run + 1; s_run[t] = (uint16_t)run; }
+    }
     __syncthreads();
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     // (one XCD's workgroups walk neighbouring tiles: their lineages converge on the same ancestor rows)
@@ -1601,26 +1612,51 @@ __device__ __forceinline__ void smooth_body(const SmoothArgs<Model>& a, double* 
             idx[k] = on ? (int32_t)i : 0;
             w[k] = on ? weight_of(tile, i) : 0.0;
         }
-        for (int t = a.T - 1; t >= 0; --t) {
-            double acc[K];
+        // Rows between two resamplings are read at the SAME slots: up to kSmoothRows of them are fetched together (independent gathers
+        // in flight instead of one dependent round trip a row: ESS-triggered schedules resample after a quarter of their steps), each
+        // row's sums taken exactly as before -- the same numbers in the same order.
+        auto rows = [&](auto rows_tag, int t_hi) {
+            constexpr int U = decltype(rows_tag)::value;
+            typename Model::store_t raw[U][L];
 #pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = 0.0;
-            const typename Model::store_t* row = a.values + (int64_t)t * a.rs;
+            for (int u = 0; u < U; ++u) {
+                const typename Model::store_t* row = a.values + (int64_t)(t_hi - u) * a.rs;
 #pragma unroll
-            for (int k = 0; k < L; ++k) {
-                const V x = static_cast<V>(row[idx[k]]);
-                Model::accumulate(x, w[k], acc);
-                const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
-                if (a.paths && tile < ntiles) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)(k % kPPT) * kThreads + tid] = x;
+                for (int k = 0; k < L; ++k) raw[u][k] = row[idx[k]];
             }
 #pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = wave_sum(acc[j]);
-            if (lane == 0) {
+            for (int u = 0; u < U; ++u) {
+                const int t = t_hi - u;
+                double acc[K];
 #pragma unroll
-                for (int j = 0; j < K; ++j) s_stat[wv * TK + t * K + j] += acc[j];
+                for (int j = 0; j < K; ++j) acc[j] = 0.0;
+#pragma unroll
+                for (int k = 0; k < L; ++k) {
+                    const V x = static_cast<V>(raw[u][k]);
+                    Model::accumulate(x, w[k], acc);
+                    const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
+                    if (a.paths && tile < ntiles) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)(k % kPPT) * kThreads + tid] = x;
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc[j] = wave_sum(acc[j]);
+                if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) s_stat[wv * TK + t * K + j] += acc[j];
+                }
             }
-            if (t > 0 && !a.identity && a.resampled[t - 1]) {
-                const int32_t* arow = a.anc + (int64_t)t * a.rs;
+        };
+        int t = a.T - 1;
+        while (t >= 0) {
+            const int r = (int)s_run[t];                                  // rows t, t-1, .., t-r+1 share the lineages' slots
+            int u = 0;
+            // (measured, us per launch, rows 1 / 2 / 4: linear_gaussian_1d<100> at 1e7 1166 / 1092 / 1223; hmm<128> at 1.25e7 1179 / 1294 / 1557 --
+            //  one-byte states gain nothing from more gathers in flight and lose the registers: profiles/r05_notes.md)
+            constexpr int kRows = sizeof(typename Model::store_t) == 1 ? 1 : kSmoothRows;
+            for (; u + kRows <= r && kRows > 1; u += kRows) rows(std::integral_constant<int, kRows>{}, t - u);
+            for (; u < r; ++u) rows(std::integral_constant<int, 1>{}, t - u);
+            t -= r;
+            if (t >= 0) {                                                 // (generation t was resampled: the lineages hop)
+                const int32_t* arow = a.anc + (int64_t)(t + 1) * a.rs;
 #pragma unroll
                 for (int k = 0; k < L; ++k) idx[k] = arow[idx[k]];
             }

@@ -974,6 +974,82 @@ __global__ __launch_bounds__(kThreads) void filter_partials_fixed_kernel(const t
     if (tid == 0) fpart_t[blockIdx.x] = 0.0;
 }
 
+// The lineage walk of a DISCRETE model in the fixed-point form, in integers: the final weights are the integers q_i and a predict
+// hit's statistic is sum_i q_i [x_t(lineage i) = s] -- exact in 64 bits, so a row's sums are taken as integers: per lane the masses
+// of the states 0 .. K-2 (the last state's follows from the lane's total, which no row changes), per wavefront two single-instruction
+// DPP scans a state (18-bit halves of values below 2^36: eight lineages of 32-bit weights) instead of a six-stage fp64 reduction --
+// the walk is bound by vector issue (r04: ~55 %), and the reductions were half of its instructions.  smooth_body's tile order.
+template <class Model>
+__device__ __forceinline__ void smooth_body_fixed_int(const SmoothArgs<Model>& a, double* s_stat, const uint32_t* __restrict__ q_last)
+{
+    using V = typename Model::value_t;
+    constexpr int K = Model::kStats;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int TK = a.T * K;
+    for (int i = tid; i < kWaves * TK; i += kThreads) s_stat[i] = 0.0;
+    __syncthreads();
+    const int64_t ntiles = (a.n + kTile - 1) / kTile;
+    auto wave_sum_u36 = [](uint64_t v) -> uint64_t {
+        const uint32_t lo = wave_sum_u32((uint32_t)v & 0x3ffffu), hi = wave_sum_u32((uint32_t)(v >> 18));
+        return ((uint64_t)hi << 18) + lo;
+    };
+    auto walk = [&](auto tiles_tag) {
+    constexpr int NT = decltype(tiles_tag)::value;
+    static_assert(NT * kPPT <= 16, "a lane's row sums stay below 2^36");
+    for (int64_t tile0 = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile0 < ntiles; tile0 += (int64_t)NT * gridDim.x) {
+        constexpr int L = NT * kPPT;
+        int32_t idx[L]; uint32_t w[L];
+        uint64_t w_lane = 0;
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
+            const int64_t i = tile * kTile + (int64_t)(k % kPPT) * kThreads + tid;
+            const bool on = tile < ntiles;
+            idx[k] = on ? (int32_t)i : 0;
+            w[k] = on ? q_last[i] : 0u;                                    // padding slots: q = 0
+            w_lane += w[k];
+        }
+        const uint64_t w_wave = wave_sum_u36(w_lane);
+        for (int t = a.T - 1; t >= 0; --t) {
+            uint64_t acc[K - 1];
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) acc[j] = 0;
+            const typename Model::store_t* row = a.values + (int64_t)t * a.rs;
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                const V x = static_cast<V>(row[idx[k]]);
+#pragma unroll
+                for (int j = 0; j < K - 1; ++j) acc[j] += (int)x == j ? (uint64_t)w[k] : 0ull;
+                const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
+                if (a.paths && tile < ntiles) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)(k % kPPT) * kThreads + tid] = x;
+            }
+            uint64_t rest = w_wave;
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) { acc[j] = wave_sum_u36(acc[j]); rest -= acc[j]; }
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < K - 1; ++j) s_stat[wv * TK + t * K + j] += u64_to_double(acc[j]) * kFixInv;
+                s_stat[wv * TK + t * K + K - 1] += u64_to_double(rest) * kFixInv;
+            }
+            if (t > 0 && !a.identity && a.resampled[t - 1]) {
+                const int32_t* arow = a.anc + (int64_t)t * a.rs;
+#pragma unroll
+                for (int k = 0; k < L; ++k) idx[k] = arow[idx[k]];
+            }
+        }
+    }
+    };
+    if (kSmoothTiles > 1 && ntiles > (int64_t)gridDim.x) walk(std::integral_constant<int, kSmoothTiles>{});
+    else walk(std::integral_constant<int, 1>{});
+    __syncthreads();
+    for (int i = tid; i < TK; i += kThreads) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kWaves; ++w2) s2 += s_stat[w2 * TK + i];
+        a.stats_part[(int64_t)i * gridDim.x + blockIdx.x] = s2;
+    }
+}
+
 // Read-out: the final weight of particle i is q_i 2^-32 (relative to exp(R)); the normaliser is the final generation's mass.
 template <class Model>
 __global__ __launch_bounds__(kThreads) void smooth_fixed_kernel(SmoothArgs<Model> a, FixedFinal ff, const uint32_t* __restrict__ q_last)
@@ -982,6 +1058,9 @@ __global__ __launch_bounds__(kThreads) void smooth_fixed_kernel(SmoothArgs<Model
     if (ff.bookkeep && blockIdx.x == 0 && wave_id() == 0) {
         const FTot t = ftot(ff.f);
         if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q, t.M);
+    }
+    if constexpr (Model::kIsInt) {
+        if (!a.rem) { smooth_body_fixed_int<Model>(a, s_stat, q_last); return; }               // (workgroup-uniform)
     }
     smooth_body<Model>(a, s_stat, [q_last](int64_t, int64_t i) { return (double)q_last[i] * kFixInv; });        // padding slots: q = 0
 }

@@ -1059,6 +1059,9 @@ def test_bench_two_ranks_on_one_gpu(scope, workload):
         assert d["config"]["host"].startswith("C++ (cpprob_hip_group_run: torch.distributed gloo"), d["config"]
         assert d["exchange_traffic_per_run"]["transport"] == "direct" and d["exchange_traffic_per_run"]["records"] > 0
         assert d["config"]["exchange_reruns"]["timed_batch"] == 0
+        # the preflight in front of the timed region: a 2e5-particle-per-rank run on the default transport, every rank's traces equal
+        # to the same population run on one GPU alone
+        assert d["preflight"]["settled_on"] == "default" and d["preflight"]["rungs"][0]["traces_equal_single_gpu_run_on_every_rank"] is True, d["preflight"]
         # where a rank-step's time goes, and which transports carried it (what the first run over real links has to explain)
         bd = d["rank_step_breakdown_us"]
         for key in ("step_and_totals", "allgather", "totals_handover", "pack", "barrier", "commit", "mailbox_wait", "steps", "transport_note"):
