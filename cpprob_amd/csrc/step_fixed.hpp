@@ -27,13 +27,15 @@
 namespace cph {
 
 // (fixed-point weights, 64-bit wavefront scans, the mass hierarchy, search and decision: cpprob/detail/fixed_mass.hpp)
+constexpr int kStrataTiles = 3;   // source tiles of an output tile staged side by side by the strata form of multinomial resampling (more: one at a time)
 template <int RS>
 struct FixedLdsT {
     int32_t slot[RS == kFixMultinomial || RS == kFixMultinomialLiteral ? kPPT : kTile];          // scatter slots of the output tile
     uint64_t scan[2][kWaves];     // per-wave totals of the in-tile scan, double-buffered across source tiles
     int iscr[kWaves];
     uint32_t ustrat[RS == kFixStratified ? kTile : 1];   // stratified: the 32-bit uniforms of the output tile's outputs
-    uint64_t mp[RS == kFixMultinomial ? 2 * kTile : 1];  // multinomial, strata form: a source tile's prefix masses (per wavefront), double-buffered
+    uint64_t mp[RS == kFixMultinomial ? kStrataTiles * kTile : 1];  // multinomial, strata form: the source tiles' prefix masses (per wavefront), side by side (or two in turn)
+    uint64_t wtot[RS == kFixMultinomial ? kStrataTiles : 1][kWaves]; // ... and their wavefronts' totals
 };
 using FixedLds = FixedLdsT<kFixSystematic>;
 
@@ -538,6 +540,57 @@ __device__ __forceinline__ void strata_walk(const uint32_t* __restrict__ offs, i
     const int c_last = __builtin_amdgcn_readfirstlane(sl.loc.c_last);
     uint64_t P = sl.loc.P;
     int it = 0;
+    // The usual case -- the probe told the last source tile and there are at most kStrataTiles of them: every tile's prefix masses
+    // staged side by side behind ONE barrier (their weights fetched together), then each output searches once, in its own tile.
+    if (c_last < nb && c_last - c + 1 <= kStrataTiles) {
+        const int nt = c_last - c + 1;
+        U4 raw[kStrataTiles];
+#pragma unroll
+        for (int j = 0; j < kStrataTiles; ++j)
+            raw[j] = j < nt ? *reinterpret_cast<const U4*>(qprev + (int64_t)(c + j) * kTile + (int64_t)tid * kPPT) : U4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < kStrataTiles; ++j) {
+            if (j < nt) {
+                uint64_t pre[kPPT];
+                uint64_t run = 0;
+#pragma unroll
+                for (int i = 0; i < kPPT; ++i) { run += (uint64_t)raw[j][i]; pre[i] = run; }
+                const uint64_t incl = wave_incl_scan_u34(run);
+                const uint64_t excl = incl - run;
+                uint64_t* Pm = L.mp + (size_t)j * kTile;
+                using UL2 = unsigned long long __attribute__((ext_vector_type(2)));
+                UL2 a0, a1;
+                a0[0] = excl + pre[0]; a0[1] = excl + pre[1]; a1[0] = excl + pre[2]; a1[1] = excl + pre[3];
+                *reinterpret_cast<UL2*>(Pm + (size_t)tid * kPPT) = a0;
+                *reinterpret_cast<UL2*>(Pm + (size_t)tid * kPPT + 2) = a1;
+                if (lane == kWave - 1) L.wtot[j][wv] = incl;
+            }
+        }
+        __syncthreads();
+        uint64_t tb[kStrataTiles + 1];                                    // prefix masses at the tiles' starts
+        tb[0] = P;
+#pragma unroll
+        for (int j = 0; j < kStrataTiles; ++j) tb[j + 1] = tb[j] + (j < nt ? L.wtot[j][0] + L.wtot[j][1] + L.wtot[j][2] + L.wtot[j][3] : 0ull);
+#pragma unroll
+        for (int i = 0; i < kPPT; ++i) {
+            if (live[i] && tau[i] >= tb[0] && tau[i] < tb[kStrataTiles]) {
+                int j = 0;
+#pragma unroll
+                for (int jj = 1; jj < kStrataTiles; ++jj) j += tau[i] >= tb[jj] ? 1 : 0;
+                uint64_t r = tau[i] - (j == 0 ? tb[0] : (j == 1 ? tb[1] : tb[2]));
+                static_assert(kStrataTiles == 3, "tile starts selected by hand");
+                const uint64_t w0s = L.wtot[j][0], w1s = L.wtot[j][1], w2s = L.wtot[j][2];
+                int seg = 0;
+                if (r >= w0s) { r -= w0s; seg = 1; if (r >= w1s) { r -= w1s; seg = 2; if (r >= w2s) { r -= w2s; seg = 3; } } }
+                const uint64_t* Ps = L.mp + (size_t)j * kTile + seg * (kTile / kWaves);
+                int a = 0, b = kTile / kWaves - 1;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) { const int mid = (a + b) >> 1; if (Ps[mid] > r) b = mid; else a = mid + 1; }
+                anc[i] = (c + j) * kTile + seg * (kTile / kWaves) + (a < kTile / kWaves ? a : kTile / kWaves - 1);
+            }
+        }
+        return;
+    }
     while (c < nb && c <= c_last) {
         if (c_last >= nb && __builtin_amdgcn_readfirstlane(P > x_hi ? 1 : 0)) break;          // the last tile is not known from the probe
         const U4 raw = *reinterpret_cast<const U4*>(qprev + (int64_t)c * kTile + (int64_t)tid * kPPT);
