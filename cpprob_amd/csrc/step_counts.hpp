@@ -74,6 +74,21 @@ struct TableCdf {
         if constexpr (RS == kFixStratified) return first_stratified(C);
         else return g(C);
     }
+    // The same for comparisons against the outputs ga and gb only (the search's probe): A is F or F + 1, so "A <= g" is "F <= g"
+    // unless F == g -- the Philox block of output F is drawn only where some lane's F hits one of the two (wave-uniform branch).
+    template <int RS>
+    __device__ __forceinline__ double first_near(double C, double ga, double gb, bool wanted) const
+    {
+        if constexpr (RS == kFixStratified) {
+            const double H = h(C), F = floor(H);
+            double r = F >= n_pop ? n_pop : F;
+            if (__any(wanted && F < n_pop && (F == ga || F == gb))) {
+                const double u = u01_32(draw_word(seed, uid0 + (uint64_t)fmin(F, n_pop - 1.0), draw));
+                if (F < n_pop && u < H - F) r = F + 1.0;
+            }
+            return r;
+        } else return g(C);
+    }
     // first output owned by the sources that follow `n0, n1` state-0/1 particles among `nv` local particles
     template <int RS = kFixSystematic>
     __device__ __forceinline__ double g_at(uint32_t n0, uint32_t n1, int64_t nv) const
@@ -181,8 +196,8 @@ __device__ __forceinline__ Located counts_locate(const Hier& h, const TableCdf& 
         const uint32_t v0 = cnt_n0(we), v1 = cnt_n1(we);
         const uint32_t i0 = wave_incl_scan_u32(v0), i1 = wave_incl_scan_u32(v1);
         const uint32_t x0 = Pc.n0 + i0 - v0, x1 = Pc.n1 + i1 - v1;        // lanes 0..4: the prefix at cs + lane (lanes >= 4 hold zeros)
-        const double gt = tc.template g_at<RS>(x0, x1, nvalid_before(cs + lane));
         const bool known = lane < 5 && cs + lane < nb;
+        const double gt = tc.template first_near<RS>(tc.cdf(tc.base0 + (double)x0, tc.base1 + (double)x1, tc.basev + (double)nvalid_before(cs + lane)), gj_first, gj_last, known);
         const unsigned long long m = __ballot(known && gt <= gj_first);
         const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
         d_out = gj_first - read_lane(gt, 0);
@@ -461,9 +476,17 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
         tc.seed = a.seed; tc.draw = kResampleDrawBase + (uint64_t)t; tc.uid0 = SHARDED ? 0 : a.pid0;
         if constexpr (RS == kFixStratified) {
-            uint32_t w[kPPT];
-            draw_words4(tc.seed, tc.uid0 + (uint64_t)gj_first + (uint64_t)tid * kPPT, tc.draw, w);
-            store4(L.ustrat, (int64_t)tid * kPPT, w);
+            // (the outputs' uniforms, staged by the three wavefronts that do not search: the second one also draws the searching
+            //  wavefront's share, so no Philox block sits on the search's chain)
+            if (!searcher) {
+                uint32_t w[kPPT];
+                draw_words4(tc.seed, tc.uid0 + (uint64_t)gj_first + (uint64_t)tid * kPPT, tc.draw, w);
+                store4(L.ustrat, (int64_t)tid * kPPT, w);
+                if (wave_id() == 1) {
+                    draw_words4(tc.seed, tc.uid0 + (uint64_t)gj_first + (uint64_t)(tid - kWave) * kPPT, tc.draw, w);
+                    store4(L.ustrat, (int64_t)(tid - kWave) * kPPT, w);
+                }
+            }
         }
         if (searcher) {
             // ---- one wavefront: the generation's totals, this shard's place in the joint population, the source tiles this output
