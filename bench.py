@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample")
     p.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (pipelined runs, gaussian SIS)")
+    p.add_argument("--no-live-pmc", action="store_true", help="do not spawn the two rocprofv3 --pmc passes that measure roofline.traffic (e.g. when bench.py itself runs under a profiler)")
     p.add_argument("--in-flight", type=int, default=3, help="contexts in flight for the secondary pipelined measurement")
     p.add_argument("--loopback-ranks", type=int, default=0, help="N = 1 only: run the library's multi-GPU driver with this many ranks on the one GPU "
                    "(loopback transport: the whole exchange protocol, program order instead of collectives); --particles is then the WHOLE population")
@@ -372,9 +373,65 @@ def cpu_as_shipped(n_sample, seed, model=None, obs=None, address="Mu", label="ga
     return {"value": n_sample / dt, "unit": "particles/s", "cores": 1, "sample": "%d particles, %s SIS with per-particle file dumps, %.1f s" % (n_sample, label, dt)}
 
 
+def pmc_child(workload, n, resampler, seed, flags):
+    """What the live PMC passes profile: the timed context's configuration, a few runs, nothing else (no floor run, no extras)."""
+    import torch  # noqa: F401
+    import cpprob_amd as cp
+    spec = workload_spec(workload, os.path.join(ROOT, "tests", "golden", "observations.npz"))
+    rid, rfl = resampler_of(resampler)
+    eng = cp.Engine(0)
+    eng.begin(spec["alg"], spec["model"], spec["obs"], n, seed=seed, resampler=rid, ess_threshold=spec["ess"], flags=flags | rfl)
+    for i in range(4):
+        eng.run(i)
+    eng.sync()
+    eng.close()
+
+
+def live_pmc_traffic(workload, n, resampler, seed, flags, dom):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: nothing
+    but --pmc on the command line, as MI355X_MICROARCH.md's HBM section prescribes) of a child process that runs this configuration,
+    corrected as that section says for gfx950 (FETCH_SIZE counts half the bytes of wide coalesced reads).  None when the profiler
+    is not there or a pass fails: the line then falls back to the committed profile and says so."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cpprob_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child", workload, str(n), resampler, str(seed), str(flags)]
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not fs:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, p.returncode, p.stderr[-200:])
+            acc = []
+            for r in csv.DictReader(open(fs[0])):
+                name = r.get("Kernel_Name", "")
+                hit = ("smc_step" in name) if dom == "smc_step" else ("sis_" in name and "finish" not in name)
+                if hit and r.get("Counter_Name") == ctr:
+                    acc.append(float(r["Counter_Value"]))
+            if not acc:
+                return None, "no %s samples of the %s kernel" % (ctr, dom)
+            vals[ctr] = (sum(acc) / len(acc), len(acc))
+        except Exception as e:      # noqa: the line falls back and says so
+            return None, "rocprofv3 --pmc %s: %s" % (ctr, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = 2.0 * vals["FETCH_SIZE"][0] * 1024.0 + vals["WRITE_SIZE"][0] * 1024.0
+    return traffic, ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE over %d launches, WRITE_SIZE over %d) of a child process on this GPU, "
+                     "bytes = 2 x FETCH_SIZE KB x 1024 + WRITE_SIZE KB x 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reads half)" % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]))
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-baseline-worker":
         print(json.dumps(cpu_baseline_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))))
+        return
+    if len(sys.argv) >= 7 and sys.argv[1] == "--pmc-child":
+        pmc_child(sys.argv[2], int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]))
         return
     args = parse()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -432,8 +489,8 @@ def main():
     reruns = 0
     xtraffic = None
     rs_id, rs_flags = resampler_of(args.resampler)
-    if args.resampler != "systematic" and (world > 1 or args.loopback_ranks > 1):
-        sys.stderr.write("bench.py: --resampler %s runs on one GPU (the exchange scope resamples systematically)\n" % args.resampler)
+    if args.resampler not in ("systematic", "stratified") and (world > 1 or args.loopback_ranks > 1):
+        sys.stderr.write("bench.py: --resampler %s runs on one GPU (the exchange scope resamples systematically or stratified)\n" % args.resampler)
         sys.exit(2)
     if world == 1 and args.loopback_ranks > 1 and smc:
         group = cp.Group([local] * args.loopback_ranks)
@@ -487,7 +544,7 @@ def main():
             native_error = (native_error + "; " if native_error else "") + "preflight: the default transport did not reproduce the single-GPU traces; measuring '%s'" % preflight["settled_on"]
     if group is not None:
         def begin_group():
-            group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"])
+            group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=rs_id, ess_threshold=spec["ess"])
         # (begin is collective over real links: it all-gathers hipIpc handles and proves the mailboxes by a round trip)
         guarded(begin_group, "cpprob_hip_group_begin (peer mappings, mailbox round trip)") if world > 1 else begin_group()
         dt, stats, summ, reruns = timed_group_runs(group, args.steps, args.warmup, world, device)
@@ -502,7 +559,7 @@ def main():
             native_error = (native_error + "; " if native_error else "") + "default transport produced a wrong posterior: conservative transport measured"
             group.transport(flags=cp.capi.GROUP_LIBRARY_COLLECTIVES | cp.capi.GROUP_SHIP_LINEAGES)
             def begin_conservative():
-                group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=cp.RESAMPLE_SYSTEMATIC, ess_threshold=spec["ess"],
+                group.begin(spec["alg"], spec["model"], spec["obs"], n_global, seed=args.seed, resampler=rs_id, ess_threshold=spec["ess"],
                             flags=cp.capi.FLAG_WALK_READOUT)
             guarded(begin_conservative, "cpprob_hip_group_begin (conservative transport)")
             dt, stats, summ, reruns = timed_group_runs(group, args.steps, args.warmup, world, device)
@@ -585,6 +642,12 @@ def main():
             traffic_src = "committed profile profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on another box, gfx950-corrected): NOT measured in this run" % os.path.basename(pmcs[-1])
             valu_frac = rec["step_kernel"].get("valu_issue_frac")
             wait_frac = rec["step_kernel"].get("wait_frac")
+    if rank == 0 and world == 1 and args.loopback_ranks <= 1 and not args.no_live_pmc:
+        live, why = live_pmc_traffic(args.workload, n_prof, args.resampler, args.seed, args.flags, dom)
+        if live is not None:
+            traffic, traffic_src = live, why
+        else:
+            traffic_src = (traffic_src or "no committed profile for this workload and size") + "; live PMC passes unavailable: " + str(why)
     hbm_frac_measured = (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_s > 0) else None
     # what bounds the dominant kernel at THIS size: within 2x of an empty launch of the same chain it is the chain's latency
     # (kernel boundary, first round trip to memory, search, gather), whatever the byte convention says

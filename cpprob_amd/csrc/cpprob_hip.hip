@@ -442,9 +442,9 @@ bool counts_eligible(const cpprob_hip_ctx* c)
            c->cfg.ess_threshold > 1.0 &&
            (c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC
                 ? (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)
-                // (stratified resampling: the same walk with the outputs' own uniforms; one population per context)
-                : (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED && c->cfg.resample_scope != CPPROB_HIP_SCOPE_EXCHANGE &&
-                   (c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)));
+                // (stratified resampling: the same walk with the outputs' own uniforms)
+                : (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED &&
+                   (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)));
 }
 
 // Philox4x32-10 on the host (cpprob/detail/rng.hpp's draw_block): the systematic offset of a resampling step is a pure function of
@@ -509,7 +509,8 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         if (c->trace_mode && !all_totals) { a.trace_prev = c->d_q[(t + 1) & 1]; a.trace_next = c->d_q[t & 1]; }
         if (c->step_protocol && c->trace_shard_run) { a.trace_prev = c->d_tr[(t + 1) & 1]; a.trace_next = c->d_tr[t & 1]; }
         ProfScope ps(c, 0);
-        if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED) hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED && all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        else if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED) hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else if (all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         if (t + 1 == c->T) { c->cur = 0; c->cur_part = 0; }
@@ -523,9 +524,9 @@ template <class Model>
 bool fixed_eligible(const cpprob_hip_ctx* c)
 {
     constexpr bool model_ok = std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value || std::is_same<Model, ModelHmmK>::value;
-    // (stratified and multinomial resampling run on the same integer masses: one population per context)
+    // (stratified and multinomial resampling run on the same integer masses; multinomial: one population per context)
     const bool own = c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND;
-    const bool systematic = c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC;
+    const bool systematic = c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC || c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED;      // (one interval of outputs per rank)
     return model_ok && !c->force_fp && !(c->cfg.flags & CPPROB_HIP_FLAG_FLOATING_POINT_STEP) && c->nb <= kCountsMaxTiles && c->pop_n <= (1ull << 28) &&
            c->cfg.algorithm == CPPROB_HIP_ALG_SMC && !counts_eligible<Model>(c) &&
            (systematic ? (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || own) : (own && c->cfg.resample_scope != CPPROB_HIP_SCOPE_EXCHANGE));
@@ -623,12 +624,14 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
                 if (sh) hipLaunchKernelGGL((smc_step_fixed_carry_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
                 else hipLaunchKernelGGL((smc_step_fixed_carry_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
                 if (rs == kFixMultinomial) hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
-                else if (rs == kFixStratified) hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+                else if (rs == kFixStratified && !sh) hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
                 else if (sh) hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, true, kFixSystematic>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
                 else hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, false, kFixSystematic>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             }
             else if (rs == kFixMultinomial) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixMultinomialLiteral) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomialLiteral>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (rs == kFixStratified && all_totals && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else if (rs == kFixStratified && all_totals) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixStratified && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixStratified && !Model::kIsInt) hipLaunchKernelGGL((smc_step_fixed_five_kernel<Model, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixStratified) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
@@ -954,8 +957,9 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     if (cfg->resample_scope != CPPROB_HIP_SCOPE_GLOBAL && cfg->resample_scope != CPPROB_HIP_SCOPE_ISLAND && cfg->resample_scope != CPPROB_HIP_SCOPE_EXCHANGE)
         return fail(c, CPPROB_HIP_EINVAL, "unknown resample_scope");
     const bool exchange = cfg->resample_scope == CPPROB_HIP_SCOPE_EXCHANGE && cfg->algorithm == CPPROB_HIP_ALG_SMC;
-    if (exchange && cfg->resampler != CPPROB_HIP_RESAMPLE_SYSTEMATIC)
-        return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope resamples systematically (one shared offset makes every rank's offspring range computable from the rank totals)");
+    if (exchange && cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL)
+        return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope resamples systematically or stratified: the outputs a rank's sources own are then ONE interval, computable from the "
+                                                 "ranks' totals (multinomial thresholds are not sorted across the ranks' boundary)");
     c->cfg = *cfg;
     // a model with ONE observe statement has nothing to resample between: smc is sis (the components of its vector-valued
     // statements are rows of the particle store, not resampling points)
@@ -1516,10 +1520,12 @@ int launch_plan(cpprob_hip_ctx* c, int t, bool fixed_layout)
         PlanFixedIn pf{};
         pf.all_totals = reinterpret_cast<const uint64_t*>(c->x_all_totals); pf.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1); pf.n_pop = (double)c->pop_n;
         pf.ess_frac = c->cfg.ess_threshold;
+        pf.rs = c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED ? kFixStratified : kFixSystematic; pf.seed = c->run_seed; pf.draw = kResampleDrawBase + (uint64_t)t + 1;
         hipLaunchKernelGGL(exchange_plan_fixed_kernel, dim3(1), dim3(kWave), 0, c->stream, g, pf, t, c->d_annex_base, c->d_xplan);
     } else if (c->counts_mode) {
         pc.e0 = c->h_e_tab[(size_t)t * 4]; pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
         pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
+        pc.rs = c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED ? kFixStratified : kFixSystematic; pc.seed = c->run_seed; pc.draw = kResampleDrawBase + (uint64_t)t + 1;
         hipLaunchKernelGGL((exchange_plan_kernel<true, false>), dim3(1), dim3(kWave), 0, c->stream, g, pc, (const double*)c->d_obound, t, c->d_annex_base, c->d_xplan, ScanArgs{});
     } else if (c->scan2_deferred) {
         const ScanArgs sa = make_scan_args(c, t, 2, c->x_all_totals, c->x_world, c->x_rank);
@@ -1558,6 +1564,7 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid, bool plan_inside
             hier_view(c, kn, a.h);
             a.pc.e0 = c->h_e_tab[(size_t)t * 4]; a.pc.e1 = c->h_e_tab[(size_t)t * 4 + 1]; a.pc.e2 = c->h_e_tab[(size_t)t * 4 + 2];
             a.pc.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1);
+            a.pc.rs = c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED ? kFixStratified : kFixSystematic; a.pc.seed = c->run_seed; a.pc.draw = kResampleDrawBase + (uint64_t)t + 1;
             if (plan_inside) hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackCounts, true>), pgrid, dim3(kThreads), 0, c->stream, a);
             else hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackCounts, false>), pgrid, dim3(kThreads), 0, c->stream, a);
             return;
@@ -1568,6 +1575,7 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid, bool plan_inside
         fhier_view(c, kn, a.f);
         a.pf.all_totals = reinterpret_cast<const uint64_t*>(c->x_all_totals); a.pf.u0 = host_resample_u0(c->run_seed, (uint64_t)t + 1); a.pf.n_pop = (double)c->pop_n;
         a.pf.ess_frac = c->cfg.ess_threshold;
+        a.pf.rs = c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED ? kFixStratified : kFixSystematic; a.pf.seed = c->run_seed; a.pf.draw = kResampleDrawBase + (uint64_t)t + 1;
         a.q_prev = c->d_q[c->cur];                                     // the weights of the generation step t just produced
         if (plan_inside) hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackFixed, true>), pgrid, dim3(kThreads), 0, c->stream, a);
         else hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackFixed, false>), pgrid, dim3(kThreads), 0, c->stream, a);

@@ -66,6 +66,7 @@ struct ExchangeGeom {
 
 struct PlanCountsIn {                 // prefix-count form: o_r from the all-gathered {n_0, n_1, particles}
     const double* all_totals; double e0, e1, e2, u0, n_pop;
+    int rs; uint64_t seed, draw;      // kFixSystematic / kFixStratified (the outputs' uniforms: Philox key, draw index)
 };
 
 // The plan as one wavefront holds it: lane r = what concerns rank r, plus the wave-uniform part.
@@ -86,7 +87,9 @@ __device__ __forceinline__ double plan_bounds_counts(const PlanCountsIn& pc, int
     tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0;
     const double W = tc.cdf(read_lane(i0, kWave - 1), read_lane(i1, kWave - 1), pc.n_pop);
     tc.inv = pc.n_pop / W;
-    double o = tc.g(tc.cdf(i0 - r0, i1 - r1, iv - rv));
+    tc.seed = pc.seed; tc.draw = pc.draw; tc.uid0 = 0;
+    const double Cb = tc.cdf(i0 - r0, i1 - r1, iv - rv);
+    double o = pc.rs == kFixStratified ? tc.first_stratified(Cb) : tc.g(Cb);
     if (lane >= world) o = pc.n_pop;
     return o;
 }
@@ -282,9 +285,9 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
 {
     using S = typename Model::store_t;
     constexpr bool COUNTS = MODE == kPackCounts, FIXED = MODE == kPackFixed;
-    __shared__ CountsLds Lc;
+    __shared__ CountsLdsT<kFixStratified> Lc;                    // (the stratified forms' layouts: the systematic ones' plus the outputs' uniforms)
     __shared__ AncestorLds Lf;
-    __shared__ FixedLds Lx;
+    __shared__ FixedLdsT<kFixStratified> Lx;
     __shared__ uint32_t s_hop[32];                              // bit tt - 1 of word (tt - 1) / 32: did step tt - 1 resample? (<= 1024 steps)
     __shared__ int64_t s_send_lo[kWorldSlots], s_send_cnt[kWorldSlots], s_send_base[kWorldSlots], s_dst_col[kWorldSlots];
     __shared__ int64_t s_nsend;
@@ -324,6 +327,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
         const FixedRanks rk = fixed_ranks(a.pf.all_totals, a.world, a.rank);
         const FixedDecision d = fixed_decide(rk.S, rk.Q, a.pf.n_pop, a.pf.ess_frac, true);
         fc.inv = d.inv; fc.u0 = a.pf.u0; fc.n_pop = a.pf.n_pop; fc.base = rk.before;
+        fc.seed = a.pf.seed; fc.draw = a.pf.draw; fc.uid0 = 0;
     }
     if constexpr (COUNTS) {
         const int lane = lane_id();
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
         if (lane < a.world) { r0 = a.pc.all_totals[3 * lane]; r1 = a.pc.all_totals[3 * lane + 1]; rv = a.pc.all_totals[3 * lane + 2]; }
         const bool before = lane < a.rank;
         tc.e0 = a.pc.e0; tc.e1 = a.pc.e1; tc.e2 = a.pc.e2; tc.u0 = a.pc.u0; tc.n_pop = a.pc.n_pop;
+        tc.seed = a.pc.seed; tc.draw = a.pc.draw; tc.uid0 = 0;
         tc.base0 = wave_sum(before ? r0 : 0.0); tc.base1 = wave_sum(before ? r1 : 0.0); tc.basev = wave_sum(before ? rv : 0.0);
         const double t0 = wave_sum(r0), t1 = wave_sum(r1);
         tc.inv = 1.0;
@@ -370,7 +375,8 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                     store4(Lx.slot, (int64_t)tid * kPPT, neg);
                 }
                 __syncthreads();
-                ancestors_fixed(a.f, fc, a.q_prev, a.n, a.nb, last_shard, (double)gj0, n_out, r < a.rank ? 0 : a.nb - 1, anc, Lx);
+                if (a.pf.rs == kFixStratified) ancestors_fixed<kFixStratified>(a.f, fc, a.q_prev, a.n, a.nb, last_shard, (double)gj0, n_out, r < a.rank ? 0 : a.nb - 1, anc, Lx);
+                else ancestors_fixed<kFixSystematic>(a.f, fc, a.q_prev, a.n, a.nb, last_shard, (double)gj0, n_out, r < a.rank ? 0 : a.nb - 1, anc, reinterpret_cast<FixedLds&>(Lx));
             } else if constexpr (COUNTS) {
                 {
                     int32_t neg[kPPT];
@@ -378,7 +384,8 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model,
                     store4(Lc.slot, (int64_t)tid * kPPT, neg);
                 }
                 __syncthreads();
-                ancestors_counts<S, true>(a.h, tc, a.values + (int64_t)row_t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, r < a.rank ? 0 : a.nb - 1, anc, Lc);
+                if (a.pc.rs == kFixStratified) ancestors_counts<S, true, kFixStratified>(a.h, tc, a.values + (int64_t)row_t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, r < a.rank ? 0 : a.nb - 1, anc, Lc);
+                else ancestors_counts<S, true, kFixSystematic>(a.h, tc, a.values + (int64_t)row_t * a.rs, a.n, a.nb, last_shard, (double)gj0, n_out, r < a.rank ? 0 : a.nb - 1, anc, reinterpret_cast<CountsLds&>(Lc));
             } else {
                 AncestorIn in;
                 in.wrel = a.wrel; in.bc = a.bc; in.bf = a.bf; in.nb = a.nb; in.n_in = a.n;

@@ -932,7 +932,7 @@ int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, co
         largest = std::max(largest, sz);
     }
     if (g->shard_begin[(size_t)g->world] != cfg->n_particles) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "shard sizes do not add up to n_particles"));
-    g->exchange = cfg->algorithm == CPPROB_HIP_ALG_SMC && cfg->resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC;
+    g->exchange = cfg->algorithm == CPPROB_HIP_ALG_SMC && (cfg->resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC || cfg->resampler == CPPROB_HIP_RESAMPLE_STRATIFIED);
     // transport defaults: the two neighbours, room for the O(sqrt(N)) outputs a rank's offspring interval leaves its shard by
     g->all_peers = 0;
     const uint64_t guess = (uint64_t)(8.0 * std::sqrt((double)cfg->n_particles)) / kTile * kTile + 4 * kTile;

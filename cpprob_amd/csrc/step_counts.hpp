@@ -344,12 +344,18 @@ __device__ __forceinline__ void counts_walk(const TableCdf& tc, const S* __restr
 }
 
 // Both parts in every wavefront (the exchange scope's packing, whose output tiles sit anywhere in the shard).
-template <class S, bool sharded>
+template <class S, bool sharded, int RS = kFixSystematic>
 __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& tc, const S* __restrict__ states, int64_t n, int nb,
-                                                 bool last_shard, double gj_first, int n_out, int guess, int32_t (&anc)[kPPT], CountsLds& L)
+                                                 bool last_shard, double gj_first, int n_out, int guess, int32_t (&anc)[kPPT], CountsLdsT<RS>& L)
 {
-    const Located loc = counts_locate(h, tc, n, nb, gj_first, n_out, guess, nullptr);
-    counts_walk<S, sharded>(tc, states, n, nb, last_shard, gj_first, n_out, loc, /* no tile was prefetched */ -16, 0u, 0u, 0u, anc, L);
+    if constexpr (RS == kFixStratified) {                        // (the outputs' uniforms, behind a barrier of their own)
+        uint32_t w[kPPT];
+        draw_words4(tc.seed, tc.uid0 + (uint64_t)gj_first + (uint64_t)threadIdx.x * kPPT, tc.draw, w);
+        store4(L.ustrat, (int64_t)threadIdx.x * kPPT, w);
+        __syncthreads();
+    }
+    const Located loc = counts_locate<RS>(h, tc, n, nb, gj_first, n_out, guess, nullptr);
+    counts_walk<S, sharded, RS>(tc, states, n, nb, last_shard, gj_first, n_out, loc, /* no tile was prefetched */ -16, 0u, 0u, 0u, anc, L);
 }
 
 struct StepFound { Located loc; double inv, base0, base1, basev; int64_t l0, l1; };      // what the searching wavefront hands the other three

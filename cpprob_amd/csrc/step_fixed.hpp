@@ -132,13 +132,16 @@ __device__ __forceinline__ void fixed_walk(const FixedCdf& fc, const uint32_t* _
     for (int k = 0; k < kPPT; ++k) anc[k] = max(v[k], excl);
 }
 
-// Both parts in every wavefront (the exchange scope's packing, whose output tiles sit anywhere in the shard).
+// Both parts in every wavefront (the exchange scope's packing, whose output tiles sit anywhere in the shard).  Stratified: the
+// outputs' uniforms are staged here first (behind a barrier of its own).
+template <int RS = kFixSystematic>
 __device__ __forceinline__ void ancestors_fixed(const FHier& f, const FixedCdf& fc, const uint32_t* __restrict__ qprev, int64_t n, int nb, bool last_shard,
-                                                double gj_first, int n_out, int guess, int32_t (&anc)[kPPT], FixedLds& L)
+                                                double gj_first, int n_out, int guess, int32_t (&anc)[kPPT], FixedLdsT<RS>& L)
 {
-    const FLocated loc = fixed_locate(f, fc, nb, gj_first, n_out, guess, nullptr);
+    if constexpr (RS == kFixStratified) { stratified_stage(L, fc.seed, fc.draw, fc.uid0 + (uint64_t)gj_first); __syncthreads(); }
+    const FLocated loc = fixed_locate<RS>(f, fc, nb, gj_first, n_out, guess, nullptr);
     const U4 z = {0u, 0u, 0u, 0u};
-    fixed_walk(fc, qprev, n, nb, last_shard, gj_first, n_out, loc, guess, false, z, z, z, anc, L);
+    fixed_walk<RS>(fc, qprev, n, nb, last_shard, gj_first, n_out, loc, guess, false, z, z, z, anc, L);
 }
 
 // all-gathered totals of the ranks: 3 words per rank {S, Q, key(M)} (they travel as 24 bytes, whatever the collective calls them)
@@ -956,8 +959,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
 // One shard of a joint population.  Five wavefronts a SIMD (96 registers; the continuous models' build wants 138 and spills ~25
 // of them): configs[3]'s shard of 1.25 10^6 particles is 1221 workgroups, and 256 CUs hold 1280 of them at five a CU but 768 at
 // three -- a second pass of workgroups behind the first costs more than the spills (profiles/r03_notes.md).
-template <class Model, bool PREFETCH>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void smc_step_fixed_sharded_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, true, PREFETCH>(a); }
+template <class Model, bool PREFETCH, int RS = kFixSystematic>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void smc_step_fixed_sharded_kernel(StepFixedArgs<Model> a) { smc_step_fixed_body<Model, true, PREFETCH, RS>(a); }
 
 // ---- the run's last generation ------------------------------------------------------------------------------------------------
 struct FixedFinal {
@@ -1148,7 +1151,7 @@ __global__ __launch_bounds__(kWave) void fixed_repair_ctrl_kernel(StepCtrl* c, F
 }
 
 // Offspring bounds of the ranks (lane r: o_r, r = 0 .. world) and the decision, from the all-gathered totals.  One wave.
-struct PlanFixedIn { const uint64_t* all_totals; double u0, n_pop, ess_frac; };
+struct PlanFixedIn { const uint64_t* all_totals; double u0, n_pop, ess_frac; int rs; uint64_t seed, draw; };      // rs: kFixSystematic / kFixStratified (the outputs' uniforms: seed, draw)
 __device__ __forceinline__ double plan_bounds_fixed(const PlanFixedIn& pf, int world, bool& resample)
 {
     const int lane = lane_id();
@@ -1160,7 +1163,8 @@ __device__ __forceinline__ double plan_bounds_fixed(const PlanFixedIn& pf, int w
     resample = d.resample;
     FixedCdf fc;
     fc.inv = d.inv; fc.u0 = pf.u0; fc.n_pop = pf.n_pop; fc.base = 0;
-    double o = fc.g(incl - s);
+    fc.seed = pf.seed; fc.draw = pf.draw; fc.uid0 = 0;
+    double o = pf.rs == kFixStratified ? fc.first_stratified(incl - s) : fc.g(incl - s);
     if (lane >= world) o = pf.n_pop;
     return o;
 }

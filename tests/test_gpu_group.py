@@ -456,3 +456,33 @@ def test_group_shards_carry_trace_words_across_ranks(engine, golden_dir, shards)
     assert out["words"][1]["records"] == out["walk"][1]["records"] > 0
     assert out["words"][1]["wire_bytes"] == out["words"][1]["records"] * 13 and out["walk"][1]["wire_bytes"] == out["walk"][1]["records"] * 9
     np.testing.assert_allclose(out["words"][0], out["walk"][0], rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("shards", [[50000, 50000], [30000, 50001, 19999], [25000] * 8, [1000, 2000, 70000, 3000, 999]])
+@pytest.mark.parametrize("model,key,T,ess", [(cp.MODEL_HMM3, "hmm16", 16, 2.0), (cp.MODEL_HMM3, "hmm128", 40, 0.5), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 25, 0.5),
+                                             (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 12, 2.0)])
+def test_group_stratified_resampling_is_bit_identical_to_one_gpu_and_the_oracle(engine, golden_dir, shards, model, key, T, ess):
+    """Stratified resampling through the exchange scope: output j sits at j + u_j (the uniform of OUTPUT j: the same on whichever
+    rank holds it), so the outputs a rank's sources own are ONE interval [A(mass before the rank), A(mass up to its end)) that every
+    rank derives from the all-gathered totals -- the plan, the packing launch's ancestor search and the sharded step kernel run the
+    stratified comb on integers (prefix counts for the every-step HMM, fixed-point masses otherwise) exactly as one GPU does: every
+    surviving trace, the decisions and the evidence equal the single-context run's, which equals the oracle's, for 2 .. 8 uneven
+    loopback shards."""
+    import torch  # noqa: F401
+    from oracle import oracle as O
+    obs = _obs(golden_dir, key)[:T]
+    n = int(sum(shards))
+    engine.begin(cp.ALG_SMC, model, obs, n, seed=23, resampler=cp.RESAMPLE_STRATIFIED, ess_threshold=ess)
+    engine.run()
+    ref_stats, ref_sum, ref_paths, ref_anc = engine.stats().copy(), engine.summary(), engine.paths(), engine.ancestors()
+    orc = O.smc(model, obs, n, 23, O.RESAMPLE_STRATIFIED, ess)
+    assert np.array_equal(ref_anc, orc["anc"]) and ref_sum["n_resampled"] == int(orc["resampled"].sum())
+    g = cp.Group([0] * len(shards))
+    g.begin(cp.ALG_SMC, model, obs, n, seed=23, resampler=cp.RESAMPLE_STRATIFIED, ess_threshold=ess, shard_sizes=shards)
+    g.run()
+    stats, s, _ = g.results()
+    paths = np.concatenate([_ctx_paths(g, r, shards[r], T, model == cp.MODEL_HMM3) for r in range(len(shards))], axis=1)
+    g.close()
+    assert s["step_form"] == ref_sum["step_form"] != cp.capi.FORM_FLOAT
+    assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-12)

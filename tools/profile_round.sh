@@ -13,8 +13,18 @@ for W in "hmm16_smc 1000000" "hmm16_smc 10000000" "lgssm100_smc 1250000" "lgssm1
   set -- $W
   D=$O/${TAG}_prof_$1_$2
   rm -rf $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --workload $1 --particles $2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $D.log 2>&1
-  python3 $R/bench.py --workload $1 --particles $2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $D.json 2>> $D.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --workload $1 --particles $2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc > $D.log 2>&1
+  python3 $R/bench.py --workload $1 --particles $2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc > $D.json 2>> $D.log
+done
+# the other resamplers (thesis Alg. 1 p.36 is multinomial): kernel stats of the headline workload and of configs[3]'s per-GPU shape
+for W in "hmm16_smc 1000000" "lgssm100_smc 1250000"; do
+  set -- $W
+  for RS in stratified multinomial multinomial_literal; do
+    D=$O/${TAG}_prof_$1_$2_$RS
+    rm -rf $D
+    rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --workload $1 --particles $2 --resampler $RS --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc > $D.log 2>&1
+    python3 $R/bench.py --workload $1 --particles $2 --resampler $RS --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc > $D.json 2>> $D.log
+  done
 done
 # every workload / size pair bench.py quotes a `traffic` figure for (its roofline block reads profiles/<tag>_pmc_traffic.json)
 for W in "hmm16_smc 1000000" "hmm16_smc 10000000" "lgssm100_smc 1250000" "lgssm100_smc 10000000" "hmm128_smc_ess 12500000"; do
@@ -23,7 +33,7 @@ for W in "hmm16_smc 1000000" "hmm16_smc 10000000" "lgssm100_smc 1250000" "lgssm1
     N=$(echo $C | cut -d' ' -f1)
     D=$O/${TAG}_pmc_$1_$2_$N
     rm -rf $D
-    rocprofv3 --pmc $C --output-format csv -d $D -- python3 $R/bench.py --workload $1 --particles $2 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $D.log 2>&1
+    rocprofv3 --pmc $C --output-format csv -d $D -- python3 $R/bench.py --workload $1 --particles $2 --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-live-pmc > $D.log 2>&1
   done
 done
 # the two 8-GPU configs whole, eight loopback ranks on this one GPU (the full exchange protocol, program order instead of collectives)

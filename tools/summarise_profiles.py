@@ -98,6 +98,26 @@ for wl, n in (("hmm16_smc", 1000000), ("hmm16_smc", 10000000), ("lgssm100_smc", 
     open(base + ".md", "w").write(md)
     notes.append(base + ".md")
 
+# the other resamplers: kernel stats + the un-profiled line of the same call
+for wl, n in (("hmm16_smc", 1000000), ("lgssm100_smc", 1250000)):
+    for rs_name in ("stratified", "multinomial", "multinomial_literal"):
+        d = "%s_prof_%s_%d_%s" % (src_tag, wl, n, rs_name)
+        ks = newest("%s/%s/*/*kernel_stats.csv" % (G, d))
+        if not ks:
+            continue
+        rows = list(csv.DictReader(open(ks)))
+        md = "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --particles %d --resampler %s --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc (MI355X, %s)\n\n" % (wl, n, rs_name, out_tag)
+        md += "| kernel | calls | total us | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n"
+        for r in rows[:12]:
+            md += "| `%s` | %s | %.1f | %.2f | %.2f | %.2f | %s |\n" % (r["Name"][:120], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"])
+        bj = "%s/%s.json" % (G, d)
+        if os.path.exists(bj) and os.path.getsize(bj):
+            b = json.load(open(bj))
+            md += "\nbench.py, same command un-profiled, same gpurun call: %.4g particles/s, %.4f ms per run, step %.2f us per launch by HIP events, step form: %s, posterior max abs err vs exact %.2e.\n" % (
+                b["value"], b["ms_per_step"], b["roofline"]["avg_launch_us"], b["roofline"]["step_form"], b["posterior_max_abs_err_vs_exact"])
+        open("profiles/%s_%s_%d_%s_kernel_stats.md" % (out_tag, wl, n, rs_name), "w").write(md)
+        notes.append("profiles/%s_%s_%d_%s_kernel_stats.md" % (out_tag, wl, n, rs_name))
+
 bp = "%s/%s_bench.json" % (G, src_tag)
 if os.path.exists(bp):
     b = json.load(open(bp))
@@ -132,6 +152,25 @@ for form in (1, 0):
             gmd += "\nThe same command un-profiled, same gpurun call: %.4f ms per run (the last call's device work, read-out included).\n" % (u["run_seconds"] * 1e3)
         except Exception:
             pass
+    if form == 1:
+        # issue counters of the fused step kernel: SQ sums over the chip, per wavefront (3907 workgroups x 4 at 10^6 particles)
+        for sub, title in (("_pmc", "issue"), ("_pmc_lds", "LDS / scalar")):
+            cc = newest("%s/%s%s/*counter_collection.csv" % (G, d, sub)) or newest("%s/%s%s/*/*counter_collection.csv" % (G, d, sub))
+            if not cc:
+                continue
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(cc)):
+                if "model_step_kernel" in r["Kernel_Name"]:
+                    acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if acc:
+                waves = ((1000000 + 255) // 256) * 4
+                c = {k: sum(v) / len(v) for k, v in acc.items()}
+                gmd += "\nPMC (%s counters, rocprofv3 --pmc in a run of its own; averages over %d launches of `model_step_kernel*`, per wavefront = / %d):\n\n| counter | per launch | per wavefront |\n|---|---|---|\n" % (title, len(next(iter(acc.values()))), waves)
+                for k in sorted(c):
+                    gmd += "| %s | %.4g | %.4g |\n" % (k, c[k], c[k] / waves)
+                if "SQ_WAVE_CYCLES" in c:
+                    gmd += "\nwait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f; valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = %.2f; scalar instructions per vector instruction = %.2f.\n" % (
+                        c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], c.get("SQ_ACTIVE_INST_VALU", 0) / c["SQ_WAVE_CYCLES"], c.get("SQ_INSTS_SALU", 0) / max(c.get("SQ_INSTS_VALU", 1), 1))
     open("profiles/%s_generic_hmm16_form%d_kernel_stats.md" % (out_tag, form), "w").write(gmd)
     notes.append("profiles/%s_generic_hmm16_form%d_kernel_stats.md" % (out_tag, form))
 
