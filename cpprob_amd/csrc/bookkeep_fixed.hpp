@@ -62,11 +62,15 @@ struct BbfArgs {
     FHier f; const uint32_t* q; int64_t n; int nb;
     double u0, ess_frac; int step, last;
     double* ess; int32_t* resampled; double* log_z; int32_t* anc;
+    uint64_t seed;                                   // stratified / multinomial: the outputs' own uniforms (draw kResampleDrawBase(2) + step + 1)
+    const uint32_t* strata_offs; int strata_k;       // multinomial, strata form: first outputs of the strata at this resampling (multinomial_strata_kernel)
 };
 
+// RS: kFixSystematic / kFixStratified / kFixMultinomial (strata form) -- the built-in models' step kernels' resampling, on the same masses
+template <int RS = kFixSystematic>
 __global__ __launch_bounds__(kThreads) void bbf_ancestors_kernel(BbfArgs a)
 {
-    __shared__ FixedLds L;
+    __shared__ FixedLdsT<RS> L;
     __shared__ __attribute__((aligned(16))) FixedFound s_found;
     const int tid = threadIdx.x;
     const int bid = (int)blockIdx.x, nb = a.nb;
@@ -74,13 +78,17 @@ __global__ __launch_bounds__(kThreads) void bbf_ancestors_kernel(BbfArgs a)
     const int64_t rem = a.n - (int64_t)bid * kTile;
     const int n_out = rem < kTile ? (int)rem : kTile;
     const double gj_first = (double)((int64_t)bid * kTile);
-    {
+    if constexpr (RS != kFixMultinomial) {
         int32_t neg[kPPT];
         lane_fill(neg, (int32_t)-1);
         store4(L.slot, (int64_t)tid * kPPT, neg);
     }
     FixedCdf fc;
     fc.u0 = a.u0; fc.n_pop = (double)a.n; fc.base = 0; fc.inv = 0.0;
+    fc.seed = a.seed; fc.draw = kResampleDrawBase + (uint64_t)a.step + 1; fc.uid0 = 0;
+    if constexpr (RS == kFixStratified) { if (!a.last) stratified_stage(L, fc.seed, fc.draw, (uint64_t)gj_first); }
+    __shared__ int s_w0, s_w1;
+    __shared__ uint64_t s_S;
     if (wave_id() == 0) {
         FTotWords tw; ftot_fetch(a.f, tw);
         const FTot tot = ftot_sum(a.f, tw);
@@ -95,16 +103,32 @@ __global__ __launch_bounds__(kThreads) void bbf_ancestors_kernel(BbfArgs a)
             *a.log_z = lz;
         }
         FLocated loc{0, 0, 0};
-        if (d.resample) loc = fixed_locate(a.f, fc, nb, gj_first, n_out, bid, nullptr);
-        if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.resample = d.resample ? 1 : 0; }
+        int w0 = 0, w1 = 0;
+        if (d.resample && !a.last) {
+            if constexpr (RS == kFixMultinomial) {
+                ProbeWords pw;
+                probe_fetch(a.f.h, bid, nb, pw);
+                const StrataLocated sl = strata_locate(a.f, a.strata_offs, a.strata_k, nb, bid, (uint32_t)((int64_t)bid * kTile), (uint32_t)((int64_t)bid * kTile + n_out - 1), tot.S, pw);
+                loc = sl.loc; w0 = sl.w0; w1 = sl.w1;
+            } else loc = fixed_locate<RS>(a.f, fc, nb, gj_first, n_out, bid, nullptr);
+        }
+        if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.resample = d.resample ? 1 : 0; s_w0 = w0; s_w1 = w1; s_S = tot.S; }
     }
     __syncthreads();
     if (a.last) return;
     int32_t anc[kPPT];
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) anc[k] = (int32_t)(j0 + k);
     if (s_found.resample) {
         fc.inv = s_found.inv;
-        const U4 z = {0u, 0u, 0u, 0u};
-        fixed_walk(fc, a.q, a.n, nb, true, gj_first, n_out, s_found.loc, bid, false, z, z, z, anc, L);
+        if constexpr (RS == kFixMultinomial) {
+            StrataLocated sl;
+            sl.loc = s_found.loc; sl.w0 = s_w0; sl.w1 = s_w1;
+            strata_walk(a.strata_offs, a.strata_k, a.q, nb, sl, s_S, j0, a.seed, kResampleDrawBase2 + (uint64_t)a.step + 1, (uint64_t)j0, anc, L);
+        } else {
+            const U4 z = {0u, 0u, 0u, 0u};
+            fixed_walk<RS>(fc, a.q, a.n, nb, true, gj_first, n_out, s_found.loc, bid, false, z, z, z, anc, L);
+        }
 #pragma unroll
         for (int k = 0; k < kPPT; ++k) anc[k] = max(anc[k], 0);
     } else {

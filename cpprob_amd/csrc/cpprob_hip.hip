@@ -77,6 +77,7 @@ struct cpprob_hip_ctx {
     int32_t* d_resampled = nullptr;
     double* d_stats_part = nullptr;
     double* d_stats = nullptr;
+    uint32_t* d_bbf_strata = nullptr; uint32_t* d_bbf_strata_top = nullptr; size_t bbf_strata_cap = 0;     // ... of the bookkeeping protocol (cpprob_hip_smc_bookkeep_fixed_rs)
     uint32_t* d_strata = nullptr;   // multinomial, strata form: [T - 1][2^k + 1] first outputs of the strata, every step of the run
     uint32_t* d_strata_top = nullptr; int strata_phase = 0; bool strata_pending = false;   // ... [2][T][64] totals of the level-6 nodes (the set in use alternates run by run)
     double* d_cdf = nullptr;        // multinomial only
@@ -899,7 +900,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     dfree(c->d_ctrl); dfree(c->d_local_totals);
     dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent); dfree(c->d_origin); dfree(c->d_remote); dfree(c->d_annex_all);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
-    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_cols); dfree(c->d_bb_cols_part); dfree(c->d_bb_cols_stat); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q);
+    dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_cols); dfree(c->d_bb_cols_part); dfree(c->d_bb_cols_stat); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q); dfree(c->d_bbf_strata); dfree(c->d_bbf_strata_top);
     dfree(c->d_gen_hier); dfree(c->d_gen_table); dfree(c->d_gen_q[0]); dfree(c->d_gen_q[1]); dfree(c->d_gen_ctrl);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -2527,7 +2528,14 @@ extern "C" {
 int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* c, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last, double ess_frac,
                                   double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc)
 {
+    return cpprob_hip_smc_bookkeep_fixed_rs(c, CPPROB_HIP_RESAMPLE_SYSTEMATIC, d_logw, n, seed, step, last, ess_frac, d_ess, d_resampled, d_log_z, d_anc);
+}
+
+int cpprob_hip_smc_bookkeep_fixed_rs(cpprob_hip_ctx* c, int32_t kind, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last, double ess_frac,
+                                     double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc)
+{
     BB_PRELUDE(c);
+    if (kind < CPPROB_HIP_RESAMPLE_SYSTEMATIC || kind > CPPROB_HIP_RESAMPLE_MULTINOMIAL) return fail(c, CPPROB_HIP_EINVAL, "unknown resampler");
     if (!d_logw || !d_ess || !d_resampled || !d_log_z || (!last && !d_anc)) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (n == 0 || n > (size_t)(1ull << 28)) return fail(c, CPPROB_HIP_EINVAL, "population size out of range (1 .. 2^28: the squares' 64-bit sum)");
     if (step < 0) return fail(c, CPPROB_HIP_EINVAL, "step out of range");
@@ -2540,8 +2548,32 @@ int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* c, const double* d_logw, size_
     hipLaunchKernelGGL(bbf_quantize_kernel, dim3(nb), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, c->d_bbf_q);
     BbfArgs a{};
     a.f = f; a.q = c->d_bbf_q; a.n = (int64_t)n; a.nb = nb; a.u0 = host_resample_u0(seed, (uint64_t)step + 1); a.ess_frac = ess_frac; a.step = step; a.last = last ? 1 : 0;
-    a.ess = d_ess; a.resampled = d_resampled; a.log_z = d_log_z; a.anc = d_anc;
-    hipLaunchKernelGGL(bbf_ancestors_kernel, dim3(last ? 1 : nb), dim3(kThreads), 0, c->stream, a);
+    a.ess = d_ess; a.resampled = d_resampled; a.log_z = d_log_z; a.anc = d_anc; a.seed = seed;
+    if (kind == CPPROB_HIP_RESAMPLE_MULTINOMIAL && !last) {
+        // strata form: the counts of this one resampling (they do not depend on the weights: one short launch, two above 64 tiles)
+        const int k = strata_levels(nb);
+        const size_t words = ((size_t)1 << k) + 1;
+        if (words > c->bbf_strata_cap) {
+            dfree(c->d_bbf_strata); dfree(c->d_bbf_strata_top);
+            HIP_TRY(c, hipMalloc(&c->d_bbf_strata, words * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_bbf_strata_top, 64 * sizeof(uint32_t)));
+            c->bbf_strata_cap = words;
+        }
+        StrataArgs sa{};
+        sa.seed = seed; sa.t0 = step + 1; sa.k = k; sa.n_out = (uint32_t)n; sa.offs = c->d_bbf_strata;
+        if (k <= kStrataTop) hipLaunchKernelGGL(multinomial_strata_kernel, dim3(1, 1), dim3(kThreads), 0, c->stream, sa);
+        else {
+            HIP_TRY(c, hipMemsetAsync(c->d_bbf_strata_top, 0, 64 * sizeof(uint32_t), c->stream));
+            sa.top = c->d_bbf_strata_top; sa.top_clear = nullptr;
+            hipLaunchKernelGGL(multinomial_strata_top_kernel, dim3(strata_groups(k), 1), dim3(kThreads), 0, c->stream, sa);
+            hipLaunchKernelGGL(multinomial_strata_bottom_kernel, dim3(64, 1), dim3(kThreads), 0, c->stream, sa);
+        }
+        a.strata_offs = c->d_bbf_strata; a.strata_k = k;
+    }
+    const dim3 grid(last ? 1 : nb);
+    if (kind == CPPROB_HIP_RESAMPLE_STRATIFIED) hipLaunchKernelGGL(bbf_ancestors_kernel<kFixStratified>, grid, dim3(kThreads), 0, c->stream, a);
+    else if (kind == CPPROB_HIP_RESAMPLE_MULTINOMIAL) hipLaunchKernelGGL(bbf_ancestors_kernel<kFixMultinomial>, grid, dim3(kThreads), 0, c->stream, a);
+    else hipLaunchKernelGGL(bbf_ancestors_kernel<kFixSystematic>, grid, dim3(kThreads), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return 0;
 }

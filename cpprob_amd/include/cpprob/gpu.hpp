@@ -322,11 +322,12 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     ModelKernelArgs a{};
     a.n = (int64_t)n; a.ld = ld; a.seed = opt.seed; a.trace_cap = (uint32_t)S; a.overflow = d_overflow_p; a.pid0 = opt.particle_offset;
     a.pred_real_cap = (uint32_t)n_real; a.pred_int_cap = (uint32_t)n_int; a.lane_block = device::kLaneBlock;
-    // SMC bookkeeping between two launches of the model body, on the device: systematic resampling runs on fixed-point weights
-    // (integer masses: three short launches, cpprob_amd/csrc/bookkeep_fixed.hpp), the other resamplers on the floating-point CDF
+    // SMC bookkeeping between two launches of the model body, on the device: every resampler runs on fixed-point weights (integer
+    // masses: three short launches, cpprob_amd/csrc/bookkeep_fixed.hpp; multinomial: the strata form, its counts in front); beyond
+    // 2^28 particles the floating-point CDF
     auto bookkeep = [&](const double* lw, int t, bool last, int32_t* anc_out, double* ess, int32_t* resd, double* logz) {
-        if (opt.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && n <= (std::size_t(1) << 28))
-            ctx.check(cpprob_hip_smc_bookkeep_fixed(ctx.get(), lw, n, opt.seed, t, last ? 1 : 0, opt.ess_threshold, ess, resd, logz, anc_out), "cpprob_hip_smc_bookkeep_fixed");
+        if (n <= (std::size_t(1) << 28))
+            ctx.check(cpprob_hip_smc_bookkeep_fixed_rs(ctx.get(), opt.resampler, lw, n, opt.seed, t, last ? 1 : 0, opt.ess_threshold, ess, resd, logz, anc_out), "cpprob_hip_smc_bookkeep_fixed_rs");
         else
             ctx.check(cpprob_hip_smc_bookkeep(ctx.get(), opt.resampler, lw, n, opt.seed, t, last ? 1 : 0, opt.ess_threshold, ess, resd, logz, anc_out), "cpprob_hip_smc_bookkeep");
     };

@@ -464,6 +464,11 @@ int cpprob_hip_smc_bookkeep(cpprob_hip_ctx* ctx, int32_t kind, const double* d_l
  * masses -- three short launches, no floating-point CDF; uniforms as above.  d_anc may be NULL when last != 0.  n <= 2^28. */
 int cpprob_hip_smc_bookkeep_fixed(cpprob_hip_ctx* ctx, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last, double ess_frac,
                                   double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc);
+/* ... and for any resampler: kind = CPPROB_HIP_RESAMPLE_* -- stratified (output j at j + u_j against the same masses) and multinomial
+ * (strata form: the counts of this resampling's thresholds per stratum in one or two short launches in front of the ancestors' launch),
+ * the arithmetic of the built-in models' step kernels.  cpprob_hip_smc_bookkeep_fixed = kind SYSTEMATIC. */
+int cpprob_hip_smc_bookkeep_fixed_rs(cpprob_hip_ctx* ctx, int32_t kind, const double* d_logw, size_t n, uint64_t seed, int32_t step, int32_t last, double ess_frac,
+                                     double* d_ess, int32_t* d_resampled, double* d_log_z, int32_t* d_anc);
 /* ---- SMC step of an UNCHANGED model with the resampling inside the model's own launch (cpprob_amd/include/cpprob/gpu.hpp:
  * model_step_kernel; replaces the loop body of reference include/cpprob/cpprob.hpp:194-201 for StateType::smc) ----------------------
  * The model translation unit owns the kernel (it is a template over the model function); the library owns what the kernel's

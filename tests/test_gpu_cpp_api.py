@@ -131,6 +131,31 @@ def test_unchanged_model_smc_equals_the_oracle_in_every_step_form(tmp_path, mode
     assert abs(res["log_evidence"] - r["log_z"]) < 1e-9
 
 
+@pytest.mark.parametrize("model,key,T,ess,oid,is_int", [("hmm16", "hmm16", 16, 2.0, O.MODEL_HMM3, True), ("linear_gaussian_1d25", "lgssm100", 25, 0.5, O.MODEL_LINEAR_GAUSSIAN_1D, False)])
+@pytest.mark.parametrize("rname,rid", [("stratified", O.RESAMPLE_STRATIFIED), ("multinomial", O.RESAMPLE_MULTINOMIAL)])
+def test_unchanged_model_smc_with_the_other_resamplers_equals_the_oracle(tmp_path, model, key, T, ess, oid, is_int, rname, rid):
+    """Stratified and multinomial resampling of an unchanged model: the bookkeeping launches between two launches of the model body
+    run on the same integer masses as the built-in models' step kernels (cpprob_hip_smc_bookkeep_fixed_rs: references from exact
+    maxima, stratified comb / strata-form multinomial) -- surviving traces array_equal to the oracle's fixed-point SMC."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    obs = z[key][:T]
+    n = 40000
+    res, _, _ = run_main(tmp_path, "--model", model, "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 3, "--ess_threshold", ess, "--json",
+                         "--generic", "--generated_file", "g", "--resampler", rname)
+    assert res["step_form"] == 0 and res["launches_per_step"] == 4
+    vg, lwg = read_dump(str(tmp_path / ("g_smc.int" if is_int else "g_smc.real")), is_int)
+    r = O.smc_ref(oid, obs, n, 3, O.REF_EXACT_MAX, rid, ess)
+    paths = np.take_along_axis(r["hist"], O.lineage(r["anc"]), axis=1)
+    assert res["n_resampled"] == int(r["resampled"].sum())
+    if is_int:
+        assert np.array_equal(vg, paths)
+    else:
+        np.testing.assert_allclose(vg, paths, rtol=0, atol=1e-10)
+        assert np.array_equal(np.argsort(vg[-1], kind="stable"), np.argsort(paths[-1], kind="stable"))
+    np.testing.assert_allclose(lwg, r["logw"], atol=1e-10)
+    assert abs(res["log_evidence"] - r["log_z"]) < 1e-9
+
+
 def test_unchanged_model_step_falls_back_to_exact_maxima_when_a_generation_leaves_its_bound(tmp_path):
     """An observation 30 sigma from every state: the observe statement's bound lies > 6 nats above every particle, the integer
     weights would lose their bits -- the device flags the generation and the run is repeated against exact maxima (two launches per
