@@ -22,11 +22,16 @@ def newest(pat):
     return max(fs, key=os.path.getmtime) if fs else None
 
 
-def counters(d):
+def counters(d, full_grid=None):
+    """Per kernel and counter: (mean, launches).  full_grid: step kernels are counted at THIS grid size only -- bench.py's launch-floor
+    run (the same kernels at 4096 particles) sits in the same process and would dilute a per-launch mean (it did in r01 .. r04: the
+    committed traffic of the headline step was 8.3 MB where the population's launches move 14.1)."""
     f = newest("%s/%s/*/*counter_collection.csv" % (G, d))
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     if f:
         for r in csv.DictReader(open(f)):
+            if full_grid is not None and "smc_step" in r["Kernel_Name"] and int(r["Grid_Size"]) != full_grid:
+                continue
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: (sum(v) / len(v), len(v)) for c, v in d2.items()} for k, d2 in acc.items()}
 
@@ -36,7 +41,8 @@ pmc = {"_comment": "rocprofv3 --pmc, one counter set per run (tools/profile_roun
                    "Per-wave issue counters are SQ sums over the chip divided by the launch's wavefronts (workgroups x 4).", "workloads": {}}
 ALGO = {"hmm16_smc": 56, "lgssm100_smc": 72, "hmm128_smc_ess": 56, "gaussian_sis": 16}
 for wl, n in (("hmm16_smc", 1000000), ("hmm16_smc", 10000000), ("lgssm100_smc", 1250000), ("lgssm100_smc", 10000000), ("hmm128_smc_ess", 12500000)):
-    fe, wr, sq = counters("%s_pmc_%s_%d_FETCH_SIZE" % (src_tag, wl, n)), counters("%s_pmc_%s_%d_WRITE_SIZE" % (src_tag, wl, n)), counters("%s_pmc_%s_%d_SQ_WAVE_CYCLES" % (src_tag, wl, n))
+    fg = ((n + 1023) // 1024) * 256
+    fe, wr, sq = counters("%s_pmc_%s_%d_FETCH_SIZE" % (src_tag, wl, n), fg), counters("%s_pmc_%s_%d_WRITE_SIZE" % (src_tag, wl, n), fg), counters("%s_pmc_%s_%d_SQ_WAVE_CYCLES" % (src_tag, wl, n), fg)
     rec = {}
     for k in fe:
         name = "step_kernel" if "smc_step" in k else ("smooth_kernel" if ("smooth" in k or "trace_readout" in k) else None)
