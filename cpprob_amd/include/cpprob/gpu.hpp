@@ -980,13 +980,23 @@ bool generic_joint_launcher(StateType algorithm, const void* observes_v, std::si
         if (distinct && !opt.joint_across_devices) { res.joint_note = "joint population across physical devices is unvalidated on real links: islands (set Options::joint_across_devices to run it)"; return false; }
         if (distinct) res.joint_note = "joint population across physical devices: not yet validated against the single-device run on real links";
     }
-    // the replay window is certified on one device first (generic_launcher's pilot: once per model and trace shape)
+    // the replay window is certified on one device first (generic_launcher's pilot) -- once per model, trace shape and window in this
+    // process: a later call reuses the verdict instead of running 8192 particles again
     {
-        Options po = opt; po.devices.clear(); po.device = opt.devices[0]; po.dump = false;
-        Result pr;
-        generic_launcher<Caller>(algorithm, observes_v, std::min<std::size_t>(n, 8192), st, po, pr, nullptr);
-        if (pr.replay_window < 0) return false;                        // the pilot refuted the window: no joint form for this model
-        res.markov_crosscheck = pr.markov_crosscheck;
+        static std::mutex jmu;
+        static std::map<std::tuple<std::size_t, std::size_t, int>, int> verdict;           // (Caller is part of the function's identity)
+        const auto key = std::make_tuple((std::size_t)st.n_observe, (std::size_t)st.n_sample, st.window);
+        int known = 0, cross = 0;
+        { std::lock_guard<std::mutex> lock(jmu); const auto it = verdict.find(key); if (it != verdict.end()) { known = 1; cross = it->second; } }
+        if (!known) {
+            Options po = opt; po.devices.clear(); po.device = opt.devices[0]; po.dump = false;
+            Result pr;
+            generic_launcher<Caller>(algorithm, observes_v, std::min<std::size_t>(n, 8192), st, po, pr, nullptr);
+            cross = pr.replay_window < 0 ? -2 : pr.markov_crosscheck;
+            std::lock_guard<std::mutex> lock(jmu); verdict[key] = cross;
+        }
+        if (cross == -2) return false;                                 // the pilot refuted the window: no joint form for this model
+        res.markov_crosscheck = cross;
     }
     StepForm form = st.bounds_fixed ? StepForm::fused_bounded : StepForm::fused_exact;
     if (opt.step_form_override == 2) form = StepForm::fused_exact;
