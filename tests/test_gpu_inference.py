@@ -265,6 +265,19 @@ def test_smc_stratified_and_multinomial_are_bit_exact_against_the_oracle(engine,
         np.testing.assert_allclose(engine.stats(), sm_self, rtol=1e-10, atol=1e-12)
 
 
+def test_multinomial_strata_counts_beyond_16384_tiles(engine, golden_dir):
+    """2 10^7 particles = 19 532 tiles = 2^15 strata: the bottom part of the strata tree runs nine levels per level-6 node (more nodes
+    than a workgroup has threads: the thread-per-node form of strata_split), the step's stratum window and the three-level mass
+    hierarchy at their largest tested size -- ancestors and states equal the oracle's."""
+    obs = _obs(golden_dir, "hmm16")[:3]
+    n = 20_000_000
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=29, resampler=cp.RESAMPLE_MULTINOMIAL, ess_threshold=2.0)
+    engine.run()
+    ref = O.smc(cp.MODEL_HMM3, obs, n, 29, cp.RESAMPLE_MULTINOMIAL, 2.0)
+    assert np.array_equal(engine.ancestors(), ref["anc"]) and np.array_equal(engine.values(), ref["hist"])
+    assert abs(engine.summary()["log_evidence"] - ref["log_z"]) < 1e-9
+
+
 @pytest.mark.parametrize("model,key,T", [(cp.MODEL_HMM3, "hmm128", 40), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 30)])
 @pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_STRATIFIED, cp.RESAMPLE_MULTINOMIAL])
 def test_paired_step_launches_are_the_single_launch_bit_for_bit(engine, golden_dir, model, key, T, resampler):
@@ -291,6 +304,9 @@ def test_paired_step_launches_are_the_single_launch_bit_for_bit(engine, golden_d
 def test_smc_tiny_and_ragged_populations(engine, golden_dir, n):
     obs = _obs(golden_dir, "hmm16")[:5]
     _compare_smc(engine, cp.MODEL_HMM3, obs, n, 3, cp.RESAMPLE_SYSTEMATIC, 2.0)          # (one and two particles included: ancestors, states, evidence)
+    for rs in (cp.RESAMPLE_STRATIFIED, cp.RESAMPLE_MULTINOMIAL):                        # ... and the other two resamplers, both integer forms
+        _compare_smc(engine, cp.MODEL_HMM3, obs, n, 3, rs, 2.0)
+        _compare_smc(engine, cp.MODEL_LINEAR_GAUSSIAN_1D, _obs(golden_dir, "lgssm100")[:5], n, 3, rs, 0.5)
     engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=3)
     engine.run()
     st = engine.stats()
