@@ -444,8 +444,11 @@ bool counts_eligible(const cpprob_hip_ctx* c)
            (c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC
                 ? (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)
                 // (stratified resampling: the same walk with the outputs' own uniforms)
-                : (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED &&
-                   (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)));
+                : c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED
+                ? (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)
+                // (multinomial, strata form: one population per context; the literal form runs on fixed-point masses)
+                : (!(c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL) && c->cfg.resample_scope != CPPROB_HIP_SCOPE_EXCHANGE &&
+                   (c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)));
 }
 
 // Philox4x32-10 on the host (cpprob/detail/rng.hpp's draw_block): the systematic offset of a resampling step is a pure function of
@@ -478,6 +481,7 @@ static void hier_view(const cpprob_hip_ctx* c, int copy, Hier& h)
 }
 
 static void hier_rotation(cpprob_hip_ctx* c, int t, int& kp, int& kn, int& kc);
+static void launch_strata(cpprob_hip_ctx* c);
 
 template <class Model>
 void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int world, int rank)
@@ -510,7 +514,13 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         if (c->trace_mode && !all_totals) { a.trace_prev = c->d_q[(t + 1) & 1]; a.trace_next = c->d_q[t & 1]; }
         if (c->step_protocol && c->trace_shard_run) { a.trace_prev = c->d_tr[(t + 1) & 1]; a.trace_next = c->d_tr[t & 1]; }
         ProfScope ps(c, 0);
-        if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED && all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL) {
+            a.strata_k = strata_levels(c->nb);
+            if (t == 0) launch_strata(c);
+            a.strata_offs = t > 0 ? c->d_strata + (size_t)(t - 1) * (((size_t)1 << a.strata_k) + 1) : nullptr;
+            hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+        }
+        else if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED && all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED) hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else if (all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
@@ -1227,6 +1237,8 @@ int cpprob_hip_infer_run(cpprob_hip_ctx* c, uint64_t run_index)
             c->profile_suspended = false;
             // (no normalisation launch at any size: the read-out works from the final generation's masses)
         } else if (c->counts_mode) {
+            c->strata_pending = c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL;
+            launch_strata(c);
             {
                 ProfScope group(c, 0, c->T);
                 c->profile_suspended = true;

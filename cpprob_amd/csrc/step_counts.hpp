@@ -164,6 +164,8 @@ struct CountsLdsT {
     uint32_t scan[2][kWaves];   // packed per-wave totals of the in-tile scan, double-buffered across source tiles
     int iscr[kWaves];
     uint32_t ustrat[RS == kFixStratified ? kTile : 1];   // stratified: the 32-bit uniforms of the output tile's outputs
+    double cd[RS == kFixMultinomial ? kStrataTiles * kTile : 1];   // multinomial: the source tiles' inclusive CDF values, side by side
+    uint32_t wtot[RS == kFixMultinomial ? kStrataTiles : 1][kWaves];  // ... and their wavefronts' packed count totals
 };
 using CountsLds = CountsLdsT<kFixSystematic>;
 
@@ -358,7 +360,196 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
     counts_walk<S, sharded, RS>(tc, states, n, nb, last_shard, gj_first, n_out, loc, /* no tile was prefetched */ -16, 0u, 0u, 0u, anc, L);
 }
 
-struct StepFound { Located loc; double inv, base0, base1, basev; int64_t l0, l1; };      // what the searching wavefront hands the other three
+// ---- multinomial resampling, strata form, on the table CDF (csrc/step_fixed.hpp states the form; the CPU restatement:
+//      orc_resample_table_multinomial) ----
+// The strata's bounds are B_w = w (W 2^-k): exact scaling, one rounded product, B_K = W.  Output s of stratum w takes
+// tau_s = fma(v_s, B_w+1 - B_w, B_w), v_s the 53-bit uniform of output s; ancestor = min{k : C_k > tau_s}, C_k the CDF of the
+// inclusive prefix counts (TableCdf::cdf: the systematic comb's own values).  One population per context.
+// The SEARCH (one wavefront): the strata of the outputs (strata_window) and the source tiles that hold their CDF range: the largest
+// tile whose starting CDF value is <= x, by the systematic search's probe of five tiles, a second probe aimed by the value, or the descent.
+struct LocatedStrata { Located loc; int w0, w1; };
+__device__ __forceinline__ LocatedStrata counts_strata_locate(const Hier& h, const TableCdf& tc, const uint32_t* __restrict__ offs, int k, int64_t n, int nb, int bid,
+                                                              uint32_t s_first, uint32_t s_last, double W, const ProbeWords& first)
+{
+    const int lane = lane_id();
+    LocatedStrata r;
+    strata_window(offs, k, nb, bid, s_first, s_last, r.w0, r.w1);
+    const double unit = ldexp(W, -k);
+    const double x_lo = (double)r.w0 * unit, x_hi = (double)(r.w1 + 1) * unit;       // (thresholds lie in [x_lo, x_hi]: the fma may round up to the bound)
+    auto nvalid_before = [&](int c) -> int64_t { const int64_t v = (int64_t)c * kTile; return v < n ? v : n; };
+    int c = 0, c_last = nb;
+    Cnt2 P{0, 0};
+    auto probe = [&](int at, const ProbeWords& pw) -> bool {
+        const int cs = at > 0 ? at - 1 : 0;
+        const Cnt2 Pc = hier_prefix_sum(cs, pw.lvl);
+        const uint64_t we = (lane < 4 && cs + lane < nb) ? pw.we : 0ull;
+        const uint32_t v0 = cnt_n0(we), v1 = cnt_n1(we);
+        const uint32_t i0 = wave_incl_scan_u32(v0), i1 = wave_incl_scan_u32(v1);
+        const uint32_t x0 = Pc.n0 + i0 - v0, x1 = Pc.n1 + i1 - v1;        // lanes 0..4: the prefix counts at tile cs + lane
+        const double cv = tc.cdf(tc.base0 + (double)x0, tc.base1 + (double)x1, tc.basev + (double)nvalid_before(cs + lane));
+        const bool known = lane < 5 && cs + lane < nb;
+        const unsigned long long m = __ballot(known && cv <= x_lo);
+        const int i_lo = m ? (63 - __builtin_clzll(m)) : -1;
+        if ((i_lo >= 0 || cs == 0) && i_lo < 4) {
+            const int i = i_lo < 0 ? 0 : i_lo;
+            c = cs + i;
+            P.n0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, i);
+            P.n1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, i);
+            const unsigned long long mh = __ballot(known && cv <= x_hi);
+            const int i_hi = mh ? (63 - __builtin_clzll(mh)) : i;
+            c_last = (i_hi >= 4 && cs + 5 < nb) ? nb : cs + (i_hi > i ? i_hi : i);
+            return true;
+        }
+        return false;
+    };
+    if (!probe(bid, first)) {
+        const double aim = x_lo * ((double)nb / (W > 0.0 ? W : 1.0));
+        const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
+        ProbeWords pw;
+        probe_fetch(h, at, nb, pw);
+        if (!probe(at, pw)) {
+            // top-down descent: the largest tile whose starting CDF value is <= x_lo
+            const HierTable* __restrict__ ht = h.table;
+            int blk = 0;
+            uint32_t p0 = 0, p1 = 0;
+            for (int l = ht->n_lev - 1; l >= 0; --l) {
+                const int idx = (blk << 6) + lane;
+                uint64_t w = 0;
+                const bool in = idx < ht->n_ent[l];
+                if (in) w = ht->lvl[h.copy][l][(int64_t)idx * (l == 0 ? 1 : kHierStride)];
+                const uint32_t v0 = cnt_n0(w), v1 = cnt_n1(w);
+                const uint32_t i0 = wave_incl_scan_u32(v0), i1 = wave_incl_scan_u32(v1);
+                const uint32_t x0 = p0 + i0 - v0, x1 = p1 + i1 - v1;
+                const int64_t tile0 = (int64_t)idx << (6 * l);
+                const int64_t nv = tile0 * kTile < n ? tile0 * kTile : n;
+                const bool ok = in && tc.cdf(tc.base0 + (double)x0, tc.base1 + (double)x1, tc.basev + (double)nv) <= x_lo;
+                const unsigned long long m = __ballot(ok);
+                const int child = m ? (63 - __builtin_clzll(m)) : 0;
+                p0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, child);
+                p1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, child);
+                blk = (blk << 6) + child;
+            }
+            c = blk; P = Cnt2{p0, p1}; c_last = nb;
+        }
+    }
+    r.loc = Located{c, c_last, P.n0, P.n1};
+    return r;
+}
+
+// The WALK (the whole workgroup): the lane's four outputs take their thresholds; the source tiles, up to kStrataTiles at a time, put
+// their particles' CDF values side by side in LDS (one count scan a tile, two barriers a group), and every output whose threshold
+// lies in the group searches them once.  uid = the id of the lane's first output (a multiple of four); j0 = its index.
+template <class S>
+__device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uint32_t* __restrict__ offs, int k, const S* __restrict__ states, int64_t n, int nb,
+                                                   const LocatedStrata& sl, double W, int64_t j0, uint64_t seed, uint64_t draw, uint64_t uid,
+                                                   int32_t (&anc)[kPPT], CountsLdsT<kFixMultinomial>& L)
+{
+    static_assert(sizeof(S) == 1 && kPPT == 4, "states travel as one byte: 4 per lane = one dword");
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const u32x4 b0 = draw_block(seed, uid >> 1, draw), b1 = draw_block(seed, (uid >> 1) + 1, draw);
+    const double v[kPPT] = {u01_53(b0.x, b0.y), u01_53(b0.z, b0.w), u01_53(b1.x, b1.y), u01_53(b1.z, b1.w)};
+    double tau[kPPT];
+    bool live[kPPT];
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i) { live[i] = false; tau[i] = 0.0; }
+    const int w0 = __builtin_amdgcn_readfirstlane(sl.w0), w1 = __builtin_amdgcn_readfirstlane(sl.w1);
+    const double unit = ldexp(W, -k);
+    {
+        uint32_t o_lo = offs[w0];
+        for (int w = w0; w <= w1; ++w) {
+            const uint32_t o_hi = offs[w + 1];
+            const double b_lo = (double)w * unit, b_hi = (double)(w + 1) * unit;
+#pragma unroll
+            for (int i = 0; i < kPPT; ++i) {
+                const int64_t s = j0 + i;
+                if (s >= (int64_t)o_lo && s < (int64_t)o_hi) { tau[i] = fma(v[i], b_hi - b_lo, b_lo); live[i] = true; }
+            }
+            o_lo = o_hi;
+        }
+    }
+    const double x_hi = (double)(w1 + 1) * unit;
+    auto nvalid_before = [&](int c) -> int64_t { const int64_t v2 = (int64_t)c * kTile; return v2 < n ? v2 : n; };
+    int c = __builtin_amdgcn_readfirstlane(sl.loc.c);
+    const int c_last = __builtin_amdgcn_readfirstlane(sl.loc.c_last);
+    uint32_t P0 = sl.loc.p0, P1 = sl.loc.p1;                              // state-0 / state-1 particles before tile c
+    const double base2 = tc.basev - tc.base0 - tc.base1;
+    bool first_group = true;
+    while (c < nb && c <= c_last) {
+        // (the last tile may be unknown: stop where a tile starts beyond the largest threshold)
+        if (c_last >= nb && __builtin_amdgcn_readfirstlane(tc.cdf(tc.base0 + (double)P0, tc.base1 + (double)P1, tc.basev + (double)nvalid_before(c)) > x_hi ? 1 : 0)) break;
+        int nt = (c_last < nb ? c_last : nb - 1) - c + 1;
+        if (nt > kStrataTiles) nt = kStrataTiles;
+        if (!first_group) __syncthreads();                              // (the previous group's searches have read the LDS arrays)
+        first_group = false;
+        uint32_t raw[kStrataTiles], qk[kStrataTiles][kPPT], runs[kStrataTiles], incls[kStrataTiles];
+#pragma unroll
+        for (int j = 0; j < kStrataTiles; ++j)
+            raw[j] = j < nt ? *reinterpret_cast<const uint32_t*>(states + (int64_t)(c + j) * kTile + (int64_t)tid * kPPT) : 0u;
+#pragma unroll
+        for (int j = 0; j < kStrataTiles; ++j) {
+            const int64_t nvt = n - (int64_t)(c + j) * kTile;             // valid particles of the tile (the shard's last one may be ragged)
+            uint32_t run = 0;
+#pragma unroll
+            for (int i = 0; i < kPPT; ++i) {
+                const uint32_t st = (raw[j] >> (8 * i)) & 0xffu;
+                const bool valid = j < nt && (int64_t)(tid * kPPT + i) < nvt;
+                run += (valid && st == 0) ? 1u : 0u;
+                run += (valid && st == 1) ? 0x10000u : 0u;
+                qk[j][i] = run;
+            }
+            runs[j] = run;
+            incls[j] = wave_incl_scan_u32(run);
+            if (lane == kWave - 1) L.wtot[j][wv] = incls[j];
+        }
+        __syncthreads();
+        double t_end = 0.0;                                               // the CDF value at the end of the group
+#pragma unroll
+        for (int j = 0; j < kStrataTiles; ++j) {
+            if (j < nt) {
+                uint32_t off = 0, tot = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) { const uint32_t x = L.wtot[j][w]; if (w < wv) off += x; tot += x; }
+                const uint32_t excl = off + incls[j] - runs[j];
+                const int64_t nvt = n - (int64_t)(c + j) * kTile;
+                const uint32_t nvb = (uint32_t)nvalid_before(c + j);
+                double cdv[kPPT];
+#pragma unroll
+                for (int i = 0; i < kPPT; ++i) {
+                    const uint32_t packed = excl + qk[j][i];
+                    const int upto = tid * kPPT + i + 1;
+                    const uint32_t n0 = P0 + (packed & 0xffffu), n1 = P1 + (packed >> 16);
+                    const uint32_t n2 = nvb + (uint32_t)((int64_t)upto > nvt ? (nvt > 0 ? nvt : 0) : upto) - n0 - n1;
+                    cdv[i] = fma((double)n2 + base2, tc.e2, fma((double)n1 + tc.base1, tc.e1, __dmul_rn((double)n0 + tc.base0, tc.e0)));
+                }
+                using D2 = double __attribute__((ext_vector_type(2)));
+                D2 a0, a1;
+                a0[0] = cdv[0]; a0[1] = cdv[1]; a1[0] = cdv[2]; a1[1] = cdv[3];
+                *reinterpret_cast<D2*>(L.cd + (size_t)j * kTile + (size_t)tid * kPPT) = a0;
+                *reinterpret_cast<D2*>(L.cd + (size_t)j * kTile + (size_t)tid * kPPT + 2) = a1;
+                P0 += tot & 0xffffu; P1 += tot >> 16;
+                t_end = tc.cdf(tc.base0 + (double)P0, tc.base1 + (double)P1, tc.basev + (double)nvalid_before(c + j + 1));
+            }
+        }
+        __syncthreads();
+        const int len = nt * kTile;
+#pragma unroll
+        for (int i = 0; i < kPPT; ++i) {
+            if (live[i] && tau[i] < t_end) {
+                int a = 0, b = len - 1;                                    // the first idx with cd[idx] > tau (cd[len - 1] = t_end > tau)
+                for (int hstep = 0; hstep < 12; ++hstep) { const int mid = (a + b) >> 1; if (L.cd[mid] > tau[i]) b = mid; else a = mid + 1; }
+                static_assert(kStrataTiles * kTile <= 4096, "twelve halvings");
+                anc[i] = c * kTile + (a < len ? a : len - 1);
+                live[i] = false;
+            }
+        }
+        c += nt;
+    }
+    // a threshold that rounded up to the population's whole mass: its last particle
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i) if (live[i]) anc[i] = (int32_t)(n - 1);
+}
+
+struct StepFound { Located loc; double inv, base0, base1, basev; int64_t l0, l1; int w0, w1; double W; };      // what the searching wavefront hands the other three
 
 template <class Model>
 struct StepCountsArgs {
@@ -378,6 +569,7 @@ struct StepCountsArgs {
     int row_w, row_r;                                           // rows of values[] this step writes / reads (t, t - 1; a filtering-only run: its two rows in turn)
     double* filter_stats;                                       // filtering-only run: [T][3], generation t-1's P(x = s) from its totals (nullptr otherwise)
     const uint32_t* trace_prev; uint32_t* trace_next;           // trace words (trace_words.hpp) of generations t-1 / t, or nullptr: short discrete traces (shards: [rs], annex included)
+    const uint32_t* strata_offs; int strata_k;                  // multinomial, strata form: first output of every stratum at this step (step_fixed.hpp: multinomial_strata_kernel)
 };
 
 // This tile's entry of generation t's hierarchy, added into the levels above (see the header of this file), and the entries of
@@ -416,7 +608,8 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     using V = typename Model::value_t;
     using S = typename Model::store_t;
     static_assert(Model::kWeightTable == 3, "prefix-count form: three table values (two stored counts)");
-    static_assert(RS == kFixSystematic || RS == kFixStratified, "prefix-count form: systematic or stratified resampling");
+    static_assert(RS == kFixSystematic || RS == kFixStratified || RS == kFixMultinomial, "prefix-count form: systematic, stratified or (strata-form) multinomial resampling");
+    static_assert(!(RS == kFixMultinomial && SHARDED), "multinomial resampling: one population per context");
     __shared__ CountsLdsT<RS> L;
     __shared__ int s_cnt[kWaves * 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_model[Model::kStagedWords];
@@ -465,7 +658,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     if (t > 0) {
         if (guess == 0) raw_m1 = 0u;
         if (guess + 1 >= nb) raw_p1 = 0u;
-        {
+        if constexpr (RS != kFixMultinomial) {
             int32_t neg[kPPT];
             lane_fill(neg, (int32_t)-1);
             store4(L.slot, (int64_t)tid * kPPT, neg);
@@ -529,7 +722,13 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
                     fs[0] = __dmul_rn(tot0, tc.e0) / W; fs[1] = __dmul_rn(tot1, tc.e1) / W; fs[2] = __dmul_rn(tot2, tc.e2) / W;
                 }
             }
-            const Located loc = counts_locate<RS>(a.h, tc, a.n, nb, gj_first, n_out, guess, &pw0);
+            Located loc{0, 0, 0, 0};
+            int sw0 = 0, sw1 = 0;
+            if constexpr (RS == kFixMultinomial) {
+                const LocatedStrata ls = counts_strata_locate(a.h, tc, a.strata_offs, a.strata_k, a.n, nb, bid, (uint32_t)((int64_t)bid * kTile),
+                                                              (uint32_t)((int64_t)bid * kTile + n_out - 1), W, pw0);
+                loc = ls.loc; sw0 = ls.w0; sw1 = ls.w1;
+            } else loc = counts_locate<RS>(a.h, tc, a.n, nb, gj_first, n_out, guess, &pw0);
             int64_t l0 = 0, l1 = 0;
             if (SHARDED) {
                 // outputs below o_lo / at or beyond o_hi descend from other shards' sources
@@ -540,7 +739,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
             }
             if (tid == 0) {
                 s_found.loc = loc; s_found.inv = tc.inv; s_found.base0 = tc.base0; s_found.base1 = tc.base1; s_found.basev = tc.basev;
-                s_found.l0 = l0; s_found.l1 = l1;
+                s_found.l0 = l0; s_found.l1 = l1; s_found.w0 = sw0; s_found.w1 = sw1; s_found.W = W;
                 Model::stage(a.mp, s_model);
             }
         }
@@ -548,7 +747,11 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         const Located loc = s_found.loc;
         tc.inv = s_found.inv;
         if (SHARDED) { tc.base0 = s_found.base0; tc.base1 = s_found.base1; tc.basev = s_found.basev; }
-        counts_walk<S, SHARDED, RS>(tc, prev_row, a.n, nb, last_shard, gj_first, n_out, loc, guess, raw_m1, raw_0, raw_p1, anc, L);
+        if constexpr (RS == kFixMultinomial) {
+            LocatedStrata ls;
+            ls.loc = loc; ls.w0 = s_found.w0; ls.w1 = s_found.w1;
+            counts_strata_walk<S>(tc, a.strata_offs, a.strata_k, prev_row, a.n, nb, ls, s_found.W, j0, tc.seed, kResampleDrawBase2 + (uint64_t)t, tc.uid0 + (uint64_t)j0, anc, L);
+        } else counts_walk<S, SHARDED, RS>(tc, prev_row, a.n, nb, last_shard, gj_first, n_out, loc, guess, raw_m1, raw_0, raw_p1, anc, L);
         if (SHARDED) {
             // the lineages of the outputs other shards' sources own arrived as annex columns, in output order (cpprob_hip exchange
             // commit)

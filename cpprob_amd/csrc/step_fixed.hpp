@@ -27,7 +27,6 @@
 namespace cph {
 
 // (fixed-point weights, 64-bit wavefront scans, the mass hierarchy, search and decision: cpprob/detail/fixed_mass.hpp)
-constexpr int kStrataTiles = 3;   // source tiles of an output tile staged side by side by the strata form of multinomial resampling (more: one at a time)
 template <int RS>
 struct FixedLdsT {
     int32_t slot[RS == kFixMultinomial || RS == kFixMultinomialLiteral ? kPPT : kTile];          // scatter slots of the output tile
@@ -275,8 +274,6 @@ __device__ __forceinline__ void fixed_multinomial_ancestors(uint64_t S, uint64_t
 //      An output tile's thresholds lie in two or three neighbouring strata, i.e. in the two or three source tiles around its own
 //      index: each of them rebuilds its prefix masses in LDS and the outputs search there.  No atomics, no launch between two steps.
 // K = the smallest power of two >= the number of tiles.  Integers throughout (the CPU restatement: orc_resample_fixed_multinomial_strata).
-constexpr uint64_t kResampleDrawBase3 = kResampleDrawBase + (1ull << 38);
-__host__ __device__ inline int strata_levels(int64_t nb) { int k = 0; while (((int64_t)1 << k) < nb) ++k; return k; }
 __device__ __forceinline__ uint64_t strata_bound(uint64_t S, uint64_t w, int k)
 {
     if (k == 0) return w ? S : 0ull;
@@ -452,27 +449,8 @@ __device__ __forceinline__ StrataLocated strata_locate(const FHier& f, const uin
                                                        uint64_t S, const ProbeWords& first)
 {
     const int lane = lane_id();
-    const int K = 1 << k;
     StrataLocated r;
-    {
-        int w_at = (int)(((int64_t)bid << k) / nb) - 31;
-        if (w_at > K + 1 - kWave) w_at = K + 1 - kWave;
-        if (w_at < 0) w_at = 0;
-        const int idx = w_at + lane;
-        const bool valid = idx <= K;
-        const uint32_t o = offs[valid ? idx : K];
-        const unsigned long long m_lo = __ballot(valid && o <= s_first), m_hi = __ballot(valid && o <= s_last);
-        const int top = K - w_at < kWave - 1 ? K - w_at : kWave - 1;          // the window's last valid lane
-        const bool ok_lo = (m_lo & 1ull) && (63 - __builtin_clzll(m_lo | 1ull)) < top;
-        const bool ok_hi = (m_hi & 1ull) && (63 - __builtin_clzll(m_hi | 1ull)) < top;
-        auto search = [&](uint32_t s) -> int {
-            int lo = 0, hi = K;                                           // offs[0] = 0 <= s < offs[K]
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= s) lo = mid; else hi = mid; }
-            return lo;
-        };
-        r.w0 = ok_lo ? w_at + (63 - __builtin_clzll(m_lo)) : search(s_first);
-        r.w1 = ok_hi ? w_at + (63 - __builtin_clzll(m_hi)) : search(s_last);
-    }
+    strata_window(offs, k, nb, bid, s_first, s_last, r.w0, r.w1);
     const uint64_t x_lo = strata_bound(S, (uint64_t)r.w0, k), b_hi = strata_bound(S, (uint64_t)r.w1 + 1, k);
     const uint64_t x_hi = b_hi > x_lo ? b_hi - 1 : x_lo;
     int c = 0, c_last = nb;

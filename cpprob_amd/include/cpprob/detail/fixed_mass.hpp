@@ -235,7 +235,11 @@ __device__ __forceinline__ uint64_t fhier_prefix_sum(int c, const uint64_t (&w)[
 //   multinomial (kFixMultinomial: binned, kFixMultinomialLiteral: one search per output): thresholds, not a comb -- csrc/step_fixed.hpp.
 // Both are functions of the exact integer C alone, so tiles, wavefronts and shards may evaluate them in any order.
 constexpr int kFixSystematic = 0, kFixStratified = 1, kFixMultinomial = 2, kFixMultinomialLiteral = 3;
-constexpr uint64_t kResampleDrawBase2 = kResampleDrawBase + (1ull << 39);   // second stage of the binned multinomial form
+constexpr uint64_t kResampleDrawBase2 = kResampleDrawBase + (1ull << 39);   // multinomial, strata form: the outputs' uniforms inside their strata
+constexpr uint64_t kResampleDrawBase3 = kResampleDrawBase + (1ull << 38);   // ... and the bits that split the thresholds over the strata
+constexpr int kStrataTiles = 3;   // source tiles of an output tile staged side by side by the strata form (more: in turn)
+// K = 2^k strata, the smallest power of two >= the number of tiles
+__host__ __device__ inline int strata_levels(int64_t nb) { int k = 0; while (((int64_t)1 << k) < nb) ++k; return k; }
 struct FixedCdf {
     double inv, u0, n_pop; uint64_t base;
     uint64_t seed, draw, uid0;                 // stratified: the run's Philox key, the resampling's draw index, the id of output 0
@@ -489,6 +493,32 @@ __device__ __forceinline__ void bbf_publish_mass(const FHier& f, int bid, int nb
             atomicAdd(e2, (ull)((old + S) & kMassMask)); atomicAdd(e2 + kHierQ, totQ);
         }
     }
+}
+
+// Multinomial resampling, strata form: the strata w0 .. w1 of the outputs [s_first, s_last] -- the largest w with offs[w] <= s (offs:
+// first output of every stratum, offs[K] = N).  One wavefront: a window of 64 offsets around the output tile's own place almost
+// surely holds both (offs[w] wanders sqrt(N) outputs off w N / K); a binary search of the whole array otherwise.
+__device__ __forceinline__ void strata_window(const uint32_t* __restrict__ offs, int k, int nb, int bid, uint32_t s_first, uint32_t s_last, int& w0, int& w1)
+{
+    const int lane = lane_id();
+    const int K = 1 << k;
+    int w_at = (int)(((int64_t)bid << k) / nb) - 31;
+    if (w_at > K + 1 - kWave) w_at = K + 1 - kWave;
+    if (w_at < 0) w_at = 0;
+    const int idx = w_at + lane;
+    const bool valid = idx <= K;
+    const uint32_t o = offs[valid ? idx : K];
+    const unsigned long long m_lo = __ballot(valid && o <= s_first), m_hi = __ballot(valid && o <= s_last);
+    const int top = K - w_at < kWave - 1 ? K - w_at : kWave - 1;          // the window's last valid lane
+    const bool ok_lo = (m_lo & 1ull) && (63 - __builtin_clzll(m_lo | 1ull)) < top;
+    const bool ok_hi = (m_hi & 1ull) && (63 - __builtin_clzll(m_hi | 1ull)) < top;
+    auto search = [&](uint32_t s) -> int {
+        int lo = 0, hi = K;                                           // offs[0] = 0 <= s < offs[K]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= s) lo = mid; else hi = mid; }
+        return lo;
+    };
+    w0 = ok_lo ? w_at + (63 - __builtin_clzll(m_lo)) : search(s_first);
+    w1 = ok_hi ? w_at + (63 - __builtin_clzll(m_hi)) : search(s_last);
 }
 
 }  // namespace cph

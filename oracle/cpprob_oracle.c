@@ -635,6 +635,44 @@ ORC_API int orc_resample_table_stratified(const int32_t *x, uint64_t n_in, const
     return 0;
 }
 
+/* ... and under MULTINOMIAL resampling, strata form (orc_resample_fixed_multinomial_strata below with the table CDF in place of  */
+/* the integer mass): the strata's bounds are B_w = w * (W 2^-k) (exact scaling, one rounded product; B_K = W), output s of        */
+/* stratum w takes tau_s = fma(v_s, B_w+1 - B_w, B_w) with v_s = the 53-bit uniform of output s, ancestor = min{k : C_k > tau_s}   */
+/* (the population's last particle if no C_k exceeds it: tau_s may round up to W).  The counts per stratum: orc_multinomial_strata. */
+ORC_API int orc_strata_levels(uint64_t n_particles);
+ORC_API void orc_multinomial_strata(uint64_t seed, uint64_t step, uint64_t n_out, int k, uint32_t *offs);
+ORC_API int orc_resample_table_multinomial(const int32_t *x, uint64_t n_in, const double e[3], uint64_t seed, uint64_t step, uint64_t n_out, int32_t *anc)
+{
+    const int k = orc_strata_levels(n_in);
+    const uint64_t K = (uint64_t)1 << k;
+    double *cdf = (double *)malloc((n_in ? n_in : 1) * sizeof(double));
+    uint32_t *offs = (uint32_t *)malloc((K + 1) * sizeof(uint32_t));
+    if (!cdf || !offs) { free(cdf); free(offs); return -1; }
+    uint64_t c[3] = { 0, 0, 0 };
+    for (uint64_t i = 0; i < n_in; ++i) {
+        if (x[i] < 0 || x[i] > 2) { free(cdf); free(offs); return -2; }
+        c[x[i]] += 1;
+        cdf[i] = table_cdf(c, e);
+    }
+    const double W = table_cdf(c, e);
+    const double unit = ldexp(W, -k);
+    orc_multinomial_strata(seed, step, n_out, k, offs);
+    for (uint64_t w = 0; w < K; ++w) {
+        const double b0 = (double)w * unit, b1 = (double)(w + 1) * unit;
+        for (uint64_t s = offs[w]; s < offs[w + 1]; ++s) {
+            uint32_t r[4];
+            orc_draw_block(seed, s >> 1, ORC_RESAMPLE_DRAW_BASE2 + step, r);
+            const double v = (s & 1) ? orc_u01_53(r[2], r[3]) : orc_u01_53(r[0], r[1]);
+            const double tau = fma(v, b1 - b0, b0);
+            uint64_t lo = 0, hi = n_in;               /* first i with cdf[i] > tau */
+            while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (cdf[mid] > tau) hi = mid; else lo = mid + 1; }
+            anc[s] = (int32_t)(lo < n_in ? lo : n_in - 1);
+        }
+    }
+    free(cdf); free(offs);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Systematic resampling on FIXED-POINT weights, order-independent form for     */
 /* continuous weights and ESS-triggered schedules (the build's own arithmetic:   */
@@ -973,7 +1011,8 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
     int do_resample = 0;
     /* every resampler runs on integer masses (the fixed-point forms above) -- except systematic / stratified resampling of the 3-state
      * HMM on an every-step schedule, which run on integer prefix COUNTS (the table forms), and ref_mode 3, the floating-point CDF */
-    const int table = (resampler == ORC_RESAMPLE_SYSTEMATIC || resampler == ORC_RESAMPLE_STRATIFIED) && model == ORC_MODEL_HMM3 && ess_frac > 1.0 && ref_mode == 0;
+    const int table = (resampler == ORC_RESAMPLE_SYSTEMATIC || resampler == ORC_RESAMPLE_STRATIFIED || resampler == ORC_RESAMPLE_MULTINOMIAL) &&
+                      model == ORC_MODEL_HMM3 && ess_frac > 1.0 && ref_mode == 0;
     const int fixed = ref_mode != 3 && !table;
     uint32_t *qw = fixed ? (uint32_t *)malloc(n * sizeof(uint32_t)) : NULL;
     uint64_t q_total = 0;
@@ -993,7 +1032,8 @@ static int orc_smc_impl(int model, const double *obs, size_t T, uint64_t n, uint
             hmm_weight_table(obs[t - 1], e, NULL);
             for (uint64_t i = 0; i < n; ++i) total[hist_int[(t - 1) * n + i]] += 1;
             if (resampler == ORC_RESAMPLE_SYSTEMATIC ? orc_resample_table_systematic(hist_int + (t - 1) * n, n, e, before, total, 1, seed, (uint64_t)t, 0, n, n, anc)
-                                                      : orc_resample_table_stratified(hist_int + (t - 1) * n, n, e, before, total, 1, seed, (uint64_t)t, 0, n, n, anc)) return -4;
+              : resampler == ORC_RESAMPLE_STRATIFIED ? orc_resample_table_stratified(hist_int + (t - 1) * n, n, e, before, total, 1, seed, (uint64_t)t, 0, n, n, anc)
+                                                      : orc_resample_table_multinomial(hist_int + (t - 1) * n, n, e, seed, (uint64_t)t, n, anc)) return -4;
         } else if (do_resample) {
             orc_resample(resampler == ORC_RESAMPLE_MULTINOMIAL_LITERAL ? ORC_RESAMPLE_MULTINOMIAL : resampler, logw, n, seed, (uint64_t)t, 0, n, n, anc, cdf);
         } else {

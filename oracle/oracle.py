@@ -63,6 +63,8 @@ def lib():
         L.orc_resample_table_systematic.argtypes = [_ip, u64, _dp, _u64p, _u64p, C.c_int, u64, u64, u64, u64, u64, _ip]
         L.orc_resample_table_stratified.restype = C.c_int
         L.orc_resample_table_stratified.argtypes = [_ip, u64, _dp, _u64p, _u64p, C.c_int, u64, u64, u64, u64, u64, _ip]
+        L.orc_resample_table_multinomial.restype = C.c_int
+        L.orc_resample_table_multinomial.argtypes = [_ip, u64, _dp, u64, u64, u64, _ip]
         L.orc_fix_weight.restype = C.c_uint32; L.orc_fix_weight.argtypes = [dbl, dbl]
         L.orc_fix_weights.argtypes = [_dp, u64, dbl, _up]
         L.orc_resample_fixed_systematic.restype = C.c_int
@@ -200,6 +202,18 @@ def resample_table_systematic(x, e, seed, step, before=None, total=None, last_sh
     rc = fn(x, len(x), e, before, total, int(bool(last_shard)), seed, step, j0, n_out, n_total_out, anc)
     if rc:
         raise RuntimeError("orc_resample_table_%s failed rc=%d" % ("stratified" if stratified else "systematic", rc))
+    return anc
+
+
+def resample_table_multinomial(x, e, seed, step, n_out=None):
+    """Multinomial resampling (strata form) of a table-weight generation on integer prefix counts (orc_resample_table_multinomial)."""
+    x = np.ascontiguousarray(x, np.int32)
+    e = np.ascontiguousarray(e, np.float64)
+    n_out = len(x) if n_out is None else n_out
+    anc = np.zeros(n_out, np.int32)
+    rc = lib().orc_resample_table_multinomial(x, len(x), e, seed, step, n_out, anc)
+    if rc:
+        raise RuntimeError("orc_resample_table_multinomial failed rc=%d" % rc)
     return anc
 
 

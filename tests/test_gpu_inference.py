@@ -240,8 +240,9 @@ def test_smc_stratified_and_multinomial_are_bit_exact_against_the_oracle(engine,
     engine.begin(cp.ALG_SMC, model, obs, n, seed=13, resampler=resampler, ess_threshold=ess, flags=cp.capi.FLAG_MULTINOMIAL_LITERAL if kind == "multinomial_literal" else 0)
     engine.run()
     s = engine.summary()
-    # (the three-state HMM on an every-step schedule: stratified resampling runs on integer prefix COUNTS like systematic)
-    counts = model == cp.MODEL_HMM3 and ess > 1.0 and resampler == cp.RESAMPLE_STRATIFIED
+    # (the three-state HMM on an every-step schedule: stratified and strata-form multinomial resampling run on integer prefix COUNTS
+    #  like systematic)
+    counts = model == cp.MODEL_HMM3 and ess > 1.0 and kind in ("stratified", "multinomial")
     assert s["step_form"] == (cp.capi.FORM_COUNTS if counts else cp.capi.FORM_FIXED)
     ref = O.smc(model, obs, n, 13, O.RESAMPLE_MULTINOMIAL_LITERAL if kind == "multinomial_literal" else resampler, ess)
     anc, vals = engine.ancestors(), engine.values()

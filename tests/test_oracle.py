@@ -492,6 +492,29 @@ def test_strata_form_of_multinomial_resampling_is_multinomial_and_nearly_sorted(
     assert abs(zsc.std() - 1.0) < 0.05 and abs(zsc.mean()) < 0.05 and np.abs(zsc).max() < 6.0    # (systematic resampling would give sd << 1)
 
 
+def test_table_weight_multinomial_is_the_integer_mass_strata_form_on_representable_weights():
+    """orc_resample_table_multinomial (strata form on the table CDF of integer prefix counts: what the 3-state HMM on an every-step
+    schedule resamples with) against orc_resample_fixed_multinomial_strata on weights both represent exactly (powers of two: B_w,
+    tau_s and every C_k are then the same numbers in double and in 64-bit integers), and its law on generic table values."""
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 3, 60000).astype(np.int32)
+    n = len(x)
+    e = np.array([1.0, 0.5, 0.25])
+    q = (e[x] * 2 ** 20).astype(np.uint32)
+    for step in (3, 4):
+        assert np.array_equal(O.resample_table_multinomial(x, e, 7, step), O.resample_fixed_multinomial_strata(q, 7, step))
+    e2 = np.array([0.3123, 1.0, 0.0712345])
+    counts = np.zeros(n)
+    reps = 100
+    for r in range(reps):
+        a = O.resample_table_multinomial(x, e2, 5, r)
+        assert a.min() >= 0 and a.max() < n
+        counts += np.bincount(a, minlength=n)
+    w = e2[x] / e2[x].sum()
+    z = (counts / reps - n * w) / np.sqrt(n * w * (1 - w) / reps)
+    assert abs(z.std() - 1.0) < 0.05 and abs(z.mean()) < 0.05 and np.abs(z).max() < 6.0
+
+
 def test_oracle_repairs_a_generation_that_loses_its_bits():
     """The rule both sides state for the fixed-point form: a generation whose heaviest particle sits more than 6 nats below the
     reference known in advance is weighed against its exact maximum instead.  With an observation ~30 sd from every particle the
