@@ -30,7 +30,7 @@ SYMBOLS = [
     "cpprob_hip_group_context", "cpprob_hip_group_results", "cpprob_hip_philox_blocks", "cpprob_hip_draw_normal", "cpprob_hip_draw_uniform_smallint",
     "cpprob_hip_draw_discrete", "cpprob_hip_draw_uniform_real", "cpprob_hip_draw_poisson", "cpprob_hip_logpdf_normal", "cpprob_hip_logpdf_uniform_real",
     "cpprob_hip_logpdf_poisson", "cpprob_hip_logpdf_uniform_smallint", "cpprob_hip_logpdf_discrete", "cpprob_hip_logsumexp_ess",
-    "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_weighted_moments_columns", "cpprob_hip_weighted_hist_columns", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_smc_bookkeep_fixed", "cpprob_hip_smc_bookkeep_fixed_rs", "cpprob_hip_generic_begin", "cpprob_hip_generic_quantize", "cpprob_hip_generic_max", "cpprob_hip_generic_quantize_ref", "cpprob_hip_generic_totals", "cpprob_hip_generic_finish", "cpprob_hip_systematic_offset", "cpprob_hip_lineage_gather", "cpprob_hip_lineage_prepare", "cpprob_hip_lineage_moments", "cpprob_hip_lineage_hist", "cpprob_hip_gather_f64",
+    "cpprob_hip_weighted_moments", "cpprob_hip_weighted_hist", "cpprob_hip_weighted_moments_columns", "cpprob_hip_weighted_hist_columns", "cpprob_hip_resample", "cpprob_hip_smc_bookkeep", "cpprob_hip_smc_bookkeep_fixed", "cpprob_hip_smc_bookkeep_fixed_rs", "cpprob_hip_generic_begin", "cpprob_hip_generic_begin_tiles", "cpprob_hip_generic_quantize", "cpprob_hip_generic_max", "cpprob_hip_generic_quantize_ref", "cpprob_hip_generic_totals", "cpprob_hip_generic_finish", "cpprob_hip_systematic_offset", "cpprob_hip_lineage_gather", "cpprob_hip_lineage_prepare", "cpprob_hip_readback_with_next_result", "cpprob_hip_lineage_moments", "cpprob_hip_lineage_hist", "cpprob_hip_gather_f64",
     "cpprob_hip_gather_i32", "cpprob_hip_profile_enable", "cpprob_hip_profile_read", "cpprob_hip_fastmath",
 ]
 
@@ -161,6 +161,7 @@ def load_library(path=None):
         "cpprob_hip_smc_bookkeep_fixed": (C.c_int, [vp, vp, sz, u64, i32, i32, dbl, vp, vp, vp, vp]),
         "cpprob_hip_smc_bookkeep_fixed_rs": (C.c_int, [vp, i32, vp, sz, u64, i32, i32, dbl, vp, vp, vp, vp]),
         "cpprob_hip_generic_begin": (C.c_int, [vp, sz, vp]),
+        "cpprob_hip_generic_begin_tiles": (C.c_int, [vp, sz, vp]),
         "cpprob_hip_generic_quantize": (C.c_int, [vp, i32, vp, sz]),
         "cpprob_hip_generic_max": (C.c_int, [vp, i32, vp, sz]),
         "cpprob_hip_generic_quantize_ref": (C.c_int, [vp, i32, vp, sz, dbl]),
@@ -169,6 +170,7 @@ def load_library(path=None):
         "cpprob_hip_systematic_offset": (dbl, [u64, u64]),
         "cpprob_hip_lineage_gather": (C.c_int, [vp, vp, vp, i32, sz, vp, i32, vp, i32, vp]),
         "cpprob_hip_lineage_prepare": (C.c_int, [vp, vp, i32, i32]),
+        "cpprob_hip_readback_with_next_result": (C.c_int, [vp, vp, vp, sz]),
         "cpprob_hip_lineage_moments": (C.c_int, [vp, vp, vp, i32, sz, vp, vp, i32, vp, vp]),
         "cpprob_hip_lineage_hist": (C.c_int, [vp, vp, vp, i32, sz, vp, vp, i32, vp, i32, vp, vp]),
         "cpprob_hip_gather_f64": (C.c_int, [vp, vp, vp, sz, vp]),

@@ -93,6 +93,10 @@ struct cpprob_hip_ctx {
     int64_t annex_cap = 0, annex_used = 0;
     double* d_obound = nullptr;     // [world + 2]: offspring-interval bounds per rank, then the resampling decision
     double* h_obound = nullptr;     // pinned host copy (the one host read-back per step of the exchange scope)
+    // read-backs of small results go through pinned memory (a copy into pageable memory blocks the host for its own round trip: three of
+    // them closed an unchanged-model run at ~25 us each) and ride ONE stream synchronisation; the caller may hang a copy of its own on it
+    char* h_pin = nullptr; size_t h_pin_cap = 0;
+    const void* ride_src = nullptr; void* ride_dst = nullptr; size_t ride_bytes = 0;
     int32_t* d_send_src = nullptr; size_t send_src_cap = 0;
     // device-resident exchange plan (exchange.hpp) and the transport geometry
     ExchangePlan* d_xplan = nullptr;
@@ -157,7 +161,7 @@ struct cpprob_hip_ctx {
     size_t bbf_per_copy = 0, bbf_q0_off = 0, bbf_m0_off = 0; int bbf_nb = 0, bbf_phase = 0; size_t bbf_cap_nb = 0;
     // cpprob_hip_generic_*: three rotating copies of a mass hierarchy, two generations of integer weights, a control block
     uint64_t* d_gen_hier = nullptr; HierTable* d_gen_table = nullptr; HierTable gen_table{}; uint32_t* d_gen_q[2] = {nullptr, nullptr}; void* d_gen_ctrl = nullptr;
-    size_t gen_per_copy = 0, gen_q0_off = 0, gen_m0_off = 0, gen_off[3] = {0, 0, 0}; int gen_nb = 0; size_t gen_cap_nb = 0;
+    size_t gen_per_copy = 0, gen_q0_off = 0, gen_m0_off = 0, gen_off[3] = {0, 0, 0}; int gen_nb = 0, gen_block = 0; size_t gen_cap_hier = 0, gen_cap_q = 0;
 
     // optional per-kernel-class timing
     bool profile = false;
@@ -910,6 +914,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     dfree(c->d_ctrl); dfree(c->d_local_totals);
     dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent); dfree(c->d_origin); dfree(c->d_remote); dfree(c->d_annex_all);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
+    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_cap = 0; }
     dfree(c->d_bb_part); dfree(c->d_bb_bc); dfree(c->d_bb_bf); dfree(c->d_bb_wrel); dfree(c->d_bb_col); dfree(c->d_bb_ctrl); dfree(c->d_bb_stats_part); dfree(c->d_bb_stats); dfree(c->d_bb_cdf); dfree(c->d_bb_cols); dfree(c->d_bb_cols_part); dfree(c->d_bb_cols_stat); dfree(c->d_bb_first); dfree(c->d_bbf_hier); dfree(c->d_bbf_table); dfree(c->d_bbf_q); dfree(c->d_bbf_strata); dfree(c->d_bbf_strata_top);
     dfree(c->d_gen_hier); dfree(c->d_gen_table); dfree(c->d_gen_q[0]); dfree(c->d_gen_q[1]); dfree(c->d_gen_ctrl);
     for (auto& ep : c->ev_used) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -2272,6 +2277,17 @@ static int columns_stats(cpprob_hip_ctx* c, const typename Col::value_t* d_x, si
     return 0;
 }
 // first_row[t] .. first_row[t + 1]: the records made in generation t's slots (h_gen[h] = the generation of record h, non-decreasing)
+static int pin_reserve(cpprob_hip_ctx* c, size_t bytes)
+{
+    if (bytes <= c->h_pin_cap) return 0;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_cap = 0; }
+    const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 16);
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), want, hipHostMallocDefault));
+    c->h_pin_cap = want;
+    return 0;
+}
+
 static int upload_first_rows(cpprob_hip_ctx* c, const int32_t* h_gen, int32_t H, int32_t T)
 {
     std::vector<int32_t> first((size_t)T + 1, 0);
@@ -2305,6 +2321,8 @@ static int lineage_stats(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t*
     const size_t part_doubles = (size_t)chunk * Col::kStats * (size_t)grid, stat_doubles = (size_t)chunk * Col::kStats;
     if (part_doubles > c->bb_cols_part) { dfree(c->d_bb_cols_part); HIP_TRY(c, hipMalloc(&c->d_bb_cols_part, part_doubles * sizeof(double))); c->bb_cols_part = part_doubles; }
     if (stat_doubles > c->bb_cols_stat) { dfree(c->d_bb_cols_stat); HIP_TRY(c, hipMalloc(&c->d_bb_cols_stat, stat_doubles * sizeof(double))); c->bb_cols_stat = stat_doubles; }
+    const size_t stats_bytes = (size_t)H * Col::kStats * sizeof(double), ride_off = (stats_bytes + sizeof(StepCtrl) + 15) / 16 * 16;
+    if (int rc = pin_reserve(c, ride_off + c->ride_bytes)) return rc;
     for (int h0 = 0; h0 < H; h0 += chunk) {
         const int nk = std::min(chunk, H - h0);
         LineageStatsArgs<Col> a{};
@@ -2313,12 +2331,17 @@ static int lineage_stats(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t*
         hipLaunchKernelGGL(lineage_stats_kernel<Col>, dim3(grid), dim3(kThreads), (size_t)kWaves * nk * Col::kStats * sizeof(double), c->stream, a);
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nk), dim3(kThreads), 0, c->stream, c->d_bb_cols_part, grid, nk, Col::kStats, 1, c->d_bb_ctrl, c->d_bb_cols_stat, 1);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(h_raw + (size_t)h0 * Col::kStats, c->d_bb_cols_stat, (size_t)nk * Col::kStats * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_pin + (size_t)h0 * Col::kStats * sizeof(double), c->d_bb_cols_stat, (size_t)nk * Col::kStats * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         if (h0 + chunk < H) HIP_TRY(c, hipStreamSynchronize(c->stream));     // (the scratch is reused by the next chunk)
     }
-    StepCtrl h{};
-    HIP_TRY(c, hipMemcpyAsync(&h, c->d_bb_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_pin + stats_bytes, c->d_bb_ctrl, sizeof(StepCtrl), hipMemcpyDeviceToHost, c->stream));
+    const bool riding = c->ride_bytes != 0;
+    if (riding) HIP_TRY(c, hipMemcpyAsync(c->h_pin + ride_off, c->ride_src, c->ride_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    StepCtrl h;
+    std::memcpy(h_raw, c->h_pin, stats_bytes);
+    std::memcpy(&h, c->h_pin + stats_bytes, sizeof h);
+    if (riding) { std::memcpy(c->ride_dst, c->h_pin + ride_off, c->ride_bytes); c->ride_src = nullptr; c->ride_dst = nullptr; c->ride_bytes = 0; }
     h_lse_ess[0] = h.M + std::log(h.W); h_lse_ess[1] = h.ess;
     return 0;
 }
@@ -2333,6 +2356,15 @@ static int lineage_args_ok(cpprob_hip_ctx* c, const void* d_anc, const void* d_r
 }
 
 extern "C" {
+
+int cpprob_hip_readback_with_next_result(cpprob_hip_ctx* c, const void* d_src, void* h_dst, size_t bytes)
+{
+    BB_PRELUDE(c);
+    if (bytes != 0 && (!d_src || !h_dst)) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (bytes > ((size_t)1 << 24)) return fail(c, CPPROB_HIP_EINVAL, "a read-back that rides a result's is a small one (<= 16 MiB)");
+    c->ride_src = bytes ? d_src : nullptr; c->ride_dst = bytes ? h_dst : nullptr; c->ride_bytes = bytes;
+    return 0;
+}
 
 int cpprob_hip_lineage_prepare(cpprob_hip_ctx* c, const int32_t* h_gen, int32_t H, int32_t T)
 {
@@ -2646,9 +2678,9 @@ __global__ __launch_bounds__(kWave) void generic_finish_kernel(FHier f, int T, d
 }
 
 // (re)lays the three-copy hierarchy out for populations of nb 256-particle blocks
-int ensure_generic(cpprob_hip_ctx* c, int nb)
+int ensure_generic(cpprob_hip_ctx* c, int nb, int block)
 {
-    if (nb != c->gen_nb || !c->d_gen_hier) {
+    if (nb != c->gen_nb || block != c->gen_block || !c->d_gen_hier) {
         size_t per_copy = 0, off[kHierMaxLevels] = {0, 0, 0};
         int nl = 0;
         HierTable t{};
@@ -2659,14 +2691,15 @@ int ensure_generic(cpprob_hip_ctx* c, int nb)
         }
         t.n_lev = nl;
         c->gen_q0_off = per_copy; c->gen_m0_off = per_copy + (size_t)nb; per_copy += 2 * (size_t)nb;
-        if ((size_t)nb > c->gen_cap_nb || !c->d_gen_hier) {
+        // (whole tiles, and one more: the step kernel's walk reads 1024-particle chunks that start at any block)
+        const size_t q_words = ((size_t)nb * (size_t)block + kTile - 1) / kTile * kTile + kTile;
+        if (3 * per_copy > c->gen_cap_hier || q_words > c->gen_cap_q || !c->d_gen_hier) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             dfree(c->d_gen_hier); dfree(c->d_gen_q[0]); dfree(c->d_gen_q[1]);
+            c->gen_cap_hier = 0; c->gen_cap_q = 0; c->gen_nb = 0;
             HIP_TRY(c, hipMalloc(&c->d_gen_hier, 3 * per_copy * sizeof(uint64_t)));
-            // (whole tiles, and one more: the step kernel's walk reads 1024-particle chunks that start at any block)
-            const size_t q_words = ((size_t)nb * kGenBlock + kTile - 1) / kTile * kTile + kTile;
             for (int k = 0; k < 2; ++k) { HIP_TRY(c, hipMalloc(&c->d_gen_q[k], q_words * sizeof(uint32_t))); HIP_TRY(c, hipMemsetAsync(c->d_gen_q[k], 0, q_words * sizeof(uint32_t), c->stream)); }
-            c->gen_cap_nb = (size_t)nb;
+            c->gen_cap_hier = 3 * per_copy; c->gen_cap_q = q_words;
         }
         for (int k = 0; k < 3; ++k)
             for (int l = 0; l < kHierMaxLevels; ++l) t.lvl[k][l] = c->d_gen_hier + (size_t)k * per_copy + off[l < nl ? l : 0];
@@ -2674,7 +2707,7 @@ int ensure_generic(cpprob_hip_ctx* c, int nb)
         if (!c->d_gen_ctrl) HIP_TRY(c, hipMalloc(&c->d_gen_ctrl, sizeof(GenericCtrlBlock)));
         HIP_TRY(c, hipMemcpyAsync(c->d_gen_table, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));               // (t is a local)
-        c->gen_table = t; c->gen_per_copy = per_copy; c->gen_nb = nb;
+        c->gen_table = t; c->gen_per_copy = per_copy; c->gen_nb = nb; c->gen_block = block;
         for (int l = 0; l < kHierMaxLevels; ++l) c->gen_off[l] = off[l];
     }
     return 0;
@@ -2694,14 +2727,14 @@ void generic_view(const cpprob_hip_ctx* c, int read, int next, int clear, FHier&
 }  // namespace
 extern "C" {
 
-int cpprob_hip_generic_begin(cpprob_hip_ctx* c, size_t n, cpprob_hip_generic_layout* out)
+static int generic_begin(cpprob_hip_ctx* c, size_t n, int block, cpprob_hip_generic_layout* out)
 {
-    BB_PRELUDE(c);
     if (!out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (block != kGenBlock && block != kTile) return fail(c, CPPROB_HIP_EINVAL, "the hierarchy's entries are blocks of 256 particles or tiles of 1024");
     if (n == 0 || n > (size_t)(1ull << 28)) return fail(c, CPPROB_HIP_EINVAL, "population size out of range (1 .. 2^28: the squares' 64-bit sum)");
-    if (n > (size_t)kCountsMaxTiles * kGenBlock) return fail(c, CPPROB_HIP_EINVAL, "population too large for the three-level mass hierarchy of 256-particle blocks (64^3 blocks)");
-    const int nb = (int)((n + kGenBlock - 1) / kGenBlock);
-    if (int rc = ensure_generic(c, nb)) return rc;
+    if (n > (size_t)kCountsMaxTiles * (size_t)block) return fail(c, CPPROB_HIP_EINVAL, "population too large for the three-level mass hierarchy (64^3 entries)");
+    const int nb = (int)((n + (size_t)block - 1) / (size_t)block);
+    if (int rc = ensure_generic(c, nb, block)) return rc;
     // a run starts from clean upper levels in every copy
     HIP_TRY(c, hipMemsetAsync(c->d_gen_hier, 0, 3 * c->gen_per_copy * sizeof(uint64_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_gen_ctrl, 0, sizeof(GenericCtrlBlock), c->stream));
@@ -2709,15 +2742,25 @@ int cpprob_hip_generic_begin(cpprob_hip_ctx* c, size_t n, cpprob_hip_generic_lay
     out->hier = c->d_gen_hier; out->per_copy = c->gen_per_copy;
     for (int l = 0; l < kHierMaxLevels; ++l) { out->lvl_off[l] = c->gen_off[l < c->gen_table.n_lev ? l : 0]; out->n_ent[l] = c->gen_table.n_ent[l]; }
     out->n_lev = c->gen_table.n_lev; out->q0_off = c->gen_q0_off; out->m0_off = c->gen_m0_off;
-    out->table = c->d_gen_table; out->q[0] = c->d_gen_q[0]; out->q[1] = c->d_gen_q[1]; out->ctrl = c->d_gen_ctrl; out->blocks = nb; out->block = kGenBlock;
+    out->table = c->d_gen_table; out->q[0] = c->d_gen_q[0]; out->q[1] = c->d_gen_q[1]; out->ctrl = c->d_gen_ctrl; out->blocks = nb; out->block = block;
     return 0;
+}
+int cpprob_hip_generic_begin(cpprob_hip_ctx* c, size_t n, cpprob_hip_generic_layout* out)
+{
+    BB_PRELUDE(c);
+    return generic_begin(c, n, kGenBlock, out);
+}
+int cpprob_hip_generic_begin_tiles(cpprob_hip_ctx* c, size_t n, cpprob_hip_generic_layout* out)
+{
+    BB_PRELUDE(c);
+    return generic_begin(c, n, kTile, out);
 }
 
 static int generic_exact_passes(cpprob_hip_ctx* c, int32_t t, const double* d_logw, size_t n, bool max_pass, bool mass_pass, int given, double ref)
 {
     if (!d_logw || t < 0) return fail(c, CPPROB_HIP_EINVAL, "bad argument");
     const int nb = (int)((n + kGenBlock - 1) / kGenBlock), nt = (int)((n + kTile - 1) / kTile);
-    if (nb != c->gen_nb || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
+    if (nb != c->gen_nb || c->gen_block != kGenBlock || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
     FHier f{};
     generic_view(c, t % 3, t % 3, (t + 1) % 3, f);
     if (max_pass) hipLaunchKernelGGL(generic_max_kernel, dim3(nt), dim3(kThreads), 0, c->stream, d_logw, (int64_t)n, f, nb);
@@ -2744,7 +2787,7 @@ int cpprob_hip_generic_totals(cpprob_hip_ctx* c, int32_t t, size_t n, uint64_t* 
 {
     BB_PRELUDE(c);
     if (!d_out3 || t < 0) return fail(c, CPPROB_HIP_EINVAL, "bad argument");
-    const int nb = (int)((n + kGenBlock - 1) / kGenBlock);
+    const int nb = (int)((n + (size_t)c->gen_block - 1) / (size_t)c->gen_block);
     if (nb != c->gen_nb || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
     FHier f{};
     generic_view(c, t % 3, t % 3, t % 3, f);
@@ -2757,7 +2800,7 @@ int cpprob_hip_generic_finish(cpprob_hip_ctx* c, int32_t T, size_t n, double gap
 {
     BB_PRELUDE(c);
     if (!d_ess || !d_resampled || !d_log_z || !d_flags || T < 1) return fail(c, CPPROB_HIP_EINVAL, "bad argument");
-    const int nb = (int)((n + kGenBlock - 1) / kGenBlock);
+    const int nb = (int)((n + (size_t)c->gen_block - 1) / (size_t)c->gen_block);
     if (nb != c->gen_nb || !c->d_gen_hier) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_generic_begin was not called for this population size");
     FHier f{};
     const int k = (T - 1) % 3;

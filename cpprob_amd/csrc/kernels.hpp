@@ -75,35 +75,7 @@ struct StepCtrl {
 
 enum { RS_SYSTEMATIC = 0, RS_STRATIFIED = 1, RS_PRECOMPUTED = 2 };
 
-// ---------------------------------------------------------------------------------------------
-// 4-wide accesses (arrays are padded to the tile: no tails)
-// ---------------------------------------------------------------------------------------------
-template <class T> struct Vec4;
-template <> struct Vec4<double> { using type = double __attribute__((ext_vector_type(4))); };
-template <> struct Vec4<int32_t> { using type = int __attribute__((ext_vector_type(4))); };
-template <> struct Vec4<int8_t> { using type = signed char __attribute__((ext_vector_type(4))); };
-template <> struct Vec4<uint32_t> { using type = unsigned int __attribute__((ext_vector_type(4))); };
-
-template <class T>
-__device__ __forceinline__ void load4(const T* __restrict__ p, int64_t i, T (&v)[kPPT])
-{
-#pragma unroll
-    for (int q = 0; q < kPPT; q += 4) {
-        const typename Vec4<T>::type x = *reinterpret_cast<const typename Vec4<T>::type*>(p + i + q);
-        v[q] = x[0]; v[q + 1] = x[1]; v[q + 2] = x[2]; v[q + 3] = x[3];
-    }
-}
-
-template <class T>
-__device__ __forceinline__ void store4(T* __restrict__ p, int64_t i, const T (&v)[kPPT])
-{
-#pragma unroll
-    for (int q = 0; q < kPPT; q += 4) {
-        typename Vec4<T>::type x;
-        x[0] = v[q]; x[1] = v[q + 1]; x[2] = v[q + 2]; x[3] = v[q + 3];
-        *reinterpret_cast<typename Vec4<T>::type*>(p + i + q) = x;
-    }
-}
+// (4-wide accesses load4 / store4: cpprob/detail/wave.hpp)
 
 // Rows of the particle store may be narrower than the type the model computes in (Model::store_t vs value_t: the HMM's
 // states 0..2 travel as one byte): converting forms of the 4-wide accesses.
@@ -513,16 +485,7 @@ template <class T> __device__ __forceinline__ void lane_prefix_sum(T (&w)[kPPT])
 #pragma unroll
     for (int k = 1; k < kPPT; ++k) w[k] += w[k - 1];
 }
-__device__ __forceinline__ void lane_prefix_max(int32_t (&v)[kPPT])
-{
-#pragma unroll
-    for (int k = 1; k < kPPT; ++k) v[k] = max(v[k], v[k - 1]);
-}
-template <class T> __device__ __forceinline__ void lane_fill(T (&v)[kPPT], T x)
-{
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) v[k] = x;
-}
+// (lane_prefix_max, lane_fill: cpprob/detail/wave.hpp)
 template <class T> __device__ __forceinline__ void lane_copy(T (&d)[kPPT], const T (&s)[kPPT])
 {
 #pragma unroll

@@ -26,111 +26,7 @@
 
 namespace cph {
 
-// (fixed-point weights, 64-bit wavefront scans, the mass hierarchy, search and decision: cpprob/detail/fixed_mass.hpp)
-template <int RS>
-struct FixedLdsT {
-    int32_t slot[RS == kFixMultinomial || RS == kFixMultinomialLiteral ? kPPT : kTile];          // scatter slots of the output tile
-    uint64_t scan[2][kWaves];     // per-wave totals of the in-tile scan, double-buffered across source tiles
-    int iscr[kWaves];
-    uint32_t ustrat[RS == kFixStratified ? kTile : 1];   // stratified: the 32-bit uniforms of the output tile's outputs
-    uint64_t mp[RS == kFixMultinomial ? kStrataTiles * kTile : 1];  // multinomial, strata form: the source tiles' prefix masses (per wavefront), side by side (or two in turn)
-    uint64_t wtot[RS == kFixMultinomial ? kStrataTiles : 1][kWaves]; // ... and their wavefronts' totals
-};
-using FixedLds = FixedLdsT<kFixSystematic>;
-
-// Stratified resampling: the uniforms of the kTile outputs that start at output id `uid_first` (= FixedCdf::uid0 + the tile's first
-// output), four per lane -- one Philox block when the id is a multiple of four.  Visible behind the caller's barrier.
-__device__ __forceinline__ void stratified_stage(FixedLdsT<kFixStratified>& L, uint64_t seed, uint64_t draw, uint64_t uid_first)
-{
-    uint32_t w[kPPT];
-    draw_words4(seed, uid_first + (uint64_t)threadIdx.x * kPPT, draw, w);
-    store4(L.ustrat, (int64_t)threadIdx.x * kPPT, w);
-}
-
-// The WALK (the whole workgroup): every source tile that owns outputs of this tile rebuilds its prefix masses (one scan), each
-// source with a non-empty range writes its index into the slot of its FIRST output, one prefix-max hands every output its
-// ancestor; -1 where the ancestor belongs to a shard that precedes this one.  q_m1 / q_0 / q_p1 = the weights of tiles guess-1,
-// guess, guess+1 fetched by the caller (have = false: none were).  Slots must hold -1 and be visible on entry.
-// Stratified: L.ustrat holds the outputs' uniforms (stratified_stage), and a boundary's place in the tile is F - gj_first + [u_F < H - F].
-using U4 = unsigned int __attribute__((ext_vector_type(4)));
-template <int RS = kFixSystematic>
-__device__ __forceinline__ void fixed_walk(const FixedCdf& fc, const uint32_t* __restrict__ qprev, int64_t n, int nb, bool last_shard, double gj_first,
-                                           int n_out, const FLocated& loc, int guess, bool have, U4 q_m1, U4 q_0, U4 q_p1, int32_t (&anc)[kPPT], FixedLdsT<RS>& L)
-{
-    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const double gj_last = gj_first + (double)(n_out - 1);
-    int c = __builtin_amdgcn_readfirstlane(loc.c), c_last = __builtin_amdgcn_readfirstlane(loc.c_last);
-    uint64_t P = loc.P;
-    auto load_q = [&](int cc) -> U4 {
-        if (have && cc == guess) return q_0;
-        if (have && cc == guess - 1) return q_m1;
-        if (have && cc == guess + 1) return q_p1;
-        U4 z = {0u, 0u, 0u, 0u};
-        return cc < nb ? *reinterpret_cast<const U4*>(qprev + (int64_t)cc * kTile + (int64_t)tid * kPPT) : z;
-    };
-    auto place = [&](double g) -> int { return (int)fmin(fmax(g - gj_first, 0.0), (double)kTile); };      // exact: integers
-    // the place, in this output tile, of the first output the sources beyond inclusive mass C own
-    auto place_of = [&](uint64_t C) -> int {
-        if constexpr (RS == kFixStratified) {
-            const double H = fc.h(C), F = floor(H), d = F - gj_first;
-            if (!(d >= 0.0)) return 0;
-            if (d >= (double)kTile) return kTile;
-            const int i = (int)d;
-            return i + (u01_32(L.ustrat[i]) < H - F ? 1 : 0);
-        } else return place(fc.g(C));
-    };
-    U4 raw = load_q(c);
-    int it = 0;
-    while (c < nb && c <= c_last) {
-        // (wave-uniform values -- the branches are made scalar so that the barrier inside the loop sits in uniform control flow)
-        if (c_last >= nb && __builtin_amdgcn_readfirstlane(fc.template first<RS>(P) > gj_last ? 1 : 0)) break;      // the last tile is not known from the probe
-        const U4 raw_next = c < c_last ? load_q(c + 1) : U4{0u, 0u, 0u, 0u};
-        const bool edge = c == nb - 1;
-        const int nvt = edge ? (int)(n - (int64_t)c * kTile) : kTile;   // valid particles of this tile (padding slots weigh 0)
-        const int vb = tid * kPPT;
-        uint64_t pre[kPPT];
-        uint64_t run = 0;
-#pragma unroll
-        for (int k = 0; k < kPPT; ++k) { run += (uint64_t)raw[k]; pre[k] = run; }
-        const uint64_t incl = wave_incl_scan_u34(run);                 // (four 32-bit weights: below 2^34)
-        if (lane == kWave - 1) L.scan[it & 1][wv] = incl;
-        __syncthreads();
-        uint64_t off = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) { const uint64_t s = L.scan[it & 1][w]; if (w < wv) off += s; tot += s; }
-        const uint64_t excl = P + off + incl - run;                     // mass before this lane's first particle
-        const int src0 = c * kTile + vb;
-        const int p_all = (edge && last_shard) ? place(fc.n_pop) : 0;
-        int p_prev = place_of(excl);
-#pragma unroll
-        for (int k = 0; k < kPPT; ++k) {
-            int p = place_of(excl + pre[k]);
-            if (edge && last_shard && vb + k + 1 == nvt) p = p_all;      // the population's last source owns the rest
-            if (edge && vb + k + 1 > nvt) p = p_prev;                   // padding slots own nothing
-            if (p > p_prev) { L.slot[p_prev] = src0 + k; p_prev = p; }
-        }
-        P += tot;
-        ++it;
-        raw = raw_next;
-        ++c;
-    }
-    __syncthreads();
-    // inclusive prefix-max over the slots
-    int32_t v[kPPT];
-    load4(L.slot, (int64_t)tid * kPPT, v);
-    lane_prefix_max(v);
-    int32_t incl = wave_incl_max_i32(v[kPPT - 1]);
-    if (lane == kWave - 1) L.iscr[wv] = incl;
-    int32_t excl = dpp_or_i32<0x138 /* wave_shr:1 */>(incl, -1);
-    if (lane == 0) excl = -1;
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w)
-        if (w < wv) excl = max(excl, L.iscr[w]);
-#pragma unroll
-    for (int k = 0; k < kPPT; ++k) anc[k] = max(v[k], excl);
-}
-
+// (fixed-point weights, 64-bit wavefront scans, the mass hierarchy, search, walk and decision: cpprob/detail/fixed_mass.hpp)
 // Both parts in every wavefront (the exchange scope's packing, whose output tiles sit anywhere in the shard).  Stratified: the
 // outputs' uniforms are staged here first (behind a barrier of its own).
 template <int RS = kFixSystematic>

@@ -106,7 +106,8 @@ struct LaunchArgs {
     const uint64_t* carry_in; uint64_t* carry_out;
     uint64_t pid0;                 // global id of lane 0's particle (shards of one population draw from the population's streams)
     uint32_t lane_block;           // lanes per workgroup: kLaneBlock or kStepBlock (the lanes' LDS state is laid out by it)
-    uint32_t fused;                // model_step_kernel: the step's observe quantises the weight and publishes the tile's mass before it ends the wavefront
+    uint32_t fused;                // 1, model_step_kernel: the step's observe quantises the weight and publishes the tile's mass before it ends the wavefront;
+                                   // 2 (kFusedQuad), model_step_kernel_quad: the step's observe ends the CALL (every later statement is dead), the kernel goes on
     FusedStep fs;
     ShardArgs sh;
 };
@@ -119,6 +120,7 @@ __device__ inline LaunchArgsPtr launch_args() { return (LaunchArgsPtr)__builtin_
 //   [ 0, 16B)  WinRec  windowed replay: four words per lane (below), a statement reads two of them
 //   [16B, 24B) log_w   the step's incremental log-weight          [24B, 32B) carried  the log-weight the particle brought along
 //   [32B, 36B) src     the lane's ancestor (its own index where the previous step did not resample)
+//   [36B, 40B) pid     quad step only (model_step_kernel_quad): the particle the lane's CURRENT call of the model body runs
 //   [36B, 64B) full replay: n_sample, n_observe, n_pred_real, n_pred_int, n_recorded, n_stored, done
 //   [64B, ..)  full replay: per wavefront, the lanes that carry a particle
 // Windowed replay (the model passed the Markov probe: statement counts do not depend on sampled values): every lane of a
@@ -143,7 +145,7 @@ __device__ inline char* lane_lds()
     extern __shared__ __attribute__((aligned(16))) char cpprob_lane_lds[];
     return cpprob_lane_lds;
 }
-__host__ __device__ inline size_t lane_lds_bytes(uint32_t lanes, bool windowed_only) { return windowed_only ? (size_t)36 * lanes : (size_t)64 * lanes + lanes / 8 + 8; }
+__host__ __device__ inline size_t lane_lds_bytes(uint32_t lanes, bool windowed_only, bool quad = false) { return windowed_only ? (size_t)(quad ? 40 : 36) * lanes : (size_t)64 * lanes + lanes / 8 + 8; }
 struct LaneState {                                   // (pointers to this lane's slots: address arithmetic on one scalar, B)
     double* log_w; double* carried; int32_t* src;
     uint32_t *n_sample, *n_observe, *n_pred_real, *n_pred_int, *n_recorded, *n_stored, *done;
@@ -158,6 +160,8 @@ __device__ inline WinRec win_rec()
 __device__ inline double& lane_log_w() { return reinterpret_cast<double*>(lane_lds() + (size_t)16 * launch_args()->lane_block)[threadIdx.x]; }
 __device__ inline double& lane_carried() { return reinterpret_cast<double*>(lane_lds() + (size_t)24 * launch_args()->lane_block)[threadIdx.x]; }
 __device__ inline int32_t& lane_src() { return reinterpret_cast<int32_t*>(lane_lds() + (size_t)32 * launch_args()->lane_block)[threadIdx.x]; }
+__device__ inline int32_t& lane_pid() { return reinterpret_cast<int32_t*>(lane_lds() + (size_t)36 * launch_args()->lane_block)[threadIdx.x]; }
+constexpr uint32_t kFusedQuad = 2u;          // LaunchArgs::fused of model_step_kernel_quad
 __device__ __forceinline__ LaneState lane_state()
 {
     const size_t B = launch_args()->lane_block;
@@ -176,6 +180,7 @@ __device__ __forceinline__ LaneState lane_state()
 __device__ __forceinline__ int64_t lane_index()
 {
     LaunchArgsPtr A = launch_args();
+    if (A->fused == kFusedQuad) return (int64_t)lane_pid();           // (a lane runs the body for four particles, one after the other)
     const int64_t i = (int64_t)blockIdx.x * A->lane_block + threadIdx.x;
     return (A->fused && i >= A->n) ? A->n - 1 : i;
 }
@@ -647,6 +652,167 @@ __device__ __forceinline__ void finish_step()
     if (launch_args()->fused) step_epilogue(); else finish_lane();
 }
 
+// ---- the QUAD step (model_step_kernel_quad, cpprob/gpu.hpp): the model body for FOUR particles a lane behind ONE ancestor search ----
+// Geometry of the library's fused step (csrc/step_fixed.hpp): a workgroup of 256 lanes owns a 1024-particle TILE -- one entry of the mass
+// hierarchy, one search (cpprob/detail/fixed_mass.hpp: fixed_locate), one walk over the source tiles with four sources a lane
+// (fixed_walk), one set of wavefront reductions and one publish -- and runs the model body four times: pass p of lane l runs particle
+// tile * 1024 + 256 p + l, so that a pass's loads and stores (carried windows, predict columns, weights) are the contiguous rows they
+// are in model_step_kernel.  What a pass leaves behind -- its integer weight, and the tile's running {mass, squares, maximum} -- rides
+// in registers across the next call; the step's observe statement ends the CALL, not the wavefront: the rest of the body runs as dead
+// statements (observe_impl), which is what this form pays for sharing the prologue: T - 1 dead iterations a call whatever the step.
+struct QuadFound { cph::FLocated loc; double inv, ref; int resample; };
+struct QuadLds {
+    cph::FixedLds walk;                          // the tile's 1024 scatter slots -> ancestors, the walk's scan words
+    QuadFound found;
+    uint64_t red[3 * kStepWaves];
+};
+__device__ __forceinline__ QuadLds& quad_lds()
+{
+    __shared__ __attribute__((aligned(16))) QuadLds s_quad;
+    return s_quad;
+}
+struct QuadStep {                                // a lane's registers across the four calls
+    uint64_t s_l, q_l;                           // mass and squares of the passes so far
+    double m_l;                                  // their largest log-weight
+    double ref;                                  // R_t
+    int64_t i_raw;                               // the current pass's slot (may lie beyond the population)
+    bool resample;
+};
+constexpr int kQuadPasses = cph::kPPT;
+
+// Prologue: generation t-1's decision and books (first wavefront), the tile's ancestors into the slots.
+__device__ __forceinline__ void quad_prologue(QuadStep& qs)
+{
+    using namespace cph;
+    LaunchArgsPtr A = launch_args();
+    QuadLds& L = quad_lds();
+    const int tid = threadIdx.x, wv = tid >> 6;
+    const int nb = A->fs.nb, bid = (int)blockIdx.x, t = A->fs.t;
+    const int64_t n = A->n;
+    const FHier f = step_hier();
+    qs.s_l = 0; qs.q_l = 0; qs.m_l = -INFINITY; qs.ref = A->fs.bound; qs.resample = false; qs.i_raw = 0;
+    if (t == 0) {
+        if (bid == 0 && tid == 0) A->fs.ctrl->ref_cur = A->fs.bound;   // R_0 = B_0
+        return;
+    }
+    // everything the prologue reads is addressed by the launch geometry: the weights of the tile's own source tile and its neighbours,
+    // the generation's totals and the probe's words, in one round trip
+    const int64_t g0 = (int64_t)bid * kTile + (int64_t)tid * kPPT;
+    const U4 zero = {0u, 0u, 0u, 0u};
+    U4 q_0 = *reinterpret_cast<const U4*>(A->fs.q_prev + g0);
+    U4 q_m1 = *reinterpret_cast<const U4*>(A->fs.q_prev + (bid > 0 ? g0 - kTile : g0));
+    U4 q_p1 = *reinterpret_cast<const U4*>(A->fs.q_prev + (bid + 1 < nb ? g0 + kTile : g0));
+    FTotWords tw{};
+    ProbeWords pw0{};
+    if (wv == 0) { ftot_fetch(f, tw); probe_fetch(f.h, bid, nb, pw0); }
+    if (bid == 0) q_m1 = zero;
+    if (bid + 1 >= nb) q_p1 = zero;
+    int32_t neg[kPPT];
+    lane_fill(neg, (int32_t)-1);
+    store4(L.walk.slot, (int64_t)tid * kPPT, neg);
+    const int64_t rem = n - (int64_t)bid * kTile;
+    const int n_out = rem < kTile ? (int)rem : kTile;
+    const double gj_first = (double)((uint64_t)bid * kTile);
+    FixedCdf fc;
+    fc.u0 = A->fs.u0; fc.n_pop = A->fs.n_pop; fc.base = 0; fc.inv = 0.0; fc.seed = 0; fc.draw = 0; fc.uid0 = 0;
+    if (wv == 0) {
+        // (as step_prologue: where every step resamples the decision needs the generation's mass alone)
+        FTot tot;
+        FixedDecision d;
+        if (A->fs.may_carry || bid == 0) {
+            tot = ftot_sum(f, tw);
+            d = fixed_decide(tot.S, tot.Q, A->fs.n_pop, A->fs.ess_frac, true);
+        } else {
+            tot.S = wave_sum_u64((tid < f.h.top_n ? tw.s : 0ull) & kMassMask); tot.Q = 0; tot.M = 0.0;
+            d.resample = tot.S > 0; d.inv = A->fs.n_pop / u64_to_double(tot.S); d.W = 0.0; d.Qd = 0.0; d.ess = 0.0;
+        }
+        fc.inv = d.inv;
+        const double r_t = fixed_reference(d.resample, tot.M, A->fs.bound);
+        if (bid == 0 && tid == 0) {
+            StepCtrl2* c = A->fs.ctrl;
+            const double ref_prev = c->ref_cur;
+            const double gap = d.W > 0.0 ? ref_prev - tot.M : 1e300;
+            c->gap_max = t == 1 ? gap : fmax(c->gap_max, gap);
+            if (gap < 0.0) *A->overflow = 4;
+            else if (gap > A->fs.gap_limit && *A->overflow == 0) *A->overflow = 5;
+            A->fs.ess[t - 1] = d.ess;
+            A->fs.resampled[t - 1] = d.resample ? 1 : 0;
+            double lz = t == 1 ? 0.0 : *A->fs.log_z;
+            if (d.resample) lz += ref_prev + log(d.W / A->fs.n_pop);
+            *A->fs.log_z = lz;
+            c->ref_cur = r_t;
+        }
+        FLocated loc{0, 0, 0};
+        if (d.resample) loc = fixed_locate<kFixSystematic>(f, fc, nb, gj_first, n_out, bid, &pw0);
+        if (tid == 0) { L.found.loc = loc; L.found.inv = d.inv; L.found.ref = r_t; L.found.resample = d.resample ? 1 : 0; }
+    }
+    __syncthreads();                                                   // slots reset, search results in place
+    qs.resample = L.found.resample != 0;
+    qs.ref = L.found.ref;
+    if (qs.resample) {
+        fc.inv = L.found.inv;
+        int32_t anc[kPPT];
+        fixed_walk<kFixSystematic>(fc, A->fs.q_prev, n, nb, true, gj_first, n_out, L.found.loc, bid, true, q_m1, q_0, q_p1, anc, L.walk);
+#pragma unroll
+        for (int k = 0; k < kPPT; ++k) anc[k] = max(anc[k], 0);       // padding outputs of the last tile
+        // (every lane read its four slots in front of the walk's last barrier: they now hold the ancestors, for the passes to pick up)
+        store4(L.walk.slot, (int64_t)tid * kPPT, anc);
+        __syncthreads();
+    }
+}
+
+// Pass p of a lane: which particle, its ancestor and carried log-weight; the lane's statement record starts over.
+__device__ __forceinline__ void quad_begin(QuadStep& qs, int p)
+{
+    using namespace cph;
+    LaunchArgsPtr A = launch_args();
+    const int tid = threadIdx.x, bid = (int)blockIdx.x, t = A->fs.t;
+    const int64_t n = A->n;
+    const int64_t base = (int64_t)bid * kTile;
+    qs.i_raw = base + (int64_t)p * kStepBlock + tid;
+    // (slots beyond the population redo its last particle -- same id, same variates, same stores -- and weigh nothing)
+    const int64_t i = qs.i_raw < n ? qs.i_raw : n - 1;
+    int32_t anc = (int32_t)i;
+    double lw_carry = 0.0;
+    if (qs.resample) {
+        anc = quad_lds().walk.slot[(int)(i - base)];
+        if (qs.i_raw < n) A->fs.anc_row[i] = anc;
+    } else if (t > 0 && A->fs.may_carry) lw_carry = A->logw_in[i];
+    lane_pid() = (int32_t)i;
+    begin_lane(anc, 0u, lw_carry);
+}
+
+// ... and what it leaves: the observe's weight as an integer, in memory and in the tile's running totals.
+__device__ __forceinline__ void quad_end(QuadStep& qs)
+{
+    LaunchArgsPtr A = launch_args();
+    const bool valid = qs.i_raw < A->n;
+    double lw = lane_carried() + lane_log_w();
+    if (!valid) lw = -INFINITY;
+    const uint32_t q = cph::fix_weight(lw, qs.ref);
+    qs.s_l += q; qs.q_l += cph::fix_square(q); qs.m_l = fmax(qs.m_l, lw);
+    A->fs.q_next[qs.i_raw] = q;                                        // (the weight arrays are padded to whole tiles)
+    if (valid && (A->fs.may_carry || A->fs.t + 1 == A->fs.T)) A->logw_out[qs.i_raw] = lw;
+}
+
+// Epilogue: the tile's totals as its entry of generation t's hierarchy.
+__device__ __forceinline__ void quad_epilogue(const QuadStep& qs)
+{
+    using namespace cph;
+    LaunchArgsPtr A = launch_args();
+    QuadLds& L = quad_lds();
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t s_w = wave_sum_u34(qs.s_l), q_w = wave_sum_u34(qs.q_l), m_w = wave_max_key(dkey(qs.m_l));      // (sums of four 32-bit terms)
+    if (lane == 0) { L.red[wv] = s_w; L.red[kStepWaves + wv] = q_w; L.red[2 * kStepWaves + wv] = m_w; }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t St = 0, Qt = 0, Mk = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kStepWaves; ++w2) { St += L.red[w2]; Qt += L.red[kStepWaves + w2]; Mk = umax64(Mk, L.red[2 * kStepWaves + w2]); }
+        fhier_publish(step_hier(), (int)blockIdx.x, A->fs.nb, St, Qt, Mk);
+    }
+}
+
 template <class Distribution>
 __device__ inline typename std::decay_t<Distribution>::result_type sample_impl(Distribution& distr)
 {
@@ -736,7 +902,15 @@ __device__ inline void observe_impl(Distribution& distr, const X& x)
                 //  step's live observe sees whatever went apart before it)
                 if (__ballot(own != w || rec.n_sample != wave_uniform(rec.n_sample)) != 0ull && A->overflow) *A->overflow = 3;
                 lane_log_w() += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
-                if (m + 1 == (lim >> 16)) { finish_step(); asm volatile("s_endpgm" ::: "memory"); }      // every lane of the wavefront is here
+                if (m + 1 == (lim >> 16)) {                                          // every lane of the wavefront is here
+                    if (A->fused == kFusedQuad) {
+                        // (the lane has more particles to run: every later statement of THIS call is made a dead one -- samples "older than the
+                        //  window", observes and predicts "of an earlier step" -- and the body returns to the kernel's loop)
+                        rec.lim_sample = 0xffffffffu; rec.lim_other = lim_own | 0xfffu;
+                        return;
+                    }
+                    finish_step(); __builtin_amdgcn_endpgm();          // (uniform control flow: scalar branches all the way here; the builtin, unlike an asm statement with a memory clobber, lets the statement counters live in registers)
+                }
             }
             return;
         }

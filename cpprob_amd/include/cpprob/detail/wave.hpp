@@ -189,4 +189,46 @@ __device__ __forceinline__ double block_sum_and_excl_scan(double& sum_v, double 
     return off + excl;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4-wide accesses (arrays are padded to the tile: no tails)
+// ---------------------------------------------------------------------------------------------
+template <class T> struct Vec4;
+template <> struct Vec4<double> { using type = double __attribute__((ext_vector_type(4))); };
+template <> struct Vec4<int32_t> { using type = int __attribute__((ext_vector_type(4))); };
+template <> struct Vec4<int8_t> { using type = signed char __attribute__((ext_vector_type(4))); };
+template <> struct Vec4<uint32_t> { using type = unsigned int __attribute__((ext_vector_type(4))); };
+
+template <class T>
+__device__ __forceinline__ void load4(const T* __restrict__ p, int64_t i, T (&v)[kPPT])
+{
+#pragma unroll
+    for (int q = 0; q < kPPT; q += 4) {
+        const typename Vec4<T>::type x = *reinterpret_cast<const typename Vec4<T>::type*>(p + i + q);
+        v[q] = x[0]; v[q + 1] = x[1]; v[q + 2] = x[2]; v[q + 3] = x[3];
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void store4(T* __restrict__ p, int64_t i, const T (&v)[kPPT])
+{
+#pragma unroll
+    for (int q = 0; q < kPPT; q += 4) {
+        typename Vec4<T>::type x;
+        x[0] = v[q]; x[1] = v[q + 1]; x[2] = v[q + 2]; x[3] = v[q + 3];
+        *reinterpret_cast<typename Vec4<T>::type*>(p + i + q) = x;
+    }
+}
+
+// in-lane helpers over the lane's kPPT values
+__device__ __forceinline__ void lane_prefix_max(int32_t (&v)[kPPT])
+{
+#pragma unroll
+    for (int k = 1; k < kPPT; ++k) v[k] = max(v[k], v[k - 1]);
+}
+template <class T> __device__ __forceinline__ void lane_fill(T (&v)[kPPT], T x)
+{
+#pragma unroll
+    for (int k = 0; k < kPPT; ++k) v[k] = x;
+}
+
 }  // namespace cph

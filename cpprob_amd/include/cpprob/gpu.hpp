@@ -130,6 +130,29 @@ __device__ __forceinline__ void model_step_body(const Tuple* __restrict__ observ
     device::step_epilogue();                                      // the run's last step: the body ran to completion
 }
 
+// The QUAD step (cpprob/detail/device_trace.hpp: quad_prologue ...): a workgroup owns a 1024-particle tile as the library's fused
+// kernels do -- ONE search, one walk with four sources a lane, one publish -- and every lane runs the model body four times.
+template <class Caller, class Tuple>
+__global__ __launch_bounds__(device::kStepBlock) void model_step_kernel_quad(ModelKernelArgs a, const Tuple* __restrict__ observes)
+{
+    (void)a;
+    {
+        const uint32_t fused = device::launch_args()->fused, win = device::launch_args()->windowed, lanes = device::launch_args()->lane_block;
+        __builtin_assume(fused == device::kFusedQuad); __builtin_assume(win == 1u); __builtin_assume(lanes == (uint32_t)device::kStepBlock);
+        const int32_t world = device::launch_args()->sh.world;
+        __builtin_assume(world == 0);
+    }
+    device::QuadStep qs;
+    device::quad_prologue(qs);
+#pragma unroll 1
+    for (int p = 0; p < device::kQuadPasses; ++p) {
+        device::quad_begin(qs, p);
+        Caller::call(*observes);
+        device::quad_end(qs);
+    }
+    device::quad_epilogue(qs);
+}
+
 // which build of the step kernel this model runs: the eight-wavefront build unless it spills more than a handful of registers
 template <class Caller, class Tuple>
 bool step_kernel_full()
@@ -231,7 +254,8 @@ private:
 enum class StepForm {
     unfused,        // model launch + cpprob_hip_smc_bookkeep(_fixed): full replay, the other resamplers, the Markov pilot
     fused_bounded,  // model_step_kernel, fixed-point weights against the dry run's per-observe bounds: ONE launch per observe
-    fused_exact     // model_step_kernel + cpprob_hip_generic_quantize (maximum pass, masses) against the generation's exact maximum: three launches per observe
+    fused_exact,    // model_step_kernel + cpprob_hip_generic_quantize (maximum pass, masses) against the generation's exact maximum: three launches per observe
+    fused_quad      // model_step_kernel_quad: fused_bounded with four particles a lane behind one ancestor search (1024-particle tiles)
 };
 constexpr double kFixGapLimit = 6.0;            // nats a generation's heaviest particle may sit below its reference (csrc/step_fixed.hpp: the same contract)
 
@@ -280,6 +304,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     const uint32_t w = (uint32_t)std::max(1, st.window);
     if (!(windowed && opt.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && n <= (std::size_t(64) * 64 * 64 * device::kStepBlock) && T > 0)) form = StepForm::unfused;
     const bool fused = form != StepForm::unfused;
+    const bool quad = form == StepForm::fused_quad;
 
     // what the host reads when the run is over, side by side -- one copy: [T] step ESS, log evidence | [T] resampling decisions, flag word
     const size_t tail_doubles = (size_t)T + 1, tail_ints = (size_t)T + 1, tail_bytes = tail_doubles * sizeof(double) + tail_ints * sizeof(int32_t);
@@ -333,7 +358,9 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     };
     cpprob_hip_generic_layout lay{};
     if (fused) {
-        ctx.check(cpprob_hip_generic_begin(ctx.get(), n, &lay), "cpprob_hip_generic_begin");      // (sizes at the first call; clears are stream-ordered)
+        // (sizes at the first call; clears are stream-ordered)
+        if (quad) ctx.check(cpprob_hip_generic_begin_tiles(ctx.get(), n, &lay), "cpprob_hip_generic_begin_tiles");
+        else ctx.check(cpprob_hip_generic_begin(ctx.get(), n, &lay), "cpprob_hip_generic_begin");
     } else if (smc && T > 0) {
         // The context sizes its own scratch (hierarchy of sums, integer weights, normalisation partials) at the first call that needs it:
         // one bookkeeping pass and one normalisation over zeroed log-weights before the clock starts -- allocation, like the buffers above.
@@ -373,10 +400,11 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         uint64_t* carry[2] = {d_c0, d_c1};
         a.windowed = 1; a.win = w;
         const dim3 sgrid((unsigned)((n + device::kStepBlock - 1) / device::kStepBlock)), sblock(device::kStepBlock);
-        const size_t step_lds = device::lane_lds_bytes(device::kStepBlock, true);
-        const bool step_full = fused && step_kernel_full<Caller, Tuple>();
+        const dim3 qgrid((unsigned)((n + cph::kTile - 1) / cph::kTile));
+        const size_t step_lds = device::lane_lds_bytes(device::kStepBlock, true, quad);
+        const bool step_full = fused && !quad && step_kernel_full<Caller, Tuple>();
         if (fused) {
-            a.lane_block = device::kStepBlock; a.fused = 1;
+            a.lane_block = device::kStepBlock; a.fused = quad ? device::kFusedQuad : 1u;
             a.fs.ess_frac = opt.ess_threshold; a.fs.n_pop = (double)n; a.fs.T = T; a.fs.nb = lay.blocks;
             a.fs.may_carry = opt.ess_threshold > 1.0 ? 0 : 1; a.fs.exact_ref = form == StepForm::fused_exact ? 1 : 0;
             a.fs.ctrl = static_cast<device::StepCtrl2*>(lay.ctrl); a.fs.ess = d_ess_p; a.fs.resampled = d_res_p; a.fs.log_z = d_logz_p;
@@ -396,9 +424,10 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
                 a.fs.f = fused_view(lay, (t + 2) % 3, t % 3, (t + 1) % 3);
                 a.fs.q_prev = lay.q[(t + 1) & 1]; a.fs.q_next = lay.q[t & 1];
                 a.fs.u0 = cpprob_hip_systematic_offset(opt.seed, (uint64_t)t);
-                a.fs.bound = form == StepForm::fused_bounded ? st.observe_bound[(size_t)t] : 0.0;
+                a.fs.bound = (form == StepForm::fused_bounded || quad) ? st.observe_bound[(size_t)t] : 0.0;
                 a.fs.t = t; a.fs.anc_row = d_anc_all + (size_t)t * n;
-                if (step_full) hipLaunchKernelGGL((model_step_kernel_full<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+                if (quad) hipLaunchKernelGGL((model_step_kernel_quad<Caller, Tuple>), qgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+                else if (step_full) hipLaunchKernelGGL((model_step_kernel_full<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
                 else hipLaunchKernelGGL((model_step_kernel<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
                 hip_check(hipGetLastError(), "model_step_kernel");
                 cur ^= 1;
@@ -416,15 +445,23 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         // traces: hit h was recorded in the slots of generation step(h); follow every final particle's lineage back to it.  When
         // nobody asked for the traces themselves, StatsPrinter's numbers are taken on that walk (cpprob_hip_lineage_moments / _hist).
         auto gens = [&](const std::vector<int>& steps) { std::vector<int32_t> g; for (int s2 : steps) g.push_back(std::min(s2, T - 1)); return g; };
+        bool tail_read = false;
         if (!store) {
+            // (the run's tail -- step ESS, evidence, decisions, flag word -- rides the LAST read-out call's result: one stream synchronisation)
+            auto ride_tail = [&]() {
+                ctx.check(cpprob_hip_readback_with_next_result(ctx.get(), d_tail, h_tail.data(), tail_bytes), "cpprob_hip_readback_with_next_result");
+                tail_read = true;
+            };
             if (n_real) {
                 const std::vector<int32_t> g = gens(st.real_row_step);
                 walk_real.resize(4 * n_real);
+                if (!n_int) ride_tail();
                 ctx.check(cpprob_hip_lineage_moments(ctx.get(), d_anc_all, d_res_p, T, n, d_real_gen, g.data(), (int32_t)g.size(), logw[cur], walk_real.data()), "cpprob_hip_lineage_moments");
             }
             if (n_int) {
                 const std::vector<int32_t> g = gens(st.int_hit_step);
                 walk_int.resize(8 * n_int);
+                ride_tail();
                 ctx.check(cpprob_hip_lineage_hist(ctx.get(), d_anc_all, d_res_p, T, n, d_int_gen, g.data(), (int32_t)g.size(), logw[cur], 8, walk_int.data(), walk_lse_ess), "cpprob_hip_lineage_hist");
             }
             stats_on_walk = true;
@@ -438,7 +475,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
             ctx.check(cpprob_hip_lineage_gather(ctx.get(), d_anc_all, d_res_p, T, n, d_int_gen, 1, g.data(), (int32_t)g.size(), d_int), "cpprob_hip_lineage_gather");
         }
         }
-        read_tail();
+        if (!tail_read) read_tail();
         res.step_ess.assign(h_ess_p, h_ess_p + T);
         log_z = h_ess_p[T];
         for (int t = 0; t < T; ++t) n_resampled += h_res_p[t];
@@ -468,7 +505,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         for (int t = 0; t < T; ++t) n_resampled += h_res_p[t];
         smc_log_z_done = true;
     }
-    res.step_form = fused ? (form == StepForm::fused_exact ? 2 : 1) : 0;
+    res.step_form = fused ? (form == StepForm::fused_exact ? 2 : (quad ? 3 : 1)) : 0;
     fill_predict_names(res, st);
     double lse_ess[2] = {0.0, 0.0};
     bool have_norm = false;
@@ -570,7 +607,7 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     }
     StepForm form = st.bounds_fixed ? StepForm::fused_bounded : StepForm::fused_exact;
     if (opt.step_form_override >= 0) {
-        if (opt.step_form_override > 2) throw std::invalid_argument("cpprob::gpu::Options::step_form_override: 0 (unfused), 1 (bounded) or 2 (exact maximum)");
+        if (opt.step_form_override > 3) throw std::invalid_argument("cpprob::gpu::Options::step_form_override: 0 (unfused), 1 (bounded), 2 (exact maximum) or 3 (bounded, four particles a lane)");
         form = static_cast<StepForm>(opt.step_form_override);
     }
     bool rows_exhausted = false;
@@ -581,7 +618,7 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
         else if (rc == 4) {
             // a generation did not fit its reference: bounded -> exact maxima -> the three-launch form (its own maximum pass); a
             // generation that has no mass in ANY form (every likelihood -inf) is the model's, not a form's
-            if (form == StepForm::fused_bounded) form = StepForm::fused_exact;
+            if (form == StepForm::fused_bounded || form == StepForm::fused_quad) form = StepForm::fused_exact;
             else if (form == StepForm::fused_exact) form = StepForm::unfused;
             else throw std::runtime_error("cpprob::inference(smc): a generation carries no mass (every particle's likelihood is zero at some observe statement)");
         }

@@ -488,9 +488,13 @@ typedef struct cpprob_hip_generic_layout {
     uint32_t* q[2];            /* integer weights, by the step's parity: padded to whole 1024-particle tiles, and one tile more */
     void* ctrl;                /* device_trace.hpp: StepCtrl2 */
     int32_t blocks;
-    int32_t block;             /* particles per hierarchy entry: 256 */
+    int32_t block;             /* particles per hierarchy entry: 256 (cpprob_hip_generic_begin) or 1024 (cpprob_hip_generic_begin_tiles) */
 } cpprob_hip_generic_layout;
 int cpprob_hip_generic_begin(cpprob_hip_ctx* ctx, size_t n, cpprob_hip_generic_layout* out);
+/* The same with one hierarchy entry per 1024-particle TILE: the layout of model_step_kernel_quad, whose workgroups run the model body
+ * for four particles a lane behind ONE ancestor search (cpprob/gpu.hpp).  n <= 64^3 * 1024 (and 2^28).  The exact-reference passes
+ * below work on 256-particle blocks only. */
+int cpprob_hip_generic_begin_tiles(cpprob_hip_ctx* ctx, size_t n, cpprob_hip_generic_layout* out);
 /* Exact-reference form (no host-known bound of a step's log-likelihood): the step's launch stored the log-weights only; two short
  * launches find the generation's exact maximum, quantise d_logw[0..n) against it into q[t & 1] and publish maxima and masses into
  * copy t % 3. */
@@ -518,6 +522,11 @@ int cpprob_hip_lineage_gather(cpprob_hip_ctx* ctx, const int32_t* d_anc, const i
  * _hist_columns against d_logw (the FINAL generation's log-weights, n of them) returns, bit for bit, without the traces' round trip through
  * memory (StatsPrinter's numbers, reference stats_printer.hpp:68-120, when nobody asked for the traces themselves).  h_out4: [H][4] =
  * {mean, variance, logsumexp, ess}; h_out: [H][k] probabilities, 1 <= k <= 8; h_lse_ess (may be NULL): {logsumexp, ess}.  Synchronises. */
+/* Hangs ONE read-back of the caller's on the next cpprob_hip_lineage_moments / cpprob_hip_lineage_hist call of this context: bytes
+ * [d_src, d_src + bytes) are copied behind that call's kernels on the context's stream, through pinned memory, and are in h_dst when
+ * the call returns -- the call's own stream synchronisation is the only one (cpprob/gpu.hpp: the run's ESS / evidence / flag tail
+ * rides the read-out's result instead of a host round trip of its own).  bytes = 0 cancels.  <= 16 MiB. */
+int cpprob_hip_readback_with_next_result(cpprob_hip_ctx* ctx, const void* d_src, void* h_dst, size_t bytes);
 /* Optional: uploads the records' generation table of the three calls above / below ahead of time (it is uploaded at their first use
  * otherwise, with a synchronisation; an unchanged table is never uploaded twice). */
 int cpprob_hip_lineage_prepare(cpprob_hip_ctx* ctx, const int32_t* h_gen, int32_t H, int32_t T);

@@ -107,11 +107,11 @@ def test_generic_and_builtin_agree_hmm_smc(tmp_path):
 
 @pytest.mark.parametrize("model,key,T,ess,oid,is_int", [("hmm16", "hmm16", 16, 2.0, O.MODEL_HMM3, True), ("hmm16", "hmm16", 16, 0.5, O.MODEL_HMM3, True),
                                                         ("linear_gaussian_1d25", "lgssm100", 25, 0.5, O.MODEL_LINEAR_GAUSSIAN_1D, False)])
-@pytest.mark.parametrize("form,ref_mode,launches", [(1, O.REF_STATEMENT_BOUND, 1), (2, O.REF_EXACT_MAX, 3), (0, O.REF_EXACT_MAX, 4)])
+@pytest.mark.parametrize("form,ref_mode,launches", [(1, O.REF_STATEMENT_BOUND, 1), (3, O.REF_STATEMENT_BOUND, 1), (2, O.REF_EXACT_MAX, 3), (0, O.REF_EXACT_MAX, 4)])
 def test_unchanged_model_smc_equals_the_oracle_in_every_step_form(tmp_path, model, key, T, ess, oid, is_int, form, ref_mode, launches):
     """cpprob::inference(StateType::smc, <unchanged model>) (reference cpprob.hpp:173-203 with models.hpp:67-80,114-141 as the model):
-    the resampling inside the model's own launch against the dry run's bounds (1), against exact maxima (2), and as separate
-    bookkeeping launches (0) -- each the oracle's fixed-point SMC with the same reference rule: surviving traces array_equal."""
+    the resampling inside the model's own launch against the dry run's bounds (1; 3: four particles a lane behind one search), against
+    exact maxima (2), and as separate bookkeeping launches (0) -- each the oracle's fixed-point SMC with the same reference rule: surviving traces array_equal."""
     z = np.load(os.path.join(GOLD, "observations.npz"))
     obs = z[key][:T]
     n = 40000
