@@ -21,7 +21,7 @@ KERNEL_CLASS_NAMES = ["smc_step", "scan_partials", "smooth", "finalize", "sis", 
 SYMBOLS = [
     "cpprob_hip_abi_version", "cpprob_hip_build_id", "cpprob_hip_device_count", "cpprob_hip_create", "cpprob_hip_destroy", "cpprob_hip_last_error",
     "cpprob_hip_stream", "cpprob_hip_sync", "cpprob_hip_set_hmm", "cpprob_hip_infer_begin", "cpprob_hip_infer_run", "cpprob_hip_infer_summary",
-    "cpprob_hip_infer_stats", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
+    "cpprob_hip_infer_stats", "cpprob_hip_infer_results", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
     "cpprob_hip_smc_finish", "cpprob_hip_filter_masses", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
     "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_exchange_direct", "cpprob_hip_exchange_traffic", "cpprob_hip_exchange_store", "cpprob_hip_exchange_remote",
@@ -101,6 +101,7 @@ def load_library(path=None):
         "cpprob_hip_infer_run": (C.c_int, [vp, u64]),
         "cpprob_hip_infer_summary": (C.c_int, [vp, C.POINTER(Summary)]),
         "cpprob_hip_infer_stats": (C.c_int, [vp, C.POINTER(dbl), sz]),
+        "cpprob_hip_infer_results": (C.c_int, [vp, vp, vp, sz, vp, vp]),
         "cpprob_hip_infer_results_device": (C.c_int, [vp, vp, sz]),
         "cpprob_hip_infer_step_trace": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(i32)]),
         "cpprob_hip_copy_values": (C.c_int, [vp, vp, sz]),
@@ -295,6 +296,15 @@ class Engine:
         out = np.zeros((self.T, self.K))
         self._chk(self.L.cpprob_hip_infer_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size))
         return out
+
+    def results(self):
+        """summary, stats and step trace in one call and one stream synchronisation (cpprob_hip_infer_results)."""
+        s = Summary()
+        out = np.zeros((self.T, self.K))
+        ess = np.zeros(self.T)
+        res = np.zeros(self.T, np.int32)
+        self._chk(self.L.cpprob_hip_infer_results(self.h, C.byref(s), out.ctypes.data, out.size, ess.ctypes.data, res.ctypes.data))
+        return {f: getattr(s, f) for f, _ in Summary._fields_}, out, ess, res
 
     def results_device(self, out):
         """{log_evidence, ess, log_norm, max_logw, stats...} of the enqueued run into a device tensor; no host sync."""

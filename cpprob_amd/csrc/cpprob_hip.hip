@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -95,7 +96,7 @@ struct cpprob_hip_ctx {
     double* h_obound = nullptr;     // pinned host copy (the one host read-back per step of the exchange scope)
     // read-backs of small results go through pinned memory (a copy into pageable memory blocks the host for its own round trip: three of
     // them closed an unchanged-model run at ~25 us each) and ride ONE stream synchronisation; the caller may hang a copy of its own on it
-    char* h_pin = nullptr; size_t h_pin_cap = 0;
+    char* h_pin = nullptr; size_t h_pin_cap = 0; uint64_t pin_seq = 0;
     const void* ride_src = nullptr; void* ride_dst = nullptr; size_t ride_bytes = 0;
     int32_t* d_send_src = nullptr; size_t send_src_cap = 0;
     // device-resident exchange plan (exchange.hpp) and the transport geometry
@@ -1334,6 +1335,72 @@ int repair_fixed_generation(cpprob_hip_ctx* c, int g)
 // Before a run's results leave the library: did the fixed-point weights keep their bits?  If not the offending generations are
 // repaired as above; where that is not possible (a shard of a joint population, a filtering-only run, a generation without mass) the
 // run is repeated in the floating-point form (runs the caller drives step by step cannot be repeated here: CPPROB_HIP_EPRECISION).
+// Small results reach the host WITHOUT copy commands and without waiting for the stream: one short launch stores them into pinned
+// (device-visible, coherent) host memory, then a sequence number behind them; the host polls that word.  (Measured on the way here,
+// per read-back of a few hundred bytes: a copy into pageable memory ~35 us of host round trip, an asynchronous copy into pinned memory
+// ~20 us each -- three of them closed every run -- and hipStreamSynchronize's own wake-up behind the last kernel.)
+constexpr size_t kPinHeader = 64;                                       // the block's first bytes: the sequence word
+struct PinSeg { const uint32_t* src; uint32_t* dst; uint32_t words; uint32_t pad; };
+struct PinSegs { PinSeg s[4]; int n; };
+__global__ __launch_bounds__(kThreads) void pin_pack_kernel(PinSegs a, unsigned long long* flag, unsigned long long seq)
+{
+    for (int k = 0; k < a.n; ++k)
+        for (uint32_t i = threadIdx.x; i < a.s[k].words; i += kThreads) a.s[k].dst[i] = a.s[k].src[i];
+    __threadfence_system();                                             // (every thread's stores are on their way before the flag is)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static int pin_reserve(cpprob_hip_ctx* c, size_t bytes)                 // bytes of data (behind the header)
+{
+    bytes += kPinHeader;
+    if (bytes <= c->h_pin_cap) return 0;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_cap = 0; }
+    const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 16);
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), want, hipHostMallocDefault));
+    std::memset(c->h_pin, 0, kPinHeader);
+    c->h_pin_cap = want; c->pin_seq = 0;
+    return 0;
+}
+static char* pin_data(cpprob_hip_ctx* c) { return c->h_pin + kPinHeader; }
+struct PinPack {
+    PinSegs segs{};
+    void add(const void* d_src, void* h_dst, size_t bytes)             // (device memory -> the context's pinned block; 4-byte words)
+    {
+        if (bytes == 0) return;
+        PinSeg& g = segs.s[segs.n++];
+        g.src = static_cast<const uint32_t*>(d_src); g.dst = static_cast<uint32_t*>(h_dst); g.words = (uint32_t)((bytes + 3) / 4); g.pad = 0;
+    }
+    // the launch; `wait` is what the host calls when it wants the bytes
+    int launch(cpprob_hip_ctx* c)
+    {
+        c->pin_seq += 1;
+        hipLaunchKernelGGL(pin_pack_kernel, dim3(1), dim3(kThreads), 0, c->stream, segs, reinterpret_cast<unsigned long long*>(c->h_pin), (unsigned long long)c->pin_seq);
+        HIP_TRY(c, hipGetLastError());
+        return 0;
+    }
+};
+// the host's side: poll the sequence word (the launch is short and last in the stream); a look at the stream every few thousand polls
+// catches a failed launch, and a stream that finished without the word showing falls back to its synchronisation
+static int pin_wait(cpprob_hip_ctx* c)
+{
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_pin);
+    const unsigned long long want = (unsigned long long)c->pin_seq;
+    for (unsigned k = 1;; ++k) {
+        if (*flag == want) break;
+        if ((k & 0x3fffu) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) { if (*flag != want) HIP_TRY(c, hipStreamSynchronize(c->stream)); break; }
+            if (q != hipErrorNotReady) { HIP_TRY(c, q); }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+
 int settle_fixed(cpprob_hip_ctx* c)
 {
     if (!c->fixed_check_pending) return 0;
@@ -1935,6 +2002,64 @@ int cpprob_hip_infer_summary(cpprob_hip_ctx* c, cpprob_hip_summary* out)
     return 0;
 }
 
+// Everything cpprob::inference reads when a run is over -- the summary, the per-predict statistics, the step trace -- behind ONE stream
+// synchronisation, through pinned memory (three calls of the single-purpose functions above cost three host round trips, each
+// a blocking copy into pageable memory: ~40 us on a 150-us run).
+static void fill_summary(const cpprob_hip_ctx* c, const StepCtrl& h, cpprob_hip_summary* out)
+{
+    out->log_evidence = h.log_z;
+    out->ess_final = h.ess;
+    out->log_norm = h.M + std::log(h.W);
+    out->max_logw = h.M;
+    out->n_predict = c->T;
+    out->stats_per_predict = c->K;
+    out->is_int = c->is_int ? 1 : 0;
+    out->n_resampled = h.n_resampled;
+    out->step_form = c->cfg.algorithm != CPPROB_HIP_ALG_SMC ? CPPROB_HIP_FORM_FLOAT : (c->fixed_mode ? CPPROB_HIP_FORM_FIXED : (c->counts_mode ? CPPROB_HIP_FORM_COUNTS : CPPROB_HIP_FORM_FLOAT));
+    out->n_requantised = c->fixed_mode ? c->n_requantised : 0;
+}
+int cpprob_hip_infer_results(cpprob_hip_ctx* c, cpprob_hip_summary* out, double* h_stats, size_t n_doubles, double* h_ess, int32_t* h_resampled)
+{
+    if (!c || !out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->ran) return fail(c, CPPROB_HIP_ESTATE, "no finished run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t T = (size_t)c->T, need = T * (size_t)c->K;
+    if (h_stats && n_doubles < need) return fail(c, CPPROB_HIP_EINVAL, "h_stats too small");
+    const bool sis = c->cfg.algorithm == CPPROB_HIP_ALG_SIS;
+    const size_t o_ctrl = 0, o_stats = (sizeof(StepCtrl) + 15) / 16 * 16, o_ess = o_stats + need * sizeof(double), o_res = o_ess + T * sizeof(double), total = o_res + T * sizeof(int32_t);
+    if (int rc = pin_reserve(c, total)) return rc;
+    for (int pass = 0; pass < 2; ++pass) {
+        char* const pin = pin_data(c);
+        PinPack pk;
+        pk.add(c->d_ctrl, pin + o_ctrl, sizeof(StepCtrl));
+        if (h_stats) pk.add(c->d_stats, pin + o_stats, need * sizeof(double));
+        if (h_ess && sis) pk.add(c->d_ess + (T - 1), pin + o_ess + (T - 1) * sizeof(double), sizeof(double));
+        else if (h_ess) pk.add(c->d_ess, pin + o_ess, T * sizeof(double));
+        if (h_resampled && !sis) pk.add(c->d_resampled, pin + o_res, T * sizeof(int32_t));
+        if (int rc = pk.launch(c)) return rc;
+        if (int rc = pin_wait(c)) return rc;
+        StepCtrl h;
+        std::memcpy(&h, pin + o_ctrl, sizeof h);
+        if (pass == 0 && c->fixed_check_pending) {
+            // (a fixed-point run is settled on the same read-back: only a generation that lost its bits costs more round trips)
+            if (h.fix_gap <= kFixGapLimit) c->fixed_check_pending = false;
+            else { if (int rc = settle_fixed(c)) return rc; continue; }
+        }
+        fill_summary(c, h, out);
+        if (h_stats) std::memcpy(h_stats, pin + o_stats, need * sizeof(double));
+        if (h_ess) {
+            std::memcpy(h_ess, pin + o_ess, T * sizeof(double));
+            if (sis) for (size_t t = 0; t + 1 < T; ++t) h_ess[t] = 0.0;                  // (one weighting pass: only the final entry is defined)
+        }
+        if (h_resampled) {
+            if (sis) for (size_t t = 0; t < T; ++t) h_resampled[t] = 0;
+            else std::memcpy(h_resampled, pin + o_res, T * sizeof(int32_t));
+        }
+        return 0;
+    }
+    return fail(c, CPPROB_HIP_ESTATE, "the run did not settle");
+}
+
 int cpprob_hip_infer_stats(cpprob_hip_ctx* c, double* h_stats, size_t n_doubles)
 {
     if (!c || !h_stats) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
@@ -2277,17 +2402,6 @@ static int columns_stats(cpprob_hip_ctx* c, const typename Col::value_t* d_x, si
     return 0;
 }
 // first_row[t] .. first_row[t + 1]: the records made in generation t's slots (h_gen[h] = the generation of record h, non-decreasing)
-static int pin_reserve(cpprob_hip_ctx* c, size_t bytes)
-{
-    if (bytes <= c->h_pin_cap) return 0;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_cap = 0; }
-    const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 16);
-    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), want, hipHostMallocDefault));
-    c->h_pin_cap = want;
-    return 0;
-}
-
 static int upload_first_rows(cpprob_hip_ctx* c, const int32_t* h_gen, int32_t H, int32_t T)
 {
     std::vector<int32_t> first((size_t)T + 1, 0);
@@ -2331,17 +2445,21 @@ static int lineage_stats(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t*
         hipLaunchKernelGGL(lineage_stats_kernel<Col>, dim3(grid), dim3(kThreads), (size_t)kWaves * nk * Col::kStats * sizeof(double), c->stream, a);
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nk), dim3(kThreads), 0, c->stream, c->d_bb_cols_part, grid, nk, Col::kStats, 1, c->d_bb_ctrl, c->d_bb_cols_stat, 1);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(c->h_pin + (size_t)h0 * Col::kStats * sizeof(double), c->d_bb_cols_stat, (size_t)nk * Col::kStats * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PinPack pk;
+        pk.add(c->d_bb_cols_stat, pin_data(c) + (size_t)h0 * Col::kStats * sizeof(double), (size_t)nk * Col::kStats * sizeof(double));
+        if (h0 + chunk >= H) {                                              // (the last chunk's launch carries the rest)
+            pk.add(c->d_bb_ctrl, pin_data(c) + stats_bytes, sizeof(StepCtrl));
+            pk.add(c->ride_src, pin_data(c) + ride_off, c->ride_bytes);
+        }
+        if (int rc = pk.launch(c)) return rc;
         if (h0 + chunk < H) HIP_TRY(c, hipStreamSynchronize(c->stream));     // (the scratch is reused by the next chunk)
     }
-    HIP_TRY(c, hipMemcpyAsync(c->h_pin + stats_bytes, c->d_bb_ctrl, sizeof(StepCtrl), hipMemcpyDeviceToHost, c->stream));
     const bool riding = c->ride_bytes != 0;
-    if (riding) HIP_TRY(c, hipMemcpyAsync(c->h_pin + ride_off, c->ride_src, c->ride_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = pin_wait(c)) return rc;
     StepCtrl h;
-    std::memcpy(h_raw, c->h_pin, stats_bytes);
-    std::memcpy(&h, c->h_pin + stats_bytes, sizeof h);
-    if (riding) { std::memcpy(c->ride_dst, c->h_pin + ride_off, c->ride_bytes); c->ride_src = nullptr; c->ride_dst = nullptr; c->ride_bytes = 0; }
+    std::memcpy(h_raw, pin_data(c), stats_bytes);
+    std::memcpy(&h, pin_data(c) + stats_bytes, sizeof h);
+    if (riding) { std::memcpy(c->ride_dst, pin_data(c) + ride_off, c->ride_bytes); c->ride_src = nullptr; c->ride_dst = nullptr; c->ride_bytes = 0; }
     h_lse_ess[0] = h.M + std::log(h.W); h_lse_ess[1] = h.ess;
     return 0;
 }
@@ -2361,7 +2479,7 @@ int cpprob_hip_readback_with_next_result(cpprob_hip_ctx* c, const void* d_src, v
 {
     BB_PRELUDE(c);
     if (bytes != 0 && (!d_src || !h_dst)) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
-    if (bytes > ((size_t)1 << 24)) return fail(c, CPPROB_HIP_EINVAL, "a read-back that rides a result's is a small one (<= 16 MiB)");
+    if (bytes > ((size_t)1 << 20) || (bytes & 3)) return fail(c, CPPROB_HIP_EINVAL, "a read-back that rides a result's is a small one (<= 1 MiB, whole 4-byte words)");
     c->ride_src = bytes ? d_src : nullptr; c->ride_dst = bytes ? h_dst : nullptr; c->ride_bytes = bytes;
     return 0;
 }

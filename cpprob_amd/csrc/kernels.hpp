@@ -200,7 +200,7 @@ __device__ __forceinline__ void scan_tail(const ScanArgs& a)
     const bool last = a.t + 1 == a.T;
     const bool rs = !a.force_no_resample && !last && (ess < a.ess_frac * a.n_pop);
     ctrl->do_resample = rs ? 1 : 0;
-    if (a.t == 0) { ctrl->log_z = 0.0; ctrl->n_resampled = 0; }
+    if (a.t == 0 || a.force_no_resample) { ctrl->log_z = 0.0; ctrl->n_resampled = 0; }      // (SIS keeps books once, at its last observe: a repeated run starts over too)
     if (rs || last) ctrl->log_z += M + log(W / a.n_pop);
     if (rs) ctrl->n_resampled += 1;
     // Resampling is local to the shard (particles never migrate): outputs 0..n_local-1 are drawn over the

@@ -208,14 +208,19 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
     ctx.check(cpprob_hip_sync(ctx.get()), "cpprob_hip_sync");          // (begin's buffer clears are allocation: not the run's time)
     const auto t0 = std::chrono::steady_clock::now();
     ctx.check(cpprob_hip_infer_run(ctx.get(), 0), "cpprob_hip_infer_run");
+    // (everything the result holds in ONE read-back behind one stream synchronisation; sizes from the model structure: the engine
+    //  fills exactly n_predict * stats_per_predict doubles -- histograms of up to 8 bins, or {mean, variance})
     cpprob_hip_summary s{};
-    ctx.check(cpprob_hip_infer_summary(ctx.get(), &s), "cpprob_hip_infer_summary");
+    const std::size_t T_guess = st.int_ids.empty() ? st.real_rows() : st.int_ids.size();
+    const std::size_t T_cap = std::max<std::size_t>(std::max(T_guess, obs.size()), 1);     // (the engine's rows: one per observation at most)
+    std::vector<double> stats(T_cap * 8);
+    res.step_ess.assign(T_cap, 0.0);
+    ctx.check(cpprob_hip_infer_results(ctx.get(), &s, stats.data(), stats.size(), res.step_ess.data(), nullptr), "cpprob_hip_infer_results");
     res.run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const std::size_t T = static_cast<std::size_t>(s.n_predict), K = static_cast<std::size_t>(s.stats_per_predict);
-    if ((s.is_int ? st.int_ids.size() : st.real_rows()) != T)
+    if ((s.is_int ? st.int_ids.size() : st.real_rows()) != T || T != T_guess)
         throw std::runtime_error("built-in model kernel and the model function disagree on the number of predict statements");
-    std::vector<double> stats(T * K);
-    ctx.check(cpprob_hip_infer_stats(ctx.get(), stats.data(), stats.size()), "cpprob_hip_infer_stats");
+    stats.resize(T * K); res.step_ess.resize(T);
     res.n_particles = n; res.log_evidence = s.log_evidence; res.ess = s.ess_final; res.log_norm = s.log_norm; res.n_resampled = s.n_resampled;
     res.used_builtin = true;
     fill_predict_names(res, st);
@@ -229,8 +234,6 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
             p.mean = p.mean_nd[0]; p.variance = p.variance_nd[0];
         }
     }
-    res.step_ess.assign(T, 0.0);
-    ctx.check(cpprob_hip_infer_step_trace(ctx.get(), res.step_ess.data(), nullptr), "cpprob_hip_infer_step_trace");
     if (store) {
         store->n = n;
         store->logw.resize(n);

@@ -184,6 +184,10 @@ int cpprob_hip_sync(cpprob_hip_ctx* ctx);
  *         real -> {mean, variance} (raw_moment(2) - mean^2, empirical_distribution.hpp:78-81);
  *         int  -> {P(x_t = 0), ..., P(x_t = k-1)} (distribution(), :30-40).
  */
+/* The three read-backs below in ONE call and behind ONE stream synchronisation (pinned staging): what cpprob::inference reads when a
+ * run is over.  h_stats ([n_predict * stats_per_predict], n_doubles its capacity), h_ess and h_resampled ([n_predict]) may be NULL.
+ * Same values, same errors as cpprob_hip_infer_summary / _stats / _step_trace. */
+int cpprob_hip_infer_results(cpprob_hip_ctx* ctx, cpprob_hip_summary* out, double* h_stats, size_t n_doubles, double* h_ess, int32_t* h_resampled);
 /* The table of CPPROB_HIP_MODEL_HMM_TABLE: h_means[k], h_transition[k * k] (row s = the weights discrete_distribution{T[s]} of
  * models.hpp:135 would be built from).  Kept by the context until the next call. */
 int cpprob_hip_set_hmm(cpprob_hip_ctx* ctx, int32_t k, const double* h_means, const double* h_transition);
@@ -523,9 +527,9 @@ int cpprob_hip_lineage_gather(cpprob_hip_ctx* ctx, const int32_t* d_anc, const i
  * memory (StatsPrinter's numbers, reference stats_printer.hpp:68-120, when nobody asked for the traces themselves).  h_out4: [H][4] =
  * {mean, variance, logsumexp, ess}; h_out: [H][k] probabilities, 1 <= k <= 8; h_lse_ess (may be NULL): {logsumexp, ess}.  Synchronises. */
 /* Hangs ONE read-back of the caller's on the next cpprob_hip_lineage_moments / cpprob_hip_lineage_hist call of this context: bytes
- * [d_src, d_src + bytes) are copied behind that call's kernels on the context's stream, through pinned memory, and are in h_dst when
+ * [d_src, d_src + bytes) are stored into pinned host memory by the launch that stores the call's own result, and are in h_dst when
  * the call returns -- the call's own stream synchronisation is the only one (cpprob/gpu.hpp: the run's ESS / evidence / flag tail
- * rides the read-out's result instead of a host round trip of its own).  bytes = 0 cancels.  <= 16 MiB. */
+ * rides the read-out's result instead of a host round trip of its own).  bytes = 0 cancels.  <= 1 MiB, a multiple of 4. */
 int cpprob_hip_readback_with_next_result(cpprob_hip_ctx* ctx, const void* d_src, void* h_dst, size_t bytes);
 /* Optional: uploads the records' generation table of the three calls above / below ahead of time (it is uploaded at their first use
  * otherwise, with a synchronisation; an unchanged table is never uploaded twice). */

@@ -131,6 +131,23 @@ def test_unchanged_model_smc_equals_the_oracle_in_every_step_form(tmp_path, mode
     assert abs(res["log_evidence"] - r["log_z"]) < 1e-9
 
 
+@pytest.mark.parametrize("n", [1, 255, 1024, 1025, 3000])
+def test_four_particles_a_lane_equals_one_particle_a_lane_on_ragged_populations(tmp_path, n):
+    """Step form 3 (model_step_kernel_quad: a workgroup owns a 1024-particle tile, one search, the model body four times a lane) against
+    form 1 on populations that end inside a tile, fill one exactly, and spill one particle into the next: the same posterior file."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    for model, key, T, ess, is_int in (("hmm16", "hmm16", 16, 2.0, True), ("linear_gaussian_1d25", "lgssm100", 25, 0.5, False)):
+        obs = z[key][:T]
+        out = {}
+        for form in (1, 3):
+            res, _, _ = run_main(tmp_path, "--model", model, "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 11, "--ess_threshold", ess, "--json",
+                                 "--generic", "--generated_file", "f%d" % form, "--step_form", form)
+            assert res["step_form"] in (form, 2)                      # (a single particle's generation may not fit the statement's bound: exact maxima then)
+            v, lw = read_dump(str(tmp_path / ("f%d_smc.%s" % (form, "int" if is_int else "real"))), is_int)
+            out[form] = (v, lw, res["log_evidence"], res["n_resampled"])
+        assert np.array_equal(out[1][0], out[3][0]) and np.array_equal(out[1][1], out[3][1]) and out[1][2] == out[3][2] and out[1][3] == out[3][3]
+
+
 @pytest.mark.parametrize("model,key,T,ess,oid,is_int", [("hmm16", "hmm16", 16, 2.0, O.MODEL_HMM3, True), ("linear_gaussian_1d25", "lgssm100", 25, 0.5, O.MODEL_LINEAR_GAUSSIAN_1D, False)])
 @pytest.mark.parametrize("rname,rid", [("stratified", O.RESAMPLE_STRATIFIED), ("multinomial", O.RESAMPLE_MULTINOMIAL)])
 def test_unchanged_model_smc_with_the_other_resamplers_equals_the_oracle(tmp_path, model, key, T, ess, oid, is_int, rname, rid):

@@ -301,6 +301,22 @@ def test_paired_step_launches_are_the_single_launch_bit_for_bit(engine, golden_d
     assert np.array_equal(a[0], ref["anc"]) and np.array_equal(a[5][1], ref["resampled"])
 
 
+@pytest.mark.parametrize("alg,model,key,T,ess", [(cp.ALG_SMC, cp.MODEL_HMM3, "hmm16", 16, 2.0), (cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 30, 0.5),
+                                                 (cp.ALG_SIS, cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 12, 0.5)])
+def test_results_in_one_call_equal_the_three_read_backs(engine, golden_dir, alg, model, key, T, ess):
+    """cpprob_hip_infer_results (summary + statistics + step trace through pinned memory behind one stream synchronisation; a
+    fixed-point run is settled on the same read-back) returns what cpprob_hip_infer_summary / _stats / _step_trace return."""
+    obs = _obs(golden_dir, key)[:T]
+    engine.begin(alg, model, obs, 50_001, seed=5, ess_threshold=ess)
+    engine.run()
+    s1, st1, ess1, res1 = engine.results()
+    s2, st2, (ess2, res2) = engine.summary(), engine.stats(), engine.step_trace()
+    assert s1 == s2 and np.array_equal(st1, st2) and np.array_equal(ess1, ess2) and np.array_equal(res1, res2)
+    engine.run()                                                         # (the same run again starts its books over: SIS keeps them once, at the last observe)
+    s3, st3, ess3, res3 = engine.results()
+    assert s3 == s1 and np.array_equal(st3, st1) and np.array_equal(ess3, ess1) and np.array_equal(res3, res1)
+
+
 @pytest.mark.parametrize("n", [1, 2, 1023, 1025, 4095, 4097, 12289])
 def test_smc_tiny_and_ragged_populations(engine, golden_dir, n):
     obs = _obs(golden_dir, "hmm16")[:5]
