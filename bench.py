@@ -767,13 +767,27 @@ def main():
             warm = sorted(float(l.split()[2]) for l in runs[1:])          # (every call but the first: each a run of its own seed)
             g_ms = warm[len(warm) // 2]
             out["generic_path"] = {"ms_per_run": g_ms, "ms_per_run_min": warm[0], "ms_per_run_max": warm[-1], "particles_per_sec": n / (g_ms * 1e-3), "replay_window": gj["replay_window"],
-                                   "step_form": {0: "model launch + three bookkeeping launches", 1: "resampling inside the model's launch (dry-run bounds)", 2: "resampling inside the model's launch + exact-maximum passes"}[gj["step_form"]],
+                                   "step_form": {0: "model launch + three bookkeeping launches", 1: "resampling inside the model's launch (dry-run bounds)", 2: "resampling inside the model's launch + exact-maximum passes",
+                                                 3: "resampling inside the model's launch, four particles a lane"}[gj["step_form"]],
                                    "launches_per_step": gj["launches_per_step"],
                                    "ms_first_call": float(first[2]) + float(first[5]), "ms_setup_first_call": float(first[5]), "ms_setup_warm_call": gj["setup_seconds"] * 1e3,
                                    "posterior_max_abs_err_vs_exact": float(np.abs(gst - spec["exact"]).max()),
                                    "vs_fused_kernels": g_ms / (dt / args.steps * 1e3),
                                    "note": "cpprob_main --generic --repeat 12: ms_per_run = the median over the eleven warm calls of a call's device work (the read-out of every predict hit included), ms_first_call = "
                                            "the first cpprob::inference call whole (context, workspace, Markov pilot, run), ms_setup_warm_call = what a later call adds to its run"}
+            # like for like: the SAME call and clock (cpprob::inference's Result::run_seconds through cpprob_main) on the built-in registration,
+            # and the four-particles-a-lane step form (--step_form 3), measured and not the engine's choice
+            def main_ms(extra):
+                with tempfile.TemporaryDirectory() as td2:
+                    cmd2 = [exe, "--model_folder", td2, "--model", "hmm16", "--smc", "--observes", obs_s, "--n_samples", str(n), "--seed", str(args.seed),
+                            "--ess_threshold", "2.0", "--no_dump", "--json", "--repeat", "12"] + extra
+                    pr2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=300)
+                w2 = sorted(float(l.split()[2]) for l in pr2.stdout.splitlines() if l.startswith("run "))[:-1]
+                return w2[len(w2) // 2]
+            b_ms = main_ms([])
+            out["generic_path"]["builtin_registration_same_call_ms"] = b_ms
+            out["generic_path"]["vs_builtin_registration_same_call"] = g_ms / b_ms
+            out["generic_path"]["four_particles_a_lane_ms"] = main_ms(["--generic", "--step_form", "3"])
             # the same population as FOUR ranks of one joint population on this GPU (loopback: the pull migration and the per-step host all-gather at work)
             with tempfile.TemporaryDirectory() as td:
                 cmd = [exe, "--model_folder", td, "--model", "hmm16", "--smc", "--observes", obs_s, "--n_samples", str(n), "--seed", str(args.seed),
