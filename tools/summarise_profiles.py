@@ -135,7 +135,7 @@ if os.path.exists(bp):
         b["roofline"]["valu_issue_frac"] = rec.get("valu_issue_frac"); b["roofline"]["wait_frac"] = rec.get("wait_frac")
     json.dump(b, open("profiles/%s_bench_n1.json" % out_tag, "w"))
 
-for form in (1, 0):
+for form in (1, 0, 3):
     d = "%s_generic_form%d" % (src_tag, form)
     ks = newest("%s/%s/*kernel_stats.csv" % (G, d)) or newest("%s/%s/*/*kernel_stats.csv" % (G, d))
     tr = newest("%s/%s/*kernel_trace.csv" % (G, d)) or newest("%s/%s/*/*kernel_trace.csv" % (G, d))
@@ -143,7 +143,7 @@ for form in (1, 0):
         continue
     rows = list(csv.DictReader(open(ks)))
     gmd = "# rocprofv3 --kernel-trace --stats -- cpprob_main --generic --model hmm16 --smc --n_samples 1000000 --repeat 8 --step_form %d (MI355X, %s; tools/profile_generic.sh)\n\n" % (form, out_tag)
-    gmd += "step form %d = %s.  Eight cpprob::inference calls + the Markov pilot (8192 particles, both replay forms) in one process.\n\n" % (form, "the resampling inside the model's launch (model_step_kernel)" if form else "model launch + three bookkeeping launches (the r03 form)")
+    gmd += "step form %d = %s.  Eight cpprob::inference calls + the Markov pilot (8192 particles, both replay forms) in one process.\n\n" % (form, {1: "the resampling inside the model's launch (model_step_kernel)", 0: "model launch + three bookkeeping launches (the r03 form)", 3: "the resampling inside the model's launch, four particles a lane behind one ancestor search (model_step_kernel_quad; opt-in)"}[form])
     gmd += "| kernel | calls | total us | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n"
     for r in rows[:10]:
         gmd += "| `%s` | %s | %.1f | %.2f | %.2f | %.2f | %s |\n" % (r["Name"][:120], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"])
