@@ -462,6 +462,10 @@ class Engine:
         self._chk(self.L.cpprob_hip_lineage_hist(self.h, _dptr(anc), _dptr(resampled), T, n, _dptr(cols), g, len(gens), _dptr(logw), k, out, None))
         return np.array(out[:]).reshape(len(gens), k)
 
+    def readback_with_next_result(self, src, out):
+        """Hang a read-back of device tensor `src` into the numpy array `out` on the next lineage_moments / lineage_hist call (one wait for both)."""
+        self._chk(self.L.cpprob_hip_readback_with_next_result(self.h, _dptr(src), out.ctypes.data, out.nbytes))
+
     def resample(self, kind, logw, seed, step, anc_out, j0=0, n_total_out=None):
         n_out = anc_out.numel()
         nt = logw.numel() if n_total_out is None else n_total_out

@@ -13,6 +13,7 @@ import pytest
 from devmem import dcat, dtensor, dzeros, dzeros_like  # noqa: F401
 
 from oracle import oracle as O
+import cpprob_amd as cp  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -492,6 +493,14 @@ def test_lineage_statistics_equal_gather_then_columns(engine, n, T, hits):
     goth = engine.lineage_hist(d_anc, d_res, d_xi, hits, d_lw, 5)
     assert np.array_equal(got, engine.weighted_moments_columns(out_x, d_lw))
     assert np.array_equal(goth, engine.weighted_hist_columns(out_xi, d_lw, 5))
+    # a read-back of the caller's rides the read-out's result (one launch into pinned memory, one wait): the bytes arrive with it
+    rider = np.zeros(min(n, 4096), np.float64)
+    engine.readback_with_next_result(d_lw, rider)
+    assert np.array_equal(engine.lineage_hist(d_anc, d_res, d_xi, hits, d_lw, 5), goth) and np.array_equal(rider, logw[:rider.size])
+    rider[:] = 0.0
+    assert np.array_equal(engine.lineage_moments(d_anc, d_res, d_x, hits, d_lw), got) and not rider.any()      # (it rode once)
+    with pytest.raises(cp.CpprobHipError):
+        engine.readback_with_next_result(d_lw, np.zeros(3, np.uint8))                                             # whole 4-byte words only
     np.testing.assert_allclose(got[0, :2], np.array(O.weighted_moments(want_x[0], logw))[:2], rtol=1e-9, atol=1e-10)
 
 
