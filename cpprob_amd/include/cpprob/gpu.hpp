@@ -296,10 +296,12 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     Context& ctx = ws->ctx;
     hip_check(hipSetDevice(opt.device), "hipSetDevice");
     hipStream_t stream = static_cast<hipStream_t>(cpprob_hip_stream(ctx.get()));
-    const int64_t ld = (int64_t)n;
+    const bool smc = algorithm == StateType::smc;
+    // (SIS without a dump: the predict columns sit a whole number of 1024-particle tiles apart, so the statistics pass reads them where they
+    //  lie -- cpprob_hip_weighted_*_columns copies columns of any other stride into padded scratch first: 80 MB each way at 10^7 particles)
+    const int64_t ld = (!smc && !store) ? (int64_t)((n + cph::kTile - 1) / cph::kTile * cph::kTile) : (int64_t)n;
     const size_t n_real = st.real_rows(), n_int = st.int_ids.size();        // a vector-valued real predict owns one column per component
     const int T = (int)st.n_observe;
-    const bool smc = algorithm == StateType::smc;
     const bool windowed = smc && st.window >= 0;
     const uint32_t w = (uint32_t)std::max(1, st.window);
     if (!(windowed && opt.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC && n <= (std::size_t(64) * 64 * 64 * device::kStepBlock) && T > 0)) form = StepForm::unfused;
@@ -315,8 +317,8 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     unsigned char* d_tail = nullptr;
     Carver carve;
     carve.add(&d_obs, 1); carve.add(&d_tail, tail_bytes);
-    carve.add(&d_real, n_real * n); carve.add(&d_logw0, n); carve.add(&d_logw1, smc ? n : 0);
-    carve.add(&d_int, n_int * n); carve.add(&d_anc, smc && !fused ? n : 0);
+    carve.add(&d_real, n_real * (size_t)ld); carve.add(&d_logw0, n); carve.add(&d_logw1, smc ? n : 0);
+    carve.add(&d_int, n_int * (size_t)ld); carve.add(&d_anc, smc && !fused ? n : 0);
     carve.add(&d_ns0, smc && !windowed ? n : 0); carve.add(&d_ns1, smc && !windowed ? n : 0);
     carve.add(&d_tr0, smc && !windowed ? S * n : 0); carve.add(&d_tr1, smc && !windowed ? S * n : 0);
     // (windowed replay's buffers)
@@ -325,6 +327,10 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     carve.add(&d_real_gen, windowed ? n_real * n : 0); carve.add(&d_int_gen, windowed ? n_int * n : 0);
     const bool grown = carve.commit(*ws);
     hip_check(hipMemcpyAsync(d_obs, observes_v, sizeof(Tuple), hipMemcpyHostToDevice, stream), "copy observes");
+    if ((size_t)ld > n) {                                           // the columns' slots behind n: finite (they weigh nothing in the statistics pass)
+        if (n_real) hip_check(hipMemset2DAsync(d_real + n, (size_t)ld * sizeof(double), 0, ((size_t)ld - n) * sizeof(double), n_real, stream), "hipMemset2DAsync");
+        if (n_int) hip_check(hipMemset2DAsync(d_int + n, (size_t)ld * sizeof(int32_t), 0, ((size_t)ld - n) * sizeof(int32_t), n_int, stream), "hipMemset2DAsync");
+    }
 
     double* const d_ess_p = reinterpret_cast<double*>(d_tail);
     double* const d_logz_p = d_ess_p + T;
@@ -510,10 +516,20 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     double lse_ess[2] = {0.0, 0.0};
     bool have_norm = false;
     // StatsPrinter's numbers of every predict hit: all columns of a kind in one device pass against the final weights
+    // (SIS: the run's tail rides the last statistics call's result -- one launch into pinned memory, one wait)
+    bool sis_tail_read = false;
+    auto ride_sis_tail = [&]() {
+        if (smc || stats_on_walk) return;
+        ctx.check(cpprob_hip_readback_with_next_result(ctx.get(), d_tail, h_tail.data(), tail_bytes), "cpprob_hip_readback_with_next_result");
+        sis_tail_read = true;
+    };
     if (n_real) {
         std::vector<double> o4(4 * n_real);
         if (stats_on_walk) o4 = walk_real;
-        else ctx.check(cpprob_hip_weighted_moments_columns(ctx.get(), d_real, n_real, n, logw[cur], n, o4.data()), "cpprob_hip_weighted_moments_columns");
+        else {
+            if (!n_int) ride_sis_tail();
+            ctx.check(cpprob_hip_weighted_moments_columns(ctx.get(), d_real, n_real, (size_t)ld, logw[cur], n, o4.data()), "cpprob_hip_weighted_moments_columns");
+        }
         lse_ess[0] = o4[2]; lse_ess[1] = o4[3]; have_norm = true;
         for (size_t k = 0, row = 0; k < st.real_ids.size(); ++k) {
             PredictStats& p = res.predicts[k];
@@ -525,7 +541,10 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
     if (n_int) {
         std::vector<double> h(8 * n_int);
         if (stats_on_walk) { h = walk_int; if (!have_norm) { lse_ess[0] = walk_lse_ess[0]; lse_ess[1] = walk_lse_ess[1]; } }
-        else ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int, n_int, n, logw[cur], n, 8, h.data(), have_norm ? nullptr : lse_ess), "cpprob_hip_weighted_hist_columns");
+        else {
+            ride_sis_tail();
+            ctx.check(cpprob_hip_weighted_hist_columns(ctx.get(), d_int, n_int, (size_t)ld, logw[cur], n, 8, h.data(), have_norm ? nullptr : lse_ess), "cpprob_hip_weighted_hist_columns");
+        }
         have_norm = true;
         for (size_t k = 0; k < n_int; ++k) {
             int top = 8;
@@ -548,7 +567,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
         if (n_real) hip_check(hipMemcpyAsync(store->real.data(), d_real, n_real * n * sizeof(double), hipMemcpyDeviceToHost, stream), "copy real predicts");
         if (n_int) hip_check(hipMemcpyAsync(store->ints.data(), d_int, n_int * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "copy int predicts");
     }
-    if (!smc) read_tail(); else hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");    // (SMC: the tail was read when the last launch had been issued)
+    if (!smc && !sis_tail_read) read_tail(); else hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");    // (SMC: the tail was read when the last launch had been issued)
     const int32_t overflow = h_res_p[T];
     if (overflow == 2)
         throw std::runtime_error("cpprob::inference: a particle executed more predict statements than the model's dry run did; the number "
