@@ -444,7 +444,10 @@ int cpprob_hip_weighted_moments(cpprob_hip_ctx* ctx, const double* d_x, const do
 /* h_out[s] = sum_i W_i [x_i == s], s < k <= 8  (distribution(), :30-40). */
 int cpprob_hip_weighted_hist(cpprob_hip_ctx* ctx, const int32_t* d_x, const double* d_logw, size_t n, int32_t k, double* h_out);
 /* ... and of n_cols columns (column j at d_x + j * col_stride, col_stride >= n) against ONE log-weight array: one normalisation, one
- * read-out launch, one synchronisation for all of them.  h_out4: [n_cols][4] as cpprob_hip_weighted_moments; h_out: [n_cols][k]. */
+ * read-out launch, one synchronisation for all of them.  h_out4: [n_cols][4] as cpprob_hip_weighted_moments; h_out: [n_cols][k].
+ * Columns whose stride is a whole number of 1024-particle tiles (col_stride % 1024 == 0, col_stride >= n rounded up to a tile) are read
+ * WHERE THEY LIE: their slots [n, col_stride) must be readable and hold finite numbers (they weigh nothing); any other stride is
+ * copied into tile-padded scratch first.  A read-back hung on the context (cpprob_hip_readback_with_next_result) rides these calls too. */
 int cpprob_hip_weighted_moments_columns(cpprob_hip_ctx* ctx, const double* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, double* h_out4);
 int cpprob_hip_weighted_hist_columns(cpprob_hip_ctx* ctx, const int32_t* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, int32_t k, double* h_out,
                                      double* h_lse_ess /* may be NULL: {logsumexp of the weights, ESS} */);
