@@ -21,11 +21,13 @@ namespace cph {
 
 // One Horner step as ONE instruction.  hipcc turns fma(p, r, c) with a loop-invariant coefficient held in a VGPR into
 // v_mov_b64 + v_fmac_f64 (the two-address form needs a scratch copy of c): an extra vector-issue slot per step in kernels whose
-// bound IS vector issue.  The three-address VOP3 form takes c where it lies.
+// bound IS vector issue.  The three-address VOP3 form takes c where it lies -- and it lies in a SCALAR register pair ("s": one
+// scalar source per VOP3 instruction on this part): the coefficients of exp / log / sincos cost no vector registers and no
+// v_mov to materialise (linear-Gaussian fixed-point step 97 -> 87 registers, four -> five wavefronts a SIMD; same bits).
 __device__ __forceinline__ double horner(double p, double r, double c)
 {
     double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "v"(c));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
     return d;
 }
 
