@@ -916,7 +916,10 @@ __device__ __forceinline__ void smooth_body_fixed_int(const SmoothArgs<Model>& a
     constexpr int K = Model::kStats;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int TK = a.T * K;
-    for (int i = tid; i < kWaves * TK; i += kThreads) s_stat[i] = 0.0;
+    // (the accumulators are INTEGERS -- the weights are: a wavefront's row sums go into them by one LDS add each, exact whatever the
+    //  order, and become doubles once, when the workgroup's partial leaves: no conversion, no fp64 add per row and state)
+    unsigned long long* s_int = reinterpret_cast<unsigned long long*>(s_stat);
+    for (int i = tid; i < kWaves * TK; i += kThreads) s_int[i] = 0ull;
     __syncthreads();
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     auto wave_sum_u36 = [](uint64_t v) -> uint64_t {
@@ -958,8 +961,8 @@ __device__ __forceinline__ void smooth_body_fixed_int(const SmoothArgs<Model>& a
             for (int j = 0; j < K - 1; ++j) { acc[j] = wave_sum_u36(acc[j]); rest -= acc[j]; }
             if (lane == 0) {
 #pragma unroll
-                for (int j = 0; j < K - 1; ++j) s_stat[wv * TK + t * K + j] += u64_to_double(acc[j]) * kFixInv;
-                s_stat[wv * TK + t * K + K - 1] += u64_to_double(rest) * kFixInv;
+                for (int j = 0; j < K - 1; ++j) __hip_atomic_fetch_add(s_int + wv * TK + t * K + j, (unsigned long long)acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(s_int + wv * TK + t * K + K - 1, (unsigned long long)rest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (t > 0 && !a.identity && a.resampled[t - 1]) {
                 const int32_t* arow = a.anc + (int64_t)t * a.rs;
@@ -973,10 +976,10 @@ __device__ __forceinline__ void smooth_body_fixed_int(const SmoothArgs<Model>& a
     else walk(std::integral_constant<int, 1>{});
     __syncthreads();
     for (int i = tid; i < TK; i += kThreads) {
-        double s2 = 0.0;
+        unsigned long long s2 = 0ull;
 #pragma unroll
-        for (int w2 = 0; w2 < kWaves; ++w2) s2 += s_stat[w2 * TK + i];
-        a.stats_part[(int64_t)i * gridDim.x + blockIdx.x] = s2;
+        for (int w2 = 0; w2 < kWaves; ++w2) s2 += s_int[w2 * TK + i];
+        a.stats_part[(int64_t)i * gridDim.x + blockIdx.x] = u64_to_double((uint64_t)s2) * kFixInv;
     }
 }
 
