@@ -763,7 +763,7 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
     // at six a CU: 1536 + 512), and one that divides the tiles badly gives some workgroups a pass more than others.  Chosen once per
     // configuration: k x residency, k = 1 .. 4, with the least padded capacity (ties: the larger grid -- shorter chains per workgroup).
     // hmm<128> at 1.25e7 particles: 2048 -> 6144 workgroups, 1.38 -> 1.20 ms; linear_gaussian_1d<100> at 1e7 keeps 2048 (eight a CU).
-    auto choose_grid = [&](auto kernel) -> int {
+    auto choose_grid = [&](auto kernel, int tiles_at_a_time = kSmoothTiles) -> int {
         if (c->walk_grid > 0) return c->walk_grid;
         int grid = c->smooth_grid, occ = 0;
         if (c->n_cu == 0) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess) c->n_cu = v; }
@@ -775,7 +775,7 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
                 for (int k = 1; k <= 4; ++k) {
                     const int64_t g = R * k;
                     if (g > c->walk_cap) break;
-                    const int64_t per = (sizeof(typename Model::store_t) == 1 && kSmoothTiles > 1 && nt > g) ? kSmoothTiles : 1;
+                    const int64_t per = (sizeof(typename Model::store_t) == 1 && tiles_at_a_time > 1 && nt > g) ? tiles_at_a_time : 1;
                     const int64_t passes = (nt + g * per - 1) / (g * per);
                     const double waste = (double)(passes * g * per) / (double)nt;
                     if (waste <= best * 1.01) { best = std::min(best, waste); grid = (int)std::min<int64_t>(g, nt); }
@@ -826,8 +826,23 @@ void launch_smooth(cpprob_hip_ctx* c, bool with_paths)
             FixedFinal ff{};
             fixed_final_view(c, ff, c->final_bookkeep_pending && !with_paths);
             if (!with_paths) c->final_bookkeep_pending = false;
-            grid_used = choose_grid(smooth_fixed_kernel<Model>);
-            hipLaunchKernelGGL(smooth_fixed_kernel<Model>, dim3(grid_used), dim3(kThreads), shm, c->stream, a, ff, (const uint32_t*)c->d_q[c->cur]);
+            bool int_walk = false;
+            if constexpr (Model::kIsInt) {
+                if (!a.rem) {                                            // every lineage on this device: the integer walk (step_fixed.hpp)
+                    int_walk = true;
+                    if (a.paths) {
+                        grid_used = choose_grid(smooth_fixed_int_kernel<Model, true>, kSmoothTilesInt);
+                        hipLaunchKernelGGL((smooth_fixed_int_kernel<Model, true>), dim3(grid_used), dim3(kThreads), shm, c->stream, a, ff, (const uint32_t*)c->d_q[c->cur]);
+                    } else {
+                        grid_used = choose_grid(smooth_fixed_int_kernel<Model, false>, kSmoothTilesInt);
+                        hipLaunchKernelGGL((smooth_fixed_int_kernel<Model, false>), dim3(grid_used), dim3(kThreads), shm, c->stream, a, ff, (const uint32_t*)c->d_q[c->cur]);
+                    }
+                }
+            }
+            if (!int_walk) {
+                grid_used = choose_grid(smooth_fixed_kernel<Model>);
+                hipLaunchKernelGGL(smooth_fixed_kernel<Model>, dim3(grid_used), dim3(kThreads), shm, c->stream, a, ff, (const uint32_t*)c->d_q[c->cur]);
+            }
             launched = true;
         }
         if (!launched) { grid_used = choose_grid(smooth_kernel<Model>); hipLaunchKernelGGL(smooth_kernel<Model>, dim3(grid_used), dim3(kThreads), shm, c->stream, a); }

@@ -909,7 +909,16 @@ __global__ __launch_bounds__(kThreads) void filter_partials_fixed_kernel(const t
 // of the states 0 .. K-2 (the last state's follows from the lane's total, which no row changes), per wavefront two single-instruction
 // DPP scans a state (18-bit halves of values below 2^36: eight lineages of 32-bit weights) instead of a six-stage fp64 reduction --
 // the walk is bound by vector issue (r04: ~55 %), and the reductions were half of its instructions.  smooth_body's tile order.
-template <class Model>
+// Tiles a workgroup of the INTEGER walk follows at a time: sixteen lineages a lane.  The kernel needs 56 registers (eight wavefronts a
+// SIMD with room to spare) and lives on gathers in flight: hmm<128> at 1.25e7 particles, us per launch, 2 / 3 / 4 tiles: 1002 / 985 / 967.
+#ifndef CPPROB_SMOOTH_TILES_INT
+#define CPPROB_SMOOTH_TILES_INT 4
+#endif
+constexpr int kSmoothTilesInt = CPPROB_SMOOTH_TILES_INT;
+// PATHS: the traces are materialised on the way (dumps / tests) -- a build of its own, so that the walk proper carries no test per lineage
+// and row.  Slots are UNSIGNED 32-bit offsets from a row's base: a gather is the load alone (scalar base + vector offset), no 64-bit
+// address arithmetic in vector registers.
+template <class Model, bool PATHS>
 __device__ __forceinline__ void smooth_body_fixed_int(const SmoothArgs<Model>& a, double* s_stat, const uint32_t* __restrict__ q_last)
 {
     using V = typename Model::value_t;
@@ -931,14 +940,14 @@ __device__ __forceinline__ void smooth_body_fixed_int(const SmoothArgs<Model>& a
     static_assert(NT * kPPT <= 16, "a lane's row sums stay below 2^36");
     for (int64_t tile0 = ntiles <= 2048 ? xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; tile0 < ntiles; tile0 += (int64_t)NT * gridDim.x) {
         constexpr int L = NT * kPPT;
-        int32_t idx[L]; uint32_t w[L];
+        uint32_t idx[L]; uint32_t w[L];
         uint64_t w_lane = 0;
 #pragma unroll
         for (int k = 0; k < L; ++k) {
             const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
             const int64_t i = tile * kTile + (int64_t)(k % kPPT) * kThreads + tid;
             const bool on = tile < ntiles;
-            idx[k] = on ? (int32_t)i : 0;
+            idx[k] = on ? (uint32_t)i : 0u;
             w[k] = on ? q_last[i] : 0u;                                    // padding slots: q = 0
             w_lane += w[k];
         }
@@ -954,7 +963,7 @@ __device__ __forceinline__ void smooth_body_fixed_int(const SmoothArgs<Model>& a
 #pragma unroll
                 for (int j = 0; j < K - 1; ++j) acc[j] += (int)x == j ? (uint64_t)w[k] : 0ull;
                 const int64_t tile = tile0 + (int64_t)(k / kPPT) * gridDim.x;
-                if (a.paths && tile < ntiles) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)(k % kPPT) * kThreads + tid] = x;
+                if (PATHS && tile < ntiles) a.paths[(int64_t)t * a.ld + tile * kTile + (int64_t)(k % kPPT) * kThreads + tid] = x;
             }
             uint64_t rest = w_wave;
 #pragma unroll
@@ -967,12 +976,12 @@ __device__ __forceinline__ void smooth_body_fixed_int(const SmoothArgs<Model>& a
             if (t > 0 && !a.identity && a.resampled[t - 1]) {
                 const int32_t* arow = a.anc + (int64_t)t * a.rs;
 #pragma unroll
-                for (int k = 0; k < L; ++k) idx[k] = arow[idx[k]];
+                for (int k = 0; k < L; ++k) idx[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(arow) + (idx[k] << 2));   // (fixed-point runs: n <= 2^28, the byte offset fits 32 bits)
             }
         }
     }
     };
-    if (kSmoothTiles > 1 && ntiles > (int64_t)gridDim.x) walk(std::integral_constant<int, kSmoothTiles>{});
+    if (kSmoothTilesInt > 1 && ntiles > (int64_t)gridDim.x) walk(std::integral_constant<int, kSmoothTilesInt>{});
     else walk(std::integral_constant<int, 1>{});
     __syncthreads();
     for (int i = tid; i < TK; i += kThreads) {
@@ -992,10 +1001,19 @@ __global__ __launch_bounds__(kThreads) void smooth_fixed_kernel(SmoothArgs<Model
         const FTot t = ftot(ff.f);
         if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q, t.M);
     }
-    if constexpr (Model::kIsInt) {
-        if (!a.rem) { smooth_body_fixed_int<Model>(a, s_stat, q_last); return; }               // (workgroup-uniform)
-    }
     smooth_body<Model>(a, s_stat, [q_last](int64_t, int64_t i) { return (double)q_last[i] * kFixInv; });        // padding slots: q = 0
+}
+// ... discrete models whose lineages stay on this device: the integer walk, a kernel of its own (the general body's registers -- remote
+// stores, fp64 sums -- would cost this one two wavefronts a SIMD, and the walk lives on loads in flight); the host picks it (launch_smooth).
+template <class Model, bool PATHS>
+__global__ __launch_bounds__(kThreads) void smooth_fixed_int_kernel(SmoothArgs<Model> a, FixedFinal ff, const uint32_t* __restrict__ q_last)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_stat[];   // [kWaves][T*K] (integers: smooth_body_fixed_int)
+    if (ff.bookkeep && blockIdx.x == 0 && wave_id() == 0) {
+        const FTot t = ftot(ff.f);
+        if (threadIdx.x == 0) fixed_final_bookkeep(ff, t.S, t.Q, t.M);
+    }
+    smooth_body_fixed_int<Model, PATHS>(a, s_stat, q_last);
 }
 
 // ---- repair of a generation whose weights lost their bits (cpprob_hip.hip: settle_fixed) -------------------------------------------
