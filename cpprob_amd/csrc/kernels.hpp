@@ -2066,13 +2066,35 @@ __global__ __launch_bounds__(kThreads) void lineage_stats_kernel(LineageStatsArg
                 const typename Col::value_t* row = a.cols + (int64_t)h * a.n;
                 typename Col::value_t x[kPPT];
 #pragma unroll
-                for (int k = 0; k < kPPT; ++k) { x[k] = row[idx[k]]; Col::accumulate(x[k], w[k], acc); }
+                for (int k = 0; k < kPPT; ++k) x[k] = row[idx[k]];
+                if constexpr (Col::kBins) {
+                    // Which bins the wavefront holds at all, as ONE mask (a bit per bin, OR-ed over the lanes): a bin nobody holds sums to an
+                    // exact zero and is neither accumulated nor reduced -- a three-state model pays for three of the eight bins.  The bins
+                    // that are taken get the sums they always got (same terms, same order).
+                    uint32_t m = 0;
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    // (a histogram bin no lane of the wavefront holds: its sum is an exact zero, not taken)
-                    if (Col::kBins && __ballot(Col::holds(x, j)) == 0) continue;
-                    const double sj = wave_sum(acc[j]);
-                    if (lane == 0) s_stat[wv * HK + (h - a.h0) * K + j] += sj;
+                    for (int k = 0; k < kPPT; ++k) m |= (uint32_t)x[k] < (uint32_t)K ? 1u << (x[k] & 31) : 0u;
+                    int32_t mm = (int32_t)m;
+                    mm |= dpp_or_i32<kDppRowShr1>(mm, 0); mm |= dpp_or_i32<kDppRowShr2>(mm, 0); mm |= dpp_or_i32<kDppRowShr4>(mm, 0); mm |= dpp_or_i32<kDppRowShr8>(mm, 0);
+                    mm |= dpp_or_i32<kDppRowBcast15, 0xA>(mm, 0); mm |= dpp_or_i32<kDppRowBcast31, 0xC>(mm, 0);
+                    const uint32_t present = (uint32_t)__builtin_amdgcn_readlane(mm, kWave - 1);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        if (!((present >> j) & 1u)) continue;                      // (scalar)
+                        double aj = 0.0;
+#pragma unroll
+                        for (int k = 0; k < kPPT; ++k) aj += x[k] == j ? w[k] : 0.0;
+                        const double sj = wave_sum(aj);
+                        if (lane == 0) s_stat[wv * HK + (h - a.h0) * K + j] += sj;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) Col::accumulate(x[k], w[k], acc);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const double sj = wave_sum(acc[j]);
+                        if (lane == 0) s_stat[wv * HK + (h - a.h0) * K + j] += sj;
+                    }
                 }
             }
             if (t > 0 && a.resampled[t - 1]) {
