@@ -1372,7 +1372,13 @@ static int pin_reserve(cpprob_hip_ctx* c, size_t bytes)                 // bytes
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 16);
-    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), want, hipHostMallocPortable | hipHostMallocMapped));
+    // (coherent, i.e. fine-grained: the host sees the sequence word while the stream is still busy; a runtime that refuses the flag
+    //  combination still gets a correct block -- pin_wait falls back to the stream's completion)
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), want, hipHostMallocCoherent | hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        c->h_pin = nullptr;
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), want, hipHostMallocPortable | hipHostMallocMapped));
+    }
     std::memset(c->h_pin, 0, kPinHeader);
     c->h_pin_cap = want; c->pin_seq = 0;
     return 0;
