@@ -1117,6 +1117,14 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     HIP_TRY(c, hipMalloc(&c->d_obs, n_obs * sizeof(double)));
     HIP_TRY(c, hipMemcpyAsync(c->d_obs, h_obs, n_obs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_resampled, 0, (size_t)c->T * sizeof(int32_t), c->stream));
+    // (the trace-word read-out's counters: allocated HERE, not by the first run that needs them -- a context made for one run paid two
+    //  hipMalloc and two clears inside that run's clock: ~40 us of a 150-us run through cpprob::inference)
+    if (cfg->algorithm == CPPROB_HIP_ALG_SMC && cfg->model == CPPROB_HIP_MODEL_HMM3 && c->T <= kTraceMaxT && !c->d_trace_cnt) {
+        HIP_TRY(c, hipMalloc(&c->d_trace_cnt, kTraceCounterWords * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_trace_arrive, sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemsetAsync(c->d_trace_cnt, 0, kTraceCounterWords * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_trace_arrive, 0, sizeof(unsigned long long), c->stream));
+    }
     HIP_TRY(c, hipMemcpyAsync(&c->d_ctrl->lz_trace, &c->d_lz_trace, sizeof(double*), hipMemcpyHostToDevice, c->stream));
     if (multinomial && c->d_strata_top) {                      // (its layout follows T; a run abandoned between its two launches leaves totals behind)
         HIP_TRY(c, hipMemsetAsync(c->d_strata_top, 0, (size_t)2 * c->T * 64 * sizeof(uint32_t), c->stream));
