@@ -45,6 +45,47 @@ private:
     cpprob_hip_ctx* h_ = nullptr;
 };
 
+// Contexts are kept between two cpprob::inference calls (the reference's call is `inference(...)` again and again, src/main.cpp:96-100):
+// a context made per call cost 1.6-2.2 ms of stream and buffer creation around a 0.2 ms run of 10^6 HMM particles.  A call leases one
+// for its device (concurrent calls get contexts of their own); cpprob::gpu::release_device_resources() destroys the idle ones -- they
+// are deliberately not torn down by static destructors, which run when the HIP runtime may already be gone.
+struct ContextPool { std::mutex mu; std::vector<std::pair<int, std::unique_ptr<Context>>> idle; };
+CPPROB_REGISTRY_VISIBLE inline ContextPool& context_pool() { static ContextPool* p = new ContextPool; return *p; }
+inline void release_contexts()
+{
+    ContextPool& p = context_pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    p.idle.clear();
+}
+class ContextLease {
+public:
+    explicit ContextLease(int device) : device_(device)
+    {
+        ContextPool& p = context_pool();
+        {
+            std::lock_guard<std::mutex> lock(p.mu);
+            for (auto it = p.idle.begin(); it != p.idle.end(); ++it)
+                if (it->first == device) { c_ = std::move(it->second); p.idle.erase(it); break; }
+        }
+        if (!c_) { c_.reset(new Context(device)); add_release_hook(&release_contexts); }
+    }
+    ~ContextLease()
+    {
+        // (a call that threw leaves its context in an unknown state: destroyed, not returned)
+        if (!ok_) return;
+        ContextPool& p = context_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        p.idle.emplace_back(device_, std::move(c_));
+    }
+    Context& operator*() const { return *c_; }
+    Context* operator->() const { return c_.get(); }
+    void done() { ok_ = true; }
+private:
+    int device_;
+    std::unique_ptr<Context> c_;
+    bool ok_ = false;
+};
+
 // ---- flatten the observes tuple into doubles (scalars and std::array<double, N>) -----------------
 template <class T, std::enable_if_t<std::is_arithmetic<T>::value, int> = 0>
 void flatten_one(std::vector<double>& out, T x) { out.push_back(static_cast<double>(x)); }
@@ -193,7 +234,9 @@ inline void run_builtin_group(StateType algorithm, int model_id, const std::vect
 inline void run_builtin(StateType algorithm, int model_id, const std::vector<double>& obs, std::size_t n, const detail::TraceStructure& st,
                         const Options& opt, Result& res, HostStore* store)
 {
-    Context ctx(opt.device);
+    const auto t_setup = std::chrono::steady_clock::now();
+    ContextLease lease(opt.device);
+    Context& ctx = *lease;
     cpprob_hip_config cfg{};
     cfg.algorithm = algorithm == StateType::smc ? CPPROB_HIP_ALG_SMC : CPPROB_HIP_ALG_SIS;
     cfg.model = model_id;
@@ -207,6 +250,7 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
     ctx.check(cpprob_hip_infer_begin(ctx.get(), &cfg, obs.data(), obs.size()), "cpprob_hip_infer_begin");
     ctx.check(cpprob_hip_sync(ctx.get()), "cpprob_hip_sync");          // (begin's buffer clears are allocation: not the run's time)
     const auto t0 = std::chrono::steady_clock::now();
+    res.setup_seconds = std::chrono::duration<double>(t0 - t_setup).count();      // (context, buffers, clears: what a call adds to its run)
     ctx.check(cpprob_hip_infer_run(ctx.get(), 0), "cpprob_hip_infer_run");
     // (everything the result holds in ONE read-back behind one stream synchronisation; sizes from the model structure: the engine
     //  fills exactly n_predict * stats_per_predict doubles -- histograms of up to 8 bins, or {mean, variance})
@@ -299,6 +343,7 @@ inline void run_builtin(StateType algorithm, int model_id, const std::vector<dou
         res.log_evidence_mean = mx + std::log(acc / R);
         res.log_evidence_sd = std::sqrt(vl / (R - 1));
     }
+    lease.done();                                                     // (the context goes back to the pool)
 }
 
 // ---- unchanged models over several GPUs ----------------------------------------------------------------------------------------
