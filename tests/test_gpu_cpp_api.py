@@ -227,6 +227,21 @@ def test_unchanged_model_keeps_its_context_and_workspace_across_inference_calls(
     assert res["workspace_grown"] is False and res["step_form"] == 1
 
 
+def test_builtin_registration_keeps_its_context_across_inference_calls(tmp_path):
+    """The same for the built-in registration (cpprob::gpu::ContextLease): a context made per call cost ~2 ms of stream and buffer
+    creation around a 0.2 ms run; a later call finds the first one's -- and, same seed, returns the same numbers; a call with another
+    model and size in between reconfigures it."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    res, out, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(z["hmm16"]), "--n_samples", 200000, "--seed", 3, "--ess_threshold", 2.0,
+                           "--json", "--no_dump", "--repeat", 4)
+    setups = [float(l.split("set-up")[1].split("ms")[0]) for l in out.splitlines() if l.startswith("run ")]
+    assert res["builtin"] and len(setups) == 4 and setups[0] > 5.0 and max(setups[1:]) < 1.0
+    once, _, _ = run_main(tmp_path, "--model", "hmm16", "--smc", "--observes", obs_str(z["hmm16"]), "--n_samples", 200000, "--seed", 6, "--ess_threshold", 2.0,
+                          "--json", "--no_dump")
+    # (--repeat moves the seed on by one a call: the fourth call on the kept context = a first call on a fresh one with that seed)
+    assert once["log_evidence"] == res["log_evidence"] and once["predicts"] == res["predicts"]
+
+
 def test_filtering_only_run_from_the_cpp_host(tmp_path):
     """cpprob::gpu::options().keep_history = false (CLI --filtering_only): the reference's call, an O(N) particle store, the
     filtering marginals instead of the whole-trace posterior, the same evidence."""
