@@ -32,10 +32,15 @@
 #include "cpprob/detail/device_trace.hpp"
 #endif
 
+// The statements are part of the model's kernel, not functions it calls: the launch's mode reaches them as compile-time facts of the
+// kernel they are inlined into (cpprob/gpu.hpp: __builtin_assume), their counters live in its registers, and the step's observe ends
+// its wavefront.  Whatever the optimisation level says about inlining (at -O3 hipcc left them as calls), they are inlined.
+#define CPPROB_STATEMENT __attribute__((always_inline))
+
 namespace cpprob {
 
 template <class Distribution, class String>
-CPPROB_HD auto sample(Distribution&& distr, const bool control, String&& address) -> typename std::decay_t<Distribution>::result_type
+CPPROB_HD CPPROB_STATEMENT auto sample(Distribution&& distr, const bool control, String&& address) -> typename std::decay_t<Distribution>::result_type
 {
     (void)control; (void)address;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -46,7 +51,7 @@ CPPROB_HD auto sample(Distribution&& distr, const bool control, String&& address
 }
 
 template <class Distribution>
-CPPROB_HD auto sample(Distribution&& distr, const bool control = false) -> typename std::decay_t<Distribution>::result_type
+CPPROB_HD CPPROB_STATEMENT auto sample(Distribution&& distr, const bool control = false) -> typename std::decay_t<Distribution>::result_type
 {
     (void)control;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -57,7 +62,7 @@ CPPROB_HD auto sample(Distribution&& distr, const bool control = false) -> typen
 }
 
 template <class Distribution>
-CPPROB_HD void observe(Distribution&& distr, const typename std::decay_t<Distribution>::result_type& x)
+CPPROB_HD CPPROB_STATEMENT void observe(Distribution&& distr, const typename std::decay_t<Distribution>::result_type& x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     device::observe_impl(distr, x);
@@ -67,7 +72,7 @@ CPPROB_HD void observe(Distribution&& distr, const typename std::decay_t<Distrib
 }
 
 template <class T, class String>
-CPPROB_HD void predict(T&& x, String&& addr)
+CPPROB_HD CPPROB_STATEMENT void predict(T&& x, String&& addr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)addr;
@@ -78,7 +83,7 @@ CPPROB_HD void predict(T&& x, String&& addr)
 }
 
 template <class T>
-CPPROB_HD void predict(T&& x)
+CPPROB_HD CPPROB_STATEMENT void predict(T&& x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     device::predict_impl(x);

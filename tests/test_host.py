@@ -274,6 +274,33 @@ def test_reference_models_header_compiles_unchanged_for_device(tmp_path):
     assert "model_kernel" in subprocess.check_output(["strings", out]).decode()
 
 
+_ONE_MODEL_TU = r"""
+#include "cpprob/gpu.hpp"
+#pragma clang force_cuda_host_device begin
+#include "target_models.hpp"
+#pragma clang force_cuda_host_device end
+CPPROB_REGISTER_MODEL(models::hmm<16>);
+"""
+
+
+def test_statements_are_inlined_into_the_model_kernels_at_every_optimisation_level(tmp_path):
+    """The statements are part of the model's kernel (the launch's mode reaches them as compile-time facts, their counters live in its
+    registers, the step's observe ends its wavefront): at -O3 hipcc used to leave cpprob::sample / observe as CALLS -- and that build
+    faulted on the device.  The device code of a model translation unit holds no call at -O3 (nor at -O2)."""
+    src = tmp_path / "one_model.hip"
+    src.write_text(_ONE_MODEL_TU)
+    for opt in ("-O3", "-O2"):
+        out = str(tmp_path / ("one_model%s.s" % opt))
+        cmd = ["/opt/rocm/bin/hipcc", opt, "-std=c++17", "--offload-arch=gfx950", "-fPIC", "--cuda-device-only", "-S",
+               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cpprob_amd", "include"), "-I", os.path.join(ROOT, "cpprob_amd", "examples"),
+               "-o", out, str(src)]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        asm = open(out).read()
+        assert "model_step_kernel" in asm and "model_kernel" in asm
+        assert "s_swappc_b64" not in asm and "s_setpc_b64" not in asm, opt
+
+
 def test_host_driver_is_plain_cpp14_and_fails_loudly_without_gpu():
     from cpprob_amd import build as B
     B.build_all()
