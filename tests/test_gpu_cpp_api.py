@@ -566,6 +566,13 @@ def test_markov_probe_finds_the_replay_window_and_changes_no_number(tmp_path, mo
     for pd, pb in zip(d["predicts"], b["predicts"]):
         if "mean" in pd: assert abs(pd["mean"] - pb["mean"]) < 0.05
         else: assert np.abs(np.array(pd["p"]) - np.array(pb["p"][:len(pd["p"])])).max() < 0.02
+    if window >= 0:
+        # ... and four particles a lane behind one ancestor search (step form 3): the default form's arithmetic, every number the same
+        q, _, _ = run_main(tmp_path, *common, "--step_form", 3)
+        assert q["step_form"] == 3 and q["replay_window"] == window
+        assert q["log_evidence"] == d["log_evidence"] and q["n_resampled"] == d["n_resampled"] and q["ess"] == d["ess"]
+        for pq, pd in zip(q["predicts"], d["predicts"]):
+            assert pq == pd
 
 
 def test_device_pilot_refutes_a_window_the_host_probe_lets_through(tmp_path):
