@@ -625,9 +625,11 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
         if (!ok) use = &st_full;
     }
     StepForm form = st.bounds_fixed ? StepForm::fused_bounded : StepForm::fused_exact;
-    // (four particles a lane pays where the population fills the chip several times over and the model's loop is short: hmm<16> at 10^7
-    //  particles 3.47-3.55 ms against 3.59-3.75; at 10^6 it is latency bound, at T >= 100 its dead iterations cost more: profiles/r05_notes.md)
-    if (form == StepForm::fused_bounded && n >= std::size_t(4000000) && st.n_observe <= 32) form = StepForm::fused_quad;
+    // (four particles a lane pays where the population fills the chip several times over and the model's loop is short -- tools/
+    //  ab_quad_threshold.sh, ms per run, one a lane / four a lane: hmm<16> 1.5e6 0.697 / 0.637, 3e6 1.22 / 1.11, 6e6 2.24 / 1.94, 1e7 3.78 / 3.27;
+    //  linear_gaussian_1d<25> 2e6 1.54 / 1.64, 3e6 2.21 / 2.18, 6e6 4.36 / 4.01; at 10^6 it is latency bound, at T >= 100 its dead iterations
+    //  cost more than the shared search saves: profiles/r05_notes.md section 8)
+    if (form == StepForm::fused_bounded && st.n_observe <= 32 && n >= std::size_t(st.n_observe <= 16 ? 1500000 : 3000000)) form = StepForm::fused_quad;
     if (opt.step_form_override >= 0) {
         if (opt.step_form_override > 3) throw std::invalid_argument("cpprob::gpu::Options::step_form_override: 0 (unfused), 1 (bounded), 2 (exact maximum) or 3 (bounded, four particles a lane)");
         form = static_cast<StepForm>(opt.step_form_override);

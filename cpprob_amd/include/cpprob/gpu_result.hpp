@@ -68,7 +68,7 @@ struct Result {
     int joint_flag = 0;                       // (a rank's share of a joint run: the flag its generations raised)
     std::string joint_note;                   // why a multi-device smc call of an unchanged model ran islands, or that its joint run is unvalidated on real links
     int step_form = 0;                        // unchanged-model smc: 0 separate bookkeeping launches, 1 fused step on bounded references, 2 fused step + exact-maximum pass,
-                                              // 3 = 1 with four particles a lane behind one ancestor search (chosen from 4e6 particles on where the model has <= 32 observes)
+                                              // 3 = 1 with four particles a lane behind one ancestor search (chosen for large populations of models with <= 32 observes)
     int launches_per_step = 0;                // unchanged-model smc: dependent launches per observe
     double setup_seconds = 0;                 // unchanged-model path: context / workspace / scratch set-up and the Markov pilot of THIS call (0.0x ms once the workspace is warm)
     bool workspace_grown = false;             // ... this call created or enlarged its device workspace
