@@ -489,8 +489,8 @@ def main():
     reruns = 0
     xtraffic = None
     rs_id, rs_flags = resampler_of(args.resampler)
-    if args.resampler not in ("systematic", "stratified") and (world > 1 or args.loopback_ranks > 1):
-        sys.stderr.write("bench.py: --resampler %s runs on one GPU (the exchange scope resamples systematically or stratified)\n" % args.resampler)
+    if args.resampler not in ("systematic", "stratified", "multinomial") and (world > 1 or args.loopback_ranks > 1):
+        sys.stderr.write("bench.py: --resampler %s runs on one GPU (the exchange scope resamples systematically, stratified or multinomially in the strata form)\n" % args.resampler)
         sys.exit(2)
     if world == 1 and args.loopback_ranks > 1 and smc:
         group = cp.Group([local] * args.loopback_ranks)

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(kThreads) void bbf_ancestors_kernel(BbfArgs a)
             if constexpr (RS == kFixMultinomial) {
                 ProbeWords pw;
                 probe_fetch(a.f.h, bid, nb, pw);
-                const StrataLocated sl = strata_locate(a.f, a.strata_offs, a.strata_k, nb, bid, (uint32_t)((int64_t)bid * kTile), (uint32_t)((int64_t)bid * kTile + n_out - 1), tot.S, pw);
+                const StrataLocated sl = strata_locate(a.f, a.strata_offs, a.strata_k, nb, strata_near(a.strata_k, nb, bid), bid, (uint32_t)((int64_t)bid * kTile),
+                                                       (uint32_t)((int64_t)bid * kTile + n_out - 1), tot.S, 0ull, tot.S, &pw);
                 loc = sl.loc; w0 = sl.w0; w1 = sl.w1;
             } else loc = fixed_locate<RS>(a.f, fc, nb, gj_first, n_out, bid, nullptr);
         }
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(kThreads) void bbf_ancestors_kernel(BbfArgs a)
         if constexpr (RS == kFixMultinomial) {
             StrataLocated sl;
             sl.loc = s_found.loc; sl.w0 = s_w0; sl.w1 = s_w1;
-            strata_walk(a.strata_offs, a.strata_k, a.q, nb, sl, s_S, j0, a.seed, kResampleDrawBase2 + (uint64_t)a.step + 1, (uint64_t)j0, anc, L);
+            bool mine[kPPT];
+            strata_walk(a.strata_offs, a.strata_k, a.q, nb, sl, s_S, j0, a.seed, kResampleDrawBase2 + (uint64_t)a.step + 1, (uint64_t)j0, anc, L, 0ull, s_S, mine);
         } else {
             const U4 z = {0u, 0u, 0u, 0u};
             fixed_walk<RS>(fc, a.q, a.n, nb, true, gj_first, n_out, s_found.loc, bid, false, z, z, z, anc, L);

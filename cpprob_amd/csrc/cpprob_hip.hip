@@ -81,6 +81,9 @@ struct cpprob_hip_ctx {
     uint32_t* d_bbf_strata = nullptr; uint32_t* d_bbf_strata_top = nullptr; size_t bbf_strata_cap = 0;     // ... of the bookkeeping protocol (cpprob_hip_smc_bookkeep_fixed_rs)
     uint32_t* d_strata = nullptr;   // multinomial, strata form: [T - 1][2^k + 1] first outputs of the strata, every step of the run
     uint32_t* d_strata_top = nullptr; int strata_phase = 0; bool strata_pending = false;   // ... [2][T][64] totals of the level-6 nodes (the set in use alternates run by run)
+    size_t strata_cap_words = 0; int strata_cap_T = 0;
+    // ... of one shard of a joint population (exchange scope, strata_cut.hpp): what the ranks' boundaries cut, rewritten by every exchange
+    uint32_t* d_cut_tab = nullptr; CutHead* d_cut_head = nullptr; uint32_t* d_cut_srccnt = nullptr;
     double* d_cdf = nullptr;        // multinomial only
     int32_t* d_anc_pre = nullptr;   // multinomial only
     double* d_local_totals = nullptr;
@@ -451,9 +454,9 @@ bool counts_eligible(const cpprob_hip_ctx* c)
                 // (stratified resampling: the same walk with the outputs' own uniforms)
                 : c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED
                 ? (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)
-                // (multinomial, strata form: one population per context; the literal form runs on fixed-point masses)
-                : (!(c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL) && c->cfg.resample_scope != CPPROB_HIP_SCOPE_EXCHANGE &&
-                   (c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)));
+                // (multinomial, strata form: a population of its own or one shard of the exchange scope; the literal form runs on fixed-point masses)
+                : (!(c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL) &&
+                   (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND)));
 }
 
 // Philox4x32-10 on the host (cpprob/detail/rng.hpp's draw_block): the systematic offset of a resampling step is a pure function of
@@ -487,6 +490,10 @@ static void hier_view(const cpprob_hip_ctx* c, int copy, Hier& h)
 
 static void hier_rotation(cpprob_hip_ctx* c, int t, int& kp, int& kn, int& kc);
 static void launch_strata(cpprob_hip_ctx* c);
+// multinomial resampling, strata form: the outputs the strata are drawn for -- the population's in the exchange scope, else this context's
+static uint64_t strata_outputs(const cpprob_hip_ctx* c) { return c->exchange ? c->pop_n : (uint64_t)c->n; }
+static int strata_k_of(const cpprob_hip_ctx* c) { return strata_levels((int64_t)((strata_outputs(c) + kTile - 1) / kTile)); }
+static CutView cut_view(const cpprob_hip_ctx* c) { return CutView{c->d_cut_tab, c->d_cut_head, c->d_cut_srccnt}; }
 
 template <class Model>
 void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int world, int rank)
@@ -520,10 +527,12 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         if (c->step_protocol && c->trace_shard_run) { a.trace_prev = c->d_tr[(t + 1) & 1]; a.trace_next = c->d_tr[t & 1]; }
         ProfScope ps(c, 0);
         if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL) {
-            a.strata_k = strata_levels(c->nb);
+            a.strata_k = strata_k_of(c);
             if (t == 0) launch_strata(c);
             a.strata_offs = t > 0 ? c->d_strata + (size_t)(t - 1) * (((size_t)1 << a.strata_k) + 1) : nullptr;
-            hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            a.cut = cut_view(c);
+            if (all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+            else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         }
         else if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED && all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED) hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
@@ -542,7 +551,9 @@ bool fixed_eligible(const cpprob_hip_ctx* c)
     constexpr bool model_ok = std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value || std::is_same<Model, ModelHmmK>::value;
     // (stratified and multinomial resampling run on the same integer masses; multinomial: one population per context)
     const bool own = c->cfg.n_global == c->cfg.n_particles || c->cfg.resample_scope == CPPROB_HIP_SCOPE_ISLAND;
-    const bool systematic = c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC || c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED;      // (one interval of outputs per rank)
+    // (one interval of outputs per rank -- the strata form of multinomial resampling: one interval + the strata the ranks' boundaries cut)
+    const bool systematic = c->cfg.resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC || c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED ||
+                            (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && !(c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL));
     return model_ok && !c->force_fp && !(c->cfg.flags & CPPROB_HIP_FLAG_FLOATING_POINT_STEP) && c->nb <= kCountsMaxTiles && c->pop_n <= (1ull << 28) &&
            c->cfg.algorithm == CPPROB_HIP_ALG_SMC && !counts_eligible<Model>(c) &&
            (systematic ? (c->cfg.resample_scope == CPPROB_HIP_SCOPE_EXCHANGE || own) : (own && c->cfg.resample_scope != CPPROB_HIP_SCOPE_EXCHANGE));
@@ -575,7 +586,8 @@ static void launch_strata(cpprob_hip_ctx* c)
     if (c->T < 2 || !c->d_strata) return;
     ProfScope ps(c, 5);
     StrataArgs sa{};
-    sa.seed = c->run_seed; sa.t0 = 1; sa.k = strata_levels(c->nb); sa.n_out = (uint32_t)c->n; sa.offs = c->d_strata;
+    // (a shard of a joint population draws the POPULATION's strata: every rank holds the whole table, a function of the seed alone)
+    sa.seed = c->run_seed; sa.t0 = 1; sa.k = strata_k_of(c); sa.n_out = (uint32_t)strata_outputs(c); sa.offs = c->d_strata;
     if (sa.k <= kStrataTop) hipLaunchKernelGGL(multinomial_strata_kernel, dim3(1, c->T - 1), dim3(kThreads), 0, c->stream, sa);
     else {
         // (two sets of the steps' level-6 totals: the bottom launch clears the set the NEXT run adds into)
@@ -609,9 +621,10 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
                      : (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL ? ((c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL) ? kFixMultinomialLiteral : kFixMultinomial) : kFixSystematic);
         if (rs == kFixMultinomial) {
             a.prefetch = 0;
-            a.strata_k = strata_levels(c->nb);
+            a.strata_k = strata_k_of(c);
             if (t == 0) launch_strata(c);
             a.strata_offs = t > 0 ? c->d_strata + (size_t)(t - 1) * (((size_t)1 << a.strata_k) + 1) : nullptr;
+            a.cut = cut_view(c);
         }
         if (rs == kFixMultinomialLiteral) {
             // the lanes' in-tile prefixes travel with the weights (ping-pong, in the halves of the floating-point form's CDF array);
@@ -634,7 +647,9 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
             // A/B form (CPPROB_HIP_FLAG_PAIRED_STEP_LAUNCH): on schedules where a step may not resample, the step as two launches, each ending
             // at once when the step is the other's (step_fixed.hpp: smc_step_fixed_carry_body).  Measured at configs[4]'s shard: the carry
             // launch takes 70 us where the two-form kernel's non-resampling launches take 81, and the second launch costs what that saves.
-            const bool paired = a.may_carry && t > 0 && (c->cfg.flags & CPPROB_HIP_FLAG_PAIRED_STEP_LAUNCH) && rs != kFixMultinomialLiteral;
+            // (the A/B form has no sharded build of the stratified / multinomial resampling launch: those shards take the one-launch step)
+            const bool paired = a.may_carry && t > 0 && (c->cfg.flags & CPPROB_HIP_FLAG_PAIRED_STEP_LAUNCH) && rs != kFixMultinomialLiteral &&
+                                !(all_totals != nullptr && rs != kFixSystematic);
             if (paired) {
                 const bool sh = all_totals != nullptr;
                 if (sh) hipLaunchKernelGGL((smc_step_fixed_carry_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
@@ -644,6 +659,7 @@ void launch_step_fixed(cpprob_hip_ctx* c, int t, const double* all_totals, int w
                 else if (sh) hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, true, kFixSystematic>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
                 else hipLaunchKernelGGL((smc_step_fixed_resampling_kernel<Model, false, kFixSystematic>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             }
+            else if (rs == kFixMultinomial && all_totals) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixMultinomial) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomial>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixMultinomialLiteral) hipLaunchKernelGGL((smc_step_fixed_kernel<Model, false, kFixMultinomialLiteral>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
             else if (rs == kFixStratified && all_totals && a.prefetch) hipLaunchKernelGGL((smc_step_fixed_sharded_kernel<Model, true, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
@@ -927,7 +943,7 @@ void cpprob_hip_destroy(cpprob_hip_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_run_buffers(c);
-    dfree(c->d_ctrl); dfree(c->d_local_totals);
+    dfree(c->d_ctrl); dfree(c->d_local_totals); dfree(c->d_cut_tab); dfree(c->d_cut_head); dfree(c->d_cut_srccnt);
     dfree(c->d_send_src); dfree(c->d_hk_thr); dfree(c->d_hk_ll); dfree(c->d_hier_table); dfree(c->d_wpart); dfree(c->d_xplan); dfree(c->d_shard_begin); dfree(c->d_slot_of_rank); dfree(c->d_xsend); dfree(c->d_xrecv); dfree(c->d_peer_recv); dfree(c->d_peer_slot); dfree(c->d_sent); dfree(c->d_origin); dfree(c->d_remote); dfree(c->d_annex_all);
     if (c->h_obound) { (void)hipHostFree(c->h_obound); c->h_obound = nullptr; }
     if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_cap = 0; }
@@ -989,9 +1005,10 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     if (cfg->resample_scope != CPPROB_HIP_SCOPE_GLOBAL && cfg->resample_scope != CPPROB_HIP_SCOPE_ISLAND && cfg->resample_scope != CPPROB_HIP_SCOPE_EXCHANGE)
         return fail(c, CPPROB_HIP_EINVAL, "unknown resample_scope");
     const bool exchange = cfg->resample_scope == CPPROB_HIP_SCOPE_EXCHANGE && cfg->algorithm == CPPROB_HIP_ALG_SMC;
-    if (exchange && cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL)
-        return fail(c, CPPROB_HIP_EUNSUPPORTED, "the exchange scope resamples systematically or stratified: the outputs a rank's sources own are then ONE interval, computable from the "
-                                                 "ranks' totals (multinomial thresholds are not sorted across the ranks' boundary)");
+    if (exchange && cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && ((cfg->flags & (CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL | CPPROB_HIP_FLAG_FLOATING_POINT_STEP)) || cfg->keep_history == 0))
+        return fail(c, CPPROB_HIP_EUNSUPPORTED, "multinomial resampling in the exchange scope is the strata form on integer weights with histories kept: its thresholds come stratum by "
+                                                 "stratum, so a rank's sources own one interval of outputs plus its share of the strata the ranks' boundaries cut (not the literal form, "
+                                                 "not the floating-point step, not keep_history = 0)");
     c->cfg = *cfg;
     // a model with ONE observe statement has nothing to resample between: smc is sis (the components of its vector-valued
     // statements are rows of the particle store, not resampling points)
@@ -1027,7 +1044,9 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
     // default: what a well-mixed run needs -- a rank's offspring interval leaves its shard by O(sqrt(N)) outputs per resampling, so
     // ~sqrt(n_global) immigrants per step and T steps of them (measured 0.5 sqrt(N) per rank-step on BASELINE configs[3]) -- and at
     // least a sixteenth of the shard; a run that needs more reports overflow and is repeated with four times as much
-    const int64_t annex_mixed = (int64_t)(std::sqrt((double)cfg->n_global) * (double)c->T) / kTile * kTile;
+    // (multinomial resampling, strata form: the two strata a rank's boundaries cut hand it up to ~a tile of immigrants a step whatever N is)
+    const int64_t annex_strata = (exchange && cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL) ? (int64_t)c->T * (kTile + kTile / 2) : 0;
+    const int64_t annex_mixed = (int64_t)(std::sqrt((double)cfg->n_global) * (double)c->T) / kTile * kTile + annex_strata;
     const int64_t annex_want = cfg->annex_kcols > 0 ? (int64_t)cfg->annex_kcols * 1024 : std::max<int64_t>(std::max<int64_t>(4 * kTile, c->ld / 16 / kTile * kTile), annex_mixed);
     const int64_t annex0 = exchange ? std::max<int64_t>(c->annex_cap, annex_want) : 0;
     c->ssz = 8;
@@ -1082,10 +1101,6 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
             HIP_TRY(c, hipMemsetAsync(c->d_annex_base, 0, (T + 1) * sizeof(int64_t), c->stream));
         }
         if (multinomial) {
-            HIP_TRY(c, hipMalloc(&c->d_strata, (size_t)T * (((size_t)1 << strata_levels(c->nb)) + 1) * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc(&c->d_strata_top, (size_t)2 * T * 64 * sizeof(uint32_t)));
-            HIP_TRY(c, hipMemsetAsync(c->d_strata_top, 0, (size_t)2 * T * 64 * sizeof(uint32_t), c->stream));
-            c->strata_phase = 0;
             HIP_TRY(c, hipMalloc(&c->d_cdf, ld * sizeof(double)));
             HIP_TRY(c, hipMalloc(&c->d_anc_pre, ld * sizeof(int32_t)));
         }
@@ -1109,6 +1124,24 @@ int cpprob_hip_infer_begin(cpprob_hip_ctx* c, const cpprob_hip_config* cfg, cons
         HIP_TRY(c, hipMemcpyAsync(c->d_hier_table, &c->hier, sizeof(HierTable), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream));     // (the layout may have changed)
         c->hier_phase = 0; c->hier_run_open = false;
+    }
+    if (multinomial) {
+        // the strata of every step of a run ([T - 1][2^k + 1]; a shard of a joint population holds the POPULATION's) and the level-6 totals
+        const size_t words = (size_t)c->T * (((size_t)1 << strata_k_of(c)) + 1);
+        if (words > c->strata_cap_words || c->T > c->strata_cap_T || !c->d_strata || !c->d_strata_top) {
+            dfree(c->d_strata); dfree(c->d_strata_top);
+            HIP_TRY(c, hipMalloc(&c->d_strata, words * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_strata_top, (size_t)2 * c->T * 64 * sizeof(uint32_t)));
+            c->strata_cap_words = words; c->strata_cap_T = c->T;
+        }
+        if (exchange && !c->d_cut_tab) {
+            HIP_TRY(c, hipMalloc(&c->d_cut_tab, (size_t)kCutSlots * kCutRow * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_cut_head, (size_t)kCutSlots * sizeof(CutHead)));
+            HIP_TRY(c, hipMalloc(&c->d_cut_srccnt, (size_t)kCutSlots * kCutSlots * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemsetAsync(c->d_cut_tab, 0, (size_t)kCutSlots * kCutRow * sizeof(uint32_t), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_cut_head, 0, (size_t)kCutSlots * sizeof(CutHead), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_cut_srccnt, 0, (size_t)kCutSlots * kCutSlots * sizeof(uint32_t), c->stream));
+        }
     }
     c->rs = c->ld + c->annex_cap;
     c->annex_used = 0; c->plan.t = -1; c->x_plan_t = -1; c->x_all_totals = nullptr;
@@ -1698,6 +1731,52 @@ void launch_pack(cpprob_hip_ctx* c, int t, R* d_send, int grid, bool plan_inside
     hipLaunchKernelGGL((exchange_pack_kernel<Model, R, kPackFloat, false>), pgrid, dim3(kThreads), 0, c->stream, a);
 }
 
+// Multinomial resampling (strata form) in the exchange scope, remote lineages: what the ranks' boundaries cut (one workgroup per
+// boundary), then the packing launch that derives the plan from it and stores every migrant into its column of the receiver's annex.
+static bool strata_exchange(const cpprob_hip_ctx* c)
+{
+    return c->exchange && c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && (c->counts_mode || c->fixed_mode);
+}
+template <class Model>
+void launch_pack_strata(cpprob_hip_ctx* c, int t, int grid)
+{
+    const int k = strata_k_of(c);
+    const uint32_t* offs = c->d_strata + (size_t)t * (((size_t)1 << k) + 1);      // the strata of the resampling in front of step t + 1
+    if (c->x_world > 1) {
+        CutArgs ca{};
+        ca.world = c->x_world; ca.shard_begin = c->d_shard_begin; ca.offs = offs; ca.k = k; ca.seed = c->run_seed; ca.draw2 = kResampleDrawBase2 + (uint64_t)t + 1;
+        ca.totals_u = reinterpret_cast<const uint64_t*>(c->x_all_totals); ca.n_pop = (double)c->pop_n; ca.ess_frac = c->cfg.ess_threshold;
+        ca.totals_d = c->x_all_totals;
+        if (c->counts_mode) { ca.e0 = c->h_e_tab[(size_t)t * 4]; ca.e1 = c->h_e_tab[(size_t)t * 4 + 1]; ca.e2 = c->h_e_tab[(size_t)t * 4 + 2]; }
+        ca.tab = c->d_cut_tab; ca.head = c->d_cut_head; ca.srccnt = c->d_cut_srccnt;
+        if (c->counts_mode) hipLaunchKernelGGL((exchange_cut_kernel<true>), dim3((unsigned)(c->x_world - 1)), dim3(kThreads), 0, c->stream, ca);
+        else hipLaunchKernelGGL((exchange_cut_kernel<false>), dim3((unsigned)(c->x_world - 1)), dim3(kThreads), 0, c->stream, ca);
+    }
+    PackStrataArgs<Model> a{};
+    a.values = static_cast<const typename Model::store_t*>(c->d_values); a.rs = c->rs; a.n = c->n; a.nb = c->nb; a.t = t;
+    a.world = c->x_world; a.rank = c->x_rank; a.pid0 = c->cfg.particle_offset; a.n_pop = (double)c->pop_n;
+    a.geom.world = c->x_world; a.geom.rank = c->x_rank; a.geom.n = c->n; a.geom.shard_begin = c->d_shard_begin; a.geom.slot_of_rank = nullptr;
+    a.geom.cap = (int64_t)1 << 40; a.geom.annex_cap = c->annex_cap; a.geom.bytes_per_value = (int)c->ssz; a.geom.sent_per_step = c->d_sent;
+    a.geom.no_history = 0; a.geom.remote = 1; a.geom.rem = c->d_remote; a.geom.annex_all = c->d_annex_all;
+    a.annex_base = c->d_annex_base; a.plan_out = c->d_xplan;
+    a.cut = cut_view(c); a.offs = offs; a.k = k; a.seed = c->run_seed; a.draw2 = kResampleDrawBase2 + (uint64_t)t + 1;
+    if (c->trace_shard_run) { a.trace_cur = c->d_tr[t & 1]; a.trace_par = t & 1; a.geom.trace_words = 1; }
+    const int kn = (t + 1 + c->hier_phase_run) % 3;                    // the copy step t wrote = the one step t + 1 reads
+    if constexpr (Model::kWeightTable == 3 && sizeof(typename Model::store_t) == 1) {
+        if (c->counts_mode) {
+            hier_view(c, kn, a.h);
+            a.totals_d = c->x_all_totals; a.e0 = c->h_e_tab[(size_t)t * 4]; a.e1 = c->h_e_tab[(size_t)t * 4 + 1]; a.e2 = c->h_e_tab[(size_t)t * 4 + 2];
+            hipLaunchKernelGGL((exchange_pack_strata_kernel<Model, kPackCounts>), dim3((unsigned)grid), dim3(kThreads), 0, c->stream, a);
+            return;
+        }
+    }
+    if constexpr (std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value || std::is_same<Model, ModelHmmK>::value) {
+        fhier_view(c, kn, a.f);
+        a.totals_u = reinterpret_cast<const uint64_t*>(c->x_all_totals); a.ess_frac = c->cfg.ess_threshold; a.q_prev = c->d_q[c->cur];
+        hipLaunchKernelGGL((exchange_pack_strata_kernel<Model, kPackFixed>), dim3((unsigned)grid), dim3(kThreads), 0, c->stream, a);
+    }
+}
+
 template <class Model, class R>
 void launch_commit(cpprob_hip_ctx* c, int t, const R* d_recv, int grid)
 {
@@ -1745,6 +1824,9 @@ int cpprob_hip_exchange_plan(cpprob_hip_ctx* c, int32_t t, int32_t world, int32_
 {
     if (!c || !h_shard_begin || !h_send_counts || !h_recv_counts) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (!c->exchange) return fail(c, CPPROB_HIP_ESTATE, "the context was not begun with resample_scope = CPPROB_HIP_SCOPE_EXCHANGE");
+    if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL)
+        return fail(c, CPPROB_HIP_EUNSUPPORTED, "multinomial resampling in the exchange scope moves its migrants by remote lineages (cpprob_hip_exchange_setup / _direct / _remote, "
+                                                 "then cpprob_hip_exchange_pack_async): the synchronising plan / pack / commit calls serve systematic and stratified resampling");
     if (t < 0 || t >= c->T) return fail(c, CPPROB_HIP_EINVAL, "step out of range");
     if (!c->step_protocol || c->step_t != t || !c->x_all_totals || world != c->x_world || rank != c->x_rank)
         return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_exchange_plan(t) follows cpprob_hip_smc_step_end(t) with the same world / rank");
@@ -1966,6 +2048,19 @@ int cpprob_hip_exchange_pack_async(cpprob_hip_ctx* c, int32_t t)
     // count form: the plan is a pure function of the all-gathered totals -- every packing workgroup derives it on its first wavefront
     // and workgroup 0 stores it (one launch less per step); floating-point form: the plan launch also combines the ranks' totals
     const bool plan_inside = c->counts_mode || c->fixed_mode;
+    if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL) {
+        if (!strata_exchange(c)) return fail(c, CPPROB_HIP_EUNSUPPORTED, "multinomial resampling in the exchange scope runs on the integer forms of the step");
+        if (c->x_peers.empty()) { c->x_plan_t = t; c->plan.t = t; return 0; }     // (a group of one: every threshold lies in its own mass)
+        if (!(c->x_remote && c->keep))
+            return fail(c, CPPROB_HIP_EUNSUPPORTED, "multinomial resampling in the exchange scope needs remote lineages (every rank addresses every rank's particle store: "
+                                                     "cpprob_hip_exchange_remote) -- its migrants are not one interval per peer, so the segment transports do not carry them");
+        c->x_plan_t = t;
+        const int grid = (int)std::min<int64_t>(std::max<int64_t>(1, (c->x_cap + kTile - 1) / kTile), 256);
+        dispatch_model(c, [&](auto m) { launch_pack_strata<decltype(m)>(c, t, grid); });
+        HIP_TRY(c, hipGetLastError());
+        c->plan.t = t;
+        return 0;
+    }
     if (c->x_peers.empty()) {
         // nobody to exchange with (a group of one): the count form's step derives everything it needs from the totals; the
         // floating-point form's plan launch still combines the ranks' totals into ctrl

@@ -225,6 +225,288 @@ __global__ __launch_bounds__(kWave) void exchange_plan_fixed_kernel(ExchangeGeom
     plan_store(g, t, pl, pw, annex_base, plan);
 }
 
+enum { kPackFloat = 0, kPackCounts = 1, kPackFixed = 2 };
+
+// ---- multinomial resampling (strata form) in the exchange scope: strata_cut.hpp states the plan ---------------------------------
+// The ranks' mass bounds, as one wavefront holds them (lane r: P_r, r = 0 .. world; P_world = the population's mass / W).
+struct CutArgs {
+    int world; const int64_t* shard_begin;
+    const uint32_t* offs; int k;                       // this resampling's strata (population-wide): first output of every stratum
+    uint64_t seed, draw2;                              // Philox key, kResampleDrawBase2 + step: the outputs' uniforms inside their strata
+    const uint64_t* totals_u; double n_pop, ess_frac;  // fixed-point form: all-gathered {S, Q, key(M)}
+    const double* totals_d; double e0, e1, e2;         // prefix-count form: all-gathered {n_0, n_1, particles}
+    uint32_t* tab; CutHead* head; uint32_t* srccnt;
+};
+// lane r: the exclusive prefix of the ranks' masses; total: every lane
+__device__ __forceinline__ uint64_t cut_bounds_fixed(const uint64_t* __restrict__ all, int world, uint64_t& total, uint64_t& squares)
+{
+    const int lane = lane_id();
+    uint64_t s = 0, q = 0;
+    if (lane < world) { s = all[3 * lane]; q = all[3 * lane + 1]; }
+    const uint64_t incl = wave_incl_scan_u64(s);
+    total = read_lane_u64(incl, kWave - 1); squares = wave_sum_u64(q);
+    return incl - s;                                   // (lanes >= world: the total)
+}
+__device__ __forceinline__ double cut_bounds_counts(const double* __restrict__ all, int world, double e0, double e1, double e2, double n_pop, double& W)
+{
+    const int lane = lane_id();
+    double r0 = 0.0, r1 = 0.0, rv = 0.0;
+    if (lane < world) { r0 = all[3 * lane]; r1 = all[3 * lane + 1]; rv = all[3 * lane + 2]; }
+    const double i0 = wave_incl_scan(r0), i1 = wave_incl_scan(r1), iv = wave_incl_scan(rv);
+    TableCdf tc;
+    tc.e0 = e0; tc.e1 = e1; tc.e2 = e2; tc.inv = 1.0; tc.u0 = 0.0; tc.n_pop = n_pop; tc.base0 = 0.0; tc.base1 = 0.0; tc.basev = 0.0; tc.seed = 0; tc.draw = 0; tc.uid0 = 0;
+    W = tc.cdf(read_lane(i0, kWave - 1), read_lane(i1, kWave - 1), n_pop);
+    return lane < world ? tc.cdf(i0 - r0, i1 - r1, iv - rv) : W;
+}
+
+// grid = world - 1: workgroup i looks at boundary b = i + 1 (between the ranks b - 1 and b); workgroup 0 also writes the two ends.
+template <bool COUNTS>
+__global__ __launch_bounds__(kThreads) void exchange_cut_kernel(CutArgs a)
+{
+    using T = typename std::conditional<COUNTS, double, uint64_t>::type;
+    __shared__ T s_P[kWorldSlots + 1];
+    __shared__ uint32_t s_begin[kWorldSlots + 1];
+    __shared__ uint32_t s_cnt[kWorldSlots];
+    __shared__ uint32_t s_wave[kWaves];
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int world = a.world, b = (int)blockIdx.x + 1;
+    const int k = a.k;
+    const uint32_t K = 1u << k;
+    T Pl, total;
+    double unit = 0.0;
+    if constexpr (COUNTS) {
+        double W;
+        Pl = cut_bounds_counts(a.totals_d, world, a.e0, a.e1, a.e2, a.n_pop, W);
+        total = W; unit = ldexp(W, -k);
+    } else {
+        uint64_t S, Q;
+        Pl = cut_bounds_fixed(a.totals_u, world, S, Q);
+        total = S;
+        if (!fixed_decide(S, Q, a.n_pop, a.ess_frac, true).resample) return;     // this generation is not resampled: nothing is cut
+    }
+    if (wv == 0) { if (lane <= world) s_P[lane] = lane < world ? Pl : total; if (lane <= world) s_begin[lane] = (uint32_t)a.shard_begin[lane]; if (lane < kWorldSlots) s_cnt[lane] = 0u; }
+    __syncthreads();
+    auto bound = [&](uint32_t w) -> T {
+        if constexpr (COUNTS) return (double)w * unit;
+        else return strata_bound(total, (uint64_t)w, k);
+    };
+    const T Pb = s_P[b];
+    // lo = min{w in [0, K] : B_w >= P_b}   (B_K = the total >= P_b)
+    uint32_t lo = 0, hi_s = K;
+    while (lo < hi_s) { const uint32_t mid = (lo + hi_s) >> 1; if (bound(mid) >= Pb) hi_s = mid; else lo = mid + 1; }
+    // hi = max{w : B_w <= P_b} (integers) / max{w : B_w < P_b} (table CDF: a threshold below may round up to the bound itself)
+    uint32_t hi;
+    if constexpr (COUNTS) hi = lo > 0 ? lo - 1 : 0;
+    else hi = (bound(lo) == Pb || lo == 0) ? lo : lo - 1;
+    const uint32_t A = a.offs[lo], Z = a.offs[hi];
+    const uint32_t len = A - Z;
+    if (tid == 0) {
+        a.head[b] = CutHead{A, Z, len > (uint32_t)kCutCap ? 1u : 0u, 0u};
+        if (b == 1) { a.head[0] = CutHead{0u, 0u, 0u, 0u}; a.head[world] = CutHead{s_begin[world], s_begin[world], 0u, 0u}; }
+    }
+    if (len == 0) return;
+    const T b_lo = bound(hi), b_hi = bound(hi + 1);
+    uint32_t* tab = a.tab + (size_t)b * kCutRow;
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < len; base += kThreads) {
+        const uint32_t i = base + (uint32_t)tid;
+        const bool valid = i < len;
+        const uint64_t s = (uint64_t)Z + (valid ? i : 0u);
+        const u32x4 blk = draw_block(a.seed, s >> 1, a.draw2);
+        const uint64_t bits = (s & 1) ? bits53(blk.z, blk.w) : bits53(blk.x, blk.y);
+        T tau;
+        if constexpr (COUNTS) tau = fma((double)bits * kTwoPowM53, b_hi - b_lo, b_lo);
+        else tau = b_lo + __umul64hi(bits << 11, b_hi - b_lo);
+        uint32_t src = 0, dst = 0;
+        for (int r = 1; r < world; ++r) { src += s_P[r] <= tau ? 1u : 0u; dst += s_begin[r] <= (uint32_t)s ? 1u : 0u; }       // (P and the shards' begins do not decrease)
+        const bool home = valid && src == dst;
+        const unsigned long long m = __ballot(home);
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(m);
+        if (valid) atomicAdd(&s_cnt[src], 1u);
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { const uint32_t x = s_wave[w]; if (w < wv) off += x; tot += x; }
+        const uint32_t cum = running + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (valid && i < (uint32_t)kCutCap) tab[i] = (src << 24) | cum;
+        running += tot;
+        __syncthreads();
+    }
+    if (tid == 0) tab[len < (uint32_t)kCutCap ? len : (uint32_t)kCutCap] = running;
+    if (tid < kWorldSlots) a.srccnt[(size_t)b * kCutSlots + tid] = s_cnt[tid];
+}
+
+// The plan of a multinomial exchange (one wave, lane = rank): who keeps how many of its own outputs, hence every rank's arrivals and
+// annex fill; this rank's regular sends; its totals.  heads / tables: the cut launch that precedes.
+__device__ __forceinline__ void plan_wave_strata(const ExchangeGeom& g, int t, const CutView& cv, bool resample, PlanLane& pl, PlanWave& pw)
+{
+    const int lane = lane_id();
+    const int world = g.world, rank = g.rank;
+    pl = PlanLane{0, 0, 0, 0, 0, 0, 0, 0};
+    pw = PlanWave{0, g.n, 0, 0, 0, 0, resample};
+    int64_t arrive = 0, sourced = 0, kept = 0;
+    uint32_t over = 0;
+    if (resample && lane < world) {
+        const uint32_t sb = (uint32_t)g.shard_begin[lane], se = (uint32_t)g.shard_begin[lane + 1];
+        const KeptCtx kc = kept_ctx(cv, lane, sb);
+        kept = (int64_t)kept_before(kc, se);
+        arrive = (int64_t)(se - sb) - kept;
+        const CutHead h0 = cv.head[lane], h1 = cv.head[lane + 1];
+        over = h0.over | h1.over;
+        // outputs this rank's sources own: its regular interval + its share of the cut strata at its two boundaries
+        sourced = h1.Z > h0.A ? (int64_t)(h1.Z - h0.A) : 0;
+        if (kc.en[0] > kc.st[0]) sourced += (int64_t)cv.srccnt[(size_t)lane * kCutSlots + lane];
+        if (kc.en[1] > kc.st[1]) sourced += (int64_t)cv.srccnt[(size_t)(lane + 1) * kCutSlots + lane];
+        if (lane != rank) {
+            // this rank's regular outputs that live in rank `lane`'s shard
+            const uint32_t A = cv.head[rank].A, Zn = cv.head[rank + 1].Z;
+            const uint32_t lo = min(max(A, sb), se), hi = min(max(Zn, sb), se);
+            pl.send_lo = (int64_t)lo; pl.send_cnt = hi > lo ? (int64_t)(hi - lo) : 0;
+        }
+    }
+    if (g.remote && lane < world) {
+        const int64_t fill = t == 0 ? 0 : g.annex_all[(int64_t)t * kWorldSlots + lane];
+        const int64_t room = g.rem->rs[lane] - g.rem->ld[lane];
+        pl.fill_next = fill + (fill + arrive > room ? 0 : arrive);
+        pl.dst_col = fill;                                               // (the step's first column on that rank: col(s) is added per output)
+    }
+    const int64_t my_arrive = read_lane((double)arrive, rank) , my_send = read_lane((double)(sourced - kept), rank);     // (below 2^32: exact)
+    pw.n_recv = my_arrive; pw.n_send = my_send > 0 ? my_send : 0;
+    pw.l0 = 0; pw.l1 = 0;
+    pw.flags = __ballot(over != 0) ? 8 : 0;
+}
+
+template <class Model>
+struct PackStrataArgs {
+    const typename Model::store_t* values; int64_t rs, n; int nb; int t;
+    int world, rank; uint64_t pid0; double n_pop;
+    ExchangeGeom geom; int64_t* annex_base; ExchangePlan* plan_out;
+    CutView cut; const uint32_t* offs; int k; uint64_t seed, draw2;
+    Hier h; const double* totals_d; double e0, e1, e2;                   // prefix-count form
+    FHier f; const uint64_t* totals_u; double ess_frac; const uint32_t* q_prev;      // fixed-point form
+    const uint32_t* trace_cur; int trace_par;
+};
+
+// The packing launch of a multinomial exchange (remote lineages): every workgroup derives the plan on its first wavefront (workgroup 0
+// stores it), then the work items -- per destination rank d: this rank's regular outputs inside d's shard, and its entries of the cut
+// strata at its two boundaries inside d's shard -- are walked tile by tile (tiles of the POPULATION's output index): thresholds, the
+// strata search among this rank's sources (step_fixed.hpp / step_counts.hpp), and each migrant stored into column col(s) of d's annex.
+template <class Model, int MODE>
+__global__ __launch_bounds__(kThreads) void exchange_pack_strata_kernel(PackStrataArgs<Model> a)
+{
+    using S = typename Model::store_t;
+    constexpr bool COUNTS = MODE == kPackCounts;
+    static_assert(MODE == kPackCounts || MODE == kPackFixed, "the integer forms");
+    __shared__ CountsLdsT<COUNTS ? kFixMultinomial : kFixSystematic> Lc;
+    __shared__ FixedLdsT<COUNTS ? kFixSystematic : kFixMultinomial> Lx;
+    __shared__ int64_t s_send_lo[kWorldSlots], s_send_cnt[kWorldSlots], s_fill[kWorldSlots];
+    __shared__ int64_t s_nsend;
+    __shared__ int s_resample;
+    __shared__ __attribute__((aligned(16))) FixedFound s_ff;
+    __shared__ __attribute__((aligned(16))) StepFound s_cf;
+    const int tid = threadIdx.x, lane = lane_id();
+    const int world = a.world, rank = a.rank;
+    // ---- this rank's place in the population, the decision ----
+    uint64_t S_tot = 0, before = 0, own = 0;
+    double W = 0.0, c_lo = 0.0, c_hi = 0.0;
+    TableCdf tc;
+    bool resample = true;
+    if constexpr (COUNTS) {
+        double r0 = 0.0, r1 = 0.0, rv = 0.0;
+        if (lane < world) { r0 = a.totals_d[3 * lane]; r1 = a.totals_d[3 * lane + 1]; rv = a.totals_d[3 * lane + 2]; }
+        const bool bef = lane < rank, upto = lane <= rank;
+        tc.e0 = a.e0; tc.e1 = a.e1; tc.e2 = a.e2; tc.u0 = 0.0; tc.n_pop = a.n_pop; tc.inv = 1.0; tc.seed = a.seed; tc.draw = 0; tc.uid0 = 0;
+        tc.base0 = wave_sum(bef ? r0 : 0.0); tc.base1 = wave_sum(bef ? r1 : 0.0); tc.basev = wave_sum(bef ? rv : 0.0);
+        W = tc.cdf(wave_sum(r0), wave_sum(r1), a.n_pop);
+        c_lo = tc.cdf(tc.base0, tc.base1, tc.basev);
+        c_hi = tc.cdf(wave_sum(upto ? r0 : 0.0), wave_sum(upto ? r1 : 0.0), wave_sum(upto ? rv : 0.0));
+    } else {
+        uint64_t s = 0, q = 0;
+        if (lane < world) { s = a.totals_u[3 * lane]; q = a.totals_u[3 * lane + 1]; }
+        S_tot = wave_sum_u64(s); before = wave_sum_u64(lane < rank ? s : 0ull); own = wave_sum_u64(lane == rank ? s : 0ull);
+        resample = fixed_decide(S_tot, wave_sum_u64(q), a.n_pop, a.ess_frac, true).resample;
+    }
+    if (wave_id() == 0) {
+        PlanLane pl; PlanWave pw;
+        plan_wave_strata(a.geom, a.t, a.cut, resample, pl, pw);
+        s_send_lo[tid] = pl.send_lo; s_send_cnt[tid] = pl.send_cnt; s_fill[tid] = pl.dst_col;
+        if (tid == 0) { s_nsend = pw.n_send; s_resample = resample ? 1 : 0; }
+        if (blockIdx.x == 0) plan_store(a.geom, a.t, pl, pw, a.annex_base, a.plan_out);
+    }
+    __syncthreads();
+    if (!s_resample || s_nsend == 0) return;                            // workgroup-uniform
+    const bool last_shard = rank + 1 == world;
+    const int64_t nb_pop = ((int64_t)a.n_pop + kTile - 1) / kTile;
+    const RemoteStores* __restrict__ rem = a.geom.rem;
+    const CutHead hme0 = a.cut.head[rank], hme1 = a.cut.head[rank + 1];
+    const bool same = hme0.A > hme0.Z && hme0.A == hme1.A && hme0.Z == hme1.Z;
+    // work items: (kind 0: regular, 1: the cut stratum of boundary `rank`, 2: of boundary `rank + 1`) x destination rank
+    for (int item = 0; item < 3 * world; ++item) {
+        const int kind = item / world, d = item - kind * world;
+        if (d == rank) continue;
+        const uint32_t sb = (uint32_t)a.geom.shard_begin[d], se = (uint32_t)a.geom.shard_begin[d + 1];
+        uint32_t lo, hi;
+        const uint32_t* tab = nullptr; uint32_t tab0 = 0;
+        if (kind == 0) { lo = (uint32_t)s_send_lo[d]; hi = lo + (uint32_t)s_send_cnt[d]; }
+        else {
+            const CutHead hb = kind == 1 ? hme0 : hme1;
+            if (kind == 2 && same) continue;
+            lo = min(max(hb.Z, sb), se); hi = min(max(hb.A, sb), se);
+            tab = a.cut.tab + (size_t)(kind == 1 ? rank : rank + 1) * kCutRow; tab0 = hb.Z;
+        }
+        if (hi <= lo) continue;                                          // uniform
+        const KeptCtx kc = kept_ctx(a.cut, d, sb);
+        S* const annex_row = static_cast<S*>(const_cast<void*>(rem->values[d])) + (int64_t)a.t * rem->rs[d] + rem->ld[d];
+        int64_t* const origin = const_cast<int64_t*>(rem->origin[d]);
+        uint32_t* const annex_trace = a.trace_cur ? rem->trace[a.trace_par][d] + rem->ld[d] : nullptr;
+        const int64_t col0 = s_fill[d], room = rem->rs[d] - rem->ld[d];
+        for (uint32_t tile = lo / kTile + blockIdx.x; (uint64_t)tile * kTile < hi; tile += gridDim.x) {
+            const uint32_t g0 = tile * kTile;
+            const uint32_t s_first = max(lo, g0), s_last = min(hi, g0 + kTile) - 1;
+            const uint64_t gj = (uint64_t)g0 + (uint64_t)tid * kPPT;
+            int32_t anc[kPPT];
+            bool mine[kPPT];
+#pragma unroll
+            for (int i = 0; i < kPPT; ++i) { anc[i] = 0; mine[i] = false; }
+            if constexpr (COUNTS) {
+                if (wave_id() == 0) {
+                    const LocatedStrata ls = counts_strata_locate(a.h, tc, a.offs, a.k, a.n, a.nb, strata_near(a.k, nb_pop, (int64_t)tile), 0, s_first, s_last, W, c_lo, c_hi, last_shard, nullptr);
+                    if (tid == 0) { s_cf.loc = ls.loc; s_cf.w0 = ls.w0; s_cf.w1 = ls.w1; }
+                }
+                __syncthreads();
+                LocatedStrata ls;
+                ls.loc = s_cf.loc; ls.w0 = s_cf.w0; ls.w1 = s_cf.w1;
+                counts_strata_walk<S>(tc, a.offs, a.k, a.values + (int64_t)a.t * a.rs, a.n, a.nb, ls, W, (int64_t)gj, a.seed, a.draw2, gj, anc, Lc, c_lo, c_hi, last_shard, mine);
+            } else {
+                if (wave_id() == 0) {
+                    const StrataLocated sl = strata_locate(a.f, a.offs, a.k, a.nb, strata_near(a.k, nb_pop, (int64_t)tile), 0, s_first, s_last, S_tot, before, own, nullptr);
+                    if (tid == 0) { s_ff.loc = sl.loc; s_ff.w0 = sl.w0; s_ff.w1 = sl.w1; }
+                }
+                __syncthreads();
+                StrataLocated sl;
+                sl.loc = s_ff.loc; sl.w0 = s_ff.w0; sl.w1 = s_ff.w1;
+                strata_walk(a.offs, a.k, a.q_prev, a.nb, sl, S_tot, (int64_t)gj, a.seed, a.draw2, gj, anc, Lx, before, own, mine);
+            }
+            const S* __restrict__ vrow = a.values + (int64_t)a.t * a.rs;
+#pragma unroll
+            for (int i = 0; i < kPPT; ++i) {
+                const uint32_t s = (uint32_t)gj + (uint32_t)i;
+                bool on = s >= lo && s < hi && mine[i];
+                if (on && tab) on = (tab[min(s - tab0, (uint32_t)kCutCap)] >> 24) == (uint32_t)rank;
+                if (!on) continue;
+                const int64_t col = col0 + (int64_t)(s - sb) - (int64_t)kept_before(kc, s);
+                if (col < room) {                                       // (an annex too small is flagged by its owner and the run repeated)
+                    const int32_t idx = anc[i];
+                    __builtin_nontemporal_store(vrow[idx], annex_row + col);
+                    __builtin_nontemporal_store(((int64_t)rank << 32) | (int64_t)idx, origin + col);
+                    if (annex_trace) annex_trace[col] = a.trace_cur[idx];
+                }
+            }
+            __syncthreads();                                            // LDS is reused by the next tile
+        }
+    }
+}
+
 // Skip rows.  A migrating particle takes its lineage x_0 .. x_t along, and extracting a lineage is a chain of t dependent gathers
 // (~1.7 us a hop: each is a row further away in memory) that no parallelism across particles shortens -- half of a long-trace run
 // in the exchange scope (profiles/r02_notes.md).  Row m of `skip` (written after step 8m, one launch every eighth step) holds, for
@@ -278,7 +560,6 @@ struct PackArgs {
     const uint32_t* trace_cur; int trace_par;                    // remote lineages with trace words: this rank's words of generation t, and t's parity
 };
 
-enum { kPackFloat = 0, kPackCounts = 1, kPackFixed = 2 };
 
 template <class Model, class R, int MODE, bool PLAN_INSIDE = false>
 __global__ __launch_bounds__(kThreads) void exchange_pack_kernel(PackArgs<Model, R> a)

@@ -97,7 +97,7 @@ __global__ void pack_joint_kernel(const double* __restrict__ stats, int n_stats,
     // (the flag word's three bits travel as three base-128 digits, so that the all-reduce's SUM over <= 63 ranks keeps them apart)
     if (i == 0) {
         const int ov = plan ? plan->overflow : 0;
-        out[n_stats] = (double)((ov & 1) + 128 * ((ov >> 1) & 1) + 16384 * ((ov >> 2) & 1));
+        out[n_stats] = (double)((ov & 1) + 128 * ((ov >> 1) & 1) + 16384 * ((ov >> 2) & 1) + 2097152 * ((ov >> 3) & 1));
         out[n_stats + 1] = (plan && has_traffic) ? (double)plan->run_records : 0.0;     // (integers below 2^53: exact in any order)
         out[n_stats + 2] = (plan && has_traffic) ? (double)plan->run_bytes : 0.0;
         out[n_stats + 3] = (dc_status && *dc_status != 0) ? 1.0 : 0.0;                  // a mailbox collective of this rank gave up waiting
@@ -766,7 +766,11 @@ int group_begin_contexts(cpprob_hip_group* g)
         }
     }
     if (int rc = setup_direct(g)) return rc;
-    return setup_remote(g);
+    if (int rc = setup_remote(g)) return rc;
+    if (g->exchange && g->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && !g->remote && (g->world > 1 || g->world1_collectives))
+        return gfail(g, CPPROB_HIP_EUNSUPPORTED, "multinomial resampling of a joint population moves its migrants by remote lineages (every rank addresses every rank's particle "
+                                                  "store); this group cannot: " + (g->transport_note.empty() ? std::string("the segment transports were requested") : g->transport_note));
+    return 0;
 }
 
 int group_enqueue(cpprob_hip_group* g, uint64_t run_index)
@@ -932,7 +936,11 @@ int cpprob_hip_group_begin(cpprob_hip_group* g, const cpprob_hip_config* cfg, co
         largest = std::max(largest, sz);
     }
     if (g->shard_begin[(size_t)g->world] != cfg->n_particles) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "shard sizes do not add up to n_particles"));
-    g->exchange = cfg->algorithm == CPPROB_HIP_ALG_SMC && (cfg->resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC || cfg->resampler == CPPROB_HIP_RESAMPLE_STRATIFIED);
+    // one joint population, every resampler: systematic and stratified (one interval of outputs per rank) and thesis Alg. 1's multinomial
+    // in its strata form (one interval + the strata the ranks' boundaries cut: strata_cut.hpp; histories kept, remote lineages).  The
+    // literal multinomial form and a filtering-only multinomial run keep the global scope (shard-local resampling, carried mass).
+    const bool strata = cfg->resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && !(cfg->flags & (CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL | CPPROB_HIP_FLAG_FLOATING_POINT_STEP)) && cfg->keep_history != 0;
+    g->exchange = cfg->algorithm == CPPROB_HIP_ALG_SMC && (cfg->resampler == CPPROB_HIP_RESAMPLE_SYSTEMATIC || cfg->resampler == CPPROB_HIP_RESAMPLE_STRATIFIED || strata);
     // transport defaults: the two neighbours, room for the O(sqrt(N)) outputs a rank's offspring interval leaves its shard by
     g->all_peers = 0;
     const uint64_t guess = (uint64_t)(8.0 * std::sqrt((double)cfg->n_particles)) / kTile * kTile + 4 * kTile;
@@ -1066,14 +1074,17 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
         // (every rank).  Results do not depend on the transport parameters, only their validity does.
         if (attempt >= 6) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "exchange transport still too small after six enlargements"));
         const long long v = (long long)joint[(size_t)g->n_stats];
-        const bool seg = v % 128 != 0, peers = (v / 128) % 128 != 0, annex = v / 16384 != 0;
+        const bool seg = v % 128 != 0, peers = (v / 128) % 128 != 0, annex = (v / 16384) % 128 != 0;
+        if (v / 2097152 != 0)
+            return gkeep(g, gfail(g, CPPROB_HIP_EUNSUPPORTED, "multinomial resampling: a stratum cut by a rank boundary holds more thresholds than the cut table (8192; a stratum's "
+                                                               "count is Binomial(N, 1/K) with mean <= 1024)"));
         uint64_t largest = 0;
         for (int r = 0; r < g->world; ++r) largest = std::max(largest, g->shard_begin[(size_t)r + 1] - g->shard_begin[(size_t)r]);
         if (peers) g->all_peers = 1;
         if (seg) g->cap = std::min<uint64_t>(largest, std::max<uint64_t>(g->cap * 4, 16384));
         if (annex || (!seg && !peers)) {
             // (0 = the context's default: max(a sixteenth of the shard, sqrt(N) T, four tiles) -- cpprob_hip_infer_begin)
-            const uint64_t mixed = (uint64_t)(std::sqrt((double)g->cfg.n_particles) * (double)g->T) / 1024;
+            const uint64_t mixed = (uint64_t)(std::sqrt((double)g->cfg.n_particles) * (double)g->T) / 1024 + (g->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL ? (uint64_t)g->T * 3 / 2 : 0);
             const int in_use = g->annex_kcols > 0 ? g->annex_kcols : (int)std::max<uint64_t>(std::max<uint64_t>(4, ((largest + 1023) / 1024) / 16), mixed);
             g->annex_kcols = in_use * 4;
         }

@@ -30,6 +30,7 @@
 #pragma once
 #include "kernels.hpp"
 #include "cpprob/detail/fixed_mass.hpp"
+#include "strata_cut.hpp"
 
 namespace cph {
 
@@ -367,15 +368,18 @@ __device__ __forceinline__ void ancestors_counts(const Hier& h, const TableCdf& 
 // inclusive prefix counts (TableCdf::cdf: the systematic comb's own values).  One population per context.
 // The SEARCH (one wavefront): the strata of the outputs (strata_window) and the source tiles that hold their CDF range: the largest
 // tile whose starting CDF value is <= x, by the systematic search's probe of five tiles, a second probe aimed by the value, or the descent.
+// One SHARD of a population (exchange scope): its sources hold the CDF range [c_lo, c_hi) of W (the population's last shard also
+// the thresholds that round up to W); only thresholds inside it are searched here.  One population: c_lo = 0, c_hi = W, last.
 struct LocatedStrata { Located loc; int w0, w1; };
-__device__ __forceinline__ LocatedStrata counts_strata_locate(const Hier& h, const TableCdf& tc, const uint32_t* __restrict__ offs, int k, int64_t n, int nb, int bid,
-                                                              uint32_t s_first, uint32_t s_last, double W, const ProbeWords& first)
+__device__ __forceinline__ LocatedStrata counts_strata_locate(const Hier& h, const TableCdf& tc, const uint32_t* __restrict__ offs, int k, int64_t n, int nb, int w_near, int guess,
+                                                              uint32_t s_first, uint32_t s_last, double W, double c_lo, double c_hi, bool last_shard, const ProbeWords* first)
 {
     const int lane = lane_id();
     LocatedStrata r;
-    strata_window(offs, k, nb, bid, s_first, s_last, r.w0, r.w1);
+    strata_window(offs, k, w_near, s_first, s_last, r.w0, r.w1);
     const double unit = ldexp(W, -k);
-    const double x_lo = (double)r.w0 * unit, x_hi = (double)(r.w1 + 1) * unit;       // (thresholds lie in [x_lo, x_hi]: the fma may round up to the bound)
+    const double x_lo = fmax((double)r.w0 * unit, c_lo), x_hi = last_shard ? (double)(r.w1 + 1) * unit : fmin((double)(r.w1 + 1) * unit, c_hi);       // (thresholds lie in [x_lo, x_hi]: the fma may round up to the bound)
+    if (x_hi < x_lo) { r.loc = Located{1, 0, 0u, 0u}; return r; }      // no threshold of these outputs lies in this shard's range
     auto nvalid_before = [&](int c) -> int64_t { const int64_t v = (int64_t)c * kTile; return v < n ? v : n; };
     int c = 0, c_last = nb;
     Cnt2 P{0, 0};
@@ -402,8 +406,8 @@ __device__ __forceinline__ LocatedStrata counts_strata_locate(const Hier& h, con
         }
         return false;
     };
-    if (!probe(bid, first)) {
-        const double aim = x_lo * ((double)nb / (W > 0.0 ? W : 1.0));
+    if (!(first && probe(guess, *first))) {
+        const double aim = (x_lo - c_lo) * ((double)nb / (c_hi - c_lo > 0.0 ? c_hi - c_lo : 1.0));
         const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
         ProbeWords pw;
         probe_fetch(h, at, nb, pw);
@@ -442,12 +446,13 @@ __device__ __forceinline__ LocatedStrata counts_strata_locate(const Hier& h, con
 template <class S>
 __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uint32_t* __restrict__ offs, int k, const S* __restrict__ states, int64_t n, int nb,
                                                    const LocatedStrata& sl, double W, int64_t j0, uint64_t seed, uint64_t draw, uint64_t uid,
-                                                   int32_t (&anc)[kPPT], CountsLdsT<kFixMultinomial>& L)
+                                                   int32_t (&anc)[kPPT], CountsLdsT<kFixMultinomial>& L, double c_lo, double c_hi, bool last_shard, bool (&mine)[kPPT])
 {
     static_assert(sizeof(S) == 1 && kPPT == 4, "states travel as one byte: 4 per lane = one dword");
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const u32x4 b0 = draw_block(seed, uid >> 1, draw), b1 = draw_block(seed, (uid >> 1) + 1, draw);
-    const double v[kPPT] = {u01_53(b0.x, b0.y), u01_53(b0.z, b0.w), u01_53(b1.x, b1.y), u01_53(b1.z, b1.w)};
+    uint64_t vb[kPPT];
+    strata_bits4(seed, draw, uid, vb);
+    const double v[kPPT] = {(double)vb[0] * kTwoPowM53, (double)vb[1] * kTwoPowM53, (double)vb[2] * kTwoPowM53, (double)vb[3] * kTwoPowM53};
     double tau[kPPT];
     bool live[kPPT];
 #pragma unroll
@@ -467,6 +472,9 @@ __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uin
             o_lo = o_hi;
         }
     }
+    // (j0 = the lane's first output in the POPULATION; of a shard's outputs only those whose threshold lies in its sources' range)
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i) { live[i] = live[i] && tau[i] >= c_lo && (last_shard || tau[i] < c_hi); mine[i] = live[i]; }
     const double x_hi = (double)(w1 + 1) * unit;
     auto nvalid_before = [&](int c) -> int64_t { const int64_t v2 = (int64_t)c * kTile; return v2 < n ? v2 : n; };
     int c = __builtin_amdgcn_readfirstlane(sl.loc.c);
@@ -549,7 +557,7 @@ __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uin
     for (int i = 0; i < kPPT; ++i) if (live[i]) anc[i] = (int32_t)(n - 1);
 }
 
-struct StepFound { Located loc; double inv, base0, base1, basev; int64_t l0, l1; int w0, w1; double W; };      // what the searching wavefront hands the other three
+struct StepFound { Located loc; double inv, base0, base1, basev; int64_t l0, l1; int w0, w1; double W, c_lo, c_hi; };      // what the searching wavefront hands the other three
 
 template <class Model>
 struct StepCountsArgs {
@@ -570,6 +578,7 @@ struct StepCountsArgs {
     double* filter_stats;                                       // filtering-only run: [T][3], generation t-1's P(x = s) from its totals (nullptr otherwise)
     const uint32_t* trace_prev; uint32_t* trace_next;           // trace words (trace_words.hpp) of generations t-1 / t, or nullptr: short discrete traces (shards: [rs], annex included)
     const uint32_t* strata_offs; int strata_k;                  // multinomial, strata form: first output of every stratum at this step (step_fixed.hpp: multinomial_strata_kernel)
+    CutView cut;                                                // ... of one shard of a joint population: what the ranks' boundaries cut (strata_cut.hpp)
 };
 
 // This tile's entry of generation t's hierarchy, added into the levels above (see the header of this file), and the entries of
@@ -609,7 +618,6 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     using S = typename Model::store_t;
     static_assert(Model::kWeightTable == 3, "prefix-count form: three table values (two stored counts)");
     static_assert(RS == kFixSystematic || RS == kFixStratified || RS == kFixMultinomial, "prefix-count form: systematic, stratified or (strata-form) multinomial resampling");
-    static_assert(!(RS == kFixMultinomial && SHARDED), "multinomial resampling: one population per context");
     __shared__ CountsLdsT<RS> L;
     __shared__ int s_cnt[kWaves * 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_model[Model::kStagedWords];
@@ -724,13 +732,22 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
             }
             Located loc{0, 0, 0, 0};
             int sw0 = 0, sw1 = 0;
+            double c_lo = 0.0, c_hi = W;
             if constexpr (RS == kFixMultinomial) {
-                const LocatedStrata ls = counts_strata_locate(a.h, tc, a.strata_offs, a.strata_k, a.n, nb, bid, (uint32_t)((int64_t)bid * kTile),
-                                                              (uint32_t)((int64_t)bid * kTile + n_out - 1), W, pw0);
+                // (a shard: strata, outputs and thresholds are the POPULATION's; only those inside this shard's CDF range are searched here)
+                const uint64_t gfirst = SHARDED ? a.pid0 + (uint64_t)bid * kTile : (uint64_t)bid * kTile;
+                const int64_t nb_pop = SHARDED ? ((int64_t)a.n_pop + kTile - 1) / kTile : (int64_t)nb;
+                if (SHARDED) {
+                    const Cnt2 tl = hier_total_sum(a.h, w_tot);
+                    c_lo = tc.cdf(tc.base0, tc.base1, tc.basev);
+                    c_hi = tc.cdf(tc.base0 + (double)tl.n0, tc.base1 + (double)tl.n1, tc.basev + (double)a.n);
+                }
+                const LocatedStrata ls = counts_strata_locate(a.h, tc, a.strata_offs, a.strata_k, a.n, nb, strata_near(a.strata_k, nb_pop, (int64_t)(gfirst / kTile)), guess, (uint32_t)gfirst,
+                                                              (uint32_t)(gfirst + (uint64_t)n_out - 1), W, c_lo, c_hi, last_shard, &pw0);
                 loc = ls.loc; sw0 = ls.w0; sw1 = ls.w1;
             } else loc = counts_locate<RS>(a.h, tc, a.n, nb, gj_first, n_out, guess, &pw0);
             int64_t l0 = 0, l1 = 0;
-            if (SHARDED) {
+            if (SHARDED && RS != kFixMultinomial) {
                 // outputs below o_lo / at or beyond o_hi descend from other shards' sources
                 const Cnt2 tl = hier_total_sum(a.h, w_tot);
                 const double o_lo = tc.template g_at<RS>(0, 0, 0), o_hi = last_shard ? a.n_pop : tc.template g_at<RS>(tl.n0, tl.n1, a.n);
@@ -739,7 +756,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
             }
             if (tid == 0) {
                 s_found.loc = loc; s_found.inv = tc.inv; s_found.base0 = tc.base0; s_found.base1 = tc.base1; s_found.basev = tc.basev;
-                s_found.l0 = l0; s_found.l1 = l1; s_found.w0 = sw0; s_found.w1 = sw1; s_found.W = W;
+                s_found.l0 = l0; s_found.l1 = l1; s_found.w0 = sw0; s_found.w1 = sw1; s_found.W = W; s_found.c_lo = c_lo; s_found.c_hi = c_hi;
                 Model::stage(a.mp, s_model);
             }
         }
@@ -750,9 +767,25 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         if constexpr (RS == kFixMultinomial) {
             LocatedStrata ls;
             ls.loc = loc; ls.w0 = s_found.w0; ls.w1 = s_found.w1;
-            counts_strata_walk<S>(tc, a.strata_offs, a.strata_k, prev_row, a.n, nb, ls, s_found.W, j0, tc.seed, kResampleDrawBase2 + (uint64_t)t, tc.uid0 + (uint64_t)j0, anc, L);
+            bool mine[kPPT];
+            const uint64_t gj = SHARDED ? a.pid0 + (uint64_t)j0 : (uint64_t)j0;            // the lane's first output in the population
+            counts_strata_walk<S>(tc, a.strata_offs, a.strata_k, prev_row, a.n, nb, ls, s_found.W, (int64_t)gj, tc.seed, kResampleDrawBase2 + (uint64_t)t, a.pid0 + (uint64_t)j0, anc, L,
+                                  s_found.c_lo, s_found.c_hi, last_shard, mine);
+            if constexpr (SHARDED) {
+                // an output whose threshold lies in another rank's range: its ancestor arrived as an annex column, in output order
+                bool out = false;
+#pragma unroll
+                for (int k = 0; k < kPPT; ++k) out = out || (!mine[k] && j0 + k < a.n);
+                if (__any(out)) {
+                    const KeptCtx kc = kept_ctx(a.cut, a.rank, (uint32_t)a.pid0);
+                    const int64_t col0 = a.ld + a.annex_base[t - 1];
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k)
+                        if (!mine[k] && j0 + k < a.n) anc[k] = (int32_t)(col0 + (j0 + k) - (int64_t)kept_before(kc, (uint32_t)(a.pid0 + (uint64_t)(j0 + k))));
+                }
+            }
         } else counts_walk<S, SHARDED, RS>(tc, prev_row, a.n, nb, last_shard, gj_first, n_out, loc, guess, raw_m1, raw_0, raw_p1, anc, L);
-        if (SHARDED) {
+        if (SHARDED && RS != kFixMultinomial) {
             // the lineages of the outputs other shards' sources own arrived as annex columns, in output order (cpprob_hip exchange
             // commit)
             const int64_t l0 = s_found.l0, l1 = s_found.l1;

@@ -23,6 +23,7 @@
 // Resolution: weights below 2^-33 of the reference are zero -- 23 nats under the heaviest admissible particle.
 #pragma once
 #include "step_counts.hpp"
+#include "strata_cut.hpp"
 
 namespace cph {
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ FixedRanks fixed_ranks(const uint64_t* __restrict__ a
     return r;
 }
 
-struct FixedFound { FLocated loc; double inv, ref; uint64_t base, S; int64_t l0, l1; int resample, w0, w1; };     // the searching wavefront's hand-over
+struct FixedFound { FLocated loc; double inv, ref; uint64_t base, S, own; int64_t l0, l1; int resample, w0, w1; };     // the searching wavefront's hand-over
 
 template <class Model>
 struct StepFixedArgs {
@@ -75,6 +76,7 @@ struct StepFixedArgs {
     // in-tile inclusive prefix at the end of every lane's four particles ([ld / 4]), read for generation t-1 / written for generation t
     const uint64_t* tile_prefix; const uint64_t* lane_prefix_prev; uint64_t* lane_prefix_next;
     const uint32_t* strata_offs; int strata_k; // multinomial, strata form: [2^k + 1] first output of every stratum's thresholds at this step (multinomial_strata_kernel)
+    CutView cut;                               // ... of one shard of a joint population: what the ranks' boundaries cut (strata_cut.hpp), written by the exchange that preceded this step
 };
 
 // ---- multinomial resampling on integer masses (thesis Alg. 1 p.36: a_j ~ Categorical(W)) ---------------------------------------
@@ -340,14 +342,19 @@ __device__ __forceinline__ int fhier_locate_mass(const HierTable* __restrict__ h
 // The SEARCH of the strata form (one wavefront): the strata w0 .. w1 of the outputs [s_first, s_last] -- the largest w with
 // o_w <= s: a window of 64 offsets around the output tile's own place almost surely holds both -- and the source tiles that hold
 // their mass range [B_w0, B_w1+1): probed around the output tile's own index like the systematic search (fixed_locate).
+// One SHARD of a population (exchange scope): these nb tiles hold the mass range [before, before + own) of the population's S, and
+// only the thresholds inside it are searched here -- the prefixes below are the shard's own, the prefix handed on is the population's.
 struct StrataLocated { FLocated loc; int w0, w1; };
-__device__ __forceinline__ StrataLocated strata_locate(const FHier& f, const uint32_t* __restrict__ offs, int k, int nb, int bid, uint32_t s_first, uint32_t s_last,
-                                                       uint64_t S, const ProbeWords& first)
+__device__ __forceinline__ StrataLocated strata_locate(const FHier& f, const uint32_t* __restrict__ offs, int k, int nb, int w_near, int guess, uint32_t s_first, uint32_t s_last,
+                                                       uint64_t S, uint64_t before, uint64_t own, const ProbeWords* first)
 {
     const int lane = lane_id();
     StrataLocated r;
-    strata_window(offs, k, nb, bid, s_first, s_last, r.w0, r.w1);
-    const uint64_t x_lo = strata_bound(S, (uint64_t)r.w0, k), b_hi = strata_bound(S, (uint64_t)r.w1 + 1, k);
+    strata_window(offs, k, w_near, s_first, s_last, r.w0, r.w1);
+    const uint64_t g_lo = strata_bound(S, (uint64_t)r.w0, k), g_hi = strata_bound(S, (uint64_t)r.w1 + 1, k);
+    const uint64_t gl = g_lo > before ? g_lo : before, gh = g_hi < before + own ? g_hi : before + own;
+    if (gh <= gl && !(own == S && before == 0)) { r.loc = FLocated{1, 0, 0}; return r; }          // no threshold of these outputs lies in this shard's mass
+    const uint64_t x_lo = gl - before, b_hi = gh - before;
     const uint64_t x_hi = b_hi > x_lo ? b_hi - 1 : x_lo;
     int c = 0, c_last = nb;
     uint64_t P = 0;
@@ -371,28 +378,32 @@ __device__ __forceinline__ StrataLocated strata_locate(const FHier& f, const uin
         }
         return false;
     };
-    if (!probe(bid, first)) {
+    if (!(first && probe(guess, *first))) {
         // aim by the mass (tile masses are comparable), then descend from the top
-        const double aim = u64_to_double(x_lo) * ((double)nb / u64_to_double(S > 0 ? S : 1));
+        const double aim = u64_to_double(x_lo) * ((double)nb / u64_to_double(own > 0 ? own : 1));
         const int at = (int)fmin(fmax(aim, 0.0), (double)(nb - 1));
         ProbeWords pw;
         probe_fetch(f.h, at, nb, pw);
         if (!probe(at, pw)) { c = fhier_locate_mass(f.h.table, f.h.copy, x_lo, P); c_last = nb; }
     }
-    r.loc = FLocated{c, c_last, P};
+    r.loc = FLocated{c, c_last, P + before};
     return r;
 }
 
 // The WALK of the strata form (the whole workgroup): the lane's four outputs take their thresholds, every source tile of the range
 // rebuilds its prefix masses in LDS (per wavefront: one scan, one barrier a tile), and the outputs whose threshold lies in the tile
 // search them.  uid = the id of the lane's first output (a multiple of four); j0 = its index in the population.
+// One shard of a population: j0 = the lane's first output's index in the POPULATION, [before, before + own) = the mass these
+// sources hold; mine[i] = output i's threshold lies in it (its ancestor is in anc[i]); the others keep what anc[] held.
 __device__ __forceinline__ void strata_walk(const uint32_t* __restrict__ offs, int k, const uint32_t* __restrict__ qprev, int nb, const StrataLocated& sl, uint64_t S,
-                                            int64_t j0, uint64_t seed, uint64_t draw, uint64_t uid, int32_t (&anc)[kPPT], FixedLdsT<kFixMultinomial>& L)
+                                            int64_t j0, uint64_t seed, uint64_t draw, uint64_t uid, int32_t (&anc)[kPPT], FixedLdsT<kFixMultinomial>& L,
+                                            uint64_t before, uint64_t own, bool (&mine)[kPPT])
 {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const u32x4 b0 = draw_block(seed, uid >> 1, draw), b1 = draw_block(seed, (uid >> 1) + 1, draw);
     uint64_t v[kPPT], tau[kPPT];
-    v[0] = bits53(b0.x, b0.y) << 11; v[1] = bits53(b0.z, b0.w) << 11; v[2] = bits53(b1.x, b1.y) << 11; v[3] = bits53(b1.z, b1.w) << 11;
+    strata_bits4(seed, draw, uid, v);
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i) v[i] <<= 11;
     bool live[kPPT];
 #pragma unroll
     for (int i = 0; i < kPPT; ++i) { live[i] = false; tau[i] = 0; }
@@ -411,6 +422,8 @@ __device__ __forceinline__ void strata_walk(const uint32_t* __restrict__ offs, i
             o_lo = o_hi; b_lo = b_hi;
         }
     }
+#pragma unroll
+    for (int i = 0; i < kPPT; ++i) { live[i] = live[i] && tau[i] >= before && tau[i] - before < own; mine[i] = live[i]; }
     const uint64_t b_end = strata_bound(S, (uint64_t)w1 + 1, k), x_first = strata_bound(S, (uint64_t)w0, k);
     const uint64_t x_hi = b_end > x_first ? b_end - 1 : x_first;
     int c = __builtin_amdgcn_readfirstlane(sl.loc.c);
@@ -545,7 +558,8 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
     using V = typename Model::value_t;
     using S = typename Model::store_t;
     constexpr bool kMulti = RS == kFixMultinomial || RS == kFixMultinomialLiteral;
-    static_assert(!(kMulti && (SHARDED || PREFETCH)), "multinomial resampling: one population per context, no source tiles to fetch ahead");
+    static_assert(!(kMulti && PREFETCH), "multinomial resampling: no source tiles to fetch ahead");
+    static_assert(!(RS == kFixMultinomialLiteral && SHARDED), "the literal multinomial form serves one population per context");
     __shared__ FixedLdsT<RS> L;
     __shared__ __attribute__((aligned(16))) FixedFound s_found;
     __shared__ uint64_t s_red[3 * kWaves];
@@ -637,7 +651,11 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
             int64_t l0 = 0, l1 = a.n;
             int sw0 = 0, sw1 = 0;
             if (d.resample && RS == kFixMultinomial) {
-                const StrataLocated sl = strata_locate(a.f, a.strata_offs, a.strata_k, nb, bid, (uint32_t)((int64_t)bid * kTile), (uint32_t)((int64_t)bid * kTile + n_out - 1), St, pw0);
+                // (a shard: the strata, their outputs and the thresholds are the POPULATION's; only those inside this shard's mass are searched here)
+                const uint64_t gfirst = SHARDED ? a.pid0 + (uint64_t)bid * kTile : (uint64_t)bid * kTile;
+                const int64_t nb_pop = SHARDED ? ((int64_t)a.n_pop + kTile - 1) / kTile : (int64_t)nb;
+                const StrataLocated sl = strata_locate(a.f, a.strata_offs, a.strata_k, nb, strata_near(a.strata_k, nb_pop, (int64_t)(gfirst / kTile)), bid, (uint32_t)gfirst,
+                                                       (uint32_t)(gfirst + (uint64_t)n_out - 1), St, before, SHARDED ? own.S : St, &pw0);
                 loc = sl.loc; sw0 = sl.w0; sw1 = sl.w1;
             } else if (d.resample && !kMulti) {
                 loc = fixed_locate<RS>(a.f, fc, nb, gj_first, n_out, guess, &pw0);
@@ -648,7 +666,7 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
                     l0 = (int64_t)fmin(fmax(o_lo - sb, 0.0), (double)a.n); l1 = (int64_t)fmin(fmax(o_hi - sb, 0.0), (double)a.n);
                 }
             }
-            if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.ref = r_t; s_found.base = before; s_found.S = St; s_found.l0 = l0; s_found.l1 = l1; s_found.resample = d.resample ? 1 : 0; s_found.w0 = sw0; s_found.w1 = sw1; }
+            if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.ref = r_t; s_found.base = before; s_found.S = St; s_found.own = SHARDED ? own.S : St; s_found.l0 = l0; s_found.l1 = l1; s_found.resample = d.resample ? 1 : 0; s_found.w0 = sw0; s_found.w1 = sw1; }
         }
         __syncthreads();                                               // slots reset, search results in place
     CPH_STAMP(2);
@@ -661,7 +679,23 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
             if constexpr (RS == kFixMultinomial) {
                 StrataLocated sl;
                 sl.loc = s_found.loc; sl.w0 = s_found.w0; sl.w1 = s_found.w1;
-                strata_walk(a.strata_offs, a.strata_k, a.q_prev, nb, sl, s_found.S, j0, fc.seed, kResampleDrawBase2 + (uint64_t)t, fc.uid0 + (uint64_t)j0, anc, L);
+                bool mine[kPPT];
+                const uint64_t gj = SHARDED ? a.pid0 + (uint64_t)j0 : (uint64_t)j0;        // the lane's first output in the population
+                strata_walk(a.strata_offs, a.strata_k, a.q_prev, nb, sl, s_found.S, (int64_t)gj, fc.seed, kResampleDrawBase2 + (uint64_t)t, a.pid0 + (uint64_t)j0, anc, L,
+                            s_found.base, s_found.own, mine);
+                if constexpr (SHARDED) {
+                    // an output whose threshold lies in another rank's mass: its ancestor arrived as an annex column, in output order
+                    bool out = false;
+#pragma unroll
+                    for (int k = 0; k < kPPT; ++k) out = out || (!mine[k] && j0 + k < a.n);
+                    if (__any(out)) {
+                        const KeptCtx kc = kept_ctx(a.cut, a.rank, (uint32_t)a.pid0);
+                        const int64_t col0 = a.ld + a.annex_base[t - 1];
+#pragma unroll
+                        for (int k = 0; k < kPPT; ++k)
+                            if (!mine[k] && j0 + k < a.n) anc[k] = (int32_t)(col0 + (j0 + k) - (int64_t)kept_before(kc, (uint32_t)(a.pid0 + (uint64_t)(j0 + k))));
+                    }
+                }
             }
         } else if (resample) {
             fc.inv = s_found.inv; fc.base = s_found.base;

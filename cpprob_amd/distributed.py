@@ -391,6 +391,92 @@ def exchange_counts(o, begins, rank):
     return send_first, send_counts, recv_counts
 
 
+class StrataCutPlan:
+    """The exchange plan of one MULTINOMIAL resampling step (strata form) over shards, as every rank's device derives it from the
+    all-gathered totals (cpprob_amd/csrc/exchange.hpp: exchange_cut_kernel, strata_kept_before).
+
+    The thresholds are generated stratum by stratum: stratum w holds the outputs [offs[w], offs[w + 1]) and its thresholds lie in
+    [B[w], B[w + 1]).  Rank r's sources hold the mass range [P[r], P[r + 1]).  A stratum that lies inside one rank's range sends all
+    its outputs to that rank's sources ("regular": one interval of outputs per rank, as under systematic resampling); only the
+    <= world - 1 strata that a rank boundary CUTS have to look at their outputs one by one:
+        lo[b] = min{w : B[w] >= P[b]},  hi[b] = max{w : B[w] <= P[b]}  (table form: B[w] < P[b] -- its thresholds may round UP to B[w + 1]),
+        A[b] = offs[lo[b]],  Z[b] = offs[hi[b]]:    rank r's regular outputs = [A[r], Z[r + 1]),  boundary b's cut stratum = [Z[b], A[b])
+    and for a cut stratum a table over its outputs: src(s) = max{r : P[r] <= tau_s} and cum(s) = #{s' < s in the stratum : src(s') =
+    the rank whose shard holds s'} ("home" outputs).  An output that does not descend from its own shard's sources takes the next free
+    annex column of its shard IN OUTPUT ORDER:   col(s) = (s - begin[d]) - kept_before(d, s),   kept_before(d, s) = #{s' in [begin[d], s) :
+    src(s') = d} -- the regular part by interval arithmetic, the <= 2 cut strata around rank d by two table look-ups.
+
+    thresholds(s_lo, s_hi) -> the thresholds of the outputs [s_lo, s_hi) (the device draws them: Philox, draw kResampleDrawBase2 + step)."""
+
+    def __init__(self, P, B, offs, begins, thresholds, table_form=False):
+        self.P = list(P); self.B = B; self.offs = [int(o) for o in offs]; self.begins = [int(b) for b in begins]
+        self.world = len(self.P) - 1
+        world, K, N = self.world, len(B) - 1, self.begins[-1]
+        assert self.offs[K] == N and len(self.begins) == world + 1
+        self.A, self.Z = [0] * (world + 1), [0] * (world + 1)
+        self.A[world] = self.Z[world] = N
+        self.tab = {}
+        for b in range(1, world):
+            lo = next(w for w in range(K + 1) if B[w] >= self.P[b])
+            below = [w for w in range(K + 1) if (B[w] < self.P[b] if table_form else B[w] <= self.P[b])]
+            hi = below[-1] if below else lo
+            self.A[b], self.Z[b] = self.offs[lo], self.offs[hi]
+            if self.A[b] > self.Z[b]:
+                st, en = self.Z[b], self.A[b]
+                tau = thresholds(st, en)
+                src = [max(r for r in range(world) if self.P[r] <= t) for t in tau]
+                dst = [self.shard_of(s) for s in range(st, en)]
+                cum, acc = [], 0
+                for a, d in zip(src, dst):
+                    cum.append(acc); acc += 1 if a == d else 0
+                cum.append(acc)
+                self.tab[b] = (src, cum)
+
+    def shard_of(self, s):
+        return max(r for r in range(self.world) if self.begins[r] <= s)
+
+    def cut_of(self, d):
+        """the boundaries whose cut strata may hold outputs of rank d's sources: d and d + 1, once if they share a stratum"""
+        bs = [b for b in (d, d + 1) if b in self.tab]
+        if len(bs) == 2 and (self.Z[bs[0]], self.A[bs[0]]) == (self.Z[bs[1]], self.A[bs[1]]):
+            bs = bs[:1]
+        return bs
+
+    def kept_before(self, d, s):
+        sb = self.begins[d]
+        kept = max(0, min(s, self.Z[d + 1]) - max(sb, self.A[d]))
+        for b in self.cut_of(d):
+            st, en = self.Z[b], self.A[b]
+            x0, x1 = min(max(sb, st), en), min(max(s, st), en)
+            if x1 > x0:
+                kept += self.tab[b][1][x1 - st] - self.tab[b][1][x0 - st]
+        return kept
+
+    def column(self, d, s):
+        """annex column (relative to the step's first) of output s on the rank d whose shard holds it; s must not descend from d"""
+        return (s - self.begins[d]) - self.kept_before(d, s)
+
+    def arrivals(self, d):
+        return (self.begins[d + 1] - self.begins[d]) - self.kept_before(d, self.begins[d + 1])
+
+    def sends(self, r):
+        """[(output, destination rank)] of the outputs rank r's sources own in other ranks' shards: the regular interval cut by
+        the shards, then the cut strata's table entries -- what the packing launch of rank r walks"""
+        out = []
+        for d in range(self.world):
+            if d == r:
+                continue
+            lo, hi = max(self.A[r], self.begins[d]), min(self.Z[r + 1], self.begins[d + 1])
+            out += [(s, d) for s in range(lo, hi)]
+        for b in self.cut_of(r):
+            st = self.Z[b]
+            for i, a in enumerate(self.tab[b][0]):
+                d = self.shard_of(st + i)
+                if a == r and d != r:
+                    out.append((st + i, d))
+        return out
+
+
 def shard_begins(n_global, world):
     return np.array([shard_bounds(n_global, world, r)[0] for r in range(world)] + [int(n_global)], np.uint64)
 

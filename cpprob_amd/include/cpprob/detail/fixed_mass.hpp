@@ -497,12 +497,14 @@ __device__ __forceinline__ void bbf_publish_mass(const FHier& f, int bid, int nb
 
 // Multinomial resampling, strata form: the strata w0 .. w1 of the outputs [s_first, s_last] -- the largest w with offs[w] <= s (offs:
 // first output of every stratum, offs[K] = N).  One wavefront: a window of 64 offsets around the output tile's own place almost
-// surely holds both (offs[w] wanders sqrt(N) outputs off w N / K); a binary search of the whole array otherwise.
-__device__ __forceinline__ void strata_window(const uint32_t* __restrict__ offs, int k, int nb, int bid, uint32_t s_first, uint32_t s_last, int& w0, int& w1)
+// surely holds both (offs[w] wanders sqrt(N) outputs off w N / K); a binary search of the whole array otherwise.  w_near = the
+// stratum the outputs are expected in: (tile of the POPULATION << k) / tiles of the population.
+__device__ __forceinline__ int strata_near(int k, int64_t nb_pop, int64_t tile_pop) { return (int)((tile_pop << k) / (nb_pop > 0 ? nb_pop : 1)); }
+__device__ __forceinline__ void strata_window(const uint32_t* __restrict__ offs, int k, int w_near, uint32_t s_first, uint32_t s_last, int& w0, int& w1)
 {
     const int lane = lane_id();
     const int K = 1 << k;
-    int w_at = (int)(((int64_t)bid << k) / nb) - 31;
+    int w_at = w_near - 31;
     if (w_at > K + 1 - kWave) w_at = K + 1 - kWave;
     if (w_at < 0) w_at = 0;
     const int idx = w_at + lane;

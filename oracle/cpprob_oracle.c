@@ -962,6 +962,125 @@ ORC_API int orc_resample_fixed_multinomial_strata(const uint32_t *q, uint64_t n_
     return 0;
 }
 
+/* The strata form over SHARDS of one population (exchange scope; thesis Alg. 1 p.36 drawn by several devices): the strata, their
+ * counts and every output's uniform are the POPULATION's (k from n_pop, output ids population-wide), so the threshold of output s is
+ * the same integer on whichever rank looks at it; these n_in sources hold the mass range [before, before + own) of `total`, and
+ * output s descends from them iff before <= tau_s < before + own -- its ancestor the first local k with before + C_k > tau_s.
+ * anc[0 .. n_pop): -1 where the ancestor is another shard's.  One shard with before = 0 is orc_resample_fixed_multinomial_strata. */
+ORC_API int orc_resample_fixed_multinomial_strata_shard(const uint32_t *q, uint64_t n_in, uint64_t before, uint64_t total, uint64_t seed, uint64_t step,
+                                                        uint64_t n_pop, int32_t *anc)
+{
+    const int k = orc_strata_levels(n_pop);
+    const uint64_t K = (uint64_t)1 << k;
+    uint64_t *cdf = (uint64_t *)malloc((n_in ? n_in : 1) * sizeof(uint64_t));
+    uint32_t *offs = (uint32_t *)malloc((K + 1) * sizeof(uint32_t));
+    if (!cdf || !offs) { free(cdf); free(offs); return -1; }
+    uint64_t c = before;
+    for (uint64_t i = 0; i < n_in; ++i) { c += q[i]; cdf[i] = c; }
+    const uint64_t end = c;
+    if (end > total) { free(cdf); free(offs); return -2; }
+    orc_multinomial_strata(seed, step, n_pop, k, offs);
+    for (uint64_t w = 0; w < K; ++w) {
+        const uint64_t b0 = strata_bound(total, w, k), b1 = strata_bound(total, w + 1, k);
+        for (uint64_t s = offs[w]; s < offs[w + 1]; ++s) {
+            uint32_t r[4];
+            orc_draw_block(seed, s >> 1, ORC_RESAMPLE_DRAW_BASE2 + step, r);
+            const uint64_t v = (s & 1) ? bits53(r[2], r[3]) : bits53(r[0], r[1]);
+            const uint64_t tau = b0 + (uint64_t)(((unsigned __int128)(v << 11) * (b1 - b0)) >> 64);
+            if (tau < before || tau >= end) { anc[s] = -1; continue; }
+            uint64_t lo = 0, hi = n_in;               /* first i with cdf[i] > tau (exists: cdf[n_in - 1] = end > tau) */
+            while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (cdf[mid] > tau) hi = mid; else lo = mid + 1; }
+            anc[s] = (int32_t)lo;
+        }
+    }
+    free(cdf); free(offs);
+    return 0;
+}
+
+/* ... and the table form over shards: before[s] / total[s] = counts of state s in the shards that precede this one / in the whole
+ * population (orc_resample_table_systematic's arguments); the CDF values are table_cdf of GLOBAL prefix counts, the rank's range is
+ * [table_cdf(before), table_cdf(before + own)) -- the population's last shard also takes the thresholds that round up to W. */
+ORC_API int orc_resample_table_multinomial_shard(const int32_t *x, uint64_t n_in, const double e[3], const uint64_t before[3], const uint64_t total[3], int last_shard,
+                                                 uint64_t seed, uint64_t step, uint64_t n_pop, int32_t *anc)
+{
+    const int k = orc_strata_levels(n_pop);
+    const uint64_t K = (uint64_t)1 << k;
+    double *cdf = (double *)malloc((n_in ? n_in : 1) * sizeof(double));
+    uint32_t *offs = (uint32_t *)malloc((K + 1) * sizeof(uint32_t));
+    if (!cdf || !offs) { free(cdf); free(offs); return -1; }
+    uint64_t c[3] = { before[0], before[1], before[2] };
+    const double c_lo = table_cdf(c, e);
+    for (uint64_t i = 0; i < n_in; ++i) {
+        if (x[i] < 0 || x[i] > 2) { free(cdf); free(offs); return -2; }
+        c[x[i]] += 1;
+        cdf[i] = table_cdf(c, e);
+    }
+    const double c_hi = table_cdf(c, e);
+    const double W = table_cdf(total, e);
+    const double unit = ldexp(W, -k);
+    orc_multinomial_strata(seed, step, n_pop, k, offs);
+    for (uint64_t w = 0; w < K; ++w) {
+        const double b0 = (double)w * unit, b1 = (double)(w + 1) * unit;
+        for (uint64_t s = offs[w]; s < offs[w + 1]; ++s) {
+            uint32_t r[4];
+            orc_draw_block(seed, s >> 1, ORC_RESAMPLE_DRAW_BASE2 + step, r);
+            const double v = (s & 1) ? orc_u01_53(r[2], r[3]) : orc_u01_53(r[0], r[1]);
+            const double tau = fma(v, b1 - b0, b0);
+            if (tau < c_lo || (!last_shard && tau >= c_hi)) { anc[s] = -1; continue; }
+            uint64_t lo = 0, hi = n_in;
+            while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (cdf[mid] > tau) hi = mid; else lo = mid + 1; }
+            anc[s] = (int32_t)(lo < n_in ? lo : n_in - 1);
+        }
+    }
+    free(cdf); free(offs);
+    return 0;
+}
+
+/* The thresholds themselves (tests of the exchange plan: which rank's mass range holds output s's threshold): tau[0 .. n_pop) as the
+ * two forms above draw them -- integers against a total mass, doubles against a table CDF's W -- and the stratum of every output. */
+ORC_API int orc_strata_thresholds_fixed(uint64_t total, uint64_t seed, uint64_t step, uint64_t n_pop, uint64_t *tau, int32_t *stratum)
+{
+    const int k = orc_strata_levels(n_pop);
+    const uint64_t K = (uint64_t)1 << k;
+    uint32_t *offs = (uint32_t *)malloc((K + 1) * sizeof(uint32_t));
+    if (!offs) return -1;
+    orc_multinomial_strata(seed, step, n_pop, k, offs);
+    for (uint64_t w = 0; w < K; ++w) {
+        const uint64_t b0 = strata_bound(total, w, k), b1 = strata_bound(total, w + 1, k);
+        for (uint64_t s = offs[w]; s < offs[w + 1]; ++s) {
+            uint32_t r[4];
+            orc_draw_block(seed, s >> 1, ORC_RESAMPLE_DRAW_BASE2 + step, r);
+            const uint64_t v = (s & 1) ? bits53(r[2], r[3]) : bits53(r[0], r[1]);
+            tau[s] = b0 + (uint64_t)(((unsigned __int128)(v << 11) * (b1 - b0)) >> 64);
+            if (stratum) stratum[s] = (int32_t)w;
+        }
+    }
+    free(offs);
+    return 0;
+}
+ORC_API int orc_strata_thresholds_table(double W, uint64_t seed, uint64_t step, uint64_t n_pop, double *tau, int32_t *stratum)
+{
+    const int k = orc_strata_levels(n_pop);
+    const uint64_t K = (uint64_t)1 << k;
+    uint32_t *offs = (uint32_t *)malloc((K + 1) * sizeof(uint32_t));
+    if (!offs) return -1;
+    const double unit = ldexp(W, -k);
+    orc_multinomial_strata(seed, step, n_pop, k, offs);
+    for (uint64_t w = 0; w < K; ++w) {
+        const double b0 = (double)w * unit, b1 = (double)(w + 1) * unit;
+        for (uint64_t s = offs[w]; s < offs[w + 1]; ++s) {
+            uint32_t r[4];
+            orc_draw_block(seed, s >> 1, ORC_RESAMPLE_DRAW_BASE2 + step, r);
+            const double v = (s & 1) ? orc_u01_53(r[2], r[3]) : orc_u01_53(r[0], r[1]);
+            tau[s] = fma(v, b1 - b0, b0);
+            if (stratum) stratum[s] = (int32_t)w;
+        }
+    }
+    free(offs);
+    return 0;
+}
+ORC_API double orc_table_cdf(const uint64_t c[3], const double e[3]) { return table_cdf(c, e); }
+
 /* e[s] = exp(ll_s - max ll) of step t of the HMM: the table the weights of generation t are drawn from */
 static void hmm_weight_table(double y, double e[3], double *mref)
 {

@@ -77,6 +77,15 @@ def lib():
         L.orc_resample_fixed_multinomial_strata.restype = C.c_int
         L.orc_resample_fixed_multinomial_strata.argtypes = [_up, u64, u64, u64, u64, _ip]
         L.orc_strata_levels.restype = C.c_int; L.orc_strata_levels.argtypes = [u64]
+        L.orc_resample_fixed_multinomial_strata_shard.restype = C.c_int
+        L.orc_resample_fixed_multinomial_strata_shard.argtypes = [_up, u64, u64, u64, u64, u64, u64, _ip]
+        L.orc_resample_table_multinomial_shard.restype = C.c_int
+        L.orc_resample_table_multinomial_shard.argtypes = [_ip, u64, _dp, _u64p, _u64p, C.c_int, u64, u64, u64, _ip]
+        L.orc_strata_thresholds_fixed.restype = C.c_int
+        L.orc_strata_thresholds_fixed.argtypes = [u64, u64, u64, u64, _u64p, _ip]
+        L.orc_strata_thresholds_table.restype = C.c_int
+        L.orc_strata_thresholds_table.argtypes = [dbl, u64, u64, u64, _dp, _ip]
+        L.orc_table_cdf.restype = dbl; L.orc_table_cdf.argtypes = [_u64p, _dp]
         L.orc_multinomial_strata.argtypes = [u64, u64, u64, C.c_int, _up]
         L.orc_set_hmm.restype = C.c_int; L.orc_set_hmm.argtypes = [C.c_int, _dp, _dp]
         L.orc_smc.restype = C.c_int
@@ -281,6 +290,49 @@ def resample_fixed_multinomial_strata(q, seed, step, n_out=None):
     if rc:
         raise RuntimeError("orc_resample_fixed_multinomial_strata failed rc=%d" % rc)
     return anc
+
+
+def resample_fixed_multinomial_strata_shard(q, seed, step, before, total, n_pop):
+    """The strata form over shards of ONE population (orc_resample_fixed_multinomial_strata_shard): ancestors of all n_pop outputs
+    among the sources q, which hold the mass range [before, before + sum q) of `total`; -1 where the ancestor is another shard's."""
+    q = np.ascontiguousarray(q, np.uint32)
+    anc = np.zeros(int(n_pop), np.int32)
+    rc = lib().orc_resample_fixed_multinomial_strata_shard(q, len(q), int(before), int(total), seed, step, int(n_pop), anc)
+    if rc:
+        raise RuntimeError("orc_resample_fixed_multinomial_strata_shard failed rc=%d" % rc)
+    return anc
+
+
+def resample_table_multinomial_shard(x, e, seed, step, before, total, last_shard, n_pop):
+    """... and the table form over shards (orc_resample_table_multinomial_shard): before / total = state counts [3]."""
+    x = np.ascontiguousarray(x, np.int32)
+    e = np.ascontiguousarray(e, np.float64)
+    anc = np.zeros(int(n_pop), np.int32)
+    rc = lib().orc_resample_table_multinomial_shard(x, len(x), e, np.ascontiguousarray(before, np.uint64), np.ascontiguousarray(total, np.uint64),
+                                                    int(bool(last_shard)), seed, step, int(n_pop), anc)
+    if rc:
+        raise RuntimeError("orc_resample_table_multinomial_shard failed rc=%d" % rc)
+    return anc
+
+
+def strata_thresholds_fixed(total, seed, step, n_pop):
+    """(tau[n_pop] uint64, stratum[n_pop]) of the strata form on integer masses."""
+    tau = np.zeros(int(n_pop), np.uint64); st = np.zeros(int(n_pop), np.int32)
+    if lib().orc_strata_thresholds_fixed(int(total), seed, step, int(n_pop), tau, st):
+        raise RuntimeError("orc_strata_thresholds_fixed failed")
+    return tau, st
+
+
+def strata_thresholds_table(W, seed, step, n_pop):
+    """(tau[n_pop] float64, stratum[n_pop]) of the strata form on the table CDF."""
+    tau = np.zeros(int(n_pop), np.float64); st = np.zeros(int(n_pop), np.int32)
+    if lib().orc_strata_thresholds_table(float(W), seed, step, int(n_pop), tau, st):
+        raise RuntimeError("orc_strata_thresholds_table failed")
+    return tau, st
+
+
+def table_cdf(counts, e):
+    return float(lib().orc_table_cdf(np.ascontiguousarray(counts, np.uint64), np.ascontiguousarray(e, np.float64)))
 
 
 def multinomial_strata(seed, step, n_out, n_particles=None):

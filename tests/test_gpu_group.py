@@ -486,3 +486,45 @@ def test_group_stratified_resampling_is_bit_identical_to_one_gpu_and_the_oracle(
     assert s["step_form"] == ref_sum["step_form"] != cp.capi.FORM_FLOAT
     assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
     np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("shards", [[50000, 50000], [30000, 50001, 19999], [25000] * 8, [1000, 2000, 70000, 3000, 999]])
+@pytest.mark.parametrize("model,key,T,ess", [(cp.MODEL_HMM3, "hmm16", 16, 2.0), (cp.MODEL_HMM3, "hmm128", 40, 0.5), (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 25, 0.5),
+                                             (cp.MODEL_LINEAR_GAUSSIAN_1D, "lgssm100", 12, 2.0)])
+def test_group_multinomial_resampling_is_bit_identical_to_one_gpu_and_the_oracle(engine, golden_dir, shards, model, key, T, ess):
+    """Thesis Alg. 1's own resampler (multinomial, strata form) through the exchange scope: the thresholds come stratum by stratum, so a
+    rank's sources own ONE interval of outputs plus their share of the <= world - 1 strata the ranks' boundaries cut -- those are
+    classified output by output in a launch every rank runs on the all-gathered totals alone (exchange_cut_kernel), and a migrant's
+    annex column is (s - shard begin) - kept_before(s) on both sides (csrc/strata_cut.hpp).  Both integer forms (prefix counts for
+    the every-step HMM, fixed-point masses otherwise): every surviving trace, the decisions and the evidence equal the single-context
+    run's, which equals the oracle's, for 2 .. 8 uneven loopback shards (odd shard begins included)."""
+    import torch  # noqa: F401
+    from oracle import oracle as O
+    obs = _obs(golden_dir, key)[:T]
+    n = int(sum(shards))
+    engine.begin(cp.ALG_SMC, model, obs, n, seed=29, resampler=cp.RESAMPLE_MULTINOMIAL, ess_threshold=ess)
+    engine.run()
+    ref_stats, ref_sum, ref_paths, ref_anc = engine.stats().copy(), engine.summary(), engine.paths(), engine.ancestors()
+    orc = O.smc(model, obs, n, 29, O.RESAMPLE_MULTINOMIAL, ess)
+    assert np.array_equal(ref_anc, orc["anc"]) and ref_sum["n_resampled"] == int(orc["resampled"].sum())
+    g = cp.Group([0] * len(shards))
+    g.begin(cp.ALG_SMC, model, obs, n, seed=29, resampler=cp.RESAMPLE_MULTINOMIAL, ess_threshold=ess, shard_sizes=shards)
+    g.run()
+    stats, s, reruns = g.results()
+    tr = g.traffic()
+    paths = np.concatenate([_ctx_paths(g, r, shards[r], T, model == cp.MODEL_HMM3) for r in range(len(shards))], axis=1)
+    g.close()
+    assert reruns == 0 and s["step_form"] == ref_sum["step_form"] != cp.capi.FORM_FLOAT
+    assert tr["records"] > 0 and tr["remote_lineages"] == 1
+    assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
+    np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-12)
+
+
+def test_group_multinomial_refuses_what_it_cannot_move(engine, golden_dir):
+    """Multinomial migrants are not one interval per peer: the segment transports refuse them loudly (no silent change of estimator)."""
+    obs = _obs(golden_dir, "hmm16")
+    g = cp.Group([0, 0])
+    g.transport(0, -1, cp.capi.GROUP_SHIP_LINEAGES)
+    with pytest.raises(cp.CpprobHipError):
+        g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 40000, seed=1, resampler=cp.RESAMPLE_MULTINOMIAL, ess_threshold=2.0)
+    g.close()

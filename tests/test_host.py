@@ -245,6 +245,95 @@ def test_gloo_exchange_scope_moves_the_single_process_lineages(tmp_path, world, 
     assert out.stdout.count("ok") == world
 
 
+_GLOO_STRATA_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from cpprob_amd import distributed as D
+from oracle import oracle as O
+world, rank, local = D.init_process_group(device_is_gpu=False)
+assert dist.get_backend() == "gloo" and world == %(world)d
+# MULTINOMIAL resampling (thesis Alg. 1, strata form) of ONE population over real processes, on CPU.  Every process holds one shard of
+# a population whose generations come from the single-process oracle run; the oracle's SHARD form stands in for the device's search on
+# each rank, the plan -- regular intervals, the strata the ranks' boundaries cut, every migrant's annex column -- is the product's
+# host statement (D.StrataCutPlan = csrc/strata_cut.hpp), the lineages travel through D.host_all_to_all, and what every rank ends up
+# holding for its outputs (own sources + annex columns, in the plan's order) must be the lineage of the ancestor the single-process run drew.
+z = np.load(os.path.join(%(root)r, "tests", "golden", "observations.npz"))
+obs = z["lgssm100"][:10]
+N, seed = %(n)d, 19
+ref = O.smc(O.MODEL_LINEAR_GAUSSIAN_1D, obs, N, seed, O.RESAMPLE_MULTINOMIAL, 2.0)       # every step resamples; fixed-point masses
+paths_all = [np.take_along_axis(ref["hist"][: t + 1], O.lineage(ref["anc"][: t + 1]), axis=1) for t in range(len(obs))]
+sizes = %(sizes)r
+begins = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+lo, hi = int(begins[rank]), int(begins[rank + 1])
+bound = -0.5 * np.log(2 * np.pi)
+k = O.lib().orc_strata_levels(N); K = 1 << k
+n_moved = 0
+for t in range(len(obs) - 1):
+    lw = -0.5 * ((obs[t] - ref["hist"][t][lo:hi]) ** 2 + np.log(2 * np.pi))
+    q = O.fix_weights(lw, bound)
+    masses = [int(m) for m in D.allgather_vector(np.array([float(int(q.astype(np.uint64).sum()))]))[:, 0]]      # (exact below 2^53)
+    P = [0]
+    for m in masses: P.append(P[-1] + m)
+    total = P[-1]
+    anc = O.resample_fixed_multinomial_strata_shard(q, seed, t + 1, P[rank], total, N)       # the stand-in for the device: -1 = another rank's
+    tau = [int(x) for x in O.strata_thresholds_fixed(total, seed, t + 1, N)[0]]
+    plan = D.StrataCutPlan(P, [(total * w) >> k for w in range(K + 1)], O.multinomial_strata(seed, t + 1, N), begins, lambda a, b: tau[a:b])
+    mine = sorted(plan.sends(rank))
+    assert all(anc[s] >= 0 for s, d in mine) and sum(anc >= 0) == len(mine) + sum(1 for s in range(lo, hi) if anc[s] >= 0)
+    width = t + 1
+    send, sc = [], []
+    for p in range(world):
+        ss = [s for s, d in mine if d == p]
+        sc.append(len(ss))
+        send.append(paths_all[t][:, lo + anc[ss]].T.reshape(-1) if ss else np.zeros(0))
+    rc = [sum(1 for s, d in plan.sends(p) if d == rank) for p in range(world)]
+    assert sum(rc) == plan.arrivals(rank)
+    h_recv = D.host_all_to_all(torch.from_numpy(np.concatenate(send)), [c * width for c in sc], [c * width for c in rc]).numpy()
+    n_moved += sum(sc)
+    annex = np.full((width, plan.arrivals(rank)), np.nan)
+    off = 0
+    for p in range(world):
+        ss = sorted(s for s, d in plan.sends(p) if d == rank)
+        recs = h_recv[off: off + len(ss) * width].reshape(len(ss), width)
+        for i, s in enumerate(ss):
+            annex[:, plan.column(rank, s)] = recs[i]
+        off += len(ss) * width
+    assert not np.isnan(annex).any()                                              # every annex column was filled exactly ... (below) with the right lineage
+    got = np.zeros((width, hi - lo))
+    for s in range(lo, hi):
+        got[:, s - lo] = paths_all[t][:, lo + anc[s]] if anc[s] >= 0 else annex[:, plan.column(rank, s)]
+    want = paths_all[t][:, ref["anc"][t + 1][lo:hi]]
+    assert np.array_equal(got, want), (rank, t)
+tot = torch.tensor([n_moved]); dist.all_reduce(tot)
+assert int(tot) > 0
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("world,sizes", [(2, [3000, 3001]), (3, [2500, 1701, 1800])])
+def test_gloo_multinomial_exchange_moves_the_single_process_lineages(tmp_path, world, sizes):
+    """Multinomial resampling of one population across real processes, on CPU: the strata cut plan (cpprob_amd/distributed.py) against
+    the single-process oracle run -- world 2, and world 3 with uneven shards that start at odd particles."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_STRATA_WORKER % {"root": ROOT, "world": world, "sizes": sizes, "n": sum(sizes)})
+    import socket
+    for attempt in range(2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(script)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if out.returncode == 0:
+            break
+    assert out.returncode == 0, out.stdout[-2500:] + out.stderr[-2500:]
+    assert out.stdout.count("ok") == world
+
+
 def test_bench_cli_parses_and_graft_entry_builds():
     import importlib
     ge = importlib.import_module("__graft_entry__")

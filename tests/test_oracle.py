@@ -526,3 +526,110 @@ def test_oracle_repairs_a_generation_that_loses_its_bits():
     b = O.smc_ref(O.MODEL_LINEAR_GAUSSIAN_1D, obs, 5000, 8, O.REF_FLOATING_POINT, O.RESAMPLE_SYSTEMATIC, 0.5)
     assert np.isfinite(a["log_z"]) and abs(a["log_z"] - b["log_z"]) < 1e-6 and np.array_equal(a["resampled"], b["resampled"])
     assert np.mean(a["anc"] != b["anc"]) < 1e-3
+
+
+def test_strata_form_is_independent_of_how_the_population_is_cut_into_shards():
+    """Multinomial resampling, strata form, over shards of ONE population (orc_resample_fixed_multinomial_strata_shard /
+    orc_resample_table_multinomial_shard: population-wide strata and output ids, each shard searching only the thresholds inside
+    its own mass range): every output is claimed by exactly one shard, and the ancestors are the single-population form's."""
+    rng = np.random.default_rng(1)
+    for n in (700, 5000, 20000):
+        lw = rng.normal(size=n) * 2
+        q = O.fix_weights(lw, lw.max() + 0.3)
+        tot = int(q.astype(np.uint64).sum())
+        ref = O.resample_fixed_multinomial_strata(q, 5, 3)
+        for cuts in ([n // 2], [n // 3, n // 3 + 5, n - 100], [10, 20, 30]):
+            b = [0] + cuts + [n]
+            got = np.full(n, -1, np.int64)
+            for r in range(len(b) - 1):
+                a = O.resample_fixed_multinomial_strata_shard(q[b[r]:b[r + 1]], 5, 3, int(q[:b[r]].astype(np.uint64).sum()), tot, n)
+                m = a >= 0
+                assert (got[m] == -1).all()
+                got[m] = a[m] + b[r]
+            assert np.array_equal(got, ref)
+        x = rng.integers(0, 3, n).astype(np.int32)
+        e = np.array([0.3, 1.0, 0.05])
+        ref = O.resample_table_multinomial(x, e, 5, 3)
+        b = [0, n // 3, n // 3 + 5, n - 100, n]
+        total = np.bincount(x, minlength=3).astype(np.uint64)
+        got = np.full(n, -1, np.int64)
+        for r in range(4):
+            a = O.resample_table_multinomial_shard(x[b[r]:b[r + 1]], e, 5, 3, np.bincount(x[:b[r]], minlength=3).astype(np.uint64), total, r == 3, n)
+            m = a >= 0
+            assert (got[m] == -1).all()
+            got[m] = a[m] + b[r]
+        assert np.array_equal(got, ref)
+
+
+def _check_cut_plan(P, sizes, seed, step, table=None):
+    from cpprob_amd import distributed as D
+    world, N = len(sizes), sum(sizes)
+    begins = np.concatenate([[0], np.cumsum(sizes)])
+    k = O.lib().orc_strata_levels(N)
+    K = 1 << k
+    offs = O.multinomial_strata(seed, step, N)
+    if table is None:
+        B = [(P[-1] * w) >> k for w in range(K + 1)]
+        tau = [int(t) for t in O.strata_thresholds_fixed(P[-1], seed, step, N)[0]]
+    else:
+        unit = np.ldexp(P[-1], -k)
+        B = [float(w) * unit for w in range(K + 1)]
+        tau = [float(t) for t in O.strata_thresholds_table(P[-1], seed, step, N)[0]]
+    plan = D.StrataCutPlan(P, B, offs, begins, lambda a, b: tau[a:b], table_form=table is not None)
+    src = [max(r for r in range(world) if P[r] <= t) for t in tau]                 # the definition: whose mass range holds the threshold
+    dst = [max(r for r in range(world) if begins[r] <= s) for s in range(N)]
+    for r in range(world):
+        assert all(src[s] == r for s in range(plan.A[r], plan.Z[r + 1]))          # a rank's regular interval is its sources' alone
+    n_mig = 0
+    for d in range(world):
+        col = 0
+        for s in range(begins[d], begins[d + 1]):
+            if src[s] != d:
+                assert plan.column(d, s) == col                                    # immigrants take the annex columns in output order
+                col += 1
+        assert plan.arrivals(d) == col
+        n_mig += col
+    sends = sorted(sum([[(s, d, r) for s, d in plan.sends(r)] for r in range(world)], []))
+    assert sends == sorted((s, dst[s], src[s]) for s in range(N) if src[s] != dst[s])
+    return n_mig
+
+
+def test_strata_cut_plan_equals_its_definition():
+    """The exchange plan of a multinomial resampling step (cpprob_amd/distributed.py: StrataCutPlan = the host statement of
+    csrc/strata_cut.hpp + exchange_cut_kernel): regular intervals + tables over the strata the ranks' boundaries cut, against the
+    definition (source rank of every threshold by comparison with the ranks' bounds; annex columns by counting) -- even and wildly
+    uneven masses, ranks without mass, several boundaries inside one stratum, boundaries exactly ON strata bounds, both forms."""
+    rng = np.random.default_rng(3)
+    moved = 0
+    for trial in range(40):
+        world = int(rng.integers(2, 7))
+        sizes = [int(x) for x in rng.integers(1, 3000, world)]
+        kind = trial % 4
+        if kind == 0:
+            masses = [int(s * 2**30 * rng.uniform(0.7, 1.3)) for s in sizes]
+        elif kind == 1:
+            masses = [int(rng.integers(1, 2**20)) if rng.random() < 0.5 else int(2**40 * rng.random()) for _ in sizes]
+            masses[0] += 2**24
+        elif kind == 2:
+            masses = [0 if rng.random() < 0.4 else int(2**36 * rng.random()) + 1 for _ in sizes]
+            masses[int(rng.integers(0, world))] += 2**24
+        else:
+            K = 1 << O.lib().orc_strata_levels(sum(sizes))
+            cuts = sorted(rng.integers(0, K + 1, world - 1))
+            Pb = [0] + [int(c) * 2**20 for c in cuts] + [K * 2**20]
+            masses = [Pb[i + 1] - Pb[i] for i in range(world)]
+        P = [0]
+        for m in masses:
+            P.append(P[-1] + int(m))
+        moved += _check_cut_plan(P, sizes, 11 + trial, 1 + trial % 5)
+    assert moved > 10000
+    moved = 0
+    for trial in range(16):
+        world = int(rng.integers(2, 6))
+        sizes = [int(x) for x in rng.integers(1, 3000, world)]
+        x = rng.integers(0, 3, sum(sizes))
+        e = np.array([1.0, 0.5, 0.25]) if trial % 3 == 0 else np.exp(-rng.random(3) * 3)          # (exactly representable: bounds may coincide)
+        begins = np.concatenate([[0], np.cumsum(sizes)])
+        P = [O.table_cdf(np.bincount(x[:b], minlength=3), e) for b in begins]
+        moved += _check_cut_plan(P, sizes, 100 + trial, 1 + trial % 3, table=e)
+    assert moved > 1000
