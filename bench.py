@@ -400,30 +400,49 @@ def live_pmc_traffic(workload, n, resampler, seed, flags, dom):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     vals = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    sq = None
+    # (a third pass of its own for the issue counters: wave cycles, cycles waiting on anything, cycles issuing vector instructions, instruction counts)
+    for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES")):
+        ctr = group[0]
         d = tempfile.mkdtemp(prefix="cpprob_pmc_", dir="/tmp")
         try:
-            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child", workload, str(n), resampler, str(seed), str(flags)]
+            cmd = [exe, "--pmc"] + list(group) + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child", workload, str(n), resampler, str(seed), str(flags)]
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not fs:
-                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, p.returncode, p.stderr[-200:])
-            acc = []
+                if len(group) > 1:
+                    sq = {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (" ".join(group), p.returncode, p.stderr[-200:])}
+                    continue
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, p.returncode, p.stderr[-200:]), None
+            acc = {c: [] for c in group}
             for r in csv.DictReader(open(fs[0])):
                 name = r.get("Kernel_Name", "")
                 hit = ("smc_step" in name) if dom == "smc_step" else ("sis_" in name and "finish" not in name)
-                if hit and r.get("Counter_Name") == ctr:
-                    acc.append(float(r["Counter_Value"]))
-            if not acc:
-                return None, "no %s samples of the %s kernel" % (ctr, dom)
-            vals[ctr] = (sum(acc) / len(acc), len(acc))
+                if hit and r.get("Counter_Name") in acc:
+                    acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if len(group) > 1:
+                if all(acc[c] for c in group):
+                    tot = {c: sum(acc[c]) for c in group}
+                    sq = {"wait_frac": tot["SQ_WAIT_ANY"] / max(tot["SQ_WAVE_CYCLES"], 1.0), "valu_issue_frac": tot["SQ_ACTIVE_INST_VALU"] / max(tot["SQ_WAVE_CYCLES"], 1.0),
+                          "valu_insts_per_wave": tot["SQ_INSTS_VALU"] / max(tot["SQ_WAVES"], 1.0), "salu_insts_per_wave": tot["SQ_INSTS_SALU"] / max(tot["SQ_WAVES"], 1.0),
+                          "launches": len(acc["SQ_WAVE_CYCLES"]),
+                          "measured_in": "this run: one rocprofv3 --pmc pass of the issue counters (SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES) over %d launches" % len(acc["SQ_WAVE_CYCLES"])}
+                else:
+                    sq = {"error": "no issue-counter samples of the %s kernel" % dom}
+                continue
+            if not acc[ctr]:
+                return None, "no %s samples of the %s kernel" % (ctr, dom), None
+            vals[ctr] = (sum(acc[ctr]) / len(acc[ctr]), len(acc[ctr]))
         except Exception as e:      # noqa: the line falls back and says so
-            return None, "rocprofv3 --pmc %s: %s" % (ctr, e)
+            if len(group) > 1:
+                sq = {"error": "rocprofv3 --pmc (issue counters): %s" % e}
+                continue
+            return None, "rocprofv3 --pmc %s: %s" % (ctr, e), None
         finally:
             shutil.rmtree(d, ignore_errors=True)
     traffic = 2.0 * vals["FETCH_SIZE"][0] * 1024.0 + vals["WRITE_SIZE"][0] * 1024.0
     return traffic, ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE over %d launches, WRITE_SIZE over %d) of a child process on this GPU, "
-                     "bytes = 2 x FETCH_SIZE KB x 1024 + WRITE_SIZE KB x 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reads half)" % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]))
+                     "bytes = 2 x FETCH_SIZE KB x 1024 + WRITE_SIZE KB x 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reads half)" % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1])), sq
 
 
 def main():
@@ -630,7 +649,7 @@ def main():
     achieved = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
     # HBM bytes per launch and issue counters from the PMC passes: collected by separate rocprofv3 --pmc runs of this same command
     # (tools/profile_round.sh) and committed with their correction notes; bench.py itself cannot run the profiler
-    traffic, traffic_src, valu_frac, wait_frac = None, None, None, None
+    traffic, traffic_src, valu_frac, wait_frac, sq_src, sq_live = None, None, None, None, None, None
     import glob
     pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if pmcs and spec["alg"] == cp.ALG_SMC and args.loopback_ranks <= 1:
@@ -642,8 +661,13 @@ def main():
             traffic_src = "committed profile profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on another box, gfx950-corrected): NOT measured in this run" % os.path.basename(pmcs[-1])
             valu_frac = rec["step_kernel"].get("valu_issue_frac")
             wait_frac = rec["step_kernel"].get("wait_frac")
+            sq_src = "committed profile profiles/%s: NOT measured in this run" % os.path.basename(pmcs[-1])
     if rank == 0 and world == 1 and args.loopback_ranks <= 1 and not args.no_live_pmc:
-        live, why = live_pmc_traffic(args.workload, n_prof, args.resampler, args.seed, args.flags, dom)
+        live, why, sq_live = live_pmc_traffic(args.workload, n_prof, args.resampler, args.seed, args.flags, dom)
+        if sq_live and "wait_frac" in sq_live:
+            valu_frac, wait_frac, sq_src = sq_live["valu_issue_frac"], sq_live["wait_frac"], sq_live["measured_in"]
+        elif sq_live:
+            sq_src = (sq_src or "no committed profile") + "; live issue-counter pass unavailable: " + sq_live.get("error", "?")
         if live is not None:
             traffic, traffic_src = live, why
         else:
@@ -657,7 +681,8 @@ def main():
     roofline = {"bound": bound, "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "step_form": FORM_NAMES.get(step_form, str(step_form)) if spec["alg"] == cp.ALG_SMC else None,
                 "layout_bytes_per_unit": layout_bytes, "achieved_layout": achieved_layout, "frac_layout": achieved_layout / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_measured_in": traffic_src, "hbm_frac_measured": hbm_frac_measured, "valu_issue_frac": valu_frac, "wait_frac": wait_frac,
+                "traffic": traffic, "traffic_measured_in": traffic_src, "hbm_frac_measured": hbm_frac_measured, "valu_issue_frac": valu_frac, "wait_frac": wait_frac, "issue_counters_measured_in": sq_src,
+                "valu_insts_per_wave": sq_live.get("valu_insts_per_wave") if sq_live else None, "salu_insts_per_wave": sq_live.get("salu_insts_per_wave") if sq_live else None,
                 "launch_floor_us": floor_us, "floor_frac": floor_us / (avg_s * 1e6) if avg_s > 0 else None, "algorithmic_bytes_per_unit": bytes_per_unit, "algorithmic_bytes_per_unit_no_resampling": light if spec["alg"] == cp.ALG_SMC else None,
                 "units_per_launch": n_prof, "avg_launch_us": avg_s * 1e6, "launches": int(dom_calls), "resampling_launches_per_run": n_res_prof if spec["alg"] == cp.ALG_SMC else None,
                 "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]}}
@@ -667,7 +692,7 @@ def main():
         "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 log-weights, 32-bit fixed-point masses" if (spec["alg"] == cp.ALG_SMC and step_form == 2) else "f64", "data": "synthetic",
-        "config": {"workload": "%s, %d particles per GPU" % (spec["desc"], n), "particles_per_gpu": n, "T": T,
+        "config": {"workload": "%s, %d particles per GPU" % (spec["desc"].replace("systematic resampling", args.resampler.replace("_", " ") + " resampling"), n), "particles_per_gpu": n, "T": T,
                    "resampler": args.resampler, "ess_threshold": spec["ess"], "scope": scope, "n_global": n_global, "collective": collective,
                    "host": host if (world > 1 or group is not None) else "one context, one stream", "exchange_reruns": reruns, "flags": args.flags},
         "particle_steps_per_sec": value * T,
@@ -788,6 +813,9 @@ def main():
             out["generic_path"]["builtin_registration_same_call_ms"] = b_ms
             out["generic_path"]["vs_builtin_registration_same_call"] = g_ms / b_ms
             out["generic_path"]["four_particles_a_lane_ms"] = main_ms(["--generic", "--step_form", "3"])
+            # the step kernels built per step (model_step_kernel_at) against the run-time kernel alone: the same call, the builds switched off
+            out["generic_path"]["step_builds_used"] = gj.get("step_builds_used")
+            out["generic_path"]["run_time_kernel_only_ms"] = main_ms(["--generic", "--no_step_builds"])
             # the same population as FOUR ranks of one joint population on this GPU (loopback: the pull migration and the per-step host all-gather at work)
             with tempfile.TemporaryDirectory() as td:
                 cmd = [exe, "--model_folder", td, "--model", "hmm16", "--smc", "--observes", obs_s, "--n_samples", str(n), "--seed", str(args.seed),
@@ -822,7 +850,8 @@ def main():
                     rp = eng.profile_read(reset=True)
                     eng.profile_enable(False)
                     sm = eng.summary()
-                    row[name] = {"ms_per_run": rdt / k2 * 1e3, "step_us": rp["smc_step"][0] * 1e3 / max(rp["smc_step"][1], 1),
+                    # (the step launches' HIP-event time over the profiled runs / the launches those runs made: k2 runs x T steps)
+                    row[name] = {"ms_per_run": rdt / k2 * 1e3, "step_us": rp["smc_step"][0] * 1e3 / (k2 * len(obs)),
                                  "resample_only_us_per_run": rp["resample"][0] * 1e3 / k2, "step_form": FORM_NAMES.get(int(sm.get("step_form", 0))),
                                  "n_resampled": sm["n_resampled"], "posterior_max_abs_err_vs_exact": float(np.abs(eng.stats() - exact).max())}
                 except Exception as e:      # noqa: reported under the key
@@ -834,6 +863,27 @@ def main():
         res["note"] = ("ms per run of a whole inference (read-out included), same seed and sizes; step_us = HIP-event mean of the step launches; resample_only_us_per_run = the launches a "
                        "resampler adds in front of its steps (strata form of multinomial: every step's stratum counts in two launches at the run's start)")
         out["resamplers"] = res
+
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "hmm16_smc" and args.resampler == "systematic" and group is None:
+        # secondary: the three resamplers as ONE joint population over eight loopback shards of this GPU (the whole exchange protocol on one
+        # stream; exact: every run equals the one-GPU run's traces bit for bit, tests/test_gpu_group.py) -- multinomial (thesis Alg. 1) in
+        # the strata form: regular intervals + the strata the ranks' boundaries cut (csrc/strata_cut.hpp)
+        sh = {}
+        for name in ("systematic", "stratified", "multinomial"):
+            try:
+                rid, rfl = resampler_of(name)
+                g8 = cp.Group([local] * 8)
+                g8.begin(spec["alg"], spec["model"], spec["obs"], n, seed=args.seed, resampler=rid, ess_threshold=spec["ess"], flags=rfl)
+                k2 = max(3, min(args.steps, 10))
+                gdt, gstats, gsum, grr = timed_group_runs(g8, k2, 2, 1, device, first_index=90_000)
+                tr8 = g8.traffic()
+                sh[name] = {"ms_per_run": gdt / k2 * 1e3, "reruns": grr if not isinstance(grr, dict) else grr.get("reruns"), "records_per_run": tr8["records"],
+                            "posterior_max_abs_err_vs_exact": float(np.abs(gstats - spec["exact"]).max())}
+                g8.close()
+            except Exception as e:      # noqa: reported under the key
+                sh[name] = {"error": str(e)}
+        sh["note"] = "cpprob_hip_group_run, 8 loopback ranks sharing this GPU and one stream (the ranks' launches serialise: a protocol figure, not a scaling one); %d particles in all" % n
+        out["sharded_resamplers"] = sh
 
     if rank == 0 and world == 1 and not args.no_extras:
         # error bars: five run seeds of the headline configuration against the exact posterior
@@ -925,6 +975,27 @@ def main():
             except Exception as e:
                 out["cpu_baseline"]["as_shipped_sis_1core"] = {"error": str(e)}
 
+    # the secondary numbers as scalars where the driver's record keeps them whole (`roofline`): every number README quotes
+    def _get(*ks):
+        d = out
+        for k in ks:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    wl0 = "hmm16_smc@%d" % n
+    out["roofline"].update({
+        "generic_ms": _get("generic_path", "ms_per_run"), "generic_vs_fused": _get("generic_path", "vs_fused_kernels"),
+        "generic_vs_builtin_same_call": _get("generic_path", "vs_builtin_registration_same_call"), "generic_step_builds_used": _get("generic_path", "step_builds_used"),
+        "generic_no_step_builds_ms": _get("generic_path", "run_time_kernel_only_ms"),
+        "stratified_vs_systematic": _get("resamplers", wl0, "stratified", "vs_systematic"), "multinomial_vs_systematic": _get("resamplers", wl0, "multinomial", "vs_systematic"),
+        "lgssm100_1250000_systematic_ms": _get("resamplers", "lgssm100_smc@1250000", "systematic", "ms_per_run"),
+        "lgssm100_1250000_multinomial_vs_systematic": _get("resamplers", "lgssm100_smc@1250000", "multinomial", "vs_systematic"),
+        "gaussian_sis_particles_per_s": _get("gaussian_sis_1e7", "particles_per_sec"),
+        "gaussian_sis_hbm_frac": (_get("gaussian_sis_1e7", "sis_kernel_GBs") / HBM_PEAK_GBS) if _get("gaussian_sis_1e7", "sis_kernel_GBs") else None,
+        "pipelined_particles_per_s": _get("pipelined", "particles_per_sec"), "filtering_only_particles_per_s": _get("filtering_only", "particles_per_sec"),
+        "multinomial_8_loopback_shards_ms": _get("sharded_resamplers", "multinomial", "ms_per_run"), "systematic_8_loopback_shards_ms": _get("sharded_resamplers", "systematic", "ms_per_run"),
+    })
     emit()
     if group is not None:
         group.close()

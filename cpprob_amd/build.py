@@ -70,18 +70,48 @@ def _tree(d, exts):
     return out
 
 
+# Step kernels built per step (cpprob/gpu.hpp: model_step_kernel_at): one source, one object per (model, part) -- the optimiser needs
+# ~a minute per build of a 128-observe model, so the builds are dealt over objects that compile side by side.
+STEPS_SRC = os.path.join(EXAMPLES, "registered_steps.hip")
+STEPS_FLAGS = ["-mllvm", "-unroll-threshold=2000000", "-mllvm", "-inline-threshold=10000000", "-mllvm", "-amdgpu-inline-max-bb=1000000",
+               "-mllvm", "-memdep-block-scan-limit=2000", "-mllvm", "-memdep-block-number-limit=2000"]
+STEPS_UNITS = [(0, 1), (1, 2), (2, 7), (3, 7)]          # (CPPROB_STEPS_MODEL, parts): hmm<16>, linear_gaussian_1d<25>, hmm<128>, linear_gaussian_1d<100>
+
+
 def build_models(force=False, verbose=False):
-    """Model translation unit: the model source compiled for host AND device by hipcc (C++17),
-    registered with the engine (cpprob/gpu.hpp)."""
-    srcs = _tree(INC, (".hpp", ".h")) + _tree(EXAMPLES, (".hpp", ".hip")) + [LIB]
+    """Model translation units: the model source compiled for host AND device by hipcc (C++17), registered with the engine
+    (cpprob/gpu.hpp); the per-step kernels in objects of their own, compiled in parallel."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = _tree(INC, (".hpp", ".h")) + _tree(EXAMPLES, (".hpp", ".hip")) + [LIB, os.path.abspath(__file__)]
     if not force and not _newer(MODELS_LIB, srcs):
         return MODELS_LIB
-    cmd = [HIPCC, "-O2", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-I", INC,
-           "-I", EXAMPLES, "-o", MODELS_LIB, os.path.join(EXAMPLES, "registered_models.hip"), "-L", LIBDIR, "-lcpprob_hip",
-           "-Wl,-rpath,$ORIGIN"]
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    common = [HIPCC, "-O2", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-c", "-I", os.path.join(ROOT, "include"), "-I", INC, "-I", EXAMPLES]
+    jobs = [(os.path.join(objdir, "registered_models.o"), common + ["-o", os.path.join(objdir, "registered_models.o"), os.path.join(EXAMPLES, "registered_models.hip")])]
+    if os.environ.get("CPPROB_NO_STEP_BUILDS", "") == "":
+        for model, parts in STEPS_UNITS:
+            for part in range(parts):
+                o = os.path.join(objdir, "steps_%d_%d.o" % (model, part))
+                jobs.append((o, common + STEPS_FLAGS + ["-DCPPROB_STEPS_MODEL=%d" % model, "-DCPPROB_STEPS_PART=%d" % part, "-DCPPROB_STEPS_PARTS=%d" % parts, "-o", o, STEPS_SRC]))
+    t0 = time.time()
+
+    def run(job):
+        t1 = time.time()
+        subprocess.check_call(job[1])
+        return job[0], time.time() - t1
+    # (the longest jobs first: the 128- and 100-observe builds)
+    order = sorted(jobs, key=lambda j: 0 if ("steps_2_" in j[0] or "steps_3_" in j[0]) else 1)
+    with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as ex:
+        done = list(ex.map(run, order))
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", MODELS_LIB] + [j[0] for j in jobs] + ["-L", LIBDIR, "-lcpprob_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if verbose:
+        print("model units: %d objects in %.0f s wall (%.0f s of compiler time; slowest %.0f s), %s = %.1f MB" %
+              (len(jobs), time.time() - t0, sum(d[1] for d in done), max(d[1] for d in done), os.path.basename(MODELS_LIB), os.path.getsize(MODELS_LIB) / 1e6))
     return MODELS_LIB
 
 

@@ -460,7 +460,9 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_strata_kernel(PackStra
         int64_t* const origin = const_cast<int64_t*>(rem->origin[d]);
         uint32_t* const annex_trace = a.trace_cur ? rem->trace[a.trace_par][d] + rem->ld[d] : nullptr;
         const int64_t col0 = s_fill[d], room = rem->rs[d] - rem->ld[d];
-        for (uint32_t tile = lo / kTile + blockIdx.x; (uint64_t)tile * kTile < hi; tile += gridDim.x) {
+        // (the items' first tiles go to different workgroups: a workgroup walks its tiles one after the other)
+        const uint32_t bx = (blockIdx.x + gridDim.x - (uint32_t)item % gridDim.x) % gridDim.x;
+        for (uint32_t tile = lo / kTile + bx; (uint64_t)tile * kTile < hi; tile += gridDim.x) {
             const uint32_t g0 = tile * kTile;
             const uint32_t s_first = max(lo, g0), s_last = min(hi, g0 + kTile) - 1;
             const uint64_t gj = (uint64_t)g0 + (uint64_t)tid * kPPT;

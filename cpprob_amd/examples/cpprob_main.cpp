@@ -37,7 +37,7 @@ void print_json(const cpprob::gpu::Result& r)
     std::cout << "{\"n\": " << r.n_particles << ", \"log_evidence\": " << r.log_evidence << ", \"ess\": " << r.ess
               << ", \"n_resampled\": " << r.n_resampled << ", \"run_seconds\": " << r.run_seconds << ", \"builtin\": " << (r.used_builtin ? "true" : "false")
               << ", \"n_gpus\": " << r.n_gpus << ", \"exchange_reruns\": " << r.exchange_reruns << ", \"replay_window\": " << r.replay_window << ", \"markov_crosscheck\": " << r.markov_crosscheck
-              << ", \"joint\": " << (r.joint ? "true" : "false") << ", \"joint_note\": \"" << r.joint_note << "\"" << ", \"step_form\": " << r.step_form << ", \"launches_per_step\": " << r.launches_per_step << ", \"setup_seconds\": " << r.setup_seconds
+              << ", \"joint\": " << (r.joint ? "true" : "false") << ", \"joint_note\": \"" << r.joint_note << "\"" << ", \"step_form\": " << r.step_form << ", \"launches_per_step\": " << r.launches_per_step << ", \"step_builds_used\": " << r.step_builds_used << ", \"setup_seconds\": " << r.setup_seconds
               << ", \"workspace_grown\": " << (r.workspace_grown ? "true" : "false") << ", \"predicts\": [";
     for (std::size_t i = 0; i < r.predicts.size(); ++i) {
         const auto& p = r.predicts[i];
@@ -138,6 +138,7 @@ int main(int argc, char** argv)
             while (p0 <= v.size()) { const std::size_t q = v.find(',', p0); opt.devices.push_back(std::stoi(v.substr(p0, q == std::string::npos ? q : q - p0))); if (q == std::string::npos) break; p0 = q + 1; }
         }
         else if (f == "--repeat") a.repeat = std::stoi(next());
+        else if (f == "--no_step_builds") opt.step_builds = false;          // unchanged-model smc: the run-time step kernel at every step (A/B against the per-step builds)
         else if (f == "--replicates") opt.replicates = std::stoi(next());
         else if (f == "--no_dump") opt.dump = false;
         else if (f == "--json") a.json = true;

@@ -140,6 +140,14 @@ struct WinRec { uint32_t &n_sample, &n_other, &lim_sample, &lim_other; };
 constexpr uint32_t kWObserve = 1u, kWPredInt = 1u << 12, kWPredReal = 1u << 22;
 constexpr uint32_t kWinMaxObserves = 4095u, kWinMaxPredicts = 1023u;
 __device__ inline uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// "some lane of the wavefront": one vector compare and a scalar branch.  Where the condition is a compile-time fact (the step kernels
+// built for ONE step: cpprob/gpu.hpp, model_step_kernel_at) it is that fact -- a ballot of `true` is the execution mask, which the
+// optimiser does not know to be non-zero, and everything behind the step's live observe would stay in the kernel as code nobody runs.
+__device__ __forceinline__ bool wave_any(bool c)
+{
+    if (__builtin_constant_p(c)) return c;
+    return __ballot(c) != 0ull;
+}
 __device__ inline char* lane_lds()
 {
     extern __shared__ __attribute__((aligned(16))) char cpprob_lane_lds[];
@@ -850,7 +858,7 @@ __device__ __forceinline__ typename std::decay_t<Distribution>::result_type samp
             rec.n_sample = n_own + 1u;
             // (the test on the lanes' own words, made uniform by the ballot: one vector compare and a scalar branch -- the scalar
             //  unit, shared by the CU's four SIMDs, is what bounds the dead iterations; the ordinal goes through it on the live path only)
-            if (__ballot(n_own < rec.lim_sample) != 0ull) return R();     // older than the window: the step does not depend on it (host probe)
+            if (wave_any(n_own < rec.lim_sample)) return R();     // older than the window: the step does not depend on it (host probe)
             const int32_t jj = (int32_t)wave_uniform(n_own);
             const int32_t base = A->fresh_lo - (int32_t)A->win;
             R v;
@@ -894,13 +902,13 @@ __device__ __forceinline__ void observe_impl(Distribution& distr, const X& x)
             const WinRec rec = win_rec();
             const uint32_t own = rec.n_other, lim_own = rec.lim_other;
             rec.n_other = own + kWObserve;
-            if (__ballot((own & 0xfffu) >= (lim_own & 0xfffu)) != 0ull) {
+            if (wave_any((own & 0xfffu) >= (lim_own & 0xfffu))) {
                 const uint32_t w = wave_uniform(own), lim = wave_uniform(lim_own);
                 const uint32_t m = w & 0xfffu;
                 // (a lane whose counters differ from its wavefront's executed other statements: the counts DO depend on sampled values,
                 //  the probe notwithstanding -- reported, and the host repeats the run with full replay; counters only grow, so the
                 //  step's live observe sees whatever went apart before it)
-                if (__ballot(own != w || rec.n_sample != wave_uniform(rec.n_sample)) != 0ull && A->overflow) *A->overflow = 3;
+                if (wave_any(own != w || rec.n_sample != wave_uniform(rec.n_sample)) && A->overflow) *A->overflow = 3;
                 lane_log_w() += logpdf<std::decay_t<Distribution>>()(distr, x);     // StateInfer::increment_log_prob, state.cpp:212-223
                 if (m + 1 == (lim >> 16)) {                                          // every lane of the wavefront is here
                     if (A->fused == kFusedQuad) {
@@ -949,7 +957,7 @@ __device__ __forceinline__ void predict_impl(const T& x)
             const WinRec rec = win_rec();
             const uint32_t own = rec.n_other;
             rec.n_other = own + (is_int ? kWPredInt : kWPredReal);
-            if (__ballot((own & 0xfffu) < (rec.lim_other & 0xfffu)) != 0ull) return;                    // an earlier step's hit: recorded by that step's launch
+            if (wave_any((own & 0xfffu) < (rec.lim_other & 0xfffu))) return;                    // an earlier step's hit: recorded by that step's launch
             const uint32_t w = wave_uniform(own);
             const uint32_t k = (w >> (is_int ? 12 : 22)) & 0x3ffu;
             if constexpr (is_int) {

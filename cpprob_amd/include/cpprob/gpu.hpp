@@ -130,6 +130,71 @@ __device__ __forceinline__ void model_step_body(const Tuple* __restrict__ observ
     device::step_epilogue();                                      // the run's last step: the body ran to completion
 }
 
+// Step kernels built for ONE step, or for the steps FROM an ordinal on (CPPROB_REGISTER_MODEL_STEPS, in a translation unit of its own).
+// model_step_kernel re-runs the model's loop from its first statement at every launch and tests every statement against the launch's
+// thresholds at run time: 0.4 - 0.7 us per dead iteration and launch, half of linear_gaussian_1d<100>'s run (O(T^2)).
+// With the step's thresholds as compile-time FACTS (__builtin_assume on the launch's arguments: the host launches a kernel only where
+// they hold) and the model's loop fully unrolled, the statement counters -- LDS words the optimiser forwards from store to load -- are
+// constants, a dead statement's test folds, its value feeds only dead statements, and the iteration vanishes with its table loads:
+//   EXACT   first_observe == FO, the window's ordinals == A FO .. A (FO + 1): the kernel is the step alone -- prologue, ONE live
+//           iteration, the publishing observe -- no loop, no dead statement (hmm<16>: 2 200 instructions against 3 600 with a loop);
+//   FROM    first_observe >= FO: the iterations below FO are gone, the others keep their run-time tests (models of many observes:
+//           one build per step costs the compiler ~a minute each at 128 observes -- GVN's store-to-load forwarding over the unrolled
+//           body -- so they get a build every T / 8 steps and run < T / 8 dead iterations a launch instead of t).
+// A = sample statements per observe (the models.hpp state-space models: 1), WIN = the replay window the host's probe finds (1).
+template <class Caller, class Tuple, int FO, int A, int WIN, bool EXACT, bool LAST>
+__global__ __launch_bounds__(device::kStepBlock) void model_step_kernel_at(ModelKernelArgs a, const Tuple* __restrict__ observes)
+{
+    (void)a;
+    {
+        const int32_t fo = device::launch_args()->first_observe, sa = device::launch_args()->stop_after, fl = device::launch_args()->fresh_lo, nf = device::launch_args()->next_fresh;
+        const uint32_t w = device::launch_args()->win;
+        __builtin_assume(w == (uint32_t)WIN);
+        if (EXACT) { __builtin_assume(fo == FO); __builtin_assume(sa == (LAST ? -1 : FO)); __builtin_assume(fl == A * FO); __builtin_assume(nf == A * (FO + 1)); }
+        else { __builtin_assume(fo >= FO); __builtin_assume(fo < 4096); __builtin_assume(fl >= A * FO); __builtin_assume(fl < (1 << 20)); __builtin_assume(nf >= A * (FO + 1)); __builtin_assume(nf < (1 << 20)); }
+    }
+    model_step_body<Caller, Tuple, false>(observes);
+}
+// the builds a model unit registered for Caller (one table per model, shared by every translation unit of the library)
+struct StepKernelEntry { int fo, a, win; bool exact, last; const void* fn; };
+template <class Caller>
+inline std::vector<StepKernelEntry>& step_kernels() { static std::vector<StepKernelEntry> v; return v; }
+// the build to launch for a step whose thresholds are these (nullptr: model_step_kernel)
+template <class Caller>
+const void* step_kernel_for(const ModelKernelArgs& a)
+{
+    const StepKernelEntry* best = nullptr;
+    for (const StepKernelEntry& e : step_kernels<Caller>()) {
+        if (e.win != (int)a.win) continue;
+        if (e.exact) {
+            if (a.first_observe == e.fo && a.stop_after == (e.last ? -1 : e.fo) && a.fresh_lo == e.a * e.fo && a.next_fresh == e.a * (e.fo + 1)) return e.fn;
+        } else if (a.first_observe >= e.fo && a.first_observe < 4096 && a.fresh_lo >= e.a * e.fo && a.next_fresh >= e.a * (e.fo + 1) && a.fresh_lo < (1 << 20) && a.next_fresh < (1 << 20)) {
+            if (!best || e.fo > best->fo) best = &e;
+        }
+    }
+    return best ? best->fn : nullptr;
+}
+constexpr int kStepExactMax = 32;               // observes up to which every step gets a build of its own
+constexpr int kStepFromBuilds = 8;              // beyond: a build every ceil(T / 8) steps
+template <class Caller, int T, int A, int WIN, int PART, int PARTS, int I>
+void register_step_build()
+{
+    using Tuple = typename Caller::observes_t;
+    constexpr bool exact = T <= kStepExactMax;
+    constexpr int G = (T + kStepFromBuilds - 1) / kStepFromBuilds;
+    constexpr int fo = exact ? I : I * G;
+    if constexpr (I % PARTS == PART && fo < T && (exact || I > 0)) {
+        constexpr bool last = exact && fo == T - 1;
+        step_kernels<Caller>().push_back(StepKernelEntry{fo, A, WIN, exact, last, reinterpret_cast<const void*>(&model_step_kernel_at<Caller, Tuple, fo, A, WIN, exact, last>)});
+    }
+}
+template <class Caller, int T, int A, int WIN, int PART, int PARTS, int... I>
+bool register_step_builds(std::integer_sequence<int, I...>)
+{
+    (register_step_build<Caller, T, A, WIN, PART, PARTS, I>(), ...);
+    return true;
+}
+
 // The QUAD step (cpprob/detail/device_trace.hpp: quad_prologue ...): a workgroup owns a 1024-particle tile as the library's fused
 // kernels do -- ONE search, one walk with four sources a lane, one publish -- and every lane runs the model body four times.
 template <class Caller, class Tuple>
@@ -291,7 +356,7 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
                   "copyable (arithmetic types, std::array of them); models with std::vector / NDArray arguments own host heap memory");
     const auto t_setup = std::chrono::steady_clock::now();
     // (what an earlier attempt of the same call reported is not this attempt's: a refuted window must not outlive its refutation)
-    res.replay_window = -1; res.step_ess.clear(); res.n_resampled = 0;
+    res.replay_window = -1; res.step_ess.clear(); res.n_resampled = 0; res.step_builds_used = 0;
     WorkspaceLease ws(opt.device);
     Context& ctx = ws->ctx;
     hip_check(hipSetDevice(opt.device), "hipSetDevice");
@@ -433,6 +498,13 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
                 a.fs.bound = (form == StepForm::fused_bounded || quad) ? st.observe_bound[(size_t)t] : 0.0;
                 a.fs.t = t; a.fs.anc_row = d_anc_all + (size_t)t * n;
                 if (quad) hipLaunchKernelGGL((model_step_kernel_quad<Caller, Tuple>), qgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+                else if (const void* at = opt.step_builds ? step_kernel_for<Caller>(a) : nullptr) {
+                    // (a build for this step: its thresholds are the kernel's compile-time facts -- checked above, where it was chosen)
+                    const Tuple* obs_p = d_obs;
+                    void* kargs[2] = {&a, &obs_p};
+                    hip_check(hipLaunchKernel(at, sgrid, sblock, kargs, step_lds, stream), "model_step_kernel_at");
+                    ++res.step_builds_used;
+                }
                 else if (step_full) hipLaunchKernelGGL((model_step_kernel_full<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
                 else hipLaunchKernelGGL((model_step_kernel<Caller, Tuple>), sgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
                 hip_check(hipGetLastError(), "model_step_kernel");
@@ -1127,6 +1199,15 @@ bool register_functor(const char* name)
 
 #define CPPROB_REGISTER_MODEL(fn) \
     static const bool CPPROB_PP_CAT(cpprob_reg_model_, __LINE__) = ::cpprob::gpu::register_model<decltype(&fn), &fn>(#fn)
+// Step kernels built per step for a model of n_observes observe statements, samples_per_observe sample statements each (see
+// model_step_kernel_at).  In a translation unit of its OWN, compiled with
+//     -mllvm -unroll-threshold=2000000 -mllvm -inline-threshold=10000000 -mllvm -amdgpu-inline-max-bb=1000000
+//     -mllvm -memdep-block-scan-limit=2000 -mllvm -memdep-block-number-limit=2000
+// (the model's loops fully unrolled, the model inlined whatever its size, store-to-load forwarding across the unrolled body); `part`
+// of `parts`: the builds are dealt over that many units, which compile side by side (cpprob_amd/build.py).
+#define CPPROB_REGISTER_MODEL_STEPS(fn, n_observes, samples_per_observe, part, parts) \
+    static const bool CPPROB_PP_CAT(cpprob_reg_steps_, __LINE__) = ::cpprob::gpu::register_step_builds< \
+        ::cpprob::gpu::FunctionCaller<decltype(&fn), &fn>, n_observes, samples_per_observe, 1, part, parts>(std::make_integer_sequence<int, (n_observes <= ::cpprob::gpu::kStepExactMax ? n_observes : ::cpprob::gpu::kStepFromBuilds)>{})
 // host function, its instantiation inside namespace cpprob_device_view (see cpprob/device_view_begin.hpp)
 #define CPPROB_REGISTER_MODEL_VIEW(host_fn, device_fn) \
     static const bool CPPROB_PP_CAT(cpprob_reg_view_, __LINE__) = ::cpprob::gpu::register_model_view<decltype(&host_fn), &host_fn, decltype(&device_fn), &device_fn>(#host_fn)

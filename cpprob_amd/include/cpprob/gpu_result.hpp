@@ -41,6 +41,8 @@ struct Options {
                                                       // the joint population (the default wherever the model has a joint form)
     int step_form_override = -1;                      // smc, unchanged-model path: -1 the engine chooses; 0 model launch + separate bookkeeping launches,
                                                       // 1 the resampling inside the model's launch against the dry run's bounds, 2 ... against exact maxima
+    bool step_builds = true;                          // smc, unchanged-model path: launch the step kernels built per step (CPPROB_REGISTER_MODEL_STEPS) where the model
+                                                      // unit holds them for a step's thresholds (false: always the run-time kernel -- the A/B switch)
     int replicates = 1;                               // built-in models: R independent runs (seeds seed .. seed + R - 1), up to three in
                                                       // flight on separate contexts; Result then carries their spread (error bars)
     bool joint_across_devices = false;                // smc, unchanged models, `devices` naming DIFFERENT GPUs: run the joint population (its peer reads have
@@ -70,6 +72,7 @@ struct Result {
     int step_form = 0;                        // unchanged-model smc: 0 separate bookkeeping launches, 1 fused step on bounded references, 2 fused step + exact-maximum pass,
                                               // 3 = 1 with four particles a lane behind one ancestor search (chosen for large populations of models with <= 32 observes)
     int launches_per_step = 0;                // unchanged-model smc: dependent launches per observe
+    int step_builds_used = 0;                 // unchanged-model smc: launches of the last attempt that ran a step kernel built for its step (model_step_kernel_at)
     double setup_seconds = 0;                 // unchanged-model path: context / workspace / scratch set-up and the Markov pilot of THIS call (0.0x ms once the workspace is warm)
     bool workspace_grown = false;             // ... this call created or enlarged its device workspace
     double run_seconds = 0;                   // device work of the run (launch to synchronise), excluding allocation and dumps

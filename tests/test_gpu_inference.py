@@ -864,8 +864,13 @@ def test_exchange_scope_world1_is_bit_identical_to_run(engine, golden_dir):
     assert np.array_equal(engine.values(), ref_vals) and cnt["records_sent"] == 0
     np.testing.assert_allclose(stats, ref_stats, rtol=1e-13, atol=1e-15)
     assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
+    # multinomial resampling in the exchange scope is the strata form over remote lineages (tests/test_gpu_group.py): the literal form and
+    # the synchronising plan / pack / commit calls refuse loudly
     with pytest.raises(cp.CpprobHipError):
-        engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, resampler=cp.RESAMPLE_MULTINOMIAL, scope=cp.SCOPE_EXCHANGE)
+        engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, resampler=cp.RESAMPLE_MULTINOMIAL, scope=cp.SCOPE_EXCHANGE, flags=cp.capi.FLAG_MULTINOMIAL_LITERAL)
+    engine.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, n, seed=4, resampler=cp.RESAMPLE_MULTINOMIAL, scope=cp.SCOPE_EXCHANGE)
+    with pytest.raises(cp.CpprobHipError):
+        D.run_exchange(engine, D.TorchCollective(engine))
 
 
 def test_contexts_in_flight_do_not_interfere(engine, golden_dir):
