@@ -23,7 +23,7 @@ SYMBOLS = [
     "cpprob_hip_stream", "cpprob_hip_sync", "cpprob_hip_set_hmm", "cpprob_hip_infer_begin", "cpprob_hip_infer_run", "cpprob_hip_infer_summary",
     "cpprob_hip_infer_stats", "cpprob_hip_infer_results", "cpprob_hip_infer_results_device", "cpprob_hip_infer_step_trace", "cpprob_hip_copy_values", "cpprob_hip_copy_ancestors",
     "cpprob_hip_copy_logw", "cpprob_hip_copy_paths", "cpprob_hip_smc_step_begin", "cpprob_hip_smc_step_end",
-    "cpprob_hip_smc_finish", "cpprob_hip_filter_masses", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
+    "cpprob_hip_smc_finish", "cpprob_hip_smc_first_bad_generation", "cpprob_hip_smc_repair_begin", "cpprob_hip_smc_repair_end", "cpprob_hip_filter_masses", "cpprob_hip_exchange_plan", "cpprob_hip_exchange_pack", "cpprob_hip_exchange_commit", "cpprob_hip_exchange_setup", "cpprob_hip_exchange_transport",
     "cpprob_hip_exchange_pack_async", "cpprob_hip_exchange_commit_async", "cpprob_hip_exchange_status", "cpprob_hip_exchange_direct", "cpprob_hip_exchange_traffic", "cpprob_hip_exchange_store", "cpprob_hip_exchange_remote",
     "cpprob_hip_group_create_external", "cpprob_hip_group_traffic", "cpprob_hip_group_profile", "cpprob_hip_group_profile_read", "cpprob_hip_group_note", "cpprob_hip_group_unique_id", "cpprob_hip_group_create", "cpprob_hip_group_destroy",
     "cpprob_hip_group_last_error", "cpprob_hip_group_begin", "cpprob_hip_group_transport", "cpprob_hip_group_run", "cpprob_hip_group_sync", "cpprob_hip_group_size",
@@ -111,6 +111,9 @@ def load_library(path=None):
         "cpprob_hip_smc_step_begin": (C.c_int, [vp, i32, u64, vp]),
         "cpprob_hip_smc_step_end": (C.c_int, [vp, i32, vp, i32, i32]),
         "cpprob_hip_smc_finish": (C.c_int, [vp]),
+        "cpprob_hip_smc_first_bad_generation": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+        "cpprob_hip_smc_repair_begin": (C.c_int, [vp, C.c_int32, vp]),
+        "cpprob_hip_smc_repair_end": (C.c_int, [vp, C.c_int32, vp, C.c_int32, C.c_int32, vp]),
         "cpprob_hip_filter_masses": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i32)]),
         "cpprob_hip_exchange_plan": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]),
         "cpprob_hip_exchange_pack": (C.c_int, [vp, i32, vp]),

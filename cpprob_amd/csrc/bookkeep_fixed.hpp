@@ -31,11 +31,19 @@ __global__ __launch_bounds__(kThreads) void bbf_max_kernel(const double* __restr
     }
 }
 
-__global__ __launch_bounds__(kThreads) void bbf_quantize_kernel(const double* __restrict__ logw, int64_t n, FHier f, uint32_t* __restrict__ q)
+// the largest log-weight of a generation held by several ranks: the maximum of the keys every rank left in word 0 of its three
+__device__ __forceinline__ double ranks_max(const uint64_t* __restrict__ all_keys, int world)
+{
+    const int lane = lane_id();
+    return dkey_inv(wave_max_u64(lane < world ? all_keys[3 * lane] : 0ull));
+}
+// all_keys != nullptr: one shard of a joint population -- the reference is the POPULATION's exact maximum (the ranks' all-gathered keys)
+__global__ __launch_bounds__(kThreads) void bbf_quantize_kernel(const double* __restrict__ logw, int64_t n, FHier f, uint32_t* __restrict__ q,
+                                                                 const uint64_t* __restrict__ all_keys = nullptr, int world = 0)
 {
     __shared__ uint64_t s_red[2 * kWaves];
     __shared__ double s_ref;
-    if (wave_id() == 0) { const double r = bbf_top_max(f); if (threadIdx.x == 0) s_ref = r; }
+    if (wave_id() == 0) { const double r = all_keys ? ranks_max(all_keys, world) : bbf_top_max(f); if (threadIdx.x == 0) s_ref = r; }
     __syncthreads();
     const double ref = s_ref;
     const int64_t j0 = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kPPT;

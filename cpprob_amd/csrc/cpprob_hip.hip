@@ -158,7 +158,8 @@ struct cpprob_hip_ctx {
     int32_t* d_bb_first = nullptr; size_t bb_first_cap = 0;
     std::vector<int32_t> bb_first_host;
     // exchange scope, mailbox collectives (group.hpp): the step's shard-totals launch carries the all-gather (device_collectives.hpp)
-    bool x_gather_on = false, x_gather_done = false; TotalsGather x_gather{}; unsigned long long x_gather_serial = 0;                              // what d_bb_first holds (an unchanged table is not uploaded again)
+    bool x_gather_on = false, x_gather_done = false; TotalsGather x_gather{}; unsigned long long x_gather_serial = 0;
+    int x_gather_tshift = 0;                 // (a run resumed behind a repaired generation numbers its collectives from there: group.hpp)                              // what d_bb_first holds (an unchanged table is not uploaded again)
 
     // cpprob_hip_smc_bookkeep_fixed: two alternating copies of a mass hierarchy + the integer weights
     uint64_t* d_bbf_hier = nullptr; HierTable* d_bbf_table = nullptr; HierTable bbf_table{}; uint32_t* d_bbf_q = nullptr;
@@ -1489,7 +1490,8 @@ int settle_fixed(cpprob_hip_ctx* c)
     }
     if (!c->last_was_infer_run)
         return fail(c, CPPROB_HIP_EPRECISION, "some generation's heaviest particle sat more than 6 nats below the fixed-point reference (an observation far from every particle): "
-                                               "repeat the run with CPPROB_HIP_FLAG_FLOATING_POINT_STEP");
+                                               "repair it in the run (cpprob_hip_smc_repair_begin / _end on every rank, from the first offending generation: StepCtrl::first_bad "
+                                               "through cpprob_hip_smc_first_bad_generation) or repeat the run with CPPROB_HIP_FLAG_FLOATING_POINT_STEP");
     c->force_fp = true;
     return cpprob_hip_infer_run(c, c->last_run_index);
 }
@@ -1509,6 +1511,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     if (t == 0 || sis) {
         c->strata_pending = !sis && c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && !(c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL);
         c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; c->annex_used = 0; c->plan.t = -1; c->x_plan_t = -1;
+        c->n_requantised = 0;
         c->final_from_counts = false; c->final_from_fixed = false;
         c->counts_mode = false; c->fixed_mode = false;
         // the integer forms serve exact joint resampling (exchange scope) and a population held by this context alone; a shard that
@@ -1539,7 +1542,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
             Hier h{};
             const int kn = (t + 1 + c->hier_phase_run) % 3;
             hier_view(c, kn, h);
-            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = t & 1; d.seq = (c->x_gather_serial << 32) | (unsigned long long)(uint32_t)(t + 1);
+            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = (t - c->x_gather_tshift) & 1; d.seq = (c->x_gather_serial << 32) | (unsigned long long)(uint32_t)(t - c->x_gather_tshift + 1);
                                   hipLaunchKernelGGL(counts_totals_gather_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals, d); }
             else hipLaunchKernelGGL(counts_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, h, (double)c->n, d_local_totals);
         }
@@ -1551,7 +1554,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
             FHier f{};
             const int kn = (t + 1 + c->hier_phase_run) % 3;
             fhier_view(c, kn, f);
-            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = t & 1; d.seq = (c->x_gather_serial << 32) | (unsigned long long)(uint32_t)(t + 1);
+            if (c->x_gather_on) { TotalsGather d = c->x_gather; d.parity = (t - c->x_gather_tshift) & 1; d.seq = (c->x_gather_serial << 32) | (unsigned long long)(uint32_t)(t - c->x_gather_tshift + 1);
                                   hipLaunchKernelGGL(fixed_totals_gather_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local_totals), d); }
             else hipLaunchKernelGGL(fixed_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local_totals));
         }
@@ -1601,6 +1604,89 @@ int cpprob_hip_smc_step_end(cpprob_hip_ctx* c, int32_t t, const double* d_all_to
         c->final_bookkeep_pending = false;
     }
     HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+// ---- a shard's generation that lost its bits: repaired in the run, as a single context's is (settle_fixed) ----------------------
+// Every rank finds the same first offending generation g in its books (they come from the all-gathered totals).  The repair is the
+// single context's, with the POPULATION's exact maximum in place of the shard's:
+//   repair_begin(g)   generation g's log-weights again from the particle store, this shard's exact maximum -> d_local3 = {key(M), 0, 0}
+//   (the caller all-gathers the 24 bytes, as it does a step's totals)
+//   repair_end(g)     masses against the largest of the ranks' maxima, the books rewound to where they stood before g,
+//                     this shard's {S, Q, key(M)} of the requantised generation -> d_local3
+//   (all-gather; cpprob_hip_smc_step_end(g); the exchange behind step g; the steps g + 1 .. T - 1 as ever; cpprob_hip_smc_finish)
+}  // extern "C"
+template <class Model>
+static int shard_repair_begin(cpprob_hip_ctx* c, int g, double* d_local3)
+{
+    if constexpr (std::is_same<Model, ModelLinearGaussian1D>::value || std::is_same<Model, ModelHmm3>::value || std::is_same<Model, ModelHmmK>::value) {
+        std::vector<int32_t> res((size_t)c->T);
+        HIP_TRY(c, hipMemcpyAsync(res.data(), c->d_resampled, res.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        int s0 = 0;
+        for (int s2 = g - 1; s2 >= 0; --s2) if (res[(size_t)s2]) { s0 = s2 + 1; break; }
+        c->cur = (g + 1) & 1;
+        hipLaunchKernelGGL(fixed_relogw_kernel<Model>, dim3((unsigned)((c->ld + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, c->mp, (const double*)c->d_obs,
+                           static_cast<const typename Model::store_t*>(c->d_values), c->rs, s0, g, c->n, c->ld, c->d_logw[c->cur]);
+        HIP_TRY(c, hipMemsetAsync(c->d_hier, 0, c->hier_entries * sizeof(uint64_t), c->stream));
+        const int ka = (g + 1 + c->hier_phase_run) % 3, kb = (ka + 1) % 3;
+        FHier f{};
+        fhier_view(c, ka, f);
+        f.h.to_next = 0; f.h.to_clear = (int64_t)(kb - ka) * (int64_t)c->hier_per_copy;
+        hipLaunchKernelGGL(bbf_max_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, (const double*)c->d_logw[c->cur], c->n, f);
+        hipLaunchKernelGGL(fixed_repair_max_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local3));
+        HIP_TRY(c, hipGetLastError());
+        return 0;
+    }
+    return fail(c, CPPROB_HIP_ESTATE, "the fixed-point form serves the state-space models");
+}
+
+extern "C" {
+
+int cpprob_hip_smc_first_bad_generation(cpprob_hip_ctx* c, int32_t* h_generation, double* h_gap)
+{
+    if (!c || !h_generation) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->begun) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_infer_begin has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    StepCtrl h{};
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *h_generation = (c->fixed_mode && !(h.fix_gap <= kFixGapLimit)) ? h.first_bad : -1;
+    if (h_gap) *h_gap = c->fixed_mode ? h.fix_gap : 0.0;
+    return 0;
+}
+
+int cpprob_hip_smc_repair_begin(cpprob_hip_ctx* c, int32_t g, double* d_local3)
+{
+    if (!c || !d_local3) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->begun || !c->step_protocol || !c->fixed_mode || !c->keep || !c->d_lz_trace) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_repair_begin: a history-keeping step-protocol run on fixed-point weights");
+    if (g < 0 || g >= c->T) return fail(c, CPPROB_HIP_EINVAL, "generation out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = 0;
+    dispatch_model(c, [&](auto m) { rc = shard_repair_begin<decltype(m)>(c, g, d_local3); });
+    return rc;
+}
+
+int cpprob_hip_smc_repair_end(cpprob_hip_ctx* c, int32_t g, const double* d_all3, int32_t world, int32_t rank, double* d_local3)
+{
+    if (!c || !d_all3 || !d_local3) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
+    if (!c->begun || !c->step_protocol || !c->fixed_mode) return fail(c, CPPROB_HIP_ESTATE, "cpprob_hip_smc_repair_end follows cpprob_hip_smc_repair_begin");
+    if (g < 0 || g >= c->T || world < 1 || world > kWave || rank < 0 || rank >= world) return fail(c, CPPROB_HIP_EINVAL, "bad generation / world / rank");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int ka = (g + 1 + c->hier_phase_run) % 3, kb = (ka + 1) % 3;
+    FHier f{};
+    fhier_view(c, ka, f);
+    f.h.to_next = 0; f.h.to_clear = (int64_t)(kb - ka) * (int64_t)c->hier_per_copy;
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(d_all3);
+    hipLaunchKernelGGL(bbf_quantize_kernel, dim3(c->nb), dim3(kThreads), 0, c->stream, (const double*)c->d_logw[c->cur], c->n, f, c->d_q[c->cur], keys, (int)world);
+    hipLaunchKernelGGL(fixed_repair_ctrl_kernel, dim3(1), dim3(kWave), 0, c->stream, c->d_ctrl, f, (int)g, (const int32_t*)c->d_resampled, keys, (int)world);
+    hipLaunchKernelGGL(fixed_totals_kernel, dim3(1), dim3(kWave), 0, c->stream, f, reinterpret_cast<uint64_t*>(d_local3));
+    HIP_TRY(c, hipGetLastError());
+    // the protocol goes on as if step g had just run: its step_end, its exchange, then step g + 1
+    c->step_t = g; c->x_plan_t = g - 1; c->plan.t = -1; c->x_all_totals = nullptr; c->ran = false;
+    if (g + 1 == c->T) { c->final_from_fixed = true; c->final_copy = ka; c->final_bookkeep_pending = true; }
+    c->n_requantised += 1;
+    c->fixed_check_pending = false;
     return 0;
 }
 

@@ -162,6 +162,8 @@ struct cpprob_hip_group {
     std::vector<hipStream_t> own_stream;               // loopback: the streams the contexts were created with
     uint64_t last_run = 0; bool ran = false;
     int reruns = 0;
+    int repair_gen = -1;                               // >= 0: the run being enqueued resumes behind this generation, requantised against its exact maximum
+    int n_requantised = 0;                             // generations repaired in the run results() last collected
     cpprob_hip_traffic traffic{};                      // of the run cpprob_hip_group_results last collected
     // worker threads (RCCL, several local ranks)
     std::vector<std::thread> workers;
@@ -342,14 +344,27 @@ int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
                                         reinterpret_cast<unsigned long long*>(g->d_all[(size_t)i]), g->d_dc_status[(size_t)i], kDcTimeoutTicks};
         c->x_gather_serial = (unsigned long long)g->dc_serial;
     }
-    struct GatherOff { cpprob_hip_ctx* c; ~GatherOff() { c->x_gather_on = false; } } gather_off{c};
-    for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
-        const bool timed = g->phase_profile && g->exchange && t + 1 < g->T;       // (the steps that run every phase)
+    struct GatherOff { cpprob_hip_ctx* c; ~GatherOff() { c->x_gather_on = false; c->x_gather_tshift = 0; } } gather_off{c};
+    // A run resumed behind a repaired generation r: two all-gathers of 24 bytes (the ranks' exact maxima, then their totals of the
+    // requantised generation) stand where step r stood, and the collectives of this enqueue are numbered from there (the mailboxes'
+    // slots alternate collective by collective: v = 0 the maxima, 1 generation r's totals, t - r + 1 step t's).
+    const int rg = sis ? -1 : g->repair_gen;
+    const int vshift = rg >= 0 ? rg - 1 : 0;
+    c->x_gather_tshift = vshift;
+    if (rg >= 0) {
+        if (int rc = cpprob_hip_smc_repair_begin(c, rg, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
+        if (talk && g->dev_coll) dc_allgather(g, i, 0, cph::kDcPost | cph::kDcWait, c->stream);
+        else if (talk) { if (int rc = coll_allgather(g, i, g->d_local[(size_t)i], g->d_all[(size_t)i], 3)) return rc; }
+        if (int rc = cpprob_hip_smc_repair_end(c, rg, talk ? g->d_all[(size_t)i] : g->d_local[(size_t)i], world, rank, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
+    }
+    for (int t = sis ? g->T - 1 : (rg >= 0 ? rg : 0); t < g->T; ++t) {
+        const bool timed = g->phase_profile && g->exchange && t + 1 < g->T && rg < 0;       // (the steps that run every phase)
+        const bool resumed = t == rg;                                                     // (generation rg exists: its totals are in d_local)
         if (timed) ph_mark(g, i, c->stream);
-        if (int rc = cpprob_hip_smc_step_begin(c, t, run_index, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c));
+        if (!resumed) { if (int rc = cpprob_hip_smc_step_begin(c, t, run_index, g->d_local[(size_t)i])) return gfail(g, rc, cpprob_hip_last_error(c)); }
         if (timed) ph_mark(g, i, c->stream);
-        if (gather_in_totals && c->x_gather_done) {}
-        else if (talk && g->dev_coll) dc_allgather(g, i, t, cph::kDcPost | cph::kDcWait, c->stream);
+        if (gather_in_totals && c->x_gather_done && !resumed) {}
+        else if (talk && g->dev_coll) dc_allgather(g, i, t - vshift, cph::kDcPost | cph::kDcWait, c->stream);
         else if (talk) { if (int rc = coll_allgather(g, i, g->d_local[(size_t)i], g->d_all[(size_t)i], 3)) return rc; }
         if (timed) ph_mark(g, i, c->stream);
         if (int rc = cpprob_hip_smc_step_end(c, t, talk ? g->d_all[(size_t)i] : g->d_local[(size_t)i], world, rank)) return gfail(g, rc, cpprob_hip_last_error(c));
@@ -362,7 +377,7 @@ int run_rank(cpprob_hip_group* g, int i, uint64_t run_index)
             else if (g->transport == kTransportDirect) {
                 // the records are already where they belong; what remains is the order: no rank may commit before every rank's
                 // packing kernel has completed, and a rank contributes to this all-gather only behind its own packing kernel
-                if (g->dev_coll) dc_barrier(g, i, t, cph::kDcPost | cph::kDcWait, c->stream);
+                if (g->dev_coll) dc_barrier(g, i, t - vshift, cph::kDcPost | cph::kDcWait, c->stream);
                 else if (int rc = coll_allgather(g, i, g->d_bar[(size_t)i], g->d_bar[(size_t)i] + 1, 1)) return rc;
             } else {
                 if (int rc = rccl_exchange(g, i, t)) return rc;
@@ -387,18 +402,32 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
     HIP_TRY(c0, hipSetDevice(c0->device));
     hipStream_t st = c0->stream;
     const bool sis = g->cfg.algorithm == CPPROB_HIP_ALG_SIS;
-    for (int t = sis ? g->T - 1 : 0; t < g->T; ++t) {
-        // (phase timing of a loopback run: the SUM over the ranks' launches of each phase -- they share the one stream)
-        const bool timed = g->phase_profile && g->exchange && t + 1 < g->T;
-        if (timed) ph_mark(g, 0, st);
-        for (int r = 0; r < world; ++r)
-            if (int rc = cpprob_hip_smc_step_begin(g->ctx[(size_t)r], t, run_index, g->d_local[(size_t)r])) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
-        if (timed) ph_mark(g, 0, st);
+    auto gather = [&](int v) {
         if (g->dev_coll) {
             // (mailboxes on one stream: every rank posts, then every rank finds what it waits for already there)
-            for (int r = 0; r < world; ++r) dc_allgather(g, r, t, cph::kDcPost, st);
-            for (int r = 0; r < world; ++r) dc_allgather(g, r, t, cph::kDcWait, st);
+            for (int r = 0; r < world; ++r) dc_allgather(g, r, v, cph::kDcPost, st);
+            for (int r = 0; r < world; ++r) dc_allgather(g, r, v, cph::kDcWait, st);
         } else hipLaunchKernelGGL(loop_allgather_kernel, dim3(1), dim3(192), 0, st, g->d_ptr_locals, g->d_ptr_alls, world);
+    };
+    // (a run resumed behind a repaired generation: run_rank states the protocol)
+    const int rg = sis ? -1 : g->repair_gen;
+    const int vshift = rg >= 0 ? rg - 1 : 0;
+    if (rg >= 0) {
+        for (int r = 0; r < world; ++r)
+            if (int rc = cpprob_hip_smc_repair_begin(g->ctx[(size_t)r], rg, g->d_local[(size_t)r])) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+        gather(0);
+        for (int r = 0; r < world; ++r)
+            if (int rc = cpprob_hip_smc_repair_end(g->ctx[(size_t)r], rg, g->d_all[(size_t)r], world, r, g->d_local[(size_t)r])) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+    }
+    for (int t = sis ? g->T - 1 : (rg >= 0 ? rg : 0); t < g->T; ++t) {
+        // (phase timing of a loopback run: the SUM over the ranks' launches of each phase -- they share the one stream)
+        const bool timed = g->phase_profile && g->exchange && t + 1 < g->T && rg < 0;
+        if (timed) ph_mark(g, 0, st);
+        if (t != rg)
+            for (int r = 0; r < world; ++r)
+                if (int rc = cpprob_hip_smc_step_begin(g->ctx[(size_t)r], t, run_index, g->d_local[(size_t)r])) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
+        if (timed) ph_mark(g, 0, st);
+        gather(t - vshift);
         if (timed) ph_mark(g, 0, st);
         for (int r = 0; r < world; ++r)
             if (int rc = cpprob_hip_smc_step_end(g->ctx[(size_t)r], t, g->d_all[(size_t)r], world, r)) return gfail(g, rc, cpprob_hip_last_error(g->ctx[(size_t)r]));
@@ -423,8 +452,8 @@ int loopback_run(cpprob_hip_group* g, uint64_t run_index)
                 }
             }
             if (g->dev_coll && g->transport == kTransportDirect) {
-                for (int r = 0; r < world; ++r) dc_barrier(g, r, t, cph::kDcPost, st);
-                for (int r = 0; r < world; ++r) dc_barrier(g, r, t, cph::kDcWait, st);
+                for (int r = 0; r < world; ++r) dc_barrier(g, r, t - vshift, cph::kDcPost, st);
+                for (int r = 0; r < world; ++r) dc_barrier(g, r, t - vshift, cph::kDcWait, st);
             }
             if (timed) ph_mark(g, 0, st);
             for (int r = 0; r < world; ++r)
@@ -998,6 +1027,7 @@ int cpprob_hip_group_run(cpprob_hip_group* g, uint64_t run_index)
 {
     if (!g) return fail(nullptr, CPPROB_HIP_EINVAL, "group is NULL");
     if (!g->begun) return gkeep(g, gfail(g, CPPROB_HIP_ESTATE, "cpprob_hip_group_begin has not been called"));
+    g->repair_gen = -1; g->n_requantised = 0;
     if (int rc = group_enqueue(g, run_index)) return gkeep(g, rc);
     g->last_run = run_index; g->ran = true;
     return 0;
@@ -1047,6 +1077,7 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
             for (size_t i = 0; i < g->d_dc_status.size(); ++i) { GHIP_TRY(g, hipSetDevice(g->ctx[i]->device)); GHIP_TRY(g, hipMemset(g->d_dc_status[i], 0, sizeof(int32_t))); }
             for (auto* x : g->ctx) x->fixed_check_pending = false;
             ++g->reruns;
+            g->repair_gen = -1; g->n_requantised = 0;
             if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
             continue;
         }
@@ -1054,14 +1085,33 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
         // every rank holds the same gap (it comes from the all-gathered totals), so every rank takes the same decision: repeat the run
         // in the floating-point form
         bool imprecise = false;
+        int first_bad = -1;
         if (c->fixed_check_pending) {
             cph::StepCtrl hc{};
             GHIP_TRY(g, hipMemcpy(&hc, c->d_ctrl, sizeof hc, hipMemcpyDeviceToHost));
             imprecise = !(hc.fix_gap <= kFixGapLimit);
+            first_bad = hc.first_bad;
         }
         for (auto* x : g->ctx) x->fixed_check_pending = false;
+        if (imprecise && c->keep && !(g->cfg.flags & CPPROB_HIP_FLAG_REPEAT_IN_FLOATING_POINT) && first_bad >= 0 && first_bad < g->T && first_bad > g->repair_gen) {
+            // Repair, in integers, as a single context does (cpprob_hip.hip: settle_fixed): the first offending generation is weighed
+            // again against the POPULATION's exact maximum and the steps behind it run again -- the sharded run stays the one-GPU
+            // run, bit for bit.  Every rank holds the same books, so every rank enters the same collectives.
+            if (g->n_requantised > g->T) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "run repaired too often"));
+            g->repair_gen = first_bad;
+            const int rc = group_enqueue(g, g->last_run);
+            if (rc) { g->repair_gen = -1; return gkeep(g, rc); }
+            ++g->n_requantised;
+            continue;
+        }
+        if (imprecise && (g->cfg.resampler != CPPROB_HIP_RESAMPLE_SYSTEMATIC || !c->keep) && g->exchange) {
+            // (the floating-point form of the exchange scope plans systematic offspring intervals only)
+            g->repair_gen = -1;
+            return gkeep(g, gfail(g, CPPROB_HIP_EPRECISION, "a generation's heaviest particle sat more than 6 nats below its fixed-point reference and could not be repaired in the run"));
+        }
         if (imprecise) {
             if (attempt >= 6) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "run repeated too often"));
+            g->repair_gen = -1;
             g->cfg.flags |= CPPROB_HIP_FLAG_FLOATING_POINT_STEP;
             if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
             ++g->reruns;
@@ -1090,8 +1140,10 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
         }
         if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
         ++g->reruns;
+        g->repair_gen = -1; g->n_requantised = 0;
         if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
     }
+    g->repair_gen = -1;
     if (h_reruns) *h_reruns = g->reruns;
     g->traffic.records = (uint64_t)joint[(size_t)g->n_stats + 1];
     g->traffic.payload_bytes = (uint64_t)joint[(size_t)g->n_stats + 2];

@@ -888,6 +888,12 @@ __global__ __launch_bounds__(kWave) void fixed_final_ctrl_kernel(FixedFinal ff, 
     const FixedRanks r = fixed_ranks(all_totals, world, 0);
     if (threadIdx.x == 0) fixed_final_bookkeep(ff, r.S, r.Q, r.M);
 }
+// the exact maximum of a generation's recomputed log-weights as a rank's contribution to the repair's all-gather: {key(M), 0, 0}
+__global__ __launch_bounds__(kWave) void fixed_repair_max_kernel(FHier f, uint64_t* __restrict__ out)
+{
+    const double m = bbf_top_max(f);
+    if (threadIdx.x == 0) { out[0] = dkey(m); out[1] = 0; out[2] = 0; }
+}
 // {S, Q, key(M)} of this shard's generation: what a sharded run all-gathers between two steps (24 bytes)
 __global__ __launch_bounds__(kWave) void fixed_totals_kernel(FHier f, uint64_t* __restrict__ out)
 {
@@ -1066,9 +1072,11 @@ __global__ __launch_bounds__(kThreads) void fixed_relogw_kernel(ModelParams mp, 
     logw[i] = i < n ? lw : -INFINITY;
 }
 // The books as they stood before generation g was weighed against its reference, with the exact maximum in that reference's place.
-__global__ __launch_bounds__(kWave) void fixed_repair_ctrl_kernel(StepCtrl* c, FHier f, int g, const int32_t* __restrict__ resampled)
+__global__ __launch_bounds__(kWave) void fixed_repair_ctrl_kernel(StepCtrl* c, FHier f, int g, const int32_t* __restrict__ resampled,
+                                                                  const uint64_t* __restrict__ all_keys = nullptr, int world = 0)
 {
-    const double m = bbf_top_max(f);
+    // (one shard of a joint population: the population's exact maximum, from the ranks' all-gathered keys)
+    const double m = all_keys ? dkey_inv(wave_max_u64(lane_id() < world ? all_keys[3 * lane_id()] : 0ull)) : bbf_top_max(f);
     if (threadIdx.x == 0) {
         c->ref_cur = m;
         c->log_z = c->lz_trace[g];

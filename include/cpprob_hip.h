@@ -234,6 +234,23 @@ int cpprob_hip_copy_paths(cpprob_hip_ctx* ctx, void* h_paths, size_t n_bytes);
 int cpprob_hip_smc_step_begin(cpprob_hip_ctx* ctx, int32_t t, uint64_t run_index, double* d_local_totals);
 int cpprob_hip_smc_step_end(cpprob_hip_ctx* ctx, int32_t t, const double* d_all_totals, int32_t world, int32_t rank);
 int cpprob_hip_smc_finish(cpprob_hip_ctx* ctx);
+/* Fixed-point form (integer masses against a reference known before the generation exists): a generation whose heaviest particle
+ * sat more than 6 nats below its reference lost too many of its 32 bits.  A single context repairs it inside cpprob_hip_infer_run
+ * (cpprob_hip_summary::n_requantised); the shards of a joint population do the same through the step protocol, in integers, so
+ * that the sharded run stays equal to the one-GPU run bit for bit (cpprob_hip_group_* drives this itself):
+ *   first_bad_generation  after cpprob_hip_smc_finish: the first offending generation g, -1 when every generation kept its bits
+ *                         (every rank reads the same g: the books come from the all-gathered totals); synchronises the stream;
+ *   repair_begin(g)       generation g's log-weights recomputed from the particle store; d_local3 = {key of this shard's exact
+ *                         maximum, 0, 0} (three 64-bit words, device): the caller all-gathers them as it does a step's totals;
+ *   repair_end(g)         d_all3 = the all-gathered words; masses of generation g against the POPULATION's exact maximum, the
+ *                         books rewound to where they stood before g; d_local3 = this shard's totals of the requantised
+ *                         generation.  The caller all-gathers them and goes on as if step g had just run: cpprob_hip_smc_step_end(g),
+ *                         the exchange behind step g, step_begin(g + 1) ... cpprob_hip_smc_finish; repeated while a later
+ *                         generation trips (each round starts later).
+ * There is no reference interface here: the reference has no SMC. */
+int cpprob_hip_smc_first_bad_generation(cpprob_hip_ctx* ctx, int32_t* h_generation, double* h_gap);
+int cpprob_hip_smc_repair_begin(cpprob_hip_ctx* ctx, int32_t g, double* d_local3);
+int cpprob_hip_smc_repair_end(cpprob_hip_ctx* ctx, int32_t g, const double* d_all3, int32_t world, int32_t rank, double* d_local3);
 /* Filtering-only shards (keep_history = 0) after finish: *joint_already = 1 -- cpprob_hip_infer_stats holds the JOINT population's
  * numbers (prefix-count form: they come from the all-gathered totals), nothing to combine; 0 -- it holds this shard's raw sums of
  * weight x f(x_t) per predict hit t and *d_masses (device, n_predict doubles) this shard's mass of generation t: the caller adds both

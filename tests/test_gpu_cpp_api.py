@@ -131,6 +131,26 @@ def test_unchanged_model_smc_equals_the_oracle_in_every_step_form(tmp_path, mode
     assert abs(res["log_evidence"] - r["log_z"]) < 1e-9
 
 
+@pytest.mark.parametrize("model,key,T,ess,is_int,used", [("hmm16", "hmm16", 16, 2.0, True, 16), ("linear_gaussian_1d25", "lgssm100", 25, 0.5, False, 25),
+                                                         ("hmm128", "hmm128", 128, 0.5, True, 112), ("linear_gaussian_1d100", "lgssm100", 100, 0.5, False, 87)])
+def test_step_kernels_built_per_step_change_no_number(tmp_path, model, key, T, ess, is_int, used):
+    """The step kernels built per step (cpprob/gpu.hpp: model_step_kernel_at -- one per step up to 32 observes, one every T / 8 steps
+    beyond; the step's thresholds as compile-time facts, dead iterations folded away) against the run-time kernel that re-runs the model's
+    loop from its first statement at every launch: the same dump, byte for byte, and the same evidence."""
+    z = np.load(os.path.join(GOLD, "observations.npz"))
+    obs = z[key][:T]
+    n = 30000
+    out = {}
+    for tag, extra in (("built", []), ("runtime", ["--no_step_builds"])):
+        res, _, _ = run_main(tmp_path, "--model", model, "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 5, "--ess_threshold", ess, "--json",
+                             "--generic", "--generated_file", tag, "--step_form", 1, *extra)
+        assert res["step_form"] == 1
+        out[tag] = (res, open(str(tmp_path / (tag + ("_smc.int" if is_int else "_smc.real")))).read())
+    assert out["built"][0]["step_builds_used"] == used and out["runtime"][0]["step_builds_used"] == 0
+    assert out["built"][1] == out["runtime"][1]
+    assert out["built"][0]["log_evidence"] == out["runtime"][0]["log_evidence"] and out["built"][0]["n_resampled"] == out["runtime"][0]["n_resampled"]
+
+
 @pytest.mark.parametrize("n", [1, 255, 1024, 1025, 3000])
 def test_four_particles_a_lane_equals_one_particle_a_lane_on_ragged_populations(tmp_path, n):
     """Step form 3 (model_step_kernel_quad: a workgroup owns a 1024-particle tile, one search, the model body four times a lane) against

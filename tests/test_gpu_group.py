@@ -528,3 +528,42 @@ def test_group_multinomial_refuses_what_it_cannot_move(engine, golden_dir):
     with pytest.raises(cp.CpprobHipError):
         g.begin(cp.ALG_SMC, cp.MODEL_HMM3, obs, 40000, seed=1, resampler=cp.RESAMPLE_MULTINOMIAL, ess_threshold=2.0)
     g.close()
+
+
+@pytest.mark.parametrize("resampler", [cp.RESAMPLE_SYSTEMATIC, cp.RESAMPLE_STRATIFIED, cp.RESAMPLE_MULTINOMIAL])
+@pytest.mark.parametrize("shards,flags", [([2500, 2500], 0), ([1000, 2501, 1499], 0), ([700] * 6 + [800], cp.capi.GROUP_MAILBOX_COLLECTIVES)])
+def test_group_run_that_loses_its_bits_is_repaired_in_integers_like_one_gpu(engine, golden_dir, resampler, shards, flags):
+    """The group twin of test_fixed_point_run_that_loses_its_bits_is_repaired_from_the_offending_generation: an observation ~30 standard
+    deviations from every particle costs a generation its bits.  The shards repair it as ONE context does -- log-weights of the first
+    offending generation recomputed from every rank's store, the POPULATION's exact maximum all-gathered (24 bytes), masses against it,
+    the books rewound, the steps behind it run again (cpprob_hip_smc_repair_begin / _end under cpprob_hip_group_results) -- so the
+    sharded run still draws the one-GPU run's ancestors, which are the oracle's: no repeat of the run, no floating-point form.  Outlier
+    in a middle, the last and the first generation; mailbox collectives too (their slots are numbered from the repaired generation)."""
+    import torch  # noqa: F401
+    from oracle import oracle as O
+    n = int(sum(shards))
+    for at, val in ((6, 40.0), (13, 35.0), (0, 9.0)):
+        obs = np.array(_obs(golden_dir, "lgssm100")[:14])
+        obs[at] = val
+        engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, resampler=resampler, ess_threshold=0.5)
+        engine.run()
+        ref_stats, ref_sum, ref_paths, ref_anc = engine.stats().copy(), engine.summary(), engine.paths(), engine.ancestors()
+        assert ref_sum["n_requantised"] >= 1
+        orc = O.smc(cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, 8, resampler, 0.5)
+        assert np.array_equal(ref_anc, orc["anc"])
+        g = cp.Group([0] * len(shards))
+        g.transport(flags=flags)
+        g.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, resampler=resampler, ess_threshold=0.5, shard_sizes=shards)
+        g.run()
+        stats, s, reruns = g.results()
+        paths = np.concatenate([_ctx_paths(g, r, shards[r], 14, False) for r in range(len(shards))], axis=1)
+        g.run(1)                                                # the group is as good as new behind a repair
+        g.run(0)
+        stats2, s2, reruns2 = g.results()
+        g.close()
+        # (a population that collapses onto one particle migrates wholesale: the transport may have had to grow -- a repeat with a larger
+        #  annex, which is not the repeat in the floating-point form this test rules out: step_form stays the fixed-point one)
+        assert reruns2 == reruns and s["step_form"] == cp.capi.FORM_FIXED and s["n_requantised"] == ref_sum["n_requantised"], (at, s, reruns, reruns2)
+        assert np.array_equal(paths, ref_paths) and s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"], at
+        np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-10)       # (sums over shards in another order, states up to 40: raw second moments of 1600)
+        assert np.array_equal(stats2, stats) and s2 == s

@@ -390,6 +390,52 @@ def test_statements_are_inlined_into_the_model_kernels_at_every_optimisation_lev
         assert "s_swappc_b64" not in asm and "s_setpc_b64" not in asm, opt
 
 
+_STEP_BUILD_TU = r"""
+#include "cpprob/gpu.hpp"
+#pragma clang force_cuda_host_device begin
+#include "target_models.hpp"
+#pragma clang force_cuda_host_device end
+using C = cpprob::gpu::FunctionCaller<decltype(&models::linear_gaussian_1d<25>), &models::linear_gaussian_1d<25>>;
+using T = C::observes_t;
+template __global__ void cpprob::gpu::model_step_kernel_at<C, T, 12, 1, 1, true, false>(cpprob::gpu::ModelKernelArgs, const T*);    // the step 12 alone
+template __global__ void cpprob::gpu::model_step_kernel_at<C, T, 16, 1, 1, false, false>(cpprob::gpu::ModelKernelArgs, const T*);   // the steps from 16 on
+template __global__ void cpprob::gpu::model_step_kernel<C, T>(cpprob::gpu::ModelKernelArgs, const T*);                              // the run-time kernel
+"""
+
+
+def test_step_kernels_built_for_a_step_hold_no_dead_iteration(tmp_path):
+    """The step ordinal as a compile-time fact (cpprob/gpu.hpp: model_step_kernel_at): with the model's loop unrolled and the statement
+    counters forwarded through LDS, the iterations in front of the step fold away -- the device code of the build for step 12 of
+    linear_gaussian_1d<25> draws ONE normal variate (one Philox block: the step's own sample) and ends in its observe; the build for
+    the steps from 16 on keeps the 9 iterations that may be live; both far smaller than the unrolled model (25 draws)."""
+    import re
+    from cpprob_amd import build as B
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_stats
+    src = tmp_path / "steps.hip"
+    src.write_text(_STEP_BUILD_TU)
+    out = str(tmp_path / "steps.s")
+    cmd = ["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "--cuda-device-only", "-S"] + B.STEPS_FLAGS + \
+          ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cpprob_amd", "include"), "-I", os.path.join(ROOT, "cpprob_amd", "examples"), "-o", out, str(src)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    asm = open(out).read()
+    assert "s_swappc_b64" not in asm                                              # the model is part of the kernel whatever its size
+    # split the listing by kernel and count the Philox blocks (its first multiplier is loaded once per block)
+    parts = re.split(r"\n(?=_ZN6cpprob3gpu\w+:)", asm)
+    draws, size = {}, {}
+    st = isa_stats.stats(out)
+    for part in parts:
+        name = part.split(":", 1)[0]
+        if not name.startswith("_ZN6cpprob3gpu"):
+            continue
+        key = "exact" if "Li12ELi1ELi1ELb1ELb0E" in name else ("from" if "Li16ELi1ELi1ELb0ELb0E" in name else "runtime")
+        draws[key] = part.lower().count("0xd2511f53")
+        size[key] = st[name]["n"]
+    assert draws["exact"] == 1 and draws["from"] == 9 and draws["runtime"] >= 25, draws
+    assert size["exact"] < size["from"] < size["runtime"] and size["exact"] < 4000, size
+
+
 def test_host_driver_is_plain_cpp14_and_fails_loudly_without_gpu():
     from cpprob_amd import build as B
     B.build_all()
