@@ -1473,7 +1473,9 @@ int settle_fixed(cpprob_hip_ctx* c)
     HIP_TRY(c, hipMemcpyAsync(&h, c->d_ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (h.fix_gap <= kFixGapLimit) return 0;
-    if (c->last_was_infer_run && c->keep && !c->exchange && c->d_lz_trace && !(c->cfg.flags & CPPROB_HIP_FLAG_REPEAT_IN_FLOATING_POINT)) {
+    // (the literal multinomial form keeps lane prefixes beside the weights that a requantised generation would leave stale: it repeats the run)
+    const bool literal = c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && (c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL);
+    if (c->last_was_infer_run && c->keep && !c->exchange && c->d_lz_trace && !literal && !(c->cfg.flags & CPPROB_HIP_FLAG_REPEAT_IN_FLOATING_POINT)) {
         int g_prev = -1;
         for (int round = 0; round <= c->T; ++round) {
             const int g = h.first_bad;
@@ -1519,6 +1521,10 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
         if (!sis && (c->exchange || c->cfg.n_global == c->cfg.n_particles))
             dispatch_model(c, [&](auto m) { c->counts_mode = counts_eligible<decltype(m)>(c); c->fixed_mode = fixed_eligible<decltype(m)>(c); });
     }
+    if ((t == 0 || sis) && c->exchange && !sis && c->cfg.resampler != CPPROB_HIP_RESAMPLE_SYSTEMATIC && !c->counts_mode && !c->fixed_mode)
+        return fail(c, CPPROB_HIP_EUNSUPPORTED, "stratified / multinomial resampling in the exchange scope run on the integer forms of the step (the floating-point form plans the ranks' "
+                                                 "offspring intervals from the ONE systematic offset): not with CPPROB_HIP_FLAG_FLOATING_POINT_STEP, beyond 2^28 particles, or for models "
+                                                 "without a fixed-point form");
     if (c->exchange && t > 0 && c->x_plan_t != t - 1)
         return fail(c, CPPROB_HIP_ESTATE, "exchange scope: the exchange of the previous step (plan / pack / commit) must run before the next step_begin");
     c->step_protocol = true; c->step_t = t; c->trace_mode = false;
@@ -2694,6 +2700,13 @@ static int lineage_stats(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t*
     return 0;
 }
 
+// A read-back armed by cpprob_hip_readback_with_next_result rides the NEXT statistics call and no other: whatever way that call ends
+// (bad arguments, a failed allocation, a device error), the caller's destination pointer does not outlive it in the context.
+struct RideDisarm {
+    cpprob_hip_ctx* c;
+    ~RideDisarm() { if (c) { c->ride_src = nullptr; c->ride_dst = nullptr; c->ride_bytes = 0; } }
+};
+
 static int lineage_args_ok(cpprob_hip_ctx* c, const void* d_anc, const void* d_resampled, int32_t T, size_t n, const void* d_cols, const int32_t* h_gen, int32_t H,
                            const void* d_logw, const void* h_out)
 {
@@ -2724,6 +2737,7 @@ int cpprob_hip_lineage_prepare(cpprob_hip_ctx* c, const int32_t* h_gen, int32_t 
 int cpprob_hip_lineage_moments(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const double* d_cols, const int32_t* h_gen, int32_t H,
                                const double* d_logw, double* h_out4)
 {
+    RideDisarm ride_guard{c};
     BB_PRELUDE(c);
     if (int rc = lineage_args_ok(c, d_anc, d_resampled, T, n, d_cols, h_gen, H, d_logw, h_out4)) return rc;
     std::vector<double> raw((size_t)H * 2);
@@ -2740,6 +2754,7 @@ int cpprob_hip_lineage_moments(cpprob_hip_ctx* c, const int32_t* d_anc, const in
 int cpprob_hip_lineage_hist(cpprob_hip_ctx* c, const int32_t* d_anc, const int32_t* d_resampled, int32_t T, size_t n, const int32_t* d_cols, const int32_t* h_gen, int32_t H,
                             const double* d_logw, int32_t k, double* h_out, double* h_lse_ess)
 {
+    RideDisarm ride_guard{c};
     BB_PRELUDE(c);
     if (int rc = lineage_args_ok(c, d_anc, d_resampled, T, n, d_cols, h_gen, H, d_logw, h_out)) return rc;
     if (k < 1 || k > 8) return fail(c, CPPROB_HIP_EINVAL, "need 1 <= k <= 8");
@@ -2754,6 +2769,7 @@ int cpprob_hip_lineage_hist(cpprob_hip_ctx* c, const int32_t* d_anc, const int32
 
 int cpprob_hip_weighted_moments_columns(cpprob_hip_ctx* c, const double* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, double* h_out4)
 {
+    RideDisarm ride_guard{c};
     BB_PRELUDE(c);
     if (!d_x || !d_logw || !h_out4) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (n == 0 || n_cols == 0 || col_stride < n) return fail(c, CPPROB_HIP_EINVAL, "empty distribution / columns closer than their length");
@@ -2771,6 +2787,7 @@ int cpprob_hip_weighted_moments_columns(cpprob_hip_ctx* c, const double* d_x, si
 int cpprob_hip_weighted_hist_columns(cpprob_hip_ctx* c, const int32_t* d_x, size_t n_cols, size_t col_stride, const double* d_logw, size_t n, int32_t k, double* h_out,
                                      double* h_lse_ess)
 {
+    RideDisarm ride_guard{c};
     BB_PRELUDE(c);
     if (!d_x || !d_logw || !h_out) return fail(c, CPPROB_HIP_EINVAL, "NULL argument");
     if (k < 1 || k > 8) return fail(c, CPPROB_HIP_EINVAL, "need 1 <= k <= 8");

@@ -30,7 +30,7 @@
 #include "cpprob/detail/dist.hpp"
 #include "models.hpp"
 #include "cpprob/detail/rng.hpp"
-#include "wave.hpp"
+#include "cpprob/detail/wave.hpp"
 
 namespace cph {
 

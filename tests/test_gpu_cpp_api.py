@@ -502,8 +502,9 @@ def test_unchanged_model_smc_over_several_ranks_is_the_single_device_population(
     v1, lw1 = read_dump(str(tmp_path / ("one_smc." + ext)), is_int)
     vm, lwm = read_dump(str(tmp_path / ("many_smc." + ext)), is_int)
     assert np.array_equal(v1, vm) and np.array_equal(lw1, lwm)
-    # (the exact-maximum form of the joint run takes the evidence's logarithms on the host: a few units in the last place of the device's)
-    assert abs(many["log_evidence"] - one["log_evidence"]) <= (16 * np.spacing(abs(one["log_evidence"])) if model == "random_scale12" else 0.0)
+    # (the joint run takes the evidence's logarithms on the HOST -- every generation's in the exact-maximum form, the last one's otherwise -- and
+    #  the one-device run on the device: the two libraries' log may differ in the last place, so the evidence is compared to a few units of it)
+    assert abs(many["log_evidence"] - one["log_evidence"]) <= 16 * np.spacing(abs(one["log_evidence"]))
     assert many["n_resampled"] == one["n_resampled"]
     for a, b in zip(one["predicts"], many["predicts"]):
         if "p" in a:

@@ -512,13 +512,18 @@ def test_fixed_point_run_that_loses_its_bits_is_repaired_from_the_offending_gene
     assert np.array_equal(engine.stats(), stf) and sf["step_form"] == s2["step_form"] == cp.capi.FORM_FLOAT and s2 == sf
     np.testing.assert_allclose(stf, O.smoothing(engine.values(), engine.ancestors(), engine.logw()), rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(stf, st, rtol=0, atol=5e-3)      # the two repairs agree as two arithmetic forms of one run do
-    # the group driver (two loopback ranks) still repeats in the floating-point form: the same answer within boundary flips
+    # the group driver (two loopback ranks) repairs in integers too -- the one-context run's evidence, bit for bit (tests/test_gpu_group.py:
+    # test_group_run_that_loses_its_bits_...) -- and repeats in the floating-point form only when told to
     g = cp.Group([0, 0])
     g.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, ess_threshold=0.5)
     g.run()
     gst, gs, reruns = g.results()
+    assert gs["log_evidence"] == s["log_evidence"] and gs["n_requantised"] == s["n_requantised"] and gs["step_form"] == cp.capi.FORM_FIXED
+    g.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, obs, n, seed=8, ess_threshold=0.5, flags=cp.capi.FLAG_REPEAT_IN_FLOATING_POINT)
+    g.run()
+    gst, gs, reruns = g.results()
     g.close()
-    assert 1 <= reruns <= 3 and abs(gs["log_evidence"] - sf["log_evidence"]) < 1e-9      # (the mass sits on a few particles: the transport may be enlarged too)
+    assert 1 <= reruns <= 4 and gs["step_form"] == cp.capi.FORM_FLOAT and abs(gs["log_evidence"] - sf["log_evidence"]) < 1e-9      # (the mass sits on a few particles: the transport may be enlarged too)
     np.testing.assert_allclose(gst, stf, rtol=0, atol=5e-3)
 
 
