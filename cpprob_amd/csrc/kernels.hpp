@@ -495,6 +495,9 @@ template <class T> __device__ __forceinline__ void lane_copy(T (&d)[kPPT], const
 #ifdef CPPROB_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;   // diagnostic build only: [nb][16] s_memrealtime stamps
 #define CPH_STAMP(k) do { if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#elif defined(CPPROB_MARKS)
+// static instruction budgets (tools/isa_budget.py): a comment line in the assembly at every stamp; instructions are counted between them
+#define CPH_STAMP(k) asm volatile("; CPH_MARK " #k ::: "memory")
 #else
 #define CPH_STAMP(k) do {} while (0)
 #endif

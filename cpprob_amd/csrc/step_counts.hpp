@@ -611,8 +611,13 @@ __device__ __forceinline__ void hier_publish(const Hier& h, int bid, int nb, uin
 
 // SHARDED: one shard of a joint population (exchange scope).  Compile-time forms: each keeps only the arguments it uses in scalar
 // registers.  The run's last step is a step like any other: the read-out works from the counts it leaves (smooth_counts_kernel).
+#ifdef CPPROB_COUNTS_WAVES
+#define CPPROB_COUNTS_OCC __attribute__((amdgpu_waves_per_eu(CPPROB_COUNTS_WAVES)))
+#else
+#define CPPROB_COUNTS_OCC
+#endif
 template <class Model, bool SHARDED, int RS = kFixSystematic>
-__global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArgs<Model> a)
+__global__ __launch_bounds__(kThreads) CPPROB_COUNTS_OCC void smc_step_counts_kernel(StepCountsArgs<Model> a)
 {
     using V = typename Model::value_t;
     using S = typename Model::store_t;
@@ -632,6 +637,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     // output tile almost surely descends from (its own index and both neighbours) and, in the workgroup's first wavefront (which
     // searches for all four), the generation's totals and the words of the search's first probe: fetched here, in one round trip
     // that the random draws below cover.
+    CPH_STAMP(0);
     const S* prev_row = a.values + (int64_t)a.row_r * a.rs;
     const bool searcher = wave_id() == 0;
     uint32_t raw_0 = 0, raw_m1 = 0, raw_p1 = 0;
@@ -659,6 +665,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     typename Model::Rand rnd[kPPT / 4];
 #pragma unroll
     for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+    CPH_STAMP(1);
 
     int32_t anc[kPPT];
 #pragma unroll
@@ -761,6 +768,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
             }
         }
         __syncthreads();                                           // slots reset, search results and the model's table in place
+        CPH_STAMP(2);
         const Located loc = s_found.loc;
         tc.inv = s_found.inv;
         if (SHARDED) { tc.base0 = s_found.base0; tc.base1 = s_found.base1; tc.basev = s_found.basev; }
@@ -801,6 +809,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         for (int k = 0; k < kPPT; ++k) anc[k] = max(anc[k], 0);   // padding outputs of the last tile
     }
 
+    CPH_STAMP(3);
     V prev[kPPT], x[kPPT];
     uint32_t tw[kPPT];
     if (traced) {
@@ -827,6 +836,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
     }
     if (a.anc) store4_write_through(a.anc + (int64_t)t * a.rs, j0, anc);                      // (a filtering-only run keeps no ancestors)
 
+    CPH_STAMP(4);
     // ---- observe #t as counts ----
     uint32_t c0 = 0, c1 = 0;
 #pragma unroll
@@ -843,6 +853,7 @@ __global__ __launch_bounds__(kThreads) void smc_step_counts_kernel(StepCountsArg
         for (int w = 0; w < kWaves; ++w) { n0 += (uint32_t)s_cnt[2 * w]; n1 += (uint32_t)s_cnt[2 * w + 1]; }
         hier_publish(a.h, bid, nb, n0, n1, true);
     }
+    CPH_STAMP(5);
 }
 
 // Read-out of a single-shard run in the prefix-count form.  The last step is an ordinary step: it leaves its generation's counts
