@@ -351,6 +351,18 @@ class Engine:
     def finish(self):
         self._chk(self.L.cpprob_hip_smc_finish(self.h))
 
+    def first_bad_generation(self):
+        """After finish(): the first generation whose fixed-point weights lost their bits (-1: none) and the run's largest gap in nats."""
+        g, gap = C.c_int32(-1), C.c_double(0.0)
+        self._chk(self.L.cpprob_hip_smc_first_bad_generation(self.h, C.byref(g), C.byref(gap)))
+        return int(g.value), float(gap.value)
+
+    def repair_begin(self, g, local3):
+        self._chk(self.L.cpprob_hip_smc_repair_begin(self.h, int(g), _dptr(local3)))
+
+    def repair_end(self, g, all3, world, rank, local3):
+        self._chk(self.L.cpprob_hip_smc_repair_end(self.h, int(g), _dptr(all3), int(world), int(rank), _dptr(local3)))
+
     # ---- exchange scope: exact global resampling with migration ----------------------------
     def exchange_plan(self, t, world, rank, shard_begin):
         """-> (do_resample, send_counts[world], recv_counts[world]) in lineage records of t + 1 values.  Host-synchronising."""

@@ -95,6 +95,7 @@ struct cpprob_hip_ctx {
     // exchange scope: exact global resampling, offspring of remote sources migrate in as annex columns
     bool exchange = false;
     int64_t annex_cap = 0, annex_used = 0;
+    std::vector<int64_t> annex_used_before;   // (synchronising exchange calls) annex columns in use before the commit that follows step t: what a repair rewinds to
     double* d_obound = nullptr;     // [world + 2]: offspring-interval bounds per rank, then the resampling decision
     double* h_obound = nullptr;     // pinned host copy (the one host read-back per step of the exchange scope)
     // read-backs of small results go through pinned memory (a copy into pageable memory blocks the host for its own round trip: three of
@@ -1513,7 +1514,7 @@ int cpprob_hip_smc_step_begin(cpprob_hip_ctx* c, int32_t t, uint64_t run_index, 
     if (t == 0 || sis) {
         c->strata_pending = !sis && c->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL && !(c->cfg.flags & CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL);
         c->run_seed = c->cfg.seed + run_index; c->cur = 0; c->cur_part = 0; c->ran = false; c->annex_used = 0; c->plan.t = -1; c->x_plan_t = -1;
-        c->n_requantised = 0;
+        c->n_requantised = 0; c->annex_used_before.clear();
         c->final_from_counts = false; c->final_from_fixed = false;
         c->counts_mode = false; c->fixed_mode = false;
         // the integer forms serve exact joint resampling (exchange scope) and a population held by this context alone; a shard that
@@ -1690,6 +1691,12 @@ int cpprob_hip_smc_repair_end(cpprob_hip_ctx* c, int32_t g, const double* d_all3
     HIP_TRY(c, hipGetLastError());
     // the protocol goes on as if step g had just run: its step_end, its exchange, then step g + 1
     c->step_t = g; c->x_plan_t = g - 1; c->plan.t = -1; c->x_all_totals = nullptr; c->ran = false;
+    // (a caller of the synchronising exchange calls: the annex as it stood before the exchange that followed step g; a step whose
+    //  exchange planned nothing left no mark -- the next marked one stands for it, the columns in use do not shrink)
+    for (size_t k = (size_t)g; k < c->annex_used_before.size(); ++k) {
+        if (c->annex_used_before[k] >= 0) { c->annex_used = c->annex_used_before[k]; break; }
+    }
+    for (size_t k = (size_t)g; k < c->annex_used_before.size(); ++k) c->annex_used_before[k] = -1;
     if (g + 1 == c->T) { c->final_from_fixed = true; c->final_copy = ka; c->final_bookkeep_pending = true; }
     c->n_requantised += 1;
     c->fixed_check_pending = false;
@@ -1960,6 +1967,8 @@ int cpprob_hip_exchange_commit(cpprob_hip_ctx* c, int32_t t, const void* d_recv)
     if (!d_recv) return fail(c, CPPROB_HIP_EINVAL, "d_recv is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->ld + c->annex_used + (int64_t)p.n_recv + kTile > (int64_t)INT32_MAX) return fail(c, CPPROB_HIP_EINVAL, "immigrant columns exceed int32 ancestor indices");
+    if (c->annex_used_before.size() < (size_t)c->T + 1) c->annex_used_before.assign((size_t)c->T + 1, -1);
+    c->annex_used_before[(size_t)t] = c->annex_used;
     if (c->annex_used + (int64_t)p.n_recv > c->annex_cap) { if (int rc = grow_annex(c, c->annex_used + (int64_t)p.n_recv)) return rc; }
     const int grid = (int)std::min<uint64_t>((p.n_recv * (uint64_t)(t + 1) + kThreads - 1) / kThreads, 2048);
     dispatch_model(c, [&](auto m) { using M = decltype(m); launch_commit<M, typename M::value_t>(c, t, static_cast<const typename M::value_t*>(d_recv), grid); });

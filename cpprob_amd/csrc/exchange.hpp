@@ -402,10 +402,12 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_strata_kernel(PackStra
     __shared__ int64_t s_send_lo[kWorldSlots], s_send_cnt[kWorldSlots], s_fill[kWorldSlots];
     __shared__ int64_t s_nsend;
     __shared__ int s_resample;
+    __shared__ uint32_t s_sb[kWorldSlots + 1];                           // the shards' first outputs (read once: the work items below are many and mostly empty)
     __shared__ __attribute__((aligned(16))) FixedFound s_ff;
     __shared__ __attribute__((aligned(16))) StepFound s_cf;
     const int tid = threadIdx.x, lane = lane_id();
     const int world = a.world, rank = a.rank;
+    if (tid <= world) s_sb[tid] = (uint32_t)a.geom.shard_begin[tid];
     // ---- this rank's place in the population, the decision ----
     uint64_t S_tot = 0, before = 0, own = 0;
     double W = 0.0, c_lo = 0.0, c_hi = 0.0;
@@ -444,13 +446,13 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_strata_kernel(PackStra
     for (int item = 0; item < 3 * world; ++item) {
         const int kind = item / world, d = item - kind * world;
         if (d == rank) continue;
-        const uint32_t sb = (uint32_t)a.geom.shard_begin[d], se = (uint32_t)a.geom.shard_begin[d + 1];
+        const uint32_t sb = s_sb[d], se = s_sb[d + 1];
         uint32_t lo, hi;
         const uint32_t* tab = nullptr; uint32_t tab0 = 0;
         if (kind == 0) { lo = (uint32_t)s_send_lo[d]; hi = lo + (uint32_t)s_send_cnt[d]; }
         else {
             const CutHead hb = kind == 1 ? hme0 : hme1;
-            if (kind == 2 && same) continue;
+            if ((kind == 2 && same) || hb.A <= hb.Z) continue;
             lo = min(max(hb.Z, sb), se); hi = min(max(hb.A, sb), se);
             tab = a.cut.tab + (size_t)(kind == 1 ? rank : rank + 1) * kCutRow; tab0 = hb.Z;
         }

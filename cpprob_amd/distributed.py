@@ -482,8 +482,12 @@ def shard_begins(n_global, world):
 
 
 def run_exchange(engine, collective, run_index=0, counters=None):
-    """run_exchange_once, repeated in the floating-point form when the fixed-point weights of the run lost too many bits (every
-    rank holds the same gap -- it comes from the all-gathered totals -- so every rank takes the same decision)."""
+    """One run of a joint population with EXACT global resampling (engine begun with scope=SCOPE_EXCHANGE on the shard
+    shard_bounds(n_global, world, rank)).  Returns (stats[T, K], summary).  counters (dict) receives the number of lineage records
+    this rank sent / received.  A generation whose fixed-point weights lost their bits is repaired in the run, in integers, as one
+    GPU repairs it (cpprob_hip_smc_repair_begin / _end: every rank holds the same first offending generation -- the books come from the
+    all-gathered totals -- so every rank enters the same collectives); CPPROB_HIP_FLAG_REPEAT_IN_FLOATING_POINT keeps the older
+    behaviour, the whole run again in the floating-point form."""
     from . import capi
     try:
         return run_exchange_once(engine, collective, run_index, counters)
@@ -495,10 +499,8 @@ def run_exchange(engine, collective, run_index=0, counters=None):
 
 
 def run_exchange_once(engine, collective, run_index=0, counters=None):
-    """One run of a joint population with EXACT global resampling (engine begun with scope=SCOPE_EXCHANGE on the shard
-    shard_bounds(n_global, world, rank)).  Returns (stats[T, K], summary).  counters (dict) receives the number of
-    lineage records this rank sent / received."""
     import torch
+    from . import capi
     dev = torch.device("cuda", engine.device)
     world, rank = collective.world, collective.rank
     n_global = int(engine.cfg.n_global)
@@ -507,28 +509,46 @@ def run_exchange_once(engine, collective, run_index=0, counters=None):
     allt = torch.zeros(3 * world, dtype=torch.float64, device=dev)
     vdtype = torch.int32 if engine.is_int else torch.float64
     torch.cuda.synchronize()                      # fills on torch's stream before the engine's stream touches them
-    send = recv = None
-    n_sent = n_recv = 0
-    for t in range(engine.T):
-        engine.step_begin(t, local, run_index)
-        collective.all_gather(local, allt)
-        engine.step_end(t, allt, world, rank)
-        if t + 1 == engine.T:
+    bufs = {"send": None, "recv": None}
+    moved = {"sent": 0, "recv": 0}
+
+    def steps(t_from, resumed):
+        """steps t_from .. T - 1; resumed: generation t_from exists already (its totals are in `local`: a repaired generation)"""
+        for t in range(t_from, engine.T):
+            if not (resumed and t == t_from):
+                engine.step_begin(t, local, run_index)
+            collective.all_gather(local, allt)
+            engine.step_end(t, allt, world, rank)
+            if t + 1 == engine.T:
+                break
+            _, sc, rc = engine.exchange_plan(t, world, rank, begins)
+            width = t + 1
+            ns, nr = int(sc.sum()), int(rc.sum())
+            if bufs["send"] is None or bufs["send"].numel() < max(ns, 1) * engine.T:
+                bufs["send"] = torch.empty(max(ns, 1) * engine.T, dtype=vdtype, device=dev)
+            if bufs["recv"] is None or bufs["recv"].numel() < max(nr, 1) * engine.T:
+                bufs["recv"] = torch.empty(max(nr, 1) * engine.T, dtype=vdtype, device=dev)
+            engine.exchange_pack(t, bufs["send"])
+            if world > 1:        # every rank takes part even with nothing to move: the peers' counts are not known here
+                collective.all_to_all_records(bufs["send"], bufs["recv"], sc, rc, width)
+            engine.exchange_commit(t, bufs["recv"])
+            moved["sent"] += ns
+            moved["recv"] += nr
+        engine.finish()
+
+    steps(0, False)
+    repeat_whole = bool(int(engine.cfg.flags) & capi.FLAG_REPEAT_IN_FLOATING_POINT)
+    last = -1
+    for _ in range(engine.T + 1):
+        g, _gap = engine.first_bad_generation()
+        if g < 0 or g <= last or repeat_whole or not engine._begin_args.get("keep_history", True):
             break
-        _, sc, rc = engine.exchange_plan(t, world, rank, begins)
-        width = t + 1
-        ns, nr = int(sc.sum()), int(rc.sum())
-        if send is None or send.numel() < max(ns, 1) * engine.T:
-            send = torch.empty(max(ns, 1) * engine.T, dtype=vdtype, device=dev)
-        if recv is None or recv.numel() < max(nr, 1) * engine.T:
-            recv = torch.empty(max(nr, 1) * engine.T, dtype=vdtype, device=dev)
-        engine.exchange_pack(t, send)
-        if world > 1:        # every rank takes part even with nothing to move: the peers' counts are not known here
-            collective.all_to_all_records(send, recv, sc, rc, width)
-        engine.exchange_commit(t, recv)
-        n_sent += ns
-        n_recv += nr
-    engine.finish()
+        engine.repair_begin(g, local)
+        collective.all_gather(local, allt)
+        engine.repair_end(g, allt, world, rank, local)
+        steps(g, True)
+        last = g
+    n_sent, n_recv = moved["sent"], moved["recv"]
     s = engine.summary()
     raw = torch.from_numpy(engine.stats()).to(dev)
     torch.cuda.current_stream().synchronize()     # the copy ran on torch's stream, the collective runs on the engine's

@@ -869,6 +869,18 @@ def test_exchange_scope_world1_is_bit_identical_to_run(engine, golden_dir):
     assert np.array_equal(engine.values(), ref_vals) and cnt["records_sent"] == 0
     np.testing.assert_allclose(stats, ref_stats, rtol=1e-13, atol=1e-15)
     assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"]
+    # a generation that loses its bits: the Python host repairs it in the run, in integers, through the same two calls the C++ group driver
+    # uses (cpprob_hip_smc_repair_begin / _end) -- the one-context run, bit for bit
+    o2 = np.array(_obs(golden_dir, "lgssm100")[:12])
+    o2[5] = 40.0
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, o2, n, seed=4, ess_threshold=0.5)
+    engine.run()
+    r_sum, r_vals, r_anc = engine.summary(), engine.values().copy(), engine.ancestors().copy()
+    assert r_sum["n_requantised"] >= 1
+    engine.begin(cp.ALG_SMC, cp.MODEL_LINEAR_GAUSSIAN_1D, o2, n, seed=4, ess_threshold=0.5, scope=cp.SCOPE_EXCHANGE)
+    stats, s = D.run_exchange(engine, D.TorchCollective(engine))
+    assert s["step_form"] == cp.capi.FORM_FIXED and s["n_requantised"] == r_sum["n_requantised"] and s["log_evidence"] == r_sum["log_evidence"]
+    assert np.array_equal(engine.values(), r_vals) and np.array_equal(engine.ancestors(), r_anc)
     # multinomial resampling in the exchange scope is the strata form over remote lineages (tests/test_gpu_group.py): the literal form and
     # the synchronising plan / pack / commit calls refuse loudly
     with pytest.raises(cp.CpprobHipError):
