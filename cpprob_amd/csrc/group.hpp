@@ -1061,6 +1061,7 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
     if (!g->ran) return gkeep(g, gfail(g, CPPROB_HIP_ESTATE, "no finished run"));
     if (h_stats && n_doubles < (size_t)g->n_stats) return gkeep(g, gfail(g, CPPROB_HIP_EINVAL, "h_stats too small"));
     std::vector<double> joint(group_joint_len(g));
+    int enlargements = 0;
     for (int attempt = 0;; ++attempt) {
         if (int rc = cpprob_hip_group_sync(g)) return gkeep(g, rc);
         cpprob_hip_ctx* c = g->ctx[0];
@@ -1081,9 +1082,38 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
             if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
             continue;
         }
+        if (joint[(size_t)g->n_stats] != 0.0) {
+            // some rank's transport was too small (every rank sees the same all-reduced flags and takes the same decision): repeat
+            // the run with what overflowed enlarged -- the annex (x4), the peer segments (x4, up to a whole shard), the peer list
+            // (every rank).  Results do not depend on the transport parameters, only their validity does.
+            // (first of all: a run whose transport overflowed holds nothing worth repairing -- and a run resumed behind a repaired generation keeps
+            //  the sticky flag of the steps in front of it, so only a run that did not overflow is ever repaired)
+            if (++enlargements > 8) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "exchange transport still too small after eight enlargements"));
+            const long long v = (long long)joint[(size_t)g->n_stats];
+            const bool seg = v % 128 != 0, peers = (v / 128) % 128 != 0, annex = (v / 16384) % 128 != 0;
+            if (v / 2097152 != 0)
+                return gkeep(g, gfail(g, CPPROB_HIP_EUNSUPPORTED, "multinomial resampling: a stratum cut by a rank boundary holds more thresholds than the cut table (8192; a stratum's "
+                                                                   "count is Binomial(N, 1/K) with mean <= 1024)"));
+            uint64_t largest = 0;
+            for (int r = 0; r < g->world; ++r) largest = std::max(largest, g->shard_begin[(size_t)r + 1] - g->shard_begin[(size_t)r]);
+            if (peers) g->all_peers = 1;
+            if (seg) g->cap = std::min<uint64_t>(largest, std::max<uint64_t>(g->cap * 4, 16384));
+            if (annex || (!seg && !peers)) {
+                // (0 = the context's default: max(a sixteenth of the shard, sqrt(N) T, four tiles) -- cpprob_hip_infer_begin)
+                const uint64_t mixed = (uint64_t)(std::sqrt((double)g->cfg.n_particles) * (double)g->T) / 1024 + (g->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL ? (uint64_t)g->T * 3 / 2 : 0);
+                const int in_use = g->annex_kcols > 0 ? g->annex_kcols : (int)std::max<uint64_t>(std::max<uint64_t>(4, ((largest + 1023) / 1024) / 16), mixed);
+                g->annex_kcols = in_use * 4;
+            }
+            if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
+            ++g->reruns;
+            g->repair_gen = -1; g->n_requantised = 0;
+            for (auto* x : g->ctx) x->fixed_check_pending = false;
+            if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
+            continue;
+        }
         // fixed-point form: did the weights keep their bits (cpprob_hip.hip: settle_fixed)?  On a run whose collectives all completed
-        // every rank holds the same gap (it comes from the all-gathered totals), so every rank takes the same decision: repeat the run
-        // in the floating-point form
+        // every rank holds the same gap and the same first offending generation (they come from the all-gathered totals), so every rank
+        // takes the same decision
         bool imprecise = false;
         int first_bad = -1;
         if (c->fixed_check_pending) {
@@ -1118,30 +1148,7 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
             if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
             continue;
         }
-        if (joint[(size_t)g->n_stats] == 0.0) break;
-        // some rank's transport was too small (every rank sees the same all-reduced flags and takes the same decision): repeat
-        // the run with what overflowed enlarged -- the annex (x4), the peer segments (x4, up to a whole shard), the peer list
-        // (every rank).  Results do not depend on the transport parameters, only their validity does.
-        if (attempt >= 6) return gkeep(g, gfail(g, CPPROB_HIP_EDEVICE, "exchange transport still too small after six enlargements"));
-        const long long v = (long long)joint[(size_t)g->n_stats];
-        const bool seg = v % 128 != 0, peers = (v / 128) % 128 != 0, annex = (v / 16384) % 128 != 0;
-        if (v / 2097152 != 0)
-            return gkeep(g, gfail(g, CPPROB_HIP_EUNSUPPORTED, "multinomial resampling: a stratum cut by a rank boundary holds more thresholds than the cut table (8192; a stratum's "
-                                                               "count is Binomial(N, 1/K) with mean <= 1024)"));
-        uint64_t largest = 0;
-        for (int r = 0; r < g->world; ++r) largest = std::max(largest, g->shard_begin[(size_t)r + 1] - g->shard_begin[(size_t)r]);
-        if (peers) g->all_peers = 1;
-        if (seg) g->cap = std::min<uint64_t>(largest, std::max<uint64_t>(g->cap * 4, 16384));
-        if (annex || (!seg && !peers)) {
-            // (0 = the context's default: max(a sixteenth of the shard, sqrt(N) T, four tiles) -- cpprob_hip_infer_begin)
-            const uint64_t mixed = (uint64_t)(std::sqrt((double)g->cfg.n_particles) * (double)g->T) / 1024 + (g->cfg.resampler == CPPROB_HIP_RESAMPLE_MULTINOMIAL ? (uint64_t)g->T * 3 / 2 : 0);
-            const int in_use = g->annex_kcols > 0 ? g->annex_kcols : (int)std::max<uint64_t>(std::max<uint64_t>(4, ((largest + 1023) / 1024) / 16), mixed);
-            g->annex_kcols = in_use * 4;
-        }
-        if (int rc = group_begin_contexts(g)) return gkeep(g, rc);
-        ++g->reruns;
-        g->repair_gen = -1; g->n_requantised = 0;
-        if (int rc = group_enqueue(g, g->last_run)) return gkeep(g, rc);
+        break;
     }
     g->repair_gen = -1;
     if (h_reruns) *h_reruns = g->reruns;

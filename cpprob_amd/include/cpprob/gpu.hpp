@@ -155,19 +155,23 @@ __global__ __launch_bounds__(device::kStepBlock) void model_step_kernel_at(Model
     }
     model_step_body<Caller, Tuple, false>(observes);
 }
+template <class Caller, class Tuple, int FO, int A, int WIN, bool LAST>
+__global__ void model_step_kernel_quad_at(ModelKernelArgs a, const Tuple* __restrict__ observes);      // (below, with the quad step)
 // the builds a model unit registered for Caller (one table per model, shared by every translation unit of the library)
-struct StepKernelEntry { int fo, a, win; bool exact, last; const void* fn; };
+struct StepKernelEntry { int fo, a, win; bool exact, last; const void* fn; const void* quad_fn; };      // quad_fn: the four-a-lane build (exact builds only)
 template <class Caller>
 inline std::vector<StepKernelEntry>& step_kernels() { static std::vector<StepKernelEntry> v; return v; }
 // the build to launch for a step whose thresholds are these (nullptr: model_step_kernel)
 template <class Caller>
-const void* step_kernel_for(const ModelKernelArgs& a)
+const void* step_kernel_for(const ModelKernelArgs& a, bool quad = false)
 {
     const StepKernelEntry* best = nullptr;
     for (const StepKernelEntry& e : step_kernels<Caller>()) {
         if (e.win != (int)a.win) continue;
         if (e.exact) {
-            if (a.first_observe == e.fo && a.stop_after == (e.last ? -1 : e.fo) && a.fresh_lo == e.a * e.fo && a.next_fresh == e.a * (e.fo + 1)) return e.fn;
+            if (a.first_observe == e.fo && a.stop_after == (e.last ? -1 : e.fo) && a.fresh_lo == e.a * e.fo && a.next_fresh == e.a * (e.fo + 1)) return quad ? e.quad_fn : e.fn;
+        } else if (quad) {
+            continue;
         } else if (a.first_observe >= e.fo && a.first_observe < 4096 && a.fresh_lo >= e.a * e.fo && a.next_fresh >= e.a * (e.fo + 1) && a.fresh_lo < (1 << 20) && a.next_fresh < (1 << 20)) {
             if (!best || e.fo > best->fo) best = &e;
         }
@@ -185,7 +189,9 @@ void register_step_build()
     constexpr int fo = exact ? I : I * G;
     if constexpr (I % PARTS == PART && fo < T && (exact || I > 0)) {
         constexpr bool last = exact && fo == T - 1;
-        step_kernels<Caller>().push_back(StepKernelEntry{fo, A, WIN, exact, last, reinterpret_cast<const void*>(&model_step_kernel_at<Caller, Tuple, fo, A, WIN, exact, last>)});
+        const void* quad_fn = nullptr;
+        if constexpr (exact) quad_fn = reinterpret_cast<const void*>(&model_step_kernel_quad_at<Caller, Tuple, fo, A, WIN, last>);
+        step_kernels<Caller>().push_back(StepKernelEntry{fo, A, WIN, exact, last, reinterpret_cast<const void*>(&model_step_kernel_at<Caller, Tuple, fo, A, WIN, exact, last>), quad_fn});
     }
 }
 template <class Caller, int T, int A, int WIN, int PART, int PARTS, int... I>
@@ -206,6 +212,33 @@ __global__ __launch_bounds__(device::kStepBlock) void model_step_kernel_quad(Mod
         __builtin_assume(fused == device::kFusedQuad); __builtin_assume(win == 1u); __builtin_assume(lanes == (uint32_t)device::kStepBlock);
         const int32_t world = device::launch_args()->sh.world;
         __builtin_assume(world == 0);
+    }
+    device::QuadStep qs;
+    device::quad_prologue(qs);
+#pragma unroll 1
+    for (int p = 0; p < device::kQuadPasses; ++p) {
+        device::quad_begin(qs, p);
+        Caller::call(*observes);
+        device::quad_end(qs);
+    }
+    device::quad_epilogue(qs);
+}
+
+// ... built for ONE step (model_step_kernel_at, EXACT): the call of the model body is then the step's live iteration alone -- the dead
+// iterations in front of it fold away, and so do those BEHIND it (the step's observe ends the CALL by making every later statement a
+// dead one: store-to-load forwarding turns that into compile-time facts too), which this form, unlike the one-a-lane step, used to run.
+template <class Caller, class Tuple, int FO, int A, int WIN, bool LAST>
+__global__ __launch_bounds__(device::kStepBlock) void model_step_kernel_quad_at(ModelKernelArgs a, const Tuple* __restrict__ observes)
+{
+    (void)a;
+    {
+        const uint32_t fused = device::launch_args()->fused, win = device::launch_args()->windowed, lanes = device::launch_args()->lane_block;
+        __builtin_assume(fused == device::kFusedQuad); __builtin_assume(win == 1u); __builtin_assume(lanes == (uint32_t)device::kStepBlock);
+        const int32_t world = device::launch_args()->sh.world;
+        __builtin_assume(world == 0);
+        const int32_t fo = device::launch_args()->first_observe, sa = device::launch_args()->stop_after, fl = device::launch_args()->fresh_lo, nf = device::launch_args()->next_fresh;
+        const uint32_t w = device::launch_args()->win;
+        __builtin_assume(w == (uint32_t)WIN); __builtin_assume(fo == FO); __builtin_assume(sa == (LAST ? -1 : FO)); __builtin_assume(fl == A * FO); __builtin_assume(nf == A * (FO + 1));
     }
     device::QuadStep qs;
     device::quad_prologue(qs);
@@ -497,7 +530,13 @@ int generic_attempt(StateType algorithm, const void* observes_v, std::size_t n, 
                 a.fs.u0 = cpprob_hip_systematic_offset(opt.seed, (uint64_t)t);
                 a.fs.bound = (form == StepForm::fused_bounded || quad) ? st.observe_bound[(size_t)t] : 0.0;
                 a.fs.t = t; a.fs.anc_row = d_anc_all + (size_t)t * n;
-                if (quad) hipLaunchKernelGGL((model_step_kernel_quad<Caller, Tuple>), qgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
+                if (const void* qat = (quad && opt.step_builds) ? step_kernel_for<Caller>(a, true) : nullptr) {
+                    const Tuple* obs_p = d_obs;
+                    void* kargs[2] = {&a, &obs_p};
+                    hip_check(hipLaunchKernel(qat, qgrid, sblock, kargs, step_lds, stream), "model_step_kernel_quad_at");
+                    ++res.step_builds_used;
+                }
+                else if (quad) hipLaunchKernelGGL((model_step_kernel_quad<Caller, Tuple>), qgrid, sblock, step_lds, stream, a, (const Tuple*)d_obs);
                 else if (const void* at = opt.step_builds ? step_kernel_for<Caller>(a) : nullptr) {
                     // (a build for this step: its thresholds are the kernel's compile-time facts -- checked above, where it was chosen)
                     const Tuple* obs_p = d_obs;
@@ -701,7 +740,13 @@ void generic_launcher(StateType algorithm, const void* observes_v, std::size_t n
     //  ab_quad_threshold.sh, ms per run, one a lane / four a lane: hmm<16> 1.5e6 0.697 / 0.637, 3e6 1.22 / 1.11, 6e6 2.24 / 1.94, 1e7 3.78 / 3.27;
     //  linear_gaussian_1d<25> 2e6 1.54 / 1.64, 3e6 2.21 / 2.18, 6e6 4.36 / 4.01; at 10^6 it is latency bound, at T >= 100 its dead iterations
     //  cost more than the shared search saves: profiles/r05_notes.md section 8)
-    if (form == StepForm::fused_bounded && st.n_observe <= 32 && n >= std::size_t(st.n_observe <= 16 ? 1500000 : 3000000)) form = StepForm::fused_quad;
+    //  With the step kernels built per step (CPPROB_REGISTER_MODEL_STEPS, <= 32 observes: one build a step) a call of the body is the live
+    //  iteration alone, in front of the step's observe AND behind it, and four a lane wins from ~7e5 particles on (tools/ab_quad_builds.sh, one /
+    //  four a lane: hmm<16> 3e5 0.256 / 0.277, 1e6 0.440 / 0.395, 3e6 1.03 / 0.81, 1e7 3.07 / 2.38; linear_gaussian_1d<25> 3e5 0.36 / 0.41, 1e6 0.70 / 0.64, 3e6 1.68 / 1.36).
+    bool exact_builds = false;
+    if (opt.step_builds) for (const StepKernelEntry& e : step_kernels<Caller>()) exact_builds = exact_builds || (e.exact && e.quad_fn);
+    const std::size_t quad_from = exact_builds ? std::size_t(700000) : std::size_t(st.n_observe <= 16 ? 1500000 : 3000000);
+    if (form == StepForm::fused_bounded && st.n_observe <= 32 && n >= quad_from) form = StepForm::fused_quad;
     if (opt.step_form_override >= 0) {
         if (opt.step_form_override > 3) throw std::invalid_argument("cpprob::gpu::Options::step_form_override: 0 (unfused), 1 (bounded), 2 (exact maximum) or 3 (bounded, four particles a lane)");
         form = static_cast<StepForm>(opt.step_form_override);

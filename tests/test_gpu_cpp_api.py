@@ -149,6 +149,12 @@ def test_step_kernels_built_per_step_change_no_number(tmp_path, model, key, T, e
     assert out["built"][0]["step_builds_used"] == used and out["runtime"][0]["step_builds_used"] == 0
     assert out["built"][1] == out["runtime"][1]
     assert out["built"][0]["log_evidence"] == out["runtime"][0]["log_evidence"] and out["built"][0]["n_resampled"] == out["runtime"][0]["n_resampled"]
+    if T <= 32:
+        # ... and four particles a lane on the builds (model_step_kernel_quad_at: a call of the body is the live iteration alone)
+        res, _, _ = run_main(tmp_path, "--model", model, "--smc", "--observes", obs_str(obs), "--n_samples", n, "--seed", 5, "--ess_threshold", ess, "--json",
+                             "--generic", "--generated_file", "quad", "--step_form", 3)
+        assert res["step_form"] == 3 and res["step_builds_used"] == used
+        assert open(str(tmp_path / ("quad" + ("_smc.int" if is_int else "_smc.real")))).read() == out["runtime"][1] and res["log_evidence"] == out["runtime"][0]["log_evidence"]
 
 
 @pytest.mark.parametrize("n", [1, 255, 1024, 1025, 3000])
