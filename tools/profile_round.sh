@@ -40,6 +40,16 @@ done
 python3 $R/bench.py --workload lgssm100_smc --particles 10000000 --loopback-ranks 8 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_loop_c4.json 2> $O/${TAG}_loop_c4.err
 python3 $R/bench.py --workload hmm128_smc_ess --particles 100000000 --loopback-ranks 8 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_loop_c5.json 2> $O/${TAG}_loop_c5.err
 python3 $R/bench.py --workload hmm16_smc --particles 8000000 --loopback-ranks 8 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/${TAG}_loop_c3x8.json 2> $O/${TAG}_loop_c3x8.err
+# multinomial resampling (thesis Alg. 1) as ONE population over eight loopback shards, beside systematic: kernel stats + the un-profiled line
+for RS in multinomial systematic; do
+  D=$O/${TAG}_prof_loop8_$RS
+  rm -rf $D
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --resampler $RS --loopback-ranks 8 --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc > $D.log 2>&1
+  python3 $R/bench.py --resampler $RS --loopback-ranks 8 --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc > $D.json 2>> $D.log
+done
+# the unchanged-model path: step kernels built per step against the run-time kernel, one / four particles a lane
+bash $R/tools/ab_step_builds.sh > /dev/null 2>&1
+bash $R/tools/ab_quad_builds.sh > /dev/null 2>&1
 # A/B of the headline's read-out (trace words vs the lineage walk), and the host's share of an exchange-scope run
 python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --flags 64 > $O/${TAG}_bench_walk_readout.json 2>> $O/${TAG}_bench.err
 python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $O/${TAG}_bench_trace_words.json 2>> $O/${TAG}_bench.err

@@ -124,6 +124,30 @@ for wl, n in (("hmm16_smc", 1000000), ("lgssm100_smc", 1250000)):
         open("profiles/%s_%s_%d_%s_kernel_stats.md" % (out_tag, wl, n, rs_name), "w").write(md)
         notes.append("profiles/%s_%s_%d_%s_kernel_stats.md" % (out_tag, wl, n, rs_name))
 
+# the three resamplers' sharded form: eight loopback ranks of one population (multinomial: the strata form over cut strata)
+for rs_name in ("multinomial", "systematic"):
+    d = "%s_prof_loop8_%s" % (src_tag, rs_name)
+    ks = newest("%s/%s/*/*kernel_stats.csv" % (G, d))
+    if not ks:
+        continue
+    rows = list(csv.DictReader(open(ks)))
+    md = "# rocprofv3 --kernel-trace --stats -- python3 bench.py --resampler %s --loopback-ranks 8 --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-live-pmc (MI355X, %s)\n\n" % (rs_name, out_tag)
+    md += "hmm<16>, 10^6 particles as ONE population over eight loopback ranks of this GPU (one stream: the ranks' launches serialise).\n\n"
+    md += "| kernel | calls | total us | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n"
+    for r in rows[:12]:
+        md += "| `%s` | %s | %.1f | %.2f | %.2f | %.2f | %s |\n" % (r["Name"][:120], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"])
+    bj = "%s/%s.json" % (G, d)
+    if os.path.exists(bj) and os.path.getsize(bj):
+        b = json.load(open(bj))
+        md += "\nbench.py, same command un-profiled, same gpurun call: %.4f ms per run, posterior max abs err vs exact %.2e; per rank-step (sum over the eight ranks' launches, us): %s.\n" % (
+            b["ms_per_step"], b["posterior_max_abs_err_vs_exact"], {k: round(v, 1) for k, v in (b.get("rank_step_breakdown_us") or {}).items() if isinstance(v, float)})
+    open("profiles/%s_hmm16_smc_1000000_loop8_%s_kernel_stats.md" % (out_tag, rs_name), "w").write(md)
+    notes.append("profiles/%s_hmm16_smc_1000000_loop8_%s_kernel_stats.md" % (out_tag, rs_name))
+for f in ("ab_step_builds.txt", "ab_quad_builds.txt", "ab_walk_r06.txt"):
+    if os.path.exists("%s/%s" % (G, f)):
+        shutil.copy("%s/%s" % (G, f), "profiles/%s_%s" % (out_tag, f))
+        notes.append("profiles/%s_%s" % (out_tag, f))
+
 bp = "%s/%s_bench.json" % (G, src_tag)
 if os.path.exists(bp):
     b = json.load(open(bp))
@@ -143,14 +167,14 @@ for form in (1, 0, 3):
         continue
     rows = list(csv.DictReader(open(ks)))
     gmd = "# rocprofv3 --kernel-trace --stats -- cpprob_main --generic --model hmm16 --smc --n_samples 1000000 --repeat 8 --step_form %d (MI355X, %s; tools/profile_generic.sh)\n\n" % (form, out_tag)
-    gmd += "step form %d = %s.  Eight cpprob::inference calls + the Markov pilot (8192 particles, both replay forms) in one process.\n\n" % (form, {1: "the resampling inside the model's launch (model_step_kernel)", 0: "model launch + three bookkeeping launches (the r03 form)", 3: "the resampling inside the model's launch, four particles a lane behind one ancestor search (model_step_kernel_quad; opt-in)"}[form])
+    gmd += "step form %d = %s.  Eight cpprob::inference calls + the Markov pilot (8192 particles, both replay forms) in one process.\n\n" % (form, {1: "the resampling inside the model's launch, one particle a lane (model_step_kernel_at: a build per step, no dead iteration; the run-time model_step_kernel where a step has none)", 0: "model launch + three bookkeeping launches (the r03 form)", 3: "the resampling inside the model's launch, four particles a lane behind one ancestor search (model_step_kernel_quad_at: a build per step, a call of the body is the live iteration alone; the engine's choice from 7e5 particles on)"}[form])
     gmd += "| kernel | calls | total us | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n"
     for r in rows[:10]:
         gmd += "| `%s` | %s | %.1f | %.2f | %.2f | %.2f | %s |\n" % (r["Name"][:120], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"])
     if tr:
         mk = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in csv.DictReader(open(tr)) if "model_" in r["Kernel_Name"])
         last = [x for _, x in mk[-16:]]
-        gmd += "\nThe last call's 16 model launches, t = 0 .. 15 (us): %s -- sum %.1f us; launch t runs t dead iterations of the model's own loop before the live one.\n" % (" ".join("%.1f" % x for x in last), sum(last))
+        gmd += "\nThe last call's 16 model launches, t = 0 .. 15 (us): %s -- sum %.1f us (r05, run-time kernel: launch t ran t dead iterations of the model's own loop before the live one: 14.0, then 25.7 + 0.39 t).\n" % (" ".join("%.1f" % x for x in last), sum(last))
     up = "%s/%s/unprofiled.json" % (G, d)
     if os.path.exists(up) and os.path.getsize(up):
         try:
