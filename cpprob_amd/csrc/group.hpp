@@ -1134,7 +1134,7 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
             ++g->n_requantised;
             continue;
         }
-        if (imprecise && (g->cfg.resampler != CPPROB_HIP_RESAMPLE_SYSTEMATIC || !c->keep) && g->exchange) {
+        if (imprecise && g->cfg.resampler != CPPROB_HIP_RESAMPLE_SYSTEMATIC && g->exchange) {
             // (the floating-point form of the exchange scope plans systematic offspring intervals only)
             g->repair_gen = -1;
             return gkeep(g, gfail(g, CPPROB_HIP_EPRECISION, "a generation's heaviest particle sat more than 6 nats below its fixed-point reference and could not be repaired in the run"));

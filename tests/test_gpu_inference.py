@@ -731,7 +731,7 @@ def _run_joint_virtual(model, alg, obs, n_per, world, seed, ess):
     return stats, summ, traces
 
 
-def _run_exchange_virtual(model, obs, n_pers, seed, ess, flags=0):
+def _run_exchange_virtual(model, obs, n_pers, seed, ess, flags=0, repair=False):
     """EXCHANGE scope over virtual ranks: plan / pack / (in-process all-to-all) / commit.  Returns the joint stats, the
     summary, every shard's materialised traces [T, n_r] and the number of migrated lineage records per step."""
     import torch
@@ -746,45 +746,71 @@ def _run_exchange_virtual(model, obs, n_pers, seed, ess, flags=0):
     locals_ = [dzeros(4, dtype=torch.float64) for _ in range(world)]
     allt = dzeros(3 * world, dtype=torch.float64)
     moved = []
-    for t in range(T):
+
+    def steps(t_from, resumed):
+        # steps t_from .. T - 1; resumed: generation t_from exists already (a repaired generation, its totals in locals_)
+        for t in range(t_from, T):
+            if not (resumed and t == t_from):
+                for r, e in enumerate(engines):
+                    e.step_begin(t, locals_[r])
+            for e in engines:
+                e.sync()
+            allt.copy_(torch.cat([l[:3] for l in locals_]))
+            torch.cuda.synchronize()
+            for r, e in enumerate(engines):
+                e.step_end(t, allt, world, r)
+            if t + 1 == T:
+                break
+            plans = [e.exchange_plan(t, world, r, begins) for r, e in enumerate(engines)]
+            decisions = {p[0] for p in plans}
+            assert len(decisions) == 1                                              # same decision everywhere
+            for a in range(world):
+                for b in range(world):
+                    assert plans[a][1][b] == plans[b][2][a]                         # what a sends to b is what b expects from a
+            width = t + 1
+            sends = []
+            for r, e in enumerate(engines):
+                buf = torch.empty(max(int(plans[r][1].sum()), 1) * width, dtype=vdt, device="cuda")
+                e.exchange_pack(t, buf)
+                e.sync()
+                sends.append(buf)
+            for dst, e in enumerate(engines):
+                parts = []
+                for src in range(world):
+                    off = int(plans[src][1][:dst].sum()) * width
+                    parts.append(sends[src][off: off + int(plans[src][1][dst]) * width])
+                recv = torch.cat(parts) if parts else torch.empty(0, dtype=vdt, device="cuda")
+                assert recv.numel() == int(plans[dst][2].sum()) * width
+                torch.cuda.synchronize()
+                e.exchange_commit(t, recv if recv.numel() else None)
+                e.sync()
+            moved.append(int(sum(p[1].sum() for p in plans)))
+        for e in engines:
+            e.finish()
+
+    steps(0, False)
+    last = -1
+    for _ in range(T + 1 if repair else 0):
+        # a generation that lost its fixed-point bits: every rank names the same one (the books come from the all-gathered totals)
+        bad = [e.first_bad_generation()[0] for e in engines]
+        assert len(set(bad)) == 1
+        g = bad[0]
+        if g < 0 or g <= last:
+            break
+        del moved[g:]
         for r, e in enumerate(engines):
-            e.step_begin(t, locals_[r])
+            e.repair_begin(g, locals_[r])
         for e in engines:
             e.sync()
         allt.copy_(torch.cat([l[:3] for l in locals_]))
         torch.cuda.synchronize()
         for r, e in enumerate(engines):
-            e.step_end(t, allt, world, r)
-        if t + 1 == T:
-            break
-        plans = [e.exchange_plan(t, world, r, begins) for r, e in enumerate(engines)]
-        flags = {p[0] for p in plans}
-        assert len(flags) == 1                                                  # same decision everywhere
-        for a in range(world):
-            for b in range(world):
-                assert plans[a][1][b] == plans[b][2][a]                         # what a sends to b is what b expects from a
-        width = t + 1
-        sends = []
-        for r, e in enumerate(engines):
-            buf = torch.empty(max(int(plans[r][1].sum()), 1) * width, dtype=vdt, device="cuda")
-            e.exchange_pack(t, buf)
-            e.sync()
-            sends.append(buf)
-        for dst, e in enumerate(engines):
-            parts = []
-            for src in range(world):
-                off = int(plans[src][1][:dst].sum()) * width
-                parts.append(sends[src][off: off + int(plans[src][1][dst]) * width])
-            recv = torch.cat(parts) if parts else torch.empty(0, dtype=vdt, device="cuda")
-            assert recv.numel() == int(plans[dst][2].sum()) * width
-            torch.cuda.synchronize()
-            e.exchange_commit(t, recv if recv.numel() else None)
-            e.sync()
-        moved.append(int(sum(p[1].sum() for p in plans)))
+            e.repair_end(g, allt, world, r, locals_[r])
+        steps(g, True)
+        last = g
     raw = np.zeros((T, K))
     summ = None
     for e in engines:
-        e.finish()
         raw += e.stats()
         s = e.summary()
         if summ is not None:
