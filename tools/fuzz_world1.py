@@ -35,7 +35,7 @@ for it in range(int(sys.argv[2])):
         g.close()
         if s["step_form"] == ref_sum["step_form"] and s["step_form"] != cp.capi.FORM_FLOAT:
             assert s["log_evidence"] == ref_sum["log_evidence"] and s["n_resampled"] == ref_sum["n_resampled"], tag + " %r %r" % (s, ref_sum)
-            np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-12, err_msg=tag)
+            np.testing.assert_allclose(stats, ref_stats, rtol=0, atol=1e-11, err_msg=tag)   # (a collapsed lineage: the variance is a difference of two ~30s)
         else:
             assert abs(s["log_evidence"] - ref_sum["log_evidence"]) < 1e-6 * max(1.0, abs(ref_sum["log_evidence"])) + 5.0 / np.sqrt(n), tag + " forms %d %d" % (s["step_form"], ref_sum["step_form"])
         print("ok", tag, s["step_form"], ref_sum["step_form"], flush=True)
