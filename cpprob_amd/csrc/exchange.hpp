@@ -443,6 +443,7 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_strata_kernel(PackStra
     const CutHead hme0 = a.cut.head[rank], hme1 = a.cut.head[rank + 1];
     const bool same = hme0.A > hme0.Z && hme0.A == hme1.A && hme0.Z == hme1.Z;
     // work items: (kind 0: regular, 1: the cut stratum of boundary `rank`, 2: of boundary `rank + 1`) x destination rank
+    uint32_t unit = 0;
     for (int item = 0; item < 3 * world; ++item) {
         const int kind = item / world, d = item - kind * world;
         if (d == rank) continue;
@@ -457,14 +458,18 @@ __global__ __launch_bounds__(kThreads) void exchange_pack_strata_kernel(PackStra
             tab = a.cut.tab + (size_t)(kind == 1 ? rank : rank + 1) * kCutRow; tab0 = hb.Z;
         }
         if (hi <= lo) continue;                                          // uniform
+        // (the work units -- the items' tiles, counted through -- go round the workgroups: a workgroup that has none of this item's
+        //  tiles reads nothing of it; with fewer units than workgroups nobody walks two)
+        const uint32_t tile0 = lo / kTile, n_tiles = (hi - 1) / kTile - tile0 + 1;
+        const uint32_t bx = (blockIdx.x + gridDim.x - unit % gridDim.x) % gridDim.x;
+        unit += n_tiles;
+        if (bx >= n_tiles) continue;
         const KeptCtx kc = kept_ctx(a.cut, d, sb);
         S* const annex_row = static_cast<S*>(const_cast<void*>(rem->values[d])) + (int64_t)a.t * rem->rs[d] + rem->ld[d];
         int64_t* const origin = const_cast<int64_t*>(rem->origin[d]);
         uint32_t* const annex_trace = a.trace_cur ? rem->trace[a.trace_par][d] + rem->ld[d] : nullptr;
         const int64_t col0 = s_fill[d], room = rem->rs[d] - rem->ld[d];
-        // (the items' first tiles go to different workgroups: a workgroup walks its tiles one after the other)
-        const uint32_t bx = (blockIdx.x + gridDim.x - (uint32_t)item % gridDim.x) % gridDim.x;
-        for (uint32_t tile = lo / kTile + bx; (uint64_t)tile * kTile < hi; tile += gridDim.x) {
+        for (uint32_t tile = tile0 + bx; tile < tile0 + n_tiles; tile += gridDim.x) {
             const uint32_t g0 = tile * kTile;
             const uint32_t s_first = max(lo, g0), s_last = min(hi, g0 + kTile) - 1;
             const uint64_t gj = (uint64_t)g0 + (uint64_t)tid * kPPT;
