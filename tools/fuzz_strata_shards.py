@@ -26,7 +26,7 @@ for it in range(int(sys.argv[2])):
     obs = np.array(z[key][:T])
     if rng.random() < 0.15:
         obs[int(rng.integers(0, T))] = 30.0 if model == cp.MODEL_LINEAR_GAUSSIAN_1D else 9.0       # an outlier: a generation loses its bits
-    world = int(rng.integers(2, 9))
+    world = int(rng.integers(2, 1 + int(os.environ.get("FUZZ_WORLD_MAX", "8"))))
     kind = int(rng.integers(0, 4))
     if kind == 0:
         sizes = [int(rng.integers(1, 40)) for _ in range(world)]                                     # everything inside one stratum
