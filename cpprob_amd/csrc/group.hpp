@@ -1093,7 +1093,7 @@ int cpprob_hip_group_results(cpprob_hip_group* g, cpprob_hip_summary* out, doubl
             const bool seg = v % 128 != 0, peers = (v / 128) % 128 != 0, annex = (v / 16384) % 128 != 0;
             if (v / 2097152 != 0)
                 return gkeep(g, gfail(g, CPPROB_HIP_EUNSUPPORTED, "multinomial resampling: a stratum cut by a rank boundary holds more thresholds than the cut table (8192; a stratum's "
-                                                                   "count is Binomial(N, 1/K) with mean <= 1024)"));
+                                                                   "count is Binomial(N, 1/K) with mean <= 256)"));
             uint64_t largest = 0;
             for (int r = 0; r < g->world; ++r) largest = std::max(largest, g->shard_begin[(size_t)r + 1] - g->shard_begin[(size_t)r]);
             if (peers) g->all_peers = 1;

@@ -460,16 +460,12 @@ __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uin
     const int w0 = __builtin_amdgcn_readfirstlane(sl.w0), w1 = __builtin_amdgcn_readfirstlane(sl.w1);
     const double unit = ldexp(W, -k);
     {
-        uint32_t o_lo = offs[w0];
-        for (int w = w0; w <= w1; ++w) {
-            const uint32_t o_hi = offs[w + 1];
-            const double b_lo = (double)w * unit, b_hi = (double)(w + 1) * unit;
+        int ws[kPPT];
+        lane_strata4(offs, k, w0, w1, (uint32_t)j0, ws, live);
 #pragma unroll
-            for (int i = 0; i < kPPT; ++i) {
-                const int64_t s = j0 + i;
-                if (s >= (int64_t)o_lo && s < (int64_t)o_hi) { tau[i] = fma(v[i], b_hi - b_lo, b_lo); live[i] = true; }
-            }
-            o_lo = o_hi;
+        for (int i = 0; i < kPPT; ++i) {
+            const double b_lo = __dmul_rn((double)ws[i], unit), b_hi = __dmul_rn((double)(ws[i] + 1), unit);
+            tau[i] = live[i] ? fma(v[i], __dsub_rn(b_hi, b_lo), b_lo) : 0.0;
         }
     }
     // (j0 = the lane's first output in the POPULATION; of a shard's outputs only those whose threshold lies in its sources' range)

@@ -171,7 +171,7 @@ __device__ __forceinline__ void fixed_multinomial_ancestors(uint64_t S, uint64_t
 //          tau_s = B_w + floor(v_s (B_w+1 - B_w)),   B_w = floor(C_N w / K),   ancestor = min{k : C_k > tau_s}.
 //      An output tile's thresholds lie in two or three neighbouring strata, i.e. in the two or three source tiles around its own
 //      index: each of them rebuilds its prefix masses in LDS and the outputs search there.  No atomics, no launch between two steps.
-// K = the smallest power of two >= the number of tiles.  Integers throughout (the CPU restatement: orc_resample_fixed_multinomial_strata).
+// K = the smallest power of two >= four times the number of tiles (strata_levels).  Integers throughout (the CPU restatement: orc_resample_fixed_multinomial_strata).
 __device__ __forceinline__ uint64_t strata_bound(uint64_t S, uint64_t w, int k)
 {
     if (k == 0) return w ? S : 0ull;
@@ -409,17 +409,12 @@ __device__ __forceinline__ void strata_walk(const uint32_t* __restrict__ offs, i
     for (int i = 0; i < kPPT; ++i) { live[i] = false; tau[i] = 0; }
     const int w0 = __builtin_amdgcn_readfirstlane(sl.w0), w1 = __builtin_amdgcn_readfirstlane(sl.w1);
     {
-        uint32_t o_lo = offs[w0];
-        uint64_t b_lo = strata_bound(S, (uint64_t)w0, k);
-        for (int w = w0; w <= w1; ++w) {
-            const uint32_t o_hi = offs[w + 1];
-            const uint64_t b_hi = strata_bound(S, (uint64_t)w + 1, k);
+        int ws[kPPT];
+        lane_strata4(offs, k, w0, w1, (uint32_t)j0, ws, live);
 #pragma unroll
-            for (int i = 0; i < kPPT; ++i) {
-                const int64_t s = j0 + i;
-                if (s >= (int64_t)o_lo && s < (int64_t)o_hi) { tau[i] = b_lo + __umul64hi(v[i], b_hi - b_lo); live[i] = true; }
-            }
-            o_lo = o_hi; b_lo = b_hi;
+        for (int i = 0; i < kPPT; ++i) {
+            const uint64_t b_lo = strata_bound(S, (uint64_t)ws[i], k), b_hi = strata_bound(S, (uint64_t)ws[i] + 1, k);
+            tau[i] = live[i] ? b_lo + __umul64hi(v[i], b_hi - b_lo) : 0ull;
         }
     }
 #pragma unroll

@@ -19,7 +19,7 @@
 
 namespace cph {
 
-constexpr int kCutCap = 8192;               // outputs of a cut stratum the table holds (a stratum's count is Binomial(N, 1/K), mean <= 1024)
+constexpr int kCutCap = 8192;               // outputs of a cut stratum the table holds (a stratum's count is Binomial(N, 1/K), mean <= 256)
 constexpr int kCutRow = kCutCap + 1;        // + the stratum's total
 constexpr uint32_t kCutCumMask = 0xffffffu;
 constexpr int kCutSlots = 64;               // boundaries 0 .. world (world <= 63)
@@ -72,6 +72,50 @@ __device__ __forceinline__ uint32_t kept_before(const KeptCtx& k, uint32_t s)
         }
     }
     return kept;
+}
+
+// The strata of a lane's four consecutive outputs s0 .. s0 + 3 among the strata w0 .. w1 of its output tile (strata_window): for every
+// output the largest w with offs[w] <= s (an empty stratum is never the answer), or in = false where the output lies outside
+// [offs[w0], offs[w1 + 1]).  The window's first outputs sit in ONE register, a stratum a lane (one load); every lane searches it for its
+// own outputs through the crossbar (ds_bpermute: no memory, no loop over the strata -- with four to eight strata a tile that loop, run
+// by every lane for every stratum, cost a 10^7-particle step 12 %).  Wavefront-uniform: offs, k, w0, w1.
+__device__ __forceinline__ void lane_strata4(const uint32_t* __restrict__ offs, int k, int w0, int w1, uint32_t s0, int (&w)[4], bool (&in)[4])
+{
+    const int lane = lane_id();
+    const int K1 = 1 << k;
+    const int n_str = w1 - w0 + 1;
+    if (n_str < kWave) {
+        const uint32_t o_reg = offs[w0 + lane <= K1 ? w0 + lane : K1];
+        const uint32_t o_first = (uint32_t)__builtin_amdgcn_readlane((int)o_reg, 0), o_end = (uint32_t)__builtin_amdgcn_readlane((int)o_reg, n_str);
+        const int n_steps = n_str > 1 ? 32 - __builtin_clz((unsigned)(n_str - 1)) : 0;
+        auto find = [&](uint32_t s) -> int {
+            int lo = 0, hi = n_str - 1;
+            for (int st = 0; st < n_steps; ++st) {
+                const int mid = (lo + hi + 1) >> 1;
+                const uint32_t val = (uint32_t)__builtin_amdgcn_ds_bpermute(mid << 2, (int)o_reg);
+                const bool le = val <= s;
+                lo = le ? mid : lo; hi = le ? hi : mid - 1;
+            }
+            return lo;
+        };
+        const int r0 = find(s0), r3 = find(s0 + 3u);
+        int r1 = r0, r2 = r0;
+        if (__any(r0 != r3)) { r1 = find(s0 + 1u); r2 = find(s0 + 2u); }       // (a stratum ends inside some lane's four outputs)
+        w[0] = w0 + r0; w[1] = w0 + r1; w[2] = w0 + r2; w[3] = w0 + r3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint32_t s = s0 + (uint32_t)i; in[i] = s >= o_first && s < o_end; }
+        return;
+    }
+    // (sixty-four strata or more for one tile of outputs -- strata of a handful of thresholds: the plain loop)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[i] = w0; in[i] = false; }
+    uint32_t o_lo = offs[w0];
+    for (int ww = w0; ww <= w1; ++ww) {
+        const uint32_t o_hi = offs[ww + 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint32_t s = s0 + (uint32_t)i; if (s >= o_lo && s < o_hi) { w[i] = ww; in[i] = true; } }
+        o_lo = o_hi;
+    }
 }
 
 }  // namespace cph

@@ -238,8 +238,12 @@ constexpr int kFixSystematic = 0, kFixStratified = 1, kFixMultinomial = 2, kFixM
 constexpr uint64_t kResampleDrawBase2 = kResampleDrawBase + (1ull << 39);   // multinomial, strata form: the outputs' uniforms inside their strata
 constexpr uint64_t kResampleDrawBase3 = kResampleDrawBase + (1ull << 38);   // ... and the bits that split the thresholds over the strata
 constexpr int kStrataTiles = 3;   // source tiles of an output tile staged side by side by the strata form (more: in turn)
-// K = 2^k strata, the smallest power of two >= the number of tiles
-__host__ __device__ inline int strata_levels(int64_t nb) { int k = 0; while (((int64_t)1 << k) < nb) ++k; return k; }
+// K = 2^k strata, the smallest power of two >= FOUR times the number of tiles (128 .. 256 thresholds a stratum on average): the strata
+// that overhang an output tile's ends add <= half a tile of mass to what its thresholds span, so its sources are two tiles, rarely three
+// -- one staged group (kStrataTiles).  With K ~ the number of tiles the span reached four and five tiles: a second group in the
+// workgroups the launch then waited for (profiles/r06_notes.md section 8).
+constexpr int kStrataPerTileLog2 = 2;
+__host__ __device__ inline int strata_levels(int64_t nb) { int k = 0; while (((int64_t)1 << k) < nb) ++k; return k + kStrataPerTileLog2; }
 struct FixedCdf {
     double inv, u0, n_pop; uint64_t base;
     uint64_t seed, draw, uid0;                 // stratified: the run's Philox key, the resampling's draw index, the id of output 0

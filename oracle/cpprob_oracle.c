@@ -846,15 +846,15 @@ ORC_API int orc_resample_fixed_multinomial(const uint32_t *q, uint64_t n_in, uin
 /*      (draw BASE2 + step) and its threshold is                                   */
 /*          tau_s = B_w + floor(v_s (B_w+1 - B_w)),  B_w = floor(C_N w / K),        */
 /*      ancestor = min{k : C_k > tau_s}.                                          */
-/* K = the smallest power of two >= the number of 1024-source tiles (a stratum    */
-/* holds 512 .. 1024 thresholds on average).  Integers throughout.                */
+/* K = the smallest power of two >= FOUR times the number of 1024-source tiles (a */
+/* stratum holds 128 .. 256 thresholds on average).  Integers throughout.         */
 /* ------------------------------------------------------------------------- */
 ORC_API int orc_strata_levels(uint64_t n_particles)
 {
     const uint64_t nb = (n_particles + ORC_TILE - 1) / ORC_TILE;
     int k = 0;
     while (((uint64_t)1 << k) < nb) ++k;
-    return k;
+    return k + 2;
 }
 
 /* popcount of the first n bits of the stream of tree node `node` (heap order: 2^l + i): words x, y, z, w of block (node << 32 | chunk), low bits first */

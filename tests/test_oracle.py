@@ -444,7 +444,7 @@ def test_strata_form_of_multinomial_resampling_is_multinomial_and_nearly_sorted(
     and iid uniforms inside each stratum.  The counts against an independent restatement (both the one-tree and the two-part form);
     their law (chi-square); the ancestors against the definition evaluated in numpy; offspring counts with multinomial, not
     systematic, variance; ancestors sorted stratum by stratum."""
-    for n_out, k in ((5000, 3), (40000, 6), (150_000, 8)):
+    for n_out, k in ((900, 2), (5000, 5), (16000, 6), (40000, 8), (150_000, 10)):           # (K = the power of two >= four times the tiles)
         assert O.lib().orc_strata_levels(n_out) == k
         assert np.array_equal(O.multinomial_strata(5, 3, n_out), _strata_offsets_in_python(5, 3, n_out, k))
     ch = []
@@ -452,7 +452,7 @@ def test_strata_form_of_multinomial_resampling_is_multinomial_and_nearly_sorted(
         m = np.diff(O.multinomial_strata(9, st, 200000).astype(np.int64))
         ex = 200000 / len(m)
         ch.append(((m - ex) ** 2 / ex).sum() / (len(m) - 1))
-    assert abs(np.mean(ch) - 1.0) < 0.05                                             # (sd of the mean of 40 reduced chi-squares with 255 dof: 0.014)
+    assert abs(np.mean(ch) - 1.0) < 0.05                                             # (sd of the mean of 40 reduced chi-squares with 1023 dof: 0.007)
     rng = np.random.default_rng(3)
     n = 20000
     lw = rng.normal(size=n) * 2.0
