@@ -540,6 +540,26 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
         else if (c->cfg.resampler == CPPROB_HIP_RESAMPLE_STRATIFIED) hipLaunchKernelGGL((smc_step_counts_kernel<Model, false, kFixStratified>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else if (all_totals) hipLaunchKernelGGL((smc_step_counts_kernel<Model, true>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
         else hipLaunchKernelGGL((smc_step_counts_kernel<Model, false>), dim3(c->nb), dim3(kThreads), 0, c->stream, a);
+#ifdef CPPROB_STAMPS
+        {
+            // diagnostic build: the phase stamps of step 8 (kernels.hpp: CPH_STAMP; 8 .. 11 = inside the multinomial walk), CPPROB_STAMP_DUMP=1
+            static unsigned long long* d_st = nullptr;
+            if (!d_st) { (void)hipMalloc(&d_st, (size_t)131072 * 16 * 8); (void)hipMemset(d_st, 0, (size_t)131072 * 16 * 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)); }
+            if (t == 8 && getenv("CPPROB_STAMP_DUMP")) {
+                (void)hipStreamSynchronize(c->stream);
+                std::vector<unsigned long long> h((size_t)c->nb * 16);
+                (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+                unsigned long long t0 = ~0ull; for (int b2 = 0; b2 < c->nb; ++b2) t0 = std::min(t0, h[(size_t)b2 * 16]);
+                fprintf(stderr, "STAMPS counts t=8 n=%lld rs=%d (us since first workgroup start) mean/max:", (long long)c->n, (int)c->cfg.resampler);
+                for (int k : {0, 1, 2, 8, 9, 10, 11, 3, 4, 5}) {
+                    double acc = 0, mx = 0;
+                    for (int b2 = 0; b2 < c->nb; ++b2) { const double v = (double)(h[(size_t)b2 * 16 + k] - t0) * 0.01; acc += v; mx = std::max(mx, v); }
+                    fprintf(stderr, " [%d] %.2f/%.2f", k, acc / c->nb, mx);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
         if (t + 1 == c->T) { c->cur = 0; c->cur_part = 0; }
     }
 }

@@ -471,6 +471,7 @@ __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uin
     // (j0 = the lane's first output in the POPULATION; of a shard's outputs only those whose threshold lies in its sources' range)
 #pragma unroll
     for (int i = 0; i < kPPT; ++i) { live[i] = live[i] && tau[i] >= c_lo && (last_shard || tau[i] < c_hi); mine[i] = live[i]; }
+    CPH_STAMP(8);
     const double x_hi = (double)(w1 + 1) * unit;
     auto nvalid_before = [&](int c) -> int64_t { const int64_t v2 = (int64_t)c * kTile; return v2 < n ? v2 : n; };
     int c = __builtin_amdgcn_readfirstlane(sl.loc.c);
@@ -506,6 +507,7 @@ __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uin
             if (lane == kWave - 1) L.wtot[j][wv] = incls[j];
         }
         __syncthreads();
+        CPH_STAMP(9);
         double t_end = 0.0;                                               // the CDF value at the end of the group
 #pragma unroll
         for (int j = 0; j < kStrataTiles; ++j) {
@@ -535,6 +537,7 @@ __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uin
             }
         }
         __syncthreads();
+        CPH_STAMP(10);
         const int len = nt * kTile;
 #pragma unroll
         for (int i = 0; i < kPPT; ++i) {
@@ -547,6 +550,7 @@ __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uin
             }
         }
         c += nt;
+        CPH_STAMP(11);
     }
     // a threshold that rounded up to the population's whole mass: its last particle
 #pragma unroll
