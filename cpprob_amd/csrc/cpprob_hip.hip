@@ -557,6 +557,24 @@ void launch_step_counts(cpprob_hip_ctx* c, int t, const double* all_totals, int 
                     fprintf(stderr, " [%d] %.2f/%.2f", k, acc / c->nb, mx);
                 }
                 fprintf(stderr, "\n");
+                for (int k : {0, 2, 3, 5}) {
+                    std::vector<double> v((size_t)c->nb);
+                    for (int b2 = 0; b2 < c->nb; ++b2) v[(size_t)b2] = (double)(h[(size_t)b2 * 16 + k] - t0) * 0.01;
+                    std::sort(v.begin(), v.end());
+                    fprintf(stderr, "   stamp %d percentiles 10/50/75/90/95/99/100: %.2f %.2f %.2f %.2f %.2f %.2f %.2f\n", k, v[v.size() / 10], v[v.size() / 2], v[v.size() * 3 / 4],
+                            v[v.size() * 9 / 10], v[v.size() * 95 / 100], v[v.size() * 99 / 100], v.back());
+                }
+                {
+                    std::vector<int> order((size_t)c->nb);
+                    for (int b2 = 0; b2 < c->nb; ++b2) order[(size_t)b2] = b2;
+                    std::sort(order.begin(), order.end(), [&](int x, int y) { return h[(size_t)x * 16 + 5] > h[(size_t)y * 16 + 5]; });
+                    for (int r = 0; r < 8 && r < c->nb; ++r) {
+                        const int b2 = order[(size_t)r];
+                        fprintf(stderr, "   slow workgroup %d:", b2);
+                        for (int k : {0, 1, 2, 3, 4, 5}) fprintf(stderr, " [%d] %.2f", k, (double)(h[(size_t)b2 * 16 + k] - t0) * 0.01);
+                        fprintf(stderr, "\n");
+                    }
+                }
             }
         }
 #endif

@@ -292,7 +292,9 @@ __device__ __forceinline__ void counts_walk(const TableCdf& tc, const S* __restr
         // 2^53 is the same double, so this IS the stated arithmetic).  What leaves is the output's place in THIS tile, clamped to
         // [0, kTile]: a source owns outputs here iff its clamped end exceeds its clamped start, which is then its first slot.
         const uint32_t nvb = (uint32_t)nvalid_before(c);                 // local particles before this tile (< 2^31)
-        auto place = [&](double g) -> int { return (int)fmin(fmax(g - gj_first, 0.0), (double)kTile); };      // exact: integers
+        // exact: integers, |g - gj_first| <= the population (< 2^31): converted, then clamped as an integer -- one 32-bit median instead
+        // of a maximum and a minimum at the fp64 rate, five times a tile
+        auto place = [&](double g) -> int { const int x = (int)(g - gj_first); return x < 0 ? 0 : (x > kTile ? kTile : x); };
         auto gk = [&](uint32_t packed, int upto) -> int {                // after `upto` particles of the tile, `packed` of them in states 0 / 1
             const uint32_t n0 = P.n0 + (packed & 0xffffu), n1 = P.n1 + (packed >> 16);
             const uint32_t n2 = nvb + (uint32_t)(EDGE && upto > nvt ? nvt : upto) - n0 - n1;

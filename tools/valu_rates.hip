@@ -102,6 +102,14 @@ __global__ __launch_bounds__(256) void rate_kernel(uint64_t* out, uint32_t seed)
 #define S(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(w[k]) : "v"((uint32_t)(w[k] >> 32)), "v"(m0) : "vcc");
             CHAIN8(S)
 #undef S
+        } else if constexpr (OP == 19) {
+#define S(k) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[k]) : "v"(b[k]), "v"(m0));
+            CHAIN8(S)
+#undef S
+        } else if constexpr (OP == 20) {
+#define S(k) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b[k]));
+            CHAIN8(S)
+#undef S
         } else if constexpr (OP == 17) {
 #define S(k) asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[k]) : "v"(d[k]), "v"(c0), "v"(b[k]) : "vcc");
             CHAIN8(S)
@@ -187,6 +195,8 @@ int main()
     run<2>("v_mul_lo_u32", 1, out, base);
     run<3>("v_mul_hi_u32", 1, out, base);
     run<11>("v_mul_u32_u24", 1, out, base);
+    run<20>("v_xor_b32", 1, out, base);
+    run<19>("v_bitop3_b32 (a ^ b ^ c)", 1, out, base);
     run<12>("v_lshl_add_u64", 1, out, base);
     run<15>("v_add_co_u32 + v_addc_co_u32", 2, out, base);
     run<4>("v_fma_f64", 1, out, base);
