@@ -71,10 +71,12 @@ extern "C" {
  * integers inside the step launch (prefix counts or fixed-point masses), bit-identical over tilings.
  *   SYSTEMATIC   one shared offset u0: output j at j + u0;
  *   STRATIFIED   output j at j + u_j, u_j the 32-bit uniform of output j;
- *   MULTINOMIAL  a_j ~ Categorical(W) iid, evaluated in two stages so that offspring stay next to their parent: per-tile offspring
- *                counts from N iid thresholds floor(u_j C_N), then each tile's offspring drawn from the tile's own weights
- *                (CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL: one threshold per output searched against the whole population -- the same
- *                law, N scattered searches). */
+ *   MULTINOMIAL  a_j ~ Categorical(W) iid, evaluated in two stages so that offspring stay next to their parent (strata form): the N
+ *                iid thresholds as counts per equal stratum of the total mass (K = 2^k strata, K >= four times the 1024-particle tiles;
+ *                exact Binomial splits down a tree of Philox popcounts: independent of the weights, drawn once per run) and iid
+ *                53-bit uniforms inside a stratum: output s of stratum w takes tau_s = B_w + floor(v_s (B_w+1 - B_w)), its ancestor
+ *                is min{k : C_k > tau_s}  (CPPROB_HIP_FLAG_MULTINOMIAL_LITERAL: one threshold floor(u_j C_N) per output searched
+ *                against the whole population -- the same law, N scattered searches). */
 #define CPPROB_HIP_RESAMPLE_SYSTEMATIC 0
 #define CPPROB_HIP_RESAMPLE_STRATIFIED 1
 #define CPPROB_HIP_RESAMPLE_MULTINOMIAL 2
