@@ -561,6 +561,9 @@ __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uin
 
 struct StepFound { Located loc; double inv, base0, base1, basev; int64_t l0, l1; int w0, w1; double W, c_lo, c_hi; };      // what the searching wavefront hands the other three
 
+#ifndef CPPROB_HAND_OVER
+#define CPPROB_HAND_OVER 1
+#endif
 template <class Model>
 struct StepCountsArgs {
     ModelParams mp; int t, T; int64_t n, ld, rs;
@@ -629,6 +632,8 @@ __global__ __launch_bounds__(kThreads) CPPROB_COUNTS_OCC void smc_step_counts_ke
     __shared__ int s_cnt[kWaves * 4];
     __shared__ __attribute__((aligned(16))) uint64_t s_model[Model::kStagedWords];
     __shared__ __attribute__((aligned(16))) StepFound s_found;
+    constexpr bool kHandOver = CPPROB_HAND_OVER;
+    __shared__ __attribute__((aligned(16))) typename Model::Rand s_rnd[kHandOver ? kWave : 1];
     const int tid = threadIdx.x;
     const int nb = (int)gridDim.x;
     const int bid = xcd_contiguous_tile((int)blockIdx.x, nb);
@@ -664,9 +669,21 @@ __global__ __launch_bounds__(kThreads) CPPROB_COUNTS_OCC void smc_step_counts_ke
             }
         }
     }
+    // The variates.  Where a search follows (t > 0) the searching wavefront does not draw its own: the search is the workgroup's serial
+    // chain and starts as soon as its loads are back; wavefront 2 draws that share too, under the search, and hands it over through LDS
+    // behind the search's barrier.
     typename Model::Rand rnd[kPPT / 4];
+    static_assert(kPPT == 4, "one draw4 a lane");
+    const bool hand_over = kHandOver && t > 0;
+    if (!(hand_over && searcher)) {
 #pragma unroll
-    for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+        for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+    }
+    if (hand_over && wave_id() == 2) {
+        typename Model::Rand r0;
+        Model::draw4(a.seed, a.pid0 + (uint64_t)((int64_t)bid * kTile + (int64_t)lane_id() * kPPT), t, r0);
+        s_rnd[lane_id()] = r0;
+    }
     CPH_STAMP(1);
 
     int32_t anc[kPPT];
@@ -770,6 +787,7 @@ __global__ __launch_bounds__(kThreads) CPPROB_COUNTS_OCC void smc_step_counts_ke
             }
         }
         __syncthreads();                                           // slots reset, search results and the model's table in place
+        if (hand_over && searcher) rnd[0] = s_rnd[lane_id()];
         CPH_STAMP(2);
         const Located loc = s_found.loc;
         tc.inv = s_found.inv;
