@@ -1,5 +1,6 @@
-# A/B of the carrying step's inputs staged through LDS by direct loads (step_fixed.hpp: LaneStage) against plain register loads behind the
-# decision (CPPROB_HIP_NO_STAGE=1), same box, alternating:   python tools/ab_stage.py [rounds]
+# A/B of the carrying step's inputs staged through LDS by direct loads (LaneStage: tools/dropped/lds_staged_carry_inputs.patch -- apply it first,
+# the shipped library has no such form) against plain register loads behind the decision (CPPROB_HIP_NO_STAGE=1), same box, alternating:
+#   python tools/ab_stage.py [rounds]        (profiles/r06_ab_stage.txt, profiles/r06_notes.md section 5)
 import os, sys, time, subprocess, json
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 if len(sys.argv) > 1 and sys.argv[1] == "child":
