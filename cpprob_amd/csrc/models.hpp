@@ -126,6 +126,9 @@ struct ModelLinearGaussian1D {
     __device__ static __forceinline__ int weight_index(value_t) { return 0; }
     struct Rand { double z[4]; };
     __device__ static __forceinline__ void draw4(uint64_t seed, uint64_t pid0, int t, Rand& r) { draw_std_normals4(seed, pid0, (uint64_t)t, r.z); }
+    // half of draw4 for an EVEN particle id: the normals of particles pid, pid + 1 (one Philox block, one Box-Muller pair)
+    static constexpr bool kHasDraw2 = true;
+    __device__ static __forceinline__ void draw2(uint64_t seed, uint64_t pid_even, int t, double& z0, double& z1) { box_muller(draw_block(seed, pid_even >> 1, (uint64_t)t), z0, z1); }
     __device__ static __forceinline__ void apply4(const ModelParams&, int t, const Rand& r, const value_t (&prev)[4], value_t (&x)[4])
     {
 #pragma unroll

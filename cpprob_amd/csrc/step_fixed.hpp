@@ -54,6 +54,12 @@ __device__ __forceinline__ FixedRanks fixed_ranks(const uint64_t* __restrict__ a
 
 struct FixedFound { FLocated loc; double inv, ref; uint64_t base, S, own; int64_t l0, l1; int resample, w0, w1; };     // the searching wavefront's hand-over
 
+#ifndef CPPROB_HAND_OVER_FIXED
+#define CPPROB_HAND_OVER_FIXED 1
+#endif
+#ifndef CPPROB_PARK_DRAWS
+#define CPPROB_PARK_DRAWS 1
+#endif
 template <class Model>
 struct StepFixedArgs {
     ModelParams mp; const double* obs; int t, T; int64_t n, ld, rs;
@@ -595,9 +601,43 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
     // the search and the walk -- measured both ways for both (profiles/r03_notes.md section 3).
     constexpr bool kDrawEarly = !Model::kIsInt;
     typename Model::Rand rnd[kPPT / 4];
+    // Early draws where a search / decision follows (t > 0): the searching wavefront does not draw its own -- its chain is the workgroup's
+    // serial part and starts at once, under the others' draws; wavefronts 1 and 3 draw one Box-Muller pair each of its lanes' four normals
+    // (half a share more each: still ahead of "own draws, then the search") and hand them over through LDS behind the search's barrier.
+    constexpr bool kHandOver = kDrawEarly && CPPROB_HAND_OVER_FIXED;
+    __shared__ double s_z[kHandOver ? 4 : 1][kHandOver ? kWave : 1];
+    const bool hand_over = kHandOver && t > 0 && (a.pid0 & 1ull) == 0;
     if constexpr (kDrawEarly) {
+        if (!(hand_over && searcher)) {
 #pragma unroll
-        for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+            for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+        }
+        if constexpr (kHandOver) {
+            if (hand_over && (wave_id() == 1 || wave_id() == 3)) {
+                const int half = wave_id() == 1 ? 0 : 1;
+                const uint64_t pid = a.pid0 + (uint64_t)((int64_t)bid * kTile + (int64_t)lane_id() * kPPT) + 2 * (uint64_t)half;
+                double z0, z1;
+                Model::draw2(a.seed, pid, t, z0, z1);
+                s_z[2 * half][lane_id()] = z0; s_z[2 * half + 1][lane_id()] = z1;
+            }
+        }
+    }
+    // Late draws (the discrete models: a few integer operations whose registers are better not live across the search and the walk) where
+    // a decision / search follows: drawn HERE all the same, by the three wavefronts that wait for the searching one (wavefront 2 also its
+    // share), and parked in LDS -- no register is live, and the Philox block leaves the chain behind the barrier.
+    constexpr bool kPark = !kDrawEarly && CPPROB_PARK_DRAWS && sizeof(typename Model::Rand) == 16 && kPPT == 4;
+    __shared__ __attribute__((aligned(16))) typename Model::Rand s_park[kPark ? kThreads : 1];
+    const bool park = kPark && t > 0;
+    if constexpr (kPark) {
+        if (park && !searcher) {
+            typename Model::Rand r1;
+            Model::draw4(a.seed, a.pid0 + (uint64_t)j0, t, r1);
+            s_park[tid] = r1;
+            if (wave_id() == 2) {
+                Model::draw4(a.seed, a.pid0 + (uint64_t)((int64_t)bid * kTile + (int64_t)lane_id() * kPPT), t, r1);
+                s_park[lane_id()] = r1;
+            }
+        }
     }
     CPH_STAMP(1);
 
@@ -664,6 +704,12 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
             if (tid == 0) { s_found.loc = loc; s_found.inv = d.inv; s_found.ref = r_t; s_found.base = before; s_found.S = St; s_found.own = SHARDED ? own.S : St; s_found.l0 = l0; s_found.l1 = l1; s_found.resample = d.resample ? 1 : 0; s_found.w0 = sw0; s_found.w1 = sw1; }
         }
         __syncthreads();                                               // slots reset, search results in place
+        if constexpr (kHandOver) {
+            if (hand_over && searcher) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rnd[0].z[k] = s_z[k][lane_id()];
+            }
+        }
     CPH_STAMP(2);
         resample = s_found.resample != 0;
         if (RESAMPLING_ONLY && !resample) return;                      // this step carries its weights: the other launch's
@@ -719,8 +765,11 @@ __device__ __forceinline__ void smc_step_fixed_body(const StepFixedArgs<Model>& 
     CPH_STAMP(3);
     const S* prev_row = a.values + (int64_t)a.row_r * a.rs;
     if constexpr (!kDrawEarly) {
+        if (park) rnd[0] = s_park[kPark ? tid : 0];                     // (behind the decision's barrier)
+        else {
 #pragma unroll
-        for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+            for (int q = 0; q < kPPT / 4; ++q) Model::draw4(a.seed, a.pid0 + (uint64_t)j0 + 4 * q, t, rnd[q]);
+        }
     }
     V prev[kPPT], x[kPPT];
     if (t > 0 && !resample) load4_as(prev_row, j0, prev);                                    // every slot extends itself: one vector load
