@@ -448,12 +448,18 @@ __device__ __forceinline__ LocatedStrata counts_strata_locate(const Hier& h, con
 template <class S>
 __device__ __forceinline__ void counts_strata_walk(const TableCdf& tc, const uint32_t* __restrict__ offs, int k, const S* __restrict__ states, int64_t n, int nb,
                                                    const LocatedStrata& sl, double W, int64_t j0, uint64_t seed, uint64_t draw, uint64_t uid,
-                                                   int32_t (&anc)[kPPT], CountsLdsT<kFixMultinomial>& L, double c_lo, double c_hi, bool last_shard, bool (&mine)[kPPT])
+                                                   int32_t (&anc)[kPPT], CountsLdsT<kFixMultinomial>& L, double c_lo, double c_hi, bool last_shard, bool (&mine)[kPPT],
+                                                   bool parked = false)
 {
     static_assert(sizeof(S) == 1 && kPPT == 4, "states travel as one byte: 4 per lane = one dword");
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     uint64_t vb[kPPT];
-    strata_bits4(seed, draw, uid, vb);
+    // (parked: the caller's wavefronts drew the outputs' bits while they waited for the search and left them where L.cd begins -- read here,
+    //  before the first barrier of the walk, behind which the CDF values overwrite them)
+    if (parked) {
+#pragma unroll
+        for (int i = 0; i < kPPT; ++i) vb[i] = reinterpret_cast<const uint64_t*>(L.cd)[i * kThreads + tid];
+    } else strata_bits4(seed, draw, uid, vb);
     const double v[kPPT] = {(double)vb[0] * kTwoPowM53, (double)vb[1] * kTwoPowM53, (double)vb[2] * kTwoPowM53, (double)vb[3] * kTwoPowM53};
     double tau[kPPT];
     bool live[kPPT];
@@ -721,6 +727,22 @@ __global__ __launch_bounds__(kThreads) CPPROB_COUNTS_OCC void smc_step_counts_ke
                 }
             }
         }
+        if constexpr (RS == kFixMultinomial) {
+            // (the 53-bit uniforms of this tile's outputs inside their strata: two Philox blocks a lane that depend on nothing but ids --
+            //  drawn by the wavefronts that wait for the search, wavefront 1 also the searching one's, and parked where L.cd begins)
+            if (!searcher) {
+                uint64_t vb[kPPT];
+                uint64_t* park = reinterpret_cast<uint64_t*>(L.cd);
+                strata_bits4(a.seed, kResampleDrawBase2 + (uint64_t)t, a.pid0 + (uint64_t)j0, vb);
+#pragma unroll
+                for (int i = 0; i < kPPT; ++i) park[i * kThreads + tid] = vb[i];
+                if (wave_id() == 1) {
+                    strata_bits4(a.seed, kResampleDrawBase2 + (uint64_t)t, a.pid0 + (uint64_t)((int64_t)bid * kTile + (int64_t)lane_id() * kPPT), vb);
+#pragma unroll
+                    for (int i = 0; i < kPPT; ++i) park[i * kThreads + lane_id()] = vb[i];
+                }
+            }
+        }
         if (searcher) {
             // ---- one wavefront: the generation's totals, this shard's place in the joint population, the source tiles this output
             //      tile draws from; the other three pick the results up behind the barrier ----
@@ -798,7 +820,7 @@ __global__ __launch_bounds__(kThreads) CPPROB_COUNTS_OCC void smc_step_counts_ke
             bool mine[kPPT];
             const uint64_t gj = SHARDED ? a.pid0 + (uint64_t)j0 : (uint64_t)j0;            // the lane's first output in the population
             counts_strata_walk<S>(tc, a.strata_offs, a.strata_k, prev_row, a.n, nb, ls, s_found.W, (int64_t)gj, tc.seed, kResampleDrawBase2 + (uint64_t)t, a.pid0 + (uint64_t)j0, anc, L,
-                                  s_found.c_lo, s_found.c_hi, last_shard, mine);
+                                  s_found.c_lo, s_found.c_hi, last_shard, mine, true);
             if constexpr (SHARDED) {
                 // an output whose threshold lies in another rank's range: its ancestor arrived as an annex column, in output order
                 bool out = false;
